@@ -1,0 +1,266 @@
+// Implicit-GEMM convolution / linear on the gfx950 matrix cores.
+//
+//   out[pixel][co] = epilogue( sum_{kh,kw,ci} x[n, ho*s-p+kh, wo*s-p+kw, ci] * w[co][kh][kw][ci] )
+//
+// GEMM view: "pixels" (N*Ho*Wo) x "channels" (Cout) x K (KH*KW*Cin).  The weight tile is the
+// MFMA A operand and the gathered activation tile the B operand, so in the 16x16 accumulator
+// fragment every lane owns 4 CONSECUTIVE output channels of one pixel: the epilogue (FrozenBN
+// scale/shift, residual / FPN top-down add, ReLU, ReLU-backward mask) works on 4-vectors and
+// stores 8 B (bf16) or 16 B (fp32) per lane.
+//
+// Tiles are staged global -> registers -> LDS (the gather needs per-lane addresses and zero
+// fill at the borders), double buffered, one barrier per K slab, next slab's global loads
+// issued before the current slab's MFMAs.  LDS rows are 64 B (4 x 16 B chunks); the chunk
+// index is XOR-swizzled per 4-row group so that the 16-lane groups of ds_read_b128 hit 16
+// distinct 16-B slots (MI355X_MICROARCH.md, LDS table).
+//
+// dtype: bf16 -> v_mfma_f32_16x16x32_bf16 (K slab 32); fp32 -> v_mfma_f32_16x16x4_f32 x4
+// (K slab 16, exact fp32 -- the parity mode).  Both share the byte geometry of the tiles.
+//
+// Replaces the cuDNN/MIOpen conv + FrozenBN + ReLU (+ residual) chain and torch Linear that
+// the reference reaches through detectron2 (aldi/align.py:72, aldi/distill.py:157,162).
+#include "common.h"
+
+namespace {
+
+struct ConvDev {
+    const void* x; const void* w; void* y; float* y_f32;
+    const float* scale; const float* shift; const void* res; const void* mask;
+    int N, H, W, Cin, Cout, KH, KW, stride, pad, Ho, Wo;
+    int relu, res_mode, out_scale, OH, OW;
+    int M, K;
+};
+
+__device__ __forceinline__ int swz(int row, int kc) {
+    // chunk permutation g = [0,2,3,1] indexed by (row>>2)&3
+    return kc ^ ((0x78 >> (((row >> 2) & 3) * 2)) & 3);
+}
+
+template <typename T> struct Mma;
+template <> struct Mma<bf16_t> {
+    static constexpr int BK = 32;
+    __device__ static __forceinline__ f32x4_t run(const uint4& a, const uint4& b, f32x4_t c) {
+        bf16x8_t av = *reinterpret_cast<const bf16x8_t*>(&a);
+        bf16x8_t bv = *reinterpret_cast<const bf16x8_t*>(&b);
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, bv, c, 0, 0, 0);
+    }
+};
+template <> struct Mma<float> {
+    static constexpr int BK = 16;
+    __device__ static __forceinline__ f32x4_t run(const uint4& a, const uint4& b, f32x4_t c) {
+        const float* af = reinterpret_cast<const float*>(&a);
+        const float* bf = reinterpret_cast<const float*>(&b);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) c = __builtin_amdgcn_mfma_f32_16x16x4f32(af[j], bf[j], c, 0, 0, 0);
+        return c;
+    }
+};
+
+template <typename T, int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(WM* WN * 64) void igemm_kernel(ConvDev p) {
+    constexpr int NT = WM * WN * 64;
+    constexpr int BK = Mma<T>::BK;
+    constexpr int EP = Elem<T>::kPer16B;           // elements per 16-B chunk
+    constexpr int A_IT = (BM * 4) / NT;            // pixel-tile chunks per thread
+    constexpr int B_IT = (BN * 4 + NT - 1) / NT;   // weight-tile chunks per thread
+    constexpr int TM = BM / WM / 16, TN = BN / WN / 16;
+    static_assert((BM * 4) % NT == 0, "tile/threads mismatch");
+
+    __shared__ uint4 lds[2][(BM + BN) * 4];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+    const T* __restrict__ X = static_cast<const T*>(p.x);
+    const T* __restrict__ Wt = static_cast<const T*>(p.w);
+
+    // per-thread gather descriptors (rows are fixed for the whole K loop)
+    int a_hi0[A_IT], a_wi0[A_IT];
+    long a_base[A_IT];
+    bool a_ok[A_IT];
+#pragma unroll
+    for (int it = 0; it < A_IT; ++it) {
+        int c = tid + it * NT, row = c >> 2;
+        int m = m0 + row;
+        a_ok[it] = m < p.M;
+        int mm = a_ok[it] ? m : 0;
+        int n = mm / (p.Ho * p.Wo);
+        int r = mm - n * (p.Ho * p.Wo);
+        int ho = r / p.Wo, wo = r - ho * p.Wo;
+        a_hi0[it] = ho * p.stride - p.pad;
+        a_wi0[it] = wo * p.stride - p.pad;
+        a_base[it] = (long)n * p.H * p.W;
+    }
+    long b_off[B_IT];
+    bool b_ok[B_IT];
+#pragma unroll
+    for (int it = 0; it < B_IT; ++it) {
+        int c = tid + it * NT, row = c >> 2, kc = c & 3;
+        int co = n0 + row;
+        b_ok[it] = (c < BN * 4) && co < p.Cout;
+        b_off[it] = (long)(b_ok[it] ? co : 0) * p.K + kc * EP;
+    }
+
+    uint4 ra[A_IT], rb[B_IT];
+    int kh = 0, kw = 0, ci0 = 0;   // tap / channel offset of the slab being LOADED (block uniform)
+
+    auto load_slab = [&](int s) {
+#pragma unroll
+        for (int it = 0; it < A_IT; ++it) {
+            int c = tid + it * NT, kc = c & 3;
+            int hi = a_hi0[it] + kh, wi = a_wi0[it] + kw;
+            bool ok = a_ok[it] && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (ok) v = *reinterpret_cast<const uint4*>(X + ((a_base[it] + (long)hi * p.W + wi) * p.Cin + ci0 + kc * EP));
+            ra[it] = v;
+        }
+#pragma unroll
+        for (int it = 0; it < B_IT; ++it) {
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (b_ok[it]) v = *reinterpret_cast<const uint4*>(Wt + b_off[it] + (long)s * BK);
+            rb[it] = v;
+        }
+        ci0 += BK;
+        if (ci0 == p.Cin) { ci0 = 0; if (++kw == p.KW) { kw = 0; ++kh; } }
+    };
+    auto store_slab = [&](int buf) {
+#pragma unroll
+        for (int it = 0; it < A_IT; ++it) {
+            int c = tid + it * NT, row = c >> 2, kc = c & 3;
+            lds[buf][row * 4 + swz(row, kc)] = ra[it];
+        }
+#pragma unroll
+        for (int it = 0; it < B_IT; ++it) {
+            int c = tid + it * NT, row = c >> 2, kc = c & 3;
+            if (c < BN * 4) lds[buf][(BM + row) * 4 + swz(row, kc)] = rb[it];
+        }
+    };
+
+    f32x4_t acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+    const int S = p.K / BK;
+    load_slab(0);
+    store_slab(0);
+    __syncthreads();
+    const int fr = lane & 15, fq = lane >> 4;
+    for (int s = 0; s < S; ++s) {
+        const int buf = s & 1;
+        if (s + 1 < S) load_slab(s + 1);
+        uint4 xf[TM], wf[TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            int row = wm * (BM / WM) + i * 16 + fr;
+            xf[i] = lds[buf][row * 4 + swz(row, fq)];
+        }
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            int row = wn * (BN / WN) + j * 16 + fr;
+            wf[j] = lds[buf][(BM + row) * 4 + swz(row, fq)];
+        }
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) acc[i][j] = Mma<T>::run(wf[j], xf[i], acc[i][j]);
+        if (s + 1 < S) store_slab(buf ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: lane owns pixel (lane&15), channels (lane>>4)*4 .. +3 of each 16x16 tile
+    T* __restrict__ Y = static_cast<T*>(p.y);
+    const T* __restrict__ R = static_cast<const T*>(p.res);
+    const T* __restrict__ Mk = static_cast<const T*>(p.mask);
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        int m = m0 + wm * (BM / WM) + i * 16 + fr;
+        if (m >= p.M) continue;
+        long oidx, ridx = 0;
+        if (p.out_scale == 1 && p.res_mode != 2) {
+            oidx = (long)m * p.Cout;
+            ridx = oidx;
+        } else {
+            int n = m / (p.Ho * p.Wo);
+            int r = m - n * (p.Ho * p.Wo);
+            int ho = r / p.Wo, wo = r - ho * p.Wo;
+            if (p.out_scale == 1) oidx = (long)m * p.Cout;
+            else oidx = (((long)n * p.OH + ho * p.out_scale) * p.OW + wo * p.out_scale) * p.Cout;
+            if (p.res_mode == 2) ridx = (((long)n * (p.Ho >> 1) + (ho >> 1)) * (p.Wo >> 1) + (wo >> 1)) * p.Cout;
+            else ridx = oidx;
+        }
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            int c = n0 + wn * (BN / WN) + j * 16 + fq * 4;
+            if (c >= p.Cout) continue;
+            float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+            if (p.scale) {
+                float4 sc = *reinterpret_cast<const float4*>(p.scale + c);
+                v[0] *= sc.x; v[1] *= sc.y; v[2] *= sc.z; v[3] *= sc.w;
+            }
+            if (p.shift) {
+                float4 sh = *reinterpret_cast<const float4*>(p.shift + c);
+                v[0] += sh.x; v[1] += sh.y; v[2] += sh.z; v[3] += sh.w;
+            }
+            if (p.res_mode) {
+                float r4[4];
+                load4(R + ridx + c, r4);
+                v[0] += r4[0]; v[1] += r4[1]; v[2] += r4[2]; v[3] += r4[3];
+            }
+            if (p.relu) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = v[r] > 0.f ? v[r] : 0.f;
+            }
+            if (Mk) {
+                float k4[4];
+                load4(Mk + oidx + c, k4);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = k4[r] > 0.f ? v[r] : 0.f;
+            }
+            if (Y) store4(Y + oidx + c, v);
+            if (p.y_f32) store4(p.y_f32 + oidx + c, v);
+        }
+    }
+}
+
+template <typename T, int BM, int BN, int WM, int WN>
+int launch(const ConvDev& d, hipStream_t st) {
+    dim3 grid(cdiv(d.M, BM), cdiv(d.Cout, BN));
+    hipLaunchKernelGGL((igemm_kernel<T, BM, BN, WM, WN>), grid, dim3(WM * WN * 64), 0, st, d);
+    ALDI_CHECK_LAUNCH();
+    return ALDI_OK;
+}
+
+template <typename T>
+int dispatch(const ConvDev& d, hipStream_t st) {
+    if (d.Cout <= 16) return launch<T, 128, 16, 4, 1>(d, st);
+    if (d.Cout <= 64) return launch<T, 128, 64, 4, 1>(d, st);
+    return launch<T, 128, 128, 2, 2>(d, st);
+}
+
+}  // namespace
+
+extern "C" int aldi_conv_igemm(const aldi_conv_args* a, aldi_stream_t stream) {
+    if (!a || !a->x || !a->w || (!a->y && !a->y_f32)) return aldi_set_error_msg(ALDI_ERR_ARG, "conv_igemm: null pointer");
+    const int bk = a->dtype == ALDI_BF16 ? 32 : 16;
+    if (a->Cin % bk != 0) return aldi_set_error_msg(ALDI_ERR_ARG, "conv_igemm: Cin must be a multiple of the K slab (32 bf16 / 16 f32)");
+    if (a->Cout % 4 != 0) return aldi_set_error_msg(ALDI_ERR_ARG, "conv_igemm: Cout must be a multiple of 4");
+    if (a->res_mode == 2 && ((a->Ho & 1) || (a->Wo & 1))) return aldi_set_error_msg(ALDI_ERR_ARG, "conv_igemm: upsample residual needs even Ho,Wo");
+    if (a->res_mode && !a->res) return aldi_set_error_msg(ALDI_ERR_ARG, "conv_igemm: res_mode set without res");
+    ConvDev d;
+    d.x = a->x; d.w = a->w; d.y = a->y; d.y_f32 = a->y_f32; d.scale = a->scale; d.shift = a->shift;
+    d.res = a->res; d.mask = a->mask;
+    d.N = a->N; d.H = a->H; d.W = a->W; d.Cin = a->Cin; d.Cout = a->Cout; d.KH = a->KH; d.KW = a->KW;
+    d.stride = a->stride; d.pad = a->pad; d.Ho = a->Ho; d.Wo = a->Wo;
+    d.relu = a->relu; d.res_mode = a->res_mode; d.out_scale = a->out_scale < 1 ? 1 : a->out_scale;
+    d.OH = a->OH; d.OW = a->OW;
+    long M = (long)a->N * a->Ho * a->Wo;
+    if (M <= 0 || M > 0x7fffffffL) return aldi_set_error_msg(ALDI_ERR_ARG, "conv_igemm: bad M");
+    d.M = (int)M;
+    d.K = a->KH * a->KW * a->Cin;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (a->dtype == ALDI_BF16) return dispatch<bf16_t>(d, st);
+    if (a->dtype == ALDI_F32) return dispatch<float>(d, st);
+    return aldi_set_error_msg(ALDI_ERR_ARG, "conv_igemm: bad dtype");
+}
