@@ -54,3 +54,16 @@ def _sig(name, *argtypes):
 
 
 conv_igemm = _sig("aldi_conv_igemm", C.POINTER(ConvArgs), c_void_p)
+
+
+class WgradArgs(C.Structure):
+    _fields_ = [
+        ("x", c_void_p), ("g", c_void_p), ("dw", c_void_p), ("scale", c_void_p),
+        ("N", c_int), ("H", c_int), ("W", c_int), ("Cin", c_int), ("Cout", c_int), ("KH", c_int), ("KW", c_int),
+        ("stride", c_int), ("pad", c_int), ("Ho", c_int), ("Wo", c_int), ("dtype", c_int),
+    ]
+
+
+conv_wgrad = _sig("aldi_conv_wgrad", C.POINTER(WgradArgs), c_void_p)
+bias_grad = _sig("aldi_bias_grad", c_void_p, c_void_p, c_int, c_int, c_int, c_void_p)
+dgrad_weights = _sig("aldi_dgrad_weights", c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p)

@@ -109,7 +109,7 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_kernel(ConvDev p) {
         for (int it = 0; it < A_IT; ++it) {
             int c = tid + it * NT, kc = c & 3;
             int hi = a_hi0[it] + kh, wi = a_wi0[it] + kw;
-            bool ok = a_ok[it] && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
+            bool ok = a_ok[it] && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W && ci0 + kc * EP < p.Cin;
             uint4 v = make_uint4(0, 0, 0, 0);
             if (ok) v = *reinterpret_cast<const uint4*>(X + ((a_base[it] + (long)hi * p.W + wi) * p.Cin + ci0 + kc * EP));
             ra[it] = v;
@@ -117,11 +117,11 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_kernel(ConvDev p) {
 #pragma unroll
         for (int it = 0; it < B_IT; ++it) {
             uint4 v = make_uint4(0, 0, 0, 0);
-            if (b_ok[it]) v = *reinterpret_cast<const uint4*>(Wt + b_off[it] + (long)s * BK);
+            if (b_ok[it] && s * BK + ((tid + it * NT) & 3) * EP < p.K) v = *reinterpret_cast<const uint4*>(Wt + b_off[it] + (long)s * BK);
             rb[it] = v;
         }
         ci0 += BK;
-        if (ci0 == p.Cin) { ci0 = 0; if (++kw == p.KW) { kw = 0; ++kh; } }
+        if (ci0 >= p.Cin) { ci0 = 0; if (++kw == p.KW) { kw = 0; ++kh; } }
     };
     auto store_slab = [&](int buf) {
 #pragma unroll
@@ -142,7 +142,7 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_kernel(ConvDev p) {
 #pragma unroll
         for (int j = 0; j < TN; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
-    const int S = p.K / BK;
+    const int S = (p.K + BK - 1) / BK;
     load_slab(0);
     store_slab(0);
     __syncthreads();
@@ -244,7 +244,9 @@ int dispatch(const ConvDev& d, hipStream_t st) {
 extern "C" int aldi_conv_igemm(const aldi_conv_args* a, aldi_stream_t stream) {
     if (!a || !a->x || !a->w || (!a->y && !a->y_f32)) return aldi_set_error_msg(ALDI_ERR_ARG, "conv_igemm: null pointer");
     const int bk = a->dtype == ALDI_BF16 ? 32 : 16;
-    if (a->Cin % bk != 0) return aldi_set_error_msg(ALDI_ERR_ARG, "conv_igemm: Cin must be a multiple of the K slab (32 bf16 / 16 f32)");
+    const int ep = a->dtype == ALDI_BF16 ? 8 : 4;
+    if (a->KH * a->KW == 1 ? (a->Cin % ep != 0) : (a->Cin % bk != 0))
+        return aldi_set_error_msg(ALDI_ERR_ARG, "conv_igemm: Cin must be a multiple of the K slab (32 bf16 / 16 f32); of a 16-B chunk for 1x1");
     if (a->Cout % 4 != 0) return aldi_set_error_msg(ALDI_ERR_ARG, "conv_igemm: Cout must be a multiple of 4");
     if (a->res_mode == 2 && ((a->Ho & 1) || (a->Wo & 1))) return aldi_set_error_msg(ALDI_ERR_ARG, "conv_igemm: upsample residual needs even Ho,Wo");
     if (a->res_mode && !a->res) return aldi_set_error_msg(ALDI_ERR_ARG, "conv_igemm: res_mode set without res");

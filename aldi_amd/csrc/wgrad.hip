@@ -1,0 +1,283 @@
+// Weight-gradient GEMM on the matrix cores:
+//
+//   dW[co][kh][kw][ci] += scale[co] * sum_{pixels p} g[p][co] * x[pix(p,kh,kw)][ci]
+//
+// The reduction runs over PIXELS, which are the slow (strided) dimension of both NHWC
+// operands, while an MFMA fragment wants 8 consecutive reduction elements per lane.  bf16
+// path: every thread loads an 8-pixel x 8-channel block (8 x 16 B, full 128-B lines per
+// wave instruction), transposes it in registers and writes 8 x 16 B to an LDS image
+// [channel][64 pixels]; fragments are then plain ds_read_b128.  The 128-B LDS rows are
+// XOR-swizzled (chunk ^ (row>>1)&7) so both the 8-lane write groups and the 16-lane read
+// groups are conflict free.  fp32 path (parity mode): mfma_f32_16x16x4f32 takes one float
+// per lane, so the LDS image stays [pixel][channel] and no transpose is needed.
+//
+// Split-K over pixel ranges (grid.z); partial tiles are accumulated into the fp32 gradient
+// buffer with hardware float atomics, which is also how micro-steps accumulate.
+//
+// Replaces cuDNN/MIOpen wgrad + torch Linear weight grad reached through autograd from
+// aldi/trainer.py:79 (`trainer.do_backward`).
+#include "common.h"
+#include <hip/amd_detail/amd_hip_unsafe_atomics.h>
+
+namespace {
+
+struct WgDev {
+    const void* x; const void* g; float* dw; const float* scale;
+    int N, H, W, Cin, Cout, KH, KW, stride, pad, Ho, Wo;
+    int M, K, pix_per_split, ident;
+};
+
+__device__ __forceinline__ int swz8(int row, int c) { return c ^ ((row >> 1) & 7); }
+
+// out[c] = pixels 0..7 of channel c, from in[p] = channels 0..7 of pixel p (16-bit elements)
+__device__ __forceinline__ void transpose8x8_b16(const uint4 in[8], uint4 out[8]) {
+    const uint32_t* r = reinterpret_cast<const uint32_t*>(in);   // r[p*4+d]
+    uint32_t* o = reinterpret_cast<uint32_t*>(out);              // o[c*4+j]
+#pragma unroll
+    for (int d = 0; d < 4; ++d)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            uint32_t a = r[(2 * j) * 4 + d], b = r[(2 * j + 1) * 4 + d];
+            o[(2 * d) * 4 + j] = (a & 0xffffu) | (b << 16);
+            o[(2 * d + 1) * 4 + j] = (a >> 16) | (b & 0xffff0000u);
+        }
+}
+
+// ------------------------------------------------------------------------------------ bf16
+// 128 (co) x 128 (kk) tile, 64 pixels per slab, 4 waves (2x2), wave tile 64x64.
+__global__ __launch_bounds__(256) void wgrad_bf16_kernel(WgDev p) {
+    constexpr int BP = 64;
+    __shared__ uint4 lds[2 * 128 * 8];   // [A rows 0..127 | B rows 0..127] x 8 chunks (32 KB)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int co0 = blockIdx.x * 128, kk0 = blockIdx.y * 128;
+    const int pbeg = blockIdx.z * p.pix_per_split;
+    const int pend = min(p.M, pbeg + p.pix_per_split);
+    const bf16_t* __restrict__ X = static_cast<const bf16_t*>(p.x);
+    const bf16_t* __restrict__ G = static_cast<const bf16_t*>(p.g);
+
+    // loader role: waves 0,1 -> g tile (channels = co); waves 2,3 -> x tile (channels = kk)
+    const bool isB = wave >= 2;
+    const int pg = lane & 7;                         // pixel group (8 pixels) inside the slab
+    const int cc = (wave & 1) * 8 + (lane >> 3);     // 8-channel chunk inside the 128-wide tile
+    int ch, kh = 0, kw = 0, ci = 0;
+    bool ch_ok;
+    if (!isB) { ch = co0 + cc * 8; ch_ok = ch < p.Cout; }
+    else {
+        ch = kk0 + cc * 8; ch_ok = ch < p.K;
+        int tap = ch / p.Cin; ci = ch - tap * p.Cin; kh = tap / p.KW; kw = tap - kh * p.KW;
+    }
+
+    const int wm = wave >> 1, wn = wave & 1;
+    f32x4_t acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    const int fr = lane & 15, fq = lane >> 4;
+
+    for (int p0 = pbeg; p0 < pend; p0 += BP) {
+        uint4 in[8], out[8];
+        int pp = p0 + pg * 8;
+        int n = 0, ho = 0, wo = 0;
+        if (isB && !p.ident) {
+            int q = min(pp, p.M - 1);
+            n = q / (p.Ho * p.Wo);
+            int r = q - n * (p.Ho * p.Wo);
+            ho = r / p.Wo; wo = r - ho * p.Wo;
+        }
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            int px = pp + r;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (ch_ok && px < pend) {
+                if (!isB) v = *reinterpret_cast<const uint4*>(G + (long)px * p.Cout + ch);
+                else if (p.ident) v = *reinterpret_cast<const uint4*>(X + (long)px * p.Cin + ci);
+                else {
+                    int hi = ho * p.stride - p.pad + kh, wi = wo * p.stride - p.pad + kw;
+                    if ((unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W)
+                        v = *reinterpret_cast<const uint4*>(X + (((long)n * p.H + hi) * p.W + wi) * p.Cin + ci);
+                }
+            }
+            in[r] = v;
+            if (++wo == p.Wo) { wo = 0; if (++ho == p.Ho) { ho = 0; ++n; } }
+        }
+        transpose8x8_b16(in, out);
+        __syncthreads();   // previous slab's fragment reads are done
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            int row = cc * 8 + c;
+            lds[((isB ? 128 : 0) + row) * 8 + swz8(row, pg)] = out[c];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            uint4 af[4], bfr[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                int row = wm * 64 + i * 16 + fr;
+                af[i] = lds[row * 8 + swz8(row, ks * 4 + fq)];
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                int row = wn * 64 + j * 16 + fr;
+                bfr[j] = lds[(128 + row) * 8 + swz8(row, ks * 4 + fq)];
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<bf16x8_t*>(&af[i]),
+                                                                         *reinterpret_cast<bf16x8_t*>(&bfr[j]), acc[i][j], 0, 0, 0);
+        }
+    }
+    // D[row = co][col = kk]
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            int co = co0 + wm * 64 + i * 16 + fq * 4 + r;
+            if (co >= p.Cout) continue;
+            float sc = p.scale ? p.scale[co] : 1.f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                int kk = kk0 + wn * 64 + j * 16 + fr;
+                if (kk < p.K) unsafeAtomicAdd(p.dw + (long)co * p.K + kk, acc[i][j][r] * sc);
+            }
+        }
+}
+
+// ------------------------------------------------------------------------------------ fp32
+// 64 (co) x 64 (kk) tile, 16 pixels per slab, 4 waves (2x2), wave tile 32x32.
+__global__ __launch_bounds__(256) void wgrad_f32_kernel(WgDev p) {
+    constexpr int BP = 16, LD = 64 + 16;           // padded row (floats)
+    __shared__ float lds[2 * BP * LD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int co0 = blockIdx.x * 64, kk0 = blockIdx.y * 64;
+    const int pbeg = blockIdx.z * p.pix_per_split;
+    const int pend = min(p.M, pbeg + p.pix_per_split);
+    const float* __restrict__ X = static_cast<const float*>(p.x);
+    const float* __restrict__ G = static_cast<const float*>(p.g);
+
+    // each thread loads one 4-float chunk of g and one of x per slab: row = tid>>4, chunk = tid&15
+    const int lrow = tid >> 4, lch = (tid & 15) * 4;
+    const int co_l = co0 + lch, kk_l = kk0 + lch;
+    int tap = 0, ci = 0, kh = 0, kw = 0;
+    if (kk_l < p.K) { tap = kk_l / p.Cin; ci = kk_l - tap * p.Cin; kh = tap / p.KW; kw = tap - kh * p.KW; }
+
+    const int wm = wave >> 1, wn = wave & 1;
+    f32x4_t acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    const int fr = lane & 15, fq = lane >> 4;
+
+    for (int p0 = pbeg; p0 < pend; p0 += BP) {
+        int px = p0 + lrow;
+        float4 gv = make_float4(0, 0, 0, 0), xv = make_float4(0, 0, 0, 0);
+        if (px < pend) {
+            if (co_l < p.Cout) gv = *reinterpret_cast<const float4*>(G + (long)px * p.Cout + co_l);
+            if (kk_l < p.K) {
+                if (p.ident) xv = *reinterpret_cast<const float4*>(X + (long)px * p.Cin + ci);
+                else {
+                    int n = px / (p.Ho * p.Wo);
+                    int r = px - n * (p.Ho * p.Wo);
+                    int ho = r / p.Wo, wo = r - ho * p.Wo;
+                    int hi = ho * p.stride - p.pad + kh, wi = wo * p.stride - p.pad + kw;
+                    if ((unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W)
+                        xv = *reinterpret_cast<const float4*>(X + (((long)n * p.H + hi) * p.W + wi) * p.Cin + ci);
+                }
+            }
+        }
+        __syncthreads();
+        *reinterpret_cast<float4*>(&lds[lrow * LD + lch]) = gv;
+        *reinterpret_cast<float4*>(&lds[(BP + lrow) * LD + lch]) = xv;
+        __syncthreads();
+#pragma unroll
+        for (int st = 0; st < BP / 4; ++st) {
+            float af[2], bfv[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) af[i] = lds[(st * 4 + fq) * LD + wm * 32 + i * 16 + fr];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) bfv[j] = lds[(BP + st * 4 + fq) * LD + wn * 32 + j * 16 + fr];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i], bfv[j], acc[i][j], 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            int co = co0 + wm * 32 + i * 16 + fq * 4 + r;
+            if (co >= p.Cout) continue;
+            float sc = p.scale ? p.scale[co] : 1.f;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                int kk = kk0 + wn * 32 + j * 16 + fr;
+                if (kk < p.K) unsafeAtomicAdd(p.dw + (long)co * p.K + kk, acc[i][j][r] * sc);
+            }
+        }
+}
+
+// db[c] += sum_p g[p][c]  (bias gradients).  grid.x = column chunks of 64, grid.y = row splits.
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ g, float* __restrict__ db, int M, int C, int rows_per_block) {
+    __shared__ float red[4][64];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int w = threadIdx.x >> 6;
+    const int r0 = blockIdx.y * rows_per_block, r1 = min(M, r0 + rows_per_block);
+    float s = 0.f;
+    if (c < C)
+        for (int r = r0 + w; r < r1; r += 4) s += Elem<T>::ld(g + (long)r * C + c);
+    red[w][threadIdx.x & 63] = s;
+    __syncthreads();
+    if (w == 0 && c < C) unsafeAtomicAdd(db + c, red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+
+}  // namespace
+
+extern "C" int aldi_conv_wgrad(const aldi_wgrad_args* a, aldi_stream_t stream) {
+    if (!a || !a->x || !a->g || !a->dw) return aldi_set_error_msg(ALDI_ERR_ARG, "conv_wgrad: null pointer");
+    const int ep = a->dtype == ALDI_BF16 ? 8 : 4;
+    if (a->Cin % ep || a->Cout % ep) return aldi_set_error_msg(ALDI_ERR_ARG, "conv_wgrad: Cin/Cout must be multiples of a 16-B chunk");
+    WgDev d;
+    d.x = a->x; d.g = a->g; d.dw = a->dw; d.scale = a->scale;
+    d.N = a->N; d.H = a->H; d.W = a->W; d.Cin = a->Cin; d.Cout = a->Cout; d.KH = a->KH; d.KW = a->KW;
+    d.stride = a->stride; d.pad = a->pad; d.Ho = a->Ho; d.Wo = a->Wo;
+    long M = (long)a->N * a->Ho * a->Wo;
+    if (M <= 0 || M > 0x7fffffffL) return aldi_set_error_msg(ALDI_ERR_ARG, "conv_wgrad: bad M");
+    d.M = (int)M;
+    d.K = a->KH * a->KW * a->Cin;
+    d.ident = (a->KH == 1 && a->KW == 1 && a->stride == 1 && a->pad == 0 && a->Ho == a->H && a->Wo == a->W) ? 1 : 0;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int tile = a->dtype == ALDI_BF16 ? 128 : 64;
+    const int bp = a->dtype == ALDI_BF16 ? 64 : 16;
+    int tiles = cdiv(d.Cout, tile) * cdiv(d.K, tile);
+    int slabs = cdiv(d.M, bp);
+    int splits = cdiv(2048, tiles);
+    if (splits > slabs / 2) splits = slabs / 2;
+    if (splits < 1) splits = 1;
+    if (splits > 512) splits = 512;
+    int slabs_per = cdiv(slabs, splits);
+    d.pix_per_split = slabs_per * bp;
+    splits = cdiv(d.M, d.pix_per_split);
+    dim3 grid(cdiv(d.Cout, tile), cdiv(d.K, tile), splits);
+    if (a->dtype == ALDI_BF16) hipLaunchKernelGGL(wgrad_bf16_kernel, grid, dim3(256), 0, st, d);
+    else if (a->dtype == ALDI_F32) hipLaunchKernelGGL(wgrad_f32_kernel, grid, dim3(256), 0, st, d);
+    else return aldi_set_error_msg(ALDI_ERR_ARG, "conv_wgrad: bad dtype");
+    ALDI_CHECK_LAUNCH();
+    return ALDI_OK;
+}
+
+extern "C" int aldi_bias_grad(const void* g, float* db, int M, int C, int dtype, aldi_stream_t stream) {
+    if (!g || !db || M <= 0 || C <= 0) return aldi_set_error_msg(ALDI_ERR_ARG, "bias_grad: bad args");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    int rows_per_block = 512;
+    dim3 grid(cdiv(C, 64), cdiv(M, rows_per_block));
+    if (dtype == ALDI_BF16) hipLaunchKernelGGL(colsum_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)g, db, M, C, rows_per_block);
+    else hipLaunchKernelGGL(colsum_kernel<float>, grid, dim3(256), 0, st, (const float*)g, db, M, C, rows_per_block);
+    ALDI_CHECK_LAUNCH();
+    return ALDI_OK;
+}

@@ -53,3 +53,28 @@ def conv2d(x: torch.Tensor, w: torch.Tensor, *, stride: int = 1, pad: int = 0,
                    int(relu), res_mode, out_scale, OH, OW, dtype_code(x.dtype))
     L.check(L.conv_igemm(C.byref(a), stream_ptr()), "aldi_conv_igemm")
     return out_f32 if want_f32 and out is None else out
+
+
+def conv_wgrad(x: torch.Tensor, g: torch.Tensor, dw: torch.Tensor, *, KH: int, KW: int, stride: int = 1, pad: int = 0,
+               scale: Optional[torch.Tensor] = None) -> None:
+    """dw [Cout,KH,KW,Cin] fp32 += scale * (g^T . im2col(x)); x [N,H,W,Cin], g [N,Ho,Wo,Cout]."""
+    N, H, W_, Cin = x.shape
+    _, Ho, Wo, Cout = g.shape
+    assert dw.dtype == torch.float32 and dw.numel() == Cout * KH * KW * Cin and x.dtype == g.dtype
+    a = L.WgradArgs(_p(x), _p(g), _p(dw), _p(scale), N, H, W_, Cin, Cout, KH, KW, stride, pad, Ho, Wo, dtype_code(x.dtype))
+    L.check(L.conv_wgrad(C.byref(a), stream_ptr()), "aldi_conv_wgrad")
+
+
+def bias_grad(g: torch.Tensor, db: torch.Tensor) -> None:
+    Cc = g.shape[-1]
+    L.check(L.bias_grad(_p(g), _p(db), g.numel() // Cc, Cc, dtype_code(g.dtype), stream_ptr()), "aldi_bias_grad")
+
+
+def dgrad_weights(w_master: torch.Tensor, scale: Optional[torch.Tensor], dtype: torch.dtype,
+                  out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """w_master fp32 [Cout,KH,KW,Cin] -> [Cin,KH,KW,Cout] rotated/transposed (x scale[co]) in `dtype`."""
+    Cout, KH, KW, Cin = w_master.shape
+    if out is None:
+        out = torch.empty((Cin, KH, KW, Cout), dtype=dtype, device=w_master.device)
+    L.check(L.dgrad_weights(_p(w_master), _p(scale), _p(out), Cout, KH, KW, Cin, dtype_code(dtype), stream_ptr()), "aldi_dgrad_weights")
+    return out

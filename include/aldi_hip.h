@@ -60,6 +60,29 @@ typedef struct {
 
 int aldi_conv_igemm(const aldi_conv_args* a, aldi_stream_t stream);
 
+/* Weight gradient: dw[Cout][KH][KW][Cin] (fp32) += scale[co] * sum_pixels g[p][co] * x[pix(p,kh,kw)][ci].
+ * Accumulates with float atomics (split-K over pixels and over micro-steps); zero dw once
+ * per optimizer step.  Replaces cuDNN wgrad / Linear weight grad reached through autograd
+ * from aldi/trainer.py:79. */
+typedef struct {
+    const void* x;      /* forward input  [N][H][W][Cin]                     */
+    const void* g;      /* grad wrt the conv output, [N][Ho][Wo][Cout]       */
+    float* dw;          /* fp32 gradient accumulator                         */
+    const float* scale; /* per-Cout multiplier (FrozenBN fold), nullable     */
+    int N, H, W, Cin, Cout, KH, KW, stride, pad, Ho, Wo;
+    int dtype;
+} aldi_wgrad_args;
+int aldi_conv_wgrad(const aldi_wgrad_args* a, aldi_stream_t stream);
+
+/* db[c] += sum_m g[m][c] (bias gradients), g is [M][C] in `dtype`. */
+int aldi_bias_grad(const void* g, float* db, int M, int C, int dtype, aldi_stream_t stream);
+
+/* Data-gradient weights: wt[Cin][KH][KW][Cout] = scale[co] * w[co][KH-1-kh][KW-1-kw][ci]
+ * (rotated + transposed, FrozenBN scale folded), so that dgrad is aldi_conv_igemm on g with
+ * pad' = KH-1-pad.  `w_master` is the fp32 master weight, output in `dtype`. */
+int aldi_dgrad_weights(const float* w_master, const float* scale, void* wt, int Cout, int KH, int KW, int Cin,
+                       int dtype, aldi_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif
