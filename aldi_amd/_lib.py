@@ -2,14 +2,18 @@
 
 The HIP library is the product: there is NO fallback.  If the shared object is missing the
 import of this module raises, and every wrapper raises ``AldiHipError`` on a non-zero status.
+
+Function prototypes are parsed from the header itself, so the binding cannot drift from the ABI.
 """
 from __future__ import annotations
 
 import ctypes as C
 import os
+import re
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libaldi_hip.so")
+HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "aldi_hip.h")
 
 
 class AldiHipError(RuntimeError):
@@ -22,16 +26,50 @@ if not os.path.exists(LIB_PATH):
         "(or `make -C aldi_amd/csrc`). There is no CPU fallback for the ALDI HIP path.")
 
 lib = C.CDLL(LIB_PATH)
-lib.aldi_last_error.restype = C.c_char_p
-lib.aldi_version.restype = C.c_int
 
 F32, BF16 = 0, 1
+MAX_IMAGES, MAX_LEVELS = 16, 5
 c_void_p, c_int, c_float, c_long = C.c_void_p, C.c_int, C.c_float, C.c_long
+
+
+def _ctype(decl: str):
+    decl = decl.strip()
+    if "*" in decl or decl.startswith("aldi_stream_t"):
+        return C.c_void_p
+    base = decl.rsplit(" ", 1)[0].replace("const", "").strip() if " " in decl else decl
+    return {"int": C.c_int, "long": C.c_long, "float": C.c_float, "size_t": C.c_size_t, "unsigned": C.c_uint,
+            "double": C.c_double}[base]
+
+
+def parse_header(path: str = HEADER_PATH):
+    """-> {name: (restype, [argtypes])} for every function prototype in the header."""
+    src = open(path).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    protos = {}
+    for m in re.finditer(r"\b(int|size_t|const char\*)\s+(aldi_\w+)\s*\(([^;{}]*?)\)\s*;", src, flags=re.S):
+        ret, name, args = m.group(1), m.group(2), m.group(3)
+        args = " ".join(args.split())
+        argtypes = [] if args in ("void", "") else [_ctype(a) for a in args.split(",")]
+        restype = {"int": C.c_int, "size_t": C.c_size_t, "const char*": C.c_char_p}[ret]
+        protos[name] = (restype, argtypes)
+    return protos
+
+
+PROTOS = parse_header()
+for _name, (_res, _args) in PROTOS.items():
+    _fn = getattr(lib, _name)        # AttributeError here == header/library mismatch: fail loudly
+    _fn.restype = _res
+    _fn.argtypes = _args
 
 
 def check(status: int, what: str = ""):
     if status != 0:
         raise AldiHipError(f"{what}: status {status}: {lib.aldi_last_error().decode()}")
+
+
+def call(name: str, *args):
+    """Invoke an int-returning entry point and raise on a non-zero status."""
+    check(getattr(lib, name)(*args), name)
 
 
 class ConvArgs(C.Structure):
@@ -46,16 +84,6 @@ class ConvArgs(C.Structure):
     ]
 
 
-def _sig(name, *argtypes):
-    fn = getattr(lib, name)
-    fn.argtypes = list(argtypes)
-    fn.restype = c_int
-    return fn
-
-
-conv_igemm = _sig("aldi_conv_igemm", C.POINTER(ConvArgs), c_void_p)
-
-
 class WgradArgs(C.Structure):
     _fields_ = [
         ("x", c_void_p), ("g", c_void_p), ("dw", c_void_p), ("scale", c_void_p),
@@ -64,6 +92,27 @@ class WgradArgs(C.Structure):
     ]
 
 
-conv_wgrad = _sig("aldi_conv_wgrad", C.POINTER(WgradArgs), c_void_p)
-bias_grad = _sig("aldi_bias_grad", c_void_p, c_void_p, c_int, c_int, c_int, c_void_p)
-dgrad_weights = _sig("aldi_dgrad_weights", c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p)
+class StemArgs(C.Structure):
+    _fields_ = [
+        ("img", c_void_p), ("w", c_void_p), ("scale", c_void_p), ("shift", c_void_p), ("y", c_void_p),
+        ("N", c_int), ("Hs", c_int), ("Ws", c_int), ("Hc", c_int), ("Wc", c_int),
+        ("h", c_int * MAX_IMAGES), ("w_img", c_int * MAX_IMAGES),
+        ("mean", c_float * 3), ("std", c_float * 3), ("dtype", c_int),
+    ]
+
+
+class RpnGeom(C.Structure):
+    _fields_ = [
+        ("num_levels", c_int), ("A", c_int), ("C", c_int),
+        ("H", c_int * MAX_LEVELS), ("W", c_int * MAX_LEVELS), ("off", c_int * (MAX_LEVELS + 1)),
+    ]
+
+
+class RoiFeats(C.Structure):
+    _fields_ = [
+        ("feat", c_void_p * 4), ("grad", c_void_p * 4), ("H", c_int * 4), ("W", c_int * 4),
+        ("scale", c_float * 4), ("C", c_int),
+    ]
+
+
+PtrArray5 = c_void_p * MAX_LEVELS

@@ -21,7 +21,338 @@ __global__ void dgrad_weights_kernel(const float* __restrict__ w, const float* _
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// Stem: (uint8 BGR - mean)/std, zero pad, conv 7x7 s2 p3 (fp32 math), FrozenBN, ReLU.
+// One block = one 16x16 tile of conv outputs of one image; a thread owns one pixel x 64 channels.
+// ------------------------------------------------------------------------------------------
+struct StemDev {
+    const uint8_t* img;   // [N][3][Hs][Ws] staging (image n occupies the top-left h[n] x w[n])
+    const float* w;       // [64][7][7][3] fp32
+    const float* scale; const float* shift;
+    void* y;              // [N][Hc][Wc][64]
+    int N, Hs, Ws, Hc, Wc;
+    int h[ALDI_MAX_IMAGES], wd[ALDI_MAX_IMAGES];
+    float mean[3], inv_std[3];
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void stem_kernel(StemDev p) {
+    constexpr int TI = 16 * 2 + 5;            // input tile edge
+    __shared__ float ws[147 * 64];            // [tap][co]
+    __shared__ float tile[3 * TI * TI];       // [c][y][x]
+    const int n = blockIdx.z;
+    const int oy0 = blockIdx.y * 16, ox0 = blockIdx.x * 16;
+    for (int i = threadIdx.x; i < 147 * 64; i += 256) {
+        int co = i & 63, tap = i >> 6;        // tap = (kh*7+kw)*3 + c
+        ws[i] = p.w[co * 147 + tap];
+    }
+    const int iy0 = oy0 * 2 - 3, ix0 = ox0 * 2 - 3;
+    const int h = p.h[n], w = p.wd[n];
+    for (int i = threadIdx.x; i < 3 * TI * TI; i += 256) {
+        int c = i / (TI * TI), r = i - c * TI * TI;
+        int yy = r / TI, xx = r - yy * TI;
+        int iy = iy0 + yy, ix = ix0 + xx;
+        float v = 0.f;
+        if (iy >= 0 && iy < h && ix >= 0 && ix < w)
+            v = ((float)p.img[(((long)n * 3 + c) * p.Hs + iy) * p.Ws + ix] - p.mean[c]) * p.inv_std[c];
+        tile[i] = v;
+    }
+    __syncthreads();
+    const int ty = threadIdx.x >> 4, tx = threadIdx.x & 15;
+    const int oy = oy0 + ty, ox = ox0 + tx;
+    float acc[64];
+#pragma unroll
+    for (int i = 0; i < 64; ++i) acc[i] = 0.f;
+    for (int kh = 0; kh < 7; ++kh)
+        for (int kw = 0; kw < 7; ++kw)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                float xv = tile[(c * TI + ty * 2 + kh) * TI + tx * 2 + kw];
+                const float4* wr = reinterpret_cast<const float4*>(&ws[((kh * 7 + kw) * 3 + c) * 64]);
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {
+                    float4 wv = wr[q];
+                    acc[q * 4 + 0] = fmaf(xv, wv.x, acc[q * 4 + 0]);
+                    acc[q * 4 + 1] = fmaf(xv, wv.y, acc[q * 4 + 1]);
+                    acc[q * 4 + 2] = fmaf(xv, wv.z, acc[q * 4 + 2]);
+                    acc[q * 4 + 3] = fmaf(xv, wv.w, acc[q * 4 + 3]);
+                }
+            }
+    if (oy < p.Hc && ox < p.Wc) {
+        T* out = static_cast<T*>(p.y) + (((long)n * p.Hc + oy) * p.Wc + ox) * 64;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            float v[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float t = acc[q * 4 + r] * p.scale[q * 4 + r] + p.shift[q * 4 + r];
+                v[r] = t > 0.f ? t : 0.f;
+            }
+            store4(out + q * 4, v);
+        }
+    }
+}
+
+// max_pool2d(kernel 3, stride 2, pad 1), NHWC, 4 channels per thread
+template <typename T>
+__global__ void maxpool3s2_kernel(const T* __restrict__ x, T* __restrict__ y, int N, int H, int W, int C, int Ho, int Wo) {
+    long total = (long)N * Ho * Wo * (C / 4);
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        int c4 = (int)(i % (C / 4));
+        long r = i / (C / 4);
+        int wo = (int)(r % Wo); r /= Wo;
+        int ho = (int)(r % Ho);
+        int n = (int)(r / Ho);
+        float m[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+        for (int dy = 0; dy < 3; ++dy) {
+            int hi = ho * 2 - 1 + dy;
+            if (hi < 0 || hi >= H) continue;
+            for (int dx = 0; dx < 3; ++dx) {
+                int wi = wo * 2 - 1 + dx;
+                if (wi < 0 || wi >= W) continue;
+                float v[4];
+                load4(x + (((long)n * H + hi) * W + wi) * C + c4 * 4, v);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) m[k] = fmaxf(m[k], v[k]);
+            }
+        }
+        store4(y + i * 4, m);
+    }
+}
+
+// y[n,ho,wo,:] = x[n,2ho,2wo,:]   (LastLevelMaxPool: max_pool2d(kernel 1, stride 2))
+template <typename T>
+__global__ void subsample2_kernel(const T* __restrict__ x, T* __restrict__ y, int N, int H, int W, int C, int Ho, int Wo) {
+    long total = (long)N * Ho * Wo * (C / 4);
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        int c4 = (int)(i % (C / 4));
+        long r = i / (C / 4);
+        int wo = (int)(r % Wo); r /= Wo;
+        int ho = (int)(r % Ho);
+        int n = (int)(r / Ho);
+        float v[4];
+        load4(x + (((long)n * H + ho * 2) * W + wo * 2) * C + c4 * 4, v);
+        store4(y + i * 4, v);
+    }
+}
+
+// gx[n,2ho,2wo,:] += gy[n,ho,wo,:]
+template <typename T>
+__global__ void subsample2_bwd_kernel(const T* __restrict__ gy, T* __restrict__ gx, int N, int H, int W, int C, int Ho, int Wo) {
+    long total = (long)N * Ho * Wo * (C / 4);
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        int c4 = (int)(i % (C / 4));
+        long r = i / (C / 4);
+        int wo = (int)(r % Wo); r /= Wo;
+        int ho = (int)(r % Ho);
+        int n = (int)(r / Ho);
+        float a[4], b[4];
+        load4(gy + i * 4, a);
+        T* dst = gx + (((long)n * H + ho * 2) * W + wo * 2) * C + c4 * 4;
+        load4(dst, b);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) b[k] += a[k];
+        store4(dst, b);
+    }
+}
+
+// backward of nearest-upsample x2 + add: out[n,h,w,:] (= or +=) sum of the 2x2 block of g
+template <typename T>
+__global__ void upsample2_bwd_kernel(const T* __restrict__ g, T* __restrict__ out, int N, int Hc, int Wc, int C, int accumulate) {
+    long total = (long)N * Hc * Wc * (C / 4);
+    const int H = Hc * 2, W = Wc * 2;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        int c4 = (int)(i % (C / 4));
+        long r = i / (C / 4);
+        int w = (int)(r % Wc); r /= Wc;
+        int h = (int)(r % Hc);
+        int n = (int)(r / Hc);
+        float s[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < 2; ++dx) {
+                float v[4];
+                load4(g + (((long)n * H + h * 2 + dy) * W + w * 2 + dx) * C + c4 * 4, v);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) s[k] += v[k];
+            }
+        if (accumulate) {
+            float o[4];
+            load4(out + i * 4, o);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) s[k] += o[k];
+        }
+        store4(out + i * 4, s);
+    }
+}
+
+// out = (a ? a : 0) + (b ? b : 0) * bscale, optionally masked by relu_src > 0; a is T, b is fp32
+template <typename T>
+__global__ void add_f32_kernel(const T* __restrict__ a, const float* __restrict__ b, const T* __restrict__ relu_src, T* __restrict__ out, long n4) {
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+        float v[4] = {0, 0, 0, 0};
+        if (a) load4(a + i * 4, v);
+        if (b) {
+            float4 t = *reinterpret_cast<const float4*>(b + i * 4);
+            v[0] += t.x; v[1] += t.y; v[2] += t.z; v[3] += t.w;
+        }
+        if (relu_src) {
+            float m[4];
+            load4(relu_src + i * 4, m);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[k] = m[k] > 0.f ? v[k] : 0.f;
+        }
+        store4(out + i * 4, v);
+    }
+}
+
+template <typename T>
+__global__ void cast_from_f32_kernel(const float* __restrict__ src, T* __restrict__ dst, long n) {
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) Elem<T>::st(dst + i, src[i]);
+}
+
+// torch.optim.SGD (momentum, dampening 0, nesterov off):  d = g + wd*p ; buf = mu*buf + d ; p -= lr*buf.
+// Also refreshes the compute-dtype copy of the weights.  Flat buffers; p/g/buf fp32.
+template <typename T>
+__global__ void sgd_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ buf, T* __restrict__ pc,
+                           long n, float lr, float mu, float wd, float gscale, int first) {
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        float w = p[i];
+        float d = g[i] * gscale + wd * w;
+        float b = first ? d : mu * buf[i] + d;
+        buf[i] = b;
+        w = w - lr * b;
+        p[i] = w;
+        if (pc) Elem<T>::st(pc + i, w);
+    }
+}
+
+// reference aldi/ema.py:43-46:  t = s*(1-alpha) + t*alpha   (copy_only: t = s, aldi/ema.py:29-30)
+template <typename T>
+__global__ void ema_kernel(float* __restrict__ t, const float* __restrict__ s, T* __restrict__ tc, long n, float one_minus_alpha, float alpha, int copy_only) {
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        float v = copy_only ? s[i] : s[i] * one_minus_alpha + t[i] * alpha;
+        t[i] = v;
+        if (tc) Elem<T>::st(tc + i, v);
+    }
+}
+
+// FrozenBN fold: scale = w * rsqrt(var + eps); shift = b - mean * scale
+__global__ void bn_fold_kernel(const float* __restrict__ w, const float* __restrict__ b, const float* __restrict__ mean,
+                               const float* __restrict__ var, float* __restrict__ scale, float* __restrict__ shift, int C, float eps) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < C) {
+        float sc = w[i] * (1.0f / sqrtf(var[i] + eps));
+        scale[i] = sc;
+        shift[i] = b[i] - mean[i] * sc;
+    }
+}
+
+static inline int nblocks(long n, int per = 256, int cap = 16384) {
+    long b = (n + per - 1) / per;
+    return (int)(b < 1 ? 1 : (b > cap ? cap : b));
+}
+
 }  // namespace
+
+#define DISPATCH_T(dtype, KERNEL, grid, block, st, ...)                                              \
+    do {                                                                                             \
+        if ((dtype) == ALDI_BF16) hipLaunchKernelGGL(KERNEL<bf16_t>, grid, block, 0, st, __VA_ARGS__); \
+        else if ((dtype) == ALDI_F32) hipLaunchKernelGGL(KERNEL<float>, grid, block, 0, st, __VA_ARGS__); \
+        else return aldi_set_error_msg(ALDI_ERR_ARG, #KERNEL ": bad dtype");                         \
+        ALDI_CHECK_LAUNCH();                                                                         \
+    } while (0)
+
+extern "C" int aldi_stem_forward(const aldi_stem_args* a, aldi_stream_t stream) {
+    if (!a || !a->img || !a->w || !a->y || a->N < 1 || a->N > ALDI_MAX_IMAGES) return aldi_set_error_msg(ALDI_ERR_ARG, "stem_forward: bad args");
+    StemDev d;
+    d.img = a->img; d.w = a->w; d.scale = a->scale; d.shift = a->shift; d.y = a->y;
+    d.N = a->N; d.Hs = a->Hs; d.Ws = a->Ws; d.Hc = a->Hc; d.Wc = a->Wc;
+    for (int i = 0; i < a->N; ++i) { d.h[i] = a->h[i]; d.wd[i] = a->w_img[i]; }
+    for (int c = 0; c < 3; ++c) { d.mean[c] = a->mean[c]; d.inv_std[c] = 1.0f / a->std[c]; }
+    dim3 grid(cdiv(a->Wc, 16), cdiv(a->Hc, 16), a->N);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    DISPATCH_T(a->dtype, stem_kernel, grid, dim3(256), st, d);
+    return ALDI_OK;
+}
+
+extern "C" int aldi_maxpool3s2(const void* x, void* y, int N, int H, int W, int C, int dtype, aldi_stream_t stream) {
+    int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+    long total = (long)N * Ho * Wo * (C / 4);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (dtype == ALDI_BF16) hipLaunchKernelGGL(maxpool3s2_kernel<bf16_t>, dim3(nblocks(total)), dim3(256), 0, st, (const bf16_t*)x, (bf16_t*)y, N, H, W, C, Ho, Wo);
+    else hipLaunchKernelGGL(maxpool3s2_kernel<float>, dim3(nblocks(total)), dim3(256), 0, st, (const float*)x, (float*)y, N, H, W, C, Ho, Wo);
+    ALDI_CHECK_LAUNCH();
+    return ALDI_OK;
+}
+
+extern "C" int aldi_subsample2(const void* x, void* y, int N, int H, int W, int C, int backward, int dtype, aldi_stream_t stream) {
+    int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+    long total = (long)N * Ho * Wo * (C / 4);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (!backward) {
+        if (dtype == ALDI_BF16) hipLaunchKernelGGL(subsample2_kernel<bf16_t>, dim3(nblocks(total)), dim3(256), 0, st, (const bf16_t*)x, (bf16_t*)y, N, H, W, C, Ho, Wo);
+        else hipLaunchKernelGGL(subsample2_kernel<float>, dim3(nblocks(total)), dim3(256), 0, st, (const float*)x, (float*)y, N, H, W, C, Ho, Wo);
+    } else {   // x = grad wrt small map [N][Ho][Wo][C], y = grad wrt big map (accumulated)
+        if (dtype == ALDI_BF16) hipLaunchKernelGGL(subsample2_bwd_kernel<bf16_t>, dim3(nblocks(total)), dim3(256), 0, st, (const bf16_t*)x, (bf16_t*)y, N, H, W, C, Ho, Wo);
+        else hipLaunchKernelGGL(subsample2_bwd_kernel<float>, dim3(nblocks(total)), dim3(256), 0, st, (const float*)x, (float*)y, N, H, W, C, Ho, Wo);
+    }
+    ALDI_CHECK_LAUNCH();
+    return ALDI_OK;
+}
+
+extern "C" int aldi_upsample2_bwd(const void* g, void* out, int N, int Hc, int Wc, int C, int accumulate, int dtype, aldi_stream_t stream) {
+    long total = (long)N * Hc * Wc * (C / 4);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (dtype == ALDI_BF16) hipLaunchKernelGGL(upsample2_bwd_kernel<bf16_t>, dim3(nblocks(total)), dim3(256), 0, st, (const bf16_t*)g, (bf16_t*)out, N, Hc, Wc, C, accumulate);
+    else hipLaunchKernelGGL(upsample2_bwd_kernel<float>, dim3(nblocks(total)), dim3(256), 0, st, (const float*)g, (float*)out, N, Hc, Wc, C, accumulate);
+    ALDI_CHECK_LAUNCH();
+    return ALDI_OK;
+}
+
+extern "C" int aldi_add_f32(const void* a, const float* b, const void* relu_src, void* out, long n, int dtype, aldi_stream_t stream) {
+    if (n % 4) return aldi_set_error_msg(ALDI_ERR_ARG, "add_f32: n must be a multiple of 4");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (dtype == ALDI_BF16) hipLaunchKernelGGL(add_f32_kernel<bf16_t>, dim3(nblocks(n / 4)), dim3(256), 0, st, (const bf16_t*)a, b, (const bf16_t*)relu_src, (bf16_t*)out, n / 4);
+    else hipLaunchKernelGGL(add_f32_kernel<float>, dim3(nblocks(n / 4)), dim3(256), 0, st, (const float*)a, b, (const float*)relu_src, (float*)out, n / 4);
+    ALDI_CHECK_LAUNCH();
+    return ALDI_OK;
+}
+
+extern "C" int aldi_cast_from_f32(const float* src, void* dst, long n, int dtype, aldi_stream_t stream) {
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (dtype == ALDI_BF16) hipLaunchKernelGGL(cast_from_f32_kernel<bf16_t>, dim3(nblocks(n)), dim3(256), 0, st, src, (bf16_t*)dst, n);
+    else hipLaunchKernelGGL(cast_from_f32_kernel<float>, dim3(nblocks(n)), dim3(256), 0, st, src, (float*)dst, n);
+    ALDI_CHECK_LAUNCH();
+    return ALDI_OK;
+}
+
+extern "C" int aldi_sgd_step(float* p, const float* g, float* buf, void* p_compute, long n, float lr, float momentum, float weight_decay,
+                             float grad_scale, int first_step, int dtype, aldi_stream_t stream) {
+    if (!p || !g || !buf) return aldi_set_error_msg(ALDI_ERR_ARG, "sgd_step: null pointer");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (dtype == ALDI_BF16) hipLaunchKernelGGL(sgd_kernel<bf16_t>, dim3(nblocks(n)), dim3(256), 0, st, p, g, buf, (bf16_t*)p_compute, n, lr, momentum, weight_decay, grad_scale, first_step);
+    else hipLaunchKernelGGL(sgd_kernel<float>, dim3(nblocks(n)), dim3(256), 0, st, p, g, buf, (float*)nullptr, n, lr, momentum, weight_decay, grad_scale, first_step);
+    ALDI_CHECK_LAUNCH();
+    return ALDI_OK;
+}
+
+extern "C" int aldi_ema_update(float* teacher, const float* student, void* teacher_compute, long n, float alpha, int copy_only, int dtype, aldi_stream_t stream) {
+    if (!teacher || !student) return aldi_set_error_msg(ALDI_ERR_ARG, "ema_update: null pointer");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const float oma = (float)(1.0 - (double)alpha);   // python computes (1 - alpha) in double, then multiplies an fp32 tensor
+    if (dtype == ALDI_BF16) hipLaunchKernelGGL(ema_kernel<bf16_t>, dim3(nblocks(n)), dim3(256), 0, st, teacher, student, (bf16_t*)teacher_compute, n, oma, alpha, copy_only);
+    else hipLaunchKernelGGL(ema_kernel<float>, dim3(nblocks(n)), dim3(256), 0, st, teacher, student, (float*)nullptr, n, oma, alpha, copy_only);
+    ALDI_CHECK_LAUNCH();
+    return ALDI_OK;
+}
+
+extern "C" int aldi_bn_fold(const float* w, const float* b, const float* mean, const float* var, float* scale, float* shift, int C, aldi_stream_t stream) {
+    hipLaunchKernelGGL(bn_fold_kernel, dim3(cdiv(C, 256)), dim3(256), 0, static_cast<hipStream_t>(stream), w, b, mean, var, scale, shift, C, 1e-5f);
+    ALDI_CHECK_LAUNCH();
+    return ALDI_OK;
+}
 
 extern "C" int aldi_dgrad_weights(const float* w_master, const float* scale, void* wt, int Cout, int KH, int KW, int Cin,
                                   int dtype, aldi_stream_t stream) {

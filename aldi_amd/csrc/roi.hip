@@ -1,0 +1,408 @@
+// ROI-head side: proposal labelling/sampling glue, ROIAlign forward/backward, box-head
+// losses (fwd+bwd) and the inference post-processing that turns teacher outputs into
+// pseudo-labels (softmax, score threshold, per-class NMS, top-k, pseudo-label threshold).
+//
+// Replaces detectron2 StandardROIHeads.label_and_sample_proposals, ROIPooler + torchvision
+// roi_align (aligned=True, sampling_ratio=0), FastRCNNOutputLayers.losses / inference and
+// the reference's own pseudo-label filter (aldi/pseudolabeler.py:51-67); call sites
+// aldi/distill.py:157,162 and aldi/pseudolabeler.py:21.
+#include "common.h"
+#include "sortscan.h"
+#include "nms.h"
+#include <hip/amd_detail/amd_hip_unsafe_atomics.h>
+
+
+namespace {
+
+// cand = proposals (count[n]) followed by the image's GT boxes (if any)  [add_ground_truth_to_proposals]
+__global__ void roi_append_gt_kernel(const float4* __restrict__ props, const int* __restrict__ pcount, int P,
+                                     const float4* __restrict__ gt, const int* __restrict__ gcount, int Gmax,
+                                     float4* __restrict__ cand, int* __restrict__ ccount, int Pcap) {
+    const int n = blockIdx.y;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int pc = pcount[n], gc = gcount[n];
+    if (i == 0) ccount[n] = pc + gc;
+    if (i >= Pcap) return;
+    float4 v = make_float4(0, 0, 0, 0);
+    if (i < pc) v = props[(long)n * P + i];
+    else if (i < pc + gc) v = gt[(long)n * Gmax + (i - pc)];
+    cand[(long)n * Pcap + i] = v;
+}
+
+// gt_classes per candidate: matched class for fg, K for bg, -2 padding
+__global__ void roi_classes_kernel(const int* __restrict__ labels, const int* __restrict__ best_idx, const int* __restrict__ gt_classes,
+                                   const int* __restrict__ gcount, int Gmax, int L, int K, int* __restrict__ cls) {
+    const int n = blockIdx.y;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= L) return;
+    const int lab = labels[(long)n * L + i];
+    int c;
+    if (lab == -2) c = -2;
+    else if (gcount[n] == 0) c = K;
+    else c = lab == 1 ? gt_classes[n * Gmax + best_idx[(long)n * L + i]] : K;
+    cls[(long)n * L + i] = c;
+}
+
+// sampled_idxs = cat(fg_list[sel_fg], bg_list[sel_bg]); rows of image n start at row_off[n]
+__global__ void roi_gather_kernel(const float4* __restrict__ cand, const int* __restrict__ cls, const int* __restrict__ best_idx, int L,
+                                  const int* __restrict__ lists, const int* __restrict__ sel, const int* __restrict__ nsel, int S,
+                                  const int* __restrict__ row_off, const float4* __restrict__ gt, const int* __restrict__ gcount, int Gmax,
+                                  float* __restrict__ rois /*[R][5]*/, int* __restrict__ r_cls, float4* __restrict__ r_gt, int* __restrict__ r_idx) {
+    const int n = blockIdx.y;
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    const int nf = nsel[n * 2], nb = nsel[n * 2 + 1];
+    if (j >= nf + nb) return;
+    const int kind = j < nf ? 0 : 1;
+    const int pos = sel[(n * 2 + kind) * S + (kind ? j - nf : j)];
+    const int idx = lists[((long)n * 2 + kind) * L + pos];
+    const int row = row_off[n] + j;
+    const float4 b = cand[(long)n * L + idx];
+    rois[row * 5 + 0] = (float)n;
+    rois[row * 5 + 1] = b.x; rois[row * 5 + 2] = b.y; rois[row * 5 + 3] = b.z; rois[row * 5 + 4] = b.w;
+    r_cls[row] = cls[(long)n * L + idx];
+    r_gt[row] = gcount[n] > 0 ? gt[(long)n * Gmax + best_idx[(long)n * L + idx]] : make_float4(0, 0, 0, 0);
+    r_idx[row] = idx;
+}
+
+// rois for inference: every proposal of every image, rows packed as [N][P] (padding rows get b = -1)
+__global__ void roi_from_proposals_kernel(const float4* __restrict__ props, const int* __restrict__ pcount, int P, float* __restrict__ rois) {
+    const int n = blockIdx.y;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= P) return;
+    const long row = (long)n * P + i;
+    const bool ok = i < pcount[n];
+    const float4 b = ok ? props[row] : make_float4(0, 0, 0, 0);
+    rois[row * 5 + 0] = ok ? (float)n : -1.f;
+    rois[row * 5 + 1] = b.x; rois[row * 5 + 2] = b.y; rois[row * 5 + 3] = b.z; rois[row * 5 + 4] = b.w;
+}
+
+struct Feats {
+    const void* f[4];
+    float* g[4];
+    int H[4], W[4];
+    float scale[4];
+    int C;
+};
+
+__device__ __forceinline__ int roi_level(float x1, float y1, float x2, float y2) {
+    // floor(4 + log2(sqrt(area)/224 + 1e-8)) clamped to [2,5], minus 2
+    float s = sqrtf((x2 - x1) * (y2 - y1));
+    float lv = floorf(4.f + log2f(s / 224.f + 1e-8f));
+    lv = fminf(fmaxf(lv, 2.f), 5.f);
+    return (int)lv - 2;
+}
+
+struct Bilin { int lo, hi; float l, h; bool dead; };
+__device__ __forceinline__ Bilin bilin_prep(float v, int size) {
+    Bilin b;
+    b.dead = v < -1.0f || v > (float)size;
+    if (v <= 0.f) v = 0.f;
+    int lo = (int)v, hi;
+    if (lo >= size - 1) { hi = lo = size - 1; v = (float)lo; }
+    else hi = lo + 1;
+    b.lo = lo; b.hi = hi;
+    b.l = v - (float)lo;
+    b.h = 1.f - b.l;
+    return b;
+}
+
+// grid (R, P): block = one output row (ph) of one ROI; thread = channel (C == blockDim.x)
+template <typename T, bool BWD>
+__global__ __launch_bounds__(256) void roialign_kernel(Feats ft, const float* __restrict__ rois, int P, T* __restrict__ pooled /*[R][P][P][C]*/) {
+    const int r = blockIdx.x, ph = blockIdx.y, c = threadIdx.x;
+    const float* rp = rois + (long)r * 5;
+    const int b = (int)rp[0];
+    if (b < 0) {
+        if (!BWD) for (int pw = 0; pw < P; ++pw) Elem<T>::st(pooled + (((long)r * P + ph) * P + pw) * ft.C + c, 0.f);
+        return;
+    }
+    const int l = roi_level(rp[1], rp[2], rp[3], rp[4]);
+    const int H = ft.H[l], W = ft.W[l];
+    const float sc = ft.scale[l];
+    const float x1 = rp[1] * sc - 0.5f, y1 = rp[2] * sc - 0.5f, x2 = rp[3] * sc - 0.5f, y2 = rp[4] * sc - 0.5f;
+    const float rw = x2 - x1, rh = y2 - y1;
+    const float bw = rw / (float)P, bh = rh / (float)P;
+    const int gh = (int)ceilf(rh / (float)P), gw = (int)ceilf(rw / (float)P);
+    const float count = (float)max(gh * gw, 1);
+    const T* F = static_cast<const T*>(ft.f[l]) + (long)b * H * W * ft.C + c;
+    float* G = BWD ? ft.g[l] + (long)b * H * W * ft.C + c : nullptr;
+    for (int pw = 0; pw < P; ++pw) {
+        T* op = pooled + (((long)r * P + ph) * P + pw) * ft.C + c;
+        float acc = 0.f, gval = 0.f;
+        if (BWD) gval = Elem<T>::ld(op) / count;
+        for (int iy = 0; iy < gh; ++iy) {
+            const float y = y1 + (float)ph * bh + ((float)iy + 0.5f) * bh / (float)gh;
+            const Bilin by = bilin_prep(y, H);
+            for (int ix = 0; ix < gw; ++ix) {
+                const float x = x1 + (float)pw * bw + ((float)ix + 0.5f) * bw / (float)gw;
+                const Bilin bx = bilin_prep(x, W);
+                if (by.dead || bx.dead) continue;
+                const float w1 = by.h * bx.h, w2 = by.h * bx.l, w3 = by.l * bx.h, w4 = by.l * bx.l;
+                const long o1 = ((long)by.lo * W + bx.lo) * ft.C, o2 = ((long)by.lo * W + bx.hi) * ft.C;
+                const long o3 = ((long)by.hi * W + bx.lo) * ft.C, o4 = ((long)by.hi * W + bx.hi) * ft.C;
+                if (!BWD) {
+                    float v = w1 * Elem<T>::ld(F + o1) + w2 * Elem<T>::ld(F + o2) + w3 * Elem<T>::ld(F + o3) + w4 * Elem<T>::ld(F + o4);
+                    acc += v;
+                } else {
+                    unsafeAtomicAdd(G + o1, gval * w1);
+                    unsafeAtomicAdd(G + o2, gval * w2);
+                    unsafeAtomicAdd(G + o3, gval * w3);
+                    unsafeAtomicAdd(G + o4, gval * w4);
+                }
+            }
+        }
+        if (!BWD) Elem<T>::st(op, acc / count);
+    }
+}
+
+// FastRCNNOutputLayers.losses: CE(mean over R) + L1 on the gt-class deltas of fg rows / R
+// pred row: [0,K] class logits, [K+1, K+1+4K) deltas (class*4+d).  grad += d(loss*gscale)/d(pred)
+__global__ __launch_bounds__(256) void box_loss_kernel(const float* __restrict__ pred, int Cp, int K, int R,
+                                                       const float* __restrict__ rois, const int* __restrict__ cls, const float4* __restrict__ gtb,
+                                                       float wx, float wy, float ww, float wh, float gs_cls, float gs_box,
+                                                       float* __restrict__ grad, float* __restrict__ loss /*[2]*/) {
+    __shared__ float red[16];
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    float l_cls = 0.f, l_box = 0.f;
+    const float invR = 1.f / (float)max(R, 1);
+    if (r < R) {
+        const float* p = pred + (long)r * Cp;
+        const int y = cls[r];
+        float m = p[0];
+        for (int k = 1; k <= K; ++k) m = fmaxf(m, p[k]);
+        float s = 0.f;
+        for (int k = 0; k <= K; ++k) s += expf(p[k] - m);
+        const float lse = m + logf(s);
+        l_cls = lse - p[y];
+        if (grad && gs_cls != 0.f)
+            for (int k = 0; k <= K; ++k) grad[(long)r * Cp + k] += (expf(p[k] - lse) - (k == y ? 1.f : 0.f)) * invR * gs_cls;
+        if (y >= 0 && y < K) {
+            const float* rp = rois + (long)r * 5;
+            float src_w = rp[3] - rp[1], src_h = rp[4] - rp[2];
+            float sx = rp[1] + 0.5f * src_w, sy = rp[2] + 0.5f * src_h;
+            const float4 t = gtb[r];
+            float tw = t.z - t.x, th = t.w - t.y;
+            float tx = t.x + 0.5f * tw, ty = t.y + 0.5f * th;
+            float d[4] = {wx * (tx - sx) / src_w, wy * (ty - sy) / src_h, ww * logf(tw / src_w), wh * logf(th / src_h)};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                float df = p[K + 1 + y * 4 + k] - d[k];
+                l_box += fabsf(df);
+                if (grad && gs_box != 0.f) grad[(long)r * Cp + K + 1 + y * 4 + k] += (df > 0.f ? 1.f : (df < 0.f ? -1.f : 0.f)) * invR * gs_box;
+            }
+        }
+    }
+    float s0 = block_sum(l_cls, red);
+    float s1 = block_sum(l_box, red);
+    if (threadIdx.x == 0) {
+        if (s0 != 0.f) unsafeAtomicAdd(loss + 0, s0 * invR);
+        if (s1 != 0.f) unsafeAtomicAdd(loss + 1, s1 * invR);
+    }
+}
+
+// ------------------------------------------------------------------------- inference post-processing
+constexpr int kDetCap = 8192;
+
+__device__ __forceinline__ float clampf(float v, float lo, float hi) { return fminf(fmaxf(v, lo), hi); }
+
+// score = softmax(logits)[k] for k < K; candidates with score > thresh appended (unordered; the sort fixes the order)
+__global__ void det_candidates_kernel(const float* __restrict__ pred, int Cp, int K, const int* __restrict__ pcount, int P, float score_thresh,
+                                      unsigned long long* __restrict__ keys /*[N][cap]*/, int* __restrict__ cnt, int* __restrict__ err) {
+    const int n = blockIdx.y;
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int r = t / K, k = t - r * K;
+    if (r >= pcount[n]) return;
+    const float* p = pred + ((long)n * P + r) * Cp;
+    float m = p[0];
+    for (int j = 1; j <= K; ++j) m = fmaxf(m, p[j]);
+    float s = 0.f;
+    for (int j = 0; j <= K; ++j) s += expf(p[j] - m);
+    const float prob = expf(p[k] - m) / s;
+    if (!isfinite(prob)) { atomicOr(err, 2); return; }
+    if (prob > score_thresh) {
+        int slot = atomicAdd(cnt + n, 1);
+        if (slot < kDetCap) keys[(long)n * kDetCap + slot] = ((unsigned long long)(~float_key_asc(prob)) << 32) | (unsigned)t;
+        else atomicOr(err, 4);
+    }
+}
+
+// sort candidates by (score desc, flat index asc); materialise boxes (decoded for the candidate's class, clipped)
+__global__ __launch_bounds__(1024) void det_sort_kernel(const float* __restrict__ pred, int Cp, int K, const float4* __restrict__ props, int P,
+                                                        const int* __restrict__ img_hw, float wx, float wy, float ww, float wh,
+                                                        unsigned long long* __restrict__ keys, int* __restrict__ cnt,
+                                                        float4* __restrict__ boxes, float* __restrict__ scores, int* __restrict__ cats, int* __restrict__ valid) {
+    extern __shared__ unsigned long long sk[];
+    const int n = blockIdx.x;
+    const int c = min(cnt[n], kDetCap);
+    int p2 = 1024;
+    while (p2 < c) p2 <<= 1;
+    for (int i = threadIdx.x; i < p2; i += blockDim.x) sk[i] = i < c ? keys[(long)n * kDetCap + i] : ~0ull;
+    __syncthreads();
+    bitonic_sort_u64(sk, p2);
+    const float ih = (float)img_hw[n * 2], iw = (float)img_hw[n * 2 + 1];
+    const float clampv = 4.135166556742356f;
+    for (int i = threadIdx.x; i < c; i += blockDim.x) {
+        unsigned long long key = sk[i];
+        int t = (int)(key & 0xffffffffu);
+        int r = t / K, k = t - r * K;
+        const float* p = pred + ((long)n * P + r) * Cp;
+        const float4 b = props[(long)n * P + r];
+        float w = b.z - b.x, h = b.w - b.y;
+        float cx = b.x + 0.5f * w, cy = b.y + 0.5f * h;
+        float dx = p[K + 1 + k * 4 + 0] / wx, dy = p[K + 1 + k * 4 + 1] / wy;
+        float dw = fminf(p[K + 1 + k * 4 + 2] / ww, clampv), dh = fminf(p[K + 1 + k * 4 + 3] / wh, clampv);
+        float pcx = dx * w + cx, pcy = dy * h + cy, pw = expf(dw) * w, phh = expf(dh) * h;
+        float4 o = make_float4(pcx - 0.5f * pw, pcy - 0.5f * phh, pcx + 0.5f * pw, pcy + 0.5f * phh);
+        o.x = clampf(o.x, 0.f, iw); o.y = clampf(o.y, 0.f, ih); o.z = clampf(o.z, 0.f, iw); o.w = clampf(o.w, 0.f, ih);
+        const long slot = (long)n * kDetCap + i;
+        boxes[slot] = o;
+        scores[slot] = key_asc_to_float(~(unsigned)(key >> 32));
+        cats[slot] = k;
+        valid[slot] = 1;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) cnt[n] = c;
+}
+
+// first `keep_count` survivors -> detections; detections with score > thr -> pseudo-labels (order preserved)
+__global__ void det_finish_kernel(const float4* __restrict__ boxes, const float* __restrict__ scores, const int* __restrict__ cats,
+                                  const int* __restrict__ keep, const int* __restrict__ keep_count, int topk, float pl_thresh,
+                                  float4* __restrict__ det_boxes, float* __restrict__ det_scores, int* __restrict__ det_cls, int* __restrict__ det_count,
+                                  float4* __restrict__ pl_boxes, int* __restrict__ pl_cls, float* __restrict__ pl_scores, int* __restrict__ pl_count) {
+    const int n = blockIdx.x;
+    if (threadIdx.x != 0) return;
+    const int kc = min(keep_count[n], topk);
+    int np = 0;
+    for (int j = 0; j < topk; ++j) {
+        float4 b = make_float4(0, 0, 0, 0);
+        float s = 0.f;
+        int c = -1;
+        if (j < kc) {
+            long slot = (long)n * kDetCap + keep[(long)n * kDetCap + j];
+            b = boxes[slot]; s = scores[slot]; c = cats[slot];
+            if (s > pl_thresh) {
+                pl_boxes[(long)n * topk + np] = b; pl_cls[n * topk + np] = c; pl_scores[n * topk + np] = s;
+                ++np;
+            }
+        }
+        det_boxes[(long)n * topk + j] = b; det_scores[n * topk + j] = s; det_cls[n * topk + j] = c;
+    }
+    for (int j = np; j < topk; ++j) { pl_boxes[(long)n * topk + j] = make_float4(0, 0, 0, 0); pl_cls[n * topk + j] = -1; pl_scores[n * topk + j] = 0.f; }
+    det_count[n] = kc;
+    pl_count[n] = np;
+}
+
+Feats make_feats(const aldi_roi_feats* f, bool bwd) {
+    Feats ft;
+    for (int l = 0; l < 4; ++l) {
+        ft.f[l] = f->feat[l]; ft.g[l] = bwd ? f->grad[l] : nullptr;
+        ft.H[l] = f->H[l]; ft.W[l] = f->W[l]; ft.scale[l] = f->scale[l];
+    }
+    ft.C = f->C;
+    return ft;
+}
+
+}  // namespace
+
+extern "C" int aldi_roi_prepare(const float* props, const int* pcount, int P, const float* gt_boxes, const int* gt_classes, const int* gt_count,
+                                int Gmax, int N, int K, float iou_thresh, float* cand, int* ccount, float* best_iou, int* best_idx,
+                                unsigned* gt_best_scratch, int* labels, int* cls, aldi_stream_t stream) {
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int L = P + Gmax;
+    hipLaunchKernelGGL(roi_append_gt_kernel, dim3(cdiv(L, 256), N), dim3(256), 0, st, (const float4*)props, pcount, P, (const float4*)gt_boxes, gt_count, Gmax,
+                       (float4*)cand, ccount, L);
+    ALDI_CHECK_LAUNCH();
+    int rc = aldi_box_match(cand, L, ccount, L, gt_boxes, gt_count, Gmax, N, iou_thresh, iou_thresh, 0, best_iou, best_idx, gt_best_scratch, labels, stream);
+    if (rc) return rc;
+    hipLaunchKernelGGL(roi_classes_kernel, dim3(cdiv(L, 256), N), dim3(256), 0, st, labels, best_idx, gt_classes, gt_count, Gmax, L, K, cls);
+    ALDI_CHECK_LAUNCH();
+    return ALDI_OK;
+}
+
+extern "C" int aldi_roi_gather(const float* cand, const int* cls, const int* best_idx, int L, const int* lists, const int* sel, const int* nsel, int S,
+                               const int* row_off, const float* gt_boxes, const int* gt_count, int Gmax, int N,
+                               float* rois, int* r_cls, float* r_gt, int* r_idx, aldi_stream_t stream) {
+    hipLaunchKernelGGL(roi_gather_kernel, dim3(cdiv(S * 2, 256), N), dim3(256), 0, static_cast<hipStream_t>(stream), (const float4*)cand, cls, best_idx, L, lists, sel, nsel, S,
+                       row_off, (const float4*)gt_boxes, gt_count, Gmax, rois, r_cls, (float4*)r_gt, r_idx);
+    ALDI_CHECK_LAUNCH();
+    return ALDI_OK;
+}
+
+extern "C" int aldi_rois_from_proposals(const float* props, const int* pcount, int P, int N, float* rois, aldi_stream_t stream) {
+    hipLaunchKernelGGL(roi_from_proposals_kernel, dim3(cdiv(P, 256), N), dim3(256), 0, static_cast<hipStream_t>(stream), (const float4*)props, pcount, P, rois);
+    ALDI_CHECK_LAUNCH();
+    return ALDI_OK;
+}
+
+extern "C" int aldi_roialign(const aldi_roi_feats* f, const float* rois, int R, int P, void* pooled, int backward, int dtype, aldi_stream_t stream) {
+    if (!f || !rois || !pooled || f->C != 256) return aldi_set_error_msg(ALDI_ERR_ARG, "roialign: bad args (C must be 256)");
+    if (R <= 0) return ALDI_OK;
+    Feats ft = make_feats(f, backward != 0);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    dim3 grid(R, P);
+    if (dtype == ALDI_BF16) {
+        if (backward) hipLaunchKernelGGL((roialign_kernel<bf16_t, true>), grid, dim3(256), 0, st, ft, rois, P, (bf16_t*)pooled);
+        else hipLaunchKernelGGL((roialign_kernel<bf16_t, false>), grid, dim3(256), 0, st, ft, rois, P, (bf16_t*)pooled);
+    } else {
+        if (backward) hipLaunchKernelGGL((roialign_kernel<float, true>), grid, dim3(256), 0, st, ft, rois, P, (float*)pooled);
+        else hipLaunchKernelGGL((roialign_kernel<float, false>), grid, dim3(256), 0, st, ft, rois, P, (float*)pooled);
+    }
+    ALDI_CHECK_LAUNCH();
+    return ALDI_OK;
+}
+
+extern "C" int aldi_box_loss(const float* pred, int Cp, int K, int R, const float* rois, const int* cls, const float* gt_boxes,
+                             const float* weights4, float grad_scale_cls, float grad_scale_box, float* grad, float* loss2, aldi_stream_t stream) {
+    if (!pred || !rois || !cls || !gt_boxes || !loss2 || !weights4) return aldi_set_error_msg(ALDI_ERR_ARG, "box_loss: null pointer");
+    if (R <= 0) return ALDI_OK;
+    hipLaunchKernelGGL(box_loss_kernel, dim3(cdiv(R, 256)), dim3(256), 0, static_cast<hipStream_t>(stream), pred, Cp, K, R, rois, cls, (const float4*)gt_boxes,
+                       weights4[0], weights4[1], weights4[2], weights4[3], grad_scale_cls, grad_scale_box, grad, loss2);
+    ALDI_CHECK_LAUNCH();
+    return ALDI_OK;
+}
+
+extern "C" size_t aldi_detections_workspace(int N) {
+    size_t cap = kDetCap, s = 0;
+    s += (size_t)N * cap * 8 + 256;                 // keys
+    s += (size_t)N * 4 + 256;                       // cnt
+    s += (size_t)N * cap * (16 + 4 + 4 + 4) + 1024; // boxes, scores, cats, valid
+    s += (size_t)N * cap * (cap / 64) * 8 + 256;    // mask
+    s += (size_t)N * cap * 4 + (size_t)N * 4 + 512; // keep, keep_count
+    return s + 1024;
+}
+
+extern "C" int aldi_detections(const float* pred, int Cp, int K, const float* props, const int* pcount, int P, int N, const int* img_hw,
+                               const float* weights4, float score_thresh, float nms_thresh, int topk, float pl_thresh, void* workspace,
+                               float* det_boxes, float* det_scores, int* det_cls, int* det_count,
+                               float* pl_boxes, int* pl_cls, float* pl_scores, int* pl_count, int* err_flag, aldi_stream_t stream) {
+    if (!pred || !props || !pcount || !img_hw || !workspace || !weights4) return aldi_set_error_msg(ALDI_ERR_ARG, "detections: null pointer");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const size_t cap = kDetCap;
+    char* w = static_cast<char*>(workspace);
+    auto take = [&](size_t bytes) { char* p = w; w += (bytes + 255) / 256 * 256; return p; };
+    auto* keys = (unsigned long long*)take((size_t)N * cap * 8);
+    auto* cnt = (int*)take((size_t)N * 4);
+    auto* boxes = (float4*)take((size_t)N * cap * 16);
+    auto* scores = (float*)take((size_t)N * cap * 4);
+    auto* cats = (int*)take((size_t)N * cap * 4);
+    auto* valid = (int*)take((size_t)N * cap * 4);
+    auto* mask = (unsigned long long*)take((size_t)N * cap * (cap / 64) * 8);
+    auto* keep = (int*)take((size_t)N * cap * 4);
+    auto* keep_count = (int*)take((size_t)N * 4);
+    hipError_t e = hipMemsetAsync(cnt, 0, (size_t)N * 4, st);
+    if (e != hipSuccess) return aldi_set_error(e, __FILE__, __LINE__);
+    hipLaunchKernelGGL(det_candidates_kernel, dim3(cdiv((long)P * K, 256), N), dim3(256), 0, st, pred, Cp, K, pcount, P, score_thresh, keys, cnt, err_flag);
+    ALDI_CHECK_LAUNCH();
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(det_sort_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kDetCap * 8);
+    hipLaunchKernelGGL(det_sort_kernel, dim3(N), dim3(1024), kDetCap * 8, st, pred, Cp, K, (const float4*)props, P, img_hw, weights4[0], weights4[1], weights4[2], weights4[3],
+                       keys, cnt, boxes, scores, cats, valid);
+    ALDI_CHECK_LAUNCH();
+    hipLaunchKernelGGL(nms_mask_kernel, dim3(cap / 64, cap / 64, N), dim3(64), 0, st, boxes, valid, cats, cnt, (int)cap, nms_thresh, mask);
+    ALDI_CHECK_LAUNCH();
+    hipLaunchKernelGGL(nms_scan_kernel, dim3(N), dim3(64), (cap / 64) * 8, st, mask, valid, cnt, (int)cap, topk, keep, keep_count);
+    ALDI_CHECK_LAUNCH();
+    hipLaunchKernelGGL(det_finish_kernel, dim3(N), dim3(64), 0, st, boxes, scores, cats, keep, keep_count, topk, pl_thresh,
+                       (float4*)det_boxes, det_scores, det_cls, det_count, (float4*)pl_boxes, pl_cls, pl_scores, pl_count);
+    ALDI_CHECK_LAUNCH();
+    return ALDI_OK;
+}

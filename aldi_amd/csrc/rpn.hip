@@ -1,0 +1,452 @@
+// RPN-side integer/index work: IoU matching, sampling lists, RPN losses (fwd+bwd), and
+// proposal generation (per-level top-k, box decode, batched NMS, post-NMS top-k).
+//
+// Everything that produces an INDEX is bit-exact against the oracle given identical fp32
+// inputs: IoU / box arithmetic follows the oracle's fp32 operation order (compiled with
+// -ffp-contract=off, IEEE division), ties resolve to the lower index, ordering is a total
+// order on (score desc, index asc).
+//
+// Replaces detectron2 RPN.label_and_sample_anchors / losses / predict_proposals and
+// torchvision batched_nms, reached from the reference at aldi/distill.py:157,162,200-202 and
+// aldi/pseudolabeler.py:21.
+#include "common.h"
+#include "sortscan.h"
+#include "nms.h"
+#include <hip/amd_detail/amd_hip_unsafe_atomics.h>
+
+namespace {
+
+__device__ __forceinline__ float iou_d2(const float4 g, const float4 a) {
+    // detectron2 pairwise_iou: inter > 0 ? inter / (area1 + area2 - inter) : 0
+    float area1 = (g.z - g.x) * (g.w - g.y);
+    float area2 = (a.z - a.x) * (a.w - a.y);
+    float w = fminf(g.z, a.z) - fmaxf(g.x, a.x);
+    float h = fminf(g.w, a.w) - fmaxf(g.y, a.y);
+    w = w > 0.f ? w : 0.f;
+    h = h > 0.f ? h : 0.f;
+    float inter = w * h;
+    return inter > 0.f ? inter / (area1 + area2 - inter) : 0.f;
+}
+
+// ---------------------------------------------------------------------------------------
+// Matcher (detectron2 Matcher): per box max/argmax IoU over GT (first max wins), per-GT best
+// ---------------------------------------------------------------------------------------
+__global__ void match_iou_kernel(const float4* __restrict__ boxes, long box_stride_n, const int* __restrict__ box_count, int L,
+                                 const float4* __restrict__ gt, const int* __restrict__ gt_count, int Gmax,
+                                 float* __restrict__ best_iou, int* __restrict__ best_idx, unsigned* __restrict__ gt_best) {
+    const int n = blockIdx.y;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int cnt = box_count ? box_count[n] : L;
+    if (i >= cnt) return;
+    const int G = gt_count[n];
+    const float4 b = boxes[n * box_stride_n + i];
+    float best = -1.f;
+    int bi = 0;
+    for (int g = 0; g < G; ++g) {
+        float v = iou_d2(gt[n * Gmax + g], b);
+        if (v > best) { best = v; bi = g; }
+        if (v > 0.f) atomicMax(gt_best + n * Gmax + g, __float_as_uint(v));
+    }
+    best_iou[(long)n * L + i] = best;
+    best_idx[(long)n * L + i] = bi;
+}
+
+__global__ void match_label_kernel(const float4* __restrict__ boxes, long box_stride_n, const int* __restrict__ box_count, int L,
+                                   const float4* __restrict__ gt, const int* __restrict__ gt_count, int Gmax,
+                                   const float* __restrict__ best_iou, const unsigned* __restrict__ gt_best,
+                                   float lo, float hi, int allow_low_quality, int* __restrict__ labels) {
+    const int n = blockIdx.y;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int cnt = box_count ? box_count[n] : L;
+    if (i >= L) return;
+    if (i >= cnt) { labels[(long)n * L + i] = -2; return; }     // padding slot, never sampled
+    const int G = gt_count[n];
+    int lab;
+    if (G == 0) lab = 0;
+    else {
+        float v = best_iou[(long)n * L + i];
+        lab = v < lo ? 0 : (v < hi ? -1 : 1);
+        if (allow_low_quality) {
+            const float4 b = boxes[n * box_stride_n + i];
+            for (int g = 0; g < G; ++g) {
+                float u = iou_d2(gt[n * Gmax + g], b);
+                if (__float_as_uint(u) == gt_best[n * Gmax + g]) { lab = 1; break; }
+            }
+        }
+    }
+    labels[(long)n * L + i] = lab;
+}
+
+// ---------------------------------------------------------------------------------------
+// ordered lists for subsample_labels: pos = (v != -1 && v != bg && v != -2), neg = (v == bg)
+// grid (2, N): blockIdx.x = kind
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void compact_kernel(const int* __restrict__ labels, int L, int bg,
+                                                       int* __restrict__ lists /*[N][2][L]*/, int* __restrict__ counts /*[N][2]*/) {
+    __shared__ int sm[17];
+    const int kind = blockIdx.x, n = blockIdx.y;
+    const int* lab = labels + (long)n * L;
+    int* out = lists + ((long)n * 2 + kind) * L;
+    int base = 0;
+    for (int s = 0; s < L; s += blockDim.x) {
+        int i = s + threadIdx.x;
+        bool f = false;
+        if (i < L) {
+            int v = lab[i];
+            f = kind == 0 ? (v != -1 && v != -2 && v != bg) : (v == bg);
+        }
+        int tot;
+        int r = block_rank(f, sm, &tot);
+        if (f) out[base + r] = i;
+        base += tot;
+    }
+    if (threadIdx.x == 0) counts[n * 2 + kind] = base;
+}
+
+// labels.fill_(-1); labels[pos_list[sel_pos]] = 1; labels[neg_list[sel_neg]] = 0
+__global__ void fill_int_kernel(int* p, long n, int v) {
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) p[i] = v;
+}
+__global__ void sample_scatter_kernel(int* __restrict__ labels, int L, const int* __restrict__ lists, const int* __restrict__ sel /*[N][2][S]*/,
+                                      const int* __restrict__ nsel /*[N][2]*/, int S) {
+    const int n = blockIdx.y, kind = blockIdx.x;
+    const int cnt = nsel[n * 2 + kind];
+    for (int j = threadIdx.x; j < cnt; j += blockDim.x) {
+        int pos = sel[(n * 2 + kind) * S + j];
+        int idx = lists[((long)n * 2 + kind) * L + pos];
+        labels[(long)n * L + idx] = kind == 0 ? 1 : 0;
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// RPN losses, forward + backward into the head-output gradient
+// ---------------------------------------------------------------------------------------
+struct Geom {
+    int nl, A, C, sumA;
+    int H[ALDI_MAX_LEVELS], W[ALDI_MAX_LEVELS], off[ALDI_MAX_LEVELS + 1];
+    float* head[ALDI_MAX_LEVELS];
+    float* grad[ALDI_MAX_LEVELS];
+};
+
+__device__ __forceinline__ int find_level(const Geom& g, int i) {
+    int l = 0;
+#pragma unroll
+    for (int k = 1; k < ALDI_MAX_LEVELS; ++k)
+        if (k < g.nl && i >= g.off[k]) l = k;
+    return l;
+}
+
+__device__ __forceinline__ float bce_logits(float x, float y) {
+    // torch binary_cross_entropy_with_logits: (1-y)*x + max(-x,0) + log(exp(-m) + exp(-x-m)), m = max(-x,0)
+    float m = fmaxf(-x, 0.f);
+    return (1.f - y) * x + m + logf(expf(-m) + expf(-x - m));
+}
+
+__device__ __forceinline__ void box_deltas(const float4 src, const float4 tgt, float wx, float wy, float ww, float wh, float d[4]) {
+    float sw = src.z - src.x, sh = src.w - src.y;
+    float sx = src.x + 0.5f * sw, sy = src.y + 0.5f * sh;
+    float tw = tgt.z - tgt.x, th = tgt.w - tgt.y;
+    float tx = tgt.x + 0.5f * tw, ty = tgt.y + 0.5f * th;
+    d[0] = wx * (tx - sx) / sw;
+    d[1] = wy * (ty - sy) / sh;
+    d[2] = ww * logf(tw / sw);
+    d[3] = wh * logf(th / sh);
+}
+
+__global__ __launch_bounds__(256) void rpn_loss_kernel(Geom g, const float4* __restrict__ anchors, const int* __restrict__ labels,
+                                                       const int* __restrict__ matched, const float4* __restrict__ gt, const int* __restrict__ gt_count,
+                                                       int Gmax, int N, float inv_norm, float gs_cls, float gs_loc, float* __restrict__ loss /*[2]*/) {
+    __shared__ float red[16];
+    const long t = blockIdx.x * (long)blockDim.x + threadIdx.x;
+    float l_cls = 0.f, l_loc = 0.f;
+    if (t < (long)N * g.sumA) {
+        const int n = (int)(t / g.sumA), i = (int)(t - (long)n * g.sumA);
+        const int lab = labels[t];
+        if (lab >= 0) {
+            const int l = find_level(g, i);
+            const int j = i - g.off[l];
+            const int cell = j / g.A, a = j - cell * g.A;
+            const long base = ((long)n * g.H[l] * g.W[l] + cell) * g.C;
+            const float x = g.head[l][base + a];
+            const float y = (float)lab;
+            l_cls = bce_logits(x, y);
+            if (g.grad[l] && gs_cls != 0.f) g.grad[l][base + a] += (1.f / (1.f + expf(-x)) - y) * inv_norm * gs_cls;
+            if (lab == 1) {
+                float4 tb = make_float4(0, 0, 0, 0);
+                if (gt_count[n] > 0) tb = gt[n * Gmax + matched[t]];
+                float d[4];
+                box_deltas(anchors[i], tb, 1.f, 1.f, 1.f, 1.f, d);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    float pr = g.head[l][base + g.A + a * 4 + k];
+                    float df = pr - d[k];
+                    l_loc += fabsf(df);
+                    if (g.grad[l] && gs_loc != 0.f) g.grad[l][base + g.A + a * 4 + k] += (df > 0.f ? 1.f : (df < 0.f ? -1.f : 0.f)) * inv_norm * gs_loc;
+                }
+            }
+        }
+    }
+    float s0 = block_sum(l_cls, red);
+    float s1 = block_sum(l_loc, red);
+    if (threadIdx.x == 0) {
+        if (s0 != 0.f) unsafeAtomicAdd(loss + 0, s0 * inv_norm);
+        if (s1 != 0.f) unsafeAtomicAdd(loss + 1, s1 * inv_norm);
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// proposals
+// ---------------------------------------------------------------------------------------
+constexpr int kTopkCap = 2048;     // >= PRE_NMS_TOPK (2000)
+constexpr int kMergeCap = 16384;   // >= 5 * 2000
+
+// per (level, image): exact top-k by (logit desc, index asc), sorted. block = 1024 threads.
+__global__ __launch_bounds__(1024) void rpn_topk_kernel(Geom g, int pre_nms_topk, unsigned long long* __restrict__ cand /*[N][nl][kTopkCap]*/,
+                                                        int* __restrict__ cand_count /*[N][nl]*/) {
+    __shared__ unsigned long long keys[kTopkCap];
+    __shared__ int hist[256];
+    __shared__ int sm[17];
+    __shared__ unsigned s_prefix;
+    __shared__ int s_need;
+    const int l = blockIdx.x, n = blockIdx.y;
+    const int nel = g.H[l] * g.W[l] * g.A;
+    const int k = min(pre_nms_topk, nel);
+    const float* head = g.head[l] + (long)n * g.H[l] * g.W[l] * g.C;
+    auto key_of = [&](int i) -> unsigned {
+        int cell = i / g.A, a = i - cell * g.A;
+        return float_key_asc(head[(long)cell * g.C + a]);
+    };
+    // radix select of the k-th largest key (MSB first)
+    unsigned prefix = 0, mask = 0;
+    int need = k;
+    for (int shift = 24; shift >= 0; shift -= 8) {
+        for (int i = threadIdx.x; i < 256; i += blockDim.x) hist[i] = 0;
+        __syncthreads();
+        for (int i = threadIdx.x; i < nel; i += blockDim.x) {
+            unsigned key = key_of(i);
+            if ((key & mask) == prefix) atomicAdd(&hist[(key >> shift) & 255], 1);
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            int acc = 0, b = 255;
+            for (; b > 0; --b) {
+                if (acc + hist[b] >= need) break;
+                acc += hist[b];
+            }
+            s_prefix = prefix | ((unsigned)b << shift);
+            s_need = need - acc;
+        }
+        __syncthreads();
+        prefix = s_prefix;
+        need = s_need;
+        mask |= 255u << shift;
+        __syncthreads();
+    }
+    const unsigned kth = prefix;      // exact key of the k-th largest; `need` of the equal keys are taken (lowest indices)
+    for (int i = threadIdx.x; i < kTopkCap; i += blockDim.x) keys[i] = ~0ull;
+    __syncthreads();
+    int base_gt = 0, base_eq = 0;
+    for (int s = 0; s < nel; s += blockDim.x) {
+        int i = s + threadIdx.x;
+        unsigned key = i < nel ? key_of(i) : 0u;
+        bool gt = i < nel && key > kth;
+        bool eq = i < nel && key == kth;
+        int tg, te;
+        int rg = block_rank(gt, sm, &tg);
+        int re = block_rank(eq, sm, &te);
+        // descending by key, ascending by index: sort key = (~key) << 32 | index
+        if (gt) keys[base_gt + rg] = ((unsigned long long)(~key) << 32) | (unsigned)i;
+        if (eq && base_eq + re < need) keys[(k - need) + base_eq + re] = ((unsigned long long)(~key) << 32) | (unsigned)i;
+        base_gt += tg;
+        base_eq += te;
+    }
+    __syncthreads();
+    bitonic_sort_u64(keys, kTopkCap);
+    unsigned long long* out = cand + ((long)n * g.nl + l) * kTopkCap;
+    for (int i = threadIdx.x; i < kTopkCap; i += blockDim.x) out[i] = keys[i];
+    if (threadIdx.x == 0) cand_count[n * g.nl + l] = k;
+}
+
+__device__ __forceinline__ float4 apply_deltas_d2(const float4 box, float dx, float dy, float dw, float dh, float wx, float wy, float ww, float wh) {
+    const float clampv = 4.135166556742356f;   // log(1000/16)
+    float w = box.z - box.x, h = box.w - box.y;
+    float cx = box.x + 0.5f * w, cy = box.y + 0.5f * h;
+    dx = dx / wx; dy = dy / wy; dw = dw / ww; dh = dh / wh;
+    dw = fminf(dw, clampv); dh = fminf(dh, clampv);
+    float pcx = dx * w + cx, pcy = dy * h + cy;
+    float pw = expf(dw) * w, ph = expf(dh) * h;
+    return make_float4(pcx - 0.5f * pw, pcy - 0.5f * ph, pcx + 0.5f * pw, pcy + 0.5f * ph);
+}
+
+__device__ __forceinline__ float clampf(float v, float lo, float hi) { return fminf(fmaxf(v, lo), hi); }
+
+// decode + clip + validity of the sorted candidates
+__global__ void rpn_decode_kernel(Geom g, const float4* __restrict__ anchors, const unsigned long long* __restrict__ cand,
+                                  const int* __restrict__ cand_count, const int* __restrict__ img_hw /*[N][2]*/,
+                                  float4* __restrict__ boxes /*[N][nl][cap]*/, float* __restrict__ scores, int* __restrict__ valid, int* __restrict__ err) {
+    const int l = blockIdx.y, n = blockIdx.z;
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    const long slot = ((long)n * g.nl + l) * kTopkCap + r;
+    if (r >= kTopkCap) return;
+    if (r >= cand_count[n * g.nl + l]) { valid[slot] = 0; return; }
+    unsigned long long key = cand[slot];
+    int i = (int)(key & 0xffffffffu);
+    int cell = i / g.A, a = i - cell * g.A;
+    const float* hp = g.head[l] + ((long)n * g.H[l] * g.W[l] + cell) * g.C;
+    float sc = hp[a];
+    float4 b = apply_deltas_d2(anchors[g.off[l] + i], hp[g.A + a * 4 + 0], hp[g.A + a * 4 + 1], hp[g.A + a * 4 + 2], hp[g.A + a * 4 + 3], 1.f, 1.f, 1.f, 1.f);
+    bool fin = isfinite(b.x) && isfinite(b.y) && isfinite(b.z) && isfinite(b.w) && isfinite(sc);
+    if (!fin) atomicOr(err, 1);
+    float ih = (float)img_hw[n * 2], iw = (float)img_hw[n * 2 + 1];
+    b.x = clampf(b.x, 0.f, iw); b.y = clampf(b.y, 0.f, ih); b.z = clampf(b.z, 0.f, iw); b.w = clampf(b.w, 0.f, ih);
+    bool ok = fin && (b.z - b.x) > 0.f && (b.w - b.y) > 0.f;
+    boxes[slot] = b;
+    scores[slot] = sc;
+    valid[slot] = ok ? 1 : 0;
+}
+
+// merge the per-level survivors of one image by (score desc, level asc, rank asc); keep post_nms_topk
+__global__ __launch_bounds__(1024) void rpn_merge_kernel(int nl, const float4* __restrict__ boxes, const float* __restrict__ scores,
+                                                         const int* __restrict__ keep, const int* __restrict__ keep_count, int post_topk,
+                                                         float4* __restrict__ out_boxes /*[N][post]*/, float* __restrict__ out_scores, int* __restrict__ out_count) {
+    extern __shared__ unsigned long long mk[];   // kMergeCap
+    const int n = blockIdx.x;
+    for (int i = threadIdx.x; i < kMergeCap; i += blockDim.x) mk[i] = ~0ull;
+    __syncthreads();
+    int base = 0;
+    for (int l = 0; l < nl; ++l) {
+        const int bl = n * nl + l;
+        const int kc = keep_count[bl];
+        for (int j = threadIdx.x; j < kc; j += blockDim.x) {
+            int r = keep[(long)bl * kTopkCap + j];
+            unsigned key = float_key_asc(scores[(long)bl * kTopkCap + r]);
+            // low 32 bits: (level << 16 | rank) keeps the concatenation order for ties
+            mk[base + j] = ((unsigned long long)(~key) << 32) | ((unsigned)l << 16) | (unsigned)r;
+        }
+        base += kc;
+    }
+    __syncthreads();
+    int p2 = 1024;
+    while (p2 < base) p2 <<= 1;
+    bitonic_sort_u64(mk, p2);
+    const int cnt = min(base, post_topk);
+    for (int j = threadIdx.x; j < post_topk; j += blockDim.x) {
+        if (j < cnt) {
+            unsigned lo = (unsigned)(mk[j] & 0xffffffffu);
+            int l = lo >> 16, r = lo & 0xffff;
+            long slot = ((long)n * nl + l) * kTopkCap + r;
+            out_boxes[(long)n * post_topk + j] = boxes[slot];
+            out_scores[(long)n * post_topk + j] = scores[slot];
+        } else {
+            out_boxes[(long)n * post_topk + j] = make_float4(0, 0, 0, 0);
+            out_scores[(long)n * post_topk + j] = 0.f;
+        }
+    }
+    if (threadIdx.x == 0) out_count[n] = cnt;
+}
+
+Geom make_geom(const aldi_rpn_geom* gm, float* const* head, float* const* grad) {
+    Geom g;
+    g.nl = gm->num_levels; g.A = gm->A; g.C = gm->C; g.sumA = gm->off[gm->num_levels];
+    for (int l = 0; l < ALDI_MAX_LEVELS; ++l) {
+        g.H[l] = gm->H[l]; g.W[l] = gm->W[l]; g.off[l] = gm->off[l];
+        g.head[l] = head ? head[l] : nullptr;
+        g.grad[l] = grad ? grad[l] : nullptr;
+    }
+    g.off[ALDI_MAX_LEVELS] = gm->off[ALDI_MAX_LEVELS];
+    return g;
+}
+
+}  // namespace
+
+extern "C" int aldi_box_match(const float* boxes, long box_stride_n, const int* box_count, int L,
+                              const float* gt_boxes, const int* gt_count, int Gmax, int N,
+                              float lo, float hi, int allow_low_quality,
+                              float* best_iou, int* best_idx, unsigned* gt_best_scratch, int* labels, aldi_stream_t stream) {
+    if (!boxes || !gt_boxes || !gt_count || !best_iou || !best_idx || !gt_best_scratch || !labels) return aldi_set_error_msg(ALDI_ERR_ARG, "box_match: null pointer");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    hipError_t e = hipMemsetAsync(gt_best_scratch, 0, sizeof(unsigned) * (size_t)N * Gmax, st);
+    if (e != hipSuccess) return aldi_set_error(e, __FILE__, __LINE__);
+    dim3 grid(cdiv(L, 256), N);
+    hipLaunchKernelGGL(match_iou_kernel, grid, dim3(256), 0, st, (const float4*)boxes, box_stride_n, box_count, L, (const float4*)gt_boxes, gt_count, Gmax,
+                       best_iou, best_idx, gt_best_scratch);
+    ALDI_CHECK_LAUNCH();
+    hipLaunchKernelGGL(match_label_kernel, grid, dim3(256), 0, st, (const float4*)boxes, box_stride_n, box_count, L, (const float4*)gt_boxes, gt_count, Gmax,
+                       best_iou, gt_best_scratch, lo, hi, allow_low_quality, labels);
+    ALDI_CHECK_LAUNCH();
+    return ALDI_OK;
+}
+
+extern "C" int aldi_compact_labels(const int* labels, int L, int N, int bg_label, int* lists, int* counts, aldi_stream_t stream) {
+    if (!labels || !lists || !counts) return aldi_set_error_msg(ALDI_ERR_ARG, "compact_labels: null pointer");
+    hipLaunchKernelGGL(compact_kernel, dim3(2, N), dim3(1024), 0, static_cast<hipStream_t>(stream), labels, L, bg_label, lists, counts);
+    ALDI_CHECK_LAUNCH();
+    return ALDI_OK;
+}
+
+extern "C" int aldi_rpn_apply_sample(int* labels, int L, int N, const int* lists, const int* sel, const int* nsel, int S, aldi_stream_t stream) {
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    long tot = (long)N * L;
+    hipLaunchKernelGGL(fill_int_kernel, dim3((int)((tot + 255) / 256 > 4096 ? 4096 : (tot + 255) / 256)), dim3(256), 0, st, labels, tot, -1);
+    ALDI_CHECK_LAUNCH();
+    hipLaunchKernelGGL(sample_scatter_kernel, dim3(2, N), dim3(256), 0, st, labels, L, lists, sel, nsel, S);
+    ALDI_CHECK_LAUNCH();
+    return ALDI_OK;
+}
+
+extern "C" int aldi_rpn_loss(const aldi_rpn_geom* gm, float* const* head, float* const* grad, const float* anchors, const int* labels, const int* matched,
+                             const float* gt_boxes, const int* gt_count, int Gmax, int N, float inv_norm, float grad_scale_cls, float grad_scale_loc, float* loss2,
+                             aldi_stream_t stream) {
+    if (!gm || !head || !anchors || !labels || !matched || !loss2) return aldi_set_error_msg(ALDI_ERR_ARG, "rpn_loss: null pointer");
+    Geom g = make_geom(gm, head, grad);
+    long tot = (long)N * g.sumA;
+    hipLaunchKernelGGL(rpn_loss_kernel, dim3((int)((tot + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), g, (const float4*)anchors, labels, matched,
+                       (const float4*)gt_boxes, gt_count, Gmax, N, inv_norm, grad_scale_cls, grad_scale_loc, loss2);
+    ALDI_CHECK_LAUNCH();
+    return ALDI_OK;
+}
+
+extern "C" size_t aldi_rpn_proposals_workspace(int N, int num_levels) {
+    size_t B = (size_t)N * num_levels, cap = kTopkCap;
+    size_t s = 0;
+    s += B * cap * 8;            // cand keys
+    s += B * 4 + 256;            // cand_count
+    s += B * cap * 16;           // boxes
+    s += B * cap * 4 * 2;        // scores, valid
+    s += B * cap * (cap / 64) * 8;   // nms mask
+    s += B * cap * 4 + B * 4 + 256;  // keep, keep_count
+    return s + 1024;
+}
+
+extern "C" int aldi_rpn_proposals(const aldi_rpn_geom* gm, float* const* head, const float* anchors, const int* img_hw, int N,
+                                  int pre_nms_topk, int post_nms_topk, float nms_thresh, void* workspace,
+                                  float* out_boxes, float* out_scores, int* out_count, int* err_flag, aldi_stream_t stream) {
+    if (!gm || !head || !anchors || !img_hw || !workspace || !out_boxes || !out_scores || !out_count || !err_flag)
+        return aldi_set_error_msg(ALDI_ERR_ARG, "rpn_proposals: null pointer");
+    if (pre_nms_topk > kTopkCap || gm->num_levels * kTopkCap > kMergeCap) return aldi_set_error_msg(ALDI_ERR_ARG, "rpn_proposals: pre_nms_topk too large");
+    Geom g = make_geom(gm, head, nullptr);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const size_t B = (size_t)N * g.nl, cap = kTopkCap;
+    char* w = static_cast<char*>(workspace);
+    auto take = [&](size_t bytes) { char* p = w; w += (bytes + 255) / 256 * 256; return p; };
+    auto* cand = (unsigned long long*)take(B * cap * 8);
+    auto* cand_count = (int*)take(B * 4);
+    auto* boxes = (float4*)take(B * cap * 16);
+    auto* scores = (float*)take(B * cap * 4);
+    auto* valid = (int*)take(B * cap * 4);
+    auto* mask = (unsigned long long*)take(B * cap * (cap / 64) * 8);
+    auto* keep = (int*)take(B * cap * 4);
+    auto* keep_count = (int*)take(B * 4);
+    hipLaunchKernelGGL(rpn_topk_kernel, dim3(g.nl, N), dim3(1024), 0, st, g, pre_nms_topk, cand, cand_count);
+    ALDI_CHECK_LAUNCH();
+    hipLaunchKernelGGL(rpn_decode_kernel, dim3(cap / 256, g.nl, N), dim3(256), 0, st, g, (const float4*)anchors, cand, cand_count, img_hw, boxes, scores, valid, err_flag);
+    ALDI_CHECK_LAUNCH();
+    hipLaunchKernelGGL(nms_mask_kernel, dim3(cap / 64, cap / 64, (unsigned)B), dim3(64), 0, st, boxes, valid, (const int*)nullptr, cand_count, (int)cap, nms_thresh, mask);
+    ALDI_CHECK_LAUNCH();
+    hipLaunchKernelGGL(nms_scan_kernel, dim3((unsigned)B), dim3(64), (cap / 64) * 8, st, mask, valid, cand_count, (int)cap, (int)cap, keep, keep_count);
+    ALDI_CHECK_LAUNCH();
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(rpn_merge_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kMergeCap * 8);
+    hipLaunchKernelGGL(rpn_merge_kernel, dim3(N), dim3(1024), kMergeCap * 8, st, g.nl, boxes, scores, keep, keep_count, post_nms_topk, (float4*)out_boxes, out_scores, out_count);
+    ALDI_CHECK_LAUNCH();
+    return ALDI_OK;
+}

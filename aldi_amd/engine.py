@@ -1,0 +1,593 @@
+"""Host orchestration of the GeneralizedRCNN (R50-FPN) forward / backward / inference on the HIP
+kernels.  This layer owns NO arithmetic: it allocates device memory through torch, sequences
+C-ABI calls (aldi_amd.ops) on the current HIP stream, and draws the sampling permutations from
+the host torch RNG in exactly the order Detectron2 does (SURVEY.md section 7 "RNG parity").
+
+What it replaces in the reference: the detectron2 ``GeneralizedRCNN.forward`` / ``.inference``
+Python + ATen/cuDNN/torchvision graph behind ``model(...)`` at aldi/trainer.py:87,
+aldi/distill.py:157,162 and aldi/pseudolabeler.py:21, and autograd's backward at aldi/trainer.py:79.
+"""
+from __future__ import annotations
+
+import math
+from collections import OrderedDict
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import torch
+
+from . import ops
+from .arch import FC_DIM, FPN_C, NUM_ANCHORS, POOL, STAGE_BLOCKS, Packed, ParamLayout, pad_to
+
+PIXEL_MEAN = (103.530, 116.280, 123.675)
+PIXEL_STD = (1.0, 1.0, 1.0)
+ANCHOR_SIZES = (32, 64, 128, 256, 512)
+ANCHOR_RATIOS = (0.5, 1.0, 2.0)
+STRIDES = (4, 8, 16, 32, 64)
+GMAX = 128            # max GT / pseudo-GT boxes per image held on device
+RPN_BATCH, RPN_POS_FRAC = 256, 0.5
+ROI_BATCH, ROI_POS_FRAC = 512, 0.25
+RPN_PRE = (2000, 1000)
+RPN_POST = (1000, 1000)
+RPN_NMS = 0.7
+ROI_WEIGHTS = (10.0, 10.0, 5.0, 5.0)
+SCORE_THRESH, NMS_TEST, DETS = 0.05, 0.5, 100
+
+
+class Weights:
+    """One model's state on device: flat fp32 master (whole state_dict incl. FrozenBN buffers),
+    compute-dtype copy of the weights, folded BN scale/shift, and (student) grads + momentum."""
+
+    def __init__(self, layout: ParamLayout, device, dtype: torch.dtype, trainable: bool):
+        self.layout, self.device, self.dtype, self.trainable = layout, device, dtype, trainable
+        L = layout
+        self.master = torch.zeros(L.n_total, dtype=torch.float32, device=device)
+        self.compute = self.master if dtype == torch.float32 else torch.zeros(L.n_weights, dtype=dtype, device=device)
+        self.bn_scale = torch.zeros(max(L.bn_channels, 1), dtype=torch.float32, device=device)
+        self.bn_shift = torch.zeros(max(L.bn_channels, 1), dtype=torch.float32, device=device)
+        self.grad = torch.zeros(L.n_train, dtype=torch.float32, device=device) if trainable else None
+        self.mom = torch.zeros(L.n_train, dtype=torch.float32, device=device) if trainable else None
+        self.first_step = True
+        self._wt: Dict[str, torch.Tensor] = {}
+        self._neg1: Dict[int, torch.Tensor] = {}
+
+    # ---- views -----------------------------------------------------------------------------
+    def w(self, name: str) -> torch.Tensor:
+        p = self.layout.t[name]
+        n = p.rows * p.kk * p.kk * p.cin
+        return self.compute[p.w_off: p.w_off + n].view(p.wshape)
+
+    def w_master(self, name: str) -> torch.Tensor:
+        p = self.layout.t[name]
+        n = p.rows * p.kk * p.kk * p.cin
+        return self.master[p.w_off: p.w_off + n].view(p.wshape)
+
+    def b(self, name: str) -> Optional[torch.Tensor]:
+        p = self.layout.t[name]
+        return self.master[p.b_off: p.b_off + p.rows] if p.bias else None
+
+    def scale(self, name: str) -> Optional[torch.Tensor]:
+        p = self.layout.t[name]
+        return self.bn_scale[p.bn_off: p.bn_off + p.rows] if p.bn else None
+
+    def shift(self, name: str) -> Optional[torch.Tensor]:
+        p = self.layout.t[name]
+        return self.bn_shift[p.bn_off: p.bn_off + p.rows] if p.bn else self.b(name)
+
+    def gw(self, name: str) -> torch.Tensor:
+        p = self.layout.t[name]
+        n = p.rows * p.kk * p.kk * p.cin
+        return self.grad[p.w_off: p.w_off + n]
+
+    def gb(self, name: str) -> torch.Tensor:
+        p = self.layout.t[name]
+        return self.grad[p.b_off: p.b_off + p.rows]
+
+    def wt(self, name: str, negate: bool = False) -> torch.Tensor:
+        """dgrad weights (rotated/transposed, BN scale folded; negated for the gradient-reversal layer)."""
+        key = name + ("-" if negate else "")
+        if key not in self._wt:
+            p = self.layout.t[name]
+            sc = self.scale(name)
+            if negate:
+                if p.rows not in self._neg1:
+                    self._neg1[p.rows] = torch.full((p.rows,), -1.0, dtype=torch.float32, device=self.device)
+                sc = self._neg1[p.rows]
+            self._wt[key] = ops.dgrad_weights(self.w_master(name), sc, self.dtype)
+        return self._wt[key]
+
+    # ---- state -------------------------------------------------------------------------------
+    def load_state_dict(self, sd: Dict[str, torch.Tensor]):
+        missing = [k for k in self.layout.state_dict_keys() if k not in sd]
+        if missing:
+            raise KeyError(f"missing keys in state_dict: {missing[:5]}{'...' if len(missing) > 5 else ''}")
+        self.master.copy_(self.layout.pack(sd).to(self.device))
+        self.refresh()
+
+    def state_dict(self) -> "OrderedDict[str, torch.Tensor]":
+        return self.layout.unpack(self.master)
+
+    def refresh(self):
+        """re-derive everything computed from the master state (after load / optimizer step / EMA)."""
+        L = self.layout
+        if L.bn_channels:
+            b = L.bn_base
+            c = L.bn_channels
+            ops.bn_fold(self.master[b:b + c], self.master[b + c:b + 2 * c], self.master[b + 2 * c:b + 3 * c],
+                        self.master[b + 3 * c:b + 4 * c], self.bn_scale, self.bn_shift, c)
+        if self.dtype != torch.float32:
+            ops.cast_from_f32(self.master[:L.n_weights], self.dtype, out=self.compute)
+        self._wt.clear()
+
+    def zero_grad(self):
+        self.grad.zero_()
+
+    def sgd_step(self, lr: float, momentum: float = 0.9, weight_decay: float = 1e-4, grad_scale: float = 1.0):
+        n = self.layout.n_train
+        ops.sgd_step(self.master, self.grad, self.mom, self.compute if self.dtype != torch.float32 else None, n, lr, momentum,
+                     weight_decay, grad_scale, self.first_step, self.dtype)
+        self.first_step = False
+        self._wt.clear()
+
+    def ema_from(self, student: "Weights", alpha: float, copy_only: bool):
+        """reference aldi/ema.py:29-57 over the whole state (params AND buffers)."""
+        n = self.layout.n_total
+        ops.ema_update(self.master, student.master, None, n, alpha, copy_only, torch.float32)
+        self.refresh()
+
+
+def make_anchors(shapes: Sequence[Tuple[int, int]], device) -> torch.Tensor:
+    """DefaultAnchorGenerator (offset 0): (sumA, 4), level-major, then (h, w, a). Host float32 math as Detectron2."""
+    out = []
+    for (h, w), size, stride in zip(shapes, ANCHOR_SIZES, STRIDES):
+        cell = []
+        for r in ANCHOR_RATIOS:
+            area = size ** 2.0
+            aw = math.sqrt(area / r)
+            ah = r * aw
+            cell.append([-aw / 2.0, -ah / 2.0, aw / 2.0, ah / 2.0])
+        cell = torch.tensor(cell, dtype=torch.float32)
+        sx = torch.arange(0, w * stride, step=stride, dtype=torch.float32)
+        sy = torch.arange(0, h * stride, step=stride, dtype=torch.float32)
+        yy, xx = torch.meshgrid(sy, sx, indexing="ij")
+        shifts = torch.stack((xx.reshape(-1), yy.reshape(-1), xx.reshape(-1), yy.reshape(-1)), dim=1)
+        out.append((shifts.view(-1, 1, 4) + cell.view(1, -1, 4)).reshape(-1, 4))
+    return torch.cat(out).contiguous().to(device)
+
+
+class Ctx(dict):
+    """Saved tensors / intermediates of one forward (what the reference reads through forward hooks)."""
+    __getattr__ = dict.__getitem__
+    __setattr__ = dict.__setitem__
+
+
+class RCNN:
+    def __init__(self, weights: Weights, num_classes: int):
+        self.wts = weights
+        self.K = num_classes
+        self.device, self.dtype = weights.device, weights.dtype
+        self.Cp = weights.layout.t["box_pred"].rows
+        self.Ch = weights.layout.t["rpn_head_out"].rows
+        self._anchor_cache: Dict[tuple, tuple] = {}
+        self._ws: Dict[str, torch.Tensor] = {}
+        self.err = torch.zeros(1, dtype=torch.int32, device=self.device)
+        self.has_img_da = "img_align.model.0" in weights.layout.t
+        self.has_ins_da = "ins_align.model.1" in weights.layout.t
+
+    # ------------------------------------------------------------------ inputs
+    def stage_images(self, images: Sequence[torch.Tensor]):
+        sizes = [(int(im.shape[1]), int(im.shape[2])) for im in images]
+        Hs = pad_to(max(s[0] for s in sizes), 32)
+        Ws = pad_to(max(s[1] for s in sizes), 32)
+        N = len(images)
+        if all(im.is_cuda for im in images):
+            st = torch.zeros((N, 3, Hs, Ws), dtype=torch.uint8, device=self.device)
+            for i, im in enumerate(images):
+                st[i, :, : sizes[i][0], : sizes[i][1]] = im
+        else:
+            host = torch.zeros((N, 3, Hs, Ws), dtype=torch.uint8).pin_memory()
+            for i, im in enumerate(images):
+                host[i, :, : sizes[i][0], : sizes[i][1]] = im
+            st = host.to(self.device, non_blocking=True)
+        hw = torch.tensor(sizes, dtype=torch.int32).to(self.device)
+        return st, sizes, hw
+
+    def stage_gt(self, instances: Sequence[dict]):
+        N = len(instances)
+        gb = torch.zeros((N, GMAX, 4), dtype=torch.float32)
+        gc = torch.zeros((N, GMAX), dtype=torch.int32)
+        cnt = torch.zeros((N,), dtype=torch.int32)
+        for i, inst in enumerate(instances):
+            b = inst["gt_boxes"]
+            b = b.tensor if hasattr(b, "tensor") else b
+            g = int(b.shape[0])
+            if g > GMAX:
+                raise ValueError(f"more than {GMAX} GT boxes in one image")
+            if g:
+                gb[i, :g] = b.reshape(-1, 4).to(torch.float32).cpu()
+                gc[i, :g] = inst["gt_classes"].to(torch.int32).cpu()
+            cnt[i] = g
+        return {"boxes": gb.to(self.device), "classes": gc.to(self.device), "count": cnt.to(self.device), "host_count": cnt.tolist()}
+
+    def geometry(self, Hs: int, Ws: int):
+        key = (Hs, Ws)
+        if key not in self._anchor_cache:
+            shapes = []
+            h, w = Hs // 4, Ws // 4
+            for l in range(4):
+                shapes.append((h, w))
+                if l < 3:
+                    h, w = h // 2, w // 2
+            shapes.append(((shapes[3][0] - 1) // 2 + 1, (shapes[3][1] - 1) // 2 + 1))
+            geom = ops.make_geom(shapes, NUM_ANCHORS, self.Ch)
+            anchors = make_anchors(shapes, self.device)
+            self._anchor_cache[key] = (shapes, geom, anchors)
+        return self._anchor_cache[key]
+
+    def workspace(self, name: str, nbytes: int) -> torch.Tensor:
+        t = self._ws.get(name)
+        if t is None or t.numel() < nbytes:
+            t = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+            self._ws[name] = t
+        return t
+
+    # ------------------------------------------------------------------ trunk
+    def conv(self, x, name, *, relu=False, res=None, res_mode=0, want_f32=False):
+        W = self.wts
+        p = W.layout.t[name]
+        return ops.conv2d(x, W.w(name), stride=p.stride, pad=p.pad, scale=W.scale(name), shift=W.shift(name), res=res, res_mode=res_mode,
+                          relu=relu, want_f32=want_f32)
+
+    def trunk(self, st_u8: torch.Tensor, sizes, save: bool) -> Ctx:
+        """preprocess + ResNet-50 + FPN -> P2..P6.  `save` keeps the activations backward needs."""
+        W = self.wts
+        c = Ctx()
+        bu = "backbone.bottom_up."
+        stem = ops.stem_forward(st_u8, sizes, W.w_master(bu + "stem.conv1"), W.scale(bu + "stem.conv1"), W.shift(bu + "stem.conv1"),
+                                PIXEL_MEAN, PIXEL_STD, self.dtype)
+        x = ops.maxpool3s2(stem)
+        del stem
+        blocks = []
+        cs = []
+        for si, nb in enumerate(STAGE_BLOCKS):
+            for b in range(nb):
+                p = f"{bu}res{si + 2}.{b}."
+                sc = self.conv(x, p + "shortcut") if b == 0 else x
+                h1 = self.conv(x, p + "conv1", relu=True)
+                h2 = self.conv(h1, p + "conv2", relu=True)
+                out = self.conv(h2, p + "conv3", relu=True, res=sc, res_mode=1)
+                if save and si > 0:
+                    blocks.append((p, x, h1, h2, out, b == 0))
+                x = out
+            cs.append(x)
+        prev = {}
+        P = {}
+        prev[5] = self.conv(cs[3], "backbone.fpn_lateral5")
+        P[5] = self.conv(prev[5], "backbone.fpn_output5")
+        for lvl in (4, 3, 2):
+            prev[lvl] = self.conv(cs[lvl - 2], f"backbone.fpn_lateral{lvl}", res=prev[lvl + 1], res_mode=2)
+            P[lvl] = self.conv(prev[lvl], f"backbone.fpn_output{lvl}")
+        P[6] = ops.subsample2(P[5])
+        c.P = [P[2], P[3], P[4], P[5], P[6]]
+        if save:
+            c.blocks, c.cs, c.prev = blocks, cs, prev
+        return c
+
+    def rpn_head(self, c: Ctx, save: bool):
+        heads, ts = [], []
+        for f in c.P:
+            t = self.conv(f, "proposal_generator.rpn_head.conv", relu=True)
+            heads.append(self.conv(t, "rpn_head_out", want_f32=True))
+            if save:
+                ts.append(t)
+        c.head = heads
+        if save:
+            c.rpn_t = ts
+
+    def box_head(self, pooled: torch.Tensor, c: Optional[Ctx] = None):
+        R = pooled.shape[0]
+        x = pooled.view(R, 1, 1, POOL * POOL * FPN_C)
+        fc1 = self.conv(x, "roi_heads.box_head.fc1", relu=True)
+        fc2 = self.conv(fc1, "roi_heads.box_head.fc2", relu=True)
+        pred = self.conv(fc2, "box_pred", want_f32=True).view(R, self.Cp)
+        if c is not None:
+            c.pooled, c.fc1, c.fc2 = pooled, fc1, fc2
+        return pred, fc2
+
+    def roi_feats(self, c: Ctx, grads=None):
+        return ops.make_roi_feats(c.P[:4], grads, [1.0 / s for s in STRIDES[:4]])
+
+    # ------------------------------------------------------------------ sampling (host RNG, D2 order)
+    def _sample(self, counts: List[List[int]], batch: int, frac: float):
+        """subsample_labels for every image: two torch.randperm draws per image (pos then neg)."""
+        N = len(counts)
+        S = batch
+        sel = torch.zeros((N, 2, S), dtype=torch.int32)
+        nsel = torch.zeros((N, 2), dtype=torch.int32)
+        for n, (npos, nneg) in enumerate(counts):
+            num_pos = min(npos, int(batch * frac))
+            num_neg = min(nneg, batch - num_pos)
+            perm1 = torch.randperm(npos)[:num_pos]
+            perm2 = torch.randperm(nneg)[:num_neg]
+            sel[n, 0, :num_pos] = perm1.to(torch.int32)
+            sel[n, 1, :num_neg] = perm2.to(torch.int32)
+            nsel[n, 0], nsel[n, 1] = num_pos, num_neg
+        return sel.to(self.device), nsel.to(self.device), nsel.tolist()
+
+    def rpn_match(self, geom, anchors, gt, N):
+        """Matcher(0.3/0.7, low-quality) on the anchors: labels before sampling, matched GT index, ordered pos/neg lists."""
+        sumA = anchors.shape[0]
+        dev = self.device
+        best_iou = torch.empty((N, sumA), dtype=torch.float32, device=dev)
+        best_idx = torch.empty((N, sumA), dtype=torch.int32, device=dev)
+        labels = torch.empty((N, sumA), dtype=torch.int32, device=dev)
+        scratch = torch.empty((N, GMAX), dtype=torch.int32, device=dev)
+        ops.box_match(anchors, 0, None, sumA, gt["boxes"], gt["count"], GMAX, N, 0.3, 0.7, True, best_iou, best_idx, scratch, labels)
+        lists = torch.empty((N, 2, sumA), dtype=torch.int32, device=dev)
+        counts = torch.empty((N, 2), dtype=torch.int32, device=dev)
+        ops.compact_labels(labels, sumA, N, 0, lists, counts)
+        return labels, best_idx, lists, counts
+
+    def rpn_sample(self, labels, lists, counts, N):
+        """host draws (2 randperm per image) -> final labels in {-1,0,1}; returns (n_valid, n_fg)."""
+        host_counts = counts.cpu().tolist()                 # device->host sync: the RNG needs the list lengths
+        sel, nsel, nsel_h = self._sample(host_counts, RPN_BATCH, RPN_POS_FRAC)
+        ops.rpn_apply_sample(labels, labels.shape[1], N, lists, sel, nsel, RPN_BATCH)
+        n_fg = sum(a for a, _ in nsel_h)
+        n_valid = sum(a + b for a, b in nsel_h)
+        return n_valid, n_fg
+
+    def proposals(self, c: Ctx, geom, anchors, hw, N, training: bool):
+        nl = 5
+        ws = self.workspace("rpn", ops.rpn_proposals_workspace(N, nl))
+        post = RPN_POST[0 if training else 1]
+        boxes = torch.empty((N, post, 4), dtype=torch.float32, device=self.device)
+        scores = torch.empty((N, post), dtype=torch.float32, device=self.device)
+        count = torch.empty((N,), dtype=torch.int32, device=self.device)
+        ops.rpn_proposals(geom, c.head, anchors, hw, N, RPN_PRE[0 if training else 1], post, RPN_NMS, ws, boxes, scores, count, self.err)
+        return boxes, scores, count
+
+    # ------------------------------------------------------------------ training forward
+    def forward_train(self, images, instances, *, roi_seed: Optional[int], scales: Dict[str, float],
+                      gt_dev: Optional[dict] = None, do_align: bool = False, labeled: bool = True,
+                      da_weights: Tuple[float, float] = (0.0, 0.0)) -> Ctx:
+        """GeneralizedRCNN.forward (training) + AlignMixin.forward (aldi/align.py:71-101), including
+        d(loss)/d(head outputs).  scales[k] multiplies d(loss_k) in backward (0 => contributes
+        nothing, as the reference's `v * 0`; 1/accum otherwise).  Loss VALUES are unscaled."""
+        N = len(images)
+        st, sizes, hw = self.stage_images(images)
+        shapes, geom, anchors = self.geometry(st.shape[2], st.shape[3])
+        gt = gt_dev if gt_dev is not None else self.stage_gt(instances)
+        c = self.trunk(st, sizes, save=True)
+        c.N, c.sizes, c.hw, c.geom, c.anchors, c.gt, c.shapes = N, sizes, hw, geom, anchors, gt, shapes
+        self.rpn_head(c, save=True)
+        dev = self.device
+        # --- RPN labels + losses
+        labels, matched, lists, counts = self.rpn_match(geom, anchors, gt, N)
+        self.rpn_sample(labels, lists, counts, N)
+        c.rpn_labels, c.rpn_matched = labels, matched
+        c.ghead = [torch.zeros_like(h) for h in c.head]
+        c.loss_rpn = torch.zeros(2, dtype=torch.float32, device=dev)
+        ops.rpn_loss(geom, c.head, c.ghead, anchors, labels, matched, gt["boxes"], gt["count"], GMAX, N, 1.0 / (RPN_BATCH * N),
+                     scales.get("loss_rpn_cls", 0.0), scales.get("loss_rpn_loc", 0.0), c.loss_rpn)
+        # --- proposals (detached)
+        c.props, c.prop_scores, c.prop_count = self.proposals(c, geom, anchors, hw, N, training=True)
+        # --- ROI heads
+        if roi_seed is not None:
+            torch.manual_seed(roi_seed)                      # ManualSeed pre-hook on roi_heads (aldi/helpers.py:25-26)
+        self.roi_sample(c, c.props, c.prop_count, gt, N)
+        self.roi_forward(c)
+        c.gpred = torch.zeros((max(c.R, 1), self.Cp), dtype=torch.float32, device=dev)
+        c.loss_box = torch.zeros(2, dtype=torch.float32, device=dev)
+        ops.box_loss(c.pred, self.Cp, self.K, c.R, c.rois, c.r_cls, c.r_gt, ROI_WEIGHTS, scales.get("loss_cls", 0.0),
+                     scales.get("loss_box_reg", 0.0), c.gpred, c.loss_box)
+        c.align = {}
+        if do_align:
+            self.align_forward(c, labeled, da_weights, scales.get("loss_da_img", 0.0), scales.get("loss_da_ins", 0.0))
+        return c
+
+    def align_forward(self, c: Ctx, labeled: bool, da_weights, gs_img: float, gs_ins: float):
+        """AlignMixin.forward (aldi/align.py:75-90): discriminators behind gradient reversal, BCE vs constant domain label."""
+        dev, T = self.device, self.dtype
+        label = 1.0 if labeled else 0.0
+        if self.has_img_da:
+            a1 = self.conv(c.P[0], "img_align.model.0", relu=True)
+            pooled = ops.avgpool(a1)
+            logit = self.conv(pooled, "img_align.model.4", want_f32=True)
+            ld = logit.shape[-1]
+            glog = torch.empty((c.N, 1, 1, ld), dtype=T, device=dev)
+            c.loss_da_img = torch.zeros(1, dtype=torch.float32, device=dev)
+            ops.domain_bce(logit, ld, c.N, label, da_weights[0], gs_img, glog, c.loss_da_img)
+            c.align["img"] = (a1, pooled, glog)
+        if self.has_ins_da and c.R > 0:
+            h = self.conv(c.fc2, "ins_align.model.1", relu=True)
+            logit = self.conv(h, "ins_align.model.3", want_f32=True)
+            ld = logit.shape[-1]
+            glog = torch.empty((c.R, 1, 1, ld), dtype=T, device=dev)
+            c.loss_da_ins = torch.zeros(1, dtype=torch.float32, device=dev)
+            ops.domain_bce(logit, ld, c.R, label, da_weights[1], gs_ins, glog, c.loss_da_ins)
+            c.align["ins"] = (h, glog)
+
+    def loss_dict(self, c: Ctx) -> "OrderedDict[str, torch.Tensor]":
+        """0-d device tensors in the key order of GeneralizedRCNN.forward (+ AlignMixin)."""
+        d = OrderedDict()
+        d["loss_cls"], d["loss_box_reg"] = c.loss_box[0], c.loss_box[1]
+        d["loss_rpn_cls"], d["loss_rpn_loc"] = c.loss_rpn[0], c.loss_rpn[1]
+        if "img" in c.align:
+            d["loss_da_img"] = c.loss_da_img[0]
+        if "ins" in c.align:
+            d["loss_da_ins"] = c.loss_da_ins[0]
+        return d
+
+    def roi_sample(self, c: Ctx, props, prop_count, gt, N):
+        dev = self.device
+        P = props.shape[1]
+        Lc = P + GMAX
+        cand = torch.empty((N, Lc, 4), dtype=torch.float32, device=dev)
+        ccount = torch.empty((N,), dtype=torch.int32, device=dev)
+        best_iou = torch.empty((N, Lc), dtype=torch.float32, device=dev)
+        best_idx = torch.empty((N, Lc), dtype=torch.int32, device=dev)
+        labels = torch.empty((N, Lc), dtype=torch.int32, device=dev)
+        cls = torch.empty((N, Lc), dtype=torch.int32, device=dev)
+        scratch = torch.empty((N, GMAX), dtype=torch.int32, device=dev)
+        ops.roi_prepare(props, prop_count, P, gt["boxes"], gt["classes"], gt["count"], GMAX, N, self.K, 0.5, cand, ccount, best_iou, best_idx,
+                        scratch, labels, cls)
+        lists = torch.empty((N, 2, Lc), dtype=torch.int32, device=dev)
+        counts = torch.empty((N, 2), dtype=torch.int32, device=dev)
+        ops.compact_labels(cls, Lc, N, self.K, lists, counts)
+        host_counts = counts.cpu().tolist()                  # device->host sync (RNG needs the list lengths)
+        sel, nsel, nsel_h = self._sample(host_counts, ROI_BATCH, ROI_POS_FRAC)
+        rows = [a + b for a, b in nsel_h]
+        row_off = [0]
+        for r in rows[:-1]:
+            row_off.append(row_off[-1] + r)
+        R = sum(rows)
+        c.R, c.rows = R, rows
+        c.rois = torch.empty((max(R, 1), 5), dtype=torch.float32, device=dev)
+        c.r_cls = torch.empty((max(R, 1),), dtype=torch.int32, device=dev)
+        c.r_gt = torch.empty((max(R, 1), 4), dtype=torch.float32, device=dev)
+        c.r_idx = torch.empty((max(R, 1),), dtype=torch.int32, device=dev)
+        ops.roi_gather(cand, cls, best_idx, Lc, lists, sel, nsel, ROI_BATCH, torch.tensor(row_off, dtype=torch.int32).to(dev),
+                       gt["boxes"], gt["count"], GMAX, N, c.rois, c.r_cls, c.r_gt, c.r_idx)
+
+    def roi_forward(self, c: Ctx):
+        R = c.R
+        pooled = torch.empty((R, POOL, POOL, FPN_C), dtype=self.dtype, device=self.device)
+        ops.roialign(self.roi_feats(c), c.rois, R, POOL, pooled, backward=False)
+        c.pred, _ = self.box_head(pooled, c)
+
+    def box_head_on(self, c_feats: Ctx, rois: torch.Tensor, R: int):
+        """teacher-side: box head on given rois (the student's sampled proposals)."""
+        pooled = torch.empty((R, POOL, POOL, FPN_C), dtype=self.dtype, device=self.device)
+        ops.roialign(self.roi_feats(c_feats), rois, R, POOL, pooled, backward=False)
+        pred, fc2 = self.box_head(pooled)
+        return pred
+
+    # ------------------------------------------------------------------ inference (teacher)
+    def inference(self, images, pl_thresh: float, keep_ctx: bool = True) -> Ctx:
+        """GeneralizedRCNN.inference(do_postprocess=False) + process_pseudo_label threshold
+        (aldi/pseudolabeler.py:15-67).  Everything stays on device."""
+        N = len(images)
+        st, sizes, hw = self.stage_images(images)
+        shapes, geom, anchors = self.geometry(st.shape[2], st.shape[3])
+        c = self.trunk(st, sizes, save=False)
+        c.N, c.sizes, c.hw, c.geom, c.anchors, c.shapes = N, sizes, hw, geom, anchors, shapes
+        self.rpn_head(c, save=False)
+        props, pscores, pcount = self.proposals(c, geom, anchors, hw, N, training=False)
+        P = props.shape[1]
+        rois = torch.empty((N * P, 5), dtype=torch.float32, device=self.device)
+        ops.rois_from_proposals(props, pcount, P, N, rois)
+        pooled = torch.empty((N * P, POOL, POOL, FPN_C), dtype=self.dtype, device=self.device)
+        ops.roialign(self.roi_feats(c), rois, N * P, POOL, pooled, backward=False)
+        pred, _ = self.box_head(pooled)
+        dev = self.device
+        ws = self.workspace("det", ops.detections_workspace(N))
+        d = Ctx()
+        d.boxes = torch.empty((N, DETS, 4), dtype=torch.float32, device=dev)
+        d.scores = torch.empty((N, DETS), dtype=torch.float32, device=dev)
+        d.classes = torch.empty((N, DETS), dtype=torch.int32, device=dev)
+        d.count = torch.empty((N,), dtype=torch.int32, device=dev)
+        pl_boxes = torch.zeros((N, GMAX, 4), dtype=torch.float32, device=dev)
+        pl_cls = torch.zeros((N, GMAX), dtype=torch.int32, device=dev)
+        pl_scores = torch.zeros((N, GMAX), dtype=torch.float32, device=dev)
+        pl_count = torch.empty((N,), dtype=torch.int32, device=dev)
+        # pl_* rows are [N][DETS] inside the kernel; allocate exact views
+        plb = torch.empty((N, DETS, 4), dtype=torch.float32, device=dev)
+        plc = torch.empty((N, DETS), dtype=torch.int32, device=dev)
+        pls = torch.empty((N, DETS), dtype=torch.float32, device=dev)
+        ops.detections(pred, self.Cp, self.K, props, pcount, P, N, hw, ROI_WEIGHTS, SCORE_THRESH, NMS_TEST, DETS, pl_thresh, ws,
+                       d.boxes, d.scores, d.classes, d.count, plb, plc, pls, pl_count, self.err)
+        pl_boxes[:, :DETS] = plb
+        pl_cls[:, :DETS] = plc
+        pl_scores[:, :DETS] = pls
+        c.det = d
+        c.pseudo = {"boxes": pl_boxes, "classes": pl_cls, "count": pl_count, "scores": pl_scores}
+        c.props, c.prop_count, c.pred_all = props, pcount, pred
+        return c
+
+    # ------------------------------------------------------------------ backward
+    def backward(self, c: Ctx):
+        """Accumulate d(sum_k scales[k] * loss_k)/d(params) into weights.grad (the scales were applied
+        where c.ghead / c.gpred / the discriminator logit grads were produced).  heads -> FPN -> res5..res3."""
+        W = self.wts
+        T = self.dtype
+        dev = self.device
+        # ---- box head (+ instance-level discriminator behind the gradient-reversal layer)
+        gP_roi = [torch.zeros(f.shape, dtype=torch.float32, device=dev) for f in c.P[:4]]
+        if c.R > 0:
+            g_extra = None
+            if "ins" in c.align:
+                h, glog = c.align["ins"]
+                self._wgrad("ins_align.model.3", h, glog)
+                g_h = ops.conv2d(glog, W.wt("ins_align.model.3"), mask=h)
+                self._wgrad("ins_align.model.1", c.fc2, g_h)
+                g_extra = ops.conv2d(g_h, W.wt("ins_align.model.1", negate=True))
+            gpred = ops.cast_from_f32(c.gpred[:c.R], T).view(c.R, 1, 1, self.Cp)
+            self._wgrad("box_pred", c.fc2, gpred)
+            g_fc2 = ops.conv2d(gpred, W.wt("box_pred"), mask=c.fc2, res=g_extra, res_mode=1 if g_extra is not None else 0)
+            self._wgrad("roi_heads.box_head.fc2", c.fc1, g_fc2)
+            g_fc1 = ops.conv2d(g_fc2, W.wt("roi_heads.box_head.fc2"), mask=c.fc1)
+            x = c.pooled.view(c.R, 1, 1, POOL * POOL * FPN_C)
+            self._wgrad("roi_heads.box_head.fc1", x, g_fc1)
+            g_pooled = ops.conv2d(g_fc1, W.wt("roi_heads.box_head.fc1")).view(c.R, POOL, POOL, FPN_C)
+            ops.roialign(self.roi_feats(c, gP_roi), c.rois, c.R, POOL, g_pooled, backward=True)
+        # ---- RPN head (shared weights over 5 levels)
+        gP = []
+        for l in range(5):
+            gh = ops.cast_from_f32(c.ghead[l], T)
+            self._wgrad("rpn_head_out", c.rpn_t[l], gh)
+            g_t = ops.conv2d(gh, W.wt("rpn_head_out"), mask=c.rpn_t[l])
+            self._wgrad("proposal_generator.rpn_head.conv", c.P[l], g_t)
+            gP.append(ops.conv2d(g_t, W.wt("proposal_generator.rpn_head.conv"), pad=1))
+        ops.subsample2_bwd(gP[4], gP[3])                               # p6 = p5[:, ::2, ::2]
+        for l in range(4):
+            ops.add_f32(gP[l], gP_roi[l], gP[l])
+        # ---- image-level discriminator behind the gradient-reversal layer
+        if "img" in c.align:
+            a1, pooled, glog = c.align["img"]
+            self._wgrad("img_align.model.4", pooled, glog)
+            g_pooled = ops.conv2d(glog, W.wt("img_align.model.4"))
+            g_a1 = ops.avgpool_bwd(g_pooled, a1)
+            self._wgrad("img_align.model.0", c.P[0], g_a1)
+            gP[0] = ops.conv2d(g_a1, W.wt("img_align.model.0", negate=True), pad=2, res=gP[0], res_mode=1)
+        # ---- FPN
+        gprev = {}
+        for i, lvl in enumerate((2, 3, 4, 5)):
+            self._wgrad(f"backbone.fpn_output{lvl}", c.prev[lvl], gP[i])
+            gprev[lvl] = ops.conv2d(gP[i], W.wt(f"backbone.fpn_output{lvl}"), pad=1)
+        for lvl in (3, 4, 5):
+            ops.upsample2_bwd(gprev[lvl - 1], gprev[lvl], accumulate=True)
+        for lvl in (2, 3, 4, 5):
+            self._wgrad(f"backbone.fpn_lateral{lvl}", c.cs[lvl - 2], gprev[lvl])
+        # ---- res5 .. res3 (stem + res2 frozen: FREEZE_AT=2)
+        g = ops.conv2d(gprev[5], W.wt("backbone.fpn_lateral5"), mask=c.cs[3])
+        blocks = c.blocks
+        bi = len(blocks) - 1
+        for si in (3, 2, 1):
+            for b in range(STAGE_BLOCKS[si] - 1, -1, -1):
+                p, xin, h1, h2, out, first = blocks[bi]
+                bi -= 1
+                self._wgrad(p + "conv3", h2, g)
+                g2 = ops.conv2d(g, W.wt(p + "conv3"), mask=h2)
+                self._wgrad(p + "conv2", h1, g2)
+                g1 = ops.conv2d(g2, W.wt(p + "conv2"), pad=1, mask=h1)
+                self._wgrad(p + "conv1", xin, g1)
+                if first:
+                    self._wgrad(p + "shortcut", xin, g)
+                    if si == 1:
+                        break                                           # stage input (res2 output) needs no gradient
+                    stride = W.layout.t[p + "conv1"].stride
+                    Hin, Win = xin.shape[1], xin.shape[2]
+                    gx = torch.zeros_like(xin)
+                    ops.conv2d(g, W.wt(p + "shortcut"), out=gx, out_scale=stride, out_hw=(Hin, Win))
+                    ops.conv2d(g1, W.wt(p + "conv1"), out=gx, out_scale=stride, out_hw=(Hin, Win), res=gx, res_mode=1)
+                    lvl = si + 1                                        # this stage's input is C_{lvl}
+                    g = ops.conv2d(gprev[lvl], W.wt(f"backbone.fpn_lateral{lvl}"), res=gx, res_mode=1, mask=xin)
+                else:
+                    g = ops.conv2d(g1, W.wt(p + "conv1"), res=g, res_mode=1, mask=xin)
+
+    def _wgrad(self, name: str, x: torch.Tensor, g: torch.Tensor):
+        W = self.wts
+        p = W.layout.t[name]
+        ops.conv_wgrad(x, g, W.gw(name), KH=p.kk, KW=p.kk, stride=p.stride, pad=p.pad, scale=W.scale(name))
+        if p.bias:
+            ops.bias_grad(g, W.gb(name))

@@ -1,8 +1,12 @@
-"""Thin torch-tensor wrappers over the C ABI (device memory + stream plumbing only)."""
+"""Thin torch-tensor wrappers over the C ABI (device memory + stream plumbing only).
+
+No arithmetic happens here: every function marshals pointers/sizes into one C-ABI call of
+libaldi_hip.so on torch's current HIP stream.
+"""
 from __future__ import annotations
 
 import ctypes as C
-from typing import Optional
+from typing import List, Optional, Sequence
 
 import torch
 
@@ -25,6 +29,7 @@ def stream_ptr() -> int:
     return torch.cuda.current_stream().cuda_stream
 
 
+# ------------------------------------------------------------------------------- dense path
 def conv2d(x: torch.Tensor, w: torch.Tensor, *, stride: int = 1, pad: int = 0,
            scale: Optional[torch.Tensor] = None, shift: Optional[torch.Tensor] = None,
            res: Optional[torch.Tensor] = None, res_mode: int = 0, relu: bool = False,
@@ -35,7 +40,7 @@ def conv2d(x: torch.Tensor, w: torch.Tensor, *, stride: int = 1, pad: int = 0,
     [N,OH,OW,Cout] tensor when out_scale > 1, which must be pre-zeroed by the caller)."""
     N, H, W_, Cin = x.shape
     Cout, KH, KW, Cin2 = w.shape
-    assert Cin == Cin2 and x.is_contiguous() and w.is_contiguous() and x.dtype == w.dtype
+    assert Cin == Cin2 and x.is_contiguous() and w.is_contiguous() and x.dtype == w.dtype, (x.shape, w.shape, x.dtype, w.dtype)
     Ho = (H + 2 * pad - KH) // stride + 1
     Wo = (W_ + 2 * pad - KW) // stride + 1
     if out_scale > 1:
@@ -51,7 +56,7 @@ def conv2d(x: torch.Tensor, w: torch.Tensor, *, stride: int = 1, pad: int = 0,
     a = L.ConvArgs(_p(x), _p(w), _p(out), _p(out_f32), _p(scale), _p(shift), _p(res), _p(mask),
                    N, H, W_, Cin, Cout, KH, KW, stride, pad, Ho, Wo,
                    int(relu), res_mode, out_scale, OH, OW, dtype_code(x.dtype))
-    L.check(L.conv_igemm(C.byref(a), stream_ptr()), "aldi_conv_igemm")
+    L.call("aldi_conv_igemm", C.byref(a), stream_ptr())
     return out_f32 if want_f32 and out is None else out
 
 
@@ -60,14 +65,14 @@ def conv_wgrad(x: torch.Tensor, g: torch.Tensor, dw: torch.Tensor, *, KH: int, K
     """dw [Cout,KH,KW,Cin] fp32 += scale * (g^T . im2col(x)); x [N,H,W,Cin], g [N,Ho,Wo,Cout]."""
     N, H, W_, Cin = x.shape
     _, Ho, Wo, Cout = g.shape
-    assert dw.dtype == torch.float32 and dw.numel() == Cout * KH * KW * Cin and x.dtype == g.dtype
+    assert dw.dtype == torch.float32 and dw.numel() == Cout * KH * KW * Cin and x.dtype == g.dtype, (dw.shape, x.shape, g.shape)
     a = L.WgradArgs(_p(x), _p(g), _p(dw), _p(scale), N, H, W_, Cin, Cout, KH, KW, stride, pad, Ho, Wo, dtype_code(x.dtype))
-    L.check(L.conv_wgrad(C.byref(a), stream_ptr()), "aldi_conv_wgrad")
+    L.call("aldi_conv_wgrad", C.byref(a), stream_ptr())
 
 
 def bias_grad(g: torch.Tensor, db: torch.Tensor) -> None:
     Cc = g.shape[-1]
-    L.check(L.bias_grad(_p(g), _p(db), g.numel() // Cc, Cc, dtype_code(g.dtype), stream_ptr()), "aldi_bias_grad")
+    L.call("aldi_bias_grad", _p(g), _p(db), g.numel() // Cc, Cc, dtype_code(g.dtype), stream_ptr())
 
 
 def dgrad_weights(w_master: torch.Tensor, scale: Optional[torch.Tensor], dtype: torch.dtype,
@@ -76,5 +81,200 @@ def dgrad_weights(w_master: torch.Tensor, scale: Optional[torch.Tensor], dtype: 
     Cout, KH, KW, Cin = w_master.shape
     if out is None:
         out = torch.empty((Cin, KH, KW, Cout), dtype=dtype, device=w_master.device)
-    L.check(L.dgrad_weights(_p(w_master), _p(scale), _p(out), Cout, KH, KW, Cin, dtype_code(dtype), stream_ptr()), "aldi_dgrad_weights")
+    L.call("aldi_dgrad_weights", _p(w_master), _p(scale), _p(out), Cout, KH, KW, Cin, dtype_code(dtype), stream_ptr())
     return out
+
+
+# ------------------------------------------------------------------------------- stem / glue
+def stem_forward(img_u8: torch.Tensor, sizes: Sequence[Sequence[int]], w: torch.Tensor, scale: torch.Tensor, shift: torch.Tensor,
+                 mean: Sequence[float], std: Sequence[float], dtype: torch.dtype) -> torch.Tensor:
+    """img_u8 [N,3,Hs,Ws] uint8 staging (Hs,Ws already padded to /32) -> [N,Hs/2,Ws/2,64]."""
+    N, _, Hs, Ws = img_u8.shape
+    Hc, Wc = Hs // 2, Ws // 2
+    y = torch.empty((N, Hc, Wc, 64), dtype=dtype, device=img_u8.device)
+    a = L.StemArgs()
+    a.img, a.w, a.scale, a.shift, a.y = _p(img_u8), _p(w), _p(scale), _p(shift), _p(y)
+    a.N, a.Hs, a.Ws, a.Hc, a.Wc = N, Hs, Ws, Hc, Wc
+    for i, (h, w_) in enumerate(sizes):
+        a.h[i], a.w_img[i] = int(h), int(w_)
+    for c in range(3):
+        a.mean[c], a.std[c] = float(mean[c]), float(std[c])
+    a.dtype = dtype_code(dtype)
+    L.call("aldi_stem_forward", C.byref(a), stream_ptr())
+    return y
+
+
+def maxpool3s2(x: torch.Tensor) -> torch.Tensor:
+    N, H, W_, Cc = x.shape
+    y = torch.empty((N, (H - 1) // 2 + 1, (W_ - 1) // 2 + 1, Cc), dtype=x.dtype, device=x.device)
+    L.call("aldi_maxpool3s2", _p(x), _p(y), N, H, W_, Cc, dtype_code(x.dtype), stream_ptr())
+    return y
+
+
+def subsample2(x: torch.Tensor) -> torch.Tensor:
+    N, H, W_, Cc = x.shape
+    y = torch.empty((N, (H - 1) // 2 + 1, (W_ - 1) // 2 + 1, Cc), dtype=x.dtype, device=x.device)
+    L.call("aldi_subsample2", _p(x), _p(y), N, H, W_, Cc, 0, dtype_code(x.dtype), stream_ptr())
+    return y
+
+
+def subsample2_bwd(g_small: torch.Tensor, g_big: torch.Tensor) -> None:
+    N, H, W_, Cc = g_big.shape
+    L.call("aldi_subsample2", _p(g_small), _p(g_big), N, H, W_, Cc, 1, dtype_code(g_big.dtype), stream_ptr())
+
+
+def upsample2_bwd(g: torch.Tensor, out: torch.Tensor, accumulate: bool) -> None:
+    N, Hc, Wc, Cc = out.shape
+    assert g.shape == (N, Hc * 2, Wc * 2, Cc)
+    L.call("aldi_upsample2_bwd", _p(g), _p(out), N, Hc, Wc, Cc, int(accumulate), dtype_code(g.dtype), stream_ptr())
+
+
+def add_f32(a: Optional[torch.Tensor], b: Optional[torch.Tensor], out: torch.Tensor, relu_src: Optional[torch.Tensor] = None) -> torch.Tensor:
+    L.call("aldi_add_f32", _p(a), _p(b), _p(relu_src), _p(out), out.numel(), dtype_code(out.dtype), stream_ptr())
+    return out
+
+
+def cast_from_f32(src: torch.Tensor, dtype: torch.dtype, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    if out is None:
+        out = torch.empty(src.shape, dtype=dtype, device=src.device)
+    L.call("aldi_cast_from_f32", _p(src), _p(out), src.numel(), dtype_code(dtype), stream_ptr())
+    return out
+
+
+def sgd_step(p, g, buf, p_compute, n, lr, momentum, weight_decay, grad_scale, first_step, dtype) -> None:
+    L.call("aldi_sgd_step", _p(p), _p(g), _p(buf), _p(p_compute), n, lr, momentum, weight_decay, grad_scale, int(first_step),
+           dtype_code(dtype), stream_ptr())
+
+
+def ema_update(teacher, student, teacher_compute, n, alpha, copy_only, dtype) -> None:
+    L.call("aldi_ema_update", _p(teacher), _p(student), _p(teacher_compute), n, alpha, int(copy_only), dtype_code(dtype), stream_ptr())
+
+
+def bn_fold(w, b, mean, var, scale, shift, Cc) -> None:
+    L.call("aldi_bn_fold", _p(w), _p(b), _p(mean), _p(var), _p(scale), _p(shift), Cc, stream_ptr())
+
+
+# ------------------------------------------------------------------------------- RPN
+def make_geom(shapes: Sequence[Sequence[int]], A: int, Cc: int) -> L.RpnGeom:
+    g = L.RpnGeom()
+    g.num_levels, g.A, g.C = len(shapes), A, Cc
+    off = 0
+    for i, (h, w) in enumerate(shapes):
+        g.H[i], g.W[i], g.off[i] = h, w, off
+        off += h * w * A
+    for i in range(len(shapes), L.MAX_LEVELS + 1):
+        g.off[i] = off
+    return g
+
+
+def ptrs(ts: Optional[Sequence[Optional[torch.Tensor]]]):
+    if ts is None:
+        return None
+    arr = L.PtrArray5()
+    for i, t in enumerate(ts):
+        arr[i] = _p(t)
+    return arr
+
+
+def box_match(boxes, box_stride_n, box_count, Lb, gt_boxes, gt_count, Gmax, N, lo, hi, lowq, best_iou, best_idx, scratch, labels):
+    L.call("aldi_box_match", _p(boxes), box_stride_n, _p(box_count), Lb, _p(gt_boxes), _p(gt_count), Gmax, N, lo, hi, int(lowq),
+           _p(best_iou), _p(best_idx), _p(scratch), _p(labels), stream_ptr())
+
+
+def compact_labels(labels, Lb, N, bg, lists, counts):
+    L.call("aldi_compact_labels", _p(labels), Lb, N, bg, _p(lists), _p(counts), stream_ptr())
+
+
+def rpn_apply_sample(labels, Lb, N, lists, sel, nsel, S):
+    L.call("aldi_rpn_apply_sample", _p(labels), Lb, N, _p(lists), _p(sel), _p(nsel), S, stream_ptr())
+
+
+def rpn_loss(geom, head, grad, anchors, labels, matched, gt_boxes, gt_count, Gmax, N, inv_norm, gs_cls, gs_loc, loss2):
+    L.call("aldi_rpn_loss", C.byref(geom), ptrs(head), ptrs(grad), _p(anchors), _p(labels), _p(matched), _p(gt_boxes), _p(gt_count), Gmax, N,
+           inv_norm, gs_cls, gs_loc, _p(loss2), stream_ptr())
+
+
+def rpn_proposals_workspace(N, nl) -> int:
+    return int(L.lib.aldi_rpn_proposals_workspace(N, nl))
+
+
+def rpn_proposals(geom, head, anchors, img_hw, N, pre, post, thr, workspace, out_boxes, out_scores, out_count, err):
+    L.call("aldi_rpn_proposals", C.byref(geom), ptrs(head), _p(anchors), _p(img_hw), N, pre, post, thr, _p(workspace),
+           _p(out_boxes), _p(out_scores), _p(out_count), _p(err), stream_ptr())
+
+
+# ------------------------------------------------------------------------------- ROI heads
+def make_roi_feats(feats: Sequence[torch.Tensor], grads: Optional[Sequence[torch.Tensor]], scales: Sequence[float]) -> L.RoiFeats:
+    f = L.RoiFeats()
+    for i, t in enumerate(feats):
+        f.feat[i] = _p(t)
+        f.grad[i] = _p(grads[i]) if grads is not None else None
+        f.H[i], f.W[i] = t.shape[1], t.shape[2]
+        f.scale[i] = scales[i]
+    f.C = feats[0].shape[3]
+    return f
+
+
+def roi_prepare(props, pcount, P, gt_boxes, gt_classes, gt_count, Gmax, N, K, thr, cand, ccount, best_iou, best_idx, scratch, labels, cls):
+    L.call("aldi_roi_prepare", _p(props), _p(pcount), P, _p(gt_boxes), _p(gt_classes), _p(gt_count), Gmax, N, K, thr, _p(cand), _p(ccount),
+           _p(best_iou), _p(best_idx), _p(scratch), _p(labels), _p(cls), stream_ptr())
+
+
+def roi_gather(cand, cls, best_idx, Lb, lists, sel, nsel, S, row_off, gt_boxes, gt_count, Gmax, N, rois, r_cls, r_gt, r_idx):
+    L.call("aldi_roi_gather", _p(cand), _p(cls), _p(best_idx), Lb, _p(lists), _p(sel), _p(nsel), S, _p(row_off), _p(gt_boxes), _p(gt_count),
+           Gmax, N, _p(rois), _p(r_cls), _p(r_gt), _p(r_idx), stream_ptr())
+
+
+def rois_from_proposals(props, pcount, P, N, rois):
+    L.call("aldi_rois_from_proposals", _p(props), _p(pcount), P, N, _p(rois), stream_ptr())
+
+
+def roialign(feats: L.RoiFeats, rois, R, P, pooled, backward: bool):
+    L.call("aldi_roialign", C.byref(feats), _p(rois), R, P, _p(pooled), int(backward), dtype_code(pooled.dtype), stream_ptr())
+
+
+def box_loss(pred, Cp, K, R, rois, cls, gt_boxes, weights4, gs_cls, gs_box, grad, loss2):
+    w = (C.c_float * 4)(*weights4)
+    L.call("aldi_box_loss", _p(pred), Cp, K, R, _p(rois), _p(cls), _p(gt_boxes), w, gs_cls, gs_box, _p(grad), _p(loss2), stream_ptr())
+
+
+def detections_workspace(N) -> int:
+    return int(L.lib.aldi_detections_workspace(N))
+
+
+def detections(pred, Cp, K, props, pcount, P, N, img_hw, weights4, score_thresh, nms_thresh, topk, pl_thresh, workspace,
+               det_boxes, det_scores, det_cls, det_count, pl_boxes, pl_cls, pl_scores, pl_count, err):
+    w = (C.c_float * 4)(*weights4)
+    L.call("aldi_detections", _p(pred), Cp, K, _p(props), _p(pcount), P, N, _p(img_hw), w, score_thresh, nms_thresh, topk, pl_thresh,
+           _p(workspace), _p(det_boxes), _p(det_scores), _p(det_cls), _p(det_count), _p(pl_boxes), _p(pl_cls), _p(pl_scores), _p(pl_count),
+           _p(err), stream_ptr())
+
+
+# ------------------------------------------------------------------------------- ALDI losses
+def rpn_distill_loss(geom, s_head, t_head, grad, labels, N, obj_T, n_valid, n_fg, do_obj, do_reg, grad_scale, loss2):
+    L.call("aldi_rpn_distill_loss", C.byref(geom), ptrs(s_head), ptrs(t_head), ptrs(grad), _p(labels), N, obj_T, n_valid, n_fg,
+           int(do_obj), int(do_reg), grad_scale, _p(loss2), stream_ptr())
+
+
+def roih_distill_loss(s_pred, t_pred, Cp, K, R, cls_T, kl, do_cls, do_reg, grad_scale, grad, loss2):
+    L.call("aldi_roih_distill_loss", _p(s_pred), _p(t_pred), Cp, K, R, cls_T, int(kl), int(do_cls), int(do_reg), grad_scale, _p(grad),
+           _p(loss2), stream_ptr())
+
+
+def domain_bce(pred, ld, R, label, weight, grad_scale, grad, loss):
+    L.call("aldi_domain_bce", _p(pred), ld, R, label, weight, grad_scale, _p(grad), _p(loss),
+           dtype_code(grad.dtype) if grad is not None else L.F32, stream_ptr())
+
+
+def avgpool(x: torch.Tensor) -> torch.Tensor:
+    N, H, W_, Cc = x.shape
+    y = torch.empty((N, 1, 1, Cc), dtype=x.dtype, device=x.device)
+    L.call("aldi_avgpool", _p(x), _p(y), N, H * W_, Cc, dtype_code(x.dtype), stream_ptr())
+    return y
+
+
+def avgpool_bwd(gy: torch.Tensor, act: torch.Tensor) -> torch.Tensor:
+    N, H, W_, Cc = act.shape
+    gx = torch.empty_like(act)
+    L.call("aldi_avgpool_bwd", _p(gy), _p(act), _p(gx), N, H * W_, Cc, dtype_code(act.dtype), stream_ptr())
+    return gx

@@ -83,6 +83,152 @@ int aldi_bias_grad(const void* g, float* db, int M, int C, int dtype, aldi_strea
 int aldi_dgrad_weights(const float* w_master, const float* scale, void* wt, int Cout, int KH, int KW, int Cin,
                        int dtype, aldi_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------
+ * Stem and glue (bandwidth-bound).
+ * ------------------------------------------------------------------------------------- */
+#define ALDI_MAX_IMAGES 16
+
+/* GeneralizedRCNN.preprocess_image + BasicStem conv1/FrozenBN/ReLU (detectron2; call sites
+ * aldi/align.py:72, aldi/pseudolabeler.py:21): (uint8 - mean)/std, zero pad AFTER
+ * normalisation, conv 7x7 s2 p3 in fp32, y = relu(conv*scale+shift) -> [N][Hc][Wc][64]. */
+typedef struct {
+    const uint8_t* img;   /* [N][3][Hs][Ws] staging; image n is the top-left h[n] x w_img[n] */
+    const float* w;       /* [64][7][7][3] fp32                                             */
+    const float* scale; const float* shift;
+    void* y;
+    int N, Hs, Ws, Hc, Wc;
+    int h[ALDI_MAX_IMAGES], w_img[ALDI_MAX_IMAGES];
+    float mean[3], std[3];
+    int dtype;
+} aldi_stem_args;
+int aldi_stem_forward(const aldi_stem_args* a, aldi_stream_t stream);
+
+/* max_pool2d(k3,s2,p1) NHWC; y is [N][(H-1)/2+1][(W-1)/2+1][C]. */
+int aldi_maxpool3s2(const void* x, void* y, int N, int H, int W, int C, int dtype, aldi_stream_t stream);
+/* LastLevelMaxPool (k1,s2): forward y = x[:, ::2, ::2]; backward (x = grad small, y = grad big) y[::2,::2] += x. */
+int aldi_subsample2(const void* x, void* y, int N, int H, int W, int C, int backward, int dtype, aldi_stream_t stream);
+/* backward of FPN nearest-upsample-x2 + add: out[N][Hc][Wc][C] (=|+=) 2x2 block sums of g[N][2Hc][2Wc][C]. */
+int aldi_upsample2_bwd(const void* g, void* out, int N, int Hc, int Wc, int C, int accumulate, int dtype, aldi_stream_t stream);
+/* out = a + b (b fp32), optionally masked by relu_src > 0; a, relu_src nullable. */
+int aldi_add_f32(const void* a, const float* b, const void* relu_src, void* out, long n, int dtype, aldi_stream_t stream);
+int aldi_cast_from_f32(const float* src, void* dst, long n, int dtype, aldi_stream_t stream);
+
+/* torch.optim.SGD step over flat fp32 buffers (detectron2 build_optimizer via aldi/trainer.py:199-208,
+ * applied at aldi/dropin.py:121); refreshes the compute-dtype copy when dtype is bf16. */
+int aldi_sgd_step(float* p, const float* g, float* buf, void* p_compute, long n, float lr, float momentum, float weight_decay,
+                  float grad_scale, int first_step, int dtype, aldi_stream_t stream);
+/* EMA teacher update over the flat state (aldi/ema.py:32-57): t = s*(1-alpha) + t*alpha, or t = s. */
+int aldi_ema_update(float* teacher, const float* student, void* teacher_compute, long n, float alpha, int copy_only, int dtype, aldi_stream_t stream);
+/* FrozenBatchNorm2d fold (detectron2): scale = w*rsqrt(var+1e-5), shift = b - mean*scale. */
+int aldi_bn_fold(const float* w, const float* b, const float* mean, const float* var, float* scale, float* shift, int C, aldi_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------
+ * RPN / matcher / sampler / proposals (integer + box arithmetic; bit-exact index results).
+ * Replaces detectron2 Matcher, subsample_labels, RPN.label_and_sample_anchors, RPN.losses,
+ * RPN.predict_proposals / find_top_rpn_proposals and torchvision batched_nms; reference call
+ * sites aldi/distill.py:157,162,200-202, aldi/pseudolabeler.py:21.
+ * ------------------------------------------------------------------------------------- */
+#define ALDI_MAX_LEVELS 5
+typedef struct {
+    int num_levels;
+    int A;                        /* anchors per cell                                        */
+    int C;                        /* channels of a head output row: [0,A) objectness logits,
+                                     [A, 5A) deltas (a*4+d), rest padding                    */
+    int H[ALDI_MAX_LEVELS], W[ALDI_MAX_LEVELS];
+    int off[ALDI_MAX_LEVELS + 1]; /* anchor offset of each level; off[num_levels] = sum A   */
+} aldi_rpn_geom;
+
+/* Matcher: boxes [*(N)][L][4] (box_stride_n = 0 when shared by all images, else L), optional
+ * per-image box_count; gt [N][Gmax][4] + gt_count[N] (device).  labels: iou<lo -> 0,
+ * lo<=iou<hi -> -1, >=hi -> 1, low-quality matches -> 1; padding slots -> -2.
+ * best_idx = argmax GT (first max).  gt_best_scratch: [N][Gmax] uint32. */
+int aldi_box_match(const float* boxes, long box_stride_n, const int* box_count, int L,
+                   const float* gt_boxes, const int* gt_count, int Gmax, int N,
+                   float lo, float hi, int allow_low_quality,
+                   float* best_iou, int* best_idx, unsigned* gt_best_scratch, int* labels, aldi_stream_t stream);
+/* subsample_labels, step 1: ordered index lists. lists [N][2][L] (0: positives = not -1/-2/bg,
+ * 1: negatives = bg), counts [N][2]. */
+int aldi_compact_labels(const int* labels, int L, int N, int bg_label, int* lists, int* counts, aldi_stream_t stream);
+/* subsample_labels, step 2 (RPN): labels.fill(-1); labels[lists[0][sel[0]]] = 1; labels[lists[1][sel[1]]] = 0.
+ * sel [N][2][S] are positions drawn by the host RNG (torch.randperm order), nsel [N][2]. */
+int aldi_rpn_apply_sample(int* labels, int L, int N, const int* lists, const int* sel, const int* nsel, int S, aldi_stream_t stream);
+/* RPN objectness BCE (sum/norm) + L1 box loss (sum/norm), and d(scale_cls*loss_cls + scale_loc*loss_loc)/d(head)
+ * added into grad[level] (fp32, same layout as head; nullable).  head[level]: fp32 [N][H][W][C]. loss2 += */
+int aldi_rpn_loss(const aldi_rpn_geom* gm, float* const* head, float* const* grad, const float* anchors, const int* labels, const int* matched,
+                  const float* gt_boxes, const int* gt_count, int Gmax, int N, float inv_norm, float grad_scale_cls, float grad_scale_loc,
+                  float* loss2, aldi_stream_t stream);
+size_t aldi_rpn_proposals_workspace(int N, int num_levels);
+/* per level top-k -> decode -> clip -> drop empty -> batched NMS -> post-NMS top-k.
+ * out_boxes [N][post][4], out_scores [N][post], out_count [N]; err_flag |= 1 on non-finite. */
+int aldi_rpn_proposals(const aldi_rpn_geom* gm, float* const* head, const float* anchors, const int* img_hw, int N,
+                       int pre_nms_topk, int post_nms_topk, float nms_thresh, void* workspace,
+                       float* out_boxes, float* out_scores, int* out_count, int* err_flag, aldi_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------
+ * ROI heads.  Replaces detectron2 StandardROIHeads.label_and_sample_proposals, ROIPooler +
+ * torchvision roi_align(aligned, 7x7, adaptive sampling), FastRCNNOutputLayers.losses and
+ * .inference (fast_rcnn_inference), plus the reference's pseudo-label threshold filter
+ * aldi/pseudolabeler.py:51-67.  Call sites: aldi/distill.py:157,162; aldi/pseudolabeler.py:21.
+ * ------------------------------------------------------------------------------------- */
+typedef struct {
+    const void* feat[4];  /* p2..p5, [N][H][W][C] in dtype                 */
+    float* grad[4];       /* fp32 gradient accumulators (backward only)    */
+    int H[4], W[4];
+    float scale[4];       /* 1/4 .. 1/32                                   */
+    int C;                /* 256                                           */
+} aldi_roi_feats;
+
+/* proposals [N][P][4]+pcount, GT -> cand [N][L=P+Gmax][4] (GT appended), ccount, matcher (iou>=thr fg),
+ * cls [N][L]: matched gt class for fg, K for bg, -2 padding. */
+int aldi_roi_prepare(const float* props, const int* pcount, int P, const float* gt_boxes, const int* gt_classes, const int* gt_count,
+                     int Gmax, int N, int K, float iou_thresh, float* cand, int* ccount, float* best_iou, int* best_idx,
+                     unsigned* gt_best_scratch, int* labels, int* cls, aldi_stream_t stream);
+/* sampled rows = cat(fg_list[sel_fg], bg_list[sel_bg]) per image, packed from row_off[n]:
+ * rois [R][5] (batch, x1,y1,x2,y2), r_cls [R], r_gt [R][4], r_idx [R] (index into cand). */
+int aldi_roi_gather(const float* cand, const int* cls, const int* best_idx, int L, const int* lists, const int* sel, const int* nsel, int S,
+                    const int* row_off, const float* gt_boxes, const int* gt_count, int Gmax, int N,
+                    float* rois, int* r_cls, float* r_gt, int* r_idx, aldi_stream_t stream);
+/* inference: rois [N*P][5] from all proposals (padding rows get batch = -1). */
+int aldi_rois_from_proposals(const float* props, const int* pcount, int P, int N, float* rois, aldi_stream_t stream);
+/* ROIAlign over 4 FPN levels (level from box size). forward: pooled [R][P][P][C] written;
+ * backward: pooled holds the gradient, scattered with float atomics into feats->grad. */
+int aldi_roialign(const aldi_roi_feats* f, const float* rois, int R, int P, void* pooled, int backward, int dtype, aldi_stream_t stream);
+/* pred fp32 [R][Cp]: [0,K] class logits, then 4K class-specific deltas. loss2 += {CE mean, L1 sum/R};
+ * grad (fp32 [R][Cp], nullable) += d(scale_cls*loss_cls + scale_box*loss_box_reg)/d(pred). */
+int aldi_box_loss(const float* pred, int Cp, int K, int R, const float* rois, const int* cls, const float* gt_boxes,
+                  const float* weights4, float grad_scale_cls, float grad_scale_box, float* grad, float* loss2, aldi_stream_t stream);
+size_t aldi_detections_workspace(int N);
+/* fast_rcnn_inference + pseudo-label filter. pred fp32 [N*P][Cp] for all proposals.
+ * det_* [N][topk], pl_* [N][topk] (detections with score > pl_thresh, order kept), counts [N]. */
+int aldi_detections(const float* pred, int Cp, int K, const float* props, const int* pcount, int P, int N, const int* img_hw,
+                    const float* weights4, float score_thresh, float nms_thresh, int topk, float pl_thresh, void* workspace,
+                    float* det_boxes, float* det_scores, int* det_cls, int* det_count,
+                    float* pl_boxes, int* pl_cls, float* pl_scores, int* pl_count, int* err_flag, aldi_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------
+ * ALDI-owned losses (forward + backward fused).
+ * ------------------------------------------------------------------------------------- */
+/* ALDIDistiller.get_rpn_losses, aldi/distill.py:193-229, including the reference's index-order
+ * behaviour: mask position q of the (N, sumA) label tensor selects position q of
+ * cat([flatten(raw_level)]) with raw_level = (N, A|4A, H, W).  heads are fp32 [N][H][W][C].
+ * n_valid / n_fg: number of labels >= 0 / == 1 (known to the host that drew the sample).
+ * loss2 += {loss_obj_bce, loss_rpn_l1}; grad[level] += d(loss*grad_scale)/d(student head). */
+int aldi_rpn_distill_loss(const aldi_rpn_geom* gm, float* const* student_head, float* const* teacher_head, float* const* grad,
+                          const int* labels, int N, float obj_temperature, int n_valid, int n_fg, int do_obj, int do_reg,
+                          float grad_scale, float* loss2, aldi_stream_t stream);
+/* ALDIDistiller.get_roih_losses, aldi/distill.py:231-278 (kl = 0: soft CE, 1: KL batchmean).
+ * pred rows fp32 [R][Cp]: [0,K] logits then 4K deltas. loss2 += {loss_cls_ce, loss_roih_l1}. */
+int aldi_roih_distill_loss(const float* student_pred, const float* teacher_pred, int Cp, int K, int R, float cls_temperature,
+                           int kl, int do_cls, int do_reg, float grad_scale, float* grad, float* loss2, aldi_stream_t stream);
+/* AlignMixin domain loss, aldi/align.py:83-84,89-90: weight * BCEWithLogits(pred[:,0], label).mean();
+ * grad [R][ld] (dtype) = d(loss*grad_scale)/d(pred) (written, other columns zero). */
+int aldi_domain_bce(const float* pred, int ld, int R, float label, float weight, float grad_scale, void* grad, float* loss,
+                    int dtype, aldi_stream_t stream);
+/* ConvDiscriminator's AdaptiveAvgPool2d(1) (aldi/align.py:114): x [N][HW][C] -> y [N][C]; and the
+ * backward through ReLU + pool: gx = act > 0 ? gy / HW : 0. */
+int aldi_avgpool(const void* x, void* y, int N, int HW, int C, int dtype, aldi_stream_t stream);
+int aldi_avgpool_bwd(const void* gy, const void* act, void* gx, int N, int HW, int C, int dtype, aldi_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -81,79 +81,6 @@ def make_cfg(**over):
 # parameters (Detectron2 state_dict key names)
 # ----------------------------------------------------------------------------
 
-def conv_specs(cfg) -> "OrderedDict[str, dict]":
-    """Every conv/linear of the model in Detectron2 state_dict order.
-
-    value: dict(cin, cout, k, stride, pad, bn(bool), bias(bool))"""
-    s = OrderedDict()
-    bu = "backbone.bottom_up."
-    s[bu + "stem.conv1"] = dict(cin=3, cout=64, k=7, stride=2, pad=3, bn=True, bias=False)
-    cin = 64
-    for si, (nb, mid, out) in enumerate(zip(cfg["stage_blocks"], cfg["stage_mid"], cfg["stage_out"])):
-        stage = f"res{si + 2}"
-        for b in range(nb):
-            stride = 2 if (b == 0 and si > 0) else 1
-            p = f"{bu}{stage}.{b}."
-            if b == 0:
-                s[p + "shortcut"] = dict(cin=cin, cout=out, k=1, stride=stride, pad=0, bn=True, bias=False)
-            # STRIDE_IN_1X1=True: the stride sits in conv1
-            s[p + "conv1"] = dict(cin=cin, cout=mid, k=1, stride=stride, pad=0, bn=True, bias=False)
-            s[p + "conv2"] = dict(cin=mid, cout=mid, k=3, stride=1, pad=1, bn=True, bias=False)
-            s[p + "conv3"] = dict(cin=mid, cout=out, k=1, stride=1, pad=0, bn=True, bias=False)
-            cin = out
-    C = cfg["fpn_channels"]
-    for lvl, cin_l in zip((2, 3, 4, 5), cfg["stage_out"]):
-        s[f"backbone.fpn_lateral{lvl}"] = dict(cin=cin_l, cout=C, k=1, stride=1, pad=0, bn=False, bias=True)
-        s[f"backbone.fpn_output{lvl}"] = dict(cin=C, cout=C, k=3, stride=1, pad=1, bn=False, bias=True)
-    A = len(cfg["anchor_ratios"])
-    rp = "proposal_generator.rpn_head."
-    s[rp + "conv"] = dict(cin=C, cout=C, k=3, stride=1, pad=1, bn=False, bias=True)
-    s[rp + "objectness_logits"] = dict(cin=C, cout=A, k=1, stride=1, pad=0, bn=False, bias=True)
-    s[rp + "anchor_deltas"] = dict(cin=C, cout=4 * A, k=1, stride=1, pad=0, bn=False, bias=True)
-    P = cfg["pooler_resolution"]
-    K = cfg["num_classes"]
-    fd = cfg["fc_dim"]
-    s["roi_heads.box_head.fc1"] = dict(cin=C * P * P, cout=fd, k=0, bn=False, bias=True)
-    s["roi_heads.box_head.fc2"] = dict(cin=fd, cout=fd, k=0, bn=False, bias=True)
-    s["roi_heads.box_predictor.cls_score"] = dict(cin=fd, cout=K + 1, k=0, bn=False, bias=True)
-    s["roi_heads.box_predictor.bbox_pred"] = dict(cin=fd, cout=4 * K, k=0, bn=False, bias=True)
-    return s
-
-
-def init_state_dict(cfg, seed: int = 1, head_gain: float = 1.0) -> "OrderedDict[str, torch.Tensor]":
-    """Synthetic weights of the R50-FPN architecture (no checkpoints offline).
-
-    MSRA init for convs; FrozenBN buffers drawn so that the BN fold is
-    exercised (non-trivial scale/shift) while activations stay O(1) through
-    the 16 residual blocks (last BN of each block is damped)."""
-    g = torch.Generator().manual_seed(seed)
-    sd = OrderedDict()
-    for name, sp in conv_specs(cfg).items():
-        if sp["k"] > 0:
-            fan_out = sp["cout"] * sp["k"] * sp["k"]
-            std = math.sqrt(2.0 / fan_out)
-            if name.endswith("objectness_logits") or name.endswith("anchor_deltas"):
-                std = 0.01 * head_gain
-            w = torch.randn(sp["cout"], sp["cin"], sp["k"], sp["k"], generator=g) * std
-        else:
-            std = math.sqrt(1.0 / sp["cin"])      # c2_xavier-like
-            if name.endswith("cls_score"):
-                std = 0.01 * head_gain
-            if name.endswith("bbox_pred"):
-                std = 0.001 * head_gain
-            w = torch.randn(sp["cout"], sp["cin"], generator=g) * std
-        sd[name + ".weight"] = w
-        if sp["bias"]:
-            sd[name + ".bias"] = torch.randn(sp["cout"], generator=g) * 0.01
-        if sp["bn"]:
-            damp = 0.25 if name.endswith("conv3") else 1.0
-            sd[name + ".norm.weight"] = (0.6 + 0.4 * torch.rand(sp["cout"], generator=g)) * damp
-            sd[name + ".norm.bias"] = torch.randn(sp["cout"], generator=g) * 0.05
-            sd[name + ".norm.running_mean"] = torch.randn(sp["cout"], generator=g) * 0.05
-            sd[name + ".norm.running_var"] = 0.5 + torch.rand(sp["cout"], generator=g)
-    return sd
-
-
 def trainable_keys(cfg, sd) -> List[str]:
     """FREEZE_AT=2: stem and res2 frozen; FrozenBN buffers are never trained."""
     out = []
