@@ -44,11 +44,23 @@ class Weights:
         self.compute = self.master if dtype == torch.float32 else torch.zeros(L.n_weights, dtype=dtype, device=device)
         self.bn_scale = torch.zeros(max(L.bn_channels, 1), dtype=torch.float32, device=device)
         self.bn_shift = torch.zeros(max(L.bn_channels, 1), dtype=torch.float32, device=device)
-        self.grad = torch.zeros(L.n_train, dtype=torch.float32, device=device) if trainable else None
-        self.mom = torch.zeros(L.n_train, dtype=torch.float32, device=device) if trainable else None
+        self._grad = None      # allocated on first use (an EMA teacher never needs them)
+        self._mom = None
         self.first_step = True
         self._wt: Dict[str, torch.Tensor] = {}
         self._neg1: Dict[int, torch.Tensor] = {}
+
+    @property
+    def grad(self) -> torch.Tensor:
+        if self._grad is None:
+            self._grad = torch.zeros(self.layout.n_train, dtype=torch.float32, device=self.device)
+        return self._grad
+
+    @property
+    def mom(self) -> torch.Tensor:
+        if self._mom is None:
+            self._mom = torch.zeros(self.layout.n_train, dtype=torch.float32, device=self.device)
+        return self._mom
 
     # ---- views -----------------------------------------------------------------------------
     def w(self, name: str) -> torch.Tensor:
@@ -120,11 +132,16 @@ class Weights:
 
     def zero_grad(self):
         self.grad.zero_()
+        self._gscale = 1.0
+
+    def scale_grad(self, f: float):
+        """deferred scalar on the gradient (applied inside the fused optimizer kernel), e.g. 1/world after all-reduce(SUM)"""
+        self._gscale = getattr(self, "_gscale", 1.0) * f
 
     def sgd_step(self, lr: float, momentum: float = 0.9, weight_decay: float = 1e-4, grad_scale: float = 1.0):
         n = self.layout.n_train
         ops.sgd_step(self.master, self.grad, self.mom, self.compute if self.dtype != torch.float32 else None, n, lr, momentum,
-                     weight_decay, grad_scale, self.first_step, self.dtype)
+                     weight_decay, grad_scale * getattr(self, "_gscale", 1.0), self.first_step, self.dtype)
         self.first_step = False
         self._wt.clear()
 
@@ -327,14 +344,17 @@ class RCNN:
         ops.compact_labels(labels, sumA, N, 0, lists, counts)
         return labels, best_idx, lists, counts
 
-    def rpn_sample(self, labels, lists, counts, N):
-        """host draws (2 randperm per image) -> final labels in {-1,0,1}; returns (n_valid, n_fg)."""
-        host_counts = counts.cpu().tolist()                 # device->host sync: the RNG needs the list lengths
+    def rpn_sample(self, lists, counts, N, host_counts=None):
+        """host draws (2 randperm per image) -> NEW label tensor in {-1,0,1}; returns (labels, n_valid, n_fg, host_counts)."""
+        if host_counts is None:
+            host_counts = counts.cpu().tolist()             # device->host sync: the RNG needs the list lengths
         sel, nsel, nsel_h = self._sample(host_counts, RPN_BATCH, RPN_POS_FRAC)
-        ops.rpn_apply_sample(labels, labels.shape[1], N, lists, sel, nsel, RPN_BATCH)
+        L_ = lists.shape[2]
+        labels = torch.empty((N, L_), dtype=torch.int32, device=self.device)
+        ops.rpn_apply_sample(labels, L_, N, lists, sel, nsel, RPN_BATCH)
         n_fg = sum(a for a, _ in nsel_h)
         n_valid = sum(a + b for a, b in nsel_h)
-        return n_valid, n_fg
+        return labels, n_valid, n_fg, host_counts
 
     def proposals(self, c: Ctx, geom, anchors, hw, N, training: bool):
         nl = 5
@@ -347,12 +367,11 @@ class RCNN:
         return boxes, scores, count
 
     # ------------------------------------------------------------------ training forward
-    def forward_train(self, images, instances, *, roi_seed: Optional[int], scales: Dict[str, float],
+    def forward_train(self, images, instances, *, roi_seed: Optional[int] = None, pre_roi_hook=None,
                       gt_dev: Optional[dict] = None, do_align: bool = False, labeled: bool = True,
                       da_weights: Tuple[float, float] = (0.0, 0.0)) -> Ctx:
-        """GeneralizedRCNN.forward (training) + AlignMixin.forward (aldi/align.py:71-101), including
-        d(loss)/d(head outputs).  scales[k] multiplies d(loss_k) in backward (0 => contributes
-        nothing, as the reference's `v * 0`; 1/accum otherwise).  Loss VALUES are unscaled."""
+        """GeneralizedRCNN.forward (training) + AlignMixin.forward (aldi/align.py:71-101): activations
+        and (unscaled) loss VALUES.  Gradients are produced later by ``backward(c, scales)``."""
         N = len(images)
         st, sizes, hw = self.stage_images(images)
         shapes, geom, anchors = self.geometry(st.shape[2], st.shape[3])
@@ -362,50 +381,58 @@ class RCNN:
         self.rpn_head(c, save=True)
         dev = self.device
         # --- RPN labels + losses
-        labels, matched, lists, counts = self.rpn_match(geom, anchors, gt, N)
-        self.rpn_sample(labels, lists, counts, N)
-        c.rpn_labels, c.rpn_matched = labels, matched
-        c.ghead = [torch.zeros_like(h) for h in c.head]
+        _, matched, lists, counts = self.rpn_match(geom, anchors, gt, N)
+        labels, _, _, c.rpn_host_counts = self.rpn_sample(lists, counts, N)
+        c.rpn_labels, c.rpn_matched, c.rpn_lists, c.rpn_counts = labels, matched, lists, counts
         c.loss_rpn = torch.zeros(2, dtype=torch.float32, device=dev)
-        ops.rpn_loss(geom, c.head, c.ghead, anchors, labels, matched, gt["boxes"], gt["count"], GMAX, N, 1.0 / (RPN_BATCH * N),
-                     scales.get("loss_rpn_cls", 0.0), scales.get("loss_rpn_loc", 0.0), c.loss_rpn)
+        ops.rpn_loss(geom, c.head, None, anchors, labels, matched, gt["boxes"], gt["count"], GMAX, N, 1.0 / (RPN_BATCH * N), 0.0, 0.0, c.loss_rpn)
         # --- proposals (detached)
         c.props, c.prop_scores, c.prop_count = self.proposals(c, geom, anchors, hw, N, training=True)
         # --- ROI heads
+        if pre_roi_hook is not None:
+            pre_roi_hook()                                   # forward pre-hooks on roi_heads (ManualSeed, aldi/helpers.py:25-26)
         if roi_seed is not None:
-            torch.manual_seed(roi_seed)                      # ManualSeed pre-hook on roi_heads (aldi/helpers.py:25-26)
+            torch.manual_seed(roi_seed)
         self.roi_sample(c, c.props, c.prop_count, gt, N)
         self.roi_forward(c)
-        c.gpred = torch.zeros((max(c.R, 1), self.Cp), dtype=torch.float32, device=dev)
         c.loss_box = torch.zeros(2, dtype=torch.float32, device=dev)
-        ops.box_loss(c.pred, self.Cp, self.K, c.R, c.rois, c.r_cls, c.r_gt, ROI_WEIGHTS, scales.get("loss_cls", 0.0),
-                     scales.get("loss_box_reg", 0.0), c.gpred, c.loss_box)
+        ops.box_loss(c.pred, self.Cp, self.K, c.R, c.rois, c.r_cls, c.r_gt, ROI_WEIGHTS, 0.0, 0.0, None, c.loss_box)
         c.align = {}
+        c.distill = None
+        c.labeled, c.da_weights = labeled, da_weights
         if do_align:
-            self.align_forward(c, labeled, da_weights, scales.get("loss_da_img", 0.0), scales.get("loss_da_ins", 0.0))
+            self.align_forward(c, labeled, da_weights)
         return c
 
-    def align_forward(self, c: Ctx, labeled: bool, da_weights, gs_img: float, gs_ins: float):
+    def align_forward(self, c: Ctx, labeled: bool, da_weights):
         """AlignMixin.forward (aldi/align.py:75-90): discriminators behind gradient reversal, BCE vs constant domain label."""
-        dev, T = self.device, self.dtype
+        dev = self.device
         label = 1.0 if labeled else 0.0
         if self.has_img_da:
             a1 = self.conv(c.P[0], "img_align.model.0", relu=True)
             pooled = ops.avgpool(a1)
             logit = self.conv(pooled, "img_align.model.4", want_f32=True)
-            ld = logit.shape[-1]
-            glog = torch.empty((c.N, 1, 1, ld), dtype=T, device=dev)
             c.loss_da_img = torch.zeros(1, dtype=torch.float32, device=dev)
-            ops.domain_bce(logit, ld, c.N, label, da_weights[0], gs_img, glog, c.loss_da_img)
-            c.align["img"] = (a1, pooled, glog)
+            ops.domain_bce(logit, logit.shape[-1], c.N, label, da_weights[0], 0.0, None, c.loss_da_img)
+            c.align["img"] = (a1, pooled, logit)
         if self.has_ins_da and c.R > 0:
             h = self.conv(c.fc2, "ins_align.model.1", relu=True)
             logit = self.conv(h, "ins_align.model.3", want_f32=True)
-            ld = logit.shape[-1]
-            glog = torch.empty((c.R, 1, 1, ld), dtype=T, device=dev)
             c.loss_da_ins = torch.zeros(1, dtype=torch.float32, device=dev)
-            ops.domain_bce(logit, ld, c.R, label, da_weights[1], gs_ins, glog, c.loss_da_ins)
-            c.align["ins"] = (h, glog)
+            ops.domain_bce(logit, logit.shape[-1], c.R, label, da_weights[1], 0.0, None, c.loss_da_ins)
+            c.align["ins"] = (h, logit)
+
+    def distill_forward(self, c: Ctx, teacher_head: List[torch.Tensor], teacher_pred: torch.Tensor, labels: torch.Tensor,
+                        n_valid: int, n_fg: int, *, obj_T: float, cls_T: float, kl: bool,
+                        do_obj: bool, do_rpn_reg: bool, do_cls: bool, do_roih_reg: bool):
+        """ALDIDistiller.get_rpn_losses + get_roih_losses (aldi/distill.py:193-278): loss values now, gradients in backward."""
+        dev = self.device
+        c.distill = dict(t_head=teacher_head, t_pred=teacher_pred, labels=labels, n_valid=n_valid, n_fg=n_fg, obj_T=obj_T, cls_T=cls_T,
+                         kl=kl, do_obj=do_obj, do_rpn_reg=do_rpn_reg, do_cls=do_cls, do_roih_reg=do_roih_reg)
+        c.loss_dist_rpn = torch.zeros(2, dtype=torch.float32, device=dev)
+        c.loss_dist_roi = torch.zeros(2, dtype=torch.float32, device=dev)
+        ops.rpn_distill_loss(c.geom, c.head, teacher_head, None, labels, c.N, obj_T, n_valid, n_fg, do_obj, do_rpn_reg, 0.0, c.loss_dist_rpn)
+        ops.roih_distill_loss(c.pred, teacher_pred, self.Cp, self.K, c.R, cls_T, kl, do_cls, do_roih_reg, 0.0, None, c.loss_dist_roi)
 
     def loss_dict(self, c: Ctx) -> "OrderedDict[str, torch.Tensor]":
         """0-d device tensors in the key order of GeneralizedRCNN.forward (+ AlignMixin)."""
@@ -416,6 +443,19 @@ class RCNN:
             d["loss_da_img"] = c.loss_da_img[0]
         if "ins" in c.align:
             d["loss_da_ins"] = c.loss_da_ins[0]
+        return d
+
+    def distill_loss_dict(self, c: Ctx) -> "OrderedDict[str, torch.Tensor]":
+        d = OrderedDict()
+        k = c.distill
+        if k["do_obj"]:
+            d["loss_obj_bce"] = c.loss_dist_rpn[0]
+        if k["do_rpn_reg"]:
+            d["loss_rpn_l1"] = c.loss_dist_rpn[1]
+        if k["do_cls"]:
+            d["loss_cls_ce"] = c.loss_dist_roi[0]
+        if k["do_roih_reg"]:
+            d["loss_roih_l1"] = c.loss_dist_roi[1]
         return d
 
     def roi_sample(self, c: Ctx, props, prop_count, gt, N):
@@ -435,6 +475,7 @@ class RCNN:
         counts = torch.empty((N, 2), dtype=torch.int32, device=dev)
         ops.compact_labels(cls, Lc, N, self.K, lists, counts)
         host_counts = counts.cpu().tolist()                  # device->host sync (RNG needs the list lengths)
+        c.roi_host_counts = host_counts
         sel, nsel, nsel_h = self._sample(host_counts, ROI_BATCH, ROI_POS_FRAC)
         rows = [a + b for a, b in nsel_h]
         row_off = [0]
@@ -505,12 +546,51 @@ class RCNN:
         return c
 
     # ------------------------------------------------------------------ backward
-    def backward(self, c: Ctx):
-        """Accumulate d(sum_k scales[k] * loss_k)/d(params) into weights.grad (the scales were applied
-        where c.ghead / c.gpred / the discriminator logit grads were produced).  heads -> FPN -> res5..res3."""
+    def backward(self, c: Ctx, scales: Dict[str, float]):
+        """Accumulate d(sum_k scales[k] * loss_k)/d(params) into weights.grad: loss gradients w.r.t. the
+        head outputs first, then heads -> FPN -> res5..res3.  A missing / zero scale contributes
+        nothing (the reference's `v * 0`)."""
         W = self.wts
         T = self.dtype
         dev = self.device
+        sc = lambda k: float(scales.get(k, 0.0))
+        scratch = torch.zeros(2, dtype=torch.float32, device=dev)
+        c.ghead = [torch.zeros_like(h) for h in c.head]
+        c.gpred = torch.zeros((max(c.R, 1), self.Cp), dtype=torch.float32, device=dev)
+        gt = c.gt
+        ops.rpn_loss(c.geom, c.head, c.ghead, c.anchors, c.rpn_labels, c.rpn_matched, gt["boxes"], gt["count"], GMAX, c.N,
+                     1.0 / (RPN_BATCH * c.N), sc("loss_rpn_cls"), sc("loss_rpn_loc"), scratch)
+        ops.box_loss(c.pred, self.Cp, self.K, c.R, c.rois, c.r_cls, c.r_gt, ROI_WEIGHTS, sc("loss_cls"), sc("loss_box_reg"), c.gpred, scratch)
+        if c.distill is not None:
+            d = c.distill
+            # each kernel handles a loss pair with ONE scale: split the call when the two scales differ
+            def rpn_d(do_obj, do_reg, s_):
+                ops.rpn_distill_loss(c.geom, c.head, d["t_head"], c.ghead, d["labels"], c.N, d["obj_T"], d["n_valid"], d["n_fg"],
+                                     do_obj, do_reg, s_, scratch)
+
+            def roi_d(do_cls, do_reg, s_):
+                ops.roih_distill_loss(c.pred, d["t_pred"], self.Cp, self.K, c.R, d["cls_T"], d["kl"], do_cls, do_reg, s_, c.gpred, scratch)
+            if sc("loss_obj_bce") == sc("loss_rpn_l1"):
+                rpn_d(d["do_obj"], d["do_rpn_reg"], sc("loss_obj_bce"))
+            else:
+                rpn_d(d["do_obj"], False, sc("loss_obj_bce"))
+                rpn_d(False, d["do_rpn_reg"], sc("loss_rpn_l1"))
+            if sc("loss_cls_ce") == sc("loss_roih_l1"):
+                roi_d(d["do_cls"], d["do_roih_reg"], sc("loss_cls_ce"))
+            else:
+                roi_d(d["do_cls"], False, sc("loss_cls_ce"))
+                roi_d(False, d["do_roih_reg"], sc("loss_roih_l1"))
+        label = 1.0 if c.labeled else 0.0
+        if "img" in c.align:
+            a1, pooled, logit = c.align["img"]
+            glog = torch.empty(logit.shape, dtype=T, device=dev)
+            ops.domain_bce(logit, logit.shape[-1], c.N, label, c.da_weights[0], sc("loss_da_img"), glog, scratch)
+            c.align["img"] = (a1, pooled, glog)
+        if "ins" in c.align:
+            h, logit = c.align["ins"]
+            glog = torch.empty(logit.shape, dtype=T, device=dev)
+            ops.domain_bce(logit, logit.shape[-1], c.R, label, c.da_weights[1], sc("loss_da_ins"), glog, scratch)
+            c.align["ins"] = (h, glog)
         # ---- box head (+ instance-level discriminator behind the gradient-reversal layer)
         gP_roi = [torch.zeros(f.shape, dtype=torch.float32, device=dev) for f in c.P[:4]]
         if c.R > 0:

@@ -1,0 +1,311 @@
+"""ALDITrainer and the step driver, with the reference's names and control flow
+(aldi/trainer.py:28-246, aldi/dropin.py:29-184).  ``run_model_labeled_unlabeled`` is the same
+schedule -- source weak/strong, target-weak alignment, distillation, loss-dict keys and 1/accum
+scaling -- driving the HIP engine through the model / distiller plugin objects."""
+from __future__ import annotations
+
+import logging
+import time
+import weakref
+from typing import Dict
+
+import torch
+import torch.distributed as dist
+
+from .dataloader import SyntheticDetectionLoader, WeakStrongDataloader
+from .distill import build_distiller
+from .ema import EMA
+from .model import build_aldi
+
+DEBUG = False
+debug_dict = {}
+
+
+def run_model_labeled_unlabeled(trainer, labeled_weak, labeled_strong, unlabeled_weak, unlabeled_strong):
+    """Mean-Teacher style iteration; see reference aldi/trainer.py:28-117 for the contract."""
+    model = trainer.model
+    backward_at_end = trainer.backward_at_end
+    model_batch_size = trainer.model_batch_size
+
+    _model = model.module if hasattr(model, "module") else model
+    do_weak = labeled_weak is not None
+    do_strong = labeled_strong is not None
+    do_align = any([getattr(_model, a, None) is not None for a in ["img_align", "ins_align"]])
+    do_distill = trainer.distiller.distill_enabled()
+
+    total_batch_size = sum([len(s or []) for s in [labeled_weak, labeled_strong, unlabeled_weak]])
+    num_grad_accum_steps = total_batch_size // model_batch_size
+
+    loss_dict = {}
+
+    def add_to_loss_dict(losses, suffix, key_conditional=lambda k: True):
+        for k, v in losses.items():
+            if key_conditional(k):
+                v = v / num_grad_accum_steps
+                if not backward_at_end:
+                    v = v.detach()
+                loss_dict[f"{k}_{suffix}"] = loss_dict.get(f"{k}_{suffix}", 0) + v
+
+    def maybe_do_backward(losses, key_conditional=lambda k: True):
+        if not backward_at_end:
+            losses = {k: v * 0 if not key_conditional(k) else v for k, v in losses.items()}
+            trainer.do_backward(sum(losses.values()) / num_grad_accum_steps, override=True)
+
+    def do_training_step(data, name="", key_conditional=lambda k: True, **kwargs):
+        for batch_i in range(0, len(data), model_batch_size):
+            loss = model(data[batch_i:batch_i + model_batch_size], **kwargs)
+            maybe_do_backward(loss, key_conditional)
+            add_to_loss_dict(loss, name, key_conditional)
+
+    def do_distill_step(teacher_data, student_data, name="", key_conditional=lambda k: True, **kwargs):
+        assert len(teacher_data) == len(student_data), "Teacher and student data must be the same length."
+        for batch_i in range(0, len(teacher_data), model_batch_size):
+            distill_loss = trainer.distiller(teacher_data[batch_i:batch_i + model_batch_size],
+                                             student_data[batch_i:batch_i + model_batch_size])
+            maybe_do_backward(distill_loss, key_conditional)
+            add_to_loss_dict(distill_loss, name, key_conditional)
+
+    if do_weak:
+        do_training_step(labeled_weak, "source_weak", lambda k: do_weak or (do_align and "_da_" in k), do_align=do_align)
+    if do_strong:
+        do_training_step(labeled_strong, "source_strong", lambda k: do_strong or (do_align and "_da_" in k), do_align=do_align)
+    if do_align:
+        do_training_step(unlabeled_weak, "target_weak", lambda k: "_da_" in k, labeled=False, do_align=True)
+    if do_distill:
+        do_distill_step(unlabeled_weak, unlabeled_strong, "distill", lambda k: k != "_")
+    return loss_dict
+
+
+class EngineSGD:
+    """torch.optim.SGD-shaped handle on the fused HIP optimizer (momentum / weight decay of detectron2's build_optimizer)."""
+    def __init__(self, model, lr, momentum=0.9, weight_decay=1e-4):
+        self.model = model
+        self.param_groups = [{"lr": lr, "momentum": momentum, "weight_decay": weight_decay}]
+
+    def zero_grad(self, set_to_none: bool = False):
+        self.model.weights.zero_grad()
+
+    def step(self):
+        g = self.param_groups[0]
+        self.model.weights.sgd_step(g["lr"], g["momentum"], g["weight_decay"])
+
+
+class WarmupMultiStepLR:
+    """detectron2 WarmupMultiStepLR (linear warmup), stepped once per iteration."""
+    def __init__(self, optimizer, base_lr, steps, gamma, warmup_factor, warmup_iters):
+        self.opt, self.base_lr, self.steps, self.gamma = optimizer, base_lr, tuple(steps), gamma
+        self.warmup_factor, self.warmup_iters = warmup_factor, warmup_iters
+        self.last_iter = 0
+        self._apply()
+
+    def lr_at(self, it):
+        wf = 1.0
+        if it < self.warmup_iters:
+            alpha = it / self.warmup_iters
+            wf = self.warmup_factor * (1 - alpha) + alpha
+        return self.base_lr * wf * self.gamma ** sum(1 for s in self.steps if s <= it)
+
+    def _apply(self):
+        self.opt.param_groups[0]["lr"] = self.lr_at(self.last_iter)
+
+    def step(self):
+        self.last_iter += 1
+        self._apply()
+
+
+class SimpleTrainer:
+    """One iteration = fetch, zero_grad, run_model, backward, (all-reduce), optimizer step (aldi/dropin.py:87-130)."""
+    def __init__(self, model, data_loader, optimizer, zero_grad_before_forward=False):
+        self.model, self.data_loader, self.optimizer = model, data_loader, optimizer
+        self._data_loader_iter_obj = None
+        self.zero_grad_before_forward = zero_grad_before_forward
+        self.last_loss_dict: Dict[str, float] = {}
+
+    @property
+    def _data_loader_iter(self):
+        if self._data_loader_iter_obj is None:
+            self._data_loader_iter_obj = iter(self.data_loader)
+        return self._data_loader_iter_obj
+
+    def run_step(self):
+        assert self.model.training, "[SimpleTrainer] model was changed to eval mode!"
+        start = time.perf_counter()
+        data = next(self._data_loader_iter)
+        data_time = time.perf_counter() - start
+        if self.zero_grad_before_forward:
+            self.optimizer.zero_grad()
+        loss_dict = self.run_model(data)
+        if isinstance(loss_dict, torch.Tensor):
+            losses = loss_dict
+            loss_dict = {"total_loss": loss_dict}
+        else:
+            losses = sum(loss_dict.values())
+        if not self.zero_grad_before_forward:
+            self.optimizer.zero_grad()
+        self.do_backward(losses)
+        self.after_backward()
+        self._write_metrics(loss_dict, data_time)
+        self.optimizer.step()
+
+    def run_model(self, data):
+        return self.model(data)
+
+    def do_backward(self, losses):
+        losses.backward()
+
+    def after_backward(self):
+        """One all-reduce of the student gradients per step (the reference's DDP reduces on every
+        micro-step backward, aldi/dropin.py:53; the sum is linear so one reduction at the end is equivalent)."""
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            g = self.model.weights.grad
+            dist.all_reduce(g, op=dist.ReduceOp.SUM)
+            self.model.weights.scale_grad(1.0 / dist.get_world_size())
+
+    def _write_metrics(self, loss_dict, data_time):
+        self.last_loss_dict = loss_dict
+        self.last_data_time = data_time
+
+
+class AMPTrainer(SimpleTrainer):
+    """Reference: fp16 autocast + GradScaler (aldi/dropin.py:131-184).  Here AMP means the bf16 compute mode of the
+    engine (fp32 master weights / accumulators); bf16 needs no loss scaling, so there is no GradScaler."""
+    def run_step(self):
+        assert self.model.training, "[AMPTrainer] model was changed to eval mode!"
+        assert torch.cuda.is_available(), "[AMPTrainer] CUDA is required for AMP training!"
+        super().run_step()
+
+
+class _ALDITrainer:
+    def __init__(self, model, data_loader, optimizer, distiller, backward_at_end=True, model_batch_size=None):
+        super().__init__(model, data_loader, optimizer, zero_grad_before_forward=not backward_at_end)
+        self.distiller = distiller
+        self.backward_at_end = backward_at_end
+        self.model_batch_size = model_batch_size
+
+    def run_model(self, data):
+        return run_model_labeled_unlabeled(self, *data)
+
+    def do_backward(self, losses, override=False):
+        if self.backward_at_end or override:
+            super().do_backward(losses)
+
+
+class ALDIAMPTrainer(_ALDITrainer, AMPTrainer):
+    pass
+
+
+class ALDISimpleTrainer(_ALDITrainer, SimpleTrainer):
+    pass
+
+
+class DefaultTrainer:
+    """Constructor sequence of the reference's DefaultTrainer (aldi/dropin.py:35-70) without the Detectron2 hook zoo."""
+    def __init__(self, cfg):
+        self.cfg = cfg
+        model = self.build_model(cfg)
+        optimizer = self.build_optimizer(cfg, model)
+        data_loader = self.build_train_loader(cfg)
+        model = self.create_ddp_model(model, broadcast_buffers=False, cfg=cfg)
+        self._trainer = self._create_trainer(cfg, model, data_loader, optimizer)
+        self.scheduler = self.build_lr_scheduler(cfg, optimizer)
+        self.start_iter = 0
+        self.iter = 0
+        self.max_iter = cfg.SOLVER.MAX_ITER
+
+    def _create_trainer(self, cfg, model, data_loader, optimizer):
+        return (AMPTrainer if cfg.SOLVER.AMP.ENABLED else SimpleTrainer)(model, data_loader, optimizer)
+
+    def create_ddp_model(self, model, broadcast_buffers, cfg):
+        """One process per GPU; gradients are all-reduced over RCCL in SimpleTrainer.after_backward.  Rank 0's weights are broadcast once."""
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            dist.broadcast(model.weights.master, src=0)
+            model.weights.refresh()
+        return model
+
+    @classmethod
+    def build_lr_scheduler(cls, cfg, optimizer):
+        S = cfg.SOLVER
+        return WarmupMultiStepLR(optimizer, S.BASE_LR, S.STEPS, S.GAMMA, S.WARMUP_FACTOR, S.WARMUP_ITERS)
+
+    @classmethod
+    def build_optimizer(cls, cfg, model):
+        return EngineSGD(model, cfg.SOLVER.BASE_LR, cfg.SOLVER.MOMENTUM, cfg.SOLVER.WEIGHT_DECAY)
+
+    def resume_or_load(self, resume=True):
+        return None
+
+    @property
+    def model(self):
+        return self._trainer.model
+
+    def before_step(self):
+        pass
+
+    def run_step(self):
+        self._trainer.run_step()
+
+    def after_step(self):
+        self.scheduler.step()
+
+    def train(self):
+        for self.iter in range(self.start_iter, self.max_iter):
+            self.before_step()
+            self.run_step()
+            self.after_step()
+        self.iter += 1
+
+
+class ALDITrainer(DefaultTrainer):
+    """Mean-Teacher trainer (aldi/trainer.py:140-246): builds student, EMA teacher and distiller; EMA tick before every step."""
+
+    def _create_trainer(self, cfg, model, data_loader, optimizer):
+        self.ema = EMA(build_aldi(cfg), cfg.EMA.ALPHA, cfg.EMA.START_ITER) if cfg.EMA.ENABLED else None
+        distiller = build_distiller(cfg=cfg, teacher=self.ema.model if cfg.EMA.ENABLED else model, student=model)
+        trainer = (ALDIAMPTrainer if cfg.SOLVER.AMP.ENABLED else ALDISimpleTrainer)(model, data_loader, optimizer, distiller,
+                                                                                    backward_at_end=cfg.SOLVER.BACKWARD_AT_END,
+                                                                                    model_batch_size=cfg.SOLVER.IMS_PER_GPU)
+        return trainer
+
+    @classmethod
+    def build_model(cls, cfg):
+        model = build_aldi(cfg)
+        logging.getLogger(__name__).info("Model: %s", type(model).__mro__)
+        return model
+
+    @classmethod
+    def build_optimizer(cls, cfg, model):
+        if cfg.SOLVER.OPTIMIZER is None or cfg.SOLVER.OPTIMIZER.upper() == "SGD":
+            return super(ALDITrainer, cls).build_optimizer(cfg, model)
+        raise ValueError(f"Unsupported optimizer/backbone combination {cfg.SOLVER.OPTIMIZER} {cfg.MODEL.BACKBONE.NAME}.")
+
+    @classmethod
+    def build_train_loader(cls, cfg):
+        """Same batch-size arithmetic as the reference (aldi/trainer.py:211-240); the loaders are synthetic
+        (datasets / decode / augmentation are outside the hot path: SURVEY.md section 8a row a20)."""
+        batch_contents = cfg.DATASETS.BATCH_CONTENTS
+        batch_ratios = cfg.DATASETS.BATCH_RATIOS
+        total_batch_size = cfg.SOLVER.IMS_PER_BATCH
+        batch_sizes = [int(total_batch_size * r / sum(batch_ratios)) for r in batch_ratios]
+        assert len(batch_contents) == len(batch_sizes), "len(cfg.DATASETS.BATCH_CONTENTS) must equal len(cfg.DATASETS.BATCH_RATIOS)."
+        assert sum(batch_sizes) == total_batch_size, f"sum(batch_sizes)={sum(batch_sizes)} must equal total_batch_size={total_batch_size}"
+        world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+        rank = dist.get_rank() if world > 1 else 0
+        labeled_bs = [batch_sizes[i] for i in range(len(batch_contents)) if batch_contents[i].startswith("labeled")]
+        labeled_bs = max(labeled_bs) if len(labeled_bs) else 0
+        unlabeled_bs = [batch_sizes[i] for i in range(len(batch_contents)) if batch_contents[i].startswith("unlabeled")]
+        unlabeled_bs = max(unlabeled_bs) if len(unlabeled_bs) else 0
+        syn = cfg.get("SYNTHETIC", {})
+        h, w = syn.get("HEIGHT", 800), syn.get("WIDTH", 1333)
+        K = cfg.MODEL.ROI_HEADS.NUM_CLASSES
+        fixed = bool(syn.get("FIXED", False))
+        labeled_loader = SyntheticDetectionLoader(labeled_bs // world, h, w, K, 1000 + 17 * rank, True, fixed=fixed) if labeled_bs > 0 else None
+        unlabeled_loader = SyntheticDetectionLoader(unlabeled_bs // world, h, w, K, 2000 + 17 * rank, False, fixed=fixed) if unlabeled_bs > 0 else None
+        return WeakStrongDataloader(labeled_loader, unlabeled_loader, batch_contents)
+
+    def before_step(self):
+        super(ALDITrainer, self).before_step()
+        if self.cfg.EMA.ENABLED:
+            self.ema.update_weights(self._trainer.model, self.iter)
+
+
+Trainer = ALDITrainer   # BASELINE.json calls it aldi.trainer.Trainer

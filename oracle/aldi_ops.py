@@ -238,6 +238,7 @@ class OracleALDI:
         self.rand = random.Random(py_seed)
         self.seed = self.rand.randint(0, 2 ** 32 - 1)        # ManualSeed.__init__ (aldi/helpers.py:19-23)
         self.last = {}
+        self.pseudo_override = None
 
     # -- model(...) = ALDI.forward -> AlignMixin.forward -> GeneralizedRCNN.forward
     def model(self, data, labeled=True, do_align=False):
@@ -277,6 +278,11 @@ class OracleALDI:
         # pseudo_label_inplace (aldi/pseudolabeler.py:15-30): teacher eval inference; its roi_heads pre-hook re-seeds
         preds = d2.inference(self.cfg, self.teacher, teacher_inputs, roi_seed=self.seed)
         pls = [process_bbox(p, self.threshold) for p in preds]
+        self.last["pseudo_own"] = pls
+        if self.pseudo_override is not None:
+            # parity tests feed the device path's pseudo-labels ("identical inputs"): discrete sampling
+            # downstream is discontinuous in these coordinates, the oracle's own are compared separately
+            pls = self.pseudo_override.pop(0)
         for ti, si, pl in zip(teacher_inputs, student_inputs, pls):
             ti["instances"] = pl
             si["instances"] = pl

@@ -252,10 +252,39 @@ def stable_desc_order(scores):
     return torch.sort(scores, descending=True, stable=True)[1]
 
 
+def _clib():
+    """liboracle.so (oracle/roi_align.c) if it has been built (make -C oracle), else None -> pure torch paths."""
+    global _CLIB
+    if _CLIB is False:
+        import ctypes
+        import os
+        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_build", "liboracle.so")
+        _CLIB = ctypes.CDLL(path) if os.path.exists(path) else None
+    return _CLIB
+
+
+_CLIB = False
+
+
 def nms(boxes, scores, thresh) -> torch.Tensor:
     """torchvision.ops.nms semantics; kept indices in descending-score order.
+    IoU > thresh suppresses; IoU = inter/(a1+a2-inter)."""
+    n = boxes.shape[0]
+    if n == 0:
+        return torch.zeros(0, dtype=torch.int64)
+    lib = _clib()
+    if lib is not None:
+        import ctypes
+        order = stable_desc_order(scores)
+        b = boxes[order].contiguous().to(torch.float32)
+        keep = torch.empty(n, dtype=torch.uint8)
+        lib.oracle_nms_sorted(ctypes.c_void_p(b.data_ptr()), ctypes.c_int(n), ctypes.c_float(thresh), ctypes.c_void_p(keep.data_ptr()))
+        return order[keep.bool()]
+    return nms_torch(boxes, scores, thresh)
 
-    Blocked bitmask formulation: IoU > thresh suppresses; IoU = inter/(a1+a2-inter)."""
+
+def nms_torch(boxes, scores, thresh) -> torch.Tensor:
+    """Blocked pure-torch formulation of the same rule."""
     n = boxes.shape[0]
     if n == 0:
         return torch.zeros(0, dtype=torch.int64)
@@ -426,10 +455,44 @@ def find_top_rpn_proposals(cfg, anchors, logits_p, deltas_p, image_sizes, traini
 # ROI heads
 # ----------------------------------------------------------------------------
 
-def roi_align(feat, rois, out_size, scale):
-    """torchvision roi_align, aligned=True, sampling_ratio=0. feat (N,C,H,W); rois (R,5) [b,x1,y1,x2,y2].
+class _RoiAlignC(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, feat, rois, out_size, scale):
+        import ctypes
+        lib = _clib()
+        feat = feat.contiguous()
+        rois = rois.contiguous().to(torch.float32)
+        N, C, H, W = feat.shape
+        R = rois.shape[0]
+        out = torch.empty(R, C, out_size, out_size, dtype=torch.float32)
+        lib.oracle_roi_align_forward(ctypes.c_void_p(feat.data_ptr()), N, C, H, W, ctypes.c_void_p(rois.data_ptr()), R, out_size,
+                                     ctypes.c_float(scale), ctypes.c_void_p(out.data_ptr()))
+        ctx.save_for_backward(rois)
+        ctx.meta = (N, C, H, W, out_size, scale)
+        return out
 
-    Differentiable w.r.t. ``feat`` (gather + weighted sum)."""
+    @staticmethod
+    def backward(ctx, gout):
+        import ctypes
+        lib = _clib()
+        (rois,) = ctx.saved_tensors
+        N, C, H, W, P, scale = ctx.meta
+        gout = gout.contiguous()
+        gfeat = torch.zeros(N, C, H, W, dtype=torch.float32)
+        lib.oracle_roi_align_backward(ctypes.c_void_p(gout.data_ptr()), N, C, H, W, ctypes.c_void_p(rois.data_ptr()), rois.shape[0], P,
+                                      ctypes.c_float(scale), ctypes.c_void_p(gfeat.data_ptr()))
+        return gfeat, None, None, None
+
+
+def roi_align(feat, rois, out_size, scale):
+    """torchvision roi_align, aligned=True, sampling_ratio=0. feat (N,C,H,W); rois (R,5) [b,x1,y1,x2,y2]."""
+    if _clib() is not None and rois.shape[0] > 0 and feat.dtype == torch.float32:
+        return _RoiAlignC.apply(feat, rois, out_size, float(scale))
+    return roi_align_torch(feat, rois, out_size, scale)
+
+
+def roi_align_torch(feat, rois, out_size, scale):
+    """Pure-torch statement of the same algorithm; differentiable w.r.t. ``feat`` (gather + weighted sum)."""
     R = rois.shape[0]
     N, C, H, W = feat.shape
     P = out_size

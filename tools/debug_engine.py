@@ -33,8 +33,8 @@ wts.load_state_dict(sd)
 m = RCNN(wts, K)
 torch.manual_seed(123)
 scales = {k: 1.0 for k in ("loss_cls", "loss_box_reg", "loss_rpn_cls", "loss_rpn_loc")}
-c = m.forward_train([d["image"] for d in data], [d["instances"] for d in data], roi_seed=77, scales=scales)
-m.backward(c)
+c = m.forward_train([d["image"] for d in data], [d["instances"] for d in data], roi_seed=77)
+m.backward(c, scales)
 torch.cuda.synchronize()
 hl = {k: float(v) for k, v in m.loss_dict(c).items()}
 print("hip   ", {k: round(v, 5) for k, v in hl.items()}, "err flag", int(m.err))
