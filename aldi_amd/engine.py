@@ -187,6 +187,9 @@ class RCNN:
         self._anchor_cache: Dict[tuple, tuple] = {}
         self._ws: Dict[str, torch.Tensor] = {}
         self.err = torch.zeros(1, dtype=torch.int32, device=self.device)
+        # the host only runs tiny torch-CPU ops (RNG draws, index packing); on a many-core host the default
+        # intra-op thread pool makes torch.randperm(268k) ~20x slower than one thread
+        torch.set_num_threads(1)
         self.has_img_da = "img_align.model.0" in weights.layout.t
         self.has_ins_da = "ins_align.model.1" in weights.layout.t
 

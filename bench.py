@@ -1,0 +1,251 @@
+#!/usr/bin/env python
+"""images/sec of the full student+teacher ALDI step (R50-FPN, 1333x800, ALDI++ config) on N MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+One "step" = one ALDI iteration on one synthetic batch per GPU (2 labeled_strong + 2 unlabeled
+weak/strong pairs, inputs resident in HBM): EMA tick, source micro-step fwd+bwd, teacher
+inference + pseudo-labels, student distill micro-step fwd+bwd with the four soft losses, one
+gradient all-reduce (N>1), SGD.  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import copy
+import json
+import os
+import random
+import subprocess
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_BF16_TFLOPS = 2500.0      # dense MFMA bf16 peak, MI355X_MICROARCH.md
+# algorithmic conv/FC work of one cfg-2 step per GPU with the teacher trunk computed once (SURVEY.md 8d / BASELINE.md 4)
+STEP_TFLOP_FUSED = 5.49
+
+
+class FixedGpuLoader:
+    """Yields the same 4-tuple every step with the uint8 images already resident in HBM."""
+    def __init__(self, data, device):
+        self.data = []
+        for part in data:
+            if part is None:
+                self.data.append(None)
+            else:
+                self.data.append([{"image": d["image"].to(device), "instances": d["instances"]} for d in part])
+
+    def __iter__(self):
+        while True:
+            yield tuple(None if p is None else [dict(d) for d in p] for p in self.data)
+
+
+def make_cfg(world, height, width, align):
+    from aldi_amd.config import add_aldi_config, get_cfg
+    cfg = get_cfg()
+    add_aldi_config(cfg)
+    cfg.merge_from_file(os.path.join(ROOT, "configs", "cityscapes", "ALDI-Best-Cityscapes.yaml"))
+    # BASE_LR is lowered: with random-init weights the reference's 0.06 diverges to inf within a few steps (same work per step)
+    cfg.merge_from_list(["SOLVER.IMS_PER_BATCH", 4 * world, "SEED", 1, "SYNTHETIC.HEIGHT", height, "SYNTHETIC.WIDTH", width, "SOLVER.BASE_LR", 1e-4,
+                         "DOMAIN_ADAPT.ALIGN.IMG_DA_ENABLED", align, "DOMAIN_ADAPT.ALIGN.INS_DA_ENABLED", align])
+    return cfg
+
+
+def profile_dense(trainer, step_fn, table_path=None):
+    """Record every dense (MFMA) launch of one step, then replay each distinct shape back-to-back on the
+    launch stream between two HIP events (GPU-bound, so event time = sum of kernel durations).
+    -> per-family {launches, flops, ms} per step, plus a per-shape table."""
+    from aldi_amd import ops
+    rec = []
+    orig_conv, orig_wg = ops.conv2d, ops.conv_wgrad
+
+    def conv2d(x, w, **kw):
+        y = orig_conv(x, w, **kw)
+        N, H, W_, Cin = x.shape
+        Cout, KH, KW, _ = w.shape
+        s, p = kw.get("stride", 1), kw.get("pad", 0)
+        Ho, Wo = (H + 2 * p - KH) // s + 1, (W_ + 2 * p - KW) // s + 1
+        kw2 = dict(kw)
+        if kw2.get("want_f32"):
+            kw2["out_f32"] = y
+        else:
+            kw2["out"] = y
+        key = ("igemm", N, H, W_, Cin, Cout, KH, s, p, kw.get("res_mode", 0), bool(kw.get("relu")), kw.get("mask") is not None,
+               kw.get("out_scale", 1), bool(kw.get("want_f32")))
+        rec.append((key, 2.0 * N * Ho * Wo * Cout * KH * KW * Cin, lambda: orig_conv(x, w, **kw2)))
+        return y
+
+    def conv_wgrad(x, g, dw, **kw):
+        orig_wg(x, g, dw, **kw)
+        key = ("wgrad",) + tuple(x.shape) + (g.shape[3], kw["KH"], kw.get("stride", 1), kw.get("pad", 0))
+        rec.append((key, 2.0 * g.numel() * kw["KH"] * kw["KW"] * x.shape[3], lambda: orig_wg(x, g, dw, **kw)))
+    ops.conv2d, ops.conv_wgrad = conv2d, conv_wgrad
+    try:
+        step_fn()
+        torch.cuda.synchronize()
+    finally:
+        ops.conv2d, ops.conv_wgrad = orig_conv, orig_wg
+    shapes = {}
+    for key, fl, fn in rec:
+        e = shapes.setdefault(key, {"count": 0, "flops": fl, "fn": fn})
+        e["count"] += 1
+    REP = 5
+    for key, e in shapes.items():
+        e["fn"]()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(REP):
+            e["fn"]()
+        e1.record()
+        e1.synchronize()
+        e["us"] = e0.elapsed_time(e1) * 1e3 / REP
+    out = {}
+    for fam in ("igemm", "wgrad"):
+        sel = [e for k, e in shapes.items() if k[0] == fam]
+        out[fam] = {"launches": sum(e["count"] for e in sel), "flops": sum(e["count"] * e["flops"] for e in sel),
+                    "ms": sum(e["count"] * e["us"] for e in sel) / 1e3, "shapes": len(sel)}
+    if table_path:
+        os.makedirs(os.path.dirname(table_path), exist_ok=True)
+        with open(table_path, "w") as f:
+            f.write("# per-shape replay of the dense launches of one ALDI step (HIP events on the launch stream, %d reps)\n" % REP)
+            f.write("# family shape... | launches/step | us/launch | TFLOP/s | ms/step\n")
+            for key, e in sorted(shapes.items(), key=lambda kv: -kv[1]["count"] * kv[1]["us"]):
+                f.write("%-90s %4d %9.1f %8.1f %8.3f\n" % (str(key), e["count"], e["us"], e["flops"] / e["us"] / 1e6, e["count"] * e["us"] / 1e3))
+    for e in shapes.values():
+        e.pop("fn")
+    return out
+
+
+def cpu_baseline(cfg, height, width):
+    """The oracle (CPU restatement, reference schedule) on a bounded sample: 1 labeled + 1 unlabeled image, 1 step."""
+    from aldi_amd import synthetic as syn
+    from oracle import aldi_ops as ao
+    from oracle import d2_rcnn as d2
+    subprocess.call(["make", "-C", os.path.join(ROOT, "oracle")], stdout=subprocess.DEVNULL)
+    cores = min(os.cpu_count() or 1, 32)     # torch-CPU conv stops scaling (and oversubscribes) beyond ~32 threads on this workload
+    torch.set_num_threads(cores)
+    K = cfg.MODEL.ROI_HEADS.NUM_CLASSES
+    data = syn.make_batch(1, 1, height, width, K, seed=5)
+    orc = ao.OracleALDI(d2.make_cfg(num_classes=K), syn.init_state_dict(K, seed=1), ema_alpha=cfg.EMA.ALPHA, lr=1e-3, ims_per_gpu=1,
+                        backward_at_end=False, py_seed=0, threshold=cfg.DOMAIN_ADAPT.TEACHER.THRESHOLD)
+    torch.manual_seed(0)
+    t0 = time.perf_counter()
+    orc.step(*data)
+    dt = time.perf_counter() - t0
+    model = "?"
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    return {"value": round(2.0 / dt, 4), "unit": "images/sec", "cores": cores, "kind": "port", "cpu_model": model,
+            "sample": f"1 ALDI step of 1 labeled + 1 unlabeled {width}x{height} image, reference schedule "
+                      f"(teacher trunk twice, state-dict EMA), fp32 torch-CPU oracle, {dt:.1f}s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--height", type=int, default=800)
+    ap.add_argument("--width", type=int, default=1333)
+    ap.add_argument("--align", action="store_true", help="BASELINE config 3: image+instance alignment on")
+    ap.add_argument("--fp32", action="store_true", help="parity mode (not the benchmark dtype)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-profile", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    torch.cuda.set_device(local)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    dev = torch.device("cuda", local)
+
+    from aldi_amd import synthetic as syn
+    from aldi_amd.trainer import ALDITrainer
+    cfg = make_cfg(world, args.height, args.width, args.align)
+    if args.fp32:
+        cfg.SOLVER.AMP.ENABLED = False
+    random.seed(1234)
+    torch.manual_seed(100 + rank)
+    tr = ALDITrainer(cfg)
+    K = cfg.MODEL.ROI_HEADS.NUM_CLASSES
+    data = syn.make_batch(2, 2, args.height, args.width, K, seed=100 + rank)
+    tr._trainer.data_loader = FixedGpuLoader(data, dev)
+    tr._trainer._data_loader_iter_obj = None
+
+    def one_step():
+        tr.before_step()
+        tr.run_step()
+        tr.after_step()
+        tr.iter += 1
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    tr.iter = 0
+    for _ in range(args.warmup):
+        one_step()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        one_step()
+    sync()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t)
+    ms = dt / args.steps * 1e3
+    imgs_per_step = 4 * world
+    value = imgs_per_step * args.steps / dt
+    err = int(tr.model.engine.err) | int(tr.ema.model.engine.err)
+    losses = {k: float(v) for k, v in tr._trainer.last_loss_dict.items()}
+    pl_count = tr.ema.model._last_inference.pseudo["count"].tolist()
+
+    out = {"metric": "images/sec (student+teacher ALDI step), R50-FPN 1333x800", "value": round(value, 3), "unit": "images/sec",
+           "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True,
+           "scaling": "weak", "vs_baseline": None, "dtype": "fp32" if args.fp32 else "bf16", "data": "synthetic",
+           "config": {"workload": "configs[%d]: ALDI++ R50-FPN Cityscapes->Foggy-shaped synthetic %dx%d, teacher EMA + distill on, align %s, "
+                                  "2 labeled_strong + 2 unlabeled (weak+strong) images per GPU" % (2 if args.align else 1, args.width, args.height,
+                                                                                                   "on" if args.align else "off"),
+                      "global_batch": imgs_per_step, "parallelism": f"dp{world}", "pseudo_label_threshold": cfg.DOMAIN_ADAPT.TEACHER.THRESHOLD,
+                      "pseudo_labels_per_image": pl_count, "weights": "random-init R50-FPN (synthetic)", "error_flag": err},
+           "final_losses": {k: round(v, 5) for k, v in losses.items()}}
+    if rank == 0 and world == 1 and not args.no_profile:
+        prof = profile_dense(tr, one_step, os.path.join(ROOT, "gpurun_out", "dense_profile.txt"))
+        ig = prof["igemm"]
+        ach = ig["flops"] / (ig["ms"] * 1e-3) / 1e12 if ig["ms"] > 0 else 0.0
+        out["roofline"] = {"bound": "mfma", "kernel": "igemm_kernel<bf16> (conv fwd + dgrad + FC)", "achieved": round(ach, 2), "peak": PEAK_BF16_TFLOPS,
+                           "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": None,
+                           "launches_per_step": ig["launches"], "kernel_ms_per_step": round(ig["ms"], 3),
+                           "avg_launch_us": round(ig["ms"] * 1e3 / max(ig["launches"], 1), 2),
+                           "algorithmic_tflop_per_step_in_kernel": round(ig["flops"] / 1e12, 3),
+                           "wgrad_kernel": {"tflops": round(prof["wgrad"]["flops"] / max(prof["wgrad"]["ms"], 1e-9) / 1e9, 2),
+                                            "ms_per_step": round(prof["wgrad"]["ms"], 3), "launches": prof["wgrad"]["launches"]},
+                           "step_algorithmic_tflop": STEP_TFLOP_FUSED if not args.align else None,
+                           "step_frac_of_mfma_peak": round(STEP_TFLOP_FUSED / (ms * 1e-3) / PEAK_BF16_TFLOPS, 4) if not args.align else None}
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(cfg, args.height, args.width)
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
