@@ -338,12 +338,14 @@ extern "C" int aldi_sgd_step(float* p, const float* g, float* buf, void* p_compu
     return ALDI_OK;
 }
 
-extern "C" int aldi_ema_update(float* teacher, const float* student, void* teacher_compute, long n, float alpha, int copy_only, int dtype, aldi_stream_t stream) {
+extern "C" int aldi_ema_update(float* teacher, const float* student, void* teacher_compute, long n, double alpha, int copy_only, int dtype, aldi_stream_t stream) {
     if (!teacher || !student) return aldi_set_error_msg(ALDI_ERR_ARG, "ema_update: null pointer");
     hipStream_t st = static_cast<hipStream_t>(stream);
-    const float oma = (float)(1.0 - (double)alpha);   // python computes (1 - alpha) in double, then multiplies an fp32 tensor
-    if (dtype == ALDI_BF16) hipLaunchKernelGGL(ema_kernel<bf16_t>, dim3(nblocks(n)), dim3(256), 0, st, teacher, student, (bf16_t*)teacher_compute, n, oma, alpha, copy_only);
-    else hipLaunchKernelGGL(ema_kernel<float>, dim3(nblocks(n)), dim3(256), 0, st, teacher, student, (float*)nullptr, n, oma, alpha, copy_only);
+    // python computes (1 - alpha) in DOUBLE; torch then casts each scalar to fp32 for the fp32 tensor multiply
+    const float oma = (float)(1.0 - alpha);
+    const float alpha_f = (float)alpha;
+    if (dtype == ALDI_BF16) hipLaunchKernelGGL(ema_kernel<bf16_t>, dim3(nblocks(n)), dim3(256), 0, st, teacher, student, (bf16_t*)teacher_compute, n, oma, alpha_f, copy_only);
+    else hipLaunchKernelGGL(ema_kernel<float>, dim3(nblocks(n)), dim3(256), 0, st, teacher, student, (float*)nullptr, n, oma, alpha_f, copy_only);
     ALDI_CHECK_LAUNCH();
     return ALDI_OK;
 }

@@ -239,11 +239,13 @@ class OracleALDI:
         self.seed = self.rand.randint(0, 2 ** 32 - 1)        # ManualSeed.__init__ (aldi/helpers.py:19-23)
         self.last = {}
         self.pseudo_override = None
+        self.proposal_override = None
 
     # -- model(...) = ALDI.forward -> AlignMixin.forward -> GeneralizedRCNN.forward
     def model(self, data, labeled=True, do_align=False):
         cap = d2.Captured()
-        losses = d2.forward_train(self.cfg, self.sd, data, roi_seed=self.seed, cap=cap)
+        rp = self.proposal_override.pop(0) if self.proposal_override else None     # parity tests: identical inputs to the ROI stage
+        losses = d2.forward_train(self.cfg, self.sd, data, roi_seed=self.seed, cap=cap, replace_proposals=rp)
         a = self.align
         if a is not None:
             if do_align:                                                         # aldi/align.py:75-90
@@ -291,7 +293,7 @@ class OracleALDI:
         scap = self.last["student_cap"]
         tcap = d2.Captured()
         with torch.no_grad():                                                    # :160-162 teacher in train mode
-            d2.forward_train(self.cfg, self.teacher, teacher_inputs, replace_proposals=scap["proposals"],
+            d2.forward_train(self.cfg, self.teacher, teacher_inputs, replace_proposals=scap["proposals_used"],
                              roi_seed=self.seed, cap=tcap)
         losses = mask_hard_losses(hard, d["do_hard_cls"], d["do_hard_obj"], d["do_hard_rpn_reg"], d["do_hard_roi_reg"])
         labels = torch.stack(d2.label_and_sample_anchors(self.cfg, tcap["anchors"],

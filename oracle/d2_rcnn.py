@@ -684,6 +684,7 @@ def forward_train(cfg, sd, batched_inputs: List[dict], replace_proposals: Option
     pre-hook on roi_heads (aldi/helpers.py:17-26); ``replace_proposals`` the
     ReplaceProposalsOnce pre-hook (aldi/helpers.py:28-42)."""
     x, sizes = preprocess(cfg, [b["image"] for b in batched_inputs])
+    x = x.to(sd["backbone.bottom_up.stem.conv1.weight"].dtype)       # fp64 state_dict -> fp64 "truth" run (tests only)
     gts = [b["instances"] for b in batched_inputs]
     feats = resnet_fpn(cfg, sd, x)
     flist = [feats[k] for k in ("p2", "p3", "p4", "p5", "p6")]
@@ -700,6 +701,8 @@ def forward_train(cfg, sd, batched_inputs: List[dict], replace_proposals: Option
         torch.manual_seed(roi_seed)
     if replace_proposals is not None:
         proposals = replace_proposals
+    if cap is not None:
+        cap["proposals_used"] = proposals
     sampled = label_and_sample_proposals(cfg, proposals, gts)
     pooled = roi_pool(cfg, flist[:4], [s["proposal_boxes"] for s in sampled])
     bh = box_head(sd, pooled)

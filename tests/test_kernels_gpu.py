@@ -1,0 +1,446 @@
+"""HIP kernels (through the C ABI) vs the reference's golden vectors and vs the CPU oracle."""
+import math
+import os
+from collections import OrderedDict
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def T(a):
+    return torch.from_numpy(np.asarray(a))
+
+
+def nhwc(t):
+    return t.permute(0, 2, 3, 1).contiguous()
+
+
+# ------------------------------------------------------------------------------------------------
+# ALDI-owned losses vs the reference's own outputs (golden fixtures)
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("tag", ["r256k8", "r64k80", "nofg"])
+def test_roih_distill_vs_reference_golden(golden_dir, tag):
+    from aldi_amd import ops
+    g = np.load(os.path.join(golden_dir, "g2_roih_losses.npz"))
+    sl, tl, sd, td = (T(g[f"{tag}_{n}"]) for n in ("s_logits", "t_logits", "s_deltas", "t_deltas"))
+    R, K1 = sl.shape
+    K = K1 - 1
+    Cp = (5 * K + 1 + 15) // 16 * 16
+    sp = torch.zeros(R, Cp)
+    tp = torch.zeros(R, Cp)
+    sp[:, :K1], sp[:, K1:K1 + 4 * K] = sl, sd
+    tp[:, :K1], tp[:, K1:K1 + 4 * K] = tl, td
+    spd, tpd = sp.to(DEV), tp.to(DEV)
+    for lt in ("CE", "KL"):
+        for Tm in (1.0, 0.5):
+            loss = torch.zeros(2, device=DEV)
+            grad = torch.zeros(R, Cp, device=DEV)
+            ops.roih_distill_loss(spd, tpd, Cp, K, R, Tm, lt == "KL", True, True, 1.0, grad, loss)
+            key = f"{tag}_{lt}_T{Tm}"
+            assert abs(float(loss[0]) - float(g[key + "_loss_cls_ce"])) < 2e-5 * max(1.0, abs(float(g[key + "_loss_cls_ce"])))
+            assert abs(float(loss[1]) - float(g[key + "_loss_roih_l1"])) < 2e-5 * max(1.0, abs(float(g[key + "_loss_roih_l1"])))
+            gc = grad.cpu()
+            np.testing.assert_allclose(gc[:, :K1].numpy(), g[key + "_dlogits"], rtol=1e-4, atol=2e-7)
+            np.testing.assert_allclose(gc[:, K1:K1 + 4 * K].numpy(), g[key + "_ddeltas"], rtol=1e-5, atol=1e-8)
+            assert float(gc[:, K1 + 4 * K:].abs().max()) == 0.0 if Cp > K1 + 4 * K else True
+
+
+@pytest.mark.parametrize("tag", ["mix", "zerofg"])
+def test_rpn_distill_index_quirk_vs_reference_golden(golden_dir, tag):
+    """The mask built in (N, sumA) order is applied to the level-major RAW (N,A,H,W) flattening."""
+    from aldi_amd import ops
+    g = np.load(os.path.join(golden_dir, "g3_rpn_losses.npz"))
+    shapes = [tuple(int(v) for v in s) for s in g["shapes"]]
+    A, N, C = 3, 2, 16
+    geom = ops.make_geom(shapes, A, C)
+
+    def pack(lo, de):
+        out = []
+        for l, (h, w) in enumerate(shapes):
+            t = torch.zeros(N, h, w, C)
+            t[..., :A] = T(lo[l]).permute(0, 2, 3, 1)
+            t[..., A:5 * A] = T(de[l]).permute(0, 2, 3, 1)
+            out.append(t.to(DEV))
+        return out
+    nl = len(shapes)
+    s_head = pack([g[f"{tag}_s_logits{l}"] for l in range(nl)], [g[f"{tag}_s_deltas{l}"] for l in range(nl)])
+    t_head = pack([g[f"{tag}_t_logits{l}"] for l in range(nl)], [g[f"{tag}_t_deltas{l}"] for l in range(nl)])
+    labels = T(g[f"{tag}_labels"]).to(torch.int32)
+    n_valid, n_fg = int((labels >= 0).sum()), int((labels == 1).sum())
+    ld = labels.to(DEV)
+    for Tm in (1.0, 0.5):
+        grads = [torch.zeros_like(h) for h in s_head]
+        loss = torch.zeros(2, device=DEV)
+        ops.rpn_distill_loss(geom, s_head, t_head, grads, ld, N, Tm, n_valid, n_fg, True, True, 1.0, loss)
+        key = f"{tag}_T{Tm}"
+        assert abs(float(loss[0]) - float(g[key + "_loss_obj_bce"])) < 2e-6 * max(1.0, float(g[key + "_loss_obj_bce"]))
+        assert abs(float(loss[1]) - float(g[key + "_loss_rpn_l1"])) < 2e-6 * max(1.0, float(g[key + "_loss_rpn_l1"]))
+        for l in range(nl):
+            gl = grads[l].cpu()
+            np.testing.assert_allclose(gl[..., :A].permute(0, 3, 1, 2).numpy(), g[f"{key}_dlogits{l}"], rtol=1e-4, atol=1e-8)
+            np.testing.assert_allclose(gl[..., A:5 * A].permute(0, 3, 1, 2).numpy(), g[f"{key}_ddeltas{l}"], rtol=1e-5, atol=1e-9)
+
+
+def test_discriminators_grl_bce_vs_reference_golden(golden_dir):
+    """ConvDiscriminator / FCDiscriminator + gradient reversal + domain BCE, fwd and bwd (aldi/align.py:76-135)."""
+    from aldi_amd import ops
+    g = np.load(os.path.join(golden_dir, "g1_discriminators.npz"))
+    f32 = torch.float32
+
+    def pad_rows(w, rows=8):
+        out = torch.zeros((rows,) + tuple(w.shape[1:]))
+        out[: w.shape[0]] = w
+        return out
+    for labeled in (1, 0):
+        # ---- conv discriminator
+        x = nhwc(T(g["conv_x"])).to(DEV)
+        w1 = T(g["conv_sd.model.0.weight"]).permute(0, 2, 3, 1).contiguous().to(DEV)
+        b1 = T(g["conv_sd.model.0.bias"]).to(DEV)
+        w2 = pad_rows(T(g["conv_sd.model.4.weight"])).view(8, 1, 1, -1).contiguous().to(DEV)
+        b2 = pad_rows(T(g["conv_sd.model.4.bias"])).to(DEV)
+        a1 = ops.conv2d(x, w1, shift=b1, relu=True)
+        pooled = ops.avgpool(a1)
+        logit = ops.conv2d(pooled, w2, shift=b2, want_f32=True)
+        np.testing.assert_allclose(logit.view(-1, 8)[:, :1].cpu().numpy(), g["conv_preds"], rtol=1e-5, atol=1e-6)
+        loss = torch.zeros(1, device=DEV)
+        glog = torch.empty(logit.shape, dtype=f32, device=DEV)
+        ops.domain_bce(logit, 8, x.shape[0], float(labeled), 0.01, 1.0, glog, loss)
+        assert abs(float(loss) - float(g[f"conv_loss_l{labeled}"])) < 1e-7
+        dw2 = torch.zeros_like(w2)
+        ops.conv_wgrad(pooled, glog, dw2, KH=1, KW=1)
+        np.testing.assert_allclose(dw2.view(8, -1)[:1].cpu().numpy(), g[f"conv_grad_l{labeled}.model.4.weight"], rtol=1e-4, atol=1e-9)
+        g_pooled = ops.conv2d(glog, ops.dgrad_weights(w2, None, f32))
+        g_a1 = ops.avgpool_bwd(g_pooled, a1)
+        dw1 = torch.zeros_like(w1)
+        ops.conv_wgrad(x, g_a1, dw1, KH=3, KW=3)
+        np.testing.assert_allclose(dw1.cpu().permute(0, 3, 1, 2).numpy(), g[f"conv_grad_l{labeled}.model.0.weight"], rtol=2e-4, atol=1e-9)
+        db1 = torch.zeros_like(b1)
+        ops.bias_grad(g_a1, db1)
+        np.testing.assert_allclose(db1.cpu().numpy(), g[f"conv_grad_l{labeled}.model.0.bias"], rtol=2e-4, atol=1e-9)
+        neg = torch.full((w1.shape[0],), -1.0, device=DEV)
+        dx = ops.conv2d(g_a1, ops.dgrad_weights(w1, neg, f32), pad=2)       # gradient reversal folded into the dgrad weights
+        np.testing.assert_allclose(dx.cpu().permute(0, 3, 1, 2).numpy(), g[f"conv_dx_l{labeled}"], rtol=2e-4, atol=1e-10)
+        # ---- fc discriminator
+        xf = T(g["fc_x"]).view(-1, 1, 1, 64).contiguous().to(DEV)
+        v1 = T(g["fc_sd.model.1.weight"]).view(64, 1, 1, 64).contiguous().to(DEV)
+        c1 = T(g["fc_sd.model.1.bias"]).to(DEV)
+        v2 = pad_rows(T(g["fc_sd.model.3.weight"])).view(8, 1, 1, 64).contiguous().to(DEV)
+        c2 = pad_rows(T(g["fc_sd.model.3.bias"])).to(DEV)
+        h = ops.conv2d(xf, v1, shift=c1, relu=True)
+        logit = ops.conv2d(h, v2, shift=c2, want_f32=True)
+        np.testing.assert_allclose(logit.view(-1, 8)[:, :1].cpu().numpy(), g["fc_preds"], rtol=1e-5, atol=1e-6)
+        loss = torch.zeros(1, device=DEV)
+        glog = torch.empty(logit.shape, dtype=f32, device=DEV)
+        ops.domain_bce(logit, 8, xf.shape[0], float(labeled), 0.01, 1.0, glog, loss)
+        assert abs(float(loss) - float(g[f"fc_loss_l{labeled}"])) < 1e-7
+        g_h = ops.conv2d(glog, ops.dgrad_weights(v2, None, f32), mask=h)
+        dv1 = torch.zeros_like(v1)
+        ops.conv_wgrad(xf, g_h, dv1, KH=1, KW=1)
+        np.testing.assert_allclose(dv1.view(64, 64).cpu().numpy(), g[f"fc_grad_l{labeled}.model.1.weight"], rtol=2e-4, atol=1e-10)
+        neg = torch.full((64,), -1.0, device=DEV)
+        dxf = ops.conv2d(g_h, ops.dgrad_weights(v1, neg, f32))
+        np.testing.assert_allclose(dxf.view(-1, 64).cpu().numpy(), g[f"fc_dx_l{labeled}"], rtol=2e-4, atol=1e-10)
+
+
+def test_ema_bit_exact_vs_reference_golden(golden_dir):
+    from aldi_amd import ops
+    g = np.load(os.path.join(golden_dir, "g5_ema.npz"))
+    keys = [k[3:] for k in g.files if k.startswith("t0.") and g[k].dtype == np.float32]
+    t0 = torch.cat([T(g["t0." + k]).reshape(-1) for k in keys]).to(DEV)
+    s = torch.cat([T(g["s." + k]).reshape(-1) for k in keys]).to(DEV)
+    exp = torch.cat([T(g["t_after_ema." + k]).reshape(-1) for k in keys if "query_embed" not in k])
+    sel = torch.cat([torch.full((g["t0." + k].size,), "query_embed" not in k) for k in keys])
+    ops.ema_update(t0, s, None, t0.numel(), float(g["alpha"]), False, torch.float32)
+    assert torch.equal(t0.cpu()[sel], exp)                                   # bit-exact lerp
+    ops.ema_update(t0, s, None, t0.numel(), float(g["alpha"]), True, torch.float32)
+    assert torch.equal(t0.cpu(), s.cpu())                                    # iter <= start_iter: copy
+
+
+def test_sgd_vs_torch_optim():
+    from aldi_amd import ops
+    g = torch.Generator().manual_seed(0)
+    p0 = torch.randn(10000, generator=g)
+    p = torch.nn.Parameter(p0.clone())
+    opt = torch.optim.SGD([p], lr=0.05, momentum=0.9, weight_decay=1e-4)
+    pd, buf = p0.to(DEV), torch.zeros(10000, device=DEV)
+    pc = torch.zeros(10000, dtype=torch.bfloat16, device=DEV)
+    for it in range(3):
+        gr = torch.randn(10000, generator=g)
+        p.grad = gr.clone()
+        opt.step()
+        ops.sgd_step(pd, gr.to(DEV), buf, pc, 10000, 0.05, 0.9, 1e-4, 1.0, it == 0, torch.bfloat16)
+    assert (pd.cpu() - p.detach()).abs().max() < 1e-6
+    assert torch.equal(pc.cpu(), pd.cpu().to(torch.bfloat16))
+
+
+# ------------------------------------------------------------------------------------------------
+# Detectron2-side kernels vs the CPU oracle
+# ------------------------------------------------------------------------------------------------
+def test_stem_and_pool_vs_oracle():
+    from aldi_amd import ops, synthetic as syn
+    from oracle import d2_rcnn as d2
+    sd = syn.init_state_dict(8, seed=2)
+    cfg = d2.make_cfg(num_classes=8)
+    g = torch.Generator().manual_seed(1)
+    imgs = [torch.randint(0, 256, (3, 75, 100), generator=g, dtype=torch.uint8), torch.randint(0, 256, (3, 96, 90), generator=g, dtype=torch.uint8)]
+    x, sizes = d2.preprocess(cfg, imgs)
+    p = "backbone.bottom_up.stem.conv1"
+    ref = F.max_pool2d(F.relu(d2.conv_bn(x, sd, p, 2, 3)), 3, 2, 1)
+    st = torch.zeros(2, 3, x.shape[2], x.shape[3], dtype=torch.uint8)
+    for i, im in enumerate(imgs):
+        st[i, :, : im.shape[1], : im.shape[2]] = im
+    scale = sd[p + ".norm.weight"] * (sd[p + ".norm.running_var"] + 1e-5).rsqrt()
+    shift = sd[p + ".norm.bias"] - sd[p + ".norm.running_mean"] * scale
+    w = sd[p + ".weight"].permute(0, 2, 3, 1).contiguous()
+    y = ops.stem_forward(st.to(DEV), sizes, w.to(DEV), scale.to(DEV), shift.to(DEV), cfg["pixel_mean"], cfg["pixel_std"], torch.float32)
+    y = ops.maxpool3s2(y)
+    torch.cuda.synchronize()
+    assert (y.cpu().permute(0, 3, 1, 2) - ref).abs().max() < 2e-5 * ref.abs().max()
+
+
+def _rand_boxes(n, w, h, g, lo=4.0, hi=120.0):
+    x1 = torch.rand(n, generator=g) * (w - lo)
+    y1 = torch.rand(n, generator=g) * (h - lo)
+    bw = lo + torch.rand(n, generator=g) * (hi - lo)
+    bh = lo + torch.rand(n, generator=g) * (hi - lo)
+    return torch.stack([x1, y1, (x1 + bw).clamp(max=w), (y1 + bh).clamp(max=h)], 1)
+
+
+@pytest.mark.parametrize("empty_gt", [False, True])
+def test_matcher_and_sampling_lists_bit_exact(empty_gt):
+    from aldi_amd import ops
+    from aldi_amd.engine import GMAX, make_anchors
+    from oracle import d2_rcnn as d2
+    shapes = [(40, 52), (20, 26), (10, 13), (5, 7), (3, 4)]
+    anchors = make_anchors(shapes, DEV)
+    cfg = d2.make_cfg(num_classes=8)
+    oa = d2.generate_anchors(cfg, shapes)
+    assert torch.equal(torch.cat(oa), anchors.cpu())                         # anchors bit-identical
+    g = torch.Generator().manual_seed(3)
+    N, sumA = 2, anchors.shape[0]
+    gts = [_rand_boxes(7, 208, 160, g), torch.zeros(0, 4) if empty_gt else _rand_boxes(3, 208, 160, g)]
+    gts[0][1] = torch.cat(oa)[1234]                                           # an exact-anchor GT (IoU == 1) and a degenerate far-away GT
+    gts[0][2] = torch.tensor([5000.0, 5000.0, 5010.0, 5010.0])
+    gb = torch.zeros(N, GMAX, 4)
+    cnt = torch.zeros(N, dtype=torch.int32)
+    for i, b in enumerate(gts):
+        gb[i, : len(b)] = b
+        cnt[i] = len(b)
+    best_iou = torch.empty(N, sumA, device=DEV)
+    best_idx = torch.empty(N, sumA, dtype=torch.int32, device=DEV)
+    labels = torch.empty(N, sumA, dtype=torch.int32, device=DEV)
+    scratch = torch.empty(N, GMAX, dtype=torch.int32, device=DEV)
+    ops.box_match(anchors, 0, None, sumA, gb.to(DEV), cnt.to(DEV), GMAX, N, 0.3, 0.7, True, best_iou, best_idx, scratch, labels)
+    lists = torch.empty(N, 2, sumA, dtype=torch.int32, device=DEV)
+    counts = torch.empty(N, 2, dtype=torch.int32, device=DEV)
+    ops.compact_labels(labels, sumA, N, 0, lists, counts)
+    for n in range(N):
+        mqm = d2.pairwise_iou(gts[n], torch.cat(oa))
+        midx, lab = d2.matcher(mqm, cfg["rpn_iou_thresholds"], [0, -1, 1], True)
+        assert torch.equal(labels[n].cpu(), lab.to(torch.int32))
+        if len(gts[n]):
+            assert torch.equal(best_idx[n].cpu(), midx.to(torch.int32))
+        pos = torch.nonzero(lab == 1).squeeze(1).to(torch.int32)
+        neg = torch.nonzero(lab == 0).squeeze(1).to(torch.int32)
+        c = counts[n].tolist()
+        assert c == [len(pos), len(neg)]
+        assert torch.equal(lists[n, 0, : c[0]].cpu(), pos) and torch.equal(lists[n, 1, : c[1]].cpu(), neg)
+    # the degenerate GT (zero IoU with every anchor) labels everything positive in Detectron2's low-quality rule
+    assert int((labels[0] == 1).sum()) == sumA
+
+
+@pytest.mark.parametrize("quantize", [False, True])
+def test_rpn_proposals_bit_exact_vs_oracle(quantize):
+    """top-k -> decode -> clip -> drop empty -> batched NMS -> top-k: identical ORDER and boxes; quantised logits force score ties."""
+    from aldi_amd import ops
+    from aldi_amd.engine import make_anchors
+    from oracle import d2_rcnn as d2
+    shapes = [(48, 64), (24, 32), (12, 16), (6, 8), (3, 4)]
+    N, A, C = 2, 3, 16
+    cfg = d2.make_cfg(num_classes=8)
+    anchors = make_anchors(shapes, DEV)
+    oa = d2.generate_anchors(cfg, shapes)
+    g = torch.Generator().manual_seed(5)
+    heads, lo, de = [], [], []
+    for (h, w) in shapes:
+        t = torch.randn(N, h, w, C, generator=g)
+        t[..., A:] *= 0.5
+        if quantize:
+            t[..., :A] = (t[..., :A] * 2).round() / 2
+        heads.append(t.to(DEV))
+        lo.append(t[..., :A].reshape(N, -1))                                  # (N, HWA)
+        de.append(t[..., A:5 * A].reshape(N, h * w * A, 4))
+    sizes = [(180, 250), (192, 256)]
+    geom = ops.make_geom(shapes, A, C)
+    hw = torch.tensor(sizes, dtype=torch.int32, device=DEV)
+    for training, pre, post in ((True, 2000, 1000), (False, 1000, 1000)):
+        ws = torch.empty(ops.rpn_proposals_workspace(N, 5), dtype=torch.uint8, device=DEV)
+        boxes = torch.empty(N, post, 4, device=DEV)
+        scores = torch.empty(N, post, device=DEV)
+        count = torch.empty(N, dtype=torch.int32, device=DEV)
+        err = torch.zeros(1, dtype=torch.int32, device=DEV)
+        ops.rpn_proposals(geom, heads, anchors, hw, N, pre, post, 0.7, ws, boxes, scores, count, err)
+        ref = d2.find_top_rpn_proposals(cfg, oa, lo, de, sizes, training)
+        assert int(err) == 0
+        for n in range(N):
+            k = int(count[n])
+            assert k == len(ref[n]["proposal_boxes"])
+            assert torch.equal(scores[n, :k].cpu(), ref[n]["objectness_logits"])
+            assert (boxes[n, :k].cpu() - ref[n]["proposal_boxes"]).abs().max() < 1e-3      # expf/ulps only; the ORDER is exact
+            # size-independent properties: sorted by score, inside the image, non-empty
+            assert bool((scores[n, 1:k] <= scores[n, : k - 1]).all())
+            b = boxes[n, :k]
+            assert bool((b[:, 0] >= 0).all() and (b[:, 2] <= sizes[n][1]).all() and (b[:, 3] <= sizes[n][0]).all())
+            assert bool(((b[:, 2] - b[:, 0]) > 0).all() and ((b[:, 3] - b[:, 1]) > 0).all())
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-5), (torch.bfloat16, 1e-2)])
+def test_roialign_fwd_bwd_vs_oracle(dtype, tol):
+    from aldi_amd import ops
+    from oracle import d2_rcnn as d2
+    g = torch.Generator().manual_seed(7)
+    N, C = 2, 256
+    shapes = [(112, 160), (56, 80), (28, 40), (14, 20)]
+    feats = [torch.randn(N, C, h, w, generator=g) for h, w in shapes]
+    if dtype == torch.bfloat16:
+        feats = [f.to(dtype).float() for f in feats]
+    boxes = torch.cat([_rand_boxes(30, 640, 448, g, lo=2.0, hi=100.0), _rand_boxes(30, 640, 448, g, lo=100.0, hi=640.0)])   # all four levels
+    boxes[0] = torch.tensor([-20.0, -10.0, 30.0, 25.0])                       # partially outside
+    boxes[1] = torch.tensor([600.0, 400.0, 700.0, 500.0])
+    bidx = torch.randint(0, N, (60,), generator=g)
+    per_img = [boxes[bidx == i] for i in range(N)]
+    cfg = d2.make_cfg(num_classes=8)
+    fr = [f.clone().requires_grad_(True) for f in feats]
+    ref = d2.roi_pool(cfg, fr, per_img)
+    go = torch.randn(ref.shape, generator=g)
+    ref.backward(go)
+    rois = torch.cat([torch.cat([torch.full((len(b), 1), float(i)), b], 1) for i, b in enumerate(per_img)]).contiguous().to(DEV)
+    fd = [nhwc(f).to(DEV, dtype) for f in feats]
+    grads = [torch.zeros(f.shape, dtype=torch.float32, device=DEV) for f in fd]
+    R = rois.shape[0]
+    pooled = torch.empty(R, 7, 7, C, dtype=dtype, device=DEV)
+    ops.roialign(ops.make_roi_feats(fd, None, [1 / 4, 1 / 8, 1 / 16, 1 / 32]), rois, R, 7, pooled, backward=False)
+    assert (pooled.float().cpu().permute(0, 3, 1, 2) - ref.detach()).abs().max() < tol * 10
+    gd = nhwc(go).to(DEV, dtype)
+    ops.roialign(ops.make_roi_feats(fd, grads, [1 / 4, 1 / 8, 1 / 16, 1 / 32]), rois, R, 7, gd, backward=True)
+    assert sorted(set(d2.assign_levels(torch.cat(per_img)).tolist())) == [0, 1, 2, 3]
+    for l in range(4):
+        e = (grads[l].cpu().permute(0, 3, 1, 2) - fr[l].grad).abs().max()
+        assert e < tol * 30 * max(1.0, float(fr[l].grad.abs().max())), (l, float(e))
+    # property: pooling a constant map returns the constant wherever the ROI lies inside the map
+    const = [torch.full(f.shape, 3.0, dtype=dtype, device=DEV) for f in fd]
+    inside = ((rois[:, 1] >= 0) & (rois[:, 2] >= 0) & (rois[:, 3] <= 640) & (rois[:, 4] <= 448)).nonzero().squeeze(1)
+    rin = rois[inside].contiguous()
+    pin = torch.empty(len(inside), 7, 7, C, dtype=dtype, device=DEV)
+    ops.roialign(ops.make_roi_feats(const, None, [1 / 4, 1 / 8, 1 / 16, 1 / 32]), rin, len(inside), 7, pin, backward=False)
+    assert len(inside) >= 50 and float((pin.float() - 3.0).abs().max()) < 1e-5
+
+
+def test_rpn_and_box_losses_vs_oracle():
+    from aldi_amd import ops
+    from aldi_amd.engine import GMAX, ROI_WEIGHTS, make_anchors
+    from oracle import d2_rcnn as d2
+    g = torch.Generator().manual_seed(9)
+    cfg = d2.make_cfg(num_classes=8)
+    shapes = [(24, 32), (12, 16), (6, 8), (3, 4), (2, 2)]
+    N, A, C = 2, 3, 16
+    anchors = make_anchors(shapes, DEV)
+    oa = d2.generate_anchors(cfg, shapes)
+    sumA = anchors.shape[0]
+    heads = [torch.randn(N, h, w, C, generator=g) for h, w in shapes]
+    lo = [t[..., :A].reshape(N, -1).clone().requires_grad_(True) for t in heads]
+    de = [t[..., A:5 * A].reshape(N, -1, 4).clone().requires_grad_(True) for t in heads]
+    gts = [_rand_boxes(4, 128, 96, g, lo=10, hi=80), _rand_boxes(2, 128, 96, g, lo=10, hi=80)]
+    labels = torch.full((N, sumA), -1, dtype=torch.int32)
+    matched = torch.zeros(N, sumA, dtype=torch.int32)
+    mgt = []
+    for n in range(N):
+        mqm = d2.pairwise_iou(gts[n], torch.cat(oa))
+        midx, lab = d2.matcher(mqm, cfg["rpn_iou_thresholds"], [0, -1, 1], True)
+        pos = torch.nonzero(lab == 1).squeeze(1)[:40]
+        neg = torch.nonzero(lab == 0).squeeze(1)[::7][:100]
+        labels[n, pos], labels[n, neg] = 1, 0
+        matched[n] = midx.to(torch.int32)
+        mgt.append(gts[n][midx])
+    ref = d2.rpn_losses(cfg, oa, lo, de, [labels[n].to(torch.int8) for n in range(N)], mgt)
+    (2.0 * ref["loss_rpn_cls"] + 0.5 * ref["loss_rpn_loc"]).backward()
+    gb = torch.zeros(N, GMAX, 4)
+    cnt = torch.zeros(N, dtype=torch.int32)
+    for i, b in enumerate(gts):
+        gb[i, : len(b)], cnt[i] = b, len(b)
+    hd = [t.to(DEV) for t in heads]
+    gr = [torch.zeros_like(t) for t in hd]
+    loss = torch.zeros(2, device=DEV)
+    ops.rpn_loss(ops.make_geom(shapes, A, C), hd, gr, anchors, labels.to(DEV), matched.to(DEV), gb.to(DEV), cnt.to(DEV), GMAX, N,
+                 1.0 / (256 * N), 2.0, 0.5, loss)
+    assert abs(float(loss[0]) - float(ref["loss_rpn_cls"])) < 1e-5 and abs(float(loss[1]) - float(ref["loss_rpn_loc"])) < 1e-5
+    for l, (h, w) in enumerate(shapes):
+        gl = gr[l].cpu()
+        assert (gl[..., :A].reshape(N, -1) - lo[l].grad).abs().max() < 1e-7
+        assert (gl[..., A:5 * A].reshape(N, -1, 4) - de[l].grad).abs().max() < 1e-7
+    # ---- box losses
+    K, R = 8, 300
+    Cp = 48
+    pred = torch.randn(R, Cp, generator=g)
+    scores = pred[:, : K + 1].clone().requires_grad_(True)
+    deltas = pred[:, K + 1: K + 1 + 4 * K].clone().requires_grad_(True)
+    pb = _rand_boxes(R, 300, 200, g)
+    gtb = _rand_boxes(R, 300, 200, g)
+    cls = torch.randint(0, K + 1, (R,), generator=g)
+    sampled = [{"gt_classes": cls, "proposal_boxes": pb, "gt_boxes": gtb}]
+    refb = d2.roi_losses(cfg, scores, deltas, sampled)
+    (refb["loss_cls"] * 0.5 + refb["loss_box_reg"] * 3.0).backward()
+    rois = torch.cat([torch.zeros(R, 1), pb], 1).contiguous().to(DEV)
+    grad = torch.zeros(R, Cp, device=DEV)
+    loss = torch.zeros(2, device=DEV)
+    ops.box_loss(pred.to(DEV), Cp, K, R, rois, cls.to(torch.int32).to(DEV), gtb.to(DEV), ROI_WEIGHTS, 0.5, 3.0, grad, loss)
+    assert abs(float(loss[0]) - float(refb["loss_cls"])) < 2e-6 * float(refb["loss_cls"]) + 1e-6
+    assert abs(float(loss[1]) - float(refb["loss_box_reg"])) < 2e-5 * float(refb["loss_box_reg"]) + 1e-6
+    assert (grad[:, : K + 1].cpu() - scores.grad).abs().max() < 1e-7
+    assert (grad[:, K + 1: K + 1 + 4 * K].cpu() - deltas.grad).abs().max() < 1e-7
+
+
+def test_detections_and_pseudolabel_filter_vs_oracle():
+    from aldi_amd import ops
+    from aldi_amd.engine import ROI_WEIGHTS
+    from oracle import aldi_ops as ao
+    from oracle import d2_rcnn as d2
+    g = torch.Generator().manual_seed(11)
+    cfg = d2.make_cfg(num_classes=8)
+    K, Cp, N, P = 8, 48, 2, 1000
+    sizes = [(200, 300), (190, 280)]
+    props = torch.stack([_rand_boxes(P, 300, 200, g, lo=8, hi=150) for _ in range(N)])
+    pcount = torch.tensor([1000, 640], dtype=torch.int32)
+    pred = torch.randn(N * P, Cp, generator=g)
+    pred[:, : K + 1] *= 3.0
+    pred[:, K + 1:] *= 0.5
+    proposals = [{"proposal_boxes": props[n, : int(pcount[n])], "image_size": sizes[n]} for n in range(N)]
+    sel = torch.cat([torch.arange(n * P, n * P + int(pcount[n])) for n in range(N)])
+    ref = d2.fast_rcnn_inference(cfg, pred[sel, : K + 1], pred[sel, K + 1: K + 1 + 4 * K], proposals)
+    ws = torch.empty(ops.detections_workspace(N), dtype=torch.uint8, device=DEV)
+    out = {k: torch.empty((N, 100) + s, dtype=d, device=DEV) for k, s, d in (("db", (4,), torch.float32), ("ds", (), torch.float32), ("dc", (), torch.int32),
+                                                                            ("pb", (4,), torch.float32), ("pc", (), torch.int32), ("ps", (), torch.float32))}
+    dcount = torch.empty(N, dtype=torch.int32, device=DEV)
+    pl_count = torch.empty(N, dtype=torch.int32, device=DEV)
+    err = torch.zeros(1, dtype=torch.int32, device=DEV)
+    thr = 0.995
+    ops.detections(pred.to(DEV), Cp, K, props.to(DEV), pcount.to(DEV), P, N, torch.tensor(sizes, dtype=torch.int32, device=DEV), ROI_WEIGHTS,
+                   0.05, 0.5, 100, thr, ws, out["db"], out["ds"], out["dc"], dcount, out["pb"], out["pc"], out["ps"], pl_count, err)
+    assert int(err) == 0
+    for n in range(N):
+        k = int(dcount[n])
+        assert k == len(ref[n]["scores"]) == 100
+        assert (out["ds"][n, :k].cpu() - ref[n]["scores"]).abs().max() < 1e-6
+        assert torch.equal(out["dc"][n, :k].cpu().long(), ref[n]["pred_classes"])
+        assert (out["db"][n, :k].cpu() - ref[n]["pred_boxes"]).abs().max() < 1e-3
+        pl = ao.process_bbox(ref[n], thr)
+        m = int(pl_count[n])
+        assert m == len(pl["scores"]) and 0 < m < 100
+        assert torch.equal(out["pc"][n, :m].cpu().long(), pl["gt_classes"])
+        assert (out["pb"][n, :m].cpu() - pl["gt_boxes"]).abs().max() < 1e-3
+        assert bool((out["ps"][n, :m] > thr).all())
