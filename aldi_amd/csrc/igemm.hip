@@ -236,6 +236,10 @@ template <typename T>
 int dispatch(const ConvDev& d, hipStream_t st) {
     if (d.Cout <= 16) return launch<T, 128, 16, 4, 1>(d, st);
     if (d.Cout <= 64) return launch<T, 128, 64, 4, 1>(d, st);
+    // the N=2 micro-batch leaves the deep layers (res4/res5, FC heads) with far fewer 128x128 tiles than the
+    // 256 CUs: fall back to 64x64 tiles (4x the workgroups) when the big tiling cannot fill the chip
+    const long big = (long)cdiv(d.M, 128) * cdiv(d.Cout, 128);
+    if (big < 200) return launch<T, 64, 64, 2, 2>(d, st);
     return launch<T, 128, 128, 2, 2>(d, st);
 }
 

@@ -75,8 +75,8 @@ __global__ __launch_bounds__(256) void wgrad_bf16_kernel(WgDev p) {
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
     const int fr = lane & 15, fq = lane >> 4;
 
-    for (int p0 = pbeg; p0 < pend; p0 += BP) {
-        uint4 in[8], out[8];
+    uint4 in[8], out[8];
+    auto load_slab = [&](int p0) {
         int pp = p0 + pg * 8;
         int n = 0, ho = 0, wo = 0;
         if (isB && !p.ident) {
@@ -101,6 +101,9 @@ __global__ __launch_bounds__(256) void wgrad_bf16_kernel(WgDev p) {
             in[r] = v;
             if (++wo == p.Wo) { wo = 0; if (++ho == p.Ho) { ho = 0; ++n; } }
         }
+    };
+    if (pbeg < pend) load_slab(pbeg);
+    for (int p0 = pbeg; p0 < pend; p0 += BP) {
         transpose8x8_b16(in, out);
         __syncthreads();   // previous slab's fragment reads are done
 #pragma unroll
@@ -108,6 +111,7 @@ __global__ __launch_bounds__(256) void wgrad_bf16_kernel(WgDev p) {
             int row = cc * 8 + c;
             lds[((isB ? 128 : 0) + row) * 8 + swz8(row, pg)] = out[c];
         }
+        if (p0 + BP < pend) load_slab(p0 + BP);   // next slab's global loads fly under this slab's MFMAs
         __syncthreads();
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
@@ -256,8 +260,8 @@ extern "C" int aldi_conv_wgrad(const aldi_wgrad_args* a, aldi_stream_t stream) {
     const int bp = a->dtype == ALDI_BF16 ? 64 : 16;
     int tiles = cdiv(d.Cout, tile) * cdiv(d.K, tile);
     int slabs = cdiv(d.M, bp);
-    int splits = cdiv(2048, tiles);
-    if (splits > slabs / 2) splits = slabs / 2;
+    int splits = cdiv(768, tiles);                 // ~3 workgroups per CU in flight ...
+    if (splits > slabs / 4) splits = slabs / 4;    // ... but at least 4 slabs of work behind every 16K-atomic epilogue
     if (splits < 1) splits = 1;
     if (splits > 512) splits = 512;
     int slabs_per = cdiv(slabs, splits);

@@ -166,10 +166,17 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    # test hook: ALDI_BENCH_BACKEND=gloo ALDI_BENCH_DEVICE=0 runs all ranks on one GPU (exercises the N>1 code path on a 1-GPU box)
+    backend = os.environ.get("ALDI_BENCH_BACKEND", "nccl")
+    if "ALDI_BENCH_DEVICE" in os.environ:
+        local = int(os.environ["ALDI_BENCH_DEVICE"])
     torch.cuda.set_device(local)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend)
     dev = torch.device("cuda", local)
 
     from aldi_amd import synthetic as syn
