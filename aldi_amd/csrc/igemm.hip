@@ -10,16 +10,17 @@
 //
 // Tiles are staged global -> registers -> LDS (the gather needs per-lane addresses and zero
 // fill at the borders), double buffered, one barrier per K slab, next slab's global loads
-// issued before the current slab's MFMAs.  LDS rows are 64 B (4 x 16 B chunks); the chunk
-// index is XOR-swizzled per 4-row group so that the 16-lane groups of ds_read_b128 hit 16
+// issued before the current slab's MFMAs.  LDS rows are 128 B (8 x 16 B chunks, two MFMA k-steps per
+// barrier); the chunk index is XOR-swizzled so that the 16-lane groups of ds_read_b128 hit 16
 // distinct 16-B slots (MI355X_MICROARCH.md, LDS table).
 //
-// dtype: bf16 -> v_mfma_f32_16x16x32_bf16 (K slab 32); fp32 -> v_mfma_f32_16x16x4_f32 x4
-// (K slab 16, exact fp32 -- the parity mode).  Both share the byte geometry of the tiles.
+// dtype: bf16 -> v_mfma_f32_16x16x32_bf16 (K slab 64); fp32 -> v_mfma_f32_16x16x4_f32 x4
+// (K slab 32, exact fp32 -- the parity mode).  Both share the byte geometry of the tiles.
 //
 // Replaces the cuDNN/MIOpen conv + FrozenBN + ReLU (+ residual) chain and torch Linear that
 // the reference reaches through detectron2 (aldi/align.py:72, aldi/distill.py:157,162).
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -28,17 +29,20 @@ struct ConvDev {
     const float* scale; const float* shift; const void* res; const void* mask;
     int N, H, W, Cin, Cout, KH, KW, stride, pad, Ho, Wo;
     int relu, res_mode, out_scale, OH, OW;
-    int M, K;
+    int M, K, xcd;
 };
 
+// LDS rows of KC 16-B chunks.  KC = 8 (128-B rows): chunk ^ (row>>1)&7; KC = 4 (64-B rows): chunk ^ g[(row>>2)&3],
+// g = [0,2,3,1].  Both make the 8-lane ds_write_b128 groups and the 16-lane ds_read_b128 groups hit distinct
+// 16-B slots of the 256-B bank row.
+template <int KC>
 __device__ __forceinline__ int swz(int row, int kc) {
-    // chunk permutation g = [0,2,3,1] indexed by (row>>2)&3
-    return kc ^ ((0x78 >> (((row >> 2) & 3) * 2)) & 3);
+    if constexpr (KC == 8) return kc ^ ((row >> 1) & 7);
+    else return kc ^ ((0x78 >> (((row >> 2) & 3) * 2)) & 3);
 }
 
 template <typename T> struct Mma;
 template <> struct Mma<bf16_t> {
-    static constexpr int BK = 32;
     __device__ static __forceinline__ f32x4_t run(const uint4& a, const uint4& b, f32x4_t c) {
         bf16x8_t av = *reinterpret_cast<const bf16x8_t*>(&a);
         bf16x8_t bv = *reinterpret_cast<const bf16x8_t*>(&b);
@@ -46,7 +50,6 @@ template <> struct Mma<bf16_t> {
     }
 };
 template <> struct Mma<float> {
-    static constexpr int BK = 16;
     __device__ static __forceinline__ f32x4_t run(const uint4& a, const uint4& b, f32x4_t c) {
         const float* af = reinterpret_cast<const float*>(&a);
         const float* bf = reinterpret_cast<const float*>(&b);
@@ -56,21 +59,31 @@ template <> struct Mma<float> {
     }
 };
 
-template <typename T, int BM, int BN, int WM, int WN>
+template <typename T, int BM, int BN, int WM, int WN, int KC>
 __global__ __launch_bounds__(WM* WN * 64) void igemm_kernel(ConvDev p) {
     constexpr int NT = WM * WN * 64;
-    constexpr int BK = Mma<T>::BK;
     constexpr int EP = Elem<T>::kPer16B;           // elements per 16-B chunk
-    constexpr int A_IT = (BM * 4) / NT;            // pixel-tile chunks per thread
-    constexpr int B_IT = (BN * 4 + NT - 1) / NT;   // weight-tile chunks per thread
+    constexpr int BK = KC * EP;                    // K slab: KC 16-B chunks per LDS row (KC=8: 64 bf16 / 32 fp32)
+    constexpr int LOG = KC == 8 ? 3 : 2;
+    constexpr int A_IT = (BM * KC) / NT;           // pixel-tile chunks per thread
+    constexpr int B_IT = (BN * KC + NT - 1) / NT;  // weight-tile chunks per thread
     constexpr int TM = BM / WM / 16, TN = BN / WN / 16;
-    static_assert((BM * 4) % NT == 0, "tile/threads mismatch");
+    static_assert((BM * KC) % NT == 0, "tile/threads mismatch");
 
-    __shared__ uint4 lds[2][(BM + BN) * 4];
+    __shared__ uint4 lds[2][(BM + BN) * KC];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
-    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+    // XCD-aware tile order: workgroup b runs on XCD b % 8 (observed dispatch); give every XCD a contiguous range of
+    // (pixel-tile, channel-tile) pairs, channel-tile fastest, so the tiles sharing an activation tile / halo rows
+    // share one L2.  Pure speed: any placement computes the same result.
+    const int nmt = gridDim.x, nnt = gridDim.y;
+    int bid = blockIdx.y * nmt + blockIdx.x;
+    if (p.xcd) {
+        const int total = nmt * nnt, q = total >> 3, r = total & 7, xcd = bid & 7, idx = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int m0 = (bid / nnt) * BM, n0 = (bid % nnt) * BN;
     const T* __restrict__ X = static_cast<const T*>(p.x);
     const T* __restrict__ Wt = static_cast<const T*>(p.w);
 
@@ -80,7 +93,7 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_kernel(ConvDev p) {
     bool a_ok[A_IT];
 #pragma unroll
     for (int it = 0; it < A_IT; ++it) {
-        int c = tid + it * NT, row = c >> 2;
+        int c = tid + it * NT, row = c >> LOG;
         int m = m0 + row;
         a_ok[it] = m < p.M;
         int mm = a_ok[it] ? m : 0;
@@ -95,9 +108,9 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_kernel(ConvDev p) {
     bool b_ok[B_IT];
 #pragma unroll
     for (int it = 0; it < B_IT; ++it) {
-        int c = tid + it * NT, row = c >> 2, kc = c & 3;
+        int c = tid + it * NT, row = c >> LOG, kc = c & (KC - 1);
         int co = n0 + row;
-        b_ok[it] = (c < BN * 4) && co < p.Cout;
+        b_ok[it] = (c < BN * KC) && co < p.Cout;
         b_off[it] = (long)(b_ok[it] ? co : 0) * p.K + kc * EP;
     }
 
@@ -107,7 +120,7 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_kernel(ConvDev p) {
     auto load_slab = [&](int s) {
 #pragma unroll
         for (int it = 0; it < A_IT; ++it) {
-            int c = tid + it * NT, kc = c & 3;
+            int c = tid + it * NT, kc = c & (KC - 1);
             int hi = a_hi0[it] + kh, wi = a_wi0[it] + kw;
             bool ok = a_ok[it] && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W && ci0 + kc * EP < p.Cin;
             uint4 v = make_uint4(0, 0, 0, 0);
@@ -117,7 +130,7 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_kernel(ConvDev p) {
 #pragma unroll
         for (int it = 0; it < B_IT; ++it) {
             uint4 v = make_uint4(0, 0, 0, 0);
-            if (b_ok[it] && s * BK + ((tid + it * NT) & 3) * EP < p.K) v = *reinterpret_cast<const uint4*>(Wt + b_off[it] + (long)s * BK);
+            if (b_ok[it] && s * BK + ((tid + it * NT) & (KC - 1)) * EP < p.K) v = *reinterpret_cast<const uint4*>(Wt + b_off[it] + (long)s * BK);
             rb[it] = v;
         }
         ci0 += BK;
@@ -126,13 +139,13 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_kernel(ConvDev p) {
     auto store_slab = [&](int buf) {
 #pragma unroll
         for (int it = 0; it < A_IT; ++it) {
-            int c = tid + it * NT, row = c >> 2, kc = c & 3;
-            lds[buf][row * 4 + swz(row, kc)] = ra[it];
+            int c = tid + it * NT, row = c >> LOG, kc = c & (KC - 1);
+            lds[buf][row * KC + swz<KC>(row, kc)] = ra[it];
         }
 #pragma unroll
         for (int it = 0; it < B_IT; ++it) {
-            int c = tid + it * NT, row = c >> 2, kc = c & 3;
-            if (c < BN * 4) lds[buf][(BM + row) * 4 + swz(row, kc)] = rb[it];
+            int c = tid + it * NT, row = c >> LOG, kc = c & (KC - 1);
+            if (c < BN * KC) lds[buf][(BM + row) * KC + swz<KC>(row, kc)] = rb[it];
         }
     };
 
@@ -150,21 +163,24 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_kernel(ConvDev p) {
     for (int s = 0; s < S; ++s) {
         const int buf = s & 1;
         if (s + 1 < S) load_slab(s + 1);
-        uint4 xf[TM], wf[TN];
 #pragma unroll
-        for (int i = 0; i < TM; ++i) {
-            int row = wm * (BM / WM) + i * 16 + fr;
-            xf[i] = lds[buf][row * 4 + swz(row, fq)];
+        for (int ks = 0; ks < KC / 4; ++ks) {
+            uint4 xf[TM], wf[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                int row = wm * (BM / WM) + i * 16 + fr;
+                xf[i] = lds[buf][row * KC + swz<KC>(row, ks * 4 + fq)];
+            }
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                int row = wn * (BN / WN) + j * 16 + fr;
+                wf[j] = lds[buf][(BM + row) * KC + swz<KC>(row, ks * 4 + fq)];
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[i][j] = Mma<T>::run(wf[j], xf[i], acc[i][j]);
         }
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            int row = wn * (BN / WN) + j * 16 + fr;
-            wf[j] = lds[buf][(BM + row) * 4 + swz(row, fq)];
-        }
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int j = 0; j < TN; ++j) acc[i][j] = Mma<T>::run(wf[j], xf[i], acc[i][j]);
         if (s + 1 < S) store_slab(buf ^ 1);
         __syncthreads();
     }
@@ -224,23 +240,35 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_kernel(ConvDev p) {
     }
 }
 
-template <typename T, int BM, int BN, int WM, int WN>
+template <typename T, int BM, int BN, int WM, int WN, int KC>
 int launch(const ConvDev& d, hipStream_t st) {
     dim3 grid(cdiv(d.M, BM), cdiv(d.Cout, BN));
-    hipLaunchKernelGGL((igemm_kernel<T, BM, BN, WM, WN>), grid, dim3(WM * WN * 64), 0, st, d);
+    hipLaunchKernelGGL((igemm_kernel<T, BM, BN, WM, WN, KC>), grid, dim3(WM * WN * 64), 0, st, d);
     ALDI_CHECK_LAUNCH();
     return ALDI_OK;
 }
 
+static int env_int(const char* name, int dflt) {
+    const char* v = getenv(name);
+    return v ? atoi(v) : dflt;
+}
+
 template <typename T>
-int dispatch(const ConvDev& d, hipStream_t st) {
-    if (d.Cout <= 16) return launch<T, 128, 16, 4, 1>(d, st);
-    if (d.Cout <= 64) return launch<T, 128, 64, 4, 1>(d, st);
+int dispatch(ConvDev& d, hipStream_t st) {
+    static const int kc_env = env_int("ALDI_IGEMM_KC", 0);     // tuning knobs (0 = heuristic)
+    static const int xcd_env = env_int("ALDI_IGEMM_XCD", 1);
+    d.xcd = xcd_env;
+    const int ep = Elem<T>::kPer16B;
+    // deep K slab (two MFMA k-steps per barrier) only when the K loop is long enough to amortise the halved occupancy
+    bool deep = kc_env ? kc_env == 8 : d.K >= 16 * 8 * ep;
+    if (d.KH * d.KW > 1 && d.Cin % (8 * ep) != 0) deep = false;
+    if (d.Cout <= 16) return launch<T, 128, 16, 4, 1, 4>(d, st);
+    if (d.Cout <= 64) return deep ? launch<T, 128, 64, 4, 1, 8>(d, st) : launch<T, 128, 64, 4, 1, 4>(d, st);
     // the N=2 micro-batch leaves the deep layers (res4/res5, FC heads) with far fewer 128x128 tiles than the
     // 256 CUs: fall back to 64x64 tiles (4x the workgroups) when the big tiling cannot fill the chip
     const long big = (long)cdiv(d.M, 128) * cdiv(d.Cout, 128);
-    if (big < 200) return launch<T, 64, 64, 2, 2>(d, st);
-    return launch<T, 128, 128, 2, 2>(d, st);
+    if (big < 200) return deep ? launch<T, 64, 64, 2, 2, 8>(d, st) : launch<T, 64, 64, 2, 2, 4>(d, st);
+    return deep ? launch<T, 128, 128, 2, 2, 8>(d, st) : launch<T, 128, 128, 2, 2, 4>(d, st);
 }
 
 }  // namespace
@@ -250,7 +278,7 @@ extern "C" int aldi_conv_igemm(const aldi_conv_args* a, aldi_stream_t stream) {
     const int bk = a->dtype == ALDI_BF16 ? 32 : 16;
     const int ep = a->dtype == ALDI_BF16 ? 8 : 4;
     if (a->KH * a->KW == 1 ? (a->Cin % ep != 0) : (a->Cin % bk != 0))
-        return aldi_set_error_msg(ALDI_ERR_ARG, "conv_igemm: Cin must be a multiple of the K slab (32 bf16 / 16 f32); of a 16-B chunk for 1x1");
+        return aldi_set_error_msg(ALDI_ERR_ARG, "conv_igemm: Cin must be a multiple of 32 (bf16) / 16 (f32) for KxK convs; of a 16-B chunk for 1x1");
     if (a->Cout % 4 != 0) return aldi_set_error_msg(ALDI_ERR_ARG, "conv_igemm: Cout must be a multiple of 4");
     if (a->res_mode == 2 && ((a->Ho & 1) || (a->Wo & 1))) return aldi_set_error_msg(ALDI_ERR_ARG, "conv_igemm: upsample residual needs even Ho,Wo");
     if (a->res_mode && !a->res) return aldi_set_error_msg(ALDI_ERR_ARG, "conv_igemm: res_mode set without res");

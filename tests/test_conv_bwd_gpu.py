@@ -10,7 +10,7 @@ CASES = [
     (2, 25, 42, 64, 64, 3, 1, 1),
     (2, 24, 40, 256, 64, 1, 1, 0),
     (2, 25, 41, 256, 512, 1, 2, 0),
-    (2, 10, 12, 32, 32, 3, 1, 0),
+    (2, 10, 12, 64, 64, 3, 1, 0),
     (1, 17, 19, 128, 16, 1, 1, 0),
     (5, 1, 1, 1024, 48, 1, 1, 0),
     (1, 50, 84, 256, 256, 3, 1, 1),

@@ -25,7 +25,7 @@ CASES = [
     (2, 24, 40, 256, 64, 1, 1, 0),
     (2, 25, 41, 256, 512, 1, 2, 0),
     (1, 13, 21, 256, 256, 3, 1, 1),
-    (2, 10, 12, 32, 32, 3, 1, 0),
+    (2, 10, 12, 64, 64, 3, 1, 0),
     (1, 17, 19, 128, 16, 1, 1, 0),
     (3, 1, 1, 12544, 1024, 1, 1, 0),
 ]
