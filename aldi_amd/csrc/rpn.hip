@@ -200,67 +200,89 @@ __global__ __launch_bounds__(256) void rpn_loss_kernel(Geom g, const float4* __r
 constexpr int kTopkCap = 2048;     // >= PRE_NMS_TOPK (2000)
 constexpr int kMergeCap = 16384;   // >= 5 * 2000
 
-// per (level, image): exact top-k by (logit desc, index asc), sorted. block = 1024 threads.
-__global__ __launch_bounds__(1024) void rpn_topk_kernel(Geom g, int pre_nms_topk, unsigned long long* __restrict__ cand /*[N][nl][kTopkCap]*/,
+// order-preserving keys of every objectness logit, [N][sumA] (level-major, (h, w, a) inside a level)
+__global__ void rpn_keys_kernel(Geom g, int N, unsigned* __restrict__ keys) {
+    const long t = blockIdx.x * (long)blockDim.x + threadIdx.x;
+    if (t >= (long)N * g.sumA) return;
+    const int n = (int)(t / g.sumA), i = (int)(t - (long)n * g.sumA);
+    const int l = find_level(g, i);
+    const int j = i - g.off[l];
+    const int cell = j / g.A, a = j - cell * g.A;
+    keys[t] = float_key_asc(g.head[l][((long)n * g.H[l] * g.W[l] + cell) * g.C + a]);
+}
+
+// per (level, image): exact top-k by (logit desc, index asc), sorted.  block = 1024 threads.
+// Radix select (12+12+8 bits) of the k-th largest key over the contiguous key array, then one streaming pass
+// collects the winners (unordered append: the bitonic sort on (key desc, index asc) fixes the order); only when
+// MORE keys tie with the k-th than fit is an index-ordered pass needed to take the lowest indices.
+__global__ __launch_bounds__(1024) void rpn_topk_kernel(Geom g, const unsigned* __restrict__ keys_all, int pre_nms_topk,
+                                                        unsigned long long* __restrict__ cand /*[N][nl][kTopkCap]*/,
                                                         int* __restrict__ cand_count /*[N][nl]*/) {
     __shared__ unsigned long long keys[kTopkCap];
-    __shared__ int hist[256];
+    __shared__ int hist[4096];
     __shared__ int sm[17];
     __shared__ unsigned s_prefix;
-    __shared__ int s_need;
+    __shared__ int s_need, s_cnt, s_bucket_count;
     const int l = blockIdx.x, n = blockIdx.y;
     const int nel = g.H[l] * g.W[l] * g.A;
     const int k = min(pre_nms_topk, nel);
-    const float* head = g.head[l] + (long)n * g.H[l] * g.W[l] * g.C;
-    auto key_of = [&](int i) -> unsigned {
-        int cell = i / g.A, a = i - cell * g.A;
-        return float_key_asc(head[(long)cell * g.C + a]);
-    };
-    // radix select of the k-th largest key (MSB first)
+    const unsigned* kp = keys_all + (long)n * g.sumA + g.off[l];
     unsigned prefix = 0, mask = 0;
     int need = k;
-    for (int shift = 24; shift >= 0; shift -= 8) {
-        for (int i = threadIdx.x; i < 256; i += blockDim.x) hist[i] = 0;
+    const int shifts[3] = {20, 8, 0};
+    const int widths[3] = {12, 12, 8};
+    int bucket_count = 0;
+    for (int ps = 0; ps < 3; ++ps) {
+        const int shift = shifts[ps], nb = 1 << widths[ps];
+        for (int i = threadIdx.x; i < nb; i += blockDim.x) hist[i] = 0;
         __syncthreads();
         for (int i = threadIdx.x; i < nel; i += blockDim.x) {
-            unsigned key = key_of(i);
-            if ((key & mask) == prefix) atomicAdd(&hist[(key >> shift) & 255], 1);
+            unsigned key = kp[i];
+            if ((key & mask) == prefix) atomicAdd(&hist[(key >> shift) & (nb - 1)], 1);
         }
         __syncthreads();
         if (threadIdx.x == 0) {
-            int acc = 0, b = 255;
+            int acc = 0, b = nb - 1;
             for (; b > 0; --b) {
                 if (acc + hist[b] >= need) break;
                 acc += hist[b];
             }
             s_prefix = prefix | ((unsigned)b << shift);
             s_need = need - acc;
+            s_bucket_count = hist[b];
         }
         __syncthreads();
         prefix = s_prefix;
         need = s_need;
-        mask |= 255u << shift;
+        bucket_count = s_bucket_count;
+        mask |= (unsigned)(nb - 1) << shift;
         __syncthreads();
     }
-    const unsigned kth = prefix;      // exact key of the k-th largest; `need` of the equal keys are taken (lowest indices)
+    const unsigned kth = prefix;      // exact key of the k-th largest; `need` of its `bucket_count` copies are taken (lowest indices)
     for (int i = threadIdx.x; i < kTopkCap; i += blockDim.x) keys[i] = ~0ull;
+    if (threadIdx.x == 0) s_cnt = 0;
     __syncthreads();
-    int base_gt = 0, base_eq = 0;
-    for (int s = 0; s < nel; s += blockDim.x) {
-        int i = s + threadIdx.x;
-        unsigned key = i < nel ? key_of(i) : 0u;
-        bool gt = i < nel && key > kth;
-        bool eq = i < nel && key == kth;
-        int tg, te;
-        int rg = block_rank(gt, sm, &tg);
-        int re = block_rank(eq, sm, &te);
-        // descending by key, ascending by index: sort key = (~key) << 32 | index
-        if (gt) keys[base_gt + rg] = ((unsigned long long)(~key) << 32) | (unsigned)i;
-        if (eq && base_eq + re < need) keys[(k - need) + base_eq + re] = ((unsigned long long)(~key) << 32) | (unsigned)i;
-        base_gt += tg;
-        base_eq += te;
+    const bool take_all_eq = bucket_count == need;
+    for (int i = threadIdx.x; i < nel; i += blockDim.x) {
+        unsigned key = kp[i];
+        if (key > kth || (take_all_eq && key == kth)) {
+            int pos = atomicAdd(&s_cnt, 1);
+            keys[pos] = ((unsigned long long)(~key) << 32) | (unsigned)i;
+        }
     }
     __syncthreads();
+    if (!take_all_eq) {               // ties beyond k: ordered selection of the lowest-index copies of the k-th key
+        int base_eq = 0;
+        for (int s0 = 0; s0 < nel && base_eq < need; s0 += blockDim.x) {
+            int i = s0 + threadIdx.x;
+            bool eq = i < nel && kp[i] == kth;
+            int te;
+            int re = block_rank(eq, sm, &te);
+            if (eq && base_eq + re < need) keys[(k - need) + base_eq + re] = ((unsigned long long)(~kth) << 32) | (unsigned)i;
+            base_eq += te;
+        }
+        __syncthreads();
+    }
     bitonic_sort_u64(keys, kTopkCap);
     unsigned long long* out = cand + ((long)n * g.nl + l) * kTopkCap;
     for (int i = threadIdx.x; i < kTopkCap; i += blockDim.x) out[i] = keys[i];
@@ -415,6 +437,7 @@ extern "C" size_t aldi_rpn_proposals_workspace(int N, int num_levels) {
     s += B * cap * 4 * 2;        // scores, valid
     s += B * cap * (cap / 64) * 8;   // nms mask
     s += B * cap * 4 + B * 4 + 256;  // keep, keep_count
+    s += (size_t)N * 512 * 1024 * 4; // objectness keys (sumA <= 512K per image)
     return s + 1024;
 }
 
@@ -437,7 +460,11 @@ extern "C" int aldi_rpn_proposals(const aldi_rpn_geom* gm, float* const* head, c
     auto* mask = (unsigned long long*)take(B * cap * (cap / 64) * 8);
     auto* keep = (int*)take(B * cap * 4);
     auto* keep_count = (int*)take(B * 4);
-    hipLaunchKernelGGL(rpn_topk_kernel, dim3(g.nl, N), dim3(1024), 0, st, g, pre_nms_topk, cand, cand_count);
+    if (g.sumA > 512 * 1024) return aldi_set_error_msg(ALDI_ERR_ARG, "rpn_proposals: more than 512K anchors per image");
+    auto* okeys = (unsigned*)take((size_t)N * g.sumA * 4);
+    hipLaunchKernelGGL(rpn_keys_kernel, dim3(cdiv((long)N * g.sumA, 256)), dim3(256), 0, st, g, N, okeys);
+    ALDI_CHECK_LAUNCH();
+    hipLaunchKernelGGL(rpn_topk_kernel, dim3(g.nl, N), dim3(1024), 0, st, g, okeys, pre_nms_topk, cand, cand_count);
     ALDI_CHECK_LAUNCH();
     hipLaunchKernelGGL(rpn_decode_kernel, dim3(cap / 256, g.nl, N), dim3(256), 0, st, g, (const float4*)anchors, cand, cand_count, img_hw, boxes, scores, valid, err_flag);
     ALDI_CHECK_LAUNCH();

@@ -225,19 +225,41 @@ __global__ __launch_bounds__(256) void wgrad_f32_kernel(WgDev p) {
         }
 }
 
-// db[c] += sum_p g[p][c]  (bias gradients).  grid.x = column chunks of 64, grid.y = row splits.
+// db[c] += sum_p g[p][c]  (bias gradients).  Rows are read as full contiguous lines: a thread owns one 16-B chunk of
+// channels (C/EP chunks per row), the block walks `rows_per_block` rows, partial sums are combined through LDS.
 template <typename T>
 __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ g, float* __restrict__ db, int M, int C, int rows_per_block) {
-    __shared__ float red[4][64];
-    const int c = blockIdx.x * 64 + (threadIdx.x & 63);
-    const int w = threadIdx.x >> 6;
-    const int r0 = blockIdx.y * rows_per_block, r1 = min(M, r0 + rows_per_block);
-    float s = 0.f;
-    if (c < C)
-        for (int r = r0 + w; r < r1; r += 4) s += Elem<T>::ld(g + (long)r * C + c);
-    red[w][threadIdx.x & 63] = s;
+    constexpr int EP = Elem<T>::kPer16B;
+    __shared__ float red[256 * EP];
+    const int chunks = C / EP;                         // 16-B chunks per row
+    const int rl = 256 / chunks > 0 ? 256 / chunks : 1; // row lanes per block iteration
+    const int ch = threadIdx.x % chunks, lane_r = threadIdx.x / chunks;
+    const int r0 = blockIdx.x * rows_per_block, r1 = min(M, r0 + rows_per_block);
+    float acc[EP];
+#pragma unroll
+    for (int k = 0; k < EP; ++k) acc[k] = 0.f;
+    if (lane_r < rl && chunks <= 256)
+        for (int r = r0 + lane_r; r < r1; r += rl) {
+            const uint4 v = *reinterpret_cast<const uint4*>(g + (long)r * C + ch * EP);
+            if constexpr (EP == 8) {
+                const uint32_t* w = reinterpret_cast<const uint32_t*>(&v);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { acc[2 * k] += __uint_as_float(w[k] << 16); acc[2 * k + 1] += __uint_as_float(w[k] & 0xffff0000u); }
+            } else {
+                const float* w = reinterpret_cast<const float*>(&v);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) acc[k] += w[k];
+            }
+        }
+#pragma unroll
+    for (int k = 0; k < EP; ++k) red[threadIdx.x * EP + k] = acc[k];
     __syncthreads();
-    if (w == 0 && c < C) unsafeAtomicAdd(db + c, red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
+    for (int c = threadIdx.x; c < C; c += 256) {
+        const int cch = c / EP, k = c % EP;
+        float s = 0.f;
+        for (int l = 0; l < rl; ++l) s += red[(l * chunks + cch) * EP + k];
+        if (s != 0.f) unsafeAtomicAdd(db + c, s);
+    }
 }
 
 }  // namespace
@@ -278,8 +300,10 @@ extern "C" int aldi_conv_wgrad(const aldi_wgrad_args* a, aldi_stream_t stream) {
 extern "C" int aldi_bias_grad(const void* g, float* db, int M, int C, int dtype, aldi_stream_t stream) {
     if (!g || !db || M <= 0 || C <= 0) return aldi_set_error_msg(ALDI_ERR_ARG, "bias_grad: bad args");
     hipStream_t st = static_cast<hipStream_t>(stream);
-    int rows_per_block = 512;
-    dim3 grid(cdiv(C, 64), cdiv(M, rows_per_block));
+    const int ep = dtype == ALDI_BF16 ? 8 : 4;
+    if (C % ep || C / ep > 256) return aldi_set_error_msg(ALDI_ERR_ARG, "bias_grad: C must be a multiple of a 16-B chunk and <= 256 chunks");
+    int rows_per_block = cdiv(M, 1024) < 64 ? 64 : cdiv(M, 1024);
+    dim3 grid(cdiv(M, rows_per_block));
     if (dtype == ALDI_BF16) hipLaunchKernelGGL(colsum_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)g, db, M, C, rows_per_block);
     else hipLaunchKernelGGL(colsum_kernel<float>, grid, dim3(256), 0, st, (const float*)g, db, M, C, rows_per_block);
     ALDI_CHECK_LAUNCH();
