@@ -217,6 +217,9 @@ def add_aldi_config(cfg: CfgNode):
     _C.SOLVER.IMS_PER_GPU = 2
     _C.SOLVER.BACKWARD_AT_END = True
     _C.SOLVER.OPTIMIZER = "SGD"
+    # aldi_amd extension (not in the reference): run the step's student passes as one fused launch sequence
+    # (numerically the sequential schedule; see aldi_amd.trainer.fused_run_model)
+    _C.SOLVER.FUSED_STEP = False
 
     _C.MODEL.CONVNEXT = CN()
     _C.MODEL.CONVNEXT.DEPTHS = [3, 3, 9, 3]

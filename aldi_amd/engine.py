@@ -317,8 +317,8 @@ class RCNN:
         return ops.make_roi_feats(c.P[:4], grads, [1.0 / s for s in STRIDES[:4]])
 
     # ------------------------------------------------------------------ sampling (host RNG, D2 order)
-    def _sample(self, counts: List[List[int]], batch: int, frac: float):
-        """subsample_labels for every image: two torch.randperm draws per image (pos then neg)."""
+    def _sample_host(self, counts: List[List[int]], batch: int, frac: float):
+        """subsample_labels for every image: two torch.randperm draws per image (pos then neg). Host tensors."""
         N = len(counts)
         S = batch
         sel = torch.zeros((N, 2, S), dtype=torch.int32)
@@ -331,7 +331,11 @@ class RCNN:
             sel[n, 0, :num_pos] = perm1.to(torch.int32)
             sel[n, 1, :num_neg] = perm2.to(torch.int32)
             nsel[n, 0], nsel[n, 1] = num_pos, num_neg
-        return sel.to(self.device), nsel.to(self.device), nsel.tolist()
+        return sel, nsel, nsel.tolist()
+
+    def _sample(self, counts: List[List[int]], batch: int, frac: float):
+        sel, nsel, h = self._sample_host(counts, batch, frac)
+        return sel.to(self.device), nsel.to(self.device), h
 
     def rpn_match(self, geom, anchors, gt, N):
         """Matcher(0.3/0.7, low-quality) on the anchors: labels before sampling, matched GT index, ordered pos/neg lists."""
@@ -351,6 +355,7 @@ class RCNN:
         """host draws (2 randperm per image) -> NEW label tensor in {-1,0,1}; returns (labels, n_valid, n_fg, host_counts)."""
         if host_counts is None:
             host_counts = counts.cpu().tolist()             # device->host sync: the RNG needs the list lengths
+        lists = lists.contiguous()
         sel, nsel, nsel_h = self._sample(host_counts, RPN_BATCH, RPN_POS_FRAC)
         L_ = lists.shape[2]
         labels = torch.empty((N, L_), dtype=torch.int32, device=self.device)
@@ -407,6 +412,178 @@ class RCNN:
             self.align_forward(c, labeled, da_weights)
         return c
 
+    # ------------------------------------------------------------------ fused multi-chunk training forward
+    def forward_train_fused(self, specs: List[dict]) -> Ctx:
+        """Several micro-batches ("chunks") of the reference schedule through ONE trunk / head launch sequence
+        (FrozenBN => no cross-image coupling, so batching the source and target student
+        passes is exact).  Each spec: dict(images, instances | gt_dev, labeled, do_align, pre_rpn, pre_roi) where
+        pre_rpn / pre_roi are host callbacks fired right before that chunk's RPN / ROI sampling draws, which keeps
+        the global torch RNG stream identical to the sequential schedule.  Losses are reduced per chunk."""
+        dev = self.device
+        images = [im for sp in specs for im in sp["images"]]
+        N = len(images)
+        st, sizes, hw = self.stage_images(images)
+        shapes, geom, anchors = self.geometry(st.shape[2], st.shape[3])
+        gts = [sp["gt_dev"] if sp.get("gt_dev") is not None else self.stage_gt(sp["instances"]) for sp in specs]
+        gt = {k: torch.cat([g[k] for g in gts]) for k in ("boxes", "classes", "count")}
+        c = self.trunk(st, sizes, save=True)
+        c.N, c.sizes, c.hw, c.geom, c.anchors, c.gt, c.shapes = N, sizes, hw, geom, anchors, gt, shapes
+        self.rpn_head(c, save=True)
+        _, matched, lists, counts = self.rpn_match(geom, anchors, gt, N)
+        c.props, c.prop_scores, c.prop_count = self.proposals(c, geom, anchors, hw, N, training=True)
+        prep = self._roi_prepare(c.props, c.prop_count, gt, N)
+        both = torch.cat([counts.view(-1), prep["counts"].view(-1)]).cpu().tolist()      # the ONE device->host sync of the student pass
+        rpn_counts = [both[2 * i: 2 * i + 2] for i in range(N)]
+        roi_counts = [both[2 * N + 2 * i: 2 * N + 2 * i + 2] for i in range(N)]
+        # host draws, chunk by chunk, in the sequential schedule's order
+        rsel, rnsel, rh, osel, onsel, oh = [], [], [], [], [], []
+        n0 = 0
+        chunks = []
+        for sp in specs:
+            n1 = n0 + len(sp["images"])
+            if sp.get("pre_rpn"):
+                sp["pre_rpn"]()
+            a, b, h_ = self._sample_host(rpn_counts[n0:n1], RPN_BATCH, RPN_POS_FRAC)
+            rsel.append(a); rnsel.append(b); rh += h_
+            if sp.get("pre_roi"):
+                sp["pre_roi"]()
+            a, b, h2 = self._sample_host(roi_counts[n0:n1], ROI_BATCH, ROI_POS_FRAC)
+            osel.append(a); onsel.append(b); oh += h2
+            chunks.append(dict(n0=n0, n1=n1, labeled=sp.get("labeled", True), do_align=sp.get("do_align", False),
+                               da_weights=sp.get("da_weights", (0.0, 0.0)), rpn_counts=rpn_counts[n0:n1], roi_counts=roi_counts[n0:n1]))
+            n0 = n1
+        labels = torch.empty((N, anchors.shape[0]), dtype=torch.int32, device=dev)
+        ops.rpn_apply_sample(labels, anchors.shape[0], N, lists, torch.cat(rsel).to(dev), torch.cat(rnsel).to(dev), RPN_BATCH)
+        c.rpn_labels, c.rpn_matched, c.rpn_lists, c.rpn_counts = labels, matched, lists, counts
+        self._roi_gather(c, prep, torch.cat(osel).to(dev), torch.cat(onsel).to(dev), oh, gt, N)
+        self.roi_forward(c)
+        # per-chunk loss values
+        r0 = 0
+        for ch in chunks:
+            n0, n1 = ch["n0"], ch["n1"]
+            r1 = r0 + sum(c.rows[n0:n1])
+            ch["r0"], ch["r1"] = r0, r1
+            ch["loss_rpn"] = torch.zeros(2, dtype=torch.float32, device=dev)
+            ch["loss_box"] = torch.zeros(2, dtype=torch.float32, device=dev)
+            nc = n1 - n0
+            ops.rpn_loss(geom, [h[n0:n1] for h in c.head], None, anchors, labels[n0:n1], matched[n0:n1], gt["boxes"][n0:n1], gt["count"][n0:n1],
+                         GMAX, nc, 1.0 / (RPN_BATCH * nc), 0.0, 0.0, ch["loss_rpn"])
+            ops.box_loss(c.pred[r0:r1], self.Cp, self.K, r1 - r0, c.rois[r0:r1], c.r_cls[r0:r1], c.r_gt[r0:r1], ROI_WEIGHTS, 0.0, 0.0, None, ch["loss_box"])
+            ch["align"] = {}
+            ch["distill"] = None
+            if ch["do_align"]:
+                self._align_forward_chunk(c, ch)
+            r0 = r1
+        c.chunks = chunks
+        c.align = {}
+        c.distill = None
+        return c
+
+    def _align_forward_chunk(self, c: Ctx, ch: dict):
+        dev = self.device
+        label = 1.0 if ch["labeled"] else 0.0
+        n0, n1, r0, r1 = ch["n0"], ch["n1"], ch["r0"], ch["r1"]
+        if self.has_img_da:
+            a1 = self.conv(c.P[0][n0:n1], "img_align.model.0", relu=True)
+            pooled = ops.avgpool(a1)
+            logit = self.conv(pooled, "img_align.model.4", want_f32=True)
+            ch["loss_da_img"] = torch.zeros(1, dtype=torch.float32, device=dev)
+            ops.domain_bce(logit, logit.shape[-1], n1 - n0, label, ch["da_weights"][0], 0.0, None, ch["loss_da_img"])
+            ch["align"]["img"] = (a1, pooled, logit)
+        if self.has_ins_da and r1 > r0:
+            h = self.conv(c.fc2[r0:r1], "ins_align.model.1", relu=True)
+            logit = self.conv(h, "ins_align.model.3", want_f32=True)
+            ch["loss_da_ins"] = torch.zeros(1, dtype=torch.float32, device=dev)
+            ops.domain_bce(logit, logit.shape[-1], r1 - r0, label, ch["da_weights"][1], 0.0, None, ch["loss_da_ins"])
+            ch["align"]["ins"] = (h, logit)
+
+    def distill_forward_chunk(self, c: Ctx, ch: dict, teacher_head, teacher_pred, labels, n_valid, n_fg, **kw):
+        """distillation losses of one chunk of a fused forward (teacher tensors cover exactly that chunk)"""
+        dev = self.device
+        n0, n1, r0, r1 = ch["n0"], ch["n1"], ch["r0"], ch["r1"]
+        ch["distill"] = dict(t_head=teacher_head, t_pred=teacher_pred, labels=labels, n_valid=n_valid, n_fg=n_fg, **kw)
+        ch["loss_dist_rpn"] = torch.zeros(2, dtype=torch.float32, device=dev)
+        ch["loss_dist_roi"] = torch.zeros(2, dtype=torch.float32, device=dev)
+        ops.rpn_distill_loss(c.geom, [h[n0:n1] for h in c.head], teacher_head, None, labels, n1 - n0, kw["obj_T"], n_valid, n_fg,
+                             kw["do_obj"], kw["do_rpn_reg"], 0.0, ch["loss_dist_rpn"])
+        ops.roih_distill_loss(c.pred[r0:r1], teacher_pred, self.Cp, self.K, r1 - r0, kw["cls_T"], kw["kl"], kw["do_cls"], kw["do_roih_reg"],
+                              0.0, None, ch["loss_dist_roi"])
+
+    def chunk_loss_dict(self, ch: dict) -> "OrderedDict[str, torch.Tensor]":
+        d = OrderedDict()
+        d["loss_cls"], d["loss_box_reg"] = ch["loss_box"][0], ch["loss_box"][1]
+        d["loss_rpn_cls"], d["loss_rpn_loc"] = ch["loss_rpn"][0], ch["loss_rpn"][1]
+        if "img" in ch["align"]:
+            d["loss_da_img"] = ch["loss_da_img"][0]
+        if "ins" in ch["align"]:
+            d["loss_da_ins"] = ch["loss_da_ins"][0]
+        return d
+
+    def chunk_distill_loss_dict(self, ch: dict) -> "OrderedDict[str, torch.Tensor]":
+        d = OrderedDict()
+        k = ch["distill"]
+        if k["do_obj"]:
+            d["loss_obj_bce"] = ch["loss_dist_rpn"][0]
+        if k["do_rpn_reg"]:
+            d["loss_rpn_l1"] = ch["loss_dist_rpn"][1]
+        if k["do_cls"]:
+            d["loss_cls_ce"] = ch["loss_dist_roi"][0]
+        if k["do_roih_reg"]:
+            d["loss_roih_l1"] = ch["loss_dist_roi"][1]
+        return d
+
+    def backward_fused(self, c: Ctx, scales: List[Dict[str, float]]):
+        """backward of forward_train_fused: per-chunk loss gradients (scales[i] for chunk i) into the shared head-gradient
+        buffers, then ONE pass heads -> FPN -> res5..res3 over all images."""
+        T, dev = self.dtype, self.device
+        scratch = torch.zeros(2, dtype=torch.float32, device=dev)
+        c.ghead = [torch.zeros_like(h) for h in c.head]
+        c.gpred = torch.zeros((max(c.R, 1), self.Cp), dtype=torch.float32, device=dev)
+        gt = c.gt
+        align_list = []
+        for ch, sc_ in zip(c.chunks, scales):
+            sc = lambda k: float(sc_.get(k, 0.0))
+            n0, n1, r0, r1 = ch["n0"], ch["n1"], ch["r0"], ch["r1"]
+            nc = n1 - n0
+            heads = [h[n0:n1] for h in c.head]
+            gheads = [g[n0:n1] for g in c.ghead]
+            ops.rpn_loss(c.geom, heads, gheads, c.anchors, c.rpn_labels[n0:n1], c.rpn_matched[n0:n1], gt["boxes"][n0:n1], gt["count"][n0:n1],
+                         GMAX, nc, 1.0 / (RPN_BATCH * nc), sc("loss_rpn_cls"), sc("loss_rpn_loc"), scratch)
+            ops.box_loss(c.pred[r0:r1], self.Cp, self.K, r1 - r0, c.rois[r0:r1], c.r_cls[r0:r1], c.r_gt[r0:r1], ROI_WEIGHTS,
+                         sc("loss_cls"), sc("loss_box_reg"), c.gpred[r0:r1], scratch)
+            d = ch["distill"]
+            if d is not None:
+                def rpn_d(do_obj, do_reg, s_):
+                    ops.rpn_distill_loss(c.geom, heads, d["t_head"], gheads, d["labels"], nc, d["obj_T"], d["n_valid"], d["n_fg"], do_obj, do_reg, s_, scratch)
+
+                def roi_d(do_cls, do_reg, s_):
+                    ops.roih_distill_loss(c.pred[r0:r1], d["t_pred"], self.Cp, self.K, r1 - r0, d["cls_T"], d["kl"], do_cls, do_reg, s_, c.gpred[r0:r1], scratch)
+                if sc("loss_obj_bce") == sc("loss_rpn_l1"):
+                    rpn_d(d["do_obj"], d["do_rpn_reg"], sc("loss_obj_bce"))
+                else:
+                    rpn_d(d["do_obj"], False, sc("loss_obj_bce"))
+                    rpn_d(False, d["do_rpn_reg"], sc("loss_rpn_l1"))
+                if sc("loss_cls_ce") == sc("loss_roih_l1"):
+                    roi_d(d["do_cls"], d["do_roih_reg"], sc("loss_cls_ce"))
+                else:
+                    roi_d(d["do_cls"], False, sc("loss_cls_ce"))
+                    roi_d(False, d["do_roih_reg"], sc("loss_roih_l1"))
+            label = 1.0 if ch["labeled"] else 0.0
+            al = dict(n0=n0, n1=n1, r0=r0, r1=r1)
+            if "img" in ch["align"]:
+                a1, pooled, logit = ch["align"]["img"]
+                glog = torch.empty(logit.shape, dtype=T, device=dev)
+                ops.domain_bce(logit, logit.shape[-1], nc, label, ch["da_weights"][0], sc("loss_da_img"), glog, scratch)
+                al["img"] = (a1, pooled, glog)
+            if "ins" in ch["align"]:
+                h, logit = ch["align"]["ins"]
+                glog = torch.empty(logit.shape, dtype=T, device=dev)
+                ops.domain_bce(logit, logit.shape[-1], r1 - r0, label, ch["da_weights"][1], sc("loss_da_ins"), glog, scratch)
+                al["ins"] = (h, glog)
+            if "img" in al or "ins" in al:
+                align_list.append(al)
+        self._backward_trunk(c, align_list)
+
     def align_forward(self, c: Ctx, labeled: bool, da_weights):
         """AlignMixin.forward (aldi/align.py:75-90): discriminators behind gradient reversal, BCE vs constant domain label."""
         dev = self.device
@@ -461,7 +638,8 @@ class RCNN:
             d["loss_roih_l1"] = c.loss_dist_roi[1]
         return d
 
-    def roi_sample(self, c: Ctx, props, prop_count, gt, N):
+    def _roi_prepare(self, props, prop_count, gt, N) -> dict:
+        """append GT, match (IoU >= 0.5), classes, ordered fg/bg lists + their counts (device)."""
         dev = self.device
         P = props.shape[1]
         Lc = P + GMAX
@@ -477,9 +655,10 @@ class RCNN:
         lists = torch.empty((N, 2, Lc), dtype=torch.int32, device=dev)
         counts = torch.empty((N, 2), dtype=torch.int32, device=dev)
         ops.compact_labels(cls, Lc, N, self.K, lists, counts)
-        host_counts = counts.cpu().tolist()                  # device->host sync (RNG needs the list lengths)
-        c.roi_host_counts = host_counts
-        sel, nsel, nsel_h = self._sample(host_counts, ROI_BATCH, ROI_POS_FRAC)
+        return dict(cand=cand, cls=cls, best_idx=best_idx, lists=lists, counts=counts, Lc=Lc)
+
+    def _roi_gather(self, c: Ctx, prep: dict, sel, nsel, nsel_h, gt, N):
+        dev = self.device
         rows = [a + b for a, b in nsel_h]
         row_off = [0]
         for r in rows[:-1]:
@@ -490,8 +669,15 @@ class RCNN:
         c.r_cls = torch.empty((max(R, 1),), dtype=torch.int32, device=dev)
         c.r_gt = torch.empty((max(R, 1), 4), dtype=torch.float32, device=dev)
         c.r_idx = torch.empty((max(R, 1),), dtype=torch.int32, device=dev)
-        ops.roi_gather(cand, cls, best_idx, Lc, lists, sel, nsel, ROI_BATCH, torch.tensor(row_off, dtype=torch.int32).to(dev),
-                       gt["boxes"], gt["count"], GMAX, N, c.rois, c.r_cls, c.r_gt, c.r_idx)
+        ops.roi_gather(prep["cand"], prep["cls"], prep["best_idx"], prep["Lc"], prep["lists"], sel, nsel, ROI_BATCH,
+                       torch.tensor(row_off, dtype=torch.int32).to(dev), gt["boxes"], gt["count"], GMAX, N, c.rois, c.r_cls, c.r_gt, c.r_idx)
+
+    def roi_sample(self, c: Ctx, props, prop_count, gt, N):
+        prep = self._roi_prepare(props, prop_count, gt, N)
+        host_counts = prep["counts"].cpu().tolist()          # device->host sync (RNG needs the list lengths)
+        c.roi_host_counts = host_counts
+        sel, nsel, nsel_h = self._sample(host_counts, ROI_BATCH, ROI_POS_FRAC)
+        self._roi_gather(c, prep, sel, nsel, nsel_h, gt, N)
 
     def roi_forward(self, c: Ctx):
         R = c.R
@@ -594,16 +780,29 @@ class RCNN:
             glog = torch.empty(logit.shape, dtype=T, device=dev)
             ops.domain_bce(logit, logit.shape[-1], c.R, label, c.da_weights[1], sc("loss_da_ins"), glog, scratch)
             c.align["ins"] = (h, glog)
+        al = dict(n0=0, n1=c.N, r0=0, r1=c.R, **c.align)
+        self._backward_trunk(c, [al] if c.align else [])
+
+    def _backward_trunk(self, c: Ctx, align_list: List[dict]):
+        """heads -> FPN -> res5..res3 given d(loss)/d(head outputs) in c.ghead / c.gpred (fp32)."""
+        W = self.wts
+        T = self.dtype
+        dev = self.device
         # ---- box head (+ instance-level discriminator behind the gradient-reversal layer)
         gP_roi = [torch.zeros(f.shape, dtype=torch.float32, device=dev) for f in c.P[:4]]
         if c.R > 0:
             g_extra = None
-            if "ins" in c.align:
-                h, glog = c.align["ins"]
+            for al in align_list:
+                if "ins" not in al:
+                    continue
+                h, glog = al["ins"]
+                r0, r1 = al["r0"], al["r1"]
                 self._wgrad("ins_align.model.3", h, glog)
                 g_h = ops.conv2d(glog, W.wt("ins_align.model.3"), mask=h)
-                self._wgrad("ins_align.model.1", c.fc2, g_h)
-                g_extra = ops.conv2d(g_h, W.wt("ins_align.model.1", negate=True))
+                self._wgrad("ins_align.model.1", c.fc2[r0:r1], g_h)
+                if g_extra is None:
+                    g_extra = torch.zeros((c.R, 1, 1, FC_DIM), dtype=T, device=dev)
+                ops.conv2d(g_h, W.wt("ins_align.model.1", negate=True), out=g_extra[r0:r1])
             gpred = ops.cast_from_f32(c.gpred[:c.R], T).view(c.R, 1, 1, self.Cp)
             self._wgrad("box_pred", c.fc2, gpred)
             g_fc2 = ops.conv2d(gpred, W.wt("box_pred"), mask=c.fc2, res=g_extra, res_mode=1 if g_extra is not None else 0)
@@ -625,13 +824,16 @@ class RCNN:
         for l in range(4):
             ops.add_f32(gP[l], gP_roi[l], gP[l])
         # ---- image-level discriminator behind the gradient-reversal layer
-        if "img" in c.align:
-            a1, pooled, glog = c.align["img"]
+        for al in align_list:
+            if "img" not in al:
+                continue
+            a1, pooled, glog = al["img"]
+            n0, n1 = al["n0"], al["n1"]
             self._wgrad("img_align.model.4", pooled, glog)
             g_pooled = ops.conv2d(glog, W.wt("img_align.model.4"))
             g_a1 = ops.avgpool_bwd(g_pooled, a1)
-            self._wgrad("img_align.model.0", c.P[0], g_a1)
-            gP[0] = ops.conv2d(g_a1, W.wt("img_align.model.0", negate=True), pad=2, res=gP[0], res_mode=1)
+            self._wgrad("img_align.model.0", c.P[0][n0:n1], g_a1)
+            ops.conv2d(g_a1, W.wt("img_align.model.0", negate=True), pad=2, res=gP[0][n0:n1], res_mode=1, out=gP[0][n0:n1])
         # ---- FPN
         gprev = {}
         for i, lvl in enumerate((2, 3, 4, 5)):

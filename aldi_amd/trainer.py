@@ -76,6 +76,99 @@ def run_model_labeled_unlabeled(trainer, labeled_weak, labeled_strong, unlabeled
     return loss_dict
 
 
+def fused_run_model(trainer, labeled_weak, labeled_strong, unlabeled_weak, unlabeled_strong):
+    """MI355X-first form of `run_model_labeled_unlabeled` for the reference's FPN configurations
+    (BATCH_CONTENTS = labeled_strong [+ unlabeled_strong], one IMS_PER_GPU chunk each): the source, the
+    target-weak alignment and the distillation student passes go through ONE trunk/head launch sequence
+    (`RCNN.forward_train_fused`) and ONE backward, with a single device->host sync for the sampling counts.
+    Same loss-dict keys, values, 1/accum scaling, `v*0` masking and global-RNG stream as the sequential
+    driver (tests/test_engine_gpu.py::test_fused_step_equals_sequential)."""
+    from .model import DevicePseudoLabels
+    from .structures import as_record
+    model, dist_ = trainer.model, trainer.distiller
+    eng = model.engine
+    bs = trainer.model_batch_size
+    do_align = any(getattr(model, a, None) is not None for a in ["img_align", "ins_align"])
+    do_distill = dist_.distill_enabled()
+    total = sum(len(s_ or []) for s_ in [labeled_weak, labeled_strong, unlabeled_weak])
+    accum = total // bs
+    has_disc = do_align
+    da = model.cfg.DOMAIN_ADAPT.ALIGN
+    da_w = (da.IMG_DA_WEIGHT, da.INS_DA_WEIGHT)
+    fire_student = lambda: model.roi_heads.fire_pre()
+    specs, names = [], []
+    specs.append(dict(images=[d["image"] for d in labeled_strong], instances=[as_record(d["instances"]) for d in labeled_strong],
+                      labeled=True, do_align=do_align, da_weights=da_w, pre_roi=fire_student))
+    names.append("source_strong")
+    if do_align:
+        specs.append(dict(images=[d["image"] for d in unlabeled_weak], instances=[as_record(d["instances"]) for d in unlabeled_weak],
+                          labeled=False, do_align=True, da_weights=da_w, pre_roi=fire_student))
+        names.append("target_weak")
+    tc = None
+    if do_distill:
+        if dist_.cls_loss_type not in ("CE", "KL"):
+            raise ValueError("cls_loss_type must be one of {CE, KL}")
+        teacher = dist_.teacher.module if hasattr(dist_.teacher, "module") else dist_.teacher
+        with torch.no_grad():
+            tc = teacher.engine.inference([d["image"] for d in unlabeled_weak], dist_.pseudo_label_threshold)
+        teacher._last_inference = tc
+        labels_ = [DevicePseudoLabels(tc.sizes[i], tc.pseudo, i) for i in range(len(unlabeled_weak))]
+        for dw, ds, lab in zip(unlabeled_weak, unlabeled_strong, labels_):
+            dw["instances"] = lab
+            ds["instances"] = lab
+
+        def pre_rpn_distill():
+            teacher.roi_heads.fire_pre()         # the teacher's eval inference re-seeds with the OLD seed (SURVEY B.3)
+            dist_.seeder.reset_seed()
+        specs.append(dict(images=[d["image"] for d in unlabeled_strong], gt_dev=tc.pseudo, labeled=True, do_align=False,
+                          pre_rpn=pre_rpn_distill, pre_roi=fire_student))
+        names.append("distill")
+    c = eng.forward_train_fused(specs)
+    loss_dict = {}
+    scales = []
+    for ch, name in zip(c.chunks, names):
+        losses = eng.chunk_loss_dict(ch)
+        sc = {}
+        if name == "distill":
+            hard = {"loss_cls": dist_.do_hard_cls, "loss_rpn_cls": dist_.do_hard_obj, "loss_rpn_loc": dist_.do_hard_rpn_reg,
+                    "loss_box_reg": dist_.do_hard_roi_reg}
+            n0, n1, r0, r1 = ch["n0"], ch["n1"], ch["r0"], ch["r1"]
+            torch.manual_seed(dist_.seeder.seed)
+            eng._sample_host(ch["roi_counts"], 512, 0.25)                    # the teacher's identical ROI draws
+            rois_t = c.rois[r0:r1].clone()
+            rois_t[:, 0] -= n0
+            t_pred = teacher.engine.box_head_on(tc, rois_t, r1 - r0)
+            labels, n_valid, n_fg, _ = eng.rpn_sample(c.rpn_lists[n0:n1], None, n1 - n0, host_counts=ch["rpn_counts"])
+            eng.distill_forward_chunk(c, ch, tc.head, t_pred, labels, n_valid, n_fg, obj_T=float(dist_.obj_temperature),
+                                      cls_T=float(dist_.cls_temperature), kl=dist_.cls_loss_type == "KL", do_obj=dist_.do_obj_dst,
+                                      do_rpn_reg=dist_.do_rpn_reg_dst, do_cls=dist_.do_cls_dst, do_roih_reg=dist_.do_roih_reg_dst)
+            out = {}
+            for k, v in losses.items():
+                out[k] = v if hard.get(k, False) else v * 0.0
+                sc[k] = (1.0 if hard.get(k, False) else 0.0) / accum
+            if has_disc:
+                out["_da"] = torch.zeros((), device=model.device)
+            for k, v in eng.chunk_distill_loss_dict(ch).items():
+                out[k] = v
+                sc[k] = 1.0 / accum
+            keep = lambda k: k != "_"
+        elif name == "target_weak":
+            out = losses
+            keep = lambda k: "_da_" in k
+            sc = {k: (1.0 / accum if "_da_" in k else 0.0) for k in losses}
+        else:
+            out = losses
+            keep = lambda k: True
+            sc = {k: 1.0 / accum for k in losses}
+        scales.append(sc)
+        for k, v in out.items():
+            if keep(k):
+                loss_dict[f"{k}_{name}"] = loss_dict.get(f"{k}_{name}", 0) + (v / accum).detach()
+    eng.backward_fused(c, scales)
+    model._last_fused = c
+    return loss_dict
+
+
 class EngineSGD:
     """torch.optim.SGD-shaped handle on the fused HIP optimizer (momentum / weight decay of detectron2's build_optimizer)."""
     def __init__(self, model, lr, momentum=0.9, weight_decay=1e-4):
@@ -181,11 +274,30 @@ class _ALDITrainer:
         self.distiller = distiller
         self.backward_at_end = backward_at_end
         self.model_batch_size = model_batch_size
+        self.fused = False
+
+    def _can_fuse(self, data):
+        lw, ls, uw, us = data
+        if not self.fused or lw is not None or ls is None or len(ls) != self.model_batch_size or hasattr(self.model, "module"):
+            return False
+        if self.distiller.distill_enabled():
+            from .distill import ALDIDistiller
+            if not isinstance(self.distiller, ALDIDistiller) or uw is None or us is None:
+                return False
+            if len(uw) != self.model_batch_size or len(us) != self.model_batch_size:
+                return False
+        return True
 
     def run_model(self, data):
+        self._fused_done = False
+        if self._can_fuse(data):
+            self._fused_done = True
+            return fused_run_model(self, *data)
         return run_model_labeled_unlabeled(self, *data)
 
     def do_backward(self, losses, override=False):
+        if getattr(self, "_fused_done", False):
+            return                                   # the fused driver already ran its single backward
         if self.backward_at_end or override:
             super().do_backward(losses)
 
@@ -264,6 +376,7 @@ class ALDITrainer(DefaultTrainer):
         trainer = (ALDIAMPTrainer if cfg.SOLVER.AMP.ENABLED else ALDISimpleTrainer)(model, data_loader, optimizer, distiller,
                                                                                     backward_at_end=cfg.SOLVER.BACKWARD_AT_END,
                                                                                     model_batch_size=cfg.SOLVER.IMS_PER_GPU)
+        trainer.fused = bool(cfg.SOLVER.get("FUSED_STEP", False))
         return trainer
 
     @classmethod

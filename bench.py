@@ -158,6 +158,7 @@ def main():
     ap.add_argument("--width", type=int, default=1333)
     ap.add_argument("--align", action="store_true", help="BASELINE config 3: image+instance alignment on")
     ap.add_argument("--fp32", action="store_true", help="parity mode (not the benchmark dtype)")
+    ap.add_argument("--sequential", action="store_true", help="reference-style sequential micro-steps instead of the fused student pass")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
     args = ap.parse_args()
@@ -184,6 +185,7 @@ def main():
     cfg = make_cfg(world, args.height, args.width, args.align)
     if args.fp32:
         cfg.SOLVER.AMP.ENABLED = False
+    cfg.SOLVER.FUSED_STEP = not args.sequential
     random.seed(1234)
     torch.manual_seed(100 + rank)
     tr = ALDITrainer(cfg)
@@ -231,7 +233,7 @@ def main():
                                   "2 labeled_strong + 2 unlabeled (weak+strong) images per GPU" % (2 if args.align else 1, args.width, args.height,
                                                                                                    "on" if args.align else "off"),
                       "global_batch": imgs_per_step, "parallelism": f"dp{world}", "pseudo_label_threshold": cfg.DOMAIN_ADAPT.TEACHER.THRESHOLD,
-                      "pseudo_labels_per_image": pl_count, "weights": "random-init R50-FPN (synthetic)", "error_flag": err},
+                      "pseudo_labels_per_image": pl_count, "schedule": "sequential micro-steps" if args.sequential else "fused source+target student pass", "weights": "random-init R50-FPN (synthetic)", "error_flag": err},
            "final_losses": {k: round(v, 5) for k, v in losses.items()}}
     if rank == 0 and world == 1 and not args.no_profile:
         prof = profile_dense(tr, one_step, os.path.join(ROOT, "gpurun_out", "dense_profile.txt"))

@@ -307,3 +307,33 @@ def test_missing_extension_or_device_fails_loudly():
     cfg.MODEL.DEVICE = "cpu"
     with pytest.raises(RuntimeError):
         build_aldi(cfg)
+
+
+@pytest.mark.parametrize("align", [False, True])
+def test_fused_step_equals_sequential(align):
+    """SOLVER.FUSED_STEP (one trunk pass for the source / target-weak / distillation student micro-batches, one
+    backward) reproduces the sequential reference schedule: same loss dict (keys, order, values), same sampled
+    indices (same RNG stream), same gradients."""
+    from aldi_amd.trainer import ALDITrainer
+    out = []
+    for fused in (False, True):
+        cfg = _cfg(align)
+        cfg.SOLVER.FUSED_STEP = fused
+        random.seed(0)
+        torch.manual_seed(11)
+        tr = ALDITrainer(cfg)
+        tr.iter = 0
+        tr.before_step()
+        t = tr._trainer
+        data = next(t._data_loader_iter)
+        t.optimizer.zero_grad()
+        ld = t.run_model(data)
+        torch.cuda.synchronize()
+        assert t._fused_done == fused
+        out.append(({k: float(v) for k, v in ld.items()}, tr.model.weights.grad.clone(), torch.get_rng_state(), random.getstate()))
+    (l0, g0, r0, p0), (l1, g1, r1, p1) = out
+    assert list(l0.keys()) == list(l1.keys())
+    for k in l0:
+        assert abs(l0[k] - l1[k]) < 2e-5 * max(1.0, abs(l0[k])), (k, l0[k], l1[k])
+    assert torch.equal(r0, r1) and p0 == p1                      # identical host RNG consumption
+    assert (g0 - g1).abs().max() < 2e-4 * g0.abs().max()
