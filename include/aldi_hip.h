@@ -229,6 +229,13 @@ int aldi_domain_bce(const float* pred, int ld, int R, float label, float weight,
 int aldi_avgpool(const void* x, void* y, int N, int HW, int C, int dtype, aldi_stream_t stream);
 int aldi_avgpool_bwd(const void* gy, const void* act, void* gx, int N, int HW, int C, int dtype, aldi_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------
+ * Host helper (no device work): out[0..k) = torch.randperm(n)[:k] on the CPU generator whose state blob
+ * (torch.get_rng_state(), 5056 bytes) is passed in and advanced exactly as torch.randperm(n) would.
+ * Replaces the torch.randperm draws of detectron2 subsample_labels (aldi/distill.py:200-202 and inside
+ * model(...)) at O(k + n/624) instead of O(n) divisions. */
+int aldi_torch_randperm_prefix(unsigned char* state, long n, long k, long* out);
+
 #ifdef __cplusplus
 }
 #endif
