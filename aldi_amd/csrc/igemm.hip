@@ -30,6 +30,7 @@ struct ConvDev {
     int N, H, W, Cin, Cout, KH, KW, stride, pad, Ho, Wo;
     int relu, res_mode, out_scale, OH, OW;
     int M, K, xcd;
+    unsigned x_bytes, w_bytes;
 };
 
 // LDS rows of KC 16-B chunks.  KC = 8 (128-B rows): chunk ^ (row>>1)&7; KC = 4 (64-B rows): chunk ^ g[(row>>2)&3],
@@ -87,54 +88,66 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_kernel(ConvDev p) {
     const T* __restrict__ X = static_cast<const T*>(p.x);
     const T* __restrict__ Wt = static_cast<const T*>(p.w);
 
-    // per-thread gather descriptors (rows are fixed for the whole K loop)
-    int a_hi0[A_IT], a_wi0[A_IT];
-    long a_base[A_IT];
-    bool a_ok[A_IT];
+    // per-thread gather descriptors (rows are fixed for the whole K loop).  Loads are raw BUFFER loads: a 32-bit
+    // per-lane byte offset against a descriptor over the whole tensor, an out-of-range offset returns zeros --
+    // so border taps / tail rows need no branch, just a select of the offset (branchy `if (ok) load` costs an
+    // exec-masked region + full waitcnt per chunk).  Tap validity is a 16-bit mask computed once per row.
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(X), 0, p.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(Wt), 0, p.w_bytes, 0x00020000);
+    constexpr unsigned OOB = 0x80000000u;
+    unsigned a_voff[A_IT], a_mask[A_IT];
 #pragma unroll
     for (int it = 0; it < A_IT; ++it) {
-        int c = tid + it * NT, row = c >> LOG;
+        int c = tid + it * NT, row = c >> LOG, kc = c & (KC - 1);
         int m = m0 + row;
-        a_ok[it] = m < p.M;
-        int mm = a_ok[it] ? m : 0;
+        bool ok = m < p.M;
+        int mm = ok ? m : 0;
         int n = mm / (p.Ho * p.Wo);
         int r = mm - n * (p.Ho * p.Wo);
         int ho = r / p.Wo, wo = r - ho * p.Wo;
-        a_hi0[it] = ho * p.stride - p.pad;
-        a_wi0[it] = wo * p.stride - p.pad;
-        a_base[it] = (long)n * p.H * p.W;
+        int hi0 = ho * p.stride - p.pad, wi0 = wo * p.stride - p.pad;
+        a_voff[it] = (unsigned)((((long)n * p.H + hi0) * p.W + wi0) * p.Cin + kc * EP) * (unsigned)sizeof(T);   // mod 2^32, tap offset added later
+        unsigned mask = 0;
+        if (ok)
+            for (int t = 0; t < p.KH * p.KW; ++t) {
+                int kh_ = t / p.KW, kw_ = t - kh_ * p.KW;
+                if ((unsigned)(hi0 + kh_) < (unsigned)p.H && (unsigned)(wi0 + kw_) < (unsigned)p.W) mask |= 1u << t;
+            }
+        a_mask[it] = mask;
     }
-    long b_off[B_IT];
-    bool b_ok[B_IT];
+    unsigned b_voff[B_IT];
 #pragma unroll
     for (int it = 0; it < B_IT; ++it) {
         int c = tid + it * NT, row = c >> LOG, kc = c & (KC - 1);
         int co = n0 + row;
-        b_ok[it] = (c < BN * KC) && co < p.Cout;
-        b_off[it] = (long)(b_ok[it] ? co : 0) * p.K + kc * EP;
+        bool ok = (c < BN * KC) && co < p.Cout;
+        b_voff[it] = ok ? (unsigned)((long)co * p.K + kc * EP) * (unsigned)sizeof(T) : OOB;
     }
+    const bool ktail = (p.K % BK) != 0;          // only 1x1 convs with a short / ragged K
 
     uint4 ra[A_IT], rb[B_IT];
-    int kh = 0, kw = 0, ci0 = 0;   // tap / channel offset of the slab being LOADED (block uniform)
+    int tap = 0, kh = 0, kw = 0, ci0 = 0;   // tap / channel offset of the slab being LOADED (block uniform)
 
     auto load_slab = [&](int s) {
+        const unsigned tap_off = (unsigned)(((kh * p.W + kw) * p.Cin + ci0) * (int)sizeof(T));
 #pragma unroll
         for (int it = 0; it < A_IT; ++it) {
-            int c = tid + it * NT, kc = c & (KC - 1);
-            int hi = a_hi0[it] + kh, wi = a_wi0[it] + kw;
-            bool ok = a_ok[it] && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W && ci0 + kc * EP < p.Cin;
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if (ok) v = *reinterpret_cast<const uint4*>(X + ((a_base[it] + (long)hi * p.W + wi) * p.Cin + ci0 + kc * EP));
-            ra[it] = v;
+            bool ok = (a_mask[it] >> tap) & 1u;
+            if (ktail) ok = ok && (ci0 + ((tid + it * NT) & (KC - 1)) * EP < p.Cin);
+            u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rx, ok ? a_voff[it] + tap_off : OOB, 0, 0);
+            ra[it] = make_uint4(v.x, v.y, v.z, v.w);
         }
+        const unsigned k_off = (unsigned)(s * BK) * (unsigned)sizeof(T);
 #pragma unroll
         for (int it = 0; it < B_IT; ++it) {
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if (b_ok[it] && s * BK + ((tid + it * NT) & (KC - 1)) * EP < p.K) v = *reinterpret_cast<const uint4*>(Wt + b_off[it] + (long)s * BK);
-            rb[it] = v;
+            unsigned off = b_voff[it] == OOB ? OOB : b_voff[it] + k_off;
+            if (ktail && s * BK + ((tid + it * NT) & (KC - 1)) * EP >= p.K) off = OOB;
+            u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rw, off, 0, 0);
+            rb[it] = make_uint4(v.x, v.y, v.z, v.w);
         }
         ci0 += BK;
-        if (ci0 >= p.Cin) { ci0 = 0; if (++kw == p.KW) { kw = 0; ++kh; } }
+        if (ci0 >= p.Cin) { ci0 = 0; ++tap; if (++kw == p.KW) { kw = 0; ++kh; } }
     };
     auto store_slab = [&](int buf) {
 #pragma unroll
@@ -293,6 +306,12 @@ extern "C" int aldi_conv_igemm(const aldi_conv_args* a, aldi_stream_t stream) {
     if (M <= 0 || M > 0x7fffffffL) return aldi_set_error_msg(ALDI_ERR_ARG, "conv_igemm: bad M");
     d.M = (int)M;
     d.K = a->KH * a->KW * a->Cin;
+    const size_t esz = a->dtype == ALDI_BF16 ? 2 : 4;
+    const size_t xb = (size_t)a->N * a->H * a->W * a->Cin * esz, wb = (size_t)a->Cout * d.K * esz;
+    if (xb >= 0x80000000ull || wb >= 0x80000000ull) return aldi_set_error_msg(ALDI_ERR_ARG, "conv_igemm: operand larger than 2 GiB (32-bit buffer offsets)");
+    if (a->KH * a->KW > 16) return aldi_set_error_msg(ALDI_ERR_ARG, "conv_igemm: at most 16 taps");
+    d.x_bytes = (unsigned)xb;
+    d.w_bytes = (unsigned)wb;
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (a->dtype == ALDI_BF16) return dispatch<bf16_t>(d, st);
     if (a->dtype == ALDI_F32) return dispatch<float>(d, st);

@@ -1,0 +1,20 @@
+"""Run one conv shape repeatedly (for rocprofv3 --pmc).  usage: conv_micro.py N H W Cin Cout k [reps] [wgrad]"""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from aldi_amd import ops
+N, H, W, Cin, Cout, k = (int(a) for a in sys.argv[1:7])
+reps = int(sys.argv[7]) if len(sys.argv) > 7 else 10
+wg = len(sys.argv) > 8 and sys.argv[8] == "wgrad"
+g = torch.Generator(device="cuda").manual_seed(0)
+x = torch.randn(N, H, W, Cin, device="cuda", generator=g).bfloat16()
+w = (torch.randn(Cout, k, k, Cin, device="cuda", generator=g) / (Cin * k * k) ** 0.5).bfloat16()
+y = torch.empty(N, H, W, Cout, device="cuda", dtype=torch.bfloat16)
+gy = torch.randn(N, H, W, Cout, device="cuda", generator=g).bfloat16()
+dw = torch.zeros(Cout, k, k, Cin, device="cuda")
+for _ in range(reps):
+    if wg:
+        ops.conv_wgrad(x, gy, dw, KH=k, KW=k, stride=1, pad=k // 2)
+    else:
+        ops.conv2d(x, w, pad=k // 2, out=y, relu=True)
+torch.cuda.synchronize()
