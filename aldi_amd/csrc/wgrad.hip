@@ -25,6 +25,7 @@ struct WgDev {
     const void* x; const void* g; float* dw; const float* scale;
     int N, H, W, Cin, Cout, KH, KW, stride, pad, Ho, Wo;
     int M, K, pix_per_split, ident;
+    unsigned x_bytes, g_bytes;
 };
 
 __device__ __forceinline__ int swz8(int row, int c) { return c ^ ((row >> 1) & 7); }
@@ -75,6 +76,12 @@ __global__ __launch_bounds__(256) void wgrad_bf16_kernel(WgDev p) {
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
     const int fr = lane & 15, fq = lane >> 4;
 
+    // raw buffer loads: 32-bit byte offsets, out-of-range offsets return zeros (no branches around the loads)
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    const __amdgpu_buffer_rsrc_t rsrc = isB ? __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(X), 0, p.x_bytes, 0x00020000)
+                                            : __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(G), 0, p.g_bytes, 0x00020000);
+    constexpr unsigned OOB = 0x80000000u;
+    const int row_elems = isB ? p.Cin : p.Cout;
     uint4 in[8], out[8];
     auto load_slab = [&](int p0) {
         int pp = p0 + pg * 8;
@@ -88,17 +95,16 @@ __global__ __launch_bounds__(256) void wgrad_bf16_kernel(WgDev p) {
 #pragma unroll
         for (int r = 0; r < 8; ++r) {
             int px = pp + r;
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if (ch_ok && px < pend) {
-                if (!isB) v = *reinterpret_cast<const uint4*>(G + (long)px * p.Cout + ch);
-                else if (p.ident) v = *reinterpret_cast<const uint4*>(X + (long)px * p.Cin + ci);
-                else {
-                    int hi = ho * p.stride - p.pad + kh, wi = wo * p.stride - p.pad + kw;
-                    if ((unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W)
-                        v = *reinterpret_cast<const uint4*>(X + (((long)n * p.H + hi) * p.W + wi) * p.Cin + ci);
-                }
+            bool ok = ch_ok && px < pend;
+            unsigned off;
+            if (!isB || p.ident) off = (unsigned)((long)px * row_elems + (isB ? ci : ch)) * 2u;
+            else {
+                int hi = ho * p.stride - p.pad + kh, wi = wo * p.stride - p.pad + kw;
+                ok = ok && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
+                off = (unsigned)((((long)n * p.H + hi) * p.W + wi) * p.Cin + ci) * 2u;
             }
-            in[r] = v;
+            u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, ok ? off : OOB, 0, 0);
+            in[r] = make_uint4(v.x, v.y, v.z, v.w);
             if (++wo == p.Wo) { wo = 0; if (++ho == p.Ho) { ho = 0; ++n; } }
         }
     };
@@ -276,6 +282,14 @@ extern "C" int aldi_conv_wgrad(const aldi_wgrad_args* a, aldi_stream_t stream) {
     if (M <= 0 || M > 0x7fffffffL) return aldi_set_error_msg(ALDI_ERR_ARG, "conv_wgrad: bad M");
     d.M = (int)M;
     d.K = a->KH * a->KW * a->Cin;
+    {
+        const size_t esz = a->dtype == ALDI_BF16 ? 2 : 4;
+        const size_t xb = (size_t)a->N * a->H * a->W * a->Cin * esz, gb = (size_t)M * a->Cout * esz;
+        if (a->dtype == ALDI_BF16 && (xb >= 0x80000000ull || gb >= 0x80000000ull))
+            return aldi_set_error_msg(ALDI_ERR_ARG, "conv_wgrad: operand larger than 2 GiB (32-bit buffer offsets)");
+        d.x_bytes = (unsigned)xb;
+        d.g_bytes = (unsigned)gb;
+    }
     d.ident = (a->KH == 1 && a->KW == 1 && a->stride == 1 && a->pad == 0 && a->Ho == a->H && a->Wo == a->W) ? 1 : 0;
     hipStream_t st = static_cast<hipStream_t>(stream);
     const int tile = a->dtype == ALDI_BF16 ? 128 : 64;
