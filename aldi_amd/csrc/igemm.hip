@@ -42,6 +42,12 @@ __device__ __forceinline__ int swz(int row, int kc) {
     else return kc ^ ((0x78 >> (((row >> 2) & 3) * 2)) & 3);
 }
 
+// 16-B-per-lane global -> LDS DMA (`buffer_load_dwordx4 ... offen lds`): LDS address = wave-uniform `dst` + lane*16;
+// an out-of-range `voff` writes zeros.
+__device__ __forceinline__ void glds16(__amdgpu_buffer_rsrc_t rsrc, uint4* dst, unsigned voff) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)dst, 16, voff, 0, 0, 0);
+}
+
 template <typename T> struct Mma;
 template <> struct Mma<bf16_t> {
     __device__ static __forceinline__ f32x4_t run(const uint4& a, const uint4& b, f32x4_t c) {
@@ -88,18 +94,23 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_kernel(ConvDev p) {
     const T* __restrict__ X = static_cast<const T*>(p.x);
     const T* __restrict__ Wt = static_cast<const T*>(p.w);
 
-    // per-thread gather descriptors (rows are fixed for the whole K loop).  Loads are raw BUFFER loads: a 32-bit
-    // per-lane byte offset against a descriptor over the whole tensor, an out-of-range offset returns zeros --
-    // so border taps / tail rows need no branch, just a select of the offset (branchy `if (ok) load` costs an
-    // exec-masked region + full waitcnt per chunk).  Tap validity is a 16-bit mask computed once per row.
-    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    // per-thread gather descriptors (rows are fixed for the whole K loop).  Tiles go global -> LDS directly
+    // (`buffer_load_dwordx4 ... lds`, LDS-DMA): no VGPR round trip and no ds_write pass, which is what bounds the
+    // register-staged form of this loop (ds_write_b128 sustains ~79 B/clk/CU).  The DMA writes lane-linearly
+    // (wave-uniform LDS base + lane*16), i.e. thread c of the tile fills LDS slot c = row*KC + (c % KC); the bank
+    // swizzle therefore moves to the SOURCE: the lane fetches logical chunk swz(row, c % KC) (the swizzle is an
+    // involution, the fragment reads keep using swz).  A 32-bit per-lane byte offset indexes a raw buffer
+    // descriptor over the whole tensor; an out-of-range offset makes the DMA write zeros -- border taps, tail rows
+    // and K tails need no branch, just a select of the offset.  Tap validity is a 16-bit mask computed once per row.
     const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(X), 0, p.x_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(Wt), 0, p.w_bytes, 0x00020000);
     constexpr unsigned OOB = 0x80000000u;
+    const int wbase = __builtin_amdgcn_readfirstlane(tid & ~63);      // first tile slot of this wave (wave-uniform)
     unsigned a_voff[A_IT], a_mask[A_IT];
+    int a_kce[A_IT];
 #pragma unroll
     for (int it = 0; it < A_IT; ++it) {
-        int c = tid + it * NT, row = c >> LOG, kc = c & (KC - 1);
+        int c = tid + it * NT, row = c >> LOG, kce = swz<KC>(row, c & (KC - 1));
         int m = m0 + row;
         bool ok = m < p.M;
         int mm = ok ? m : 0;
@@ -107,7 +118,8 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_kernel(ConvDev p) {
         int r = mm - n * (p.Ho * p.Wo);
         int ho = r / p.Wo, wo = r - ho * p.Wo;
         int hi0 = ho * p.stride - p.pad, wi0 = wo * p.stride - p.pad;
-        a_voff[it] = (unsigned)((((long)n * p.H + hi0) * p.W + wi0) * p.Cin + kc * EP) * (unsigned)sizeof(T);   // mod 2^32, tap offset added later
+        a_voff[it] = (unsigned)((((long)n * p.H + hi0) * p.W + wi0) * p.Cin + kce * EP) * (unsigned)sizeof(T);   // mod 2^32, tap offset added later
+        a_kce[it] = kce * EP;
         unsigned mask = 0;
         if (ok)
             for (int t = 0; t < p.KH * p.KW; ++t) {
@@ -117,49 +129,38 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_kernel(ConvDev p) {
         a_mask[it] = mask;
     }
     unsigned b_voff[B_IT];
+    int b_kce[B_IT];
 #pragma unroll
     for (int it = 0; it < B_IT; ++it) {
-        int c = tid + it * NT, row = c >> LOG, kc = c & (KC - 1);
+        int c = tid + it * NT, row = c >> LOG, kce = swz<KC>(row, c & (KC - 1));
         int co = n0 + row;
         bool ok = (c < BN * KC) && co < p.Cout;
-        b_voff[it] = ok ? (unsigned)((long)co * p.K + kc * EP) * (unsigned)sizeof(T) : OOB;
+        b_voff[it] = ok ? (unsigned)((long)co * p.K + kce * EP) * (unsigned)sizeof(T) : OOB;
+        b_kce[it] = kce * EP;
     }
     const bool ktail = (p.K % BK) != 0;          // only 1x1 convs with a short / ragged K
 
-    uint4 ra[A_IT], rb[B_IT];
     int tap = 0, kh = 0, kw = 0, ci0 = 0;   // tap / channel offset of the slab being LOADED (block uniform)
 
-    auto load_slab = [&](int s) {
+    auto issue_slab = [&](int s, int buf) {
         const unsigned tap_off = (unsigned)(((kh * p.W + kw) * p.Cin + ci0) * (int)sizeof(T));
 #pragma unroll
         for (int it = 0; it < A_IT; ++it) {
             bool ok = (a_mask[it] >> tap) & 1u;
-            if (ktail) ok = ok && (ci0 + ((tid + it * NT) & (KC - 1)) * EP < p.Cin);
-            u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rx, ok ? a_voff[it] + tap_off : OOB, 0, 0);
-            ra[it] = make_uint4(v.x, v.y, v.z, v.w);
+            if (ktail) ok = ok && (ci0 + a_kce[it] < p.Cin);
+            glds16(rx, &lds[buf][wbase + it * NT], ok ? a_voff[it] + tap_off : OOB);
         }
         const unsigned k_off = (unsigned)(s * BK) * (unsigned)sizeof(T);
 #pragma unroll
         for (int it = 0; it < B_IT; ++it) {
-            unsigned off = b_voff[it] == OOB ? OOB : b_voff[it] + k_off;
-            if (ktail && s * BK + ((tid + it * NT) & (KC - 1)) * EP >= p.K) off = OOB;
-            u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rw, off, 0, 0);
-            rb[it] = make_uint4(v.x, v.y, v.z, v.w);
+            if (wbase + it * NT < BN * KC) {                               // wave-uniform
+                unsigned off = b_voff[it] == OOB ? OOB : b_voff[it] + k_off;
+                if (ktail && s * BK + b_kce[it] >= p.K) off = OOB;
+                glds16(rw, &lds[buf][BM * KC + wbase + it * NT], off);
+            }
         }
         ci0 += BK;
         if (ci0 >= p.Cin) { ci0 = 0; ++tap; if (++kw == p.KW) { kw = 0; ++kh; } }
-    };
-    auto store_slab = [&](int buf) {
-#pragma unroll
-        for (int it = 0; it < A_IT; ++it) {
-            int c = tid + it * NT, row = c >> LOG, kc = c & (KC - 1);
-            lds[buf][row * KC + swz<KC>(row, kc)] = ra[it];
-        }
-#pragma unroll
-        for (int it = 0; it < B_IT; ++it) {
-            int c = tid + it * NT, row = c >> LOG, kc = c & (KC - 1);
-            if (c < BN * KC) lds[buf][(BM + row) * KC + swz<KC>(row, kc)] = rb[it];
-        }
     };
 
     f32x4_t acc[TM][TN];
@@ -169,13 +170,12 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_kernel(ConvDev p) {
         for (int j = 0; j < TN; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
     const int S = (p.K + BK - 1) / BK;
-    load_slab(0);
-    store_slab(0);
-    __syncthreads();
+    issue_slab(0, 0);
+    __syncthreads();                          // (the compiler drains the LDS-DMA with vmcnt(0) ahead of the barrier)
     const int fr = lane & 15, fq = lane >> 4;
     for (int s = 0; s < S; ++s) {
         const int buf = s & 1;
-        if (s + 1 < S) load_slab(s + 1);
+        if (s + 1 < S) issue_slab(s + 1, buf ^ 1);   // next slab streams into the other buffer under this slab's MFMAs
 #pragma unroll
         for (int ks = 0; ks < KC / 4; ++ks) {
             uint4 xf[TM], wf[TN];
@@ -194,7 +194,6 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_kernel(ConvDev p) {
 #pragma unroll
                 for (int j = 0; j < TN; ++j) acc[i][j] = Mma<T>::run(wf[j], xf[i], acc[i][j]);
         }
-        if (s + 1 < S) store_slab(buf ^ 1);
         __syncthreads();
     }
 
