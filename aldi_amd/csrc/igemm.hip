@@ -77,7 +77,8 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_kernel(ConvDev p) {
     constexpr int TM = BM / WM / 16, TN = BN / WN / 16;
     static_assert((BM * KC) % NT == 0, "tile/threads mismatch");
 
-    __shared__ uint4 lds[2][(BM + BN) * KC];
+    constexpr int NBUF = 3;                        // LDS ring: two slabs of DMA in flight across the barrier
+    __shared__ uint4 lds[NBUF][(BM + BN) * KC];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
@@ -169,13 +170,23 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_kernel(ConvDev p) {
 #pragma unroll
         for (int j = 0; j < TN; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
+    // Pipeline: slab s+2 is issued while slab s is computed, slab s+1 is in flight across the barrier.  The wait is a
+    // COUNTED vmcnt (every wave waits for its own DMA pieces of slab s, leaving slab s+1's outstanding) followed by a raw
+    // s_barrier: __syncthreads() would drain the DMA queue (vmcnt(0)) at every slab (cdna_hip_programming.md section 5).
+    // WAR: slab s+2 overwrites the buffer read while computing slab s-1; it is issued after the barrier of iteration s,
+    // which every wave passes only after finishing slab s-1.
+    constexpr int N_DMA = A_IT + (BN * KC) / NT;   // DMA instructions per slab of the wave that issues the fewest
     const int S = (p.K + BK - 1) / BK;
     issue_slab(0, 0);
-    __syncthreads();                          // (the compiler drains the LDS-DMA with vmcnt(0) ahead of the barrier)
+    if (S > 1) issue_slab(1, 1);
     const int fr = lane & 15, fq = lane >> 4;
+    int buf = 0, nbuf = 2;
     for (int s = 0; s < S; ++s) {
-        const int buf = s & 1;
-        if (s + 1 < S) issue_slab(s + 1, buf ^ 1);   // next slab streams into the other buffer under this slab's MFMAs
+        if (s + 1 < S) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N_DMA) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        if (s + 2 < S) issue_slab(s + 2, nbuf);
 #pragma unroll
         for (int ks = 0; ks < KC / 4; ++ks) {
             uint4 xf[TM], wf[TN];
@@ -194,7 +205,8 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_kernel(ConvDev p) {
 #pragma unroll
                 for (int j = 0; j < TN; ++j) acc[i][j] = Mma<T>::run(wf[j], xf[i], acc[i][j]);
         }
-        __syncthreads();
+        buf = buf == NBUF - 1 ? 0 : buf + 1;
+        nbuf = nbuf == NBUF - 1 ? 0 : nbuf + 1;
     }
 
     // ---- epilogue: lane owns pixel (lane&15), channels (lane>>4)*4 .. +3 of each 16x16 tile
@@ -272,7 +284,7 @@ int dispatch(ConvDev& d, hipStream_t st) {
     d.xcd = xcd_env;
     const int ep = Elem<T>::kPer16B;
     // deep K slab (two MFMA k-steps per barrier) only when the K loop is long enough to amortise the halved occupancy
-    bool deep = kc_env ? kc_env == 8 : d.K >= 16 * 8 * ep;
+    bool deep = kc_env == 8;                       // 3-deep LDS ring: shallow (64-B) slabs keep 3 workgroups per CU
     if (d.KH * d.KW > 1 && d.Cin % (8 * ep) != 0) deep = false;
     if (d.Cout <= 16) return launch<T, 128, 16, 4, 1, 4>(d, st);
     if (d.Cout <= 64) return deep ? launch<T, 128, 64, 4, 1, 8>(d, st) : launch<T, 128, 64, 4, 1, 4>(d, st);
