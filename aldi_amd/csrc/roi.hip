@@ -125,33 +125,76 @@ __global__ __launch_bounds__(256) void roialign_kernel(Feats ft, const float* __
     const int gh = (int)ceilf(rh / (float)P), gw = (int)ceilf(rw / (float)P);
     const float count = (float)max(gh * gw, 1);
     const T* F = static_cast<const T*>(ft.f[l]) + (long)b * H * W * ft.C + c;
-    float* G = BWD ? ft.g[l] + (long)b * H * W * ft.C + c : nullptr;
-    for (int pw = 0; pw < P; ++pw) {
-        T* op = pooled + (((long)r * P + ph) * P + pw) * ft.C + c;
-        float acc = 0.f, gval = 0.f;
-        if (BWD) gval = Elem<T>::ld(op) / count;
+    if constexpr (!BWD) {
+        for (int pw = 0; pw < P; ++pw) {
+            T* op = pooled + (((long)r * P + ph) * P + pw) * ft.C + c;
+            float acc = 0.f;
+            for (int iy = 0; iy < gh; ++iy) {
+                const float y = y1 + (float)ph * bh + ((float)iy + 0.5f) * bh / (float)gh;
+                const Bilin by = bilin_prep(y, H);
+                for (int ix = 0; ix < gw; ++ix) {
+                    const float x = x1 + (float)pw * bw + ((float)ix + 0.5f) * bw / (float)gw;
+                    const Bilin bx = bilin_prep(x, W);
+                    if (by.dead || bx.dead) continue;
+                    const float w1 = by.h * bx.h, w2 = by.h * bx.l, w3 = by.l * bx.h, w4 = by.l * bx.l;
+                    const long o1 = ((long)by.lo * W + bx.lo) * ft.C, o2 = ((long)by.lo * W + bx.hi) * ft.C;
+                    const long o3 = ((long)by.hi * W + bx.lo) * ft.C, o4 = ((long)by.hi * W + bx.hi) * ft.C;
+                    acc += w1 * Elem<T>::ld(F + o1) + w2 * Elem<T>::ld(F + o2) + w3 * Elem<T>::ld(F + o3) + w4 * Elem<T>::ld(F + o4);
+                }
+            }
+            Elem<T>::st(op, acc / count);
+        }
+    } else {
+        // Backward.  For one sample row (iy) the sample columns sweep left -> right over all P bins, touching the pixel
+        // pairs (xlo, xlo+1) of the two feature rows (ylo, yhi): keep that 2x2 window in registers and flush a column with
+        // ONE atomic per row when the sweep leaves it -- ~2 atomics per touched pixel instead of 4 per sample.
+        float* G = ft.g[l] + (long)b * H * W * ft.C + c;
+        float gbin[8];
+#pragma unroll
+        for (int pw = 0; pw < 8; ++pw)
+            gbin[pw] = pw < P ? Elem<T>::ld(pooled + (((long)r * P + ph) * P + pw) * ft.C + c) / count : 0.f;
         for (int iy = 0; iy < gh; ++iy) {
             const float y = y1 + (float)ph * bh + ((float)iy + 0.5f) * bh / (float)gh;
             const Bilin by = bilin_prep(y, H);
-            for (int ix = 0; ix < gw; ++ix) {
-                const float x = x1 + (float)pw * bw + ((float)ix + 0.5f) * bw / (float)gw;
-                const Bilin bx = bilin_prep(x, W);
-                if (by.dead || bx.dead) continue;
-                const float w1 = by.h * bx.h, w2 = by.h * bx.l, w3 = by.l * bx.h, w4 = by.l * bx.l;
-                const long o1 = ((long)by.lo * W + bx.lo) * ft.C, o2 = ((long)by.lo * W + bx.hi) * ft.C;
-                const long o3 = ((long)by.hi * W + bx.lo) * ft.C, o4 = ((long)by.hi * W + bx.hi) * ft.C;
-                if (!BWD) {
-                    float v = w1 * Elem<T>::ld(F + o1) + w2 * Elem<T>::ld(F + o2) + w3 * Elem<T>::ld(F + o3) + w4 * Elem<T>::ld(F + o4);
-                    acc += v;
-                } else {
-                    unsafeAtomicAdd(G + o1, gval * w1);
-                    unsafeAtomicAdd(G + o2, gval * w2);
-                    unsafeAtomicAdd(G + o3, gval * w3);
-                    unsafeAtomicAdd(G + o4, gval * w4);
+            if (by.dead) continue;
+            float* Glo = G + (long)by.lo * W * ft.C;
+            float* Ghi = G + (long)by.hi * W * ft.C;
+            int cur = -1;                       // window covers pixel columns cur, cur+1
+            float a0l = 0.f, a0h = 0.f, a1l = 0.f, a1h = 0.f;   // [column 0/1][row lo/hi]
+            auto flush0 = [&]() {
+                if (a0l != 0.f) unsafeAtomicAdd(Glo + (long)cur * ft.C, a0l);
+                if (a0h != 0.f) unsafeAtomicAdd(Ghi + (long)cur * ft.C, a0h);
+            };
+            auto flush1 = [&]() {
+                if (a1l != 0.f) unsafeAtomicAdd(Glo + (long)(cur + 1) * ft.C, a1l);
+                if (a1h != 0.f) unsafeAtomicAdd(Ghi + (long)(cur + 1) * ft.C, a1h);
+            };
+            for (int pw = 0; pw < P; ++pw) {
+                const float gv = gbin[pw];
+                for (int ix = 0; ix < gw; ++ix) {
+                    const float x = x1 + (float)pw * bw + ((float)ix + 0.5f) * bw / (float)gw;
+                    const Bilin bx = bilin_prep(x, W);
+                    if (bx.dead) continue;
+                    if (bx.lo != cur) {         // the sweep moved on (lo is non-decreasing along the row)
+                        if (cur >= 0) {
+                            flush0();
+                            if (bx.lo == cur + 1) { a0l = a1l; a0h = a1h; }
+                            else { flush1(); a0l = 0.f; a0h = 0.f; }
+                        }
+                        a1l = 0.f; a1h = 0.f;
+                        cur = bx.lo;
+                    }
+                    const float gl = gv * by.h, gh_ = gv * by.l;
+                    a0l += gl * bx.h; a0h += gh_ * bx.h;
+                    if (bx.hi != bx.lo) { a1l += gl * bx.l; a1h += gh_ * bx.l; }
+                    else { a0l += gl * bx.l; a0h += gh_ * bx.l; }     // clamped at the right border: both taps hit the same pixel
                 }
             }
+            if (cur >= 0) {
+                flush0();
+                if (cur + 1 < W) flush1();
+            }
         }
-        if (!BWD) Elem<T>::st(op, acc / count);
     }
 }
 
