@@ -213,6 +213,88 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_kernel(ConvDev p) {
     T* __restrict__ Y = static_cast<T*>(p.y);
     const T* __restrict__ R = static_cast<const T*>(p.res);
     const T* __restrict__ Mk = static_cast<const T*>(p.mask);
+    if constexpr (sizeof(T) == 2) {
+        // bf16 fast path: the accumulator fragment gives every lane 8 B per pixel (32-B runs per pixel row) -- poor store /
+        // residual-load granularity for what are mostly HBM-bound layers.  Stage scale*acc+shift through LDS (padded rows,
+        // conflict-free 8-B writes) and let every lane finish 16 B of one pixel row: 256-B coalesced residual / mask
+        // loads and stores.  (conv*scale+shift is rounded to bf16 before the residual add; the fp32 parity mode keeps
+        // the single-rounding direct path below.)
+        if (Y && !p.y_f32 && (p.Cout & 7) == 0) {
+            constexpr int ROWB = BN * 2 + 16;
+            static_assert(BM * ROWB <= NBUF * (BM + BN) * KC * 16, "staging tile must fit in the pipeline buffers");
+            unsigned char* stg = reinterpret_cast<unsigned char*>(&lds[0][0]);
+            __syncthreads();                    // every wave is done reading the last slab
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    const int rowl = wm * (BM / WM) + i * 16 + fr, coll = wn * (BN / WN) + j * 16 + fq * 4;
+                    const int c = n0 + coll;
+                    float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+                    if (c < p.Cout) {
+                        if (p.scale) {
+                            float4 sc = *reinterpret_cast<const float4*>(p.scale + c);
+                            v[0] *= sc.x; v[1] *= sc.y; v[2] *= sc.z; v[3] *= sc.w;
+                        }
+                        if (p.shift) {
+                            float4 sh = *reinterpret_cast<const float4*>(p.shift + c);
+                            v[0] += sh.x; v[1] += sh.y; v[2] += sh.z; v[3] += sh.w;
+                        }
+                    }
+                    store4(reinterpret_cast<bf16_t*>(stg + rowl * ROWB + coll * 2), v);
+                }
+            __syncthreads();
+            constexpr int CPR = BN / 8;          // 16-B chunks per tile row
+            for (int k = tid; k < BM * CPR; k += NT) {
+                const int rowl = k / CPR, ch8 = k - rowl * CPR;
+                const int m = m0 + rowl, c = n0 + ch8 * 8;
+                if (m >= p.M || c >= p.Cout) continue;
+                long oidx, ridx;
+                if (p.out_scale == 1 && p.res_mode != 2) {
+                    oidx = (long)m * p.Cout;
+                    ridx = oidx;
+                } else {
+                    int n = m / (p.Ho * p.Wo);
+                    int r = m - n * (p.Ho * p.Wo);
+                    int ho = r / p.Wo, wo = r - ho * p.Wo;
+                    if (p.out_scale == 1) oidx = (long)m * p.Cout;
+                    else oidx = (((long)n * p.OH + ho * p.out_scale) * p.OW + wo * p.out_scale) * p.Cout;
+                    if (p.res_mode == 2) ridx = (((long)n * (p.Ho >> 1) + (ho >> 1)) * (p.Wo >> 1) + (wo >> 1)) * p.Cout;
+                    else ridx = oidx;
+                }
+                const uint4 raw = *reinterpret_cast<const uint4*>(stg + rowl * ROWB + ch8 * 16);
+                const uint32_t* rw_ = reinterpret_cast<const uint32_t*>(&raw);
+                float v[8];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { v[2 * q] = __uint_as_float(rw_[q] << 16); v[2 * q + 1] = __uint_as_float(rw_[q] & 0xffff0000u); }
+                if (p.res_mode) {
+                    const uint4 rr = *reinterpret_cast<const uint4*>(R + ridx + c);
+                    const uint32_t* r32 = reinterpret_cast<const uint32_t*>(&rr);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) { v[2 * q] += __uint_as_float(r32[q] << 16); v[2 * q + 1] += __uint_as_float(r32[q] & 0xffff0000u); }
+                }
+                if (p.relu) {
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) v[q] = v[q] > 0.f ? v[q] : 0.f;
+                }
+                if (Mk) {
+                    const uint4 mm = *reinterpret_cast<const uint4*>(Mk + oidx + c);
+                    const uint32_t* m32 = reinterpret_cast<const uint32_t*>(&mm);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        if (!(__uint_as_float(m32[q] << 16) > 0.f)) v[2 * q] = 0.f;
+                        if (!(__uint_as_float(m32[q] & 0xffff0000u) > 0.f)) v[2 * q + 1] = 0.f;
+                    }
+                }
+                uint4 o;
+                uint32_t* o32 = reinterpret_cast<uint32_t*>(&o);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) o32[q] = (uint32_t)f32_to_bf16(v[2 * q]) | ((uint32_t)f32_to_bf16(v[2 * q + 1]) << 16);
+                *reinterpret_cast<uint4*>(Y + oidx + c) = o;
+            }
+            return;
+        }
+    }
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
         int m = m0 + wm * (BM / WM) + i * 16 + fr;
