@@ -22,12 +22,15 @@ typedef __attribute__((ext_vector_type(4))) float f32x4_t;    // MFMA 16x16 accu
 __device__ __forceinline__ float bf16_to_f32(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
 
 // round-to-nearest-even, NaN preserved (same rule as torch's float->bfloat16)
-__device__ __forceinline__ bf16_t f32_to_bf16(float f) {
-    uint32_t u = __float_as_uint(f);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return (bf16_t)(u >> 16);
+// (gfx950 has the conversion in hardware: v_cvt_pk_bf16_f32, two values per instruction)
+typedef __bf16 hwbf16x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t pack2_bf16(float lo, float hi) {
+    f32x2_t v = {lo, hi};
+    hwbf16x2_t b = __builtin_convertvector(v, hwbf16x2_t);
+    return *reinterpret_cast<uint32_t*>(&b);
 }
+__device__ __forceinline__ bf16_t f32_to_bf16(float f) { return (bf16_t)(pack2_bf16(f, 0.f) & 0xffffu); }
 
 template <typename T> struct Elem;
 template <> struct Elem<float> {
@@ -56,8 +59,8 @@ __device__ __forceinline__ void store4(float* p, const float v[4]) {
 }
 __device__ __forceinline__ void store4(bf16_t* p, const float v[4]) {
     uint2 t;
-    t.x = (uint32_t)f32_to_bf16(v[0]) | ((uint32_t)f32_to_bf16(v[1]) << 16);
-    t.y = (uint32_t)f32_to_bf16(v[2]) | ((uint32_t)f32_to_bf16(v[3]) << 16);
+    t.x = pack2_bf16(v[0], v[1]);
+    t.y = pack2_bf16(v[2], v[3]);
     *reinterpret_cast<uint2*>(p) = t;
 }
 

@@ -29,7 +29,7 @@ struct ConvDev {
     const float* scale; const float* shift; const void* res; const void* mask;
     int N, H, W, Cin, Cout, KH, KW, stride, pad, Ho, Wo;
     int relu, res_mode, out_scale, OH, OW;
-    int M, K, xcd;
+    int M, K, xcd, dbg;
     unsigned x_bytes, w_bytes;
 };
 
@@ -109,25 +109,30 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_kernel(ConvDev p) {
     const int wbase = __builtin_amdgcn_readfirstlane(tid & ~63);      // first tile slot of this wave (wave-uniform)
     unsigned a_voff[A_IT], a_mask[A_IT];
     int a_kce[A_IT];
+    const bool ident = p.KH * p.KW == 1 && p.stride == 1 && p.pad == 0;   // 1x1: pixel index == input index, no divisions
 #pragma unroll
     for (int it = 0; it < A_IT; ++it) {
         int c = tid + it * NT, row = c >> LOG, kce = swz<KC>(row, c & (KC - 1));
         int m = m0 + row;
         bool ok = m < p.M;
+        a_kce[it] = kce * EP;
+        if (ident) {
+            a_voff[it] = ((unsigned)m * (unsigned)p.Cin + (unsigned)(kce * EP)) * (unsigned)sizeof(T);
+            a_mask[it] = ok ? 1u : 0u;
+            continue;
+        }
         int mm = ok ? m : 0;
         int n = mm / (p.Ho * p.Wo);
         int r = mm - n * (p.Ho * p.Wo);
         int ho = r / p.Wo, wo = r - ho * p.Wo;
         int hi0 = ho * p.stride - p.pad, wi0 = wo * p.stride - p.pad;
         a_voff[it] = (unsigned)((((long)n * p.H + hi0) * p.W + wi0) * p.Cin + kce * EP) * (unsigned)sizeof(T);   // mod 2^32, tap offset added later
-        a_kce[it] = kce * EP;
-        unsigned mask = 0;
-        if (ok)
-            for (int t = 0; t < p.KH * p.KW; ++t) {
-                int kh_ = t / p.KW, kw_ = t - kh_ * p.KW;
-                if ((unsigned)(hi0 + kh_) < (unsigned)p.H && (unsigned)(wi0 + kw_) < (unsigned)p.W) mask |= 1u << t;
-            }
-        a_mask[it] = mask;
+        unsigned mask = 0, colbits = 0;
+        for (int kw_ = 0; kw_ < p.KW; ++kw_)
+            if ((unsigned)(wi0 + kw_) < (unsigned)p.W) colbits |= 1u << kw_;
+        for (int kh_ = 0; kh_ < p.KH; ++kh_)
+            if ((unsigned)(hi0 + kh_) < (unsigned)p.H) mask |= colbits << (kh_ * p.KW);
+        a_mask[it] = ok ? mask : 0u;
     }
     unsigned b_voff[B_IT];
     int b_kce[B_IT];
@@ -176,7 +181,7 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_kernel(ConvDev p) {
     // WAR: slab s+2 overwrites the buffer read while computing slab s-1; it is issued after the barrier of iteration s,
     // which every wave passes only after finishing slab s-1.
     constexpr int N_DMA = A_IT + (BN * KC) / NT;   // DMA instructions per slab of the wave that issues the fewest
-    const int S = (p.K + BK - 1) / BK;
+    const int S = (p.dbg & 8) ? 1 : (p.K + BK - 1) / BK;
     issue_slab(0, 0);
     if (S > 1) issue_slab(1, 1);
     const int fr = lane & 15, fq = lane >> 4;
@@ -186,7 +191,8 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_kernel(ConvDev p) {
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
-        if (s + 2 < S) issue_slab(s + 2, nbuf);
+        if (s + 2 < S && !(p.dbg & 1)) issue_slab(s + 2, nbuf);
+        if (!(p.dbg & 2))
 #pragma unroll
         for (int ks = 0; ks < KC / 4; ++ks) {
             uint4 xf[TM], wf[TN];
@@ -209,6 +215,7 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_kernel(ConvDev p) {
         nbuf = nbuf == NBUF - 1 ? 0 : nbuf + 1;
     }
 
+    if (p.dbg & 4) return;
     // ---- epilogue: lane owns pixel (lane&15), channels (lane>>4)*4 .. +3 of each 16x16 tile
     T* __restrict__ Y = static_cast<T*>(p.y);
     const T* __restrict__ R = static_cast<const T*>(p.res);
@@ -219,38 +226,53 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_kernel(ConvDev p) {
         // conflict-free 8-B writes) and let every lane finish 16 B of one pixel row: 256-B coalesced residual / mask
         // loads and stores.  (conv*scale+shift is rounded to bf16 before the residual add; the fp32 parity mode keeps
         // the single-rounding direct path below.)
-        if (Y && !p.y_f32 && (p.Cout & 7) == 0) {
-            constexpr int ROWB = BN * 2 + 16;
-            static_assert(BM * ROWB <= NBUF * (BM + BN) * KC * 16, "staging tile must fit in the pipeline buffers");
+        constexpr int ROWB = BN * 2 + 16;
+        constexpr bool kStageFits = BM * ROWB <= NBUF * (BM + BN) * KC * 16;   // staging tile reuses the pipeline buffers
+        if (kStageFits && Y && !p.y_f32 && (p.Cout & 7) == 0) {
+            // The epilogue is instruction-bound if written naively (wave64 VALU ops cost 4 cycles each and a block only
+            // moves 32 KB): hardware bf16 packing, per-column scale/shift hoisted, immediate LDS offsets, and packed
+            // 16-bit integer ops for ReLU / mask when there is no residual to add.
             unsigned char* stg = reinterpret_cast<unsigned char*>(&lds[0][0]);
             __syncthreads();                    // every wave is done reading the last slab
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
+            {
+                unsigned char* wr = stg + (wm * (BM / WM) + fr) * ROWB + (wn * (BN / WN) + fq * 4) * 2;
 #pragma unroll
                 for (int j = 0; j < TN; ++j) {
-                    const int rowl = wm * (BM / WM) + i * 16 + fr, coll = wn * (BN / WN) + j * 16 + fq * 4;
-                    const int c = n0 + coll;
-                    float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+                    const int c = n0 + wn * (BN / WN) + j * 16 + fq * 4;
+                    float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
                     if (c < p.Cout) {
-                        if (p.scale) {
-                            float4 sc = *reinterpret_cast<const float4*>(p.scale + c);
-                            v[0] *= sc.x; v[1] *= sc.y; v[2] *= sc.z; v[3] *= sc.w;
-                        }
-                        if (p.shift) {
-                            float4 sh = *reinterpret_cast<const float4*>(p.shift + c);
-                            v[0] += sh.x; v[1] += sh.y; v[2] += sh.z; v[3] += sh.w;
-                        }
+                        if (p.scale) sc = *reinterpret_cast<const float4*>(p.scale + c);
+                        if (p.shift) sh = *reinterpret_cast<const float4*>(p.shift + c);
                     }
-                    store4(reinterpret_cast<bf16_t*>(stg + rowl * ROWB + coll * 2), v);
+#pragma unroll
+                    for (int i = 0; i < TM; ++i) {
+                        uint2 t;
+                        if (p.scale || p.shift) {
+                            t.x = pack2_bf16(acc[i][j][0] * sc.x + sh.x, acc[i][j][1] * sc.y + sh.y);
+                            t.y = pack2_bf16(acc[i][j][2] * sc.z + sh.z, acc[i][j][3] * sc.w + sh.w);
+                        } else {
+                            t.x = pack2_bf16(acc[i][j][0], acc[i][j][1]);
+                            t.y = pack2_bf16(acc[i][j][2], acc[i][j][3]);
+                        }
+                        *reinterpret_cast<uint2*>(wr + i * 16 * ROWB + j * 32) = t;
+                    }
                 }
+            }
             __syncthreads();
             constexpr int CPR = BN / 8;          // 16-B chunks per tile row
-            for (int k = tid; k < BM * CPR; k += NT) {
-                const int rowl = k / CPR, ch8 = k - rowl * CPR;
-                const int m = m0 + rowl, c = n0 + ch8 * 8;
-                if (m >= p.M || c >= p.Cout) continue;
+            constexpr int RPI = NT / CPR;        // tile rows covered per iteration
+            const int rowl0 = tid / CPR, ch8 = tid % CPR;
+            const int c = n0 + ch8 * 8;
+            if (c >= p.Cout) return;
+            const bool plain = p.out_scale == 1 && p.res_mode != 2;
+            const unsigned char* rd = stg + rowl0 * ROWB + ch8 * 16;
+            typedef short s16x2_t __attribute__((ext_vector_type(2)));
+#pragma unroll
+            for (int it = 0; it < BM / RPI; ++it) {
+                const int m = m0 + rowl0 + it * RPI;
+                if (m >= p.M) break;
                 long oidx, ridx;
-                if (p.out_scale == 1 && p.res_mode != 2) {
+                if (plain) {
                     oidx = (long)m * p.Cout;
                     ridx = oidx;
                 } else {
@@ -262,35 +284,41 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_kernel(ConvDev p) {
                     if (p.res_mode == 2) ridx = (((long)n * (p.Ho >> 1) + (ho >> 1)) * (p.Wo >> 1) + (wo >> 1)) * p.Cout;
                     else ridx = oidx;
                 }
-                const uint4 raw = *reinterpret_cast<const uint4*>(stg + rowl * ROWB + ch8 * 16);
-                const uint32_t* rw_ = reinterpret_cast<const uint32_t*>(&raw);
-                float v[8];
-#pragma unroll
-                for (int q = 0; q < 4; ++q) { v[2 * q] = __uint_as_float(rw_[q] << 16); v[2 * q + 1] = __uint_as_float(rw_[q] & 0xffff0000u); }
+                uint4 raw = *reinterpret_cast<const uint4*>(rd + it * RPI * ROWB);
+                uint32_t* rw_ = reinterpret_cast<uint32_t*>(&raw);
                 if (p.res_mode) {
                     const uint4 rr = *reinterpret_cast<const uint4*>(R + ridx + c);
                     const uint32_t* r32 = reinterpret_cast<const uint32_t*>(&rr);
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) { v[2 * q] += __uint_as_float(r32[q] << 16); v[2 * q + 1] += __uint_as_float(r32[q] & 0xffff0000u); }
-                }
-                if (p.relu) {
+                    for (int q = 0; q < 4; ++q) {
+                        float lo = __uint_as_float(rw_[q] << 16) + __uint_as_float(r32[q] << 16);
+                        float hi = __uint_as_float(rw_[q] & 0xffff0000u) + __uint_as_float(r32[q] & 0xffff0000u);
+                        if (p.relu) { lo = fmaxf(lo, 0.f); hi = fmaxf(hi, 0.f); }
+                        rw_[q] = pack2_bf16(lo, hi);
+                    }
+                } else if (p.relu) {
+                    // bf16 as int16: negative floats (and -0) are negative integers
 #pragma unroll
-                    for (int q = 0; q < 8; ++q) v[q] = v[q] > 0.f ? v[q] : 0.f;
+                    for (int q = 0; q < 4; ++q) {
+                        s16x2_t v = *reinterpret_cast<s16x2_t*>(&rw_[q]);
+                        v = __builtin_elementwise_max(v, s16x2_t{0, 0});
+                        rw_[q] = *reinterpret_cast<uint32_t*>(&v);
+                    }
                 }
                 if (Mk) {
+                    // keep where the forward activation (a ReLU output, so >= 0) is > 0: multiply the bit patterns by 0 / 1
                     const uint4 mm = *reinterpret_cast<const uint4*>(Mk + oidx + c);
                     const uint32_t* m32 = reinterpret_cast<const uint32_t*>(&mm);
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
-                        if (!(__uint_as_float(m32[q] << 16) > 0.f)) v[2 * q] = 0.f;
-                        if (!(__uint_as_float(m32[q] & 0xffff0000u) > 0.f)) v[2 * q + 1] = 0.f;
+                        s16x2_t k = *reinterpret_cast<const s16x2_t*>(&m32[q]);
+                        k = __builtin_elementwise_min(__builtin_elementwise_max(k, s16x2_t{0, 0}), s16x2_t{1, 1});
+                        s16x2_t v = *reinterpret_cast<s16x2_t*>(&rw_[q]);
+                        v = v * k;
+                        rw_[q] = *reinterpret_cast<uint32_t*>(&v);
                     }
                 }
-                uint4 o;
-                uint32_t* o32 = reinterpret_cast<uint32_t*>(&o);
-#pragma unroll
-                for (int q = 0; q < 4; ++q) o32[q] = (uint32_t)f32_to_bf16(v[2 * q]) | ((uint32_t)f32_to_bf16(v[2 * q + 1]) << 16);
-                *reinterpret_cast<uint4*>(Y + oidx + c) = o;
+                *reinterpret_cast<uint4*>(Y + oidx + c) = raw;
             }
             return;
         }
@@ -363,7 +391,10 @@ template <typename T>
 int dispatch(ConvDev& d, hipStream_t st) {
     static const int kc_env = env_int("ALDI_IGEMM_KC", 0);     // tuning knobs (0 = heuristic)
     static const int xcd_env = env_int("ALDI_IGEMM_XCD", 1);
+    static const int tile_env = env_int("ALDI_IGEMM_TILE", 0);
     d.xcd = xcd_env;
+    static const int dbg_env = env_int("ALDI_IGEMM_DBG", 0);
+    d.dbg = dbg_env;
     const int ep = Elem<T>::kPer16B;
     // deep K slab (two MFMA k-steps per barrier) only when the K loop is long enough to amortise the halved occupancy
     bool deep = kc_env == 8;                       // 3-deep LDS ring: shallow (64-B) slabs keep 3 workgroups per CU
@@ -373,6 +404,9 @@ int dispatch(ConvDev& d, hipStream_t st) {
     // the N=2 micro-batch leaves the deep layers (res4/res5, FC heads) with far fewer 128x128 tiles than the
     // 256 CUs: fall back to 64x64 tiles (4x the workgroups) when the big tiling cannot fill the chip
     const long big = (long)cdiv(d.M, 128) * cdiv(d.Cout, 128);
+    if (tile_env == 1 && big >= 1024) return launch<T, 256, 128, 4, 2, 4>(d, st);
+    if (tile_env == 2 && big >= 1024 && d.Cout >= 256) return launch<T, 128, 256, 2, 4, 4>(d, st);
+    if (tile_env == 3 && big >= 2048 && d.Cout >= 256) return launch<T, 256, 256, 4, 4, 4>(d, st);
     if (big < 200) return deep ? launch<T, 64, 64, 2, 2, 8>(d, st) : launch<T, 64, 64, 2, 2, 4>(d, st);
     return deep ? launch<T, 128, 128, 2, 2, 8>(d, st) : launch<T, 128, 128, 2, 2, 4>(d, st);
 }

@@ -76,13 +76,17 @@ def profile_dense(trainer, step_fn, table_path=None):
             kw2["out"] = y
         key = ("igemm", N, H, W_, Cin, Cout, KH, s, p, kw.get("res_mode", 0), bool(kw.get("relu")), kw.get("mask") is not None,
                kw.get("out_scale", 1), bool(kw.get("want_f32")))
-        rec.append((key, 2.0 * N * Ho * Wo * Cout * KH * KW * Cin, lambda: orig_conv(x, w, **kw2)))
+        esz = x.element_size()
+        nby = esz * (x.numel() + w.numel() + N * Ho * Wo * Cout * kw.get("out_scale", 1) ** 2 * (2 if kw.get("mask") is not None else 1)
+                     + (N * Ho * Wo * Cout // (4 if kw.get("res_mode", 0) == 2 else 1) if kw.get("res_mode", 0) else 0))
+        rec.append((key, 2.0 * N * Ho * Wo * Cout * KH * KW * Cin, lambda: orig_conv(x, w, **kw2), nby))
         return y
 
     def conv_wgrad(x, g, dw, **kw):
         orig_wg(x, g, dw, **kw)
         key = ("wgrad",) + tuple(x.shape) + (g.shape[3], kw["KH"], kw.get("stride", 1), kw.get("pad", 0))
-        rec.append((key, 2.0 * g.numel() * kw["KH"] * kw["KW"] * x.shape[3], lambda: orig_wg(x, g, dw, **kw)))
+        rec.append((key, 2.0 * g.numel() * kw["KH"] * kw["KW"] * x.shape[3], lambda: orig_wg(x, g, dw, **kw),
+                    x.element_size() * (x.numel() + g.numel()) + 4 * dw.numel()))
     ops.conv2d, ops.conv_wgrad = conv2d, conv_wgrad
     try:
         step_fn()
@@ -90,8 +94,8 @@ def profile_dense(trainer, step_fn, table_path=None):
     finally:
         ops.conv2d, ops.conv_wgrad = orig_conv, orig_wg
     shapes = {}
-    for key, fl, fn in rec:
-        e = shapes.setdefault(key, {"count": 0, "flops": fl, "fn": fn})
+    for key, fl, fn, nby in rec:
+        e = shapes.setdefault(key, {"count": 0, "flops": fl, "fn": fn, "bytes": nby})
         e["count"] += 1
     REP = 5
     for key, e in shapes.items():
@@ -107,7 +111,8 @@ def profile_dense(trainer, step_fn, table_path=None):
     for fam in ("igemm", "wgrad"):
         sel = [e for k, e in shapes.items() if k[0] == fam]
         out[fam] = {"launches": sum(e["count"] for e in sel), "flops": sum(e["count"] * e["flops"] for e in sel),
-                    "ms": sum(e["count"] * e["us"] for e in sel) / 1e3, "shapes": len(sel)}
+                    "ms": sum(e["count"] * e["us"] for e in sel) / 1e3, "shapes": len(sel),
+                    "bytes": sum(e["count"] * e["bytes"] for e in sel)}
     if table_path:
         os.makedirs(os.path.dirname(table_path), exist_ok=True)
         with open(table_path, "w") as f:
@@ -239,8 +244,18 @@ def main():
         prof = profile_dense(tr, one_step, os.path.join(ROOT, "gpurun_out", "dense_profile.txt"))
         ig = prof["igemm"]
         ach = ig["flops"] / (ig["ms"] * 1e-3) / 1e12 if ig["ms"] > 0 else 0.0
+        # HBM traffic cannot be read from inside the process: it comes from the separate rocprofv3 --pmc passes of this same
+        # command (tools/profile_step.sh; FETCH_SIZE x2 gfx950 correction + WRITE_SIZE), committed under profiles/.
+        traffic = None
+        try:
+            with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
+                traffic = round(json.load(f)["igemm"]["hbm_bytes_per_launch"])
+        except (OSError, KeyError, ValueError):
+            pass
         out["roofline"] = {"bound": "mfma", "kernel": "igemm_kernel<bf16> (conv fwd + dgrad + FC)", "achieved": round(ach, 2), "peak": PEAK_BF16_TFLOPS,
-                           "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": None,
+                           "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
+                           "traffic_unit": "HBM bytes per igemm launch (rocprofv3 PMC passes, profiles/r01_pmc_traffic.json)",
+                           "algorithmic_bytes_per_launch": round(ig["bytes"] / max(ig["launches"], 1)),
                            "launches_per_step": ig["launches"], "kernel_ms_per_step": round(ig["ms"], 3),
                            "avg_launch_us": round(ig["ms"] * 1e3 / max(ig["launches"], 1), 2),
                            "algorithmic_tflop_per_step_in_kernel": round(ig["flops"] / 1e12, 3),

@@ -12,9 +12,17 @@ w = (torch.randn(Cout, k, k, Cin, device="cuda", generator=g) / (Cin * k * k) **
 y = torch.empty(N, H, W, Cout, device="cuda", dtype=torch.bfloat16)
 gy = torch.randn(N, H, W, Cout, device="cuda", generator=g).bfloat16()
 dw = torch.zeros(Cout, k, k, Cin, device="cuda")
-for _ in range(reps):
+def run():
     if wg:
         ops.conv_wgrad(x, gy, dw, KH=k, KW=k, stride=1, pad=k // 2)
     else:
         ops.conv2d(x, w, pad=k // 2, out=y, relu=True)
+run()
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record()
+for _ in range(reps):
+    run()
+e1.record()
 torch.cuda.synchronize()
+us = e0.elapsed_time(e1) * 1e3 / reps
+print("%s %s: %.1f us  %.1f TFLOP/s" % ("wgrad" if wg else "igemm", sys.argv[1:7], us, 2.0 * N * H * W * Cin * Cout * k * k / us / 1e6))

@@ -1,0 +1,63 @@
+"""Summarise rocprofv3 output of `bench.py` per ALDI step (test/measurement tooling, not product code).
+
+usage: rocprof_summary.py stats <dir> <title>          kernel-trace: per-kernel table for ONE step (between two sgd_kernel launches)
+       rocprof_summary.py pmc <fetch_dir> <write_dir>  PMC passes: per-launch HBM traffic of the igemm / wgrad kernels -> JSON
+"""
+import collections
+import csv
+import glob
+import json
+import sqlite3
+import sys
+
+
+def stats(d, title):
+    dbs = glob.glob(d + "/**/*_results.db", recursive=True)
+    con = sqlite3.connect(dbs[0])
+    cur = con.cursor()
+    tabs = [r[0] for r in cur.execute("select name from sqlite_master where type in ('table','view')")]
+    kt = "kernels" if "kernels" in tabs else [t for t in tabs if "kernel_dispatch" in t][0]
+    cols = [r[1] for r in cur.execute(f"pragma table_info({kt})")]
+    name = "name" if "name" in cols else "kernel_name"
+    rows = list(cur.execute(f"select {name}, start, end from {kt} order by start"))
+    sgd = [i for i, r in enumerate(rows) if "sgd_kernel" in r[0]]
+    a, b = sgd[-2], sgd[-1]
+    step = rows[a + 1:b + 1]
+    wall = (rows[b][2] - rows[a][2]) / 1e6
+    agg = collections.defaultdict(lambda: [0, 0.0])
+    for n, s, e in step:
+        agg[n][0] += 1
+        agg[n][1] += (e - s) / 1e3
+    busy = sum(v[1] for v in agg.values())
+    print(f"# {title}")
+    print(f"# one ALDI step (between two sgd_kernel launches): wall {wall:.2f} ms (under the profiler), GPU kernel busy {busy / 1e3:.2f} ms, {len(step)} kernel launches")
+    print("%-100s %6s %10s %10s %6s" % ("kernel", "calls", "total_us", "avg_us", "pct"))
+    for n, (c, t) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+        print("%-100s %6d %10.1f %10.1f %6.1f" % (n[:100], c, t, t / c, 100 * t / busy))
+
+
+def pmc(fetch_dir, write_dir):
+    res = {}
+    for key, d, ctr in (("fetch", fetch_dir, "FETCH_SIZE"), ("write", write_dir, "WRITE_SIZE")):
+        per = collections.defaultdict(list)
+        for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
+            for r in csv.DictReader(open(f)):
+                if r["Counter_Name"] != ctr:
+                    continue
+                k = "igemm" if "igemm_kernel" in r["Kernel_Name"] else "wgrad" if "wgrad_bf16" in r["Kernel_Name"] else None
+                if k:
+                    per[k].append(float(r["Counter_Value"]))
+        res[key] = {k: (sum(v) / len(v), len(v)) for k, v in per.items()}
+    out = {}
+    for k in ("igemm", "wgrad"):
+        f, nf = res["fetch"].get(k, (0, 0))
+        w, nw = res["write"].get(k, (0, 0))
+        # rocprofv3 reports FETCH_SIZE / WRITE_SIZE in KiB-like units of 1 KB on this stack; gfx950 FETCH_SIZE counts 128-B
+        # requests at 64 B (MI355X_MICROARCH.md "HBM"): double it.  WRITE_SIZE is used as reported (uncalibrated).
+        out[k] = {"fetch_size_raw_kb_per_launch": f, "write_size_raw_kb_per_launch": w, "launches_fetch_pass": nf, "launches_write_pass": nw,
+                  "hbm_bytes_per_launch": (2.0 * f + w) * 1024.0}
+    print(json.dumps(out, indent=1))
+
+
+if __name__ == "__main__":
+    {"stats": stats, "pmc": pmc}[sys.argv[1]](*sys.argv[2:])
