@@ -48,25 +48,52 @@ __device__ __forceinline__ void glds16(__amdgpu_buffer_rsrc_t rsrc, uint4* dst, 
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)dst, 16, voff, 0, 0, 0);
 }
 
+typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));   // one 16-B LDS fragment (4 VGPRs)
+
+// Fragment reads are hand-issued `ds_read_b128`: behind an LDS-DMA in flight the compiler cannot tell which ring slot a
+// C++ LDS load aliases and drains the whole DMA queue (`s_waitcnt vmcnt(0)`) before the first read of every K slab,
+// which serialises loads and MFMAs inside a wave.  The asm reads are invisible to that scoreboard; frag_wait() is the
+// matching hand-placed lgkmcnt wait, tied to the fragments by "+v" so no MFMA can be scheduled above it.
+__device__ __forceinline__ unsigned lds_addr(const void* p) {
+    return (unsigned)(uintptr_t)(const __attribute__((address_space(3))) void*)p;
+}
+template <int OFF>
+__device__ __forceinline__ u32x4_t frag_read(unsigned addr) {
+    u32x4_t v;
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
+    return v;
+}
+
+template <int N, int ROWB, int I = 0>
+__device__ __forceinline__ void frag_read_all(u32x4_t* f, unsigned addr) {   // fragments of rows 16 apart
+    if constexpr (I < N) {
+        f[I] = frag_read<I * 16 * ROWB>(addr);
+        frag_read_all<N, ROWB, I + 1>(f, addr);
+    }
+}
+template <int NA, int NB>
+__device__ __forceinline__ void frag_wait(u32x4_t* a, u32x4_t* b) {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int i = 0; i < NA; ++i) asm volatile("" : "+v"(a[i]));
+#pragma unroll
+    for (int i = 0; i < NB; ++i) asm volatile("" : "+v"(b[i]));
+}
 template <typename T> struct Mma;
 template <> struct Mma<bf16_t> {
-    __device__ static __forceinline__ f32x4_t run(const uint4& a, const uint4& b, f32x4_t c) {
-        bf16x8_t av = *reinterpret_cast<const bf16x8_t*>(&a);
-        bf16x8_t bv = *reinterpret_cast<const bf16x8_t*>(&b);
-        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, bv, c, 0, 0, 0);
+    __device__ static __forceinline__ f32x4_t run(const u32x4_t& a, const u32x4_t& b, f32x4_t c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
     }
 };
 template <> struct Mma<float> {
-    __device__ static __forceinline__ f32x4_t run(const uint4& a, const uint4& b, f32x4_t c) {
-        const float* af = reinterpret_cast<const float*>(&a);
-        const float* bf = reinterpret_cast<const float*>(&b);
+    __device__ static __forceinline__ f32x4_t run(const u32x4_t& a, const u32x4_t& b, f32x4_t c) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) c = __builtin_amdgcn_mfma_f32_16x16x4f32(af[j], bf[j], c, 0, 0, 0);
+        for (int j = 0; j < 4; ++j) c = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a[j]), __uint_as_float(b[j]), c, 0, 0, 0);
         return c;
     }
 };
 
-template <typename T, int BM, int BN, int WM, int WN, int KC>
+template <typename T, int BM, int BN, int WM, int WN, int KC, bool PIPE>
 __global__ __launch_bounds__(WM* WN * 64) void igemm_kernel(ConvDev p) {
     constexpr int NT = WM * WN * 64;
     constexpr int EP = Elem<T>::kPer16B;           // elements per 16-B chunk
@@ -78,7 +105,7 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_kernel(ConvDev p) {
     static_assert((BM * KC) % NT == 0, "tile/threads mismatch");
 
     constexpr int NBUF = 3;                        // LDS ring: two slabs of DMA in flight across the barrier
-    __shared__ uint4 lds[NBUF][(BM + BN) * KC];
+    __shared__ __attribute__((aligned(128))) uint4 lds[NBUF][(BM + BN) * KC];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
@@ -154,7 +181,9 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_kernel(ConvDev p) {
         for (int it = 0; it < A_IT; ++it) {
             bool ok = (a_mask[it] >> tap) & 1u;
             if (ktail) ok = ok && (ci0 + a_kce[it] < p.Cin);
-            glds16(rx, &lds[buf][wbase + it * NT], ok ? a_voff[it] + tap_off : OOB);
+            unsigned vo = ok ? a_voff[it] + tap_off : OOB;
+            if (p.dbg & 16) vo &= 0xfffu;
+            glds16(rx, &lds[buf][wbase + it * NT], vo);
         }
         const unsigned k_off = (unsigned)(s * BK) * (unsigned)sizeof(T);
 #pragma unroll
@@ -162,6 +191,7 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_kernel(ConvDev p) {
             if (wbase + it * NT < BN * KC) {                               // wave-uniform
                 unsigned off = b_voff[it] == OOB ? OOB : b_voff[it] + k_off;
                 if (ktail && s * BK + b_kce[it] >= p.K) off = OOB;
+                if (p.dbg & 16) off &= 0xfffu;
                 glds16(rw, &lds[buf][BM * KC + wbase + it * NT], off);
             }
         }
@@ -175,44 +205,78 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_kernel(ConvDev p) {
 #pragma unroll
         for (int j = 0; j < TN; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
-    // Pipeline: slab s+2 is issued while slab s is computed, slab s+1 is in flight across the barrier.  The wait is a
-    // COUNTED vmcnt (every wave waits for its own DMA pieces of slab s, leaving slab s+1's outstanding) followed by a raw
-    // s_barrier: __syncthreads() would drain the DMA queue (vmcnt(0)) at every slab (cdna_hip_programming.md section 5).
-    // WAR: slab s+2 overwrites the buffer read while computing slab s-1; it is issued after the barrier of iteration s,
-    // which every wave passes only after finishing slab s-1.
+    // Software pipeline, three levels deep (NBUF = 3 LDS slabs + two fragment register sets):
+    //   iteration s:  wait for MY DMA pieces of slab s+1 (counted vmcnt: slab s+2 stays in flight) -> raw s_barrier (slab s+1
+    //   visible, everyone is done reading slab s) -> issue the fragment reads of slab s+1 into the spare register set ->
+    //   issue the DMA of slab s+3 into the buffer slab s just vacated -> 16 MFMAs on slab s from registers -> lgkmcnt wait.
+    // So the LDS read latency and the DMA both run under the MFMAs of the same wave, not only under other waves'.
+    // __syncthreads() would drain the DMA queue (vmcnt(0)) at every slab (cdna_hip_programming.md section 5).
+    static_assert(KC == 4, "the register-pipelined loop reads one k-step (4 chunks) per slab");
     constexpr int N_DMA = A_IT + (BN * KC) / NT;   // DMA instructions per slab of the wave that issues the fewest
     const int S = (p.dbg & 8) ? 1 : (p.K + BK - 1) / BK;
     issue_slab(0, 0);
     if (S > 1) issue_slab(1, 1);
     const int fr = lane & 15, fq = lane >> 4;
+    constexpr unsigned SLAB_BYTES = (BM + BN) * KC * 16;
+    const int xrow = wm * (BM / WM) + fr, wrow = wn * (BN / WN) + fr;
+    const unsigned x_rd0 = lds_addr(&lds[0][0]) + (unsigned)(xrow * KC + swz<KC>(xrow, fq)) * 16u;
+    const unsigned w_rd0 = lds_addr(&lds[0][0]) + (unsigned)((BM + wrow) * KC + swz<KC>(wrow, fq)) * 16u;
+    if constexpr (PIPE) {
+    if (S > 2) issue_slab(2, 2);
+    u32x4_t xf0[TM], wf0[TN], xf1[TM], wf1[TN];
+    if (S > 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * N_DMA) : "memory");
+    else if (S > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N_DMA) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    frag_read_all<TM, KC * 16>(xf0, x_rd0);
+    frag_read_all<TN, KC * 16>(wf0, w_rd0);
+    frag_wait<TM, TN>(xf0, wf0);
+    int rbuf = 1, ibuf = 0;                         // buffer of slab s+1 (next reads) / of slab s (next DMA target)
+    auto step = [&](int s, u32x4_t* xc, u32x4_t* wc, u32x4_t* xn, u32x4_t* wn_) {
+        const bool more = s + 1 < S;
+        if (more) {
+            if (s + 2 < S) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N_DMA) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            frag_read_all<TM, KC * 16>(xn, x_rd0 + (unsigned)rbuf * SLAB_BYTES);
+            frag_read_all<TN, KC * 16>(wn_, w_rd0 + (unsigned)rbuf * SLAB_BYTES);
+            if (s + 3 < S) issue_slab(s + 3, ibuf);
+        }
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) acc[i][j] = Mma<T>::run(wc[j], xc[i], acc[i][j]);
+        if (more) frag_wait<TM, TN>(xn, wn_);
+        rbuf = rbuf == NBUF - 1 ? 0 : rbuf + 1;
+        ibuf = ibuf == NBUF - 1 ? 0 : ibuf + 1;
+    };
+    for (int s = 0; s < S; s += 2) {
+        step(s, xf0, wf0, xf1, wf1);
+        if (s + 1 < S) step(s + 1, xf1, wf1, xf0, wf0);
+    }
+    } else {
+    // two-level form (no fragment double buffering): slab s+2 is issued while slab s is computed; used by the 8-wave
+    // tile, where the extra fragment registers and issue slots cost more than the in-wave overlap returns
     int buf = 0, nbuf = 2;
     for (int s = 0; s < S; ++s) {
         if (s + 1 < S) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N_DMA) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
-        if (s + 2 < S && !(p.dbg & 1)) issue_slab(s + 2, nbuf);
-        if (!(p.dbg & 2))
+        if (s + 2 < S) issue_slab(s + 2, nbuf);
+        u32x4_t xf[TM], wf[TN];
+        frag_read_all<TM, KC * 16>(xf, x_rd0 + (unsigned)buf * SLAB_BYTES);
+        frag_read_all<TN, KC * 16>(wf, w_rd0 + (unsigned)buf * SLAB_BYTES);
+        frag_wait<TM, TN>(xf, wf);
 #pragma unroll
-        for (int ks = 0; ks < KC / 4; ++ks) {
-            uint4 xf[TM], wf[TN];
+        for (int i = 0; i < TM; ++i)
 #pragma unroll
-            for (int i = 0; i < TM; ++i) {
-                int row = wm * (BM / WM) + i * 16 + fr;
-                xf[i] = lds[buf][row * KC + swz<KC>(row, ks * 4 + fq)];
-            }
-#pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                int row = wn * (BN / WN) + j * 16 + fr;
-                wf[j] = lds[buf][(BM + row) * KC + swz<KC>(row, ks * 4 + fq)];
-            }
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j) acc[i][j] = Mma<T>::run(wf[j], xf[i], acc[i][j]);
-        }
+            for (int j = 0; j < TN; ++j) acc[i][j] = Mma<T>::run(wf[j], xf[i], acc[i][j]);
         buf = buf == NBUF - 1 ? 0 : buf + 1;
         nbuf = nbuf == NBUF - 1 ? 0 : nbuf + 1;
+    }
     }
 
     if (p.dbg & 4) return;
@@ -374,10 +438,10 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_kernel(ConvDev p) {
     }
 }
 
-template <typename T, int BM, int BN, int WM, int WN, int KC>
+template <typename T, int BM, int BN, int WM, int WN, int KC, bool PIPE = true>
 int launch(const ConvDev& d, hipStream_t st) {
     dim3 grid(cdiv(d.M, BM), cdiv(d.Cout, BN));
-    hipLaunchKernelGGL((igemm_kernel<T, BM, BN, WM, WN, KC>), grid, dim3(WM * WN * 64), 0, st, d);
+    hipLaunchKernelGGL((igemm_kernel<T, BM, BN, WM, WN, KC, PIPE>), grid, dim3(WM * WN * 64), 0, st, d);
     ALDI_CHECK_LAUNCH();
     return ALDI_OK;
 }
@@ -389,26 +453,23 @@ static int env_int(const char* name, int dflt) {
 
 template <typename T>
 int dispatch(ConvDev& d, hipStream_t st) {
-    static const int kc_env = env_int("ALDI_IGEMM_KC", 0);     // tuning knobs (0 = heuristic)
     static const int xcd_env = env_int("ALDI_IGEMM_XCD", 1);
     static const int tile_env = env_int("ALDI_IGEMM_TILE", 0);
     d.xcd = xcd_env;
     static const int dbg_env = env_int("ALDI_IGEMM_DBG", 0);
     d.dbg = dbg_env;
     const int ep = Elem<T>::kPer16B;
-    // deep K slab (two MFMA k-steps per barrier) only when the K loop is long enough to amortise the halved occupancy
-    bool deep = kc_env == 8;                       // 3-deep LDS ring: shallow (64-B) slabs keep 3 workgroups per CU
-    if (d.KH * d.KW > 1 && d.Cin % (8 * ep) != 0) deep = false;
     if (d.Cout <= 16) return launch<T, 128, 16, 4, 1, 4>(d, st);
-    if (d.Cout <= 64) return deep ? launch<T, 128, 64, 4, 1, 8>(d, st) : launch<T, 128, 64, 4, 1, 4>(d, st);
+    if (d.Cout <= 64) return launch<T, 128, 64, 4, 1, 4>(d, st);
     // the N=2 micro-batch leaves the deep layers (res4/res5, FC heads) with far fewer 128x128 tiles than the
     // 256 CUs: fall back to 64x64 tiles (4x the workgroups) when the big tiling cannot fill the chip
     const long big = (long)cdiv(d.M, 128) * cdiv(d.Cout, 128);
-    if (tile_env == 1 && big >= 1024) return launch<T, 256, 128, 4, 2, 4>(d, st);
-    if (tile_env == 2 && big >= 1024 && d.Cout >= 256) return launch<T, 128, 256, 2, 4, 4>(d, st);
-    if (tile_env == 3 && big >= 2048 && d.Cout >= 256) return launch<T, 256, 256, 4, 4, 4>(d, st);
-    if (big < 200) return deep ? launch<T, 64, 64, 2, 2, 8>(d, st) : launch<T, 64, 64, 2, 2, 4>(d, st);
-    return deep ? launch<T, 128, 128, 2, 2, 8>(d, st) : launch<T, 128, 128, 2, 2, 4>(d, st);
+    // long-K convs with thousands of tiles are bound by the L2 -> CU path (~31 B/clk/CU measured): the 256x128 tile
+    // (8 waves) moves 25 % fewer bytes per flop
+    static const int big_tile_min = env_int("ALDI_IGEMM_BIGTILE_MIN", 1024);
+    if (tile_env != 9 && big >= big_tile_min && d.K >= 1024) return launch<T, 256, 128, 4, 2, 4, false>(d, st);
+    if (big < 200) return launch<T, 64, 64, 2, 2, 4>(d, st);
+    return launch<T, 128, 128, 2, 2, 4>(d, st);
 }
 
 }  // namespace

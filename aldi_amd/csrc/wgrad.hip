@@ -18,13 +18,14 @@
 // aldi/trainer.py:79 (`trainer.do_backward`).
 #include "common.h"
 #include <hip/amd_detail/amd_hip_unsafe_atomics.h>
+#include <stdlib.h>
 
 namespace {
 
 struct WgDev {
     const void* x; const void* g; float* dw; const float* scale;
     int N, H, W, Cin, Cout, KH, KW, stride, pad, Ho, Wo;
-    int M, K, pix_per_split, ident;
+    int M, K, pix_per_split, ident, xcd;
     unsigned x_bytes, g_bytes;
 };
 
@@ -49,7 +50,7 @@ __device__ __forceinline__ void transpose8x8_b16(const uint4 in[8], uint4 out[8]
 __global__ __launch_bounds__(256) void wgrad_bf16_kernel(WgDev p) {
     constexpr int BP = 64;
     __shared__ uint4 lds[2 * 128 * 8];   // [A rows 0..127 | B rows 0..127] x 8 chunks (32 KB)
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // uniform loader role
     const int co0 = blockIdx.x * 128, kk0 = blockIdx.y * 128;
     const int pbeg = blockIdx.z * p.pix_per_split;
     const int pend = min(p.M, pbeg + p.pix_per_split);
@@ -78,8 +79,12 @@ __global__ __launch_bounds__(256) void wgrad_bf16_kernel(WgDev p) {
 
     // raw buffer loads: 32-bit byte offsets, out-of-range offsets return zeros (no branches around the loads)
     typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-    const __amdgpu_buffer_rsrc_t rsrc = isB ? __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(X), 0, p.x_bytes, 0x00020000)
-                                            : __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(G), 0, p.g_bytes, 0x00020000);
+    // built from wave-uniform scalars only: a descriptor the compiler believes divergent costs a waterfall loop per load
+    const uintptr_t base = reinterpret_cast<uintptr_t>(isB ? p.x : p.g);
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        reinterpret_cast<void*>(((uintptr_t)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)(base >> 32)) << 32) |
+                                (uintptr_t)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)base)),
+        0, __builtin_amdgcn_readfirstlane(isB ? p.x_bytes : p.g_bytes), 0x00020000);
     constexpr unsigned OOB = 0x80000000u;
     const int row_elems = isB ? p.Cin : p.Cout;
     uint4 in[8], out[8];
@@ -154,6 +159,177 @@ __global__ __launch_bounds__(256) void wgrad_bf16_kernel(WgDev p) {
                 if (kk < p.K) unsafeAtomicAdd(p.dw + (long)co * p.K + kk, acc[i][j][r] * sc);
             }
         }
+}
+
+// Lean form of the same kernel for the shapes the network actually has (1x1 stride-1 convs / FC, and stride-1 "same"
+// KxK convs with Cin % 64 == 0).  wgrad_bf16_kernel above spends ~800 instructions per 32 MFMAs (64-bit gather addresses,
+// per-load border tests, mask/shift/or transposes); wave64 VALU ops cost 4 cycles each, so it is issue bound at ~14 % of
+// the MFMA peak.  Here:
+//   * "same" geometry makes the tap offset linear in the pixel index: offset = (pixel + dh*W + dw) * Cin + ci, mod 2^32;
+//   * border validity depends on the pixel only and the tap is wave uniform (Cin % 64 == 0), so each lane tracks ONE pixel
+//     of the slab incrementally, the wave ballots, and the per-load lane mask is a byte of the ballot replicated on the
+//     scalar unit -> one v_cndmask per load picks the out-of-range offset (buffer loads return zeros there);
+//   * the g operand needs no tests at all: its buffer descriptor ends at the split's last pixel;
+//   * the 8x8 16-bit transposes are v_perm_b32, one per output register.
+__device__ __forceinline__ void wgrad_bf16_lean_body(const WgDev& p, uint4* lds) {
+    constexpr int BP = 64;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform role -> scalar descriptors
+    // XCD-aware order: workgroup b runs on XCD b % 8; give every XCD a contiguous range of (split, tile) pairs, tile
+    // fastest, so the tiles of one pixel range (which re-read the same x / g rows) share one L2.
+    int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+    {
+        const int gx = gridDim.x, gy = gridDim.y, total = gx * gy * gridDim.z;
+        int bid = bx + gx * (by + gy * bz);
+        if (p.xcd) {
+            const int q = total >> 3, r = total & 7, xcd = bid & 7, idx = bid >> 3;
+            bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+        }
+        bx = bid % gx; bid /= gx;
+        by = bid % gy; bz = bid / gy;
+    }
+    const int co0 = bx * 128, kk0 = by * 128;
+    const int pbeg = bz * p.pix_per_split;
+    const int pend = min(p.M, pbeg + p.pix_per_split);
+    if (pbeg >= pend) return;
+
+    const bool isB = wave >= 2;                      // waves 0,1 load the g tile, waves 2,3 the x tile
+    const int pg = lane & 7;                         // 8-pixel group inside the slab
+    const int cc = (wave & 1) * 8 + (lane >> 3);     // 8-channel chunk inside the 128-wide tile
+    constexpr unsigned OOB = 0x80000000u;
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+    // per-lane byte offset of (pixel pbeg + pg*8, this lane's channel chunk); later pixels / slabs are uniform adds
+    unsigned off0;
+    int dh = 0, dw = 0;
+    if (!isB) {
+        const int ch = co0 + cc * 8;
+        off0 = ch < p.Cout ? ((unsigned)(pbeg + pg * 8) * (unsigned)p.Cout + (unsigned)ch) * 2u : OOB;
+    } else {
+        const int ch = kk0 + cc * 8;
+        const int tap = ch / p.Cin, ci = ch - tap * p.Cin;
+        const int kh = tap / p.KW, kw = tap - kh * p.KW;
+        dh = kh - p.pad; dw = kw - p.pad;
+        off0 = ch < p.K ? ((unsigned)(pbeg + pg * 8 + dh * p.W + dw) * (unsigned)p.Cin + (unsigned)ci) * 2u : OOB;
+    }
+    // everything the load instructions take from scalar registers is built from wave-uniform values only (a descriptor the
+    // compiler believes divergent costs a readfirstlane "waterfall" loop around every load)
+    const bool track = isB && !p.ident;             // border validity needed (KxK x-loader waves)
+    const unsigned row_bytes = (unsigned)(isB ? p.Cin : p.Cout) * 2u;
+    const unsigned g_lim = (unsigned)pend * (unsigned)p.Cout * 2u;    // g rows >= pend read as zeros
+    const unsigned lim = isB ? p.x_bytes : (g_lim < p.g_bytes ? g_lim : p.g_bytes);
+    const uintptr_t base = reinterpret_cast<uintptr_t>(isB ? p.x : p.g);
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        reinterpret_cast<void*>(((uintptr_t)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)(base >> 32)) << 32) |
+                                (uintptr_t)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)base)),
+        0, __builtin_amdgcn_readfirstlane(lim), 0x00020000);
+    // the pixel this lane tracks for the ballot: bit l of the ballot <-> slab pixel (l&7)*8 + (l>>3)
+    int ho = 0, wo = 0;
+    if (track) {
+        int q = pbeg + pg * 8 + (lane >> 3);
+        int r = q % (p.H * p.W);
+        ho = r / p.W; wo = r - ho * p.W;
+    }
+    const int adv_h = BP / p.W, adv_w = BP - adv_h * p.W;
+
+    uint4 in[8], out[8];
+    unsigned off = off0;
+    auto load_slab = [&]() {
+        unsigned long long bal = ~0ull;
+        if (track) {
+            bal = __ballot((unsigned)(ho + dh) < (unsigned)p.H && (unsigned)(wo + dw) < (unsigned)p.W);
+            wo += adv_w; ho += adv_h;
+            if (wo >= p.W) { wo -= p.W; ++ho; }
+            while (ho >= p.H) ho -= p.H;
+        }
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            unsigned o = off + (unsigned)r * row_bytes;
+            if (track) {
+                const unsigned half = __builtin_amdgcn_readfirstlane((unsigned)(bal >> (r < 4 ? 0 : 32)));
+                const unsigned rep = ((half >> (8 * (r & 3))) & 0xffu) * 0x01010101u;                 // scalar unit
+                const unsigned long long lm = ((unsigned long long)rep << 32) | rep;
+                asm volatile("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(o) : "v"(OOB), "v"(o), "s"(lm));
+            }
+            u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, o, 0, 0);
+            in[r] = make_uint4(v.x, v.y, v.z, v.w);
+        }
+        off += BP * row_bytes;
+    };
+
+    const int wm = wave >> 1, wn = wave & 1;
+    f32x4_t acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    const int fr = lane & 15, fq = lane >> 4;
+    // LDS slots are loop invariant and differ only by immediates / one XOR: fragment rows i*16 apart share the swizzle
+    // term ((row>>1)&7 sees only fr), the second k-step flips chunk bit 2; write rows c share pg ^ (cc&1)*4 up to c>>1.
+    const int ra = wm * 64 + fr, rb = wn * 64 + fr;
+    const int ia0 = ra * 8 + swz8(ra, fq);
+    const int ib0 = (128 + rb) * 8 + swz8(rb, fq);
+    const int iw = ((isB ? 128 : 0) + cc * 8) * 8;
+    const int wu = pg ^ ((cc & 1) << 2);
+
+    load_slab();
+    for (int p0 = pbeg; p0 < pend; p0 += BP) {
+        {   // out[c] = pixels 0..7 of channel c
+            const uint32_t* rr = reinterpret_cast<const uint32_t*>(in);
+            uint32_t* oo = reinterpret_cast<uint32_t*>(out);
+#pragma unroll
+            for (int d = 0; d < 4; ++d)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const uint32_t a = rr[(2 * j) * 4 + d], b = rr[(2 * j + 1) * 4 + d];
+                    oo[(2 * d) * 4 + j] = __builtin_amdgcn_perm(b, a, 0x05040100u);       // (a & 0xffff) | (b << 16)
+                    oo[(2 * d + 1) * 4 + j] = __builtin_amdgcn_perm(b, a, 0x07060302u);   // (a >> 16) | (b & 0xffff0000)
+                }
+        }
+        __syncthreads();   // previous slab's fragment reads are done
+#pragma unroll
+        for (int c = 0; c < 8; ++c) lds[iw + c * 8 + (wu ^ (c >> 1))] = out[c];
+        if (p0 + BP < pend) load_slab();   // next slab's global loads fly under this slab's MFMAs
+        __syncthreads();
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            uint4 af[4], bfr[4];
+            const int ia = ia0 ^ (ks * 4), ib = ib0 ^ (ks * 4);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) af[i] = lds[ia + i * 128];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) bfr[j] = lds[ib + j * 128];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<bf16x8_t*>(&af[i]),
+                                                                         *reinterpret_cast<bf16x8_t*>(&bfr[j]), acc[i][j], 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            int co = co0 + wm * 64 + i * 16 + fq * 4 + r;
+            if (co >= p.Cout) continue;
+            float sc = p.scale ? p.scale[co] : 1.f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                int kk = kk0 + wn * 64 + j * 16 + fr;
+                if (kk < p.K) unsafeAtomicAdd(p.dw + (long)co * p.K + kk, acc[i][j][r] * sc);
+            }
+        }
+}
+
+// two register budgets: 3 workgroups per CU (<= 168 VGPRs) for short pixel ranges, where latency hiding comes from
+// occupancy, and the unconstrained schedule (2 per CU, deeper load hoisting) for long ones
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void wgrad_bf16_lean3_kernel(WgDev p) {
+    __shared__ uint4 lds[2 * 128 * 8];
+    wgrad_bf16_lean_body(p, lds);
+}
+__global__ __launch_bounds__(256) void wgrad_bf16_lean2_kernel(WgDev p) {
+    __shared__ uint4 lds[2 * 128 * 8];
+    wgrad_bf16_lean_body(p, lds);
 }
 
 // ------------------------------------------------------------------------------------ fp32
@@ -296,7 +472,10 @@ extern "C" int aldi_conv_wgrad(const aldi_wgrad_args* a, aldi_stream_t stream) {
     const int bp = a->dtype == ALDI_BF16 ? 64 : 16;
     int tiles = cdiv(d.Cout, tile) * cdiv(d.K, tile);
     int slabs = cdiv(d.M, bp);
-    int splits = cdiv(768, tiles);                 // ~3 workgroups per CU in flight ...
+    static const int slots_env = getenv("ALDI_WGRAD_SLOTS") ? atoi(getenv("ALDI_WGRAD_SLOTS")) : 384;
+    // the kernel is bound per CU (L2 -> CU path, LDS), not by latency: few, long splits (1-2 workgroups per CU) beat
+    // many short ones, whose 16K-atomic epilogues also contend on the same dW lines
+    int splits = cdiv(slots_env, tiles);
     if (splits > slabs / 4) splits = slabs / 4;    // ... but at least 4 slabs of work behind every 16K-atomic epilogue
     if (splits < 1) splits = 1;
     if (splits > 512) splits = 512;
@@ -304,7 +483,16 @@ extern "C" int aldi_conv_wgrad(const aldi_wgrad_args* a, aldi_stream_t stream) {
     d.pix_per_split = slabs_per * bp;
     splits = cdiv(d.M, d.pix_per_split);
     dim3 grid(cdiv(d.Cout, tile), cdiv(d.K, tile), splits);
-    if (a->dtype == ALDI_BF16) hipLaunchKernelGGL(wgrad_bf16_kernel, grid, dim3(256), 0, st, d);
+    static const int xcd_env = getenv("ALDI_WGRAD_XCD") ? atoi(getenv("ALDI_WGRAD_XCD")) : 1;
+    d.xcd = xcd_env;
+    static const int lean_env = getenv("ALDI_WGRAD_LEAN") ? atoi(getenv("ALDI_WGRAD_LEAN")) : 1;
+    const bool same = a->stride == 1 && a->Ho == a->H && a->Wo == a->W && 2 * a->pad == a->KH - 1 && a->KH == a->KW && a->Cin % 64 == 0;
+    if (a->dtype == ALDI_BF16 && lean_env && (d.ident || same)) {
+        const bool deep = lean_env == 2;
+        if (deep) hipLaunchKernelGGL(wgrad_bf16_lean2_kernel, grid, dim3(256), 0, st, d);
+        else hipLaunchKernelGGL(wgrad_bf16_lean3_kernel, grid, dim3(256), 0, st, d);
+    }
+    else if (a->dtype == ALDI_BF16) hipLaunchKernelGGL(wgrad_bf16_kernel, grid, dim3(256), 0, st, d);
     else if (a->dtype == ALDI_F32) hipLaunchKernelGGL(wgrad_f32_kernel, grid, dim3(256), 0, st, d);
     else return aldi_set_error_msg(ALDI_ERR_ARG, "conv_wgrad: bad dtype");
     ALDI_CHECK_LAUNCH();
