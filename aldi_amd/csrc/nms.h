@@ -42,57 +42,96 @@ static __global__ __launch_bounds__(64) void nms_mask_kernel(const float4* __res
     if (i < n) mask[((long)b * cap + i) * (cap / 64) + cb] = bits;
 }
 
-// one wave per batch item: sequential resolution in 64-box chunks
-static __global__ __launch_bounds__(64) void nms_scan_kernel(const unsigned long long* __restrict__ mask, const int* __restrict__ valid,
-                                                      const int* __restrict__ count, int cap, int max_keep,
-                                                      int* __restrict__ keep /*[B][cap]*/, int* __restrict__ keep_count) {
-    extern __shared__ unsigned long long removed[];   // cap/64 words
-    const int b = blockIdx.x, lane = threadIdx.x;
+// One 1024-thread workgroup per batch item; greedy resolution in 64-box chunks.  The chain is serial by nature, so the
+// kernel is built around its latency: wave 0 resolves a chunk entirely on the scalar unit (readlane with constant lane
+// ids), while ALL 16 waves hold that chunk's suppression rows for the later words in registers -- loaded one chunk ahead,
+// unconditionally (64 rows x words x 8 B), so no global load sits on the chain -- and fold the kept rows into
+// `removed` with a 6-step wave OR-reduction.
+template <int KMAX>   // 64-bit row words per thread: ceil((cap/64 - 1) / 16)
+static __global__ __launch_bounds__(1024) void nms_scan_kernel(const unsigned long long* __restrict__ mask, const int* __restrict__ valid,
+                                                               const int* __restrict__ count, int cap, int max_keep,
+                                                               int* __restrict__ keep /*[B][cap]*/, int* __restrict__ keep_count) {
+    extern __shared__ unsigned long long removed[];   // cap/64 words, then [kept word, nk]
+    constexpr int NW = 16;
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int n = count ? count[b] : cap;
     const int words = cap / 64;
-    for (int w = lane; w < words; w += 64) removed[w] = 0;
+    unsigned long long* kept_sh = removed + words;
+    for (int w = tid; w < words + 2; w += 1024) removed[w] = 0;
+    const int chunks = (n + 63) / 64;
+    const unsigned long long* mrow = mask + (long)b * cap * words;
+    unsigned long long cur[KMAX], nxt[KMAX], diag_cur = 0, diag_nxt = 0;
+    int v_cur = 0, v_nxt = 0;
+    auto load_rows = [&](int c, unsigned long long* r, unsigned long long& diag, int& v) {
+        const int i = c * 64 + lane;
+        const bool in = i < n;
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k) {
+            const int w = c + 1 + wave + k * NW;
+            r[k] = (in && w < words) ? mrow[(long)i * words + w] : 0ull;
+        }
+        if (wave == 0) {
+            diag = in ? mrow[(long)i * words + c] : 0ull;
+            v = in ? valid[(long)b * cap + i] : 0;
+        }
+    };
+    if (chunks > 0) load_rows(0, cur, diag_cur, v_cur);
     __syncthreads();
     int nk = 0;
-    const int chunks = (n + 63) / 64;
-    for (int c = 0; c < chunks && nk < max_keep; ++c) {
-        const int i = c * 64 + lane;
-        const bool v = i < n && valid[(long)b * cap + i];
-        const unsigned long long diag = (i < n) ? ((c * 64 <= i) ? mask[((long)b * cap + i) * words + c] : 0ull) : 0ull;
-        unsigned long long rem = removed[c];
-        unsigned long long inval = ~__ballot(v);
-        rem |= inval;
-        // resolve inside the chunk: box t survives iff not removed when reached
-        unsigned long long kept = 0;
-        for (int t = 0; t < 64; ++t) {
-            unsigned long long dt = __shfl(diag, t, 64);
-            if (!((rem >> t) & 1ull)) { kept |= 1ull << t; rem |= dt; }
-        }
-        // limit to max_keep
-        int kc = __popcll(kept);
-        if (nk + kc > max_keep) {
-            int allow = max_keep - nk;
-            unsigned long long kk = 0;
-            for (int t = 0; t < 64 && allow > 0; ++t)
-                if ((kept >> t) & 1ull) { kk |= 1ull << t; --allow; }
-            kept = kk;
-            kc = __popcll(kept);
-        }
-        if ((kept >> lane) & 1ull) keep[(long)b * cap + nk + __popcll(kept & ((1ull << lane) - 1ull))] = i;
-        nk += kc;
-        // OR the kept rows into the later words
-        __syncthreads();
-        for (int w = c + 1 + lane; w < words; w += 64) {
-            unsigned long long acc = removed[w];
-            unsigned long long kk = kept;
-            while (kk) {
-                int t = __ffsll((long long)kk) - 1;
-                kk &= kk - 1;
-                acc |= mask[((long)b * cap + c * 64 + t) * words + w];
+    for (int c = 0; c < chunks; ++c) {
+        if (c + 1 < chunks) load_rows(c + 1, nxt, diag_nxt, v_nxt);
+        if (wave == 0) {
+            unsigned long long rem = removed[c] | ~__ballot(v_cur != 0);
+            unsigned long long kept = 0;
+            const unsigned dlo = (unsigned)diag_cur, dhi = (unsigned)(diag_cur >> 32);
+#pragma unroll
+            for (int t = 0; t < 64; ++t) {
+                const unsigned long long dt = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane(dhi, t) << 32) |
+                                              (unsigned long long)(unsigned)__builtin_amdgcn_readlane(dlo, t);
+                if (!((rem >> t) & 1ull)) { kept |= 1ull << t; rem |= dt; }
             }
-            removed[w] = acc;
+            int kc = __popcll(kept);
+            if (nk + kc > max_keep) {           // keep only the first (max_keep - nk) survivors
+                int allow = max_keep - nk;
+                unsigned long long kk = 0;
+                for (int t = 0; t < 64 && allow > 0; ++t)
+                    if ((kept >> t) & 1ull) { kk |= 1ull << t; --allow; }
+                kept = kk;
+                kc = __popcll(kept);
+            }
+            if ((kept >> lane) & 1ull) keep[(long)b * cap + nk + __popcll(kept & ((1ull << lane) - 1ull))] = c * 64 + lane;
+            if (lane == 0) { kept_sh[0] = kept; kept_sh[1] = (unsigned long long)(nk + kc); }
         }
         __syncthreads();
+        const unsigned long long kept = kept_sh[0];
+        nk = (int)kept_sh[1];
+        const bool mine = (kept >> lane) & 1ull;
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k) {
+            const int w = c + 1 + wave + k * NW;
+            if (w < words) {                                       // wave uniform
+                unsigned long long x = mine ? cur[k] : 0ull;
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) x |= __shfl_xor(x, o, 64);
+                if (lane == 0) removed[w] |= x;                    // word w is owned by exactly one wave
+            }
+        }
+        __syncthreads();
+        if (nk >= max_keep) break;
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k) cur[k] = nxt[k];
+        diag_cur = diag_nxt; v_cur = v_nxt;
     }
-    if (lane == 0) keep_count[b] = nk;
+    if (tid == 0) keep_count[b] = nk;
 }
 
+// launch helper: picks the per-thread row-word count for `cap`
+static inline bool nms_scan_launch(hipStream_t st, int B, const unsigned long long* mask, const int* valid, const int* count, int cap, int max_keep,
+                                   int* keep, int* keep_count) {
+    const int words = cap / 64;
+    const size_t sh = (size_t)(words + 2) * 8;
+    if (words <= 33) hipLaunchKernelGGL(nms_scan_kernel<2>, dim3(B), dim3(1024), sh, st, mask, valid, count, cap, max_keep, keep, keep_count);
+    else if (words <= 129) hipLaunchKernelGGL(nms_scan_kernel<8>, dim3(B), dim3(1024), sh, st, mask, valid, count, cap, max_keep, keep, keep_count);
+    else return false;
+    return true;
+}

@@ -442,7 +442,7 @@ extern "C" int aldi_detections(const float* pred, int Cp, int K, const float* pr
     ALDI_CHECK_LAUNCH();
     hipLaunchKernelGGL(nms_mask_kernel, dim3(cap / 64, cap / 64, N), dim3(64), 0, st, boxes, valid, cats, cnt, (int)cap, nms_thresh, mask);
     ALDI_CHECK_LAUNCH();
-    hipLaunchKernelGGL(nms_scan_kernel, dim3(N), dim3(64), (cap / 64) * 8, st, mask, valid, cnt, (int)cap, topk, keep, keep_count);
+    if (!nms_scan_launch(st, N, mask, valid, cnt, (int)cap, topk, keep, keep_count)) return aldi_set_error_msg(ALDI_ERR_ARG, "detections: NMS capacity too large");
     ALDI_CHECK_LAUNCH();
     hipLaunchKernelGGL(det_finish_kernel, dim3(N), dim3(64), 0, st, boxes, scores, cats, keep, keep_count, topk, pl_thresh,
                        (float4*)det_boxes, det_scores, det_cls, det_count, (float4*)pl_boxes, pl_cls, pl_scores, pl_count);

@@ -81,26 +81,66 @@ __global__ void match_label_kernel(const float4* __restrict__ boxes, long box_st
 // ordered lists for subsample_labels: pos = (v != -1 && v != bg && v != -2), neg = (v == bg)
 // grid (2, N): blockIdx.x = kind
 // ---------------------------------------------------------------------------------------
+// one workgroup per (kind, image); a thread owns 16 consecutive labels per pass (four 16-B loads), so the block-wide
+// scan (two barriers) is paid once per 16K labels instead of once per 1K
 __global__ __launch_bounds__(1024) void compact_kernel(const int* __restrict__ labels, int L, int bg,
                                                        int* __restrict__ lists /*[N][2][L]*/, int* __restrict__ counts /*[N][2]*/) {
-    __shared__ int sm[17];
+    constexpr int IT = 16;
+    __shared__ int wsum[16];
     const int kind = blockIdx.x, n = blockIdx.y;
     const int* lab = labels + (long)n * L;
     int* out = lists + ((long)n * 2 + kind) * L;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const bool vec_ok = ((reinterpret_cast<uintptr_t>(lab) & 15) == 0);
     int base = 0;
-    for (int s = 0; s < L; s += blockDim.x) {
-        int i = s + threadIdx.x;
-        bool f = false;
-        if (i < L) {
-            int v = lab[i];
-            f = kind == 0 ? (v != -1 && v != -2 && v != bg) : (v == bg);
+    for (int s = 0; s < L; s += 1024 * IT) {
+        const int i0 = s + tid * IT;
+        unsigned bits = 0;
+        if (i0 + IT <= L && vec_ok) {
+#pragma unroll
+            for (int q = 0; q < IT / 4; ++q) {
+                const int4 v = *reinterpret_cast<const int4*>(lab + i0 + q * 4);
+                const int vv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const bool f = kind == 0 ? (vv[k] != -1 && vv[k] != -2 && vv[k] != bg) : (vv[k] == bg);
+                    bits |= (unsigned)f << (q * 4 + k);
+                }
+            }
+        } else {
+            for (int k = 0; k < IT; ++k)
+                if (i0 + k < L) {
+                    const int v = lab[i0 + k];
+                    const bool f = kind == 0 ? (v != -1 && v != -2 && v != bg) : (v == bg);
+                    bits |= (unsigned)f << k;
+                }
         }
-        int tot;
-        int r = block_rank(f, sm, &tot);
-        if (f) out[base + r] = i;
+        const int cnt = __popc(bits);
+        int incl = cnt;                       // inclusive wave scan
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            int t = __shfl_up(incl, o, 64);
+            if (lane >= o) incl += t;
+        }
+        __syncthreads();                      // previous pass's wsum reads are done
+        if (lane == 63) wsum[w] = incl;
+        __syncthreads();
+        int wbase = 0, tot = 0;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int c = wsum[i];
+            if (i < w) wbase += c;
+            tot += c;
+        }
+        int pos = base + wbase + incl - cnt;
+        while (bits) {
+            const int k = __ffs(bits) - 1;
+            bits &= bits - 1;
+            out[pos++] = i0 + k;
+        }
         base += tot;
     }
-    if (threadIdx.x == 0) counts[n * 2 + kind] = base;
+    if (tid == 0) counts[n * 2 + kind] = base;
 }
 
 // labels.fill_(-1); labels[pos_list[sel_pos]] = 1; labels[neg_list[sel_neg]] = 0
@@ -211,6 +251,44 @@ __global__ void rpn_keys_kernel(Geom g, int N, unsigned* __restrict__ keys) {
     keys[t] = float_key_asc(g.head[l][((long)n * g.H[l] * g.W[l] + cell) * g.C + a]);
 }
 
+// Visit every key of a contiguous range with 16-B loads (scalar head/tail for alignment).  `f(key, index, active)` is
+// called the same number of times by every thread of the block (it may ballot).
+template <class F>
+__device__ __forceinline__ void for_each_key(const unsigned* __restrict__ kp, int nel, F f) {
+    const int tid = threadIdx.x, nt = blockDim.x;
+    int head = (int)((4 - ((reinterpret_cast<uintptr_t>(kp) >> 2) & 3)) & 3);
+    if (head > nel) head = nel;
+    const int nvec = (nel - head) >> 2;
+    for (int base = 0; base < nvec; base += nt) {
+        const int v = base + tid;
+        const bool ok = v < nvec;
+        uint4 q = make_uint4(0, 0, 0, 0);
+        if (ok) q = *reinterpret_cast<const uint4*>(kp + head + v * 4);
+        const int i0 = head + v * 4;
+        f(q.x, i0, ok); f(q.y, i0 + 1, ok); f(q.z, i0 + 2, ok); f(q.w, i0 + 3, ok);
+    }
+    const int tail0 = head + nvec * 4, rest = head + (nel - tail0);     // < 8 stragglers
+    const bool ok = tid < rest;
+    const int idx = tid < head ? tid : tail0 + (tid - head);
+    f(ok ? kp[idx] : 0u, idx, ok);
+}
+
+// LDS histogram increment with wave aggregation: objectness logits cluster (at init nearly all share the leading key
+// bits), and 64 lanes hitting one LDS counter serialise.  Up to three leader rounds fold equal buckets into one add.
+__device__ __forceinline__ void hist_add(int* hist, unsigned bucket, bool active) {
+    const int lane = threadIdx.x & 63;
+    unsigned long long todo = __ballot(active);
+#pragma unroll 1
+    for (int r = 0; r < 3 && todo; ++r) {
+        const int leader = __ffsll((long long)todo) - 1;
+        const unsigned bsel = (unsigned)__builtin_amdgcn_readlane((int)bucket, leader);
+        const unsigned long long same = __ballot(active && bucket == bsel) & todo;
+        if (lane == leader) atomicAdd(&hist[bsel], __popcll(same));
+        todo &= ~same;
+    }
+    if ((todo >> lane) & 1ull) atomicAdd(&hist[bucket], 1);
+}
+
 // per (level, image): exact top-k by (logit desc, index asc), sorted.  block = 1024 threads.
 // Radix select (12+12+8 bits) of the k-th largest key over the contiguous key array, then one streaming pass
 // collects the winners (unordered append: the bitonic sort on (key desc, index asc) fixes the order); only when
@@ -236,20 +314,34 @@ __global__ __launch_bounds__(1024) void rpn_topk_kernel(Geom g, const unsigned* 
         const int shift = shifts[ps], nb = 1 << widths[ps];
         for (int i = threadIdx.x; i < nb; i += blockDim.x) hist[i] = 0;
         __syncthreads();
-        for (int i = threadIdx.x; i < nel; i += blockDim.x) {
-            unsigned key = kp[i];
-            if ((key & mask) == prefix) atomicAdd(&hist[(key >> shift) & (nb - 1)], 1);
-        }
+        for_each_key(kp, nel, [&](unsigned key, int, bool ok) {
+            hist_add(hist, (key >> shift) & (nb - 1), ok && (key & mask) == prefix);
+        });
         __syncthreads();
-        if (threadIdx.x == 0) {
-            int acc = 0, b = nb - 1;
-            for (; b > 0; --b) {
-                if (acc + hist[b] >= need) break;
-                acc += hist[b];
+        if (threadIdx.x < 64) {      // one wave walks the histogram from the top, 64 buckets per step
+            const int lane = threadIdx.x;
+            int acc = 0, found = -1, facc = 0;
+            for (int top = nb - 64; top >= 0 && found < 0; top -= 64) {
+                const int c = hist[top + 63 - lane];            // lane 0 = highest bucket of the group
+                int incl = c;
+#pragma unroll
+                for (int o = 1; o < 64; o <<= 1) {
+                    int t = __shfl_up(incl, o, 64);
+                    if (lane >= o) incl += t;
+                }
+                const unsigned long long hit = __ballot(acc + incl >= need);
+                if (hit) {
+                    const int hl = __ffsll((long long)hit) - 1;
+                    found = top + 63 - hl;
+                    facc = acc + __shfl(incl, hl, 64) - __shfl(c, hl, 64);
+                } else acc += __shfl(incl, 63, 64);
             }
-            s_prefix = prefix | ((unsigned)b << shift);
-            s_need = need - acc;
-            s_bucket_count = hist[b];
+            if (found < 0) { found = 0; facc = acc - hist[0]; }   // unreachable when need <= matching keys
+            if (lane == 0) {
+                s_prefix = prefix | ((unsigned)found << shift);
+                s_need = need - facc;
+                s_bucket_count = hist[found];
+            }
         }
         __syncthreads();
         prefix = s_prefix;
@@ -263,13 +355,12 @@ __global__ __launch_bounds__(1024) void rpn_topk_kernel(Geom g, const unsigned* 
     if (threadIdx.x == 0) s_cnt = 0;
     __syncthreads();
     const bool take_all_eq = bucket_count == need;
-    for (int i = threadIdx.x; i < nel; i += blockDim.x) {
-        unsigned key = kp[i];
-        if (key > kth || (take_all_eq && key == kth)) {
+    for_each_key(kp, nel, [&](unsigned key, int i, bool ok) {
+        if (ok && (key > kth || (take_all_eq && key == kth))) {
             int pos = atomicAdd(&s_cnt, 1);
             keys[pos] = ((unsigned long long)(~key) << 32) | (unsigned)i;
         }
-    }
+    });
     __syncthreads();
     if (!take_all_eq) {               // ties beyond k: ordered selection of the lowest-index copies of the k-th key
         int base_eq = 0;
@@ -470,7 +561,7 @@ extern "C" int aldi_rpn_proposals(const aldi_rpn_geom* gm, float* const* head, c
     ALDI_CHECK_LAUNCH();
     hipLaunchKernelGGL(nms_mask_kernel, dim3(cap / 64, cap / 64, (unsigned)B), dim3(64), 0, st, boxes, valid, (const int*)nullptr, cand_count, (int)cap, nms_thresh, mask);
     ALDI_CHECK_LAUNCH();
-    hipLaunchKernelGGL(nms_scan_kernel, dim3((unsigned)B), dim3(64), (cap / 64) * 8, st, mask, valid, cand_count, (int)cap, (int)cap, keep, keep_count);
+    if (!nms_scan_launch(st, (int)B, mask, valid, cand_count, (int)cap, (int)cap, keep, keep_count)) return aldi_set_error_msg(ALDI_ERR_ARG, "rpn_proposals: NMS capacity too large");
     ALDI_CHECK_LAUNCH();
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(rpn_merge_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kMergeCap * 8);
     hipLaunchKernelGGL(rpn_merge_kernel, dim3(N), dim3(1024), kMergeCap * 8, st, g.nl, boxes, scores, keep, keep_count, post_nms_topk, (float4*)out_boxes, out_scores, out_count);
