@@ -198,6 +198,79 @@ __global__ __launch_bounds__(256) void roialign_kernel(Feats ft, const float* __
     }
 }
 
+// Forward, vector form: a lane owns one 16-B group of channels (8 bf16 / 4 fp32) of one output bin, so the bilinear
+// bookkeeping (identical for every channel) is paid once per 16 B of feature data instead of once per element, and a tap
+// is fetched as 512 contiguous bytes per bin.  grid (R, P): block = one output row of one ROI, bins side by side.
+template <typename T>
+__global__ __launch_bounds__(256) void roialign_fwd_vec_kernel(Feats ft, const float* __restrict__ rois, int P, T* __restrict__ pooled /*[R][P][P][C]*/) {
+    constexpr int EP = Elem<T>::kPer16B;
+    const int r = blockIdx.x, ph = blockIdx.y;
+    const int lpb = ft.C / EP;                       // lanes per bin (32 / 64)
+    const int cg = threadIdx.x % lpb, bin0 = threadIdx.x / lpb, nbin = 256 / lpb;
+    const float* rp = rois + (long)r * 5;
+    const int b = (int)rp[0];
+    if (b < 0) {
+        for (int pw = bin0; pw < P; pw += nbin)
+            *reinterpret_cast<uint4*>(pooled + (((long)r * P + ph) * P + pw) * ft.C + cg * EP) = make_uint4(0, 0, 0, 0);
+        return;
+    }
+    const int l = roi_level(rp[1], rp[2], rp[3], rp[4]);
+    const int H = ft.H[l], W = ft.W[l];
+    const float sc = ft.scale[l];
+    const float x1 = rp[1] * sc - 0.5f, y1 = rp[2] * sc - 0.5f, x2 = rp[3] * sc - 0.5f, y2 = rp[4] * sc - 0.5f;
+    const float rw = x2 - x1, rh = y2 - y1;
+    const float bw = rw / (float)P, bh = rh / (float)P;
+    const int gh = (int)ceilf(rh / (float)P), gw = (int)ceilf(rw / (float)P);
+    const float count = (float)max(gh * gw, 1);
+    const T* F = static_cast<const T*>(ft.f[l]) + (long)b * H * W * ft.C + cg * EP;
+    for (int pw = bin0; pw < P; pw += nbin) {
+        float acc[EP];
+#pragma unroll
+        for (int e = 0; e < EP; ++e) acc[e] = 0.f;
+        for (int iy = 0; iy < gh; ++iy) {
+            const float y = y1 + (float)ph * bh + ((float)iy + 0.5f) * bh / (float)gh;
+            const Bilin by = bilin_prep(y, H);
+            for (int ix = 0; ix < gw; ++ix) {
+                const float x = x1 + (float)pw * bw + ((float)ix + 0.5f) * bw / (float)gw;
+                const Bilin bx = bilin_prep(x, W);
+                if (by.dead || bx.dead) continue;
+                const float w1 = by.h * bx.h, w2 = by.h * bx.l, w3 = by.l * bx.h, w4 = by.l * bx.l;
+                const uint4 q1 = *reinterpret_cast<const uint4*>(F + ((long)by.lo * W + bx.lo) * ft.C);
+                const uint4 q2 = *reinterpret_cast<const uint4*>(F + ((long)by.lo * W + bx.hi) * ft.C);
+                const uint4 q3 = *reinterpret_cast<const uint4*>(F + ((long)by.hi * W + bx.lo) * ft.C);
+                const uint4 q4 = *reinterpret_cast<const uint4*>(F + ((long)by.hi * W + bx.hi) * ft.C);
+                const uint32_t* u1 = reinterpret_cast<const uint32_t*>(&q1);
+                const uint32_t* u2 = reinterpret_cast<const uint32_t*>(&q2);
+                const uint32_t* u3 = reinterpret_cast<const uint32_t*>(&q3);
+                const uint32_t* u4 = reinterpret_cast<const uint32_t*>(&q4);
+                if constexpr (EP == 8) {
+#pragma unroll
+                    for (int d = 0; d < 4; ++d) {
+                        // same association as the scalar form: ((w1*f1 + w2*f2) + w3*f3) + w4*f4, then += into acc
+                        acc[2 * d] += w1 * __uint_as_float(u1[d] << 16) + w2 * __uint_as_float(u2[d] << 16) + w3 * __uint_as_float(u3[d] << 16) +
+                                      w4 * __uint_as_float(u4[d] << 16);
+                        acc[2 * d + 1] += w1 * __uint_as_float(u1[d] & 0xffff0000u) + w2 * __uint_as_float(u2[d] & 0xffff0000u) +
+                                          w3 * __uint_as_float(u3[d] & 0xffff0000u) + w4 * __uint_as_float(u4[d] & 0xffff0000u);
+                    }
+                } else {
+#pragma unroll
+                    for (int d = 0; d < 4; ++d)
+                        acc[d] += w1 * __uint_as_float(u1[d]) + w2 * __uint_as_float(u2[d]) + w3 * __uint_as_float(u3[d]) + w4 * __uint_as_float(u4[d]);
+                }
+            }
+        }
+        T* op = pooled + (((long)r * P + ph) * P + pw) * ft.C + cg * EP;
+        if constexpr (EP == 8) {
+            uint4 o;
+            o.x = pack2_bf16(acc[0] / count, acc[1] / count); o.y = pack2_bf16(acc[2] / count, acc[3] / count);
+            o.z = pack2_bf16(acc[4] / count, acc[5] / count); o.w = pack2_bf16(acc[6] / count, acc[7] / count);
+            *reinterpret_cast<uint4*>(op) = o;
+        } else {
+            *reinterpret_cast<float4*>(op) = make_float4(acc[0] / count, acc[1] / count, acc[2] / count, acc[3] / count);
+        }
+    }
+}
+
 // FastRCNNOutputLayers.losses: CE(mean over R) + L1 on the gt-class deltas of fg rows / R
 // pred row: [0,K] class logits, [K+1, K+1+4K) deltas (class*4+d).  grad += d(loss*gscale)/d(pred)
 __global__ __launch_bounds__(256) void box_loss_kernel(const float* __restrict__ pred, int Cp, int K, int R,
@@ -385,10 +458,10 @@ extern "C" int aldi_roialign(const aldi_roi_feats* f, const float* rois, int R, 
     dim3 grid(R, P);
     if (dtype == ALDI_BF16) {
         if (backward) hipLaunchKernelGGL((roialign_kernel<bf16_t, true>), grid, dim3(256), 0, st, ft, rois, P, (bf16_t*)pooled);
-        else hipLaunchKernelGGL((roialign_kernel<bf16_t, false>), grid, dim3(256), 0, st, ft, rois, P, (bf16_t*)pooled);
+        else hipLaunchKernelGGL((roialign_fwd_vec_kernel<bf16_t>), grid, dim3(256), 0, st, ft, rois, P, (bf16_t*)pooled);
     } else {
         if (backward) hipLaunchKernelGGL((roialign_kernel<float, true>), grid, dim3(256), 0, st, ft, rois, P, (float*)pooled);
-        else hipLaunchKernelGGL((roialign_kernel<float, false>), grid, dim3(256), 0, st, ft, rois, P, (float*)pooled);
+        else hipLaunchKernelGGL((roialign_fwd_vec_kernel<float>), grid, dim3(256), 0, st, ft, rois, P, (float*)pooled);
     }
     ALDI_CHECK_LAUNCH();
     return ALDI_OK;
