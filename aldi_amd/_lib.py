@@ -115,4 +115,9 @@ class RoiFeats(C.Structure):
     ]
 
 
+class DgwItem(C.Structure):
+    _fields_ = [("w_master", c_void_p), ("scale", c_void_p), ("wt", c_void_p),
+                ("Cout", c_int), ("KH", c_int), ("KW", c_int), ("Cin", c_int), ("tile_begin", c_int), ("reserved", c_int)]
+
+
 PtrArray5 = c_void_p * MAX_LEVELS

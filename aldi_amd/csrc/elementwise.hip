@@ -21,6 +21,32 @@ __global__ void dgrad_weights_kernel(const float* __restrict__ w, const float* _
     }
 }
 
+// all layers in one launch: block = one 1024-element tile of one layer (found by a scan of the tile offsets)
+template <typename T>
+__global__ __launch_bounds__(256) void dgrad_weights_batch_kernel(const aldi_dgw_item* __restrict__ items, int n_items) {
+    const int tile = blockIdx.x;
+    int it = 0;
+    while (it + 1 < n_items && items[it + 1].tile_begin <= tile) ++it;
+    const aldi_dgw_item d = items[it];
+    const unsigned Cout = d.Cout, KH = d.KH, KW = d.KW, Cin = d.Cin;
+    const unsigned total = Cout * KH * KW * Cin;
+    const unsigned base = (unsigned)(tile - d.tile_begin) * 1024u;
+    T* __restrict__ wt = static_cast<T*>(d.wt);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const unsigned i = base + k * 256u + threadIdx.x;
+        if (i >= total) break;
+        const unsigned co = i % Cout;
+        unsigned r = i / Cout;
+        const unsigned kw = r % KW; r /= KW;
+        const unsigned kh = r % KH;
+        const unsigned ci = r / KH;
+        float v = d.w_master[((co * KH + (KH - 1 - kh)) * KW + (KW - 1 - kw)) * Cin + ci];
+        if (d.scale) v *= d.scale[co];
+        Elem<T>::st(wt + i, v);
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // Stem: (uint8 BGR - mean)/std, zero pad, conv 7x7 s2 p3 (fp32 math), FrozenBN, ReLU.
 // One block = one 16x16 tile of conv outputs of one image; a thread owns one pixel x 64 channels.
@@ -352,6 +378,16 @@ extern "C" int aldi_ema_update(float* teacher, const float* student, void* teach
 
 extern "C" int aldi_bn_fold(const float* w, const float* b, const float* mean, const float* var, float* scale, float* shift, int C, aldi_stream_t stream) {
     hipLaunchKernelGGL(bn_fold_kernel, dim3(cdiv(C, 256)), dim3(256), 0, static_cast<hipStream_t>(stream), w, b, mean, var, scale, shift, C, 1e-5f);
+    ALDI_CHECK_LAUNCH();
+    return ALDI_OK;
+}
+
+extern "C" int aldi_dgrad_weights_batch(const aldi_dgw_item* items, int n_items, int total_tiles, int dtype, aldi_stream_t stream) {
+    if (!items || n_items <= 0 || total_tiles <= 0) return aldi_set_error_msg(ALDI_ERR_ARG, "dgrad_weights_batch: bad args");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (dtype == ALDI_BF16) hipLaunchKernelGGL(dgrad_weights_batch_kernel<bf16_t>, dim3(total_tiles), dim3(256), 0, st, items, n_items);
+    else if (dtype == ALDI_F32) hipLaunchKernelGGL(dgrad_weights_batch_kernel<float>, dim3(total_tiles), dim3(256), 0, st, items, n_items);
+    else return aldi_set_error_msg(ALDI_ERR_ARG, "dgrad_weights_batch: bad dtype");
     ALDI_CHECK_LAUNCH();
     return ALDI_OK;
 }

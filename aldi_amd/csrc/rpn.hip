@@ -37,18 +37,28 @@ __global__ void match_iou_kernel(const float4* __restrict__ boxes, long box_stri
     const int n = blockIdx.y;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const int cnt = box_count ? box_count[n] : L;
-    if (i >= cnt) return;
+    const bool active = i < cnt;
     const int G = gt_count[n];
-    const float4 b = boxes[n * box_stride_n + i];
+    const float4 b = active ? boxes[n * box_stride_n + i] : make_float4(0.f, 0.f, 0.f, 0.f);
     float best = -1.f;
     int bi = 0;
+    const int lane = threadIdx.x & 63;
     for (int g = 0; g < G; ++g) {
-        float v = iou_d2(gt[n * Gmax + g], b);
+        float v = active ? iou_d2(gt[n * Gmax + g], b) : 0.f;
         if (v > best) { best = v; bi = g; }
-        if (v > 0.f) atomicMax(gt_best + n * Gmax + g, __float_as_uint(v));
+        // per-GT best IoU: one atomic per wave that overlaps the GT at all (neighbouring anchors share a wave, most
+        // waves overlap no GT), not one per (anchor, GT) pair on a handful of addresses
+        if (__ballot(v > 0.f)) {
+            float wm = v;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) wm = fmaxf(wm, __shfl_xor(wm, o, 64));
+            if (lane == 0) atomicMax(gt_best + n * Gmax + g, __float_as_uint(wm));
+        }
     }
-    best_iou[(long)n * L + i] = best;
-    best_idx[(long)n * L + i] = bi;
+    if (active) {
+        best_iou[(long)n * L + i] = best;
+        best_idx[(long)n * L + i] = bi;
+    }
 }
 
 __global__ void match_label_kernel(const float4* __restrict__ boxes, long box_stride_n, const int* __restrict__ box_count, int L,
@@ -418,42 +428,58 @@ __global__ void rpn_decode_kernel(Geom g, const float4* __restrict__ anchors, co
     valid[slot] = ok ? 1 : 0;
 }
 
-// merge the per-level survivors of one image by (score desc, level asc, rank asc); keep post_nms_topk
+// merge the per-level survivors of one image by (score desc, level asc, rank asc); keep post_nms_topk.
+// Every level's survivor list is already in that order (NMS keeps score order), so an element's final position is its
+// own rank plus, for every other level, the number of that level's elements ordered before it: a binary search per
+// level over keys staged in LDS -- O(n log n) with no barriers instead of a 16K-element bitonic network.
 __global__ __launch_bounds__(1024) void rpn_merge_kernel(int nl, const float4* __restrict__ boxes, const float* __restrict__ scores,
                                                          const int* __restrict__ keep, const int* __restrict__ keep_count, int post_topk,
                                                          float4* __restrict__ out_boxes /*[N][post]*/, float* __restrict__ out_scores, int* __restrict__ out_count) {
-    extern __shared__ unsigned long long mk[];   // kMergeCap
+    extern __shared__ unsigned mkeys[];          // kMergeCap keys, ascending key == descending score
+    __shared__ int lbase[ALDI_MAX_LEVELS + 1];
     const int n = blockIdx.x;
-    for (int i = threadIdx.x; i < kMergeCap; i += blockDim.x) mk[i] = ~0ull;
-    __syncthreads();
-    int base = 0;
-    for (int l = 0; l < nl; ++l) {
-        const int bl = n * nl + l;
-        const int kc = keep_count[bl];
-        for (int j = threadIdx.x; j < kc; j += blockDim.x) {
-            int r = keep[(long)bl * kTopkCap + j];
-            unsigned key = float_key_asc(scores[(long)bl * kTopkCap + r]);
-            // low 32 bits: (level << 16 | rank) keeps the concatenation order for ties
-            mk[base + j] = ((unsigned long long)(~key) << 32) | ((unsigned)l << 16) | (unsigned)r;
-        }
-        base += kc;
+    if (threadIdx.x == 0) {
+        int acc = 0;
+        for (int l = 0; l < nl; ++l) { lbase[l] = acc; acc += keep_count[n * nl + l]; }
+        lbase[nl] = acc;
     }
     __syncthreads();
-    int p2 = 1024;
-    while (p2 < base) p2 <<= 1;
-    bitonic_sort_u64(mk, p2);
-    const int cnt = min(base, post_topk);
-    for (int j = threadIdx.x; j < post_topk; j += blockDim.x) {
-        if (j < cnt) {
-            unsigned lo = (unsigned)(mk[j] & 0xffffffffu);
-            int l = lo >> 16, r = lo & 0xffff;
-            long slot = ((long)n * nl + l) * kTopkCap + r;
-            out_boxes[(long)n * post_topk + j] = boxes[slot];
-            out_scores[(long)n * post_topk + j] = scores[slot];
-        } else {
-            out_boxes[(long)n * post_topk + j] = make_float4(0, 0, 0, 0);
-            out_scores[(long)n * post_topk + j] = 0.f;
+    const int total = lbase[nl];
+    for (int l = 0; l < nl; ++l) {
+        const int bl = n * nl + l, kc = lbase[l + 1] - lbase[l];
+        for (int j = threadIdx.x; j < kc; j += blockDim.x)
+            mkeys[lbase[l] + j] = ~float_key_asc(scores[(long)bl * kTopkCap + keep[(long)bl * kTopkCap + j]]);
+    }
+    __syncthreads();
+    const int cnt = min(total, post_topk);
+    for (int e = threadIdx.x; e < total; e += blockDim.x) {
+        int l = 0;
+        while (e >= lbase[l + 1]) ++l;
+        const int j = e - lbase[l];
+        const unsigned key = mkeys[e];
+        int pos = j;
+        for (int o = 0; o < nl; ++o) {
+            if (o == l) continue;
+            // elements of level o ordered before (key, l): key_o < key, or key_o == key when o < l
+            const unsigned* ko = mkeys + lbase[o];
+            int lo = 0, hi = lbase[o + 1] - lbase[o];
+            while (lo < hi) {
+                const int mid = (lo + hi) >> 1;
+                const unsigned km = ko[mid];
+                const bool before = o < l ? km <= key : km < key;
+                if (before) lo = mid + 1; else hi = mid;
+            }
+            pos += lo;
         }
+        if (pos < post_topk) {
+            const long slot = ((long)n * nl + l) * kTopkCap + keep[((long)n * nl + l) * kTopkCap + j];
+            out_boxes[(long)n * post_topk + pos] = boxes[slot];
+            out_scores[(long)n * post_topk + pos] = scores[slot];
+        }
+    }
+    for (int j = cnt + threadIdx.x; j < post_topk; j += blockDim.x) {
+        out_boxes[(long)n * post_topk + j] = make_float4(0, 0, 0, 0);
+        out_scores[(long)n * post_topk + j] = 0.f;
     }
     if (threadIdx.x == 0) out_count[n] = cnt;
 }
@@ -563,8 +589,8 @@ extern "C" int aldi_rpn_proposals(const aldi_rpn_geom* gm, float* const* head, c
     ALDI_CHECK_LAUNCH();
     if (!nms_scan_launch(st, (int)B, mask, valid, cand_count, (int)cap, (int)cap, keep, keep_count)) return aldi_set_error_msg(ALDI_ERR_ARG, "rpn_proposals: NMS capacity too large");
     ALDI_CHECK_LAUNCH();
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(rpn_merge_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kMergeCap * 8);
-    hipLaunchKernelGGL(rpn_merge_kernel, dim3(N), dim3(1024), kMergeCap * 8, st, g.nl, boxes, scores, keep, keep_count, post_nms_topk, (float4*)out_boxes, out_scores, out_count);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(rpn_merge_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kMergeCap * 4);
+    hipLaunchKernelGGL(rpn_merge_kernel, dim3(N), dim3(1024), kMergeCap * 4, st, g.nl, boxes, scores, keep, keep_count, post_nms_topk, (float4*)out_boxes, out_scores, out_count);
     ALDI_CHECK_LAUNCH();
     return ALDI_OK;
 }

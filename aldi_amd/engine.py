@@ -80,6 +80,8 @@ class Weights:
         self._mom = None
         self.first_step = True
         self._wt: Dict[str, torch.Tensor] = {}
+        self._wt_keys: List[str] = []          # dgrad weights requested so far (re-derived in one launch per refresh)
+        self._wt_plan = None
         self._neg1: Dict[int, torch.Tensor] = {}
 
     @property
@@ -130,14 +132,36 @@ class Weights:
         """dgrad weights (rotated/transposed, BN scale folded; negated for the gradient-reversal layer)."""
         key = name + ("-" if negate else "")
         if key not in self._wt:
-            p = self.layout.t[name]
-            sc = self.scale(name)
-            if negate:
-                if p.rows not in self._neg1:
-                    self._neg1[p.rows] = torch.full((p.rows,), -1.0, dtype=torch.float32, device=self.device)
-                sc = self._neg1[p.rows]
-            self._wt[key] = ops.dgrad_weights(self.w_master(name), sc, self.dtype)
+            # first request of this layer: single-layer kernel now, and from the next refresh() on it is part of the one
+            # batched launch that re-derives every requested layer right after the weights change
+            self._wt[key] = ops.dgrad_weights(self.w_master(name), self._wt_scale(name, negate), self.dtype)
+            if key not in self._wt_keys:
+                self._wt_keys.append(key)
+                self._wt_plan = None
         return self._wt[key]
+
+    def _wt_scale(self, name: str, negate: bool):
+        if not negate:
+            return self.scale(name)
+        rows = self.layout.t[name].rows
+        if rows not in self._neg1:
+            self._neg1[rows] = torch.full((rows,), -1.0, dtype=torch.float32, device=self.device)
+        return self._neg1[rows]
+
+    def _refresh_wt(self):
+        self._wt.clear()
+        if not self._wt_keys:
+            return
+        if self._wt_plan is None:
+            ent = []
+            for key in self._wt_keys:
+                neg = key.endswith("-")
+                name = key[:-1] if neg else key
+                ent.append((self.w_master(name), self._wt_scale(name, neg)))
+            self._wt_plan = ops.DgradWeightsPlan(ent, self.dtype)
+        self._wt_plan.run()
+        for key, o in zip(self._wt_keys, self._wt_plan.out):
+            self._wt[key] = o
 
     # ---- state -------------------------------------------------------------------------------
     def load_state_dict(self, sd: Dict[str, torch.Tensor]):
@@ -160,7 +184,7 @@ class Weights:
                         self.master[b + 3 * c:b + 4 * c], self.bn_scale, self.bn_shift, c)
         if self.dtype != torch.float32:
             ops.cast_from_f32(self.master[:L.n_weights], self.dtype, out=self.compute)
-        self._wt.clear()
+        self._refresh_wt()
 
     def zero_grad(self):
         self.grad.zero_()
@@ -175,7 +199,7 @@ class Weights:
         ops.sgd_step(self.master, self.grad, self.mom, self.compute if self.dtype != torch.float32 else None, n, lr, momentum,
                      weight_decay, grad_scale * getattr(self, "_gscale", 1.0), self.first_step, self.dtype)
         self.first_step = False
-        self._wt.clear()
+        self._refresh_wt()
 
     def ema_from(self, student: "Weights", alpha: float, copy_only: bool):
         """reference aldi/ema.py:29-57 over the whole state (params AND buffers)."""

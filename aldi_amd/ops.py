@@ -85,6 +85,41 @@ def dgrad_weights(w_master: torch.Tensor, scale: Optional[torch.Tensor], dtype: 
     return out
 
 
+class DgradWeightsPlan:
+    """All data-gradient weights of a model in one launch (aldi_dgrad_weights_batch).  `entries` = [(w_master, scale|None)];
+    outputs live in one persistent buffer (`out[i]` = [Cin,KH,KW,Cout] view).  Inputs must keep their storage (they are
+    views of the flat master / scale buffers)."""
+
+    def __init__(self, entries, dtype: torch.dtype):
+        dev = entries[0][0].device
+        self.dtype = dtype
+        self.keep = list(entries)
+        sizes = [w.numel() for w, _ in entries]
+        offs, tot = [], 0
+        for n in sizes:
+            offs.append(tot)
+            tot += (n + 63) // 64 * 64
+        self.buf = torch.empty(tot, dtype=dtype, device=dev)
+        self.out = []
+        items = (L.DgwItem * len(entries))()
+        tile = 0
+        for i, (w, sc) in enumerate(entries):
+            Cout, KH, KW, Cin = w.shape
+            o = self.buf[offs[i]:offs[i] + sizes[i]].view(Cin, KH, KW, Cout)
+            self.out.append(o)
+            it = items[i]
+            it.w_master, it.scale, it.wt = w.data_ptr(), (sc.data_ptr() if sc is not None else None), o.data_ptr()
+            it.Cout, it.KH, it.KW, it.Cin, it.tile_begin, it.reserved = Cout, KH, KW, Cin, tile, 0
+            tile += (sizes[i] + 1023) // 1024
+        self.total_tiles = tile
+        self.n = len(entries)
+        raw = torch.frombuffer(bytearray(bytes(items)), dtype=torch.uint8)
+        self.items = raw.to(dev)
+
+    def run(self):
+        L.call("aldi_dgrad_weights_batch", _p(self.items), self.n, self.total_tiles, dtype_code(self.dtype), stream_ptr())
+
+
 # ------------------------------------------------------------------------------- stem / glue
 def stem_forward(img_u8: torch.Tensor, sizes: Sequence[Sequence[int]], w: torch.Tensor, scale: torch.Tensor, shift: torch.Tensor,
                  mean: Sequence[float], std: Sequence[float], dtype: torch.dtype) -> torch.Tensor:

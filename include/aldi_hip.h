@@ -83,6 +83,18 @@ int aldi_bias_grad(const void* g, float* db, int M, int C, int dtype, aldi_strea
 int aldi_dgrad_weights(const float* w_master, const float* scale, void* wt, int Cout, int KH, int KW, int Cin,
                        int dtype, aldi_stream_t stream);
 
+/* Batched form: one launch re-derives the data-gradient weights of every layer after an optimizer step.  `items` is a
+ * DEVICE array of n_items descriptors; layer i owns the 1024-element tiles [tile_begin_i, tile_begin_{i+1}) of the launch
+ * (tile_begin ascending, total_tiles = end of the last layer). */
+typedef struct aldi_dgw_item {
+    const float* w_master;   /* [Cout][KH][KW][Cin] fp32 */
+    const float* scale;      /* [Cout] or NULL */
+    void* wt;                /* [Cin][KH][KW][Cout] in `dtype` */
+    int Cout, KH, KW, Cin;
+    int tile_begin, reserved;
+} aldi_dgw_item;
+int aldi_dgrad_weights_batch(const aldi_dgw_item* items, int n_items, int total_tiles, int dtype, aldi_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------
  * Stem and glue (bandwidth-bound).
  * ------------------------------------------------------------------------------------- */
