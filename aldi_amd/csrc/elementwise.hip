@@ -21,29 +21,41 @@ __global__ void dgrad_weights_kernel(const float* __restrict__ w, const float* _
     }
 }
 
-// all layers in one launch: block = one 1024-element tile of one layer (found by a scan of the tile offsets)
+// all layers in one launch: block = one 32 (co) x 32 (ci) tile of one tap of one layer, transposed through LDS so that
+// both the fp32 reads (along ci) and the `dtype` writes (along co) are contiguous runs.
+// tiles of a layer: tap-major, then co-tile, then ci-tile.
 template <typename T>
 __global__ __launch_bounds__(256) void dgrad_weights_batch_kernel(const aldi_dgw_item* __restrict__ items, int n_items) {
+    __shared__ float tl[32][33];
     const int tile = blockIdx.x;
     int it = 0;
     while (it + 1 < n_items && items[it + 1].tile_begin <= tile) ++it;
     const aldi_dgw_item d = items[it];
-    const unsigned Cout = d.Cout, KH = d.KH, KW = d.KW, Cin = d.Cin;
-    const unsigned total = Cout * KH * KW * Cin;
-    const unsigned base = (unsigned)(tile - d.tile_begin) * 1024u;
+    const int Cout = d.Cout, KH = d.KH, KW = d.KW, Cin = d.Cin, T_ = KH * KW;
+    const int nci = (Cin + 31) >> 5, nco = (Cout + 31) >> 5;
+    int t = tile - d.tile_begin;
+    const int cit = t % nci; t /= nci;
+    const int cot = t % nco;
+    const int tap = t / nco;                         // output tap (kh, kw); the source tap is the rotated one
+    const int kh = tap / KW, kw = tap - kh * KW;
+    const int stap = (KH - 1 - kh) * KW + (KW - 1 - kw);
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;          // 32 x 8
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int co = cot * 32 + ty + k * 8, ci = cit * 32 + tx;
+        float v = 0.f;
+        if (co < Cout && ci < Cin) {
+            v = d.w_master[((long)co * T_ + stap) * Cin + ci];
+            if (d.scale) v *= d.scale[co];
+        }
+        tl[ty + k * 8][tx] = v;
+    }
+    __syncthreads();
     T* __restrict__ wt = static_cast<T*>(d.wt);
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        const unsigned i = base + k * 256u + threadIdx.x;
-        if (i >= total) break;
-        const unsigned co = i % Cout;
-        unsigned r = i / Cout;
-        const unsigned kw = r % KW; r /= KW;
-        const unsigned kh = r % KH;
-        const unsigned ci = r / KH;
-        float v = d.w_master[((co * KH + (KH - 1 - kh)) * KW + (KW - 1 - kw)) * Cin + ci];
-        if (d.scale) v *= d.scale[co];
-        Elem<T>::st(wt + i, v);
+        const int ci = cit * 32 + ty + k * 8, co = cot * 32 + tx;
+        if (co < Cout && ci < Cin) Elem<T>::st(wt + ((long)ci * T_ + tap) * Cout + co, tl[tx][ty + k * 8]);
     }
 }
 

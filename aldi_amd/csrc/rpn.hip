@@ -97,6 +97,7 @@ __global__ __launch_bounds__(1024) void compact_kernel(const int* __restrict__ l
                                                        int* __restrict__ lists /*[N][2][L]*/, int* __restrict__ counts /*[N][2]*/) {
     constexpr int IT = 16;
     __shared__ int wsum[16];
+    __shared__ int stage[1024 * IT];
     const int kind = blockIdx.x, n = blockIdx.y;
     const int* lab = labels + (long)n * L;
     int* out = lists + ((long)n * 2 + kind) * L;
@@ -142,12 +143,16 @@ __global__ __launch_bounds__(1024) void compact_kernel(const int* __restrict__ l
             if (i < w) wbase += c;
             tot += c;
         }
-        int pos = base + wbase + incl - cnt;
+        // a thread's picks are contiguous in the output but threads are 16 labels apart: stage the pass through LDS so
+        // the global writes are full lines instead of 4-B pieces on 64 different lines per instruction
+        int pos = wbase + incl - cnt;
         while (bits) {
             const int k = __ffs(bits) - 1;
             bits &= bits - 1;
-            out[pos++] = i0 + k;
+            stage[pos++] = i0 + k;
         }
+        __syncthreads();
+        for (int j = tid; j < tot; j += 1024) out[base + j] = stage[j];
         base += tot;
     }
     if (tid == 0) counts[n * 2 + kind] = base;
@@ -299,95 +304,157 @@ __device__ __forceinline__ void hist_add(int* hist, unsigned bucket, bool active
     if ((todo >> lane) & 1ull) atomicAdd(&hist[bucket], 1);
 }
 
-// per (level, image): exact top-k by (logit desc, index asc), sorted.  block = 1024 threads.
-// Radix select (12+12+8 bits) of the k-th largest key over the contiguous key array, then one streaming pass
-// collects the winners (unordered append: the bitonic sort on (key desc, index asc) fixes the order); only when
-// MORE keys tie with the k-th than fit is an index-ordered pass needed to take the lowest indices.
-__global__ __launch_bounds__(1024) void rpn_topk_kernel(Geom g, const unsigned* __restrict__ keys_all, int pre_nms_topk,
-                                                        unsigned long long* __restrict__ cand /*[N][nl][kTopkCap]*/,
-                                                        int* __restrict__ cand_count /*[N][nl]*/) {
-    __shared__ unsigned long long keys[kTopkCap];
-    __shared__ int hist[4096];
-    __shared__ int sm[17];
-    __shared__ unsigned s_prefix;
-    __shared__ int s_need, s_cnt, s_bucket_count;
-    const int l = blockIdx.x, n = blockIdx.y;
-    const int nel = g.H[l] * g.W[l] * g.A;
-    const int k = min(pre_nms_topk, nel);
-    const unsigned* kp = keys_all + (long)n * g.sumA + g.off[l];
-    unsigned prefix = 0, mask = 0;
-    int need = k;
-    const int shifts[3] = {20, 8, 0};
-    const int widths[3] = {12, 12, 8};
-    int bucket_count = 0;
-    for (int ps = 0; ps < 3; ++ps) {
-        const int shift = shifts[ps], nb = 1 << widths[ps];
-        for (int i = threadIdx.x; i < nb; i += blockDim.x) hist[i] = 0;
-        __syncthreads();
-        for_each_key(kp, nel, [&](unsigned key, int, bool ok) {
-            hist_add(hist, (key >> shift) & (nb - 1), ok && (key & mask) == prefix);
-        });
-        __syncthreads();
-        if (threadIdx.x < 64) {      // one wave walks the histogram from the top, 64 buckets per step
-            const int lane = threadIdx.x;
-            int acc = 0, found = -1, facc = 0;
-            for (int top = nb - 64; top >= 0 && found < 0; top -= 64) {
-                const int c = hist[top + 63 - lane];            // lane 0 = highest bucket of the group
-                int incl = c;
+// ---------------------------------------------------------------------------------------
+// Exact top-k per (level, image) by (logit desc, index asc): radix select (12+12+8 bits) of the k-th largest key, one
+// streaming pass that collects the winners (unordered; a bitonic sort on (key desc, index asc) fixes the order), and an
+// index-ordered pass only when MORE keys tie with the k-th than fit.  One workgroup per (level, image) would leave a
+// 200K-key level on a single CU (the radix passes are instruction bound there), so a level is cut into 8192-key chunks,
+// every pass is its own launch (the launch boundary is the grid-wide barrier), and the per-(level, image) histograms live in global
+// memory:   hist(pass 0) -> [find bucket] hist(pass 1) -> [find] hist(pass 2) -> [find] collect -> sort.
+// Each workgroup re-derives the selected bucket from the previous pass's histogram (4096 bins, trivial) instead of
+// waiting for a separate "find" launch; chunk 0 records the chain state for the next launch.
+// ---------------------------------------------------------------------------------------
+constexpr int kTopkChunk = 8192;
+struct TopkState { unsigned prefix, mask; int need, bucket_count; };
+
+// highest bucket b with count(buckets > b) < need <= count(buckets >= b); 1024 threads, nb in {256, 4096}
+__device__ __forceinline__ void find_bucket(const int* __restrict__ hist, int nb, int need, int* sm /*>=20*/, int* bucket, int* above, int* bcount) {
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int per = nb / 1024 > 0 ? nb / 1024 : 1;           // 4 bins per thread for 4096, 1 for 256 (threads >= nb idle)
+    int c[4] = {0, 0, 0, 0}, sum = 0;
+    const int hi = nb - 1 - tid * per;                       // thread 0 owns the highest bins
+    if (hi >= 0)
+        for (int k = 0; k < per; ++k) { c[k] = hist[hi - k]; sum += c[k]; }
+    int incl = sum;
 #pragma unroll
-                for (int o = 1; o < 64; o <<= 1) {
-                    int t = __shfl_up(incl, o, 64);
-                    if (lane >= o) incl += t;
-                }
-                const unsigned long long hit = __ballot(acc + incl >= need);
-                if (hit) {
-                    const int hl = __ffsll((long long)hit) - 1;
-                    found = top + 63 - hl;
-                    facc = acc + __shfl(incl, hl, 64) - __shfl(c, hl, 64);
-                } else acc += __shfl(incl, 63, 64);
-            }
-            if (found < 0) { found = 0; facc = acc - hist[0]; }   // unreachable when need <= matching keys
-            if (lane == 0) {
-                s_prefix = prefix | ((unsigned)found << shift);
-                s_need = need - facc;
-                s_bucket_count = hist[found];
-            }
-        }
-        __syncthreads();
-        prefix = s_prefix;
-        need = s_need;
-        bucket_count = s_bucket_count;
-        mask |= (unsigned)(nb - 1) << shift;
-        __syncthreads();
+    for (int o = 1; o < 64; o <<= 1) {
+        int t = __shfl_up(incl, o, 64);
+        if (lane >= o) incl += t;
     }
-    const unsigned kth = prefix;      // exact key of the k-th largest; `need` of its `bucket_count` copies are taken (lowest indices)
-    for (int i = threadIdx.x; i < kTopkCap; i += blockDim.x) keys[i] = ~0ull;
-    if (threadIdx.x == 0) s_cnt = 0;
     __syncthreads();
-    const bool take_all_eq = bucket_count == need;
-    for_each_key(kp, nel, [&](unsigned key, int i, bool ok) {
-        if (ok && (key > kth || (take_all_eq && key == kth))) {
-            int pos = atomicAdd(&s_cnt, 1);
-            keys[pos] = ((unsigned long long)(~key) << 32) | (unsigned)i;
+    if (lane == 63) sm[w] = incl;
+    if (tid == 0) { sm[17] = 0; sm[18] = 0; sm[19] = 0; }
+    __syncthreads();
+    int wb = 0;
+    for (int i = 0; i < w; ++i) wb += sm[i];
+    const int excl = wb + incl - sum;
+    if (excl < need && need <= excl + sum) {                 // exactly one thread when need <= total
+        int acc = excl;
+        for (int k = 0; k < per; ++k) {
+            if (acc + c[k] >= need) { sm[17] = hi - k; sm[18] = acc; sm[19] = c[k]; break; }
+            acc += c[k];
         }
+    }
+    __syncthreads();
+    *bucket = sm[17]; *above = sm[18]; *bcount = sm[19];
+    __syncthreads();
+}
+
+// pass p (0,1,2): advance the chain with the previous histogram, then histogram this chunk's matching keys
+__global__ __launch_bounds__(1024) void topk_hist_kernel(Geom g, const unsigned* __restrict__ keys_all, int pre_nms_topk, int pass,
+                                                         int* __restrict__ hists /*[3][B][4096]*/, TopkState* __restrict__ state /*[B]*/) {
+    __shared__ int hist[4096];
+    __shared__ int sm[20];
+    const int c = blockIdx.x, l = blockIdx.y, n = blockIdx.z, B = gridDim.y * gridDim.z, bl = n * g.nl + l;
+    const int nel = g.H[l] * g.W[l] * g.A;
+    if (c * kTopkChunk >= nel) return;
+    const int shifts[3] = {20, 8, 0}, widths[3] = {12, 12, 8};
+    TopkState s;
+    s.prefix = 0; s.mask = 0; s.need = min(pre_nms_topk, nel); s.bucket_count = 0;      // chain start (passes 0 and 1)
+    if (pass > 0) {
+        if (pass > 1) s = state[bl];
+        int b, above, bc;
+        find_bucket(hists + ((long)(pass - 1) * B + bl) * 4096, 1 << widths[pass - 1], s.need, sm, &b, &above, &bc);
+        s.prefix |= (unsigned)b << shifts[pass - 1];
+        s.mask |= (unsigned)((1 << widths[pass - 1]) - 1) << shifts[pass - 1];
+        s.need -= above;
+        s.bucket_count = bc;
+    }
+    const int shift = shifts[pass], nb = 1 << widths[pass];
+    for (int i = threadIdx.x; i < nb; i += 1024) hist[i] = 0;
+    __syncthreads();
+    const unsigned* kp = keys_all + (long)n * g.sumA + g.off[l] + (long)c * kTopkChunk;
+    const int cnt = min(kTopkChunk, nel - c * kTopkChunk);
+    for_each_key(kp, cnt, [&](unsigned key, int, bool ok) {
+        hist_add(hist, (key >> shift) & (nb - 1), ok && (key & s.mask) == s.prefix);
     });
     __syncthreads();
-    if (!take_all_eq) {               // ties beyond k: ordered selection of the lowest-index copies of the k-th key
+    int* out = hists + ((long)pass * B + bl) * 4096;
+    for (int i = threadIdx.x; i < nb; i += 1024) {
+        const int v = hist[i];
+        if (v) atomicAdd(out + i, v);
+    }
+    // the next launch reads the state this launch started from (+ this launch's bucket): written by a workgroup that
+    // only reads its own copy, after everyone in THIS launch can only have read the previous launch's value
+    if (c == 0 && threadIdx.x == 0 && pass > 0) state[B + bl] = s;   // staging slot, promoted below
+}
+
+// promote the staged chain state (a launch boundary separates it from the readers)
+__global__ void topk_promote_kernel(TopkState* __restrict__ state, int B) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < B) state[i] = state[B + i];
+}
+
+// final: k-th key from the last histogram, collect the winners of this chunk (unordered append)
+__global__ __launch_bounds__(1024) void topk_collect_kernel(Geom g, const unsigned* __restrict__ keys_all, int* __restrict__ hists, const TopkState* __restrict__ state,
+                                                            unsigned long long* __restrict__ cand /*[B][kTopkCap]*/, int* __restrict__ fill /*[B]*/,
+                                                            TopkState* __restrict__ final_state /*[B]*/) {
+    __shared__ int sm[20];
+    const int c = blockIdx.x, l = blockIdx.y, n = blockIdx.z, B = gridDim.y * gridDim.z, bl = n * g.nl + l;
+    const int nel = g.H[l] * g.W[l] * g.A;
+    if (c * kTopkChunk >= nel) return;
+    TopkState s = state[bl];
+    int b, above, bc;
+    find_bucket(hists + ((long)2 * B + bl) * 4096, 256, s.need, sm, &b, &above, &bc);
+    const unsigned kth = s.prefix | (unsigned)b;
+    const int need = s.need - above;                 // copies of kth to take (lowest indices), of `bc`
+    const bool take_all_eq = bc == need;
+    if (c == 0 && threadIdx.x == 0) { TopkState f; f.prefix = kth; f.mask = ~0u; f.need = need; f.bucket_count = bc; final_state[bl] = f; }
+    const unsigned* kp = keys_all + (long)n * g.sumA + g.off[l] + (long)c * kTopkChunk;
+    const int cnt = min(kTopkChunk, nel - c * kTopkChunk);
+    unsigned long long* out = cand + (long)bl * kTopkCap;
+    const int lane = threadIdx.x & 63;
+    for_each_key(kp, cnt, [&](unsigned key, int i, bool ok) {
+        const bool win = ok && (key > kth || (take_all_eq && key == kth));
+        const unsigned long long m = __ballot(win);
+        if (m) {                                      // one global atomic per wave
+            int base = 0;
+            if (lane == 0) base = atomicAdd(fill + bl, __popcll(m));
+            base = __shfl(base, 0, 64);
+            if (win) out[base + __popcll(m & ((1ull << lane) - 1ull))] = ((unsigned long long)(~key) << 32) | (unsigned)(c * kTopkChunk + i);
+        }
+    });
+}
+
+// per (level, image): bring the candidates into LDS, resolve ties beyond k (rare), sort by (key desc, index asc)
+__global__ __launch_bounds__(1024) void topk_sort_kernel(Geom g, const unsigned* __restrict__ keys_all, int pre_nms_topk, const TopkState* __restrict__ final_state,
+                                                         const int* __restrict__ fill, unsigned long long* __restrict__ cand, int* __restrict__ cand_count) {
+    __shared__ unsigned long long keys[kTopkCap];
+    __shared__ int sm[17];
+    const int l = blockIdx.x, n = blockIdx.y, bl = n * g.nl + l;
+    const int nel = g.H[l] * g.W[l] * g.A;
+    const int k = min(pre_nms_topk, nel);
+    const TopkState f = final_state[bl];
+    const int have = fill[bl];
+    unsigned long long* io = cand + (long)bl * kTopkCap;
+    for (int i = threadIdx.x; i < kTopkCap; i += 1024) keys[i] = i < have ? io[i] : ~0ull;
+    __syncthreads();
+    if (f.bucket_count != f.need) {                  // more copies of the k-th key than fit: take the lowest indices
+        const unsigned* kp = keys_all + (long)n * g.sumA + g.off[l];
         int base_eq = 0;
-        for (int s0 = 0; s0 < nel && base_eq < need; s0 += blockDim.x) {
-            int i = s0 + threadIdx.x;
-            bool eq = i < nel && kp[i] == kth;
+        for (int s0 = 0; s0 < nel && base_eq < f.need; s0 += 1024) {
+            const int i = s0 + threadIdx.x;
+            const bool eq = i < nel && kp[i] == f.prefix;
             int te;
-            int re = block_rank(eq, sm, &te);
-            if (eq && base_eq + re < need) keys[(k - need) + base_eq + re] = ((unsigned long long)(~kth) << 32) | (unsigned)i;
+            const int re = block_rank(eq, sm, &te);
+            if (eq && base_eq + re < f.need) keys[(k - f.need) + base_eq + re] = ((unsigned long long)(~f.prefix) << 32) | (unsigned)i;
             base_eq += te;
         }
         __syncthreads();
     }
     bitonic_sort_u64(keys, kTopkCap);
-    unsigned long long* out = cand + ((long)n * g.nl + l) * kTopkCap;
-    for (int i = threadIdx.x; i < kTopkCap; i += blockDim.x) out[i] = keys[i];
-    if (threadIdx.x == 0) cand_count[n * g.nl + l] = k;
+    for (int i = threadIdx.x; i < kTopkCap; i += 1024) io[i] = keys[i];
+    if (threadIdx.x == 0) cand_count[bl] = k;
 }
 
 __device__ __forceinline__ float4 apply_deltas_d2(const float4 box, float dx, float dy, float dw, float dh, float wx, float wy, float ww, float wh) {
@@ -555,6 +622,7 @@ extern "C" size_t aldi_rpn_proposals_workspace(int N, int num_levels) {
     s += B * cap * (cap / 64) * 8;   // nms mask
     s += B * cap * 4 + B * 4 + 256;  // keep, keep_count
     s += (size_t)N * 512 * 1024 * 4; // objectness keys (sumA <= 512K per image)
+    s += (size_t)3 * B * 4096 * 4 + 3 * B * 16 + B * 4 + 1024;   // radix-select histograms, chain state, fill counters
     return s + 1024;
 }
 
@@ -581,8 +649,26 @@ extern "C" int aldi_rpn_proposals(const aldi_rpn_geom* gm, float* const* head, c
     auto* okeys = (unsigned*)take((size_t)N * g.sumA * 4);
     hipLaunchKernelGGL(rpn_keys_kernel, dim3(cdiv((long)N * g.sumA, 256)), dim3(256), 0, st, g, N, okeys);
     ALDI_CHECK_LAUNCH();
-    hipLaunchKernelGGL(rpn_topk_kernel, dim3(g.nl, N), dim3(1024), 0, st, g, okeys, pre_nms_topk, cand, cand_count);
-    ALDI_CHECK_LAUNCH();
+    {
+        // exact top-k per (level, image): multi-workgroup radix select (see topk_hist_kernel)
+        auto* hists = (int*)take((size_t)3 * B * 4096 * 4);
+        auto* tstate = (TopkState*)take((size_t)3 * B * sizeof(TopkState));     // [current | staging | final]
+        auto* fill = (int*)take(B * 4);
+        hipError_t e = hipMemsetAsync(hists, 0, (size_t)((char*)fill + B * 4 - (char*)hists), st);
+        if (e != hipSuccess) return aldi_set_error(e, __FILE__, __LINE__);
+        int max_nel = 0;
+        for (int l = 0; l < g.nl; ++l) max_nel = g.H[l] * g.W[l] * g.A > max_nel ? g.H[l] * g.W[l] * g.A : max_nel;
+        dim3 grid(cdiv(max_nel, kTopkChunk), g.nl, N);
+        for (int pass = 0; pass < 3; ++pass) {
+            hipLaunchKernelGGL(topk_hist_kernel, grid, dim3(1024), 0, st, g, okeys, pre_nms_topk, pass, hists, tstate);
+            ALDI_CHECK_LAUNCH();
+            if (pass > 0) { hipLaunchKernelGGL(topk_promote_kernel, dim3(cdiv((long)B, 64)), dim3(64), 0, st, tstate, (int)B); ALDI_CHECK_LAUNCH(); }
+        }
+        hipLaunchKernelGGL(topk_collect_kernel, grid, dim3(1024), 0, st, g, okeys, hists, tstate, cand, fill, tstate + 2 * B);
+        ALDI_CHECK_LAUNCH();
+        hipLaunchKernelGGL(topk_sort_kernel, dim3(g.nl, N), dim3(1024), 0, st, g, okeys, pre_nms_topk, tstate + 2 * B, fill, cand, cand_count);
+        ALDI_CHECK_LAUNCH();
+    }
     hipLaunchKernelGGL(rpn_decode_kernel, dim3(cap / 256, g.nl, N), dim3(256), 0, st, g, (const float4*)anchors, cand, cand_count, img_hw, boxes, scores, valid, err_flag);
     ALDI_CHECK_LAUNCH();
     hipLaunchKernelGGL(nms_mask_kernel, dim3(cap / 64, cap / 64, (unsigned)B), dim3(64), 0, st, boxes, valid, (const int*)nullptr, cand_count, (int)cap, nms_thresh, mask);

@@ -110,7 +110,7 @@ class DgradWeightsPlan:
             it = items[i]
             it.w_master, it.scale, it.wt = w.data_ptr(), (sc.data_ptr() if sc is not None else None), o.data_ptr()
             it.Cout, it.KH, it.KW, it.Cin, it.tile_begin, it.reserved = Cout, KH, KW, Cin, tile, 0
-            tile += (sizes[i] + 1023) // 1024
+            tile += KH * KW * ((Cout + 31) // 32) * ((Cin + 31) // 32)
         self.total_tiles = tile
         self.n = len(entries)
         raw = torch.frombuffer(bytearray(bytes(items)), dtype=torch.uint8)

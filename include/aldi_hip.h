@@ -84,7 +84,8 @@ int aldi_dgrad_weights(const float* w_master, const float* scale, void* wt, int 
                        int dtype, aldi_stream_t stream);
 
 /* Batched form: one launch re-derives the data-gradient weights of every layer after an optimizer step.  `items` is a
- * DEVICE array of n_items descriptors; layer i owns the 1024-element tiles [tile_begin_i, tile_begin_{i+1}) of the launch
+ * DEVICE array of n_items descriptors; layer i owns the tiles [tile_begin_i, tile_begin_{i+1}) of the launch, one tile =
+ * 32 output channels x 32 input channels of one tap: KH*KW * ceil(Cout/32) * ceil(Cin/32) tiles per layer
  * (tile_begin ascending, total_tiles = end of the last layer). */
 typedef struct aldi_dgw_item {
     const float* w_master;   /* [Cout][KH][KW][Cin] fp32 */
