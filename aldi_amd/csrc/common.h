@@ -64,6 +64,21 @@ __device__ __forceinline__ void store4(bf16_t* p, const float v[4]) {
     *reinterpret_cast<uint2*>(p) = t;
 }
 
+// fp32 atomic add through a raw buffer descriptor: fire-and-forget (no returned value, so no wait), and an offset with
+// bit 31 set is out of range and dropped by the hardware -- "if (valid) atomicAdd(...)" becomes a select of the
+// offset.  (A C++ atomic inside a per-element branch makes hipcc wait vmcnt(0) after every single one.)
+constexpr unsigned kBufOOB = 0x80000000u;
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc_uniform(const void* ptr, unsigned bytes) {
+    const uintptr_t a = reinterpret_cast<uintptr_t>(ptr);
+    return __builtin_amdgcn_make_buffer_rsrc(
+        reinterpret_cast<void*>(((uintptr_t)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)(a >> 32)) << 32) |
+                                (uintptr_t)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)a)),
+        0, __builtin_amdgcn_readfirstlane(bytes), 0x00020000);
+}
+__device__ __forceinline__ void buf_atomic_add_f32(__amdgpu_buffer_rsrc_t r, unsigned byte_off, float v) {
+    __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(v, r, byte_off, 0, 0);
+}
+
 __device__ __forceinline__ float warp_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

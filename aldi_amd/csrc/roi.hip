@@ -79,6 +79,7 @@ __global__ void roi_from_proposals_kernel(const float4* __restrict__ props, cons
 struct Feats {
     const void* f[4];
     float* g[4];
+    unsigned gbytes[4];
     int H[4], W[4];
     float scale[4];
     int C;
@@ -148,7 +149,10 @@ __global__ __launch_bounds__(256) void roialign_kernel(Feats ft, const float* __
         // Backward.  For one sample row (iy) the sample columns sweep left -> right over all P bins, touching the pixel
         // pairs (xlo, xlo+1) of the two feature rows (ylo, yhi): keep that 2x2 window in registers and flush a column with
         // ONE atomic per row when the sweep leaves it -- ~2 atomics per touched pixel instead of 4 per sample.
-        float* G = ft.g[l] + (long)b * H * W * ft.C + c;
+        // fire-and-forget buffer atomics on this level's gradient map (block-uniform descriptor); a zero contribution
+        // or an out-of-map column becomes an out-of-range offset, which the hardware drops -- no branch, no wait
+        const __amdgpu_buffer_rsrc_t rg = make_rsrc_uniform(ft.g[l], ft.gbytes[l]);
+        const unsigned gbase = ((unsigned)b * (unsigned)(H * W) * (unsigned)ft.C + (unsigned)c) * 4u;
         float gbin[8];
 #pragma unroll
         for (int pw = 0; pw < 8; ++pw)
@@ -157,17 +161,18 @@ __global__ __launch_bounds__(256) void roialign_kernel(Feats ft, const float* __
             const float y = y1 + (float)ph * bh + ((float)iy + 0.5f) * bh / (float)gh;
             const Bilin by = bilin_prep(y, H);
             if (by.dead) continue;
-            float* Glo = G + (long)by.lo * W * ft.C;
-            float* Ghi = G + (long)by.hi * W * ft.C;
+            const unsigned Glo = gbase + (unsigned)(by.lo * W) * (unsigned)ft.C * 4u;
+            const unsigned Ghi = gbase + (unsigned)(by.hi * W) * (unsigned)ft.C * 4u;
+            const unsigned cstep = (unsigned)ft.C * 4u;
             int cur = -1;                       // window covers pixel columns cur, cur+1
             float a0l = 0.f, a0h = 0.f, a1l = 0.f, a1h = 0.f;   // [column 0/1][row lo/hi]
             auto flush0 = [&]() {
-                if (a0l != 0.f) unsafeAtomicAdd(Glo + (long)cur * ft.C, a0l);
-                if (a0h != 0.f) unsafeAtomicAdd(Ghi + (long)cur * ft.C, a0h);
+                buf_atomic_add_f32(rg, a0l != 0.f ? Glo + (unsigned)cur * cstep : kBufOOB, a0l);
+                buf_atomic_add_f32(rg, a0h != 0.f ? Ghi + (unsigned)cur * cstep : kBufOOB, a0h);
             };
             auto flush1 = [&]() {
-                if (a1l != 0.f) unsafeAtomicAdd(Glo + (long)(cur + 1) * ft.C, a1l);
-                if (a1h != 0.f) unsafeAtomicAdd(Ghi + (long)(cur + 1) * ft.C, a1h);
+                buf_atomic_add_f32(rg, a1l != 0.f ? Glo + (unsigned)(cur + 1) * cstep : kBufOOB, a1l);
+                buf_atomic_add_f32(rg, a1h != 0.f ? Ghi + (unsigned)(cur + 1) * cstep : kBufOOB, a1h);
             };
             for (int pw = 0; pw < P; ++pw) {
                 const float gv = gbin[pw];
@@ -412,6 +417,7 @@ Feats make_feats(const aldi_roi_feats* f, bool bwd) {
     Feats ft;
     for (int l = 0; l < 4; ++l) {
         ft.f[l] = f->feat[l]; ft.g[l] = bwd ? f->grad[l] : nullptr;
+        ft.gbytes[l] = 0x7fffffffu;   // the maps are far below 2 GiB; the bound only has to reject the "dropped" offsets (bit 31)
         ft.H[l] = f->H[l]; ft.W[l] = f->W[l]; ft.scale[l] = f->scale[l];
     }
     ft.C = f->C;

@@ -26,7 +26,7 @@ struct WgDev {
     const void* x; const void* g; float* dw; const float* scale;
     int N, H, W, Cin, Cout, KH, KW, stride, pad, Ho, Wo;
     int M, K, pix_per_split, ident, xcd;
-    unsigned x_bytes, g_bytes;
+    unsigned x_bytes, g_bytes, dw_bytes;
 };
 
 __device__ __forceinline__ int swz8(int row, int c) { return c ^ ((row >> 1) & 7); }
@@ -54,8 +54,6 @@ __global__ __launch_bounds__(256) void wgrad_bf16_kernel(WgDev p) {
     const int co0 = blockIdx.x * 128, kk0 = blockIdx.y * 128;
     const int pbeg = blockIdx.z * p.pix_per_split;
     const int pend = min(p.M, pbeg + p.pix_per_split);
-    const bf16_t* __restrict__ X = static_cast<const bf16_t*>(p.x);
-    const bf16_t* __restrict__ G = static_cast<const bf16_t*>(p.g);
 
     // loader role: waves 0,1 -> g tile (channels = co); waves 2,3 -> x tile (channels = kk)
     const bool isB = wave >= 2;
@@ -146,19 +144,23 @@ __global__ __launch_bounds__(256) void wgrad_bf16_kernel(WgDev p) {
         }
     }
     // D[row = co][col = kk]
+    {   // split-K partial tile -> fp32 gradient: 64 fire-and-forget buffer atomics per lane, out-of-tile lanes dropped
+        const __amdgpu_buffer_rsrc_t rdw = make_rsrc_uniform(p.dw, p.dw_bytes);
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            int co = co0 + wm * 64 + i * 16 + fq * 4 + r;
-            if (co >= p.Cout) continue;
-            float sc = p.scale ? p.scale[co] : 1.f;
+            for (int r = 0; r < 4; ++r) {
+                const int co = co0 + wm * 64 + i * 16 + fq * 4 + r;
+                const bool cok = co < p.Cout;
+                const float sc = p.scale ? p.scale[cok ? co : 0] : 1.f;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                int kk = kk0 + wn * 64 + j * 16 + fr;
-                if (kk < p.K) unsafeAtomicAdd(p.dw + (long)co * p.K + kk, acc[i][j][r] * sc);
+                for (int j = 0; j < 4; ++j) {
+                    const int kk = kk0 + wn * 64 + j * 16 + fr;
+                    const unsigned off = (cok && kk < p.K) ? ((unsigned)co * (unsigned)p.K + (unsigned)kk) * 4u : kBufOOB;
+                    buf_atomic_add_f32(rdw, off, acc[i][j][r] * sc);
+                }
             }
-        }
+    }
 }
 
 // Lean form of the same kernel for the shapes the network actually has (1x1 stride-1 convs / FC, and stride-1 "same"
@@ -306,28 +308,27 @@ __device__ __forceinline__ void wgrad_bf16_lean_body(const WgDev& p, uint4* lds)
                                                                          *reinterpret_cast<bf16x8_t*>(&bfr[j]), acc[i][j], 0, 0, 0);
         }
     }
+    {   // split-K partial tile -> fp32 gradient: 64 fire-and-forget buffer atomics per lane, out-of-tile lanes dropped
+        const __amdgpu_buffer_rsrc_t rdw = make_rsrc_uniform(p.dw, p.dw_bytes);
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            int co = co0 + wm * 64 + i * 16 + fq * 4 + r;
-            if (co >= p.Cout) continue;
-            float sc = p.scale ? p.scale[co] : 1.f;
+            for (int r = 0; r < 4; ++r) {
+                const int co = co0 + wm * 64 + i * 16 + fq * 4 + r;
+                const bool cok = co < p.Cout;
+                const float sc = p.scale ? p.scale[cok ? co : 0] : 1.f;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                int kk = kk0 + wn * 64 + j * 16 + fr;
-                if (kk < p.K) unsafeAtomicAdd(p.dw + (long)co * p.K + kk, acc[i][j][r] * sc);
+                for (int j = 0; j < 4; ++j) {
+                    const int kk = kk0 + wn * 64 + j * 16 + fr;
+                    const unsigned off = (cok && kk < p.K) ? ((unsigned)co * (unsigned)p.K + (unsigned)kk) * 4u : kBufOOB;
+                    buf_atomic_add_f32(rdw, off, acc[i][j][r] * sc);
+                }
             }
-        }
+    }
 }
 
-// two register budgets: 3 workgroups per CU (<= 168 VGPRs) for short pixel ranges, where latency hiding comes from
-// occupancy, and the unconstrained schedule (2 per CU, deeper load hoisting) for long ones
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void wgrad_bf16_lean3_kernel(WgDev p) {
-    __shared__ uint4 lds[2 * 128 * 8];
-    wgrad_bf16_lean_body(p, lds);
-}
-__global__ __launch_bounds__(256) void wgrad_bf16_lean2_kernel(WgDev p) {
+// <= 168 VGPRs: three workgroups per CU
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void wgrad_bf16_lean_kernel(WgDev p) {
     __shared__ uint4 lds[2 * 128 * 8];
     wgrad_bf16_lean_body(p, lds);
 }
@@ -465,6 +466,9 @@ extern "C" int aldi_conv_wgrad(const aldi_wgrad_args* a, aldi_stream_t stream) {
             return aldi_set_error_msg(ALDI_ERR_ARG, "conv_wgrad: operand larger than 2 GiB (32-bit buffer offsets)");
         d.x_bytes = (unsigned)xb;
         d.g_bytes = (unsigned)gb;
+        const size_t wb = (size_t)a->Cout * d.K * 4;
+        if (wb >= 0x80000000ull) return aldi_set_error_msg(ALDI_ERR_ARG, "conv_wgrad: gradient larger than 2 GiB (32-bit buffer offsets)");
+        d.dw_bytes = (unsigned)wb;
     }
     d.ident = (a->KH == 1 && a->KW == 1 && a->stride == 1 && a->pad == 0 && a->Ho == a->H && a->Wo == a->W) ? 1 : 0;
     hipStream_t st = static_cast<hipStream_t>(stream);
@@ -487,11 +491,7 @@ extern "C" int aldi_conv_wgrad(const aldi_wgrad_args* a, aldi_stream_t stream) {
     d.xcd = xcd_env;
     static const int lean_env = getenv("ALDI_WGRAD_LEAN") ? atoi(getenv("ALDI_WGRAD_LEAN")) : 1;
     const bool same = a->stride == 1 && a->Ho == a->H && a->Wo == a->W && 2 * a->pad == a->KH - 1 && a->KH == a->KW && a->Cin % 64 == 0;
-    if (a->dtype == ALDI_BF16 && lean_env && (d.ident || same)) {
-        const bool deep = lean_env == 2;
-        if (deep) hipLaunchKernelGGL(wgrad_bf16_lean2_kernel, grid, dim3(256), 0, st, d);
-        else hipLaunchKernelGGL(wgrad_bf16_lean3_kernel, grid, dim3(256), 0, st, d);
-    }
+    if (a->dtype == ALDI_BF16 && lean_env && (d.ident || same)) hipLaunchKernelGGL(wgrad_bf16_lean_kernel, grid, dim3(256), 0, st, d);
     else if (a->dtype == ALDI_BF16) hipLaunchKernelGGL(wgrad_bf16_kernel, grid, dim3(256), 0, st, d);
     else if (a->dtype == ALDI_F32) hipLaunchKernelGGL(wgrad_f32_kernel, grid, dim3(256), 0, st, d);
     else return aldi_set_error_msg(ALDI_ERR_ARG, "conv_wgrad: bad dtype");
