@@ -1,6 +1,7 @@
 // Small bandwidth-bound kernels around the dense path: weight re-layouts, casts, stem,
 // pooling, FPN glue, optimizer and EMA streams.
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -127,6 +128,87 @@ __global__ __launch_bounds__(256) void stem_kernel(StemDev p) {
                 v[r] = t > 0.f ? t : 0.f;
             }
             store4(out + q * 4, v);
+        }
+    }
+}
+
+// bf16 form on the matrix cores.  GEMM view per block: 256 pixels (16x16) x 64 channels x K, with the reduction laid
+// out as k = (c*7 + kh)*8 + kw (kw = 7 is a zero-weight pad, 21 (c,kh) rows padded to 24 -> K = 192 = 6 MFMA k-steps), so
+// that the 8 consecutive k of a fragment lane are 8 consecutive input columns of one (c, row) of the LDS image tile --
+// the im2col gather is four aligned ds_read_b32.  The fp32 kernel above is VALU bound (147x64 FMAs per pixel).
+__global__ __launch_bounds__(256) void stem_mfma_kernel(StemDev p) {
+    constexpr int TH = 37, TW = 40, WK = 200;            // tile rows / padded row (elements); padded weight row
+    __shared__ __attribute__((aligned(16))) bf16_t wl[64 * WK];
+    __shared__ __attribute__((aligned(16))) bf16_t tile[3 * TH * TW];
+    const int n = blockIdx.z;
+    const int oy0 = blockIdx.y * 16, ox0 = blockIdx.x * 16;
+    for (int i = threadIdx.x; i < 64 * 192; i += 256) {
+        const int co = i / 192, k = i - co * 192;
+        const int idx = k >> 3, kw = k & 7;
+        float v = 0.f;
+        if (idx < 21 && kw < 7) {
+            const int c = idx / 7, kh = idx - c * 7;
+            v = p.w[co * 147 + (kh * 7 + kw) * 3 + c];
+        }
+        wl[co * WK + k] = f32_to_bf16(v);
+    }
+    const int iy0 = oy0 * 2 - 3, ix0 = ox0 * 2 - 3;
+    const int h = p.h[n], w = p.wd[n];
+    for (int i = threadIdx.x; i < 3 * TH * TW; i += 256) {
+        const int c = i / (TH * TW), r = i - c * TH * TW;
+        const int yy = r / TW, xx = r - yy * TW;
+        const int iy = iy0 + yy, ix = ix0 + xx;
+        float v = 0.f;
+        if (xx < TH && iy >= 0 && iy < h && ix >= 0 && ix < w)
+            v = ((float)p.img[(((long)n * 3 + c) * p.Hs + iy) * p.Ws + ix] - p.mean[c]) * p.inv_std[c];
+        tile[i] = f32_to_bf16(v);
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int fr = lane & 15, fq = lane >> 4;
+    f32x4_t acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    const uint32_t* tile32 = reinterpret_cast<const uint32_t*>(tile);
+    const uint4* wl16 = reinterpret_cast<const uint4*>(wl);
+#pragma unroll
+    for (int s = 0; s < 6; ++s) {
+        int idx = s * 4 + fq;
+        idx = idx < 21 ? idx : 20;                       // padded rows carry zero weights; keep the address inside the tile
+        const int c = idx / 7, kh = idx - c * 7;
+        uint4 xf[4], wf[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int ty = wave * 4 + i;
+            const int e = ((c * TH + ty * 2 + kh) * TW + fr * 2) >> 1;       // 32-bit word index (fr*2 is even)
+            xf[i] = make_uint4(tile32[e], tile32[e + 1], tile32[e + 2], tile32[e + 3]);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) wf[j] = wl16[((j * 16 + fr) * WK + (s * 4 + fq) * 8) >> 3];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<bf16x8_t*>(&wf[j]), *reinterpret_cast<bf16x8_t*>(&xf[i]),
+                                                                     acc[i][j], 0, 0, 0);
+    }
+    // lane owns pixel (row wave*4+i, column fr), channels j*16 + fq*4 .. +3
+    bf16_t* Y = static_cast<bf16_t*>(p.y);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int ch = j * 16 + fq * 4;
+        const float4 sc = *reinterpret_cast<const float4*>(p.scale + ch), sh = *reinterpret_cast<const float4*>(p.shift + ch);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int oy = oy0 + wave * 4 + i, ox = ox0 + fr;
+            if (oy < p.Hc && ox < p.Wc) {
+                uint2 o;
+                o.x = pack2_bf16(fmaxf(acc[i][j][0] * sc.x + sh.x, 0.f), fmaxf(acc[i][j][1] * sc.y + sh.y, 0.f));
+                o.y = pack2_bf16(fmaxf(acc[i][j][2] * sc.z + sh.z, 0.f), fmaxf(acc[i][j][3] * sc.w + sh.w, 0.f));
+                *reinterpret_cast<uint2*>(Y + (((long)n * p.Hc + oy) * p.Wc + ox) * 64 + ch) = o;
+            }
         }
     }
 }
@@ -311,6 +393,12 @@ extern "C" int aldi_stem_forward(const aldi_stem_args* a, aldi_stream_t stream) 
     for (int c = 0; c < 3; ++c) { d.mean[c] = a->mean[c]; d.inv_std[c] = 1.0f / a->std[c]; }
     dim3 grid(cdiv(a->Wc, 16), cdiv(a->Hc, 16), a->N);
     hipStream_t st = static_cast<hipStream_t>(stream);
+    static const int mfma_env = getenv("ALDI_STEM_MFMA") ? atoi(getenv("ALDI_STEM_MFMA")) : 1;
+    if (a->dtype == ALDI_BF16 && mfma_env && a->scale && a->shift) {
+        hipLaunchKernelGGL(stem_mfma_kernel, grid, dim3(256), 0, st, d);
+        ALDI_CHECK_LAUNCH();
+        return ALDI_OK;
+    }
     DISPATCH_T(a->dtype, stem_kernel, grid, dim3(256), st, d);
     return ALDI_OK;
 }

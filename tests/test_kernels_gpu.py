@@ -201,6 +201,14 @@ def test_stem_and_pool_vs_oracle():
     y = ops.maxpool3s2(y)
     torch.cuda.synchronize()
     assert (y.cpu().permute(0, 3, 1, 2) - ref).abs().max() < 2e-5 * ref.abs().max()
+    # bf16 mode runs the stem on the matrix cores (bf16 image / weights, fp32 accumulation): the oracle with its inputs
+    # rounded to bf16 is the yardstick, up to accumulation order and the bf16 rounding of the output
+    xb, wb = x.bfloat16().float(), sd[p + ".weight"].bfloat16().float()
+    refb = F.relu(F.conv2d(xb, wb, None, 2, 3) * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1))
+    yb = ops.stem_forward(st.to(DEV), sizes, w.to(DEV), scale.to(DEV), shift.to(DEV), cfg["pixel_mean"], cfg["pixel_std"], torch.bfloat16)
+    torch.cuda.synchronize()
+    err = (yb.float().cpu().permute(0, 3, 1, 2) - refb).abs().max()
+    assert err < 8e-3 * refb.abs().max(), float(err / refb.abs().max())
 
 
 def _rand_boxes(n, w, h, g, lo=4.0, hi=120.0):
