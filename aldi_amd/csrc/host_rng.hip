@@ -9,7 +9,7 @@
 // Mersenne state.  Operates on the 5056-byte blob of torch.get_rng_state() / set_rng_state().
 #include "common.h"
 #include <string.h>
-#include <unordered_map>
+#include <vector>
 
 namespace {
 
@@ -19,12 +19,26 @@ struct Mt {
     uint32_t s[MT_N];
     int left;
     uint64_t next;
+    // The state refill is what `discard` spends its time in (a 268k-entry permutation skips ~430 refills per image), so
+    // it is written 4 lanes wide (baseline SSE2, no target switches): within a refill, element i reads s[i+1] (not yet rewritten) and s[i+397] / s[i-227]
+    // (old / rewritten >= 227 elements ago), so blocks of 4 consecutive elements are independent.
+    typedef uint32_t v4u __attribute__((vector_size(16)));
+    static inline v4u ld4(const uint32_t* p) { v4u v; memcpy(&v, p, 16); return v; }
+    static inline void st4(uint32_t* p, v4u v) { memcpy(p, &v, 16); }
+    static inline v4u twist4(v4u u, v4u v) {
+        const v4u hi = {0x80000000u, 0x80000000u, 0x80000000u, 0x80000000u};
+        const v4u mag = {0x9908b0dfu, 0x9908b0dfu, 0x9908b0dfu, 0x9908b0dfu};
+        const v4u one = {1, 1, 1, 1};
+        return (((u & hi) | (v & ~hi)) >> 1) ^ ((0u - (v & one)) & mag);
+    }
+    static inline uint32_t twist1(uint32_t u, uint32_t v) { return (((u & 0x80000000u) | (v & 0x7fffffffu)) >> 1) ^ ((v & 1u) ? 0x9908b0dfu : 0u); }
     void regen() {
-        auto twist = [](uint32_t u, uint32_t v) { return (((u & 0x80000000u) | (v & 0x7fffffffu)) >> 1) ^ ((v & 1u) ? 0x9908b0dfu : 0u); };
-        uint32_t* p = s;
-        for (int j = MT_N - MT_M + 1; --j; p++) *p = p[MT_M] ^ twist(p[0], p[1]);
-        for (int j = MT_M; --j; p++) *p = p[MT_M - MT_N] ^ twist(p[0], p[1]);
-        *p = p[MT_M - MT_N] ^ twist(p[0], s[0]);
+        int i = 0;
+        for (; i + 4 <= MT_N - MT_M; i += 4) st4(s + i, ld4(s + i + MT_M) ^ twist4(ld4(s + i), ld4(s + i + 1)));
+        for (; i < MT_N - MT_M; ++i) s[i] = s[i + MT_M] ^ twist1(s[i], s[i + 1]);
+        for (; i + 4 <= MT_N - 1; i += 4) st4(s + i, ld4(s + i + MT_M - MT_N) ^ twist4(ld4(s + i), ld4(s + i + 1)));
+        for (; i < MT_N - 1; ++i) s[i] = s[i + MT_M - MT_N] ^ twist1(s[i], s[i + 1]);
+        s[MT_N - 1] = s[MT_M - 1] ^ twist1(s[MT_N - 1], s[0]);
         left = MT_N;
         next = 0;
     }
@@ -66,17 +80,27 @@ extern "C" int aldi_torch_randperm_prefix(unsigned char* state, long n, long k, 
     for (int i = 0; i < MT_N; ++i) { memcpy(&w, state + 24 + 8 * i, 8); mt.s[i] = (uint32_t)w; }
     mt.left = left;
     mt.next = next;
-    std::unordered_map<long, long> moved;
-    moved.reserve((size_t)(2 * k + 8));
-    auto get = [&](long p) { auto it = moved.find(p); return it == moved.end() ? p : it->second; };
+    // sparse image of the permutation array: position -> value for the <= 2k positions touched so far (open addressing;
+    // a node-based map costs more than the shuffle itself for the small lists)
+    size_t cap = 64;
+    while (cap < (size_t)(4 * k + 16)) cap <<= 1;
+    std::vector<long> keys(cap, -1), vals(cap);
+    const size_t hmask = cap - 1;
+    auto slot = [&](long pos) {
+        size_t h = ((uint64_t)pos * 0x9E3779B97F4A7C15ull >> 20) & hmask;
+        while (keys[h] != -1 && keys[h] != pos) h = (h + 1) & hmask;
+        return h;
+    };
+    auto get = [&](long pos) { size_t h = slot(pos); return keys[h] == pos ? vals[h] : pos; };
+    auto put = [&](long pos, long v) { size_t h = slot(pos); keys[h] = pos; vals[h] = v; };
     const long iters = n > 0 ? n - 1 : 0;           // the reference loop: for (i = 0; i < n - 1; i++)
     const long run = k < iters ? k : iters;
     for (long i = 0; i < run; ++i) {
         long z = (long)(mt.draw() % (uint64_t)(n - i));
         long j = z + i;
         long vi = get(i), vj = get(j);
-        moved[i] = vj;
-        moved[j] = vi;
+        put(i, vj);
+        put(j, vi);
     }
     mt.discard(iters - run);
     for (long i = 0; i < k; ++i) out[i] = get(i);

@@ -91,68 +91,49 @@ __global__ void match_label_kernel(const float4* __restrict__ boxes, long box_st
 // ordered lists for subsample_labels: pos = (v != -1 && v != bg && v != -2), neg = (v == bg)
 // grid (2, N): blockIdx.x = kind
 // ---------------------------------------------------------------------------------------
-// one workgroup per (kind, image); a thread owns 16 consecutive labels per pass (four 16-B loads), so the block-wide
-// scan (two barriers) is paid once per 16K labels instead of once per 1K
+// one workgroup per (kind, image).  Per pass a WAVE owns 1024 consecutive labels as 16 coalesced rows of 64: a ballot per
+// row gives the in-row rank, the 16 popcounts the wave total; one block scan of the 16 wave totals per pass (16K labels),
+// then lanes with the flag set write consecutive output slots (coalesced) straight to global memory.
 __global__ __launch_bounds__(1024) void compact_kernel(const int* __restrict__ labels, int L, int bg,
                                                        int* __restrict__ lists /*[N][2][L]*/, int* __restrict__ counts /*[N][2]*/) {
-    constexpr int IT = 16;
+    constexpr int ROWS = 16;
     __shared__ int wsum[16];
-    __shared__ int stage[1024 * IT];
     const int kind = blockIdx.x, n = blockIdx.y;
     const int* lab = labels + (long)n * L;
     int* out = lists + ((long)n * 2 + kind) * L;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const bool vec_ok = ((reinterpret_cast<uintptr_t>(lab) & 15) == 0);
+    const unsigned long long lt = (1ull << lane) - 1ull;
     int base = 0;
-    for (int s = 0; s < L; s += 1024 * IT) {
-        const int i0 = s + tid * IT;
-        unsigned bits = 0;
-        if (i0 + IT <= L && vec_ok) {
+    for (int s = 0; s < L; s += 1024 * ROWS) {
+        const int i0 = s + w * (64 * ROWS) + lane;
+        unsigned long long m[ROWS];
+        int wtot = 0;
 #pragma unroll
-            for (int q = 0; q < IT / 4; ++q) {
-                const int4 v = *reinterpret_cast<const int4*>(lab + i0 + q * 4);
-                const int vv[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const bool f = kind == 0 ? (vv[k] != -1 && vv[k] != -2 && vv[k] != bg) : (vv[k] == bg);
-                    bits |= (unsigned)f << (q * 4 + k);
-                }
+        for (int k = 0; k < ROWS; ++k) {
+            const int i = i0 + k * 64;
+            bool f = false;
+            if (i < L) {
+                const int v = lab[i];
+                f = kind == 0 ? (v != -1 && v != -2 && v != bg) : (v == bg);
             }
-        } else {
-            for (int k = 0; k < IT; ++k)
-                if (i0 + k < L) {
-                    const int v = lab[i0 + k];
-                    const bool f = kind == 0 ? (v != -1 && v != -2 && v != bg) : (v == bg);
-                    bits |= (unsigned)f << k;
-                }
-        }
-        const int cnt = __popc(bits);
-        int incl = cnt;                       // inclusive wave scan
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            int t = __shfl_up(incl, o, 64);
-            if (lane >= o) incl += t;
+            m[k] = __ballot(f);
+            wtot += __popcll(m[k]);
         }
         __syncthreads();                      // previous pass's wsum reads are done
-        if (lane == 63) wsum[w] = incl;
+        if (lane == 0) wsum[w] = wtot;
         __syncthreads();
-        int wbase = 0, tot = 0;
+        int pos = base, tot = 0;
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
             const int c = wsum[i];
-            if (i < w) wbase += c;
+            if (i < w) pos += c;
             tot += c;
         }
-        // a thread's picks are contiguous in the output but threads are 16 labels apart: stage the pass through LDS so
-        // the global writes are full lines instead of 4-B pieces on 64 different lines per instruction
-        int pos = wbase + incl - cnt;
-        while (bits) {
-            const int k = __ffs(bits) - 1;
-            bits &= bits - 1;
-            stage[pos++] = i0 + k;
+#pragma unroll
+        for (int k = 0; k < ROWS; ++k) {
+            if ((m[k] >> lane) & 1ull) out[pos + __popcll(m[k] & lt)] = i0 + k * 64;
+            pos += __popcll(m[k]);
         }
-        __syncthreads();
-        for (int j = tid; j < tot; j += 1024) out[base + j] = stage[j];
         base += tot;
     }
     if (tid == 0) counts[n * 2 + kind] = base;

@@ -36,6 +36,27 @@ def stats(d, title):
         print("%-100s %6d %10.1f %10.1f %6.1f" % (n[:100], c, t, t / c, 100 * t / busy))
 
 
+def gaps(d, top="15"):
+    """largest idle gaps on the GPU timeline inside one step (host sync points / launch-bound stretches)"""
+    dbs = glob.glob(d + "/**/*_results.db", recursive=True)
+    cur = sqlite3.connect(dbs[0]).cursor()
+    tabs = [r[0] for r in cur.execute("select name from sqlite_master where type in ('table','view')")]
+    kt = "kernels" if "kernels" in tabs else [t for t in tabs if "kernel_dispatch" in t][0]
+    cols = [r[1] for r in cur.execute(f"pragma table_info({kt})")]
+    name = "name" if "name" in cols else "kernel_name"
+    rows = list(cur.execute(f"select {name}, start, end from {kt} order by start"))
+    sgd = [i for i, r in enumerate(rows) if "sgd_kernel" in r[0]]
+    a, b = sgd[-2], sgd[-1]
+    step = rows[a:b + 1]
+    g = []
+    for (n0, s0, e0), (n1, s1, e1) in zip(step[:-1], step[1:]):
+        g.append(((s1 - e0) / 1e3, n0[:60], n1[:60]))
+    tot = sum(x[0] for x in g if x[0] > 0)
+    print(f"# idle between kernels in one step: {tot / 1e3:.2f} ms over {len(g)} gaps; gaps > 20 us: {sum(x[0] for x in g if x[0] > 20) / 1e3:.2f} ms")
+    for us, n0, n1 in sorted(g, reverse=True)[:int(top)]:
+        print("%9.1f us   after %-60s before %s" % (us, n0, n1))
+
+
 def pmc(fetch_dir, write_dir):
     res = {}
     for key, d, ctr in (("fetch", fetch_dir, "FETCH_SIZE"), ("write", write_dir, "WRITE_SIZE")):
@@ -60,4 +81,4 @@ def pmc(fetch_dir, write_dir):
 
 
 if __name__ == "__main__":
-    {"stats": stats, "pmc": pmc}[sys.argv[1]](*sys.argv[2:])
+    {"stats": stats, "pmc": pmc, "gaps": gaps}[sys.argv[1]](*sys.argv[2:])
