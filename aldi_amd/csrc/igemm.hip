@@ -331,58 +331,81 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_kernel(ConvDev p) {
             const bool plain = p.out_scale == 1 && p.res_mode != 2;
             const unsigned char* rd = stg + rowl0 * ROWB + ch8 * 16;
             typedef short s16x2_t __attribute__((ext_vector_type(2)));
+            // Branch-free and latency-flat: byte offsets (out-of-tile rows -> the dropped/zero-filled range), then ALL the
+            // residual / mask loads of this lane in flight at once, then the arithmetic and the stores.  (A load next to a
+            // store inside one loop body is serialised behind it: Y and R may alias as far as the compiler knows.)
+            constexpr int NI = BM / RPI;
+            constexpr unsigned OOBX = 0x80000000u;
+            const __amdgpu_buffer_rsrc_t ry = make_rsrc_uniform(Y, 0x7fffffffu);
+            unsigned ooff[NI], roff[NI];
 #pragma unroll
-            for (int it = 0; it < BM / RPI; ++it) {
+            for (int it = 0; it < NI; ++it) {
                 const int m = m0 + rowl0 + it * RPI;
-                if (m >= p.M) break;
-                long oidx, ridx;
+                const bool ok = m < p.M;
+                unsigned oidx, ridx;
                 if (plain) {
-                    oidx = (long)m * p.Cout;
+                    oidx = (unsigned)m * (unsigned)p.Cout;
                     ridx = oidx;
                 } else {
-                    int n = m / (p.Ho * p.Wo);
-                    int r = m - n * (p.Ho * p.Wo);
-                    int ho = r / p.Wo, wo = r - ho * p.Wo;
-                    if (p.out_scale == 1) oidx = (long)m * p.Cout;
-                    else oidx = (((long)n * p.OH + ho * p.out_scale) * p.OW + wo * p.out_scale) * p.Cout;
-                    if (p.res_mode == 2) ridx = (((long)n * (p.Ho >> 1) + (ho >> 1)) * (p.Wo >> 1) + (wo >> 1)) * p.Cout;
+                    const int mm = ok ? m : 0;
+                    const int n = mm / (p.Ho * p.Wo);
+                    const int r = mm - n * (p.Ho * p.Wo);
+                    const int ho = r / p.Wo, wo = r - ho * p.Wo;
+                    if (p.out_scale == 1) oidx = (unsigned)mm * (unsigned)p.Cout;
+                    else oidx = (unsigned)((((long)n * p.OH + ho * p.out_scale) * p.OW + wo * p.out_scale) * p.Cout);
+                    if (p.res_mode == 2) ridx = (unsigned)((((long)n * (p.Ho >> 1) + (ho >> 1)) * (p.Wo >> 1) + (wo >> 1)) * p.Cout);
                     else ridx = oidx;
                 }
-                uint4 raw = *reinterpret_cast<const uint4*>(rd + it * RPI * ROWB);
-                uint32_t* rw_ = reinterpret_cast<uint32_t*>(&raw);
+                ooff[it] = ok ? (oidx + (unsigned)c) * 2u : OOBX;
+                roff[it] = ok ? (ridx + (unsigned)c) * 2u : OOBX;
+            }
+            u32x4_t rres[NI], rmsk[NI];
+            if (p.res_mode) {
+                const __amdgpu_buffer_rsrc_t rr_ = make_rsrc_uniform(R, 0x7fffffffu);
+#pragma unroll
+                for (int it = 0; it < NI; ++it) rres[it] = __builtin_amdgcn_raw_buffer_load_b128(rr_, roff[it], 0, 0);
+            }
+            if (Mk) {
+                const __amdgpu_buffer_rsrc_t rm_ = make_rsrc_uniform(Mk, 0x7fffffffu);
+#pragma unroll
+                for (int it = 0; it < NI; ++it) rmsk[it] = __builtin_amdgcn_raw_buffer_load_b128(rm_, ooff[it], 0, 0);
+            }
+#pragma unroll
+            for (int it = 0; it < NI; ++it) {
+                const uint4 raw4 = *reinterpret_cast<const uint4*>(rd + it * RPI * ROWB);
+                uint32_t raw[4] = {raw4.x, raw4.y, raw4.z, raw4.w};
                 if (p.res_mode) {
-                    const uint4 rr = *reinterpret_cast<const uint4*>(R + ridx + c);
-                    const uint32_t* r32 = reinterpret_cast<const uint32_t*>(&rr);
+                    const uint32_t rs[4] = {rres[it].x, rres[it].y, rres[it].z, rres[it].w};
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
-                        float lo = __uint_as_float(rw_[q] << 16) + __uint_as_float(r32[q] << 16);
-                        float hi = __uint_as_float(rw_[q] & 0xffff0000u) + __uint_as_float(r32[q] & 0xffff0000u);
+                        float lo = __uint_as_float(raw[q] << 16) + __uint_as_float(rs[q] << 16);
+                        float hi = __uint_as_float(raw[q] & 0xffff0000u) + __uint_as_float(rs[q] & 0xffff0000u);
                         if (p.relu) { lo = fmaxf(lo, 0.f); hi = fmaxf(hi, 0.f); }
-                        rw_[q] = pack2_bf16(lo, hi);
+                        raw[q] = pack2_bf16(lo, hi);
                     }
                 } else if (p.relu) {
                     // bf16 as int16: negative floats (and -0) are negative integers
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
-                        s16x2_t v = *reinterpret_cast<s16x2_t*>(&rw_[q]);
+                        s16x2_t v = *reinterpret_cast<s16x2_t*>(&raw[q]);
                         v = __builtin_elementwise_max(v, s16x2_t{0, 0});
-                        rw_[q] = *reinterpret_cast<uint32_t*>(&v);
+                        raw[q] = *reinterpret_cast<uint32_t*>(&v);
                     }
                 }
                 if (Mk) {
                     // keep where the forward activation (a ReLU output, so >= 0) is > 0: multiply the bit patterns by 0 / 1
-                    const uint4 mm = *reinterpret_cast<const uint4*>(Mk + oidx + c);
-                    const uint32_t* m32 = reinterpret_cast<const uint32_t*>(&mm);
+                    const uint32_t ms[4] = {rmsk[it].x, rmsk[it].y, rmsk[it].z, rmsk[it].w};
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
-                        s16x2_t k = *reinterpret_cast<const s16x2_t*>(&m32[q]);
+                        s16x2_t k = *reinterpret_cast<const s16x2_t*>(&ms[q]);
                         k = __builtin_elementwise_min(__builtin_elementwise_max(k, s16x2_t{0, 0}), s16x2_t{1, 1});
-                        s16x2_t v = *reinterpret_cast<s16x2_t*>(&rw_[q]);
+                        s16x2_t v = *reinterpret_cast<s16x2_t*>(&raw[q]);
                         v = v * k;
-                        rw_[q] = *reinterpret_cast<uint32_t*>(&v);
+                        raw[q] = *reinterpret_cast<uint32_t*>(&v);
                     }
                 }
-                *reinterpret_cast<uint4*>(Y + oidx + c) = raw;
+                const u32x4_t ov = {raw[0], raw[1], raw[2], raw[3]};
+                __builtin_amdgcn_raw_buffer_store_b128(ov, ry, ooff[it], 0, 0);
             }
             return;
         }
@@ -458,7 +481,6 @@ int dispatch(ConvDev& d, hipStream_t st) {
     d.xcd = xcd_env;
     static const int dbg_env = env_int("ALDI_IGEMM_DBG", 0);
     d.dbg = dbg_env;
-    const int ep = Elem<T>::kPer16B;
     if (d.Cout <= 16) return launch<T, 128, 16, 4, 1, 4>(d, st);
     if (d.Cout <= 64) return launch<T, 128, 64, 4, 1, 4>(d, st);
     // the N=2 micro-batch leaves the deep layers (res4/res5, FC heads) with far fewer 128x128 tiles than the
@@ -496,7 +518,9 @@ extern "C" int aldi_conv_igemm(const aldi_conv_args* a, aldi_stream_t stream) {
     d.K = a->KH * a->KW * a->Cin;
     const size_t esz = a->dtype == ALDI_BF16 ? 2 : 4;
     const size_t xb = (size_t)a->N * a->H * a->W * a->Cin * esz, wb = (size_t)a->Cout * d.K * esz;
-    if (xb >= 0x80000000ull || wb >= 0x80000000ull) return aldi_set_error_msg(ALDI_ERR_ARG, "conv_igemm: operand larger than 2 GiB (32-bit buffer offsets)");
+    const size_t yb = (size_t)a->N * (d.out_scale > 1 ? (size_t)a->OH * a->OW : (size_t)a->Ho * a->Wo) * a->Cout * esz;
+    if (xb >= 0x80000000ull || wb >= 0x80000000ull || yb >= 0x80000000ull)
+        return aldi_set_error_msg(ALDI_ERR_ARG, "conv_igemm: operand larger than 2 GiB (32-bit buffer offsets)");
     if (a->KH * a->KW > 16) return aldi_set_error_msg(ALDI_ERR_ARG, "conv_igemm: at most 16 taps");
     d.x_bytes = (unsigned)xb;
     d.w_bytes = (unsigned)wb;
