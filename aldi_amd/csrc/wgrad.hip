@@ -173,7 +173,13 @@ __global__ __launch_bounds__(256) void wgrad_bf16_kernel(WgDev p) {
 //     scalar unit -> one v_cndmask per load picks the out-of-range offset (buffer loads return zeros there);
 //   * the g operand needs no tests at all: its buffer descriptor ends at the split's last pixel;
 //   * the 8x8 16-bit transposes are v_perm_b32, one per output register.
+// TCO x TKK output tile (channels of g x (tap, channel) of x), 64 pixels per slab; (TCO + TKK) / 64 waves, each loading 64
+// channels of one operand and owning a (TCO / WM) x (TKK / WN) piece of the accumulator.
+template <int TCO, int TKK, int WM, int WN>
 __device__ __forceinline__ void wgrad_bf16_lean_body(const WgDev& p, uint4* lds) {
+    static_assert(WM * WN * 64 == TCO + TKK, "one loader wave per 64 channels");
+    constexpr int NGW = TCO / 64;                    // g-loader waves
+    constexpr int TM = TCO / WM / 16, TN = TKK / WN / 16;
     constexpr int BP = 64;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform role -> scalar descriptors
     // XCD-aware order: workgroup b runs on XCD b % 8; give every XCD a contiguous range of (split, tile) pairs, tile
@@ -189,14 +195,14 @@ __device__ __forceinline__ void wgrad_bf16_lean_body(const WgDev& p, uint4* lds)
         bx = bid % gx; bid /= gx;
         by = bid % gy; bz = bid / gy;
     }
-    const int co0 = bx * 128, kk0 = by * 128;
+    const int co0 = bx * TCO, kk0 = by * TKK;
     const int pbeg = bz * p.pix_per_split;
     const int pend = min(p.M, pbeg + p.pix_per_split);
     if (pbeg >= pend) return;
 
-    const bool isB = wave >= 2;                      // waves 0,1 load the g tile, waves 2,3 the x tile
+    const bool isB = wave >= NGW;                    // the first TCO/64 waves load the g tile, the rest the x tile
     const int pg = lane & 7;                         // 8-pixel group inside the slab
-    const int cc = (wave & 1) * 8 + (lane >> 3);     // 8-channel chunk inside the 128-wide tile
+    const int cc = (isB ? wave - NGW : wave) * 8 + (lane >> 3);     // 8-channel chunk inside this operand's tile
     constexpr unsigned OOB = 0x80000000u;
     typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
@@ -258,19 +264,19 @@ __device__ __forceinline__ void wgrad_bf16_lean_body(const WgDev& p, uint4* lds)
         off += BP * row_bytes;
     };
 
-    const int wm = wave >> 1, wn = wave & 1;
-    f32x4_t acc[4][4];
+    const int wm = wave / WN, wn = wave % WN;
+    f32x4_t acc[TM][TN];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < TN; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
     const int fr = lane & 15, fq = lane >> 4;
     // LDS slots are loop invariant and differ only by immediates / one XOR: fragment rows i*16 apart share the swizzle
     // term ((row>>1)&7 sees only fr), the second k-step flips chunk bit 2; write rows c share pg ^ (cc&1)*4 up to c>>1.
-    const int ra = wm * 64 + fr, rb = wn * 64 + fr;
+    const int ra = wm * (TCO / WM) + fr, rb = wn * (TKK / WN) + fr;
     const int ia0 = ra * 8 + swz8(ra, fq);
-    const int ib0 = (128 + rb) * 8 + swz8(rb, fq);
-    const int iw = ((isB ? 128 : 0) + cc * 8) * 8;
+    const int ib0 = (TCO + rb) * 8 + swz8(rb, fq);
+    const int iw = ((isB ? TCO : 0) + cc * 8) * 8;
     const int wu = pg ^ ((cc & 1) << 2);
 
     load_slab();
@@ -294,16 +300,16 @@ __device__ __forceinline__ void wgrad_bf16_lean_body(const WgDev& p, uint4* lds)
         __syncthreads();
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-            uint4 af[4], bfr[4];
+            uint4 af[TM], bfr[TN];
             const int ia = ia0 ^ (ks * 4), ib = ib0 ^ (ks * 4);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) af[i] = lds[ia + i * 128];
+            for (int i = 0; i < TM; ++i) af[i] = lds[ia + i * 128];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) bfr[j] = lds[ib + j * 128];
+            for (int j = 0; j < TN; ++j) bfr[j] = lds[ib + j * 128];
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
+                for (int j = 0; j < TN; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<bf16x8_t*>(&af[i]),
                                                                          *reinterpret_cast<bf16x8_t*>(&bfr[j]), acc[i][j], 0, 0, 0);
         }
@@ -311,15 +317,15 @@ __device__ __forceinline__ void wgrad_bf16_lean_body(const WgDev& p, uint4* lds)
     {   // split-K partial tile -> fp32 gradient: 64 fire-and-forget buffer atomics per lane, out-of-tile lanes dropped
         const __amdgpu_buffer_rsrc_t rdw = make_rsrc_uniform(p.dw, p.dw_bytes);
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < TM; ++i)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int co = co0 + wm * 64 + i * 16 + fq * 4 + r;
+                const int co = co0 + wm * (TCO / WM) + i * 16 + fq * 4 + r;
                 const bool cok = co < p.Cout;
                 const float sc = p.scale ? p.scale[cok ? co : 0] : 1.f;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int kk = kk0 + wn * 64 + j * 16 + fr;
+                for (int j = 0; j < TN; ++j) {
+                    const int kk = kk0 + wn * (TKK / WN) + j * 16 + fr;
                     const unsigned off = (cok && kk < p.K) ? ((unsigned)co * (unsigned)p.K + (unsigned)kk) * 4u : kBufOOB;
                     buf_atomic_add_f32(rdw, off, acc[i][j][r] * sc);
                 }
@@ -330,7 +336,13 @@ __device__ __forceinline__ void wgrad_bf16_lean_body(const WgDev& p, uint4* lds)
 // <= 168 VGPRs: three workgroups per CU
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void wgrad_bf16_lean_kernel(WgDev p) {
     __shared__ uint4 lds[2 * 128 * 8];
-    wgrad_bf16_lean_body(p, lds);
+    wgrad_bf16_lean_body<128, 128, 2, 2>(p, lds);
+}
+// 256 x 256 tile, 8 waves (128 x 64 each), one workgroup per CU: half the L2 -> CU bytes per FLOP, for layers whose
+// pixel ranges are long enough to amortise the 256-KB atomic epilogue
+__global__ __launch_bounds__(512) void wgrad_bf16_big_kernel(WgDev p) {
+    __shared__ uint4 lds[2 * 256 * 8];
+    wgrad_bf16_lean_body<256, 256, 2, 4>(p, lds);
 }
 
 // ------------------------------------------------------------------------------------ fp32
@@ -472,14 +484,27 @@ extern "C" int aldi_conv_wgrad(const aldi_wgrad_args* a, aldi_stream_t stream) {
     }
     d.ident = (a->KH == 1 && a->KW == 1 && a->stride == 1 && a->pad == 0 && a->Ho == a->H && a->Wo == a->W) ? 1 : 0;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    const int tile = a->dtype == ALDI_BF16 ? 128 : 64;
+    static const int lean_env = getenv("ALDI_WGRAD_LEAN") ? atoi(getenv("ALDI_WGRAD_LEAN")) : 1;
+    static const int big_min_env = getenv("ALDI_WGRAD_BIG_MIN") ? atoi(getenv("ALDI_WGRAD_BIG_MIN")) : 28;
+    static const int big_slots_env = getenv("ALDI_WGRAD_BIG_SLOTS") ? atoi(getenv("ALDI_WGRAD_BIG_SLOTS")) : 256;
+    const bool same = a->stride == 1 && a->Ho == a->H && a->Wo == a->W && 2 * a->pad == a->KH - 1 && a->KH == a->KW && a->Cin % 64 == 0;
+    const bool lean = a->dtype == ALDI_BF16 && lean_env && (d.ident || same);
     const int bp = a->dtype == ALDI_BF16 ? 64 : 16;
-    int tiles = cdiv(d.Cout, tile) * cdiv(d.K, tile);
     int slabs = cdiv(d.M, bp);
-    static const int slots_env = getenv("ALDI_WGRAD_SLOTS") ? atoi(getenv("ALDI_WGRAD_SLOTS")) : 384;
+    // 256x256 tile (one 8-wave workgroup per CU) when every workgroup still gets a long pixel range
+    bool big = false;
+    if (lean && big_min_env > 0 && d.Cout % 256 == 0 && d.K % 256 == 0) {
+        const int tb = (d.Cout / 256) * (d.K / 256);
+        const int sb = big_slots_env / tb;            // floor: one 8-wave workgroup per CU, never 257 of them
+        big = slabs / (sb > 0 ? sb : 1) >= big_min_env;
+    }
+    const int tile = big ? 256 : (a->dtype == ALDI_BF16 ? 128 : 64);
+    int tiles = cdiv(d.Cout, tile) * cdiv(d.K, tile);
+    static const int slots_env_ = getenv("ALDI_WGRAD_SLOTS") ? atoi(getenv("ALDI_WGRAD_SLOTS")) : 384;
+    const int slots_env = big ? big_slots_env : slots_env_;
     // the kernel is bound per CU (L2 -> CU path, LDS), not by latency: few, long splits (1-2 workgroups per CU) beat
     // many short ones, whose 16K-atomic epilogues also contend on the same dW lines
-    int splits = cdiv(slots_env, tiles);
+    int splits = big ? slots_env / tiles : cdiv(slots_env, tiles);
     if (splits > slabs / 4) splits = slabs / 4;    // ... but at least 4 slabs of work behind every 16K-atomic epilogue
     if (splits < 1) splits = 1;
     if (splits > 512) splits = 512;
@@ -489,9 +514,8 @@ extern "C" int aldi_conv_wgrad(const aldi_wgrad_args* a, aldi_stream_t stream) {
     dim3 grid(cdiv(d.Cout, tile), cdiv(d.K, tile), splits);
     static const int xcd_env = getenv("ALDI_WGRAD_XCD") ? atoi(getenv("ALDI_WGRAD_XCD")) : 1;
     d.xcd = xcd_env;
-    static const int lean_env = getenv("ALDI_WGRAD_LEAN") ? atoi(getenv("ALDI_WGRAD_LEAN")) : 1;
-    const bool same = a->stride == 1 && a->Ho == a->H && a->Wo == a->W && 2 * a->pad == a->KH - 1 && a->KH == a->KW && a->Cin % 64 == 0;
-    if (a->dtype == ALDI_BF16 && lean_env && (d.ident || same)) hipLaunchKernelGGL(wgrad_bf16_lean_kernel, grid, dim3(256), 0, st, d);
+    if (big) hipLaunchKernelGGL(wgrad_bf16_big_kernel, grid, dim3(512), 0, st, d);
+    else if (lean) hipLaunchKernelGGL(wgrad_bf16_lean_kernel, grid, dim3(256), 0, st, d);
     else if (a->dtype == ALDI_BF16) hipLaunchKernelGGL(wgrad_bf16_kernel, grid, dim3(256), 0, st, d);
     else if (a->dtype == ALDI_F32) hipLaunchKernelGGL(wgrad_f32_kernel, grid, dim3(256), 0, st, d);
     else return aldi_set_error_msg(ALDI_ERR_ARG, "conv_wgrad: bad dtype");
