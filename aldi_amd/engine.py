@@ -868,6 +868,7 @@ class RCNN:
             self._wgrad("roi_heads.box_head.fc1", x, g_fc1)
             g_pooled = ops.conv2d(g_fc1, W.wt("roi_heads.box_head.fc1")).view(c.R, POOL, POOL, FPN_C)
             ops.roialign(self.roi_feats(c, gP_roi), c.rois, c.R, POOL, g_pooled, backward=True)
+        self._grads_final(["box_pred", "roi_heads.box_head.fc2", "roi_heads.box_head.fc1"])
         # ---- RPN head (shared weights over 5 levels)
         gP = []
         for l in range(5):
@@ -899,14 +900,18 @@ class RCNN:
             ops.upsample2_bwd(gprev[lvl - 1], gprev[lvl], accumulate=True)
         for lvl in (2, 3, 4, 5):
             self._wgrad(f"backbone.fpn_lateral{lvl}", c.cs[lvl - 2], gprev[lvl])
+        self._grads_final(["rpn_head_out", "proposal_generator.rpn_head.conv"] + [f"backbone.fpn_output{l}" for l in (2, 3, 4, 5)] +
+                          [f"backbone.fpn_lateral{l}" for l in (2, 3, 4, 5)])
         # ---- res5 .. res3 (stem + res2 frozen: FREEZE_AT=2)
         g = ops.conv2d(gprev[5], W.wt("backbone.fpn_lateral5"), mask=c.cs[3])
         blocks = c.blocks
         bi = len(blocks) - 1
         for si in (3, 2, 1):
+            stage_names: List[str] = []
             for b in range(STAGE_BLOCKS[si] - 1, -1, -1):
                 p, xin, h1, h2, out, first = blocks[bi]
                 bi -= 1
+                stage_names += [p + "conv3", p + "conv2", p + "conv1"] + ([p + "shortcut"] if first else [])
                 self._wgrad(p + "conv3", h2, g)
                 g2 = ops.conv2d(g, W.wt(p + "conv3"), mask=h2)
                 self._wgrad(p + "conv2", h1, g2)
@@ -914,6 +919,7 @@ class RCNN:
                 self._wgrad(p + "conv1", xin, g1)
                 if first:
                     self._wgrad(p + "shortcut", xin, g)
+                    self._grads_final(stage_names)
                     if si == 1:
                         break                                           # stage input (res2 output) needs no gradient
                     stride = W.layout.t[p + "conv1"].stride
@@ -925,6 +931,21 @@ class RCNN:
                     g = ops.conv2d(gprev[lvl], W.wt(f"backbone.fpn_lateral{lvl}"), res=gx, res_mode=1, mask=xin)
                 else:
                     g = ops.conv2d(g1, W.wt(p + "conv1"), res=g, res_mode=1, mask=xin)
+
+    def _grads_final(self, names: List[str]):
+        """tell the gradient exchange (if one is attached: data-parallel fused step) that these layers' gradients are
+        complete for this step -- every kernel writing them has been enqueued."""
+        cb = getattr(self, "grad_ready", None)
+        if cb is None:
+            return
+        t = self.wts.layout.t
+        ranges = []
+        for n in names:
+            p = t[n]
+            ranges.append((p.w_off, p.w_off + p.rows * p.kk * p.kk * p.cin))
+            if p.bias:
+                ranges.append((p.b_off, p.b_off + p.rows))
+        cb(ranges)
 
     def _wgrad(self, name: str, x: torch.Tensor, g: torch.Tensor):
         W = self.wts

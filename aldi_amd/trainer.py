@@ -233,7 +233,7 @@ class SimpleTrainer:
             loss_dict = {"total_loss": loss_dict}
         else:
             losses = sum(loss_dict.values())
-        if not self.zero_grad_before_forward:
+        if not self.zero_grad_before_forward and not getattr(self, "_fused_done", False):
             self.optimizer.zero_grad()
         self.do_backward(losses)
         self.after_backward()
@@ -250,8 +250,12 @@ class SimpleTrainer:
         """One all-reduce of the student gradients per step (the reference's DDP reduces on every
         micro-step backward, aldi/dropin.py:53; the sum is linear so one reduction at the end is equivalent)."""
         if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-            g = self.model.weights.grad
-            dist.all_reduce(g, op=dist.ReduceOp.SUM)
+            red = getattr(self, "_reducer", None)
+            if red is not None:                  # fused step: most of the exchange already ran under the backward
+                red.finish()
+                self._reducer = None
+            else:
+                dist.all_reduce(self.model.weights.grad, op=dist.ReduceOp.SUM)
             self.model.weights.scale_grad(1.0 / dist.get_world_size())
 
     def _write_metrics(self, loss_dict, data_time):
@@ -292,7 +296,17 @@ class _ALDITrainer:
         self._fused_done = False
         if self._can_fuse(data):
             self._fused_done = True
-            return fused_run_model(self, *data)
+            if not self.zero_grad_before_forward:
+                self.optimizer.zero_grad()           # the fused driver runs its backward inside run_model
+            eng = self.model.engine
+            if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+                from .reduce import BucketedReducer
+                self._reducer = BucketedReducer(self.model.weights.grad)
+                eng.grad_ready = self._reducer.ready
+            try:
+                return fused_run_model(self, *data)
+            finally:
+                eng.grad_ready = None
         return run_model_labeled_unlabeled(self, *data)
 
     def do_backward(self, losses, override=False):

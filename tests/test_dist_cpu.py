@@ -53,3 +53,49 @@ def test_gradient_allreduce_world2_gloo():
     for rank, head, total in res:
         assert head == ref[:5].tolist()
         assert abs(total - float(ref.sum())) < 1e-2
+
+
+def _worker_bucketed(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from aldi_amd.reduce import BucketedReducer
+    n = 3_000_000
+    g = torch.Generator().manual_seed(7 + rank)
+    grad = torch.randn(n, generator=g)
+    ref = grad.clone()
+    dist.all_reduce(ref, op=dist.ReduceOp.SUM)
+    red = BucketedReducer(grad)
+    # reports arrive out of order, overlap, include pieces below the launch threshold, and leave gaps for finish()
+    red.ready([(2_000_000, 2_900_000), (2_900_000, 2_900_100)])
+    red.ready([(100, 200)])
+    red.ready([(500_000, 1_200_000), (1_100_000, 1_500_000), (200, 300_000)])
+    red.finish()
+    q.put((rank, bool(torch.equal(grad, ref)), float((grad - ref).abs().max())))
+    dist.destroy_process_group()
+
+
+def test_bucketed_overlapped_allreduce_world2_gloo():
+    """the fused step's overlapped exchange == one all-reduce of the whole buffer (every element reduced exactly once)"""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_worker_bucketed, args=(r, 2, port, q)) for r in range(2)]
+    for p in ps:
+        p.start()
+    res = sorted(q.get(timeout=180) for _ in range(2))
+    for p in ps:
+        p.join(timeout=60)
+    for rank, same, err in res:
+        assert same, (rank, err)
+
+
+def test_range_helpers():
+    from aldi_amd.reduce import complement, merge_ranges
+    assert merge_ranges([(5, 9), (0, 3), (3, 4), (8, 12), (20, 20)]) == [(0, 4), (5, 12)]
+    assert complement([(5, 9), (0, 3)], 12) == [(3, 5), (9, 12)]
+    assert complement([], 4) == [(0, 4)]
+    assert complement([(0, 4)], 4) == []

@@ -337,3 +337,53 @@ def test_fused_step_equals_sequential(align):
         assert abs(l0[k] - l1[k]) < 2e-5 * max(1.0, abs(l0[k])), (k, l0[k], l1[k])
     assert torch.equal(r0, r1) and p0 == p1                      # identical host RNG consumption
     assert (g0 - g1).abs().max() < 2e-4 * g0.abs().max()
+
+
+@pytest.mark.parametrize("align", [False, True])
+def test_overlapped_exchange_hook_reports_final_gradients(align):
+    """Data-parallel fused step: the engine reports layer groups to the gradient exchange while the backward is still
+    being enqueued.  Every reported range must already hold its FINAL value at that point of the stream (nothing
+    writes it later), ranges must not overlap, and together they must cover the detector's trainable convolutions."""
+    from aldi_amd.reduce import complement, merge_ranges
+    from aldi_amd.trainer import ALDITrainer
+    cfg = _cfg(align)
+    cfg.SOLVER.FUSED_STEP = True
+    random.seed(0)
+    torch.manual_seed(11)
+    tr = ALDITrainer(cfg)
+    tr.iter = 0
+    tr.before_step()
+    t = tr._trainer
+    data = next(t._data_loader_iter)
+    t.optimizer.zero_grad()
+    W = tr.model.weights
+    snaps = []
+
+    def ready(ranges):
+        for lo, hi in ranges:
+            snaps.append((lo, hi, W.grad[lo:hi].clone()))        # stream-ordered snapshot
+
+    tr.model.engine.grad_ready = ready
+    try:
+        t.run_model(data)
+    finally:
+        tr.model.engine.grad_ready = None
+    torch.cuda.synchronize()
+    assert t._fused_done and len(snaps) > 40
+    spans = sorted((lo, hi) for lo, hi, _ in snaps)
+    for (a0, a1), (b0, b1) in zip(spans[:-1], spans[1:]):
+        assert a1 <= b0, "a range was reported twice"
+    for lo, hi, g in snaps:
+        assert torch.equal(g, W.grad[lo:hi]), (lo, hi)
+        assert g.abs().max() > 0
+    # what was never reported is exactly what the hook does not know about: the alignment discriminators
+    lay = W.layout
+    rest = complement(merge_ranges(spans), lay.n_train)
+    disc = [(p.w_off, p.w_off + p.rows * p.kk * p.kk * p.cin) for n, p in lay.t.items() if p.trainable and "_align" in n]
+    disc += [(p.b_off, p.b_off + p.rows) for n, p in lay.t.items() if p.trainable and "_align" in n and p.bias]
+    in_disc = torch.zeros(lay.n_train, dtype=torch.bool, device=W.grad.device)
+    for d0, d1 in disc:
+        in_disc[d0:d1] = True
+    for lo, hi in rest:                                          # every unreported non-zero element lies in a discriminator
+        g = W.grad[lo:hi]
+        assert float(g[~in_disc[lo:hi]].abs().sum()) == 0.0, (lo, hi)
