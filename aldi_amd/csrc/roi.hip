@@ -276,6 +276,127 @@ __global__ __launch_bounds__(256) void roialign_fwd_vec_kernel(Feats ft, const f
     }
 }
 
+// Backward as a GATHER (no atomics, deterministic): one workgroup owns a 32-pixel segment of one feature-map row of one
+// (level, image), finds the ROIs that can touch it, and for each of them builds the separable bilinear footprint
+//   rowc[ph]      = sum over the bin's sample rows of the weight they put on THIS row        (7 values)
+//   colc[px][pw]  = the same along x for every pixel of the segment                           (32 x 7)
+// with the forward's own bilin_prep (same clamps, same dead samples), so that
+//   dG[py][px][c] = sum_roi 1/count * sum_pw colc[px][pw] * ( sum_ph rowc[ph] * g_pooled[roi][ph][pw][c] ).
+// Thread = channel; the 32 pixel accumulators stay in registers; every gradient element is written exactly once
+// (the scatter form issues ~880 MB of fp32 atomics per step and is bound by them).
+constexpr int kSeg = 32;
+struct GatherGeom { int blk_off[5]; int segs[4]; int N; };
+
+template <typename T>
+__global__ __launch_bounds__(256) void roialign_bwd_gather_kernel(Feats ft, GatherGeom gg, const float* __restrict__ rois, int R, int P,
+                                                                  const T* __restrict__ gp /*[R][P][P][C]*/) {
+    __shared__ int cand[256];
+    __shared__ int sm[17];
+    __shared__ float rowc[8];
+    __shared__ float colc[kSeg][8];
+    __shared__ int pwlo[kSeg], pwhi[kSeg];
+    __shared__ float gsum[7][256];
+    const int tid = threadIdx.x, c = tid;
+    int l = 0;
+    while (l < 3 && (int)blockIdx.x >= gg.blk_off[l + 1]) ++l;
+    const int H = ft.H[l], W = ft.W[l];
+    int t = blockIdx.x - gg.blk_off[l];
+    const int seg = t % gg.segs[l]; t /= gg.segs[l];
+    const int py = t % H, b = t / H;
+    const int px0 = seg * kSeg;
+    const float sc = ft.scale[l];
+    float acc[kSeg];
+#pragma unroll
+    for (int i = 0; i < kSeg; ++i) acc[i] = 0.f;
+
+    for (int base = 0; base < R; base += 256) {
+        // ---- candidates of this chunk: same image, same level, footprint bounding box meets the segment
+        const int r = base + tid;
+        bool hit = false;
+        if (r < R) {
+            const float* rp = rois + (long)r * 5;
+            if ((int)rp[0] == b && roi_level(rp[1], rp[2], rp[3], rp[4]) == l) {
+                const float x1 = rp[1] * sc - 0.5f, y1 = rp[2] * sc - 0.5f, x2 = rp[3] * sc - 0.5f, y2 = rp[4] * sc - 0.5f;
+                const int r0 = min(max((int)floorf(y1) - 1, 0), H - 1), r1 = min(max((int)floorf(y2) + 2, 0), H - 1);
+                const int c0 = min(max((int)floorf(x1) - 1, 0), W - 1), c1 = min(max((int)floorf(x2) + 2, 0), W - 1);
+                hit = py >= r0 && py <= r1 && c1 >= px0 && c0 < px0 + kSeg;
+            }
+        }
+        int ncand;
+        const int rank = block_rank(hit, sm, &ncand);
+        if (hit) cand[rank] = r;
+        __syncthreads();
+        for (int q = 0; q < ncand; ++q) {
+            const int rr = cand[q];
+            const float* rp = rois + (long)rr * 5;
+            const float x1 = rp[1] * sc - 0.5f, y1 = rp[2] * sc - 0.5f, x2 = rp[3] * sc - 0.5f, y2 = rp[4] * sc - 0.5f;
+            const float rw = x2 - x1, rh = y2 - y1;
+            const float bw = rw / (float)P, bh = rh / (float)P;
+            const int gh = (int)ceilf(rh / (float)P), gw = (int)ceilf(rw / (float)P);
+            const float inv_count = 1.f / (float)max(gh * gw, 1);
+            if (tid < 8) {
+                float a = 0.f;
+                if (tid < P)
+                    for (int iy = 0; iy < gh; ++iy) {
+                        const Bilin by = bilin_prep(y1 + (float)tid * bh + ((float)iy + 0.5f) * bh / (float)gh, H);
+                        if (by.dead) continue;
+                        if (by.lo == py) a += by.h;
+                        if (by.hi == py) a += by.l;
+                    }
+                rowc[tid] = a;
+            }
+            if (tid < kSeg * 8) {
+                const int pxl = tid >> 3, pw = tid & 7;
+                float a = 0.f;
+                if (pw < P) {
+                    const int px = px0 + pxl;
+                    for (int ix = 0; ix < gw; ++ix) {
+                        const Bilin bx = bilin_prep(x1 + (float)pw * bw + ((float)ix + 0.5f) * bw / (float)gw, W);
+                        if (bx.dead) continue;
+                        if (bx.lo == px) a += bx.h;
+                        if (bx.hi == px) a += bx.l;
+                    }
+                }
+                colc[pxl][pw] = a;
+            }
+            __syncthreads();
+            if (tid < kSeg) {                 // bins with a non-zero weight on this pixel (a contiguous run)
+                int lo = 8, hi = -1;
+                for (int pw = 0; pw < P; ++pw)
+                    if (colc[tid][pw] != 0.f) { lo = min(lo, pw); hi = pw; }
+                pwlo[tid] = lo; pwhi[tid] = hi;
+            }
+            // per-bin-column gradient of this ROI weighted onto this row
+            {
+                float gs[7];
+#pragma unroll
+                for (int pw = 0; pw < 7; ++pw) gs[pw] = 0.f;
+                const T* g0 = gp + (long)rr * P * P * ft.C + c;
+                for (int ph = 0; ph < P; ++ph) {
+                    const float rc = rowc[ph];
+                    if (rc == 0.f) continue;
+#pragma unroll
+                    for (int pw = 0; pw < 7; ++pw)
+                        if (pw < P) gs[pw] += rc * Elem<T>::ld(g0 + (long)(ph * P + pw) * ft.C);
+                }
+#pragma unroll
+                for (int pw = 0; pw < 7; ++pw) gsum[pw][c] = gs[pw] * inv_count;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < kSeg; ++i) {
+                const int lo = pwlo[i], hi = pwhi[i];
+                for (int pw = lo; pw <= hi; ++pw) acc[i] += colc[i][pw] * gsum[pw][c];
+            }
+            __syncthreads();                  // tables are rewritten by the next candidate
+        }
+    }
+    float* G = ft.g[l] + (((long)b * H + py) * W + px0) * ft.C + c;
+#pragma unroll
+    for (int i = 0; i < kSeg; ++i)
+        if (px0 + i < W) G[(long)i * ft.C] = acc[i];
+}
+
 // FastRCNNOutputLayers.losses: CE(mean over R) + L1 on the gt-class deltas of fg rows / R
 // pred row: [0,K] class logits, [K+1, K+1+4K) deltas (class*4+d).  grad += d(loss*gscale)/d(pred)
 __global__ __launch_bounds__(256) void box_loss_kernel(const float* __restrict__ pred, int Cp, int K, int R,
@@ -469,6 +590,28 @@ extern "C" int aldi_roialign(const aldi_roi_feats* f, const float* rois, int R, 
         if (backward) hipLaunchKernelGGL((roialign_kernel<float, true>), grid, dim3(256), 0, st, ft, rois, P, (float*)pooled);
         else hipLaunchKernelGGL((roialign_fwd_vec_kernel<float>), grid, dim3(256), 0, st, ft, rois, P, (float*)pooled);
     }
+    ALDI_CHECK_LAUNCH();
+    return ALDI_OK;
+}
+
+extern "C" int aldi_roialign_backward(const aldi_roi_feats* f, const float* rois, int R, int P, const void* g_pooled, int N, int dtype,
+                                      aldi_stream_t stream) {
+    if (!f || !rois || !g_pooled || f->C != 256 || P > 7 || N < 1) return aldi_set_error_msg(ALDI_ERR_ARG, "roialign_backward: bad args (C must be 256, P <= 7)");
+    Feats ft = make_feats(f, true);
+    GatherGeom gg;
+    gg.N = N;
+    int off = 0;
+    for (int l = 0; l < 4; ++l) {
+        if (!ft.g[l]) return aldi_set_error_msg(ALDI_ERR_ARG, "roialign_backward: missing gradient map");
+        gg.blk_off[l] = off;
+        gg.segs[l] = cdiv(ft.W[l], kSeg);
+        off += N * ft.H[l] * gg.segs[l];
+    }
+    gg.blk_off[4] = off;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (dtype == ALDI_BF16) hipLaunchKernelGGL((roialign_bwd_gather_kernel<bf16_t>), dim3(off), dim3(256), 0, st, ft, gg, rois, R, P, (const bf16_t*)g_pooled);
+    else if (dtype == ALDI_F32) hipLaunchKernelGGL((roialign_bwd_gather_kernel<float>), dim3(off), dim3(256), 0, st, ft, gg, rois, R, P, (const float*)g_pooled);
+    else return aldi_set_error_msg(ALDI_ERR_ARG, "roialign_backward: bad dtype");
     ALDI_CHECK_LAUNCH();
     return ALDI_OK;
 }

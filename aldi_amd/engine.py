@@ -845,7 +845,7 @@ class RCNN:
         T = self.dtype
         dev = self.device
         # ---- box head (+ instance-level discriminator behind the gradient-reversal layer)
-        gP_roi = [torch.zeros(f.shape, dtype=torch.float32, device=dev) for f in c.P[:4]]
+        gP_roi = [(torch.empty if c.R > 0 else torch.zeros)(f.shape, dtype=torch.float32, device=dev) for f in c.P[:4]]
         if c.R > 0:
             g_extra = None
             for al in align_list:
@@ -867,7 +867,7 @@ class RCNN:
             x = c.pooled.view(c.R, 1, 1, POOL * POOL * FPN_C)
             self._wgrad("roi_heads.box_head.fc1", x, g_fc1)
             g_pooled = ops.conv2d(g_fc1, W.wt("roi_heads.box_head.fc1")).view(c.R, POOL, POOL, FPN_C)
-            ops.roialign(self.roi_feats(c, gP_roi), c.rois, c.R, POOL, g_pooled, backward=True)
+            ops.roialign_backward(self.roi_feats(c, gP_roi), c.rois, c.R, POOL, g_pooled, c.N)
         self._grads_final(["box_pred", "roi_heads.box_head.fc2", "roi_heads.box_head.fc1"])
         # ---- RPN head (shared weights over 5 levels)
         gP = []

@@ -268,6 +268,11 @@ def roialign(feats: L.RoiFeats, rois, R, P, pooled, backward: bool):
     L.call("aldi_roialign", C.byref(feats), _p(rois), R, P, _p(pooled), int(backward), dtype_code(pooled.dtype), stream_ptr())
 
 
+def roialign_backward(feats: L.RoiFeats, rois, R, P, g_pooled, N):
+    """gather form: overwrites the fp32 gradient maps of `feats` (each element written once, no atomics)"""
+    L.call("aldi_roialign_backward", C.byref(feats), _p(rois), R, P, _p(g_pooled), N, dtype_code(g_pooled.dtype), stream_ptr())
+
+
 def box_loss(pred, Cp, K, R, rois, cls, gt_boxes, weights4, gs_cls, gs_box, grad, loss2):
     w = (C.c_float * 4)(*weights4)
     L.call("aldi_box_loss", _p(pred), Cp, K, R, _p(rois), _p(cls), _p(gt_boxes), w, gs_cls, gs_box, _p(grad), _p(loss2), stream_ptr())

@@ -206,6 +206,12 @@ int aldi_rois_from_proposals(const float* props, const int* pcount, int P, int N
 /* ROIAlign over 4 FPN levels (level from box size). forward: pooled [R][P][P][C] written;
  * backward: pooled holds the gradient, scattered with float atomics into feats->grad. */
 int aldi_roialign(const aldi_roi_feats* f, const float* rois, int R, int P, void* pooled, int backward, int dtype, aldi_stream_t stream);
+/* ROIAlign backward as a gather: OVERWRITES the four fp32 gradient maps f->grad[l] ([N][H_l][W_l][C], no zero-fill needed) with
+ * d(loss)/d(feature) given g_pooled [R][P][P][C] in `dtype`; every element is written exactly once (deterministic, no atomics).
+ * `aldi_roialign(..., backward=1)` is the accumulating scatter form of the same operator. */
+int aldi_roialign_backward(const aldi_roi_feats* f, const float* rois, int R, int P, const void* g_pooled, int N, int dtype,
+                           aldi_stream_t stream);
+
 /* pred fp32 [R][Cp]: [0,K] class logits, then 4K class-specific deltas. loss2 += {CE mean, L1 sum/R};
  * grad (fp32 [R][Cp], nullable) += d(scale_cls*loss_cls + scale_box*loss_box_reg)/d(pred). */
 int aldi_box_loss(const float* pred, int Cp, int K, int R, const float* rois, const int* cls, const float* gt_boxes,

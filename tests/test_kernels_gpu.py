@@ -340,6 +340,16 @@ def test_roialign_fwd_bwd_vs_oracle(dtype, tol):
     for l in range(4):
         e = (grads[l].cpu().permute(0, 3, 1, 2) - fr[l].grad).abs().max()
         assert e < tol * 30 * max(1.0, float(fr[l].grad.abs().max())), (l, float(e))
+    # gather form of the backward (what the engine runs): overwrites uninitialised maps, no atomics, same values
+    grads2 = [torch.full(f.shape, float("nan"), dtype=torch.float32, device=DEV) for f in fd]
+    ops.roialign_backward(ops.make_roi_feats(fd, grads2, [1 / 4, 1 / 8, 1 / 16, 1 / 32]), rois, R, 7, gd, N)
+    for l in range(4):
+        e = (grads2[l].cpu().permute(0, 3, 1, 2) - fr[l].grad).abs().max()
+        assert e < tol * 30 * max(1.0, float(fr[l].grad.abs().max())), (l, float(e))
+        assert (grads2[l] - grads[l]).abs().max() < 2e-5 * max(1.0, float(grads[l].abs().max()))      # scatter vs gather
+    again = [torch.empty_like(t) for t in grads2]
+    ops.roialign_backward(ops.make_roi_feats(fd, again, [1 / 4, 1 / 8, 1 / 16, 1 / 32]), rois, R, 7, gd, N)
+    assert all(torch.equal(a, b) for a, b in zip(again, grads2))                                       # deterministic
     # property: pooling a constant map returns the constant wherever the ROI lies inside the map
     const = [torch.full(f.shape, 3.0, dtype=dtype, device=DEV) for f in fd]
     inside = ((rois[:, 1] >= 0) & (rois[:, 2] >= 0) & (rois[:, 3] <= 640) & (rois[:, 4] <= 448)).nonzero().squeeze(1)
