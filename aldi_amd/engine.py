@@ -10,6 +10,7 @@ aldi/distill.py:157,162 and aldi/pseudolabeler.py:21, and autograd's backward at
 from __future__ import annotations
 
 import math
+import os
 from collections import OrderedDict
 from typing import Dict, List, Optional, Sequence, Tuple
 
@@ -931,6 +932,7 @@ class RCNN:
                     g = ops.conv2d(gprev[lvl], W.wt(f"backbone.fpn_lateral{lvl}"), res=gx, res_mode=1, mask=xin)
                 else:
                     g = ops.conv2d(g1, W.wt(p + "conv1"), res=g, res_mode=1, mask=xin)
+        self._join_wgrads()
 
     def _grads_final(self, names: List[str]):
         """tell the gradient exchange (if one is attached: data-parallel fused step) that these layers' gradients are
@@ -938,6 +940,7 @@ class RCNN:
         cb = getattr(self, "grad_ready", None)
         if cb is None:
             return
+        self._join_wgrads()
         t = self.wts.layout.t
         ranges = []
         for n in names:
@@ -948,8 +951,35 @@ class RCNN:
         cb(ranges)
 
     def _wgrad(self, name: str, x: torch.Tensor, g: torch.Tensor):
+        """weight (+ bias) gradient of one layer.  The data-gradient chain never reads these results, so they run on a
+        second HIP stream beside it: a wgrad launch of a deep layer is only 1-2 workgroups per CU, the dgrad igemm of
+        the same layer likewise, and neither fills the chip on its own."""
         W = self.wts
         p = W.layout.t[name]
-        ops.conv_wgrad(x, g, W.gw(name), KH=p.kk, KW=p.kk, stride=p.stride, pad=p.pad, scale=W.scale(name))
-        if p.bias:
-            ops.bias_grad(g, W.gb(name))
+        side = self._wgrad_stream()
+        if side is None:
+            ops.conv_wgrad(x, g, W.gw(name), KH=p.kk, KW=p.kk, stride=p.stride, pad=p.pad, scale=W.scale(name))
+            if p.bias:
+                ops.bias_grad(g, W.gb(name))
+            return
+        ev = torch.cuda.Event()
+        ev.record()                                  # g (and x) are complete once the main stream gets here
+        side.wait_event(ev)
+        g.record_stream(side)                        # g is a temporary of the main stream's allocator
+        with torch.cuda.stream(side):
+            ops.conv_wgrad(x, g, W.gw(name), KH=p.kk, KW=p.kk, stride=p.stride, pad=p.pad, scale=W.scale(name))
+            if p.bias:
+                ops.bias_grad(g, W.gb(name))
+        self._wgrad_pending = True
+
+    def _wgrad_stream(self):
+        if not hasattr(self, "_wg_side"):
+            self._wg_side = torch.cuda.Stream(device=self.device) if os.environ.get("ALDI_WGRAD_STREAM", "1") == "1" else None
+            self._wgrad_pending = False
+        return self._wg_side
+
+    def _join_wgrads(self):
+        """main stream waits for every weight-gradient kernel issued so far"""
+        if getattr(self, "_wg_side", None) is not None and self._wgrad_pending:
+            torch.cuda.current_stream().wait_stream(self._wg_side)
+            self._wgrad_pending = False
