@@ -481,13 +481,19 @@ class RCNN:
         N = len(images)
         st, sizes, hw = self.stage_images(images)
         shapes, geom, anchors = self.geometry(st.shape[2], st.shape[3])
+        # everything that does not need ground truth first: a chunk's GT may be the pseudo-labels of a teacher inference
+        # still running on another stream (spec["gt_wait"] joins it)
+        c = self.trunk(st, sizes, save=True)
+        c.N, c.sizes, c.hw, c.geom, c.anchors, c.shapes = N, sizes, hw, geom, anchors, shapes
+        self.rpn_head(c, save=True)
+        c.props, c.prop_scores, c.prop_count = self.proposals(c, geom, anchors, hw, N, training=True)
+        for sp in specs:
+            if sp.get("gt_wait") is not None:
+                sp["gt_wait"]()
         gts = [sp["gt_dev"] if sp.get("gt_dev") is not None else self.stage_gt(sp["instances"]) for sp in specs]
         gt = {k: torch.cat([g[k] for g in gts]) for k in ("boxes", "classes", "count")}
-        c = self.trunk(st, sizes, save=True)
-        c.N, c.sizes, c.hw, c.geom, c.anchors, c.gt, c.shapes = N, sizes, hw, geom, anchors, gt, shapes
-        self.rpn_head(c, save=True)
+        c.gt = gt
         _, matched, lists, counts = self.rpn_match(geom, anchors, gt, N)
-        c.props, c.prop_scores, c.prop_count = self.proposals(c, geom, anchors, hw, N, training=True)
         prep = self._roi_prepare(c.props, c.prop_count, gt, N)
         both = torch.cat([counts.view(-1), prep["counts"].view(-1)]).cpu().tolist()      # the ONE device->host sync of the student pass
         rpn_counts = [both[2 * i: 2 * i + 2] for i in range(N)]

@@ -5,6 +5,7 @@ scaling -- driving the HIP engine through the model / distiller plugin objects."
 from __future__ import annotations
 
 import logging
+import os
 import time
 import weakref
 from typing import Dict
@@ -76,6 +77,19 @@ def run_model_labeled_unlabeled(trainer, labeled_weak, labeled_strong, unlabeled
     return loss_dict
 
 
+_TEACHER_STREAMS = {}
+
+
+def _teacher_stream(device):
+    """second HIP stream for the teacher's inference (ALDI_TEACHER_STREAM=0 keeps everything on one stream)"""
+    if os.environ.get("ALDI_TEACHER_STREAM", "1") != "1" or torch.device(device).type != "cuda":
+        return None
+    key = str(device)
+    if key not in _TEACHER_STREAMS:
+        _TEACHER_STREAMS[key] = torch.cuda.Stream(device=device)
+    return _TEACHER_STREAMS[key]
+
+
 def fused_run_model(trainer, labeled_weak, labeled_strong, unlabeled_weak, unlabeled_strong):
     """MI355X-first form of `run_model_labeled_unlabeled` for the reference's FPN configurations
     (BATCH_CONTENTS = labeled_strong [+ unlabeled_strong], one IMS_PER_GPU chunk each): the source, the
@@ -109,8 +123,19 @@ def fused_run_model(trainer, labeled_weak, labeled_strong, unlabeled_weak, unlab
         if dist_.cls_loss_type not in ("CE", "KL"):
             raise ValueError("cls_loss_type must be one of {CE, KL}")
         teacher = dist_.teacher.module if hasattr(dist_.teacher, "module") else dist_.teacher
-        with torch.no_grad():
-            tc = teacher.engine.inference([d["image"] for d in unlabeled_weak], dist_.pseudo_label_threshold)
+        # the teacher's inference (N = 2, mostly small launches) runs on its own HIP stream beside the student's trunk /
+        # RPN head / proposal generation, none of which needs the pseudo-labels; the student joins right before matching
+        gt_wait = None
+        side = _teacher_stream(model.device)
+        if side is not None:
+            main = torch.cuda.current_stream()
+            side.wait_stream(main)               # teacher weights (EMA) and last step's readers of the teacher's outputs
+            with torch.cuda.stream(side), torch.no_grad():
+                tc = teacher.engine.inference([d["image"] for d in unlabeled_weak], dist_.pseudo_label_threshold)
+            gt_wait = lambda: torch.cuda.current_stream().wait_stream(side)
+        else:
+            with torch.no_grad():
+                tc = teacher.engine.inference([d["image"] for d in unlabeled_weak], dist_.pseudo_label_threshold)
         teacher._last_inference = tc
         labels_ = [DevicePseudoLabels(tc.sizes[i], tc.pseudo, i) for i in range(len(unlabeled_weak))]
         for dw, ds, lab in zip(unlabeled_weak, unlabeled_strong, labels_):
@@ -120,7 +145,7 @@ def fused_run_model(trainer, labeled_weak, labeled_strong, unlabeled_weak, unlab
         def pre_rpn_distill():
             teacher.roi_heads.fire_pre()         # the teacher's eval inference re-seeds with the OLD seed
             dist_.seeder.reset_seed()
-        specs.append(dict(images=[d["image"] for d in unlabeled_strong], gt_dev=tc.pseudo, labeled=True, do_align=False,
+        specs.append(dict(images=[d["image"] for d in unlabeled_strong], gt_dev=tc.pseudo, gt_wait=gt_wait, labeled=True, do_align=False,
                           pre_rpn=pre_rpn_distill, pre_roi=fire_student))
         names.append("distill")
     c = eng.forward_train_fused(specs)
