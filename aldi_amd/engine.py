@@ -273,6 +273,7 @@ class RCNN:
         gb = torch.zeros((N, GMAX, 4), dtype=torch.float32)
         gc = torch.zeros((N, GMAX), dtype=torch.int32)
         cnt = torch.zeros((N,), dtype=torch.int32)
+        on_dev = []
         for i, inst in enumerate(instances):
             b = inst["gt_boxes"]
             b = b.tensor if hasattr(b, "tensor") else b
@@ -280,10 +281,17 @@ class RCNN:
             if g > GMAX:
                 raise ValueError(f"more than {GMAX} GT boxes in one image")
             if g:
-                gb[i, :g] = b.reshape(-1, 4).to(torch.float32).cpu()
-                gc[i, :g] = inst["gt_classes"].to(torch.int32).cpu()
+                if b.is_cuda:                        # already resident: no host round trip
+                    on_dev.append((i, g, b, inst["gt_classes"]))
+                else:
+                    gb[i, :g] = b.reshape(-1, 4).to(torch.float32)
+                    gc[i, :g] = inst["gt_classes"].to(torch.int32)
             cnt[i] = g
-        return {"boxes": gb.to(self.device), "classes": gc.to(self.device), "count": cnt.to(self.device), "host_count": cnt.tolist()}
+        gbd, gcd, cntd = ops.upload_packed([gb, gc, cnt], self.device)
+        for i, g, b, cl in on_dev:
+            gbd[i, :g] = b.reshape(-1, 4).to(torch.float32)
+            gcd[i, :g] = cl.to(torch.int32)
+        return {"boxes": gbd, "classes": gcd, "count": cntd, "host_count": cnt.tolist()}
 
     def geometry(self, Hs: int, Ws: int):
         key = (Hs, Ws)
@@ -392,7 +400,8 @@ class RCNN:
 
     def _sample(self, counts: List[List[int]], batch: int, frac: float):
         sel, nsel, h = self._sample_host(counts, batch, frac)
-        return sel.to(self.device), nsel.to(self.device), h
+        sel_d, nsel_d = ops.upload_packed([sel, nsel], self.device)
+        return sel_d, nsel_d, h
 
     def rpn_match(self, geom, anchors, gt, N):
         """Matcher(0.3/0.7, low-quality) on the anchors: labels before sampling, matched GT index, ordered pos/neg lists."""
@@ -516,9 +525,10 @@ class RCNN:
                                da_weights=sp.get("da_weights", (0.0, 0.0)), rpn_counts=rpn_counts[n0:n1], roi_counts=roi_counts[n0:n1]))
             n0 = n1
         labels = torch.empty((N, anchors.shape[0]), dtype=torch.int32, device=dev)
-        ops.rpn_apply_sample(labels, anchors.shape[0], N, lists, torch.cat(rsel).to(dev), torch.cat(rnsel).to(dev), RPN_BATCH)
+        rsel_d, rnsel_d, osel_d, onsel_d = ops.upload_packed([torch.cat(rsel), torch.cat(rnsel), torch.cat(osel), torch.cat(onsel)], dev)
+        ops.rpn_apply_sample(labels, anchors.shape[0], N, lists, rsel_d, rnsel_d, RPN_BATCH)
         c.rpn_labels, c.rpn_matched, c.rpn_lists, c.rpn_counts = labels, matched, lists, counts
-        self._roi_gather(c, prep, torch.cat(osel).to(dev), torch.cat(onsel).to(dev), oh, gt, N)
+        self._roi_gather(c, prep, osel_d, onsel_d, oh, gt, N)
         self.roi_forward(c)
         # per-chunk loss values
         r0 = 0

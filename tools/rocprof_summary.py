@@ -57,6 +57,32 @@ def gaps(d, top="15"):
         print("%9.1f us   after %-60s before %s" % (us, n0, n1))
 
 
+def overlap(d):
+    """multi-stream view of one step: union busy time, time with >= 2 kernels in flight, idle time"""
+    dbs = glob.glob(d + "/**/*_results.db", recursive=True)
+    cur = sqlite3.connect(dbs[0]).cursor()
+    tabs = [r[0] for r in cur.execute("select name from sqlite_master where type in ('table','view')")]
+    kt = "kernels" if "kernels" in tabs else [t for t in tabs if "kernel_dispatch" in t][0]
+    cols = [r[1] for r in cur.execute(f"pragma table_info({kt})")]
+    name = "name" if "name" in cols else "kernel_name"
+    rows = list(cur.execute(f"select {name}, start, end from {kt} order by start"))
+    sgd = [i for i, r in enumerate(rows) if "sgd_kernel" in r[0]]
+    a, b = sgd[-2], sgd[-1]
+    t0, t1 = rows[a][2], rows[b][2]
+    ev = []
+    for n, s, e in rows[a + 1:b + 1]:
+        ev.append((s, 1)); ev.append((e, -1))
+    ev.sort()
+    depth, last, busy, multi = 0, t0, 0, 0
+    for t, dlt in ev:
+        if depth >= 1: busy += t - last
+        if depth >= 2: multi += t - last
+        depth += dlt; last = t
+    tot = sum(e - s for _, s, e in rows[a + 1:b + 1])
+    print(f"# step wall {(t1 - t0) / 1e6:.2f} ms | some kernel running {busy / 1e6:.2f} ms | >= 2 kernels in flight {multi / 1e6:.2f} ms | "
+          f"idle {(t1 - t0 - busy) / 1e6:.2f} ms | sum of kernel durations {tot / 1e6:.2f} ms")
+
+
 def pmc(fetch_dir, write_dir):
     res = {}
     for key, d, ctr in (("fetch", fetch_dir, "FETCH_SIZE"), ("write", write_dir, "WRITE_SIZE")):
@@ -81,4 +107,4 @@ def pmc(fetch_dir, write_dir):
 
 
 if __name__ == "__main__":
-    {"stats": stats, "pmc": pmc, "gaps": gaps}[sys.argv[1]](*sys.argv[2:])
+    {"stats": stats, "pmc": pmc, "gaps": gaps, "overlap": overlap}[sys.argv[1]](*sys.argv[2:])
