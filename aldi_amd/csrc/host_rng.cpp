@@ -7,7 +7,9 @@
 // driven by the generator's mt19937 (`z = random() % (n - i); swap(r[i], r[z + i])`), so position i is final
 // after iteration i: run k iterations on a sparse map, then discard the remaining n-1-k draws by advancing the
 // Mersenne state.  Operates on the 5056-byte blob of torch.get_rng_state() / set_rng_state().
-#include "common.h"
+#include <stdint.h>
+#include "../../include/aldi_hip.h"
+int aldi_set_error_msg(int code, const char* msg);   // core.hip
 #include <string.h>
 #include <vector>
 
@@ -19,28 +21,32 @@ struct Mt {
     uint32_t s[MT_N];
     int left;
     uint64_t next;
-    // The state refill is what `discard` spends its time in (a 268k-entry permutation skips ~430 refills per image), so
-    // it is written 4 lanes wide (baseline SSE2, no target switches): within a refill, element i reads s[i+1] (not yet rewritten) and s[i+397] / s[i-227]
-    // (old / rewritten >= 227 elements ago), so blocks of 4 consecutive elements are independent.
-    typedef uint32_t v4u __attribute__((vector_size(16)));
-    static inline v4u ld4(const uint32_t* p) { v4u v; memcpy(&v, p, 16); return v; }
-    static inline void st4(uint32_t* p, v4u v) { memcpy(p, &v, 16); }
-    static inline v4u twist4(v4u u, v4u v) {
-        const v4u hi = {0x80000000u, 0x80000000u, 0x80000000u, 0x80000000u};
-        const v4u mag = {0x9908b0dfu, 0x9908b0dfu, 0x9908b0dfu, 0x9908b0dfu};
-        const v4u one = {1, 1, 1, 1};
-        return (((u & hi) | (v & ~hi)) >> 1) ^ ((0u - (v & one)) & mag);
-    }
-    static inline uint32_t twist1(uint32_t u, uint32_t v) { return (((u & 0x80000000u) | (v & 0x7fffffffu)) >> 1) ^ ((v & 1u) ? 0x9908b0dfu : 0u); }
-    void regen() {
-        int i = 0;
-        for (; i + 4 <= MT_N - MT_M; i += 4) st4(s + i, ld4(s + i + MT_M) ^ twist4(ld4(s + i), ld4(s + i + 1)));
-        for (; i < MT_N - MT_M; ++i) s[i] = s[i + MT_M] ^ twist1(s[i], s[i + 1]);
-        for (; i + 4 <= MT_N - 1; i += 4) st4(s + i, ld4(s + i + MT_M - MT_N) ^ twist4(ld4(s + i), ld4(s + i + 1)));
-        for (; i < MT_N - 1; ++i) s[i] = s[i + MT_M - MT_N] ^ twist1(s[i], s[i + 1]);
+    // The state refill is what `discard` spends its time in (a 268k-entry permutation skips ~430 refills per image).  Within
+    // a refill, element i reads s[i+1] (not yet rewritten) and s[i+397] / s[i-227] (old / rewritten >= 227 elements ago), so
+    // blocks of W consecutive elements are independent: W = 8 with AVX2 (chosen at run time), 4 with baseline SSE2.
+#define MT_LD(p) ({ vu v_; memcpy(&v_, (p), sizeof(v_)); v_; })
+#define MT_TWIST(u, v) ((((u) & 0x80000000u) | ((v) & 0x7fffffffu)) >> 1) ^ ((0u - ((v) & 1u)) & 0x9908b0dfu)
+    template <int W>
+    __attribute__((always_inline)) inline void regen_w() {
+        typedef uint32_t vu __attribute__((vector_size(W * 4)));
+        constexpr int A = MT_N - MT_M;                         // 227: elements whose partner is s[i + 397]
+        constexpr int A_VEC = A / W * W, B_VEC = A + (MT_N - 1 - A) / W * W;
+        for (int i = 0; i < A_VEC; i += W) { vu a = MT_LD(s + i), b = MT_LD(s + i + 1), r = MT_LD(s + i + MT_M) ^ (MT_TWIST(a, b)); memcpy(s + i, &r, sizeof(r)); }
+        for (int i = A_VEC; i < A; ++i) s[i] = s[i + MT_M] ^ twist1(s[i], s[i + 1]);
+        for (int i = A; i < B_VEC; i += W) { vu a = MT_LD(s + i), b = MT_LD(s + i + 1), r = MT_LD(s + i - A) ^ (MT_TWIST(a, b)); memcpy(s + i, &r, sizeof(r)); }
+        for (int i = B_VEC; i < MT_N - 1; ++i) s[i] = s[i - A] ^ twist1(s[i], s[i + 1]);
         s[MT_N - 1] = s[MT_M - 1] ^ twist1(s[MT_N - 1], s[0]);
         left = MT_N;
         next = 0;
+    }
+#undef MT_LD
+#undef MT_TWIST
+    static inline uint32_t twist1(uint32_t u, uint32_t v) { return (((u & 0x80000000u) | (v & 0x7fffffffu)) >> 1) ^ ((v & 1u) ? 0x9908b0dfu : 0u); }
+    __attribute__((target("avx2"))) void regen_avx2() { regen_w<8>(); }
+    void regen_sse2() { regen_w<4>(); }
+    void regen() {
+        static const bool avx2 = __builtin_cpu_supports("avx2");
+        if (avx2) regen_avx2(); else regen_sse2();
     }
     uint32_t draw() {
         if (--left == 0) regen();
