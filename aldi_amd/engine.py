@@ -495,7 +495,15 @@ class RCNN:
         c = self.trunk(st, sizes, save=True)
         c.N, c.sizes, c.hw, c.geom, c.anchors, c.shapes = N, sizes, hw, geom, anchors, shapes
         self.rpn_head(c, save=True)
-        c.props, c.prop_scores, c.prop_count = self.proposals(c, geom, anchors, hw, N, training=True)
+        # proposal generation (top-k, NMS: latency-bound, a handful of workgroups) runs beside anchor matching / label
+        # compaction on the second stream; ROI preparation needs both
+        side = self._wgrad_stream()
+        if side is not None:
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                c.props, c.prop_scores, c.prop_count = self.proposals(c, geom, anchors, hw, N, training=True)
+        else:
+            c.props, c.prop_scores, c.prop_count = self.proposals(c, geom, anchors, hw, N, training=True)
         for sp in specs:
             if sp.get("gt_wait") is not None:
                 sp["gt_wait"]()
@@ -503,6 +511,8 @@ class RCNN:
         gt = {k: torch.cat([g[k] for g in gts]) for k in ("boxes", "classes", "count")}
         c.gt = gt
         _, matched, lists, counts = self.rpn_match(geom, anchors, gt, N)
+        if side is not None:
+            torch.cuda.current_stream().wait_stream(side)
         prep = self._roi_prepare(c.props, c.prop_count, gt, N)
         both = torch.cat([counts.view(-1), prep["counts"].view(-1)]).cpu().tolist()      # the ONE device->host sync of the student pass
         rpn_counts = [both[2 * i: 2 * i + 2] for i in range(N)]
@@ -529,6 +539,12 @@ class RCNN:
         ops.rpn_apply_sample(labels, anchors.shape[0], N, lists, rsel_d, rnsel_d, RPN_BATCH)
         c.rpn_labels, c.rpn_matched, c.rpn_lists, c.rpn_counts = labels, matched, lists, counts
         self._roi_gather(c, prep, osel_d, onsel_d, oh, gt, N)
+        r0 = 0
+        for ch, sp in zip(chunks, specs):                   # e.g. the teacher's box head on this chunk's ROIs, on its own stream
+            r1 = r0 + sum(c.rows[ch["n0"]:ch["n1"]])
+            if sp.get("post_rois") is not None:
+                sp["post_rois"](c, ch["n0"], r0, r1)
+            r0 = r1
         self.roi_forward(c)
         # per-chunk loss values
         r0 = 0

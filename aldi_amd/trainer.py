@@ -145,8 +145,21 @@ def fused_run_model(trainer, labeled_weak, labeled_strong, unlabeled_weak, unlab
         def pre_rpn_distill():
             teacher.roi_heads.fire_pre()         # the teacher's eval inference re-seeds with the OLD seed
             dist_.seeder.reset_seed()
+        t_out = {}
+
+        def teacher_box_head(c_, n0, r0, r1):
+            """the teacher's box head on the student's sampled proposals (aldi/distill.py:160-162), beside the student's own"""
+            rois_t = c_.rois[r0:r1].clone()
+            rois_t[:, 0] -= n0
+            if side is not None:
+                side.wait_stream(torch.cuda.current_stream())
+                rois_t.record_stream(side)
+                with torch.cuda.stream(side), torch.no_grad():
+                    t_out["pred"] = teacher.engine.box_head_on(tc, rois_t, r1 - r0)
+            else:
+                t_out["pred"] = teacher.engine.box_head_on(tc, rois_t, r1 - r0)
         specs.append(dict(images=[d["image"] for d in unlabeled_strong], gt_dev=tc.pseudo, gt_wait=gt_wait, labeled=True, do_align=False,
-                          pre_rpn=pre_rpn_distill, pre_roi=fire_student))
+                          pre_rpn=pre_rpn_distill, pre_roi=fire_student, post_rois=teacher_box_head))
         names.append("distill")
     c = eng.forward_train_fused(specs)
     loss_dict = {}
@@ -160,9 +173,9 @@ def fused_run_model(trainer, labeled_weak, labeled_strong, unlabeled_weak, unlab
             n0, n1, r0, r1 = ch["n0"], ch["n1"], ch["r0"], ch["r1"]
             torch.manual_seed(dist_.seeder.seed)
             eng._sample_host(ch["roi_counts"], 512, 0.25)                    # the teacher's identical ROI draws
-            rois_t = c.rois[r0:r1].clone()
-            rois_t[:, 0] -= n0
-            t_pred = teacher.engine.box_head_on(tc, rois_t, r1 - r0)
+            if side is not None:
+                torch.cuda.current_stream().wait_stream(side)
+            t_pred = t_out["pred"]
             labels, n_valid, n_fg, _ = eng.rpn_sample(c.rpn_lists[n0:n1], None, n1 - n0, host_counts=ch["rpn_counts"])
             eng.distill_forward_chunk(c, ch, tc.head, t_pred, labels, n_valid, n_fg, obj_T=float(dist_.obj_temperature),
                                       cls_T=float(dist_.cls_temperature), kl=dist_.cls_loss_type == "KL", do_obj=dist_.do_obj_dst,

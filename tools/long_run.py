@@ -1,0 +1,21 @@
+import sys, os, json, subprocess
+sys.path.insert(0, "/root/repo")
+import torch, time, random
+import bench
+from aldi_amd import synthetic as syn
+from aldi_amd.trainer import ALDITrainer
+cfg = bench.make_cfg(1, 800, 1333, False); cfg.SOLVER.FUSED_STEP = True
+random.seed(1234); torch.manual_seed(100)
+tr = ALDITrainer(cfg)
+data = syn.make_batch(2, 2, 800, 1333, 8, seed=100)
+tr._trainer.data_loader = bench.FixedGpuLoader(data, torch.device("cuda"))
+tr.iter = 0
+def one():
+    tr.before_step(); tr.run_step(); tr.after_step(); tr.iter += 1
+for k in range(120):
+    one()
+    if k % 20 == 19:
+        torch.cuda.synchronize()
+        l = tr._trainer.last_loss_dict
+        tot = sum(float(v) for v in l.values())
+        print(k + 1, "alloc MB %.0f reserved MB %.0f max MB %.0f" % (torch.cuda.memory_allocated() / 1e6, torch.cuda.memory_reserved() / 1e6, torch.cuda.max_memory_allocated() / 1e6), "loss %.4f" % tot, "err", int(tr.model.engine.err))
