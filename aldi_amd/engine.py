@@ -505,6 +505,9 @@ class RCNN:
         else:
             c.props, c.prop_scores, c.prop_count = self.proposals(c, geom, anchors, hw, N, training=True)
         for sp in specs:
+            if sp.get("gt_lazy") is not None:              # e.g. launch the teacher now, behind the student's label-free work
+                sp["gt_dev"] = sp["gt_lazy"]()
+        for sp in specs:
             if sp.get("gt_wait") is not None:
                 sp["gt_wait"]()
         gts = [sp["gt_dev"] if sp.get("gt_dev") is not None else self.stage_gt(sp["instances"]) for sp in specs]

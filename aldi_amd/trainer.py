@@ -123,24 +123,27 @@ def fused_run_model(trainer, labeled_weak, labeled_strong, unlabeled_weak, unlab
         if dist_.cls_loss_type not in ("CE", "KL"):
             raise ValueError("cls_loss_type must be one of {CE, KL}")
         teacher = dist_.teacher.module if hasattr(dist_.teacher, "module") else dist_.teacher
-        # the teacher's inference (N = 2, mostly small launches) runs on its own HIP stream beside the student's trunk /
-        # RPN head / proposal generation, none of which needs the pseudo-labels; the student joins right before matching
-        gt_wait = None
+        # The teacher's inference (N = 2, mostly small launches) runs on its own HIP stream beside the student's trunk / RPN head
+        # / proposal generation, none of which needs the pseudo-labels.  It is ENQUEUED after them (the engine calls
+        # `gt_lazy` once the student's label-free work is in the queue): the host needs ~3 ms to issue the teacher's launches,
+        # and issued first they would simply run alone while the student's kernels are still being queued behind them.
         side = _teacher_stream(model.device)
+        ev0 = None
         if side is not None:
-            main = torch.cuda.current_stream()
-            side.wait_stream(main)               # teacher weights (EMA) and last step's readers of the teacher's outputs
-            with torch.cuda.stream(side), torch.no_grad():
-                tc = teacher.engine.inference([d["image"] for d in unlabeled_weak], dist_.pseudo_label_threshold)
-            gt_wait = lambda: torch.cuda.current_stream().wait_stream(side)
-        else:
-            with torch.no_grad():
-                tc = teacher.engine.inference([d["image"] for d in unlabeled_weak], dist_.pseudo_label_threshold)
-        teacher._last_inference = tc
-        labels_ = [DevicePseudoLabels(tc.sizes[i], tc.pseudo, i) for i in range(len(unlabeled_weak))]
-        for dw, ds, lab in zip(unlabeled_weak, unlabeled_strong, labels_):
-            dw["instances"] = lab
-            ds["instances"] = lab
+            ev0 = torch.cuda.Event()
+            ev0.record()                          # previous step's optimizer / EMA / readers of the teacher's outputs
+        st_ = {}
+
+        def teacher_gt():
+            if side is not None:
+                side.wait_event(ev0)
+                with torch.cuda.stream(side), torch.no_grad():
+                    st_["tc"] = teacher.engine.inference([d["image"] for d in unlabeled_weak], dist_.pseudo_label_threshold)
+            else:
+                with torch.no_grad():
+                    st_["tc"] = teacher.engine.inference([d["image"] for d in unlabeled_weak], dist_.pseudo_label_threshold)
+            return st_["tc"].pseudo
+        gt_wait = (lambda: torch.cuda.current_stream().wait_stream(side)) if side is not None else None
 
         def pre_rpn_distill():
             teacher.roi_heads.fire_pre()         # the teacher's eval inference re-seeds with the OLD seed
@@ -155,13 +158,20 @@ def fused_run_model(trainer, labeled_weak, labeled_strong, unlabeled_weak, unlab
                 side.wait_stream(torch.cuda.current_stream())
                 rois_t.record_stream(side)
                 with torch.cuda.stream(side), torch.no_grad():
-                    t_out["pred"] = teacher.engine.box_head_on(tc, rois_t, r1 - r0)
+                    t_out["pred"] = teacher.engine.box_head_on(st_["tc"], rois_t, r1 - r0)
             else:
-                t_out["pred"] = teacher.engine.box_head_on(tc, rois_t, r1 - r0)
-        specs.append(dict(images=[d["image"] for d in unlabeled_strong], gt_dev=tc.pseudo, gt_wait=gt_wait, labeled=True, do_align=False,
+                t_out["pred"] = teacher.engine.box_head_on(st_["tc"], rois_t, r1 - r0)
+        specs.append(dict(images=[d["image"] for d in unlabeled_strong], gt_lazy=teacher_gt, gt_wait=gt_wait, labeled=True, do_align=False,
                           pre_rpn=pre_rpn_distill, pre_roi=fire_student, post_rois=teacher_box_head))
         names.append("distill")
     c = eng.forward_train_fused(specs)
+    if do_distill:
+        tc = st_["tc"]
+        teacher._last_inference = tc
+        labels_ = [DevicePseudoLabels(tc.sizes[i], tc.pseudo, i) for i in range(len(unlabeled_weak))]
+        for dw, ds, lab in zip(unlabeled_weak, unlabeled_strong, labels_):
+            dw["instances"] = lab
+            ds["instances"] = lab
     loss_dict = {}
     scales = []
     for ch, name in zip(c.chunks, names):

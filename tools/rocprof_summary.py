@@ -83,6 +83,38 @@ def overlap(d):
           f"idle {(t1 - t0 - busy) / 1e6:.2f} ms | sum of kernel durations {tot / 1e6:.2f} ms")
 
 
+def phases(d):
+    """where the step's wall time goes: offsets of marker kernels from the end of the previous optimizer step"""
+    dbs = glob.glob(d + "/**/*_results.db", recursive=True)
+    cur = sqlite3.connect(dbs[0]).cursor()
+    tabs = [r[0] for r in cur.execute("select name from sqlite_master where type in ('table','view')")]
+    kt = "kernels" if "kernels" in tabs else [t for t in tabs if "kernel_dispatch" in t][0]
+    cols = [r[1] for r in cur.execute(f"pragma table_info({kt})")]
+    name = "name" if "name" in cols else "kernel_name"
+    rows = list(cur.execute(f"select {name}, start, end from {kt} order by start"))
+    sgd = [i for i, r in enumerate(rows) if "sgd_kernel" in r[0]]
+    a, b = sgd[-2], sgd[-1]
+    t0 = rows[a][2]
+    step = rows[a + 1:b + 1]
+    def first(sub): 
+        for n, s, e in step:
+            if sub in n: return (s - t0) / 1e6
+        return float("nan")
+    def last(sub):
+        v = float("nan")
+        for n, s, e in step:
+            if sub in n: v = (e - t0) / 1e6
+        return v
+    marks = [("first stem (forward starts)", first("stem_")), ("last stem start", max((s - t0) / 1e6 for n, s, e in step if "stem_" in n)),
+             ("first topk_hist (proposals)", first("topk_hist")), ("det_finish end (teacher inference done)", last("det_finish")),
+             ("match_iou first", first("match_iou")), ("compact end (counts ready -> host sync)", last("compact_kernel")),
+             ("sample_scatter first (host sampling done)", first("sample_scatter")), ("roi_gather", first("roi_gather")),
+             ("first wgrad (backward running)", first("wgrad_")), ("roialign bwd start", first("roialign_bwd")), ("roialign bwd end", last("roialign_bwd")),
+             ("last igemm end", last("igemm_kernel")), ("last wgrad end", last("wgrad_")), ("sgd start", (rows[b][1] - t0) / 1e6), ("sgd end", (rows[b][2] - t0) / 1e6)]
+    for k, v in marks:
+        print("%8.2f ms  %s" % (v, k))
+
+
 def pmc(fetch_dir, write_dir):
     res = {}
     for key, d, ctr in (("fetch", fetch_dir, "FETCH_SIZE"), ("write", write_dir, "WRITE_SIZE")):
@@ -107,4 +139,4 @@ def pmc(fetch_dir, write_dir):
 
 
 if __name__ == "__main__":
-    {"stats": stats, "pmc": pmc, "gaps": gaps, "overlap": overlap}[sys.argv[1]](*sys.argv[2:])
+    {"stats": stats, "pmc": pmc, "gaps": gaps, "overlap": overlap, "phases": phases}[sys.argv[1]](*sys.argv[2:])
