@@ -387,3 +387,69 @@ def test_overlapped_exchange_hook_reports_final_gradients(align):
     for lo, hi in rest:                                          # every unreported non-zero element lies in a discriminator
         g = W.grad[lo:hi]
         assert float(g[~in_disc[lo:hi]].abs().sum()) == 0.0, (lo, hi)
+
+
+def test_ragged_batch_vs_oracle_fp32():
+    """images of different sizes in one batch (zero padded to the common /32 size, the reference's ImageList): anchors
+    of the padding, clipping to each image's own size and the per-image ROI sampling must all follow the oracle."""
+    from aldi_amd import synthetic as syn
+    from oracle import d2_rcnn as d2
+    cfg = d2.make_cfg(num_classes=K)
+    sd = syn.init_state_dict(K, seed=3)
+    _, data, _, _ = syn.make_batch(2, 0, H, W, K, seed=4, boxes_per_image=(4, 5))
+    h1, w1 = H - 45, W - 70                                       # second image smaller (and not a multiple of 32)
+    data[1]["image"] = data[1]["image"][:, :h1, :w1].contiguous()
+    b = data[1]["instances"]["gt_boxes"]
+    b = b.tensor if hasattr(b, "tensor") else b
+    b[:, 0::2] = b[:, 0::2].clamp(max=float(w1))
+    b[:, 1::2] = b[:, 1::2].clamp(max=float(h1))
+    keep = ((b[:, 2] - b[:, 0]) > 4) & ((b[:, 3] - b[:, 1]) > 4)
+    data[1]["instances"]["gt_boxes"] = b[keep]
+    data[1]["instances"]["gt_classes"] = data[1]["instances"]["gt_classes"][keep]
+    osd = {k: v.clone() for k, v in sd.items()}
+    for k in d2.trainable_keys(cfg, osd):
+        osd[k].requires_grad_(True)
+    torch.manual_seed(5)
+    cap = d2.Captured()
+    ol = d2.forward_train(cfg, osd, data, roi_seed=9, cap=cap)
+    sum(ol.values()).backward()
+    lay, wts, m = _engine(torch.float32, sd)
+    torch.manual_seed(5)
+    c = m.forward_train([d["image"] for d in data], [d["instances"] for d in data], roi_seed=9)
+    m.backward(c, {k: 1.0 for k in ol})
+    torch.cuda.synchronize()
+    assert int(m.err) == 0 and c.sizes == [(H, W), (h1, w1)]
+    hl = {k: float(v) for k, v in m.loss_dict(c).items()}
+    for k in ol:
+        assert abs(hl[k] - float(ol[k])) < 1e-3 * max(1.0, abs(float(ol[k]))), (k, hl[k], float(ol[k]))
+    assert torch.equal(c.rpn_labels.cpu(), torch.stack(cap["rpn_gt_labels"]).to(torch.int32))
+    r_idx = c.r_idx.cpu()[: c.R].long()
+    row0 = swapped = 0
+    for n in range(2):
+        po = cap["proposals"][n]
+        kk = len(po["proposal_boxes"])
+        assert int(c.prop_count[n]) == kk
+        mine = c.props[n, :kk].cpu()
+        # same proposals; two fp32 implementations may swap neighbours whose scores agree to the last ulp, so rows are
+        # matched by coordinates and at most a handful may sit at a different rank
+        dist = (mine[:, None, :] - po["proposal_boxes"][None, :, :]).abs().amax(-1)
+        best, perm = dist.min(1)
+        assert float(best.max()) < 2e-3
+        assert int((perm != torch.arange(kk)).sum()) <= 6, int((perm != torch.arange(kk)).sum())
+        lim = torch.tensor([c.sizes[n][1], c.sizes[n][0]] * 2, dtype=torch.float32)
+        assert bool((mine <= lim).all())                                                   # clipped to the image's OWN size
+        rows = c.rows[n]
+        idx = r_idx[row0:row0 + rows]
+        ref_idx = cap["sampled"][n]["sampled_idxs"]
+        assert bool((idx == ref_idx.long()).all()), n                                      # the draws pick POSITIONS: identical
+        swapped += int((perm != torch.arange(kk)).sum())
+        row0 += rows
+    cls_diff = int((c.r_cls.cpu()[: c.R] != torch.cat([s["gt_classes"] for s in cap["sampled"]]).to(torch.int32)).sum())
+    assert cls_diff <= swapped, (cls_diff, swapped)                                        # classes differ only where ranks swapped
+    g = _unpack_grad(lay, wts)
+    for k in d2.trainable_keys(cfg, osd):
+        ref = osd[k].grad
+        if ref is None:
+            continue
+        den = max(float(ref.abs().max()), 1e-6)
+        assert float((g[k] - ref).abs().max()) / den < 8e-3, k

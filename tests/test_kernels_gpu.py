@@ -262,13 +262,14 @@ def test_matcher_and_sampling_lists_bit_exact(empty_gt):
     assert int((labels[0] == 1).sum()) == sumA
 
 
+@pytest.mark.parametrize("shapes", [[(48, 64), (24, 32), (12, 16), (6, 8), (3, 4)],
+                                    [(104, 152), (52, 76), (26, 38), (13, 19), (7, 10)]])   # p2: 2 / 6 radix-select chunks, ragged last chunk
 @pytest.mark.parametrize("quantize", [False, True])
-def test_rpn_proposals_bit_exact_vs_oracle(quantize):
+def test_rpn_proposals_bit_exact_vs_oracle(quantize, shapes):
     """top-k -> decode -> clip -> drop empty -> batched NMS -> top-k: identical ORDER and boxes; quantised logits force score ties."""
     from aldi_amd import ops
     from aldi_amd.engine import make_anchors
     from oracle import d2_rcnn as d2
-    shapes = [(48, 64), (24, 32), (12, 16), (6, 8), (3, 4)]
     N, A, C = 2, 3, 16
     cfg = d2.make_cfg(num_classes=8)
     anchors = make_anchors(shapes, DEV)
@@ -283,7 +284,7 @@ def test_rpn_proposals_bit_exact_vs_oracle(quantize):
         heads.append(t.to(DEV))
         lo.append(t[..., :A].reshape(N, -1))                                  # (N, HWA)
         de.append(t[..., A:5 * A].reshape(N, h * w * A, 4))
-    sizes = [(180, 250), (192, 256)]
+    sizes = [(shapes[0][0] * 4 - 12, shapes[0][1] * 4 - 6), (shapes[0][0] * 4, shapes[0][1] * 4)]
     geom = ops.make_geom(shapes, A, C)
     hw = torch.tensor(sizes, dtype=torch.int32, device=DEV)
     for training, pre, post in ((True, 2000, 1000), (False, 1000, 1000)):
