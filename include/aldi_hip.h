@@ -255,6 +255,29 @@ int aldi_avgpool_bwd(const void* gy, const void* act, void* gx, int N, int HW, i
  * model(...)) at O(k + n/624) instead of O(n) divisions. */
 int aldi_torch_randperm_prefix(unsigned char* state, long n, long k, long* out);
 
+/* ---------------------------------------------------------------------------------------
+ * Strong augmentation on the device (the step next to the hot path).  Images are HWC uint8 in HBM;
+ * the random parameters are drawn on the host in the reference's order (aldi_amd/aug.py) and passed in.  Bit-identical to
+ * the reference's numpy / scipy arithmetic.
+ * --------------------------------------------------------------------------------------- */
+/* *sum = exact integer sum of n bytes (RandomContrast blends with image.mean(); detectron2 transforms reached from
+ * aldi/aug.py:47-51). */
+int aldi_aug_sum_u8(const unsigned char* img, long n, unsigned long long* sum, aldi_stream_t stream);
+/* BlendTransform in place: mode 0 contrast (needs *sum of this image), 1 brightness, 2 saturation / grayscale (w = 0);
+ * `w` is the drawn weight (dst_weight; src_weight = 1 - w).  aldi/aug.py:47-53. */
+int aldi_aug_blend(unsigned char* img, int H, int W, int mode, double w, const unsigned long long* sum, aldi_stream_t stream);
+/* RandomBlurTransform.apply_image (aldi/aug.py:85-91): scipy gaussian_filter(sigma) over the three axes of the HWC float32
+ * image; `weights` = the 2*radius+1 normalised taps in double (DEVICE pointer), tmp0/tmp1 = H*W*3 floats of scratch. */
+int aldi_aug_blur(const unsigned char* img, unsigned char* out, float* tmp0, float* tmp1, int H, int W, const double* weights, int radius,
+                  aldi_stream_t stream);
+/* RandomEraseTransform (value="random", aldi/aug.py:113-131): img[h0:h0+h, w0:w0+w, :] = clip(fill * 255); fill = the
+ * np.random.rand(h, w, 3) draw as float32, [h][w][3]. */
+int aldi_aug_erase(unsigned char* img, int H, int W, int h0, int w0, int h, int w, const float* fill, aldi_stream_t stream);
+/* MICTransform (aldi/aug.py:154-171): zero every pixel whose block (nearest-resized mh x mw mask, 1 = keep) is masked. */
+int aldi_aug_mic(unsigned char* img, int H, int W, const unsigned char* mask, int mh, int mw, aldi_stream_t stream);
+/* HWC uint8 -> CHW uint8 (the layout `dataset_dict["image"]` has in the reference, aldi/dataloader.py). */
+int aldi_aug_hwc_to_chw(const unsigned char* in, unsigned char* out, int H, int W, aldi_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -148,7 +148,35 @@ class _Comm(types.ModuleType):
         return True
 
 
+class _Transform:
+    """fvcore.transforms.transform.Transform: only what aldi/aug.py's transforms touch (constructor + _set_attributes)"""
+    def __init__(self):
+        pass
+
+    def _set_attributes(self, params=None):
+        if params:
+            for k, v in params.items():
+                if k != "self" and not k.startswith("_"):
+                    setattr(self, k, v)
+
+
+class _NoOpTransform(_Transform):
+    def apply_image(self, img):
+        return img
+
+
+def _cv2_resize(src, dsize, interpolation=0):
+    """cv2.resize(..., INTER_NEAREST) restated (cv2 is absent): x_ofs = min(floor(x * src_w / dst_w), src_w - 1)"""
+    W, H = dsize
+    sh, sw = src.shape[:2]
+    ys = np.minimum(np.floor(np.arange(H) * (sh / H)).astype(np.int64), sh - 1)
+    xs = np.minimum(np.floor(np.arange(W) * (sw / W)).astype(np.int64), sw - 1)
+    return src[ys][:, xs]
+
+
 REAL = {
+    "fvcore.transforms.transform": {"Transform": _Transform, "NoOpTransform": _NoOpTransform},
+    "cv2": {"resize": _cv2_resize, "INTER_NEAREST": 0},
     "detectron2.utils.registry": {"Registry": Registry},
     "detectron2.config": {"configurable": configurable, "CfgNode": dict},
     "detectron2.structures": {"Boxes": Boxes, "Instances": Instances},
@@ -201,7 +229,7 @@ def import_reference():
     sys.meta_path.insert(0, _Finder())
     sys.path.insert(0, REF)
     mods = {}
-    for n in ("helpers", "align", "ema", "pseudolabeler", "distill", "dataloader", "trainer"):
+    for n in ("helpers", "align", "ema", "pseudolabeler", "distill", "dataloader", "trainer", "aug"):
         mods[n] = importlib.import_module("aldi." + n)
     return mods
 
@@ -530,8 +558,38 @@ def g8(m):
     print("wrote g8_hard_mask.json")
 
 
+# ----------------------------------------------------------------------------
+# G9  strong augmentation, ALDI-owned transforms (aldi/aug.py:80-171): blur (real scipy), random erase, MIC block mask
+#     (cv2.resize NEAREST stubbed above).  RNG seeds are stored so that the drawn parameters can be re-derived.
+# ----------------------------------------------------------------------------
+def g9(m):
+    aug = m["aug"]
+    rng = np.random.default_rng(2024)
+    out = {}
+    for tag, (H, W) in (("a", (40, 56)), ("b", (33, 47))):
+        img = rng.integers(0, 256, (H, W, 3), dtype=np.uint8)
+        img[: H // 3] = (img[: H // 3].astype(np.int32) // 8 + 220).clip(0, 255).astype(np.uint8)     # a bright band: exercises the clip
+        out[f"img_{tag}"] = img
+        for i, seed in enumerate((3, 17, 99)):
+            random.seed(seed)
+            out[f"blur_{tag}{i}"] = aug.RandomBlurTransform((0.1, 2.0)).apply_image(img.copy())
+            out[f"blur_{tag}{i}_seed"] = np.int64(seed)
+        for i, (seed, (sl, sh, r1, r2)) in enumerate(((5, (0.05, 0.2, 0.3, 3.3)), (6, (0.02, 0.2, 0.1, 6)), (7, (0.02, 0.2, 0.05, 8)))):
+            random.seed(seed)
+            np.random.seed(seed)
+            out[f"erase_{tag}{i}"] = aug.RandomEraseTransform(sl=sl, sh=sh, r1=r1, r2=r2, value="random").apply_image(img.copy())
+            out[f"erase_{tag}{i}_cfg"] = np.array([seed, sl, sh, r1, r2], dtype=np.float64)
+        for i, (seed, ratio, block) in enumerate(((11, 0.5, 8), (12, 0.3, 5))):
+            np.random.seed(seed)
+            out[f"mic_{tag}{i}"] = aug.MICTransform(ratio, block).apply_image(img.copy())
+            out[f"mic_{tag}{i}_cfg"] = np.array([seed, ratio, block], dtype=np.float64)
+    save("g9_aug", **out)
+
+
 if __name__ == "__main__":
     random.seed(0)
     mods = import_reference()
-    for fn in (g1, g2, g3, g4, g5, g6, g7, g8):
-        fn(mods)
+    only = sys.argv[1:]
+    for fn in (g1, g2, g3, g4, g5, g6, g7, g8, g9):
+        if not only or fn.__name__ in only:
+            fn(mods)
