@@ -69,13 +69,21 @@ __global__ __launch_bounds__(256) void blur_axis_kernel(const IN* __restrict__ i
     const long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
     if (i >= total) return;
     // element index along the axis and the base offset of its line
-    const long l = (i / stride) % len;
+    const long l = (i / stride) % len;               // position along the filtered axis
     const long base = i - l * stride;
     double tmp = (double)(float)in[i] * wts[r];
-    for (int j = -r; j < 0; ++j) {
-        const double a = (double)(float)in[base + (long)reflect((int)l + j, len) * stride];
-        const double b = (double)(float)in[base + (long)reflect((int)l - j, len) * stride];
-        tmp += (a + b) * wts[j + r];
+    if (l >= r && l + r < len) {                       // interior: no border arithmetic (the reflect() modulo dominated the kernel)
+        for (int j = -r; j < 0; ++j) {
+            const double a = (double)(float)in[i + (long)j * stride];
+            const double b = (double)(float)in[i - (long)j * stride];
+            tmp += (a + b) * wts[j + r];
+        }
+    } else {
+        for (int j = -r; j < 0; ++j) {
+            const double a = (double)(float)in[base + (long)reflect((int)l + j, len) * stride];
+            const double b = (double)(float)in[base + (long)reflect((int)l - j, len) * stride];
+            tmp += (a + b) * wts[j + r];
+        }
     }
     out[i] = (float)tmp;
 }
