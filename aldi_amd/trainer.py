@@ -382,6 +382,7 @@ class DefaultTrainer:
         model = self.create_ddp_model(model, broadcast_buffers=False, cfg=cfg)
         self._trainer = self._create_trainer(cfg, model, data_loader, optimizer)
         self.scheduler = self.build_lr_scheduler(cfg, optimizer)
+        self.checkpointer = self._create_checkpointer(model, cfg)
         self.start_iter = 0
         self.iter = 0
         self.max_iter = cfg.SOLVER.MAX_ITER
@@ -405,8 +406,17 @@ class DefaultTrainer:
     def build_optimizer(cls, cfg, model):
         return EngineSGD(model, cfg.SOLVER.BASE_LR, cfg.SOLVER.MOMENTUM, cfg.SOLVER.WEIGHT_DECAY)
 
+    def _create_checkpointer(self, model, cfg, ckpt_cls=None):
+        from .checkpoint import DetectionCheckpointer
+        return (ckpt_cls or DetectionCheckpointer)(model, cfg.OUTPUT_DIR)
+
     def resume_or_load(self, resume=True):
-        return None
+        """detectron2 DefaultTrainer.resume_or_load: last checkpoint of OUTPUT_DIR when resuming, else cfg.MODEL.WEIGHTS
+        (an empty string = keep the initial weights); the iteration counter continues after a resume."""
+        ret = self.checkpointer.resume_or_load(self.cfg.MODEL.WEIGHTS, resume=resume)
+        if resume and self.checkpointer.has_checkpoint():
+            self.start_iter = self.iter = int(ret.get("iteration", -1)) + 1
+        return ret
 
     @property
     def model(self):
@@ -440,6 +450,14 @@ class ALDITrainer(DefaultTrainer):
                                                                                     model_batch_size=cfg.SOLVER.IMS_PER_GPU)
         trainer.fused = bool(cfg.SOLVER.get("FUSED_STEP", False))
         return trainer
+
+    def _create_checkpointer(self, model, cfg):
+        """aldi/trainer.py:151-156: EMA-aware start + the teacher as a checkpointable"""
+        from .checkpoint import DetectionCheckpointer, DetectionCheckpointerWithEMA
+        checkpointer = super()._create_checkpointer(model, cfg, ckpt_cls=DetectionCheckpointerWithEMA if cfg.EMA.LOAD_FROM_EMA_ON_START else DetectionCheckpointer)
+        if cfg.EMA.ENABLED:
+            checkpointer.add_checkpointable("ema", self.ema)
+        return checkpointer
 
     @classmethod
     def build_model(cls, cfg):

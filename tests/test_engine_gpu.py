@@ -453,3 +453,35 @@ def test_ragged_batch_vs_oracle_fp32():
             continue
         den = max(float(ref.abs().max()), 1e-6)
         assert float((g[k] - ref).abs().max()) / den < 8e-3, k
+
+
+def test_checkpoint_round_trip_and_ema_start(tmp_path):
+    """save -> new trainer -> resume restores student, teacher and iteration; a fresh run started from the same file with
+    EMA.LOAD_FROM_EMA_ON_START begins from the TEACHER's weights (aldi/checkpoint.py:20-32, aldi/trainer.py:151-156)."""
+    from aldi_amd.trainer import ALDITrainer
+    cfg = _cfg(False)
+    cfg.OUTPUT_DIR = str(tmp_path / "run")
+    random.seed(0); torch.manual_seed(3)
+    tr = ALDITrainer(cfg)
+    for tr.iter in range(2):
+        tr.before_step(); tr.run_step(); tr.after_step()
+    tr.checkpointer.save("model_0000001", iteration=1)
+    s_sd, t_sd = tr.model.state_dict(), tr.ema.model.state_dict()
+    assert any(not torch.equal(s_sd[k], t_sd[k]) for k in s_sd)              # the teacher lags the student
+    raw = torch.load(os.path.join(cfg.OUTPUT_DIR, "model_0000001.pth"), weights_only=False)
+    assert set(raw) == {"model", "ema", "iteration"} and all(k.startswith("model.") for k in raw["ema"])
+    assert "backbone.bottom_up.res2.0.conv1.weight" in raw["model"] and "roi_heads.box_predictor.cls_score.weight" in raw["model"]
+    tr2 = ALDITrainer(cfg)
+    tr2.resume_or_load(resume=True)
+    assert tr2.start_iter == 2
+    for k in s_sd:
+        assert torch.equal(tr2.model.state_dict()[k], s_sd[k]), k
+        assert torch.equal(tr2.ema.model.state_dict()[k], t_sd[k]), k
+    cfg3 = _cfg(False)
+    cfg3.OUTPUT_DIR = str(tmp_path / "other")
+    cfg3.MODEL.WEIGHTS = os.path.join(cfg.OUTPUT_DIR, "model_0000001.pth")
+    tr3 = ALDITrainer(cfg3)
+    tr3.resume_or_load(resume=False)
+    assert tr3.start_iter == 0
+    for k in s_sd:
+        assert torch.equal(tr3.model.state_dict()[k], t_sd[k]), k             # student := checkpoint's EMA weights
