@@ -372,12 +372,20 @@ __global__ __launch_bounds__(256) void roialign_bwd_gather_kernel(Feats ft, Gath
 #pragma unroll
                 for (int pw = 0; pw < 7; ++pw) gs[pw] = 0.f;
                 const T* g0 = gp + (long)rr * P * P * ft.C + c;
-                for (int ph = 0; ph < P; ++ph) {
-                    const float rc = rowc[ph];
-                    if (rc == 0.f) continue;
+                // all P*P loads in flight at once (a `continue` on zero row weights would put one L2 round trip per bin row
+                // on the critical path of every candidate)
+                if (P == 7) {
 #pragma unroll
-                    for (int pw = 0; pw < 7; ++pw)
-                        if (pw < P) gs[pw] += rc * Elem<T>::ld(g0 + (long)(ph * P + pw) * ft.C);
+                    for (int ph = 0; ph < 7; ++ph) {
+                        const float rc = rowc[ph];
+#pragma unroll
+                        for (int pw = 0; pw < 7; ++pw) gs[pw] += rc * Elem<T>::ld(g0 + (long)(ph * 7 + pw) * ft.C);
+                    }
+                } else {
+                    for (int ph = 0; ph < P; ++ph) {
+                        const float rc = rowc[ph];
+                        for (int pw = 0; pw < P; ++pw) gs[pw] += rc * Elem<T>::ld(g0 + (long)(ph * P + pw) * ft.C);
+                    }
                 }
 #pragma unroll
                 for (int pw = 0; pw < 7; ++pw) gsum[pw][c] = gs[pw] * inv_count;
