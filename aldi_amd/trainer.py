@@ -174,6 +174,7 @@ def fused_run_model(trainer, labeled_weak, labeled_strong, unlabeled_weak, unlab
             ds["instances"] = lab
     loss_dict = {}
     scales = []
+    entries = []
     for ch, name in zip(c.chunks, names):
         losses = eng.chunk_loss_dict(ch)
         sc = {}
@@ -192,7 +193,7 @@ def fused_run_model(trainer, labeled_weak, labeled_strong, unlabeled_weak, unlab
                                       do_rpn_reg=dist_.do_rpn_reg_dst, do_cls=dist_.do_cls_dst, do_roih_reg=dist_.do_roih_reg_dst)
             out = {}
             for k, v in losses.items():
-                out[k] = v if hard.get(k, False) else v * 0.0
+                out[k] = v if hard.get(k, False) else (v, 0.0)      # the reference's `v * 0.0`, applied in the batched arithmetic below
                 sc[k] = (1.0 if hard.get(k, False) else 0.0) / accum
             if has_disc:
                 out["_da"] = torch.zeros((), device=model.device)
@@ -211,7 +212,20 @@ def fused_run_model(trainer, labeled_weak, labeled_strong, unlabeled_weak, unlab
         scales.append(sc)
         for k, v in out.items():
             if keep(k):
-                loss_dict[f"{k}_{name}"] = loss_dict.get(f"{k}_{name}", 0) + (v / accum).detach()
+                entries.append((f"{k}_{name}", v))
+    # loss-dict arithmetic (`v * 0.0` masking, `/ accum`) for all entries in a handful of launches instead of two or three
+    # 0-d kernels per entry (the host issues those at ~10 us apiece in the middle of the step)
+    kept = [(n_, v) for n_, v in entries if not isinstance(v, tuple)]
+    masked = [(n_, v[0]) for n_, v in entries if isinstance(v, tuple)]
+    vals = {}
+    if kept:
+        kv = (torch.stack([v for _, v in kept]) / accum).detach()
+        vals.update({n_: kv[i] for i, (n_, _) in enumerate(kept)})
+    if masked:
+        mv = ((torch.stack([v for _, v in masked]) * 0.0) / accum).detach()
+        vals.update({n_: mv[i] for i, (n_, _) in enumerate(masked)})
+    for n_, _ in entries:                                        # original key order
+        loss_dict[n_] = loss_dict[n_] + vals[n_] if n_ in loss_dict else vals[n_]
     eng.backward_fused(c, scales)
     model._last_fused = c
     return loss_dict

@@ -115,6 +115,24 @@ def phases(d):
         print("%8.2f ms  %s" % (v, k))
 
 
+def window(d, first="compact_kernel", last="wgrad_"):
+    """kernel sequence between the last `first` kernel and the first `last` kernel of a step (the latency-bound middle)"""
+    dbs = glob.glob(d + "/**/*_results.db", recursive=True)
+    cur = sqlite3.connect(dbs[0]).cursor()
+    tabs = [r[0] for r in cur.execute("select name from sqlite_master where type in ('table','view')")]
+    kt = "kernels" if "kernels" in tabs else [t for t in tabs if "kernel_dispatch" in t][0]
+    cols = [r[1] for r in cur.execute(f"pragma table_info({kt})")]
+    name = "name" if "name" in cols else "kernel_name"
+    rows = list(cur.execute(f"select {name}, start, end from {kt} order by start"))
+    sgd = [i for i, r in enumerate(rows) if "sgd_kernel" in r[0]]
+    step = rows[sgd[-2] + 1:sgd[-1] + 1]
+    i0 = max(i for i, r in enumerate(step) if first in r[0])
+    i1 = min(i for i, r in enumerate(step) if last in r[0] and i > i0)
+    t0 = step[i0][2]
+    for n, s_, e in step[i0:i1 + 1]:
+        print("%8.1f us  +%6.1f us  %s" % ((s_ - t0) / 1e3, (e - s_) / 1e3, n[:110]))
+
+
 def pmc(fetch_dir, write_dir):
     res = {}
     for key, d, ctr in (("fetch", fetch_dir, "FETCH_SIZE"), ("write", write_dir, "WRITE_SIZE")):
@@ -139,4 +157,4 @@ def pmc(fetch_dir, write_dir):
 
 
 if __name__ == "__main__":
-    {"stats": stats, "pmc": pmc, "gaps": gaps, "overlap": overlap, "phases": phases}[sys.argv[1]](*sys.argv[2:])
+    {"stats": stats, "pmc": pmc, "gaps": gaps, "overlap": overlap, "phases": phases, "window": window}[sys.argv[1]](*sys.argv[2:])
