@@ -93,7 +93,7 @@ template <> struct Mma<float> {
     }
 };
 
-template <typename T, int BM, int BN, int WM, int WN, int KC, bool PIPE>
+template <typename T, int BM, int BN, int WM, int WN, int KC, bool PIPE, bool HALO = false>
 __global__ __launch_bounds__(WM* WN * 64) void igemm_kernel(ConvDev p) {
     constexpr int NT = WM * WN * 64;
     constexpr int EP = Elem<T>::kPer16B;           // elements per 16-B chunk
@@ -105,7 +105,9 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_kernel(ConvDev p) {
     static_assert((BM * KC) % NT == 0, "tile/threads mismatch");
 
     constexpr int NBUF = 3;                        // LDS ring: two slabs of DMA in flight across the barrier
-    __shared__ __attribute__((aligned(128))) uint4 lds[NBUF][(BM + BN) * KC];
+    constexpr int SLOTS = HALO ? ((BM + 2) * KC + 63) / 64 * 64 + 3 * BN * KC : (BM + BN) * KC;     // per ring stage
+    constexpr int NSTAGE = HALO ? 2 : NBUF;
+    __shared__ __attribute__((aligned(128))) uint4 lds[NSTAGE][SLOTS];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
@@ -134,6 +136,104 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_kernel(ConvDev p) {
     const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(Wt), 0, p.w_bytes, 0x00020000);
     constexpr unsigned OOB = 0x80000000u;
     const int wbase = __builtin_amdgcn_readfirstlane(tid & ~63);      // first tile slot of this wave (wave-uniform)
+    f32x4_t acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+    const int fr = lane & 15, fq = lane >> 4;
+    if constexpr (HALO) {
+    // ---- 3x3 / stride 1 / pad 1 with operand reuse across the three horizontal taps -------------------------------
+    // For a fixed (kh, 32-channel chunk) the pixel tiles of kw = 0,1,2 are the same BM+2 consecutive input pixels
+    // shifted by one row of the LDS image: load that "halo" slab ONCE and point the three taps' fragment reads at rows
+    // +0/+1/+2.  The K loop is bound by the L2 -> CU fill path, and the pixel tile is half of its bytes: a group of three
+    // k-steps now moves (BM+2) + 3*BN rows instead of 3*(BM+BN).  What the shift cannot express is the zero padding at
+    // the left / right image border (the neighbouring LDS row holds the previous / next image row's pixel): those
+    // fragments are zeroed in registers (two of the three taps, 4 v_cndmask each).  Vertical padding and the tile's own
+    // ends are out-of-range DMA offsets as before.
+    static_assert(KC == 4, "halo form: one MFMA k-step per tap");
+    constexpr int AS = ((BM + 2) * KC + 63) / 64 * 64;          // halo slots, padded to whole waves of DMA
+    constexpr int WS = 3 * BN * KC;                              // three taps of weights
+    constexpr int AH_IT = (AS + NT - 1) / NT, WH_IT = WS / NT;
+    static_assert(WS % NT == 0, "weight slots per thread");
+    unsigned ha_voff[AH_IT], ha_mask[AH_IT];
+#pragma unroll
+    for (int it = 0; it < AH_IT; ++it) {
+        const int c = tid + it * NT, row = c >> 2, kce = swz<KC>(row, c & 3);
+        const int q0 = m0 - 1 + row;                             // input pixel under the CENTRE row (kh = 1), flat index
+        const bool ok = row < BM + 2 && q0 >= 0 && q0 < p.M;
+        const int qq = ok ? q0 : 0;
+        const int h0 = (qq / p.W) % p.H;
+        ha_voff[it] = ((unsigned)qq * (unsigned)p.Cin + (unsigned)(kce * EP)) * (unsigned)sizeof(T);
+        ha_mask[it] = ok ? ((h0 >= 1 ? 1u : 0u) | 2u | (h0 <= p.H - 2 ? 4u : 0u)) : 0u;
+    }
+    unsigned hw_voff[WH_IT];
+#pragma unroll
+    for (int it = 0; it < WH_IT; ++it) {
+        const int c = tid + it * NT, kwi = c / (BN * KC), rem = c - kwi * (BN * KC), row = rem >> 2, kce = swz<KC>(row, rem & 3);
+        const int co = n0 + row;
+        hw_voff[it] = co < p.Cout ? ((unsigned)co * (unsigned)p.K + (unsigned)(kwi * p.Cin + kce * EP)) * (unsigned)sizeof(T) : OOB;
+    }
+    int gkh = 0, gci = 0;                                        // (kh, channel chunk) of the group being LOADED
+    auto issue_group = [&](int buf) {
+        const unsigned a_off = (unsigned)(((gkh - 1) * p.W * p.Cin + gci) * (int)sizeof(T));
+#pragma unroll
+        for (int it = 0; it < AH_IT; ++it)
+            if (wbase + it * NT < AS)                            // wave uniform
+                glds16(rx, &lds[buf][wbase + it * NT], ((ha_mask[it] >> gkh) & 1u) ? ha_voff[it] + a_off : OOB);
+        const unsigned w_off = (unsigned)((gkh * 3 * p.Cin + gci) * (int)sizeof(T));
+#pragma unroll
+        for (int it = 0; it < WH_IT; ++it)
+            glds16(rw, &lds[buf][AS + wbase + it * NT], hw_voff[it] == OOB ? OOB : hw_voff[it] + w_off);
+        gci += BK;
+        if (gci >= p.Cin) { gci = 0; ++gkh; }
+    };
+    // left / right image border of this lane's fragment rows
+    bool edge_l[TM], edge_r[TM];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int m = m0 + wm * (BM / WM) + i * 16 + fr;
+        const int wo = m % p.W;
+        edge_l[i] = wo == 0;
+        edge_r[i] = wo == p.W - 1;
+    }
+    const int xrow = wm * (BM / WM) + fr, wrow = wn * (BN / WN) + fr;
+    const unsigned lbase = lds_addr(&lds[0][0]);
+    unsigned x_rd[3];
+#pragma unroll
+    for (int kw = 0; kw < 3; ++kw) x_rd[kw] = lbase + (unsigned)((xrow + kw) * KC + swz<KC>(xrow + kw, fq)) * 16u;
+    const unsigned w_rd = lbase + (unsigned)((AS + wrow * KC) + swz<KC>(wrow, fq)) * 16u;
+    constexpr unsigned GROUP_BYTES = (AS + WS) * 16;
+    const int G = 3 * (p.Cin / BK);
+    issue_group(0);
+    int buf = 0;
+    for (int g = 0; g < G; ++g) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        if (g + 1 < G) issue_group(buf ^ 1);
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) {
+            u32x4_t xf[TM], wf[TN];
+            frag_read_all<TM, KC * 16>(xf, x_rd[kw] + (unsigned)buf * GROUP_BYTES);
+            frag_read_all<TN, KC * 16>(wf, w_rd + (unsigned)buf * GROUP_BYTES + (unsigned)(kw * BN * KC * 16));
+            frag_wait<TM, TN>(xf, wf);
+            if (kw != 1) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    const bool z = kw == 0 ? edge_l[i] : edge_r[i];
+                    xf[i] = z ? u32x4_t{0u, 0u, 0u, 0u} : xf[i];
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[i][j] = Mma<T>::run(wf[j], xf[i], acc[i][j]);
+        }
+        buf ^= 1;
+    }
+    } else {
     unsigned a_voff[A_IT], a_mask[A_IT];
     int a_kce[A_IT];
     const bool ident = p.KH * p.KW == 1 && p.stride == 1 && p.pad == 0;   // 1x1: pixel index == input index, no divisions
@@ -199,12 +299,6 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_kernel(ConvDev p) {
         if (ci0 >= p.Cin) { ci0 = 0; ++tap; if (++kw == p.KW) { kw = 0; ++kh; } }
     };
 
-    f32x4_t acc[TM][TN];
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-
     // Software pipeline, three levels deep (NBUF = 3 LDS slabs + two fragment register sets):
     //   iteration s:  wait for MY DMA pieces of slab s+1 (counted vmcnt: slab s+2 stays in flight) -> raw s_barrier (slab s+1
     //   visible, everyone is done reading slab s) -> issue the fragment reads of slab s+1 into the spare register set ->
@@ -216,7 +310,6 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_kernel(ConvDev p) {
     const int S = (p.dbg & 8) ? 1 : (p.K + BK - 1) / BK;
     issue_slab(0, 0);
     if (S > 1) issue_slab(1, 1);
-    const int fr = lane & 15, fq = lane >> 4;
     constexpr unsigned SLAB_BYTES = (BM + BN) * KC * 16;
     const int xrow = wm * (BM / WM) + fr, wrow = wn * (BN / WN) + fr;
     const unsigned x_rd0 = lds_addr(&lds[0][0]) + (unsigned)(xrow * KC + swz<KC>(xrow, fq)) * 16u;
@@ -279,6 +372,8 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_kernel(ConvDev p) {
     }
     }
 
+    }
+
     if (p.dbg & 4) return;
     // ---- epilogue: lane owns pixel (lane&15), channels (lane>>4)*4 .. +3 of each 16x16 tile
     T* __restrict__ Y = static_cast<T*>(p.y);
@@ -291,7 +386,7 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_kernel(ConvDev p) {
         // loads and stores.  (conv*scale+shift is rounded to bf16 before the residual add; the fp32 parity mode keeps
         // the single-rounding direct path below.)
         constexpr int ROWB = BN * 2 + 16;
-        constexpr bool kStageFits = BM * ROWB <= NBUF * (BM + BN) * KC * 16;   // staging tile reuses the pipeline buffers
+        constexpr bool kStageFits = BM * ROWB <= NSTAGE * SLOTS * 16;   // staging tile reuses the pipeline buffers
         if (kStageFits && Y && !p.y_f32 && (p.Cout & 7) == 0) {
             // The epilogue is instruction-bound if written naively (wave64 VALU ops cost 4 cycles each and a block only
             // moves 32 KB): hardware bf16 packing, per-column scale/shift hoisted, immediate LDS offsets, and packed
@@ -461,10 +556,10 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_kernel(ConvDev p) {
     }
 }
 
-template <typename T, int BM, int BN, int WM, int WN, int KC, bool PIPE = true>
+template <typename T, int BM, int BN, int WM, int WN, int KC, bool PIPE = true, bool HALO = false>
 int launch(const ConvDev& d, hipStream_t st) {
     dim3 grid(cdiv(d.M, BM), cdiv(d.Cout, BN));
-    hipLaunchKernelGGL((igemm_kernel<T, BM, BN, WM, WN, KC, PIPE>), grid, dim3(WM * WN * 64), 0, st, d);
+    hipLaunchKernelGGL((igemm_kernel<T, BM, BN, WM, WN, KC, PIPE, HALO>), grid, dim3(WM * WN * 64), 0, st, d);
     ALDI_CHECK_LAUNCH();
     return ALDI_OK;
 }
@@ -481,14 +576,24 @@ int dispatch(ConvDev& d, hipStream_t st) {
     d.xcd = xcd_env;
     static const int dbg_env = env_int("ALDI_IGEMM_DBG", 0);
     d.dbg = dbg_env;
-    if (d.Cout <= 16) return launch<T, 128, 16, 4, 1, 4>(d, st);
-    if (d.Cout <= 64) return launch<T, 128, 64, 4, 1, 4>(d, st);
     // the N=2 micro-batch leaves the deep layers (res4/res5, FC heads) with far fewer 128x128 tiles than the
     // 256 CUs: fall back to 64x64 tiles (4x the workgroups) when the big tiling cannot fill the chip
     const long big = (long)cdiv(d.M, 128) * cdiv(d.Cout, 128);
     // long-K convs with thousands of tiles are bound by the L2 -> CU path (~31 B/clk/CU measured): the 256x128 tile
     // (8 waves) moves 25 % fewer bytes per flop
     static const int big_tile_min = env_int("ALDI_IGEMM_BIGTILE_MIN", 1024);
+    // 3x3 / stride 1 / pad 1 (every 3x3 of the network): halo form, the pixel tile is loaded once per three taps
+    static const int halo_env = env_int("ALDI_IGEMM_HALO", 1);
+    if constexpr (sizeof(T) == 2) {
+        const bool same3 = d.KH == 3 && d.KW == 3 && d.stride == 1 && d.pad == 1 && d.Ho == d.H && d.Wo == d.W && d.Cin % 32 == 0 && d.out_scale == 1;
+        if (halo_env && same3) {
+            if (d.Cout <= 64) return launch<T, 128, 64, 4, 1, 4, false, true>(d, st);
+            if (big >= big_tile_min) return launch<T, 256, 128, 4, 2, 4, false, true>(d, st);
+            return launch<T, 128, 128, 2, 2, 4, false, true>(d, st);
+        }
+    }
+    if (d.Cout <= 16) return launch<T, 128, 16, 4, 1, 4>(d, st);
+    if (d.Cout <= 64) return launch<T, 128, 64, 4, 1, 4>(d, st);
     if (tile_env != 9 && big >= big_tile_min && d.K >= 1024) return launch<T, 256, 128, 4, 2, 4, false>(d, st);
     if (big < 200) return launch<T, 64, 64, 2, 2, 4>(d, st);
     return launch<T, 128, 128, 2, 2, 4>(d, st);
