@@ -213,23 +213,31 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_kernel(ConvDev p) {
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
         if (g + 1 < G) issue_group(buf ^ 1);
+        // the three taps of the group: fragments of tap kw+1 are read while tap kw's MFMAs run
+        u32x4_t xf[2][TM], wf[2][TN];
+        const unsigned gb = (unsigned)buf * GROUP_BYTES;
+        frag_read_all<TM, KC * 16>(xf[0], x_rd[0] + gb);
+        frag_read_all<TN, KC * 16>(wf[0], w_rd + gb);
+        frag_wait<TM, TN>(xf[0], wf[0]);
 #pragma unroll
         for (int kw = 0; kw < 3; ++kw) {
-            u32x4_t xf[TM], wf[TN];
-            frag_read_all<TM, KC * 16>(xf, x_rd[kw] + (unsigned)buf * GROUP_BYTES);
-            frag_read_all<TN, KC * 16>(wf, w_rd + (unsigned)buf * GROUP_BYTES + (unsigned)(kw * BN * KC * 16));
-            frag_wait<TM, TN>(xf, wf);
+            const int cur = kw & 1, nxt = cur ^ 1;
+            if (kw < 2) {
+                frag_read_all<TM, KC * 16>(xf[nxt], x_rd[kw + 1] + gb);
+                frag_read_all<TN, KC * 16>(wf[nxt], w_rd + gb + (unsigned)((kw + 1) * BN * KC * 16));
+            }
             if (kw != 1) {
 #pragma unroll
                 for (int i = 0; i < TM; ++i) {
                     const bool z = kw == 0 ? edge_l[i] : edge_r[i];
-                    xf[i] = z ? u32x4_t{0u, 0u, 0u, 0u} : xf[i];
+                    xf[cur][i] = z ? u32x4_t{0u, 0u, 0u, 0u} : xf[cur][i];
                 }
             }
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int j = 0; j < TN; ++j) acc[i][j] = Mma<T>::run(wf[j], xf[i], acc[i][j]);
+                for (int j = 0; j < TN; ++j) acc[i][j] = Mma<T>::run(wf[cur][j], xf[cur][i], acc[i][j]);
+            if (kw < 2) frag_wait<TM, TN>(xf[nxt], wf[nxt]);
         }
         buf ^= 1;
     }
