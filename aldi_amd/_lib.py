@@ -120,4 +120,14 @@ class DgwItem(C.Structure):
                 ("Cout", c_int), ("KH", c_int), ("KW", c_int), ("Cin", c_int), ("tile_begin", c_int), ("reserved", c_int)]
 
 
+class AttnArgs(C.Structure):
+    _fields_ = [
+        ("qkv", c_void_p), ("rel_h", c_void_p), ("rel_w", c_void_p),
+        ("Qp", c_void_p), ("Kp", c_void_p), ("KpT", c_void_p), ("VT", c_void_p), ("QsT", c_void_p),
+        ("O", c_void_p), ("lse", c_void_p), ("dO", c_void_p), ("dOT", c_void_p), ("dQp", c_void_p), ("delta", c_void_p),
+        ("dqkv", c_void_p), ("drel_h", c_void_p), ("drel_w", c_void_p),
+        ("nB", c_int), ("gh", c_int), ("gw", c_int), ("heads", c_int), ("Dq", c_int), ("scale", c_float),
+    ]
+
+
 PtrArray5 = c_void_p * MAX_LEVELS

@@ -1,0 +1,733 @@
+// Multi-head attention with decomposed relative position bias for the ViTDet trunk (gfx950, bf16 MFMA).
+//
+// Reference semantics: detectron2 `modeling/backbone/vit.py` Attention.forward + `utils.add_decomposed_rel_pos`, as used by
+// aldi/backbone.py:21-43 (checkpointed_vit_forward) -- detectron2 itself is not vendored in the reference tree; the
+// behaviour is pinned in tests against transformers' VitDetAttention (same algorithm, installed in the image).
+//
+//   attn[q,k] = (scale*q).k + q.Rh[qh-kh+gh-1] + q.Rw[qw-kw+gw-1];   out = softmax(attn) v
+//
+// The bias is decomposed, so it folds into the QK^T product: Q' = [scale*q | q.Rh[..kh..] | q.Rw[..kw..]] (64+gh+gw wide,
+// padded to a multiple of 32) against K' = [k | onehot(kh) | onehot(kw)] gives attn exactly in the fp32 MFMA accumulator,
+// and in the backward pass dS.K' returns the bias gradients as extra columns of dQ' without any segmented reduction.
+//
+// Layouts (per attention "batch" bh = b*heads + h; L tokens of a gh x gw grid; Lp = L rounded up to 64):
+//   Qp, Kp  [BH][L][Dq] bf16      KpT [BH][Dq][Lp]      VT, QsT, dOT [BH][64][Lp]      (transposes are zero-padded to Lp)
+//   O, dO   [nB*L][heads*64]      qkv, dqkv [nB*L][3*heads*64]   (q | k | v, head-major inside each third)
+//
+// MFMA convention (v_mfma_f32_16x16x32_bf16): D[i][j] = sum_k A[i][k] B[j][k]; lane l holds A row / B column l%16 with
+// k = 8*(l/16)..+7, and D column l%16, rows 4*(l/16)..+3.  Scores are produced TRANSPOSED (keys = rows) so that a lane
+// owns one query column: the softmax statistics are per-lane scalars, and the probabilities are already in B-operand
+// position for the P.V product (the k order inside a 32-key step is permuted consistently on the V^T side).
+#include "common.h"
+
+namespace {
+
+typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
+
+constexpr int HD = 64;          // head dim
+constexpr int TROW = 72;        // LDS row (elements) of a [.][64] bf16 tile: 144 B = 9 x 16 B (odd => conflict-free b128 reads)
+
+__device__ __forceinline__ f32x4_t mma(u32x4_t a, u32x4_t b, f32x4_t c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+}
+__device__ __forceinline__ u32x4_t ld16(const bf16_t* p) { return *reinterpret_cast<const u32x4_t*>(p); }
+__device__ __forceinline__ u32x4_t zero16() { u32x4_t z = {0u, 0u, 0u, 0u}; return z; }
+// A-operand fragment whose 8 k-slots are {c0..c0+3} and {c0+16..c0+19} of an LDS row (the permuted 32-step)
+__device__ __forceinline__ u32x4_t ld_perm(const bf16_t* row, int c0) {
+    u32x2_t lo = *reinterpret_cast<const u32x2_t*>(row + c0);
+    u32x2_t hi = *reinterpret_cast<const u32x2_t*>(row + c0 + 16);
+    u32x4_t v = {lo.x, lo.y, hi.x, hi.y};
+    return v;
+}
+// two accumulator blocks (rows 4g..4g+3 of 16-row blocks 2s and 2s+1) -> one B-operand fragment in the permuted order
+__device__ __forceinline__ u32x4_t pack_perm(f32x4_t a, f32x4_t b) {
+    u32x4_t v = {pack2_bf16(a[0], a[1]), pack2_bf16(a[2], a[3]), pack2_bf16(b[0], b[1]), pack2_bf16(b[2], b[3])};
+    return v;
+}
+
+// cooperative copy of `rows` x `cols` bf16 (cols % 8 == 0) into an LDS tile; rows >= valid_rows are zero-filled
+__device__ __forceinline__ void tile_load(bf16_t* dst, int dst_row, const bf16_t* src, long src_row, int rows, int valid_rows, int cols,
+                                          int nthreads) {
+    const int cpr = cols >> 3;
+    for (int id = threadIdx.x; id < rows * cpr; id += nthreads) {
+        const int r = id / cpr, ch = id - r * cpr;
+        u32x4_t v = r < valid_rows ? ld16(src + (long)r * src_row + ch * 8) : zero16();
+        *reinterpret_cast<u32x4_t*>(dst + r * dst_row + ch * 8) = v;
+    }
+}
+
+struct AttnDev {
+    const bf16_t *qkv, *Qp, *Kp, *KpT, *VT, *QsT, *dOT, *O, *dO;
+    bf16_t *Ow, *dQp, *dqkv;
+    float *lse; const float* lse_r; const float* delta;
+    int nB, L, Lp, heads, Dq;
+};
+
+// ------------------------------------------------------------------------------------------------ forward
+template <int NKS, int NW>
+__global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(AttnDev a) {
+    constexpr int DQ = NKS * 32, KROW = DQ + 8;
+    extern __shared__ __align__(16) unsigned char smem[];
+    bf16_t* Ks = reinterpret_cast<bf16_t*>(smem);            // [64 keys][KROW]
+    bf16_t* Vs = Ks + 64 * KROW;                              // [64 d][TROW]  (V^T tile)
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = lane & 15, g = lane >> 4;
+    const int bh = blockIdx.y, b = bh / a.heads, h = bh - b * a.heads;
+    const int L = a.L, q0 = blockIdx.x * (NW * 32) + wave * 32;
+
+    u32x4_t qf[2][NKS];
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) {
+        const int q = q0 + 16 * qb + c;
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks)
+            qf[qb][ks] = q < L ? ld16(a.Qp + ((long)bh * L + q) * DQ + ks * 32 + g * 8) : zero16();
+    }
+    f32x4_t o[4][2];
+    float m[2], ls[2];
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) {
+        m[qb] = -INFINITY; ls[qb] = 0.f;
+#pragma unroll
+        for (int db = 0; db < 4; ++db) o[db][qb] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    }
+    const int nkt = a.Lp >> 6;
+    for (int kt = 0; kt < nkt; ++kt) {
+        __syncthreads();
+        tile_load(Ks, KROW, a.Kp + ((long)bh * L + kt * 64) * DQ, DQ, 64, L - kt * 64, DQ, NW * 64);
+        tile_load(Vs, TROW, a.VT + (long)bh * HD * a.Lp + kt * 64, a.Lp, 64, 64, 64, NW * 64);
+        __syncthreads();
+        f32x4_t st[4][2];
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+            for (int qb = 0; qb < 2; ++qb) st[kb][qb] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks)
+#pragma unroll
+            for (int kb = 0; kb < 4; ++kb) {
+                const u32x4_t kf = ld16(Ks + (16 * kb + c) * KROW + ks * 32 + g * 8);
+#pragma unroll
+                for (int qb = 0; qb < 2; ++qb) st[kb][qb] = mma(kf, qf[qb][ks], st[kb][qb]);
+            }
+        if (kt == nkt - 1) {
+#pragma unroll
+            for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    if (kt * 64 + 16 * kb + 4 * g + i >= L) { st[kb][0][i] = -INFINITY; st[kb][1][i] = -INFINITY; }
+        }
+        u32x4_t pf[2][2];
+#pragma unroll
+        for (int qb = 0; qb < 2; ++qb) {
+            float mx = -INFINITY;
+#pragma unroll
+            for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) mx = fmaxf(mx, st[kb][qb][i]);
+            mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            const float mn = fmaxf(m[qb], mx);
+            const float alpha = __expf(m[qb] - mn);      // first tile: exp(-inf) = 0
+            m[qb] = mn;
+            float s = 0.f;
+#pragma unroll
+            for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float p = __expf(st[kb][qb][i] - mn);
+                    st[kb][qb][i] = p;
+                    s += p;
+                }
+            ls[qb] = ls[qb] * alpha + s;
+#pragma unroll
+            for (int db = 0; db < 4; ++db)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) o[db][qb][i] *= alpha;
+            pf[qb][0] = pack_perm(st[0][qb], st[1][qb]);
+            pf[qb][1] = pack_perm(st[2][qb], st[3][qb]);
+        }
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+            for (int db = 0; db < 4; ++db) {
+                const u32x4_t vf = ld_perm(Vs + (16 * db + c) * TROW, 32 * s2 + 4 * g);
+#pragma unroll
+                for (int qb = 0; qb < 2; ++qb) o[db][qb] = mma(vf, pf[qb][s2], o[db][qb]);
+            }
+    }
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) {
+        float l = ls[qb];
+        l += __shfl_xor(l, 16, 64);
+        l += __shfl_xor(l, 32, 64);
+        const int q = q0 + 16 * qb + c;
+        if (q < L) {
+            const float inv = 1.f / l;
+            bf16_t* orow = a.Ow + ((long)b * L + q) * (a.heads * HD) + h * HD;
+#pragma unroll
+            for (int db = 0; db < 4; ++db) {
+                uint2 t;
+                t.x = pack2_bf16(o[db][qb][0] * inv, o[db][qb][1] * inv);
+                t.y = pack2_bf16(o[db][qb][2] * inv, o[db][qb][3] * inv);
+                *reinterpret_cast<uint2*>(orow + 16 * db + 4 * g) = t;
+            }
+            if (g == 0) a.lse[(long)bh * L + q] = m[qb] + __logf(l);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ backward: dQ'
+// one block owns NW*32 queries and sweeps the key tiles: dQ'^T[d'][q] += K'^T[d'][keys] . dS[q][keys]
+template <int NKS, int NW>
+__global__ __launch_bounds__(NW * 64) void attn_bwd_dq_kernel(AttnDev a) {
+    constexpr int DQ = NKS * 32, KROW = DQ + 8;
+    extern __shared__ __align__(16) unsigned char smem[];
+    bf16_t* Ks = reinterpret_cast<bf16_t*>(smem);            // [64 keys][KROW]
+    bf16_t* KTs = Ks + 64 * KROW;                             // [DQ][TROW]      (K'^T tile)
+    bf16_t* Vs = KTs + DQ * TROW;                             // [64 keys][TROW] (V rows)
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = lane & 15, g = lane >> 4;
+    const int bh = blockIdx.y, b = bh / a.heads, h = bh - b * a.heads;
+    const int L = a.L, q0 = blockIdx.x * (NW * 32) + wave * 32, ld3 = 3 * a.heads * HD, ld1 = a.heads * HD;
+
+    u32x4_t qf[2][NKS], dof[2][2];
+    float lse[2], dl[2];
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) {
+        const int q = q0 + 16 * qb + c;
+        const bool ok = q < L;
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) qf[qb][ks] = ok ? ld16(a.Qp + ((long)bh * L + q) * DQ + ks * 32 + g * 8) : zero16();
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) dof[qb][ks] = ok ? ld16(a.dO + ((long)b * L + q) * ld1 + h * HD + ks * 32 + g * 8) : zero16();
+        lse[qb] = ok ? a.lse_r[(long)bh * L + q] : INFINITY;
+        dl[qb] = ok ? a.delta[(long)bh * L + q] : 0.f;
+    }
+    f32x4_t dq[2 * NKS][2];
+#pragma unroll
+    for (int i = 0; i < 2 * NKS; ++i) { dq[i][0] = f32x4_t{0.f, 0.f, 0.f, 0.f}; dq[i][1] = f32x4_t{0.f, 0.f, 0.f, 0.f}; }
+
+    const int nkt = a.Lp >> 6;
+    for (int kt = 0; kt < nkt; ++kt) {
+        __syncthreads();
+        tile_load(Ks, KROW, a.Kp + ((long)bh * L + kt * 64) * DQ, DQ, 64, L - kt * 64, DQ, NW * 64);
+        tile_load(KTs, TROW, a.KpT + (long)bh * DQ * a.Lp + kt * 64, a.Lp, DQ, DQ, 64, NW * 64);
+        tile_load(Vs, TROW, a.qkv + ((long)b * L + kt * 64) * ld3 + 2 * ld1 + h * HD, ld3, 64, L - kt * 64, 64, NW * 64);
+        __syncthreads();
+        f32x4_t st[4][2], dp[4][2];
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+            for (int qb = 0; qb < 2; ++qb) { st[kb][qb] = f32x4_t{0.f, 0.f, 0.f, 0.f}; dp[kb][qb] = f32x4_t{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks)
+#pragma unroll
+            for (int kb = 0; kb < 4; ++kb) {
+                const u32x4_t kf = ld16(Ks + (16 * kb + c) * KROW + ks * 32 + g * 8);
+#pragma unroll
+                for (int qb = 0; qb < 2; ++qb) st[kb][qb] = mma(kf, qf[qb][ks], st[kb][qb]);
+            }
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int kb = 0; kb < 4; ++kb) {
+                const u32x4_t vf = ld16(Vs + (16 * kb + c) * TROW + ks * 32 + g * 8);
+#pragma unroll
+                for (int qb = 0; qb < 2; ++qb) dp[kb][qb] = mma(vf, dof[qb][ks], dp[kb][qb]);
+            }
+        u32x4_t dsf[2][2];
+#pragma unroll
+        for (int qb = 0; qb < 2; ++qb) {
+#pragma unroll
+            for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const bool valid = kt * 64 + 16 * kb + 4 * g + i < L;
+                    const float p = valid ? __expf(st[kb][qb][i] - lse[qb]) : 0.f;
+                    st[kb][qb][i] = p * (dp[kb][qb][i] - dl[qb]);
+                }
+            dsf[qb][0] = pack_perm(st[0][qb], st[1][qb]);
+            dsf[qb][1] = pack_perm(st[2][qb], st[3][qb]);
+        }
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+            for (int db = 0; db < 2 * NKS; ++db) {
+                const u32x4_t kt_f = ld_perm(KTs + (16 * db + c) * TROW, 32 * s2 + 4 * g);
+#pragma unroll
+                for (int qb = 0; qb < 2; ++qb) dq[db][qb] = mma(kt_f, dsf[qb][s2], dq[db][qb]);
+            }
+    }
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) {
+        const int q = q0 + 16 * qb + c;
+        if (q < L) {
+            bf16_t* row = a.dQp + ((long)bh * L + q) * DQ;
+#pragma unroll
+            for (int db = 0; db < 2 * NKS; ++db) {
+                uint2 t;
+                t.x = pack2_bf16(dq[db][qb][0], dq[db][qb][1]);
+                t.y = pack2_bf16(dq[db][qb][2], dq[db][qb][3]);
+                *reinterpret_cast<uint2*>(row + 16 * db + 4 * g) = t;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ backward: dK, dV
+// one block owns 128 keys (32 per wave) and sweeps the query tiles:
+//   dV^T[d][key] += dO^T[d][q] . P[q][key]        dK^T[d][key] += (scale*q)^T[d][q] . dS[q][key]
+template <int NKS>
+__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnDev a) {
+    constexpr int DQ = NKS * 32, KROW = DQ + 8;
+    extern __shared__ __align__(16) unsigned char smem[];
+    bf16_t* Qs = reinterpret_cast<bf16_t*>(smem);            // [64 q][KROW]
+    bf16_t* dOs = Qs + 64 * KROW;                             // [64 q][TROW]
+    bf16_t* QTs = dOs + 64 * TROW;                            // [64 d][TROW]  ((scale*q)^T tile)
+    bf16_t* dOTs = QTs + 64 * TROW;                           // [64 d][TROW]
+    float* lse_s = reinterpret_cast<float*>(dOTs + 64 * TROW);   // [64]
+    float* dl_s = lse_s + 64;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = lane & 15, g = lane >> 4;
+    const int bh = blockIdx.y, b = bh / a.heads, h = bh - b * a.heads;
+    const int L = a.L, k0 = blockIdx.x * 128 + wave * 32, ld3 = 3 * a.heads * HD, ld1 = a.heads * HD;
+
+    u32x4_t kf[2][NKS], vf[2][2];
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+        const int key = k0 + 16 * kb + c;
+        const bool ok = key < L;
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) kf[kb][ks] = ok ? ld16(a.Kp + ((long)bh * L + key) * DQ + ks * 32 + g * 8) : zero16();
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+            vf[kb][ks] = ok ? ld16(a.qkv + ((long)b * L + key) * ld3 + 2 * ld1 + h * HD + ks * 32 + g * 8) : zero16();
+    }
+    f32x4_t dv[4][2], dk[4][2];
+#pragma unroll
+    for (int db = 0; db < 4; ++db)
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) { dv[db][kb] = f32x4_t{0.f, 0.f, 0.f, 0.f}; dk[db][kb] = f32x4_t{0.f, 0.f, 0.f, 0.f}; }
+
+    const int nqt = a.Lp >> 6;
+    for (int qt = 0; qt < nqt; ++qt) {
+        __syncthreads();
+        tile_load(Qs, KROW, a.Qp + ((long)bh * L + qt * 64) * DQ, DQ, 64, L - qt * 64, DQ, 256);
+        tile_load(dOs, TROW, a.dO + ((long)b * L + qt * 64) * ld1 + h * HD, ld1, 64, L - qt * 64, 64, 256);
+        tile_load(QTs, TROW, a.QsT + (long)bh * HD * a.Lp + qt * 64, a.Lp, 64, 64, 64, 256);
+        tile_load(dOTs, TROW, a.dOT + (long)bh * HD * a.Lp + qt * 64, a.Lp, 64, 64, 64, 256);
+        if (threadIdx.x < 64) {
+            const int q = qt * 64 + threadIdx.x;
+            lse_s[threadIdx.x] = q < L ? a.lse_r[(long)bh * L + q] : INFINITY;
+            dl_s[threadIdx.x] = q < L ? a.delta[(long)bh * L + q] : 0.f;
+        }
+        __syncthreads();
+        f32x4_t s[4][2], dp[4][2];
+#pragma unroll
+        for (int qb = 0; qb < 4; ++qb)
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) { s[qb][kb] = f32x4_t{0.f, 0.f, 0.f, 0.f}; dp[qb][kb] = f32x4_t{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks)
+#pragma unroll
+            for (int qb = 0; qb < 4; ++qb) {
+                const u32x4_t qfr = ld16(Qs + (16 * qb + c) * KROW + ks * 32 + g * 8);
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb) s[qb][kb] = mma(qfr, kf[kb][ks], s[qb][kb]);
+            }
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int qb = 0; qb < 4; ++qb) {
+                const u32x4_t dofr = ld16(dOs + (16 * qb + c) * TROW + ks * 32 + g * 8);
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb) dp[qb][kb] = mma(dofr, vf[kb][ks], dp[qb][kb]);
+            }
+        u32x4_t pf[2][2], dsf[2][2];
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+            for (int qb = 0; qb < 4; ++qb) {
+                const f32x4_t l4 = *reinterpret_cast<const f32x4_t*>(lse_s + 16 * qb + 4 * g);
+                const f32x4_t d4 = *reinterpret_cast<const f32x4_t*>(dl_s + 16 * qb + 4 * g);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float p = __expf(s[qb][kb][i] - l4[i]);     // rows past L: lse = +inf => 0
+                    s[qb][kb][i] = p;
+                    dp[qb][kb][i] = p * (dp[qb][kb][i] - d4[i]);
+                }
+            }
+            pf[kb][0] = pack_perm(s[0][kb], s[1][kb]);
+            pf[kb][1] = pack_perm(s[2][kb], s[3][kb]);
+            dsf[kb][0] = pack_perm(dp[0][kb], dp[1][kb]);
+            dsf[kb][1] = pack_perm(dp[2][kb], dp[3][kb]);
+        }
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+            for (int db = 0; db < 4; ++db) {
+                const u32x4_t dot_f = ld_perm(dOTs + (16 * db + c) * TROW, 32 * s2 + 4 * g);
+                const u32x4_t qt_f = ld_perm(QTs + (16 * db + c) * TROW, 32 * s2 + 4 * g);
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb) {
+                    dv[db][kb] = mma(dot_f, pf[kb][s2], dv[db][kb]);
+                    dk[db][kb] = mma(qt_f, dsf[kb][s2], dk[db][kb]);
+                }
+            }
+    }
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+        const int key = k0 + 16 * kb + c;
+        if (key < L) {
+            bf16_t* row = a.dqkv + ((long)b * L + key) * ld3 + h * HD;
+#pragma unroll
+            for (int db = 0; db < 4; ++db) {
+                uint2 t;
+                t.x = pack2_bf16(dk[db][kb][0], dk[db][kb][1]);
+                t.y = pack2_bf16(dk[db][kb][2], dk[db][kb][3]);
+                *reinterpret_cast<uint2*>(row + ld1 + 16 * db + 4 * g) = t;
+                t.x = pack2_bf16(dv[db][kb][0], dv[db][kb][1]);
+                t.y = pack2_bf16(dv[db][kb][2], dv[db][kb][3]);
+                *reinterpret_cast<uint2*>(row + 2 * ld1 + 16 * db + 4 * g) = t;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ operand preparation
+// One block per (bh, 64-token tile): builds Q' / K' rows and the transposed copies the MFMA kernels stream.
+struct PrepDev {
+    const bf16_t* qkv; const float *rel_h, *rel_w;
+    bf16_t *Qp, *Kp, *KpT, *VT, *QsT;
+    int nB, L, Lp, heads, Dq, gh, gw; float scale;
+};
+constexpr int QROW = 65;    // fp32 LDS rows of 64 + 1: a column walk hits 64 different banks
+
+__global__ __launch_bounds__(256) void attn_prep_kernel(PrepDev a) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    float* qs = reinterpret_cast<float*>(smem);        // [64][QROW]  q (unscaled)
+    float* th = qs + 64 * QROW;                         // [2gh-1][QROW]
+    float* tw = th + (2 * a.gh - 1) * QROW;             // [2gw-1][QROW]
+    bf16_t* kv = reinterpret_cast<bf16_t*>(tw + (2 * a.gw - 1) * QROW);   // [2][64][64] raw k, v
+    bf16_t* qp = kv + 2 * 64 * 64;                                         // [64][Dq] finished Q' rows (for the transposes)
+    const int bh = blockIdx.y, b = bh / a.heads, h = bh - b * a.heads, t0 = blockIdx.x * 64;
+    const int L = a.L, Dq = a.Dq, gh = a.gh, gw = a.gw, ld3 = 3 * a.heads * HD, ld1 = a.heads * HD;
+    const int nrel = gh + gw;
+    for (int id = threadIdx.x; id < 64 * 64; id += 256) {
+        const int t = id >> 6, d = id & 63;
+        const bool ok = t0 + t < L;
+        const bf16_t* row = a.qkv + ((long)b * L + t0 + t) * ld3 + h * HD + d;
+        qs[t * QROW + d] = ok ? bf16_to_f32(row[0]) : 0.f;
+        kv[t * 64 + d] = ok ? row[ld1] : (bf16_t)0;
+        kv[64 * 64 + t * 64 + d] = ok ? row[2 * ld1] : (bf16_t)0;
+    }
+    if (a.rel_h) {
+        for (int id = threadIdx.x; id < (2 * gh - 1) * 64; id += 256) th[(id >> 6) * QROW + (id & 63)] = a.rel_h[id];
+        for (int id = threadIdx.x; id < (2 * gw - 1) * 64; id += 256) tw[(id >> 6) * QROW + (id & 63)] = a.rel_w[id];
+    }
+    __syncthreads();
+    // Q' rows into LDS (bf16)
+    for (int id = threadIdx.x; id < 64 * Dq; id += 256) {
+        const int e = id >> 6, t = id & 63;         // lanes walk tokens: the table row differs per lane, the column does not
+        const int tok = t0 + t;
+        float v = 0.f;
+        if (e < 64) v = qs[t * QROW + e] * a.scale;
+        else if (a.rel_h && e < 64 + nrel && tok < L) {
+            const int qh = tok / gw, qw = tok - qh * gw;
+            const float* tab = e < 64 + gh ? th + (qh - (e - 64) + gh - 1) * QROW : tw + (qw - (e - 64 - gh) + gw - 1) * QROW;
+            const float* qr = qs + t * QROW;
+            for (int d = 0; d < 64; ++d) v += qr[d] * tab[d];
+        }
+        qp[t * Dq + e] = f32_to_bf16(v);
+    }
+    __syncthreads();
+    // row-major outputs: Q' and K'
+    const int cpr = Dq >> 3;
+    for (int id = threadIdx.x; id < 64 * cpr; id += 256) {
+        const int t = id / cpr, ch = id - t * cpr, tok = t0 + t;
+        if (tok >= L) continue;
+        *reinterpret_cast<u32x4_t*>(a.Qp + ((long)bh * L + tok) * Dq + ch * 8) = *reinterpret_cast<const u32x4_t*>(qp + t * Dq + ch * 8);
+        u32x4_t kvv;
+        if (ch < 8) kvv = *reinterpret_cast<const u32x4_t*>(kv + t * 64 + ch * 8);
+        else {
+            const int kh = tok / gw, kw = tok - kh * gw;
+            const int hot_h = a.rel_h ? 64 + kh : -1, hot_w = a.rel_h ? 64 + gh + kw : -1, e0 = ch * 8;
+            unsigned wv[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const unsigned lo = (e0 + 2 * j == hot_h || e0 + 2 * j == hot_w) ? 0x3f80u : 0u;
+                const unsigned hi = (e0 + 2 * j + 1 == hot_h || e0 + 2 * j + 1 == hot_w) ? 0x3f80u : 0u;
+                wv[j] = lo | (hi << 16);
+            }
+            kvv = u32x4_t{wv[0], wv[1], wv[2], wv[3]};
+        }
+        *reinterpret_cast<u32x4_t*>(a.Kp + ((long)bh * L + tok) * Dq + ch * 8) = kvv;
+    }
+    // transposed outputs (8 tokens = 16 B per store): K'^T [Dq][Lp], V^T [64][Lp], (scale q)^T [64][Lp]
+    for (int id = threadIdx.x; id < (Dq + 128) * 8; id += 256) {
+        const int r = id >> 3, ch = id & 7;
+        unsigned short v[8];
+        bf16_t* dst;
+        if (r < Dq) {
+            dst = a.KpT + ((long)bh * Dq + r) * a.Lp + t0 + ch * 8;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int t = ch * 8 + j, tok = t0 + t;
+                if (r < 64) v[j] = kv[t * 64 + r];
+                else {
+                    const int kh = tok / gw, kw = tok - kh * gw;
+                    v[j] = (a.rel_h && tok < L && (r == 64 + kh || r == 64 + gh + kw)) ? 0x3f80 : 0;
+                }
+            }
+        } else if (r < Dq + 64) {
+            const int d = r - Dq;
+            dst = a.VT + ((long)bh * HD + d) * a.Lp + t0 + ch * 8;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = kv[64 * 64 + (ch * 8 + j) * 64 + d];
+        } else {
+            const int d = r - Dq - 64;
+            dst = a.QsT + ((long)bh * HD + d) * a.Lp + t0 + ch * 8;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = qp[(ch * 8 + j) * Dq + d];
+        }
+        u32x4_t o = {v[0] | ((unsigned)v[1] << 16), v[2] | ((unsigned)v[3] << 16), v[4] | ((unsigned)v[5] << 16), v[6] | ((unsigned)v[7] << 16)};
+        *reinterpret_cast<u32x4_t*>(dst) = o;
+    }
+}
+
+// delta[q] = sum_d O.dO and dO^T, one block per (bh, 64-token tile)
+struct BprepDev { const bf16_t *O, *dO; bf16_t* dOT; float* delta; int nB, L, Lp, heads; };
+__global__ __launch_bounds__(256) void attn_bwd_prep_kernel(BprepDev a) {
+    __shared__ bf16_t dos[64 * 66];
+    const int bh = blockIdx.y, b = bh / a.heads, h = bh - b * a.heads, t0 = blockIdx.x * 64, ld1 = a.heads * HD;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int t = wave; t < 64; t += 4) {
+        const int tok = t0 + t;
+        float p = 0.f;
+        bf16_t dv = 0;
+        if (tok < a.L) {
+            const long off = ((long)b * a.L + tok) * ld1 + h * HD + lane;
+            dv = a.dO[off];
+            p = bf16_to_f32(dv) * bf16_to_f32(a.O[off]);
+        }
+        dos[t * 66 + lane] = dv;
+        p = warp_sum(p);
+        if (lane == 0 && tok < a.L) a.delta[(long)bh * a.L + tok] = p;
+    }
+    __syncthreads();
+    for (int id = threadIdx.x; id < 64 * 8; id += 256) {
+        const int d = id >> 3, ch = id & 7;
+        unsigned short v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = dos[(ch * 8 + j) * 66 + d];
+        u32x4_t o = {v[0] | ((unsigned)v[1] << 16), v[2] | ((unsigned)v[3] << 16), v[4] | ((unsigned)v[5] << 16), v[6] | ((unsigned)v[7] << 16)};
+        *reinterpret_cast<u32x4_t*>(a.dOT + ((long)bh * HD + d) * a.Lp + t0 + ch * 8) = o;
+    }
+}
+
+// dQ' -> dq (the q slot of dqkv):  dq[t] = scale * dQ'[t][:64] + sum_e dQ'[t][64+e] * table_row(t, e).  One block per (bh, tile).
+struct RbwdDev {
+    const bf16_t *qkv, *dQp; const float *rel_h, *rel_w;
+    bf16_t* dqkv; float *drel_h, *drel_w;
+    int nB, L, heads, Dq, gh, gw, tiles_per_block; float scale;
+};
+
+__global__ __launch_bounds__(256) void attn_rel_dq_kernel(RbwdDev a) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    float* th = reinterpret_cast<float*>(smem);
+    float* tw = th + (2 * a.gh - 1) * QROW;
+    float* dr = tw + (2 * a.gw - 1) * QROW;             // [64][nrel+1] rel columns of dQ'
+    const int bh = blockIdx.y, b = bh / a.heads, h = bh - b * a.heads, t0 = blockIdx.x * 64;
+    const int L = a.L, Dq = a.Dq, gh = a.gh, gw = a.gw, ld3 = 3 * a.heads * HD, nrel = gh + gw, DR = nrel + 1;
+    const bool rel = a.rel_h != nullptr;
+    if (rel) {
+        for (int id = threadIdx.x; id < (2 * gh - 1) * 64; id += 256) th[(id >> 6) * QROW + (id & 63)] = a.rel_h[id];
+        for (int id = threadIdx.x; id < (2 * gw - 1) * 64; id += 256) tw[(id >> 6) * QROW + (id & 63)] = a.rel_w[id];
+        for (int id = threadIdx.x; id < 64 * nrel; id += 256) {
+            const int t = id / nrel, e = id - t * nrel;
+            dr[t * DR + e] = t0 + t < L ? bf16_to_f32(a.dQp[((long)bh * L + t0 + t) * Dq + 64 + e]) : 0.f;
+        }
+    }
+    __syncthreads();
+    for (int id = threadIdx.x; id < 64 * 64; id += 256) {
+        const int t = id >> 6, d = id & 63, tok = t0 + t;
+        if (tok >= L) continue;
+        float v = a.scale * bf16_to_f32(a.dQp[((long)bh * L + tok) * Dq + d]);
+        if (rel) {
+            const int qh = tok / gw, qw = tok - qh * gw;
+            const float* drr = dr + t * DR;
+            for (int kh = 0; kh < gh; ++kh) v += drr[kh] * th[(qh - kh + gh - 1) * QROW + d];
+            for (int kw = 0; kw < gw; ++kw) v += drr[gh + kw] * tw[(qw - kw + gw - 1) * QROW + d];
+        }
+        a.dqkv[((long)b * L + tok) * ld3 + h * HD + d] = f32_to_bf16(v);
+    }
+}
+
+// table gradients: row r of d(rel_h) collects q[t] * dQ'[t][64+kh] over (t, kh) with qh(t) - kh + gh - 1 == r (same for w).
+// One block per (bh, group of tiles); thread (r mod 4, column) owns its accumulators in LDS, one atomic per entry per block.
+__global__ __launch_bounds__(256) void attn_rel_dtab_kernel(RbwdDev a) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    float* qs = reinterpret_cast<float*>(smem);        // [64][QROW] q
+    float* dr = qs + 64 * QROW;                         // [64][nrel+1]
+    const int gh = a.gh, gw = a.gw, nrel = gh + gw, DR = nrel + 1, nrows = (2 * gh - 1) + (2 * gw - 1);
+    float* acc = dr + 64 * DR;                          // [nrows][64]
+    const int bh = blockIdx.y, b = bh / a.heads, h = bh - b * a.heads;
+    const int L = a.L, Dq = a.Dq, ld3 = 3 * a.heads * HD;
+    const int cc = threadIdx.x & 63, r0 = threadIdx.x >> 6;
+    for (int r = r0; r < nrows; r += 4) acc[r * 64 + cc] = 0.f;
+    const int ntiles = (L + 63) >> 6;
+    for (int ti = 0; ti < a.tiles_per_block; ++ti) {
+        const int tile = blockIdx.x * a.tiles_per_block + ti;
+        if (tile >= ntiles) break;
+        const int t0 = tile * 64, nt = min(64, L - t0);
+        __syncthreads();
+        for (int id = threadIdx.x; id < 64 * 64; id += 256) {
+            const int t = id >> 6, d = id & 63;
+            qs[t * QROW + d] = t < nt ? bf16_to_f32(a.qkv[((long)b * L + t0 + t) * ld3 + h * HD + d]) : 0.f;
+        }
+        for (int id = threadIdx.x; id < 64 * nrel; id += 256) {
+            const int t = id / nrel, e = id - t * nrel;
+            dr[t * DR + e] = t < nt ? bf16_to_f32(a.dQp[((long)bh * L + t0 + t) * Dq + 64 + e]) : 0.f;
+        }
+        __syncthreads();
+        const int qh0 = t0 / gw, qw0 = t0 - qh0 * gw;
+        for (int r = r0; r < nrows; r += 4) {
+            const bool is_h = r < 2 * gh - 1;
+            const int rr = is_h ? r : r - (2 * gh - 1);
+            float s = 0.f;
+            int qh = qh0, qw = qw0;
+            for (int t = 0; t < nt; ++t) {
+                const int k = is_h ? qh + gh - 1 - rr : qw + gw - 1 - rr;
+                if (k >= 0 && k < (is_h ? gh : gw)) s += dr[t * DR + (is_h ? k : gh + k)] * qs[t * QROW + cc];
+                if (++qw == gw) { qw = 0; ++qh; }
+            }
+            acc[r * 64 + cc] += s;
+        }
+    }
+    for (int r = r0; r < nrows; r += 4) {
+        if (r < 2 * gh - 1) atomicAdd(a.drel_h + r * 64 + cc, acc[r * 64 + cc]);
+        else atomicAdd(a.drel_w + (r - (2 * gh - 1)) * 64 + cc, acc[r * 64 + cc]);
+    }
+}
+
+template <typename K>
+int set_lds(K kernel, size_t bytes) {
+    if (bytes > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+        if (e != hipSuccess) return aldi_set_error(e, __FILE__, __LINE__);
+    }
+    return ALDI_OK;
+}
+
+AttnDev to_dev(const aldi_attn_args* p) {
+    AttnDev a{};
+    a.qkv = (const bf16_t*)p->qkv; a.Qp = (const bf16_t*)p->Qp; a.Kp = (const bf16_t*)p->Kp; a.KpT = (const bf16_t*)p->KpT;
+    a.VT = (const bf16_t*)p->VT; a.QsT = (const bf16_t*)p->QsT; a.dOT = (const bf16_t*)p->dOT; a.O = (const bf16_t*)p->O;
+    a.dO = (const bf16_t*)p->dO; a.Ow = (bf16_t*)p->O; a.dQp = (bf16_t*)p->dQp; a.dqkv = (bf16_t*)p->dqkv;
+    a.lse = p->lse; a.lse_r = p->lse; a.delta = p->delta;
+    a.nB = p->nB; a.L = p->gh * p->gw; a.Lp = (a.L + 63) / 64 * 64; a.heads = p->heads; a.Dq = p->Dq;
+    return a;
+}
+
+int check_args(const aldi_attn_args* p) {
+    if (!p || p->nB <= 0 || p->gh <= 0 || p->gw <= 0 || p->heads <= 0) return aldi_set_error_msg(ALDI_ERR_ARG, "attn: bad sizes");
+    const int need = p->rel_h ? 64 + p->gh + p->gw : 64;
+    if (p->Dq % 32 || p->Dq < need || p->Dq > 256) return aldi_set_error_msg(ALDI_ERR_ARG, "attn: Dq must be a multiple of 32 in [64+gh+gw, 256]");
+    if ((p->rel_h == nullptr) != (p->rel_w == nullptr)) return aldi_set_error_msg(ALDI_ERR_ARG, "attn: rel_h and rel_w go together");
+    return ALDI_OK;
+}
+
+template <int NKS>
+int launch_fwd(const AttnDev& a, hipStream_t st) {
+    constexpr int DQ = NKS * 32;
+    const size_t lds = (size_t)(64 * (DQ + 8) + 64 * TROW) * 2;
+    if (a.L <= 7 * 32) {        // a whole window in one block: K/V tiles are read once
+        if (int e = set_lds(attn_fwd_kernel<NKS, 7>, lds)) return e;
+        hipLaunchKernelGGL((attn_fwd_kernel<NKS, 7>), dim3(1, a.nB * a.heads), dim3(7 * 64), lds, st, a);
+    } else {
+        if (int e = set_lds(attn_fwd_kernel<NKS, 4>, lds)) return e;
+        hipLaunchKernelGGL((attn_fwd_kernel<NKS, 4>), dim3(cdiv(a.L, 128), a.nB * a.heads), dim3(256), lds, st, a);
+    }
+    ALDI_CHECK_LAUNCH();
+    return ALDI_OK;
+}
+template <int NKS>
+int launch_bwd(const AttnDev& a, hipStream_t st) {
+    constexpr int DQ = NKS * 32;
+    const size_t lds_q = (size_t)(64 * (DQ + 8) + DQ * TROW + 64 * TROW) * 2;
+    const size_t lds_kv = (size_t)(64 * (DQ + 8) + 3 * 64 * TROW) * 2 + 128 * 4;
+    if (a.L <= 7 * 32) {
+        if (int e = set_lds(attn_bwd_dq_kernel<NKS, 7>, lds_q)) return e;
+        hipLaunchKernelGGL((attn_bwd_dq_kernel<NKS, 7>), dim3(1, a.nB * a.heads), dim3(7 * 64), lds_q, st, a);
+    } else {
+        if (int e = set_lds(attn_bwd_dq_kernel<NKS, 4>, lds_q)) return e;
+        hipLaunchKernelGGL((attn_bwd_dq_kernel<NKS, 4>), dim3(cdiv(a.L, 128), a.nB * a.heads), dim3(256), lds_q, st, a);
+    }
+    ALDI_CHECK_LAUNCH();
+    if (int e = set_lds(attn_bwd_dkv_kernel<NKS>, lds_kv)) return e;
+    hipLaunchKernelGGL((attn_bwd_dkv_kernel<NKS>), dim3(cdiv(a.L, 128), a.nB * a.heads), dim3(256), lds_kv, st, a);
+    ALDI_CHECK_LAUNCH();
+    return ALDI_OK;
+}
+
+#define ATTN_DISPATCH(fn, a, st)                                           \
+    switch ((a).Dq / 32) {                                                 \
+        case 2: return fn<2>(a, st);                                       \
+        case 3: return fn<3>(a, st);                                       \
+        case 4: return fn<4>(a, st);                                       \
+        case 5: return fn<5>(a, st);                                       \
+        case 6: return fn<6>(a, st);                                       \
+        case 7: return fn<7>(a, st);                                       \
+        case 8: return fn<8>(a, st);                                       \
+        default: return aldi_set_error_msg(ALDI_ERR_ARG, "attn: unsupported Dq"); \
+    }
+
+int dispatch_fwd(const AttnDev& a, hipStream_t st) { ATTN_DISPATCH(launch_fwd, a, st) }
+int dispatch_bwd(const AttnDev& a, hipStream_t st) { ATTN_DISPATCH(launch_bwd, a, st) }
+
+}  // namespace
+
+extern "C" int aldi_attn_prepare(const aldi_attn_args* p, aldi_stream_t stream) {
+    if (int e = check_args(p)) return e;
+    PrepDev a{};
+    a.qkv = (const bf16_t*)p->qkv; a.rel_h = p->rel_h; a.rel_w = p->rel_w;
+    a.Qp = (bf16_t*)p->Qp; a.Kp = (bf16_t*)p->Kp; a.KpT = (bf16_t*)p->KpT; a.VT = (bf16_t*)p->VT; a.QsT = (bf16_t*)p->QsT;
+    a.nB = p->nB; a.L = p->gh * p->gw; a.Lp = (a.L + 63) / 64 * 64; a.heads = p->heads; a.Dq = p->Dq; a.gh = p->gh; a.gw = p->gw;
+    a.scale = p->scale;
+    const size_t lds = (size_t)(64 + 2 * p->gh - 1 + 2 * p->gw - 1) * QROW * 4 + (size_t)(2 * 64 * 64 + 64 * p->Dq) * 2;
+    if (int e = set_lds(attn_prep_kernel, lds)) return e;
+    hipLaunchKernelGGL(attn_prep_kernel, dim3(a.Lp / 64, a.nB * a.heads), dim3(256), lds, (hipStream_t)stream, a);
+    ALDI_CHECK_LAUNCH();
+    return ALDI_OK;
+}
+
+extern "C" int aldi_attn_forward(const aldi_attn_args* p, aldi_stream_t stream) {
+    if (int e = check_args(p)) return e;
+    return dispatch_fwd(to_dev(p), (hipStream_t)stream);
+}
+
+extern "C" int aldi_attn_backward(const aldi_attn_args* p, aldi_stream_t stream) {
+    if (int e = check_args(p)) return e;
+    if (p->rel_h && (!p->drel_h || !p->drel_w)) return aldi_set_error_msg(ALDI_ERR_ARG, "attn: drel_h / drel_w missing");
+    hipStream_t st = (hipStream_t)stream;
+    AttnDev a = to_dev(p);
+    BprepDev bp{a.O, a.dO, (bf16_t*)p->dOT, p->delta, a.nB, a.L, a.Lp, a.heads};
+    hipLaunchKernelGGL(attn_bwd_prep_kernel, dim3(a.Lp / 64, a.nB * a.heads), dim3(256), 0, st, bp);
+    ALDI_CHECK_LAUNCH();
+    if (int e = dispatch_bwd(a, st)) return e;
+    RbwdDev r{};
+    r.qkv = a.qkv; r.dQp = a.dQp; r.rel_h = p->rel_h; r.rel_w = p->rel_w; r.dqkv = a.dqkv; r.drel_h = p->drel_h; r.drel_w = p->drel_w;
+    r.nB = a.nB; r.L = a.L; r.heads = a.heads; r.Dq = a.Dq; r.gh = p->gh; r.gw = p->gw; r.scale = p->scale;
+    const int ntiles = a.Lp / 64, nrel = p->gh + p->gw, ntab = 2 * p->gh - 1 + 2 * p->gw - 1;
+    r.tiles_per_block = ntiles > 8 ? 8 : ntiles;
+    const size_t lds_q = (size_t)ntab * QROW * 4 + (size_t)64 * (nrel + 1) * 4;
+    if (int e = set_lds(attn_rel_dq_kernel, lds_q)) return e;
+    hipLaunchKernelGGL(attn_rel_dq_kernel, dim3(ntiles, a.nB * a.heads), dim3(256), lds_q, st, r);
+    ALDI_CHECK_LAUNCH();
+    if (p->rel_h) {
+        const size_t lds_t = (size_t)64 * QROW * 4 + (size_t)64 * (nrel + 1) * 4 + (size_t)ntab * 64 * 4;
+        if (int e = set_lds(attn_rel_dtab_kernel, lds_t)) return e;
+        hipLaunchKernelGGL(attn_rel_dtab_kernel, dim3(cdiv(ntiles, r.tiles_per_block), a.nB * a.heads), dim3(256), lds_t, st, r);
+        ALDI_CHECK_LAUNCH();
+    }
+    return ALDI_OK;
+}

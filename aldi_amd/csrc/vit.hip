@@ -1,0 +1,490 @@
+// Token-wise kernels of the ViTDet trunk (gfx950): LayerNorm fwd/bwd with window (un)partition folded into the row map,
+// exact GELU fwd/bwd, row gather-add (residuals, drop-path scale, window un-partition), patch extraction, table / grid
+// resampling (relative and absolute position embeddings) and AdamW.  All of them are HBM-bound: 16-B accesses, one pass.
+//
+// Reference semantics: detectron2 `modeling/backbone/vit.py` (Block / ViT), `backbone/utils.py` (window_partition,
+// get_rel_pos, get_abs_pos) as driven by aldi/backbone.py:21-43; optimizer aldi/backbone.py:66-84 (AdamW, D2 common/optim.py).
+#include "common.h"
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------ LayerNorm
+// One wave per output row.  `map` (nullable) gathers: output row r normalises source row map[r]; map[r] < 0 is a padding
+// row of a partitioned window and is written as zeros (detectron2 pads AFTER norm1, so the padded tokens are exact zeros).
+constexpr int LN_MAXCH = 4;     // C <= 1024, C % 4 == 0; lane chunk j (4 channels at (lane + 64 j) * 4) is live iff inside C
+
+template <typename T>
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, const int* __restrict__ map, const float* __restrict__ gamma,
+                                                      const float* __restrict__ beta, T* __restrict__ y, float* __restrict__ mean,
+                                                      float* __restrict__ rstd, int rows, int C, float eps) {
+    const int lane = threadIdx.x & 63, r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= rows) return;
+    const long src = map ? map[r] : r;
+    T* yr = y + (long)r * C;
+    if (src < 0) {
+        const float z[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < LN_MAXCH; ++j) if ((lane + 64 * j) * 4 < C) store4(yr + (lane + 64 * j) * 4, z);
+        if (lane == 0) { mean[r] = 0.f; rstd[r] = 0.f; }
+        return;
+    }
+    const T* xr = x + src * C;
+    float v[LN_MAXCH][4];
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < LN_MAXCH; ++j)
+        if ((lane + 64 * j) * 4 < C) {
+            load4(xr + (lane + 64 * j) * 4, v[j]);
+            s += (v[j][0] + v[j][1]) + (v[j][2] + v[j][3]);
+        }
+    const float mu = warp_sum(s) / (float)C;
+    float q = 0.f;
+#pragma unroll
+    for (int j = 0; j < LN_MAXCH; ++j)
+        if ((lane + 64 * j) * 4 < C) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { v[j][i] -= mu; q += v[j][i] * v[j][i]; }
+        }
+    const float rs = rsqrtf(warp_sum(q) / (float)C + eps);
+#pragma unroll
+    for (int j = 0; j < LN_MAXCH; ++j)
+        if ((lane + 64 * j) * 4 < C) {
+            float gm[4], bt[4], o[4];
+            load4(gamma + (lane + 64 * j) * 4, gm);
+            load4(beta + (lane + 64 * j) * 4, bt);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) o[i] = v[j][i] * rs * gm[i] + bt[i];
+            store4(yr + (lane + 64 * j) * 4, o);
+        }
+    if (lane == 0) { mean[r] = mu; rstd[r] = rs; }
+}
+
+// dx[src] = rstd * (g*gamma - mean(g*gamma) - xhat * mean(g*gamma*xhat)) (+ res[src]);  dgamma += g*xhat, dbeta += g
+template <typename T>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ g, const T* __restrict__ x, const int* __restrict__ map,
+                                                      const float* __restrict__ gamma, const float* __restrict__ mean,
+                                                      const float* __restrict__ rstd, const T* __restrict__ res, T* __restrict__ dx,
+                                                      float* __restrict__ dgamma, float* __restrict__ dbeta, int rows, int C, int rows_per_block) {
+    __shared__ float red[4 * 1024];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float dg[LN_MAXCH][4], db[LN_MAXCH][4], gm[LN_MAXCH][4];
+#pragma unroll
+    for (int j = 0; j < LN_MAXCH; ++j) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { dg[j][i] = 0.f; db[j][i] = 0.f; gm[j][i] = 0.f; }
+        if ((lane + 64 * j) * 4 < C) load4(gamma + (lane + 64 * j) * 4, gm[j]);
+    }
+    const int r_end = min(rows, (int)(blockIdx.x + 1) * rows_per_block);
+    for (int r = blockIdx.x * rows_per_block + wave; r < r_end; r += 4) {
+        const long src = map ? map[r] : r;
+        if (src < 0) continue;
+        const float mu = mean[r], rs = rstd[r];
+        float gv[LN_MAXCH][4], xh[LN_MAXCH][4];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int j = 0; j < LN_MAXCH; ++j)
+            if ((lane + 64 * j) * 4 < C) {
+                load4(g + (long)r * C + (lane + 64 * j) * 4, gv[j]);
+                load4(x + src * C + (lane + 64 * j) * 4, xh[j]);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    xh[j][i] = (xh[j][i] - mu) * rs;
+                    dg[j][i] += gv[j][i] * xh[j][i];
+                    db[j][i] += gv[j][i];
+                    gv[j][i] *= gm[j][i];
+                    s1 += gv[j][i];
+                    s2 += gv[j][i] * xh[j][i];
+                }
+            }
+        s1 = warp_sum(s1) / (float)C;
+        s2 = warp_sum(s2) / (float)C;
+#pragma unroll
+        for (int j = 0; j < LN_MAXCH; ++j)
+            if ((lane + 64 * j) * 4 < C) {
+                float o[4], rv[4] = {0.f, 0.f, 0.f, 0.f};
+                if (res) load4(res + src * C + (lane + 64 * j) * 4, rv);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) o[i] = rs * (gv[j][i] - s1 - xh[j][i] * s2) + rv[i];
+                store4(dx + src * C + (lane + 64 * j) * 4, o);
+            }
+    }
+    // block reduction of the parameter gradients, then one atomic per column
+    for (int pass = 0; pass < 2; ++pass) {
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < LN_MAXCH; ++j)
+            if ((lane + 64 * j) * 4 < C) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) red[wave * 1024 + (lane + 64 * j) * 4 + i] = pass ? db[j][i] : dg[j][i];
+            }
+        __syncthreads();
+        for (int cidx = threadIdx.x; cidx < C; cidx += 256) {
+            const float t = (red[cidx] + red[1024 + cidx]) + (red[2048 + cidx] + red[3072 + cidx]);
+            atomicAdd((pass ? dbeta : dgamma) + cidx, t);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ GELU (erf form)
+template <typename T>
+__global__ void gelu_kernel(const T* __restrict__ x, const T* __restrict__ g, T* __restrict__ out, long n4) {
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+        float v[4], gv[4], o[4];
+        load4(x + i * 4, v);
+        if (g) load4(g + i * 4, gv);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float cdf = 0.5f * (1.f + erff(v[k] * 0.70710678118654752f));
+            o[k] = g ? gv[k] * (cdf + v[k] * 0.3989422804014327f * __expf(-0.5f * v[k] * v[k])) : v[k] * cdf;
+        }
+        store4(out + i * 4, o);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ row gather-add
+// out[r] = (a ? a[r] : 0) + s(r) * (idx >= 0 ? b[idx] : 0), idx = map ? map[r] : r, s(r) = scale ? scale[r / rows_per_sample] : 1
+template <typename T>
+__global__ void rows_add_kernel(const T* __restrict__ a, const T* __restrict__ b, const int* __restrict__ map, const float* __restrict__ scale,
+                                T* __restrict__ out, int rows, int C, int rows_per_sample) {
+    const int c4 = C >> 2;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < (long)rows * c4; i += (long)gridDim.x * blockDim.x) {
+        const int r = (int)(i / c4), cc = (int)(i - (long)r * c4) * 4;
+        const long idx = map ? map[r] : r;
+        float av[4] = {0.f, 0.f, 0.f, 0.f}, bv[4] = {0.f, 0.f, 0.f, 0.f}, o[4];
+        if (a) load4(a + (long)r * C + cc, av);
+        if (idx >= 0) load4(b + idx * C + cc, bv);
+        const float s = scale ? scale[r / rows_per_sample] : 1.f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) o[k] = av[k] + s * bv[k];
+        store4(out + (long)r * C + cc, o);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ patch extraction
+// uint8 CHW staging -> normalised bf16/fp32 rows [N*gh*gw][3*P*P] in the (c, ph, pw) order of a conv weight [Cout][3][P][P];
+// pixels outside image n (the zero padding of ImageList) contribute (0 - mean)/std * 0 = 0, as in the reference where the
+// batch is padded AFTER normalisation.
+template <typename T>
+__global__ void patchify_kernel(const uint8_t* __restrict__ img, T* __restrict__ out, int N, int Hs, int Ws, int P, int gh, int gw,
+                                const int* __restrict__ hw, float m0, float m1, float m2, float is0, float is1, float is2) {
+    const int K = 3 * P * P;
+    const long total = (long)N * gh * gw * (K >> 2);
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int k = (int)(i % (K >> 2)) * 4;
+        const long tok = i / (K >> 2);
+        const int n = (int)(tok / (gh * gw)), t = (int)(tok - (long)n * gh * gw), ty = t / gw, tx = t - ty * gw;
+        const int c = k / (P * P), rem = k - c * P * P, py = rem / P, px = rem - py * P;
+        const int y = ty * P + py, x0 = tx * P + px;
+        const float mean = c == 0 ? m0 : (c == 1 ? m1 : m2), is = c == 0 ? is0 : (c == 1 ? is1 : is2);
+        const int h = hw[2 * n], w = hw[2 * n + 1];
+        float o[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int x = x0 + j;
+            o[j] = (y < h && x < w) ? ((float)img[(((long)n * 3 + c) * Hs + y) * Ws + x] - mean) * is : 0.f;
+        }
+        store4(out + tok * K + k, o);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ resampling
+// 1-D linear resize of a table [L0][C] -> [L1][C] (F.interpolate mode="linear", align_corners=False), fwd and bwd (fp32)
+__device__ __forceinline__ void lin_taps(int i, int L0, int L1, int& i0, int& i1, float& lam) {
+    const float scale = (float)L0 / (float)L1;
+    float src = ((float)i + 0.5f) * scale - 0.5f;
+    src = src < 0.f ? 0.f : src;
+    i0 = (int)src;
+    i1 = i0 + (i0 < L0 - 1 ? 1 : 0);
+    lam = src - (float)i0;
+}
+__global__ void linear_resize_kernel(const float* __restrict__ in, float* __restrict__ out, int L0, int L1, int C, int backward) {
+    const int i = blockIdx.x;
+    int i0, i1; float lam;
+    lin_taps(i, L0, L1, i0, i1, lam);
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        if (!backward) out[i * C + c] = (1.f - lam) * in[i0 * C + c] + lam * in[i1 * C + c];
+        else {   // in = grad wrt resized [L1][C], out = grad wrt table [L0][C] (pre-zeroed or accumulating)
+            const float gv = in[i * C + c];
+            atomicAdd(out + i0 * C + c, (1.f - lam) * gv);
+            atomicAdd(out + i1 * C + c, lam * gv);
+        }
+    }
+}
+
+// bicubic (A = -0.75, align_corners=False, border indices clamped) resize of a grid [S0][S0][C] -> [gh][gw][C]
+__device__ __forceinline__ void cubic_w(float t, float w[4]) {
+    const float A = -0.75f;
+    const float x0 = t + 1.f, x1 = t, x2 = 1.f - t, x3 = 2.f - t;
+    w[0] = ((A * x0 - 5.f * A) * x0 + 8.f * A) * x0 - 4.f * A;
+    w[1] = ((A + 2.f) * x1 - (A + 3.f)) * x1 * x1 + 1.f;
+    w[2] = ((A + 2.f) * x2 - (A + 3.f)) * x2 * x2 + 1.f;
+    w[3] = ((A * x3 - 5.f * A) * x3 + 8.f * A) * x3 - 4.f * A;
+}
+__global__ void bicubic_resize_kernel(const float* __restrict__ in, float* __restrict__ out, int S0h, int S0w, int gh, int gw, int C,
+                                      int backward) {
+    const int oy = blockIdx.x / gw, ox = blockIdx.x - oy * gw;
+    const float sy = ((float)oy + 0.5f) * ((float)S0h / (float)gh) - 0.5f, sx = ((float)ox + 0.5f) * ((float)S0w / (float)gw) - 0.5f;
+    const float fy = floorf(sy), fx = floorf(sx);
+    float wy[4], wx[4];
+    cubic_w(sy - fy, wy);
+    cubic_w(sx - fx, wx);
+    int iy[4], ix[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        iy[k] = min(max((int)fy - 1 + k, 0), S0h - 1);
+        ix[k] = min(max((int)fx - 1 + k, 0), S0w - 1);
+    }
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        if (!backward) {
+            float acc = 0.f;
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+                float row = 0.f;
+#pragma unroll
+                for (int b = 0; b < 4; ++b) row += wx[b] * in[((long)iy[a] * S0w + ix[b]) * C + c];
+                acc += wy[a] * row;
+            }
+            out[(long)blockIdx.x * C + c] = acc;
+        } else {
+            const float gv = in[(long)blockIdx.x * C + c];
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int b = 0; b < 4; ++b) atomicAdd(out + ((long)iy[a] * S0w + ix[b]) * C + c, wy[a] * wx[b] * gv);
+        }
+    }
+}
+
+// y[n][t][:] = x[n][t][:] + pos[t][:]  (pos fp32 [T][C]); backward of pos = sum over n of g
+template <typename T>
+__global__ void add_pos_kernel(const T* __restrict__ x, const float* __restrict__ pos, T* __restrict__ y, int N, long TC4) {
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < (long)N * TC4; i += (long)gridDim.x * blockDim.x) {
+        float v[4], p[4];
+        load4(x + i * 4, v);
+        load4(pos + (i % TC4) * 4, p);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] += p[k];
+        store4(y + i * 4, v);
+    }
+}
+template <typename T>
+__global__ void sum_batch_kernel(const T* __restrict__ g, float* __restrict__ out, int N, long TC4) {
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < TC4; i += (long)gridDim.x * blockDim.x) {
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int n = 0; n < N; ++n) {
+            float v[4];
+            load4(g + ((long)n * TC4 + i) * 4, v);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) acc[k] += v[k];
+        }
+        store4(out + i * 4, acc);
+    }
+}
+
+
+// ------------------------------------------------------------------------------------------------ 2x2/2 max pool (NHWC)
+// forward writes the pooled value and the winning tap (first maximum in row-major window order, torch's tie rule);
+// backward routes the gradient to that tap and zeroes the rest.
+template <typename T>
+__global__ void maxpool2_kernel(const T* __restrict__ x, T* __restrict__ y, uint8_t* __restrict__ idx, int N, int H, int W, int C) {
+    const int Ho = H >> 1, Wo = W >> 1, c4 = C >> 2;
+    const long total = (long)N * Ho * Wo * c4;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int cc = (int)(i % c4) * 4;
+        long pix = i / c4;
+        const int wo = (int)(pix % Wo); pix /= Wo;
+        const int ho = (int)(pix % Ho), n = (int)(pix / Ho);
+        float best[4];
+        uint8_t bi[4] = {0, 0, 0, 0};
+        load4(x + (((long)n * H + 2 * ho) * W + 2 * wo) * C + cc, best);
+#pragma unroll
+        for (int t = 1; t < 4; ++t) {
+            float v[4];
+            load4(x + (((long)n * H + 2 * ho + (t >> 1)) * W + 2 * wo + (t & 1)) * C + cc, v);
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (v[k] > best[k] || v[k] != v[k]) { best[k] = v[k]; bi[k] = (uint8_t)t; }
+        }
+        store4(y + i * 4, best);
+        *reinterpret_cast<uint32_t*>(idx + i * 4) = bi[0] | (bi[1] << 8) | (bi[2] << 16) | ((uint32_t)bi[3] << 24);
+    }
+}
+template <typename T>
+__global__ void maxpool2_bwd_kernel(const T* __restrict__ g, const uint8_t* __restrict__ idx, T* __restrict__ dx, int N, int H, int W, int C) {
+    const int Ho = H >> 1, Wo = W >> 1, c4 = C >> 2;
+    const long total = (long)N * Ho * Wo * c4;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int cc = (int)(i % c4) * 4;
+        long pix = i / c4;
+        const int wo = (int)(pix % Wo); pix /= Wo;
+        const int ho = (int)(pix % Ho), n = (int)(pix / Ho);
+        float gv[4];
+        load4(g + i * 4, gv);
+        const uint32_t b = *reinterpret_cast<const uint32_t*>(idx + i * 4);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            float o[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) o[k] = ((b >> (8 * k)) & 0xffu) == (uint32_t)t ? gv[k] : 0.f;
+            store4(dx + (((long)n * H + 2 * ho + (t >> 1)) * W + 2 * wo + (t & 1)) * C + cc, o);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ AdamW
+// torch.optim.AdamW (decoupled decay, bias-corrected): p *= 1 - lr*wd; m, v moments; p -= lr/bc1 * m / (sqrt(v)/sqrt(bc2) + eps)
+// lr_scale / wd_mask are per-element-segment factors resolved by the host into per-launch scalars.
+template <typename T>
+__global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                             T* __restrict__ p_compute, long n, float lr, float beta1, float beta2, float eps, float wd, float bc1,
+                             float bc2_sqrt, float grad_scale) {
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const float gr = g[i] * grad_scale;
+        float pv = p[i] * (1.f - lr * wd);
+        const float mv = beta1 * m[i] + (1.f - beta1) * gr;
+        const float vv = beta2 * v[i] + (1.f - beta2) * gr * gr;
+        m[i] = mv; v[i] = vv;
+        const float denom = sqrtf(vv) / bc2_sqrt + eps;
+        pv -= (lr / bc1) * (mv / denom);
+        p[i] = pv;
+        if (p_compute) Elem<T>::st(p_compute + i, pv);
+    }
+}
+
+inline int grid_for(long work, int block = 256) {
+    long b = (work + block - 1) / block;
+    return (int)(b < 1 ? 1 : (b > 65535 * 4 ? 65535 * 4 : b));
+}
+
+}  // namespace
+
+#define VIT_DISPATCH(dtype, expr_f32, expr_bf16)                                   \
+    do {                                                                           \
+        if ((dtype) == ALDI_F32) { expr_f32; }                                     \
+        else if ((dtype) == ALDI_BF16) { expr_bf16; }                              \
+        else return aldi_set_error_msg(ALDI_ERR_ARG, "vit: bad dtype");            \
+    } while (0)
+
+extern "C" int aldi_layernorm_forward(const void* x, const int* map, const float* gamma, const float* beta, void* y, float* mean,
+                                      float* rstd, int rows, int C, float eps, int dtype, aldi_stream_t stream) {
+    if (C % 4 || C > 1024 || rows <= 0) return aldi_set_error_msg(ALDI_ERR_ARG, "layernorm: C must be a multiple of 4, <= 1024");
+    hipStream_t st = (hipStream_t)stream;
+    VIT_DISPATCH(dtype,
+        hipLaunchKernelGGL(ln_fwd_kernel<float>, dim3(cdiv(rows, 4)), dim3(256), 0, st, (const float*)x, map, gamma, beta, (float*)y, mean, rstd, rows, C, eps),
+        hipLaunchKernelGGL(ln_fwd_kernel<bf16_t>, dim3(cdiv(rows, 4)), dim3(256), 0, st, (const bf16_t*)x, map, gamma, beta, (bf16_t*)y, mean, rstd, rows, C, eps));
+    ALDI_CHECK_LAUNCH();
+    return ALDI_OK;
+}
+
+extern "C" int aldi_layernorm_backward(const void* g, const void* x, const int* map, const float* gamma, const float* mean, const float* rstd,
+                                       const void* res, void* dx, float* dgamma, float* dbeta, int rows, int C, int dtype,
+                                       aldi_stream_t stream) {
+    if (C % 4 || C > 1024 || rows <= 0) return aldi_set_error_msg(ALDI_ERR_ARG, "layernorm: C must be a multiple of 4, <= 1024");
+    hipStream_t st = (hipStream_t)stream;
+    const int rpb = 32;
+    VIT_DISPATCH(dtype,
+        hipLaunchKernelGGL(ln_bwd_kernel<float>, dim3(cdiv(rows, rpb)), dim3(256), 0, st, (const float*)g, (const float*)x, map, gamma, mean, rstd,
+                           (const float*)res, (float*)dx, dgamma, dbeta, rows, C, rpb),
+        hipLaunchKernelGGL(ln_bwd_kernel<bf16_t>, dim3(cdiv(rows, rpb)), dim3(256), 0, st, (const bf16_t*)g, (const bf16_t*)x, map, gamma, mean, rstd,
+                           (const bf16_t*)res, (bf16_t*)dx, dgamma, dbeta, rows, C, rpb));
+    ALDI_CHECK_LAUNCH();
+    return ALDI_OK;
+}
+
+extern "C" int aldi_gelu(const void* x, const void* g, void* out, long n, int dtype, aldi_stream_t stream) {
+    if (n % 4) return aldi_set_error_msg(ALDI_ERR_ARG, "gelu: n % 4 != 0");
+    hipStream_t st = (hipStream_t)stream;
+    VIT_DISPATCH(dtype,
+        hipLaunchKernelGGL(gelu_kernel<float>, dim3(grid_for(n / 4)), dim3(256), 0, st, (const float*)x, (const float*)g, (float*)out, n / 4),
+        hipLaunchKernelGGL(gelu_kernel<bf16_t>, dim3(grid_for(n / 4)), dim3(256), 0, st, (const bf16_t*)x, (const bf16_t*)g, (bf16_t*)out, n / 4));
+    ALDI_CHECK_LAUNCH();
+    return ALDI_OK;
+}
+
+extern "C" int aldi_rows_add(const void* a, const void* b, const int* map, const float* scale, void* out, int rows, int C,
+                             int rows_per_sample, int dtype, aldi_stream_t stream) {
+    if (C % 4 || rows <= 0 || rows_per_sample <= 0) return aldi_set_error_msg(ALDI_ERR_ARG, "rows_add: bad sizes");
+    hipStream_t st = (hipStream_t)stream;
+    const long work = (long)rows * (C / 4);
+    VIT_DISPATCH(dtype,
+        hipLaunchKernelGGL(rows_add_kernel<float>, dim3(grid_for(work)), dim3(256), 0, st, (const float*)a, (const float*)b, map, scale, (float*)out, rows, C, rows_per_sample),
+        hipLaunchKernelGGL(rows_add_kernel<bf16_t>, dim3(grid_for(work)), dim3(256), 0, st, (const bf16_t*)a, (const bf16_t*)b, map, scale, (bf16_t*)out, rows, C, rows_per_sample));
+    ALDI_CHECK_LAUNCH();
+    return ALDI_OK;
+}
+
+extern "C" int aldi_patchify(const uint8_t* img, void* out, int N, int Hs, int Ws, int P, const int* hw, const float* mean, const float* std,
+                             int dtype, aldi_stream_t stream) {
+    if (P % 4 || Hs % P || Ws % P || N <= 0) return aldi_set_error_msg(ALDI_ERR_ARG, "patchify: bad sizes");
+    hipStream_t st = (hipStream_t)stream;
+    const int gh = Hs / P, gw = Ws / P;
+    const long work = (long)N * gh * gw * (3 * P * P / 4);
+    VIT_DISPATCH(dtype,
+        hipLaunchKernelGGL(patchify_kernel<float>, dim3(grid_for(work)), dim3(256), 0, st, img, (float*)out, N, Hs, Ws, P, gh, gw, hw, mean[0], mean[1], mean[2], 1.f / std[0], 1.f / std[1], 1.f / std[2]),
+        hipLaunchKernelGGL(patchify_kernel<bf16_t>, dim3(grid_for(work)), dim3(256), 0, st, img, (bf16_t*)out, N, Hs, Ws, P, gh, gw, hw, mean[0], mean[1], mean[2], 1.f / std[0], 1.f / std[1], 1.f / std[2]));
+    ALDI_CHECK_LAUNCH();
+    return ALDI_OK;
+}
+
+extern "C" int aldi_linear_resize(const float* in, float* out, int L0, int L1, int C, int backward, aldi_stream_t stream) {
+    if (L0 <= 0 || L1 <= 0 || C <= 0) return aldi_set_error_msg(ALDI_ERR_ARG, "linear_resize: bad sizes");
+    hipLaunchKernelGGL(linear_resize_kernel, dim3(L1), dim3(64), 0, (hipStream_t)stream, in, out, L0, L1, C, backward);
+    ALDI_CHECK_LAUNCH();
+    return ALDI_OK;
+}
+
+extern "C" int aldi_bicubic_resize(const float* in, float* out, int S0h, int S0w, int gh, int gw, int C, int backward, aldi_stream_t stream) {
+    if (S0h <= 0 || S0w <= 0 || gh <= 0 || gw <= 0 || C <= 0) return aldi_set_error_msg(ALDI_ERR_ARG, "bicubic_resize: bad sizes");
+    hipLaunchKernelGGL(bicubic_resize_kernel, dim3(gh * gw), dim3(256), 0, (hipStream_t)stream, in, out, S0h, S0w, gh, gw, C, backward);
+    ALDI_CHECK_LAUNCH();
+    return ALDI_OK;
+}
+
+extern "C" int aldi_add_pos(const void* x, const float* pos, void* y, int N, long TC, int dtype, aldi_stream_t stream) {
+    if (TC % 4 || N <= 0) return aldi_set_error_msg(ALDI_ERR_ARG, "add_pos: bad sizes");
+    hipStream_t st = (hipStream_t)stream;
+    VIT_DISPATCH(dtype,
+        hipLaunchKernelGGL(add_pos_kernel<float>, dim3(grid_for(N * TC / 4)), dim3(256), 0, st, (const float*)x, pos, (float*)y, N, TC / 4),
+        hipLaunchKernelGGL(add_pos_kernel<bf16_t>, dim3(grid_for(N * TC / 4)), dim3(256), 0, st, (const bf16_t*)x, pos, (bf16_t*)y, N, TC / 4));
+    ALDI_CHECK_LAUNCH();
+    return ALDI_OK;
+}
+
+extern "C" int aldi_sum_batch(const void* g, float* out, int N, long TC, int dtype, aldi_stream_t stream) {
+    if (TC % 4 || N <= 0) return aldi_set_error_msg(ALDI_ERR_ARG, "sum_batch: bad sizes");
+    hipStream_t st = (hipStream_t)stream;
+    VIT_DISPATCH(dtype,
+        hipLaunchKernelGGL(sum_batch_kernel<float>, dim3(grid_for(TC / 4)), dim3(256), 0, st, (const float*)g, out, N, TC / 4),
+        hipLaunchKernelGGL(sum_batch_kernel<bf16_t>, dim3(grid_for(TC / 4)), dim3(256), 0, st, (const bf16_t*)g, out, N, TC / 4));
+    ALDI_CHECK_LAUNCH();
+    return ALDI_OK;
+}
+
+extern "C" int aldi_adamw_step(float* p, const float* g, float* m, float* v, void* p_compute, long n, float lr, float beta1, float beta2,
+                               float eps, float weight_decay, int step, float grad_scale, int dtype, aldi_stream_t stream) {
+    if (n <= 0 || step < 1) return aldi_set_error_msg(ALDI_ERR_ARG, "adamw: bad sizes");
+    hipStream_t st = (hipStream_t)stream;
+    const float bc1 = 1.f - powf(beta1, (float)step), bc2s = sqrtf(1.f - powf(beta2, (float)step));
+    VIT_DISPATCH(dtype,
+        hipLaunchKernelGGL(adamw_kernel<float>, dim3(grid_for(n)), dim3(256), 0, st, p, g, m, v, (float*)p_compute, n, lr, beta1, beta2, eps, weight_decay, bc1, bc2s, grad_scale),
+        hipLaunchKernelGGL(adamw_kernel<bf16_t>, dim3(grid_for(n)), dim3(256), 0, st, p, g, m, v, (bf16_t*)p_compute, n, lr, beta1, beta2, eps, weight_decay, bc1, bc2s, grad_scale));
+    ALDI_CHECK_LAUNCH();
+    return ALDI_OK;
+}
+
+extern "C" int aldi_maxpool2(const void* x, void* y, unsigned char* idx, int N, int H, int W, int C, int backward, int dtype,
+                             aldi_stream_t stream) {
+    if (H % 2 || W % 2 || C % 4 || N <= 0) return aldi_set_error_msg(ALDI_ERR_ARG, "maxpool2: H, W must be even and C % 4 == 0");
+    hipStream_t st = (hipStream_t)stream;
+    const long work = (long)N * (H / 2) * (W / 2) * (C / 4);
+    if (!backward) {
+        VIT_DISPATCH(dtype,
+            hipLaunchKernelGGL(maxpool2_kernel<float>, dim3(grid_for(work)), dim3(256), 0, st, (const float*)x, (float*)y, idx, N, H, W, C),
+            hipLaunchKernelGGL(maxpool2_kernel<bf16_t>, dim3(grid_for(work)), dim3(256), 0, st, (const bf16_t*)x, (bf16_t*)y, idx, N, H, W, C));
+    } else {   // x = gradient wrt the pooled map, y = gradient wrt the input map (fully written)
+        VIT_DISPATCH(dtype,
+            hipLaunchKernelGGL(maxpool2_bwd_kernel<float>, dim3(grid_for(work)), dim3(256), 0, st, (const float*)x, idx, (float*)y, N, H, W, C),
+            hipLaunchKernelGGL(maxpool2_bwd_kernel<bf16_t>, dim3(grid_for(work)), dim3(256), 0, st, (const bf16_t*)x, idx, (bf16_t*)y, N, H, W, C));
+    }
+    ALDI_CHECK_LAUNCH();
+    return ALDI_OK;
+}

@@ -423,7 +423,7 @@ __global__ __launch_bounds__(256) void wgrad_f32_kernel(WgDev p) {
 // db[c] += sum_p g[p][c]  (bias gradients).  Rows are read as full contiguous lines: a thread owns one 16-B chunk of
 // channels (C/EP chunks per row), the block walks `rows_per_block` rows, partial sums are combined through LDS.
 template <typename T>
-__global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ g, float* __restrict__ db, int M, int C, int rows_per_block) {
+__global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ g, float* __restrict__ db, int M, int C, int ld, int rows_per_block) {
     constexpr int EP = Elem<T>::kPer16B;
     __shared__ float red[256 * EP];
     const int chunks = C / EP;                         // 16-B chunks per row
@@ -435,7 +435,7 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ g, fl
     for (int k = 0; k < EP; ++k) acc[k] = 0.f;
     if (lane_r < rl && chunks <= 256)
         for (int r = r0 + lane_r; r < r1; r += rl) {
-            const uint4 v = *reinterpret_cast<const uint4*>(g + (long)r * C + ch * EP);
+            const uint4 v = *reinterpret_cast<const uint4*>(g + (long)r * ld + ch * EP);
             if constexpr (EP == 8) {
                 const uint32_t* w = reinterpret_cast<const uint32_t*>(&v);
 #pragma unroll
@@ -527,11 +527,14 @@ extern "C" int aldi_bias_grad(const void* g, float* db, int M, int C, int dtype,
     if (!g || !db || M <= 0 || C <= 0) return aldi_set_error_msg(ALDI_ERR_ARG, "bias_grad: bad args");
     hipStream_t st = static_cast<hipStream_t>(stream);
     const int ep = dtype == ALDI_BF16 ? 8 : 4;
-    if (C % ep || C / ep > 256) return aldi_set_error_msg(ALDI_ERR_ARG, "bias_grad: C must be a multiple of a 16-B chunk and <= 256 chunks");
+    if (C % ep) return aldi_set_error_msg(ALDI_ERR_ARG, "bias_grad: C must be a multiple of a 16-B chunk");
     int rows_per_block = cdiv(M, 1024) < 64 ? 64 : cdiv(M, 1024);
     dim3 grid(cdiv(M, rows_per_block));
-    if (dtype == ALDI_BF16) hipLaunchKernelGGL(colsum_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)g, db, M, C, rows_per_block);
-    else hipLaunchKernelGGL(colsum_kernel<float>, grid, dim3(256), 0, st, (const float*)g, db, M, C, rows_per_block);
+    for (int c0 = 0; c0 < C; c0 += 256 * ep) {       // a block covers at most 256 16-B chunks of a row: wider rows go in column slices
+        const int cs = C - c0 < 256 * ep ? C - c0 : 256 * ep;
+        if (dtype == ALDI_BF16) hipLaunchKernelGGL(colsum_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)g + c0, db + c0, M, cs, C, rows_per_block);
+        else hipLaunchKernelGGL(colsum_kernel<float>, grid, dim3(256), 0, st, (const float*)g + c0, db + c0, M, cs, C, rows_per_block);
+    }
     ALDI_CHECK_LAUNCH();
     return ALDI_OK;
 }

@@ -278,6 +278,68 @@ int aldi_aug_mic(unsigned char* img, int H, int W, const unsigned char* mask, in
 /* HWC uint8 -> CHW uint8 (the layout `dataset_dict["image"]` has in the reference, aldi/dataloader.py). */
 int aldi_aug_hwc_to_chw(const unsigned char* in, unsigned char* out, int H, int W, aldi_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------------------------------
+ * ViTDet trunk (BASELINE cfg 4).  Replaces, for the ALDI step, the torch modules that
+ * aldi/backbone.py:21-43 (checkpointed_vit_forward) drives: detectron2 modeling/backbone/vit.py Block / Attention /
+ * PatchEmbed and backbone/utils.py window_partition / get_rel_pos / get_abs_pos (detectron2 is not vendored in the
+ * reference; transformers' VitDet* modules implement the same algorithm and pin the tests).  Linear layers run on
+ * aldi_conv_igemm / aldi_conv_wgrad with H = W = 1.
+ * ------------------------------------------------------------------------------------------------------------------ */
+
+/* LayerNorm over the last dim (C % 256 == 0, C <= 1024), rows of `dtype`, fp32 affine and statistics.
+ * map (nullable): output row r reads source row map[r]; map[r] < 0 writes a zero row (window padding). */
+int aldi_layernorm_forward(const void* x, const int* map, const float* gamma, const float* beta, void* y, float* mean,
+                           float* rstd, int rows, int C, float eps, int dtype, aldi_stream_t stream);
+/* g is indexed like y; dx (and the optional residual gradient `res`) like x.  dgamma / dbeta accumulate (fp32 atomics). */
+int aldi_layernorm_backward(const void* g, const void* x, const int* map, const float* gamma, const float* mean, const float* rstd,
+                            const void* res, void* dx, float* dgamma, float* dbeta, int rows, int C, int dtype,
+                            aldi_stream_t stream);
+/* exact (erf) GELU: g == NULL -> out = gelu(x); else out = g * gelu'(x) */
+int aldi_gelu(const void* x, const void* g, void* out, long n, int dtype, aldi_stream_t stream);
+/* out[r] = (a ? a[r] : 0) + s * (idx >= 0 ? b[idx] : 0), idx = map ? map[r] : r, s = scale ? scale[r / rows_per_sample] : 1
+ * (residual add, drop-path scaling, window un-partition and its transpose) */
+int aldi_rows_add(const void* a, const void* b, const int* map, const float* scale, void* out, int rows, int C,
+                  int rows_per_sample, int dtype, aldi_stream_t stream);
+/* uint8 [N][3][Hs][Ws] staging -> normalised rows [N*(Hs/P)*(Ws/P)][3*P*P] (c, ph, pw order); hw = int[2N] image sizes (device),
+ * mean / std = float[3] (host) */
+int aldi_patchify(const uint8_t* img, void* out, int N, int Hs, int Ws, int P, const int* hw, const float* mean, const float* std,
+                  int dtype, aldi_stream_t stream);
+/* F.interpolate(mode="linear", align_corners=False) of a table [L0][C] -> [L1][C]; backward: in = d[L1][C], out += d[L0][C] */
+int aldi_linear_resize(const float* in, float* out, int L0, int L1, int C, int backward, aldi_stream_t stream);
+/* F.interpolate(mode="bicubic", align_corners=False) of a grid [S0h][S0w][C] -> [gh][gw][C]; backward accumulates likewise */
+int aldi_bicubic_resize(const float* in, float* out, int S0h, int S0w, int gh, int gw, int C, int backward, aldi_stream_t stream);
+/* y[n] = x[n] + pos (pos fp32 [TC]); aldi_sum_batch: out[TC] = sum_n g[n] (gradient of pos) */
+int aldi_add_pos(const void* x, const float* pos, void* y, int N, long TC, int dtype, aldi_stream_t stream);
+int aldi_sum_batch(const void* g, float* out, int N, long TC, int dtype, aldi_stream_t stream);
+/* 2x2 stride-2 max pool, NHWC (SimpleFeaturePyramid scale 0.5).  forward: x [N][H][W][C] -> y [N][H/2][W/2][C], idx = winning tap
+ * (first maximum in window order); backward: x = d(pooled), y = d(input) [N][H][W][C], fully written. */
+int aldi_maxpool2(const void* x, void* y, unsigned char* idx, int N, int H, int W, int C, int backward, int dtype, aldi_stream_t stream);
+/* torch.optim.AdamW step `step` (1-based) on a flat fp32 segment; p_compute (nullable) receives the `dtype` copy */
+int aldi_adamw_step(float* p, const float* g, float* m, float* v, void* p_compute, long n, float lr, float beta1, float beta2,
+                    float eps, float weight_decay, int step, float grad_scale, int dtype, aldi_stream_t stream);
+
+/* Attention with decomposed relative position bias, head dim 64, bf16.  nB = images x windows, each a gh x gw token grid
+ * (L = gh*gw, Lp = L rounded up to 64); Dq = 64 + gh + gw rounded up to 32 (64 when rel_h == NULL), at most 256.
+ * Workspaces: Qp, Kp, dQp [nB*heads][L][Dq]; KpT [nB*heads][Dq][Lp]; VT, QsT, dOT [nB*heads][64][Lp]; lse, delta [nB*heads][L]. */
+typedef struct {
+    const void* qkv;        /* [nB*L][3*heads*64]: q | k | v                                   */
+    const float* rel_h;     /* [2*gh-1][64] fp32 (already resized to this grid), nullable      */
+    const float* rel_w;     /* [2*gw-1][64]                                                    */
+    void *Qp, *Kp, *KpT, *VT, *QsT;      /* written by aldi_attn_prepare                        */
+    void* O;                /* [nB*L][heads*64]: written by forward, read by backward          */
+    float* lse;             /* written by forward, read by backward                            */
+    const void* dO;         /* backward input, like O                                          */
+    void *dOT, *dQp;        /* backward scratch                                                */
+    float* delta;           /* backward scratch                                                */
+    void* dqkv;             /* backward output, like qkv                                       */
+    float *drel_h, *drel_w; /* backward outputs, accumulate (fp32 atomics), nullable iff rel_h */
+    int nB, gh, gw, heads, Dq;
+    float scale;            /* head_dim ** -0.5                                                */
+} aldi_attn_args;
+int aldi_attn_prepare(const aldi_attn_args* a, aldi_stream_t stream);
+int aldi_attn_forward(const aldi_attn_args* a, aldi_stream_t stream);
+int aldi_attn_backward(const aldi_attn_args* a, aldi_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif
