@@ -562,50 +562,91 @@ __global__ __launch_bounds__(256) void attn_rel_dq_kernel(RbwdDev a) {
     }
 }
 
-// table gradients: row r of d(rel_h) collects q[t] * dQ'[t][64+kh] over (t, kh) with qh(t) - kh + gh - 1 == r (same for w).
-// One block per (bh, group of tiles); thread (r mod 4, column) owns its accumulators in LDS, one atomic per entry per block.
-__global__ __launch_bounds__(256) void attn_rel_dtab_kernel(RbwdDev a) {
+// table gradients on the matrix cores.  d(rel_w)[r] = sum_t E[t][r] * q[t] with the skewed operand
+// E[t][r] = dQ'[t][64 + gh + (qw(t) + gw - 1 - r)] (zero outside the band), likewise d(rel_h): one [rows x tokens].[tokens x 64]
+// product per (image, head).  A fragments are gathered from an LDS copy of the bias columns of dQ' (8 two-byte reads per
+// fragment); B fragments come from the (scale*q)^T tile the attention backward already streams, and the 1/scale is applied to
+// the accumulator.  One block per (bh, group of 64-token tiles); wave w owns row blocks w, w+4, ...
+constexpr int DT_MAXRB = 6;      // (2gh-1 + 2gw-1) <= 4 * 6 * 16 = 384 rows
+
+__global__ __launch_bounds__(256) void attn_rel_dtab_kernel(RbwdDev a, const bf16_t* __restrict__ QsT, int Lp) {
     extern __shared__ __align__(16) unsigned char smem[];
-    float* qs = reinterpret_cast<float*>(smem);        // [64][QROW] q
-    float* dr = qs + 64 * QROW;                         // [64][nrel+1]
-    const int gh = a.gh, gw = a.gw, nrel = gh + gw, DR = nrel + 1, nrows = (2 * gh - 1) + (2 * gw - 1);
-    float* acc = dr + 64 * DR;                          // [nrows][64]
-    const int bh = blockIdx.y, b = bh / a.heads, h = bh - b * a.heads;
-    const int L = a.L, Dq = a.Dq, ld3 = 3 * a.heads * HD;
-    const int cc = threadIdx.x & 63, r0 = threadIdx.x >> 6;
-    for (int r = r0; r < nrows; r += 4) acc[r * 64 + cc] = 0.f;
+    const int gh = a.gh, gw = a.gw, nrows = (2 * gh - 1) + (2 * gw - 1), DRB = a.Dq - 64 + 8;   // bias columns + a zero slot (16 B)
+    bf16_t* drs = reinterpret_cast<bf16_t*>(smem);                   // [64 t][DRB]
+    bf16_t* QTs = drs + 64 * DRB;                                    // [64 c][TROW]
+    int* ph = reinterpret_cast<int*>(QTs + 64 * TROW);               // [64] qh(t) + gh - 1
+    int* pw = ph + 64;                                               // [64] qw(t) + gw - 1
+    const int bh = blockIdx.y, L = a.L, Dq = a.Dq;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = lane & 15, g = lane >> 4;
+    const int nrb = (nrows + 15) >> 4, zero_col = Dq - 64;
+    f32x4_t acc[DT_MAXRB][4];
+#pragma unroll
+    for (int i = 0; i < DT_MAXRB; ++i)
+#pragma unroll
+        for (int cb = 0; cb < 4; ++cb) acc[i][cb] = f32x4_t{0.f, 0.f, 0.f, 0.f};
     const int ntiles = (L + 63) >> 6;
     for (int ti = 0; ti < a.tiles_per_block; ++ti) {
         const int tile = blockIdx.x * a.tiles_per_block + ti;
         if (tile >= ntiles) break;
-        const int t0 = tile * 64, nt = min(64, L - t0);
+        const int t0 = tile * 64;
         __syncthreads();
-        for (int id = threadIdx.x; id < 64 * 64; id += 256) {
-            const int t = id >> 6, d = id & 63;
-            qs[t * QROW + d] = t < nt ? bf16_to_f32(a.qkv[((long)b * L + t0 + t) * ld3 + h * HD + d]) : 0.f;
-        }
-        for (int id = threadIdx.x; id < 64 * nrel; id += 256) {
-            const int t = id / nrel, e = id - t * nrel;
-            dr[t * DR + e] = t < nt ? bf16_to_f32(a.dQp[((long)bh * L + t0 + t) * Dq + 64 + e]) : 0.f;
-        }
-        __syncthreads();
-        const int qh0 = t0 / gw, qw0 = t0 - qh0 * gw;
-        for (int r = r0; r < nrows; r += 4) {
-            const bool is_h = r < 2 * gh - 1;
-            const int rr = is_h ? r : r - (2 * gh - 1);
-            float s = 0.f;
-            int qh = qh0, qw = qw0;
-            for (int t = 0; t < nt; ++t) {
-                const int k = is_h ? qh + gh - 1 - rr : qw + gw - 1 - rr;
-                if (k >= 0 && k < (is_h ? gh : gw)) s += dr[t * DR + (is_h ? k : gh + k)] * qs[t * QROW + cc];
-                if (++qw == gw) { qw = 0; ++qh; }
+        {   // bias columns of dQ' (16-B chunks; rows past L and the extra slot are zeros)
+            const int cpr = DRB >> 3;
+            for (int id = threadIdx.x; id < 64 * cpr; id += 256) {
+                const int t = id / cpr, ch = id - t * cpr;
+                u32x4_t v = (t0 + t < L && ch < cpr - 1) ? ld16(a.dQp + ((long)bh * L + t0 + t) * Dq + 64 + ch * 8) : zero16();
+                *reinterpret_cast<u32x4_t*>(drs + t * DRB + ch * 8) = v;
             }
-            acc[r * 64 + cc] += s;
+        }
+        tile_load(QTs, TROW, QsT + (long)bh * HD * Lp + t0, Lp, 64, 64, 64, 256);
+        if (threadIdx.x < 64) {
+            const int tok = t0 + threadIdx.x, qh = tok / gw;
+            ph[threadIdx.x] = qh + gh - 1;
+            pw[threadIdx.x] = tok - qh * gw + gw - 1;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            int p_h[8], p_w[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { p_h[j] = ph[32 * ks + 8 * g + j]; p_w[j] = pw[32 * ks + 8 * g + j]; }
+            u32x4_t qf[4];
+#pragma unroll
+            for (int cb = 0; cb < 4; ++cb) qf[cb] = ld16(QTs + (16 * cb + c) * TROW + 32 * ks + 8 * g);
+#pragma unroll
+            for (int i = 0; i < DT_MAXRB; ++i) {
+                const int rb = wave + 4 * i;
+                if (rb >= nrb) break;
+                const int r = 16 * rb + c;
+                const bool is_h = r < 2 * gh - 1;
+                const int rr = is_h ? r : r - (2 * gh - 1), kmax = (r < nrows) ? (is_h ? gh : gw) : 0, cbase = is_h ? 0 : gh;
+                unsigned short e[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int k = (is_h ? p_h[j] : p_w[j]) - rr;
+                    const int col = (k >= 0 && k < kmax) ? cbase + k : zero_col;
+                    e[j] = drs[(32 * ks + 8 * g + j) * DRB + col];
+                }
+                const u32x4_t af = {e[0] | ((unsigned)e[1] << 16), e[2] | ((unsigned)e[3] << 16), e[4] | ((unsigned)e[5] << 16),
+                                    e[6] | ((unsigned)e[7] << 16)};
+#pragma unroll
+                for (int cb = 0; cb < 4; ++cb) acc[i][cb] = mma(af, qf[cb], acc[i][cb]);
+            }
         }
     }
-    for (int r = r0; r < nrows; r += 4) {
-        if (r < 2 * gh - 1) atomicAdd(a.drel_h + r * 64 + cc, acc[r * 64 + cc]);
-        else atomicAdd(a.drel_w + (r - (2 * gh - 1)) * 64 + cc, acc[r * 64 + cc]);
+    const float inv_scale = 1.f / a.scale;
+#pragma unroll
+    for (int i = 0; i < DT_MAXRB; ++i) {
+        const int rb = wave + 4 * i;
+        if (rb >= nrb) break;
+#pragma unroll
+        for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int r = 16 * rb + 4 * g + k, col = 16 * cb + c;
+                if (r < 2 * gh - 1) atomicAdd(a.drel_h + r * 64 + col, acc[i][cb][k] * inv_scale);
+                else if (r < nrows) atomicAdd(a.drel_w + (r - (2 * gh - 1)) * 64 + col, acc[i][cb][k] * inv_scale);
+            }
     }
 }
 
@@ -724,9 +765,10 @@ extern "C" int aldi_attn_backward(const aldi_attn_args* p, aldi_stream_t stream)
     hipLaunchKernelGGL(attn_rel_dq_kernel, dim3(ntiles, a.nB * a.heads), dim3(256), lds_q, st, r);
     ALDI_CHECK_LAUNCH();
     if (p->rel_h) {
-        const size_t lds_t = (size_t)64 * QROW * 4 + (size_t)64 * (nrel + 1) * 4 + (size_t)ntab * 64 * 4;
+        if (ntab > 4 * DT_MAXRB * 16) return aldi_set_error_msg(ALDI_ERR_ARG, "attn: 2(gh+gw)-2 > 384 table rows");
+        const size_t lds_t = (size_t)(64 * (a.Dq - 64 + 8) + 64 * TROW) * 2 + 128 * 4;
         if (int e = set_lds(attn_rel_dtab_kernel, lds_t)) return e;
-        hipLaunchKernelGGL(attn_rel_dtab_kernel, dim3(cdiv(ntiles, r.tiles_per_block), a.nB * a.heads), dim3(256), lds_t, st, r);
+        hipLaunchKernelGGL(attn_rel_dtab_kernel, dim3(cdiv(ntiles, r.tiles_per_block), a.nB * a.heads), dim3(256), lds_t, st, r, a.QsT, a.Lp);
         ALDI_CHECK_LAUNCH();
     }
     return ALDI_OK;

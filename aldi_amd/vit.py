@@ -286,10 +286,21 @@ class ViT:
         if key not in self._geom:
             c = self.cfg
             win, inv, nW = window_maps(N, gh, gw, c.window, self.device)
-            self._geom[key] = dict(win=win, inv=inv, nW=nW,
+            self._geom[key] = dict(win=win, inv=inv, nW=nW, att={},
                                    att_w=V.Attention(nW, c.window, c.window, c.heads, self.device),
                                    att_g=V.Attention(N, gh, gw, c.heads, self.device))
         return self._geom[key]
+
+    def _attention(self, geo: dict, i: int, N: int, gh: int, gw: int, save: bool) -> V.Attention:
+        """inference shares one workspace per geometry; a training pass keeps one per block so that backward finds the
+        operands (Q', K', their transposes) still in place instead of rebuilding them (~0.1 GB per block, HBM is 288 GB)"""
+        glob = i in self.cfg.global_blocks
+        if not save:
+            return geo["att_g"] if glob else geo["att_w"]
+        if i not in geo["att"]:
+            c = self.cfg
+            geo["att"][i] = V.Attention(N, gh, gw, c.heads, self.device) if glob else V.Attention(geo["nW"], c.window, c.window, c.heads, self.device)
+        return geo["att"][i]
 
     def _linear(self, x, name, res=None):
         y = ops.conv2d(x.view(x.shape[0], 1, 1, x.shape[1]), self.p.lin_w(name + ".weight"), shift=self.p.m(name + ".bias"),
@@ -349,12 +360,13 @@ class ViT:
         for i in range(c.depth):
             glob = i in c.global_blocks
             b = f"blocks.{i}."
-            att = geo["att_g"] if glob else geo["att_w"]
+            att = self._attention(geo, i, N, gh, gw, save)
             y1, mean1, rstd1 = V.layernorm_forward(x, p.m(b + "norm1.weight"), p.m(b + "norm1.bias"), eps=c.ln_eps,
                                                    row_map=None if glob else geo["win"])
             qkv = self._linear(y1, b + "attn.qkv")
             th, tw = self._rel_tables(i, gh, gw)
             O, lse = att.forward(qkv, th, tw)
+            att_ver = att.version
             s1 = ds[i, 0] if ds is not None else None
             if glob and s1 is None:
                 x1 = self._linear(O, b + "attn.proj", res=x)
@@ -371,7 +383,7 @@ class ViT:
                 x2 = V.rows_add(x1, self._linear(a1, b + "mlp.fc2"), rows=T, scale=s2, rows_per_sample=gh * gw)
             if save:
                 ctx.blocks.append(Ctx(x=x, y1=y1, mean1=mean1, rstd1=rstd1, qkv=qkv, O=O, lse=lse, x1=x1, y2=y2, mean2=mean2, rstd2=rstd2,
-                                      h1=h1, a1=a1, s1=s1, s2=s2))
+                                      h1=h1, a1=a1, s1=s1, s2=s2, att_ver=att_ver))
             x = x2
         ctx.out = x
         return ctx
@@ -387,7 +399,7 @@ class ViT:
             glob = i in c.global_blocks
             b = f"blocks.{i}."
             s = ctx.blocks[i]
-            att = geo["att_g"] if glob else geo["att_w"]
+            att = self._attention(geo, i, N, gh, gw, True)
             # ---- MLP branch
             df2 = g if s.s2 is None else V.rows_add(None, g, rows=T, scale=s.s2, rows_per_sample=gh * gw)
             da1 = self._linear_bwd(s.a1, df2, b + "mlp.fc2")
@@ -411,7 +423,7 @@ class ViT:
             resized_h, resized_w = th.data_ptr() != rh_m.data_ptr(), tw.data_ptr() != rw_m.data_ptr()
             dth = torch.zeros_like(th) if resized_h else p.g(b + "attn.rel_pos_h")
             dtw = torch.zeros_like(tw) if resized_w else p.g(b + "attn.rel_pos_w")
-            dqkv = att.backward(s.qkv, th, tw, s.O, s.lse, dO, dth, dtw)
+            dqkv = att.backward(s.qkv, th, tw, s.O, s.lse, dO, dth, dtw, prepared=(att.version == s.att_ver))
             if resized_h:
                 V.linear_resize_backward(dth, p.g(b + "attn.rel_pos_h"))
             if resized_w:

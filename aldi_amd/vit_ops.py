@@ -147,6 +147,7 @@ class Attention:
         self.dOT = torch.empty((BH, 64, self.Lp), **bf)
         self.dQp = torch.empty((BH, self.L, self.Dq), **bf)
         self.delta = torch.empty((BH, self.L), dtype=torch.float32, device=device)
+        self.version = 0          # bumped by every prepare: tells a later backward whether the operands are still its own
 
     def _args(self, qkv, rel_h, rel_w, O, lse, dO=None, dqkv=None, drel_h=None, drel_w=None):
         a = L.AttnArgs()
@@ -171,6 +172,7 @@ class Attention:
         lse = torch.empty((self.nB * self.heads, self.L), dtype=torch.float32, device=qkv.device)
         a = self._args(qkv, rel_h, rel_w, O, lse)
         L.call("aldi_attn_prepare", C.byref(a), stream_ptr())
+        self.version += 1
         L.call("aldi_attn_forward", C.byref(a), stream_ptr())
         return O, lse
 
@@ -180,5 +182,6 @@ class Attention:
         a = self._args(qkv, rel_h, rel_w, O, lse, dO, dqkv, drel_h, drel_w)
         if not prepared:
             L.call("aldi_attn_prepare", C.byref(a), stream_ptr())
+            self.version += 1
         L.call("aldi_attn_backward", C.byref(a), stream_ptr())
         return dqkv

@@ -11,7 +11,9 @@ import sqlite3
 import sys
 
 
-def stats(d, title):
+def stats(d, title, delim="sgd_kernel", per_step="1"):
+    """per-kernel table of ONE step: the launches between the last two step-closing optimizer launches (`delim` kernel,
+    `per_step` of them per step)"""
     dbs = glob.glob(d + "/**/*_results.db", recursive=True)
     con = sqlite3.connect(dbs[0])
     cur = con.cursor()
@@ -20,8 +22,8 @@ def stats(d, title):
     cols = [r[1] for r in cur.execute(f"pragma table_info({kt})")]
     name = "name" if "name" in cols else "kernel_name"
     rows = list(cur.execute(f"select {name}, start, end from {kt} order by start"))
-    sgd = [i for i, r in enumerate(rows) if "sgd_kernel" in r[0]]
-    a, b = sgd[-2], sgd[-1]
+    sgd = [i for i, r in enumerate(rows) if delim in r[0]]
+    a, b = sgd[-1 - int(per_step)], sgd[-1]
     step = rows[a + 1:b + 1]
     wall = (rows[b][2] - rows[a][2]) / 1e6
     agg = collections.defaultdict(lambda: [0, 0.0])
@@ -30,7 +32,7 @@ def stats(d, title):
         agg[n][1] += (e - s) / 1e3
     busy = sum(v[1] for v in agg.values())
     print(f"# {title}")
-    print(f"# one ALDI step (between two sgd_kernel launches): wall {wall:.2f} ms (under the profiler), GPU kernel busy {busy / 1e3:.2f} ms, {len(step)} kernel launches")
+    print(f"# one step (between two closing {delim} launches): wall {wall:.2f} ms (under the profiler), GPU kernel busy {busy / 1e3:.2f} ms, {len(step)} kernel launches")
     print("%-100s %6s %10s %10s %6s" % ("kernel", "calls", "total_us", "avg_us", "pct"))
     for n, (c, t) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
         print("%-100s %6d %10.1f %10.1f %6.1f" % (n[:100], c, t, t / c, 100 * t / busy))
@@ -45,8 +47,8 @@ def gaps(d, top="15"):
     cols = [r[1] for r in cur.execute(f"pragma table_info({kt})")]
     name = "name" if "name" in cols else "kernel_name"
     rows = list(cur.execute(f"select {name}, start, end from {kt} order by start"))
-    sgd = [i for i, r in enumerate(rows) if "sgd_kernel" in r[0]]
-    a, b = sgd[-2], sgd[-1]
+    sgd = [i for i, r in enumerate(rows) if delim in r[0]]
+    a, b = sgd[-1 - int(per_step)], sgd[-1]
     step = rows[a:b + 1]
     g = []
     for (n0, s0, e0), (n1, s1, e1) in zip(step[:-1], step[1:]):
@@ -66,8 +68,8 @@ def overlap(d):
     cols = [r[1] for r in cur.execute(f"pragma table_info({kt})")]
     name = "name" if "name" in cols else "kernel_name"
     rows = list(cur.execute(f"select {name}, start, end from {kt} order by start"))
-    sgd = [i for i, r in enumerate(rows) if "sgd_kernel" in r[0]]
-    a, b = sgd[-2], sgd[-1]
+    sgd = [i for i, r in enumerate(rows) if delim in r[0]]
+    a, b = sgd[-1 - int(per_step)], sgd[-1]
     t0, t1 = rows[a][2], rows[b][2]
     ev = []
     for n, s, e in rows[a + 1:b + 1]:
@@ -92,8 +94,8 @@ def phases(d):
     cols = [r[1] for r in cur.execute(f"pragma table_info({kt})")]
     name = "name" if "name" in cols else "kernel_name"
     rows = list(cur.execute(f"select {name}, start, end from {kt} order by start"))
-    sgd = [i for i, r in enumerate(rows) if "sgd_kernel" in r[0]]
-    a, b = sgd[-2], sgd[-1]
+    sgd = [i for i, r in enumerate(rows) if delim in r[0]]
+    a, b = sgd[-1 - int(per_step)], sgd[-1]
     t0 = rows[a][2]
     step = rows[a + 1:b + 1]
     def first(sub): 
