@@ -46,15 +46,34 @@ __device__ __forceinline__ u32x4_t pack_perm(f32x4_t a, f32x4_t b) {
     return v;
 }
 
-// cooperative copy of `rows` x `cols` bf16 (cols % 8 == 0) into an LDS tile; rows >= valid_rows are zero-filled
-__device__ __forceinline__ void tile_load(bf16_t* dst, int dst_row, const bf16_t* src, long src_row, int rows, int valid_rows, int cols,
-                                          int nthreads) {
-    const int cpr = cols >> 3;
-    for (int id = threadIdx.x; id < rows * cpr; id += nthreads) {
-        const int r = id / cpr, ch = id - r * cpr;
-        u32x4_t v = r < valid_rows ? ld16(src + (long)r * src_row + ch * 8) : zero16();
-        *reinterpret_cast<u32x4_t*>(dst + r * dst_row + ch * 8) = v;
+// Cooperative copy of a ROWS x COLS bf16 tile (COLS % 8 == 0) into LDS in two phases: fetch() issues every 16-B global load
+// of this thread back to back into registers, store() writes them to LDS.  (A rolled "load, store, next chunk" loop waits
+// for each load in turn: ~16 serial L2 round trips per tile.)  Splitting the phases also lets a kernel fetch tile k+1 before
+// it computes on tile k.  Rows >= valid_rows are zero-filled.
+template <int ROWS, int COLS, int NT>
+struct Tile {
+    static constexpr int CPR = COLS / 8, TOTAL = ROWS * CPR, N = (TOTAL + NT - 1) / NT;
+    u32x4_t v[N];
+    __device__ __forceinline__ void fetch(const bf16_t* src, long src_row, int valid_rows) {
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            const int id = threadIdx.x + i * NT, r = id / CPR, ch = id - r * CPR;
+            v[i] = (id < TOTAL && r < valid_rows) ? ld16(src + (long)r * src_row + ch * 8) : zero16();
+        }
     }
+    __device__ __forceinline__ void store(bf16_t* dst, int dst_row) const {
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            const int id = threadIdx.x + i * NT, r = id / CPR, ch = id - r * CPR;
+            if (id < TOTAL) *reinterpret_cast<u32x4_t*>(dst + r * dst_row + ch * 8) = v[i];
+        }
+    }
+};
+template <int ROWS, int COLS, int NT>
+__device__ __forceinline__ void tile_load(bf16_t* dst, int dst_row, const bf16_t* src, long src_row, int valid_rows) {
+    Tile<ROWS, COLS, NT> t;
+    t.fetch(src, src_row, valid_rows);
+    t.store(dst, dst_row);
 }
 
 struct AttnDev {
@@ -66,7 +85,7 @@ struct AttnDev {
 
 // ------------------------------------------------------------------------------------------------ forward
 template <int NKS, int NW>
-__global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(AttnDev a) {
+__global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void attn_fwd_kernel(AttnDev a) {   // two 4-wave blocks per CU: one loads while the other computes
     constexpr int DQ = NKS * 32, KROW = DQ + 8;
     extern __shared__ __align__(16) unsigned char smem[];
     bf16_t* Ks = reinterpret_cast<bf16_t*>(smem);            // [64 keys][KROW]
@@ -94,8 +113,8 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(AttnDev a) {
     const int nkt = a.Lp >> 6;
     for (int kt = 0; kt < nkt; ++kt) {
         __syncthreads();
-        tile_load(Ks, KROW, a.Kp + ((long)bh * L + kt * 64) * DQ, DQ, 64, L - kt * 64, DQ, NW * 64);
-        tile_load(Vs, TROW, a.VT + (long)bh * HD * a.Lp + kt * 64, a.Lp, 64, 64, 64, NW * 64);
+        tile_load<64, DQ, NW * 64>(Ks, KROW, a.Kp + ((long)bh * L + kt * 64) * DQ, DQ, L - kt * 64);
+        tile_load<64, 64, NW * 64>(Vs, TROW, a.VT + (long)bh * HD * a.Lp + kt * 64, a.Lp, 64);
         __syncthreads();
         f32x4_t st[4][2];
 #pragma unroll
@@ -208,12 +227,22 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dq_kernel(AttnDev a) {
     for (int i = 0; i < 2 * NKS; ++i) { dq[i][0] = f32x4_t{0.f, 0.f, 0.f, 0.f}; dq[i][1] = f32x4_t{0.f, 0.f, 0.f, 0.f}; }
 
     const int nkt = a.Lp >> 6;
+    Tile<64, DQ, NW * 64> tK;
+    Tile<DQ, 64, NW * 64> tKT;
+    Tile<64, 64, NW * 64> tV;
+    auto fetch = [&](int kt) {
+        tK.fetch(a.Kp + ((long)bh * L + kt * 64) * DQ, DQ, L - kt * 64);
+        tKT.fetch(a.KpT + (long)bh * DQ * a.Lp + kt * 64, a.Lp, DQ);
+        tV.fetch(a.qkv + ((long)b * L + kt * 64) * ld3 + 2 * ld1 + h * HD, ld3, L - kt * 64);
+    };
+    fetch(0);
     for (int kt = 0; kt < nkt; ++kt) {
         __syncthreads();
-        tile_load(Ks, KROW, a.Kp + ((long)bh * L + kt * 64) * DQ, DQ, 64, L - kt * 64, DQ, NW * 64);
-        tile_load(KTs, TROW, a.KpT + (long)bh * DQ * a.Lp + kt * 64, a.Lp, DQ, DQ, 64, NW * 64);
-        tile_load(Vs, TROW, a.qkv + ((long)b * L + kt * 64) * ld3 + 2 * ld1 + h * HD, ld3, 64, L - kt * 64, 64, NW * 64);
+        tK.store(Ks, KROW);
+        tKT.store(KTs, TROW);
+        tV.store(Vs, TROW);
         __syncthreads();
+        if (kt + 1 < nkt) fetch(kt + 1);          // in flight while this tile is computed
         f32x4_t st[4][2], dp[4][2];
 #pragma unroll
         for (int kb = 0; kb < 4; ++kb)
@@ -309,18 +338,30 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnDev a) {
         for (int kb = 0; kb < 2; ++kb) { dv[db][kb] = f32x4_t{0.f, 0.f, 0.f, 0.f}; dk[db][kb] = f32x4_t{0.f, 0.f, 0.f, 0.f}; }
 
     const int nqt = a.Lp >> 6;
-    for (int qt = 0; qt < nqt; ++qt) {
-        __syncthreads();
-        tile_load(Qs, KROW, a.Qp + ((long)bh * L + qt * 64) * DQ, DQ, 64, L - qt * 64, DQ, 256);
-        tile_load(dOs, TROW, a.dO + ((long)b * L + qt * 64) * ld1 + h * HD, ld1, 64, L - qt * 64, 64, 256);
-        tile_load(QTs, TROW, a.QsT + (long)bh * HD * a.Lp + qt * 64, a.Lp, 64, 64, 64, 256);
-        tile_load(dOTs, TROW, a.dOT + (long)bh * HD * a.Lp + qt * 64, a.Lp, 64, 64, 64, 256);
+    Tile<64, DQ, 256> tQ;
+    Tile<64, 64, 256> tdO, tQT, tdOT;
+    float lse_n = 0.f, dl_n = 0.f;
+    auto fetch = [&](int qt) {
+        tQ.fetch(a.Qp + ((long)bh * L + qt * 64) * DQ, DQ, L - qt * 64);
+        tdO.fetch(a.dO + ((long)b * L + qt * 64) * ld1 + h * HD, ld1, L - qt * 64);
+        tQT.fetch(a.QsT + (long)bh * HD * a.Lp + qt * 64, a.Lp, 64);
+        tdOT.fetch(a.dOT + (long)bh * HD * a.Lp + qt * 64, a.Lp, 64);
         if (threadIdx.x < 64) {
             const int q = qt * 64 + threadIdx.x;
-            lse_s[threadIdx.x] = q < L ? a.lse_r[(long)bh * L + q] : INFINITY;
-            dl_s[threadIdx.x] = q < L ? a.delta[(long)bh * L + q] : 0.f;
+            lse_n = q < L ? a.lse_r[(long)bh * L + q] : INFINITY;
+            dl_n = q < L ? a.delta[(long)bh * L + q] : 0.f;
         }
+    };
+    fetch(0);
+    for (int qt = 0; qt < nqt; ++qt) {
         __syncthreads();
+        tQ.store(Qs, KROW);
+        tdO.store(dOs, TROW);
+        tQT.store(QTs, TROW);
+        tdOT.store(dOTs, TROW);
+        if (threadIdx.x < 64) { lse_s[threadIdx.x] = lse_n; dl_s[threadIdx.x] = dl_n; }
+        __syncthreads();
+        if (qt + 1 < nqt) fetch(qt + 1);          // in flight while this tile is computed
         f32x4_t s[4][2], dp[4][2];
 #pragma unroll
         for (int qb = 0; qb < 4; ++qb)
@@ -598,7 +639,7 @@ __global__ __launch_bounds__(256) void attn_rel_dtab_kernel(RbwdDev a, const bf1
                 *reinterpret_cast<u32x4_t*>(drs + t * DRB + ch * 8) = v;
             }
         }
-        tile_load(QTs, TROW, QsT + (long)bh * HD * Lp + t0, Lp, 64, 64, 64, 256);
+        tile_load<64, 64, 256>(QTs, TROW, QsT + (long)bh * HD * Lp + t0, Lp, 64);
         if (threadIdx.x < 64) {
             const int tok = t0 + threadIdx.x, qh = tok / gw;
             ph[threadIdx.x] = qh + gh - 1;
