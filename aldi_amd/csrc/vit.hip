@@ -16,7 +16,7 @@ constexpr int LN_MAXCH = 4;     // C <= 1024, C % 4 == 0; lane chunk j (4 channe
 template <typename T>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, const int* __restrict__ map, const float* __restrict__ gamma,
                                                       const float* __restrict__ beta, T* __restrict__ y, float* __restrict__ mean,
-                                                      float* __restrict__ rstd, int rows, int C, float eps) {
+                                                      float* __restrict__ rstd, int rows, int C, float eps, int relu) {
     const int lane = threadIdx.x & 63, r = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (r >= rows) return;
     const long src = map ? map[r] : r;
@@ -52,7 +52,10 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, co
             load4(gamma + (lane + 64 * j) * 4, gm);
             load4(beta + (lane + 64 * j) * 4, bt);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) o[i] = v[j][i] * rs * gm[i] + bt[i];
+            for (int i = 0; i < 4; ++i) {
+                o[i] = v[j][i] * rs * gm[i] + bt[i];
+                if (relu) o[i] = fmaxf(o[i], 0.f);
+            }
             store4(yr + (lane + 64 * j) * 4, o);
         }
     if (lane == 0) { mean[r] = mu; rstd[r] = rs; }
@@ -62,8 +65,8 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, co
 template <typename T>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ g, const T* __restrict__ x, const int* __restrict__ map,
                                                       const float* __restrict__ gamma, const float* __restrict__ mean,
-                                                      const float* __restrict__ rstd, const T* __restrict__ res, T* __restrict__ dx,
-                                                      float* __restrict__ dgamma, float* __restrict__ dbeta, int rows, int C, int rows_per_block) {
+                                                      const float* __restrict__ rstd, const T* __restrict__ res, const T* __restrict__ mask,
+                                                      T* __restrict__ dx, float* __restrict__ dgamma, float* __restrict__ dbeta, int rows, int C, int rows_per_block) {
     __shared__ float red[4 * 1024];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     float dg[LN_MAXCH][4], db[LN_MAXCH][4], gm[LN_MAXCH][4];
@@ -84,6 +87,12 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ g, co
         for (int j = 0; j < LN_MAXCH; ++j)
             if ((lane + 64 * j) * 4 < C) {
                 load4(g + (long)r * C + (lane + 64 * j) * 4, gv[j]);
+                if (mask) {      // ReLU after the norm: the gradient passes where the activation was positive
+                    float mv[4];
+                    load4(mask + (long)r * C + (lane + 64 * j) * 4, mv);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) gv[j][i] = mv[i] > 0.f ? gv[j][i] : 0.f;
+                }
                 load4(x + src * C + (lane + 64 * j) * 4, xh[j]);
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
@@ -365,27 +374,27 @@ inline int grid_for(long work, int block = 256) {
     } while (0)
 
 extern "C" int aldi_layernorm_forward(const void* x, const int* map, const float* gamma, const float* beta, void* y, float* mean,
-                                      float* rstd, int rows, int C, float eps, int dtype, aldi_stream_t stream) {
+                                      float* rstd, int rows, int C, float eps, int relu, int dtype, aldi_stream_t stream) {
     if (C % 4 || C > 1024 || rows <= 0) return aldi_set_error_msg(ALDI_ERR_ARG, "layernorm: C must be a multiple of 4, <= 1024");
     hipStream_t st = (hipStream_t)stream;
     VIT_DISPATCH(dtype,
-        hipLaunchKernelGGL(ln_fwd_kernel<float>, dim3(cdiv(rows, 4)), dim3(256), 0, st, (const float*)x, map, gamma, beta, (float*)y, mean, rstd, rows, C, eps),
-        hipLaunchKernelGGL(ln_fwd_kernel<bf16_t>, dim3(cdiv(rows, 4)), dim3(256), 0, st, (const bf16_t*)x, map, gamma, beta, (bf16_t*)y, mean, rstd, rows, C, eps));
+        hipLaunchKernelGGL(ln_fwd_kernel<float>, dim3(cdiv(rows, 4)), dim3(256), 0, st, (const float*)x, map, gamma, beta, (float*)y, mean, rstd, rows, C, eps, relu),
+        hipLaunchKernelGGL(ln_fwd_kernel<bf16_t>, dim3(cdiv(rows, 4)), dim3(256), 0, st, (const bf16_t*)x, map, gamma, beta, (bf16_t*)y, mean, rstd, rows, C, eps, relu));
     ALDI_CHECK_LAUNCH();
     return ALDI_OK;
 }
 
 extern "C" int aldi_layernorm_backward(const void* g, const void* x, const int* map, const float* gamma, const float* mean, const float* rstd,
-                                       const void* res, void* dx, float* dgamma, float* dbeta, int rows, int C, int dtype,
+                                       const void* res, const void* mask, void* dx, float* dgamma, float* dbeta, int rows, int C, int dtype,
                                        aldi_stream_t stream) {
     if (C % 4 || C > 1024 || rows <= 0) return aldi_set_error_msg(ALDI_ERR_ARG, "layernorm: C must be a multiple of 4, <= 1024");
     hipStream_t st = (hipStream_t)stream;
     const int rpb = 32;
     VIT_DISPATCH(dtype,
         hipLaunchKernelGGL(ln_bwd_kernel<float>, dim3(cdiv(rows, rpb)), dim3(256), 0, st, (const float*)g, (const float*)x, map, gamma, mean, rstd,
-                           (const float*)res, (float*)dx, dgamma, dbeta, rows, C, rpb),
+                           (const float*)res, (const float*)mask, (float*)dx, dgamma, dbeta, rows, C, rpb),
         hipLaunchKernelGGL(ln_bwd_kernel<bf16_t>, dim3(cdiv(rows, rpb)), dim3(256), 0, st, (const bf16_t*)g, (const bf16_t*)x, map, gamma, mean, rstd,
-                           (const bf16_t*)res, (bf16_t*)dx, dgamma, dbeta, rows, C, rpb));
+                           (const bf16_t*)res, (const bf16_t*)mask, (bf16_t*)dx, dgamma, dbeta, rows, C, rpb));
     ALDI_CHECK_LAUNCH();
     return ALDI_OK;
 }

@@ -35,7 +35,12 @@ class VitConfig:
     rel_input: int = 64              # img_size // patch (1024/16): table length of the global blocks = 2*rel_input - 1
     drop_path_rate: float = 0.1
     sfp: bool = False                # also hold SimpleFeaturePyramid parameters (backbone.simfp_*)
+    num_classes: int = 0             # > 0: also hold the ViTDet RPN / box head (configs/Base-RCNN-VitDetB.yaml:7-14)
     fpn_channels: int = 256
+    box_convs: int = 4
+    fc_dim: int = 1024
+    pool: int = 7
+    num_anchors: int = 3
     ln_eps: float = 1e-6
     prefix: str = "backbone.net."
     pixel_mean: Tuple[float, float, float] = (123.675, 116.28, 103.53)
@@ -68,7 +73,51 @@ class VitConfig:
             s[b + "mlp.fc2.bias"] = ((E,), True)
         if self.sfp:
             s.update(self.sfp_spec())
+        if self.num_classes > 0:
+            s.update(self.heads_spec())
         return s
+
+    def heads_spec(self):
+        """RPN.CONV_DIMS [-1, -1] (two 3x3+ReLU convs, detectron2 StandardRPNHead), ROI_BOX_HEAD NUM_CONV 4 / NORM "LN" / NUM_FC 1
+        (FastRCNNConvFCHead), FastRCNNOutputLayers."""
+        C, K, A = self.fpn_channels, self.num_classes, self.num_anchors
+        s = OrderedDict()
+        rp = "proposal_generator.rpn_head."
+        for i in range(2):
+            s[f"{rp}conv.conv{i}.weight"] = ((C, C, 3, 3), True)
+            s[f"{rp}conv.conv{i}.bias"] = ((C,), True)
+        s[rp + "objectness_logits.weight"] = ((A, C, 1, 1), True)
+        s[rp + "anchor_deltas.weight"] = ((4 * A, C, 1, 1), True)
+        s[rp + "objectness_logits.bias"] = ((A,), True)
+        s[rp + "anchor_deltas.bias"] = ((4 * A,), True)
+        bh = "roi_heads.box_head."
+        for i in range(1, self.box_convs + 1):
+            s[f"{bh}conv{i}.weight"] = ((C, C, 3, 3), True)
+            s[f"{bh}conv{i}.norm.weight"] = ((C,), True)
+            s[f"{bh}conv{i}.norm.bias"] = ((C,), True)
+        s[bh + "fc1.weight"] = ((self.fc_dim, C * self.pool * self.pool), True)
+        s[bh + "fc1.bias"] = ((self.fc_dim,), True)
+        bp = "roi_heads.box_predictor."
+        s[bp + "cls_score.weight"] = ((K + 1, self.fc_dim), True)
+        s[bp + "bbox_pred.weight"] = ((4 * K, self.fc_dim), True)
+        s[bp + "cls_score.bias"] = ((K + 1,), True)
+        s[bp + "bbox_pred.bias"] = ((4 * K,), True)
+        return s
+
+    def packs(self) -> "OrderedDict[str, Tuple[List[str], int]]":
+        """engine tensors made of several state_dict entries stored back to back (rows concatenated, zero rows up to a multiple
+        of 16): pack name -> (member names, total elements incl. padding)"""
+        if self.num_classes <= 0:
+            return OrderedDict()
+        C, K, A = self.fpn_channels, self.num_classes, self.num_anchors
+        rp, bp = "proposal_generator.rpn_head.", "roi_heads.box_predictor."
+        r1, r2 = (5 * A + 15) // 16 * 16, (5 * K + 1 + 15) // 16 * 16
+        return OrderedDict([
+            ("rpn_head_out.weight", ([rp + "objectness_logits.weight", rp + "anchor_deltas.weight"], r1 * C)),
+            ("rpn_head_out.bias", ([rp + "objectness_logits.bias", rp + "anchor_deltas.bias"], r1)),
+            ("box_pred.weight", ([bp + "cls_score.weight", bp + "bbox_pred.weight"], r2 * self.fc_dim)),
+            ("box_pred.bias", ([bp + "cls_score.bias", bp + "bbox_pred.bias"], r2)),
+        ])
 
     def sfp_spec(self):
         """detectron2 SimpleFeaturePyramid(scale_factors=(4, 2, 1, 0.5), out_channels=256, norm="LN") module names.  Its norms are
@@ -111,10 +160,25 @@ class VitParams:
         self.cfg, self.device, self.trainable = cfg, device, trainable
         self.spec = cfg.spec()
         self.off: Dict[str, int] = {}
+        self.pack_off: Dict[str, Tuple[int, int]] = {}
+        packs = cfg.packs()
+        first = {members[0]: pk for pk, (members, _) in packs.items()}
+        packed = {m for members, _ in packs.values() for m in members}
         off = 0
         for decay in (True, False):
             for name, (shape, d) in self.spec.items():
                 if d != decay:
+                    continue
+                if name in first:                              # a pack: members back to back, padding after the last
+                    members, total = packs[first[name]]
+                    self.pack_off[first[name]] = (off, total)
+                    o = off
+                    for mname in members:
+                        self.off[mname] = o
+                        o += torch.Size(self.spec[mname][0]).numel()
+                    off += _pad64(total)
+                    continue
+                if name in packed:
                     continue
                 self.off[name] = off
                 n = 1
@@ -124,6 +188,7 @@ class VitParams:
             if decay:
                 self.n_decay = off
         self.n = off
+        self.n_train = off
         self.master = torch.zeros(self.n, dtype=torch.float32, device=device)
         self.compute = torch.zeros(self.n, dtype=torch.bfloat16, device=device)
         self._grad = self._m = self._v = None
@@ -168,6 +233,17 @@ class VitParams:
     def g(self, name, shape=None):
         return self._view(self.grad, self.full(name), shape)
 
+    def pack(self, buf, name, shape):         # a packed engine tensor (see VitConfig.packs)
+        o, n = self.pack_off[name]
+        return buf[o:o + n].view(shape)
+
+    def state_dict_keys(self) -> List[str]:
+        return list(self.spec.keys())
+
+    @property
+    def layout(self):                         # the trainer / EMA / checkpointer address a model's parameters through `.layout`
+        return self
+
     def lin_w(self, name):                    # Linear weight [out, in] as the 1x1 conv weight [out, 1, 1, in]
         o, i = self.spec[self.full(name)][0]
         return self.w(name, (o, 1, 1, i))
@@ -187,7 +263,12 @@ class VitParams:
         return self._wt_plan.out[self._wt_names.index(name)]
 
     # ---- state ------------------------------------------------------------------------------------------
-    def load_state_dict(self, sd: Dict[str, torch.Tensor]):
+    def load_state_dict(self, sd: Dict[str, torch.Tensor], strict: bool = True):
+        self.master.copy_(self.flatten(sd).to(self.device))
+        self.refresh()
+
+    def flatten(self, sd: Dict[str, torch.Tensor]) -> torch.Tensor:
+        """detectron2-shaped state_dict -> the flat fp32 layout (CPU tensor)"""
         missing = [k for k in self.spec if k not in sd]
         if missing:
             raise KeyError(f"missing keys in state_dict: {missing[:5]}{'...' if len(missing) > 5 else ''}")
@@ -198,9 +279,11 @@ class VitParams:
                 raise ValueError(f"{name}: shape {tuple(t.shape)} != {tuple(shape)}")
             if self.nhwc(name):
                 t = t.permute(0, 2, 3, 1).contiguous()
+            elif name.endswith("box_head.fc1.weight"):     # detectron2 flattens (C, 7, 7); the ROIAlign output here is (7, 7, C)
+                P_ = self.cfg.pool
+                t = t.view(shape[0], -1, P_, P_).permute(0, 2, 3, 1).contiguous()
             flat[self.off[name]:self.off[name] + t.numel()] = t.reshape(-1)
-        self.master.copy_(flat.to(self.device))
-        self.refresh()
+        return flat
 
     def state_dict(self) -> "OrderedDict[str, torch.Tensor]":
         return self.state_dict_like(self.master)
@@ -211,6 +294,9 @@ class VitParams:
         out = OrderedDict()
         for name in self.spec:
             t = flat[self.off[name]:self.off[name] + self._numel(name)].view(self.shape(name))
+            if name.endswith("box_head.fc1.weight"):
+                P_ = self.cfg.pool
+                t = t.view(t.shape[0], P_, P_, -1).permute(0, 3, 1, 2).reshape(t.shape[0], -1)
             out[name] = (t.permute(0, 3, 1, 2) if self.nhwc(name) else t).contiguous().clone()
         return out
 

@@ -15,7 +15,7 @@ from .ops import _p, dtype_code, stream_ptr
 
 
 def layernorm_forward(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, *, eps: float = 1e-6,
-                      row_map: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+                      row_map: Optional[torch.Tensor] = None, relu: bool = False) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
     """x [rows_src, C] -> (y [rows, C], mean [rows], rstd [rows]); rows = len(row_map) if given (gather, -1 = zero row)."""
     Cc = x.shape[-1]
     rows = row_map.numel() if row_map is not None else x.numel() // Cc
@@ -23,19 +23,20 @@ def layernorm_forward(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, 
     mean = torch.empty(rows, dtype=torch.float32, device=x.device)
     rstd = torch.empty(rows, dtype=torch.float32, device=x.device)
     L.call("aldi_layernorm_forward", _p(x), _p(row_map), _p(gamma), _p(beta), _p(y), _p(mean), _p(rstd), rows, Cc, float(eps),
-           dtype_code(x.dtype), stream_ptr())
+           int(relu), dtype_code(x.dtype), stream_ptr())
     return y, mean, rstd
 
 
 def layernorm_backward(g: torch.Tensor, x: torch.Tensor, gamma: torch.Tensor, mean: torch.Tensor, rstd: torch.Tensor,
                        dgamma: torch.Tensor, dbeta: torch.Tensor, *, row_map: Optional[torch.Tensor] = None,
-                       res: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+                       res: Optional[torch.Tensor] = None, mask: Optional[torch.Tensor] = None,
+                       out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """-> dx shaped like x (+ res); dgamma / dbeta (fp32) accumulate."""
     Cc = x.shape[-1]
     rows = g.numel() // Cc
     if out is None:
         out = torch.empty_like(x)
-    L.call("aldi_layernorm_backward", _p(g), _p(x), _p(row_map), _p(gamma), _p(mean), _p(rstd), _p(res), _p(out), _p(dgamma), _p(dbeta),
+    L.call("aldi_layernorm_backward", _p(g), _p(x), _p(row_map), _p(gamma), _p(mean), _p(rstd), _p(res), _p(mask), _p(out), _p(dgamma), _p(dbeta),
            rows, Cc, dtype_code(x.dtype), stream_ptr())
     return out
 

@@ -286,13 +286,15 @@ int aldi_aug_hwc_to_chw(const unsigned char* in, unsigned char* out, int H, int 
  * aldi_conv_igemm / aldi_conv_wgrad with H = W = 1.
  * ------------------------------------------------------------------------------------------------------------------ */
 
-/* LayerNorm over the last dim (C % 256 == 0, C <= 1024), rows of `dtype`, fp32 affine and statistics.
- * map (nullable): output row r reads source row map[r]; map[r] < 0 writes a zero row (window padding). */
+/* LayerNorm over the last dim (C % 4 == 0, C <= 1024), rows of `dtype`, fp32 affine and statistics.
+ * map (nullable): output row r reads source row map[r]; map[r] < 0 writes a zero row (window padding).
+ * relu != 0 applies ReLU to the output (detectron2 Conv2d(norm=LN, activation=ReLU) of the ViTDet box head). */
 int aldi_layernorm_forward(const void* x, const int* map, const float* gamma, const float* beta, void* y, float* mean,
-                           float* rstd, int rows, int C, float eps, int dtype, aldi_stream_t stream);
-/* g is indexed like y; dx (and the optional residual gradient `res`) like x.  dgamma / dbeta accumulate (fp32 atomics). */
+                           float* rstd, int rows, int C, float eps, int relu, int dtype, aldi_stream_t stream);
+/* g is indexed like y; dx (and the optional residual gradient `res`) like x.  mask (nullable, indexed like g): g counts only
+ * where mask > 0 (pass the forward output when relu was set).  dgamma / dbeta accumulate (fp32 atomics). */
 int aldi_layernorm_backward(const void* g, const void* x, const int* map, const float* gamma, const float* mean, const float* rstd,
-                            const void* res, void* dx, float* dgamma, float* dbeta, int rows, int C, int dtype,
+                            const void* res, const void* mask, void* dx, float* dgamma, float* dbeta, int rows, int C, int dtype,
                             aldi_stream_t stream);
 /* exact (erf) GELU: g == NULL -> out = gelu(x); else out = g * gelu'(x) */
 int aldi_gelu(const void* x, const void* g, void* out, long n, int dtype, aldi_stream_t stream);

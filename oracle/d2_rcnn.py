@@ -679,17 +679,20 @@ class Captured(dict):
 
 
 def forward_train(cfg, sd, batched_inputs: List[dict], replace_proposals: Optional[List[dict]] = None,
-                  roi_seed: Optional[int] = None, cap: Optional[Captured] = None) -> Dict[str, torch.Tensor]:
+                  roi_seed: Optional[int] = None, cap: Optional[Captured] = None, arch: Optional[dict] = None) -> Dict[str, torch.Tensor]:
     """GeneralizedRCNN.forward (training).  ``roi_seed`` mimics the ManualSeed
     pre-hook on roi_heads (aldi/helpers.py:17-26); ``replace_proposals`` the
     ReplaceProposalsOnce pre-hook (aldi/helpers.py:28-42)."""
+    # `arch` swaps the architecture-specific callables (oracle/d2_vitdet.py: ViTDet trunk, 2-conv RPN head, conv+FC box head);
+    # everything else -- anchors, matching, sampling, proposals, ROIAlign, losses -- is shared
+    arch = arch or {}
     x, sizes = preprocess(cfg, [b["image"] for b in batched_inputs])
-    x = x.to(sd["backbone.bottom_up.stem.conv1.weight"].dtype)       # fp64 state_dict -> fp64 "truth" run (tests only)
+    x = x.to(next(iter(sd.values())).dtype)       # fp64 state_dict -> fp64 "truth" run (tests only)
     gts = [b["instances"] for b in batched_inputs]
-    feats = resnet_fpn(cfg, sd, x)
+    feats = arch.get("backbone", resnet_fpn)(cfg, sd, x)
     flist = [feats[k] for k in ("p2", "p3", "p4", "p5", "p6")]
     anchors = generate_anchors(cfg, [tuple(f.shape[-2:]) for f in flist])
-    logits, deltas = rpn_head(cfg, sd, flist)
+    logits, deltas = arch.get("rpn_head", rpn_head)(cfg, sd, flist)
     lo, de = rpn_permute(logits, deltas)
     gt_labels, gt_boxes = label_and_sample_anchors(cfg, anchors, gts)
     losses_rpn = rpn_losses(cfg, anchors, lo, de, gt_labels, gt_boxes)
@@ -705,7 +708,7 @@ def forward_train(cfg, sd, batched_inputs: List[dict], replace_proposals: Option
         cap["proposals_used"] = proposals
     sampled = label_and_sample_proposals(cfg, proposals, gts)
     pooled = roi_pool(cfg, flist[:4], [s["proposal_boxes"] for s in sampled])
-    bh = box_head(sd, pooled)
+    bh = arch.get("box_head", box_head)(sd, pooled)
     scores, bdeltas = box_predictor(sd, bh)
     losses = roi_losses(cfg, scores, bdeltas, sampled)
     losses.update(losses_rpn)
