@@ -110,9 +110,14 @@ class GeneralizedRCNN:
         if self.device.type != "cuda":
             raise RuntimeError("aldi_amd runs on the MI355X HIP path only (MODEL.DEVICE must be cuda); there is no CPU fallback")
         self.dtype = torch.bfloat16 if cfg.SOLVER.AMP.ENABLED else torch.float32
-        self.layout = ParamLayout(self.num_classes, self._img_da, self._ins_da)
-        self.weights = Weights(self.layout, self.device, self.dtype, trainable=True)
-        self.engine = RCNN(self.weights, self.num_classes)
+        self.vitdet = str(cfg.MODEL.BACKBONE.NAME).startswith("build_vitdet")
+        seed = cfg.SEED if cfg.SEED is not None and cfg.SEED >= 0 else 1
+        if self.vitdet:
+            self._build_vitdet(seed)
+        else:
+            self.layout = ParamLayout(self.num_classes, self._img_da, self._ins_da)
+            self.weights = Weights(self.layout, self.device, self.dtype, trainable=True)
+            self.engine = RCNN(self.weights, self.num_classes)
         self.training = True
         self._anchor = torch.zeros((), device=self.device, requires_grad=True)
         self._last: _Holder = None
@@ -124,11 +129,38 @@ class GeneralizedRCNN:
         self.roi_heads = HookPoint(self, "roi_heads")
         self.roi_heads.box_predictor = HookPoint(self, "box_predictor")
         self.roi_heads.box_head = HookPoint(self, "box_head")
-        seed = cfg.SEED if cfg.SEED is not None and cfg.SEED >= 0 else 1
         if cfg.MODEL.WEIGHTS:
             self._load_file(cfg.MODEL.WEIGHTS)
+        elif self.vitdet:
+            self.weights.init_random(seed)
         else:
             self.load_state_dict(synthetic.init_state_dict(self.num_classes, seed=seed, img_da=self._img_da, ins_da=self._ins_da))
+
+    def vit_config(self):
+        """reference aldi/backbone.py:36-64 (build_vitdet_b_backbone / build_vitdet_l_backbone over detectron2's model_zoo
+        common/models/mask_rcnn_vitdet.py) + configs/Base-RCNN-VitDetB.yaml:7-19"""
+        from .vit import VitConfig
+        cfg = self.cfg
+        M = cfg.MODEL
+        if M.ROI_BOX_HEAD.NORM != "LN" or M.ROI_BOX_HEAD.NUM_FC != 1 or list(M.RPN.CONV_DIMS) != [-1, -1]:
+            raise ValueError("the ViTDet engine implements the head layout of configs/Base-RCNN-VitDetB.yaml (NORM LN, NUM_FC 1, RPN.CONV_DIMS [-1, -1])")
+        large = "vitdet_l" in M.BACKBONE.NAME
+        kw = dict(embed=1024, depth=24, heads=16, drop_path_rate=0.4,
+                  global_blocks=(5, 11, 17, 23)) if large else dict(embed=768, depth=12, heads=12, drop_path_rate=0.1, global_blocks=(2, 5, 8, 11))
+        syn = cfg.get("SYNTHETIC", {})
+        return VitConfig(sfp=True, num_classes=self.num_classes, box_convs=M.ROI_BOX_HEAD.NUM_CONV, fc_dim=M.ROI_BOX_HEAD.FC_DIM,
+                         pixel_mean=tuple(M.PIXEL_MEAN), pixel_std=tuple(M.PIXEL_STD), **{**kw, **dict(syn.get("VIT", {}))})
+
+    def _build_vitdet(self, seed: int):
+        from .vit import VitParams
+        from .vitdet import VitDetRCNN
+        if self._img_da or self._ins_da:
+            raise ValueError("adversarial alignment is not wired for the ViTDet trunk")
+        if self.dtype != torch.bfloat16:
+            raise ValueError("the ViTDet trunk runs in bf16 (SOLVER.AMP.ENABLED True): its attention kernels are bf16 MFMA")
+        self.weights = VitParams(self.vit_config(), self.device)
+        self.layout = self.weights
+        self.engine = VitDetRCNN(self.weights, self.num_classes, seed=seed)
 
     # ---- nn.Module-like surface -------------------------------------------------------------
     def to(self, device):
@@ -161,10 +193,13 @@ class GeneralizedRCNN:
             if k in ("weights", "engine", "_anchor", "_last", "backbone", "proposal_generator", "roi_heads"):
                 continue
             setattr(new, k, copy.deepcopy(v, memo) if k not in ("cfg", "layout", "device", "dtype") else v)
-        new.weights = Weights(self.layout, self.device, self.dtype, trainable=True)
+        if self.vitdet:
+            new._build_vitdet(1)
+        else:
+            new.weights = Weights(self.layout, self.device, self.dtype, trainable=True)
+            new.engine = RCNN(new.weights, self.num_classes)
         new.weights.master.copy_(self.weights.master)
         new.weights.refresh()
-        new.engine = RCNN(new.weights, self.num_classes)
         new._anchor = torch.zeros((), device=self.device, requires_grad=True)
         new._last = None
         new.backbone = HookPoint(new, "backbone")

@@ -245,6 +245,22 @@ class EngineSGD:
         self.model.weights.sgd_step(g["lr"], g["momentum"], g["weight_decay"])
 
 
+class EngineAdamW:
+    """torch.optim.AdamW-shaped handle on the fused HIP AdamW of the ViTDet model (reference aldi/backbone.py:66-84: detectron2
+    common/optim.py AdamW -- betas (0.9, 0.999), weight_decay 0.1, none on the blocks' LayerNorms and on pos_embed; the
+    layer-wise lr decay is off by default there, and here)."""
+    def __init__(self, model, lr, weight_decay=0.1, betas=(0.9, 0.999)):
+        self.model = model
+        self.param_groups = [{"lr": lr, "weight_decay": weight_decay, "betas": betas}]
+
+    def zero_grad(self, set_to_none: bool = False):
+        self.model.weights.zero_grad()
+
+    def step(self):
+        g = self.param_groups[0]
+        self.model.weights.adamw_step(g["lr"], betas=g["betas"], weight_decay=g["weight_decay"])
+
+
 class WarmupMultiStepLR:
     """detectron2 WarmupMultiStepLR (linear warmup), stepped once per iteration."""
     def __init__(self, optimizer, base_lr, steps, gamma, warmup_factor, warmup_iters):
@@ -482,7 +498,11 @@ class ALDITrainer(DefaultTrainer):
     @classmethod
     def build_optimizer(cls, cfg, model):
         if cfg.SOLVER.OPTIMIZER is None or cfg.SOLVER.OPTIMIZER.upper() == "SGD":
+            if getattr(model, "vitdet", False):
+                raise ValueError("the ViTDet model is trained with SOLVER.OPTIMIZER ADAMW (configs/Base-RCNN-VitDetB.yaml)")
             return super(ALDITrainer, cls).build_optimizer(cfg, model)
+        if cfg.SOLVER.OPTIMIZER.upper() == "ADAMW" and getattr(model, "vitdet", False):      # reference aldi/trainer.py:200-209
+            return EngineAdamW(model, cfg.SOLVER.BASE_LR)
         raise ValueError(f"Unsupported optimizer/backbone combination {cfg.SOLVER.OPTIMIZER} {cfg.MODEL.BACKBONE.NAME}.")
 
     @classmethod

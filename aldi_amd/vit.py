@@ -319,6 +319,11 @@ class VitParams:
 
     def zero_grad(self):
         self.grad.zero_()
+        self._gscale = 1.0
+
+    def scale_grad(self, f: float):
+        """deferred scalar on the gradient (folded into the optimizer kernel), e.g. 1/world after all-reduce(SUM)"""
+        self._gscale = getattr(self, "_gscale", 1.0) * f
 
     def adamw_step(self, lr: float, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 0.1, grad_scale: float = 1.0):
         """torch.optim.AdamW over [decayed | weight_decay = 0 (norms, pos_embed)] -- detectron2 get_default_optimizer_params with
@@ -331,7 +336,7 @@ class VitParams:
         for lo, hi, wd in ((0, nd, weight_decay), (nd, self.n, 0.0)):
             if hi > lo:
                 V.adamw_step(self.master[lo:hi], self.grad[lo:hi], self._m[lo:hi], self._v[lo:hi], self.compute[lo:hi], lr=lr, betas=betas,
-                             eps=eps, weight_decay=wd, step=self.step_count, grad_scale=grad_scale)
+                             eps=eps, weight_decay=wd, step=self.step_count, grad_scale=grad_scale * getattr(self, "_gscale", 1.0))
         if self._wt_plan is not None:
             self._wt_plan.run()
 

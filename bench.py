@@ -44,10 +44,14 @@ class FixedGpuLoader:
             yield tuple(None if p is None else [dict(d) for d in p] for p in self.data)
 
 
-def make_cfg(world, height, width, align):
+def make_cfg(world, height, width, align, workload="r50_fpn"):
     from aldi_amd.config import add_aldi_config, get_cfg
     cfg = get_cfg()
     add_aldi_config(cfg)
+    if workload == "vitdet_b":          # BASELINE configs[3] (cfg 4): ViTDet-B, AdamW, one labeled + one unlabeled image per GPU and step
+        cfg.merge_from_file(os.path.join(ROOT, "configs", "cityscapes", "ALDI-VitDetB-Cityscapes.yaml"))
+        cfg.merge_from_list(["SOLVER.IMS_PER_BATCH", 2 * world, "SEED", 1, "SYNTHETIC.HEIGHT", height, "SYNTHETIC.WIDTH", width])
+        return cfg
     cfg.merge_from_file(os.path.join(ROOT, "configs", "cityscapes", "ALDI-Best-Cityscapes.yaml"))
     # BASE_LR is lowered: with random-init weights the reference's 0.06 diverges to inf within a few steps (same work per step)
     cfg.merge_from_list(["SOLVER.IMS_PER_BATCH", 4 * world, "SEED", 1, "SYNTHETIC.HEIGHT", height, "SYNTHETIC.WIDTH", width, "SOLVER.BASE_LR", 1e-4,
@@ -166,7 +170,12 @@ def main():
     ap.add_argument("--sequential", action="store_true", help="reference-style sequential micro-steps instead of the fused student pass")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
+    ap.add_argument("--workload", default="r50_fpn", choices=["r50_fpn", "vitdet_b"],
+                    help="r50_fpn = the headline configuration (default); vitdet_b = BASELINE cfg 4 (SURVEY 8(f) rank 1), reported beside it")
     args = ap.parse_args()
+    vitdet = args.workload == "vitdet_b"
+    if vitdet:
+        args.no_profile = args.no_cpu_baseline = True      # the roofline / CPU legs are defined for the headline workload
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -187,7 +196,7 @@ def main():
 
     from aldi_amd import synthetic as syn
     from aldi_amd.trainer import ALDITrainer
-    cfg = make_cfg(world, args.height, args.width, args.align)
+    cfg = make_cfg(world, args.height, args.width, args.align, args.workload)
     if args.fp32:
         cfg.SOLVER.AMP.ENABLED = False
     cfg.SOLVER.FUSED_STEP = not args.sequential
@@ -195,7 +204,8 @@ def main():
     torch.manual_seed(100 + rank)
     tr = ALDITrainer(cfg)
     K = cfg.MODEL.ROI_HEADS.NUM_CLASSES
-    data = syn.make_batch(2, 2, args.height, args.width, K, seed=100 + rank)
+    per = 1 if vitdet else 2
+    data = syn.make_batch(per, per, args.height, args.width, K, seed=100 + rank)
     tr._trainer.data_loader = FixedGpuLoader(data, dev)
     tr._trainer._data_loader_iter_obj = None
 
@@ -225,20 +235,21 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t)
     ms = dt / args.steps * 1e3
-    imgs_per_step = 4 * world
+    imgs_per_step = 2 * per * world
     value = imgs_per_step * args.steps / dt
     err = int(tr.model.engine.err) | int(tr.ema.model.engine.err)
     losses = {k: float(v) for k, v in tr._trainer.last_loss_dict.items()}
     pl_count = tr.ema.model._last_inference.pseudo["count"].tolist()
 
-    out = {"metric": "images/sec (student+teacher ALDI step), R50-FPN 1333x800", "value": round(value, 3), "unit": "images/sec",
+    arch_name = "ViTDet-B" if vitdet else "R50-FPN"
+    out = {"metric": f"images/sec (student+teacher ALDI step), {arch_name} 1333x800", "value": round(value, 3), "unit": "images/sec",
            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True,
            "scaling": "weak", "vs_baseline": None, "dtype": "fp32" if args.fp32 else "bf16", "data": "synthetic",
-           "config": {"workload": "configs[%d]: ALDI++ R50-FPN Cityscapes->Foggy-shaped synthetic %dx%d, teacher EMA + distill on, align %s, "
-                                  "2 labeled_strong + 2 unlabeled (weak+strong) images per GPU" % (2 if args.align else 1, args.width, args.height,
-                                                                                                   "on" if args.align else "off"),
+           "config": {"workload": "configs[%d]: ALDI++ %s Cityscapes->Foggy-shaped synthetic %dx%d, teacher EMA + distill on, align %s, "
+                                  "%d labeled_strong + %d unlabeled (weak+strong) images per GPU" % (3 if vitdet else (2 if args.align else 1), arch_name, args.width,
+                                                                                                   args.height, "on" if args.align else "off", per, per),
                       "global_batch": imgs_per_step, "parallelism": f"dp{world}", "pseudo_label_threshold": cfg.DOMAIN_ADAPT.TEACHER.THRESHOLD,
-                      "pseudo_labels_per_image": pl_count, "schedule": "sequential micro-steps" if args.sequential else "fused source+target student pass", "weights": "random-init R50-FPN (synthetic)", "error_flag": err},
+                      "pseudo_labels_per_image": pl_count, "schedule": "sequential micro-steps" if args.sequential else "fused source+target student pass", "weights": f"random-init {arch_name} (synthetic)", "error_flag": err},
            "final_losses": {k: round(v, 5) for k, v in losses.items()}}
     if rank == 0 and world == 1 and not args.no_profile:
         prof = profile_dense(tr, one_step, os.path.join(ROOT, "gpurun_out", "dense_profile.txt"))

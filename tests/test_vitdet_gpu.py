@@ -169,3 +169,60 @@ def test_vitdet_adamw_overfits_one_batch():
         params.adamw_step(2e-4)
     assert all(t == t for t in totals)
     assert totals[-1] < 0.8 * totals[0], totals
+
+
+# ------------------------------------------------------------------------------------------------ the ALDI trainer on ViTDet
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _trainer_cfg(fused=True):
+    from aldi_amd.config import CfgNode, add_aldi_config, get_cfg
+    cfg = get_cfg()
+    add_aldi_config(cfg)
+    cfg.merge_from_file(os.path.join(ROOT, "configs", "cityscapes", "ALDI-VitDetB-Cityscapes.yaml"))
+    cfg.merge_from_list(["SOLVER.IMS_PER_BATCH", 2, "SOLVER.WARMUP_ITERS", 0, "SEED", 1, "EMA.ALPHA", 0.9, "SYNTHETIC.HEIGHT", 128,
+                         "SYNTHETIC.WIDTH", 160, "SOLVER.BASE_LR", 2e-4])
+    cfg.SYNTHETIC.VIT = CfgNode(dict(embed=128, depth=4, heads=2, window=7, global_blocks=(1, 3), pretrain_grid=4, rel_input=10))
+    cfg.SOLVER.FUSED_STEP = fused
+    return cfg
+
+
+@pytest.mark.parametrize("fused", [True, False])
+def test_vitdet_aldi_trainer_runs(fused, tmp_path):
+    """cfg 4 through the reference-shaped trainer (EMA tick, teacher inference -> pseudo labels, distillation student step,
+    AdamW) on a ViT-tiny detector: losses finite with the reference's key set, the teacher trails the student by the EMA, the
+    checkpoint holds detectron2-shaped `model` + `ema` state and restores bit-exactly."""
+    import random
+    from aldi_amd.trainer import ALDITrainer, EngineAdamW
+    cfg = _trainer_cfg(fused)
+    cfg.OUTPUT_DIR = str(tmp_path)
+    random.seed(0)
+    torch.manual_seed(3)
+    tr = ALDITrainer(cfg)
+    assert tr.model.vitdet and isinstance(tr._trainer.optimizer, EngineAdamW)
+    w0 = tr.model.weights.master.clone()
+    for _ in range(3):
+        tr.before_step()
+        tr.run_step()
+        tr.after_step()
+        tr.iter += 1
+    torch.cuda.synchronize()
+    ld = tr._trainer.last_loss_dict
+    keys = set(ld)
+    assert {"loss_cls_source_strong", "loss_rpn_loc_source_strong", "loss_obj_bce_distill", "loss_cls_ce_distill", "loss_rpn_l1_distill",
+            "loss_roih_l1_distill"} <= keys, keys
+    assert all(float(v) == float(v) and abs(float(v)) < 1e4 for v in ld.values()), ld
+    assert int(tr.model.engine.err) == 0 and int(tr.ema.model.engine.err) == 0
+    s, t = tr.model.weights.master, tr.ema.model.weights.master
+    assert (s - w0).abs().max() > 0 and (t - s).abs().max() > 0 and (t - w0).abs().max() > 0
+    sd = tr.model.state_dict()
+    assert "backbone.net.blocks.0.attn.qkv.weight" in sd and sd["backbone.simfp_2.0.weight"].shape == (128, 64, 2, 2)
+    assert sd["roi_heads.box_head.fc1.weight"].shape == (1024, 256 * 49)
+    # checkpoint round trip
+    ck = tr.checkpointer
+    ck.save("vitdet_test")
+    blob = torch.load(os.path.join(str(tmp_path), "vitdet_test.pth"), map_location="cpu")
+    assert "model" in blob and "ema" in blob
+    tr.model.weights.master.zero_()
+    ck.load(os.path.join(str(tmp_path), "vitdet_test.pth"))
+    assert torch.equal(tr.model.weights.master, s)
