@@ -10,9 +10,12 @@ import time
 import weakref
 from typing import Dict
 
+from collections import OrderedDict
+
 import torch
 import torch.distributed as dist
 
+from . import synthetic
 from .dataloader import SyntheticDetectionLoader, WeakStrongDataloader
 from .distill import build_distiller
 from .ema import EMA
@@ -533,6 +536,54 @@ class ALDITrainer(DefaultTrainer):
         super(ALDITrainer, self).before_step()
         if self.cfg.EMA.ENABLED:
             self.ema.update_weights(self._trainer.model, self.iter)
+
+    # ---- evaluation (reference aldi/trainer.py:166-196: COCO evaluator, EvalHook on the EMA model, BestCheckpointer on bbox/AP50)
+    @classmethod
+    def build_test_loader(cls, cfg, dataset_name):
+        """synthetic validation split: a finite list of batches of {image, image_id, height, width} + detectron2-format records"""
+        syn_ = cfg.get("SYNTHETIC", {})
+        h, w = syn_.get("HEIGHT", 800), syn_.get("WIDTH", 1333)
+        n, K = int(syn_.get("VAL_IMAGES", 8)), cfg.MODEL.ROI_HEADS.NUM_CLASSES
+        g = torch.Generator().manual_seed(4242)
+        batches, records = [], []
+        for i in range(n):
+            img, inst = synthetic.make_image(h, w, int(torch.randint(5, 21, (1,), generator=g)), K, g)
+            batches.append([{"image": img, "image_id": i, "height": h, "width": w}])
+            records.append(dict(image_id=i, height=h, width=w,
+                                annotations=[dict(bbox=b.tolist(), bbox_mode="XYXY_ABS", category_id=int(c))
+                                             for b, c in zip(inst["gt_boxes"], inst["gt_classes"])]))
+        return batches, records
+
+    @classmethod
+    def build_evaluator(cls, cfg, dataset_name, output_folder=None, dataset_dicts=None):
+        """Just do COCO Evaluation."""
+        from .evaluation import Detectron2COCOEvaluatorAdapter
+        if output_folder is None:
+            output_folder = os.path.join(cfg.OUTPUT_DIR, "inference")
+        return Detectron2COCOEvaluatorAdapter(dataset_name, dataset_dicts or [], cfg.MODEL.ROI_HEADS.NUM_CLASSES, output_dir=output_folder)
+
+    @classmethod
+    def test(cls, cfg, model, evaluators=None):
+        """detectron2 DefaultTrainer.test: {dataset: {"bbox": {...}}} (flattened to the single dict when there is one dataset)"""
+        from .evaluation import inference_on_dataset
+        names = list(cfg.DATASETS.TEST) or ["synthetic_val"]
+        results = OrderedDict()
+        for i, name in enumerate(names):
+            loader, records = cls.build_test_loader(cfg, name)
+            ev = evaluators[i] if evaluators is not None else cls.build_evaluator(cfg, name, dataset_dicts=records)
+            results[name] = inference_on_dataset(model, loader, ev)
+        return results[names[0]] if len(results) == 1 else results
+
+    def after_step(self):
+        super(ALDITrainer, self).after_step()
+        period = self.cfg.TEST.EVAL_PERIOD
+        if period > 0 and (self.iter + 1) % period == 0:
+            self._last_eval_results = self.test(self.cfg, self.ema.model if self.cfg.EMA.ENABLED else self.model)
+            ap50 = self._last_eval_results.get("bbox", {}).get("AP50", float("nan"))
+            if ap50 == ap50 and ap50 > getattr(self, "_best_ap50", float("-inf")):       # BestCheckpointer(..., "bbox/AP50", "max")
+                self._best_ap50 = ap50
+                name = (list(self.cfg.DATASETS.TEST) or ["synthetic_val"])[0]
+                self.checkpointer.save(f"{name}_model_best", iteration=self.iter)
 
 
 Trainer = ALDITrainer   # BASELINE.json calls it aldi.trainer.Trainer

@@ -485,3 +485,53 @@ def test_checkpoint_round_trip_and_ema_start(tmp_path):
     assert tr3.start_iter == 0
     for k in s_sd:
         assert torch.equal(tr3.model.state_dict()[k], t_sd[k]), k             # student := checkpoint's EMA weights
+
+
+def test_teacher_coco_evaluation_and_best_checkpoint(tmp_path):
+    """COCO box AP of the EMA teacher through the trainer's test() (reference aldi/trainer.py:166-196), and the
+    BestCheckpointer behaviour on bbox/AP50.  Random weights score ~0; an oracle 'model' that returns the ground truth scores 100,
+    through the same loader / evaluator / rescaling path."""
+    from aldi_amd.structures import Boxes, Instances
+    from aldi_amd.trainer import ALDITrainer
+    cfg = _cfg(False, bf16=True)
+    cfg.OUTPUT_DIR = str(tmp_path)
+    cfg.TEST.EVAL_PERIOD = 2
+    cfg.SYNTHETIC.VAL_IMAGES = 3
+    random.seed(0)
+    torch.manual_seed(1)
+    tr = ALDITrainer(cfg)
+    res = ALDITrainer.test(cfg, tr.ema.model)
+    assert set(res["bbox"]) == {"AP", "AP50", "AP75", "APs", "APm", "APl"}
+    assert all((v != v) or 0.0 <= v <= 100.0 for v in res["bbox"].values())
+    assert tr.ema.model.training                                  # test() restores the mode it found
+
+    loader, records = ALDITrainer.build_test_loader(cfg, "synthetic_val")
+
+    class GroundTruthModel:                                        # returns every annotation as a confident detection
+        training = False
+
+        def eval(self):
+            return self
+
+        def train(self, mode=True):
+            return self
+
+        def __call__(self, inputs):
+            out = []
+            for d in inputs:
+                r = records[d["image_id"]]
+                inst = Instances((d["height"], d["width"]))
+                inst.pred_boxes = Boxes(torch.tensor([a["bbox"] for a in r["annotations"]], dtype=torch.float32).reshape(-1, 4))
+                inst.scores = torch.linspace(0.99, 0.5, len(r["annotations"]))
+                inst.pred_classes = torch.tensor([a["category_id"] for a in r["annotations"]], dtype=torch.int64)
+                out.append(inst)
+            return out
+    perfect = ALDITrainer.test(cfg, GroundTruthModel())
+    assert perfect["bbox"]["AP"] == pytest.approx(100.0) and perfect["bbox"]["AP50"] == pytest.approx(100.0)
+
+    for _ in range(2):                                             # EVAL_PERIOD = 2: evaluated after the second step
+        tr.before_step()
+        tr.run_step()
+        tr.after_step()
+        tr.iter += 1
+    assert hasattr(tr, "_last_eval_results") and "bbox" in tr._last_eval_results
