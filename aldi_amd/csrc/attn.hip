@@ -441,44 +441,73 @@ struct PrepDev {
     bf16_t *Qp, *Kp, *KpT, *VT, *QsT;
     int nB, L, Lp, heads, Dq, gh, gw; float scale;
 };
-constexpr int QROW = 65;    // fp32 LDS rows of 64 + 1: a column walk hits 64 different banks
-
 __global__ __launch_bounds__(256) void attn_prep_kernel(PrepDev a) {
     extern __shared__ __align__(16) unsigned char smem[];
-    float* qs = reinterpret_cast<float*>(smem);        // [64][QROW]  q (unscaled)
-    float* th = qs + 64 * QROW;                         // [2gh-1][QROW]
-    float* tw = th + (2 * a.gh - 1) * QROW;             // [2gw-1][QROW]
-    bf16_t* kv = reinterpret_cast<bf16_t*>(tw + (2 * a.gw - 1) * QROW);   // [2][64][64] raw k, v
-    bf16_t* qp = kv + 2 * 64 * 64;                                         // [64][Dq] finished Q' rows (for the transposes)
+    const int gh = a.gh, gw = a.gw, nh = 2 * gh - 1, nrows = a.rel_h ? nh + 2 * gw - 1 : 0, nrb = (nrows + 15) >> 4;
+    bf16_t* qb = reinterpret_cast<bf16_t*>(smem);      // [64 t][TROW]   q (unscaled)
+    bf16_t* tab = qb + 64 * TROW;                       // [nrb*16][TROW] rel_h rows, then rel_w rows (bf16; zero rows pad the last block)
+    bf16_t* kv = tab + nrb * 16 * TROW;                 // [2][64][64] raw k, v
+    bf16_t* qp = kv + 2 * 64 * 64;                      // [64][Dq] finished Q' rows (for the transposes)
+    int* ph = reinterpret_cast<int*>(qp + 64 * a.Dq);   // [64] qh(t) + gh - 1
+    int* pw = ph + 64;                                  // [64] qw(t) + gw - 1
     const int bh = blockIdx.y, b = bh / a.heads, h = bh - b * a.heads, t0 = blockIdx.x * 64;
-    const int L = a.L, Dq = a.Dq, gh = a.gh, gw = a.gw, ld3 = 3 * a.heads * HD, ld1 = a.heads * HD;
-    const int nrel = gh + gw;
+    const int L = a.L, Dq = a.Dq, ld3 = 3 * a.heads * HD, ld1 = a.heads * HD;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = lane & 15, g = lane >> 4;
+    for (int id = threadIdx.x; id < 64 * 8; id += 256) {                 // q, k, v rows of this tile, 16 B at a time
+        const int t = id >> 3, ch = id & 7;
+        const bool ok = t0 + t < L;
+        const bf16_t* row = a.qkv + ((long)b * L + t0 + t) * ld3 + h * HD + ch * 8;
+        *reinterpret_cast<u32x4_t*>(qb + t * TROW + ch * 8) = ok ? ld16(row) : zero16();
+        *reinterpret_cast<u32x4_t*>(kv + t * 64 + ch * 8) = ok ? ld16(row + ld1) : zero16();
+        *reinterpret_cast<u32x4_t*>(kv + 64 * 64 + t * 64 + ch * 8) = ok ? ld16(row + 2 * ld1) : zero16();
+    }
+    for (int id = threadIdx.x; id < nrb * 16 * 16; id += 256) {           // tables fp32 -> bf16 (autocast would feed the einsum fp16)
+        const int r = id >> 4, c4 = (id & 15) * 4;
+        float v[4] = {0.f, 0.f, 0.f, 0.f};
+        if (r < nrows) load4((r < nh ? a.rel_h + r * 64 : a.rel_w + (r - nh) * 64) + c4, v);
+        store4(tab + r * TROW + c4, v);
+    }
+    if (threadIdx.x < 64) {
+        const int tok = t0 + threadIdx.x, qh = tok / gw;
+        ph[threadIdx.x] = qh + gh - 1;
+        pw[threadIdx.x] = tok - qh * gw + gw - 1;
+    }
+    for (int id = threadIdx.x; id < 64 * (Dq >> 1); id += 256) reinterpret_cast<uint32_t*>(qp)[id] = 0u;
+    __syncthreads();
+    // scaled q (scale = 2^-3 for head dim 64: exact in bf16)
     for (int id = threadIdx.x; id < 64 * 64; id += 256) {
         const int t = id >> 6, d = id & 63;
-        const bool ok = t0 + t < L;
-        const bf16_t* row = a.qkv + ((long)b * L + t0 + t) * ld3 + h * HD + d;
-        qs[t * QROW + d] = ok ? bf16_to_f32(row[0]) : 0.f;
-        kv[t * 64 + d] = ok ? row[ld1] : (bf16_t)0;
-        kv[64 * 64 + t * 64 + d] = ok ? row[2 * ld1] : (bf16_t)0;
+        qp[t * Dq + d] = f32_to_bf16(bf16_to_f32(qb[t * TROW + d]) * a.scale);
     }
-    if (a.rel_h) {
-        for (int id = threadIdx.x; id < (2 * gh - 1) * 64; id += 256) th[(id >> 6) * QROW + (id & 63)] = a.rel_h[id];
-        for (int id = threadIdx.x; id < (2 * gw - 1) * 64; id += 256) tw[(id >> 6) * QROW + (id & 63)] = a.rel_w[id];
-    }
-    __syncthreads();
-    // Q' rows into LDS (bf16)
-    for (int id = threadIdx.x; id < 64 * Dq; id += 256) {
-        const int e = id >> 6, t = id & 63;         // lanes walk tokens: the table row differs per lane, the column does not
-        const int tok = t0 + t;
-        float v = 0.f;
-        if (e < 64) v = qs[t * QROW + e] * a.scale;
-        else if (a.rel_h && e < 64 + nrel && tok < L) {
-            const int qh = tok / gw, qw = tok - qh * gw;
-            const float* tab = e < 64 + gh ? th + (qh - (e - 64) + gh - 1) * QROW : tw + (qw - (e - 64 - gh) + gw - 1) * QROW;
-            const float* qr = qs + t * QROW;
-            for (int d = 0; d < 64; ++d) v += qr[d] * tab[d];
+    // bias columns: E[r][t] = table_row(r) . q[t] on the matrix cores (rows = table rows, columns = tokens), then entry (r, t) lands in
+    // column kh = qh(t) + gh - 1 - r (resp. kw) of Q'[t] when that is a valid key coordinate.  Wave w owns row blocks w, w+4, ...
+    if (nrows) {
+        u32x4_t qf[4][2];
+#pragma unroll
+        for (int tb = 0; tb < 4; ++tb)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) qf[tb][ks] = ld16(qb + (16 * tb + c) * TROW + 32 * ks + 8 * g);
+        for (int rb = wave; rb < nrb; rb += 4) {
+            const u32x4_t a0 = ld16(tab + (16 * rb + c) * TROW + 8 * g), a1 = ld16(tab + (16 * rb + c) * TROW + 32 + 8 * g);
+#pragma unroll
+            for (int tb = 0; tb < 4; ++tb) {
+                f32x4_t e = f32x4_t{0.f, 0.f, 0.f, 0.f};
+                e = mma(a0, qf[tb][0], e);
+                e = mma(a1, qf[tb][1], e);
+                const int t = 16 * tb + c, p_h = ph[t], p_w = pw[t];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int r = 16 * rb + 4 * g + i;
+                    if (r < nh) {
+                        const int kh = p_h - r;
+                        if (kh >= 0 && kh < gh) qp[t * Dq + 64 + kh] = f32_to_bf16(e[i]);
+                    } else if (r < nrows) {
+                        const int kw = p_w - (r - nh);
+                        if (kw >= 0 && kw < gw) qp[t * Dq + 64 + gh + kw] = f32_to_bf16(e[i]);
+                    }
+                }
+            }
         }
-        qp[t * Dq + e] = f32_to_bf16(v);
     }
     __syncthreads();
     // row-major outputs: Q' and K'
@@ -573,33 +602,72 @@ struct RbwdDev {
 };
 
 __global__ __launch_bounds__(256) void attn_rel_dq_kernel(RbwdDev a) {
+    // dq^T[c][t] = scale * dQ'[t][c] + sum_r R^T[c][r] * E[t][r], E[t][r] = dQ'[t][bias column qh(t) + gh - 1 - r] (the same skewed
+    // operand as the table gradient): A = transposed tables from LDS, B = E gathered from the bias columns, 2-byte LDS reads.
     extern __shared__ __align__(16) unsigned char smem[];
-    float* th = reinterpret_cast<float*>(smem);
-    float* tw = th + (2 * a.gh - 1) * QROW;
-    float* dr = tw + (2 * a.gw - 1) * QROW;             // [64][nrel+1] rel columns of dQ'
+    const int gh = a.gh, gw = a.gw, nh = 2 * gh - 1, nrows = a.rel_h ? nh + 2 * gw - 1 : 0, nks = (nrows + 31) >> 5;
+    const int RT = nks * 32 + 8, DRB = a.Dq - 64 + 8, zero_col = a.Dq - 64;
+    bf16_t* rt = reinterpret_cast<bf16_t*>(smem);       // [64 c][RT]  tables transposed (bf16), zero beyond nrows
+    bf16_t* drs = rt + 64 * RT;                          // [64 t][DRB] bias columns of dQ' + a zero slot
+    int* ph = reinterpret_cast<int*>(drs + 64 * DRB);
+    int* pw = ph + 64;
     const int bh = blockIdx.y, b = bh / a.heads, h = bh - b * a.heads, t0 = blockIdx.x * 64;
-    const int L = a.L, Dq = a.Dq, gh = a.gh, gw = a.gw, ld3 = 3 * a.heads * HD, nrel = gh + gw, DR = nrel + 1;
-    const bool rel = a.rel_h != nullptr;
-    if (rel) {
-        for (int id = threadIdx.x; id < (2 * gh - 1) * 64; id += 256) th[(id >> 6) * QROW + (id & 63)] = a.rel_h[id];
-        for (int id = threadIdx.x; id < (2 * gw - 1) * 64; id += 256) tw[(id >> 6) * QROW + (id & 63)] = a.rel_w[id];
-        for (int id = threadIdx.x; id < 64 * nrel; id += 256) {
-            const int t = id / nrel, e = id - t * nrel;
-            dr[t * DR + e] = t0 + t < L ? bf16_to_f32(a.dQp[((long)bh * L + t0 + t) * Dq + 64 + e]) : 0.f;
+    const int L = a.L, Dq = a.Dq, ld3 = 3 * a.heads * HD;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = lane & 15, g = lane >> 4;
+    if (nrows) {
+        for (int id = threadIdx.x; id < 64 * (RT >> 1); id += 256) reinterpret_cast<uint32_t*>(rt)[id] = 0u;
+        __syncthreads();
+        for (int id = threadIdx.x; id < nrows * 64; id += 256) {
+            const int r = id >> 6, cc = id & 63;
+            rt[cc * RT + r] = f32_to_bf16(r < nh ? a.rel_h[r * 64 + cc] : a.rel_w[(r - nh) * 64 + cc]);
+        }
+        const int cpr = DRB >> 3;
+        for (int id = threadIdx.x; id < 64 * cpr; id += 256) {
+            const int t = id / cpr, ch = id - t * cpr;
+            u32x4_t v = (t0 + t < L && ch < cpr - 1) ? ld16(a.dQp + ((long)bh * L + t0 + t) * Dq + 64 + ch * 8) : zero16();
+            *reinterpret_cast<u32x4_t*>(drs + t * DRB + ch * 8) = v;
+        }
+        if (threadIdx.x < 64) {
+            const int tok = t0 + threadIdx.x, qh = tok / gw;
+            ph[threadIdx.x] = qh + gh - 1;
+            pw[threadIdx.x] = tok - qh * gw + gw - 1;
         }
     }
     __syncthreads();
-    for (int id = threadIdx.x; id < 64 * 64; id += 256) {
-        const int t = id >> 6, d = id & 63, tok = t0 + t;
-        if (tok >= L) continue;
-        float v = a.scale * bf16_to_f32(a.dQp[((long)bh * L + tok) * Dq + d]);
-        if (rel) {
-            const int qh = tok / gw, qw = tok - qh * gw;
-            const float* drr = dr + t * DR;
-            for (int kh = 0; kh < gh; ++kh) v += drr[kh] * th[(qh - kh + gh - 1) * QROW + d];
-            for (int kw = 0; kw < gw; ++kw) v += drr[gh + kw] * tw[(qw - kw + gw - 1) * QROW + d];
+    const int t = 16 * wave + c, tok = t0 + t;           // wave w owns tokens 16w .. 16w+15 (MFMA columns)
+    f32x4_t acc[4];
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb) acc[cb] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    if (nrows) {
+        const int p_h = ph[t], p_w = pw[t];
+        const bf16_t* drow = drs + t * DRB;
+        for (int ks = 0; ks < nks; ++ks) {
+            unsigned short e[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int r = 32 * ks + 8 * g + j;
+                const bool is_h = r < nh;
+                const int k = is_h ? p_h - r : p_w - (r - nh);
+                const bool ok = r < nrows && k >= 0 && k < (is_h ? gh : gw);
+                e[j] = drow[ok ? (is_h ? k : gh + k) : zero_col];
+            }
+            const u32x4_t ef = {e[0] | ((unsigned)e[1] << 16), e[2] | ((unsigned)e[3] << 16), e[4] | ((unsigned)e[5] << 16),
+                                e[6] | ((unsigned)e[7] << 16)};
+#pragma unroll
+            for (int cb = 0; cb < 4; ++cb) acc[cb] = mma(ld16(rt + (16 * cb + c) * RT + 32 * ks + 8 * g), ef, acc[cb]);
         }
-        a.dqkv[((long)b * L + tok) * ld3 + h * HD + d] = f32_to_bf16(v);
+    }
+    if (tok < L) {
+        const bf16_t* src = a.dQp + ((long)bh * L + tok) * Dq;
+        bf16_t* dst = a.dqkv + ((long)b * L + tok) * ld3 + h * HD;
+#pragma unroll
+        for (int cb = 0; cb < 4; ++cb) {
+            float v[4];
+            load4(src + 16 * cb + 4 * g, v);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[i] = a.scale * v[i] + acc[cb][i];
+            store4(dst + 16 * cb + 4 * g, v);
+        }
     }
 }
 
@@ -775,7 +843,8 @@ extern "C" int aldi_attn_prepare(const aldi_attn_args* p, aldi_stream_t stream) 
     a.Qp = (bf16_t*)p->Qp; a.Kp = (bf16_t*)p->Kp; a.KpT = (bf16_t*)p->KpT; a.VT = (bf16_t*)p->VT; a.QsT = (bf16_t*)p->QsT;
     a.nB = p->nB; a.L = p->gh * p->gw; a.Lp = (a.L + 63) / 64 * 64; a.heads = p->heads; a.Dq = p->Dq; a.gh = p->gh; a.gw = p->gw;
     a.scale = p->scale;
-    const size_t lds = (size_t)(64 + 2 * p->gh - 1 + 2 * p->gw - 1) * QROW * 4 + (size_t)(2 * 64 * 64 + 64 * p->Dq) * 2;
+    const int nrb = p->rel_h ? (2 * p->gh - 1 + 2 * p->gw - 1 + 15) / 16 : 0;
+    const size_t lds = (size_t)(64 * TROW + nrb * 16 * TROW + 2 * 64 * 64 + 64 * p->Dq) * 2 + 128 * 4;
     if (int e = set_lds(attn_prep_kernel, lds)) return e;
     hipLaunchKernelGGL(attn_prep_kernel, dim3(a.Lp / 64, a.nB * a.heads), dim3(256), lds, (hipStream_t)stream, a);
     ALDI_CHECK_LAUNCH();
@@ -799,9 +868,9 @@ extern "C" int aldi_attn_backward(const aldi_attn_args* p, aldi_stream_t stream)
     RbwdDev r{};
     r.qkv = a.qkv; r.dQp = a.dQp; r.rel_h = p->rel_h; r.rel_w = p->rel_w; r.dqkv = a.dqkv; r.drel_h = p->drel_h; r.drel_w = p->drel_w;
     r.nB = a.nB; r.L = a.L; r.heads = a.heads; r.Dq = a.Dq; r.gh = p->gh; r.gw = p->gw; r.scale = p->scale;
-    const int ntiles = a.Lp / 64, nrel = p->gh + p->gw, ntab = 2 * p->gh - 1 + 2 * p->gw - 1;
+    const int ntiles = a.Lp / 64, ntab = 2 * p->gh - 1 + 2 * p->gw - 1;
     r.tiles_per_block = ntiles > 8 ? 8 : ntiles;
-    const size_t lds_q = (size_t)ntab * QROW * 4 + (size_t)64 * (nrel + 1) * 4;
+    const size_t lds_q = p->rel_h ? (size_t)(64 * ((ntab + 31) / 32 * 32 + 8) + 64 * (a.Dq - 64 + 8)) * 2 + 128 * 4 : 16;
     if (int e = set_lds(attn_rel_dq_kernel, lds_q)) return e;
     hipLaunchKernelGGL(attn_rel_dq_kernel, dim3(ntiles, a.nB * a.heads), dim3(256), lds_q, st, r);
     ALDI_CHECK_LAUNCH();
