@@ -137,13 +137,15 @@ class Attention:
         self.nB, self.gh, self.gw, self.heads, self.rel = nB, gh, gw, heads, rel
         self.L = gh * gw
         self.Lp = (self.L + 63) // 64 * 64
-        self.Dq = ((64 + gh + gw) if rel else 64) + 31 >> 5 << 5
+        dq, tiled, vtc = C.c_int(), C.c_int(), C.c_long()
+        L.call("aldi_attn_layout", gh, gw, int(rel), C.byref(dq), C.byref(tiled), C.byref(vtc))
+        self.Dq, self.tiled = dq.value, bool(tiled.value)
         BH = nB * heads
         bf = dict(dtype=torch.bfloat16, device=device)
         self.Qp = torch.empty((BH, self.L, self.Dq), **bf)
         self.Kp = torch.empty((BH, self.L, self.Dq), **bf)
         self.KpT = torch.empty((BH, self.Dq, self.Lp), **bf)
-        self.VT = torch.empty((BH, 64, self.Lp), **bf)
+        self.VT = torch.empty((BH, 64, vtc.value), **bf)
         self.QsT = torch.empty((BH, 64, self.Lp), **bf)
         self.dOT = torch.empty((BH, 64, self.Lp), **bf)
         self.dQp = torch.empty((BH, self.L, self.Dq), **bf)

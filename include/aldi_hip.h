@@ -321,8 +321,9 @@ int aldi_adamw_step(float* p, const float* g, float* m, float* v, void* p_comput
                     float eps, float weight_decay, int step, float grad_scale, int dtype, aldi_stream_t stream);
 
 /* Attention with decomposed relative position bias, head dim 64, bf16.  nB = images x windows, each a gh x gw token grid
- * (L = gh*gw, Lp = L rounded up to 64); Dq = 64 + gh + gw rounded up to 32 (64 when rel_h == NULL), at most 256.
- * Workspaces: Qp, Kp, dQp [nB*heads][L][Dq]; KpT [nB*heads][Dq][Lp]; VT, QsT, dOT [nB*heads][64][Lp]; lse, delta [nB*heads][L]. */
+ * (L = gh*gw, Lp = L rounded up to 64); Dq from aldi_attn_layout (64 + gh + gw rounded up to 32 on small grids; 64 when rel_h == NULL),
+ * at most 256.  Workspaces: Qp, Kp, dQp [nB*heads][L][Dq]; KpT [nB*heads][Dq][Lp]; VT [nB*heads][64][vt_cols]; QsT, dOT [nB*heads][64][Lp];
+ * lse, delta [nB*heads][L]. */
 typedef struct {
     const void* qkv;        /* [nB*L][3*heads*64]: q | k | v                                   */
     const float* rel_h;     /* [2*gh-1][64] fp32 (already resized to this grid), nullable      */
@@ -338,6 +339,9 @@ typedef struct {
     int nB, gh, gw, heads, Dq;
     float scale;            /* head_dim ** -0.5                                                */
 } aldi_attn_args;
+/* layout the kernels use for a gh x gw grid: Dq, whether the tiled path (8x8 key blocks: Dq = 64 + ceil8(gh) + ceil8(gw) rounded to 32)
+ * is taken, and the number of columns VT must provide per (image, head, channel) row (>= Lp) */
+int aldi_attn_layout(int gh, int gw, int rel, int* Dq, int* tiled, long* vt_cols);
 int aldi_attn_prepare(const aldi_attn_args* a, aldi_stream_t stream);
 int aldi_attn_forward(const aldi_attn_args* a, aldi_stream_t stream);
 int aldi_attn_backward(const aldi_attn_args* a, aldi_stream_t stream);

@@ -204,7 +204,10 @@ def _attn_reference(qkv, rel_h, rel_w, nB, gh, gw, heads):
 @pytest.mark.parametrize("nB,gh,gw,heads,rel", [
     (6, 14, 14, 3, True),       # ViTDet window (L = 196: one block per window-head)
     (2, 10, 13, 2, True),       # small global grid, ragged tiles
-    (1, 50, 84, 2, True),       # the cfg-4 global grid: 4200 tokens, Dq = 224
+    (1, 50, 84, 2, True),       # the cfg-4 global grid: 4200 tokens; tiled path (8x8 key blocks), Dq = 224 columns of Q'
+    (2, 17, 23, 2, True),       # tiled path, ragged last row / column of key blocks, two images
+    (1, 16, 24, 3, True),       # tiled path, grid an exact multiple of the 8x8 blocks
+    (2, 33, 7, 1, True),        # tiled path, a single ragged column of blocks
     (2, 9, 20, 2, False),       # no relative positions
     (3, 4, 5, 1, True),         # L < 64
 ])
