@@ -972,11 +972,12 @@ __global__ __launch_bounds__(256) void attn_bwd_dq2d_kernel(AttnDev a) {
     bf16_t* KTs = Ks + 64 * TROW;                             // [64 d][TROW]     k^T
     bf16_t* Vs = KTs + 64 * TROW;                             // [64 slots][TROW] v rows
     const int NB = a.Dq - 64;                                 // bias columns (h block, w block, zero padding)
-    float* accB = reinterpret_cast<float*>(Vs + 64 * TROW);  // [128 q][NB]
+    const int NBP = NB + 1;                                   // odd row stride: the 16 queries of a lane group fall into different banks
+    float* accB = reinterpret_cast<float*>(Vs + 64 * TROW);  // [128 q][NBP]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = lane & 15, g = lane >> 4;
     const int bh = blockIdx.y, b = bh / a.heads, h = bh - b * a.heads;
     const int L = a.L, Dq = a.Dq, q0 = blockIdx.x * 128 + wave * 32, ld3 = 3 * a.heads * HD, ld1 = a.heads * HD;
-    for (int i = threadIdx.x; i < 128 * NB; i += 256) accB[i] = 0.f;
+    for (int i = threadIdx.x; i < 128 * NBP; i += 256) accB[i] = 0.f;
     u32x4_t qf[2][2], dof[2][2], oh[4], ohT[2];
     const bf16_t* qrow[2];
     float lse[2], dl[2];
@@ -1076,7 +1077,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq2d_kernel(AttnDev a) {
         const int col0 = g < 2 ? 8 * th + 4 * g : a.wofs + 8 * tw + 4 * (g - 2);
 #pragma unroll
         for (int qb = 0; qb < 2; ++qb) {
-            float* row = accB + (wave * 32 + 16 * qb + c) * NB + col0;
+            float* row = accB + (wave * 32 + 16 * qb + c) * NBP + col0;
 #pragma unroll
             for (int i = 0; i < 4; ++i) row[i] += db16[qb][i];
         }
@@ -1098,7 +1099,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq2d_kernel(AttnDev a) {
     // this wave's 32 rows of bias-column gradients (only this wave touched them)
     for (int idx = lane; idx < 32 * (NB >> 2); idx += 64) {
         const int qi = idx / (NB >> 2), c4 = (idx - qi * (NB >> 2)) * 4, q = q0 + qi;
-        if (q < L) store4(a.dQp + ((long)bh * L + q) * Dq + 64 + c4, accB + (wave * 32 + qi) * NB + c4);
+        if (q < L) store4(a.dQp + ((long)bh * L + q) * Dq + 64 + c4, accB + (wave * 32 + qi) * NBP + c4);
     }
 }
 
@@ -1304,7 +1305,7 @@ int dispatch_fwd(const AttnDev& a, int tiled, hipStream_t st) {
 }
 int dispatch_bwd(const AttnDev& a, int tiled, hipStream_t st) {
     if (tiled) {
-        const size_t lds_q = (size_t)3 * 64 * TROW * 2 + (size_t)128 * (a.Dq - 64) * 4;
+        const size_t lds_q = (size_t)3 * 64 * TROW * 2 + (size_t)128 * (a.Dq - 64 + 1) * 4;
         if (int e = set_lds(attn_bwd_dq2d_kernel, lds_q)) return e;
         hipLaunchKernelGGL(attn_bwd_dq2d_kernel, dim3(cdiv(a.L, 128), a.nB * a.heads), dim3(256), lds_q, st, a);
         ALDI_CHECK_LAUNCH();
