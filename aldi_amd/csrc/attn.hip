@@ -440,7 +440,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnDev a) {
 struct PrepDev {
     const bf16_t* qkv; const float *rel_h, *rel_w;
     bf16_t *Qp, *Kp, *KpT, *VT, *QsT;
-    int nB, L, Lp, heads, Dq, gh, gw, wofs, tiled; float scale;
+    int nB, L, Lp, heads, Dq, gh, gw, wofs, tiled, tiles_per_block; float scale;
 };
 __global__ __launch_bounds__(256) void attn_prep_kernel(PrepDev a) {
     extern __shared__ __align__(16) unsigned char smem[];
@@ -451,9 +451,21 @@ __global__ __launch_bounds__(256) void attn_prep_kernel(PrepDev a) {
     bf16_t* qp = kv + 2 * 64 * 64;                      // [64][Dq] finished Q' rows (for the transposes)
     int* ph = reinterpret_cast<int*>(qp + 64 * a.Dq);   // [64] qh(t) + gh - 1
     int* pw = ph + 64;                                  // [64] qw(t) + gw - 1
-    const int bh = blockIdx.y, b = bh / a.heads, h = bh - b * a.heads, t0 = blockIdx.x * 64;
+    const int bh = blockIdx.y, b = bh / a.heads, h = bh - b * a.heads;
     const int L = a.L, Dq = a.Dq, ld3 = 3 * a.heads * HD, ld1 = a.heads * HD;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = lane & 15, g = lane >> 4;
+    for (int id = threadIdx.x; id < nrb * 16 * 16; id += 256) {           // tables fp32 -> bf16 (autocast would feed the einsum fp16)
+        const int r = id >> 4, c4 = (id & 15) * 4;
+        float v[4] = {0.f, 0.f, 0.f, 0.f};
+        if (r < nrows) load4((r < nh ? a.rel_h + r * 64 : a.rel_w + (r - nh) * 64) + c4, v);
+        store4(tab + r * TROW + c4, v);
+    }
+    // several 64-token tiles of one (image, head) per block: the tables are converted once
+    for (int ti = 0; ti < a.tiles_per_block; ++ti) {
+    const int tile = blockIdx.x * a.tiles_per_block + ti;
+    if (tile * 64 >= a.Lp) break;
+    const int t0 = tile * 64;
+    __syncthreads();
     for (int id = threadIdx.x; id < 64 * 8; id += 256) {                 // q, k, v rows of this tile, 16 B at a time
         const int t = id >> 3, ch = id & 7;
         const bool ok = t0 + t < L;
@@ -461,12 +473,6 @@ __global__ __launch_bounds__(256) void attn_prep_kernel(PrepDev a) {
         *reinterpret_cast<u32x4_t*>(qb + t * TROW + ch * 8) = ok ? ld16(row) : zero16();
         *reinterpret_cast<u32x4_t*>(kv + t * 64 + ch * 8) = ok ? ld16(row + ld1) : zero16();
         *reinterpret_cast<u32x4_t*>(kv + 64 * 64 + t * 64 + ch * 8) = ok ? ld16(row + 2 * ld1) : zero16();
-    }
-    for (int id = threadIdx.x; id < nrb * 16 * 16; id += 256) {           // tables fp32 -> bf16 (autocast would feed the einsum fp16)
-        const int r = id >> 4, c4 = (id & 15) * 4;
-        float v[4] = {0.f, 0.f, 0.f, 0.f};
-        if (r < nrows) load4((r < nh ? a.rel_h + r * 64 : a.rel_w + (r - nh) * 64) + c4, v);
-        store4(tab + r * TROW + c4, v);
     }
     if (threadIdx.x < 64) {
         const int tok = t0 + threadIdx.x, qh = tok / gw;
@@ -564,6 +570,7 @@ __global__ __launch_bounds__(256) void attn_prep_kernel(PrepDev a) {
         }
         u32x4_t o = {v[0] | ((unsigned)v[1] << 16), v[2] | ((unsigned)v[3] << 16), v[4] | ((unsigned)v[5] << 16), v[6] | ((unsigned)v[7] << 16)};
         *reinterpret_cast<u32x4_t*>(dst) = o;
+    }
     }
 }
 
@@ -1338,7 +1345,8 @@ extern "C" int aldi_attn_prepare(const aldi_attn_args* p, aldi_stream_t stream) 
     const int nrb = p->rel_h ? (2 * p->gh - 1 + 2 * p->gw - 1 + 15) / 16 : 0;
     const size_t lds = (size_t)(64 * TROW + nrb * 16 * TROW + 2 * 64 * 64 + 64 * p->Dq) * 2 + 128 * 4;
     if (int e = set_lds(attn_prep_kernel, lds)) return e;
-    hipLaunchKernelGGL(attn_prep_kernel, dim3(a.Lp / 64, a.nB * a.heads), dim3(256), lds, (hipStream_t)stream, a);
+    a.tiles_per_block = a.Lp / 64 >= 16 ? 4 : 1;      // long sequences: amortise the table conversion (68 KB of fp32 per block on 50 x 84)
+    hipLaunchKernelGGL(attn_prep_kernel, dim3(cdiv(a.Lp / 64, a.tiles_per_block), a.nB * a.heads), dim3(256), lds, (hipStream_t)stream, a);
     ALDI_CHECK_LAUNCH();
     if (l.tiled) {
         const AttnDev d = to_dev(p);
