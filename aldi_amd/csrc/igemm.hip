@@ -593,15 +593,26 @@ int dispatch(ConvDev& d, hipStream_t st) {
     static const int big_tile_k = env_int("ALDI_IGEMM_BIGTILE_K", 1024);
     // 3x3 / stride 1 / pad 1 (every 3x3 of the network): halo form, the pixel tile is loaded once per three taps
     static const int halo_env = env_int("ALDI_IGEMM_HALO", 1);
+    static const int force = env_int("ALDI_IGEMM_FORCE", 0);     // experiments: 1 = 128x128, 2 = 128x64, 3 = 64x64, 4 = 256x128
     if constexpr (sizeof(T) == 2) {
         const bool same3 = d.KH == 3 && d.KW == 3 && d.stride == 1 && d.pad == 1 && d.Ho == d.H && d.Wo == d.W && d.Cin % 32 == 0 && d.out_scale == 1;
         if (halo_env && same3) {
+            if (force == 1) return launch<T, 128, 128, 2, 2, 4, false, true>(d, st);
+            if (force == 2) return launch<T, 128, 64, 4, 1, 4, false, true>(d, st);
+            if (force == 4) return launch<T, 256, 128, 4, 2, 4, false, true>(d, st);
             if (d.Cout <= 64) return launch<T, 128, 64, 4, 1, 4, false, true>(d, st);
             if (big >= big_tile_min) return launch<T, 256, 128, 4, 2, 4, false, true>(d, st);
-            return launch<T, 128, 128, 2, 2, 4, false, true>(d, st);
+            // below ~1000 128x128 tiles the tile count of this network sits just above a multiple of the 256 CUs (16800 pixels =
+            // 131.25 row tiles: 264 / 528 tiles) and the last partial round costs as much as a full one; half-width tiles halve that
+            // tail (measured 8-25 % faster on every res3..res5 / FPN p3..p6 3x3 at N = 2 and 4)
+            return launch<T, 128, 64, 4, 1, 4, false, true>(d, st);
         }
     }
     if (d.Cout <= 16) return launch<T, 128, 16, 4, 1, 4>(d, st);
+    if (force == 1) return launch<T, 128, 128, 2, 2, 4>(d, st);
+    if (force == 2) return launch<T, 128, 64, 4, 1, 4>(d, st);
+    if (force == 3) return launch<T, 64, 64, 2, 2, 4>(d, st);
+    if (force == 4) return launch<T, 256, 128, 4, 2, 4, false>(d, st);
     if (d.Cout <= 64) return launch<T, 128, 64, 4, 1, 4>(d, st);
     if (tile_env != 9 && big >= big_tile_min && d.K >= big_tile_k) return launch<T, 256, 128, 4, 2, 4, false>(d, st);
     if (big < 200) return launch<T, 64, 64, 2, 2, 4>(d, st);

@@ -11,6 +11,9 @@ import sqlite3
 import sys
 
 
+delim, per_step = "sgd_kernel", "1"        # step-closing optimizer kernel (gaps / overlap / phases use the R50 defaults)
+
+
 def stats(d, title, delim="sgd_kernel", per_step="1"):
     """per-kernel table of ONE step: the launches between the last two step-closing optimizer launches (`delim` kernel,
     `per_step` of them per step)"""
