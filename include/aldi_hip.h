@@ -346,6 +346,20 @@ int aldi_attn_prepare(const aldi_attn_args* a, aldi_stream_t stream);
 int aldi_attn_forward(const aldi_attn_args* a, aldi_stream_t stream);
 int aldi_attn_backward(const aldi_attn_args* a, aldi_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------------------------------
+ * Multi-scale deformable attention sampling (Deformable-DETR; BASELINE configs[4]), fp32.
+ * Replaces MSDeformAttnFunction.apply(value, spatial_shapes, level_start_index, sampling_locations, attention_weights,
+ * im2col_step) of the reference's absent aldi/detr/libs submodule (.gitmodules:4-6; configs/Base-DETR.yaml:1-81).
+ * value [N][S][M][D] (S = sum_l H_l*W_l, D = 32 or 64); spatial_shapes int[L][2] = (H, W); level_start_index int[L];
+ * sampling_loc [N][Lq][M][L][P][2] = (x, y) in [0, 1]; attn_weight [N][Lq][M][L][P]; out [N][Lq][M*D].
+ * backward: grad_value is zeroed and accumulated (fp32 atomics); grad_sampling_loc / grad_attn_weight are fully written.
+ * ------------------------------------------------------------------------------------------------------------------ */
+int aldi_ms_deform_attn_forward(const float* value, const int* spatial_shapes, const int* level_start_index, const float* sampling_loc,
+                                const float* attn_weight, float* out, int N, int S, int M, int D, int Lq, int L, int P, aldi_stream_t stream);
+int aldi_ms_deform_attn_backward(const float* value, const int* spatial_shapes, const int* level_start_index, const float* sampling_loc,
+                                 const float* attn_weight, const float* grad_out, float* grad_value, float* grad_sampling_loc,
+                                 float* grad_attn_weight, int N, int S, int M, int D, int Lq, int L, int P, aldi_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif
