@@ -227,6 +227,18 @@ class ParamLayout:
                     sd[f"{name}.norm.{f}"] = tmp[f"{name}.norm.{f}"]
         return sd
 
+    def ranges(self, names) -> List[Tuple[int, int]]:
+        """flat-buffer element ranges (weights + biases) of engine tensors, padded extents: the layout rounds every tensor up to 64
+        elements and the padding never receives gradient, so neighbouring layers merge into ONE contiguous range and nothing is left
+        between them for the gradient exchange to reduce piecemeal"""
+        out = []
+        for n in names:
+            p = self.t[n]
+            out.append((p.w_off, p.w_off + pad_to(p.rows * p.kk * p.kk * p.cin, 64)))
+            if p.bias:
+                out.append((p.b_off, p.b_off + pad_to(p.rows, 64)))
+        return out
+
     def state_dict_keys(self) -> List[str]:
         keys = []
         for name, c in self.d2.items():

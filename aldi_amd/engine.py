@@ -976,14 +976,7 @@ class RCNN:
         if cb is None:
             return
         self._join_wgrads()
-        t = self.wts.layout.t
-        ranges = []
-        for n in names:
-            p = t[n]
-            ranges.append((p.w_off, p.w_off + p.rows * p.kk * p.kk * p.cin))
-            if p.bias:
-                ranges.append((p.b_off, p.b_off + p.rows))
-        cb(ranges)
+        cb(self.wts.layout.ranges(names))
 
     def _wgrad(self, name: str, x: torch.Tensor, g: torch.Tensor):
         """weight (+ bias) gradient of one layer.  The data-gradient chain never reads these results, so they run on a

@@ -237,6 +237,21 @@ class VitParams:
         o, n = self.pack_off[name]
         return buf[o:o + n].view(shape)
 
+    def ranges(self, names) -> List[Tuple[int, int]]:
+        """flat-buffer element ranges of the given state_dict names (full names), for the overlapped gradient exchange.  Extents
+        include the 64-element layout padding (never written) so that neighbouring tensors merge into one contiguous range"""
+        packed = {m: pk for pk, (members, _) in self.cfg.packs().items() for m in members}
+        out = []
+        for n in names:
+            if n in packed:
+                o, tot = self.pack_off[packed[n]]
+                r = (o, o + _pad64(tot))
+            else:
+                r = (self.off[n], self.off[n] + _pad64(self._numel(n)))
+            if r not in out:
+                out.append(r)
+        return out
+
     def state_dict_keys(self) -> List[str]:
         return list(self.spec.keys())
 
@@ -371,6 +386,7 @@ class ViT:
         self.cfg = params.cfg
         self.device = params.device
         self._geom: Dict[Tuple[int, int, int], dict] = {}
+        self.grad_ready = None           # callback(ranges): data-parallel overlapped exchange (reduce.BucketedReducer.ready)
 
     def geometry(self, N: int, gh: int, gw: int) -> dict:
         key = (N, gh, gw)
@@ -522,6 +538,8 @@ class ViT:
             dy1 = self._linear_bwd(s.y1, dqkv, b + "attn.qkv")
             g = V.layernorm_backward(dy1, s.x, p.m(b + "norm1.weight"), s.mean1, s.rstd1, p.g(b + "norm1.weight"), p.g(b + "norm1.bias"),
                                      row_map=None if glob else geo["win"], res=dx1)
+            if self.grad_ready is not None:                     # this block's gradients are final: the exchange may start on them
+                self.grad_ready(p.ranges([n for n in p.spec if n.startswith(f"{c.prefix}blocks.{i}.")]))
         # ---- embeddings
         G = c.pretrain_grid
         dpos = V.sum_batch(g, N).view(gh, gw, E)
@@ -531,6 +549,8 @@ class ViT:
         else:
             gpos += dpos
         self._linear_bwd_patch(ctx.patches, g)
+        if self.grad_ready is not None:
+            self.grad_ready(p.ranges([c.prefix + "pos_embed", c.prefix + "patch_embed.proj.weight", c.prefix + "patch_embed.proj.bias"]))
 
     def _linear_bwd_patch(self, patches, g):
         T = patches.shape[0]

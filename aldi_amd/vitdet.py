@@ -161,8 +161,17 @@ class VitDetRCNN(RCNN):
         ops.subsample2_bwd(gP[4], gP[3])                               # p6 = p5[:, ::2, ::2]
         for l in range(4):
             ops.add_f32(gP[l], gP_roi[l], gP[l])
+        cb = getattr(self, "grad_ready", None)
+        if cb is not None:                                             # heads are final: start their exchange under the trunk backward
+            cb(self.vp.ranges([n for n in self.vp.spec if n.startswith(("proposal_generator.", "roi_heads."))]))
         gx = self.sfp.backward(c.sfp_ctx, gP[:4])
-        self.vit.backward(c.vit_ctx, gx.view(-1, cfg.embed))
+        if cb is not None:
+            cb(self.vp.ranges([n for n in self.vp.spec if n.startswith("backbone.simfp_")]))
+        self.vit.grad_ready = cb
+        try:
+            self.vit.backward(c.vit_ctx, gx.view(-1, cfg.embed))
+        finally:
+            self.vit.grad_ready = None
 
     def _grads_final(self, names):
         return

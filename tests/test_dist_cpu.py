@@ -99,3 +99,56 @@ def test_range_helpers():
     assert complement([(5, 9), (0, 3)], 12) == [(3, 5), (9, 12)]
     assert complement([], 4) == [(0, 4)]
     assert complement([(0, 4)], 4) == []
+
+
+def _count_collectives(n, reports):
+    """run BucketedReducer's bookkeeping over a sequence of ready() reports with the collective stubbed out"""
+    from aldi_amd.reduce import BucketedReducer
+
+    class Counting(BucketedReducer):
+        def __init__(self, n_):
+            self.n_, self.done, self.pending, self.works, self.sizes = n_, [], [], [], []
+
+        def _launch(self, lo, hi):
+            self.sizes.append(hi - lo)
+            self.done.append((lo, hi))
+
+        def finish(self):
+            from aldi_amd.reduce import complement
+            for lo, hi in complement(self.done, self.n_):
+                self._launch(lo, hi)
+    r = Counting(n)
+    for rep in reports:
+        r.ready(rep)
+    r.finish()
+    return r.sizes
+
+
+def test_exchange_launches_few_large_collectives():
+    """the overlapped exchange must not dissolve into hundreds of latency-bound collectives: reported ranges carry their layout
+    padding, so each layer group is ONE contiguous range and finish() has only the never-reported remainder left"""
+    from aldi_amd.arch import STAGE_BLOCKS, ParamLayout
+    lay = ParamLayout(8)
+    bu = "backbone.bottom_up."
+    groups = [["box_pred", "roi_heads.box_head.fc2", "roi_heads.box_head.fc1"],
+              ["rpn_head_out", "proposal_generator.rpn_head.conv"] + [f"backbone.fpn_output{l}" for l in (2, 3, 4, 5)] + [f"backbone.fpn_lateral{l}" for l in (2, 3, 4, 5)]]
+    for si in (3, 2, 1):
+        names = []
+        for b in range(STAGE_BLOCKS[si]):
+            p = f"{bu}res{si + 2}.{b}."
+            names += [p + "conv3", p + "conv2", p + "conv1"] + ([p + "shortcut"] if b == 0 else [])
+        groups.append(names)
+    sizes = _count_collectives(lay.n_train, [lay.ranges(g) for g in groups])
+    assert sum(sizes) == lay.n_train and len(sizes) <= 12, (len(sizes), sorted(sizes)[:10])
+    assert min(sizes) >= 4096 or len(sizes) <= 8
+
+    from aldi_amd.vit import VitConfig, VitParams
+    cfg = VitConfig(sfp=True, num_classes=8)
+    P = VitParams(cfg, "cpu")
+    reports = [P.ranges([n for n in P.spec if n.startswith(("proposal_generator.", "roi_heads."))]),
+               P.ranges([n for n in P.spec if n.startswith("backbone.simfp_")])]
+    for i in reversed(range(cfg.depth)):
+        reports.append(P.ranges([n for n in P.spec if n.startswith(f"{cfg.prefix}blocks.{i}.")]))
+    reports.append(P.ranges([cfg.prefix + "pos_embed", cfg.prefix + "patch_embed.proj.weight", cfg.prefix + "patch_embed.proj.bias"]))
+    sizes = _count_collectives(P.n, reports)
+    assert sum(sizes) == P.n and len(sizes) <= 20, (len(sizes), sorted(sizes)[:10])

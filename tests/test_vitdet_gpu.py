@@ -252,3 +252,43 @@ def test_vitdet_fused_step_equals_sequential():
         assert abs(lf[k] - ls[k]) < 2e-2 * max(1.0, abs(ls[k])), (k, lf[k], ls[k])
     gf, gs = out[True][1], out[False][1]
     assert ((gf - gs).norm() / gs.norm()).item() < 3e-2
+
+
+def test_vitdet_overlapped_exchange_reports_final_gradients():
+    """data-parallel fused step on ViTDet: heads, SimpleFeaturePyramid, every transformer block (last to first) and the embeddings
+    are reported to the gradient exchange as soon as their backward is enqueued; each reported range already holds its FINAL
+    value in stream order, no range is reported twice, and together they cover every parameter"""
+    import random
+    from aldi_amd.reduce import complement, merge_ranges
+    from aldi_amd.trainer import ALDITrainer
+    cfg = _trainer_cfg(True)
+    random.seed(0)
+    torch.manual_seed(5)
+    tr = ALDITrainer(cfg)
+    tr.iter = 0
+    tr.before_step()
+    t = tr._trainer
+    data = next(t._data_loader_iter)
+    t.optimizer.zero_grad()
+    W = tr.model.weights
+    snaps = []
+
+    def ready(ranges):
+        for lo, hi in ranges:
+            snaps.append((lo, hi, W.grad[lo:hi].clone()))            # stream-ordered snapshot
+
+    tr.model.engine.grad_ready = ready
+    try:
+        t.run_model(data)
+    finally:
+        tr.model.engine.grad_ready = None
+    torch.cuda.synchronize()
+    assert t._fused_done and len(snaps) > 60
+    spans = sorted((lo, hi) for lo, hi, _ in snaps)
+    for (a0, a1), (b0, b1) in zip(spans[:-1], spans[1:]):
+        assert a1 <= b0, "a range was reported twice"
+    for lo, hi, g in snaps:
+        assert torch.equal(g, W.grad[lo:hi]), (lo, hi)
+    # the unreported remainder is layout padding only
+    rest = complement(merge_ranges(spans), W.n)
+    assert all(float(W.grad[lo:hi].abs().sum()) == 0.0 for lo, hi in rest)
