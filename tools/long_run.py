@@ -1,13 +1,15 @@
 import sys, os, json, subprocess
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, time, random
 import bench
 from aldi_amd import synthetic as syn
 from aldi_amd.trainer import ALDITrainer
-cfg = bench.make_cfg(1, 800, 1333, False); cfg.SOLVER.FUSED_STEP = True
+wl = sys.argv[1] if len(sys.argv) > 1 else "r50_fpn"          # or vitdet_b
+cfg = bench.make_cfg(1, 800, 1333, False, wl); cfg.SOLVER.FUSED_STEP = True
 random.seed(1234); torch.manual_seed(100)
 tr = ALDITrainer(cfg)
-data = syn.make_batch(2, 2, 800, 1333, 8, seed=100)
+per = 1 if wl == "vitdet_b" else 2
+data = syn.make_batch(per, per, 800, 1333, 8, seed=100)
 tr._trainer.data_loader = bench.FixedGpuLoader(data, torch.device("cuda"))
 tr.iter = 0
 def one():
