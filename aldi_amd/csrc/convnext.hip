@@ -1,0 +1,206 @@
+// ConvNeXt-specific kernels (reference aldi/backbone.py:189-225, ConvNextBlock): depthwise 7x7 convolution (forward,
+// data gradient = the same kernel with the taps flipped, weight gradient) and the layer-scale residual
+// out = x + s * gamma (.) y with its backward.  NHWC, 8 channels (16 B of bf16) per lane; the pointwise layers, LayerNorm and GELU
+// of the block run on the igemm / LayerNorm / GELU kernels.
+//
+// First versions: every output vector re-reads its 49 input vectors through L1/L2 (no LDS tile), which is ~10x the
+// compulsory traffic at cache rates; the LDS-tiled form is the next step if this trunk becomes a benchmarked workload.
+#include "common.h"
+
+namespace {
+
+__device__ __forceinline__ void load8(const bf16_t* p, float v[8]) {
+    const uint4 t = *reinterpret_cast<const uint4*>(p);
+    const uint32_t w[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { v[2 * k] = __uint_as_float(w[k] << 16); v[2 * k + 1] = __uint_as_float(w[k] & 0xffff0000u); }
+}
+__device__ __forceinline__ void load8(const float* p, float v[8]) { load4(p, v); load4(p + 4, v + 4); }
+__device__ __forceinline__ void store8(bf16_t* p, const float v[8]) {
+    uint4 t;
+    t.x = pack2_bf16(v[0], v[1]); t.y = pack2_bf16(v[2], v[3]); t.z = pack2_bf16(v[4], v[5]); t.w = pack2_bf16(v[6], v[7]);
+    *reinterpret_cast<uint4*>(p) = t;
+}
+__device__ __forceinline__ void store8(float* p, const float v[8]) { store4(p, v); store4(p + 4, v + 4); }
+
+// y[n][h][w][c] = bias[c] + sum_{kh,kw} x[n][h+kh-3][w+kw-3][c] * wt[kh][kw][c]     (flip: taps mirrored, no bias: data gradient)
+template <typename T>
+__global__ __launch_bounds__(256) void dwconv7_kernel(const T* __restrict__ x, const T* __restrict__ wt, const float* __restrict__ bias,
+                                                       T* __restrict__ y, int N, int H, int W, int C, int flip) {
+    const int c8 = C >> 3;
+    const long total = (long)N * H * W * c8;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int cc = (int)(i % c8) * 8;
+        long pix = i / c8;
+        const int w0 = (int)(pix % W); pix /= W;
+        const int h0 = (int)(pix % H), n = (int)(pix / H);
+        float acc[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) acc[k] = (bias && !flip) ? bias[cc + k] : 0.f;
+        for (int kh = 0; kh < 7; ++kh) {
+            const int h = h0 + kh - 3;
+            if (h < 0 || h >= H) continue;
+#pragma unroll
+            for (int kw = 0; kw < 7; ++kw) {
+                const int w = w0 + kw - 3;
+                if (w < 0 || w >= W) continue;
+                float xv[8], wv[8];
+                load8(x + (((long)n * H + h) * W + w) * C + cc, xv);
+                load8(wt + ((flip ? (6 - kh) * 7 + (6 - kw) : kh * 7 + kw) * (long)C) + cc, wv);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) acc[k] += xv[k] * wv[k];
+            }
+        }
+        store8(y + i * 8, acc);
+    }
+}
+
+// dw[kh][kw][c] += sum_{n,h,w} x[n][h+kh-3][w+kw-3][c] * g[n][h][w][c]; one block = (pixel chunk, 8-channel group, kernel row kh):
+// each thread keeps the 7 taps of its row for 8 channels, the block reduces through LDS, one atomic per (tap, channel)
+template <typename T>
+__global__ __launch_bounds__(256) void dwconv7_wgrad_kernel(const T* __restrict__ x, const T* __restrict__ g, float* __restrict__ dw, int N, int H,
+                                                             int W, int C, int pix_per_block) {
+    __shared__ float red[256 * 8];
+    const int c8 = C >> 3, cc = (blockIdx.y % c8) * 8, kh = blockIdx.y / c8;
+    const long npix = (long)N * H * W, p0 = (long)blockIdx.x * pix_per_block, p1 = min(npix, p0 + pix_per_block);
+    float acc[7][8];
+#pragma unroll
+    for (int kw = 0; kw < 7; ++kw)
+#pragma unroll
+        for (int k = 0; k < 8; ++k) acc[kw][k] = 0.f;
+    for (long p = p0 + threadIdx.x; p < p1; p += 256) {
+        const int w0 = (int)(p % W), h0 = (int)((p / W) % H), n = (int)(p / ((long)W * H));
+        const int h = h0 + kh - 3;
+        if (h < 0 || h >= H) continue;
+        float gv[8];
+        load8(g + p * C + cc, gv);
+#pragma unroll
+        for (int kw = 0; kw < 7; ++kw) {
+            const int w = w0 + kw - 3;
+            if (w < 0 || w >= W) continue;
+            float xv[8];
+            load8(x + (((long)n * H + h) * W + w) * C + cc, xv);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) acc[kw][k] += xv[k] * gv[k];
+        }
+    }
+    for (int kw = 0; kw < 7; ++kw) {
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 8; ++k) red[threadIdx.x * 8 + k] = acc[kw][k];
+        __syncthreads();
+        for (int s = 128; s > 0; s >>= 1) {
+            if (threadIdx.x < s) {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) red[threadIdx.x * 8 + k] += red[(threadIdx.x + s) * 8 + k];
+            }
+            __syncthreads();
+        }
+        if (threadIdx.x < 8) atomicAdd(dw + (long)(kh * 7 + kw) * C + cc + threadIdx.x, red[threadIdx.x]);
+    }
+}
+
+// out[r][c] = x[r][c] + s(r) * gamma[c] * y[r][c]
+template <typename T>
+__global__ void scale_add_kernel(const T* __restrict__ x, const T* __restrict__ y, const float* __restrict__ gamma, const float* __restrict__ scale,
+                                 T* __restrict__ out, long rows, int C, int rows_per_sample) {
+    const int c8 = C >> 3;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < rows * c8; i += (long)gridDim.x * blockDim.x) {
+        const long r = i / c8;
+        const int cc = (int)(i - r * c8) * 8;
+        float xv[8], yv[8], o[8];
+        load8(x + i * 8, xv);
+        load8(y + i * 8, yv);
+        const float s = scale ? scale[r / rows_per_sample] : 1.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) o[k] = xv[k] + s * gamma[cc + k] * yv[k];
+        store8(out + i * 8, o);
+    }
+}
+
+// dy[r][c] = s(r) * gamma[c] * g[r][c];  dgamma[c] += sum_r s(r) * g[r][c] * y[r][c]
+template <typename T>
+__global__ __launch_bounds__(256) void scale_add_bwd_kernel(const T* __restrict__ g, const T* __restrict__ y, const float* __restrict__ gamma,
+                                                             const float* __restrict__ scale, T* __restrict__ dy, float* __restrict__ dgamma, long rows,
+                                                             int C, int rows_per_sample, int rows_per_block) {
+    const int c8 = C >> 3;
+    const long r0 = (long)blockIdx.x * rows_per_block, r1 = min(rows, r0 + rows_per_block);
+    for (int ch = threadIdx.x; ch < c8; ch += 256) {          // a thread owns channel groups; rows are walked sequentially (coalesced across threads)
+        float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, gm[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) gm[k] = gamma[ch * 8 + k];
+        for (long r = r0; r < r1; ++r) {
+            float gv[8], yv[8], o[8];
+            load8(g + (r * c8 + ch) * 8, gv);
+            load8(y + (r * c8 + ch) * 8, yv);
+            const float s = scale ? scale[r / rows_per_sample] : 1.f;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { o[k] = s * gm[k] * gv[k]; acc[k] += s * gv[k] * yv[k]; }
+            store8(dy + (r * c8 + ch) * 8, o);
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) atomicAdd(dgamma + ch * 8 + k, acc[k]);
+    }
+}
+
+inline int grid_for(long work, int block = 256) {
+    long b = (work + block - 1) / block;
+    return (int)(b < 1 ? 1 : (b > 65535 * 8 ? 65535 * 8 : b));
+}
+
+}  // namespace
+
+#define CNX_DISPATCH(dtype, f32, bf16)                                              \
+    do {                                                                            \
+        if ((dtype) == ALDI_F32) { f32; }                                           \
+        else if ((dtype) == ALDI_BF16) { bf16; }                                    \
+        else return aldi_set_error_msg(ALDI_ERR_ARG, "convnext: bad dtype");       \
+    } while (0)
+
+extern "C" int aldi_dwconv7(const void* x, const void* wt, const float* bias, void* y, int N, int H, int W, int C, int flip, int dtype,
+                            aldi_stream_t stream) {
+    if (!x || !wt || !y || C % 8 || N <= 0 || H <= 0 || W <= 0) return aldi_set_error_msg(ALDI_ERR_ARG, "dwconv7: bad args (C % 8 == 0)");
+    hipStream_t st = (hipStream_t)stream;
+    const long work = (long)N * H * W * (C / 8);
+    CNX_DISPATCH(dtype,
+        hipLaunchKernelGGL(dwconv7_kernel<float>, dim3(grid_for(work)), dim3(256), 0, st, (const float*)x, (const float*)wt, bias, (float*)y, N, H, W, C, flip),
+        hipLaunchKernelGGL(dwconv7_kernel<bf16_t>, dim3(grid_for(work)), dim3(256), 0, st, (const bf16_t*)x, (const bf16_t*)wt, bias, (bf16_t*)y, N, H, W, C, flip));
+    ALDI_CHECK_LAUNCH();
+    return ALDI_OK;
+}
+
+extern "C" int aldi_dwconv7_wgrad(const void* x, const void* g, float* dw, int N, int H, int W, int C, int dtype, aldi_stream_t stream) {
+    if (!x || !g || !dw || C % 8 || N <= 0 || H <= 0 || W <= 0) return aldi_set_error_msg(ALDI_ERR_ARG, "dwconv7_wgrad: bad args (C % 8 == 0)");
+    hipStream_t st = (hipStream_t)stream;
+    const long npix = (long)N * H * W;
+    const int ppb = npix > 256 * 64 ? (int)((npix + 63) / 64) : 256 * 4 < npix ? 256 * 4 : (int)npix;   // <= 64 pixel chunks on big maps
+    dim3 grid(cdiv(npix, ppb), (C / 8) * 7);
+    CNX_DISPATCH(dtype,
+        hipLaunchKernelGGL(dwconv7_wgrad_kernel<float>, grid, dim3(256), 0, st, (const float*)x, (const float*)g, dw, N, H, W, C, ppb),
+        hipLaunchKernelGGL(dwconv7_wgrad_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)x, (const bf16_t*)g, dw, N, H, W, C, ppb));
+    ALDI_CHECK_LAUNCH();
+    return ALDI_OK;
+}
+
+extern "C" int aldi_scale_add(const void* x, const void* y, const float* gamma, const float* scale, void* out, long rows, int C, int rows_per_sample,
+                              int dtype, aldi_stream_t stream) {
+    if (!x || !y || !gamma || !out || C % 8 || rows <= 0 || rows_per_sample <= 0) return aldi_set_error_msg(ALDI_ERR_ARG, "scale_add: bad args");
+    hipStream_t st = (hipStream_t)stream;
+    CNX_DISPATCH(dtype,
+        hipLaunchKernelGGL(scale_add_kernel<float>, dim3(grid_for(rows * (C / 8))), dim3(256), 0, st, (const float*)x, (const float*)y, gamma, scale, (float*)out, rows, C, rows_per_sample),
+        hipLaunchKernelGGL(scale_add_kernel<bf16_t>, dim3(grid_for(rows * (C / 8))), dim3(256), 0, st, (const bf16_t*)x, (const bf16_t*)y, gamma, scale, (bf16_t*)out, rows, C, rows_per_sample));
+    ALDI_CHECK_LAUNCH();
+    return ALDI_OK;
+}
+
+extern "C" int aldi_scale_add_backward(const void* g, const void* y, const float* gamma, const float* scale, void* dy, float* dgamma, long rows, int C,
+                                       int rows_per_sample, int dtype, aldi_stream_t stream) {
+    if (!g || !y || !gamma || !dy || !dgamma || C % 8 || rows <= 0 || rows_per_sample <= 0) return aldi_set_error_msg(ALDI_ERR_ARG, "scale_add_backward: bad args");
+    hipStream_t st = (hipStream_t)stream;
+    const int rpb = rows > 4096 ? (int)((rows + 1023) / 1024) : 4;
+    CNX_DISPATCH(dtype,
+        hipLaunchKernelGGL(scale_add_bwd_kernel<float>, dim3(cdiv(rows, rpb)), dim3(256), 0, st, (const float*)g, (const float*)y, gamma, scale, (float*)dy, dgamma, rows, C, rows_per_sample, rpb),
+        hipLaunchKernelGGL(scale_add_bwd_kernel<bf16_t>, dim3(cdiv(rows, rpb)), dim3(256), 0, st, (const bf16_t*)g, (const bf16_t*)y, gamma, scale, (bf16_t*)dy, dgamma, rows, C, rows_per_sample, rpb));
+    ALDI_CHECK_LAUNCH();
+    return ALDI_OK;
+}

@@ -208,10 +208,17 @@ class VitParams:
     def nhwc(self, name: str) -> bool:
         """conv [Cout,Cin,k,k] / deconv [Cin,Cout,2,2] weights live as [d0][k][k][d1] in the flat buffers (the kernels' layout);
         the patch embedding stays (c, ph, pw): that is the order aldi_patchify emits."""
-        return len(self.spec[name][0]) == 4 and "patch_embed" not in name
+        return len(self.spec[name][0]) == 4 and "patch_embed" not in name and not self.depthwise(name) and \
+            not name.endswith("downsample_layers.0.0.weight")      # ConvNeXt's 4x4/4 stem runs on patch rows, like patch_embed
+
+    def depthwise(self, name: str) -> bool:
+        """ConvNeXt depthwise kernels [C,1,7,7] live as [7,7,C] (what aldi_dwconv7 reads)"""
+        return name.endswith("dwconv.weight")
 
     def shape(self, name: str):
         sh = self.spec[name][0]
+        if self.depthwise(name):
+            return (sh[2], sh[3], sh[0])
         return (sh[0], sh[2], sh[3], sh[1]) if self.nhwc(name) else sh
 
     def _view(self, buf, name, shape=None):
@@ -294,6 +301,8 @@ class VitParams:
                 raise ValueError(f"{name}: shape {tuple(t.shape)} != {tuple(shape)}")
             if self.nhwc(name):
                 t = t.permute(0, 2, 3, 1).contiguous()
+            elif self.depthwise(name):
+                t = t[:, 0].permute(1, 2, 0).contiguous()
             elif name.endswith("box_head.fc1.weight"):     # detectron2 flattens (C, 7, 7); the ROIAlign output here is (7, 7, C)
                 P_ = self.cfg.pool
                 t = t.view(shape[0], -1, P_, P_).permute(0, 2, 3, 1).contiguous()
@@ -312,6 +321,8 @@ class VitParams:
             if name.endswith("box_head.fc1.weight"):
                 P_ = self.cfg.pool
                 t = t.view(t.shape[0], P_, P_, -1).permute(0, 3, 1, 2).reshape(t.shape[0], -1)
+            if self.depthwise(name):
+                t = t.permute(2, 0, 1).unsqueeze(1)
             out[name] = (t.permute(0, 3, 1, 2) if self.nhwc(name) else t).contiguous().clone()
         return out
 

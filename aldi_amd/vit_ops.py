@@ -188,3 +188,33 @@ class Attention:
             self.version += 1
         L.call("aldi_attn_backward", C.byref(a), stream_ptr())
         return dqkv
+
+
+# ------------------------------------------------------------------------------------------------- ConvNeXt
+def dwconv7(x: torch.Tensor, wt: torch.Tensor, bias: Optional[torch.Tensor], flip: bool = False) -> torch.Tensor:
+    """x [N,H,W,C], wt [7,7,C] (same dtype), bias fp32 -> depthwise 7x7 / pad 3; flip = data gradient (mirrored taps, no bias)"""
+    N, H, W_, Cc = x.shape
+    y = torch.empty_like(x)
+    L.call("aldi_dwconv7", _p(x), _p(wt), _p(bias), _p(y), N, H, W_, Cc, int(flip), dtype_code(x.dtype), stream_ptr())
+    return y
+
+
+def dwconv7_wgrad(x: torch.Tensor, g: torch.Tensor, dw: torch.Tensor) -> None:
+    N, H, W_, Cc = x.shape
+    L.call("aldi_dwconv7_wgrad", _p(x), _p(g), _p(dw), N, H, W_, Cc, dtype_code(x.dtype), stream_ptr())
+
+
+def scale_add(x: torch.Tensor, y: torch.Tensor, gamma: torch.Tensor, scale: Optional[torch.Tensor], rows_per_sample: int) -> torch.Tensor:
+    Cc = x.shape[-1]
+    out = torch.empty_like(x)
+    L.call("aldi_scale_add", _p(x), _p(y), _p(gamma), _p(scale), _p(out), x.numel() // Cc, Cc, rows_per_sample, dtype_code(x.dtype), stream_ptr())
+    return out
+
+
+def scale_add_backward(g: torch.Tensor, y: torch.Tensor, gamma: torch.Tensor, scale: Optional[torch.Tensor], dgamma: torch.Tensor,
+                       rows_per_sample: int) -> torch.Tensor:
+    Cc = g.shape[-1]
+    dy = torch.empty_like(g)
+    L.call("aldi_scale_add_backward", _p(g), _p(y), _p(gamma), _p(scale), _p(dy), _p(dgamma), g.numel() // Cc, Cc, rows_per_sample,
+           dtype_code(g.dtype), stream_ptr())
+    return dy

@@ -360,6 +360,19 @@ int aldi_ms_deform_attn_backward(const float* value, const int* spatial_shapes, 
                                  const float* attn_weight, const float* grad_out, float* grad_value, float* grad_sampling_loc,
                                  float* grad_attn_weight, int N, int S, int M, int D, int Lq, int L, int P, aldi_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------------------------------
+ * ConvNeXt trunk (reference aldi/backbone.py:189-352).  Depthwise 7x7 / pad 3 convolution, NHWC, C % 8 == 0; wt is [7][7][C]
+ * (the reference's [C][1][7][7] transposed), bias fp32.  flip != 0 mirrors the taps and ignores bias: the data gradient.
+ * aldi_dwconv7_wgrad accumulates dw [7][7][C] (fp32 atomics).  Layer scale: out = x + s(r) * gamma (.) y with s per sample
+ * (stochastic depth; nullable = 1) and its backward (dy fully written, dgamma accumulated).
+ * ------------------------------------------------------------------------------------------------------------------ */
+int aldi_dwconv7(const void* x, const void* wt, const float* bias, void* y, int N, int H, int W, int C, int flip, int dtype, aldi_stream_t stream);
+int aldi_dwconv7_wgrad(const void* x, const void* g, float* dw, int N, int H, int W, int C, int dtype, aldi_stream_t stream);
+int aldi_scale_add(const void* x, const void* y, const float* gamma, const float* scale, void* out, long rows, int C, int rows_per_sample,
+                   int dtype, aldi_stream_t stream);
+int aldi_scale_add_backward(const void* g, const void* y, const float* gamma, const float* scale, void* dy, float* dgamma, long rows, int C,
+                            int rows_per_sample, int dtype, aldi_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -188,6 +188,7 @@ REAL = {
     "detectron2.modeling.meta_arch.rcnn": {"GeneralizedRCNN": _AnyBase},
     "detectron2.modeling.meta_arch.build": {"META_ARCH_REGISTRY": Registry("META_ARCH")},
     "fvcore.nn": {"smooth_l1_loss": _smooth_l1_loss},
+    "detectron2.modeling.backbone": {"Backbone": torch.nn.Module},        # aldi/backbone.py ConvNeXt(Backbone) is a plain nn.Module
 }
 
 
@@ -229,7 +230,7 @@ def import_reference():
     sys.meta_path.insert(0, _Finder())
     sys.path.insert(0, REF)
     mods = {}
-    for n in ("helpers", "align", "ema", "pseudolabeler", "distill", "dataloader", "trainer", "aug"):
+    for n in ("helpers", "align", "ema", "pseudolabeler", "distill", "dataloader", "trainer", "aug", "backbone"):
         mods[n] = importlib.import_module("aldi." + n)
     return mods
 
@@ -586,10 +587,50 @@ def g9(m):
     save("g9_aug", **out)
 
 
+# ----------------------------------------------------------------------------
+# G10  ConvNeXt trunk (aldi/backbone.py:189-352): the reference's own class on a small configuration -- state_dict, input,
+#      the four normalised stage outputs, and every parameter / input gradient of a weighted sum of the outputs
+# ----------------------------------------------------------------------------
+def g10(m):
+    torch.manual_seed(21)
+    B = m["backbone"]
+    net = B.ConvNeXt(in_chans=3, depths=[1, 1, 2, 1], dims=[32, 64, 96, 128], drop_path_rate=0.0, layer_scale_init_value=1e-6,
+                     out_features=[0, 1, 2, 3]).float()
+    with torch.no_grad():           # the stock init leaves gamma at 1e-6 and every bias at 0: give each parameter a value that matters
+        for n, p in net.named_parameters():
+            if n.endswith("gamma"):
+                p.copy_(0.5 + 0.2 * torch.randn_like(p))
+            elif n.endswith("bias"):
+                p.copy_(0.1 * torch.randn_like(p))
+            elif "norm" in n or n.endswith("downsample_layers.0.1.weight") or (".0.weight" in n and "downsample_layers." in n and p.dim() == 1):
+                p.copy_(1.0 + 0.1 * torch.randn_like(p))
+            elif "dwconv.weight" in n:
+                p.copy_(torch.randn_like(p) * 0.15)
+            else:
+                p.copy_(torch.randn_like(p) * (1.5 / max(p[0].numel(), 1)) ** 0.5)
+            p.copy_(p.bfloat16().float())                         # both sides use bf16-representable weights
+    img = torch.randint(0, 256, (2, 3, 64, 96), dtype=torch.uint8)
+    mean = torch.tensor([103.530, 116.280, 123.675]).view(1, 3, 1, 1)          # detectron2 defaults, kept by Base-RCNN-ConvNeXt-FPN.yaml
+    x = (img.float() - mean).requires_grad_(True)
+    outs = net(x)
+    gs = [torch.randn_like(outs[i]).bfloat16().float() for i in range(4)]
+    torch.autograd.backward([outs[i] for i in range(4)], gs)
+    out = {"img": img}
+    for i in range(4):
+        out[f"out{i}"] = outs[i].detach()
+        out[f"gout{i}"] = gs[i]
+    for k, v in net.state_dict().items():
+        out["sd." + k] = v
+    for k, p in net.named_parameters():
+        out["grad." + k] = p.grad
+    out["keys"] = np.array(list(net.state_dict().keys()))
+    save("g10_convnext", **out)
+
+
 if __name__ == "__main__":
     random.seed(0)
     mods = import_reference()
     only = sys.argv[1:]
-    for fn in (g1, g2, g3, g4, g5, g6, g7, g8, g9):
+    for fn in (g1, g2, g3, g4, g5, g6, g7, g8, g9, g10):
         if not only or fn.__name__ in only:
             fn(mods)
