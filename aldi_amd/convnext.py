@@ -30,11 +30,64 @@ class ConvNeXtConfig:
     ln_eps: float = 1e-6
     prefix: str = "backbone.bottom_up."
     pool: int = 7
+    num_classes: int = 0             # > 0: also hold FPN + the standard Faster R-CNN heads (build_convnext_fpn_backbone detector)
+    fpn_channels: int = 256
+    fc_dim: int = 1024
+    num_anchors: int = 3
+    anchor_sizes: Tuple[int, ...] = (64, 128, 256, 512, 1024)      # configs/Base-RCNN-ConvNeXt-FPN.yaml:18
     pixel_mean: Tuple[float, float, float] = (103.530, 116.280, 123.675)      # configs/Base-RCNN-ConvNeXt-FPN.yaml keeps detectron2's defaults
     pixel_std: Tuple[float, float, float] = (1.0, 1.0, 1.0)
 
+    def init_value(self, name, shape):
+        """the reference's initial values where they are not a random matrix (aldi/backbone.py:207,287-290): LayerNorm weights 1,
+        layer scale gamma = LAYER_SCALE_INIT_VALUE (biases 0 and trunc_normal(0.02) matrices are VitParams.init_random's defaults)"""
+        if name.startswith(self.prefix) and name.endswith("gamma"):
+            return torch.full(shape, float(self.layer_scale_init_value))
+        if name.startswith(self.prefix) and len(shape) == 1 and name.endswith(".weight"):
+            return torch.ones(shape)
+        return None
+
     def packs(self):
-        return OrderedDict()
+        if self.num_classes <= 0:
+            return OrderedDict()
+        C, K, A = self.fpn_channels, self.num_classes, self.num_anchors
+        rp, bp = "proposal_generator.rpn_head.", "roi_heads.box_predictor."
+        r1, r2 = (5 * A + 15) // 16 * 16, (5 * K + 1 + 15) // 16 * 16
+        return OrderedDict([
+            ("rpn_head_out.weight", ([rp + "objectness_logits.weight", rp + "anchor_deltas.weight"], r1 * C)),
+            ("rpn_head_out.bias", ([rp + "objectness_logits.bias", rp + "anchor_deltas.bias"], r1)),
+            ("box_pred.weight", ([bp + "cls_score.weight", bp + "bbox_pred.weight"], r2 * self.fc_dim)),
+            ("box_pred.bias", ([bp + "cls_score.bias", bp + "bbox_pred.bias"], r2)),
+        ])
+
+    def detector_spec(self):
+        """detectron2 FPN (fuse sum, no norm, LastLevelMaxPool) on the four stage outputs + StandardRPNHead + FastRCNNConvFCHead(2 FC)
+        + FastRCNNOutputLayers, as `build_convnext_fpn_backbone` (aldi/backbone.py:373-392) and Base-RCNN-ConvNeXt-FPN.yaml assemble"""
+        C, K, A, d = self.fpn_channels, self.num_classes, self.num_anchors, self.dims
+        s = OrderedDict()
+        for lvl in (2, 3, 4, 5):
+            s[f"backbone.fpn_lateral{lvl}.weight"] = ((C, d[lvl - 2], 1, 1), True)
+            s[f"backbone.fpn_lateral{lvl}.bias"] = ((C,), True)
+            s[f"backbone.fpn_output{lvl}.weight"] = ((C, C, 3, 3), True)
+            s[f"backbone.fpn_output{lvl}.bias"] = ((C,), True)
+        rp = "proposal_generator.rpn_head."
+        s[rp + "conv.weight"] = ((C, C, 3, 3), True)
+        s[rp + "conv.bias"] = ((C,), True)
+        s[rp + "objectness_logits.weight"] = ((A, C, 1, 1), True)
+        s[rp + "anchor_deltas.weight"] = ((4 * A, C, 1, 1), True)
+        s[rp + "objectness_logits.bias"] = ((A,), True)
+        s[rp + "anchor_deltas.bias"] = ((4 * A,), True)
+        bh = "roi_heads.box_head."
+        s[bh + "fc1.weight"] = ((self.fc_dim, C * self.pool * self.pool), True)
+        s[bh + "fc1.bias"] = ((self.fc_dim,), True)
+        s[bh + "fc2.weight"] = ((self.fc_dim, self.fc_dim), True)
+        s[bh + "fc2.bias"] = ((self.fc_dim,), True)
+        bp = "roi_heads.box_predictor."
+        s[bp + "cls_score.weight"] = ((K + 1, self.fc_dim), True)
+        s[bp + "bbox_pred.weight"] = ((4 * K, self.fc_dim), True)
+        s[bp + "cls_score.bias"] = ((K + 1,), True)
+        s[bp + "bbox_pred.bias"] = ((4 * K,), True)
+        return s
 
     def spec(self):
         """reference module state_dict order (aldi/backbone.py:239-285); weight decay on everything (the reference's AdamW setup
@@ -65,6 +118,8 @@ class ConvNeXtConfig:
         for i in range(4):
             s[f"{p}norm{i}.weight"] = ((d[i],), True)
             s[f"{p}norm{i}.bias"] = ((d[i],), True)
+        if self.num_classes > 0:
+            s.update(self.detector_spec())
         return s
 
 
@@ -191,3 +246,116 @@ class ConvNeXt:
         T = ctx.patches.shape[0]
         ops.conv_wgrad(ctx.patches.view(T, 1, 1, 48), g.reshape(T, 1, 1, -1), p.g(pre + "0.0.weight"), KH=1, KW=1)
         ops.bias_grad(g.reshape(T, -1), p.g(pre + "0.0.bias"))
+
+
+def _engine_base():
+    from .vitdet import FlatParamRCNN
+    return FlatParamRCNN
+
+
+class ConvNeXtRCNN(_engine_base()):
+    """ConvNeXt-FPN Faster R-CNN on the HIP engine (reference aldi/backbone.py:373-392 + configs/Base-RCNN-ConvNeXt-FPN.yaml): only the
+    trunk, the FPN and the heads' parameter plumbing are specific; anchors (sizes 64..1024), proposals, matching, sampling, ROIAlign,
+    losses, distillation and the fused student pass are engine.RCNN's."""
+
+    def __init__(self, params: VitParams, num_classes: int, seed: int = 0):
+        self._init_flat(params, num_classes, seed)
+        self.net = ConvNeXt(params)
+        self.anchor_sizes = tuple(params.cfg.anchor_sizes)
+
+    # ------------------------------------------------------------------ forward
+    def trunk(self, st_u8: torch.Tensor, sizes, save: bool) -> Ctx:
+        N = st_u8.shape[0]
+        ds = self.net.drop_path_scales(N, self.drop_gen) if save else None
+        cn = self.net.forward(st_u8, sizes, save=save, drop_scales=ds)
+        cs = cn.outs
+        prev, P = {}, {}
+        prev[5] = ops.conv2d(cs[3], self._w("backbone.fpn_lateral5"), shift=self._b("backbone.fpn_lateral5"))
+        P[5] = ops.conv2d(prev[5], self._w("backbone.fpn_output5"), pad=1, shift=self._b("backbone.fpn_output5"))
+        for lvl in (4, 3, 2):
+            prev[lvl] = ops.conv2d(cs[lvl - 2], self._w(f"backbone.fpn_lateral{lvl}"), shift=self._b(f"backbone.fpn_lateral{lvl}"),
+                                   res=prev[lvl + 1], res_mode=2)
+            P[lvl] = ops.conv2d(prev[lvl], self._w(f"backbone.fpn_output{lvl}"), pad=1, shift=self._b(f"backbone.fpn_output{lvl}"))
+        c = Ctx()
+        c.P = [P[2], P[3], P[4], P[5], ops.subsample2(P[5])]
+        if save:
+            c.cn_ctx, c.cs, c.prev = cn, cs, prev
+        return c
+
+    def rpn_head(self, c: Ctx, save: bool):
+        rp = "proposal_generator.rpn_head."
+        w_out, b_out = self._pack_w("rpn_head_out", self.vp.cfg.fpn_channels)
+        heads, ts = [], []
+        for f in c.P:
+            t = ops.conv2d(f, self._w(rp + "conv"), pad=1, shift=self._b(rp + "conv"), relu=True)
+            heads.append(ops.conv2d(t, w_out, shift=b_out, want_f32=True))
+            if save:
+                ts.append(t)
+        c.head = heads
+        if save:
+            c.rpn_t = ts
+
+    def box_head(self, pooled: torch.Tensor, c: Optional[Ctx] = None):
+        cfg = self.vp.cfg
+        R = pooled.shape[0]
+        bh = "roi_heads.box_head."
+        x = pooled.view(R, 1, 1, -1)
+        fc1 = ops.conv2d(x, self.vp.w(bh + "fc1.weight", (cfg.fc_dim, 1, 1, x.shape[-1])), shift=self._b(bh + "fc1"), relu=True)
+        fc2 = ops.conv2d(fc1, self.vp.lin_w(bh + "fc2.weight"), shift=self._b(bh + "fc2"), relu=True)
+        w_out, b_out = self._pack_w("box_pred", cfg.fc_dim)
+        pred = ops.conv2d(fc2, w_out, shift=b_out, want_f32=True).view(R, self.Cp)
+        if c is not None:
+            c.pooled, c.fc1, c.fc2 = pooled, fc1, fc2
+        return pred, fc2
+
+    # ------------------------------------------------------------------ backward
+    def _backward_trunk(self, c: Ctx, align_list):
+        assert not align_list, "adversarial alignment is not wired for the ConvNeXt trunk"
+        cfg, vp, T, dev = self.vp.cfg, self.vp, torch.bfloat16, self.device
+        C, bh, rp = cfg.fpn_channels, "roi_heads.box_head.", "proposal_generator.rpn_head."
+        gP_roi = [(torch.empty if c.R > 0 else torch.zeros)(f.shape, dtype=torch.float32, device=dev) for f in c.P[:4]]
+        if c.R > 0:
+            gpred = ops.cast_from_f32(c.gpred[:c.R], T).view(c.R, 1, 1, self.Cp)
+            self._wg_pack("box_pred", c.fc2, gpred, cfg.fc_dim)
+            g_fc2 = ops.conv2d(gpred, self._pack_wt("box_pred", cfg.fc_dim), mask=c.fc2)
+            ops.conv_wgrad(c.fc1, g_fc2, vp.g(bh + "fc2.weight"), KH=1, KW=1)
+            ops.bias_grad(g_fc2.view(c.R, -1), vp.g(bh + "fc2.bias"))
+            g_fc1 = ops.conv2d(g_fc2, vp.wt(bh + "fc2.weight"), mask=c.fc1)
+            x = c.pooled.view(c.R, 1, 1, -1)
+            ops.conv_wgrad(x, g_fc1, vp.g(bh + "fc1.weight"), KH=1, KW=1)
+            ops.bias_grad(g_fc1.view(c.R, -1), vp.g(bh + "fc1.bias"))
+            g_pooled = ops.conv2d(g_fc1, vp.wt(bh + "fc1.weight")).view(c.R, cfg.pool, cfg.pool, C)
+            ops.roialign_backward(self.roi_feats(c, gP_roi), c.rois, c.R, cfg.pool, g_pooled, c.N)
+        gP = []
+        wt_out = self._pack_wt("rpn_head_out", C)
+        for l in range(5):
+            gh = ops.cast_from_f32(c.ghead[l], T)
+            self._wg_pack("rpn_head_out", c.rpn_t[l], gh, C)
+            g_t = ops.conv2d(gh, wt_out, mask=c.rpn_t[l])
+            self._wg(rp + "conv", c.P[l], g_t, 3)
+            ops.bias_grad(g_t.view(-1, C), vp.g(rp + "conv.bias"))
+            gP.append(ops.conv2d(g_t, vp.wt(rp + "conv.weight"), pad=1))
+        ops.subsample2_bwd(gP[4], gP[3])
+        for l in range(4):
+            ops.add_f32(gP[l], gP_roi[l], gP[l])
+        cb = getattr(self, "grad_ready", None)
+        if cb is not None:
+            cb(vp.ranges([n for n in vp.spec if n.startswith(("proposal_generator.", "roi_heads."))]))
+        # FPN
+        gprev = {}
+        for i, lvl in enumerate((2, 3, 4, 5)):
+            self._wg(f"backbone.fpn_output{lvl}", c.prev[lvl], gP[i], 3)
+            ops.bias_grad(gP[i].view(-1, C), vp.g(f"backbone.fpn_output{lvl}.bias"))
+            gprev[lvl] = ops.conv2d(gP[i], vp.wt(f"backbone.fpn_output{lvl}.weight"), pad=1)
+        for lvl in (3, 4, 5):
+            ops.upsample2_bwd(gprev[lvl - 1], gprev[lvl], accumulate=True)
+        gc = []
+        for lvl in (2, 3, 4, 5):
+            self._wg(f"backbone.fpn_lateral{lvl}", c.cs[lvl - 2], gprev[lvl], 1)
+            ops.bias_grad(gprev[lvl].view(-1, C), vp.g(f"backbone.fpn_lateral{lvl}.bias"))
+            gc.append(ops.conv2d(gprev[lvl], vp.wt(f"backbone.fpn_lateral{lvl}.weight")))
+        if cb is not None:
+            cb(vp.ranges([n for n in vp.spec if n.startswith("backbone.fpn_")]))
+        self.net.backward(c.cn_ctx, gc)
+        if cb is not None:
+            cb(vp.ranges([n for n in vp.spec if n.startswith(cfg.prefix)]))

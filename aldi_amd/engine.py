@@ -209,10 +209,10 @@ class Weights:
         self.refresh()
 
 
-def make_anchors(shapes: Sequence[Tuple[int, int]], device) -> torch.Tensor:
+def make_anchors(shapes: Sequence[Tuple[int, int]], device, sizes: Sequence[float] = ANCHOR_SIZES) -> torch.Tensor:
     """DefaultAnchorGenerator (offset 0): (sumA, 4), level-major, then (h, w, a). Host float32 math as Detectron2."""
     out = []
-    for (h, w), size, stride in zip(shapes, ANCHOR_SIZES, STRIDES):
+    for (h, w), size, stride in zip(shapes, sizes, STRIDES):
         cell = []
         for r in ANCHOR_RATIOS:
             area = size ** 2.0
@@ -304,7 +304,7 @@ class RCNN:
                     h, w = h // 2, w // 2
             shapes.append(((shapes[3][0] - 1) // 2 + 1, (shapes[3][1] - 1) // 2 + 1))
             geom = ops.make_geom(shapes, NUM_ANCHORS, self.Ch)
-            anchors = make_anchors(shapes, self.device)
+            anchors = make_anchors(shapes, self.device, getattr(self, "anchor_sizes", ANCHOR_SIZES))
             self._anchor_cache[key] = (shapes, geom, anchors)
         return self._anchor_cache[key]
 

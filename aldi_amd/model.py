@@ -112,8 +112,12 @@ class GeneralizedRCNN:
         self.dtype = torch.bfloat16 if cfg.SOLVER.AMP.ENABLED else torch.float32
         self.vitdet = str(cfg.MODEL.BACKBONE.NAME).startswith("build_vitdet")
         seed = cfg.SEED if cfg.SEED is not None and cfg.SEED >= 0 else 1
+        self.convnext = str(cfg.MODEL.BACKBONE.NAME) == "build_convnext_fpn_backbone"
+        self.adamw = self.vitdet or self.convnext          # flat-container models are trained with the HIP AdamW
         if self.vitdet:
             self._build_vitdet(seed)
+        elif self.convnext:
+            self._build_convnext(seed)
         else:
             self.layout = ParamLayout(self.num_classes, self._img_da, self._ins_da)
             self.weights = Weights(self.layout, self.device, self.dtype, trainable=True)
@@ -131,7 +135,7 @@ class GeneralizedRCNN:
         self.roi_heads.box_head = HookPoint(self, "box_head")
         if cfg.MODEL.WEIGHTS:
             self._load_file(cfg.MODEL.WEIGHTS)
-        elif self.vitdet:
+        elif self.vitdet or self.convnext:
             self.weights.init_random(seed)
         else:
             self.load_state_dict(synthetic.init_state_dict(self.num_classes, seed=seed, img_da=self._img_da, ins_da=self._ins_da))
@@ -150,6 +154,23 @@ class GeneralizedRCNN:
         syn = cfg.get("SYNTHETIC", {})
         return VitConfig(sfp=True, num_classes=self.num_classes, box_convs=M.ROI_BOX_HEAD.NUM_CONV, fc_dim=M.ROI_BOX_HEAD.FC_DIM,
                          pixel_mean=tuple(M.PIXEL_MEAN), pixel_std=tuple(M.PIXEL_STD), **{**kw, **dict(syn.get("VIT", {}))})
+
+    def _build_convnext(self, seed: int):
+        """reference aldi/backbone.py:354-392 (build_convnext_fpn_backbone) + configs/Base-RCNN-ConvNeXt-FPN.yaml"""
+        from .convnext import ConvNeXtConfig, ConvNeXtRCNN
+        from .vit import VitParams
+        if self._img_da or self._ins_da:
+            raise ValueError("adversarial alignment is not wired for the ConvNeXt trunk")
+        if self.dtype != torch.bfloat16:
+            raise ValueError("the ConvNeXt trunk runs in bf16 (SOLVER.AMP.ENABLED True)")
+        M = self.cfg.MODEL
+        ccfg = ConvNeXtConfig(depths=tuple(M.CONVNEXT.DEPTHS), dims=tuple(M.CONVNEXT.DIMS), drop_path_rate=float(M.CONVNEXT.DROP_PATH_RATE),
+                              layer_scale_init_value=float(M.CONVNEXT.LAYER_SCALE_INIT_VALUE), num_classes=self.num_classes,
+                              fc_dim=M.ROI_BOX_HEAD.FC_DIM, anchor_sizes=tuple(int(s_[0]) for s_ in M.ANCHOR_GENERATOR.SIZES),
+                              pixel_mean=tuple(M.PIXEL_MEAN), pixel_std=tuple(M.PIXEL_STD))
+        self.weights = VitParams(ccfg, self.device)
+        self.layout = self.weights
+        self.engine = ConvNeXtRCNN(self.weights, self.num_classes, seed=seed)
 
     def _build_vitdet(self, seed: int):
         from .vit import VitParams
@@ -195,6 +216,8 @@ class GeneralizedRCNN:
             setattr(new, k, copy.deepcopy(v, memo) if k not in ("cfg", "layout", "device", "dtype") else v)
         if self.vitdet:
             new._build_vitdet(1)
+        elif self.convnext:
+            new._build_convnext(1)
         else:
             new.weights = Weights(self.layout, self.device, self.dtype, trainable=True)
             new.engine = RCNN(new.weights, self.num_classes)

@@ -501,10 +501,10 @@ class ALDITrainer(DefaultTrainer):
     @classmethod
     def build_optimizer(cls, cfg, model):
         if cfg.SOLVER.OPTIMIZER is None or cfg.SOLVER.OPTIMIZER.upper() == "SGD":
-            if getattr(model, "vitdet", False):
-                raise ValueError("the ViTDet model is trained with SOLVER.OPTIMIZER ADAMW (configs/Base-RCNN-VitDetB.yaml)")
+            if getattr(model, "adamw", False):
+                raise ValueError("the ViTDet / ConvNeXt models are trained with SOLVER.OPTIMIZER ADAMW (their Base-RCNN-*.yaml)")
             return super(ALDITrainer, cls).build_optimizer(cfg, model)
-        if cfg.SOLVER.OPTIMIZER.upper() == "ADAMW" and getattr(model, "vitdet", False):      # reference aldi/trainer.py:200-209
+        if cfg.SOLVER.OPTIMIZER.upper() == "ADAMW" and getattr(model, "adamw", False):       # reference aldi/trainer.py:200-209
             return EngineAdamW(model, cfg.SOLVER.BASE_LR)
         raise ValueError(f"Unsupported optimizer/backbone combination {cfg.SOLVER.OPTIMIZER} {cfg.MODEL.BACKBONE.NAME}.")
 

@@ -329,8 +329,12 @@ class VitParams:
     def init_random(self, seed: int = 0, std: float = 0.02):
         g = torch.Generator().manual_seed(seed)
         sd = OrderedDict()
+        custom = getattr(self.cfg, "init_value", None)
         for name, (shape, _) in self.spec.items():
-            if name.endswith(("norm1.weight", "norm2.weight", "norm.weight", "simfp_2.1.weight")):
+            v = custom(name, shape) if custom is not None else None
+            if v is not None:
+                sd[name] = v
+            elif name.endswith(("norm1.weight", "norm2.weight", "norm.weight", "simfp_2.1.weight")):
                 sd[name] = torch.ones(shape)
             elif name.endswith(".bias"):
                 sd[name] = torch.zeros(shape)

@@ -17,14 +17,15 @@ from .engine import RCNN, Ctx
 from .vit import SimpleFeaturePyramid, ViT, VitConfig, VitParams
 
 
-class VitDetRCNN(RCNN):
-    def __init__(self, params: VitParams, num_classes: int, seed: int = 0):
+class FlatParamRCNN(RCNN):
+    """engine.RCNN over a `VitParams` flat container (detectron2-named parameters, packed predictor rows) instead of the R50
+    `Weights` / `ParamLayout`: shared by the ViTDet and ConvNeXt-FPN detectors, which override the architecture-specific methods"""
+
+    def _init_flat(self, params: VitParams, num_classes: int, seed: int):
         cfg = params.cfg
-        assert cfg.sfp and cfg.num_classes == num_classes
+        assert cfg.num_classes == num_classes
         self.vp = params
-        self.wts = params                       # what engine.RCNN calls `weights` (only touched by the overrides below)
-        self.vit = ViT(params)
-        self.sfp = SimpleFeaturePyramid(params)
+        self.wts = params                       # what engine.RCNN calls `weights` (only touched by the overrides)
         self.K = num_classes
         self.device, self.dtype = params.device, torch.bfloat16
         self.Cp = (5 * num_classes + 1 + 15) // 16 * 16
@@ -34,7 +35,6 @@ class VitDetRCNN(RCNN):
         torch.set_num_threads(1)
         self.has_img_da = self.has_ins_da = False
         self.drop_gen = torch.Generator().manual_seed(seed)     # stochastic-depth masks (host-drawn, see ViT.drop_path_scales)
-        self._wt_pack = {}
 
     # ------------------------------------------------------------------ small helpers over the flat parameter container
     def _w(self, name):
@@ -59,6 +59,20 @@ class VitDetRCNN(RCNN):
         rows = self.Ch if name == "rpn_head_out" else self.Cp
         ops.conv_wgrad(x, g, self.vp.pack(self.vp.grad, name + ".weight", (rows * cin,)), KH=1, KW=1)
         ops.bias_grad(g.view(-1, rows), self.vp.pack(self.vp.grad, name + ".bias", (rows,)))
+
+    def _grads_final(self, names):
+        return
+
+    def _wgrad(self, name, x, g):
+        raise RuntimeError("engine.RCNN._wgrad is tied to the R50-FPN layout; the flat-container engines do not use it")
+
+
+class VitDetRCNN(FlatParamRCNN):
+    def __init__(self, params: VitParams, num_classes: int, seed: int = 0):
+        assert params.cfg.sfp
+        self._init_flat(params, num_classes, seed)
+        self.vit = ViT(params)
+        self.sfp = SimpleFeaturePyramid(params)
 
     # ------------------------------------------------------------------ forward
     def trunk(self, st_u8: torch.Tensor, sizes, save: bool) -> Ctx:
@@ -173,8 +187,3 @@ class VitDetRCNN(RCNN):
         finally:
             self.vit.grad_ready = None
 
-    def _grads_final(self, names):
-        return
-
-    def _wgrad(self, name, x, g):
-        raise RuntimeError("engine.RCNN._wgrad is tied to the R50-FPN layout; the ViTDet overrides do not use it")

@@ -89,3 +89,117 @@ def test_convnext_trunk_vs_reference_class_golden(golden_dir):
         if e_inf > 6e-2 or e_2 > 3e-2:
             bad[k] = (round(e_inf, 4), round(e_2, 4))
     assert not bad, bad
+
+
+# ------------------------------------------------------------------------------------------------ the ConvNeXt-FPN detector
+K = 8
+CC = dict(depths=(1, 1, 2, 1), dims=(32, 64, 96, 128))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _detector(seed=0, drop=0.0):
+    from aldi_amd.convnext import ConvNeXtConfig, ConvNeXtRCNN
+    from aldi_amd.vit import VitParams
+    cfg = ConvNeXtConfig(depths=CC["depths"], dims=CC["dims"], drop_path_rate=drop, num_classes=K, fc_dim=256)
+    params = VitParams(cfg, DEV)
+    g = torch.Generator().manual_seed(seed)
+    sd = {}
+    for name, (shape, _) in params.spec.items():
+        if name.endswith("gamma"):
+            t = 0.5 + 0.1 * torch.randn(shape, generator=g)
+        elif len(shape) == 1 and name.endswith(".weight"):
+            t = 1 + 0.1 * torch.randn(shape, generator=g)
+        elif name.endswith("bias"):
+            t = 0.02 * torch.randn(shape, generator=g)
+        elif name.endswith("dwconv.weight"):
+            t = 0.15 * torch.randn(shape, generator=g)
+        else:
+            fan_in = 1
+            for v in shape[1:]:
+                fan_in *= v
+            t = torch.randn(shape, generator=g) * (2.0 / fan_in) ** 0.5
+        sd[name] = t.bfloat16().float()
+    params.load_state_dict(sd)
+    return cfg, params, sd, ConvNeXtRCNN(params, K)
+
+
+def _batch(seed=0):
+    from aldi_amd import synthetic as syn
+    _, data, _, _ = syn.make_batch(2, 0, 128, 160, K, seed=seed, boxes_per_image=(3, 6))
+    return data
+
+
+def test_convnext_fpn_train_step_close_to_oracle():
+    """one training step of the ConvNeXt-FPN detector (anchor sizes 64..1024) vs the fp32 CPU oracle on identical inputs and RNG draws:
+    losses within 8 % (bf16 trunk), every parameter group receives gradient"""
+    from oracle import d2_convnext as oc
+    from oracle import d2_rcnn as d2
+    cfg, params, sd, m = _detector(5)
+    data = _batch(0)
+    ocfg = d2.make_cfg(num_classes=K, pixel_mean=cfg.pixel_mean, pixel_std=cfg.pixel_std, anchor_sizes=cfg.anchor_sizes, fc_dim=256)
+    torch.manual_seed(5)
+    ol = d2.forward_train(ocfg, sd, data, roi_seed=9, arch=oc.arch(CC))
+    torch.manual_seed(5)
+    c = m.forward_train([d["image"] for d in data], [d["instances"] for d in data], roi_seed=9)
+    params.zero_grad()
+    m.backward(c, {k: 1.0 for k in ol})
+    torch.cuda.synchronize()
+    assert int(m.err) == 0
+    hl = {k: float(v) for k, v in m.loss_dict(c).items()}
+    for k in ol:
+        assert abs(hl[k] - float(ol[k])) < 0.08 * max(1.0, abs(float(ol[k]))), (k, hl[k], float(ol[k]))
+    g = params.state_dict_like(params.grad)
+    dead = [k for k, v in g.items() if v.abs().max() == 0]
+    assert not dead and torch.isfinite(params.grad).all(), dead[:8]
+
+
+def test_convnext_fpn_adamw_overfits_one_batch():
+    cfg, params, sd, m = _detector(7, drop=0.1)
+    data = _batch(1)
+    imgs, insts = [d["image"] for d in data], [d["instances"] for d in data]
+    totals = []
+    for it in range(10):
+        torch.manual_seed(11)
+        c = m.forward_train(imgs, insts, roi_seed=13)
+        ld = m.loss_dict(c)
+        totals.append(sum(float(v) for v in ld.values()))
+        params.zero_grad()
+        m.backward(c, {k: 1.0 for k in ld})
+        params.adamw_step(2e-4)
+    assert all(t == t for t in totals) and totals[-1] < 0.8 * totals[0], totals
+
+
+@pytest.mark.parametrize("fused", [True, False])
+def test_convnext_fpn_aldi_trainer_runs(fused, tmp_path):
+    """configs/cityscapes/ALDI-Best-ConvNeXt-Cityscapes.yaml through the reference-shaped trainer (EMA teacher, pseudo labels, soft
+    distillation, AdamW) on a small ConvNeXt: finite losses with the reference's key set, teacher trails the student, checkpoint keys"""
+    import random
+    from aldi_amd.config import add_aldi_config, get_cfg
+    from aldi_amd.trainer import ALDITrainer, EngineAdamW
+    cfg = get_cfg()
+    add_aldi_config(cfg)
+    cfg.merge_from_file(os.path.join(ROOT, "configs", "cityscapes", "ALDI-Best-ConvNeXt-Cityscapes.yaml"))
+    cfg.merge_from_list(["SOLVER.IMS_PER_BATCH", 4, "SOLVER.IMS_PER_GPU", 2, "SOLVER.WARMUP_ITERS", 0, "SEED", 1, "EMA.ALPHA", 0.9,
+                         "SYNTHETIC.HEIGHT", 128, "SYNTHETIC.WIDTH", 160, "SOLVER.BASE_LR", 2e-4])
+    cfg.MODEL.CONVNEXT.DEPTHS, cfg.MODEL.CONVNEXT.DIMS = [1, 1, 2, 1], [32, 64, 96, 128]
+    cfg.SOLVER.FUSED_STEP = fused
+    cfg.OUTPUT_DIR = str(tmp_path)
+    random.seed(0)
+    torch.manual_seed(3)
+    tr = ALDITrainer(cfg)
+    assert tr.model.convnext and isinstance(tr._trainer.optimizer, EngineAdamW)
+    w0 = tr.model.weights.master.clone()
+    for _ in range(3):
+        tr.before_step()
+        tr.run_step()
+        tr.after_step()
+        tr.iter += 1
+    torch.cuda.synchronize()
+    ld = tr._trainer.last_loss_dict
+    assert {"loss_cls_source_strong", "loss_obj_bce_distill", "loss_cls_ce_distill", "loss_rpn_l1_distill", "loss_roih_l1_distill"} <= set(ld)
+    assert all(float(v) == float(v) and abs(float(v)) < 1e4 for v in ld.values()), ld
+    assert int(tr.model.engine.err) == 0 and int(tr.ema.model.engine.err) == 0
+    s, t = tr.model.weights.master, tr.ema.model.weights.master
+    assert (s - w0).abs().max() > 0 and (t - s).abs().max() > 0
+    sd = tr.model.state_dict()
+    assert sd["backbone.bottom_up.stages.2.1.dwconv.weight"].shape == (96, 1, 7, 7) and "backbone.fpn_lateral3.weight" in sd
