@@ -55,48 +55,52 @@ __global__ __launch_bounds__(256) void dwconv7_kernel(const T* __restrict__ x, c
     }
 }
 
-// dw[kh][kw][c] += sum_{n,h,w} x[n][h+kh-3][w+kw-3][c] * g[n][h][w][c]; one block = (pixel chunk, 8-channel group, kernel row kh):
-// each thread keeps the 7 taps of its row for 8 channels, the block reduces through LDS, one atomic per (tap, channel)
+// dw[kh][kw][c] += sum_{n,h,w} x[n][h+kh-3][w+kw-3][c] * g[n][h][w][c].  One block = (pixel chunk, up to 256 channels, kernel row kh):
+// lanes run along the channels (CG channel groups of 8: one coalesced 16-B load per lane), 256 / CG pixel lanes walk the chunk;
+// each thread keeps the 7 taps of its row for 8 channels, the pixel lanes meet in LDS, one atomic per (tap, channel) per block.
 template <typename T>
 __global__ __launch_bounds__(256) void dwconv7_wgrad_kernel(const T* __restrict__ x, const T* __restrict__ g, float* __restrict__ dw, int N, int H,
-                                                             int W, int C, int pix_per_block) {
+                                                             int W, int C, int pix_per_block, int CG) {
     __shared__ float red[256 * 8];
-    const int c8 = C >> 3, cc = (blockIdx.y % c8) * 8, kh = blockIdx.y / c8;
+    const int c8 = C >> 3, ngrp = (c8 + CG - 1) / CG;
+    const int kh = blockIdx.y / ngrp, cg = (blockIdx.y - kh * ngrp) * CG + threadIdx.x % CG, pl = threadIdx.x / CG, npl = 256 / CG;
+    const bool live = cg < c8;
+    const int cc = cg * 8;
     const long npix = (long)N * H * W, p0 = (long)blockIdx.x * pix_per_block, p1 = min(npix, p0 + pix_per_block);
     float acc[7][8];
 #pragma unroll
     for (int kw = 0; kw < 7; ++kw)
 #pragma unroll
         for (int k = 0; k < 8; ++k) acc[kw][k] = 0.f;
-    for (long p = p0 + threadIdx.x; p < p1; p += 256) {
-        const int w0 = (int)(p % W), h0 = (int)((p / W) % H), n = (int)(p / ((long)W * H));
-        const int h = h0 + kh - 3;
-        if (h < 0 || h >= H) continue;
-        float gv[8];
-        load8(g + p * C + cc, gv);
+    if (live)
+        for (long p = p0 + pl; p < p1; p += npl) {
+            const int w0 = (int)(p % W), h0 = (int)((p / W) % H), n = (int)(p / ((long)W * H));
+            const int h = h0 + kh - 3;
+            if (h < 0 || h >= H) continue;
+            float gv[8];
+            load8(g + p * C + cc, gv);
 #pragma unroll
-        for (int kw = 0; kw < 7; ++kw) {
-            const int w = w0 + kw - 3;
-            if (w < 0 || w >= W) continue;
-            float xv[8];
-            load8(x + (((long)n * H + h) * W + w) * C + cc, xv);
+            for (int kw = 0; kw < 7; ++kw) {
+                const int w = w0 + kw - 3;
+                if (w < 0 || w >= W) continue;
+                float xv[8];
+                load8(x + (((long)n * H + h) * W + w) * C + cc, xv);
 #pragma unroll
-            for (int k = 0; k < 8; ++k) acc[kw][k] += xv[k] * gv[k];
+                for (int k = 0; k < 8; ++k) acc[kw][k] += xv[k] * gv[k];
+            }
         }
-    }
     for (int kw = 0; kw < 7; ++kw) {
         __syncthreads();
 #pragma unroll
         for (int k = 0; k < 8; ++k) red[threadIdx.x * 8 + k] = acc[kw][k];
         __syncthreads();
-        for (int s = 128; s > 0; s >>= 1) {
-            if (threadIdx.x < s) {
-#pragma unroll
-                for (int k = 0; k < 8; ++k) red[threadIdx.x * 8 + k] += red[(threadIdx.x + s) * 8 + k];
-            }
-            __syncthreads();
+        if (threadIdx.x < CG * 8) {                    // thread t sums channel (t / 8 group, t % 8) over the pixel lanes
+            const int grp = threadIdx.x >> 3, k = threadIdx.x & 7;
+            float s = 0.f;
+            for (int q = 0; q < npl; ++q) s += red[(q * CG + grp) * 8 + k];
+            const int cgo = (blockIdx.y - kh * ngrp) * CG + grp;
+            if (cgo < c8) atomicAdd(dw + (long)(kh * 7 + kw) * C + cgo * 8 + k, s);
         }
-        if (threadIdx.x < 8) atomicAdd(dw + (long)(kh * 7 + kw) * C + cc + threadIdx.x, red[threadIdx.x]);
     }
 }
 
@@ -118,28 +122,40 @@ __global__ void scale_add_kernel(const T* __restrict__ x, const T* __restrict__ 
     }
 }
 
-// dy[r][c] = s(r) * gamma[c] * g[r][c];  dgamma[c] += sum_r s(r) * g[r][c] * y[r][c]
+// dy[r][c] = s(r) * gamma[c] * g[r][c];  dgamma[c] += sum_r s(r) * g[r][c] * y[r][c].  Lanes run along the channel groups (CG of them,
+// coalesced), 256 / CG row lanes walk the block's rows; the row lanes meet in LDS (ds_add_f32), one global atomic per channel.
 template <typename T>
 __global__ __launch_bounds__(256) void scale_add_bwd_kernel(const T* __restrict__ g, const T* __restrict__ y, const float* __restrict__ gamma,
                                                              const float* __restrict__ scale, T* __restrict__ dy, float* __restrict__ dgamma, long rows,
-                                                             int C, int rows_per_sample, int rows_per_block) {
-    const int c8 = C >> 3;
+                                                             int C, int rows_per_sample, int rows_per_block, int CG) {
+    __shared__ float dg_s[256 * 8];
+    const int c8 = C >> 3, ngrp = (c8 + CG - 1) / CG;
+    const int cg = (blockIdx.y % ngrp) * CG + threadIdx.x % CG, rl = threadIdx.x / CG, nrl = 256 / CG;
+    const bool live = cg < c8;
     const long r0 = (long)blockIdx.x * rows_per_block, r1 = min(rows, r0 + rows_per_block);
-    for (int ch = threadIdx.x; ch < c8; ch += 256) {          // a thread owns channel groups; rows are walked sequentially (coalesced across threads)
-        float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, gm[8];
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, gm[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (live) {
 #pragma unroll
-        for (int k = 0; k < 8; ++k) gm[k] = gamma[ch * 8 + k];
-        for (long r = r0; r < r1; ++r) {
+        for (int k = 0; k < 8; ++k) gm[k] = gamma[cg * 8 + k];
+        for (long r = r0 + rl; r < r1; r += nrl) {
             float gv[8], yv[8], o[8];
-            load8(g + (r * c8 + ch) * 8, gv);
-            load8(y + (r * c8 + ch) * 8, yv);
+            load8(g + (r * c8 + cg) * 8, gv);
+            load8(y + (r * c8 + cg) * 8, yv);
             const float s = scale ? scale[r / rows_per_sample] : 1.f;
 #pragma unroll
             for (int k = 0; k < 8; ++k) { o[k] = s * gm[k] * gv[k]; acc[k] += s * gv[k] * yv[k]; }
-            store8(dy + (r * c8 + ch) * 8, o);
+            store8(dy + (r * c8 + cg) * 8, o);
         }
+    }
 #pragma unroll
-        for (int k = 0; k < 8; ++k) atomicAdd(dgamma + ch * 8 + k, acc[k]);
+    for (int k = 0; k < 8; ++k) dg_s[threadIdx.x * 8 + k] = acc[k];
+    __syncthreads();
+    if (threadIdx.x < CG * 8) {
+        const int grp = threadIdx.x >> 3, k = threadIdx.x & 7;
+        float s = 0.f;
+        for (int q = 0; q < nrl; ++q) s += dg_s[(q * CG + grp) * 8 + k];
+        const int cgo = (blockIdx.y % ngrp) * CG + grp;
+        if (cgo < c8) atomicAdd(dgamma + cgo * 8 + k, s);
     }
 }
 
@@ -173,11 +189,16 @@ extern "C" int aldi_dwconv7_wgrad(const void* x, const void* g, float* dw, int N
     if (!x || !g || !dw || C % 8 || N <= 0 || H <= 0 || W <= 0) return aldi_set_error_msg(ALDI_ERR_ARG, "dwconv7_wgrad: bad args (C % 8 == 0)");
     hipStream_t st = (hipStream_t)stream;
     const long npix = (long)N * H * W;
-    const int ppb = npix > 256 * 64 ? (int)((npix + 63) / 64) : 256 * 4 < npix ? 256 * 4 : (int)npix;   // <= 64 pixel chunks on big maps
-    dim3 grid(cdiv(npix, ppb), (C / 8) * 7);
+    const int c8 = C / 8, CG = c8 >= 32 ? 32 : (c8 >= 16 ? 16 : (c8 >= 8 ? 8 : (c8 >= 4 ? 4 : (c8 >= 2 ? 2 : 1))));   // channel groups per block
+    const int ngrp = (c8 + CG - 1) / CG;
+    // enough blocks to fill the chip (>= ~2048), at least 256 pixels each
+    long chunks = 2048 / (7 * ngrp) + 1;
+    if (chunks > npix / 256 + 1) chunks = npix / 256 + 1;
+    const int ppb = (int)((npix + chunks - 1) / chunks);
+    dim3 grid(cdiv(npix, ppb), ngrp * 7);
     CNX_DISPATCH(dtype,
-        hipLaunchKernelGGL(dwconv7_wgrad_kernel<float>, grid, dim3(256), 0, st, (const float*)x, (const float*)g, dw, N, H, W, C, ppb),
-        hipLaunchKernelGGL(dwconv7_wgrad_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)x, (const bf16_t*)g, dw, N, H, W, C, ppb));
+        hipLaunchKernelGGL(dwconv7_wgrad_kernel<float>, grid, dim3(256), 0, st, (const float*)x, (const float*)g, dw, N, H, W, C, ppb, CG),
+        hipLaunchKernelGGL(dwconv7_wgrad_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)x, (const bf16_t*)g, dw, N, H, W, C, ppb, CG));
     ALDI_CHECK_LAUNCH();
     return ALDI_OK;
 }
@@ -197,10 +218,15 @@ extern "C" int aldi_scale_add_backward(const void* g, const void* y, const float
                                        int rows_per_sample, int dtype, aldi_stream_t stream) {
     if (!g || !y || !gamma || !dy || !dgamma || C % 8 || rows <= 0 || rows_per_sample <= 0) return aldi_set_error_msg(ALDI_ERR_ARG, "scale_add_backward: bad args");
     hipStream_t st = (hipStream_t)stream;
-    const int rpb = rows > 4096 ? (int)((rows + 1023) / 1024) : 4;
+    const int c8 = C / 8, CG = c8 >= 32 ? 32 : (c8 >= 16 ? 16 : (c8 >= 8 ? 8 : (c8 >= 4 ? 4 : (c8 >= 2 ? 2 : 1))));
+    const int ngrp = (c8 + CG - 1) / CG;
+    long chunks = 2048 / ngrp + 1;
+    if (chunks > rows / 64 + 1) chunks = rows / 64 + 1;
+    const int rpb = (int)((rows + chunks - 1) / chunks);
+    dim3 grid(cdiv(rows, rpb), ngrp);
     CNX_DISPATCH(dtype,
-        hipLaunchKernelGGL(scale_add_bwd_kernel<float>, dim3(cdiv(rows, rpb)), dim3(256), 0, st, (const float*)g, (const float*)y, gamma, scale, (float*)dy, dgamma, rows, C, rows_per_sample, rpb),
-        hipLaunchKernelGGL(scale_add_bwd_kernel<bf16_t>, dim3(cdiv(rows, rpb)), dim3(256), 0, st, (const bf16_t*)g, (const bf16_t*)y, gamma, scale, (bf16_t*)dy, dgamma, rows, C, rows_per_sample, rpb));
+        hipLaunchKernelGGL(scale_add_bwd_kernel<float>, grid, dim3(256), 0, st, (const float*)g, (const float*)y, gamma, scale, (float*)dy, dgamma, rows, C, rows_per_sample, rpb, CG),
+        hipLaunchKernelGGL(scale_add_bwd_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)g, (const bf16_t*)y, gamma, scale, (bf16_t*)dy, dgamma, rows, C, rows_per_sample, rpb, CG));
     ALDI_CHECK_LAUNCH();
     return ALDI_OK;
 }

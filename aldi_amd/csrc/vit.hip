@@ -11,7 +11,7 @@ namespace {
 // ------------------------------------------------------------------------------------------------ LayerNorm
 // One wave per output row.  `map` (nullable) gathers: output row r normalises source row map[r]; map[r] < 0 is a padding
 // row of a partitioned window and is written as zeros (detectron2 pads AFTER norm1, so the padded tokens are exact zeros).
-constexpr int LN_MAXCH = 4;     // C <= 1024, C % 4 == 0; lane chunk j (4 channels at (lane + 64 j) * 4) is live iff inside C
+constexpr int LN_MAXCH = 8;     // C <= 2048 (ConvNeXt-L stage 3 is 1536 wide), C % 4 == 0; lane chunk j (4 channels at (lane + 64 j) * 4) is live iff inside C
 
 template <typename T>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, const int* __restrict__ map, const float* __restrict__ gamma,
@@ -67,7 +67,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ g, co
                                                       const float* __restrict__ gamma, const float* __restrict__ mean,
                                                       const float* __restrict__ rstd, const T* __restrict__ res, const T* __restrict__ mask,
                                                       T* __restrict__ dx, float* __restrict__ dgamma, float* __restrict__ dbeta, int rows, int C, int rows_per_block) {
-    __shared__ float red[4 * 1024];
+    __shared__ float red[4 * 2048];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     float dg[LN_MAXCH][4], db[LN_MAXCH][4], gm[LN_MAXCH][4];
 #pragma unroll
@@ -123,11 +123,11 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ g, co
         for (int j = 0; j < LN_MAXCH; ++j)
             if ((lane + 64 * j) * 4 < C) {
 #pragma unroll
-                for (int i = 0; i < 4; ++i) red[wave * 1024 + (lane + 64 * j) * 4 + i] = pass ? db[j][i] : dg[j][i];
+                for (int i = 0; i < 4; ++i) red[wave * 2048 + (lane + 64 * j) * 4 + i] = pass ? db[j][i] : dg[j][i];
             }
         __syncthreads();
         for (int cidx = threadIdx.x; cidx < C; cidx += 256) {
-            const float t = (red[cidx] + red[1024 + cidx]) + (red[2048 + cidx] + red[3072 + cidx]);
+            const float t = (red[cidx] + red[2048 + cidx]) + (red[4096 + cidx] + red[6144 + cidx]);
             atomicAdd((pass ? dbeta : dgamma) + cidx, t);
         }
     }
@@ -375,7 +375,7 @@ inline int grid_for(long work, int block = 256) {
 
 extern "C" int aldi_layernorm_forward(const void* x, const int* map, const float* gamma, const float* beta, void* y, float* mean,
                                       float* rstd, int rows, int C, float eps, int relu, int dtype, aldi_stream_t stream) {
-    if (C % 4 || C > 1024 || rows <= 0) return aldi_set_error_msg(ALDI_ERR_ARG, "layernorm: C must be a multiple of 4, <= 1024");
+    if (C % 4 || C > 2048 || rows <= 0) return aldi_set_error_msg(ALDI_ERR_ARG, "layernorm: C must be a multiple of 4, <= 2048");
     hipStream_t st = (hipStream_t)stream;
     VIT_DISPATCH(dtype,
         hipLaunchKernelGGL(ln_fwd_kernel<float>, dim3(cdiv(rows, 4)), dim3(256), 0, st, (const float*)x, map, gamma, beta, (float*)y, mean, rstd, rows, C, eps, relu),
@@ -387,7 +387,7 @@ extern "C" int aldi_layernorm_forward(const void* x, const int* map, const float
 extern "C" int aldi_layernorm_backward(const void* g, const void* x, const int* map, const float* gamma, const float* mean, const float* rstd,
                                        const void* res, const void* mask, void* dx, float* dgamma, float* dbeta, int rows, int C, int dtype,
                                        aldi_stream_t stream) {
-    if (C % 4 || C > 1024 || rows <= 0) return aldi_set_error_msg(ALDI_ERR_ARG, "layernorm: C must be a multiple of 4, <= 1024");
+    if (C % 4 || C > 2048 || rows <= 0) return aldi_set_error_msg(ALDI_ERR_ARG, "layernorm: C must be a multiple of 4, <= 2048");
     hipStream_t st = (hipStream_t)stream;
     const int rpb = 32;
     VIT_DISPATCH(dtype,

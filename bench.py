@@ -48,6 +48,10 @@ def make_cfg(world, height, width, align, workload="r50_fpn"):
     from aldi_amd.config import add_aldi_config, get_cfg
     cfg = get_cfg()
     add_aldi_config(cfg)
+    if workload == "convnext_l":        # reference configs/cityscapes/ALDI-Best-ConvNeXt-Cityscapes.yaml: ConvNeXt-L FPN, AdamW; 2 + 2 images per GPU here
+        cfg.merge_from_file(os.path.join(ROOT, "configs", "cityscapes", "ALDI-Best-ConvNeXt-Cityscapes.yaml"))
+        cfg.merge_from_list(["SOLVER.IMS_PER_BATCH", 4 * world, "SOLVER.IMS_PER_GPU", 2, "SEED", 1, "SYNTHETIC.HEIGHT", height, "SYNTHETIC.WIDTH", width])
+        return cfg
     if workload == "vitdet_b":          # BASELINE configs[3] (cfg 4): ViTDet-B, AdamW, one labeled + one unlabeled image per GPU and step
         cfg.merge_from_file(os.path.join(ROOT, "configs", "cityscapes", "ALDI-VitDetB-Cityscapes.yaml"))
         cfg.merge_from_list(["SOLVER.IMS_PER_BATCH", 2 * world, "SEED", 1, "SYNTHETIC.HEIGHT", height, "SYNTHETIC.WIDTH", width])
@@ -170,11 +174,11 @@ def main():
     ap.add_argument("--sequential", action="store_true", help="reference-style sequential micro-steps instead of the fused student pass")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
-    ap.add_argument("--workload", default="r50_fpn", choices=["r50_fpn", "vitdet_b"],
+    ap.add_argument("--workload", default="r50_fpn", choices=["r50_fpn", "vitdet_b", "convnext_l"],
                     help="r50_fpn = the headline configuration (default); vitdet_b = BASELINE cfg 4 (SURVEY 8(f) rank 1), reported beside it")
     args = ap.parse_args()
     vitdet = args.workload == "vitdet_b"
-    if vitdet:
+    if args.workload != "r50_fpn":
         args.no_profile = args.no_cpu_baseline = True      # the roofline / CPU legs are defined for the headline workload
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -241,12 +245,12 @@ def main():
     losses = {k: float(v) for k, v in tr._trainer.last_loss_dict.items()}
     pl_count = tr.ema.model._last_inference.pseudo["count"].tolist()
 
-    arch_name = "ViTDet-B" if vitdet else "R50-FPN"
+    arch_name = {"vitdet_b": "ViTDet-B", "convnext_l": "ConvNeXt-L-FPN"}.get(args.workload, "R50-FPN")
     out = {"metric": f"images/sec (student+teacher ALDI step), {arch_name} 1333x800", "value": round(value, 3), "unit": "images/sec",
            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True,
            "scaling": "weak", "vs_baseline": None, "dtype": "fp32" if args.fp32 else "bf16", "data": "synthetic",
            "config": {"workload": "configs[%d]: ALDI++ %s Cityscapes->Foggy-shaped synthetic %dx%d, teacher EMA + distill on, align %s, "
-                                  "%d labeled_strong + %d unlabeled (weak+strong) images per GPU" % (3 if vitdet else (2 if args.align else 1), arch_name, args.width,
+                                  "%d labeled_strong + %d unlabeled (weak+strong) images per GPU" % ({"vitdet_b": 3, "convnext_l": -1}.get(args.workload, 2 if args.align else 1), arch_name, args.width,
                                                                                                    args.height, "on" if args.align else "off", per, per),
                       "global_batch": imgs_per_step, "parallelism": f"dp{world}", "pseudo_label_threshold": cfg.DOMAIN_ADAPT.TEACHER.THRESHOLD,
                       "pseudo_labels_per_image": pl_count, "schedule": "sequential micro-steps" if args.sequential else "fused source+target student pass", "weights": f"random-init {arch_name} (synthetic)", "error_flag": err},

@@ -286,7 +286,7 @@ int aldi_aug_hwc_to_chw(const unsigned char* in, unsigned char* out, int H, int 
  * aldi_conv_igemm / aldi_conv_wgrad with H = W = 1.
  * ------------------------------------------------------------------------------------------------------------------ */
 
-/* LayerNorm over the last dim (C % 4 == 0, C <= 1024), rows of `dtype`, fp32 affine and statistics.
+/* LayerNorm over the last dim (C % 4 == 0, C <= 2048), rows of `dtype`, fp32 affine and statistics.
  * map (nullable): output row r reads source row map[r]; map[r] < 0 writes a zero row (window padding).
  * relu != 0 applies ReLU to the output (detectron2 Conv2d(norm=LN, activation=ReLU) of the ViTDet box head). */
 int aldi_layernorm_forward(const void* x, const int* map, const float* gamma, const float* beta, void* y, float* mean,
