@@ -24,34 +24,50 @@ __device__ __forceinline__ void store8(bf16_t* p, const float v[8]) {
 __device__ __forceinline__ void store8(float* p, const float v[8]) { store4(p, v); store4(p + 4, v + 4); }
 
 // y[n][h][w][c] = bias[c] + sum_{kh,kw} x[n][h+kh-3][w+kw-3][c] * wt[kh][kw][c]     (flip: taps mirrored, no bias: data gradient)
+// A thread owns WB = 4 consecutive output pixels of a row for 8 channels: per kernel row it loads the 10 input vectors the four
+// windows share (instead of 4 x 7) and the 7 tap vectors once -- 2.8x fewer loads per output than one pixel per thread.
+constexpr int WB = 4;
 template <typename T>
 __global__ __launch_bounds__(256) void dwconv7_kernel(const T* __restrict__ x, const T* __restrict__ wt, const float* __restrict__ bias,
                                                        T* __restrict__ y, int N, int H, int W, int C, int flip) {
-    const int c8 = C >> 3;
-    const long total = (long)N * H * W * c8;
+    const int c8 = C >> 3, wblocks = (W + WB - 1) / WB;
+    const long total = (long)N * H * wblocks * c8;
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         const int cc = (int)(i % c8) * 8;
-        long pix = i / c8;
-        const int w0 = (int)(pix % W); pix /= W;
-        const int h0 = (int)(pix % H), n = (int)(pix / H);
-        float acc[8];
+        long r = i / c8;
+        const int w0 = (int)(r % wblocks) * WB; r /= wblocks;
+        const int h0 = (int)(r % H), n = (int)(r / H);
+        float acc[WB][8];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) acc[k] = (bias && !flip) ? bias[cc + k] : 0.f;
+        for (int j = 0; j < WB; ++j)
+#pragma unroll
+            for (int k = 0; k < 8; ++k) acc[j][k] = (bias && !flip) ? bias[cc + k] : 0.f;
         for (int kh = 0; kh < 7; ++kh) {
             const int h = h0 + kh - 3;
             if (h < 0 || h >= H) continue;
+            float xv[WB + 6][8];
+#pragma unroll
+            for (int t = 0; t < WB + 6; ++t) {
+                const int w = w0 + t - 3;
+                if (w >= 0 && w < W) load8(x + (((long)n * H + h) * W + w) * C + cc, xv[t]);
+                else {
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) xv[t][k] = 0.f;
+                }
+            }
 #pragma unroll
             for (int kw = 0; kw < 7; ++kw) {
-                const int w = w0 + kw - 3;
-                if (w < 0 || w >= W) continue;
-                float xv[8], wv[8];
-                load8(x + (((long)n * H + h) * W + w) * C + cc, xv);
+                float wv[8];
                 load8(wt + ((flip ? (6 - kh) * 7 + (6 - kw) : kh * 7 + kw) * (long)C) + cc, wv);
 #pragma unroll
-                for (int k = 0; k < 8; ++k) acc[k] += xv[k] * wv[k];
+                for (int j = 0; j < WB; ++j)
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) acc[j][k] += xv[j + kw][k] * wv[k];
             }
         }
-        store8(y + i * 8, acc);
+#pragma unroll
+        for (int j = 0; j < WB; ++j)
+            if (w0 + j < W) store8(y + (((long)n * H + h0) * W + w0 + j) * C + cc, acc[j]);
     }
 }
 
@@ -177,7 +193,7 @@ extern "C" int aldi_dwconv7(const void* x, const void* wt, const float* bias, vo
                             aldi_stream_t stream) {
     if (!x || !wt || !y || C % 8 || N <= 0 || H <= 0 || W <= 0) return aldi_set_error_msg(ALDI_ERR_ARG, "dwconv7: bad args (C % 8 == 0)");
     hipStream_t st = (hipStream_t)stream;
-    const long work = (long)N * H * W * (C / 8);
+    const long work = (long)N * H * ((W + 3) / 4) * (C / 8);
     CNX_DISPATCH(dtype,
         hipLaunchKernelGGL(dwconv7_kernel<float>, dim3(grid_for(work)), dim3(256), 0, st, (const float*)x, (const float*)wt, bias, (float*)y, N, H, W, C, flip),
         hipLaunchKernelGGL(dwconv7_kernel<bf16_t>, dim3(grid_for(work)), dim3(256), 0, st, (const bf16_t*)x, (const bf16_t*)wt, bias, (bf16_t*)y, N, H, W, C, flip));
