@@ -46,13 +46,19 @@ __global__ __launch_bounds__(256) void dwconv7_kernel(const T* __restrict__ x, c
             const int h = h0 + kh - 3;
             if (h < 0 || h >= H) continue;
             float xv[WB + 6][8];
+            const T* xrow = x + (((long)n * H + h) * W) * C + cc;
+            if (w0 >= 3 && w0 + WB + 3 <= W) {                   // interior of the row: no per-vector bounds checks
 #pragma unroll
-            for (int t = 0; t < WB + 6; ++t) {
-                const int w = w0 + t - 3;
-                if (w >= 0 && w < W) load8(x + (((long)n * H + h) * W + w) * C + cc, xv[t]);
-                else {
+                for (int t = 0; t < WB + 6; ++t) load8(xrow + (long)(w0 + t - 3) * C, xv[t]);
+            } else {
 #pragma unroll
-                    for (int k = 0; k < 8; ++k) xv[t][k] = 0.f;
+                for (int t = 0; t < WB + 6; ++t) {
+                    const int w = w0 + t - 3;
+                    if (w >= 0 && w < W) load8(xrow + (long)w * C, xv[t]);
+                    else {
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) xv[t][k] = 0.f;
+                    }
                 }
             }
 #pragma unroll
@@ -62,7 +68,7 @@ __global__ __launch_bounds__(256) void dwconv7_kernel(const T* __restrict__ x, c
 #pragma unroll
                 for (int j = 0; j < WB; ++j)
 #pragma unroll
-                    for (int k = 0; k < 8; ++k) acc[j][k] += xv[j + kw][k] * wv[k];
+                    for (int k = 0; k < 8; ++k) acc[j][k] = fmaf(xv[j + kw][k], wv[k], acc[j][k]);     // explicit FMA: packs into v_pk_fma_f32
             }
         }
 #pragma unroll
@@ -102,7 +108,7 @@ __global__ __launch_bounds__(256) void dwconv7_wgrad_kernel(const T* __restrict_
                 float xv[8];
                 load8(x + (((long)n * H + h) * W + w) * C + cc, xv);
 #pragma unroll
-                for (int k = 0; k < 8; ++k) acc[kw][k] += xv[k] * gv[k];
+                for (int k = 0; k < 8; ++k) acc[kw][k] = fmaf(xv[k], gv[k], acc[kw][k]);
             }
         }
     for (int kw = 0; kw < 7; ++kw) {
