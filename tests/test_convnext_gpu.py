@@ -203,3 +203,27 @@ def test_convnext_fpn_aldi_trainer_runs(fused, tmp_path):
     assert (s - w0).abs().max() > 0 and (t - s).abs().max() > 0
     sd = tr.model.state_dict()
     assert sd["backbone.bottom_up.stages.2.1.dwconv.weight"].shape == (96, 1, 7, 7) and "backbone.fpn_lateral3.weight" in sd
+
+
+def test_convnext_trunk_ragged_batch_vs_oracle():
+    """images of different sizes in one batch: the padding of the staging buffer must enter the 4x4 stem as zeros of the NORMALISED
+    image (detectron2 pads after normalisation), here with stochastic depth on (host-drawn multipliers fed to both sides)"""
+    from aldi_amd.convnext import ConvNeXt, ConvNeXtConfig
+    from aldi_amd.vit import VitParams
+    from oracle import d2_convnext as oc
+    cfg, params, sd, _ = _detector(9)
+    net = ConvNeXt(params)
+    torch.manual_seed(10)
+    img = torch.randint(0, 256, (2, 3, 96, 128), dtype=torch.uint8, device=DEV)
+    sizes = [(96, 128), (70, 90)]
+    img[1, :, 70:, :] = 0
+    img[1, :, :, 90:] = 0
+    ds = torch.tensor([[1.0, 0.0], [1.25, 1.25], [0.0, 1.0 / 0.7], [1.0, 1.0], [2.0, 0.0]])        # one row per block (5 blocks)
+    ctx = net.forward(img, sizes, save=False, drop_scales=ds)
+    x = img.float() - torch.tensor(cfg.pixel_mean, device=DEV).view(1, 3, 1, 1)
+    x[1, :, 70:, :] = 0
+    x[1, :, :, 90:] = 0
+    sdd = {k: v.to(DEV) for k, v in sd.items()}
+    ref = oc.convnext_forward(CC, sdd, x, drop_scales=ds.to(DEV))
+    for i in range(4):
+        assert relerr(ctx.outs[i], ref[i].permute(0, 2, 3, 1)) < 4e-2, i
