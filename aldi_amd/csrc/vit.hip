@@ -11,9 +11,9 @@ namespace {
 // ------------------------------------------------------------------------------------------------ LayerNorm
 // One wave per output row.  `map` (nullable) gathers: output row r normalises source row map[r]; map[r] < 0 is a padding
 // row of a partitioned window and is written as zeros (detectron2 pads AFTER norm1, so the padded tokens are exact zeros).
-constexpr int LN_MAXCH = 8;     // C <= 2048 (ConvNeXt-L stage 3 is 1536 wide), C % 4 == 0; lane chunk j (4 channels at (lane + 64 j) * 4) is live iff inside C
+// C <= 2048 (ConvNeXt-L stage 3 is 1536 wide), C % 4 == 0; instantiated for 4 chunks (C <= 1024: half the registers) and 8; lane chunk j (4 channels at (lane + 64 j) * 4) is live iff inside C
 
-template <typename T>
+template <typename T, int LN_MAXCH>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, const int* __restrict__ map, const float* __restrict__ gamma,
                                                       const float* __restrict__ beta, T* __restrict__ y, float* __restrict__ mean,
                                                       float* __restrict__ rstd, int rows, int C, float eps, int relu) {
@@ -62,12 +62,12 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, co
 }
 
 // dx[src] = rstd * (g*gamma - mean(g*gamma) - xhat * mean(g*gamma*xhat)) (+ res[src]);  dgamma += g*xhat, dbeta += g
-template <typename T>
+template <typename T, int LN_MAXCH>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ g, const T* __restrict__ x, const int* __restrict__ map,
                                                       const float* __restrict__ gamma, const float* __restrict__ mean,
                                                       const float* __restrict__ rstd, const T* __restrict__ res, const T* __restrict__ mask,
                                                       T* __restrict__ dx, float* __restrict__ dgamma, float* __restrict__ dbeta, int rows, int C, int rows_per_block) {
-    __shared__ float red[4 * 2048];
+    __shared__ float red[4 * LN_MAXCH * 256];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     float dg[LN_MAXCH][4], db[LN_MAXCH][4], gm[LN_MAXCH][4];
 #pragma unroll
@@ -123,11 +123,12 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ g, co
         for (int j = 0; j < LN_MAXCH; ++j)
             if ((lane + 64 * j) * 4 < C) {
 #pragma unroll
-                for (int i = 0; i < 4; ++i) red[wave * 2048 + (lane + 64 * j) * 4 + i] = pass ? db[j][i] : dg[j][i];
+                for (int i = 0; i < 4; ++i) red[wave * (LN_MAXCH * 256) + (lane + 64 * j) * 4 + i] = pass ? db[j][i] : dg[j][i];
             }
         __syncthreads();
         for (int cidx = threadIdx.x; cidx < C; cidx += 256) {
-            const float t = (red[cidx] + red[2048 + cidx]) + (red[4096 + cidx] + red[6144 + cidx]);
+            constexpr int RS = LN_MAXCH * 256;
+            const float t = (red[cidx] + red[RS + cidx]) + (red[2 * RS + cidx] + red[3 * RS + cidx]);
             atomicAdd((pass ? dbeta : dgamma) + cidx, t);
         }
     }
@@ -377,9 +378,15 @@ extern "C" int aldi_layernorm_forward(const void* x, const int* map, const float
                                       float* rstd, int rows, int C, float eps, int relu, int dtype, aldi_stream_t stream) {
     if (C % 4 || C > 2048 || rows <= 0) return aldi_set_error_msg(ALDI_ERR_ARG, "layernorm: C must be a multiple of 4, <= 2048");
     hipStream_t st = (hipStream_t)stream;
-    VIT_DISPATCH(dtype,
-        hipLaunchKernelGGL(ln_fwd_kernel<float>, dim3(cdiv(rows, 4)), dim3(256), 0, st, (const float*)x, map, gamma, beta, (float*)y, mean, rstd, rows, C, eps, relu),
-        hipLaunchKernelGGL(ln_fwd_kernel<bf16_t>, dim3(cdiv(rows, 4)), dim3(256), 0, st, (const bf16_t*)x, map, gamma, beta, (bf16_t*)y, mean, rstd, rows, C, eps, relu));
+    if (C <= 1024) {
+        VIT_DISPATCH(dtype,
+            hipLaunchKernelGGL((ln_fwd_kernel<float, 4>), dim3(cdiv(rows, 4)), dim3(256), 0, st, (const float*)x, map, gamma, beta, (float*)y, mean, rstd, rows, C, eps, relu),
+            hipLaunchKernelGGL((ln_fwd_kernel<bf16_t, 4>), dim3(cdiv(rows, 4)), dim3(256), 0, st, (const bf16_t*)x, map, gamma, beta, (bf16_t*)y, mean, rstd, rows, C, eps, relu));
+    } else {
+        VIT_DISPATCH(dtype,
+            hipLaunchKernelGGL((ln_fwd_kernel<float, 8>), dim3(cdiv(rows, 4)), dim3(256), 0, st, (const float*)x, map, gamma, beta, (float*)y, mean, rstd, rows, C, eps, relu),
+            hipLaunchKernelGGL((ln_fwd_kernel<bf16_t, 8>), dim3(cdiv(rows, 4)), dim3(256), 0, st, (const bf16_t*)x, map, gamma, beta, (bf16_t*)y, mean, rstd, rows, C, eps, relu));
+    }
     ALDI_CHECK_LAUNCH();
     return ALDI_OK;
 }
@@ -390,11 +397,19 @@ extern "C" int aldi_layernorm_backward(const void* g, const void* x, const int* 
     if (C % 4 || C > 2048 || rows <= 0) return aldi_set_error_msg(ALDI_ERR_ARG, "layernorm: C must be a multiple of 4, <= 2048");
     hipStream_t st = (hipStream_t)stream;
     const int rpb = 32;
+    if (C <= 1024) {
     VIT_DISPATCH(dtype,
-        hipLaunchKernelGGL(ln_bwd_kernel<float>, dim3(cdiv(rows, rpb)), dim3(256), 0, st, (const float*)g, (const float*)x, map, gamma, mean, rstd,
+        hipLaunchKernelGGL((ln_bwd_kernel<float, 4>), dim3(cdiv(rows, rpb)), dim3(256), 0, st, (const float*)g, (const float*)x, map, gamma, mean, rstd,
                            (const float*)res, (const float*)mask, (float*)dx, dgamma, dbeta, rows, C, rpb),
-        hipLaunchKernelGGL(ln_bwd_kernel<bf16_t>, dim3(cdiv(rows, rpb)), dim3(256), 0, st, (const bf16_t*)g, (const bf16_t*)x, map, gamma, mean, rstd,
+        hipLaunchKernelGGL((ln_bwd_kernel<bf16_t, 4>), dim3(cdiv(rows, rpb)), dim3(256), 0, st, (const bf16_t*)g, (const bf16_t*)x, map, gamma, mean, rstd,
                            (const bf16_t*)res, (const bf16_t*)mask, (bf16_t*)dx, dgamma, dbeta, rows, C, rpb));
+    } else {
+    VIT_DISPATCH(dtype,
+        hipLaunchKernelGGL((ln_bwd_kernel<float, 8>), dim3(cdiv(rows, rpb)), dim3(256), 0, st, (const float*)g, (const float*)x, map, gamma, mean, rstd,
+                           (const float*)res, (const float*)mask, (float*)dx, dgamma, dbeta, rows, C, rpb),
+        hipLaunchKernelGGL((ln_bwd_kernel<bf16_t, 8>), dim3(cdiv(rows, rpb)), dim3(256), 0, st, (const bf16_t*)g, (const bf16_t*)x, map, gamma, mean, rstd,
+                           (const bf16_t*)res, (const bf16_t*)mask, (bf16_t*)dx, dgamma, dbeta, rows, C, rpb));
+    }
     ALDI_CHECK_LAUNCH();
     return ALDI_OK;
 }
