@@ -561,8 +561,8 @@ class ViT:
         gpos = p.g("pos_embed")[0, 1:].view(G, G, E)
         if (G, G) != (gh, gw):
             V.bicubic_resize_backward(dpos, gpos)
-        else:
-            gpos += dpos
+        else:                                                          # same grid as pre-training: plain accumulation (a kernel, not torch arithmetic)
+            V.rows_add(gpos.reshape(-1, E), dpos.reshape(-1, E), rows=gh * gw, out=gpos.reshape(-1, E))
         self._linear_bwd_patch(ctx.patches, g)
         if self.grad_ready is not None:
             self.grad_ready(p.ranges([c.prefix + "pos_embed", c.prefix + "patch_embed.proj.weight", c.prefix + "patch_embed.proj.bias"]))
