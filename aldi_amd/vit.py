@@ -403,14 +403,20 @@ class ViT:
         self._geom: Dict[Tuple[int, int, int], dict] = {}
         self.grad_ready = None           # callback(ranges): data-parallel overlapped exchange (reduce.BucketedReducer.ready)
 
+    MAX_GEOMETRIES = 4            # multi-scale training sees many (N, gh, gw): each holds ~0.1 GB of attention operands per block
+
     def geometry(self, N: int, gh: int, gw: int) -> dict:
         key = (N, gh, gw)
-        if key not in self._geom:
-            c = self.cfg
-            win, inv, nW = window_maps(N, gh, gw, c.window, self.device)
-            self._geom[key] = dict(win=win, inv=inv, nW=nW, att={},
-                                   att_w=V.Attention(nW, c.window, c.window, c.heads, self.device),
-                                   att_g=V.Attention(N, gh, gw, c.heads, self.device))
+        if key in self._geom:
+            self._geom[key] = self._geom.pop(key)                     # most recently used last
+            return self._geom[key]
+        c = self.cfg
+        win, inv, nW = window_maps(N, gh, gw, c.window, self.device)
+        self._geom[key] = dict(win=win, inv=inv, nW=nW, att={},
+                               att_w=V.Attention(nW, c.window, c.window, c.heads, self.device),
+                               att_g=V.Attention(N, gh, gw, c.heads, self.device))
+        while len(self._geom) > self.MAX_GEOMETRIES:                  # least recently used geometry (and its workspaces) goes
+            self._geom.pop(next(iter(self._geom)))
         return self._geom[key]
 
     def _attention(self, geo: dict, i: int, N: int, gh: int, gw: int, save: bool) -> V.Attention:

@@ -433,3 +433,21 @@ def test_simple_feature_pyramid_fwd_bwd():
         if e > 6e-2:
             bad[name] = e
     assert not bad, bad
+
+
+def test_vit_geometry_cache_is_bounded():
+    """multi-scale inputs: per-geometry attention workspaces are kept for the most recent few shapes only, and a pass whose geometry
+    was evicted and rebuilt still produces the same tokens"""
+    from aldi_amd.vit import ViT, VitConfig, VitParams
+    cfg = VitConfig(embed=128, depth=2, heads=2, window=7, global_blocks=(1,), pretrain_grid=4, rel_input=10, drop_path_rate=0.0)
+    params = VitParams(cfg, DEV)
+    params.init_random(1)
+    vit = ViT(params)
+    torch.manual_seed(0)
+    first = torch.randint(0, 256, (1, 3, 64, 96), dtype=torch.uint8, device=DEV)
+    ref = vit.forward(first, [(64, 96)], save=False).out.clone()
+    for h, w in ((64, 64), (96, 64), (96, 96), (128, 64), (64, 128), (128, 96)):
+        vit.forward(torch.randint(0, 256, (1, 3, h, w), dtype=torch.uint8, device=DEV), [(h, w)], save=True)
+    assert len(vit._geom) <= ViT.MAX_GEOMETRIES and (1, 4, 6) not in vit._geom
+    again = vit.forward(first, [(64, 96)], save=False).out
+    assert torch.equal(again, ref)
