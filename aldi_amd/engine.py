@@ -306,6 +306,10 @@ class RCNN:
             geom = ops.make_geom(shapes, NUM_ANCHORS, self.Ch)
             anchors = make_anchors(shapes, self.device, getattr(self, "anchor_sizes", ANCHOR_SIZES))
             self._anchor_cache[key] = (shapes, geom, anchors)
+            while len(self._anchor_cache) > 16:               # multi-scale training: keep the most recent padded sizes only (4 MB of anchors each)
+                self._anchor_cache.pop(next(iter(self._anchor_cache)))
+        else:
+            self._anchor_cache[key] = self._anchor_cache.pop(key)
         return self._anchor_cache[key]
 
     def workspace(self, name: str, nbytes: int) -> torch.Tensor:
