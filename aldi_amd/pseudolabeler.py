@@ -34,27 +34,24 @@ def pseudo_label_inplace(model, unlabeled_weak, unlabeled_strong, threshold):
 
 
 def process_pseudo_label(proposals, cur_threshold):
-    list_instances = []
-    num_proposal_output = 0.0
-    for proposal_bbox_inst in proposals:
-        proposal_bbox_inst = process_bbox(proposal_bbox_inst, thres=cur_threshold)
-        num_proposal_output += len(proposal_bbox_inst)
-        list_instances.append(proposal_bbox_inst)
-    num_proposal_output = num_proposal_output / len(proposals)
-    return list_instances, num_proposal_output
+    """-> (filtered Instances per image, mean number kept): the host-side form of what `aldi_detections` does on the device
+    (reference aldi/pseudolabeler.py:40-49, same name and return shape)"""
+    kept = [process_bbox(inst, thres=cur_threshold) for inst in proposals]
+    return kept, sum(len(k) for k in kept) / len(proposals)
 
 
 def process_bbox(proposal_bbox_inst, thres=0.7):
-    """Host-side statement of the filter (strict >), for Instances that are already materialised."""
-    valid_map = proposal_bbox_inst.scores > thres
-    new_proposal_inst = Instances(proposal_bbox_inst.image_size)
-    new_proposal_inst.gt_boxes = Boxes(proposal_bbox_inst.pred_boxes.tensor[valid_map, :]).to("cpu")
-    new_proposal_inst.gt_classes = proposal_bbox_inst.pred_classes[valid_map].to("cpu")
-    new_proposal_inst.scores = proposal_bbox_inst.scores[valid_map].to("cpu")
-    return new_proposal_inst
+    """keep detections scoring strictly above `thres`, renamed to ground-truth fields and moved to the host (aldi/pseudolabeler.py:51-67)"""
+    keep = proposal_bbox_inst.scores > thres
+    out = Instances(proposal_bbox_inst.image_size)
+    for dst, src in (("gt_classes", proposal_bbox_inst.pred_classes), ("scores", proposal_bbox_inst.scores)):
+        setattr(out, dst, src[keep].to("cpu"))
+    out.gt_boxes = Boxes(proposal_bbox_inst.pred_boxes.tensor[keep]).to("cpu")
+    return out
 
 
 def add_label(unlabled_data, label):
-    for unlabel_datum, lab_inst in zip(unlabled_data, label):
-        unlabel_datum["instances"] = lab_inst
+    """attach pseudo labels as the `instances` of each dict (the SAME object for the weak and the strong view); returns its input"""
+    for datum, inst in zip(unlabled_data, label):
+        datum["instances"] = inst
     return unlabled_data
