@@ -535,3 +535,28 @@ def test_teacher_coco_evaluation_and_best_checkpoint(tmp_path):
         tr.after_step()
         tr.iter += 1
     assert hasattr(tr, "_last_eval_results") and "bbox" in tr._last_eval_results
+
+
+def test_hard_distiller_runs_through_the_trainer():
+    """`HardDistiller` (pseudo-label-only self-training, the distiller the reference's DETR config uses: aldi/distill.py:62-84): teacher
+    inference -> thresholded pseudo labels -> the student's ordinary supervised losses on them, through the sequential driver"""
+    from aldi_amd.distill import HardDistiller
+    from aldi_amd.trainer import ALDITrainer
+    cfg = _cfg(False, bf16=True)
+    cfg.merge_from_list(["DOMAIN_ADAPT.DISTILL.DISTILLER_NAME", "HardDistiller", "DOMAIN_ADAPT.DISTILL.HARD_ROIH_CLS_ENABLED", True,
+                         "DOMAIN_ADAPT.DISTILL.HARD_ROIH_REG_ENABLED", True, "DOMAIN_ADAPT.DISTILL.HARD_OBJ_ENABLED", True,
+                         "DOMAIN_ADAPT.DISTILL.HARD_RPN_REG_ENABLED", True, "DOMAIN_ADAPT.TEACHER.THRESHOLD", 0.05])
+    random.seed(0)
+    torch.manual_seed(2)
+    tr = ALDITrainer(cfg)
+    assert isinstance(tr._trainer.distiller, HardDistiller) and tr._trainer.distiller.distill_enabled()
+    for _ in range(2):
+        tr.before_step()
+        tr.run_step()
+        tr.after_step()
+        tr.iter += 1
+    torch.cuda.synchronize()
+    ld = tr._trainer.last_loss_dict
+    assert {"loss_cls_distill", "loss_box_reg_distill", "loss_rpn_cls_distill", "loss_rpn_loc_distill"} <= set(ld), set(ld)
+    assert all(float(v) == float(v) for v in ld.values()) and int(tr.model.engine.err) == 0
+    assert float(tr.model.weights.grad.abs().max()) > 0
