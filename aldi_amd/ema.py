@@ -19,7 +19,7 @@ class EMA:
         for key in self.model.layout.state_dict_keys():
             if key not in skeys:
                 raise Exception("{} is not found in student model".format(key))
-            if any(k in key for k in self.exclude_keys):
+            if any(k in key for k in self.exclude_keys) and not hasattr(self.model.weights, "off"):
                 raise NotImplementedError("excluded (copied) keys are not part of the R50-FPN layout")
 
     def _init_ema_weights(self, model):
@@ -31,6 +31,18 @@ class EMA:
         s = self._student(model)
         self._check(s)
         self.model.weights.ema_from(s.weights, self.alpha, copy_only=False)
+        self._copy_excluded(s)
+
+    def _copy_excluded(self, student):
+        """keys matching `exclude_keys` are copied from the student instead of averaged (reference aldi/ema.py:39-41: DETR's
+        query embeddings); flat-container models address them by state_dict name"""
+        W = self.model.weights
+        names = [k for k in self.model.layout.state_dict_keys() if any(x in k for x in self.exclude_keys)]
+        if not names:
+            return
+        for lo, hi in W.ranges(names):
+            W.master[lo:hi].copy_(student.weights.master[lo:hi])
+        W.refresh()
 
     def update_weights(self, model, iter):
         if iter <= self.start_iter:

@@ -292,3 +292,26 @@ def test_vitdet_overlapped_exchange_reports_final_gradients():
     # the unreported remainder is layout padding only
     rest = complement(merge_ranges(spans), W.n)
     assert all(float(W.grad[lo:hi].abs().sum()) == 0.0 for lo, hi in rest)
+
+
+def test_ema_copies_excluded_keys_instead_of_averaging():
+    """reference aldi/ema.py:17,39-41: keys listed in `exclude_keys` (DETR's query_embed) are copied from the student; everything else
+    follows teacher = alpha * teacher + (1 - alpha) * student.  Exercised on the flat container with pos_embed standing in."""
+    import random
+    from aldi_amd.trainer import ALDITrainer
+    cfg = _trainer_cfg(True)
+    random.seed(0)
+    torch.manual_seed(7)
+    tr = ALDITrainer(cfg)
+    tr.ema.exclude_keys = ["pos_embed"]
+    tr.before_step()                                   # iter 0 <= start_iter: teacher := student
+    S, Tm = tr.model.weights, tr.ema.model.weights
+    t0 = Tm.master.clone()
+    S.master.add_(0.01 * torch.randn_like(S.master))
+    tr.iter = 1
+    tr.before_step()
+    (lo, hi), = S.ranges(["backbone.net.pos_embed"])
+    assert torch.equal(Tm.master[lo:hi], S.master[lo:hi])
+    other = slice(0, lo)
+    assert torch.allclose(Tm.master[other], 0.9 * t0[other] + 0.1 * S.master[other], atol=1e-6)
+    assert not torch.equal(Tm.master[other], S.master[other])
