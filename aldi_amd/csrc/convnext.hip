@@ -77,39 +77,55 @@ __global__ __launch_bounds__(256) void dwconv7_kernel(const T* __restrict__ x, c
     }
 }
 
-// dw[kh][kw][c] += sum_{n,h,w} x[n][h+kh-3][w+kw-3][c] * g[n][h][w][c].  One block = (pixel chunk, up to 256 channels, kernel row kh):
-// lanes run along the channels (CG channel groups of 8: one coalesced 16-B load per lane), 256 / CG pixel lanes walk the chunk;
-// each thread keeps the 7 taps of its row for 8 channels, the pixel lanes meet in LDS, one atomic per (tap, channel) per block.
+// dw[kh][kw][c] += sum_{n,h,w} x[n][h+kh-3][w+kw-3][c] * g[n][h][w][c].  One block = (chunk of pixel quads, up to 256 channels, kernel row
+// kh): lanes run along the channels (CG channel groups of 8: one coalesced 16-B load per lane), 256 / CG pixel lanes walk the chunk in
+// quads of WB = 4 consecutive pixels of a row, so the four windows share their 10 input vectors; each thread keeps the 7 taps of its
+// kernel row for 8 channels, the pixel lanes meet in LDS, one atomic per (tap, channel) per block.
 template <typename T>
 __global__ __launch_bounds__(256) void dwconv7_wgrad_kernel(const T* __restrict__ x, const T* __restrict__ g, float* __restrict__ dw, int N, int H,
-                                                             int W, int C, int pix_per_block, int CG) {
+                                                             int W, int C, int quads_per_block, int CG) {
     __shared__ float red[256 * 8];
-    const int c8 = C >> 3, ngrp = (c8 + CG - 1) / CG;
+    const int c8 = C >> 3, ngrp = (c8 + CG - 1) / CG, wblocks = (W + WB - 1) / WB;
     const int kh = blockIdx.y / ngrp, cg = (blockIdx.y - kh * ngrp) * CG + threadIdx.x % CG, pl = threadIdx.x / CG, npl = 256 / CG;
     const bool live = cg < c8;
     const int cc = cg * 8;
-    const long npix = (long)N * H * W, p0 = (long)blockIdx.x * pix_per_block, p1 = min(npix, p0 + pix_per_block);
+    const long nquads = (long)N * H * wblocks, q0 = (long)blockIdx.x * quads_per_block, q1 = min(nquads, q0 + quads_per_block);
     float acc[7][8];
 #pragma unroll
     for (int kw = 0; kw < 7; ++kw)
 #pragma unroll
         for (int k = 0; k < 8; ++k) acc[kw][k] = 0.f;
     if (live)
-        for (long p = p0 + pl; p < p1; p += npl) {
-            const int w0 = (int)(p % W), h0 = (int)((p / W) % H), n = (int)(p / ((long)W * H));
+        for (long q = q0 + pl; q < q1; q += npl) {
+            const int w0 = (int)(q % wblocks) * WB, h0 = (int)((q / wblocks) % H), n = (int)(q / ((long)wblocks * H));
             const int h = h0 + kh - 3;
             if (h < 0 || h >= H) continue;
-            float gv[8];
-            load8(g + p * C + cc, gv);
+            float gv[WB][8], xv[WB + 6][8];
+            const T* grow = g + (((long)n * H + h0) * W) * C + cc;
+            const T* xrow = x + (((long)n * H + h) * W) * C + cc;
 #pragma unroll
-            for (int kw = 0; kw < 7; ++kw) {
-                const int w = w0 + kw - 3;
-                if (w < 0 || w >= W) continue;
-                float xv[8];
-                load8(x + (((long)n * H + h) * W + w) * C + cc, xv);
+            for (int j = 0; j < WB; ++j) {
+                if (w0 + j < W) load8(grow + (long)(w0 + j) * C, gv[j]);
+                else {
 #pragma unroll
-                for (int k = 0; k < 8; ++k) acc[kw][k] = fmaf(xv[k], gv[k], acc[kw][k]);
+                    for (int k = 0; k < 8; ++k) gv[j][k] = 0.f;
+                }
             }
+#pragma unroll
+            for (int t = 0; t < WB + 6; ++t) {
+                const int w = w0 + t - 3;
+                if (w >= 0 && w < W) load8(xrow + (long)w * C, xv[t]);
+                else {
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) xv[t][k] = 0.f;
+                }
+            }
+#pragma unroll
+            for (int kw = 0; kw < 7; ++kw)
+#pragma unroll
+                for (int j = 0; j < WB; ++j)
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) acc[kw][k] = fmaf(xv[j + kw][k], gv[j][k], acc[kw][k]);
         }
     for (int kw = 0; kw < 7; ++kw) {
         __syncthreads();
@@ -210,14 +226,14 @@ extern "C" int aldi_dwconv7(const void* x, const void* wt, const float* bias, vo
 extern "C" int aldi_dwconv7_wgrad(const void* x, const void* g, float* dw, int N, int H, int W, int C, int dtype, aldi_stream_t stream) {
     if (!x || !g || !dw || C % 8 || N <= 0 || H <= 0 || W <= 0) return aldi_set_error_msg(ALDI_ERR_ARG, "dwconv7_wgrad: bad args (C % 8 == 0)");
     hipStream_t st = (hipStream_t)stream;
-    const long npix = (long)N * H * W;
     const int c8 = C / 8, CG = c8 >= 32 ? 32 : (c8 >= 16 ? 16 : (c8 >= 8 ? 8 : (c8 >= 4 ? 4 : (c8 >= 2 ? 2 : 1))));   // channel groups per block
     const int ngrp = (c8 + CG - 1) / CG;
-    // enough blocks to fill the chip (>= ~2048), at least 256 pixels each
-    long chunks = 2048 / (7 * ngrp) + 1;
-    if (chunks > npix / 256 + 1) chunks = npix / 256 + 1;
-    const int ppb = (int)((npix + chunks - 1) / chunks);
-    dim3 grid(cdiv(npix, ppb), ngrp * 7);
+    // ~1024 blocks over the chip, at least 64 quads (256 pixels) each: the per-block LDS reduction and atomics stay a small fraction
+    const long nquads = (long)N * H * ((W + 3) / 4);
+    long chunks = 1024 / (7 * ngrp) + 1;
+    if (chunks > nquads / 64 + 1) chunks = nquads / 64 + 1;
+    const int ppb = (int)((nquads + chunks - 1) / chunks);
+    dim3 grid(cdiv(nquads, ppb), ngrp * 7);
     CNX_DISPATCH(dtype,
         hipLaunchKernelGGL(dwconv7_wgrad_kernel<float>, grid, dim3(256), 0, st, (const float*)x, (const float*)g, dw, N, H, W, C, ppb, CG),
         hipLaunchKernelGGL(dwconv7_wgrad_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)x, (const bf16_t*)g, dw, N, H, W, C, ppb, CG));
