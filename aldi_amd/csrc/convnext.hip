@@ -32,7 +32,10 @@ __global__ __launch_bounds__(256) void dwconv7_kernel(const T* __restrict__ x, c
                                                        T* __restrict__ y, int N, int H, int W, int C, int flip) {
     const int c8 = C >> 3, wblocks = (W + WB - 1) / WB;
     const long total = (long)N * H * wblocks * c8;
-    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    // workgroup b runs on XCD b % 8, each with its own L2: give every XCD a contiguous band of rows, so that the 7 input rows an
+    // output row needs are re-read from THAT L2 and not fetched from HBM by eight different ones (gridDim.x is a multiple of 8)
+    const long lb = (long)(blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+    for (long i = lb * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         const int cc = (int)(i % c8) * 8;
         long r = i / c8;
         const int w0 = (int)(r % wblocks) * WB; r /= wblocks;
@@ -86,10 +89,15 @@ __global__ __launch_bounds__(256) void dwconv7_wgrad_kernel(const T* __restrict_
                                                              int W, int C, int quads_per_block, int CG) {
     __shared__ float red[256 * 8];
     const int c8 = C >> 3, ngrp = (c8 + CG - 1) / CG, wblocks = (W + WB - 1) / WB;
-    const int kh = blockIdx.y / ngrp, cg = (blockIdx.y - kh * ngrp) * CG + threadIdx.x % CG, pl = threadIdx.x / CG, npl = 256 / CG;
+    // 1-D grid of 8 * ceil(chunks / 8) * (7 * ngrp) blocks: XCD b % 8 owns the chunks congruent to it and walks the 7 * ngrp (kernel row,
+    // channel group) blocks of one chunk back to back, so g and the 7 input rows of that chunk are served by ONE L2 instead of
+    // being fetched from HBM once per kernel row
+    const int per = 7 * ngrp, xcd = blockIdx.x & 7, seq = blockIdx.x >> 3;
+    const int chunk = (seq / per) * 8 + xcd, by = seq % per;
+    const int kh = by / ngrp, cg = (by - kh * ngrp) * CG + threadIdx.x % CG, pl = threadIdx.x / CG, npl = 256 / CG;
     const bool live = cg < c8;
     const int cc = cg * 8;
-    const long nquads = (long)N * H * wblocks, q0 = (long)blockIdx.x * quads_per_block, q1 = min(nquads, q0 + quads_per_block);
+    const long nquads = (long)N * H * wblocks, q0 = (long)chunk * quads_per_block, q1 = min(nquads, q0 + quads_per_block);
     float acc[7][8];
 #pragma unroll
     for (int kw = 0; kw < 7; ++kw)
@@ -136,7 +144,7 @@ __global__ __launch_bounds__(256) void dwconv7_wgrad_kernel(const T* __restrict_
             const int grp = threadIdx.x >> 3, k = threadIdx.x & 7;
             float s = 0.f;
             for (int q = 0; q < npl; ++q) s += red[(q * CG + grp) * 8 + k];
-            const int cgo = (blockIdx.y - kh * ngrp) * CG + grp;
+            const int cgo = (by - kh * ngrp) * CG + grp;
             if (cgo < c8) atomicAdd(dw + (long)(kh * 7 + kw) * C + cgo * 8 + k, s);
         }
     }
@@ -216,9 +224,10 @@ extern "C" int aldi_dwconv7(const void* x, const void* wt, const float* bias, vo
     if (!x || !wt || !y || C % 8 || N <= 0 || H <= 0 || W <= 0) return aldi_set_error_msg(ALDI_ERR_ARG, "dwconv7: bad args (C % 8 == 0)");
     hipStream_t st = (hipStream_t)stream;
     const long work = (long)N * H * ((W + 3) / 4) * (C / 8);
+    const int nblk = (grid_for(work) + 7) / 8 * 8;
     CNX_DISPATCH(dtype,
-        hipLaunchKernelGGL(dwconv7_kernel<float>, dim3(grid_for(work)), dim3(256), 0, st, (const float*)x, (const float*)wt, bias, (float*)y, N, H, W, C, flip),
-        hipLaunchKernelGGL(dwconv7_kernel<bf16_t>, dim3(grid_for(work)), dim3(256), 0, st, (const bf16_t*)x, (const bf16_t*)wt, bias, (bf16_t*)y, N, H, W, C, flip));
+        hipLaunchKernelGGL(dwconv7_kernel<float>, dim3(nblk), dim3(256), 0, st, (const float*)x, (const float*)wt, bias, (float*)y, N, H, W, C, flip),
+        hipLaunchKernelGGL(dwconv7_kernel<bf16_t>, dim3(nblk), dim3(256), 0, st, (const bf16_t*)x, (const bf16_t*)wt, bias, (bf16_t*)y, N, H, W, C, flip));
     ALDI_CHECK_LAUNCH();
     return ALDI_OK;
 }
@@ -233,7 +242,8 @@ extern "C" int aldi_dwconv7_wgrad(const void* x, const void* g, float* dw, int N
     long chunks = 1024 / (7 * ngrp) + 1;
     if (chunks > nquads / 64 + 1) chunks = nquads / 64 + 1;
     const int ppb = (int)((nquads + chunks - 1) / chunks);
-    dim3 grid(cdiv(nquads, ppb), ngrp * 7);
+    const int nchunks8 = (cdiv(nquads, ppb) + 7) / 8;
+    dim3 grid(8 * nchunks8 * (ngrp * 7));
     CNX_DISPATCH(dtype,
         hipLaunchKernelGGL(dwconv7_wgrad_kernel<float>, grid, dim3(256), 0, st, (const float*)x, (const float*)g, dw, N, H, W, C, ppb, CG),
         hipLaunchKernelGGL(dwconv7_wgrad_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)x, (const bf16_t*)g, dw, N, H, W, C, ppb, CG));
