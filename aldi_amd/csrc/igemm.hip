@@ -590,7 +590,10 @@ int dispatch(ConvDev& d, hipStream_t st) {
     // long-K convs with thousands of tiles are bound by the L2 -> CU path (~31 B/clk/CU measured): the 256x128 tile
     // (8 waves) moves 25 % fewer bytes per flop
     static const int big_tile_min = env_int("ALDI_IGEMM_BIGTILE_MIN", 1024);
-    static const int big_tile_k = env_int("ALDI_IGEMM_BIGTILE_K", 1024);
+    // plain token GEMMs (ViT / ConvNeXt linears: K >= 768, M in the thousands): the 256x128 tile already pays from ~770 tiles on
+    // (+10 % at K = 768, +30 % at K = 3072 measured); the short-K 1x1 convs of the R50 trunk are HBM-bound and stay on 128x128
+    static const int big_tile_k = env_int("ALDI_IGEMM_BIGTILE_K", 768);
+    static const int lin_tile_min = env_int("ALDI_IGEMM_LINTILE_MIN", 768);
     // 3x3 / stride 1 / pad 1 (every 3x3 of the network): halo form, the pixel tile is loaded once per three taps
     static const int halo_env = env_int("ALDI_IGEMM_HALO", 1);
     static const int force = env_int("ALDI_IGEMM_FORCE", 0);     // experiments: 1 = 128x128, 2 = 128x64, 3 = 64x64, 4 = 256x128
@@ -614,7 +617,7 @@ int dispatch(ConvDev& d, hipStream_t st) {
     if (force == 3) return launch<T, 64, 64, 2, 2, 4>(d, st);
     if (force == 4) return launch<T, 256, 128, 4, 2, 4, false>(d, st);
     if (d.Cout <= 64) return launch<T, 128, 64, 4, 1, 4>(d, st);
-    if (tile_env != 9 && big >= big_tile_min && d.K >= big_tile_k) return launch<T, 256, 128, 4, 2, 4, false>(d, st);
+    if (tile_env != 9 && big >= lin_tile_min && d.K >= big_tile_k) return launch<T, 256, 128, 4, 2, 4, false>(d, st);
     if (big < 200) return launch<T, 64, 64, 2, 2, 4>(d, st);
     return launch<T, 128, 128, 2, 2, 4>(d, st);
 }
