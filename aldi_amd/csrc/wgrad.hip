@@ -422,34 +422,45 @@ __global__ __launch_bounds__(256) void wgrad_f32_kernel(WgDev p) {
 
 // db[c] += sum_p g[p][c]  (bias gradients).  Rows are read as full contiguous lines: a thread owns one 16-B chunk of
 // channels (C/EP chunks per row), the block walks `rows_per_block` rows, partial sums are combined through LDS.
-template <typename T>
-__global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ g, float* __restrict__ db, int M, int C, int ld, int rows_per_block) {
+template <typename T, int NT>
+__global__ __launch_bounds__(NT) void colsum_kernel(const T* __restrict__ g, float* __restrict__ db, int M, int C, int ld, int rows_per_block) {
     constexpr int EP = Elem<T>::kPer16B;
-    __shared__ float red[256 * EP];
-    const int chunks = C / EP;                         // 16-B chunks per row
-    const int rl = 256 / chunks > 0 ? 256 / chunks : 1; // row lanes per block iteration
+    __shared__ float red[NT * EP];
+    const int chunks = C / EP;                         // 16-B chunks per row (<= 256)
+    const int rl = NT / chunks;                        // row lanes per block iteration
     const int ch = threadIdx.x % chunks, lane_r = threadIdx.x / chunks;
     const int r0 = blockIdx.x * rows_per_block, r1 = min(M, r0 + rows_per_block);
     float acc[EP];
 #pragma unroll
     for (int k = 0; k < EP; ++k) acc[k] = 0.f;
-    if (lane_r < rl && chunks <= 256)
-        for (int r = r0 + lane_r; r < r1; r += rl) {
-            const uint4 v = *reinterpret_cast<const uint4*>(g + (long)r * ld + ch * EP);
-            if constexpr (EP == 8) {
-                const uint32_t* w = reinterpret_cast<const uint32_t*>(&v);
+    auto add = [&](const uint4& v) {
+        if constexpr (EP == 8) {
+            const uint32_t* w = reinterpret_cast<const uint32_t*>(&v);
 #pragma unroll
-                for (int k = 0; k < 4; ++k) { acc[2 * k] += __uint_as_float(w[k] << 16); acc[2 * k + 1] += __uint_as_float(w[k] & 0xffff0000u); }
-            } else {
-                const float* w = reinterpret_cast<const float*>(&v);
+            for (int k = 0; k < 4; ++k) { acc[2 * k] += __uint_as_float(w[k] << 16); acc[2 * k + 1] += __uint_as_float(w[k] & 0xffff0000u); }
+        } else {
+            const float* w = reinterpret_cast<const float*>(&v);
 #pragma unroll
-                for (int k = 0; k < 4; ++k) acc[k] += w[k];
-            }
+            for (int k = 0; k < 4; ++k) acc[k] += w[k];
         }
+    };
+    if (lane_r < rl) {
+        // a streaming read with nothing to hide its latency behind: four independent 16-B loads in flight per lane
+        const T* __restrict__ col = g + ch * EP;
+        int r = r0 + lane_r;
+        for (; r + 3 * rl < r1; r += 4 * rl) {
+            const uint4 v0 = *reinterpret_cast<const uint4*>(col + (long)r * ld);
+            const uint4 v1 = *reinterpret_cast<const uint4*>(col + (long)(r + rl) * ld);
+            const uint4 v2 = *reinterpret_cast<const uint4*>(col + (long)(r + 2 * rl) * ld);
+            const uint4 v3 = *reinterpret_cast<const uint4*>(col + (long)(r + 3 * rl) * ld);
+            add(v0); add(v1); add(v2); add(v3);
+        }
+        for (; r < r1; r += rl) add(*reinterpret_cast<const uint4*>(col + (long)r * ld));
+    }
 #pragma unroll
     for (int k = 0; k < EP; ++k) red[threadIdx.x * EP + k] = acc[k];
     __syncthreads();
-    for (int c = threadIdx.x; c < C; c += 256) {
+    for (int c = threadIdx.x; c < C; c += NT) {
         const int cch = c / EP, k = c % EP;
         float s = 0.f;
         for (int l = 0; l < rl; ++l) s += red[(l * chunks + cch) * EP + k];
@@ -528,12 +539,24 @@ extern "C" int aldi_bias_grad(const void* g, float* db, int M, int C, int dtype,
     hipStream_t st = static_cast<hipStream_t>(stream);
     const int ep = dtype == ALDI_BF16 ? 8 : 4;
     if (C % ep) return aldi_set_error_msg(ALDI_ERR_ARG, "bias_grad: C must be a multiple of a 16-B chunk");
-    int rows_per_block = cdiv(M, 1024) < 64 ? 64 : cdiv(M, 1024);
+    // enough workgroups to keep every CU's memory pipeline busy (the old 64-row floor left 1 workgroup per CU on a 16800-row
+    // matrix), bounded below so that the per-workgroup LDS reduction + C atomics stay a small part of the work
+    static const int target_blocks = getenv("ALDI_COLSUM_BLOCKS") ? atoi(getenv("ALDI_COLSUM_BLOCKS")) : 256;
+    static const int min_rows = getenv("ALDI_COLSUM_MINROWS") ? atoi(getenv("ALDI_COLSUM_MINROWS")) : 16;
+    static const int nt_env = getenv("ALDI_COLSUM_NT") ? atoi(getenv("ALDI_COLSUM_NT")) : 1024;
+    static const int block_kb = getenv("ALDI_COLSUM_BLOCK_KB") ? atoi(getenv("ALDI_COLSUM_BLOCK_KB")) : 384;
+    const long row_bytes = (long)C * (dtype == ALDI_BF16 ? 2 : 4);
+    int rows_per_block = cdiv(M, target_blocks);
+    const int by_bytes = (int)(((long)block_kb << 10) / row_bytes);
+    if (rows_per_block < by_bytes) rows_per_block = by_bytes;
+    if (rows_per_block < min_rows) rows_per_block = min_rows;
     dim3 grid(cdiv(M, rows_per_block));
     for (int c0 = 0; c0 < C; c0 += 256 * ep) {       // a block covers at most 256 16-B chunks of a row: wider rows go in column slices
         const int cs = C - c0 < 256 * ep ? C - c0 : 256 * ep;
-        if (dtype == ALDI_BF16) hipLaunchKernelGGL(colsum_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)g + c0, db + c0, M, cs, C, rows_per_block);
-        else hipLaunchKernelGGL(colsum_kernel<float>, grid, dim3(256), 0, st, (const float*)g + c0, db + c0, M, cs, C, rows_per_block);
+        if (dtype == ALDI_BF16) {
+            if (nt_env == 1024) hipLaunchKernelGGL((colsum_kernel<bf16_t, 1024>), grid, dim3(1024), 0, st, (const bf16_t*)g + c0, db + c0, M, cs, C, rows_per_block);
+            else hipLaunchKernelGGL((colsum_kernel<bf16_t, 256>), grid, dim3(256), 0, st, (const bf16_t*)g + c0, db + c0, M, cs, C, rows_per_block);
+        } else hipLaunchKernelGGL((colsum_kernel<float, 256>), grid, dim3(256), 0, st, (const float*)g + c0, db + c0, M, cs, C, rows_per_block);
     }
     ALDI_CHECK_LAUNCH();
     return ALDI_OK;

@@ -74,3 +74,16 @@ def test_bias_grad():
         ops.bias_grad(gd, db)
         ref = gd.float().cpu().sum(0)
         assert (db.cpu() - ref).abs().max() < 1e-2 if dt == torch.bfloat16 else 1e-3
+
+
+@pytest.mark.parametrize("rows,C", [(1, 8), (17, 2048), (4201, 1536), (16800, 3072), (70001, 192), (333, 6144)])
+def test_bias_grad_shapes(rows, C):
+    """ragged row counts, rows shorter / longer than one workgroup pass, column slices (C > 2048); accumulates into db"""
+    from aldi_amd import ops
+    gen = torch.Generator().manual_seed(rows + C)
+    g = torch.randn(rows, C, generator=gen).bfloat16()
+    db0 = torch.randn(C, generator=gen)
+    db = db0.cuda()
+    ops.bias_grad(g.cuda(), db)
+    ref = db0.double() + g.double().sum(0)
+    assert (db.cpu().double() - ref).abs().max().item() <= 2e-5 * max(1.0, rows ** 0.5) * 4
