@@ -61,6 +61,18 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, co
     if (lane == 0) { mean[r] = mu; rstd[r] = rs; }
 }
 
+// a 4-element run as it sits in memory (bf16: two 32-bit words), converted to fp32 only when it is used
+template <typename T> struct Raw4;
+template <> struct Raw4<float> { float4 v; };
+template <> struct Raw4<bf16_t> { uint2 v; };
+__device__ __forceinline__ void ldraw(const float* p, Raw4<float>& r) { r.v = *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ void ldraw(const bf16_t* p, Raw4<bf16_t>& r) { r.v = *reinterpret_cast<const uint2*>(p); }
+__device__ __forceinline__ void cvt4(const Raw4<float>& r, float o[4]) { o[0] = r.v.x; o[1] = r.v.y; o[2] = r.v.z; o[3] = r.v.w; }
+__device__ __forceinline__ void cvt4(const Raw4<bf16_t>& r, float o[4]) {
+    o[0] = __uint_as_float(r.v.x << 16); o[1] = __uint_as_float(r.v.x & 0xffff0000u);
+    o[2] = __uint_as_float(r.v.y << 16); o[3] = __uint_as_float(r.v.y & 0xffff0000u);
+}
+
 // dx[src] = rstd * (g*gamma - mean(g*gamma) - xhat * mean(g*gamma*xhat)) (+ res[src]);  dgamma += g*xhat, dbeta += g
 template <typename T, int LN_MAXCH>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ g, const T* __restrict__ x, const int* __restrict__ map,
@@ -77,44 +89,79 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ g, co
         if ((lane + 64 * j) * 4 < C) load4(gamma + (lane + 64 * j) * 4, gm[j]);
     }
     const int r_end = min(rows, (int)(blockIdx.x + 1) * rows_per_block);
-    for (int r = blockIdx.x * rows_per_block + wave; r < r_end; r += 4) {
-        const long src = map ? map[r] : r;
-        if (src < 0) continue;
-        const float mu = mean[r], rs = rstd[r];
-        float gv[LN_MAXCH][4], xh[LN_MAXCH][4];
-        float s1 = 0.f, s2 = 0.f;
+    // A wave walks its rows one at a time, and a row is a load -> reduce -> store chain: with nothing else in flight the kernel
+    // runs at the latency of that chain, not at HBM rate.  The operands of the NEXT row (kept as raw 16-bit pairs: half the
+    // registers) are requested before the current row is reduced; the residual comes with them instead of after the reduction.
+    constexpr bool kPrefetch = LN_MAXCH <= 4 && sizeof(T) == 2;
+    struct RowIn {
+        Raw4<T> g[LN_MAXCH], x[LN_MAXCH], m[LN_MAXCH], rv[LN_MAXCH];
+        float mu, rs;
+        long src;
+    };
+    auto fetch = [&](int r, RowIn& in) {
+        in.src = map ? map[r] : r;
+        if (in.src < 0) return;
+        in.mu = mean[r];
+        in.rs = rstd[r];
 #pragma unroll
         for (int j = 0; j < LN_MAXCH; ++j)
             if ((lane + 64 * j) * 4 < C) {
-                load4(g + (long)r * C + (lane + 64 * j) * 4, gv[j]);
-                if (mask) {      // ReLU after the norm: the gradient passes where the activation was positive
-                    float mv[4];
-                    load4(mask + (long)r * C + (lane + 64 * j) * 4, mv);
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) gv[j][i] = mv[i] > 0.f ? gv[j][i] : 0.f;
-                }
-                load4(x + src * C + (lane + 64 * j) * 4, xh[j]);
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    xh[j][i] = (xh[j][i] - mu) * rs;
-                    dg[j][i] += gv[j][i] * xh[j][i];
-                    db[j][i] += gv[j][i];
-                    gv[j][i] *= gm[j][i];
-                    s1 += gv[j][i];
-                    s2 += gv[j][i] * xh[j][i];
-                }
+                const int off = (lane + 64 * j) * 4;
+                ldraw(g + (long)r * C + off, in.g[j]);
+                if (mask) ldraw(mask + (long)r * C + off, in.m[j]);
+                ldraw(x + in.src * C + off, in.x[j]);
+                if (res) ldraw(res + in.src * C + off, in.rv[j]);
             }
-        s1 = warp_sum(s1) / (float)C;
-        s2 = warp_sum(s2) / (float)C;
+    };
+    RowIn cur, nxt;
+    int r = blockIdx.x * rows_per_block + wave;
+    if (kPrefetch && r < r_end) fetch(r, cur);
+    for (; r < r_end; r += 4) {
+        if constexpr (kPrefetch) {
+            nxt.src = -1;
+            if (r + 4 < r_end) fetch(r + 4, nxt);
+        } else {
+            fetch(r, cur);
+        }
+        if (cur.src >= 0) {
+            const long src = cur.src;
+            const float mu = cur.mu, rs = cur.rs;
+            float gv[LN_MAXCH][4], xh[LN_MAXCH][4];
+            float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-        for (int j = 0; j < LN_MAXCH; ++j)
-            if ((lane + 64 * j) * 4 < C) {
-                float o[4], rv[4] = {0.f, 0.f, 0.f, 0.f};
-                if (res) load4(res + src * C + (lane + 64 * j) * 4, rv);
+            for (int j = 0; j < LN_MAXCH; ++j)
+                if ((lane + 64 * j) * 4 < C) {
+                    cvt4(cur.g[j], gv[j]);
+                    if (mask) {      // ReLU after the norm: the gradient passes where the activation was positive
+                        float mv[4];
+                        cvt4(cur.m[j], mv);
 #pragma unroll
-                for (int i = 0; i < 4; ++i) o[i] = rs * (gv[j][i] - s1 - xh[j][i] * s2) + rv[i];
-                store4(dx + src * C + (lane + 64 * j) * 4, o);
-            }
+                        for (int i = 0; i < 4; ++i) gv[j][i] = mv[i] > 0.f ? gv[j][i] : 0.f;
+                    }
+                    cvt4(cur.x[j], xh[j]);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        xh[j][i] = (xh[j][i] - mu) * rs;
+                        dg[j][i] += gv[j][i] * xh[j][i];
+                        db[j][i] += gv[j][i];
+                        gv[j][i] *= gm[j][i];
+                        s1 += gv[j][i];
+                        s2 += gv[j][i] * xh[j][i];
+                    }
+                }
+            s1 = warp_sum(s1) / (float)C;
+            s2 = warp_sum(s2) / (float)C;
+#pragma unroll
+            for (int j = 0; j < LN_MAXCH; ++j)
+                if ((lane + 64 * j) * 4 < C) {
+                    float o[4], rv[4] = {0.f, 0.f, 0.f, 0.f};
+                    if (res) cvt4(cur.rv[j], rv);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) o[i] = rs * (gv[j][i] - s1 - xh[j][i] * s2) + rv[i];
+                    store4(dx + src * C + (lane + 64 * j) * 4, o);
+                }
+        }
+        if constexpr (kPrefetch) cur = nxt;
     }
     // block reduction of the parameter gradients, then one atomic per column
     for (int pass = 0; pass < 2; ++pass) {
@@ -396,7 +443,9 @@ extern "C" int aldi_layernorm_backward(const void* g, const void* x, const int* 
                                        aldi_stream_t stream) {
     if (C % 4 || C > 2048 || rows <= 0) return aldi_set_error_msg(ALDI_ERR_ARG, "layernorm: C must be a multiple of 4, <= 2048");
     hipStream_t st = (hipStream_t)stream;
-    const int rpb = 32;
+    // one round of workgroups (2 per CU at this register count: 513 would run as two rounds), each ending with 2*C atomics
+    static const int target_blocks = getenv("ALDI_LN_BWD_BLOCKS") ? atoi(getenv("ALDI_LN_BWD_BLOCKS")) : 512;
+    const int rpb = cdiv(rows, target_blocks) < 32 ? 32 : cdiv(rows, target_blocks);
     if (C <= 1024) {
     VIT_DISPATCH(dtype,
         hipLaunchKernelGGL((ln_bwd_kernel<float, 4>), dim3(cdiv(rows, rpb)), dim3(256), 0, st, (const float*)g, (const float*)x, map, gamma, mean, rstd,
