@@ -23,6 +23,25 @@ __device__ __forceinline__ void store8(bf16_t* p, const float v[8]) {
 }
 __device__ __forceinline__ void store8(float* p, const float v[8]) { store4(p, v); store4(p + 4, v + 4); }
 
+// 8 channels as they sit in memory (bf16: one 16-B vector), unpacked a channel pair at a time where they are used
+template <typename T> struct Raw8;
+template <> struct Raw8<float> { float v[8]; };
+template <> struct Raw8<bf16_t> { uint32_t w[4]; };
+__device__ __forceinline__ void ldraw8(const float* p, Raw8<float>& r) { load4(p, r.v); load4(p + 4, r.v + 4); }
+__device__ __forceinline__ void ldraw8(const bf16_t* p, Raw8<bf16_t>& r) {
+    const uint4 t = *reinterpret_cast<const uint4*>(p);
+    r.w[0] = t.x; r.w[1] = t.y; r.w[2] = t.z; r.w[3] = t.w;
+}
+__device__ __forceinline__ void zero8(Raw8<float>& r) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) r.v[k] = 0.f;
+}
+__device__ __forceinline__ void zero8(Raw8<bf16_t>& r) { r.w[0] = r.w[1] = r.w[2] = r.w[3] = 0u; }
+__device__ __forceinline__ void pair_of(const Raw8<float>& r, int p2, float o[2]) { o[0] = r.v[2 * p2]; o[1] = r.v[2 * p2 + 1]; }
+__device__ __forceinline__ void pair_of(const Raw8<bf16_t>& r, int p2, float o[2]) {
+    o[0] = __uint_as_float(r.w[p2] << 16); o[1] = __uint_as_float(r.w[p2] & 0xffff0000u);
+}
+
 // y[n][h][w][c] = bias[c] + sum_{kh,kw} x[n][h+kh-3][w+kw-3][c] * wt[kh][kw][c]     (flip: taps mirrored, no bias: data gradient)
 // A thread owns WB = 4 consecutive output pixels of a row for 8 channels: per kernel row it loads the 10 input vectors the four
 // windows share (instead of 4 x 7) and the 7 tap vectors once -- 2.8x fewer loads per output than one pixel per thread.
@@ -103,38 +122,60 @@ __global__ __launch_bounds__(256) void dwconv7_wgrad_kernel(const T* __restrict_
     for (int kw = 0; kw < 7; ++kw)
 #pragma unroll
         for (int k = 0; k < 8; ++k) acc[kw][k] = 0.f;
-    if (live)
-        for (long q = q0 + pl; q < q1; q += npl) {
-            const int w0 = (int)(q % wblocks) * WB, h0 = (int)((q / wblocks) % H), n = (int)(q / ((long)wblocks * H));
-            const int h = h0 + kh - 3;
-            if (h < 0 || h >= H) continue;
-            float gv[WB][8], xv[WB + 6][8];
-            const T* grow = g + (((long)n * H + h0) * W) * C + cc;
-            const T* xrow = x + (((long)n * H + h) * W) * C + cc;
+    // A quad is a load -> 224-FMA chain and the 56 accumulators leave room for two waves per SIMD: without help the kernel runs at
+    // the latency of that chain.  The 14 vectors of the NEXT quad are requested (kept raw: 16 B per vector) before the current quad
+    // is multiplied, and the current one is unpacked a channel pair at a time (28 live floats instead of 112).
+    struct Quad {
+        Raw8<T> g[WB], x[WB + 6];
+        bool ok;
+    };
+    auto fetch = [&](long q, Quad& Q) {
+        const int w0 = (int)(q % wblocks) * WB, h0 = (int)((q / wblocks) % H), n = (int)(q / ((long)wblocks * H));
+        const int h = h0 + kh - 3;
+        Q.ok = h >= 0 && h < H;
+        if (!Q.ok) return;
+        const T* grow = g + (((long)n * H + h0) * W) * C + cc;
+        const T* xrow = x + (((long)n * H + h) * W) * C + cc;
 #pragma unroll
-            for (int j = 0; j < WB; ++j) {
-                if (w0 + j < W) load8(grow + (long)(w0 + j) * C, gv[j]);
-                else {
-#pragma unroll
-                    for (int k = 0; k < 8; ++k) gv[j][k] = 0.f;
-                }
-            }
-#pragma unroll
-            for (int t = 0; t < WB + 6; ++t) {
-                const int w = w0 + t - 3;
-                if (w >= 0 && w < W) load8(xrow + (long)w * C, xv[t]);
-                else {
-#pragma unroll
-                    for (int k = 0; k < 8; ++k) xv[t][k] = 0.f;
-                }
-            }
-#pragma unroll
-            for (int kw = 0; kw < 7; ++kw)
-#pragma unroll
-                for (int j = 0; j < WB; ++j)
-#pragma unroll
-                    for (int k = 0; k < 8; ++k) acc[kw][k] = fmaf(xv[j + kw][k], gv[j][k], acc[kw][k]);
+        for (int j = 0; j < WB; ++j) {
+            if (w0 + j < W) ldraw8(grow + (long)(w0 + j) * C, Q.g[j]);
+            else zero8(Q.g[j]);
         }
+#pragma unroll
+        for (int t = 0; t < WB + 6; ++t) {
+            const int w = w0 + t - 3;
+            if (w >= 0 && w < W) ldraw8(xrow + (long)w * C, Q.x[t]);
+            else zero8(Q.x[t]);
+        }
+    };
+    if (live) {
+        Quad cur, nxt;
+        long q = q0 + pl;
+        cur.ok = false;
+        if (q < q1) fetch(q, cur);
+        for (; q < q1; q += npl) {
+            nxt.ok = false;
+            if (q + npl < q1) fetch(q + npl, nxt);
+            if (cur.ok) {
+#pragma unroll
+                for (int p2 = 0; p2 < 4; ++p2) {          // channel pair p2 of the lane's 8
+                    float gv[WB][2], xv[WB + 6][2];
+#pragma unroll
+                    for (int j = 0; j < WB; ++j) pair_of(cur.g[j], p2, gv[j]);
+#pragma unroll
+                    for (int t = 0; t < WB + 6; ++t) pair_of(cur.x[t], p2, xv[t]);
+#pragma unroll
+                    for (int kw = 0; kw < 7; ++kw)
+#pragma unroll
+                        for (int j = 0; j < WB; ++j) {
+                            acc[kw][2 * p2] = fmaf(xv[j + kw][0], gv[j][0], acc[kw][2 * p2]);
+                            acc[kw][2 * p2 + 1] = fmaf(xv[j + kw][1], gv[j][1], acc[kw][2 * p2 + 1]);
+                        }
+                }
+            }
+            cur = nxt;
+        }
+    }
     for (int kw = 0; kw < 7; ++kw) {
         __syncthreads();
 #pragma unroll
