@@ -3,8 +3,9 @@
 // out = x + s * gamma (.) y with its backward.  NHWC, 8 channels (16 B of bf16) per lane; the pointwise layers, LayerNorm and GELU
 // of the block run on the igemm / LayerNorm / GELU kernels.
 //
-// First versions: every output vector re-reads its 49 input vectors through L1/L2 (no LDS tile), which is ~10x the
-// compulsory traffic at cache rates; the LDS-tiled form is the next step if this trunk becomes a benchmarked workload.
+// No LDS tile: every output vector re-reads its input vectors through L1/L2 (XCD-aware block order keeps them in one L2).  Both
+// kernels are instruction- and latency-bound, not HBM-bound: operands are prefetched one step ahead as raw 16-B vectors into
+// ping-pong register buffers and unpacked a channel pair at a time (v_pk_fma_f32 on the pair).
 #include "common.h"
 
 namespace {
@@ -47,55 +48,98 @@ __device__ __forceinline__ void pair_of(const Raw8<bf16_t>& r, int p2, float o[2
 // windows share (instead of 4 x 7) and the 7 tap vectors once -- 2.8x fewer loads per output than one pixel per thread.
 constexpr int WB = 4;
 template <typename T>
-__global__ __launch_bounds__(256) void dwconv7_kernel(const T* __restrict__ x, const T* __restrict__ wt, const float* __restrict__ bias,
+__global__ __launch_bounds__(256, 2) void dwconv7_kernel(const T* __restrict__ x, const T* __restrict__ wt, const float* __restrict__ bias,
                                                        T* __restrict__ y, int N, int H, int W, int C, int flip) {
     const int c8 = C >> 3, wblocks = (W + WB - 1) / WB;
     const long total = (long)N * H * wblocks * c8;
     // workgroup b runs on XCD b % 8, each with its own L2: give every XCD a contiguous band of rows, so that the 7 input rows an
     // output row needs are re-read from THAT L2 and not fetched from HBM by eight different ones (gridDim.x is a multiple of 8)
     const long lb = (long)(blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
-    for (long i = lb * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        const int cc = (int)(i % c8) * 8;
-        long r = i / c8;
-        const int w0 = (int)(r % wblocks) * WB; r /= wblocks;
-        const int h0 = (int)(r % H), n = (int)(r / H);
-        float acc[WB][8];
+    const long stride = (long)gridDim.x * blockDim.x;
+    // One kernel row of one output quad = 10 input + 7 tap vectors feeding 224 FMAs.  The vectors of the NEXT kernel row (of the
+    // next quad after row 6) are requested, raw, before the current row is multiplied; the current row is unpacked a channel pair
+    // at a time, so that two rows of operands and the 32 accumulators fit the registers of two waves per SIMD.
+    struct Pos { int cc, w0, h0, n; bool valid; };
+    struct Row {
+        Raw8<T> x[WB + 6];
+        const T* taps;
+        bool ok;
+    };
+    auto decode = [&](long i) {
+        Pos p;
+        p.valid = i < total;
+        const long ii = p.valid ? i : 0;
+        p.cc = (int)(ii % c8) * 8;
+        long r = ii / c8;
+        p.w0 = (int)(r % wblocks) * WB; r /= wblocks;
+        p.h0 = (int)(r % H); p.n = (int)(r / H);
+        return p;
+    };
+    auto fetch = [&](const Pos& p, int kh, Row& R) {
+        const int h = p.h0 + kh - 3;
+        R.ok = p.valid && h >= 0 && h < H;
+        if (!R.ok) return;
+        const T* xrow = x + (((long)p.n * H + h) * W) * C + p.cc;
+        if (p.w0 >= 3 && p.w0 + WB + 3 <= W) {               // interior of the row: no per-vector bounds selects
+#pragma unroll
+            for (int t = 0; t < WB + 6; ++t) ldraw8(xrow + (long)(p.w0 + t - 3) * C, R.x[t]);
+        } else {
+#pragma unroll
+            for (int t = 0; t < WB + 6; ++t) {
+                const int w = p.w0 + t - 3;
+                if (w >= 0 && w < W) ldraw8(xrow + (long)w * C, R.x[t]);
+                else zero8(R.x[t]);
+            }
+        }
+        R.taps = wt + (long)(flip ? (6 - kh) * 7 + 6 : kh * 7) * C + p.cc;
+    };
+    const long wstep = flip ? -(long)C : (long)C;
+    long i = lb * blockDim.x + threadIdx.x;
+    Pos pc = decode(i), pn;
+    Row A, B;                                                 // ping-pong: even kernel rows in A, odd ones in B (no register copies)
+    fetch(pc, 0, A);
+    for (; i < total; i += stride) {
+        pn = decode(i + stride);
+        float acc[WB][8], b8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if (bias && !flip) { load4(bias + pc.cc, b8); load4(bias + pc.cc + 4, b8 + 4); }
 #pragma unroll
         for (int j = 0; j < WB; ++j)
 #pragma unroll
-            for (int k = 0; k < 8; ++k) acc[j][k] = (bias && !flip) ? bias[cc + k] : 0.f;
-        for (int kh = 0; kh < 7; ++kh) {
-            const int h = h0 + kh - 3;
-            if (h < 0 || h >= H) continue;
-            float xv[WB + 6][8];
-            const T* xrow = x + (((long)n * H + h) * W) * C + cc;
-            if (w0 >= 3 && w0 + WB + 3 <= W) {                   // interior of the row: no per-vector bounds checks
+            for (int k = 0; k < 8; ++k) acc[j][k] = b8[k];
+        auto multiply = [&](const Row& cur) {
+            if (!cur.ok) return;
+            Raw8<T> tw[7];                                   // the 7 tap vectors of this kernel row: L1-resident, 7 loads in flight
 #pragma unroll
-                for (int t = 0; t < WB + 6; ++t) load8(xrow + (long)(w0 + t - 3) * C, xv[t]);
-            } else {
+            for (int kw = 0; kw < 7; ++kw) ldraw8(cur.taps + kw * wstep, tw[kw]);
 #pragma unroll
-                for (int t = 0; t < WB + 6; ++t) {
-                    const int w = w0 + t - 3;
-                    if (w >= 0 && w < W) load8(xrow + (long)w * C, xv[t]);
-                    else {
+            for (int p2 = 0; p2 < 4; ++p2) {
+                float xv[WB + 6][2], wv[7][2];
 #pragma unroll
-                        for (int k = 0; k < 8; ++k) xv[t][k] = 0.f;
+                for (int t = 0; t < WB + 6; ++t) pair_of(cur.x[t], p2, xv[t]);
+#pragma unroll
+                for (int kw = 0; kw < 7; ++kw) pair_of(tw[kw], p2, wv[kw]);
+#pragma unroll
+                for (int kw = 0; kw < 7; ++kw)
+#pragma unroll
+                    for (int j = 0; j < WB; ++j) {           // explicit FMAs on a channel pair: v_pk_fma_f32
+                        acc[j][2 * p2] = fmaf(xv[j + kw][0], wv[kw][0], acc[j][2 * p2]);
+                        acc[j][2 * p2 + 1] = fmaf(xv[j + kw][1], wv[kw][1], acc[j][2 * p2 + 1]);
                     }
-                }
             }
-#pragma unroll
-            for (int kw = 0; kw < 7; ++kw) {
-                float wv[8];
-                load8(wt + ((flip ? (6 - kh) * 7 + (6 - kw) : kh * 7 + kw) * (long)C) + cc, wv);
-#pragma unroll
-                for (int j = 0; j < WB; ++j)
-#pragma unroll
-                    for (int k = 0; k < 8; ++k) acc[j][k] = fmaf(xv[j + kw][k], wv[k], acc[j][k]);     // explicit FMA: packs into v_pk_fma_f32
-            }
+        };
+#pragma unroll 1
+        for (int t = 0; t < 4; ++t) {                        // rows 2t (A) and 2t+1 (B); "row 7" is empty
+            if (t < 3) fetch(pc, 2 * t + 1, B);
+            else B.ok = false;
+            multiply(A);
+            if (t < 3) fetch(pc, 2 * t + 2, A);
+            else fetch(pn, 0, A);
+            multiply(B);
         }
 #pragma unroll
         for (int j = 0; j < WB; ++j)
-            if (w0 + j < W) store8(y + (((long)n * H + h0) * W + w0 + j) * C + cc, acc[j]);
+            if (pc.w0 + j < W) store8(y + (((long)pc.n * H + pc.h0) * W + pc.w0 + j) * C + pc.cc, acc[j]);
+        pc = pn;
     }
 }
 
@@ -136,44 +180,56 @@ __global__ __launch_bounds__(256) void dwconv7_wgrad_kernel(const T* __restrict_
         if (!Q.ok) return;
         const T* grow = g + (((long)n * H + h0) * W) * C + cc;
         const T* xrow = x + (((long)n * H + h) * W) * C + cc;
+        if (w0 >= 3 && w0 + WB + 3 <= W) {                   // interior of the row: no per-vector bounds selects
 #pragma unroll
-        for (int j = 0; j < WB; ++j) {
-            if (w0 + j < W) ldraw8(grow + (long)(w0 + j) * C, Q.g[j]);
-            else zero8(Q.g[j]);
+            for (int j = 0; j < WB; ++j) ldraw8(grow + (long)(w0 + j) * C, Q.g[j]);
+#pragma unroll
+            for (int t = 0; t < WB + 6; ++t) ldraw8(xrow + (long)(w0 + t - 3) * C, Q.x[t]);
+        } else {
+#pragma unroll
+            for (int j = 0; j < WB; ++j) {
+                if (w0 + j < W) ldraw8(grow + (long)(w0 + j) * C, Q.g[j]);
+                else zero8(Q.g[j]);
+            }
+#pragma unroll
+            for (int t = 0; t < WB + 6; ++t) {
+                const int w = w0 + t - 3;
+                if (w >= 0 && w < W) ldraw8(xrow + (long)w * C, Q.x[t]);
+                else zero8(Q.x[t]);
+            }
         }
+    };
+    auto multiply = [&](const Quad& cur) {
+        if (!cur.ok) return;
 #pragma unroll
-        for (int t = 0; t < WB + 6; ++t) {
-            const int w = w0 + t - 3;
-            if (w >= 0 && w < W) ldraw8(xrow + (long)w * C, Q.x[t]);
-            else zero8(Q.x[t]);
+        for (int p2 = 0; p2 < 4; ++p2) {          // channel pair p2 of the lane's 8
+            float gv[WB][2], xv[WB + 6][2];
+#pragma unroll
+            for (int j = 0; j < WB; ++j) pair_of(cur.g[j], p2, gv[j]);
+#pragma unroll
+            for (int t = 0; t < WB + 6; ++t) pair_of(cur.x[t], p2, xv[t]);
+#pragma unroll
+            for (int kw = 0; kw < 7; ++kw)
+#pragma unroll
+                for (int j = 0; j < WB; ++j) {
+                    acc[kw][2 * p2] = fmaf(xv[j + kw][0], gv[j][0], acc[kw][2 * p2]);
+                    acc[kw][2 * p2 + 1] = fmaf(xv[j + kw][1], gv[j][1], acc[kw][2 * p2 + 1]);
+                }
         }
     };
     if (live) {
-        Quad cur, nxt;
+        Quad A, B;                                // ping-pong buffers: no register copies
         long q = q0 + pl;
-        cur.ok = false;
-        if (q < q1) fetch(q, cur);
-        for (; q < q1; q += npl) {
-            nxt.ok = false;
-            if (q + npl < q1) fetch(q + npl, nxt);
-            if (cur.ok) {
-#pragma unroll
-                for (int p2 = 0; p2 < 4; ++p2) {          // channel pair p2 of the lane's 8
-                    float gv[WB][2], xv[WB + 6][2];
-#pragma unroll
-                    for (int j = 0; j < WB; ++j) pair_of(cur.g[j], p2, gv[j]);
-#pragma unroll
-                    for (int t = 0; t < WB + 6; ++t) pair_of(cur.x[t], p2, xv[t]);
-#pragma unroll
-                    for (int kw = 0; kw < 7; ++kw)
-#pragma unroll
-                        for (int j = 0; j < WB; ++j) {
-                            acc[kw][2 * p2] = fmaf(xv[j + kw][0], gv[j][0], acc[kw][2 * p2]);
-                            acc[kw][2 * p2 + 1] = fmaf(xv[j + kw][1], gv[j][1], acc[kw][2 * p2 + 1]);
-                        }
-                }
-            }
-            cur = nxt;
+        A.ok = false;
+        if (q < q1) fetch(q, A);
+#pragma unroll 1
+        for (; q < q1; q += 2 * npl) {
+            B.ok = false;
+            if (q + npl < q1) fetch(q + npl, B);
+            multiply(A);
+            A.ok = false;
+            if (q + 2 * npl < q1) fetch(q + 2 * npl, A);
+            multiply(B);
         }
     }
     for (int kw = 0; kw < 7; ++kw) {

@@ -23,10 +23,14 @@ def l2err(a, b):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-def test_dwconv7_fwd_bwd_vs_torch(dtype):
+@pytest.mark.parametrize("shape", [(2, 13, 17, 64), (1, 5, 3, 8), (1, 9, 41, 200), (4, 50, 84, 768)],
+                         ids=["small", "tiny", "ragged", "stage2"])
+def test_dwconv7_fwd_bwd_vs_torch(dtype, shape):
+    """tiny: H < 7, W < one pixel quad; ragged: W % 4 != 0, channel groups not a power of two; stage2: a ConvNeXt-L stage-2 map
+    (threads walk several quads: the cross-quad operand prefetch and its tail)"""
     from aldi_amd import vit_ops as V
     torch.manual_seed(0)
-    N, H, W, C = 2, 13, 17, 64
+    N, H, W, C = shape
     x = torch.randn(N, H, W, C, device=DEV).to(dtype)
     w = (torch.randn(C, 1, 7, 7, device=DEV) * 0.2).to(dtype)
     b = torch.randn(C, device=DEV) * 0.1
