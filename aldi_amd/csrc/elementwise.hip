@@ -29,8 +29,12 @@ template <typename T>
 __global__ __launch_bounds__(256) void dgrad_weights_batch_kernel(const aldi_dgw_item* __restrict__ items, int n_items) {
     __shared__ float tl[32][33];
     const int tile = blockIdx.x;
-    int it = 0;
-    while (it + 1 < n_items && items[it + 1].tile_begin <= tile) ++it;
+    int it = 0, hi = n_items - 1;                     // last item whose tile_begin <= tile (hundreds of layers: bisect, not scan)
+    while (it < hi) {
+        const int mid = (it + hi + 1) >> 1;
+        if (items[mid].tile_begin <= tile) it = mid;
+        else hi = mid - 1;
+    }
     const aldi_dgw_item d = items[it];
     const int Cout = d.Cout, KH = d.KH, KW = d.KW, Cin = d.Cin, T_ = KH * KW;
     const int nci = (Cin + 31) >> 5, nco = (Cout + 31) >> 5;
