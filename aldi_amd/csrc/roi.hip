@@ -297,10 +297,13 @@ __global__ __launch_bounds__(256) void roialign_bwd_gather_kernel(Feats ft, Gath
     __shared__ int pwlo[kSeg], pwhi[kSeg];
     __shared__ float gsum[7][256];
     const int tid = threadIdx.x, c = tid;
+    // coarse levels first: their segments see most of an image's large ROIs (hundreds of candidates each) and would otherwise
+    // start last, alone on the chip, after the thousands of light P2 segments
+    const int bid = (int)(gridDim.x - 1 - blockIdx.x);
     int l = 0;
-    while (l < 3 && (int)blockIdx.x >= gg.blk_off[l + 1]) ++l;
+    while (l < 3 && bid >= gg.blk_off[l + 1]) ++l;
     const int H = ft.H[l], W = ft.W[l];
-    int t = blockIdx.x - gg.blk_off[l];
+    int t = bid - gg.blk_off[l];
     const int seg = t % gg.segs[l]; t /= gg.segs[l];
     const int py = t % H, b = t / H;
     const int px0 = seg * kSeg;
