@@ -973,7 +973,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd2d_kernel(AttnDev a) {
 
 // dQ' of the tiled path: 4 accumulator blocks for the q part; the 16 bias columns of each tile are added into an LDS row per
 // query at the tile's column offsets (each (query, column) has exactly one owner lane: plain read-modify-write)
-__global__ __launch_bounds__(256) void attn_bwd_dq2d_kernel(AttnDev a) {
+__global__ __launch_bounds__(256, 2) void attn_bwd_dq2d_kernel(AttnDev a) {
     extern __shared__ __align__(16) unsigned char smem[];
     bf16_t* Ks = reinterpret_cast<bf16_t*>(smem);            // [64 slots][TROW] k rows
     bf16_t* KTs = Ks + 64 * TROW;                             // [64 d][TROW]     k^T
