@@ -213,6 +213,32 @@ __global__ void gelu_kernel(const T* __restrict__ x, const T* __restrict__ g, T*
     }
 }
 
+// bf16, n % 8 == 0, 16-B aligned: 8 elements (one 16-B vector) per lane and step
+__global__ void gelu8_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ g, bf16_t* __restrict__ out, long n8) {
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n8; i += (long)gridDim.x * blockDim.x) {
+        const uint4 xv = *reinterpret_cast<const uint4*>(x + i * 8);
+        uint4 gq = make_uint4(0u, 0u, 0u, 0u);
+        if (g) gq = *reinterpret_cast<const uint4*>(g + i * 8);
+        const uint32_t xw[4] = {xv.x, xv.y, xv.z, xv.w}, gw[4] = {gq.x, gq.y, gq.z, gq.w};
+        uint32_t ow[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float v0 = __uint_as_float(xw[k] << 16), v1 = __uint_as_float(xw[k] & 0xffff0000u);
+            float c0, e0, c1, e1, o0, o1;
+            gelu_terms(v0, c0, e0);
+            gelu_terms(v1, c1, e1);
+            if (g) {
+                o0 = __uint_as_float(gw[k] << 16) * fmaf(v0 * 0.3989422804014327f, e0, c0);
+                o1 = __uint_as_float(gw[k] & 0xffff0000u) * fmaf(v1 * 0.3989422804014327f, e1, c1);
+            } else {
+                o0 = v0 * c0; o1 = v1 * c1;
+            }
+            ow[k] = pack2_bf16(o0, o1);
+        }
+        *reinterpret_cast<uint4*>(out + i * 8) = make_uint4(ow[0], ow[1], ow[2], ow[3]);
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ row gather-add
 // out[r] = (a ? a[r] : 0) + s(r) * (idx >= 0 ? b[idx] : 0), idx = map ? map[r] : r, s(r) = scale ? scale[r / rows_per_sample] : 1
 template <typename T>
@@ -229,6 +255,27 @@ __global__ void rows_add_kernel(const T* __restrict__ a, const T* __restrict__ b
 #pragma unroll
         for (int k = 0; k < 4; ++k) o[k] = av[k] + s * bv[k];
         store4(out + (long)r * C + cc, o);
+    }
+}
+
+// bf16, C % 8 == 0, 16-B aligned rows: one 16-B vector per lane and step
+__global__ void rows_add8_kernel(const bf16_t* __restrict__ a, const bf16_t* __restrict__ b, const int* __restrict__ map, const float* __restrict__ scale,
+                                 bf16_t* __restrict__ out, int rows, int C, int rows_per_sample) {
+    const int c8 = C >> 3;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < (long)rows * c8; i += (long)gridDim.x * blockDim.x) {
+        const int r = (int)(i / c8), cc = (int)(i - (long)r * c8) * 8;
+        const long idx = map ? map[r] : r;
+        uint4 av = make_uint4(0u, 0u, 0u, 0u), bv = make_uint4(0u, 0u, 0u, 0u);
+        if (a) av = *reinterpret_cast<const uint4*>(a + (long)r * C + cc);
+        if (idx >= 0) bv = *reinterpret_cast<const uint4*>(b + idx * C + cc);
+        const float s = scale ? scale[r / rows_per_sample] : 1.f;
+        const uint32_t aw[4] = {av.x, av.y, av.z, av.w}, bw[4] = {bv.x, bv.y, bv.z, bv.w};
+        uint32_t ow[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            ow[k] = pack2_bf16(__uint_as_float(aw[k] << 16) + s * __uint_as_float(bw[k] << 16),
+                               __uint_as_float(aw[k] & 0xffff0000u) + s * __uint_as_float(bw[k] & 0xffff0000u));
+        *reinterpret_cast<uint4*>(out + (long)r * C + cc) = make_uint4(ow[0], ow[1], ow[2], ow[3]);
     }
 }
 
@@ -482,6 +529,11 @@ extern "C" int aldi_layernorm_backward(const void* g, const void* x, const int* 
 extern "C" int aldi_gelu(const void* x, const void* g, void* out, long n, int dtype, aldi_stream_t stream) {
     if (n % 4) return aldi_set_error_msg(ALDI_ERR_ARG, "gelu: n % 4 != 0");
     hipStream_t st = (hipStream_t)stream;
+    if (dtype == ALDI_BF16 && n % 8 == 0 && (((uintptr_t)x | (uintptr_t)g | (uintptr_t)out) & 15) == 0) {
+        hipLaunchKernelGGL(gelu8_kernel, dim3(grid_for(n / 8)), dim3(256), 0, st, (const bf16_t*)x, (const bf16_t*)g, (bf16_t*)out, n / 8);
+        ALDI_CHECK_LAUNCH();
+        return ALDI_OK;
+    }
     VIT_DISPATCH(dtype,
         hipLaunchKernelGGL(gelu_kernel<float>, dim3(grid_for(n / 4)), dim3(256), 0, st, (const float*)x, (const float*)g, (float*)out, n / 4),
         hipLaunchKernelGGL(gelu_kernel<bf16_t>, dim3(grid_for(n / 4)), dim3(256), 0, st, (const bf16_t*)x, (const bf16_t*)g, (bf16_t*)out, n / 4));
@@ -493,6 +545,12 @@ extern "C" int aldi_rows_add(const void* a, const void* b, const int* map, const
                              int rows_per_sample, int dtype, aldi_stream_t stream) {
     if (C % 4 || rows <= 0 || rows_per_sample <= 0) return aldi_set_error_msg(ALDI_ERR_ARG, "rows_add: bad sizes");
     hipStream_t st = (hipStream_t)stream;
+    if (dtype == ALDI_BF16 && C % 8 == 0 && (((uintptr_t)a | (uintptr_t)b | (uintptr_t)out) & 15) == 0) {
+        hipLaunchKernelGGL(rows_add8_kernel, dim3(grid_for((long)rows * (C / 8))), dim3(256), 0, st, (const bf16_t*)a, (const bf16_t*)b, map, scale, (bf16_t*)out, rows, C,
+                           rows_per_sample);
+        ALDI_CHECK_LAUNCH();
+        return ALDI_OK;
+    }
     const long work = (long)rows * (C / 4);
     VIT_DISPATCH(dtype,
         hipLaunchKernelGGL(rows_add_kernel<float>, dim3(grid_for(work)), dim3(256), 0, st, (const float*)a, (const float*)b, map, scale, (float*)out, rows, C, rows_per_sample),
