@@ -8,12 +8,41 @@
 
 namespace {
 
+// VW (4 or 8) consecutive elements <-> fp32: bf16 rows move as one 8-B or 16-B vector per lane
+template <int VW> __device__ __forceinline__ void loadv(const float* p, float* v) {
+#pragma unroll
+    for (int i = 0; i < VW; i += 4) load4(p + i, v + i);
+}
+template <int VW> __device__ __forceinline__ void loadv(const bf16_t* p, float* v) {
+    if constexpr (VW == 8) {
+        const uint4 t = *reinterpret_cast<const uint4*>(p);
+        const uint32_t w[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { v[2 * k] = __uint_as_float(w[k] << 16); v[2 * k + 1] = __uint_as_float(w[k] & 0xffff0000u); }
+    } else {
+        load4(p, v);
+    }
+}
+template <int VW> __device__ __forceinline__ void storev(float* p, const float* v) {
+#pragma unroll
+    for (int i = 0; i < VW; i += 4) store4(p + i, v + i);
+}
+template <int VW> __device__ __forceinline__ void storev(bf16_t* p, const float* v) {
+    if constexpr (VW == 8) {
+        uint4 t;
+        t.x = pack2_bf16(v[0], v[1]); t.y = pack2_bf16(v[2], v[3]); t.z = pack2_bf16(v[4], v[5]); t.w = pack2_bf16(v[6], v[7]);
+        *reinterpret_cast<uint4*>(p) = t;
+    } else {
+        store4(p, v);
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ LayerNorm
 // One wave per output row.  `map` (nullable) gathers: output row r normalises source row map[r]; map[r] < 0 is a padding
 // row of a partitioned window and is written as zeros (detectron2 pads AFTER norm1, so the padded tokens are exact zeros).
 // C <= 2048 (ConvNeXt-L stage 3 is 1536 wide), C % 4 == 0; instantiated for 4 chunks (C <= 1024: half the registers) and 8; lane chunk j (4 channels at (lane + 64 j) * 4) is live iff inside C
 
-template <typename T, int LN_MAXCH>
+template <typename T, int LN_MAXCH, int VW>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, const int* __restrict__ map, const float* __restrict__ gamma,
                                                       const float* __restrict__ beta, T* __restrict__ y, float* __restrict__ mean,
                                                       float* __restrict__ rstd, int rows, int C, float eps, int relu) {
@@ -22,79 +51,97 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, co
     const long src = map ? map[r] : r;
     T* yr = y + (long)r * C;
     if (src < 0) {
-        const float z[4] = {0.f, 0.f, 0.f, 0.f};
-        for (int j = 0; j < LN_MAXCH; ++j) if ((lane + 64 * j) * 4 < C) store4(yr + (lane + 64 * j) * 4, z);
+        float z[VW];
+#pragma unroll
+        for (int i = 0; i < VW; ++i) z[i] = 0.f;
+        for (int j = 0; j < LN_MAXCH; ++j) if ((lane + 64 * j) * VW < C) storev<VW>(yr + (lane + 64 * j) * VW, z);
         if (lane == 0) { mean[r] = 0.f; rstd[r] = 0.f; }
         return;
     }
     const T* xr = x + src * C;
-    float v[LN_MAXCH][4];
+    float v[LN_MAXCH][VW];
     float s = 0.f;
 #pragma unroll
     for (int j = 0; j < LN_MAXCH; ++j)
-        if ((lane + 64 * j) * 4 < C) {
-            load4(xr + (lane + 64 * j) * 4, v[j]);
-            s += (v[j][0] + v[j][1]) + (v[j][2] + v[j][3]);
+        if ((lane + 64 * j) * VW < C) {
+            loadv<VW>(xr + (lane + 64 * j) * VW, v[j]);
+            {
+#pragma unroll
+            for (int i = 0; i < VW; i += 4) s += (v[j][i] + v[j][i + 1]) + (v[j][i + 2] + v[j][i + 3]);
+        }
         }
     const float mu = warp_sum(s) / (float)C;
     float q = 0.f;
 #pragma unroll
     for (int j = 0; j < LN_MAXCH; ++j)
-        if ((lane + 64 * j) * 4 < C) {
+        if ((lane + 64 * j) * VW < C) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) { v[j][i] -= mu; q += v[j][i] * v[j][i]; }
+            for (int i = 0; i < VW; ++i) { v[j][i] -= mu; q += v[j][i] * v[j][i]; }
         }
     const float rs = rsqrtf(warp_sum(q) / (float)C + eps);
 #pragma unroll
     for (int j = 0; j < LN_MAXCH; ++j)
-        if ((lane + 64 * j) * 4 < C) {
-            float gm[4], bt[4], o[4];
-            load4(gamma + (lane + 64 * j) * 4, gm);
-            load4(beta + (lane + 64 * j) * 4, bt);
+        if ((lane + 64 * j) * VW < C) {
+            float gm[VW], bt[VW], o[VW];
+            loadv<VW>(gamma + (lane + 64 * j) * VW, gm);
+            loadv<VW>(beta + (lane + 64 * j) * VW, bt);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
+            for (int i = 0; i < VW; ++i) {
                 o[i] = v[j][i] * rs * gm[i] + bt[i];
                 if (relu) o[i] = fmaxf(o[i], 0.f);
             }
-            store4(yr + (lane + 64 * j) * 4, o);
+            storev<VW>(yr + (lane + 64 * j) * VW, o);
         }
     if (lane == 0) { mean[r] = mu; rstd[r] = rs; }
 }
 
-// a 4-element run as it sits in memory (bf16: two 32-bit words), converted to fp32 only when it is used
-template <typename T> struct Raw4;
-template <> struct Raw4<float> { float4 v; };
-template <> struct Raw4<bf16_t> { uint2 v; };
-__device__ __forceinline__ void ldraw(const float* p, Raw4<float>& r) { r.v = *reinterpret_cast<const float4*>(p); }
-__device__ __forceinline__ void ldraw(const bf16_t* p, Raw4<bf16_t>& r) { r.v = *reinterpret_cast<const uint2*>(p); }
-__device__ __forceinline__ void cvt4(const Raw4<float>& r, float o[4]) { o[0] = r.v.x; o[1] = r.v.y; o[2] = r.v.z; o[3] = r.v.w; }
-__device__ __forceinline__ void cvt4(const Raw4<bf16_t>& r, float o[4]) {
-    o[0] = __uint_as_float(r.v.x << 16); o[1] = __uint_as_float(r.v.x & 0xffff0000u);
-    o[2] = __uint_as_float(r.v.y << 16); o[3] = __uint_as_float(r.v.y & 0xffff0000u);
+// a VW-element run (4 or 8) as it sits in memory (bf16: 32-bit words holding two elements), converted to fp32 only when it is used
+template <typename T, int VW> struct RawV;
+template <int VW> struct RawV<float, VW> { float v[VW]; };
+template <int VW> struct RawV<bf16_t, VW> { uint32_t w[VW / 2]; };
+template <int VW> __device__ __forceinline__ void ldrawv(const float* p, RawV<float, VW>& r) {
+#pragma unroll
+    for (int i = 0; i < VW; i += 4) load4(p + i, r.v + i);
+}
+__device__ __forceinline__ void ldrawv(const bf16_t* p, RawV<bf16_t, 4>& r) {
+    const uint2 t = *reinterpret_cast<const uint2*>(p);
+    r.w[0] = t.x; r.w[1] = t.y;
+}
+__device__ __forceinline__ void ldrawv(const bf16_t* p, RawV<bf16_t, 8>& r) {
+    const uint4 t = *reinterpret_cast<const uint4*>(p);
+    r.w[0] = t.x; r.w[1] = t.y; r.w[2] = t.z; r.w[3] = t.w;
+}
+template <int VW> __device__ __forceinline__ void cvtv(const RawV<float, VW>& r, float* o) {
+#pragma unroll
+    for (int i = 0; i < VW; ++i) o[i] = r.v[i];
+}
+template <int VW> __device__ __forceinline__ void cvtv(const RawV<bf16_t, VW>& r, float* o) {
+#pragma unroll
+    for (int i = 0; i < VW / 2; ++i) { o[2 * i] = __uint_as_float(r.w[i] << 16); o[2 * i + 1] = __uint_as_float(r.w[i] & 0xffff0000u); }
 }
 
 // dx[src] = rstd * (g*gamma - mean(g*gamma) - xhat * mean(g*gamma*xhat)) (+ res[src]);  dgamma += g*xhat, dbeta += g
-template <typename T, int LN_MAXCH>
+template <typename T, int LN_MAXCH, int VW>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ g, const T* __restrict__ x, const int* __restrict__ map,
                                                       const float* __restrict__ gamma, const float* __restrict__ mean,
                                                       const float* __restrict__ rstd, const T* __restrict__ res, const T* __restrict__ mask,
                                                       T* __restrict__ dx, float* __restrict__ dgamma, float* __restrict__ dbeta, int rows, int C, int rows_per_block) {
-    __shared__ float red[4 * LN_MAXCH * 256];
+    __shared__ float red[4 * LN_MAXCH * 64 * VW];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    float dg[LN_MAXCH][4], db[LN_MAXCH][4], gm[LN_MAXCH][4];
+    float dg[LN_MAXCH][VW], db[LN_MAXCH][VW], gm[LN_MAXCH][VW];
 #pragma unroll
     for (int j = 0; j < LN_MAXCH; ++j) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) { dg[j][i] = 0.f; db[j][i] = 0.f; gm[j][i] = 0.f; }
-        if ((lane + 64 * j) * 4 < C) load4(gamma + (lane + 64 * j) * 4, gm[j]);
+        for (int i = 0; i < VW; ++i) { dg[j][i] = 0.f; db[j][i] = 0.f; gm[j][i] = 0.f; }
+        if ((lane + 64 * j) * VW < C) loadv<VW>(gamma + (lane + 64 * j) * VW, gm[j]);
     }
     const int r_end = min(rows, (int)(blockIdx.x + 1) * rows_per_block);
     // A wave walks its rows one at a time, and a row is a load -> reduce -> store chain: with nothing else in flight the kernel
     // runs at the latency of that chain, not at HBM rate.  The operands of the NEXT row (kept as raw 16-bit pairs: half the
     // registers) are requested before the current row is reduced; the residual comes with them instead of after the reduction.
-    constexpr bool kPrefetch = LN_MAXCH <= 4 && sizeof(T) == 2;
+    constexpr bool kPrefetch = LN_MAXCH * VW <= 16 && sizeof(T) == 2;
     struct RowIn {
-        Raw4<T> g[LN_MAXCH], x[LN_MAXCH], m[LN_MAXCH], rv[LN_MAXCH];
+        RawV<T, VW> g[LN_MAXCH], x[LN_MAXCH], m[LN_MAXCH], rv[LN_MAXCH];
         float mu, rs;
         long src;
     };
@@ -105,12 +152,12 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ g, co
         in.rs = rstd[r];
 #pragma unroll
         for (int j = 0; j < LN_MAXCH; ++j)
-            if ((lane + 64 * j) * 4 < C) {
-                const int off = (lane + 64 * j) * 4;
-                ldraw(g + (long)r * C + off, in.g[j]);
-                if (mask) ldraw(mask + (long)r * C + off, in.m[j]);
-                ldraw(x + in.src * C + off, in.x[j]);
-                if (res) ldraw(res + in.src * C + off, in.rv[j]);
+            if ((lane + 64 * j) * VW < C) {
+                const int off = (lane + 64 * j) * VW;
+                ldrawv(g + (long)r * C + off, in.g[j]);
+                if (mask) ldrawv(mask + (long)r * C + off, in.m[j]);
+                ldrawv(x + in.src * C + off, in.x[j]);
+                if (res) ldrawv(res + in.src * C + off, in.rv[j]);
             }
     };
     RowIn cur, nxt;
@@ -126,21 +173,21 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ g, co
         if (cur.src >= 0) {
             const long src = cur.src;
             const float mu = cur.mu, rs = cur.rs;
-            float gv[LN_MAXCH][4], xh[LN_MAXCH][4];
+            float gv[LN_MAXCH][VW], xh[LN_MAXCH][VW];
             float s1 = 0.f, s2 = 0.f;
 #pragma unroll
             for (int j = 0; j < LN_MAXCH; ++j)
-                if ((lane + 64 * j) * 4 < C) {
-                    cvt4(cur.g[j], gv[j]);
+                if ((lane + 64 * j) * VW < C) {
+                    cvtv(cur.g[j], gv[j]);
                     if (mask) {      // ReLU after the norm: the gradient passes where the activation was positive
-                        float mv[4];
-                        cvt4(cur.m[j], mv);
+                        float mv[VW];
+                        cvtv(cur.m[j], mv);
 #pragma unroll
-                        for (int i = 0; i < 4; ++i) gv[j][i] = mv[i] > 0.f ? gv[j][i] : 0.f;
+                        for (int i = 0; i < VW; ++i) gv[j][i] = mv[i] > 0.f ? gv[j][i] : 0.f;
                     }
-                    cvt4(cur.x[j], xh[j]);
+                    cvtv(cur.x[j], xh[j]);
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) {
+                    for (int i = 0; i < VW; ++i) {
                         xh[j][i] = (xh[j][i] - mu) * rs;
                         dg[j][i] += gv[j][i] * xh[j][i];
                         db[j][i] += gv[j][i];
@@ -153,12 +200,14 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ g, co
             s2 = warp_sum(s2) / (float)C;
 #pragma unroll
             for (int j = 0; j < LN_MAXCH; ++j)
-                if ((lane + 64 * j) * 4 < C) {
-                    float o[4], rv[4] = {0.f, 0.f, 0.f, 0.f};
-                    if (res) cvt4(cur.rv[j], rv);
+                if ((lane + 64 * j) * VW < C) {
+                    float o[VW], rv[VW];
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) o[i] = rs * (gv[j][i] - s1 - xh[j][i] * s2) + rv[i];
-                    store4(dx + src * C + (lane + 64 * j) * 4, o);
+                    for (int i = 0; i < VW; ++i) rv[i] = 0.f;
+                    if (res) cvtv(cur.rv[j], rv);
+#pragma unroll
+                    for (int i = 0; i < VW; ++i) o[i] = rs * (gv[j][i] - s1 - xh[j][i] * s2) + rv[i];
+                    storev<VW>(dx + src * C + (lane + 64 * j) * VW, o);
                 }
         }
         if constexpr (kPrefetch) cur = nxt;
@@ -168,13 +217,13 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ g, co
         __syncthreads();
 #pragma unroll
         for (int j = 0; j < LN_MAXCH; ++j)
-            if ((lane + 64 * j) * 4 < C) {
+            if ((lane + 64 * j) * VW < C) {
 #pragma unroll
-                for (int i = 0; i < 4; ++i) red[wave * (LN_MAXCH * 256) + (lane + 64 * j) * 4 + i] = pass ? db[j][i] : dg[j][i];
+                for (int i = 0; i < VW; ++i) red[wave * (LN_MAXCH * 64 * VW) + (lane + 64 * j) * VW + i] = pass ? db[j][i] : dg[j][i];
             }
         __syncthreads();
         for (int cidx = threadIdx.x; cidx < C; cidx += 256) {
-            constexpr int RS = LN_MAXCH * 256;
+            constexpr int RS = LN_MAXCH * 64 * VW;
             const float t = (red[cidx] + red[RS + cidx]) + (red[2 * RS + cidx] + red[3 * RS + cidx]);
             atomicAdd((pass ? dbeta : dgamma) + cidx, t);
         }
@@ -488,15 +537,18 @@ extern "C" int aldi_layernorm_forward(const void* x, const int* map, const float
                                       float* rstd, int rows, int C, float eps, int relu, int dtype, aldi_stream_t stream) {
     if (C % 4 || C > 2048 || rows <= 0) return aldi_set_error_msg(ALDI_ERR_ARG, "layernorm: C must be a multiple of 4, <= 2048");
     hipStream_t st = (hipStream_t)stream;
-    if (C <= 1024) {
-        VIT_DISPATCH(dtype,
-            hipLaunchKernelGGL((ln_fwd_kernel<float, 4>), dim3(cdiv(rows, 4)), dim3(256), 0, st, (const float*)x, map, gamma, beta, (float*)y, mean, rstd, rows, C, eps, relu),
-            hipLaunchKernelGGL((ln_fwd_kernel<bf16_t, 4>), dim3(cdiv(rows, 4)), dim3(256), 0, st, (const bf16_t*)x, map, gamma, beta, (bf16_t*)y, mean, rstd, rows, C, eps, relu));
+    // bf16 rows of whole 16-B vectors: 8 channels per lane chunk (one 16-B access), half the chunks
+    const bool v8 = dtype == ALDI_BF16 && C % 8 == 0 && (((uintptr_t)x | (uintptr_t)y) & 15) == 0;
+#define LN_FWD(T_, MC, VW_) hipLaunchKernelGGL((ln_fwd_kernel<T_, MC, VW_>), dim3(cdiv(rows, 4)), dim3(256), 0, st, (const T_*)x, map, gamma, beta, (T_*)y, mean, rstd, rows, C, eps, relu)
+    if (v8) {
+        if (C <= 1024) LN_FWD(bf16_t, 2, 8);
+        else LN_FWD(bf16_t, 4, 8);
+    } else if (C <= 1024) {
+        VIT_DISPATCH(dtype, LN_FWD(float, 4, 4), LN_FWD(bf16_t, 4, 4));
     } else {
-        VIT_DISPATCH(dtype,
-            hipLaunchKernelGGL((ln_fwd_kernel<float, 8>), dim3(cdiv(rows, 4)), dim3(256), 0, st, (const float*)x, map, gamma, beta, (float*)y, mean, rstd, rows, C, eps, relu),
-            hipLaunchKernelGGL((ln_fwd_kernel<bf16_t, 8>), dim3(cdiv(rows, 4)), dim3(256), 0, st, (const bf16_t*)x, map, gamma, beta, (bf16_t*)y, mean, rstd, rows, C, eps, relu));
+        VIT_DISPATCH(dtype, LN_FWD(float, 8, 4), LN_FWD(bf16_t, 8, 4));
     }
+#undef LN_FWD
     ALDI_CHECK_LAUNCH();
     return ALDI_OK;
 }
@@ -509,19 +561,18 @@ extern "C" int aldi_layernorm_backward(const void* g, const void* x, const int* 
     // one round of workgroups (2 per CU at this register count: 513 would run as two rounds), each ending with 2*C atomics
     static const int target_blocks = getenv("ALDI_LN_BWD_BLOCKS") ? atoi(getenv("ALDI_LN_BWD_BLOCKS")) : 512;
     const int rpb = cdiv(rows, target_blocks) < 32 ? 32 : cdiv(rows, target_blocks);
-    if (C <= 1024) {
-    VIT_DISPATCH(dtype,
-        hipLaunchKernelGGL((ln_bwd_kernel<float, 4>), dim3(cdiv(rows, rpb)), dim3(256), 0, st, (const float*)g, (const float*)x, map, gamma, mean, rstd,
-                           (const float*)res, (const float*)mask, (float*)dx, dgamma, dbeta, rows, C, rpb),
-        hipLaunchKernelGGL((ln_bwd_kernel<bf16_t, 4>), dim3(cdiv(rows, rpb)), dim3(256), 0, st, (const bf16_t*)g, (const bf16_t*)x, map, gamma, mean, rstd,
-                           (const bf16_t*)res, (const bf16_t*)mask, (bf16_t*)dx, dgamma, dbeta, rows, C, rpb));
+    const bool v8 = dtype == ALDI_BF16 && C % 8 == 0 && (((uintptr_t)g | (uintptr_t)x | (uintptr_t)res | (uintptr_t)mask | (uintptr_t)dx) & 15) == 0;
+#define LN_BWD(T_, MC, VW_) hipLaunchKernelGGL((ln_bwd_kernel<T_, MC, VW_>), dim3(cdiv(rows, rpb)), dim3(256), 0, st, (const T_*)g, (const T_*)x, map, gamma, mean, rstd, \
+                                               (const T_*)res, (const T_*)mask, (T_*)dx, dgamma, dbeta, rows, C, rpb)
+    if (v8) {
+        if (C <= 1024) LN_BWD(bf16_t, 2, 8);
+        else LN_BWD(bf16_t, 4, 8);
+    } else if (C <= 1024) {
+        VIT_DISPATCH(dtype, LN_BWD(float, 4, 4), LN_BWD(bf16_t, 4, 4));
     } else {
-    VIT_DISPATCH(dtype,
-        hipLaunchKernelGGL((ln_bwd_kernel<float, 8>), dim3(cdiv(rows, rpb)), dim3(256), 0, st, (const float*)g, (const float*)x, map, gamma, mean, rstd,
-                           (const float*)res, (const float*)mask, (float*)dx, dgamma, dbeta, rows, C, rpb),
-        hipLaunchKernelGGL((ln_bwd_kernel<bf16_t, 8>), dim3(cdiv(rows, rpb)), dim3(256), 0, st, (const bf16_t*)g, (const bf16_t*)x, map, gamma, mean, rstd,
-                           (const bf16_t*)res, (const bf16_t*)mask, (bf16_t*)dx, dgamma, dbeta, rows, C, rpb));
+        VIT_DISPATCH(dtype, LN_BWD(float, 8, 4), LN_BWD(bf16_t, 8, 4));
     }
+#undef LN_BWD
     ALDI_CHECK_LAUNCH();
     return ALDI_OK;
 }
