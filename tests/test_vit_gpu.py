@@ -18,7 +18,7 @@ def relerr(a, b):
 
 # ------------------------------------------------------------------------------------------------ LayerNorm
 @pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-5), (torch.bfloat16, 1.2e-2)])
-@pytest.mark.parametrize("C", [256, 768, 1536])
+@pytest.mark.parametrize("C", [100, 256, 768, 1028, 1536])     # 100 / 1028: rows that are not whole 16-B vectors (4-wide lane chunks in bf16 too)
 def test_layernorm_fwd_bwd(dtype, tol, C):
     from aldi_amd import vit_ops as V
     torch.manual_seed(0)
