@@ -280,14 +280,36 @@ __global__ __launch_bounds__(256) void scale_add_bwd_kernel(const T* __restrict_
     if (live) {
 #pragma unroll
         for (int k = 0; k < 8; ++k) gm[k] = gamma[cg * 8 + k];
-        for (long r = r0 + rl; r < r1; r += nrl) {
-            float gv[8], yv[8], o[8];
-            load8(g + (r * c8 + cg) * 8, gv);
-            load8(y + (r * c8 + cg) * 8, yv);
+        auto finish = [&](long r, const Raw8<T>& gr, const Raw8<T>& yr) {
             const float s = scale ? scale[r / rows_per_sample] : 1.f;
+            float o[8];
 #pragma unroll
-            for (int k = 0; k < 8; ++k) { o[k] = s * gm[k] * gv[k]; acc[k] += s * gv[k] * yv[k]; }
+            for (int p2 = 0; p2 < 4; ++p2) {
+                float gv[2], yv[2];
+                pair_of(gr, p2, gv);
+                pair_of(yr, p2, yv);
+#pragma unroll
+                for (int e = 0; e < 2; ++e) { o[2 * p2 + e] = s * gm[2 * p2 + e] * gv[e]; acc[2 * p2 + e] += s * gv[e] * yv[e]; }
+            }
             store8(dy + (r * c8 + cg) * 8, o);
+        };
+        // a streaming read-modify-write with one row per lane and step runs at the latency of its loads: four rows (8 vectors) in flight
+        long r = r0 + rl;
+        for (; r + 3 * nrl < r1; r += 4 * nrl) {
+            Raw8<T> gr[4], yr[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                ldraw8(g + ((r + u * nrl) * c8 + cg) * 8, gr[u]);
+                ldraw8(y + ((r + u * nrl) * c8 + cg) * 8, yr[u]);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) finish(r + u * nrl, gr[u], yr[u]);
+        }
+        for (; r < r1; r += nrl) {
+            Raw8<T> gr, yr;
+            ldraw8(g + (r * c8 + cg) * 8, gr);
+            ldraw8(y + (r * c8 + cg) * 8, yr);
+            finish(r, gr, yr);
         }
     }
 #pragma unroll
@@ -365,7 +387,10 @@ extern "C" int aldi_scale_add_backward(const void* g, const void* y, const float
     hipStream_t st = (hipStream_t)stream;
     const int c8 = C / 8, CG = c8 >= 32 ? 32 : (c8 >= 16 ? 16 : (c8 >= 8 ? 8 : (c8 >= 4 ? 4 : (c8 >= 2 ? 2 : 1))));
     const int ngrp = (c8 + CG - 1) / CG;
-    long chunks = 2048 / ngrp + 1;
+    // every workgroup ends with CG * 8 atomics onto the same C addresses, which serialise in L2 (as in the bias-gradient sum): few,
+    // long workgroups with four rows in flight per lane instead of ~2000 short ones
+    static const int target_blocks = getenv("ALDI_SAB_BLOCKS") ? atoi(getenv("ALDI_SAB_BLOCKS")) : 512;
+    long chunks = target_blocks / ngrp + 1;
     if (chunks > rows / 64 + 1) chunks = rows / 64 + 1;
     const int rpb = (int)((rows + chunks - 1) / chunks);
     dim3 grid(cdiv(rows, rpb), ngrp);
