@@ -541,7 +541,8 @@ extern "C" int aldi_layernorm_forward(const void* x, const int* map, const float
     const bool v8 = dtype == ALDI_BF16 && C % 8 == 0 && (((uintptr_t)x | (uintptr_t)y) & 15) == 0;
 #define LN_FWD(T_, MC, VW_) hipLaunchKernelGGL((ln_fwd_kernel<T_, MC, VW_>), dim3(cdiv(rows, 4)), dim3(256), 0, st, (const T_*)x, map, gamma, beta, (T_*)y, mean, rstd, rows, C, eps, relu)
     if (v8) {
-        if (C <= 1024) LN_FWD(bf16_t, 2, 8);
+        if (C <= 512) LN_FWD(bf16_t, 1, 8);          // one chunk per lane: half the registers of the 2-chunk form
+        else if (C <= 1024) LN_FWD(bf16_t, 2, 8);
         else LN_FWD(bf16_t, 4, 8);
     } else if (C <= 1024) {
         VIT_DISPATCH(dtype, LN_FWD(float, 4, 4), LN_FWD(bf16_t, 4, 4));
@@ -559,13 +560,17 @@ extern "C" int aldi_layernorm_backward(const void* g, const void* x, const int* 
     if (C % 4 || C > 2048 || rows <= 0) return aldi_set_error_msg(ALDI_ERR_ARG, "layernorm: C must be a multiple of 4, <= 2048");
     hipStream_t st = (hipStream_t)stream;
     // one round of workgroups (2 per CU at this register count: 513 would run as two rounds), each ending with 2*C atomics
-    static const int target_blocks = getenv("ALDI_LN_BWD_BLOCKS") ? atoi(getenv("ALDI_LN_BWD_BLOCKS")) : 512;
-    const int rpb = cdiv(rows, target_blocks) < 32 ? 32 : cdiv(rows, target_blocks);
+    // (the single-chunk form for C <= 512 needs half the registers: four workgroups per CU)
+    static const int target_wide = getenv("ALDI_LN_BWD_BLOCKS") ? atoi(getenv("ALDI_LN_BWD_BLOCKS")) : 512;
+    static const int target_narrow = getenv("ALDI_LN_BWD_BLOCKS_NARROW") ? atoi(getenv("ALDI_LN_BWD_BLOCKS_NARROW")) : 1024;
     const bool v8 = dtype == ALDI_BF16 && C % 8 == 0 && (((uintptr_t)g | (uintptr_t)x | (uintptr_t)res | (uintptr_t)mask | (uintptr_t)dx) & 15) == 0;
+    const int target_blocks = v8 && C <= 512 ? target_narrow : target_wide;
+    const int rpb = cdiv(rows, target_blocks) < 32 ? 32 : cdiv(rows, target_blocks);
 #define LN_BWD(T_, MC, VW_) hipLaunchKernelGGL((ln_bwd_kernel<T_, MC, VW_>), dim3(cdiv(rows, rpb)), dim3(256), 0, st, (const T_*)g, (const T_*)x, map, gamma, mean, rstd, \
                                                (const T_*)res, (const T_*)mask, (T_*)dx, dgamma, dbeta, rows, C, rpb)
     if (v8) {
-        if (C <= 1024) LN_BWD(bf16_t, 2, 8);
+        if (C <= 512) LN_BWD(bf16_t, 1, 8);
+        else if (C <= 1024) LN_BWD(bf16_t, 2, 8);
         else LN_BWD(bf16_t, 4, 8);
     } else if (C <= 1024) {
         VIT_DISPATCH(dtype, LN_BWD(float, 4, 4), LN_BWD(bf16_t, 4, 4));
