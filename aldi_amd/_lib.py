@@ -72,6 +72,26 @@ def call(name: str, *args):
     check(getattr(lib, name)(*args), name)
 
 
+def set_tuning(name: str, value: int):
+    """aldi_set_tuning: select a dispatch arm / launch geometry at run time (include/aldi_hip.h lists the knobs)."""
+    call("aldi_set_tuning", name.encode(), int(value))
+
+
+def get_tuning(name: str) -> int:
+    v = C.c_int(0)
+    call("aldi_get_tuning", name.encode(), C.byref(v))
+    return v.value
+
+
+def reset_tuning():
+    call("aldi_reset_tuning")
+
+
+def last_dispatch() -> str:
+    """kernel variant chosen by the most recent aldi_conv_igemm / aldi_conv_wgrad call of this thread"""
+    return lib.aldi_last_dispatch().decode()
+
+
 class ConvArgs(C.Structure):
     _fields_ = [
         ("x", c_void_p), ("w", c_void_p), ("y", c_void_p), ("y_f32", c_void_p),

@@ -14,6 +14,16 @@
 int aldi_set_error(hipError_t e, const char* file, int line);
 int aldi_set_error_msg(int code, const char* msg);
 
+// run-time tuning knobs (aldi_set_tuning / ALDI_<NAME> environment defaults; core.hip)
+struct AldiTuning {
+    int igemm_xcd, igemm_tile, igemm_dbg, igemm_bigtile_min, igemm_bigtile_k, igemm_lintile_min, igemm_halo, igemm_force;
+    int wgrad_lean, wgrad_big_min, wgrad_big_slots, wgrad_slots, wgrad_xcd;
+    int colsum_blocks, colsum_minrows, colsum_nt, colsum_block_kb;
+    int stem_mfma, sab_blocks, ln_bwd_blocks, ln_bwd_blocks_narrow;
+};
+AldiTuning& aldi_tuning();
+void aldi_note_dispatch(const char* kernel);   // what aldi_last_dispatch() reports (thread local)
+
 typedef uint16_t bf16_t;  // raw bf16 storage
 
 typedef __attribute__((ext_vector_type(8))) short bf16x8_t;   // MFMA bf16 A/B fragment (4 VGPRs)

@@ -389,7 +389,7 @@ extern "C" int aldi_scale_add_backward(const void* g, const void* y, const float
     const int ngrp = (c8 + CG - 1) / CG;
     // every workgroup ends with CG * 8 atomics onto the same C addresses, which serialise in L2 (as in the bias-gradient sum): few,
     // long workgroups with four rows in flight per lane instead of ~2000 short ones
-    static const int target_blocks = getenv("ALDI_SAB_BLOCKS") ? atoi(getenv("ALDI_SAB_BLOCKS")) : 512;
+    const int target_blocks = aldi_tuning().sab_blocks;
     long chunks = target_blocks / ngrp + 1;
     if (chunks > rows / 64 + 1) chunks = rows / 64 + 1;
     const int rpb = (int)((rows + chunks - 1) / chunks);

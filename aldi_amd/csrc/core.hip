@@ -15,3 +15,71 @@ int aldi_set_error_msg(int code, const char* msg) {
 }
 extern "C" const char* aldi_last_error(void) { return g_err; }
 extern "C" int aldi_version(void) { return 1; }
+
+// ---- tuning knobs (include/aldi_hip.h: aldi_set_tuning) -------------------------------------------------------------
+// One table; the defaults can be overridden once from the environment (ALDI_<UPPER-CASE NAME>) and at any time through
+// the C ABI, so a single test process can select every dispatch arm.
+#include <stdlib.h>
+namespace {
+struct Knob { const char* name; int AldiTuning::*field; int dflt; };
+const Knob kKnobs[] = {
+    {"igemm_xcd", &AldiTuning::igemm_xcd, 1},
+    {"igemm_tile", &AldiTuning::igemm_tile, 0},
+    {"igemm_dbg", &AldiTuning::igemm_dbg, 0},
+    {"igemm_bigtile_min", &AldiTuning::igemm_bigtile_min, 1024},
+    {"igemm_bigtile_k", &AldiTuning::igemm_bigtile_k, 768},
+    {"igemm_lintile_min", &AldiTuning::igemm_lintile_min, 768},
+    {"igemm_halo", &AldiTuning::igemm_halo, 1},
+    {"igemm_force", &AldiTuning::igemm_force, 0},
+    {"wgrad_lean", &AldiTuning::wgrad_lean, 1},
+    {"wgrad_big_min", &AldiTuning::wgrad_big_min, 28},
+    {"wgrad_big_slots", &AldiTuning::wgrad_big_slots, 256},
+    {"wgrad_slots", &AldiTuning::wgrad_slots, 384},
+    {"wgrad_xcd", &AldiTuning::wgrad_xcd, 1},
+    {"colsum_blocks", &AldiTuning::colsum_blocks, 256},
+    {"colsum_minrows", &AldiTuning::colsum_minrows, 16},
+    {"colsum_nt", &AldiTuning::colsum_nt, 1024},
+    {"colsum_block_kb", &AldiTuning::colsum_block_kb, 384},
+    {"stem_mfma", &AldiTuning::stem_mfma, 1},
+    {"sab_blocks", &AldiTuning::sab_blocks, 512},
+    {"ln_bwd_blocks", &AldiTuning::ln_bwd_blocks, 512},
+    {"ln_bwd_blocks_narrow", &AldiTuning::ln_bwd_blocks_narrow, 1024},
+};
+AldiTuning make_tuning() {
+    AldiTuning t;
+    for (const Knob& k : kKnobs) {
+        char env[64] = "ALDI_";
+        size_t n = strlen(env);
+        for (const char* c = k.name; *c && n + 1 < sizeof(env); ++c) env[n++] = (*c >= 'a' && *c <= 'z') ? (char)(*c - 32) : *c;
+        env[n] = 0;
+        const char* v = getenv(env);
+        t.*(k.field) = v ? atoi(v) : k.dflt;
+    }
+    return t;
+}
+thread_local char g_dispatch[160] = "";
+}  // namespace
+
+AldiTuning& aldi_tuning() {
+    static AldiTuning t = make_tuning();
+    return t;
+}
+void aldi_note_dispatch(const char* kernel) { snprintf(g_dispatch, sizeof(g_dispatch), "%s", kernel); }
+
+extern "C" int aldi_set_tuning(const char* name, int value) {
+    if (!name) return aldi_set_error_msg(ALDI_ERR_ARG, "set_tuning: null name");
+    for (const Knob& k : kKnobs)
+        if (!strcmp(k.name, name)) { aldi_tuning().*(k.field) = value; return ALDI_OK; }
+    return aldi_set_error_msg(ALDI_ERR_ARG, "set_tuning: unknown knob");
+}
+extern "C" int aldi_get_tuning(const char* name, int* value) {
+    if (!name || !value) return aldi_set_error_msg(ALDI_ERR_ARG, "get_tuning: null argument");
+    for (const Knob& k : kKnobs)
+        if (!strcmp(k.name, name)) { *value = aldi_tuning().*(k.field); return ALDI_OK; }
+    return aldi_set_error_msg(ALDI_ERR_ARG, "get_tuning: unknown knob");
+}
+extern "C" int aldi_reset_tuning(void) {
+    aldi_tuning() = make_tuning();
+    return ALDI_OK;
+}
+extern "C" const char* aldi_last_dispatch(void) { return g_dispatch; }

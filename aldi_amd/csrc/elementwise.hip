@@ -397,7 +397,7 @@ extern "C" int aldi_stem_forward(const aldi_stem_args* a, aldi_stream_t stream) 
     for (int c = 0; c < 3; ++c) { d.mean[c] = a->mean[c]; d.inv_std[c] = 1.0f / a->std[c]; }
     dim3 grid(cdiv(a->Wc, 16), cdiv(a->Hc, 16), a->N);
     hipStream_t st = static_cast<hipStream_t>(stream);
-    static const int mfma_env = getenv("ALDI_STEM_MFMA") ? atoi(getenv("ALDI_STEM_MFMA")) : 1;
+    const int mfma_env = aldi_tuning().stem_mfma;
     if (a->dtype == ALDI_BF16 && mfma_env && a->scale && a->shift) {
         hipLaunchKernelGGL(stem_mfma_kernel, grid, dim3(256), 0, st, d);
         ALDI_CHECK_LAUNCH();

@@ -8,11 +8,13 @@
 // scale/shift, residual / FPN top-down add, ReLU, ReLU-backward mask) works on 4-vectors and
 // stores 8 B (bf16) or 16 B (fp32) per lane.
 //
-// Tiles are staged global -> registers -> LDS (the gather needs per-lane addresses and zero
-// fill at the borders), double buffered, one barrier per K slab, next slab's global loads
-// issued before the current slab's MFMAs.  LDS rows are 128 B (8 x 16 B chunks, two MFMA k-steps per
-// barrier); the chunk index is XOR-swizzled so that the 16-lane groups of ds_read_b128 hit 16
-// distinct 16-B slots (MI355X_MICROARCH.md, LDS table).
+// Tiles go global -> LDS directly by LDS-DMA (`buffer_load_dwordx4 ... lds`): a 32-bit per-lane byte offset into a raw
+// buffer descriptor, where an out-of-range offset writes zeros (border taps, tile tails and K tails are selects of the
+// offset, never branches).  LDS rows are 64 B (four 16-B chunks = one MFMA k-step per slab); the bank swizzle is applied
+// on the SOURCE address because the DMA writes lane-linearly.  Three-slab LDS ring with counted `vmcnt` waits and raw
+// `s_barrier`; fragments are hand-issued `ds_read_b128` into two register sets so the reads of slab s+1 run under the
+// MFMAs of slab s.  3x3 / stride-1 / pad-1 convs use the "halo" form: one (BM+2)-pixel slab serves the three
+// horizontal taps (see the HALO branch).
 //
 // dtype: bf16 -> v_mfma_f32_16x16x32_bf16 (K slab 64); fp32 -> v_mfma_f32_16x16x4_f32 x4
 // (K slab 32, exact fp32 -- the parity mode).  Both share the byte geometry of the tiles.
@@ -20,6 +22,7 @@
 // Replaces the cuDNN/MIOpen conv + FrozenBN + ReLU (+ residual) chain and torch Linear that
 // the reference reaches through detectron2 (aldi/align.py:72, aldi/distill.py:157,162).
 #include "common.h"
+#include <stdio.h>
 #include <stdlib.h>
 
 namespace {
@@ -569,55 +572,52 @@ int launch(const ConvDev& d, hipStream_t st) {
     dim3 grid(cdiv(d.M, BM), cdiv(d.Cout, BN));
     hipLaunchKernelGGL((igemm_kernel<T, BM, BN, WM, WN, KC, PIPE, HALO>), grid, dim3(WM * WN * 64), 0, st, d);
     ALDI_CHECK_LAUNCH();
+    char name[96];
+    snprintf(name, sizeof(name), "igemm<%s,%d,%d,%d,%d,%s,%s>", sizeof(T) == 2 ? "bf16" : "f32", BM, BN, WM, WN, PIPE ? "pipe" : "flat", HALO ? "halo" : "tap");
+    aldi_note_dispatch(name);
     return ALDI_OK;
 }
 
-static int env_int(const char* name, int dflt) {
-    const char* v = getenv(name);
-    return v ? atoi(v) : dflt;
-}
-
+// Tile selection.  Every arm is reachable from a test through aldi_set_tuning("igemm_force", ...) and named by
+// aldi_last_dispatch(); the thresholds are knobs of the same table (include/aldi_hip.h).
 template <typename T>
 int dispatch(ConvDev& d, hipStream_t st) {
-    static const int xcd_env = env_int("ALDI_IGEMM_XCD", 1);
-    static const int tile_env = env_int("ALDI_IGEMM_TILE", 0);
-    d.xcd = xcd_env;
-    static const int dbg_env = env_int("ALDI_IGEMM_DBG", 0);
-    d.dbg = dbg_env;
+    const AldiTuning& tn = aldi_tuning();
+    d.xcd = tn.igemm_xcd;
+    d.dbg = tn.igemm_dbg;
     // the N=2 micro-batch leaves the deep layers (res4/res5, FC heads) with far fewer 128x128 tiles than the
     // 256 CUs: fall back to 64x64 tiles (4x the workgroups) when the big tiling cannot fill the chip
     const long big = (long)cdiv(d.M, 128) * cdiv(d.Cout, 128);
-    // long-K convs with thousands of tiles are bound by the L2 -> CU path (~31 B/clk/CU measured): the 256x128 tile
-    // (8 waves) moves 25 % fewer bytes per flop
-    static const int big_tile_min = env_int("ALDI_IGEMM_BIGTILE_MIN", 1024);
-    // plain token GEMMs (ViT / ConvNeXt linears: K >= 768, M in the thousands): the 256x128 tile already pays from ~770 tiles on
-    // (+10 % at K = 768, +30 % at K = 3072 measured); the short-K 1x1 convs of the R50 trunk are HBM-bound and stay on 128x128
-    static const int big_tile_k = env_int("ALDI_IGEMM_BIGTILE_K", 768);
-    static const int lin_tile_min = env_int("ALDI_IGEMM_LINTILE_MIN", 768);
-    // 3x3 / stride 1 / pad 1 (every 3x3 of the network): halo form, the pixel tile is loaded once per three taps
-    static const int halo_env = env_int("ALDI_IGEMM_HALO", 1);
-    static const int force = env_int("ALDI_IGEMM_FORCE", 0);     // experiments: 1 = 128x128, 2 = 128x64, 3 = 64x64, 4 = 256x128
+    // igemm_bigtile_min: long-K convs with thousands of tiles are bound by the L2 -> CU path (~31 B/clk/CU measured): the
+    // 256x128 tile (8 waves) moves 25 % fewer bytes per flop.
+    // igemm_bigtile_k / igemm_lintile_min: plain token GEMMs (ViT / ConvNeXt linears: K >= 768, M in the thousands): the
+    // 256x128 tile already pays from ~770 tiles on (+10 % at K = 768, +30 % at K = 3072 measured); the short-K 1x1 convs of
+    // the R50 trunk are HBM-bound and stay on 128x128.
+    // igemm_halo: 3x3 / stride 1 / pad 1 (every 3x3 of the network): halo form, the pixel tile is loaded once per three taps.
+    const int force = tn.igemm_force;     // 0 = heuristics; 1 = 128x128, 2 = 128x64, 3 = 64x64, 4 = 256x128, 5 = 128x16
     if constexpr (sizeof(T) == 2) {
         const bool same3 = d.KH == 3 && d.KW == 3 && d.stride == 1 && d.pad == 1 && d.Ho == d.H && d.Wo == d.W && d.Cin % 32 == 0 && d.out_scale == 1;
-        if (halo_env && same3) {
+        if (tn.igemm_halo && same3) {
             if (force == 1) return launch<T, 128, 128, 2, 2, 4, false, true>(d, st);
             if (force == 2) return launch<T, 128, 64, 4, 1, 4, false, true>(d, st);
             if (force == 4) return launch<T, 256, 128, 4, 2, 4, false, true>(d, st);
-            if (d.Cout <= 64) return launch<T, 128, 64, 4, 1, 4, false, true>(d, st);
-            if (big >= big_tile_min) return launch<T, 256, 128, 4, 2, 4, false, true>(d, st);
-            // below ~1000 128x128 tiles the tile count of this network sits just above a multiple of the 256 CUs (16800 pixels =
-            // 131.25 row tiles: 264 / 528 tiles) and the last partial round costs as much as a full one; half-width tiles halve that
-            // tail (measured 8-25 % faster on every res3..res5 / FPN p3..p6 3x3 at N = 2 and 4)
-            return launch<T, 128, 64, 4, 1, 4, false, true>(d, st);
+            if (force == 0 || force == 3) {      // (no 64x64 halo form; 5 = the 128x16 tap form)
+                if (d.Cout <= 64) return launch<T, 128, 64, 4, 1, 4, false, true>(d, st);
+                if (big >= tn.igemm_bigtile_min) return launch<T, 256, 128, 4, 2, 4, false, true>(d, st);
+                // below ~1000 128x128 tiles the tile count of this network sits just above a multiple of the 256 CUs (16800 pixels =
+                // 131.25 row tiles: 264 / 528 tiles) and the last partial round costs as much as a full one; half-width tiles halve that
+                // tail (measured 8-25 % faster on every res3..res5 / FPN p3..p6 3x3 at N = 2 and 4)
+                return launch<T, 128, 64, 4, 1, 4, false, true>(d, st);
+            }
         }
     }
-    if (d.Cout <= 16) return launch<T, 128, 16, 4, 1, 4>(d, st);
+    if (force == 5 || (force == 0 && d.Cout <= 16)) return launch<T, 128, 16, 4, 1, 4>(d, st);
     if (force == 1) return launch<T, 128, 128, 2, 2, 4>(d, st);
     if (force == 2) return launch<T, 128, 64, 4, 1, 4>(d, st);
     if (force == 3) return launch<T, 64, 64, 2, 2, 4>(d, st);
     if (force == 4) return launch<T, 256, 128, 4, 2, 4, false>(d, st);
     if (d.Cout <= 64) return launch<T, 128, 64, 4, 1, 4>(d, st);
-    if (tile_env != 9 && big >= lin_tile_min && d.K >= big_tile_k) return launch<T, 256, 128, 4, 2, 4, false>(d, st);
+    if (tn.igemm_tile != 9 && big >= tn.igemm_lintile_min && d.K >= tn.igemm_bigtile_k) return launch<T, 256, 128, 4, 2, 4, false>(d, st);
     if (big < 200) return launch<T, 64, 64, 2, 2, 4>(d, st);
     return launch<T, 128, 128, 2, 2, 4>(d, st);
 }

@@ -561,8 +561,8 @@ extern "C" int aldi_layernorm_backward(const void* g, const void* x, const int* 
     hipStream_t st = (hipStream_t)stream;
     // one round of workgroups (2 per CU at this register count: 513 would run as two rounds), each ending with 2*C atomics
     // (the single-chunk form for C <= 512 needs half the registers: four workgroups per CU)
-    static const int target_wide = getenv("ALDI_LN_BWD_BLOCKS") ? atoi(getenv("ALDI_LN_BWD_BLOCKS")) : 512;
-    static const int target_narrow = getenv("ALDI_LN_BWD_BLOCKS_NARROW") ? atoi(getenv("ALDI_LN_BWD_BLOCKS_NARROW")) : 1024;
+    const int target_wide = aldi_tuning().ln_bwd_blocks;
+    const int target_narrow = aldi_tuning().ln_bwd_blocks_narrow;
     const bool v8 = dtype == ALDI_BF16 && C % 8 == 0 && (((uintptr_t)g | (uintptr_t)x | (uintptr_t)res | (uintptr_t)mask | (uintptr_t)dx) & 15) == 0;
     const int target_blocks = v8 && C <= 512 ? target_narrow : target_wide;
     const int rpb = cdiv(rows, target_blocks) < 32 ? 32 : cdiv(rows, target_blocks);

@@ -18,6 +18,7 @@
 // aldi/trainer.py:79 (`trainer.do_backward`).
 #include "common.h"
 #include <hip/amd_detail/amd_hip_unsafe_atomics.h>
+#include <stdio.h>
 #include <stdlib.h>
 
 namespace {
@@ -495,9 +496,8 @@ extern "C" int aldi_conv_wgrad(const aldi_wgrad_args* a, aldi_stream_t stream) {
     }
     d.ident = (a->KH == 1 && a->KW == 1 && a->stride == 1 && a->pad == 0 && a->Ho == a->H && a->Wo == a->W) ? 1 : 0;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    static const int lean_env = getenv("ALDI_WGRAD_LEAN") ? atoi(getenv("ALDI_WGRAD_LEAN")) : 1;
-    static const int big_min_env = getenv("ALDI_WGRAD_BIG_MIN") ? atoi(getenv("ALDI_WGRAD_BIG_MIN")) : 28;
-    static const int big_slots_env = getenv("ALDI_WGRAD_BIG_SLOTS") ? atoi(getenv("ALDI_WGRAD_BIG_SLOTS")) : 256;
+    const AldiTuning& tn = aldi_tuning();
+    const int lean_env = tn.wgrad_lean, big_min_env = tn.wgrad_big_min, big_slots_env = tn.wgrad_big_slots;
     const bool same = a->stride == 1 && a->Ho == a->H && a->Wo == a->W && 2 * a->pad == a->KH - 1 && a->KH == a->KW && a->Cin % 64 == 0;
     const bool lean = a->dtype == ALDI_BF16 && lean_env && (d.ident || same);
     const int bp = a->dtype == ALDI_BF16 ? 64 : 16;
@@ -511,7 +511,7 @@ extern "C" int aldi_conv_wgrad(const aldi_wgrad_args* a, aldi_stream_t stream) {
     }
     const int tile = big ? 256 : (a->dtype == ALDI_BF16 ? 128 : 64);
     int tiles = cdiv(d.Cout, tile) * cdiv(d.K, tile);
-    static const int slots_env_ = getenv("ALDI_WGRAD_SLOTS") ? atoi(getenv("ALDI_WGRAD_SLOTS")) : 384;
+    const int slots_env_ = tn.wgrad_slots;
     const int slots_env = big ? big_slots_env : slots_env_;
     // the kernel is bound per CU (L2 -> CU path, LDS), not by latency: few, long splits (1-2 workgroups per CU) beat
     // many short ones, whose 16K-atomic epilogues also contend on the same dW lines
@@ -523,14 +523,19 @@ extern "C" int aldi_conv_wgrad(const aldi_wgrad_args* a, aldi_stream_t stream) {
     d.pix_per_split = slabs_per * bp;
     splits = cdiv(d.M, d.pix_per_split);
     dim3 grid(cdiv(d.Cout, tile), cdiv(d.K, tile), splits);
-    static const int xcd_env = getenv("ALDI_WGRAD_XCD") ? atoi(getenv("ALDI_WGRAD_XCD")) : 1;
-    d.xcd = xcd_env;
-    if (big) hipLaunchKernelGGL(wgrad_bf16_big_kernel, grid, dim3(512), 0, st, d);
-    else if (lean) hipLaunchKernelGGL(wgrad_bf16_lean_kernel, grid, dim3(256), 0, st, d);
-    else if (a->dtype == ALDI_BF16) hipLaunchKernelGGL(wgrad_bf16_kernel, grid, dim3(256), 0, st, d);
-    else if (a->dtype == ALDI_F32) hipLaunchKernelGGL(wgrad_f32_kernel, grid, dim3(256), 0, st, d);
+    d.xcd = tn.wgrad_xcd;
+    const char* which;
+    if (big) { hipLaunchKernelGGL(wgrad_bf16_big_kernel, grid, dim3(512), 0, st, d); which = "wgrad_bf16_big"; }
+    else if (lean) { hipLaunchKernelGGL(wgrad_bf16_lean_kernel, grid, dim3(256), 0, st, d); which = "wgrad_bf16_lean"; }
+    else if (a->dtype == ALDI_BF16) { hipLaunchKernelGGL(wgrad_bf16_kernel, grid, dim3(256), 0, st, d); which = "wgrad_bf16_generic"; }
+    else if (a->dtype == ALDI_F32) { hipLaunchKernelGGL(wgrad_f32_kernel, grid, dim3(256), 0, st, d); which = "wgrad_f32"; }
     else return aldi_set_error_msg(ALDI_ERR_ARG, "conv_wgrad: bad dtype");
     ALDI_CHECK_LAUNCH();
+    {
+        char name[96];
+        snprintf(name, sizeof(name), "%s splits=%d", which, splits);
+        aldi_note_dispatch(name);
+    }
     return ALDI_OK;
 }
 
@@ -541,10 +546,8 @@ extern "C" int aldi_bias_grad(const void* g, float* db, int M, int C, int dtype,
     if (C % ep) return aldi_set_error_msg(ALDI_ERR_ARG, "bias_grad: C must be a multiple of a 16-B chunk");
     // enough workgroups to keep every CU's memory pipeline busy (the old 64-row floor left 1 workgroup per CU on a 16800-row
     // matrix), bounded below so that the per-workgroup LDS reduction + C atomics stay a small part of the work
-    static const int target_blocks = getenv("ALDI_COLSUM_BLOCKS") ? atoi(getenv("ALDI_COLSUM_BLOCKS")) : 256;
-    static const int min_rows = getenv("ALDI_COLSUM_MINROWS") ? atoi(getenv("ALDI_COLSUM_MINROWS")) : 16;
-    static const int nt_env = getenv("ALDI_COLSUM_NT") ? atoi(getenv("ALDI_COLSUM_NT")) : 1024;
-    static const int block_kb = getenv("ALDI_COLSUM_BLOCK_KB") ? atoi(getenv("ALDI_COLSUM_BLOCK_KB")) : 384;
+    const AldiTuning& tn = aldi_tuning();
+    const int target_blocks = tn.colsum_blocks, min_rows = tn.colsum_minrows, nt_env = tn.colsum_nt, block_kb = tn.colsum_block_kb;
     const long row_bytes = (long)C * (dtype == ALDI_BF16 ? 2 : 4);
     int rows_per_block = cdiv(M, target_blocks);
     const int by_bytes = (int)(((long)block_kb << 10) / row_bytes);

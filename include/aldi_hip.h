@@ -30,6 +30,29 @@ enum { ALDI_OK = 0, ALDI_ERR_HIP = -1, ALDI_ERR_ARG = -2 };
 const char* aldi_last_error(void);
 int aldi_version(void);
 
+/* Tuning knobs of the kernel dispatchers (test / experiment surface; the defaults are what the benchmark runs).
+ * Each knob can also be preset from the environment as ALDI_<UPPER-CASE NAME>, read once at first use.
+ *   igemm_force          0 heuristics | 1 128x128 | 2 128x64 | 3 64x64 | 4 256x128 | 5 128x16 tile of aldi_conv_igemm
+ *   igemm_halo           1 = 3x3/stride-1/pad-1 bf16 convs use the halo form (one pixel slab per three taps)
+ *   igemm_bigtile_min    128x128-tile count from which a 3x3 conv takes the 256x128 halo tile (1024)
+ *   igemm_lintile_min, igemm_bigtile_k   tile count / K from which a 1x1 conv or linear takes the 256x128 tile (768, 768)
+ *   igemm_tile           9 = never use the 256x128 tile for 1x1 / linear
+ *   igemm_xcd            1 = XCD-aware workgroup -> tile order
+ *   igemm_dbg            ablation bits (4 skip epilogue, 8 one K slab, 16 L1-resident loads): results are WRONG when set
+ *   wgrad_lean           1 = lean bf16 weight-gradient kernel for 1x1 and "same" KxK convs (0: generic gather kernel)
+ *   wgrad_big_min        slabs (64 pixels) per workgroup from which the 256x256 tile is used (28; 0 = never)
+ *   wgrad_big_slots, wgrad_slots   target workgroup counts of the 256x256 / 128x128 forms (256, 384)
+ *   wgrad_xcd            1 = XCD-aware order
+ *   colsum_blocks, colsum_minrows, colsum_nt, colsum_block_kb   aldi_bias_grad launch geometry
+ *   stem_mfma            1 = MFMA stem kernel in bf16 mode
+ *   sab_blocks, ln_bwd_blocks, ln_bwd_blocks_narrow   ConvNeXt scale-and-bias / LayerNorm backward launch geometry
+ * aldi_last_dispatch(): name of the kernel variant chosen by the most recent aldi_conv_igemm / aldi_conv_wgrad call on
+ * this thread, e.g. "igemm<bf16,256,128,4,2,flat,halo>" or "wgrad_bf16_big splits=4" (valid until the next call). */
+int aldi_set_tuning(const char* name, int value);
+int aldi_get_tuning(const char* name, int* value);
+int aldi_reset_tuning(void);
+const char* aldi_last_dispatch(void);
+
 /* ---------------------------------------------------------------------------------------
  * Dense path: convolution / linear as implicit GEMM on MFMA.
  * Replaces: cuDNN/MIOpen conv2d + FrozenBN affine + ReLU + residual add and torch Linear

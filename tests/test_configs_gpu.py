@@ -1,0 +1,204 @@
+"""BASELINE.json configs[0] (Base-RCNN-FPN.yaml, R50 source-only, K = 80, 800x800) end to end, and the
+benchmark configuration (configs[1], 1333x800, 2 + 2 images) in the benchmark dtype against the same step in
+the fp32 parity mode (VERDICT r01 missing #3, next #1).
+
+Reference path: aldi/trainer.py:28-117 with DATASETS.BATCH_CONTENTS = ("labeled_weak",) (the default of
+aldi/config.py:12, not overridden by configs/Base-RCNN-FPN.yaml), EMA / distillation / alignment off."""
+import os
+import random
+import subprocess
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module", autouse=True)
+def oracle_lib():
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle")], stdout=subprocess.DEVNULL)
+
+
+def _cfg1(h, w, bf16, lr=0.002):
+    from aldi_amd.config import add_aldi_config, get_cfg
+    cfg = get_cfg()
+    add_aldi_config(cfg)
+    cfg.merge_from_file(os.path.join(ROOT, "configs", "Base-RCNN-FPN.yaml"))
+    cfg.merge_from_list(["SOLVER.IMS_PER_BATCH", 2, "SOLVER.AMP.ENABLED", bf16, "SOLVER.BASE_LR", lr, "SOLVER.WARMUP_ITERS", 0, "SEED", 1,
+                         "SYNTHETIC.HEIGHT", h, "SYNTHETIC.WIDTH", w])
+    return cfg
+
+
+def test_cfg1_is_source_only_k80():
+    cfg = _cfg1(800, 800, True)
+    assert cfg.MODEL.ROI_HEADS.NUM_CLASSES == 80 and tuple(cfg.DATASETS.BATCH_CONTENTS) == ("labeled_weak",)
+    assert not cfg.EMA.ENABLED and not cfg.DOMAIN_ADAPT.TEACHER.ENABLED
+
+
+def test_cfg1_iterations_vs_oracle_fp32():
+    """two source-only iterations (K = 80) at a size the oracle finishes in seconds: loss dict (keys, order, values to
+    1e-3), sampled ROI indices bit-exact, SGD update."""
+    from aldi_amd import synthetic as syn
+    from aldi_amd.trainer import ALDITrainer
+    from oracle import aldi_ops as ao
+    from oracle import d2_rcnn as d2
+    K, H, W = 80, 160, 160
+    cfg = _cfg1(H, W, False)
+    random.seed(0)
+    torch.manual_seed(21)
+    tr = ALDITrainer(cfg)
+    assert tr.ema is None or not cfg.EMA.ENABLED
+    lay = tr.model.layout
+    off = dict(do_hard_cls=False, do_hard_obj=False, do_hard_rpn_reg=False, do_hard_roi_reg=False, do_cls_dst=False, do_obj_dst=False,
+               do_rpn_reg_dst=False, do_roih_reg_dst=False, cls_temperature=1.0, obj_temperature=1.0, cls_loss_type="CE")
+    orc = ao.OracleALDI(d2.make_cfg(num_classes=K), syn.init_state_dict(K, seed=1), lr=0.002, ims_per_gpu=2, backward_at_end=False, py_seed=0,
+                        distill=off)
+    loader = iter(ALDITrainer.build_train_loader(cfg))
+    hip_idx, hip_props = [], []
+    mfwd = type(tr.model).forward
+
+    def fwd(self, *a, **kw):
+        out = mfwd(self, *a, **kw)
+        c_ = self._last.ctx
+        hip_idx.append(c_.r_idx[: c_.R].cpu())
+        hip_props.append([{"proposal_boxes": c_.props[i, :n].cpu(), "objectness_logits": c_.prop_scores[i, :n].cpu(), "image_size": c_.sizes[i]}
+                          for i, n in enumerate(c_.prop_count.tolist())])
+        return out
+    type(tr.model).forward = fwd
+    try:
+        for it in range(2):
+            hip_idx.clear()
+            hip_props.clear()
+            s_sd = tr.model.state_dict()
+            mflat = torch.zeros(lay.n_total)
+            mflat[: lay.n_train] = tr.model.weights.mom.cpu()
+            mom = lay.unpack(mflat)
+            rng = torch.get_rng_state()
+            tr.iter = it
+            tr.before_step()
+            tr.run_step()
+            tr.after_step()
+            torch.cuda.synchronize()
+            hip = {k: float(v) for k, v in tr._trainer.last_loss_dict.items()}
+            orc.sd = {k: v.clone() for k, v in s_sd.items()}
+            for k in orc.train_keys:
+                orc.sd[k].requires_grad_(True)
+            orc.bufs = {k: mom[k].clone() for k in orc.train_keys} if it > 0 else {}
+            orc.iter = it
+            orc.proposal_override = [list(p_) for p_ in hip_props]
+            torch.set_rng_state(rng)
+            ref = orc.step(*next(loader))
+            assert list(ref.keys()) == list(hip.keys()) == ["loss_cls_source_weak", "loss_box_reg_source_weak", "loss_rpn_cls_source_weak",
+                                                            "loss_rpn_loc_source_weak"]
+            oidx = torch.cat([s_["sampled_idxs"] for s_ in orc.last["student_cap"]["sampled"]]).to(torch.int32)
+            assert torch.equal(hip_idx[0], oidx)
+            for k in ref:
+                assert abs(ref[k] - hip[k]) < 1e-3 * max(1.0, abs(ref[k])), (it, k, ref[k], hip[k])
+            hs = tr.model.state_dict()
+            for k in ("roi_heads.box_predictor.cls_score.weight", "roi_heads.box_predictor.bbox_pred.weight", "backbone.fpn_output2.weight",
+                      "backbone.bottom_up.res4.2.conv1.weight"):
+                upd = (orc.sd[k].detach() - s_sd[k]).abs().max()
+                assert (hs[k] - orc.sd[k].detach()).abs().max() <= 2e-2 * float(upd) + 1e-9, (it, k)
+    finally:
+        type(tr.model).forward = mfwd
+    assert int(tr.model.engine.err) == 0
+
+
+def test_cfg1_fullsize_bf16_properties():
+    """800x800, K = 80, 2 images, benchmark dtype: three iterations through the default dispatch; size-independent properties."""
+    from aldi_amd.trainer import ALDITrainer
+    cfg = _cfg1(800, 800, True, lr=1e-4)
+    random.seed(0)
+    torch.manual_seed(2)
+    tr = ALDITrainer(cfg)
+    w0 = tr.model.weights.master.clone()
+    for it in range(3):
+        tr.iter = it
+        tr.before_step()
+        tr.run_step()
+        tr.after_step()
+    torch.cuda.synchronize()
+    c = tr.model._last.ctx
+    assert [tuple(p.shape[1:3]) for p in c.P] == [(200, 200), (100, 100), (50, 50), (25, 25), (13, 13)]
+    assert c.anchors.shape[0] == 159882                                     # anchors per image of cfg 1
+    assert c.R == 1024 and c.rows == [512, 512]
+    lab = c.rpn_labels
+    for n in range(2):
+        npos, nneg = int((lab[n] == 1).sum()), int((lab[n] == 0).sum())
+        assert npos <= 128 and npos + nneg == 256
+        cls = c.r_cls[n * 512:(n + 1) * 512]
+        assert int((cls < 80).sum()) <= 128 and bool(((cls >= 0) & (cls <= 80)).all())
+    ld = {k: float(v) for k, v in tr._trainer.last_loss_dict.items()}
+    assert all(v == v and 0.0 <= v < 1e3 for v in ld.values()), ld
+    assert 3.0 < ld["loss_cls_source_weak"] < 6.0                           # ~log(81) with random-init heads
+    lay = tr.model.layout
+    w1 = tr.model.weights.master
+    assert torch.isfinite(w1).all()
+    assert not torch.equal(w1[: lay.n_train], w0[: lay.n_train]) and torch.equal(w1[lay.n_train:], w0[lay.n_train:])   # frozen part untouched
+    assert int(tr.model.engine.err) == 0
+
+
+def _bench_trainer(bf16, fused=True):
+    from aldi_amd.config import add_aldi_config, get_cfg
+    from aldi_amd.trainer import ALDITrainer
+    cfg = get_cfg()
+    add_aldi_config(cfg)
+    cfg.merge_from_file(os.path.join(ROOT, "configs", "cityscapes", "ALDI-Best-Cityscapes.yaml"))
+    cfg.merge_from_list(["SOLVER.IMS_PER_BATCH", 4, "SEED", 1, "SYNTHETIC.HEIGHT", 800, "SYNTHETIC.WIDTH", 1333, "SOLVER.BASE_LR", 1e-4,
+                         "SOLVER.AMP.ENABLED", bf16])
+    cfg.SOLVER.FUSED_STEP = fused
+    random.seed(1234)
+    torch.manual_seed(100)
+    return ALDITrainer(cfg)
+
+
+def test_benchmark_step_bf16_vs_fp32_parity_mode():
+    """The benchmark step itself (configs[1]: 1333x800, 2 labeled + 2 unlabeled, fused schedule, default dispatch = the
+    256x128 halo igemm, the long-K tiles and the 256x256 wgrad) in bf16 against the SAME step in the fp32 parity mode,
+    whose kernels are the ones held to 1e-3 against the oracle.  Identical weights, inputs and RNG stream:
+      * the source chunk's sampled anchor labels are identical (they depend on GT and RNG only);
+      * every loss agrees within the bf16 bound; the ROI counts agree;
+      * the weight gradients agree in direction (cosine) layer group by layer group."""
+    from aldi_amd import synthetic as syn
+    out = {}
+    for name, bf16 in (("fp32", False), ("bf16", True)):
+        tr = _bench_trainer(bf16)
+        data = syn.make_batch(2, 2, 800, 1333, 8, seed=100)
+        random.seed(77)
+        torch.manual_seed(5)
+        tr.iter = 0
+        tr.before_step()
+        t = tr._trainer
+        t.optimizer.zero_grad()
+        ld = t.run_model(tuple(None if p is None else [dict(d) for d in p] for p in data))
+        torch.cuda.synchronize()
+        c = tr.model._last_fused
+        out[name] = dict(losses={k: float(v) for k, v in ld.items()}, labels=c.rpn_labels[:2].cpu(), R=c.R, rows=list(c.rows),
+                         grad=tr.model.weights.grad.clone(), layout=tr.model.layout,
+                         pl=tr.ema.model._last_inference.pseudo["count"].tolist(), err=int(tr.model.engine.err) | int(tr.ema.model.engine.err))
+        del tr
+        torch.cuda.empty_cache()
+    a, b = out["fp32"], out["bf16"]
+    assert a["err"] == 0 and b["err"] == 0
+    assert torch.equal(a["labels"], b["labels"])                          # source chunk: bit-identical anchor sampling
+    assert a["R"] == b["R"] == 2048 and a["rows"] == b["rows"]
+    assert list(a["losses"]) == list(b["losses"])
+    for k in a["losses"]:
+        x, y = a["losses"][k], b["losses"][k]
+        assert abs(x - y) <= 0.08 * max(1.0, abs(x)), (k, x, y)           # the bf16 bound of tests/test_engine_gpu.py
+    assert all(abs(p - q) <= 2 for p, q in zip(a["pl"], b["pl"])), (a["pl"], b["pl"])
+    lay = a["layout"]
+    groups = {"box head": ["roi_heads.box_head.fc1", "roi_heads.box_head.fc2", "box_pred"],
+              "rpn + fpn": ["proposal_generator.rpn_head.conv", "rpn_head_out"] + [f"backbone.fpn_output{l}" for l in (2, 3, 4, 5)] +
+                           [f"backbone.fpn_lateral{l}" for l in (2, 3, 4, 5)]}
+    for st in (3, 4, 5):
+        groups[f"res{st}"] = [n for n in lay.t if f".res{st}." in n]
+    for gname, names in groups.items():
+        ga = torch.cat([a["grad"][lo:hi] for lo, hi in lay.ranges(names)])
+        gb = torch.cat([b["grad"][lo:hi] for lo, hi in lay.ranges(names)])
+        assert torch.isfinite(gb).all()
+        cos = float((ga * gb).sum() / (ga.norm() * gb.norm() + 1e-30))
+        # the ROI samples differ (proposals are discontinuous in the scores), so this is a statistical agreement, not a rounding bound
+        print("grad cosine bf16 vs fp32:", gname, round(cos, 4))
+        assert cos > 0.5, (gname, cos)
