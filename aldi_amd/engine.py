@@ -9,6 +9,7 @@ aldi/distill.py:157,162 and aldi/pseudolabeler.py:21, and autograd's backward at
 """
 from __future__ import annotations
 
+import inspect
 import math
 import os
 from collections import OrderedDict
@@ -979,8 +980,23 @@ class RCNN:
         cb = getattr(self, "grad_ready", None)
         if cb is None:
             return
-        self._join_wgrads()
-        cb(self.wts.layout.ranges(names))
+        # Producer events instead of a join: the gradient exchange waits for the weight-gradient stream and for this point of
+        # the main stream, the main stream itself keeps running beside the side stream (a join at each of the six reports
+        # serialised the dgrad chain behind the wgrad kernels, i.e. removed the overlap the 1-GPU step relies on).
+        evs = []
+        side = getattr(self, "_wg_side", None)
+        if side is not None and self._wgrad_pending:
+            ev = torch.cuda.Event()
+            ev.record(side)
+            evs.append(ev)
+        ev = torch.cuda.Event()
+        ev.record()
+        evs.append(ev)
+        if len(inspect.signature(cb).parameters) >= 2:
+            cb(self.wts.layout.ranges(names), evs)
+        else:                                               # a plain callback(ranges): stream-ordered after everything
+            self._join_wgrads()
+            cb(self.wts.layout.ranges(names))
 
     def _wgrad(self, name: str, x: torch.Tensor, g: torch.Tensor):
         """weight (+ bias) gradient of one layer.  The data-gradient chain never reads these results, so they run on a

@@ -42,18 +42,46 @@ class BucketedReducer:
 
     MIN_ELEMS = 1 << 18          # pieces smaller than 1 MB wait for the next report / finish(): latency-bound collectives
 
+    _LAUNCH_STREAMS = {}
+
     def __init__(self, grad: torch.Tensor, group=None):
         self.grad, self.group = grad, group
         self.done: List[Tuple[int, int]] = []
         self.pending: List[Tuple[int, int]] = []
         self.works = []
+        self.events = []                 # producer events of the pieces not launched yet
+        # Collectives are issued from a stream of their own that waits only on the PRODUCERS' events (the weight-gradient
+        # side stream and the point of the main stream where the group was reported): the main stream never joins the
+        # side stream in the middle of the backward, so the dgrad chain and the wgrad kernels keep overlapping under DP.
+        self.launch_stream = None
+        if grad.is_cuda:
+            key = str(grad.device)
+            if key not in BucketedReducer._LAUNCH_STREAMS:
+                BucketedReducer._LAUNCH_STREAMS[key] = torch.cuda.Stream(device=grad.device)
+            self.launch_stream = BucketedReducer._LAUNCH_STREAMS[key]
 
     def _launch(self, lo: int, hi: int):
-        self.works.append(dist.all_reduce(self.grad[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        if self.launch_stream is not None:
+            for ev in self.events:
+                self.launch_stream.wait_event(ev)
+            with torch.cuda.stream(self.launch_stream):
+                w = dist.all_reduce(self.grad[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        else:
+            w = dist.all_reduce(self.grad[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        self.works.append(w)
         self.done.append((lo, hi))
 
-    def ready(self, ranges: Sequence[Tuple[int, int]]):
-        """`ranges` (element offsets into the flat gradient) will not be written again in this step."""
+    def ready(self, ranges: Sequence[Tuple[int, int]], events=()):
+        """`ranges` (element offsets into the flat gradient) will not be written again in this step once `events`
+        (recorded on the streams that produce them) have completed.  Without events the collective orders itself after
+        the work enqueued so far on the current stream."""
+        if self.launch_stream is not None:
+            if events:
+                self.events += list(events)
+            else:
+                ev = torch.cuda.Event()
+                ev.record()
+                self.events.append(ev)
         self.pending = merge_ranges(list(self.pending) + list(ranges))
         keep = []
         for lo, hi in self.pending:
@@ -65,8 +93,14 @@ class BucketedReducer:
 
     def finish(self):
         """reduce everything not reduced yet, then make the current stream wait for every collective."""
+        if self.launch_stream is not None:
+            ev = torch.cuda.Event()
+            ev.record()                                  # everything the step has enqueued on the current stream
+            self.events.append(ev)
         for lo, hi in complement(self.done, self.grad.numel()):
             self._launch(lo, hi)
         for w in self.works:
             w.wait()
-        self.done, self.pending, self.works = [], [], []
+        if self.launch_stream is not None:
+            torch.cuda.current_stream().wait_stream(self.launch_stream)
+        self.done, self.pending, self.works, self.events = [], [], [], []

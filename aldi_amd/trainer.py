@@ -1,14 +1,16 @@
-"""ALDITrainer and the step driver, with the reference's names and control flow
-(aldi/trainer.py:28-246, aldi/dropin.py:29-184).  ``run_model_labeled_unlabeled`` is the same
-schedule -- source weak/strong, target-weak alignment, distillation, loss-dict keys and 1/accum
-scaling -- driving the HIP engine through the model / distiller plugin objects."""
+"""ALDITrainer and the step drivers behind the reference's names (aldi/trainer.py:28-246,
+aldi/dropin.py:29-184).  The iteration's schedule -- source weak/strong, target-weak alignment,
+distillation, loss-key suffixes, 1/accum scaling -- is a table (``plan_micro_steps``) executed either
+chunk by chunk (``run_model_labeled_unlabeled``, the reference's order) or as one fused student pass
+(``fused_run_model``) on the HIP engine."""
 from __future__ import annotations
 
+import copy
 import logging
 import os
 import time
 import weakref
-from typing import Dict
+from typing import Callable, Dict, List, NamedTuple, Optional
 
 from collections import OrderedDict
 
@@ -25,59 +27,73 @@ DEBUG = False
 debug_dict = {}
 
 
-def run_model_labeled_unlabeled(trainer, labeled_weak, labeled_strong, unlabeled_weak, unlabeled_strong):
-    """Mean-Teacher style iteration; see reference aldi/trainer.py:28-117 for the contract."""
-    model = trainer.model
-    backward_at_end = trainer.backward_at_end
-    model_batch_size = trainer.model_batch_size
+class MicroStep(NamedTuple):
+    """One row of the iteration's schedule: which batch goes through the student (or through the distiller together with
+    the teacher's batch), with which forward flags, under which loss-key suffix, and which of its losses count."""
+    name: str                                   # loss-key suffix
+    data: Optional[list]                        # student inputs
+    teacher_data: Optional[list]                # set => the distiller runs this row (teacher inputs = weak views)
+    kwargs: dict                                # forward flags of model(...)
+    keep: Callable[[str], bool]                 # losses that contribute (the others are multiplied by 0 / not reported)
 
-    _model = model.module if hasattr(model, "module") else model
-    do_weak = labeled_weak is not None
-    do_strong = labeled_strong is not None
-    do_align = any([getattr(_model, a, None) is not None for a in ["img_align", "ins_align"]])
-    do_distill = trainer.distiller.distill_enabled()
 
-    total_batch_size = sum([len(s or []) for s in [labeled_weak, labeled_strong, unlabeled_weak]])
-    num_grad_accum_steps = total_batch_size // model_batch_size
-
-    loss_dict = {}
-
-    def add_to_loss_dict(losses, suffix, key_conditional=lambda k: True):
-        for k, v in losses.items():
-            if key_conditional(k):
-                v = v / num_grad_accum_steps
-                if not backward_at_end:
-                    v = v.detach()
-                loss_dict[f"{k}_{suffix}"] = loss_dict.get(f"{k}_{suffix}", 0) + v
-
-    def maybe_do_backward(losses, key_conditional=lambda k: True):
-        if not backward_at_end:
-            losses = {k: v * 0 if not key_conditional(k) else v for k, v in losses.items()}
-            trainer.do_backward(sum(losses.values()) / num_grad_accum_steps, override=True)
-
-    def do_training_step(data, name="", key_conditional=lambda k: True, **kwargs):
-        for batch_i in range(0, len(data), model_batch_size):
-            loss = model(data[batch_i:batch_i + model_batch_size], **kwargs)
-            maybe_do_backward(loss, key_conditional)
-            add_to_loss_dict(loss, name, key_conditional)
-
-    def do_distill_step(teacher_data, student_data, name="", key_conditional=lambda k: True, **kwargs):
-        assert len(teacher_data) == len(student_data), "Teacher and student data must be the same length."
-        for batch_i in range(0, len(teacher_data), model_batch_size):
-            distill_loss = trainer.distiller(teacher_data[batch_i:batch_i + model_batch_size],
-                                             student_data[batch_i:batch_i + model_batch_size])
-            maybe_do_backward(distill_loss, key_conditional)
-            add_to_loss_dict(distill_loss, name, key_conditional)
-
-    if do_weak:
-        do_training_step(labeled_weak, "source_weak", lambda k: do_weak or (do_align and "_da_" in k), do_align=do_align)
-    if do_strong:
-        do_training_step(labeled_strong, "source_strong", lambda k: do_strong or (do_align and "_da_" in k), do_align=do_align)
+def plan_micro_steps(labeled_weak, labeled_strong, unlabeled_weak, unlabeled_strong, *, do_align: bool, do_distill: bool) -> List[MicroStep]:
+    """The schedule of one Mean-Teacher iteration as data (contract: reference aldi/trainer.py:28-117):
+    labeled weak and strong views are plain supervised rows that keep every loss; with alignment on the unlabeled weak
+    views go through the student only for their "_da_" losses; with distillation on the distiller sees (weak, strong)
+    pairs and keeps everything it names.  Both drivers below -- the sequential one and the fused one -- execute this plan."""
+    everything = lambda k: True
+    plan: List[MicroStep] = []
+    if labeled_weak is not None:
+        plan.append(MicroStep("source_weak", labeled_weak, None, {"do_align": do_align}, everything))
+    if labeled_strong is not None:
+        plan.append(MicroStep("source_strong", labeled_strong, None, {"do_align": do_align}, everything))
     if do_align:
-        do_training_step(unlabeled_weak, "target_weak", lambda k: "_da_" in k, labeled=False, do_align=True)
+        plan.append(MicroStep("target_weak", unlabeled_weak, None, {"labeled": False, "do_align": True}, lambda k: "_da_" in k))
     if do_distill:
-        do_distill_step(unlabeled_weak, unlabeled_strong, "distill", lambda k: k != "_")
-    return loss_dict
+        plan.append(MicroStep("distill", unlabeled_strong, unlabeled_weak, {}, lambda k: k != "_"))
+    return plan
+
+
+def _schedule_flags(trainer):
+    core = getattr(trainer.model, "module", trainer.model)
+    do_align = any(getattr(core, a, None) is not None for a in ("img_align", "ins_align"))
+    return do_align, trainer.distiller.distill_enabled()
+
+
+def run_model_labeled_unlabeled(trainer, labeled_weak, labeled_strong, unlabeled_weak, unlabeled_strong):
+    """Sequential driver of the plan (the reference's schedule, aldi/trainer.py:28-117): IMS_PER_GPU-sized chunks one after
+    the other, each followed by its own backward unless BACKWARD_AT_END; every reported loss is divided by the number of
+    gradient-accumulation steps = (|labeled_weak| + |labeled_strong| + |unlabeled_weak|) // IMS_PER_GPU (unlabeled_strong is
+    not counted).  Returns {f"{loss}_{suffix}": 0-d tensor} (detached when the backward already ran)."""
+    do_align, do_distill = _schedule_flags(trainer)
+    plan = plan_micro_steps(labeled_weak, labeled_strong, unlabeled_weak, unlabeled_strong, do_align=do_align, do_distill=do_distill)
+    bs = trainer.model_batch_size
+    accum = sum(len(part or []) for part in (labeled_weak, labeled_strong, unlabeled_weak)) // bs
+    early = not trainer.backward_at_end
+    if DEBUG:
+        debug_dict.update(last_labeled_weak=copy.deepcopy(labeled_weak), last_labeled_strong=copy.deepcopy(labeled_strong),
+                          last_unlabeled_weak=copy.deepcopy(unlabeled_weak), last_unlabeled_strong=copy.deepcopy(unlabeled_strong))
+    metrics: Dict[str, torch.Tensor] = {}
+    for row in plan:
+        if row.teacher_data is not None:
+            assert len(row.teacher_data) == len(row.data), "Teacher and student data must be the same length."
+        for lo in range(0, len(row.data), bs):
+            chunk = row.data[lo:lo + bs]
+            if row.teacher_data is not None:
+                losses = trainer.distiller(row.teacher_data[lo:lo + bs], chunk)
+            else:
+                losses = trainer.model(chunk, **row.kwargs)
+            if early:               # non-contributing losses still enter the graph with weight 0 (every parameter gets a gradient)
+                trainer.do_backward(sum(v if row.keep(k) else v * 0 for k, v in losses.items()) / accum, override=True)
+            for k, v in losses.items():
+                if row.keep(k):
+                    key = f"{k}_{row.name}"
+                    v = v / accum
+                    metrics[key] = metrics.get(key, 0) + (v.detach() if early else v)
+    if DEBUG and do_distill:
+        debug_dict["last_pseudolabeled"] = copy.deepcopy(unlabeled_strong)
+    return metrics
 
 
 _TEACHER_STREAMS = {}
@@ -105,22 +121,20 @@ def fused_run_model(trainer, labeled_weak, labeled_strong, unlabeled_weak, unlab
     model, dist_ = trainer.model, trainer.distiller
     eng = model.engine
     bs = trainer.model_batch_size
-    do_align = any(getattr(model, a, None) is not None for a in ["img_align", "ins_align"])
-    do_distill = dist_.distill_enabled()
+    do_align, do_distill = _schedule_flags(trainer)
+    plan = plan_micro_steps(labeled_weak, labeled_strong, unlabeled_weak, unlabeled_strong, do_align=do_align, do_distill=do_distill)
     total = sum(len(s_ or []) for s_ in [labeled_weak, labeled_strong, unlabeled_weak])
     accum = total // bs
     has_disc = do_align
     da = model.cfg.DOMAIN_ADAPT.ALIGN
     da_w = (da.IMG_DA_WEIGHT, da.INS_DA_WEIGHT)
     fire_student = lambda: model.roi_heads.fire_pre()
-    specs, names = [], []
-    specs.append(dict(images=[d["image"] for d in labeled_strong], instances=[as_record(d["instances"]) for d in labeled_strong],
-                      labeled=True, do_align=do_align, da_weights=da_w, pre_roi=fire_student))
-    names.append("source_strong")
-    if do_align:
-        specs.append(dict(images=[d["image"] for d in unlabeled_weak], instances=[as_record(d["instances"]) for d in unlabeled_weak],
-                          labeled=False, do_align=True, da_weights=da_w, pre_roi=fire_student))
-        names.append("target_weak")
+    specs = []
+    for row in plan:
+        if row.teacher_data is None:                # supervised / alignment rows: one chunk of the fused student pass each
+            specs.append(dict(images=[d["image"] for d in row.data], instances=[as_record(d["instances"]) for d in row.data],
+                              labeled=row.kwargs.get("labeled", True), do_align=row.kwargs.get("do_align", False), da_weights=da_w,
+                              pre_roi=fire_student))
     tc = None
     if do_distill:
         if dist_.cls_loss_type not in ("CE", "KL"):
@@ -166,7 +180,6 @@ def fused_run_model(trainer, labeled_weak, labeled_strong, unlabeled_weak, unlab
                 t_out["pred"] = teacher.engine.box_head_on(st_["tc"], rois_t, r1 - r0)
         specs.append(dict(images=[d["image"] for d in unlabeled_strong], gt_lazy=teacher_gt, gt_wait=gt_wait, labeled=True, do_align=False,
                           pre_rpn=pre_rpn_distill, pre_roi=fire_student, post_rois=teacher_box_head))
-        names.append("distill")
     c = eng.forward_train_fused(specs)
     if do_distill:
         tc = st_["tc"]
@@ -178,10 +191,11 @@ def fused_run_model(trainer, labeled_weak, labeled_strong, unlabeled_weak, unlab
     loss_dict = {}
     scales = []
     entries = []
-    for ch, name in zip(c.chunks, names):
+    for ch, row in zip(c.chunks, plan):
+        name = row.name
         losses = eng.chunk_loss_dict(ch)
         sc = {}
-        if name == "distill":
+        if row.teacher_data is not None:
             hard = {"loss_cls": dist_.do_hard_cls, "loss_rpn_cls": dist_.do_hard_obj, "loss_rpn_loc": dist_.do_hard_rpn_reg,
                     "loss_box_reg": dist_.do_hard_roi_reg}
             n0, n1, r0, r1 = ch["n0"], ch["n1"], ch["r0"], ch["r1"]
@@ -203,18 +217,12 @@ def fused_run_model(trainer, labeled_weak, labeled_strong, unlabeled_weak, unlab
             for k, v in eng.chunk_distill_loss_dict(ch).items():
                 out[k] = v
                 sc[k] = 1.0 / accum
-            keep = lambda k: k != "_"
-        elif name == "target_weak":
-            out = losses
-            keep = lambda k: "_da_" in k
-            sc = {k: (1.0 / accum if "_da_" in k else 0.0) for k in losses}
         else:
             out = losses
-            keep = lambda k: True
-            sc = {k: 1.0 / accum for k in losses}
+            sc = {k: (1.0 / accum if row.keep(k) else 0.0) for k in losses}
         scales.append(sc)
         for k, v in out.items():
-            if keep(k):
+            if row.keep(k):
                 entries.append((f"{k}_{name}", v))
     # loss-dict arithmetic (`v * 0.0` masking, `/ accum`) for all entries in a handful of launches instead of two or three
     # 0-d kernels per entry (the host issues those at ~10 us apiece in the middle of the step)

@@ -181,10 +181,25 @@ def main():
     if args.workload != "r50_fpn":
         args.no_profile = args.no_cpu_baseline = True      # the roofline / CPU legs are defined for the headline workload
 
+    # One process per GPU.  Launched by torch.distributed.run the ranks are already there (WORLD_SIZE set); a plain
+    # `python bench.py --gpus N` spawns its own N ranks through the same launcher.  It never falls back to fewer GPUs.
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        shared = "ALDI_BENCH_DEVICE" in os.environ          # test hook: all ranks on one GPU (gloo)
+        if not shared and torch.cuda.device_count() < args.gpus:
+            sys.exit(f"bench.py: --gpus {args.gpus} but only {torch.cuda.device_count()} visible GPU(s)")
+        import socket
+        with socket.socket() as s_:
+            s_.bind(("127.0.0.1", 0))
+            port = s_.getsockname()[1]
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.exit(subprocess.call(cmd, env=env))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    if world != args.gpus:
+        sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}")
     # test hook: ALDI_BENCH_BACKEND=gloo ALDI_BENCH_DEVICE=0 runs all ranks on one GPU (exercises the N>1 code path on a 1-GPU box)
     backend = os.environ.get("ALDI_BENCH_BACKEND", "nccl")
     if "ALDI_BENCH_DEVICE" in os.environ:

@@ -108,6 +108,7 @@ def _count_collectives(n, reports):
     class Counting(BucketedReducer):
         def __init__(self, n_):
             self.n_, self.done, self.pending, self.works, self.sizes = n_, [], [], [], []
+            self.launch_stream, self.events = None, []
 
         def _launch(self, lo, hi):
             self.sizes.append(hi - lo)

@@ -1,0 +1,203 @@
+"""The real data-parallel step on 2 ranks (VERDICT r01 missing #2 / SURVEY 8(e) "test without a cluster"): two processes
+share cuda:0 and exchange gradients over gloo, each running `ALDITrainer` iterations with the fused schedule and the
+overlapped `BucketedReducer`.  Checked:
+  (a) identical student weights on both ranks after the steps;
+  (b) world = 2 with per-rank batches == world = 1 processing both ranks' batches and averaging the gradients (fp32 mode);
+  (c) the EMA teacher is bit-identical across ranks (it is never communicated: reference aldi/ema.py:19-27);
+and `bench.py --gpus N` launches its own ranks (and refuses to run on fewer GPUs than asked).
+
+Reference: DDP wrap aldi/dropin.py:53,84-85; per-rank loaders aldi/trainer.py:214-238."""
+import json
+import os
+import random
+import socket
+import subprocess
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+K, H, W = 8, 192, 256
+ITERS = 2
+
+
+def _cfg(world, align):
+    from aldi_amd.config import add_aldi_config, get_cfg
+    cfg = get_cfg()
+    add_aldi_config(cfg)
+    cfg.merge_from_file(os.path.join(ROOT, "configs", "cityscapes", "ALDI-Best-Cityscapes.yaml"))
+    cfg.merge_from_list(["SOLVER.IMS_PER_BATCH", 4 * world, "SOLVER.AMP.ENABLED", False, "SOLVER.BASE_LR", 0.002, "SOLVER.WARMUP_ITERS", 0,
+                         "SEED", 1, "EMA.ALPHA", 0.9, "SYNTHETIC.HEIGHT", H, "SYNTHETIC.WIDTH", W,
+                         "DOMAIN_ADAPT.ALIGN.IMG_DA_ENABLED", align, "DOMAIN_ADAPT.ALIGN.INS_DA_ENABLED", align])
+    cfg.SOLVER.FUSED_STEP = True
+    return cfg
+
+
+def _rank_data(rank, it):
+    from aldi_amd import synthetic as syn
+    return syn.make_batch(2, 2, H, W, K, seed=1000 * it + 31 * rank + 5)
+
+
+class _ListLoader:
+    def __init__(self, batches):
+        self.batches = batches
+
+    def __iter__(self):
+        return iter(self.batches)
+
+
+def _rank_main(rank, world, port, align, out_path):
+    """one rank of the 2-process run (executed via `python tests/test_dist_gpu.py rank ...`)"""
+    import torch.distributed as dist
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from aldi_amd.trainer import ALDITrainer
+    random.seed(1234)
+    torch.manual_seed(9)
+    tr = ALDITrainer(_cfg(world, align))
+    t = tr._trainer
+    t.data_loader = _ListLoader([_rank_data(rank, it) for it in range(ITERS)])
+    t._data_loader_iter_obj = None
+    random.seed(99)
+    torch.manual_seed(500 + rank)
+    fused, losses = [], []
+    for it in range(ITERS):
+        tr.iter = it
+        tr.before_step()
+        tr.run_step()
+        tr.after_step()
+        fused.append(bool(t._fused_done))
+        losses.append({k: float(v) for k, v in t.last_loss_dict.items()})
+    torch.cuda.synchronize()
+    torch.save(dict(student=tr.model.weights.master.cpu(), teacher=tr.ema.model.weights.master.cpu(), fused=fused, losses=losses,
+                    err=int(tr.model.engine.err) | int(tr.ema.model.engine.err)), out_path)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _run_two_ranks(tmp_path, align):
+    port = _free_port()
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    procs, outs = [], []
+    for r in range(2):
+        outs.append(str(tmp_path / f"rank{r}.pt"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), "rank", str(r), "2", str(port), str(int(align)), outs[-1]],
+                                      env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+    logs = []
+    for p in procs:
+        try:
+            o, _ = p.communicate(timeout=600)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        logs.append(o.decode(errors="replace")[-3000:])
+    assert all(p.returncode == 0 for p in procs), logs
+    return [torch.load(o) for o in outs]
+
+
+def _world1_emulation(align):
+    """ONE process: both ranks' batches through the same fused step, gradients accumulated and averaged, one SGD.  Each rank's
+    host RNG streams (python `random`, torch CPU generator, the distiller's ManualSeed) are kept separately and swapped in
+    around that rank's pass, exactly as the two processes own them."""
+    from aldi_amd.trainer import ALDITrainer
+    random.seed(1234)
+    torch.manual_seed(9)
+    tr = ALDITrainer(_cfg(1, align))
+    t = tr._trainer
+    seeder = t.distiller.seeder
+    st = []
+    for r in range(2):
+        random.seed(99)
+        torch.manual_seed(500 + r)
+        st.append(dict(py=random.getstate(), th=torch.get_rng_state(), seed=seeder.seed))
+    losses = []
+    for it in range(ITERS):
+        tr.iter = it
+        tr.before_step()                                  # EMA tick
+        t.optimizer.zero_grad()
+        per_rank = []
+        for r in range(2):
+            random.setstate(st[r]["py"])
+            torch.set_rng_state(st[r]["th"])
+            seeder.seed = st[r]["seed"]
+            ld = t.run_model(_rank_data(r, it))
+            assert t._fused_done
+            per_rank.append({k: float(v) for k, v in ld.items()})
+            st[r] = dict(py=random.getstate(), th=torch.get_rng_state(), seed=seeder.seed)
+        tr.model.weights.scale_grad(0.5)                  # mean over the two ranks
+        t.optimizer.step()
+        tr.after_step()
+        losses.append(per_rank)
+    torch.cuda.synchronize()
+    return tr.model.weights.master.cpu(), tr.ema.model.weights.master.cpu(), losses, tr.model.layout
+
+
+@pytest.mark.parametrize("align", [False, True])
+def test_two_ranks_equal_one_rank_with_both_batches(tmp_path, align):
+    res = _run_two_ranks(tmp_path, align)
+    assert all(r["err"] == 0 for r in res)
+    assert all(all(r["fused"]) for r in res), "the data-parallel step must take the fused + overlapped-exchange path"
+    # (a) identical weights on every rank, (c) identical teacher
+    assert torch.equal(res[0]["student"], res[1]["student"])
+    assert torch.equal(res[0]["teacher"], res[1]["teacher"])
+    # (b) == one rank that processes both batches and averages
+    w1, t1, losses1, lay = _world1_emulation(align)
+    for it in range(ITERS):
+        for r in range(2):
+            a, b = res[r]["losses"][it], losses1[it][r]
+            assert list(a) == list(b)
+            for k in a:
+                assert abs(a[k] - b[k]) <= 1e-5 * max(1.0, abs(b[k])), (it, r, k, a[k], b[k])
+    w2 = res[0]["student"]
+    n = lay.n_train
+    assert torch.equal(w2[n:], w1[n:])                                    # frozen part
+    d = (w2[:n] - w1[:n]).abs().max().item()
+    assert d <= 1e-6 * max(1.0, w1[:n].abs().max().item()), d             # fp32: atomics / summation order only
+    assert (res[0]["teacher"] - t1).abs().max().item() <= 1e-6 * max(1.0, t1.abs().max().item())
+    # and the step did move the weights
+    from aldi_amd.trainer import ALDITrainer
+    random.seed(1234)
+    torch.manual_seed(9)
+    w0 = ALDITrainer(_cfg(1, align)).model.weights.master.cpu()
+    assert (w2[:n] - w0[:n]).abs().max().item() > 1e-5
+
+
+def _bench(args, extra_env=None, timeout=900):
+    env = dict(os.environ, **(extra_env or {}))
+    env.pop("WORLD_SIZE", None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=timeout)
+    return p.returncode, p.stdout.decode(errors="replace")
+
+
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus 2` (no launcher) spawns 2 ranks; on this 1-GPU box they share cuda:0 over gloo through the test hook"""
+    rc, out = _bench(["--gpus", "2", "--steps", "2", "--warmup", "1", "--height", str(H), "--width", str(W), "--no-cpu-baseline", "--no-profile"],
+                     {"ALDI_BENCH_BACKEND": "gloo", "ALDI_BENCH_DEVICE": "0"})
+    assert rc == 0, out[-3000:]
+    line = [l for l in out.splitlines() if l.startswith("{") and '"metric"' in l]
+    assert len(line) == 1, out[-3000:]
+    j = json.loads(line[0])
+    assert j["n_gpus"] == 2 and j["config"]["global_batch"] == 8 and j["config"]["parallelism"] == "dp2" and j["scaling"] == "weak"
+    assert j["config"]["error_flag"] == 0 and j["value"] > 0
+
+
+def test_bench_refuses_fewer_gpus_than_asked():
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("needs a box with fewer GPUs than requested")
+    rc, out = _bench(["--gpus", "2", "--steps", "1", "--warmup", "0", "--height", str(H), "--width", str(W), "--no-cpu-baseline", "--no-profile"])
+    assert rc != 0 and '"metric"' not in out, out[-2000:]
+
+
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "rank":
+    _rank_main(int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), bool(int(sys.argv[5])), sys.argv[6])
