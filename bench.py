@@ -133,33 +133,142 @@ def profile_dense(trainer, step_fn, table_path=None):
     return out
 
 
+def _cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "?"
+
+
 def cpu_baseline(cfg, height, width):
-    """The oracle (CPU restatement, reference schedule) on a bounded sample: 1 labeled + 1 unlabeled image, 1 step."""
+    """The oracle (CPU restatement of the reference schedule: teacher trunk twice, state-dict EMA, fp32 torch-CPU) timed on
+    this box's host cores, on bounded samples (SURVEY 8(d) / BASELINE.md section 3): 1 warm-up + 3 timed steps with all
+    cores on the headline workload's images (1 labeled + 1 unlabeled per step), the same on cfg 1 (source-only, K = 80,
+    800x800), and a single-thread figure on a reduced image so that the default run stays within minutes."""
     from aldi_amd import synthetic as syn
     from oracle import aldi_ops as ao
     from oracle import d2_rcnn as d2
     subprocess.call(["make", "-C", os.path.join(ROOT, "oracle")], stdout=subprocess.DEVNULL)
-    cores = min(os.cpu_count() or 1, 32)     # torch-CPU conv stops scaling (and oversubscribes) beyond ~32 threads on this workload
-    torch.set_num_threads(cores)
+    ncpu = os.cpu_count() or 1
     K = cfg.MODEL.ROI_HEADS.NUM_CLASSES
+
+    def timed(orc, data, steps, warm):
+        torch.manual_seed(0)
+        for _ in range(warm):
+            orc.step(*syn.clone_batch(data))
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            orc.step(*syn.clone_batch(data))
+        return (time.perf_counter() - t0) / steps
+
+    def aldi_oracle(k):
+        return ao.OracleALDI(d2.make_cfg(num_classes=k), syn.init_state_dict(k, seed=1), ema_alpha=cfg.EMA.ALPHA, lr=1e-4, ims_per_gpu=1,
+                             backward_at_end=False, py_seed=0, threshold=cfg.DOMAIN_ADAPT.TEACHER.THRESHOLD)
+    # (1) headline workload, all cores
+    torch.set_num_threads(ncpu)
     data = syn.make_batch(1, 1, height, width, K, seed=5)
-    orc = ao.OracleALDI(d2.make_cfg(num_classes=K), syn.init_state_dict(K, seed=1), ema_alpha=cfg.EMA.ALPHA, lr=1e-3, ims_per_gpu=1,
-                        backward_at_end=False, py_seed=0, threshold=cfg.DOMAIN_ADAPT.TEACHER.THRESHOLD)
-    torch.manual_seed(0)
-    t0 = time.perf_counter()
-    orc.step(*data)
-    dt = time.perf_counter() - t0
-    model = "?"
+    dt = timed(aldi_oracle(K), data, 3, 1)
+    out = {"value": round(2.0 / dt, 4), "unit": "images/sec", "cores": ncpu, "kind": "port", "cpu_model": _cpu_model(),
+           "sample": f"ALDI steps of 1 labeled + 1 unlabeled {width}x{height} image (reference schedule: teacher trunk twice, state-dict "
+                     f"EMA), fp32 torch-CPU oracle, {ncpu} threads, 1 warm-up + 3 timed steps, {dt:.2f} s/step"}
+    # (2) cfg 1: Base-RCNN-FPN.yaml source-only, K = 80, 2 images of 800x800
+    off = dict(do_hard_cls=False, do_hard_obj=False, do_hard_rpn_reg=False, do_hard_roi_reg=False, do_cls_dst=False, do_obj_dst=False,
+               do_rpn_reg_dst=False, do_roih_reg_dst=False, cls_temperature=1.0, obj_temperature=1.0, cls_loss_type="CE")
+    orc1 = ao.OracleALDI(d2.make_cfg(num_classes=80), syn.init_state_dict(80, seed=1), lr=1e-4, ims_per_gpu=2, backward_at_end=False, py_seed=0, distill=off)
+    d1 = syn.make_batch(2, 0, 800, 800, 80, seed=6)
+    d1 = (d1[1], None, None, None)                       # BATCH_CONTENTS = ("labeled_weak",)
+    dt1 = timed(orc1, d1, 3, 1)
+    out["cfg1"] = {"value": round(2.0 / dt1, 4), "unit": "images/sec", "cores": ncpu,
+                   "sample": f"configs[0]: source-only R50-FPN, K=80, 2 images 800x800 per step, 1 warm-up + 3 timed steps, {dt1:.2f} s/step"}
+    # (3) one thread, reduced image (a full-size single-thread step takes minutes)
+    torch.set_num_threads(1)
+    hs, ws = 320, 512
+    dts = timed(aldi_oracle(K), syn.make_batch(1, 1, hs, ws, K, seed=5), 1, 0)
+    out["single_thread"] = {"value": round(2.0 / dts, 4), "unit": "images/sec", "cores": 1,
+                            "sample": f"1 ALDI step of 1 labeled + 1 unlabeled {ws}x{hs} image ({hs * ws / (height * width):.3f} of the headline "
+                                      f"pixels per image), 1 thread, {dts:.2f} s/step"}
+    torch.set_num_threads(1)
+    return out
+
+
+def profile_insitu(step_fn, table_path=None):
+    """One step with a HIP-event pair around EVERY dense launch, recorded on the stream the kernel is launched on (the
+    engine runs three streams: torch's current stream at the call IS the launch stream).  Durations are what the kernel
+    took inside the real step -- other streams' kernels sharing the chip included -- not warm back-to-back replays.
+    -> per-family {launches, flops, ms, bytes}."""
+    from aldi_amd import ops
+    rec = []
+    orig_conv, orig_wg = ops.conv2d, ops.conv_wgrad
+
+    def conv2d(x, w, **kw):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        y = orig_conv(x, w, **kw)
+        e1.record()
+        N, H, W_, Cin = x.shape
+        Cout, KH, KW, _ = w.shape
+        s, p = kw.get("stride", 1), kw.get("pad", 0)
+        Ho, Wo = (H + 2 * p - KH) // s + 1, (W_ + 2 * p - KW) // s + 1
+        key = ("igemm", N, H, W_, Cin, Cout, KH, s, p, kw.get("res_mode", 0), bool(kw.get("relu")), kw.get("mask") is not None,
+               kw.get("out_scale", 1), bool(kw.get("want_f32")))
+        esz = x.element_size()
+        osz = 4 if kw.get("want_f32") else esz
+        nby = esz * (x.numel() + w.numel()) + osz * N * Ho * Wo * Cout \
+            + (esz * N * Ho * Wo * Cout if kw.get("mask") is not None else 0) \
+            + (esz * N * Ho * Wo * Cout // (4 if kw.get("res_mode", 0) == 2 else 1) if kw.get("res_mode", 0) else 0)
+        rec.append((key, 2.0 * N * Ho * Wo * Cout * KH * KW * Cin, nby, e0, e1))
+        return y
+
+    def conv_wgrad(x, g, dw, **kw):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        orig_wg(x, g, dw, **kw)
+        e1.record()
+        key = ("wgrad",) + tuple(x.shape) + (g.shape[3], kw["KH"], kw.get("stride", 1), kw.get("pad", 0))
+        rec.append((key, 2.0 * g.numel() * kw["KH"] * kw["KW"] * x.shape[3], x.element_size() * (x.numel() + g.numel()) + 8 * dw.numel(), e0, e1))
+    ops.conv2d, ops.conv_wgrad = conv2d, conv_wgrad
     try:
-        for line in open("/proc/cpuinfo"):
-            if line.startswith("model name"):
-                model = line.split(":", 1)[1].strip()
-                break
-    except OSError:
-        pass
-    return {"value": round(2.0 / dt, 4), "unit": "images/sec", "cores": cores, "kind": "port", "cpu_model": model,
-            "sample": f"1 ALDI step of 1 labeled + 1 unlabeled {width}x{height} image, reference schedule "
-                      f"(teacher trunk twice, state-dict EMA), fp32 torch-CPU oracle, {dt:.1f}s"}
+        step_fn()
+        torch.cuda.synchronize()
+    finally:
+        ops.conv2d, ops.conv_wgrad = orig_conv, orig_wg
+    shapes, out = {}, {}
+    for fam in ("igemm", "wgrad"):
+        out[fam] = {"launches": 0, "flops": 0.0, "ms": 0.0, "bytes": 0}
+    for key, fl, nby, e0, e1 in rec:
+        us = e0.elapsed_time(e1) * 1e3
+        f = out[key[0]]
+        f["launches"] += 1; f["flops"] += fl; f["ms"] += us / 1e3; f["bytes"] += nby
+        e = shapes.setdefault(key, {"count": 0, "flops": fl, "us": 0.0})
+        e["count"] += 1; e["us"] += us
+    if table_path:
+        os.makedirs(os.path.dirname(table_path), exist_ok=True)
+        with open(table_path, "w") as f:
+            f.write("# dense launches of ONE ALDI step, timed in situ (HIP events on the launch stream around every launch)\n")
+            f.write("# family shape... | launches/step | mean us/launch | TFLOP/s | ms/step\n")
+            for key, e in sorted(shapes.items(), key=lambda kv: -kv[1]["us"]):
+                f.write("%-90s %4d %9.1f %8.1f %8.3f\n" % (str(key), e["count"], e["us"] / e["count"], e["flops"] * e["count"] / e["us"] / 1e6, e["us"] / 1e3))
+    return out
+
+
+def matching_traffic():
+    """HBM bytes per launch from the rocprofv3 PMC passes of this same command (tools/profile_step.sh), accepted only when the
+    counter file was produced from THIS source tree (tools/source_hash.py); otherwise None."""
+    import glob
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from source_hash import source_hash
+    here = source_hash(ROOT)
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")), reverse=True):
+        try:
+            j = json.load(open(f))
+        except (OSError, ValueError):
+            continue
+        if j.get("source_sha256") == here and "igemm" in j:
+            return j, os.path.relpath(f, ROOT)
+    return None, None
 
 
 def main():
@@ -174,6 +283,7 @@ def main():
     ap.add_argument("--sequential", action="store_true", help="reference-style sequential micro-steps instead of the fused student pass")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
+    ap.add_argument("--replay-profile", action="store_true", help="additionally replay every dense shape back-to-back (isolated per-shape table for tuning)")
     ap.add_argument("--workload", default="r50_fpn", choices=["r50_fpn", "vitdet_b", "convnext_l"],
                     help="r50_fpn = the headline configuration (default); vitdet_b = BASELINE cfg 4 (SURVEY 8(f) rank 1), reported beside it")
     args = ap.parse_args()
@@ -271,26 +381,28 @@ def main():
                       "pseudo_labels_per_image": pl_count, "schedule": "sequential micro-steps" if args.sequential else "fused source+target student pass", "weights": f"random-init {arch_name} (synthetic)", "error_flag": err},
            "final_losses": {k: round(v, 5) for k, v in losses.items()}}
     if rank == 0 and world == 1 and not args.no_profile:
-        prof = profile_dense(tr, one_step, os.path.join(ROOT, "gpurun_out", "dense_profile.txt"))
-        ig = prof["igemm"]
+        prof = profile_insitu(one_step, os.path.join(ROOT, "gpurun_out", "dense_profile_insitu.txt"))
+        if args.replay_profile:
+            profile_dense(tr, one_step, os.path.join(ROOT, "gpurun_out", "dense_profile.txt"))
+        ig, wg = prof["igemm"], prof["wgrad"]
         ach = ig["flops"] / (ig["ms"] * 1e-3) / 1e12 if ig["ms"] > 0 else 0.0
-        # HBM traffic cannot be read from inside the process: it comes from the separate rocprofv3 --pmc passes of this same
-        # command (tools/profile_step.sh; FETCH_SIZE x2 gfx950 correction + WRITE_SIZE), committed under profiles/.
-        traffic = None
-        try:
-            with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
-                traffic = round(json.load(f)["igemm"]["hbm_bytes_per_launch"])
-        except (OSError, KeyError, ValueError):
-            pass
+        tj, tfile = matching_traffic()
         out["roofline"] = {"bound": "mfma", "kernel": "igemm_kernel<bf16> (conv fwd + dgrad + FC)", "achieved": round(ach, 2), "peak": PEAK_BF16_TFLOPS,
-                           "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
-                           "traffic_unit": "HBM bytes per igemm launch (rocprofv3 PMC passes, profiles/r01_pmc_traffic.json)",
+                           "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4),
+                           "traffic": round(tj["igemm"]["hbm_bytes_per_launch"]) if tj else None,
+                           "traffic_unit": "HBM bytes per igemm launch, rocprofv3 PMC passes of this command (FETCH_SIZE x2 + WRITE_SIZE)",
+                           "traffic_source": tfile if tj else "no profiles/r*_pmc_traffic.json matches this source tree (tools/source_hash.py)",
+                           "timing": "HIP events on the launch stream around every launch of one in-situ step (three streams active)",
                            "algorithmic_bytes_per_launch": round(ig["bytes"] / max(ig["launches"], 1)),
                            "launches_per_step": ig["launches"], "kernel_ms_per_step": round(ig["ms"], 3),
                            "avg_launch_us": round(ig["ms"] * 1e3 / max(ig["launches"], 1), 2),
                            "algorithmic_tflop_per_step_in_kernel": round(ig["flops"] / 1e12, 3),
-                           "wgrad_kernel": {"tflops": round(prof["wgrad"]["flops"] / max(prof["wgrad"]["ms"], 1e-9) / 1e9, 2),
-                                            "ms_per_step": round(prof["wgrad"]["ms"], 3), "launches": prof["wgrad"]["launches"]},
+                           "wgrad_kernel": {"achieved": round(wg["flops"] / max(wg["ms"], 1e-9) / 1e9, 2), "unit": "TFLOP/s",
+                                            "frac": round(wg["flops"] / max(wg["ms"], 1e-9) / 1e9 / PEAK_BF16_TFLOPS, 4),
+                                            "kernel_ms_per_step": round(wg["ms"], 3), "launches_per_step": wg["launches"],
+                                            "avg_launch_us": round(wg["ms"] * 1e3 / max(wg["launches"], 1), 2),
+                                            "algorithmic_bytes_per_launch": round(wg["bytes"] / max(wg["launches"], 1)),
+                                            "traffic": round(tj["wgrad"]["hbm_bytes_per_launch"]) if tj and "wgrad" in tj else None},
                            "step_algorithmic_tflop": STEP_TFLOP_FUSED if not args.align else None,
                            "step_frac_of_mfma_peak": round(STEP_TFLOP_FUSED / (ms * 1e-3) / PEAK_BF16_TFLOPS, 4) if not args.align else None}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

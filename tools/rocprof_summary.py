@@ -138,7 +138,7 @@ def window(d, first="compact_kernel", last="wgrad_"):
         print("%8.1f us  +%6.1f us  %s" % ((s_ - t0) / 1e3, (e - s_) / 1e3, n[:110]))
 
 
-def pmc(fetch_dir, write_dir):
+def pmc(fetch_dir, write_dir, source_sha="", git_sha=""):
     res = {}
     for key, d, ctr in (("fetch", fetch_dir, "FETCH_SIZE"), ("write", write_dir, "WRITE_SIZE")):
         per = collections.defaultdict(list)
@@ -150,7 +150,7 @@ def pmc(fetch_dir, write_dir):
                 if k:
                     per[k].append(float(r["Counter_Value"]))
         res[key] = {k: (sum(v) / len(v), len(v)) for k, v in per.items()}
-    out = {}
+    out = {"source_sha256": source_sha, "git_sha": git_sha}
     for k in ("igemm", "wgrad"):
         f, nf = res["fetch"].get(k, (0, 0))
         w, nw = res["write"].get(k, (0, 0))
