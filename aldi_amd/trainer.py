@@ -255,21 +255,59 @@ class EngineSGD:
         g = self.param_groups[0]
         self.model.weights.sgd_step(g["lr"], g["momentum"], g["weight_decay"])
 
+    def state_dict(self):
+        """checkpointable (detectron2 saves the optimizer through `trainer._trainer.optimizer`): the flat momentum buffer"""
+        W = self.model.weights
+        return {"format": "aldi_amd.flat_sgd", "param_groups": [dict(g) for g in self.param_groups],
+                "momentum_buffer": None if W._mom is None else W.mom.detach().cpu().clone(), "first_step": bool(W.first_step)}
+
+    def load_state_dict(self, sd):
+        W = self.model.weights
+        if sd.get("format") != "aldi_amd.flat_sgd":
+            logging.getLogger(__name__).warning("optimizer state of a foreign format: momentum restarts from zero")
+            return
+        for g, h in zip(self.param_groups, sd.get("param_groups", [])):
+            g.update({k: v for k, v in h.items() if k in ("momentum", "weight_decay")})
+        if sd.get("momentum_buffer") is not None:
+            W.mom.copy_(sd["momentum_buffer"].to(W.mom.device))
+        W.first_step = bool(sd.get("first_step", sd.get("momentum_buffer") is None))
+
 
 class EngineAdamW:
-    """torch.optim.AdamW-shaped handle on the fused HIP AdamW of the ViTDet model (reference aldi/backbone.py:66-84: detectron2
-    common/optim.py AdamW -- betas (0.9, 0.999), weight_decay 0.1, none on the blocks' LayerNorms and on pos_embed; the
-    layer-wise lr decay is off by default there, and here)."""
-    def __init__(self, model, lr, weight_decay=0.1, betas=(0.9, 0.999)):
+    """torch.optim.AdamW-shaped handle on the fused HIP AdamW of the ViTDet / ConvNeXt models (reference aldi/backbone.py:66-84:
+    detectron2 common/optim.py AdamW -- betas (0.9, 0.999), weight_decay 0.1, none on the norms and on pos_embed).
+    `lr_decay_rate` = ViTDet's layer-wise lr decay, which the reference turns on exactly for build_vitdet_b_backbone
+    (aldi/trainer.py:204 -> get_vit_lr_decay_rate(num_layers=12, lr_decay_rate=0.7))."""
+    def __init__(self, model, lr, weight_decay=0.1, betas=(0.9, 0.999), lr_decay_rate=None, num_layers=12):
         self.model = model
         self.param_groups = [{"lr": lr, "weight_decay": weight_decay, "betas": betas}]
+        self.lr_decay_rate, self.num_layers = lr_decay_rate, num_layers
 
     def zero_grad(self, set_to_none: bool = False):
         self.model.weights.zero_grad()
 
     def step(self):
         g = self.param_groups[0]
-        self.model.weights.adamw_step(g["lr"], betas=g["betas"], weight_decay=g["weight_decay"])
+        kw = {}
+        if self.lr_decay_rate is not None:
+            kw = dict(lr_decay_rate=self.lr_decay_rate, num_layers=self.num_layers)
+        self.model.weights.adamw_step(g["lr"], betas=g["betas"], weight_decay=g["weight_decay"], **kw)
+
+    def state_dict(self):
+        W = self.model.weights
+        has = getattr(W, "_m", None) is not None
+        return {"format": "aldi_amd.flat_adamw", "param_groups": [dict(g) for g in self.param_groups], "step": int(getattr(W, "step_count", 0)),
+                "exp_avg": W._m.detach().cpu().clone() if has else None, "exp_avg_sq": W._v.detach().cpu().clone() if has else None}
+
+    def load_state_dict(self, sd):
+        W = self.model.weights
+        if sd.get("format") != "aldi_amd.flat_adamw":
+            logging.getLogger(__name__).warning("optimizer state of a foreign format: AdamW moments restart from zero")
+            return
+        if sd.get("exp_avg") is not None:
+            W._m = sd["exp_avg"].to(W.device).clone()
+            W._v = sd["exp_avg_sq"].to(W.device).clone()
+        W.step_count = int(sd.get("step", 0))
 
 
 class WarmupMultiStepLR:
@@ -292,6 +330,13 @@ class WarmupMultiStepLR:
 
     def step(self):
         self.last_iter += 1
+        self._apply()
+
+    def state_dict(self):
+        return {"last_epoch": self.last_iter}           # torch's scheduler key name
+
+    def load_state_dict(self, sd):
+        self.last_iter = int(sd["last_epoch"])
         self._apply()
 
 
@@ -448,15 +493,39 @@ class DefaultTrainer:
         return EngineSGD(model, cfg.SOLVER.BASE_LR, cfg.SOLVER.MOMENTUM, cfg.SOLVER.WEIGHT_DECAY)
 
     def _create_checkpointer(self, model, cfg, ckpt_cls=None):
+        """aldi/dropin.py:77-82: the trainer itself (iteration, LR-scheduler hook, optimizer) is a checkpointable"""
         from .checkpoint import DetectionCheckpointer
-        return (ckpt_cls or DetectionCheckpointer)(model, cfg.OUTPUT_DIR)
+        return (ckpt_cls or DetectionCheckpointer)(model, cfg.OUTPUT_DIR, trainer=weakref.proxy(self))
+
+    def state_dict(self):
+        """detectron2 TrainerBase / SimpleTrainer.state_dict layout"""
+        ret = {"iteration": self.iter, "hooks": {"LRScheduler": self.scheduler.state_dict()}}
+        opt = self._trainer.optimizer
+        if hasattr(opt, "state_dict"):
+            ret["_trainer"] = {"optimizer": opt.state_dict()}
+        return ret
+
+    def load_state_dict(self, sd):
+        self.iter = int(sd["iteration"])
+        sched = sd.get("hooks", {}).get("LRScheduler")
+        if sched is not None:
+            self.scheduler.load_state_dict(sched)
+        else:                                            # file without scheduler state: the schedule is a function of the iteration
+            self.scheduler.load_state_dict({"last_epoch": self.iter + 1})
+        opt = sd.get("_trainer", {}).get("optimizer")
+        if opt is not None and hasattr(self._trainer.optimizer, "load_state_dict"):
+            self._trainer.optimizer.load_state_dict(opt)
 
     def resume_or_load(self, resume=True):
-        """detectron2 DefaultTrainer.resume_or_load: last checkpoint of OUTPUT_DIR when resuming, else cfg.MODEL.WEIGHTS
-        (an empty string = keep the initial weights); the iteration counter continues after a resume."""
+        """detectron2 DefaultTrainer.resume_or_load: last checkpoint of OUTPUT_DIR when resuming (model, EMA, optimizer momentum,
+        LR schedule position and iteration continue), else cfg.MODEL.WEIGHTS (an empty string = keep the initial weights)."""
         ret = self.checkpointer.resume_or_load(self.cfg.MODEL.WEIGHTS, resume=resume)
         if resume and self.checkpointer.has_checkpoint():
-            self.start_iter = self.iter = int(ret.get("iteration", -1)) + 1
+            if "trainer" not in ret:                     # e.g. a file written by an evaluation-only tool
+                self.iter = int(ret.get("iteration", -1))
+                self.scheduler.load_state_dict({"last_epoch": self.iter + 1})
+            self.start_iter = self.iter + 1
+            self.iter = self.start_iter
         return ret
 
     @property
@@ -469,8 +538,19 @@ class DefaultTrainer:
     def run_step(self):
         self._trainer.run_step()
 
+    def _is_main_process(self):
+        return not (dist.is_available() and dist.is_initialized()) or dist.get_rank() == 0
+
     def after_step(self):
+        """LRScheduler hook, then detectron2's PeriodicCheckpointer (fvcore): `model_{iter:07d}` every SOLVER.CHECKPOINT_PERIOD
+        iterations and `model_final` after the last one, main process only."""
         self.scheduler.step()
+        period = int(self.cfg.SOLVER.get("CHECKPOINT_PERIOD", 0) or 0)
+        if self._is_main_process() and self.cfg.OUTPUT_DIR:
+            if period > 0 and (self.iter + 1) % period == 0 and self.iter < self.max_iter - 1:
+                self.checkpointer.save("model_{:07d}".format(self.iter), iteration=self.iter)
+            if self.iter >= self.max_iter - 1:
+                self.checkpointer.save("model_final", iteration=self.iter)
 
     def train(self):
         for self.iter in range(self.start_iter, self.max_iter):
@@ -513,7 +593,8 @@ class ALDITrainer(DefaultTrainer):
                 raise ValueError("the ViTDet / ConvNeXt models are trained with SOLVER.OPTIMIZER ADAMW (their Base-RCNN-*.yaml)")
             return super(ALDITrainer, cls).build_optimizer(cfg, model)
         if cfg.SOLVER.OPTIMIZER.upper() == "ADAMW" and getattr(model, "adamw", False):       # reference aldi/trainer.py:200-209
-            return EngineAdamW(model, cfg.SOLVER.BASE_LR)
+            vitdet_b = cfg.MODEL.BACKBONE.NAME == "build_vitdet_b_backbone"          # include_vit_lr_decay of the reference
+            return EngineAdamW(model, cfg.SOLVER.BASE_LR, lr_decay_rate=0.7 if vitdet_b else None, num_layers=12)
         raise ValueError(f"Unsupported optimizer/backbone combination {cfg.SOLVER.OPTIMIZER} {cfg.MODEL.BACKBONE.NAME}.")
 
     @classmethod
@@ -575,23 +656,36 @@ class ALDITrainer(DefaultTrainer):
         """detectron2 DefaultTrainer.test: {dataset: {"bbox": {...}}} (flattened to the single dict when there is one dataset)"""
         from .evaluation import inference_on_dataset
         names = list(cfg.DATASETS.TEST) or ["synthetic_val"]
+        world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+        rank = dist.get_rank() if world > 1 else 0
         results = OrderedDict()
         for i, name in enumerate(names):
             loader, records = cls.build_test_loader(cfg, name)
             ev = evaluators[i] if evaluators is not None else cls.build_evaluator(cfg, name, dataset_dicts=records)
-            results[name] = inference_on_dataset(model, loader, ev)
+            # detectron2's InferenceSampler: every rank runs a disjoint shard of the test set, the evaluator gathers the
+            # predictions on rank 0 (each detection counted once; the ground truth stays the full set)
+            results[name] = inference_on_dataset(model, loader[rank::world] if world > 1 else loader, ev)
         return results[names[0]] if len(results) == 1 else results
 
     def after_step(self):
+        """aldi/trainer.py:173-196: EvalHook on the EMA model (the student without EMA) every TEST.EVAL_PERIOD iterations and
+        after the last one; BestCheckpointer on `bbox/AP50` (one test set) or `<test_set>/bbox/AP50` (several), "max",
+        written as `<test_set>_model_best.pth` by the main process."""
         super(ALDITrainer, self).after_step()
         period = self.cfg.TEST.EVAL_PERIOD
-        if period > 0 and (self.iter + 1) % period == 0:
+        last = self.iter >= self.max_iter - 1
+        if period > 0 and ((self.iter + 1) % period == 0 or last):
             self._last_eval_results = self.test(self.cfg, self.ema.model if self.cfg.EMA.ENABLED else self.model)
-            ap50 = self._last_eval_results.get("bbox", {}).get("AP50", float("nan"))
-            if ap50 == ap50 and ap50 > getattr(self, "_best_ap50", float("-inf")):       # BestCheckpointer(..., "bbox/AP50", "max")
-                self._best_ap50 = ap50
-                name = (list(self.cfg.DATASETS.TEST) or ["synthetic_val"])[0]
-                self.checkpointer.save(f"{name}_model_best", iteration=self.iter)
+            names = list(self.cfg.DATASETS.TEST) or ["synthetic_val"]
+            if not self._is_main_process():
+                return
+            best = self.__dict__.setdefault("_best_ap50", {})
+            for name in names:
+                res = self._last_eval_results if len(names) == 1 else self._last_eval_results.get(name, {})
+                ap50 = res.get("bbox", {}).get("AP50", float("nan"))
+                if ap50 == ap50 and ap50 > best.get(name, float("-inf")):
+                    best[name] = ap50
+                    self.checkpointer.save(f"{name}_model_best", iteration=self.iter)
 
 
 Trainer = ALDITrainer   # BASELINE.json calls it aldi.trainer.Trainer

@@ -355,18 +355,52 @@ class VitParams:
         """deferred scalar on the gradient (folded into the optimizer kernel), e.g. 1/world after all-reduce(SUM)"""
         self._gscale = getattr(self, "_gscale", 1.0) * f
 
-    def adamw_step(self, lr: float, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 0.1, grad_scale: float = 1.0):
+    def lr_factor(self, name: str, lr_decay_rate: float, num_layers: int) -> float:
+        """detectron2 `get_vit_lr_decay_rate` (ViTDet layer-wise lr decay) as the reference enables it for
+        build_vitdet_b_backbone (aldi/backbone.py:73-79, aldi/trainer.py:204): blocks.i -> rate^(num_layers - i),
+        pos_embed / patch_embed -> rate^(num_layers + 1), everything outside the ViT (pyramid, heads) -> 1."""
+        layer_id = num_layers + 1
+        if name.startswith("backbone"):
+            if ".pos_embed" in name or ".patch_embed" in name:
+                layer_id = 0
+            elif ".blocks." in name and ".residual." not in name:
+                layer_id = int(name[name.find(".blocks."):].split(".")[2]) + 1
+        return lr_decay_rate ** (num_layers + 1 - layer_id)
+
+    def lr_groups(self, lr_decay_rate: Optional[float], num_layers: int) -> List[Tuple[int, int, bool, float]]:
+        """contiguous (lo, hi, decayed?, lr factor) pieces of the flat layout, adjacent tensors with equal settings merged"""
+        key = (lr_decay_rate, num_layers)
+        cache = self.__dict__.setdefault("_lr_groups", {})
+        if key not in cache:
+            nd = self.n_decay
+            starts = sorted((self.off[name], 1.0 if lr_decay_rate is None else self.lr_factor(name, lr_decay_rate, num_layers)) for name in self.spec)
+            pieces = []
+            for i, (lo, f) in enumerate(starts):                  # a tensor owns everything up to the next tensor (layout padding included)
+                hi = starts[i + 1][0] if i + 1 < len(starts) else self.n
+                lo = 0 if i == 0 else lo
+                for a, b in ((lo, min(hi, nd)), (max(lo, nd), hi)):   # never straddle the decayed / non-decayed boundary
+                    if b > a:
+                        if pieces and pieces[-1][1] == a and pieces[-1][2] == (a < nd) and pieces[-1][3] == f:
+                            pieces[-1][1] = b
+                        else:
+                            pieces.append([a, b, a < nd, f])
+            cache[key] = [tuple(p) for p in pieces]
+        return cache[key]
+
+    def adamw_step(self, lr: float, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 0.1, grad_scale: float = 1.0,
+                   lr_decay_rate: Optional[float] = None, num_layers: int = 12):
         """torch.optim.AdamW over [decayed | weight_decay = 0 (norms, pos_embed)] -- detectron2 get_default_optimizer_params with
-        weight_decay_norm = 0 and the pos_embed override of aldi/backbone.py:80."""
+        weight_decay_norm = 0 and the pos_embed override of aldi/backbone.py:80; `lr_decay_rate` turns on the layer-wise lr
+        decay (one launch per run of equal lr factor: 28 for ViT-B instead of 2)."""
         if self._m is None:
             self._m = torch.zeros(self.n, dtype=torch.float32, device=self.device)
             self._v = torch.zeros(self.n, dtype=torch.float32, device=self.device)
         self.step_count += 1
-        nd = self.n_decay
-        for lo, hi, wd in ((0, nd, weight_decay), (nd, self.n, 0.0)):
+        for lo, hi, dec, f in self.lr_groups(lr_decay_rate, num_layers):
             if hi > lo:
-                V.adamw_step(self.master[lo:hi], self.grad[lo:hi], self._m[lo:hi], self._v[lo:hi], self.compute[lo:hi], lr=lr, betas=betas,
-                             eps=eps, weight_decay=wd, step=self.step_count, grad_scale=grad_scale * getattr(self, "_gscale", 1.0))
+                V.adamw_step(self.master[lo:hi], self.grad[lo:hi], self._m[lo:hi], self._v[lo:hi], self.compute[lo:hi], lr=lr * f, betas=betas,
+                             eps=eps, weight_decay=weight_decay if dec else 0.0, step=self.step_count,
+                             grad_scale=grad_scale * getattr(self, "_gscale", 1.0))
         if self._wt_plan is not None:
             self._wt_plan.run()
 

@@ -76,3 +76,121 @@ def test_partial_and_mismatched_state_dicts(tmp_path):
     with pytest.raises(NotImplementedError):
         ck.load("R-50.pkl")
     assert ck.load("") == {}
+
+
+# ---- trainer-level checkpointing (CHECKPOINT_PERIOD / model_final / optimizer + LR-schedule resume)
+class _Weights:
+    def __init__(self):
+        self._mom = None
+        self.first_step = True
+        self.dev = torch.device("cpu")
+
+    @property
+    def mom(self):
+        if self._mom is None:
+            self._mom = torch.zeros(10)
+        return self._mom
+
+    def zero_grad(self):
+        pass
+
+    def sgd_step(self, lr, momentum, wd):
+        self.mom.add_(lr)
+        self.first_step = False
+
+
+class _TModel(_Model):
+    training = True
+
+    def __init__(self, v):
+        super().__init__(v)
+        self.weights = _Weights()
+
+
+def _mini_trainer(tmp_path, max_iter, period):
+    """DefaultTrainer with its collaborators replaced by host-only stand-ins (no GPU): what is under test is the hook logic"""
+    from aldi_amd.config import add_aldi_config, get_cfg
+    from aldi_amd import trainer as T
+
+    class Mini(T.DefaultTrainer):
+        @classmethod
+        def build_model(cls, cfg):
+            return _TModel(1)
+
+        @classmethod
+        def build_train_loader(cls, cfg):
+            return None
+
+        def _create_trainer(self, cfg, model, data_loader, optimizer):
+            class Step:
+                def __init__(s):
+                    s.model, s.optimizer = model, optimizer
+
+                def run_step(s):
+                    s.optimizer.step()
+            return Step()
+    cfg = get_cfg()
+    add_aldi_config(cfg)
+    cfg.merge_from_list(["OUTPUT_DIR", str(tmp_path), "SOLVER.MAX_ITER", max_iter, "SOLVER.CHECKPOINT_PERIOD", period, "SOLVER.BASE_LR", 0.1,
+                         "SOLVER.WARMUP_ITERS", 4, "SOLVER.WARMUP_FACTOR", 0.1, "SOLVER.STEPS", (6,), "SOLVER.GAMMA", 0.5])
+    return Mini(cfg)
+
+
+def test_periodic_and_final_checkpoints_and_full_resume(tmp_path):
+    tr = _mini_trainer(tmp_path, 10, 4)
+    tr.resume_or_load(resume=False)
+    lrs = []
+    for tr.iter in range(0, 6):                                      # "crash" after iteration 5
+        lrs.append(tr._trainer.optimizer.param_groups[0]["lr"])
+        tr.before_step(); tr.run_step(); tr.after_step()
+    files = sorted(f for f in os.listdir(tmp_path) if f.endswith(".pth"))
+    assert files == ["model_0000003.pth"] and open(tmp_path / "last_checkpoint").read() == "model_0000003.pth"
+    raw = torch.load(tmp_path / "model_0000003.pth", weights_only=False)
+    assert raw["iteration"] == 3 and raw["trainer"]["iteration"] == 3 and raw["trainer"]["hooks"]["LRScheduler"] == {"last_epoch": 4}
+    assert raw["trainer"]["_trainer"]["optimizer"]["format"] == "aldi_amd.flat_sgd"
+    # a fresh process resumes: iteration, LR schedule position and momentum continue
+    tr2 = _mini_trainer(tmp_path, 10, 4)
+    tr2.resume_or_load(resume=True)
+    assert tr2.start_iter == 4 and tr2.scheduler.last_iter == 4
+    assert tr2._trainer.optimizer.param_groups[0]["lr"] == lrs[4]   # not the warm-up start again
+    assert torch.allclose(tr2.model.weights.mom, torch.full((10,), sum(lrs[:4])))
+    assert tr2.model.weights.first_step is False
+    tr2.train()
+    files = sorted(f for f in os.listdir(tmp_path) if f.endswith(".pth"))
+    assert files == ["model_0000003.pth", "model_0000007.pth", "model_final.pth"]
+    assert torch.load(tmp_path / "model_final.pth", weights_only=False)["iteration"] == 9
+    # the schedule the resumed run followed == an uninterrupted run's
+    ref = _mini_trainer(tmp_path / "ref", 10, 0)
+    assert [ref.scheduler.lr_at(i) for i in range(10)][4] == lrs[4]
+    assert tr2._trainer.optimizer.param_groups[0]["lr"] == ref.scheduler.lr_at(10)
+
+
+def test_best_checkpoint_per_test_set(tmp_path):
+    """two DATASETS.TEST entries: results are keyed by data set, one `<test_set>_model_best` each (reference aldi/trainer.py:186-194)"""
+    from aldi_amd.config import add_aldi_config, get_cfg
+    from aldi_amd import trainer as T
+    saved = []
+
+    class Ck:
+        def save(self, name, **kw):
+            saved.append((name, kw.get("iteration")))
+
+    class Sched:
+        def step(self):
+            pass
+    cfg = get_cfg()
+    add_aldi_config(cfg)
+    cfg.merge_from_list(["OUTPUT_DIR", "", "TEST.EVAL_PERIOD", 2, "SOLVER.MAX_ITER", 100, "DATASETS.TEST", ("a_val", "b_val")])
+    tr = T.ALDITrainer.__new__(T.ALDITrainer)
+    tr.cfg, tr.checkpointer, tr.scheduler, tr.max_iter = cfg, Ck(), Sched(), 100
+    tr.ema = None
+    scores = iter([{"a_val": {"bbox": {"AP50": 10.0}}, "b_val": {"bbox": {"AP50": 30.0}}},
+                   {"a_val": {"bbox": {"AP50": 12.0}}, "b_val": {"bbox": {"AP50": 29.0}}}])
+    tr.test = lambda cfg_, model_: next(scores)
+    type(tr).model = property(lambda self: None)
+    try:
+        for tr.iter in range(4):
+            tr.after_step()
+    finally:
+        type(tr).model = T.DefaultTrainer.model
+    assert saved == [("a_val_model_best", 1), ("b_val_model_best", 1), ("a_val_model_best", 3)]

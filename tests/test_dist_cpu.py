@@ -153,3 +153,79 @@ def test_exchange_launches_few_large_collectives():
     reports.append(P.ranges([cfg.prefix + "pos_embed", cfg.prefix + "patch_embed.proj.weight", cfg.prefix + "patch_embed.proj.bias"]))
     sizes = _count_collectives(P.n, reports)
     assert sum(sizes) == P.n and len(sizes) <= 20, (len(sizes), sorted(sizes)[:10])
+
+
+# ---- distributed evaluation: the test set is sharded by rank and gathered once (detections were counted world times)
+class _FakeDetector:
+    """stand-in for the EMA model in ALDITrainer.test: noisy ground truth + false positives, a pure function of the image id"""
+    training = False
+
+    def __init__(self, records):
+        self.records = {r["image_id"]: r for r in records}
+
+    def eval(self):
+        return self
+
+    def train(self, mode=True):
+        return self
+
+    def __call__(self, inputs):
+        from aldi_amd.structures import Boxes, Instances
+        out = []
+        for inp in inputs:
+            r = self.records[inp["image_id"]]
+            g = torch.Generator().manual_seed(100 + inp["image_id"])
+            b = torch.tensor([a["bbox"] for a in r["annotations"]], dtype=torch.float32).reshape(-1, 4)
+            c = torch.tensor([a["category_id"] for a in r["annotations"]], dtype=torch.int64)
+            keep = torch.rand(len(b), generator=g) > 0.3
+            b, c = b[keep] + torch.randn(int(keep.sum()), 4, generator=g) * 3.0, c[keep]
+            fp = torch.rand(4, 4, generator=g) * 100
+            fp[:, 2:] += fp[:, :2] + 20
+            boxes = torch.cat([b, fp, b[:2] + 1.0])                 # duplicates of matched GT must count as false positives ONCE
+            cls = torch.cat([c, torch.randint(0, 8, (4,), generator=g), c[:2]])
+            sc = torch.rand(len(boxes), generator=g)
+            out.append({"instances": Instances((inp["height"], inp["width"]), pred_boxes=Boxes(boxes), scores=sc, pred_classes=cls)})
+        return out
+
+
+def _eval_cfg():
+    from aldi_amd.config import add_aldi_config, get_cfg
+    cfg = get_cfg()
+    add_aldi_config(cfg)
+    cfg.merge_from_list(["MODEL.ROI_HEADS.NUM_CLASSES", 8, "SYNTHETIC.HEIGHT", 96, "SYNTHETIC.WIDTH", 128, "SYNTHETIC.VAL_IMAGES", 7])
+    return cfg
+
+
+def _worker_eval(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from aldi_amd.trainer import ALDITrainer
+    cfg = _eval_cfg()
+    _, records = ALDITrainer.build_test_loader(cfg, "synthetic_val")
+    res = ALDITrainer.test(cfg, _FakeDetector(records))
+    q.put((rank, dict(res.get("bbox", {})) if res else {}))
+    dist.destroy_process_group()
+
+
+def test_distributed_evaluation_equals_single_process():
+    from aldi_amd.trainer import ALDITrainer
+    cfg = _eval_cfg()
+    _, records = ALDITrainer.build_test_loader(cfg, "synthetic_val")
+    ref = ALDITrainer.test(cfg, _FakeDetector(records))["bbox"]
+    assert 0.0 < ref["AP50"] < 100.0
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_worker_eval, args=(r, 2, port, q)) for r in range(2)]
+    for p in ps:
+        p.start()
+    res = dict(q.get(timeout=180) for _ in range(2))
+    for p in ps:
+        p.join(timeout=60)
+    assert res[1] == {}                                           # only the main process reports
+    for k in ("AP", "AP50", "AP75"):
+        assert abs(res[0][k] - ref[k]) < 1e-9, (k, res[0][k], ref[k])

@@ -184,3 +184,25 @@ def test_registries_expose_reference_names():
     assert trainer.Trainer is trainer.ALDITrainer
     with pytest.raises(KeyError):
         DISTILLER_REGISTRY.get("nope")
+
+
+def test_vit_layerwise_lr_decay_groups():
+    """ViTDet-B AdamW param groups: detectron2 get_vit_lr_decay_rate(num_layers=12, lr_decay_rate=0.7) as the
+    reference enables it for build_vitdet_b_backbone (aldi/backbone.py:73-79, aldi/trainer.py:204)."""
+    from aldi_amd.vit import VitConfig, VitParams
+    cfg = VitConfig(sfp=True, num_classes=8)
+    P = VitParams(cfg, "cpu")
+    pre = cfg.prefix
+    assert abs(P.lr_factor(pre + "blocks.0.attn.qkv.weight", 0.7, 12) - 0.7 ** 12) < 1e-15
+    assert abs(P.lr_factor(pre + "blocks.11.mlp.fc2.bias", 0.7, 12) - 0.7) < 1e-15
+    assert abs(P.lr_factor(pre + "pos_embed", 0.7, 12) - 0.7 ** 13) < 1e-15
+    assert abs(P.lr_factor(pre + "patch_embed.proj.weight", 0.7, 12) - 0.7 ** 13) < 1e-15
+    assert P.lr_factor("backbone.simfp_2.0.weight", 0.7, 12) == 1.0 and P.lr_factor("roi_heads.box_predictor.cls_score.weight", 0.7, 12) == 1.0
+    assert len(P.lr_groups(None, 12)) == 2                                  # decay off: [decayed | norms + pos_embed]
+    g = P.lr_groups(0.7, 12)
+    assert g[0][0] == 0 and g[-1][1] == P.n and all(a[1] == b[0] for a, b in zip(g[:-1], g[1:]))   # a partition of the flat state
+    assert len(g) <= 30
+    for name in P.spec:
+        lo = P.off[name]
+        (piece,) = [x for x in g if x[0] <= lo < x[1]]
+        assert piece[2] == (lo < P.n_decay) and abs(piece[3] - P.lr_factor(name, 0.7, 12)) < 1e-15, name
