@@ -8,13 +8,24 @@ state, so files written by the reference load here and vice versa.  The EMA chec
 `model.` prefix exactly like the reference's `EMA` module.
 
 `DetectionCheckpointerWithEMA.resume_or_load(path, resume=False)` additionally starts the model from the file's `ema`
-entry (burn-in with EMA, `cfg.EMA.LOAD_FROM_EMA_ON_START`).  Not implemented: the `.pkl` model-zoo / Caffe2 name
-heuristics (`align_and_update_state_dicts`) -- a `.pkl` path raises."""
+entry (burn-in with EMA, `cfg.EMA.LOAD_FROM_EMA_ON_START`).
+
+`.pkl` files (reference configs/Base-RCNN-FPN.yaml:3 `detectron2://ImageNetPretrained/MSRA/R-50.pkl`, docs/MODELS.md model
+zoo) are read as detectron2's `DetectionCheckpointer._load_file` does: a pickle holding {"model": {name: ndarray}, "__author__",
+["matching_heuristics"]}.  Files flagged `matching_heuristics` carry Caffe2 names (`res2_0_branch2a_w`, `res2_0_branch2a_bn_s`,
+`conv1_w`, `res_conv1_bn_b`, `fc1000_w` ...): they go through the published renaming rules of detectron2's
+`c2_model_loading.convert_basic_c2_names` and are then matched to the model's keys by longest dotted suffix
+(`align_and_update_state_dicts`: `backbone.bottom_up.res2.0.conv1.weight` <- `res2.0.conv1.weight`).  FrozenBN statistics
+absent from such a file (the MSRA weights have the affine only) load as mean 0 / var 1, detectron2's
+`FrozenBatchNorm2d._load_from_state_dict` rule.  `detectron2://` URLs need a local copy (no network): pass the file path.
+Parity of the renaming is unpinned (detectron2 absent); tests build a Caffe2-named file from known weights."""
 from __future__ import annotations
 
 import logging
 import os
-from typing import Any, Dict, Optional
+import pickle
+import re
+from typing import Any, Dict, List, Optional
 
 import torch
 
@@ -22,6 +33,73 @@ import torch
 class _IncompatibleKeys:
     def __init__(self, missing_keys, unexpected_keys, incorrect_shapes):
         self.missing_keys, self.unexpected_keys, self.incorrect_shapes = missing_keys, unexpected_keys, incorrect_shapes
+
+
+def convert_c2_names(names: List[str]) -> List[str]:
+    """Caffe2 / MSRA blob names -> detectron2 parameter-name suffixes (the basic rules: backbone + norm layers)."""
+    out = []
+    for k in names:
+        k = k.replace("_", ".")
+        k = re.sub(r"\.b$", ".bias", k)
+        k = re.sub(r"\.w$", ".weight", k)
+        k = re.sub(r"bn\.s$", "norm.weight", k)
+        k = re.sub(r"bn\.bias$", "norm.bias", k)
+        k = re.sub(r"bn\.rm$", "norm.running_mean", k)
+        k = re.sub(r"bn\.running\.mean$", "norm.running_mean", k)
+        k = re.sub(r"bn\.riv$", "norm.running_var", k)
+        k = re.sub(r"bn\.running\.var$", "norm.running_var", k)
+        k = re.sub(r"bn\.gamma$", "norm.weight", k)
+        k = re.sub(r"bn\.beta$", "norm.bias", k)
+        k = re.sub(r"gn\.s$", "norm.weight", k)
+        k = re.sub(r"gn\.bias$", "norm.bias", k)
+        k = re.sub(r"^res\.conv1\.norm\.", "conv1.norm.", k)          # the stem's norm is stored as res_conv1_bn_*
+        k = re.sub(r"^conv1\.", "stem.conv1.", k)
+        k = k.replace(".branch1.", ".shortcut.").replace(".branch2a.", ".conv1.").replace(".branch2b.", ".conv2.").replace(".branch2c.", ".conv3.")
+        out.append(k)
+    return out
+
+
+def align_by_suffix(model_keys: List[str], ckpt_keys: List[str]) -> Dict[str, str]:
+    """model key -> checkpoint key whose name is the LONGEST dotted suffix of it (detectron2 align_and_update_state_dicts)"""
+    match: Dict[str, str] = {}
+    for mk in model_keys:
+        best = None
+        for ck in ckpt_keys:
+            if mk == ck or mk.endswith("." + ck):
+                if best is None or len(ck) > len(best):
+                    best = ck
+        if best is not None:
+            match[mk] = best
+    return match
+
+
+def load_pkl(path: str, model_keys: List[str]) -> Dict[str, Any]:
+    """detectron2 model-zoo / Caffe2 `.pkl` -> {"model": {detectron2 key: tensor}, ...}"""
+    with open(path, "rb") as f:
+        data = pickle.load(f, encoding="latin1")
+    if "model" in data and "__author__" in data:
+        raw = data["model"]
+    else:                                              # a bare Caffe2 blob dict
+        raw = data["blobs"] if "blobs" in data else data
+        data = {"model": raw, "__author__": "Caffe2", "matching_heuristics": True}
+    raw = {k: torch.as_tensor(v) for k, v in raw.items() if not k.endswith("_momentum")}
+    if data.get("matching_heuristics", False):
+        names = list(raw.keys())
+        conv = dict(zip(convert_c2_names(names), names))
+        match = align_by_suffix(model_keys, list(conv.keys()))
+        model = {mk: raw[conv[ck]] for mk, ck in match.items()}
+        for mk in model_keys:                          # FrozenBN buffers absent from an affine-only file
+            if mk not in model and mk.endswith(".norm.running_mean") and mk[:-len("running_mean")] + "weight" in model:
+                model[mk] = torch.zeros_like(model[mk[:-len("running_mean")] + "weight"])
+            if mk not in model and mk.endswith(".norm.running_var") and mk[:-len("running_var")] + "weight" in model:
+                model[mk] = torch.ones_like(model[mk[:-len("running_var")] + "weight"])
+        used = set(match.values())
+        data["unmatched_checkpoint_keys"] = [conv[k] for k in conv if k not in used]
+    else:
+        model = raw
+    out = {k: v for k, v in data.items() if k != "model"}
+    out["model"] = model
+    return out
 
 
 class DetectionCheckpointer:
@@ -86,11 +164,16 @@ class DetectionCheckpointer:
         if not path:
             self.logger.info("No checkpoint found. Initializing model from scratch")
             return {}
-        if path.endswith(".pkl"):
-            raise NotImplementedError("model-zoo .pkl checkpoints (Caffe2 / detectron2 name heuristics) are not supported; convert to .pth")
+        if path.startswith("detectron2://"):
+            raise AssertionError(f"{path}: model-zoo URLs cannot be fetched here (no network); download the file and pass its path")
         if not os.path.isfile(path):
             raise AssertionError(f"Checkpoint {path} not found!")
-        ck = torch.load(path, map_location="cpu", weights_only=False)
+        if path.endswith(".pkl"):
+            ck = load_pkl(path, list(self.model.state_dict().keys()))
+            if ck.get("unmatched_checkpoint_keys"):
+                self.logger.warning("checkpoint keys not used by the model: %s", ", ".join(ck["unmatched_checkpoint_keys"][:8]))
+        else:
+            ck = torch.load(path, map_location="cpu", weights_only=False)
         if "model" not in ck:                        # a bare state_dict
             ck = {"model": ck}
         self._log_incompatible_keys(self._load_model(ck.pop("model")))

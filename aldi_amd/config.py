@@ -221,6 +221,7 @@ def add_aldi_config(cfg: CfgNode):
     # aldi_amd extension (not in the reference): run the step's student passes as one fused launch sequence
     # (numerically the sequential schedule; see aldi_amd.trainer.fused_run_model)
     _C.SOLVER.FUSED_STEP = False
+    _C.SOLVER.STEP_GRAPH = False          # replay the fused step's two device phases as hipGraphs (aldi_amd/fused_step.py)
 
     _C.MODEL.CONVNEXT = CN()
     _C.MODEL.CONVNEXT.DEPTHS = [3, 3, 9, 3]

@@ -43,8 +43,14 @@ __device__ __forceinline__ float bce_logits(float x, float y) {
 
 // reference aldi/distill.py:203-227.  labels: [N][sumA] int in {-1,0,1} (flat index = mask position).
 __global__ __launch_bounds__(256) void rpn_distill_kernel(DGeom g, const int* __restrict__ labels, float inv_T, float inv_valid, float inv_fg4,
+                                                          const int* __restrict__ counts /* device {n_valid, n_fg} or null */,
                                                           int do_obj, int do_reg, float gscale, float* __restrict__ loss /*[2]*/) {
     __shared__ float red[16];
+    if (counts) {
+        const int nv = counts[0], nf = counts[1];
+        inv_valid = nv > 0 ? 1.f / (float)nv : 0.f;
+        inv_fg4 = nf > 0 ? 1.f / (float)(4 * nf) : 0.f;
+    }
     const long q = blockIdx.x * (long)blockDim.x + threadIdx.x;
     float l_obj = 0.f, l_reg = 0.f;
     if (q < (long)g.N * g.sumA) {
@@ -183,8 +189,8 @@ __global__ void avgpool_bwd_kernel(const T* __restrict__ gy, const T* __restrict
 }  // namespace
 
 extern "C" int aldi_rpn_distill_loss(const aldi_rpn_geom* gm, float* const* student_head, float* const* teacher_head, float* const* grad,
-                                     const int* labels, int N, float obj_temperature, int n_valid, int n_fg, int do_obj, int do_reg,
-                                     float grad_scale, float* loss2, aldi_stream_t stream) {
+                                     const int* labels, int N, float obj_temperature, int n_valid, int n_fg, const int* n_valid_fg_dev,
+                                     int do_obj, int do_reg, float grad_scale, float* loss2, aldi_stream_t stream) {
     if (!gm || !student_head || !teacher_head || !labels || !loss2) return aldi_set_error_msg(ALDI_ERR_ARG, "rpn_distill_loss: null pointer");
     DGeom g;
     g.nl = gm->num_levels; g.A = gm->A; g.C = gm->C; g.sumA = gm->off[gm->num_levels]; g.N = N;
@@ -197,7 +203,7 @@ extern "C" int aldi_rpn_distill_loss(const aldi_rpn_geom* gm, float* const* stud
     float inv_valid = n_valid > 0 ? 1.f / (float)n_valid : 0.f;
     float inv_fg4 = n_fg > 0 ? 1.f / (float)(4 * n_fg) : 0.f;
     hipLaunchKernelGGL(rpn_distill_kernel, dim3((int)((tot + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), g, labels,
-                       1.f / obj_temperature, inv_valid, inv_fg4, do_obj, do_reg, grad_scale, loss2);
+                       1.f / obj_temperature, inv_valid, inv_fg4, n_valid_fg_dev, do_obj, do_reg, grad_scale, loss2);
     ALDI_CHECK_LAUNCH();
     return ALDI_OK;
 }

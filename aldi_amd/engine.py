@@ -602,7 +602,7 @@ class RCNN:
         ch["loss_dist_rpn"] = torch.zeros(2, dtype=torch.float32, device=dev)
         ch["loss_dist_roi"] = torch.zeros(2, dtype=torch.float32, device=dev)
         ops.rpn_distill_loss(c.geom, [h[n0:n1] for h in c.head], teacher_head, None, labels, n1 - n0, kw["obj_T"], n_valid, n_fg,
-                             kw["do_obj"], kw["do_rpn_reg"], 0.0, ch["loss_dist_rpn"])
+                             kw["do_obj"], kw["do_rpn_reg"], 0.0, ch["loss_dist_rpn"], counts_dev=kw.get("counts_dev"))
         ops.roih_distill_loss(c.pred[r0:r1], teacher_pred, self.Cp, self.K, r1 - r0, kw["cls_T"], kw["kl"], kw["do_cls"], kw["do_roih_reg"],
                               0.0, None, ch["loss_dist_roi"])
 
@@ -651,7 +651,8 @@ class RCNN:
             d = ch["distill"]
             if d is not None:
                 def rpn_d(do_obj, do_reg, s_):
-                    ops.rpn_distill_loss(c.geom, heads, d["t_head"], gheads, d["labels"], nc, d["obj_T"], d["n_valid"], d["n_fg"], do_obj, do_reg, s_, scratch)
+                    ops.rpn_distill_loss(c.geom, heads, d["t_head"], gheads, d["labels"], nc, d["obj_T"], d["n_valid"], d["n_fg"], do_obj, do_reg, s_, scratch,
+                                         counts_dev=d.get("counts_dev"))
 
                 def roi_d(do_cls, do_reg, s_):
                     ops.roih_distill_loss(c.pred[r0:r1], d["t_pred"], self.Cp, self.K, r1 - r0, d["cls_T"], d["kl"], do_cls, do_reg, s_, c.gpred[r0:r1], scratch)
@@ -754,7 +755,7 @@ class RCNN:
         ops.compact_labels(cls, Lc, N, self.K, lists, counts)
         return dict(cand=cand, cls=cls, best_idx=best_idx, lists=lists, counts=counts, Lc=Lc)
 
-    def _roi_gather(self, c: Ctx, prep: dict, sel, nsel, nsel_h, gt, N):
+    def _roi_gather(self, c: Ctx, prep: dict, sel, nsel, nsel_h, gt, N, row_off_dev=None):
         dev = self.device
         rows = [a + b for a, b in nsel_h]
         row_off = [0]
@@ -766,8 +767,10 @@ class RCNN:
         c.r_cls = torch.empty((max(R, 1),), dtype=torch.int32, device=dev)
         c.r_gt = torch.empty((max(R, 1), 4), dtype=torch.float32, device=dev)
         c.r_idx = torch.empty((max(R, 1),), dtype=torch.int32, device=dev)
+        if row_off_dev is None:
+            row_off_dev = torch.tensor(row_off, dtype=torch.int32).to(dev)
         ops.roi_gather(prep["cand"], prep["cls"], prep["best_idx"], prep["Lc"], prep["lists"], sel, nsel, ROI_BATCH,
-                       torch.tensor(row_off, dtype=torch.int32).to(dev), gt["boxes"], gt["count"], GMAX, N, c.rois, c.r_cls, c.r_gt, c.r_idx)
+                       row_off_dev, gt["boxes"], gt["count"], GMAX, N, c.rois, c.r_cls, c.r_gt, c.r_idx)
 
     def roi_sample(self, c: Ctx, props, prop_count, gt, N):
         prep = self._roi_prepare(props, prop_count, gt, N)
@@ -790,11 +793,11 @@ class RCNN:
         return pred
 
     # ------------------------------------------------------------------ inference (teacher)
-    def inference(self, images, pl_thresh: float, keep_ctx: bool = True) -> Ctx:
+    def inference(self, images, pl_thresh: float, keep_ctx: bool = True, staged=None) -> Ctx:
         """GeneralizedRCNN.inference(do_postprocess=False) + process_pseudo_label threshold
-        (aldi/pseudolabeler.py:15-67).  Everything stays on device."""
-        N = len(images)
-        st, sizes, hw = self.stage_images(images)
+        (aldi/pseudolabeler.py:15-67).  Everything stays on device.  `staged` = (uint8 batch, sizes, hw) already in HBM."""
+        st, sizes, hw = staged if staged is not None else self.stage_images(images)
+        N = st.shape[0]
         shapes, geom, anchors = self.geometry(st.shape[2], st.shape[3])
         c = self.trunk(st, sizes, save=False)
         c.N, c.sizes, c.hw, c.geom, c.anchors, c.shapes = N, sizes, hw, geom, anchors, shapes

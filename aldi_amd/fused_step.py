@@ -1,0 +1,432 @@
+"""The fused ALDI iteration of the R50-FPN engine as three explicit phases, replayable as HIP graphs.
+
+    phase A  (device, label-free)   student trunk + RPN head + proposals | teacher inference + pseudo-labels (own stream)
+                                    -> anchor matching, ROI candidate lists, list lengths -> pinned host memory
+    host                            the ONE synchronisation of the step; every `torch.randperm` draw of the reference
+                                    schedule (RPN / ROI sampling per micro-step, the teacher's replay, the fresh
+                                    RPN-distillation sample), in the reference's order -> one pinned upload buffer
+    phase B  (device)               sampled labels / ROIs, box heads (student + teacher), all losses, the single backward
+
+What the phases replace: the body of `run_model_labeled_unlabeled` (reference aldi/trainer.py:28-117) with the student
+micro-steps batched into one trunk pass, `ALDIDistiller._distill_forward` (aldi/distill.py:144-168) and the
+loss-dict arithmetic.  Same loss keys, values, 1/accum scaling, `v*0` masking and global-RNG stream as the sequential
+driver (tests/test_engine_gpu.py::test_fused_step_equals_sequential).
+
+Neither device phase reads anything from the host except through fixed buffers, and no launch argument changes from
+step to step, so each phase is captured ONCE into a hipGraph (`torch.cuda.CUDAGraph`: torch's allocator keeps the
+captured tensors resident) and replayed: the Python sequencer then issues ~10 launches per step instead of ~450
+(SOLVER.STEP_GRAPH, on by default in bench.py).  Phase B's shape depends on the number of sampled ROIs (512 per image
+unless an image has fewer candidates): one graph per distinct row tuple.  Under data parallelism phase B stays eager (its
+backward launches the overlapped gradient exchange, reduce.BucketedReducer)."""
+from __future__ import annotations
+
+import os
+from types import SimpleNamespace
+from typing import Dict, List, Optional
+
+import torch
+
+from . import ops
+from .arch import pad_to
+from .engine import GMAX, RCNN, ROI_BATCH, ROI_POS_FRAC, ROI_WEIGHTS, RPN_BATCH, RPN_POS_FRAC, Ctx
+from .structures import as_record
+
+
+def _pinned(nbytes: int) -> torch.Tensor:
+    return torch.empty(max(nbytes, 16), dtype=torch.uint8).pin_memory()
+
+
+class _Packed:
+    """several small int32 / float32 host arrays in ONE pinned buffer with a device mirror: a single asynchronous copy"""
+
+    def __init__(self, spec, device):
+        self.spec, off = {}, 0
+        for name, shape, dtype in spec:
+            n = 1
+            for s_ in shape:
+                n *= s_
+            nb = n * 4
+            self.spec[name] = (off, nb, tuple(shape), dtype)
+            off += (nb + 15) // 16 * 16
+        self.host = _pinned(off)
+        self.host.zero_()
+        self.dev = torch.zeros(self.host.numel(), dtype=torch.uint8, device=device)
+
+    def h(self, name) -> torch.Tensor:
+        o, nb, shape, dt = self.spec[name]
+        return self.host[o:o + nb].view(dt).view(shape)
+
+    def d(self, name) -> torch.Tensor:
+        o, nb, shape, dt = self.spec[name]
+        return self.dev[o:o + nb].view(dt).view(shape)
+
+    def upload(self):
+        self.dev.copy_(self.host, non_blocking=True)
+
+
+class FusedStep:
+    def __init__(self, trainer):
+        self.tr = trainer
+        self.static: Dict[tuple, SimpleNamespace] = {}
+        self.steps_done = 0
+        self.pool = None
+        self.graph_enabled = bool(trainer.model.cfg.SOLVER.get("STEP_GRAPH", False)) and os.environ.get("ALDI_STEP_GRAPH", "1") == "1"
+        self.warmup = 3                     # eager steps before capturing (lazy initialisation: anchors, dgrad weights, workspaces)
+        self.stats = dict(captures=0, replays_a=0, replays_b=0, eager=0)
+
+    # ------------------------------------------------------------------------------------------------ phase 0: inputs
+    def _stage_images(self, S, slot: str, images):
+        """uint8 images (host or device) -> the static padded batch of this slot (same storage every step)"""
+        sizes = [(int(im.shape[1]), int(im.shape[2])) for im in images]
+        Hs, Ws = pad_to(max(s[0] for s in sizes), 32), pad_to(max(s[1] for s in sizes), 32)
+        key = (slot, len(images), Hs, Ws)
+        st = S.bufs.get(key)
+        dev = self.eng.device
+        if st is None:
+            st = SimpleNamespace(img=torch.zeros((len(images), 3, Hs, Ws), dtype=torch.uint8, device=dev), sizes=None,
+                                 hw=torch.zeros((len(images), 2), dtype=torch.int32, device=dev))
+            S.bufs[key] = st
+        if st.sizes != sizes:
+            if st.sizes is not None:
+                st.img.zero_()                               # smaller images than last step: the padding must read zero
+            st.hw.copy_(torch.tensor(sizes, dtype=torch.int32))
+            st.sizes = sizes
+        for i, im in enumerate(images):
+            st.img[i, :, : sizes[i][0], : sizes[i][1]].copy_(im, non_blocking=True)
+        return st
+
+    def _stage_gt(self, S, insts: List[dict]):
+        """ground truth of the labeled chunks (host records) -> static device buffers through one pinned upload"""
+        n = len(insts)
+        if S.gt_pack is None or S.gt_pack.n != n:
+            S.gt_pack = _Packed([("boxes", (n, GMAX, 4), torch.float32), ("classes", (n, GMAX), torch.int32), ("count", (n,), torch.int32)], self.eng.device)
+            S.gt_pack.n = n
+        P = S.gt_pack
+        gb, gc, cnt = P.h("boxes"), P.h("classes"), P.h("count")
+        gb.zero_(); gc.zero_()
+        for i, inst in enumerate(insts):
+            b = inst["gt_boxes"]
+            b = b.tensor if hasattr(b, "tensor") else b
+            g = int(b.shape[0])
+            if g > GMAX:
+                raise ValueError(f"more than {GMAX} GT boxes in one image")
+            if g:
+                gb[i, :g] = b.reshape(-1, 4).to(torch.float32).cpu()
+                gc[i, :g] = inst["gt_classes"].to(torch.int32).cpu()
+            cnt[i] = g
+        P.upload()
+        return {"boxes": P.d("boxes"), "classes": P.d("classes"), "count": P.d("count")}
+
+    # ------------------------------------------------------------------------------------------------ phase A
+    def _phase_a(self, S):
+        eng, teng, dist_ = self.eng, self.teng, self.tr.distiller
+        main = torch.cuda.current_stream()
+        ev0 = torch.cuda.Event()
+        ev0.record(main)                                     # the teacher may start here: beside the student's trunk
+        N = S.N
+        stu = S.stu
+        shapes, geom, anchors = eng.geometry(stu.img.shape[2], stu.img.shape[3])
+        c = eng.trunk(stu.img, stu.sizes, save=True)
+        c.N, c.sizes, c.hw, c.geom, c.anchors, c.shapes = N, stu.sizes, stu.hw, geom, anchors, shapes
+        eng.rpn_head(c, save=True)
+        # proposal generation (top-k, NMS: latency-bound, a handful of workgroups) beside anchor matching on the second stream
+        side = eng._wgrad_stream()
+        if side is not None:
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                c.props, c.prop_scores, c.prop_count = eng.proposals(c, geom, anchors, stu.hw, N, training=True)
+        else:
+            c.props, c.prop_scores, c.prop_count = eng.proposals(c, geom, anchors, stu.hw, N, training=True)
+        tc = None
+        if S.distill:
+            # The teacher's inference (N = 2, mostly small launches) runs on its own stream beside the student's label-free work
+            # and is ENQUEUED after it (issued first its launches would run alone while the student's are still being queued).
+            tside = S.tside
+            tea = S.tea
+            if tside is not None:
+                tside.wait_event(ev0)
+                with torch.cuda.stream(tside), torch.no_grad():
+                    tc = teng.inference(None, dist_.pseudo_label_threshold, staged=(tea.img, tea.sizes, tea.hw))
+                main.wait_stream(tside)
+            else:
+                with torch.no_grad():
+                    tc = teng.inference(None, dist_.pseudo_label_threshold, staged=(tea.img, tea.sizes, tea.hw))
+        # ground truth per chunk: uploaded labels | none (target-weak alignment rows) | the teacher's pseudo-labels
+        parts, lab0 = [], 0
+        for ch in S.chunks:
+            n = ch["n1"] - ch["n0"]
+            if ch["kind"] == "distill":
+                parts.append({k: tc.pseudo[k] for k in ("boxes", "classes", "count")})
+            elif ch["kind"] == "labeled":
+                parts.append({k: S.gt_lab[k][lab0:lab0 + n] for k in ("boxes", "classes", "count")})
+                lab0 += n
+            else:
+                parts.append(S.gt_none(n))
+        gt = {k: torch.cat([p[k] for p in parts]) for k in ("boxes", "classes", "count")}
+        c.gt = gt
+        _, matched, lists, counts = eng.rpn_match(geom, anchors, gt, N)
+        c.rpn_matched, c.rpn_lists, c.rpn_counts = matched, lists, counts
+        if side is not None:
+            main.wait_stream(side)
+        prep = eng._roi_prepare(c.props, c.prop_count, gt, N)
+        S.h_counts.copy_(torch.cat([counts.view(-1), prep["counts"].view(-1)]).view(torch.uint8), non_blocking=True)
+        return SimpleNamespace(c=c, tc=tc, prep=prep)
+
+    # ------------------------------------------------------------------------------------------------ host phase
+    def _host_draws(self, S, A):
+        """every sampling draw of the iteration on the global CPU generator, in the reference's order"""
+        eng, dist_, model = self.eng, self.tr.distiller, self.tr.model
+        N = S.N
+        both = S.h_counts.view(torch.int32).tolist()
+        rpn_counts = [both[2 * i: 2 * i + 2] for i in range(N)]
+        roi_counts = [both[2 * N + 2 * i: 2 * N + 2 * i + 2] for i in range(N)]
+        U = S.up
+        rsel, rnsel, osel, onsel = U.h("rsel"), U.h("rnsel"), U.h("osel"), U.h("onsel")
+        rows: List[int] = []
+        for ch in S.chunks:
+            n0, n1 = ch["n0"], ch["n1"]
+            if ch["kind"] == "distill":
+                self.teacher.roi_heads.fire_pre()        # the teacher's eval inference re-seeds with the OLD seed
+                dist_.seeder.reset_seed()
+            a, b, _ = eng._sample_host(rpn_counts[n0:n1], RPN_BATCH, RPN_POS_FRAC)
+            rsel[n0:n1], rnsel[n0:n1] = a, b
+            model.roi_heads.fire_pre()                   # ManualSeed pre-hook of the student's roi_heads (aldi/helpers.py:25-26)
+            a, b, oh = eng._sample_host(roi_counts[n0:n1], ROI_BATCH, ROI_POS_FRAC)
+            osel[n0:n1], onsel[n0:n1] = a, b
+            rows += [x + y for x, y in oh]
+            ch["rpn_counts"], ch["roi_counts"] = rpn_counts[n0:n1], roi_counts[n0:n1]
+        off = 0
+        ro = U.h("row_off")
+        for i, r in enumerate(rows):
+            ro[i] = off
+            off += r
+        r0 = 0
+        for ch in S.chunks:
+            r1 = r0 + sum(rows[ch["n0"]:ch["n1"]])
+            ch["r0"], ch["r1"] = r0, r1
+            r0 = r1
+        n_valid = n_fg = 0
+        if S.distill:
+            ch = S.chunks[-1]
+            torch.manual_seed(dist_.seeder.seed)
+            eng._sample_host(ch["roi_counts"], ROI_BATCH, ROI_POS_FRAC)          # the teacher's identical ROI draws (aldi/distill.py:160-162)
+            a, b, dh = eng._sample_host(ch["rpn_counts"], RPN_BATCH, RPN_POS_FRAC)   # fresh sample of get_rpn_losses (aldi/distill.py:200-202)
+            U.h("dsel")[:], U.h("dnsel")[:] = a, b
+            n_fg = sum(x for x, _ in dh)
+            n_valid = sum(x + y for x, y in dh)
+            nvf = U.h("nvf")
+            nvf[0], nvf[1] = n_valid, n_fg
+        return SimpleNamespace(rows=rows, R=sum(rows), n_valid=n_valid, n_fg=n_fg, key=tuple(rows))
+
+    # ------------------------------------------------------------------------------------------------ phase B
+    def _phase_b(self, S, A, Hst):
+        eng, teng, dist_, model = self.eng, self.teng, self.tr.distiller, self.tr.model
+        c, tc, prep = A.c, A.tc, A.prep
+        dev = eng.device
+        main = torch.cuda.current_stream()
+        N = S.N
+        U = S.up
+        U.upload()
+        sumA = c.anchors.shape[0]
+        labels = torch.empty((N, sumA), dtype=torch.int32, device=dev)
+        ops.rpn_apply_sample(labels, sumA, N, c.rpn_lists, U.d("rsel"), U.d("rnsel"), RPN_BATCH)
+        c.rpn_labels = labels
+        oh = [[0, r] for r in Hst.rows]                       # only the row sums are used downstream
+        eng._roi_gather(c, prep, U.d("osel"), U.d("onsel"), oh, c.gt, N, row_off_dev=U.d("row_off"))
+        t_pred = None
+        if S.distill:
+            ch = S.chunks[-1]
+            n0, r0, r1 = ch["n0"], ch["r0"], ch["r1"]
+            rois_t = c.rois[r0:r1].clone()
+            rois_t[:, 0] -= n0
+            tside = S.tside
+            if tside is not None:                              # the teacher's box head on the student's sampled proposals, beside the student's own
+                tside.wait_stream(main)
+                rois_t.record_stream(tside)
+                with torch.cuda.stream(tside), torch.no_grad():
+                    t_pred = teng.box_head_on(tc, rois_t, r1 - r0)
+            else:
+                with torch.no_grad():
+                    t_pred = teng.box_head_on(tc, rois_t, r1 - r0)
+        eng.roi_forward(c)
+        accum = S.accum
+        entries, scales = [], []
+        for ch in S.chunks:
+            n0, n1, r0, r1 = ch["n0"], ch["n1"], ch["r0"], ch["r1"]
+            nc = n1 - n0
+            ch["loss_rpn"] = torch.zeros(2, dtype=torch.float32, device=dev)
+            ch["loss_box"] = torch.zeros(2, dtype=torch.float32, device=dev)
+            ops.rpn_loss(c.geom, [h[n0:n1] for h in c.head], None, c.anchors, labels[n0:n1], c.rpn_matched[n0:n1], c.gt["boxes"][n0:n1],
+                         c.gt["count"][n0:n1], GMAX, nc, 1.0 / (RPN_BATCH * nc), 0.0, 0.0, ch["loss_rpn"])
+            ops.box_loss(c.pred[r0:r1], eng.Cp, eng.K, r1 - r0, c.rois[r0:r1], c.r_cls[r0:r1], c.r_gt[r0:r1], ROI_WEIGHTS, 0.0, 0.0, None, ch["loss_box"])
+            ch["align"], ch["distill"] = {}, None
+            if ch["do_align"]:
+                eng._align_forward_chunk(c, ch)
+            losses = eng.chunk_loss_dict(ch)
+            keep = ch["keep"]
+            if ch["kind"] == "distill":
+                hard = {"loss_cls": dist_.do_hard_cls, "loss_rpn_cls": dist_.do_hard_obj, "loss_rpn_loc": dist_.do_hard_rpn_reg,
+                        "loss_box_reg": dist_.do_hard_roi_reg}
+                if S.tside is not None:
+                    main.wait_stream(S.tside)
+                dl = torch.empty((nc, sumA), dtype=torch.int32, device=dev)
+                ops.rpn_apply_sample(dl, sumA, nc, c.rpn_lists[n0:n1], U.d("dsel"), U.d("dnsel"), RPN_BATCH)
+                eng.distill_forward_chunk(c, ch, tc.head, t_pred, dl, Hst.n_valid, Hst.n_fg, obj_T=float(dist_.obj_temperature),
+                                          cls_T=float(dist_.cls_temperature), kl=dist_.cls_loss_type == "KL", do_obj=dist_.do_obj_dst,
+                                          do_rpn_reg=dist_.do_rpn_reg_dst, do_cls=dist_.do_cls_dst, do_roih_reg=dist_.do_roih_reg_dst,
+                                          counts_dev=U.d("nvf"))
+                out, sc = {}, {}
+                for k, v in losses.items():
+                    out[k] = v if hard.get(k, False) else (v, 0.0)      # the reference's `v * 0.0` (aldi/distill.py:181-186)
+                    sc[k] = (1.0 if hard.get(k, False) else 0.0) / accum
+                if S.has_disc:
+                    out["_da"] = torch.zeros((), device=dev)
+                for k, v in eng.chunk_distill_loss_dict(ch).items():
+                    out[k] = v
+                    sc[k] = 1.0 / accum
+            else:
+                out = losses
+                sc = {k: (1.0 / accum if keep(k) else 0.0) for k in losses}
+            scales.append(sc)
+            for k, v in out.items():
+                if keep(k):
+                    entries.append((f"{k}_{ch['name']}", v))
+        # loss-dict arithmetic (`v * 0.0`, `/ accum`) for all entries in a handful of launches
+        kept = [(n_, v) for n_, v in entries if not isinstance(v, tuple)]
+        masked = [(n_, v[0]) for n_, v in entries if isinstance(v, tuple)]
+        vals = {}
+        if kept:
+            kv = (torch.stack([v for _, v in kept]) / accum).detach()
+            vals.update({n_: kv[i] for i, (n_, _) in enumerate(kept)})
+        if masked:
+            mv = ((torch.stack([v for _, v in masked]) * 0.0) / accum).detach()
+            vals.update({n_: mv[i] for i, (n_, _) in enumerate(masked)})
+        loss_dict = {}
+        for n_, _ in entries:                                  # original key order
+            loss_dict[n_] = loss_dict[n_] + vals[n_] if n_ in loss_dict else vals[n_]
+        c.chunks = S.chunks
+        c.align, c.distill = {}, None
+        eng.backward_fused(c, scales)
+        fields = {k: c[k] for k in ("rpn_labels", "R", "rows", "rois", "r_cls", "r_gt", "r_idx", "pred", "pooled", "fc1", "fc2", "ghead", "gpred") if k in c}
+        return SimpleNamespace(loss_dict=loss_dict, fields=fields, chunks=[dict(ch) for ch in S.chunks])
+
+    # ------------------------------------------------------------------------------------------------ driver
+    def _static_for(self, key):
+        S = self.static.get(key)
+        if S is None:
+            if len(self.static) >= 4:                          # multi-scale input: keep the most recent shapes only
+                self.static.pop(next(iter(self.static)))
+            S = SimpleNamespace(bufs={}, gt_pack=None, up=None, h_counts=None, graph_a=None, A=None, graphs_b={}, none_gt={})
+            self.static[key] = S
+        else:
+            self.static[key] = self.static.pop(key)
+        return S
+
+    def run(self, labeled_weak, labeled_strong, unlabeled_weak, unlabeled_strong):
+        from .model import DevicePseudoLabels
+        from .trainer import _schedule_flags, _teacher_stream, plan_micro_steps
+        tr = self.tr
+        model, dist_ = tr.model, tr.distiller
+        self.eng = eng = model.engine
+        do_align, do_distill = _schedule_flags(tr)
+        plan = plan_micro_steps(labeled_weak, labeled_strong, unlabeled_weak, unlabeled_strong, do_align=do_align, do_distill=do_distill)
+        bs = tr.model_batch_size
+        accum = sum(len(s_ or []) for s_ in (labeled_weak, labeled_strong, unlabeled_weak)) // bs
+        if do_distill and dist_.cls_loss_type not in ("CE", "KL"):
+            raise ValueError("cls_loss_type must be one of {CE, KL}")
+        self.teacher = teacher = (dist_.teacher.module if hasattr(dist_.teacher, "module") else dist_.teacher) if do_distill else None
+        self.teng = teacher.engine if teacher is not None else None
+        dev = eng.device
+        # ---- phase 0: describe the chunks, stage the inputs into their fixed buffers
+        images, lab_insts, chunks, n0 = [], [], [], 0
+        da = model.cfg.DOMAIN_ADAPT.ALIGN
+        for row in plan:
+            n1 = n0 + len(row.data)
+            kind = "distill" if row.teacher_data is not None else ("labeled" if row.kwargs.get("labeled", True) else "unlabeled")
+            chunks.append(dict(name=row.name, kind=kind, n0=n0, n1=n1, labeled=row.kwargs.get("labeled", True),
+                               do_align=row.kwargs.get("do_align", False) and kind != "distill", da_weights=(da.IMG_DA_WEIGHT, da.INS_DA_WEIGHT),
+                               keep=row.keep))
+            images += [d["image"] for d in row.data]
+            if kind == "labeled":
+                lab_insts += [as_record(d["instances"]) for d in row.data]
+            n0 = n1
+        N = n0
+        key = (tuple((ch["name"], ch["n1"] - ch["n0"]) for ch in chunks), tuple(tuple(im.shape[1:]) for im in images),
+               tuple(tuple(d["image"].shape[1:]) for d in (unlabeled_weak or [])) if do_distill else ())
+        S = self._static_for(key)
+        S.N, S.chunks, S.accum, S.distill, S.has_disc = N, chunks, accum, do_distill, do_align
+        S.tside = _teacher_stream(dev) if do_distill else None
+        S.stu = self._stage_images(S, "student", images)
+        S.tea = self._stage_images(S, "teacher", [d["image"] for d in unlabeled_weak]) if do_distill else None
+        S.gt_lab = self._stage_gt(S, lab_insts) if lab_insts else None
+
+        def gt_none(n):
+            if n not in S.none_gt:
+                S.none_gt[n] = {"boxes": torch.zeros((n, GMAX, 4), dtype=torch.float32, device=dev),
+                                "classes": torch.zeros((n, GMAX), dtype=torch.int32, device=dev), "count": torch.zeros((n,), dtype=torch.int32, device=dev)}
+            return S.none_gt[n]
+        S.gt_none = gt_none
+        if S.up is None:
+            nd = (chunks[-1]["n1"] - chunks[-1]["n0"]) if do_distill else 1
+            S.up = _Packed([("rsel", (N, 2, RPN_BATCH), torch.int32), ("rnsel", (N, 2), torch.int32), ("osel", (N, 2, ROI_BATCH), torch.int32),
+                            ("onsel", (N, 2), torch.int32), ("row_off", (N,), torch.int32), ("dsel", (nd, 2, RPN_BATCH), torch.int32),
+                            ("dnsel", (nd, 2), torch.int32), ("nvf", (2,), torch.int32)], dev)
+            S.h_counts = _pinned(4 * N * 4)
+        # (the ViTDet / ConvNeXt trunks draw their stochastic-depth masks on the host every step: their launches are not replayable as recorded)
+        use_graph = self.graph_enabled and self.steps_done >= self.warmup and type(eng) is RCNN
+        # ---- phase A
+        if use_graph:
+            if S.graph_a is None:
+                S.graph_a, S.A = self._capture(lambda: self._phase_a(S))
+            S.graph_a.replay()
+            self.stats["replays_a"] += 1
+            A = S.A
+        else:
+            A = self._phase_a(S)
+        c, tc = A.c, A.tc
+        torch.cuda.current_stream().synchronize()                  # the ONE device->host sync: list lengths for the host RNG
+        # ---- host: all sampling draws
+        Hst = self._host_draws(S, A)
+        # ---- phase B
+        graph_b = use_graph and getattr(eng, "grad_ready", None) is None
+        if graph_b:
+            ent = S.graphs_b.get(Hst.key)
+            if ent is None:
+                if len(S.graphs_b) >= 4:
+                    S.graphs_b.pop(next(iter(S.graphs_b)))
+                ent = self._capture(lambda: self._phase_b(S, A, Hst))
+                S.graphs_b[Hst.key] = ent
+            ent[0].replay()
+            self.stats["replays_b"] += 1
+            B = ent[1]
+            c.update(B.fields)
+            for ch, saved in zip(S.chunks, B.chunks):
+                keep_host = {k: ch[k] for k in ("rpn_counts", "roi_counts")}
+                ch.update(saved)
+                ch.update(keep_host)
+            c.chunks = S.chunks
+        else:
+            B = self._phase_b(S, A, Hst)
+            if not use_graph:
+                self.stats["eager"] += 1
+        self.steps_done += 1
+        if do_distill:
+            teacher._last_inference = tc
+            labels_ = [DevicePseudoLabels(tc.sizes[i], tc.pseudo, i) for i in range(len(unlabeled_weak))]
+            for dw, ds, lab in zip(unlabeled_weak, unlabeled_strong, labels_):
+                dw["instances"] = lab
+                ds["instances"] = lab
+        model._last_fused = c
+        return dict(B.loss_dict)
+
+    def _capture(self, fn):
+        """record `fn`'s launches (all streams it forks to and joins from) into one hipGraph; its tensors stay allocated in the
+        graphs' shared pool, so the Python objects `fn` returns remain valid views of what every replay recomputes"""
+        if self.pool is None:
+            self.pool = torch.cuda.graph_pool_handle()
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, pool=self.pool, capture_error_mode="thread_local"):
+            out = fn()
+        self.stats["captures"] += 1
+        return g, out

@@ -313,9 +313,10 @@ def detections(pred, Cp, K, props, pcount, P, N, img_hw, weights4, score_thresh,
 
 
 # ------------------------------------------------------------------------------- ALDI losses
-def rpn_distill_loss(geom, s_head, t_head, grad, labels, N, obj_T, n_valid, n_fg, do_obj, do_reg, grad_scale, loss2):
-    L.call("aldi_rpn_distill_loss", C.byref(geom), ptrs(s_head), ptrs(t_head), ptrs(grad), _p(labels), N, obj_T, n_valid, n_fg,
-           int(do_obj), int(do_reg), grad_scale, _p(loss2), stream_ptr())
+def rpn_distill_loss(geom, s_head, t_head, grad, labels, N, obj_T, n_valid, n_fg, do_obj, do_reg, grad_scale, loss2, counts_dev=None):
+    """counts_dev: device int32[2] {n_valid, n_fg} overriding the two host ints (graph-captured steps)"""
+    L.call("aldi_rpn_distill_loss", C.byref(geom), ptrs(s_head), ptrs(t_head), ptrs(grad), _p(labels), N, obj_T, int(n_valid), int(n_fg),
+           _p(counts_dev), int(do_obj), int(do_reg), grad_scale, _p(loss2), stream_ptr())
 
 
 def roih_distill_loss(s_pred, t_pred, Cp, K, R, cls_T, kl, do_cls, do_reg, grad_scale, grad, loss2):

@@ -438,7 +438,12 @@ class _ALDITrainer:
                 self._reducer = BucketedReducer(self.model.weights.grad)
                 eng.grad_ready = self._reducer.ready
             try:
-                return fused_run_model(self, *data)
+                if os.environ.get("ALDI_FUSED_LEGACY", "0") == "1":
+                    return fused_run_model(self, *data)
+                if getattr(self, "_fused_step", None) is None:
+                    from .fused_step import FusedStep
+                    self._fused_step = FusedStep(self)
+                return self._fused_step.run(*data)
             finally:
                 eng.grad_ready = None
         return run_model_labeled_unlabeled(self, *data)

@@ -253,11 +253,12 @@ int aldi_detections(const float* pred, int Cp, int K, const float* props, const 
 /* ALDIDistiller.get_rpn_losses, aldi/distill.py:193-229, including the reference's index-order
  * behaviour: mask position q of the (N, sumA) label tensor selects position q of
  * cat([flatten(raw_level)]) with raw_level = (N, A|4A, H, W).  heads are fp32 [N][H][W][C].
- * n_valid / n_fg: number of labels >= 0 / == 1 (known to the host that drew the sample).
+ * n_valid / n_fg: number of labels >= 0 / == 1 (known to the host that drew the sample); when n_valid_fg_dev is set the two
+ * counts are read from that DEVICE int[2] instead (a launch recorded in a hipGraph must not bake in per-step values).
  * loss2 += {loss_obj_bce, loss_rpn_l1}; grad[level] += d(loss*grad_scale)/d(student head). */
 int aldi_rpn_distill_loss(const aldi_rpn_geom* gm, float* const* student_head, float* const* teacher_head, float* const* grad,
-                          const int* labels, int N, float obj_temperature, int n_valid, int n_fg, int do_obj, int do_reg,
-                          float grad_scale, float* loss2, aldi_stream_t stream);
+                          const int* labels, int N, float obj_temperature, int n_valid, int n_fg, const int* n_valid_fg_dev,
+                          int do_obj, int do_reg, float grad_scale, float* loss2, aldi_stream_t stream);
 /* ALDIDistiller.get_roih_losses, aldi/distill.py:231-278 (kl = 0: soft CE, 1: KL batchmean).
  * pred rows fp32 [R][Cp]: [0,K] logits then 4K deltas. loss2 += {loss_cls_ce, loss_roih_l1}. */
 int aldi_roih_distill_loss(const float* student_pred, const float* teacher_pred, int Cp, int K, int R, float cls_temperature,

@@ -73,8 +73,10 @@ def test_partial_and_mismatched_state_dicts(tmp_path):
     ck = DetectionCheckpointer(m, "")
     ck.load(str(tmp_path / "x.pth"))
     assert float(m.sd["a.weight"].sum()) == 0.0 and float(m.sd["b.bias"][0]) == 1.5      # wrong shape skipped, kept
-    with pytest.raises(NotImplementedError):
-        ck.load("R-50.pkl")
+    with pytest.raises(AssertionError):
+        ck.load("R-50.pkl")                                  # a missing file, of either format
+    with pytest.raises(AssertionError):
+        ck.load("detectron2://ImageNetPretrained/MSRA/R-50.pkl")   # model-zoo URLs need a local copy (no network)
     assert ck.load("") == {}
 
 
@@ -194,3 +196,63 @@ def test_best_checkpoint_per_test_set(tmp_path):
     finally:
         type(tr).model = T.DefaultTrainer.model
     assert saved == [("a_val_model_best", 1), ("b_val_model_best", 1), ("a_val_model_best", 3)]
+
+
+# ---- model-zoo .pkl files (reference configs/Base-RCNN-FPN.yaml:3: detectron2://ImageNetPretrained/MSRA/R-50.pkl)
+def test_c2_name_conversion_rules():
+    from aldi_amd.checkpoint import convert_c2_names
+    src = ["conv1_w", "res_conv1_bn_s", "res_conv1_bn_b", "res2_0_branch2a_w", "res2_0_branch2a_bn_s", "res2_0_branch2b_bn_b",
+           "res2_0_branch1_w", "res3_1_branch2c_w", "fc1000_w", "fc1000_b", "res4_5_branch2b_bn_rm", "res4_5_branch2b_bn_riv"]
+    assert convert_c2_names(src) == ["stem.conv1.weight", "stem.conv1.norm.weight", "stem.conv1.norm.bias", "res2.0.conv1.weight",
+                                     "res2.0.conv1.norm.weight", "res2.0.conv2.norm.bias", "res2.0.shortcut.weight", "res3.1.conv3.weight",
+                                     "fc1000.weight", "fc1000.bias", "res4.5.conv2.norm.running_mean", "res4.5.conv2.norm.running_var"]
+
+
+def test_msra_style_pkl_loads_into_the_r50_layout(tmp_path):
+    """a Caffe2-named, affine-only backbone file (the MSRA R-50 layout) built from known weights lands on the right detectron2
+    keys; heads / FPN keep the model's own values; missing FrozenBN statistics become mean 0 / var 1"""
+    import pickle
+    import numpy as np
+    from aldi_amd import synthetic as syn
+    from aldi_amd.arch import ParamLayout
+    lay = ParamLayout(8)
+    sd = syn.init_state_dict(8, seed=3)
+
+    class M:
+        def __init__(self):
+            self.sd = {k: torch.zeros_like(sd[k]) + 7.0 for k in lay.state_dict_keys()}
+
+        def state_dict(self):
+            return dict(self.sd)
+
+        def load_state_dict(self, new):
+            self.sd = dict(new)
+    blobs = {}
+    bu = "backbone.bottom_up."
+    back = {"stem.conv1": "conv1", "shortcut": "branch1", "conv1": "branch2a", "conv2": "branch2b", "conv3": "branch2c"}
+    for k, v in sd.items():
+        if not k.startswith(bu) or "running_" in k:
+            continue
+        parts = k[len(bu):].split(".")
+        if parts[0] == "stem":
+            base = "conv1" if parts[2] == "weight" else "res_conv1_bn"
+            name = base + {"weight": "_w" if base == "conv1" else "_s", "bias": "_b"}[parts[-1]]
+        else:
+            base = f"{parts[0]}_{parts[1]}_{back[parts[2]]}"
+            name = base + ("_w" if parts[3] == "weight" else ("_bn_s" if parts[-1] == "weight" else "_bn_b"))
+        blobs[name] = v.numpy()
+    blobs["fc1000_w"] = np.zeros((1000, 2048), np.float32)
+    with open(tmp_path / "R-50.pkl", "wb") as f:
+        pickle.dump({"model": blobs, "__author__": "Caffe2", "matching_heuristics": True}, f)
+    m = M()
+    ret = DetectionCheckpointer(m, "").load(str(tmp_path / "R-50.pkl"), checkpointables=[])
+    assert ret["unmatched_checkpoint_keys"] == ["fc1000_w"]
+    for k in lay.state_dict_keys():
+        if k.startswith(bu) and k.endswith("running_mean"):
+            assert float(m.sd[k].abs().max()) == 0.0
+        elif k.startswith(bu) and k.endswith("running_var"):
+            assert bool((m.sd[k] == 1).all())
+        elif k.startswith(bu):
+            assert torch.equal(m.sd[k], sd[k]), k
+        else:
+            assert bool((m.sd[k] == 7.0).all()), k                          # FPN / RPN / ROI heads untouched
