@@ -25,11 +25,11 @@ class _DiscriminatorView:
 
 
 class ConvDiscriminator(_DiscriminatorView):
-    """Conv2d(C, hidden, 3, padding=0) -> ReLU -> AdaptiveAvgPool2d(1) -> Flatten -> Linear(hidden, 1) (aldi/align.py:103-119)."""
+    """[Conv2d(., hidden_i, 3, padding=0) -> ReLU]* -> AdaptiveAvgPool2d(1) -> Flatten -> Linear(., 1) (aldi/align.py:103-119)."""
 
 
 class FCDiscriminator(_DiscriminatorView):
-    """Flatten -> Linear(C, hidden) -> ReLU -> Linear(hidden, 1) (aldi/align.py:121-135)."""
+    """Flatten -> [Linear(., hidden_i) -> ReLU]* -> Linear(., 1) (aldi/align.py:121-135)."""
 
 
 @ALIGN_MIXIN_REGISTRY.register()
@@ -40,14 +40,9 @@ class AlignMixin(GeneralizedRCNN):
         self.img_da_layer = a.IMG_DA_LAYER
         self.img_da_weight = a.IMG_DA_WEIGHT
         self.ins_da_weight = a.INS_DA_WEIGHT
-        if a.IMG_DA_ENABLED:
-            assert a.IMG_DA_LAYER == "p2" and list(a.IMG_DA_HIDDEN_DIMS) == [256] and a.IMG_DA_INPUT_DIM == 256, \
-                "HIP path implements the reference default image discriminator (p2, 256 -> [256] -> 1)"
-        if a.INS_DA_ENABLED:
-            assert list(a.INS_DA_HIDDEN_DIMS) == [1024] and a.INS_DA_INPUT_DIM == 1024, \
-                "HIP path implements the reference default instance discriminator (1024 -> [1024] -> 1)"
-        self.img_align = ConvDiscriminator(self, "img_align", ("model.0", "model.4")) if a.IMG_DA_ENABLED else None
-        self.ins_align = FCDiscriminator(self, "ins_align", ("model.1", "model.3")) if a.INS_DA_ENABLED else None
+        # any FPN level / hidden_dims list (aldi/align.py:22-52): the engine builds the layer chain from the layout's names
+        self.img_align = ConvDiscriminator(self, "img_align", tuple(n[len("img_align."):] for n in self.engine.img_da_layers)) if a.IMG_DA_ENABLED else None
+        self.ins_align = FCDiscriminator(self, "ins_align", tuple(n[len("ins_align."):] for n in self.engine.ins_da_layers)) if a.INS_DA_ENABLED else None
 
     def forward(self, *args, do_align=False, labeled=True, **kwargs):
         output = super().forward(*args, do_align=do_align, labeled=labeled, **kwargs)

@@ -71,15 +71,47 @@ def d2_convs(num_classes: int) -> "OrderedDict[str, Conv]":
     return s
 
 
-def disc_convs(img: bool, ins: bool) -> "OrderedDict[str, Conv]":
-    """Discriminator modules added by AlignMixin (reference aldi/align.py:41-42,103-135)."""
+FPN_LEVELS = ("p2", "p3", "p4", "p5", "p6")
+
+
+def da_spec(img, ins):
+    """Normalised discriminator specs.  `img` / `ins`: False | True (the reference defaults, aldi/config.py:41-49) | dict with
+    the DOMAIN_ADAPT.ALIGN keys in lower case: img {layer, input_dim, hidden_dims}, ins {input_dim, hidden_dims}."""
+    def norm(v, dflt):
+        if not v:
+            return None
+        d = dict(dflt)
+        if isinstance(v, dict):
+            d.update(v)
+        d["hidden_dims"] = [int(x) for x in d["hidden_dims"]]
+        return d
+    i = norm(img, dict(layer="p2", input_dim=256, hidden_dims=[256]))
+    if i is not None and i["layer"] not in FPN_LEVELS:
+        raise ValueError(f"DOMAIN_ADAPT.ALIGN.IMG_DA_LAYER must be one of {FPN_LEVELS}, got {i['layer']}")
+    return i, norm(ins, dict(input_dim=1024, hidden_dims=[1024]))
+
+
+def disc_convs(img, ins) -> "OrderedDict[str, Conv]":
+    """Discriminator modules added by AlignMixin (reference aldi/align.py:41-42,103-135) for ANY hidden_dims list, under the
+    nn.Sequential indices of the reference: ConvDiscriminator = [Conv2d(k=3, no padding), ReLU] per hidden dim, then
+    AdaptiveAvgPool2d, Flatten, Linear(., 1)  ->  convs at model.0, model.2, ..., the Linear at model.(2n+2);
+    FCDiscriminator = Flatten, [Linear, ReLU] per hidden dim, Linear(., 1)  ->  model.1, model.3, ..., model.(2n+1)."""
+    img, ins = da_spec(img, ins)
     s: "OrderedDict[str, Conv]" = OrderedDict()
     if img:
-        s["img_align.model.0"] = Conv("img_align.model.0", 256, 256, 3, 1, 0, bias=True)
-        s["img_align.model.4"] = Conv("img_align.model.4", 256, 1, 0, bias=True)
+        prev = img["input_dim"]
+        for i, d in enumerate(img["hidden_dims"]):
+            s[f"img_align.model.{2 * i}"] = Conv(f"img_align.model.{2 * i}", prev, d, 3, 1, 0, bias=True)
+            prev = d
+        n = len(img["hidden_dims"])
+        s[f"img_align.model.{2 * n + 2}"] = Conv(f"img_align.model.{2 * n + 2}", prev, 1, 0, bias=True)
     if ins:
-        s["ins_align.model.1"] = Conv("ins_align.model.1", 1024, 1024, 0, bias=True)
-        s["ins_align.model.3"] = Conv("ins_align.model.3", 1024, 1, 0, bias=True)
+        prev = ins["input_dim"]
+        for i, d in enumerate(ins["hidden_dims"]):
+            s[f"ins_align.model.{2 * i + 1}"] = Conv(f"ins_align.model.{2 * i + 1}", prev, d, 0, bias=True)
+            prev = d
+        n = len(ins["hidden_dims"])
+        s[f"ins_align.model.{2 * n + 1}"] = Conv(f"ins_align.model.{2 * n + 1}", prev, 1, 0, bias=True)
     return s
 
 
@@ -110,7 +142,7 @@ class Packed:
         return (self.rows, self.kk, self.kk, self.cin)
 
 
-def engine_tensors(num_classes: int, img_da: bool, ins_da: bool) -> "OrderedDict[str, Packed]":
+def engine_tensors(num_classes: int, img_da=False, ins_da=False) -> "OrderedDict[str, Packed]":
     d2 = d2_convs(num_classes)
     out: "OrderedDict[str, Packed]" = OrderedDict()
     for name, c in d2.items():
@@ -132,8 +164,9 @@ def engine_tensors(num_classes: int, img_da: bool, ins_da: bool) -> "OrderedDict
 class ParamLayout:
     """Flat fp32 layout: [trainable weights+biases | frozen weights | bn_w | bn_b | bn_mean | bn_var]."""
 
-    def __init__(self, num_classes: int, img_da: bool = False, ins_da: bool = False):
+    def __init__(self, num_classes: int, img_da=False, ins_da=False):
         self.num_classes = num_classes
+        self.img_da, self.ins_da = da_spec(img_da, ins_da)
         self.d2 = d2_convs(num_classes)
         self.d2.update(disc_convs(img_da, ins_da))
         self.t = engine_tensors(num_classes, img_da, ins_da)

@@ -248,8 +248,15 @@ class RCNN:
         # the host only runs tiny torch-CPU ops (RNG draws, index packing); on a many-core host the default
         # intra-op thread pool makes torch.randperm(268k) ~20x slower than one thread
         torch.set_num_threads(1)
-        self.has_img_da = "img_align.model.0" in weights.layout.t
-        self.has_ins_da = "ins_align.model.1" in weights.layout.t
+        # discriminator layers in nn.Sequential order (hidden convs / linears, the last entry is the 1-logit Linear) and the FPN
+        # level the image-level one reads (aldi/align.py:22-52)
+        idx = lambda n: int(n.rsplit(".", 1)[1])
+        names = list(getattr(weights.layout, "t", {}))
+        self.img_da_layers = sorted((n for n in names if n.startswith("img_align.model.")), key=idx)
+        self.ins_da_layers = sorted((n for n in names if n.startswith("ins_align.model.")), key=idx)
+        self.has_img_da, self.has_ins_da = bool(self.img_da_layers), bool(self.ins_da_layers)
+        spec = getattr(weights.layout, "img_da", None)
+        self.img_da_level = ("p2", "p3", "p4", "p5", "p6").index(spec["layer"]) if spec else 0
 
     # ------------------------------------------------------------------ inputs
     def stage_images(self, images: Sequence[torch.Tensor]):
@@ -581,18 +588,30 @@ class RCNN:
         label = 1.0 if ch["labeled"] else 0.0
         n0, n1, r0, r1 = ch["n0"], ch["n1"], ch["r0"], ch["r1"]
         if self.has_img_da:
-            a1 = self.conv(c.P[0][n0:n1], "img_align.model.0", relu=True)
-            pooled = ops.avgpool(a1)
-            logit = self.conv(pooled, "img_align.model.4", want_f32=True)
+            acts, pooled, logit = self._img_disc_forward(c.P[self.img_da_level][n0:n1])
             ch["loss_da_img"] = torch.zeros(1, dtype=torch.float32, device=dev)
             ops.domain_bce(logit, logit.shape[-1], n1 - n0, label, ch["da_weights"][0], 0.0, None, ch["loss_da_img"])
-            ch["align"]["img"] = (a1, pooled, logit)
+            ch["align"]["img"] = (acts, pooled, logit)
         if self.has_ins_da and r1 > r0:
-            h = self.conv(c.fc2[r0:r1], "ins_align.model.1", relu=True)
-            logit = self.conv(h, "ins_align.model.3", want_f32=True)
+            acts, logit = self._ins_disc_forward(c.fc2[r0:r1])
             ch["loss_da_ins"] = torch.zeros(1, dtype=torch.float32, device=dev)
             ops.domain_bce(logit, logit.shape[-1], r1 - r0, label, ch["da_weights"][1], 0.0, None, ch["loss_da_ins"])
-            ch["align"]["ins"] = (h, logit)
+            ch["align"]["ins"] = (acts, logit)
+
+    def _img_disc_forward(self, feat: torch.Tensor):
+        """ConvDiscriminator (aldi/align.py:103-119): [Conv2d(k=3, no padding) + ReLU] per hidden dim -> global average -> Linear"""
+        acts = [feat]
+        for name in self.img_da_layers[:-1]:
+            acts.append(self.conv(acts[-1], name, relu=True))
+        pooled = ops.avgpool(acts[-1])
+        return acts, pooled, self.conv(pooled, self.img_da_layers[-1], want_f32=True)
+
+    def _ins_disc_forward(self, feat: torch.Tensor):
+        """FCDiscriminator (aldi/align.py:121-135): [Linear + ReLU] per hidden dim -> Linear"""
+        acts = [feat]
+        for name in self.ins_da_layers[:-1]:
+            acts.append(self.conv(acts[-1], name, relu=True))
+        return acts, self.conv(acts[-1], self.ins_da_layers[-1], want_f32=True)
 
     def distill_forward_chunk(self, c: Ctx, ch: dict, teacher_head, teacher_pred, labels, n_valid, n_fg, **kw):
         """distillation losses of one chunk of a fused forward (teacher tensors cover exactly that chunk)"""
@@ -669,15 +688,15 @@ class RCNN:
             label = 1.0 if ch["labeled"] else 0.0
             al = dict(n0=n0, n1=n1, r0=r0, r1=r1)
             if "img" in ch["align"]:
-                a1, pooled, logit = ch["align"]["img"]
+                acts, pooled, logit = ch["align"]["img"]
                 glog = torch.empty(logit.shape, dtype=T, device=dev)
                 ops.domain_bce(logit, logit.shape[-1], nc, label, ch["da_weights"][0], sc("loss_da_img"), glog, scratch)
-                al["img"] = (a1, pooled, glog)
+                al["img"] = (acts, pooled, glog)
             if "ins" in ch["align"]:
-                h, logit = ch["align"]["ins"]
+                acts, logit = ch["align"]["ins"]
                 glog = torch.empty(logit.shape, dtype=T, device=dev)
                 ops.domain_bce(logit, logit.shape[-1], r1 - r0, label, ch["da_weights"][1], sc("loss_da_ins"), glog, scratch)
-                al["ins"] = (h, glog)
+                al["ins"] = (acts, glog)
             if "img" in al or "ins" in al:
                 align_list.append(al)
         self._backward_trunk(c, align_list)
@@ -687,18 +706,15 @@ class RCNN:
         dev = self.device
         label = 1.0 if labeled else 0.0
         if self.has_img_da:
-            a1 = self.conv(c.P[0], "img_align.model.0", relu=True)
-            pooled = ops.avgpool(a1)
-            logit = self.conv(pooled, "img_align.model.4", want_f32=True)
+            acts, pooled, logit = self._img_disc_forward(c.P[self.img_da_level])
             c.loss_da_img = torch.zeros(1, dtype=torch.float32, device=dev)
             ops.domain_bce(logit, logit.shape[-1], c.N, label, da_weights[0], 0.0, None, c.loss_da_img)
-            c.align["img"] = (a1, pooled, logit)
+            c.align["img"] = (acts, pooled, logit)
         if self.has_ins_da and c.R > 0:
-            h = self.conv(c.fc2, "ins_align.model.1", relu=True)
-            logit = self.conv(h, "ins_align.model.3", want_f32=True)
+            acts, logit = self._ins_disc_forward(c.fc2)
             c.loss_da_ins = torch.zeros(1, dtype=torch.float32, device=dev)
             ops.domain_bce(logit, logit.shape[-1], c.R, label, da_weights[1], 0.0, None, c.loss_da_ins)
-            c.align["ins"] = (h, logit)
+            c.align["ins"] = (acts, logit)
 
     def distill_forward(self, c: Ctx, teacher_head: List[torch.Tensor], teacher_pred: torch.Tensor, labels: torch.Tensor,
                         n_valid: int, n_fg: int, *, obj_T: float, cls_T: float, kl: bool,
@@ -871,15 +887,15 @@ class RCNN:
                 roi_d(False, d["do_roih_reg"], sc("loss_roih_l1"))
         label = 1.0 if c.labeled else 0.0
         if "img" in c.align:
-            a1, pooled, logit = c.align["img"]
+            acts, pooled, logit = c.align["img"]
             glog = torch.empty(logit.shape, dtype=T, device=dev)
             ops.domain_bce(logit, logit.shape[-1], c.N, label, c.da_weights[0], sc("loss_da_img"), glog, scratch)
-            c.align["img"] = (a1, pooled, glog)
+            c.align["img"] = (acts, pooled, glog)
         if "ins" in c.align:
-            h, logit = c.align["ins"]
+            acts, logit = c.align["ins"]
             glog = torch.empty(logit.shape, dtype=T, device=dev)
             ops.domain_bce(logit, logit.shape[-1], c.R, label, c.da_weights[1], sc("loss_da_ins"), glog, scratch)
-            c.align["ins"] = (h, glog)
+            c.align["ins"] = (acts, glog)
         al = dict(n0=0, n1=c.N, r0=0, r1=c.R, **c.align)
         self._backward_trunk(c, [al] if c.align else [])
 
@@ -895,14 +911,17 @@ class RCNN:
             for al in align_list:
                 if "ins" not in al:
                     continue
-                h, glog = al["ins"]
+                acts, g_ = al["ins"]
                 r0, r1 = al["r0"], al["r1"]
-                self._wgrad("ins_align.model.3", h, glog)
-                g_h = ops.conv2d(glog, W.wt("ins_align.model.3"), mask=h)
-                self._wgrad("ins_align.model.1", c.fc2[r0:r1], g_h)
                 if g_extra is None:
                     g_extra = torch.zeros((c.R, 1, 1, FC_DIM), dtype=T, device=dev)
-                ops.conv2d(g_h, W.wt("ins_align.model.1", negate=True), out=g_extra[r0:r1])
+                L_ = self.ins_da_layers
+                for i in range(len(L_) - 1, -1, -1):             # last Linear first; the gradient-reversal layer sits below layer 0
+                    self._wgrad(L_[i], acts[i], g_)
+                    if i == 0:
+                        ops.conv2d(g_, W.wt(L_[0], negate=True), out=g_extra[r0:r1])
+                    else:
+                        g_ = ops.conv2d(g_, W.wt(L_[i]), mask=acts[i])      # acts[i] is the ReLU output of layer i-1
             gpred = ops.cast_from_f32(c.gpred[:c.R], T).view(c.R, 1, 1, self.Cp)
             self._wgrad("box_pred", c.fc2, gpred)
             g_fc2 = ops.conv2d(gpred, W.wt("box_pred"), mask=c.fc2, res=g_extra, res_mode=1 if g_extra is not None else 0)
@@ -921,20 +940,30 @@ class RCNN:
             g_t = ops.conv2d(gh, W.wt("rpn_head_out"), mask=c.rpn_t[l])
             self._wgrad("proposal_generator.rpn_head.conv", c.P[l], g_t)
             gP.append(ops.conv2d(g_t, W.wt("proposal_generator.rpn_head.conv"), pad=1))
-        ops.subsample2_bwd(gP[4], gP[3])                               # p6 = p5[:, ::2, ::2]
         for l in range(4):
             ops.add_f32(gP[l], gP_roi[l], gP[l])
-        # ---- image-level discriminator behind the gradient-reversal layer
+        # ---- image-level discriminator behind the gradient-reversal layer (on any of p2..p6)
         for al in align_list:
             if "img" not in al:
                 continue
-            a1, pooled, glog = al["img"]
+            acts, pooled, glog = al["img"]
             n0, n1 = al["n0"], al["n1"]
-            self._wgrad("img_align.model.4", pooled, glog)
-            g_pooled = ops.conv2d(glog, W.wt("img_align.model.4"))
-            g_a1 = ops.avgpool_bwd(g_pooled, a1)
-            self._wgrad("img_align.model.0", c.P[0][n0:n1], g_a1)
-            ops.conv2d(g_a1, W.wt("img_align.model.0", negate=True), pad=2, res=gP[0][n0:n1], res_mode=1, out=gP[0][n0:n1])
+            L_ = self.img_da_layers
+            lvl = self.img_da_level
+            self._wgrad(L_[-1], pooled, glog)
+            g_pooled = ops.conv2d(glog, W.wt(L_[-1], negate=len(L_) == 1))
+            if len(L_) == 1:                                     # no hidden layer: the reversed gradient of the average pool itself
+                hw = acts[0].shape[1] * acts[0].shape[2]
+                gP[lvl][n0:n1] += (g_pooled.float() / hw).to(T)
+                continue
+            g_ = ops.avgpool_bwd(g_pooled, acts[-1])             # through the average pool and the last hidden ReLU
+            for i in range(len(L_) - 2, -1, -1):
+                self._wgrad(L_[i], acts[i], g_)
+                if i == 0:
+                    ops.conv2d(g_, W.wt(L_[0], negate=True), pad=2, res=gP[lvl][n0:n1], res_mode=1, out=gP[lvl][n0:n1])
+                else:
+                    g_ = ops.conv2d(g_, W.wt(L_[i]), pad=2, mask=acts[i])
+        ops.subsample2_bwd(gP[4], gP[3])                               # p6 = p5[:, ::2, ::2]
         # ---- FPN
         gprev = {}
         for i, lvl in enumerate((2, 3, 4, 5)):

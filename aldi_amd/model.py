@@ -104,8 +104,11 @@ class GeneralizedRCNN:
         self.cfg = cfg
         self.num_classes = cfg.MODEL.ROI_HEADS.NUM_CLASSES
         da = cfg.get("DOMAIN_ADAPT", {}).get("ALIGN", {}) if hasattr(cfg, "get") else {}
-        self._img_da = bool(da.get("IMG_DA_ENABLED", False))
-        self._ins_da = bool(da.get("INS_DA_ENABLED", False))
+        # False, or the discriminator's shape (any FPN level / hidden_dims list: aldi/align.py:22-52, aldi/config.py:41-49)
+        self._img_da = dict(layer=da.get("IMG_DA_LAYER", "p2"), input_dim=da.get("IMG_DA_INPUT_DIM", 256),
+                            hidden_dims=list(da.get("IMG_DA_HIDDEN_DIMS", [256]))) if da.get("IMG_DA_ENABLED", False) else False
+        self._ins_da = dict(input_dim=da.get("INS_DA_INPUT_DIM", 1024),
+                            hidden_dims=list(da.get("INS_DA_HIDDEN_DIMS", [1024]))) if da.get("INS_DA_ENABLED", False) else False
         self.device = torch.device(cfg.MODEL.DEVICE)
         if self.device.type != "cuda":
             raise RuntimeError("aldi_amd runs on the MI355X HIP path only (MODEL.DEVICE must be cuda); there is no CPU fallback")

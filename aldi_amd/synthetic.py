@@ -12,7 +12,7 @@ import torch
 from .arch import d2_convs, disc_convs
 
 
-def init_state_dict(num_classes: int, seed: int = 1, head_gain: float = 12.0, img_da: bool = False, ins_da: bool = False,
+def init_state_dict(num_classes: int, seed: int = 1, head_gain: float = 12.0, img_da=False, ins_da=False,
                     input_rms: float = 75.0) -> "OrderedDict[str, torch.Tensor]":
     """Random-init weights of the R50-FPN Faster R-CNN in Detectron2 state_dict layout.
 

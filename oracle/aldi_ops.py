@@ -97,16 +97,31 @@ def mask_hard_losses(hard_losses: Dict[str, torch.Tensor], do_hard_cls, do_hard_
 # alignment
 # ----------------------------------------------------------------------------
 
-def conv_discriminator(x, w1, b1, w2, b2):
-    """reference aldi/align.py:103-119: Conv2d(k=3, pad 0) -> ReLU -> AdaptiveAvgPool2d(1) -> Flatten -> Linear."""
-    h = F.relu(F.conv2d(x, w1, b1))
+def conv_discriminator(x, *params):
+    """reference aldi/align.py:103-119: [Conv2d(k=3, pad 0) -> ReLU] per hidden dim -> AdaptiveAvgPool2d(1) -> Flatten -> Linear.
+    params = (w, b) pairs in module order, the last pair is the Linear."""
+    h = x
+    for i in range(0, len(params) - 2, 2):
+        h = F.relu(F.conv2d(h, params[i], params[i + 1]))
     h = h.mean(dim=(2, 3))
-    return F.linear(h, w2, b2)
+    return F.linear(h, params[-2], params[-1])
 
 
-def fc_discriminator(x, w1, b1, w2, b2):
-    """reference aldi/align.py:121-135: Flatten -> Linear -> ReLU -> Linear."""
-    return F.linear(F.relu(F.linear(x.flatten(1), w1, b1)), w2, b2)
+def fc_discriminator(x, *params):
+    """reference aldi/align.py:121-135: Flatten -> [Linear -> ReLU] per hidden dim -> Linear."""
+    h = x.flatten(1)
+    for i in range(0, len(params) - 2, 2):
+        h = F.relu(F.linear(h, params[i], params[i + 1]))
+    return F.linear(h, params[-2], params[-1])
+
+
+def disc_params(P: dict, prefix: str):
+    """(w, b) pairs of one discriminator from a state_dict, in nn.Sequential index order"""
+    idx = sorted({int(k.split(".")[2]) for k in P if k.startswith(prefix + ".model.")})
+    out = []
+    for i in idx:
+        out += [P[f"{prefix}.model.{i}.weight"], P[f"{prefix}.model.{i}.bias"]]
+    return out
 
 
 class _GradReverse(torch.autograd.Function):
@@ -252,13 +267,11 @@ class OracleALDI:
                 P = a["params"]
                 if a.get("img"):
                     f = grad_reverse(cap["features"][a.get("img_layer", "p2")])
-                    pr = conv_discriminator(f, P["img_align.model.0.weight"], P["img_align.model.0.bias"],
-                                            P["img_align.model.4.weight"], P["img_align.model.4.bias"])
+                    pr = conv_discriminator(f, *disc_params(P, "img_align"))
                     losses["loss_da_img"] = domain_loss(pr, labeled, a["img_w"])
                 if a.get("ins"):
                     f = grad_reverse(cap["box_head_out"])
-                    pr = fc_discriminator(f, P["ins_align.model.1.weight"], P["ins_align.model.1.bias"],
-                                          P["ins_align.model.3.weight"], P["ins_align.model.3.bias"])
+                    pr = fc_discriminator(f, *disc_params(P, "ins_align"))
                     losses["loss_da_ins"] = domain_loss(pr, labeled, a["ins_w"])
             elif a.get("img") or a.get("ins"):                                   # aldi/align.py:91-100
                 fake = 0

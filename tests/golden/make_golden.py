@@ -627,10 +627,40 @@ def g10(m):
     save("g10_convnext", **out)
 
 
+# ----------------------------------------------------------------------------
+# G11  discriminators with other hidden_dims lists (aldi/align.py:103-135 build ANY list: two hidden layers, none at all)
+# ----------------------------------------------------------------------------
+def g11(m):
+    out = {}
+    torch.manual_seed(23)
+    nets = {"conv2": (m["align"].ConvDiscriminator(32, hidden_dims=[16, 32]), torch.randn(2, 32, 9, 11)),
+            "conv0": (m["align"].ConvDiscriminator(32, hidden_dims=[]), torch.randn(2, 32, 5, 6)),
+            "fc2": (m["align"].FCDiscriminator(64, hidden_dims=[32, 16]), torch.randn(16, 64)),
+            "fc0": (m["align"].FCDiscriminator(64, hidden_dims=[]), torch.randn(16, 64))}
+    for tag, (net, x) in nets.items():
+        for labeled in (1, 0):
+            xi = x.clone().requires_grad_(True)
+            for p in net.parameters():
+                p.grad = None
+            preds = net(m["helpers"].grad_reverse(xi))
+            loss = 0.01 * F.binary_cross_entropy_with_logits(preds, torch.FloatTensor(preds.data.size()).fill_(labeled))
+            loss.backward()
+            out[f"{tag}_x"] = x
+            out[f"{tag}_preds"] = preds
+            out[f"{tag}_loss_l{labeled}"] = loss
+            out[f"{tag}_dx_l{labeled}"] = xi.grad
+            for k, p in net.named_parameters():
+                out[f"{tag}_grad_l{labeled}.{k}"] = p.grad
+        for k, v in net.state_dict().items():
+            out[f"{tag}_sd.{k}"] = v
+        out[f"{tag}_keys"] = np.array(list(net.state_dict().keys()))
+    save("g11_discriminators_deep", **out)
+
+
 if __name__ == "__main__":
     random.seed(0)
     mods = import_reference()
     only = sys.argv[1:]
-    for fn in (g1, g2, g3, g4, g5, g6, g7, g8, g9, g10):
+    for fn in (g1, g2, g3, g4, g5, g6, g7, g8, g9, g10, g11):
         if not only or fn.__name__ in only:
             fn(mods)

@@ -114,18 +114,25 @@ def test_train_step_bf16_close_to_oracle():
     assert torch.isfinite(wts.grad).all() and float(wts.grad.abs().max()) > 0
 
 
+DEEP = dict(img=dict(layer="p3", input_dim=256, hidden_dims=[64, 32]), ins=dict(input_dim=1024, hidden_dims=[128, 64]))
+
+
 def _cfg(align, bf16=False, lr=0.002):
+    """align: False | True (the reference's default discriminators) | "deep" (another FPN level, two hidden layers each)"""
     from aldi_amd.config import add_aldi_config, get_cfg
     cfg = get_cfg()
     add_aldi_config(cfg)
     cfg.merge_from_file(os.path.join(ROOT, "configs", "cityscapes", "ALDI-Best-Cityscapes.yaml"))
     cfg.merge_from_list(["SOLVER.IMS_PER_BATCH", 4, "SOLVER.AMP.ENABLED", bf16, "SOLVER.BASE_LR", lr, "SOLVER.WARMUP_ITERS", 0, "SEED", 1,
                          "EMA.ALPHA", 0.9, "SYNTHETIC.HEIGHT", H, "SYNTHETIC.WIDTH", W,
-                         "DOMAIN_ADAPT.ALIGN.IMG_DA_ENABLED", align, "DOMAIN_ADAPT.ALIGN.INS_DA_ENABLED", align])
+                         "DOMAIN_ADAPT.ALIGN.IMG_DA_ENABLED", bool(align), "DOMAIN_ADAPT.ALIGN.INS_DA_ENABLED", bool(align)])
+    if align == "deep":
+        cfg.merge_from_list(["DOMAIN_ADAPT.ALIGN.IMG_DA_LAYER", DEEP["img"]["layer"], "DOMAIN_ADAPT.ALIGN.IMG_DA_HIDDEN_DIMS", DEEP["img"]["hidden_dims"],
+                             "DOMAIN_ADAPT.ALIGN.INS_DA_HIDDEN_DIMS", DEEP["ins"]["hidden_dims"]])
     return cfg
 
 
-@pytest.mark.parametrize("align", [False, True])
+@pytest.mark.parametrize("align", [False, True, "deep"])
 def test_full_aldi_iterations_vs_oracle(align):
     """BASELINE configs[1] (distill on) and configs[2] (+ image/instance alignment): iterations of
     EMA tick + source step + [target-weak alignment step] + distillation step + SGD on HIP vs the
@@ -153,10 +160,11 @@ def test_full_aldi_iterations_vs_oracle(align):
                      "scores": c.pseudo["scores"][i, :n].cpu()} for i, n in enumerate(cnt)])
         return c
     type(pl).__call__ = wrapped
-    sd0 = syn.init_state_dict(K, seed=1, img_da=align, ins_da=align)
+    sd0 = syn.init_state_dict(K, seed=1, img_da=DEEP["img"] if align == "deep" else align, ins_da=DEEP["ins"] if align == "deep" else align)
     disc = lambda k: k.startswith(("img_align", "ins_align"))
     orc = ao.OracleALDI(d2.make_cfg(num_classes=K), {k: v for k, v in sd0.items() if not disc(k)}, ema_alpha=0.9, lr=0.002,
-                        align=dict(img=True, ins=True, img_w=0.01, ins_w=0.01, params={}) if align else None, ims_per_gpu=2,
+                        align=dict(img=True, ins=True, img_w=0.01, ins_w=0.01, params={}, img_layer=DEEP["img"]["layer"] if align == "deep" else "p2")
+                        if align else None, ims_per_gpu=2,
                         backward_at_end=False, py_seed=0)
     loader = iter(ALDITrainer.build_train_loader(cfg))
     # sampled-ROI index sets of every student forward, both sides
@@ -309,7 +317,7 @@ def test_missing_extension_or_device_fails_loudly():
         build_aldi(cfg)
 
 
-@pytest.mark.parametrize("align", [False, True])
+@pytest.mark.parametrize("align", [False, True, "deep"])
 def test_fused_step_equals_sequential(align):
     """SOLVER.FUSED_STEP (one trunk pass for the source / target-weak / distillation student micro-batches, one
     backward) reproduces the sequential reference schedule: same loss dict (keys, order, values), same sampled

@@ -162,3 +162,33 @@ def test_g8_hard_mask(golden_dir):
         out.update({"loss_cls_ce": torch.tensor(0.3), "loss_roih_l1": torch.tensor(0.4)})
         assert list(out.keys()) == res[key]["keys"]
         assert {k: round(float(v), 6) for k, v in out.items()} == res[key]["values"]
+
+
+@pytest.mark.parametrize("tag", ["conv2", "conv0", "fc2", "fc0"])
+def test_g11_discriminators_with_other_hidden_dims(golden_dir, tag):
+    """two hidden layers and none at all (aldi/align.py:103-135 accept any hidden_dims list)"""
+    g = load(golden_dir, "g11_discriminators_deep.npz")
+    keys = [str(k) for k in g[f"{tag}_keys"]]
+    assert keys == {"conv2": ["model.0.weight", "model.0.bias", "model.2.weight", "model.2.bias", "model.6.weight", "model.6.bias"],
+                    "conv0": ["model.2.weight", "model.2.bias"],
+                    "fc2": ["model.1.weight", "model.1.bias", "model.3.weight", "model.3.bias", "model.5.weight", "model.5.bias"],
+                    "fc0": ["model.1.weight", "model.1.bias"]}[tag]
+    from aldi_amd.arch import disc_convs                      # the engine's layout uses the same nn.Sequential indices
+    spec = {"conv2": dict(img=dict(input_dim=32, hidden_dims=[16, 32]), ins=False), "conv0": dict(img=dict(input_dim=32, hidden_dims=[]), ins=False),
+            "fc2": dict(img=False, ins=dict(input_dim=64, hidden_dims=[32, 16])), "fc0": dict(img=False, ins=dict(input_dim=64, hidden_dims=[]))}[tag]
+    pre = "img_align." if tag.startswith("conv") else "ins_align."
+    assert [pre + k.rsplit(".", 1)[0] for k in keys[::2]] == list(disc_convs(spec["img"], spec["ins"]))
+    fn = ao.conv_discriminator if tag.startswith("conv") else ao.fc_discriminator
+    P = [T(g[f"{tag}_sd.{k}"]).clone().requires_grad_(True) for k in keys]
+    for labeled in (1, 0):
+        x = T(g[f"{tag}_x"]).clone().requires_grad_(True)
+        for p in P:
+            p.grad = None
+        preds = fn(ao.grad_reverse(x), *P)
+        loss = ao.domain_loss(preds, bool(labeled), 0.01)
+        loss.backward()
+        np.testing.assert_allclose(preds.detach().numpy(), g[f"{tag}_preds"], rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(float(loss), float(g[f"{tag}_loss_l{labeled}"]), rtol=1e-6)
+        np.testing.assert_allclose(x.grad.numpy(), g[f"{tag}_dx_l{labeled}"], rtol=1e-4, atol=1e-9)
+        for p, k in zip(P, keys):
+            np.testing.assert_allclose(p.grad.numpy(), g[f"{tag}_grad_l{labeled}.{k}"], rtol=1e-4, atol=1e-8)
