@@ -136,11 +136,27 @@ class Weights:
         if key not in self._wt:
             # first request of this layer: single-layer kernel now, and from the next refresh() on it is part of the one
             # batched launch that re-derives every requested layer right after the weights change
-            self._wt[key] = ops.dgrad_weights(self.w_master(name), self._wt_scale(name, negate), self.dtype)
+            self._wt[key] = ops.dgrad_weights(*self._wt_source(key), self.dtype)
             if key not in self._wt_keys:
                 self._wt_keys.append(key)
                 self._wt_plan = None
         return self._wt[key]
+
+    def wt_flat(self, name: str) -> torch.Tensor:
+        """[KH*KW*Cin][1][1][Cout] = the layer's weight matrix transposed, rows in (tap, ci) order: one 1x1 GEMM with it gives the
+        data-gradient contributions of a pixel to its KHxKW neighbourhood (sparse RPN backward)"""
+        return self.wt(name + "@flat")
+
+    def _wt_source(self, key: str):
+        """(fp32 master view, per-Cout scale) a dgrad-weight key is derived from"""
+        neg = key.endswith("-")
+        key = key[:-1] if neg else key
+        flat = key.endswith("@flat")
+        name = key[:-len("@flat")] if flat else key
+        w = self.w_master(name)
+        if flat:
+            w = w.view(w.shape[0], 1, 1, -1)
+        return w, self._wt_scale(name, neg)
 
     def _wt_scale(self, name: str, negate: bool):
         if not negate:
@@ -155,12 +171,7 @@ class Weights:
         if not self._wt_keys:
             return
         if self._wt_plan is None:
-            ent = []
-            for key in self._wt_keys:
-                neg = key.endswith("-")
-                name = key[:-1] if neg else key
-                ent.append((self.w_master(name), self._wt_scale(name, neg)))
-            self._wt_plan = ops.DgradWeightsPlan(ent, self.dtype)
+            self._wt_plan = ops.DgradWeightsPlan([self._wt_source(key) for key in self._wt_keys], self.dtype)
         self._wt_plan.run()
         for key, o in zip(self._wt_keys, self._wt_plan.out):
             self._wt[key] = o
@@ -255,6 +266,7 @@ class RCNN:
         self.img_da_layers = sorted((n for n in names if n.startswith("img_align.model.")), key=idx)
         self.ins_da_layers = sorted((n for n in names if n.startswith("ins_align.model.")), key=idx)
         self.has_img_da, self.has_ins_da = bool(self.img_da_layers), bool(self.ins_da_layers)
+        self.sparse_rpn_backward = os.environ.get("ALDI_RPN_SPARSE_BWD", "1") == "1"      # tests flip the attribute to compare with the dense form
         spec = getattr(weights.layout, "img_da", None)
         self.img_da_level = ("p2", "p3", "p4", "p5", "p6").index(spec["layer"]) if spec else 0
 
@@ -933,15 +945,18 @@ class RCNN:
             ops.roialign_backward(self.roi_feats(c, gP_roi), c.rois, c.R, POOL, g_pooled, c.N)
         self._grads_final(["box_pred", "roi_heads.box_head.fc2", "roi_heads.box_head.fc1"])
         # ---- RPN head (shared weights over 5 levels)
-        gP = []
-        for l in range(5):
-            gh = ops.cast_from_f32(c.ghead[l], T)
-            self._wgrad("rpn_head_out", c.rpn_t[l], gh)
-            g_t = ops.conv2d(gh, W.wt("rpn_head_out"), mask=c.rpn_t[l])
-            self._wgrad("proposal_generator.rpn_head.conv", c.P[l], g_t)
-            gP.append(ops.conv2d(g_t, W.wt("proposal_generator.rpn_head.conv"), pad=1))
-        for l in range(4):
-            ops.add_f32(gP[l], gP_roi[l], gP[l])
+        if self.sparse_rpn_backward:
+            gP = self._rpn_head_backward_sparse(c, gP_roi)
+        else:
+            gP = []
+            for l in range(5):
+                gh = ops.cast_from_f32(c.ghead[l], T)
+                self._wgrad("rpn_head_out", c.rpn_t[l], gh)
+                g_t = ops.conv2d(gh, W.wt("rpn_head_out"), mask=c.rpn_t[l])
+                self._wgrad("proposal_generator.rpn_head.conv", c.P[l], g_t)
+                gP.append(ops.conv2d(g_t, W.wt("proposal_generator.rpn_head.conv"), pad=1))
+            for l in range(4):
+                ops.add_f32(gP[l], gP_roi[l], gP[l])
         # ---- image-level discriminator behind the gradient-reversal layer (on any of p2..p6)
         for al in align_list:
             if "img" not in al:
@@ -1006,6 +1021,29 @@ class RCNN:
                     g = ops.conv2d(g1, W.wt(p + "conv1"), res=g, res_mode=1, mask=xin)
         self._join_wgrads()
 
+    def _rpn_head_backward_sparse(self, c: Ctx, gP_roi: List[torch.Tensor]) -> List[torch.Tensor]:
+        """RPN head backward over the ACTIVE pixels only (csrc/rpn_sparse.hip): d(loss)/d(head outputs) is non-zero at the sampled
+        anchors' pixels, at most RPN_BATCH per image and sample (the RPN losses' sample + the distillation losses' fresh one), i.e.
+        <= 2 * 256 * N of the 358 k pixel positions.  Returns d(loss)/d(P_l) in the compute dtype, ROIAlign's contribution
+        (gP_roi, fp32) included -- summed in fp32 and rounded once."""
+        W, T, dev = self.wts, self.dtype, self.device
+        N, Cf, Ch = c.N, FPN_C, self.Ch
+        cap = 2 * RPN_BATCH * N
+        idx = torch.empty(cap, dtype=torch.int32, device=dev)
+        count = torch.empty(1, dtype=torch.int32, device=dev)
+        ops.rpn_active_pixels(c.geom, c.ghead, N, cap, idx, count, self.err)
+        G = torch.empty((cap, 1, 1, Ch), dtype=T, device=dev)
+        Tm = torch.empty((cap, 1, 1, Cf), dtype=T, device=dev)
+        X9 = torch.empty((cap, 1, 1, 9 * Cf), dtype=T, device=dev)
+        ops.rpn_sparse_gather(c.geom, c.ghead, c.rpn_t, c.P, N, Cf, cap, idx, count, G, Tm, X9)
+        self._wgrad("rpn_head_out", Tm, G, temp_x=True)
+        g_t = ops.conv2d(G, W.wt("rpn_head_out"), mask=Tm)
+        self._wgrad("proposal_generator.rpn_head.conv", X9, g_t, flat=True, temp_x=True)
+        Y = ops.conv2d(g_t, W.wt_flat("proposal_generator.rpn_head.conv"))           # [cap][9][Cf]: contributions to the 3x3 neighbourhood
+        g32 = list(gP_roi) + [torch.zeros(c.P[4].shape, dtype=torch.float32, device=dev)]
+        ops.rpn_sparse_scatter(c.geom, g32, Y, N, Cf, cap, idx, count)
+        return [ops.cast_from_f32(g, T) for g in g32]
+
     def _grads_final(self, names: List[str]):
         """tell the gradient exchange (if one is attached: data-parallel fused step) that these layers' gradients are
         complete for this step -- every kernel writing them has been enqueued."""
@@ -1030,15 +1068,16 @@ class RCNN:
             self._join_wgrads()
             cb(self.wts.layout.ranges(names))
 
-    def _wgrad(self, name: str, x: torch.Tensor, g: torch.Tensor):
-        """weight (+ bias) gradient of one layer.  The data-gradient chain never reads these results, so they run on a
+    def _wgrad(self, name: str, x: torch.Tensor, g: torch.Tensor, flat: bool = False, temp_x: bool = False):
+        """weight (+ bias) gradient of one layer (`flat`: x holds im2col rows [S][KH*KW*Cin], the gradient is a plain GEMM).  The data-gradient chain never reads these results, so they run on a
         second HIP stream beside it: a wgrad launch of a deep layer is only 1-2 workgroups per CU, the dgrad igemm of
         the same layer likewise, and neither fills the chip on its own."""
         W = self.wts
         p = W.layout.t[name]
         side = self._wgrad_stream()
+        geo = dict(KH=1, KW=1, stride=1, pad=0) if flat else dict(KH=p.kk, KW=p.kk, stride=p.stride, pad=p.pad)
         if side is None:
-            ops.conv_wgrad(x, g, W.gw(name), KH=p.kk, KW=p.kk, stride=p.stride, pad=p.pad, scale=W.scale(name))
+            ops.conv_wgrad(x, g, W.gw(name), scale=W.scale(name), **geo)
             if p.bias:
                 ops.bias_grad(g, W.gb(name))
             return
@@ -1046,8 +1085,10 @@ class RCNN:
         ev.record()                                  # g (and x) are complete once the main stream gets here
         side.wait_event(ev)
         g.record_stream(side)                        # g is a temporary of the main stream's allocator
+        if temp_x:
+            x.record_stream(side)                    # x is a temporary too (gathered rows), not a saved activation
         with torch.cuda.stream(side):
-            ops.conv_wgrad(x, g, W.gw(name), KH=p.kk, KW=p.kk, stride=p.stride, pad=p.pad, scale=W.scale(name))
+            ops.conv_wgrad(x, g, W.gw(name), scale=W.scale(name), **geo)
             if p.bias:
                 ops.bias_grad(g, W.gb(name))
         self._wgrad_pending = True

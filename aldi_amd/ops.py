@@ -260,6 +260,19 @@ def rpn_proposals(geom, head, anchors, img_hw, N, pre, post, thr, workspace, out
            _p(out_boxes), _p(out_scores), _p(out_count), _p(err), stream_ptr())
 
 
+def rpn_active_pixels(geom, ghead, N, cap, idx, count, err):
+    L.call("aldi_rpn_active_pixels", C.byref(geom), ptrs(ghead), N, cap, _p(idx), _p(count), _p(err), stream_ptr())
+
+
+def rpn_sparse_gather(geom, ghead, hidden, feat, N, Cf, cap, idx, count, G, Tm, X9):
+    L.call("aldi_rpn_sparse_gather", C.byref(geom), ptrs(ghead), ptrs(hidden), ptrs(feat), N, Cf, cap, _p(idx), _p(count), _p(G), _p(Tm), _p(X9),
+           dtype_code(G.dtype), stream_ptr())
+
+
+def rpn_sparse_scatter(geom, gfeat, Y, N, Cf, cap, idx, count):
+    L.call("aldi_rpn_sparse_scatter", C.byref(geom), ptrs(gfeat), _p(Y), N, Cf, cap, _p(idx), _p(count), dtype_code(Y.dtype), stream_ptr())
+
+
 # ------------------------------------------------------------------------------- ROI heads
 def make_roi_feats(feats: Sequence[torch.Tensor], grads: Optional[Sequence[torch.Tensor]], scales: Sequence[float]) -> L.RoiFeats:
     f = L.RoiFeats()

@@ -386,10 +386,17 @@ def main():
                                   "%d labeled_strong + %d unlabeled (weak+strong) images per GPU" % ({"vitdet_b": 3, "convnext_l": -1}.get(args.workload, 2 if args.align else 1), arch_name, args.width,
                                                                                                    args.height, "on" if args.align else "off", per, per),
                       "global_batch": imgs_per_step, "parallelism": f"dp{world}", "pseudo_label_threshold": cfg.DOMAIN_ADAPT.TEACHER.THRESHOLD,
-                      "pseudo_labels_per_image": pl_count, "schedule": "sequential micro-steps" if args.sequential else "fused source+target student pass" + ("" if args.no_graph or world > 1 else ", two hipGraph replays per step"), "weights": f"random-init {arch_name} (synthetic)", "error_flag": err},
+                      "pseudo_labels_per_image": pl_count, "schedule": "sequential micro-steps" if args.sequential else "fused source+target student pass" + ("" if args.no_graph or world > 1 else ", two hipGraph replays per step"), "weights": f"random-init {arch_name} (synthetic)", "error_flag": err,
+                      "step_graphs": dict(getattr(getattr(tr._trainer, "_fused_step", None), "stats", {}))},
            "final_losses": {k: round(v, 5) for k, v in losses.items()}}
     if rank == 0 and world == 1 and not args.no_profile:
+        fs = getattr(tr._trainer, "_fused_step", None)
+        graph_was = fs.graph_enabled if fs is not None else False
+        if fs is not None:
+            fs.graph_enabled = False                # the profiled step issues every launch from Python so that each one can be bracketed
         prof = profile_insitu(one_step, os.path.join(ROOT, "gpurun_out", "dense_profile_insitu.txt"))
+        if fs is not None:
+            fs.graph_enabled = graph_was
         if args.replay_profile:
             profile_dense(tr, one_step, os.path.join(ROOT, "gpurun_out", "dense_profile.txt"))
         ig, wg = prof["igemm"], prof["wgrad"]

@@ -200,6 +200,21 @@ int aldi_rpn_proposals(const aldi_rpn_geom* gm, float* const* head, const float*
                        int pre_nms_topk, int post_nms_topk, float nms_thresh, void* workspace,
                        float* out_boxes, float* out_scores, int* out_count, int* err_flag, aldi_stream_t stream);
 
+/* Sparse backward of the RPN head (what autograd runs as dense convolutions over all five levels, reached from
+ * aldi/trainer.py:79): d(loss)/d(head outputs) is non-zero only at the sampled anchors' pixels (<= 256 per image and sample).
+ *   aldi_rpn_active_pixels   idx[0..*count) = global row (level-major pixel position, row = N*sum_{k<l}H_k W_k + (n*H_l+h)*W_l+w)
+ *                            of every pixel whose C head-gradient channels are not all zero; *count (device) is reset first;
+ *                            err_flag |= 2 when more than `cap` pixels are active.  Order of the list is unspecified.
+ *   aldi_rpn_sparse_gather   rows s < min(*count, cap): G[s][C] = grad_head (in dtype), Tm[s][Cf] = hidden[l][pixel],
+ *                            X9[s][tap][Cf] = feat[l][pixel + (tap/3-1, tap%3-1)] (zero outside the image); rows >= count zero.
+ *   aldi_rpn_sparse_scatter  gfeat[l][pixel + (tap/3-1, tap%3-1)][ci] += Y[s][tap][ci] (fp32 atomics), Y in dtype [cap][9][Cf]. */
+int aldi_rpn_active_pixels(const aldi_rpn_geom* gm, float* const* grad_head, int N, int cap, int* idx, int* count, int* err_flag,
+                           aldi_stream_t stream);
+int aldi_rpn_sparse_gather(const aldi_rpn_geom* gm, float* const* grad_head, const void* const* hidden, const void* const* feat, int N, int Cf,
+                           int cap, const int* idx, const int* count, void* G, void* Tm, void* X9, int dtype, aldi_stream_t stream);
+int aldi_rpn_sparse_scatter(const aldi_rpn_geom* gm, float* const* gfeat, const void* Y, int N, int Cf, int cap, const int* idx,
+                            const int* count, int dtype, aldi_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------
  * ROI heads.  Replaces detectron2 StandardROIHeads.label_and_sample_proposals, ROIPooler +
  * torchvision roi_align(aligned, 7x7, adaptive sampling), FastRCNNOutputLayers.losses and

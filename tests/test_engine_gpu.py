@@ -477,7 +477,8 @@ def test_checkpoint_round_trip_and_ema_start(tmp_path):
     s_sd, t_sd = tr.model.state_dict(), tr.ema.model.state_dict()
     assert any(not torch.equal(s_sd[k], t_sd[k]) for k in s_sd)              # the teacher lags the student
     raw = torch.load(os.path.join(cfg.OUTPUT_DIR, "model_0000001.pth"), weights_only=False)
-    assert set(raw) == {"model", "ema", "iteration"} and all(k.startswith("model.") for k in raw["ema"])
+    assert set(raw) == {"model", "ema", "trainer", "iteration"} and all(k.startswith("model.") for k in raw["ema"])
+    assert raw["trainer"]["iteration"] == 1 and raw["trainer"]["_trainer"]["optimizer"]["format"] == "aldi_amd.flat_sgd"
     assert "backbone.bottom_up.res2.0.conv1.weight" in raw["model"] and "roi_heads.box_predictor.cls_score.weight" in raw["model"]
     tr2 = ALDITrainer(cfg)
     tr2.resume_or_load(resume=True)
@@ -568,3 +569,41 @@ def test_hard_distiller_runs_through_the_trainer():
     assert {"loss_cls_distill", "loss_box_reg_distill", "loss_rpn_cls_distill", "loss_rpn_loc_distill"} <= set(ld), set(ld)
     assert all(float(v) == float(v) for v in ld.values()) and int(tr.model.engine.err) == 0
     assert float(tr.model.weights.grad.abs().max()) > 0
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-5), (torch.bfloat16, 1.5e-2)])
+def test_sparse_rpn_head_backward_equals_dense(dtype, tol):
+    """the RPN head's backward over the sampled anchors' pixels only (csrc/rpn_sparse.hip) == the dense convolutions over all
+    five levels it replaces: every parameter gradient, including what flows on into FPN / res3-5 through d(loss)/d(P_l)"""
+    from aldi_amd import synthetic as syn
+    sd = syn.init_state_dict(K, seed=1)
+    _, data, _, _ = syn.make_batch(2, 0, H, W, K, seed=0, boxes_per_image=(3, 6))
+    lay, wts, m = _engine(dtype, sd)
+    torch.manual_seed(5)
+    c = m.forward_train([d["image"] for d in data], [d["instances"] for d in data], roi_seed=9)
+    scales = {"loss_cls": 1.0, "loss_box_reg": 1.0, "loss_rpn_cls": 1.0, "loss_rpn_loc": 1.0}
+    grads = {}
+    for sparse in (True, False):
+        m.sparse_rpn_backward = sparse
+        wts.zero_grad()
+        m.backward(c, scales)
+        torch.cuda.synchronize()
+        grads[sparse] = wts.grad.clone()
+    assert int(m.err) == 0
+    a, b = grads[True], grads[False]
+    names = ["rpn_head_out", "proposal_generator.rpn_head.conv", "backbone.fpn_output2", "backbone.fpn_output5", "backbone.fpn_lateral3",
+             "backbone.bottom_up.res5.2.conv3", "backbone.bottom_up.res3.0.conv1", "roi_heads.box_head.fc1"]
+    for n in names:
+        for lo, hi in lay.ranges([n]):
+            ref = b[lo:hi]
+            assert float(ref.abs().max()) > 0, n
+            assert float((a[lo:hi] - ref).abs().max()) <= tol * float(ref.abs().max()), (n, float((a[lo:hi] - ref).abs().max()), float(ref.abs().max()))
+    # RPN-only losses: with the ROI heads' losses off the ONLY gradient source is the sparse path
+    for sparse in (True, False):
+        m.sparse_rpn_backward = sparse
+        wts.zero_grad()
+        m.backward(c, {"loss_rpn_cls": 1.0, "loss_rpn_loc": 0.5})
+        torch.cuda.synchronize()
+        grads[sparse] = wts.grad.clone()
+    a, b = grads[True], grads[False]
+    assert float(b.abs().max()) > 0 and float((a - b).abs().max()) <= tol * float(b.abs().max())
