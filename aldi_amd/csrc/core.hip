@@ -36,6 +36,7 @@ const Knob kKnobs[] = {
     {"wgrad_big_slots", &AldiTuning::wgrad_big_slots, 256},
     {"wgrad_slots", &AldiTuning::wgrad_slots, 384},
     {"wgrad_xcd", &AldiTuning::wgrad_xcd, 1},
+    {"wgrad_dma", &AldiTuning::wgrad_dma, 0},
     {"colsum_blocks", &AldiTuning::colsum_blocks, 256},
     {"colsum_minrows", &AldiTuning::colsum_minrows, 16},
     {"colsum_nt", &AldiTuning::colsum_nt, 1024},

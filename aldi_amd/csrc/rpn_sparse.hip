@@ -1,13 +1,14 @@
 // Sparse backward of the RPN head.
 //
 // The gradient of the RPN losses (and of the RPN distillation losses) with respect to the head outputs is non-zero only
-// at the SAMPLED anchors: 256 per image (aldi/distill.py:200-202 draws another 256 per distillation image), i.e. at
-// <= 512 * N of the N * sum(H_l * W_l) = 358 k pixel positions of the five levels.  Everything downstream of it inside
+// at the positions the SAMPLED anchors select: 256 per image for the RPN losses, and for the distillation losses the
+// <= 256 + 4 * 128 positions the reference's masks pick (aldi/distill.py:200-227), i.e. at <= 1024 * N of the
+// N * sum(H_l * W_l) = 358 k pixel positions of the five levels.  Everything downstream of it inside
 // the head -- the 1x1 heads' data/weight gradients, the ReLU mask, the shared 3x3 conv's weight gradient and its data
 // gradient -- is a sum over those pixels only.  Detectron2 / autograd (reached from aldi/trainer.py:79) run them as
 // dense convolutions over all five levels; here the active pixels are listed, their rows gathered into small dense
 // matrices ([S][16] head gradient, [S][256] hidden activation, [S][9][256] im2col of the level feature), the GEMMs run
-// on S <= 2048 rows through the ordinary igemm / wgrad kernels, and the data gradient is scattered back into the fp32
+// on S <= 1024 N rows through the ordinary igemm / wgrad kernels, and the data gradient is scattered back into the fp32
 // level gradients.  Exact: the dropped terms are products with zeros.
 #include "common.h"
 #include <hip/amd_detail/amd_hip_unsafe_atomics.h>

@@ -346,6 +346,196 @@ __global__ __launch_bounds__(512) void wgrad_bf16_big_kernel(WgDev p) {
     wgrad_bf16_lean_body<256, 256, 2, 4>(p, lds);
 }
 
+// ------------------------------------------------------------------------------------ bf16, LDS-DMA + transpose reads
+// The lean kernel above moves every operand byte global -> VGPR -> (8x8 transposes in registers) -> LDS -> VGPR: its loop is
+// bound by that staging, not by the matrix cores.  gfx950 can do both halves in hardware:
+//   * `buffer_load_dwordx4 ... lds` (LDS-DMA) writes 16 B per lane straight into LDS, lane-linear;
+//   * `ds_read_b64_tr_b16` hands a lane four 16-bit elements that are 32 B (one LDS row) apart -- i.e. four PIXELS of one
+//     channel out of an image stored pixel-major, which is exactly the MFMA operand when the reduction runs over pixels.
+// LDS image of one operand for a 32-pixel slab: per 16-channel block a [32 pixels][16 channels] array (32-B rows, 1 KB): one
+// wave-wide DMA instruction fills one block (lane i -> pixel i/2, channel half i%2), two transpose reads (pixels 0-15 and
+// 16-31 of the block, 512 contiguous bytes each: conflict free) give a 16-channel x 32-pixel MFMA fragment.  The order of
+// the 32 pixels inside a fragment is the hardware's (lane group q holds pixels 4q..4q+3 and 16+4q..16+4q+3); both operands
+// use the same one, and a reduction does not care.  Three-slab LDS ring, counted vmcnt, raw barriers, as in igemm.hip.
+// Same domain as the lean kernel (1x1 stride-1 and "same" KxK convs, Cin % 16 == 0 for KxK), same split-K atomics epilogue.
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void glds16w(__amdgpu_buffer_rsrc_t rsrc, void* dst, unsigned voff) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)dst, 16, voff, 0, 0, 0);
+}
+typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
+template <int OFF>
+__device__ __forceinline__ u32x2_t tr_read(unsigned addr) {
+    u32x2_t v;
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
+    return v;
+}
+template <int N, int I = 0>
+__device__ __forceinline__ void tr_read_frags(u32x2_t* lo, u32x2_t* hi, unsigned addr) {      // fragments are 1 KB apart
+    if constexpr (I < N) {
+        lo[I] = tr_read<I * 1024>(addr);
+        hi[I] = tr_read<I * 1024 + 512>(addr);
+        tr_read_frags<N, I + 1>(lo, hi, addr);
+    }
+}
+
+template <int TCO, int TKK, int WM, int WN>
+__global__ __launch_bounds__(WM* WN * 64) void wgrad_bf16_dma_kernel(WgDev p) {
+    constexpr int NW = WM * WN, NT = NW * 64;
+    constexpr int BP = 32;                              // pixels per slab = one MFMA k-step
+    constexpr int GB = TCO / 16, XB = TKK / 16;         // 16-channel blocks of the g / x tile
+    constexpr int NBLK = GB + XB;
+    static_assert(NBLK % NW == 0, "every wave issues the same number of DMA instructions per slab");
+    constexpr int PER_WAVE = NBLK / NW;
+    constexpr int TM = TCO / WM / 16, TN = TKK / WN / 16;
+    constexpr int NBUF = 3;
+    constexpr int STAGE = NBLK * 1024;                  // bytes per ring stage
+    __shared__ __attribute__((aligned(1024))) unsigned char lds[NBUF * STAGE];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+    {
+        const int gx = gridDim.x, gy = gridDim.y, total = gx * gy * gridDim.z;
+        int bid = bx + gx * (by + gy * bz);
+        if (p.xcd) {
+            const int q = total >> 3, r = total & 7, xcd = bid & 7, idx = bid >> 3;
+            bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+        }
+        bx = bid % gx; bid /= gx;
+        by = bid % gy; bz = bid / gy;
+    }
+    const int co0 = bx * TCO, kk0 = by * TKK;
+    const int pbeg = bz * p.pix_per_split;
+    const int pend = min(p.M, pbeg + p.pix_per_split);
+    if (pbeg >= pend) return;
+
+    constexpr unsigned OOB = 0x80000000u;
+    const __amdgpu_buffer_rsrc_t rg = make_rsrc_uniform(p.g, min((unsigned)pend * (unsigned)p.Cout * 2u, p.g_bytes));   // g rows >= pend read as zeros
+    const __amdgpu_buffer_rsrc_t rx = make_rsrc_uniform(p.x, p.x_bytes);
+
+    // this wave's DMA instructions: block b = wave * PER_WAVE + k (blocks 0..GB-1: g tile, GB..: x tile)
+    const int lp = lane >> 1, lh = lane & 1;            // slab pixel / channel half this lane copies
+    unsigned voff[PER_WAVE];                            // byte offset of (pixel pbeg + lp, this block's channels); OOB for channel tails
+    int tapbit[PER_WAVE];                               // x blocks of KxK convs: bit index of the tap in the pixel's validity mask (-1: none)
+#pragma unroll
+    for (int k = 0; k < PER_WAVE; ++k) {
+        const int b = wave * PER_WAVE + k;
+        tapbit[k] = -1;
+        if (b < GB) {
+            const int ch = co0 + b * 16 + lh * 8;
+            voff[k] = ch < p.Cout ? ((unsigned)(pbeg + lp) * (unsigned)p.Cout + (unsigned)ch) * 2u : OOB;
+        } else {
+            const int ch = kk0 + (b - GB) * 16 + lh * 8;
+            if (ch >= p.K) { voff[k] = OOB; continue; }
+            const int tap = ch / p.Cin, ci = ch - tap * p.Cin;
+            const int kh = tap / p.KW, kw = tap - kh * p.KW;
+            voff[k] = ((unsigned)(pbeg + lp + (kh - p.pad) * p.W + (kw - p.pad)) * (unsigned)p.Cin + (unsigned)ci) * 2u;    // mod 2^32
+            if (!p.ident) tapbit[k] = tap;
+        }
+    }
+    // validity of this lane's pixel for each tap of a "same" KxK conv (at most 25 taps): recomputed per slab from (h, w)
+    int ph = 0, pw = 0;
+    if (!p.ident) {
+        const int r = (pbeg + lp) % (p.H * p.W);
+        ph = r / p.W; pw = r - ph * p.W;
+    }
+    const unsigned x_row = (unsigned)p.Cin * 2u, g_row = (unsigned)p.Cout * 2u;
+    int ld_pix = pbeg;                                  // first pixel of the slab being LOADED
+
+    auto issue_slab = [&](int buf) {
+        unsigned mask = ~0u;
+        bool in = true;
+        if (!p.ident) {
+            mask = 0u;
+            for (int kh = 0; kh < p.KH; ++kh)
+                for (int kw = 0; kw < p.KW; ++kw)
+                    if ((unsigned)(ph + kh - p.pad) < (unsigned)p.H && (unsigned)(pw + kw - p.pad) < (unsigned)p.W) mask |= 1u << (kh * p.KW + kw);
+        }
+        in = ld_pix + lp < pend;
+        const unsigned adv = (unsigned)(ld_pix - pbeg);
+#pragma unroll
+        for (int k = 0; k < PER_WAVE; ++k) {
+            const int b = wave * PER_WAVE + k;
+            unsigned vo;
+            if (b < GB) vo = voff[k] == OOB ? OOB : voff[k] + adv * g_row;
+            else {
+                const bool ok = in && voff[k] != OOB && (tapbit[k] < 0 || ((mask >> tapbit[k]) & 1u));
+                vo = ok ? voff[k] + adv * x_row : OOB;
+            }
+            if (b < GB) glds16w(rg, lds + buf * STAGE + b * 1024 + 0, vo);
+            else glds16w(rx, lds + buf * STAGE + b * 1024 + 0, vo);
+        }
+        ld_pix += BP;
+        if (!p.ident) {
+            pw += BP;
+            while (pw >= p.W) { pw -= p.W; ++ph; }
+            while (ph >= p.H) ph -= p.H;
+        }
+    };
+
+    const int wm = wave / WN, wn = wave % WN;
+    f32x4_t acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    const int fr = lane & 15, fq = lane >> 4;
+    // transpose read (measured: tools/probes/tr_probe.hip): the 16 lanes of group q cover the [4 pixels][16 channels] block of
+    // pixels 4q..4q+3 -- lane l points at the 8 B of pixel row 4q + (l&15)/4, channels 4*(l&3)..+3 -- and lane l RECEIVES
+    // channel l&15 of the four pixels: the MFMA operand row of that lane
+    const unsigned lane_off = (unsigned)((fq * 4 + ((lane & 15) >> 2)) * 32 + (lane & 3) * 8);
+    const unsigned lbase = (unsigned)(uintptr_t)(const __attribute__((address_space(3))) void*)lds;
+    const unsigned a_rd = lbase + (unsigned)(wm * TM) * 1024u + lane_off;
+    const unsigned b_rd = lbase + (unsigned)(GB + wn * TN) * 1024u + lane_off;
+
+    const int S = (pend - pbeg + BP - 1) / BP;
+    issue_slab(0);
+    if (S > 1) issue_slab(1);
+    int buf = 0, nbuf = 2;
+    for (int s = 0; s < S; ++s) {
+        if (s + 1 < S) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER_WAVE) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        if (s + 2 < S) issue_slab(nbuf);
+        u32x2_t alo[TM], ahi[TM], blo[TN], bhi[TN];
+        tr_read_frags<TM>(alo, ahi, a_rd + (unsigned)buf * STAGE);
+        tr_read_frags<TN>(blo, bhi, b_rd + (unsigned)buf * STAGE);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int i = 0; i < TM; ++i) asm volatile("" : "+v"(alo[i]), "+v"(ahi[i]));
+#pragma unroll
+        for (int j = 0; j < TN; ++j) asm volatile("" : "+v"(blo[j]), "+v"(bhi[j]));
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const u32x4 af = {alo[i][0], alo[i][1], ahi[i][0], ahi[i][1]};
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const u32x4 bf = {blo[j][0], blo[j][1], bhi[j][0], bhi[j][1]};
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, af), __builtin_bit_cast(bf16x8_t, bf), acc[i][j], 0, 0, 0);
+            }
+        }
+        buf = buf == NBUF - 1 ? 0 : buf + 1;
+        nbuf = nbuf == NBUF - 1 ? 0 : nbuf + 1;
+    }
+    {   // split-K partial tile -> fp32 gradient (fire-and-forget buffer atomics, out-of-tile lanes dropped)
+        const __amdgpu_buffer_rsrc_t rdw = make_rsrc_uniform(p.dw, p.dw_bytes);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int co = co0 + (wm * TM + i) * 16 + fq * 4 + r;
+                const bool cok = co < p.Cout;
+                const float sc = p.scale ? p.scale[cok ? co : 0] : 1.f;
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    const int kk = kk0 + (wn * TN + j) * 16 + fr;
+                    const unsigned off = (cok && kk < p.K) ? ((unsigned)co * (unsigned)p.K + (unsigned)kk) * 4u : kBufOOB;
+                    buf_atomic_add_f32(rdw, off, acc[i][j][r] * sc);
+                }
+            }
+    }
+}
+
 // ------------------------------------------------------------------------------------ fp32
 // 64 (co) x 64 (kk) tile, 16 pixels per slab, 4 waves (2x2), wave tile 32x32.
 __global__ __launch_bounds__(256) void wgrad_f32_kernel(WgDev p) {
@@ -525,7 +715,22 @@ extern "C" int aldi_conv_wgrad(const aldi_wgrad_args* a, aldi_stream_t stream) {
     dim3 grid(cdiv(d.Cout, tile), cdiv(d.K, tile), splits);
     d.xcd = tn.wgrad_xcd;
     const char* which;
-    if (big) { hipLaunchKernelGGL(wgrad_bf16_big_kernel, grid, dim3(512), 0, st, d); which = "wgrad_bf16_big"; }
+    // LDS-DMA + transpose-read form (wgrad_dma: 0 off, 1 = 128x128 tile in place of the lean kernel, 2 = also in place of the 256x256 one)
+    const bool dma = lean && tn.wgrad_dma > 0 && (d.ident ? a->Cin % 8 == 0 : a->Cin % 16 == 0) && a->KH * a->KW <= 25 && !(big && tn.wgrad_dma < 2);
+    if (dma) {
+        if (big) {       // re-derive the split for the 128x128 tile
+            tiles = cdiv(d.Cout, 128) * cdiv(d.K, 128);
+            splits = cdiv(slots_env_, tiles);
+            if (splits > slabs / 4) splits = slabs / 4;
+            if (splits < 1) splits = 1;
+            slabs_per = cdiv(slabs, splits);
+            d.pix_per_split = slabs_per * bp;
+            splits = cdiv(d.M, d.pix_per_split);
+            grid = dim3(cdiv(d.Cout, 128), cdiv(d.K, 128), splits);
+        }
+        hipLaunchKernelGGL((wgrad_bf16_dma_kernel<128, 128, 2, 2>), grid, dim3(256), 0, st, d);
+        which = "wgrad_bf16_dma";
+    } else if (big) { hipLaunchKernelGGL(wgrad_bf16_big_kernel, grid, dim3(512), 0, st, d); which = "wgrad_bf16_big"; }
     else if (lean) { hipLaunchKernelGGL(wgrad_bf16_lean_kernel, grid, dim3(256), 0, st, d); which = "wgrad_bf16_lean"; }
     else if (a->dtype == ALDI_BF16) { hipLaunchKernelGGL(wgrad_bf16_kernel, grid, dim3(256), 0, st, d); which = "wgrad_bf16_generic"; }
     else if (a->dtype == ALDI_F32) { hipLaunchKernelGGL(wgrad_f32_kernel, grid, dim3(256), 0, st, d); which = "wgrad_f32"; }

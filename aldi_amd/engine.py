@@ -1023,12 +1023,16 @@ class RCNN:
 
     def _rpn_head_backward_sparse(self, c: Ctx, gP_roi: List[torch.Tensor]) -> List[torch.Tensor]:
         """RPN head backward over the ACTIVE pixels only (csrc/rpn_sparse.hip): d(loss)/d(head outputs) is non-zero at the sampled
-        anchors' pixels, at most RPN_BATCH per image and sample (the RPN losses' sample + the distillation losses' fresh one), i.e.
-        <= 2 * 256 * N of the 358 k pixel positions.  Returns d(loss)/d(P_l) in the compute dtype, ROIAlign's contribution
+        anchors' pixels (the RPN losses' sample + the positions the distillation losses' fresh sample selects), i.e. at
+        <= 4 * 256 * N of the 358 k pixel positions.  Returns d(loss)/d(P_l) in the compute dtype, ROIAlign's contribution
         (gP_roi, fp32) included -- summed in fp32 and rounded once."""
         W, T, dev = self.wts, self.dtype, self.device
         N, Cf, Ch = c.N, FPN_C, self.Ch
-        cap = 2 * RPN_BATCH * N
+        # bound on the active pixels of one image: RPN_BATCH sampled anchors of the RPN losses + RPN_BATCH mask positions of the
+        # distillation objectness loss + 4 per foreground position (<= RPN_BATCH / 2) of the distillation L1: the reference's
+        # `repeat_interleave(fg, 4)` mask lands on four consecutive positions of the RAW (N, 4A, H, W) layout, i.e. on four
+        # different pixels (SURVEY B.1)
+        cap = 4 * RPN_BATCH * N
         idx = torch.empty(cap, dtype=torch.int32, device=dev)
         count = torch.empty(1, dtype=torch.int32, device=dev)
         ops.rpn_active_pixels(c.geom, c.ghead, N, cap, idx, count, self.err)

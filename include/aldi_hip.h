@@ -43,6 +43,7 @@ int aldi_version(void);
  *   wgrad_big_min        slabs (64 pixels) per workgroup from which the 256x256 tile is used (28; 0 = never)
  *   wgrad_big_slots, wgrad_slots   target workgroup counts of the 256x256 / 128x128 forms (256, 384)
  *   wgrad_xcd            1 = XCD-aware order
+ *   wgrad_dma            LDS-DMA + ds_read_b64_tr_b16 weight-gradient kernel: 0 off, 1 in place of the lean kernel, 2 also of the 256x256
  *   colsum_blocks, colsum_minrows, colsum_nt, colsum_block_kb   aldi_bias_grad launch geometry
  *   stem_mfma            1 = MFMA stem kernel in bf16 mode
  *   sab_blocks, ln_bwd_blocks, ln_bwd_blocks_narrow   ConvNeXt scale-and-bias / LayerNorm backward launch geometry

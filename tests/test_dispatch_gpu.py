@@ -358,3 +358,28 @@ def test_wgrad_split_count_does_not_change_the_result(slots):
 
 def test_wgrad_fp32_fullsize():
     _check_wgrad((2, 100, 168, 256, 256, 3, 1, 1), torch.float32, "wgrad_f32")
+
+
+# ---------------------------------------------------------------------------------- LDS-DMA + transpose-read weight gradient
+DMA_CASES = [
+    (2, 25, 42, 256, 256, 3, 1, 1),        # ragged M, border taps, tile-aligned channels
+    (1, 19, 23, 256, 512, 1, 1, 0),        # 1x1
+    (3, 9, 130, 64, 256, 3, 1, 1),         # Cin = 64: two taps per 128-column tile; rows wider than a slab
+    (2, 13, 21, 256, 256, 3, 1, 1),        # p6-sized level: W < 32, a slab spans several image rows
+    (4, 1, 1, 1032, 48, 1, 1, 0),          # linear, ragged K and Cout below the tile
+    (4, 50, 84, 256, 256, 3, 1, 1),        # res4 conv2 at benchmark scale
+    (4, 100, 168, 128, 512, 1, 1, 0),      # res3 conv3
+    (4, 200, 336, 256, 256, 3, 1, 1),      # p2 3x3 (the 256x256 tile's shape)
+    (2048, 1, 1, 12544, 1024, 1, 1, 0),    # box head FC1
+    (4, 200, 336, 256, 16, 1, 1, 0),       # RPN heads
+]
+
+
+@pytest.mark.parametrize("case", DMA_CASES)
+def test_wgrad_dma_kernel(case):
+    _check_wgrad(case, torch.bfloat16, "wgrad_bf16_dma", knobs=[("wgrad_dma", 2)])
+
+
+@pytest.mark.parametrize("slots", [1, 1000])
+def test_wgrad_dma_split_counts(slots):
+    _check_wgrad((2, 50, 84, 256, 256, 3, 1, 1), torch.bfloat16, "wgrad_bf16_dma", knobs=[("wgrad_dma", 2), ("wgrad_slots", slots)])
