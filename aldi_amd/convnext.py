@@ -325,7 +325,7 @@ class ConvNeXtRCNN(_engine_base()):
             ops.conv_wgrad(x, g_fc1, vp.g(bh + "fc1.weight"), KH=1, KW=1)
             ops.bias_grad(g_fc1.view(c.R, -1), vp.g(bh + "fc1.bias"))
             g_pooled = ops.conv2d(g_fc1, vp.wt(bh + "fc1.weight")).view(c.R, cfg.pool, cfg.pool, C)
-            ops.roialign_backward(self.roi_feats(c, gP_roi), c.rois, c.R, cfg.pool, g_pooled, c.N)
+            ops.roialign_backward(self.roi_feats(c, gP_roi), c.rois, c.R, cfg.pool, g_pooled, c.N, rois_sorted=True)
         gP = []
         wt_out = self._pack_wt("rpn_head_out", C)
         for l in range(5):

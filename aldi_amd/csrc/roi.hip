@@ -289,8 +289,9 @@ struct GatherGeom { int blk_off[5]; int segs[4]; int N; };
 
 template <typename T>
 __global__ __launch_bounds__(256) void roialign_bwd_gather_kernel(Feats ft, GatherGeom gg, const float* __restrict__ rois, int R, int P,
-                                                                  const T* __restrict__ gp /*[R][P][P][C]*/) {
+                                                                  const T* __restrict__ gp /*[R][P][P][C]*/, int sorted) {
     __shared__ int cand[256];
+    __shared__ int range[2];
     __shared__ int sm[17];
     __shared__ float rowc[8];
     __shared__ float colc[kSeg][8];
@@ -312,11 +313,27 @@ __global__ __launch_bounds__(256) void roialign_bwd_gather_kernel(Feats ft, Gath
 #pragma unroll
     for (int i = 0; i < kSeg; ++i) acc[i] = 0.f;
 
-    for (int base = 0; base < R; base += 256) {
+    // ROI rows are grouped by image (the engine concatenates the per-image samples): only this image's rows can hit the segment
+    // -- a binary search instead of scanning all R rows in every one of the ~12 k workgroups
+    int r_lo = 0, r_hi = R;
+    if (sorted) {
+        if (tid < 2) {
+            const float key = (float)(b + tid);          // first row with image index >= b, resp. >= b + 1
+            int lo = 0, hi = R;
+            while (lo < hi) {
+                const int mid = (lo + hi) >> 1;
+                if (rois[(long)mid * 5] < key) lo = mid + 1; else hi = mid;
+            }
+            range[tid] = lo;
+        }
+        __syncthreads();
+        r_lo = range[0]; r_hi = range[1];
+    }
+    for (int base = r_lo; base < r_hi; base += 256) {
         // ---- candidates of this chunk: same image, same level, footprint bounding box meets the segment
         const int r = base + tid;
         bool hit = false;
-        if (r < R) {
+        if (r < r_hi) {
             const float* rp = rois + (long)r * 5;
             if ((int)rp[0] == b && roi_level(rp[1], rp[2], rp[3], rp[4]) == l) {
                 const float x1 = rp[1] * sc - 0.5f, y1 = rp[2] * sc - 0.5f, x2 = rp[3] * sc - 0.5f, y2 = rp[4] * sc - 0.5f;
@@ -605,8 +622,8 @@ extern "C" int aldi_roialign(const aldi_roi_feats* f, const float* rois, int R, 
     return ALDI_OK;
 }
 
-extern "C" int aldi_roialign_backward(const aldi_roi_feats* f, const float* rois, int R, int P, const void* g_pooled, int N, int dtype,
-                                      aldi_stream_t stream) {
+extern "C" int aldi_roialign_backward(const aldi_roi_feats* f, const float* rois, int R, int P, const void* g_pooled, int N, int rois_sorted,
+                                      int dtype, aldi_stream_t stream) {
     if (!f || !rois || !g_pooled || f->C != 256 || P > 7 || N < 1) return aldi_set_error_msg(ALDI_ERR_ARG, "roialign_backward: bad args (C must be 256, P <= 7)");
     Feats ft = make_feats(f, true);
     GatherGeom gg;
@@ -620,8 +637,8 @@ extern "C" int aldi_roialign_backward(const aldi_roi_feats* f, const float* rois
     }
     gg.blk_off[4] = off;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    if (dtype == ALDI_BF16) hipLaunchKernelGGL((roialign_bwd_gather_kernel<bf16_t>), dim3(off), dim3(256), 0, st, ft, gg, rois, R, P, (const bf16_t*)g_pooled);
-    else if (dtype == ALDI_F32) hipLaunchKernelGGL((roialign_bwd_gather_kernel<float>), dim3(off), dim3(256), 0, st, ft, gg, rois, R, P, (const float*)g_pooled);
+    if (dtype == ALDI_BF16) hipLaunchKernelGGL((roialign_bwd_gather_kernel<bf16_t>), dim3(off), dim3(256), 0, st, ft, gg, rois, R, P, (const bf16_t*)g_pooled, rois_sorted);
+    else if (dtype == ALDI_F32) hipLaunchKernelGGL((roialign_bwd_gather_kernel<float>), dim3(off), dim3(256), 0, st, ft, gg, rois, R, P, (const float*)g_pooled, rois_sorted);
     else return aldi_set_error_msg(ALDI_ERR_ARG, "roialign_backward: bad dtype");
     ALDI_CHECK_LAUNCH();
     return ALDI_OK;

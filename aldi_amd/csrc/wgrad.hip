@@ -26,7 +26,7 @@ namespace {
 struct WgDev {
     const void* x; const void* g; float* dw; const float* scale;
     int N, H, W, Cin, Cout, KH, KW, stride, pad, Ho, Wo;
-    int M, K, pix_per_split, ident, xcd;
+    int M, K, pix_per_split, ident, xcd, dbg;
     unsigned x_bytes, g_bytes, dw_bytes;
 };
 
@@ -315,6 +315,15 @@ __device__ __forceinline__ void wgrad_bf16_lean_body(const WgDev& p, uint4* lds)
                                                                          *reinterpret_cast<bf16x8_t*>(&bfr[j]), acc[i][j], 0, 0, 0);
         }
     }
+    if (p.dbg & 1) {     // ablation (wgrad_dbg): no atomics -- every accumulator stays live through one sum
+        float t = 0.f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) t += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
+        if (t == 123.456f) p.dw[0] = t;
+        return;
+    }
     {   // split-K partial tile -> fp32 gradient: 64 fire-and-forget buffer atomics per lane, out-of-tile lanes dropped
         const __amdgpu_buffer_rsrc_t rdw = make_rsrc_uniform(p.dw, p.dw_bytes);
 #pragma unroll
@@ -517,6 +526,15 @@ __global__ __launch_bounds__(WM* WN * 64) void wgrad_bf16_dma_kernel(WgDev p) {
         buf = buf == NBUF - 1 ? 0 : buf + 1;
         nbuf = nbuf == NBUF - 1 ? 0 : nbuf + 1;
     }
+    if (p.dbg & 1) {     // ablation (wgrad_dbg): no atomics
+        float t = 0.f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) t += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
+        if (t == 123.456f) p.dw[0] = t;
+        return;
+    }
     {   // split-K partial tile -> fp32 gradient (fire-and-forget buffer atomics, out-of-tile lanes dropped)
         const __amdgpu_buffer_rsrc_t rdw = make_rsrc_uniform(p.dw, p.dw_bytes);
 #pragma unroll
@@ -714,6 +732,7 @@ extern "C" int aldi_conv_wgrad(const aldi_wgrad_args* a, aldi_stream_t stream) {
     splits = cdiv(d.M, d.pix_per_split);
     dim3 grid(cdiv(d.Cout, tile), cdiv(d.K, tile), splits);
     d.xcd = tn.wgrad_xcd;
+    d.dbg = tn.wgrad_dbg;
     const char* which;
     // LDS-DMA + transpose-read form (wgrad_dma: 0 off, 1 = 128x128 tile in place of the lean kernel, 2 = also in place of the 256x256 one)
     const bool dma = lean && tn.wgrad_dma > 0 && (d.ident ? a->Cin % 8 == 0 : a->Cin % 16 == 0) && a->KH * a->KW <= 25 && !(big && tn.wgrad_dma < 2);

@@ -942,7 +942,7 @@ class RCNN:
             x = c.pooled.view(c.R, 1, 1, POOL * POOL * FPN_C)
             self._wgrad("roi_heads.box_head.fc1", x, g_fc1)
             g_pooled = ops.conv2d(g_fc1, W.wt("roi_heads.box_head.fc1")).view(c.R, POOL, POOL, FPN_C)
-            ops.roialign_backward(self.roi_feats(c, gP_roi), c.rois, c.R, POOL, g_pooled, c.N)
+            ops.roialign_backward(self.roi_feats(c, gP_roi), c.rois, c.R, POOL, g_pooled, c.N, rois_sorted=True)
         self._grads_final(["box_pred", "roi_heads.box_head.fc2", "roi_heads.box_head.fc1"])
         # ---- RPN head (shared weights over 5 levels)
         if self.sparse_rpn_backward:

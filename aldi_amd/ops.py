@@ -303,9 +303,9 @@ def roialign(feats: L.RoiFeats, rois, R, P, pooled, backward: bool):
     L.call("aldi_roialign", C.byref(feats), _p(rois), R, P, _p(pooled), int(backward), dtype_code(pooled.dtype), stream_ptr())
 
 
-def roialign_backward(feats: L.RoiFeats, rois, R, P, g_pooled, N):
+def roialign_backward(feats: L.RoiFeats, rois, R, P, g_pooled, N, rois_sorted: bool = False):
     """gather form: overwrites the fp32 gradient maps of `feats` (each element written once, no atomics)"""
-    L.call("aldi_roialign_backward", C.byref(feats), _p(rois), R, P, _p(g_pooled), N, dtype_code(g_pooled.dtype), stream_ptr())
+    L.call("aldi_roialign_backward", C.byref(feats), _p(rois), R, P, _p(g_pooled), N, int(rois_sorted), dtype_code(g_pooled.dtype), stream_ptr())
 
 
 def box_loss(pred, Cp, K, R, rois, cls, gt_boxes, weights4, gs_cls, gs_box, grad, loss2):

@@ -170,7 +170,7 @@ class VitDetRCNN(FlatParamRCNN):
         gP_roi = [(torch.empty if c.R > 0 else torch.zeros)(f.shape, dtype=torch.float32, device=dev) for f in c.P[:4]]
         if c.R > 0:
             g_pooled = self._box_head_backward(c)
-            ops.roialign_backward(self.roi_feats(c, gP_roi), c.rois, c.R, cfg.pool, g_pooled, c.N)
+            ops.roialign_backward(self.roi_feats(c, gP_roi), c.rois, c.R, cfg.pool, g_pooled, c.N, rois_sorted=True)
         gP = self._rpn_head_backward(c)
         ops.subsample2_bwd(gP[4], gP[3])                               # p6 = p5[:, ::2, ::2]
         for l in range(4):

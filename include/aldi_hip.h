@@ -43,6 +43,7 @@ int aldi_version(void);
  *   wgrad_big_min        slabs (64 pixels) per workgroup from which the 256x256 tile is used (28; 0 = never)
  *   wgrad_big_slots, wgrad_slots   target workgroup counts of the 256x256 / 128x128 forms (256, 384)
  *   wgrad_xcd            1 = XCD-aware order
+ *   wgrad_dbg            ablation bits (1 = skip the atomic epilogue): results are WRONG when set
  *   wgrad_dma            LDS-DMA + ds_read_b64_tr_b16 weight-gradient kernel: 0 off, 1 in place of the lean kernel, 2 also of the 256x256
  *   colsum_blocks, colsum_minrows, colsum_nt, colsum_block_kb   aldi_bias_grad launch geometry
  *   stem_mfma            1 = MFMA stem kernel in bf16 mode
@@ -247,8 +248,9 @@ int aldi_rois_from_proposals(const float* props, const int* pcount, int P, int N
 int aldi_roialign(const aldi_roi_feats* f, const float* rois, int R, int P, void* pooled, int backward, int dtype, aldi_stream_t stream);
 /* ROIAlign backward as a gather: OVERWRITES the four fp32 gradient maps f->grad[l] ([N][H_l][W_l][C], no zero-fill needed) with
  * d(loss)/d(feature) given g_pooled [R][P][P][C] in `dtype`; every element is written exactly once (deterministic, no atomics).
- * `aldi_roialign(..., backward=1)` is the accumulating scatter form of the same operator. */
-int aldi_roialign_backward(const aldi_roi_feats* f, const float* rois, int R, int P, const void* g_pooled, int N, int dtype,
+ * `aldi_roialign(..., backward=1)` is the accumulating scatter form of the same operator.  rois_sorted = 1 promises that the ROI
+ * rows are grouped by ascending image index (what label_and_sample_proposals produces): each workgroup then scans its image's rows only. */
+int aldi_roialign_backward(const aldi_roi_feats* f, const float* rois, int R, int P, const void* g_pooled, int N, int rois_sorted, int dtype,
                            aldi_stream_t stream);
 
 /* pred fp32 [R][Cp]: [0,K] class logits, then 4K class-specific deltas. loss2 += {CE mean, L1 sum/R};

@@ -351,6 +351,10 @@ def test_roialign_fwd_bwd_vs_oracle(dtype, tol):
     again = [torch.empty_like(t) for t in grads2]
     ops.roialign_backward(ops.make_roi_feats(fd, again, [1 / 4, 1 / 8, 1 / 16, 1 / 32]), rois, R, 7, gd, N)
     assert all(torch.equal(a, b) for a, b in zip(again, grads2))                                       # deterministic
+    # rows grouped by image (as the engine produces them): each workgroup scans its image's rows only -- same bits
+    srt = [torch.empty_like(t) for t in grads2]
+    ops.roialign_backward(ops.make_roi_feats(fd, srt, [1 / 4, 1 / 8, 1 / 16, 1 / 32]), rois, R, 7, gd, N, rois_sorted=True)
+    assert all(torch.equal(a, b) for a, b in zip(srt, grads2))
     # property: pooling a constant map returns the constant wherever the ROI lies inside the map
     const = [torch.full(f.shape, 3.0, dtype=dtype, device=DEV) for f in fd]
     inside = ((rois[:, 1] >= 0) & (rois[:, 2] >= 0) & (rois[:, 3] <= 640) & (rois[:, 4] <= 448)).nonzero().squeeze(1)
