@@ -177,12 +177,10 @@ __global__ __launch_bounds__(256) void wgrad_bf16_kernel(WgDev p) {
 // TCO x TKK output tile (channels of g x (tap, channel) of x), 64 pixels per slab; (TCO + TKK) / 64 waves, each loading 64
 // channels of one operand and owning a (TCO / WM) x (TKK / WN) piece of the accumulator.
 template <int TCO, int TKK, int WM, int WN>
+__device__ __forceinline__ void wgrad_bf16_lean_tile(const WgDev& p, uint4* lds, int bx, int by, int bz);
+
+template <int TCO, int TKK, int WM, int WN>
 __device__ __forceinline__ void wgrad_bf16_lean_body(const WgDev& p, uint4* lds) {
-    static_assert(WM * WN * 64 == TCO + TKK, "one loader wave per 64 channels");
-    constexpr int NGW = TCO / 64;                    // g-loader waves
-    constexpr int TM = TCO / WM / 16, TN = TKK / WN / 16;
-    constexpr int BP = 64;
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform role -> scalar descriptors
     // XCD-aware order: workgroup b runs on XCD b % 8; give every XCD a contiguous range of (split, tile) pairs, tile
     // fastest, so the tiles of one pixel range (which re-read the same x / g rows) share one L2.
     int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
@@ -196,6 +194,16 @@ __device__ __forceinline__ void wgrad_bf16_lean_body(const WgDev& p, uint4* lds)
         bx = bid % gx; bid /= gx;
         by = bid % gy; bz = bid / gy;
     }
+    wgrad_bf16_lean_tile<TCO, TKK, WM, WN>(p, lds, bx, by, bz);
+}
+
+template <int TCO, int TKK, int WM, int WN>
+__device__ __forceinline__ void wgrad_bf16_lean_tile(const WgDev& p, uint4* lds, int bx, int by, int bz) {
+    static_assert(WM * WN * 64 == TCO + TKK, "one loader wave per 64 channels");
+    constexpr int NGW = TCO / 64;                    // g-loader waves
+    constexpr int TM = TCO / WM / 16, TN = TKK / WN / 16;
+    constexpr int BP = 64;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform role -> scalar descriptors
     const int co0 = bx * TCO, kk0 = by * TKK;
     const int pbeg = bz * p.pix_per_split;
     const int pend = min(p.M, pbeg + p.pix_per_split);
@@ -348,6 +356,32 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void w
     __shared__ uint4 lds[2 * 128 * 8];
     wgrad_bf16_lean_body<128, 128, 2, 2>(p, lds);
 }
+// Grouped form: the weight gradients of SEVERAL layers in one launch.  A bottleneck stage's layers are small GEMMs (16-36 output
+// tiles each) over the same 16800 pixels; launched one by one each needs an 11-24-way pixel split to occupy the chip, and every
+// split ends in 16 K float atomics -- 20-50 % of the kernel time (tools/wgrad_sweep.py) -- plus a launch and a tail per layer.
+// The backward pass does not need them one by one (nothing reads a weight gradient before the optimizer), so the engine
+// collects a stage's layers and launches them together: hundreds of tiles, (almost) no pixel split, a handful of atomics.
+constexpr int kMaxGroup = 24;
+struct WgGroup {
+    int n;
+    int wg_begin[kMaxGroup + 1];      // first workgroup of each problem; wg_begin[n] = grid size
+    int gx[kMaxGroup], gy[kMaxGroup]; // output tiles of each problem (its workgroups: tile-fastest, then split)
+    WgDev p[kMaxGroup];
+};
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void wgrad_bf16_lean_group_kernel(WgGroup G) {
+    __shared__ uint4 lds[2 * 128 * 8];
+    // longest problems first in the launch order is the host's job; here: which problem does this workgroup belong to
+    const int bid = (int)blockIdx.x;
+    int i = 0;
+    for (int k = 1; k < G.n; ++k)
+        if (bid >= G.wg_begin[k]) i = k;
+    i = __builtin_amdgcn_readfirstlane(i);
+    const int local = bid - G.wg_begin[i];
+    const int tiles = G.gx[i] * G.gy[i];
+    const int t = local % tiles, bz = local / tiles;
+    wgrad_bf16_lean_tile<128, 128, 2, 2>(G.p[i], lds, t % G.gx[i], t / G.gx[i], bz);
+}
+
 // 256 x 256 tile, 8 waves (128 x 64 each), one workgroup per CU: half the L2 -> CU bytes per FLOP, for layers whose
 // pixel ranges are long enough to amortise the 256-KB atomic epilogue
 __global__ __launch_bounds__(512) void wgrad_bf16_big_kernel(WgDev p) {
@@ -679,11 +713,12 @@ __global__ __launch_bounds__(NT) void colsum_kernel(const T* __restrict__ g, flo
 
 }  // namespace
 
-extern "C" int aldi_conv_wgrad(const aldi_wgrad_args* a, aldi_stream_t stream) {
+namespace {
+// validated device-side description of one weight-gradient problem
+int fill_wgdev(const aldi_wgrad_args* a, WgDev& d) {
     if (!a || !a->x || !a->g || !a->dw) return aldi_set_error_msg(ALDI_ERR_ARG, "conv_wgrad: null pointer");
     const int ep = a->dtype == ALDI_BF16 ? 8 : 4;
     if (a->Cin % ep || a->Cout % ep) return aldi_set_error_msg(ALDI_ERR_ARG, "conv_wgrad: Cin/Cout must be multiples of a 16-B chunk");
-    WgDev d;
     d.x = a->x; d.g = a->g; d.dw = a->dw; d.scale = a->scale;
     d.N = a->N; d.H = a->H; d.W = a->W; d.Cin = a->Cin; d.Cout = a->Cout; d.KH = a->KH; d.KW = a->KW;
     d.stride = a->stride; d.pad = a->pad; d.Ho = a->Ho; d.Wo = a->Wo;
@@ -691,18 +726,100 @@ extern "C" int aldi_conv_wgrad(const aldi_wgrad_args* a, aldi_stream_t stream) {
     if (M <= 0 || M > 0x7fffffffL) return aldi_set_error_msg(ALDI_ERR_ARG, "conv_wgrad: bad M");
     d.M = (int)M;
     d.K = a->KH * a->KW * a->Cin;
-    {
-        const size_t esz = a->dtype == ALDI_BF16 ? 2 : 4;
-        const size_t xb = (size_t)a->N * a->H * a->W * a->Cin * esz, gb = (size_t)M * a->Cout * esz;
-        if (a->dtype == ALDI_BF16 && (xb >= 0x80000000ull || gb >= 0x80000000ull))
-            return aldi_set_error_msg(ALDI_ERR_ARG, "conv_wgrad: operand larger than 2 GiB (32-bit buffer offsets)");
-        d.x_bytes = (unsigned)xb;
-        d.g_bytes = (unsigned)gb;
-        const size_t wb = (size_t)a->Cout * d.K * 4;
-        if (wb >= 0x80000000ull) return aldi_set_error_msg(ALDI_ERR_ARG, "conv_wgrad: gradient larger than 2 GiB (32-bit buffer offsets)");
-        d.dw_bytes = (unsigned)wb;
-    }
+    const size_t esz = a->dtype == ALDI_BF16 ? 2 : 4;
+    const size_t xb = (size_t)a->N * a->H * a->W * a->Cin * esz, gb = (size_t)M * a->Cout * esz;
+    if (a->dtype == ALDI_BF16 && (xb >= 0x80000000ull || gb >= 0x80000000ull))
+        return aldi_set_error_msg(ALDI_ERR_ARG, "conv_wgrad: operand larger than 2 GiB (32-bit buffer offsets)");
+    d.x_bytes = (unsigned)xb;
+    d.g_bytes = (unsigned)gb;
+    const size_t wb = (size_t)a->Cout * d.K * 4;
+    if (wb >= 0x80000000ull) return aldi_set_error_msg(ALDI_ERR_ARG, "conv_wgrad: gradient larger than 2 GiB (32-bit buffer offsets)");
+    d.dw_bytes = (unsigned)wb;
     d.ident = (a->KH == 1 && a->KW == 1 && a->stride == 1 && a->pad == 0 && a->Ho == a->H && a->Wo == a->W) ? 1 : 0;
+    d.pix_per_split = d.M; d.xcd = 0; d.dbg = 0;
+    return ALDI_OK;
+}
+bool lean_eligible(const aldi_wgrad_args* a, const WgDev& d) {
+    const bool same = a->stride == 1 && a->Ho == a->H && a->Wo == a->W && 2 * a->pad == a->KH - 1 && a->KH == a->KW && a->Cin % 64 == 0;
+    return a->dtype == ALDI_BF16 && (d.ident || same);
+}
+// 256x256 tile (one 8-wave workgroup per CU) when every workgroup still gets a long pixel range
+bool wants_big_tile(const WgDev& d, const AldiTuning& tn) {
+    if (tn.wgrad_big_min <= 0 || d.Cout % 256 || d.K % 256) return false;
+    const int tb = (d.Cout / 256) * (d.K / 256);
+    const int sb = tn.wgrad_big_slots / tb;            // floor: one 8-wave workgroup per CU, never 257 of them
+    return cdiv(d.M, 64) / (sb > 0 ? sb : 1) >= tn.wgrad_big_min;
+}
+}  // namespace
+
+extern "C" int aldi_conv_wgrad_group(const aldi_wgrad_args* args, int n, aldi_stream_t stream) {
+    if (!args || n < 1) return aldi_set_error_msg(ALDI_ERR_ARG, "conv_wgrad_group: no problems");
+    const AldiTuning& tn = aldi_tuning();
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    // problems the lean 128x128 kernel cannot take (fp32, strided, unpadded ...) go through the single-problem dispatcher
+    static thread_local WgGroup G;
+    int order[kMaxGroup];
+    int ng = 0;
+    for (int i = 0; i < n; ++i) {
+        WgDev d;
+        if (int rc = fill_wgdev(&args[i], d)) return rc;
+        if (!lean_eligible(&args[i], d) || !tn.wgrad_lean || ng == kMaxGroup || wants_big_tile(d, tn)) {      // (the big tile has its own launch)
+            if (int rc = aldi_conv_wgrad(&args[i], stream)) return rc;
+            continue;
+        }
+        d.dbg = tn.wgrad_dbg;
+        G.p[ng] = d;
+        order[ng] = ng;
+        ++ng;
+    }
+    if (ng == 0) return ALDI_OK;
+    // Pixels per workgroup: ONE value T for the whole group (workgroups of equal length), the largest for which the launch
+    // still has wgrad_group_slots workgroups -- i.e. as few pixel splits (atomic epilogues) as filling the chip allows.
+    long tiles_of[kMaxGroup];
+    long maxM = 0;
+    for (int i = 0; i < ng; ++i) {
+        tiles_of[i] = (long)cdiv(G.p[i].Cout, 128) * cdiv(G.p[i].K, 128);
+        if (G.p[i].M > maxM) maxM = G.p[i].M;
+    }
+    auto wgs_for = [&](long T) {
+        long w = 0;
+        for (int i = 0; i < ng; ++i) w += tiles_of[i] * cdiv(G.p[i].M, T);
+        return w;
+    };
+    long T = (maxM + 63) / 64 * 64;
+    const long target = tn.wgrad_group_slots;
+    while (T > 256 && wgs_for(T) < target) T = (T / 2 + 63) / 64 * 64;       // >= 4 slabs behind every epilogue
+    // longest-running problems first (K x K convs before 1x1: more k-steps per pixel do not matter, pixels per workgroup do)
+    for (int i = 1; i < ng; ++i)
+        for (int j = i; j > 0 && G.p[order[j]].M > G.p[order[j - 1]].M; --j) { int t_ = order[j]; order[j] = order[j - 1]; order[j - 1] = t_; }
+    static thread_local WgGroup L_;
+    L_.n = ng;
+    int wg = 0;
+    for (int k = 0; k < ng; ++k) {
+        WgDev d = G.p[order[k]];
+        d.pix_per_split = (int)(T < d.M ? T : (d.M + 63) / 64 * 64);
+        L_.p[k] = d;
+        L_.gx[k] = cdiv(d.Cout, 128);
+        L_.gy[k] = cdiv(d.K, 128);
+        L_.wg_begin[k] = wg;
+        wg += L_.gx[k] * L_.gy[k] * cdiv(d.M, d.pix_per_split);
+    }
+    for (int k = ng; k <= kMaxGroup; ++k) L_.wg_begin[k] = wg;
+    hipLaunchKernelGGL(wgrad_bf16_lean_group_kernel, dim3(wg), dim3(256), 0, st, L_);
+    ALDI_CHECK_LAUNCH();
+    {
+        char name[96];
+        snprintf(name, sizeof(name), "wgrad_bf16_lean_group n=%d wgs=%d pix=%ld", ng, wg, T);
+        aldi_note_dispatch(name);
+    }
+    return ALDI_OK;
+}
+
+extern "C" int aldi_conv_wgrad(const aldi_wgrad_args* a, aldi_stream_t stream) {
+    WgDev d;
+    if (int rc = fill_wgdev(a, d)) return rc;
+    long M = d.M;
+    (void)M;
     hipStream_t st = static_cast<hipStream_t>(stream);
     const AldiTuning& tn = aldi_tuning();
     const int lean_env = tn.wgrad_lean, big_min_env = tn.wgrad_big_min, big_slots_env = tn.wgrad_big_slots;
@@ -710,13 +827,8 @@ extern "C" int aldi_conv_wgrad(const aldi_wgrad_args* a, aldi_stream_t stream) {
     const bool lean = a->dtype == ALDI_BF16 && lean_env && (d.ident || same);
     const int bp = a->dtype == ALDI_BF16 ? 64 : 16;
     int slabs = cdiv(d.M, bp);
-    // 256x256 tile (one 8-wave workgroup per CU) when every workgroup still gets a long pixel range
-    bool big = false;
-    if (lean && big_min_env > 0 && d.Cout % 256 == 0 && d.K % 256 == 0) {
-        const int tb = (d.Cout / 256) * (d.K / 256);
-        const int sb = big_slots_env / tb;            // floor: one 8-wave workgroup per CU, never 257 of them
-        big = slabs / (sb > 0 ? sb : 1) >= big_min_env;
-    }
+    const bool big = lean && wants_big_tile(d, tn);
+    (void)big_min_env;
     const int tile = big ? 256 : (a->dtype == ALDI_BF16 ? 128 : 64);
     int tiles = cdiv(d.Cout, tile) * cdiv(d.K, tile);
     const int slots_env_ = tn.wgrad_slots;

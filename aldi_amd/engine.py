@@ -266,6 +266,8 @@ class RCNN:
         self.img_da_layers = sorted((n for n in names if n.startswith("img_align.model.")), key=idx)
         self.ins_da_layers = sorted((n for n in names if n.startswith("ins_align.model.")), key=idx)
         self.has_img_da, self.has_ins_da = bool(self.img_da_layers), bool(self.ins_da_layers)
+        self.group_wgrad = os.environ.get("ALDI_WGRAD_GROUP", "1") == "1"                # bf16: a layer group's weight gradients in one launch
+        self._wg_queue: list = []
         self.sparse_rpn_backward = os.environ.get("ALDI_RPN_SPARSE_BWD", "1") == "1"      # tests flip the attribute to compare with the dense form
         spec = getattr(weights.layout, "img_da", None)
         self.img_da_level = ("p2", "p3", "p4", "p5", "p6").index(spec["layer"]) if spec else 0
@@ -1051,6 +1053,7 @@ class RCNN:
     def _grads_final(self, names: List[str]):
         """tell the gradient exchange (if one is attached: data-parallel fused step) that these layers' gradients are
         complete for this step -- every kernel writing them has been enqueued."""
+        self._flush_wgrads()
         cb = getattr(self, "grad_ready", None)
         if cb is None:
             return
@@ -1073,15 +1076,20 @@ class RCNN:
             cb(self.wts.layout.ranges(names))
 
     def _wgrad(self, name: str, x: torch.Tensor, g: torch.Tensor, flat: bool = False, temp_x: bool = False):
-        """weight (+ bias) gradient of one layer (`flat`: x holds im2col rows [S][KH*KW*Cin], the gradient is a plain GEMM).  The data-gradient chain never reads these results, so they run on a
-        second HIP stream beside it: a wgrad launch of a deep layer is only 1-2 workgroups per CU, the dgrad igemm of
-        the same layer likewise, and neither fills the chip on its own."""
+        """weight (+ bias) gradient of one layer (`flat`: x holds im2col rows [S][KH*KW*Cin], the gradient is a plain GEMM).
+        Nothing reads these results before the optimizer, so (a) in bf16 mode they are only QUEUED here and launched per layer
+        group -- a stage's small GEMMs in one grouped launch, csrc/wgrad.hip -- when `_grads_final` / `_join_wgrads` flushes,
+        and (b) they run on a second HIP stream beside the data-gradient chain."""
         W = self.wts
         p = W.layout.t[name]
-        side = self._wgrad_stream()
         geo = dict(KH=1, KW=1, stride=1, pad=0) if flat else dict(KH=p.kk, KW=p.kk, stride=p.stride, pad=p.pad)
+        geo["scale"] = W.scale(name)
+        if getattr(self, "group_wgrad", False) and self.dtype == torch.bfloat16:
+            self._wg_queue.append((x, g, W.gw(name), geo, W.gb(name) if p.bias else None, temp_x))
+            return
+        side = self._wgrad_stream()
         if side is None:
-            ops.conv_wgrad(x, g, W.gw(name), scale=W.scale(name), **geo)
+            ops.conv_wgrad(x, g, W.gw(name), **geo)
             if p.bias:
                 ops.bias_grad(g, W.gb(name))
             return
@@ -1092,9 +1100,36 @@ class RCNN:
         if temp_x:
             x.record_stream(side)                    # x is a temporary too (gathered rows), not a saved activation
         with torch.cuda.stream(side):
-            ops.conv_wgrad(x, g, W.gw(name), scale=W.scale(name), **geo)
+            ops.conv_wgrad(x, g, W.gw(name), **geo)
             if p.bias:
                 ops.bias_grad(g, W.gb(name))
+        self._wgrad_pending = True
+
+    def _flush_wgrads(self):
+        """launch the queued weight gradients: one grouped launch (+ the bias sums) on the weight-gradient stream"""
+        q = getattr(self, "_wg_queue", None)
+        if not q:
+            return
+        self._wg_queue = []
+        side = self._wgrad_stream()
+
+        def launch():
+            ops.conv_wgrad_group([(x, g, dw, geo) for x, g, dw, geo, _, _ in q])
+            for _, g, _, _, gb, _ in q:
+                if gb is not None:
+                    ops.bias_grad(g, gb)
+        if side is None:
+            launch()
+            return
+        ev = torch.cuda.Event()
+        ev.record()
+        side.wait_event(ev)
+        for x, g, _, _, _, temp_x in q:
+            g.record_stream(side)
+            if temp_x:
+                x.record_stream(side)
+        with torch.cuda.stream(side):
+            launch()
         self._wgrad_pending = True
 
     def _wgrad_stream(self):
@@ -1105,6 +1140,7 @@ class RCNN:
 
     def _join_wgrads(self):
         """main stream waits for every weight-gradient kernel issued so far"""
+        self._flush_wgrads()
         if getattr(self, "_wg_side", None) is not None and self._wgrad_pending:
             torch.cuda.current_stream().wait_stream(self._wg_side)
             self._wgrad_pending = False

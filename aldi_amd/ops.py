@@ -92,6 +92,19 @@ def conv_wgrad(x: torch.Tensor, g: torch.Tensor, dw: torch.Tensor, *, KH: int, K
     L.call("aldi_conv_wgrad", C.byref(a), stream_ptr())
 
 
+def conv_wgrad_group(problems) -> None:
+    """several weight gradients in one launch (aldi_conv_wgrad_group); problems = [(x, g, dw, dict(KH, KW, stride, pad, scale))]"""
+    arr = (L.WgradArgs * len(problems))()
+    for i, (x, g, dw, kw) in enumerate(problems):
+        N, H, W_, Cin = x.shape
+        _, Ho, Wo, Cout = g.shape
+        KH, KW = kw["KH"], kw["KW"]
+        assert dw.dtype == torch.float32 and dw.numel() == Cout * KH * KW * Cin and x.dtype == g.dtype, (dw.shape, x.shape, g.shape)
+        arr[i] = L.WgradArgs(_p(x), _p(g), _p(dw), _p(kw.get("scale")), N, H, W_, Cin, Cout, KH, KW, kw.get("stride", 1), kw.get("pad", 0), Ho, Wo,
+                             dtype_code(x.dtype))
+    L.call("aldi_conv_wgrad_group", arr, len(problems), stream_ptr())
+
+
 def bias_grad(g: torch.Tensor, db: torch.Tensor) -> None:
     Cc = g.shape[-1]
     L.call("aldi_bias_grad", _p(g), _p(db), g.numel() // Cc, Cc, dtype_code(g.dtype), stream_ptr())

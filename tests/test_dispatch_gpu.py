@@ -383,3 +383,57 @@ def test_wgrad_dma_kernel(case):
 @pytest.mark.parametrize("slots", [1, 1000])
 def test_wgrad_dma_split_counts(slots):
     _check_wgrad((2, 50, 84, 256, 256, 3, 1, 1), torch.bfloat16, "wgrad_bf16_dma", knobs=[("wgrad_dma", 2), ("wgrad_slots", slots)])
+
+
+# ---------------------------------------------------------------------------------- grouped weight gradients (one launch per layer group)
+def test_wgrad_group_equals_single_launches():
+    """a res4-like stage (the small GEMMs over the same pixels), a p2 3x3 (goes to its own 256x256-tile launch), a strided 1x1 and
+    an fp32 problem (forwarded to the single-problem dispatcher) through aldi_conv_wgrad_group == one aldi_conv_wgrad each"""
+    from aldi_amd import _lib as L
+    from aldi_amd import ops
+    gen = torch.Generator().manual_seed(3)
+    dev = "cuda"
+    cases = [(4, 50, 84, 256, 256, 3, 1, 1), (4, 50, 84, 1024, 256, 1, 1, 0), (4, 50, 84, 256, 1024, 1, 1, 0), (4, 50, 84, 256, 256, 3, 1, 1),
+             (4, 25, 42, 512, 512, 3, 1, 1), (2, 200, 336, 256, 256, 3, 1, 1), (4, 100, 168, 256, 512, 1, 2, 0), (4096, 1, 1, 2304, 256, 1, 1, 0),
+             (4096, 1, 1, 256, 16, 1, 1, 0)]
+    probs, refs = [], []
+    for (N, H, W_, Cin, Cout, k, stride, pad) in cases:
+        Ho, Wo = (H + 2 * pad - k) // stride + 1, (W_ + 2 * pad - k) // stride + 1
+        x = torch.randn(N, H, W_, Cin, generator=gen).to(dev, torch.bfloat16)
+        g = (torch.randn(N, Ho, Wo, Cout, generator=gen) * 0.1).to(dev, torch.bfloat16)
+        sc = (0.5 + torch.rand(Cout, generator=gen)).to(dev)
+        dw0 = torch.randn(Cout, k, k, Cin, generator=gen).to(dev)
+        geo = dict(KH=k, KW=k, stride=stride, pad=pad, scale=sc)
+        one = dw0.clone()
+        ops.conv_wgrad(x, g, one, **geo)
+        refs.append(one)
+        probs.append((x, g, dw0.clone(), geo))
+    ops.conv_wgrad_group(probs)
+    name = L.last_dispatch()
+    torch.cuda.synchronize()
+    assert name.startswith("wgrad_bf16_lean_group n=7"), name          # 9 problems: p2 3x3 -> big tile, strided -> generic, 7 grouped
+    for (x, g, dw, geo), ref, case in zip(probs, refs, cases):
+        e = (dw - ref).abs().max().item()
+        assert e <= 2e-5 * max(1.0, ref.abs().max().item()) * max(1.0, (x.shape[0] * x.shape[1] * x.shape[2] / 1024) ** 0.5), (case, e)
+    # fewer pixel splits than the single launches: the whole group fits ~one wave of workgroups
+    wgs = int(name.split("wgs=")[1].split()[0])
+    assert 300 <= wgs <= 1200, name
+
+
+@pytest.mark.parametrize("slots", [1, 4000])
+def test_wgrad_group_split_policy(slots):
+    from aldi_amd import _lib as L
+    from aldi_amd import ops
+    L.set_tuning("wgrad_group_slots", slots)
+    gen = torch.Generator().manual_seed(4)
+    probs, refs = [], []
+    for (N, H, W_, Cin, Cout, k) in [(2, 25, 42, 256, 256, 3), (1, 19, 23, 256, 512, 1), (3, 9, 130, 64, 256, 3)]:
+        x = torch.randn(N, H, W_, Cin, generator=gen).to("cuda", torch.bfloat16)
+        g = (torch.randn(N, H, W_, Cout, generator=gen) * 0.1).to("cuda", torch.bfloat16)
+        dw = torch.zeros(Cout, k, k, Cin, device="cuda")
+        refs.append(_wgrad_ref(x, g, k, 1, k // 2))
+        probs.append((x, g, dw, dict(KH=k, KW=k, stride=1, pad=k // 2)))
+    ops.conv_wgrad_group(probs)
+    torch.cuda.synchronize()
+    for (x, g, dw, _), ref in zip(probs, refs):
+        assert (dw.double() - ref).abs().max().item() <= 3e-6 * max(1.0, ref.abs().max().item()) * 2
