@@ -238,12 +238,23 @@ def profile_insitu(step_fn, table_path=None):
         e1.record()
         key = ("wgrad",) + tuple(x.shape) + (g.shape[3], kw["KH"], kw.get("stride", 1), kw.get("pad", 0))
         rec.append((key, 2.0 * g.numel() * kw["KH"] * kw["KW"] * x.shape[3], x.element_size() * (x.numel() + g.numel()) + 8 * dw.numel(), e0, e1))
-    ops.conv2d, ops.conv_wgrad = conv2d, conv_wgrad
+    orig_group = ops.conv_wgrad_group
+
+    def conv_wgrad_group(problems):
+        """a layer group's weight gradients in one launch: timed as one, its FLOPs / bytes are the sums"""
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        orig_group(problems)
+        e1.record()
+        fl = sum(2.0 * g.numel() * kw["KH"] * kw["KW"] * x.shape[3] for x, g, dw, kw in problems)
+        nby = sum(x.element_size() * (x.numel() + g.numel()) + 8 * dw.numel() for x, g, dw, kw in problems)
+        rec.append((("wgrad", "group of %d" % len(problems)) + tuple(sorted({tuple(x.shape) for x, _, _, _ in problems}))[:3], fl, nby, e0, e1))
+    ops.conv2d, ops.conv_wgrad, ops.conv_wgrad_group = conv2d, conv_wgrad, conv_wgrad_group
     try:
         step_fn()
         torch.cuda.synchronize()
     finally:
-        ops.conv2d, ops.conv_wgrad = orig_conv, orig_wg
+        ops.conv2d, ops.conv_wgrad, ops.conv_wgrad_group = orig_conv, orig_wg, orig_group
     shapes, out = {}, {}
     for fam in ("igemm", "wgrad"):
         out[fam] = {"launches": 0, "flops": 0.0, "ms": 0.0, "bytes": 0}
