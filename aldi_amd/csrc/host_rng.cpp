@@ -11,6 +11,7 @@
 #include "../../include/aldi_hip.h"
 int aldi_set_error_msg(int code, const char* msg);   // core.hip
 #include <string.h>
+#include <thread>
 #include <vector>
 
 namespace {
@@ -74,11 +75,11 @@ struct Mt {
 
 }  // namespace
 
-// state: CPUGeneratorImplState blob {u64 seed; i32 left; i32 seeded; u64 next; u64 state[624]; ...}.  out: k int64.
-extern "C" int aldi_torch_randperm_prefix(unsigned char* state, long n, long k, long* out) {
-    if (k > n) k = n;
-    if (!state || n < 0 || k < 0 || (k > 0 && !out)) return aldi_set_error_msg(ALDI_ERR_ARG, "torch_randperm_prefix: bad args");
-    Mt mt;
+namespace {
+
+constexpr int kBlobBytes = 5056;          // CPUGeneratorImplState: legacy state (5048 B) + float normal sample + its valid flag
+
+void load_blob(const unsigned char* state, Mt& mt) {
     int32_t left;
     uint64_t next, w;
     memcpy(&left, state + 8, 4);
@@ -86,6 +87,27 @@ extern "C" int aldi_torch_randperm_prefix(unsigned char* state, long n, long k, 
     for (int i = 0; i < MT_N; ++i) { memcpy(&w, state + 24 + 8 * i, 8); mt.s[i] = (uint32_t)w; }
     mt.left = left;
     mt.next = next;
+}
+void store_blob(unsigned char* state, const Mt& mt) {
+    const int32_t left = mt.left;
+    const uint64_t next = mt.next;
+    uint64_t w;
+    memcpy(state + 8, &left, 4);
+    memcpy(state + 16, &next, 8);
+    for (int i = 0; i < MT_N; ++i) { w = mt.s[i]; memcpy(state + 24 + 8 * i, &w, 8); }
+}
+// at::mt19937(seed): what torch.manual_seed leaves in the engine (left = 1: the first draw regenerates the state)
+void seed_mt(Mt& mt, uint64_t seed) {
+    mt.s[0] = (uint32_t)(seed & 0xffffffffu);
+    for (int j = 1; j < MT_N; ++j) mt.s[j] = 1812433253u * (mt.s[j - 1] ^ (mt.s[j - 1] >> 30)) + (uint32_t)j;
+    mt.left = 1;
+    mt.next = 0;
+}
+
+// first k entries of torch.randperm(n) from `mt`, which ends where torch's generator would
+template <typename OutT>
+void randperm_prefix(Mt& mt, long n, long k, OutT* out) {
+    if (k > n) k = n;
     // sparse image of the permutation array: position -> value for the <= 2k positions touched so far (open addressing;
     // a node-based map costs more than the shuffle itself for the small lists)
     size_t cap = 64;
@@ -109,11 +131,75 @@ extern "C" int aldi_torch_randperm_prefix(unsigned char* state, long n, long k, 
         put(j, vi);
     }
     mt.discard(iters - run);
-    for (long i = 0; i < k; ++i) out[i] = get(i);
-    left = mt.left;
-    next = mt.next;
-    memcpy(state + 8, &left, 4);
-    memcpy(state + 16, &next, 8);
-    for (int i = 0; i < MT_N; ++i) { w = mt.s[i]; memcpy(state + 24 + 8 * i, &w, 8); }
+    for (long i = 0; i < k; ++i) out[i] = (OutT)get(i);
+}
+
+}  // namespace
+
+// state: CPUGeneratorImplState blob {u64 seed; i32 left; i32 seeded; u64 next; u64 state[624]; ...}.  out: k int64.
+extern "C" int aldi_torch_randperm_prefix(unsigned char* state, long n, long k, long* out) {
+    if (k > n) k = n;
+    if (!state || n < 0 || k < 0 || (k > 0 && !out)) return aldi_set_error_msg(ALDI_ERR_ARG, "torch_randperm_prefix: bad args");
+    Mt mt;
+    load_blob(state, mt);
+    randperm_prefix<long>(mt, n, k, out);
+    store_blob(state, mt);
+    return ALDI_OK;
+}
+
+// A whole iteration's sampling draws in one call.  script: nops rows of {kind, a, b, out_off}:
+//   kind 0  draw: the first min(b, a) entries of torch.randperm(a) -> out[out_off ...] (int32); out_off < 0 discards them
+//   kind 1  torch.manual_seed(a)
+// The generator state after a manual_seed does not depend on anything before it, so the script splits into segments at the
+// seeds and the segments run on `threads` host threads (the cost is the Mersenne-Twister skip-ahead of the 268k-entry negative
+// lists: ~80 us each, six per iteration); the blob ends as the sequential execution leaves it.
+extern "C" int aldi_torch_rng_script(unsigned char* state, const long* script, int nops, int* out, int threads) {
+    if (!state || !script || nops < 0 || (!out && nops > 0)) return aldi_set_error_msg(ALDI_ERR_ARG, "torch_rng_script: bad args");
+    struct Seg { int begin, end; bool seeded; uint64_t seed; Mt mt; };
+    std::vector<Seg> segs;
+    segs.push_back(Seg{0, 0, false, 0, Mt()});
+    for (int i = 0; i < nops; ++i) {
+        const long kind = script[4 * i];
+        if (kind == 1) {
+            segs.back().end = i;
+            segs.push_back(Seg{i + 1, i + 1, true, (uint64_t)script[4 * i + 1], Mt()});
+        } else if (kind != 0 || script[4 * i + 1] < 0 || script[4 * i + 2] < 0) {
+            return aldi_set_error_msg(ALDI_ERR_ARG, "torch_rng_script: bad op");
+        }
+    }
+    segs.back().end = nops;
+    auto run = [&](Seg& sg) {
+        if (sg.seeded) seed_mt(sg.mt, sg.seed);
+        else load_blob(state, sg.mt);
+        static thread_local std::vector<int> scratch;
+        for (int i = sg.begin; i < sg.end; ++i) {
+            const long n = script[4 * i + 1], k = script[4 * i + 2], off = script[4 * i + 3];
+            int* dst = out + off;
+            if (off < 0) {
+                scratch.resize((size_t)(k < n ? k : n) + 1);
+                dst = scratch.data();
+            }
+            randperm_prefix<int>(sg.mt, n, k, dst);
+        }
+    };
+    if (threads > 1 && segs.size() > 1) {
+        std::vector<std::thread> pool;
+        for (size_t i = 1; i < segs.size(); ++i) pool.emplace_back(run, std::ref(segs[i]));
+        run(segs[0]);
+        for (auto& t : pool) t.join();
+    } else {
+        for (auto& sg : segs) run(sg);
+    }
+    const Seg& last = segs.back();
+    if (last.seeded) {                     // what torch.manual_seed(seed) + the draws leave in the blob
+        const uint64_t seed = last.seed;
+        const int32_t one = 1, zero = 0;
+        memcpy(state, &seed, 8);
+        memcpy(state + 12, &one, 4);       // seeded
+        memset(state + 24 + 8 * MT_N, 0, 24);                 // normal_x, normal_y, normal_rho
+        memcpy(state + 24 + 8 * MT_N + 24, &zero, 4);         // normal_is_valid
+        memset(state + kBlobBytes - 8, 0, 8);                 // next_float_normal_sample + its valid flag
+    }
+    store_blob(state, last.mt);
     return ALDI_OK;
 }

@@ -173,26 +173,77 @@ class FusedStep:
         return SimpleNamespace(c=c, tc=tc, prep=prep)
 
     # ------------------------------------------------------------------------------------------------ host phase
+    def _hooks_are_standard(self) -> bool:
+        """the only forward pre-hooks on the two roi_heads are the distiller's own (ManualSeed on both, ReplaceProposalsOnce on the
+        teacher: aldi/distill.py:131-138): then the host phase can run as one scripted C call instead of firing Python hooks"""
+        dist_, model = self.tr.distiller, self.tr.model
+        seeder = getattr(dist_, "seeder", None)
+        if seeder is None or model.roi_heads.pre_hooks != [seeder]:
+            return False
+        if self.teacher is not None:
+            rep = getattr(dist_, "teacher_proposal_replacer", None)
+            if self.teacher.roi_heads.pre_hooks != [seeder, rep] or rep is None or rep.proposals is not None:
+                return False
+        return True
+
     def _host_draws(self, S, A):
-        """every sampling draw of the iteration on the global CPU generator, in the reference's order"""
+        """every sampling draw of the iteration on the global CPU generator, in the reference's order:
+        per micro-step the RPN sample (two randperm per image), `torch.manual_seed(seed)` by the roi_heads pre-hook, the ROI
+        sample; for the distillation micro-step first the teacher's eval inference re-seeds with the OLD seed and the seeder
+        draws a new one (aldi/distill.py:148-150), afterwards the teacher's train-mode forward repeats the ROI draws under the
+        same seed and `get_rpn_losses` draws a fresh RPN sample (aldi/distill.py:160-162,200-202)."""
         eng, dist_, model = self.eng, self.tr.distiller, self.tr.model
         N = S.N
         both = S.h_counts.view(torch.int32).tolist()
         rpn_counts = [both[2 * i: 2 * i + 2] for i in range(N)]
         roi_counts = [both[2 * N + 2 * i: 2 * N + 2 * i + 2] for i in range(N)]
         U = S.up
-        rsel, rnsel, osel, onsel = U.h("rsel"), U.h("rnsel"), U.h("osel"), U.h("onsel")
+        from . import engine as E
+        E.randperm_prefix(1, 1)                            # (first use verifies the C generator against torch.randperm; draws nothing)
+        scripted = self._hooks_are_standard() and bool(E._FAST_RANDPERM) and os.environ.get("ALDI_HOST_RNG_SCRIPT", "1") == "1"
+        script: List[int] = []
+
+        def sample(name, nname, row0, counts, batch, frac):
+            """subsample_labels for the images `row0 ...`: positives then negatives, two randperm per image"""
+            o0 = U.spec[name][0] // 4 if name != "-" else 0
+            nsel = U.h(nname) if nname else None
+            per = []
+            if not scripted:
+                a, b, hh = eng._sample_host(counts, batch, frac)
+                if name != "-":
+                    U.h(name)[row0:row0 + len(counts)], nsel[row0:row0 + len(counts)] = a, b
+                return hh
+            for i, (npos, nneg) in enumerate(counts):
+                num_pos = min(npos, int(batch * frac))
+                num_neg = min(nneg, batch - num_pos)
+                keep = name != "-"
+                base = o0 + (row0 + i) * 2 * batch
+                script.extend((0, npos, num_pos, base if keep else -1, 0, nneg, num_neg, base + batch if keep else -1))
+                if keep:
+                    nsel[row0 + i, 0], nsel[row0 + i, 1] = num_pos, num_neg
+                per.append([num_pos, num_neg])
+            return per
+
+        def reseed():
+            if scripted:
+                script.extend((1, dist_.seeder.seed, 0, 0))
+            else:
+                torch.manual_seed(dist_.seeder.seed)
         rows: List[int] = []
         for ch in S.chunks:
             n0, n1 = ch["n0"], ch["n1"]
             if ch["kind"] == "distill":
-                self.teacher.roi_heads.fire_pre()        # the teacher's eval inference re-seeds with the OLD seed (SURVEY B.3)
+                if scripted:
+                    reseed()                               # the teacher's eval inference fired ManualSeed with the OLD seed (SURVEY B.3)
+                else:
+                    self.teacher.roi_heads.fire_pre()
                 dist_.seeder.reset_seed()
-            a, b, _ = eng._sample_host(rpn_counts[n0:n1], RPN_BATCH, RPN_POS_FRAC)
-            rsel[n0:n1], rnsel[n0:n1] = a, b
-            model.roi_heads.fire_pre()                   # ManualSeed pre-hook of the student's roi_heads (aldi/helpers.py:25-26)
-            a, b, oh = eng._sample_host(roi_counts[n0:n1], ROI_BATCH, ROI_POS_FRAC)
-            osel[n0:n1], onsel[n0:n1] = a, b
+            sample("rsel", "rnsel", n0, rpn_counts[n0:n1], RPN_BATCH, RPN_POS_FRAC)
+            if scripted:
+                reseed()                                   # ManualSeed pre-hook of the student's roi_heads (aldi/helpers.py:25-26)
+            else:
+                model.roi_heads.fire_pre()
+            oh = sample("osel", "onsel", n0, roi_counts[n0:n1], ROI_BATCH, ROI_POS_FRAC)
             rows += [x + y for x, y in oh]
             ch["rpn_counts"], ch["roi_counts"] = rpn_counts[n0:n1], roi_counts[n0:n1]
         off = 0
@@ -208,14 +259,20 @@ class FusedStep:
         n_valid = n_fg = 0
         if S.distill:
             ch = S.chunks[-1]
-            torch.manual_seed(dist_.seeder.seed)
-            eng._sample_host(ch["roi_counts"], ROI_BATCH, ROI_POS_FRAC)          # the teacher's identical ROI draws (aldi/distill.py:160-162)
-            a, b, dh = eng._sample_host(ch["rpn_counts"], RPN_BATCH, RPN_POS_FRAC)   # fresh sample of get_rpn_losses (aldi/distill.py:200-202)
-            U.h("dsel")[:], U.h("dnsel")[:] = a, b
+            reseed()
+            sample("-", None, 0, ch["roi_counts"], ROI_BATCH, ROI_POS_FRAC)            # the teacher's identical ROI draws (aldi/distill.py:160-162)
+            dh = sample("dsel", "dnsel", 0, ch["rpn_counts"], RPN_BATCH, RPN_POS_FRAC)     # fresh sample of get_rpn_losses (aldi/distill.py:200-202)
             n_fg = sum(x for x, _ in dh)
             n_valid = sum(x + y for x, y in dh)
             nvf = U.h("nvf")
             nvf[0], nvf[1] = n_valid, n_fg
+        if scripted and script:
+            import ctypes as C
+            from . import _lib as L
+            arr = (C.c_long * len(script))(*script)
+            st = torch.get_rng_state()
+            L.call("aldi_torch_rng_script", st.data_ptr(), arr, len(script) // 4, U.host.data_ptr(), 4)
+            torch.set_rng_state(st)
         return SimpleNamespace(rows=rows, R=sum(rows), n_valid=n_valid, n_fg=n_fg, key=tuple(rows))
 
     # ------------------------------------------------------------------------------------------------ phase B

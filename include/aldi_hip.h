@@ -304,6 +304,10 @@ int aldi_avgpool_bwd(const void* gy, const void* act, void* gx, int N, int HW, i
  * Replaces the torch.randperm draws of detectron2 subsample_labels (aldi/distill.py:200-202 and inside
  * model(...)) at O(k + n/624) instead of O(n) divisions. */
 int aldi_torch_randperm_prefix(unsigned char* state, long n, long k, long* out);
+/* A whole iteration's sampling draws in one host call: script = nops rows {kind, a, b, out_off} (longs): kind 0 = the first
+ * min(b, a) entries of torch.randperm(a) -> out[out_off ...] (int32; out_off < 0: discarded), kind 1 = torch.manual_seed(a).
+ * Segments between seeds are independent and run on `threads` host threads; the state blob ends as torch would leave it. */
+int aldi_torch_rng_script(unsigned char* state, const long* script, int nops, int* out, int threads);
 
 /* ---------------------------------------------------------------------------------------
  * Strong augmentation on the device (the step next to the hot path).  Images are HWC uint8 in HBM;
