@@ -85,6 +85,8 @@ class Weights:
         self._wt_keys: List[str] = []          # dgrad weights requested so far (re-derived in one launch per refresh)
         self._wt_plan = None
         self._neg1: Dict[int, torch.Tensor] = {}
+        self.lazy_wt = False             # True: sgd_step leaves the dgrad weights stale until someone asks / refreshes
+        self._wt_dirty = False
 
     @property
     def grad(self) -> torch.Tensor:
@@ -133,6 +135,8 @@ class Weights:
     def wt(self, name: str, negate: bool = False) -> torch.Tensor:
         """dgrad weights (rotated/transposed, BN scale folded; negated for the gradient-reversal layer)."""
         key = name + ("-" if negate else "")
+        if self._wt_dirty:
+            self._refresh_wt()
         if key not in self._wt:
             # first request of this layer: single-layer kernel now, and from the next refresh() on it is part of the one
             # batched launch that re-derives every requested layer right after the weights change
@@ -167,6 +171,7 @@ class Weights:
         return self._neg1[rows]
 
     def _refresh_wt(self):
+        self._wt_dirty = False
         self._wt.clear()
         if not self._wt_keys:
             return
@@ -212,7 +217,10 @@ class Weights:
         ops.sgd_step(self.master, self.grad, self.mom, self.compute if self.dtype != torch.float32 else None, n, lr, momentum,
                      weight_decay, grad_scale * getattr(self, "_gscale", 1.0), self.first_step, self.dtype)
         self.first_step = False
-        self._refresh_wt()
+        if self.lazy_wt:
+            self._wt_dirty = True        # re-derived where the next backward needs them (the fused step does it beside its forward)
+        else:
+            self._refresh_wt()
 
     def ema_from(self, student: "Weights", alpha: float, copy_only: bool):
         """reference aldi/ema.py:29-57 over the whole state (params AND buffers)."""

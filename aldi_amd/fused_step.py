@@ -135,22 +135,28 @@ class FusedStep:
             side.wait_stream(main)
             with torch.cuda.stream(side):
                 c.props, c.prop_scores, c.prop_count = eng.proposals(c, geom, anchors, stu.hw, N, training=True)
+                eng.wts._refresh_wt()                       # the backward's dgrad weights of the weights SGD just wrote: off the critical path
         else:
             c.props, c.prop_scores, c.prop_count = eng.proposals(c, geom, anchors, stu.hw, N, training=True)
+            eng.wts._refresh_wt()
         tc = None
         if S.distill:
             # The teacher's inference (N = 2, mostly small launches) runs on its own stream beside the student's label-free work
             # and is ENQUEUED after it (issued first its launches would run alone while the student's are still being queued).
             tside = S.tside
             tea = S.tea
+            def teacher_pass():
+                if S.ema_mode is not None:                   # the EMA tick of this iteration (aldi/trainer.py:242-246), beside the student's forward
+                    teng.wts.ema_from(eng.wts, S.ema_alpha, copy_only=S.ema_mode == "copy")
+                return teng.inference(None, dist_.pseudo_label_threshold, staged=(tea.img, tea.sizes, tea.hw))
             if tside is not None:
                 tside.wait_event(ev0)
                 with torch.cuda.stream(tside), torch.no_grad():
-                    tc = teng.inference(None, dist_.pseudo_label_threshold, staged=(tea.img, tea.sizes, tea.hw))
+                    tc = teacher_pass()
                 main.wait_stream(tside)
             else:
                 with torch.no_grad():
-                    tc = teng.inference(None, dist_.pseudo_label_threshold, staged=(tea.img, tea.sizes, tea.hw))
+                    tc = teacher_pass()
         # ground truth per chunk: uploaded labels | none (target-weak alignment rows) | the teacher's pseudo-labels
         parts, lab0 = [], 0
         for ch in S.chunks:
@@ -379,7 +385,7 @@ class FusedStep:
             self.static[key] = self.static.pop(key)
         return S
 
-    def run(self, labeled_weak, labeled_strong, unlabeled_weak, unlabeled_strong):
+    def run(self, labeled_weak, labeled_strong, unlabeled_weak, unlabeled_strong, ema=None):
         from .model import DevicePseudoLabels
         from .trainer import _schedule_flags, _teacher_stream, plan_micro_steps
         tr = self.tr
@@ -408,10 +414,19 @@ class FusedStep:
                 lab_insts += [as_record(d["instances"]) for d in row.data]
             n0 = n1
         N = n0
+        # the EMA tick handed over by ALDITrainer.before_step: copy while iter <= start_iter, else lerp (aldi/ema.py:52-57)
+        ema_mode = None
+        if ema is not None:
+            if do_distill and ema[0].model is teacher:
+                ema_mode = "copy" if ema[1] <= ema[0].start_iter else "lerp"
+            else:
+                ema[0].update_weights(model, ema[1])               # not the teacher of this step's distiller: nothing to overlap with
         key = (tuple((ch["name"], ch["n1"] - ch["n0"]) for ch in chunks), tuple(tuple(im.shape[1:]) for im in images),
-               tuple(tuple(d["image"].shape[1:]) for d in (unlabeled_weak or [])) if do_distill else ())
+               tuple(tuple(d["image"].shape[1:]) for d in (unlabeled_weak or [])) if do_distill else (), ema_mode)
         S = self._static_for(key)
         S.N, S.chunks, S.accum, S.distill, S.has_disc = N, chunks, accum, do_distill, do_align
+        S.ema_mode, S.ema_alpha = ema_mode, (ema[0].alpha if ema is not None else None)
+        eng.wts.lazy_wt = True
         S.tside = _teacher_stream(dev) if do_distill else None
         S.stu = self._stage_images(S, "student", images)
         S.tea = self._stage_images(S, "teacher", [d["image"] for d in unlabeled_weak]) if do_distill else None

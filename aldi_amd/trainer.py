@@ -428,6 +428,10 @@ class _ALDITrainer:
 
     def run_model(self, data):
         self._fused_done = False
+        pending_ema = self.__dict__.pop("_pending_ema", None)       # the EMA tick `before_step` left for the fused step to run
+        if pending_ema is not None and not self._can_fuse(data):
+            pending_ema[0].update_weights(self.model, pending_ema[1])
+            pending_ema = None
         if self._can_fuse(data):
             self._fused_done = True
             if not self.zero_grad_before_forward:
@@ -443,7 +447,7 @@ class _ALDITrainer:
                 if getattr(self, "_fused_step", None) is None:
                     from .fused_step import FusedStep
                     self._fused_step = FusedStep(self)
-                return self._fused_step.run(*data)
+                return self._fused_step.run(*data, ema=pending_ema)
             finally:
                 eng.grad_ready = None
         return run_model_labeled_unlabeled(self, *data)
@@ -629,7 +633,13 @@ class ALDITrainer(DefaultTrainer):
     def before_step(self):
         super(ALDITrainer, self).before_step()
         if self.cfg.EMA.ENABLED:
-            self.ema.update_weights(self._trainer.model, self.iter)
+            t = self._trainer
+            if getattr(t, "fused", False) and os.environ.get("ALDI_FUSED_LEGACY", "0") != "1" and type(t.model.engine).__name__ == "RCNN":
+                # the fused step runs the tick on the teacher's stream, beside the student's forward (only the teacher's
+                # inference needs the new weights); `run_model` falls back to running it right away when it cannot fuse
+                t._pending_ema = (self.ema, self.iter)
+            else:
+                self.ema.update_weights(t.model, self.iter)
 
     # ---- evaluation (reference aldi/trainer.py:166-196: COCO evaluator, EvalHook on the EMA model, BestCheckpointer on bbox/AP50)
     @classmethod
