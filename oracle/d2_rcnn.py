@@ -124,7 +124,8 @@ def preprocess(cfg, images: List[torch.Tensor]) -> Tuple[torch.Tensor, List[Tupl
     return out, sizes
 
 
-def resnet_fpn(cfg, sd, x) -> "OrderedDict[str, torch.Tensor]":
+def resnet_fpn(cfg, sd, x, stages_out: Optional[list] = None) -> "OrderedDict[str, torch.Tensor]":
+    """`stages_out` (a list) receives the bottom-up stage outputs res2..res5 (secondary cross-check against an independent ResNet)"""
     bu = "backbone.bottom_up."
     x = F.relu(conv_bn(x, sd, bu + "stem.conv1", 2, 3))
     x = F.max_pool2d(x, kernel_size=3, stride=2, padding=1)
@@ -140,6 +141,8 @@ def resnet_fpn(cfg, sd, x) -> "OrderedDict[str, torch.Tensor]":
             h = conv_bn(h, sd, p + "conv3", 1, 0)
             x = F.relu(h + sc)
         cs.append(x)
+    if stages_out is not None:
+        stages_out.extend(cs)
     # FPN top-down, FUSE_TYPE="sum", NORM=""
     feats = OrderedDict()
     prev = F.conv2d(cs[3], sd["backbone.fpn_lateral5.weight"], sd["backbone.fpn_lateral5.bias"])
