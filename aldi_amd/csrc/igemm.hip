@@ -96,8 +96,10 @@ template <> struct Mma<float> {
     }
 };
 
+// body of one workgroup: tile `bid` of an nmt x nnt tile grid of problem p (launched alone: igemm_kernel; as one of several
+// problems of the same layer shape sharing a launch: igemm_group_kernel)
 template <typename T, int BM, int BN, int WM, int WN, int KC, bool PIPE, bool HALO = false>
-__global__ __launch_bounds__(WM* WN * 64) void igemm_kernel(ConvDev p) {
+__device__ __forceinline__ void igemm_body(const ConvDev& p, int bid, const int nmt, const int nnt) {
     constexpr int NT = WM * WN * 64;
     constexpr int EP = Elem<T>::kPer16B;           // elements per 16-B chunk
     constexpr int BK = KC * EP;                    // K slab: KC 16-B chunks per LDS row (KC=8: 64 bf16 / 32 fp32)
@@ -117,8 +119,6 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_kernel(ConvDev p) {
     // XCD-aware tile order: workgroup b runs on XCD b % 8 (observed dispatch); give every XCD a contiguous range of
     // (pixel-tile, channel-tile) pairs, channel-tile fastest, so the tiles sharing an activation tile / halo rows
     // share one L2.  Pure speed: any placement computes the same result.
-    const int nmt = gridDim.x, nnt = gridDim.y;
-    int bid = blockIdx.y * nmt + blockIdx.x;
     if (p.xcd) {
         const int total = nmt * nnt, q = total >> 3, r = total & 7, xcd = bid & 7, idx = bid >> 3;
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
@@ -567,8 +567,54 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_kernel(ConvDev p) {
     }
 }
 
+template <typename T, int BM, int BN, int WM, int WN, int KC, bool PIPE, bool HALO = false>
+__global__ __launch_bounds__(WM* WN * 64) void igemm_kernel(ConvDev p) {
+    igemm_body<T, BM, BN, WM, WN, KC, PIPE, HALO>(p, (int)(blockIdx.y * gridDim.x + blockIdx.x), (int)gridDim.x, (int)gridDim.y);
+}
+
+// Several problems of ONE layer shape in one launch -- the student's and the teacher's pass through the same layer (different
+// weights, different images): the two launches' fixed costs (ramp-up, partial last wave of tiles, dependent-launch gap: ~10 us
+// per 3x3 layer at these sizes) are paid once, and the smaller problem's tiles fill the larger one's tail.
+constexpr int kMaxConvGroup = 4;
+struct ConvGroup {
+    int n;
+    int wg_begin[kMaxConvGroup + 1];          // first workgroup of each problem (multiples of 8: the XCD-aware tile order assumes it)
+    int nmt[kMaxConvGroup], nnt[kMaxConvGroup];
+    ConvDev p[kMaxConvGroup];
+};
+template <typename T, int BM, int BN, int WM, int WN, int KC, bool PIPE, bool HALO = false>
+__global__ __launch_bounds__(WM* WN * 64) void igemm_group_kernel(ConvGroup G) {
+    const int bid = (int)blockIdx.x;
+    int i = 0;
+    for (int k = 1; k < G.n; ++k)
+        if (bid >= G.wg_begin[k]) i = k;
+    i = __builtin_amdgcn_readfirstlane(i);
+    const int local = bid - G.wg_begin[i];
+    if (local >= G.nmt[i] * G.nnt[i]) return;  // alignment padding
+    igemm_body<T, BM, BN, WM, WN, KC, PIPE, HALO>(G.p[i], local, G.nmt[i], G.nnt[i]);
+}
+
+static thread_local const ConvGroup* g_group = nullptr;      // set by aldi_conv_igemm_group around dispatch<T>()
+
 template <typename T, int BM, int BN, int WM, int WN, int KC, bool PIPE = true, bool HALO = false>
 int launch(const ConvDev& d, hipStream_t st) {
+    if (g_group) {
+        ConvGroup G = *g_group;
+        int wg = 0;
+        for (int i = 0; i < G.n; ++i) {
+            G.p[i].xcd = d.xcd; G.p[i].dbg = d.dbg;
+            G.nmt[i] = cdiv(G.p[i].M, BM); G.nnt[i] = cdiv(G.p[i].Cout, BN);
+            G.wg_begin[i] = wg;
+            wg += (G.nmt[i] * G.nnt[i] + 7) / 8 * 8;
+        }
+        for (int i = G.n; i <= kMaxConvGroup; ++i) G.wg_begin[i] = wg;
+        hipLaunchKernelGGL((igemm_group_kernel<T, BM, BN, WM, WN, KC, PIPE, HALO>), dim3(wg), dim3(WM * WN * 64), 0, st, G);
+        ALDI_CHECK_LAUNCH();
+        char name[112];
+        snprintf(name, sizeof(name), "igemm_group%d<%s,%d,%d,%d,%d,%s,%s>", G.n, sizeof(T) == 2 ? "bf16" : "f32", BM, BN, WM, WN, PIPE ? "pipe" : "flat", HALO ? "halo" : "tap");
+        aldi_note_dispatch(name);
+        return ALDI_OK;
+    }
     dim3 grid(cdiv(d.M, BM), cdiv(d.Cout, BN));
     hipLaunchKernelGGL((igemm_kernel<T, BM, BN, WM, WN, KC, PIPE, HALO>), grid, dim3(WM * WN * 64), 0, st, d);
     ALDI_CHECK_LAUNCH();
@@ -624,16 +670,17 @@ int dispatch(ConvDev& d, hipStream_t st) {
 
 }  // namespace
 
-extern "C" int aldi_conv_igemm(const aldi_conv_args* a, aldi_stream_t stream) {
+namespace {
+int fill_convdev(const aldi_conv_args* a, ConvDev& d) {
     if (!a || !a->x || !a->w || (!a->y && !a->y_f32)) return aldi_set_error_msg(ALDI_ERR_ARG, "conv_igemm: null pointer");
     const int bk = a->dtype == ALDI_BF16 ? 32 : 16;
     const int ep = a->dtype == ALDI_BF16 ? 8 : 4;
+    if (a->dtype != ALDI_BF16 && a->dtype != ALDI_F32) return aldi_set_error_msg(ALDI_ERR_ARG, "conv_igemm: bad dtype");
     if (a->KH * a->KW == 1 ? (a->Cin % ep != 0) : (a->Cin % bk != 0))
         return aldi_set_error_msg(ALDI_ERR_ARG, "conv_igemm: Cin must be a multiple of 32 (bf16) / 16 (f32) for KxK convs; of a 16-B chunk for 1x1");
     if (a->Cout % 4 != 0) return aldi_set_error_msg(ALDI_ERR_ARG, "conv_igemm: Cout must be a multiple of 4");
     if (a->res_mode == 2 && ((a->Ho & 1) || (a->Wo & 1))) return aldi_set_error_msg(ALDI_ERR_ARG, "conv_igemm: upsample residual needs even Ho,Wo");
     if (a->res_mode && !a->res) return aldi_set_error_msg(ALDI_ERR_ARG, "conv_igemm: res_mode set without res");
-    ConvDev d;
     d.x = a->x; d.w = a->w; d.y = a->y; d.y_f32 = a->y_f32; d.scale = a->scale; d.shift = a->shift;
     d.res = a->res; d.mask = a->mask;
     d.N = a->N; d.H = a->H; d.W = a->W; d.Cin = a->Cin; d.Cout = a->Cout; d.KH = a->KH; d.KW = a->KW;
@@ -652,8 +699,47 @@ extern "C" int aldi_conv_igemm(const aldi_conv_args* a, aldi_stream_t stream) {
     if (a->KH * a->KW > 16) return aldi_set_error_msg(ALDI_ERR_ARG, "conv_igemm: at most 16 taps");
     d.x_bytes = (unsigned)xb;
     d.w_bytes = (unsigned)wb;
+    d.xcd = 0; d.dbg = 0;
+    return ALDI_OK;
+}
+}  // namespace
+
+extern "C" int aldi_conv_igemm(const aldi_conv_args* a, aldi_stream_t stream) {
+    ConvDev d;
+    if (int rc = fill_convdev(a, d)) return rc;
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (a->dtype == ALDI_BF16) return dispatch<bf16_t>(d, st);
-    if (a->dtype == ALDI_F32) return dispatch<float>(d, st);
-    return aldi_set_error_msg(ALDI_ERR_ARG, "conv_igemm: bad dtype");
+    return dispatch<float>(d, st);
+}
+
+extern "C" int aldi_conv_igemm_group(const aldi_conv_args* args, int n, aldi_stream_t stream) {
+    if (!args || n < 1) return aldi_set_error_msg(ALDI_ERR_ARG, "conv_igemm_group: no problems");
+    bool same = n <= kMaxConvGroup && aldi_tuning().igemm_group;
+    for (int i = 1; i < n && same; ++i) {
+        const aldi_conv_args &a = args[0], &b = args[i];
+        // one layer shape: everything that selects code paths inside the kernel template is equal, only N (and the tensors) differ
+        same = a.dtype == b.dtype && a.H == b.H && a.W == b.W && a.Cin == b.Cin && a.Cout == b.Cout && a.KH == b.KH && a.KW == b.KW &&
+               a.stride == b.stride && a.pad == b.pad && a.Ho == b.Ho && a.Wo == b.Wo && a.out_scale == b.out_scale &&
+               (a.y != nullptr) == (b.y != nullptr) && (a.y_f32 != nullptr) == (b.y_f32 != nullptr);
+    }
+    if (!same || n == 1) {
+        for (int i = 0; i < n; ++i)
+            if (int rc = aldi_conv_igemm(&args[i], stream)) return rc;
+        return ALDI_OK;
+    }
+    static thread_local ConvGroup G;
+    G.n = n;
+    long Msum = 0;
+    for (int i = 0; i < n; ++i) {
+        if (int rc = fill_convdev(&args[i], G.p[i])) return rc;
+        Msum += G.p[i].M;
+    }
+    // the tile template is chosen for the COMBINED pixel count (the heuristics look at M, Cout, K and the conv geometry only)
+    ConvDev d = G.p[0];
+    d.M = (int)(Msum > 0x7fffffffL ? 0x7fffffffL : Msum);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    g_group = &G;
+    const int rc = args[0].dtype == ALDI_BF16 ? dispatch<bf16_t>(d, st) : dispatch<float>(d, st);
+    g_group = nullptr;
+    return rc;
 }

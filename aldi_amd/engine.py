@@ -350,14 +350,64 @@ class RCNN:
         return t
 
     # ------------------------------------------------------------------ trunk
-    def conv(self, x, name, *, relu=False, res=None, res_mode=0, want_f32=False):
+    def _conv_call(self, x, name, *, relu=False, res=None, res_mode=0, want_f32=False):
+        """(x, weight, conv2d kwargs) of layer `name` applied to x"""
         W = self.wts
         p = W.layout.t[name]
-        return ops.conv2d(x, W.w(name), stride=p.stride, pad=p.pad, scale=W.scale(name), shift=W.shift(name), res=res, res_mode=res_mode,
-                          relu=relu, want_f32=want_f32)
+        return x, W.w(name), dict(stride=p.stride, pad=p.pad, scale=W.scale(name), shift=W.shift(name), res=res, res_mode=res_mode, relu=relu,
+                                  want_f32=want_f32)
+
+    def conv(self, x, name, **kw):
+        x, w, kw = self._conv_call(x, name, **kw)
+        return ops.conv2d(x, w, **kw)
+
+    # The trunk and the RPN head are written as generators that YIELD their convolutions ((x, layer name, flags) -> output): run
+    # alone (`_drive`) each request is one launch; two models of the same architecture run in lockstep (`drive_pair`: the
+    # student's N = 4 batch and the teacher's N = 2 batch through their own weights) share ONE launch per layer.
+    def _drive(self, gen):
+        try:
+            req = next(gen)
+            while True:
+                req = gen.send(self.conv(req[0], req[1], **req[2]))
+        except StopIteration as e:
+            return e.value
+
+    @staticmethod
+    def drive_pair(eng_a, gen_a, eng_b, gen_b):
+        """advance two engines' generators together, one grouped launch per pair of requests -> (result_a, result_b)"""
+        res = [None, None]
+        try:
+            ra = next(gen_a)
+        except StopIteration as e:
+            ra, res[0] = None, e.value
+        try:
+            rb = next(gen_b)
+        except StopIteration as e:
+            rb, res[1] = None, e.value
+        while ra is not None or rb is not None:
+            if ra is not None and rb is not None:
+                ya, yb = ops.conv2d_group([eng_a._conv_call(ra[0], ra[1], **ra[2]), eng_b._conv_call(rb[0], rb[1], **rb[2])])
+            elif ra is not None:
+                ya = eng_a.conv(ra[0], ra[1], **ra[2])
+            else:
+                yb = eng_b.conv(rb[0], rb[1], **rb[2])
+            if ra is not None:
+                try:
+                    ra = gen_a.send(ya)
+                except StopIteration as e:
+                    ra, res[0] = None, e.value
+            if rb is not None:
+                try:
+                    rb = gen_b.send(yb)
+                except StopIteration as e:
+                    rb, res[1] = None, e.value
+        return res[0], res[1]
 
     def trunk(self, st_u8: torch.Tensor, sizes, save: bool) -> Ctx:
         """preprocess + ResNet-50 + FPN -> P2..P6.  `save` keeps the activations backward needs."""
+        return self._drive(self.trunk_steps(st_u8, sizes, save))
+
+    def trunk_steps(self, st_u8: torch.Tensor, sizes, save: bool):
         W = self.wts
         c = Ctx()
         bu = "backbone.bottom_up."
@@ -370,21 +420,21 @@ class RCNN:
         for si, nb in enumerate(STAGE_BLOCKS):
             for b in range(nb):
                 p = f"{bu}res{si + 2}.{b}."
-                sc = self.conv(x, p + "shortcut") if b == 0 else x
-                h1 = self.conv(x, p + "conv1", relu=True)
-                h2 = self.conv(h1, p + "conv2", relu=True)
-                out = self.conv(h2, p + "conv3", relu=True, res=sc, res_mode=1)
+                sc = (yield x, p + "shortcut", {}) if b == 0 else x
+                h1 = yield x, p + "conv1", dict(relu=True)
+                h2 = yield h1, p + "conv2", dict(relu=True)
+                out = yield h2, p + "conv3", dict(relu=True, res=sc, res_mode=1)
                 if save and si > 0:
                     blocks.append((p, x, h1, h2, out, b == 0))
                 x = out
             cs.append(x)
         prev = {}
         P = {}
-        prev[5] = self.conv(cs[3], "backbone.fpn_lateral5")
-        P[5] = self.conv(prev[5], "backbone.fpn_output5")
+        prev[5] = yield cs[3], "backbone.fpn_lateral5", {}
+        P[5] = yield prev[5], "backbone.fpn_output5", {}
         for lvl in (4, 3, 2):
-            prev[lvl] = self.conv(cs[lvl - 2], f"backbone.fpn_lateral{lvl}", res=prev[lvl + 1], res_mode=2)
-            P[lvl] = self.conv(prev[lvl], f"backbone.fpn_output{lvl}")
+            prev[lvl] = yield cs[lvl - 2], f"backbone.fpn_lateral{lvl}", dict(res=prev[lvl + 1], res_mode=2)
+            P[lvl] = yield prev[lvl], f"backbone.fpn_output{lvl}", {}
         P[6] = ops.subsample2(P[5])
         c.P = [P[2], P[3], P[4], P[5], P[6]]
         if save:
@@ -392,10 +442,13 @@ class RCNN:
         return c
 
     def rpn_head(self, c: Ctx, save: bool):
+        self._drive(self.rpn_head_steps(c, save))
+
+    def rpn_head_steps(self, c: Ctx, save: bool):
         heads, ts = [], []
         for f in c.P:
-            t = self.conv(f, "proposal_generator.rpn_head.conv", relu=True)
-            heads.append(self.conv(t, "rpn_head_out", want_f32=True))
+            t = yield f, "proposal_generator.rpn_head.conv", dict(relu=True)
+            heads.append((yield t, "rpn_head_out", dict(want_f32=True)))
             if save:
                 ts.append(t)
         c.head = heads
@@ -835,11 +888,15 @@ class RCNN:
         """GeneralizedRCNN.inference(do_postprocess=False) + process_pseudo_label threshold
         (aldi/pseudolabeler.py:15-67).  Everything stays on device.  `staged` = (uint8 batch, sizes, hw) already in HBM."""
         st, sizes, hw = staged if staged is not None else self.stage_images(images)
+        c = self.trunk(st, sizes, save=False)
+        self.rpn_head(c, save=False)
+        return self.inference_heads(c, st, sizes, hw, pl_thresh)
+
+    def inference_heads(self, c: Ctx, st, sizes, hw, pl_thresh: float) -> Ctx:
+        """everything of the inference pass after the trunk and the RPN head (which may have run paired with another model's)"""
         N = st.shape[0]
         shapes, geom, anchors = self.geometry(st.shape[2], st.shape[3])
-        c = self.trunk(st, sizes, save=False)
         c.N, c.sizes, c.hw, c.geom, c.anchors, c.shapes = N, sizes, hw, geom, anchors, shapes
-        self.rpn_head(c, save=False)
         props, pscores, pcount = self.proposals(c, geom, anchors, hw, N, training=False)
         P = props.shape[1]
         rois = torch.empty((N * P, 5), dtype=torch.float32, device=self.device)

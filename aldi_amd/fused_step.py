@@ -71,6 +71,7 @@ class FusedStep:
         self.steps_done = 0
         self.pool = None
         self.graph_enabled = bool(trainer.model.cfg.SOLVER.get("STEP_GRAPH", False)) and os.environ.get("ALDI_STEP_GRAPH", "1") == "1"
+        self.pair_forward = os.environ.get("ALDI_PAIR_FORWARD", "1") == "1"     # student + teacher trunk / RPN head: one launch per layer
         self.warmup = 3                     # eager steps before capturing (lazy initialisation: anchors, dgrad weights, workspaces)
         self.stats = dict(captures=0, replays_a=0, replays_b=0, eager=0)
 
@@ -125,10 +126,22 @@ class FusedStep:
         ev0.record(main)                                     # the teacher may start here: beside the student's trunk
         N = S.N
         stu = S.stu
+        tea, tside = S.tea, S.tside
         shapes, geom, anchors = eng.geometry(stu.img.shape[2], stu.img.shape[3])
-        c = eng.trunk(stu.img, stu.sizes, save=True)
+        pair = S.distill and self.pair_forward and type(eng) is RCNN and type(teng) is RCNN
+        tcx = None
+        if pair:
+            # Student (N = 4) and teacher (N = 2) go through the same layers with different weights: ONE launch per layer for both
+            # (engine.RCNN.drive_pair -> aldi_conv_igemm_group) instead of two half-empty ones on two streams.  The EMA tick has
+            # to come first then (the teacher's weights are read from the first layer on).
+            if S.ema_mode is not None:
+                teng.wts.ema_from(eng.wts, S.ema_alpha, copy_only=S.ema_mode == "copy")
+            c, tcx = RCNN.drive_pair(eng, eng.trunk_steps(stu.img, stu.sizes, True), teng, teng.trunk_steps(tea.img, tea.sizes, False))
+            RCNN.drive_pair(eng, eng.rpn_head_steps(c, True), teng, teng.rpn_head_steps(tcx, False))
+        else:
+            c = eng.trunk(stu.img, stu.sizes, save=True)
+            eng.rpn_head(c, save=True)
         c.N, c.sizes, c.hw, c.geom, c.anchors, c.shapes = N, stu.sizes, stu.hw, geom, anchors, shapes
-        eng.rpn_head(c, save=True)
         # proposal generation (top-k, NMS: latency-bound, a handful of workgroups) beside anchor matching on the second stream
         side = eng._wgrad_stream()
         if side is not None:
@@ -143,14 +156,17 @@ class FusedStep:
         if S.distill:
             # The teacher's inference (N = 2, mostly small launches) runs on its own stream beside the student's label-free work
             # and is ENQUEUED after it (issued first its launches would run alone while the student's are still being queued).
-            tside = S.tside
-            tea = S.tea
             def teacher_pass():
+                if pair:
+                    return teng.inference_heads(tcx, tea.img, tea.sizes, tea.hw, dist_.pseudo_label_threshold)
                 if S.ema_mode is not None:                   # the EMA tick of this iteration (aldi/trainer.py:242-246), beside the student's forward
                     teng.wts.ema_from(eng.wts, S.ema_alpha, copy_only=S.ema_mode == "copy")
                 return teng.inference(None, dist_.pseudo_label_threshold, staged=(tea.img, tea.sizes, tea.hw))
             if tside is not None:
-                tside.wait_event(ev0)
+                if pair:
+                    tside.wait_stream(main)
+                else:
+                    tside.wait_event(ev0)
                 with torch.cuda.stream(tside), torch.no_grad():
                     tc = teacher_pass()
                 main.wait_stream(tside)

@@ -82,6 +82,42 @@ def conv2d(x: torch.Tensor, w: torch.Tensor, *, stride: int = 1, pad: int = 0,
     return out_f32 if want_f32 and out is None else out
 
 
+def _conv_args(x, w, *, stride=1, pad=0, scale=None, shift=None, res=None, res_mode=0, relu=False, mask=None, out=None, out_f32=None,
+               want_f32=False, out_scale=1, out_hw=None):
+    """(ConvArgs, result tensor) of one conv2d call -- shared by the single and the grouped launch"""
+    N, H, W_, Cin = x.shape
+    Cout, KH, KW, Cin2 = w.shape
+    assert Cin == Cin2 and x.is_contiguous() and w.is_contiguous() and x.dtype == w.dtype, (x.shape, w.shape, x.dtype, w.dtype)
+    Ho = (H + 2 * pad - KH) // stride + 1
+    Wo = (W_ + 2 * pad - KW) // stride + 1
+    if out_scale > 1:
+        OH, OW = out_hw
+        shape = (N, OH, OW, Cout)
+    else:
+        OH = OW = 0
+        shape = (N, Ho, Wo, Cout)
+    if out is None and not want_f32:
+        out = torch.empty(shape, dtype=x.dtype, device=x.device)
+    if want_f32 and out_f32 is None:
+        out_f32 = torch.empty(shape, dtype=torch.float32, device=x.device)
+    a = L.ConvArgs(_p(x), _p(w), _p(out), _p(out_f32), _p(scale), _p(shift), _p(res), _p(mask),
+                   N, H, W_, Cin, Cout, KH, KW, stride, pad, Ho, Wo,
+                   int(relu), res_mode, out_scale, OH, OW, dtype_code(x.dtype))
+    return a, (out_f32 if want_f32 and out is None else out)
+
+
+def conv2d_group(calls) -> List[torch.Tensor]:
+    """calls = [(x, w, kwargs-of-conv2d)]: the same layer applied to several batches with several weight sets (student / teacher)
+    in ONE launch (aldi_conv_igemm_group; anything else than one common layer shape degrades to single launches inside)"""
+    arr = (L.ConvArgs * len(calls))()
+    outs = []
+    for i, (x, w, kw) in enumerate(calls):
+        arr[i], y = _conv_args(x, w, **kw)
+        outs.append(y)
+    L.call("aldi_conv_igemm_group", arr, len(calls), stream_ptr())
+    return outs
+
+
 def conv_wgrad(x: torch.Tensor, g: torch.Tensor, dw: torch.Tensor, *, KH: int, KW: int, stride: int = 1, pad: int = 0,
                scale: Optional[torch.Tensor] = None) -> None:
     """dw [Cout,KH,KW,Cin] fp32 += scale * (g^T . im2col(x)); x [N,H,W,Cin], g [N,Ho,Wo,Cout]."""

@@ -33,6 +33,7 @@ int aldi_version(void);
 /* Tuning knobs of the kernel dispatchers (test / experiment surface; the defaults are what the benchmark runs).
  * Each knob can also be preset from the environment as ALDI_<UPPER-CASE NAME>, read once at first use.
  *   igemm_force          0 heuristics | 1 128x128 | 2 128x64 | 3 64x64 | 4 256x128 | 5 128x16 tile of aldi_conv_igemm
+ *   igemm_group          1 = aldi_conv_igemm_group shares one launch (0: always n single launches)
  *   igemm_halo           1 = 3x3/stride-1/pad-1 bf16 convs use the halo form (one pixel slab per three taps)
  *   igemm_bigtile_min    128x128-tile count from which a 3x3 conv takes the 256x128 halo tile (1024)
  *   igemm_lintile_min, igemm_bigtile_k   tile count / K from which a 1x1 conv or linear takes the 256x128 tile (768, 768)
@@ -85,6 +86,10 @@ typedef struct {
 } aldi_conv_args;
 
 int aldi_conv_igemm(const aldi_conv_args* a, aldi_stream_t stream);
+/* n (<= 4) convolutions of ONE layer shape -- same geometry and channel counts, different tensors / batch sizes: the student's
+ * and the teacher's pass through a layer (aldi/distill.py:157,162 run them as two model calls) -- in ONE launch; any other
+ * combination (or igemm_group = 0) falls back to n single launches.  Same arithmetic as n aldi_conv_igemm calls. */
+int aldi_conv_igemm_group(const aldi_conv_args* args, int n, aldi_stream_t stream);
 
 /* Weight gradient: dw[Cout][KH][KW][Cin] (fp32) += scale[co] * sum_pixels g[p][co] * x[pix(p,kh,kw)][ci].
  * Accumulates with float atomics (split-K over pixels and over micro-steps); zero dw once

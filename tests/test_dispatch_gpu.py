@@ -437,3 +437,73 @@ def test_wgrad_group_split_policy(slots):
     torch.cuda.synchronize()
     for (x, g, dw, _), ref in zip(probs, refs):
         assert (dw.double() - ref).abs().max().item() <= 3e-6 * max(1.0, ref.abs().max().item()) * 2
+
+
+# ---------------------------------------------------------------------------------- grouped convolutions (student + teacher through one layer)
+GROUP_CASES = [
+    # (H, W, Cin, Cout, k, stride, pad), batch sizes, template of the COMBINED problem
+    ((50, 84, 256, 256, 3, 1, 1), (4, 2), "igemm_group2<bf16,128,64,4,1,flat,halo>"),
+    ((200, 336, 256, 256, 3, 1, 1), (4, 2), "igemm_group2<bf16,256,128,4,2,flat,halo>"),
+    ((100, 168, 256, 256, 3, 1, 1), (4, 2), "igemm_group2<bf16,256,128,4,2,flat,halo>"),       # 1575 tiles together
+    ((50, 84, 1024, 256, 1, 1, 0), (4, 2), "igemm_group2<bf16,128,128,2,2,pipe,tap>"),
+    ((25, 42, 1024, 2048, 1, 2, 0), (4, 2), "igemm_group2<bf16,128,128,2,2,pipe,tap>"),         # strided shortcut
+    ((13, 21, 256, 16, 1, 1, 0), (4, 2), "igemm_group2<bf16,128,16,4,1,pipe,tap>"),             # RPN heads on p6: ragged, tiny
+    ((19, 23, 64, 96, 3, 1, 1), (3, 1, 2), "igemm_group3<bf16,128,64,4,1,flat,halo>"),
+]
+
+
+@pytest.mark.parametrize("geo,batches,expect", GROUP_CASES)
+def test_conv_group_equals_single_launches(geo, batches, expect):
+    """n problems of one layer shape (own weights, own batch size, own epilogue tensors) in one launch == n single launches"""
+    from aldi_amd import _lib as L
+    from aldi_amd import ops
+    H, W_, Cin, Cout, k, stride, pad = geo
+    gen = torch.Generator().manual_seed(sum(geo) + sum(batches))
+    dev = "cuda"
+    Ho, Wo = (H + 2 * pad - k) // stride + 1, (W_ + 2 * pad - k) // stride + 1
+    calls, singles = [], []
+    for N in batches:
+        x = torch.randn(N, H, W_, Cin, generator=gen).to(dev, torch.bfloat16)
+        w = (torch.randn(Cout, k, k, Cin, generator=gen) / (Cin * k * k) ** 0.5).to(dev, torch.bfloat16)
+        sc = (0.5 + torch.rand(Cout, generator=gen)).to(dev)
+        sh = (torch.randn(Cout, generator=gen) * 0.1).to(dev)
+        res = torch.randn(N, Ho, Wo, Cout, generator=gen).to(dev, torch.bfloat16)
+        kw = dict(stride=stride, pad=pad, scale=sc, shift=sh, res=res, res_mode=1, relu=True)
+        calls.append((x, w, kw))
+        singles.append(ops.conv2d(x, w, **kw))
+    single_name = L.last_dispatch()
+    outs = ops.conv2d_group(calls)
+    name = L.last_dispatch()
+    torch.cuda.synchronize()
+    assert name == expect, (name, single_name)
+    for (x, w, kw), a, b in zip(calls, outs, singles):
+        assert a.shape == b.shape
+        # same products, possibly another tile template (sum order) and therefore another bf16 rounding of a few outputs
+        d = (a.float() - b.float()).abs().max().item()
+        assert d <= 2e-2 * max(1.0, b.float().abs().max().item()), d
+        pix = _sample_pixels(x.shape[0], Ho, Wo)
+        ref = _conv_ref_at(x.float().cpu(), w.float().cpu(), pix, stride, pad, Ho, Wo) * kw["scale"].double().cpu() + kw["shift"].double().cpu()
+        ref = torch.relu(ref.float().bfloat16().double() + kw["res"].view(-1, Cout)[pix.to(dev)].double().cpu())
+        got = a.view(-1, Cout)[pix.to(dev)].double().cpu()
+        assert ((got - ref).abs() / ref.abs().clamp(min=1.0)).max().item() <= 8e-3
+    # fp32 side output variant and the switch-off knob
+    calls32 = [(x, w, dict(stride=stride, pad=pad, want_f32=True)) for x, w, _ in calls]
+    o32 = ops.conv2d_group(calls32)
+    L.set_tuning("igemm_group", 0)
+    o32b = ops.conv2d_group(calls32)
+    assert not L.last_dispatch().startswith("igemm_group")
+    torch.cuda.synchronize()
+    for a, b in zip(o32, o32b):
+        assert (a - b).abs().max().item() <= 2e-5 * max(1.0, b.abs().max().item())
+
+
+def test_conv_group_of_different_layers_falls_back():
+    from aldi_amd import _lib as L
+    from aldi_amd import ops
+    x1 = torch.randn(2, 20, 24, 64, device="cuda").bfloat16()
+    x2 = torch.randn(2, 10, 12, 64, device="cuda").bfloat16()
+    w = torch.randn(64, 3, 3, 64, device="cuda").bfloat16()
+    a, b = ops.conv2d_group([(x1, w, dict(pad=1)), (x2, w, dict(pad=1))])
+    assert not L.last_dispatch().startswith("igemm_group")
+    torch.cuda.synchronize()
+    assert torch.equal(a, ops.conv2d(x1, w, pad=1)) and torch.equal(b, ops.conv2d(x2, w, pad=1))

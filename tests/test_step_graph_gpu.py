@@ -99,3 +99,33 @@ def test_env_switch_disables_graphs(monkeypatch):
         tr.before_step(); tr.run_step(); tr.after_step()
     torch.cuda.synchronize()
     assert tr._trainer._fused_step.stats["captures"] == 0
+
+
+def test_paired_student_teacher_forward_equals_separate_passes():
+    """phase A with the student's and the teacher's trunk / RPN head sharing one launch per layer (aldi_conv_igemm_group) == the
+    two separate passes: pseudo-labels, sampled indices and losses of the same step from the same state"""
+    a, b = _trainer(False, False), _trainer(False, False)
+    for it in range(3):
+        _copy_state(a, b)
+        rng, py = torch.get_rng_state(), random.getstate()
+        la = _step(a, it)
+        assert a._trainer._fused_step.pair_forward
+        torch.set_rng_state(rng)
+        random.setstate(py)
+        b_fs = getattr(b._trainer, "_fused_step", None)
+        if b_fs is not None:
+            b_fs.pair_forward = False
+        else:
+            os.environ["ALDI_PAIR_FORWARD"] = "0"
+        try:
+            lb = _step(b, it)
+        finally:
+            os.environ.pop("ALDI_PAIR_FORWARD", None)
+        assert not b._trainer._fused_step.pair_forward
+        ta, tb = a.ema.model._last_inference, b.ema.model._last_inference
+        assert torch.equal(ta.pseudo["count"], tb.pseudo["count"]) and torch.equal(ta.pseudo["classes"], tb.pseudo["classes"])
+        assert (ta.pseudo["boxes"] - tb.pseudo["boxes"]).abs().max().item() <= 1e-3
+        ca, cb = a.model._last_fused, b.model._last_fused
+        assert torch.equal(ca.rpn_labels, cb.rpn_labels) and torch.equal(ca.r_idx[: ca.R], cb.r_idx[: cb.R])
+        for k in la:
+            assert abs(la[k] - lb[k]) <= 2e-5 * max(1.0, abs(la[k])), (it, k, la[k], lb[k])
