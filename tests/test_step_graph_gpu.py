@@ -108,19 +108,15 @@ def test_paired_student_teacher_forward_equals_separate_passes():
     for it in range(3):
         _copy_state(a, b)
         rng, py = torch.get_rng_state(), random.getstate()
-        la = _step(a, it)
+        os.environ["ALDI_PAIR_FORWARD"] = "1"                 # read when the trainer creates its FusedStep (first iteration)
+        try:
+            la = _step(a, it)
+        finally:
+            os.environ.pop("ALDI_PAIR_FORWARD", None)
         assert a._trainer._fused_step.pair_forward
         torch.set_rng_state(rng)
         random.setstate(py)
-        b_fs = getattr(b._trainer, "_fused_step", None)
-        if b_fs is not None:
-            b_fs.pair_forward = False
-        else:
-            os.environ["ALDI_PAIR_FORWARD"] = "0"
-        try:
-            lb = _step(b, it)
-        finally:
-            os.environ.pop("ALDI_PAIR_FORWARD", None)
+        lb = _step(b, it)
         assert not b._trainer._fused_step.pair_forward
         ta, tb = a.ema.model._last_inference, b.ema.model._last_inference
         assert torch.equal(ta.pseudo["count"], tb.pseudo["count"]) and torch.equal(ta.pseudo["classes"], tb.pseudo["classes"])
