@@ -75,6 +75,7 @@ class FusedStep:
         # shared launches save (~0.5 ms of fixed per-launch cost) is less than what the lost concurrency costs (the teacher's
         # latency-bound proposal / box-head / detection chain then runs alone after the paired trunk, and the EMA tick before it)
         self.pair_forward = os.environ.get("ALDI_PAIR_FORWARD", "0") == "1"
+        self.teacher_first = os.environ.get("ALDI_TEACHER_FIRST", "0") == "1"
         self.warmup = 3                     # eager steps before capturing (lazy initialisation: anchors, dgrad weights, workspaces)
         self.stats = dict(captures=0, replays_a=0, replays_b=0, eager=0)
 
@@ -142,6 +143,15 @@ class FusedStep:
             c, tcx = RCNN.drive_pair(eng, eng.trunk_steps(stu.img, stu.sizes, True), teng, teng.trunk_steps(tea.img, tea.sizes, False))
             RCNN.drive_pair(eng, eng.rpn_head_steps(c, True), teng, teng.rpn_head_steps(tcx, False))
         else:
+            if S.distill and self.teacher_first and tside is not None:
+                # issue order inside the captured graph: the teacher's chain (trunk -> proposals -> box head -> detections -> pseudo
+                # labels) is the longer dependency chain of phase A -- the student's anchor matching waits for it -- so its nodes go
+                # first; the student's trunk is enqueued right behind and fills the chip beside it
+                tside.wait_event(ev0)
+                with torch.cuda.stream(tside), torch.no_grad():
+                    if S.ema_mode is not None:
+                        teng.wts.ema_from(eng.wts, S.ema_alpha, copy_only=S.ema_mode == "copy")
+                    tc_early = teng.inference(None, dist_.pseudo_label_threshold, staged=(tea.img, tea.sizes, tea.hw))
             c = eng.trunk(stu.img, stu.sizes, save=True)
             eng.rpn_head(c, save=True)
         c.N, c.sizes, c.hw, c.geom, c.anchors, c.shapes = N, stu.sizes, stu.hw, geom, anchors, shapes
@@ -165,7 +175,10 @@ class FusedStep:
                 if S.ema_mode is not None:                   # the EMA tick of this iteration (aldi/trainer.py:242-246), beside the student's forward
                     teng.wts.ema_from(eng.wts, S.ema_alpha, copy_only=S.ema_mode == "copy")
                 return teng.inference(None, dist_.pseudo_label_threshold, staged=(tea.img, tea.sizes, tea.hw))
-            if tside is not None:
+            if tside is not None and self.teacher_first and not pair:
+                tc = tc_early
+                main.wait_stream(tside)
+            elif tside is not None:
                 if pair:
                     tside.wait_stream(main)
                 else:
@@ -479,7 +492,7 @@ class FusedStep:
         # ---- host: all sampling draws
         Hst = self._host_draws(S, A)
         # ---- phase B
-        graph_b = use_graph and getattr(eng, "grad_ready", None) is None
+        graph_b = use_graph and getattr(eng, "grad_ready", None) is None and os.environ.get("ALDI_STEP_GRAPH_B", "1") == "1"
         if graph_b:
             ent = S.graphs_b.get(Hst.key)
             if ent is None:
