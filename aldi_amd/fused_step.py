@@ -161,10 +161,12 @@ class FusedStep:
             side.wait_stream(main)
             with torch.cuda.stream(side):
                 c.props, c.prop_scores, c.prop_count = eng.proposals(c, geom, anchors, stu.hw, N, training=True)
-                eng.wts._refresh_wt()                       # the backward's dgrad weights of the weights SGD just wrote: off the critical path
+                if S.lazy_wt:
+                    eng.wts._refresh_wt()                   # the backward's dgrad weights of the weights SGD just wrote: off the critical path
         else:
             c.props, c.prop_scores, c.prop_count = eng.proposals(c, geom, anchors, stu.hw, N, training=True)
-            eng.wts._refresh_wt()
+            if S.lazy_wt:
+                eng.wts._refresh_wt()
         tc = None
         if S.distill:
             # The teacher's inference (N = 2, mostly small launches) runs on its own stream beside the student's label-free work
@@ -458,7 +460,9 @@ class FusedStep:
         S = self._static_for(key)
         S.N, S.chunks, S.accum, S.distill, S.has_disc = N, chunks, accum, do_distill, do_align
         S.ema_mode, S.ema_alpha = ema_mode, (ema[0].alpha if ema is not None else None)
-        eng.wts.lazy_wt = True
+        S.lazy_wt = hasattr(eng.wts, "_refresh_wt")               # (the flat-container models re-derive theirs inside adamw_step)
+        if S.lazy_wt:
+            eng.wts.lazy_wt = True
         S.tside = _teacher_stream(dev) if do_distill else None
         S.stu = self._stage_images(S, "student", images)
         S.tea = self._stage_images(S, "teacher", [d["image"] for d in unlabeled_weak]) if do_distill else None
