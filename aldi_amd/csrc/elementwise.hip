@@ -217,6 +217,139 @@ __global__ __launch_bounds__(256) void stem_mfma_kernel(StemDev p) {
     }
 }
 
+// Stem + max-pool in one kernel (bf16).  Unfused, the 7x7/2 conv writes its [N][400][672][64] map (206 MB for the step's six
+// images) only for the 3x3/2 max-pool to read it back; both kernels are then bound by that round trip and by the per-workgroup
+// weight conversion.  Here a workgroup produces a 7x7 tile of POOLED pixels: it computes the 16x16 tile of conv outputs that
+// starts one row / column before the first window (rows 2*py0-1 .. 2*py0+14: fifteen of them cover the seven windows; one conv row
+// per tile edge is computed twice), keeps it in LDS after FrozenBN + ReLU (-inf where the conv pixel lies outside the map: the
+// pool pads with -inf), and writes 16-B channel chunks of the 3x3 maxima.  Weights arrive pre-packed in the MFMA k order
+// (aldi_stem_pack_weights: once per weight refresh instead of 12 K scalar loads + conversions per workgroup).  Same MFMA sequence
+// per conv pixel as stem_mfma_kernel, so the result equals maxpool3s2(stem) bit for bit.
+constexpr int kStemWK = 200;              // padded weight row (elements) of the packed [64][WK] bf16 image
+__global__ void stem_pack_kernel(const float* __restrict__ w, bf16_t* __restrict__ wpk) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= 64 * kStemWK) return;
+    const int co = i / kStemWK, k = i - co * kStemWK;
+    const int idx = k >> 3, kw = k & 7;
+    float v = 0.f;
+    if (k < 192 && idx < 21 && kw < 7) {
+        const int c = idx / 7, kh = idx - c * 7;
+        v = w[co * 147 + (kh * 7 + kw) * 3 + c];
+    }
+    wpk[i] = f32_to_bf16(v);
+}
+
+struct StemPoolDev {
+    StemDev s;
+    const bf16_t* wpk;
+    bf16_t* yp;           // [N][Hp][Wp][64]
+    int Hp, Wp;
+};
+
+__global__ __launch_bounds__(256) void stem_pool_mfma_kernel(StemPoolDev q) {
+    const StemDev& p = q.s;
+    constexpr int TH = 37, TW = 40, WK = kStemWK, PT = 7, CS = 144;   // CS: bytes per conv pixel in the LDS conv tile (128 + pad)
+    constexpr int kWlBytes = 64 * WK * 2, kTileBytes = 3 * TH * TW * 2, kCtBytes = 256 * CS;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[(kWlBytes + kTileBytes) > kCtBytes ? (kWlBytes + kTileBytes) : kCtBytes];
+    bf16_t* wl = reinterpret_cast<bf16_t*>(smem);
+    bf16_t* tile = reinterpret_cast<bf16_t*>(smem + kWlBytes);
+    const int n = blockIdx.z;
+    const int py0 = blockIdx.y * PT, px0 = blockIdx.x * PT;
+    const int cy0 = 2 * py0 - 1, cx0 = 2 * px0 - 1;         // first conv pixel of the 16x16 tile
+    {   // packed weights: 1600 16-B chunks
+        const uint4* src = reinterpret_cast<const uint4*>(q.wpk);
+        uint4* dst = reinterpret_cast<uint4*>(wl);
+        for (int i = threadIdx.x; i < 64 * WK / 8; i += 256) dst[i] = src[i];
+    }
+    const int iy0 = cy0 * 2 - 3, ix0 = cx0 * 2 - 3;
+    const int h = p.h[n], w = p.wd[n];
+    {   // input tile: thread t copies 20 consecutive columns of one (channel, row)
+        const int r = threadIdx.x >> 1, half = threadIdx.x & 1;
+        if (r < 3 * TH) {
+            const int c = r / TH, yy = r - c * TH;
+            const int iy = iy0 + yy;
+            const bool rok = iy >= 0 && iy < h;
+            const uint8_t* row = p.img + (((long)n * 3 + c) * p.Hs + (rok ? iy : 0)) * p.Ws;
+            const float mean = p.mean[c], inv = p.inv_std[c];
+#pragma unroll
+            for (int k = 0; k < 20; ++k) {
+                const int xx = half * 20 + k, ix = ix0 + xx;
+                float v = 0.f;
+                if (rok && xx < TH && ix >= 0 && ix < w) v = ((float)row[ix] - mean) * inv;
+                tile[(c * TH + yy) * TW + xx] = f32_to_bf16(v);
+            }
+        }
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int fr = lane & 15, fq = lane >> 4;
+    f32x4_t acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    {
+        const uint32_t* tile32 = reinterpret_cast<const uint32_t*>(tile);
+        const uint4* wl16 = reinterpret_cast<const uint4*>(wl);
+#pragma unroll
+        for (int s = 0; s < 6; ++s) {
+            int idx = s * 4 + fq;
+            idx = idx < 21 ? idx : 20;                       // padded rows carry zero weights; keep the address inside the tile
+            const int c = idx / 7, kh = idx - c * 7;
+            uint4 xf[4], wf[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int ty = wave * 4 + i;
+                const int e = ((c * TH + ty * 2 + kh) * TW + fr * 2) >> 1;
+                xf[i] = make_uint4(tile32[e], tile32[e + 1], tile32[e + 2], tile32[e + 3]);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) wf[j] = wl16[((j * 16 + fr) * WK + (s * 4 + fq) * 8) >> 3];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<bf16x8_t*>(&wf[j]), *reinterpret_cast<bf16x8_t*>(&xf[i]),
+                                                                         acc[i][j], 0, 0, 0);
+        }
+    }
+    __syncthreads();                                        // everyone is done with wl / tile: the conv tile takes their place
+    // lane owns conv pixel (row wave*4+i, column fr), channels j*16 + fq*4 .. +3
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int ch = j * 16 + fq * 4;
+        const float4 sc = *reinterpret_cast<const float4*>(p.scale + ch), sh = *reinterpret_cast<const float4*>(p.shift + ch);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int ry = wave * 4 + i, cy = cy0 + ry, cx = cx0 + fr;
+            uint2 o;
+            if (cy >= 0 && cy < p.Hc && cx >= 0 && cx < p.Wc) {
+                o.x = pack2_bf16(fmaxf(acc[i][j][0] * sc.x + sh.x, 0.f), fmaxf(acc[i][j][1] * sc.y + sh.y, 0.f));
+                o.y = pack2_bf16(fmaxf(acc[i][j][2] * sc.z + sh.z, 0.f), fmaxf(acc[i][j][3] * sc.w + sh.w, 0.f));
+            } else {
+                o.x = o.y = 0xff80ff80u;                     // -inf, -inf
+            }
+            *reinterpret_cast<uint2*>(smem + (ry * 16 + fr) * CS + ch * 2) = o;
+        }
+    }
+    __syncthreads();
+    typedef short s16x8_t __attribute__((ext_vector_type(8)));
+    for (int item = threadIdx.x; item < PT * PT * 8; item += 256) {
+        const int chunk = item & 7, pp = item >> 3;
+        const int pi = pp / PT, pj = pp - pi * PT;
+        const int py = py0 + pi, px = px0 + pj;
+        if (py >= q.Hp || px >= q.Wp) continue;
+        // ReLU outputs are >= 0 and the padding is -inf: as signed 16-bit integers bf16 patterns order like the values
+        s16x8_t m = *reinterpret_cast<const s16x8_t*>(smem + ((2 * pi) * 16 + 2 * pj) * CS + chunk * 16);
+#pragma unroll
+        for (int d = 1; d < 9; ++d) {
+            const s16x8_t v = *reinterpret_cast<const s16x8_t*>(smem + ((2 * pi + d / 3) * 16 + 2 * pj + d % 3) * CS + chunk * 16);
+            m = __builtin_elementwise_max(m, v);
+        }
+        *reinterpret_cast<s16x8_t*>(q.yp + (((long)n * q.Hp + py) * q.Wp + px) * 64 + chunk * 8) = m;
+    }
+}
+
 // max_pool2d(kernel 3, stride 2, pad 1), NHWC, 4 channels per thread
 template <typename T>
 __global__ void maxpool3s2_kernel(const T* __restrict__ x, T* __restrict__ y, int N, int H, int W, int C, int Ho, int Wo) {
@@ -404,6 +537,31 @@ extern "C" int aldi_stem_forward(const aldi_stem_args* a, aldi_stream_t stream) 
         return ALDI_OK;
     }
     DISPATCH_T(a->dtype, stem_kernel, grid, dim3(256), st, d);
+    return ALDI_OK;
+}
+
+extern "C" int aldi_stem_pack_weights(const float* w, void* w_packed, aldi_stream_t stream) {
+    if (!w || !w_packed) return aldi_set_error_msg(ALDI_ERR_ARG, "stem_pack_weights: null pointer");
+    hipLaunchKernelGGL(stem_pack_kernel, dim3(cdiv(64 * kStemWK, 256)), dim3(256), 0, static_cast<hipStream_t>(stream), w, (bf16_t*)w_packed);
+    ALDI_CHECK_LAUNCH();
+    return ALDI_OK;
+}
+
+extern "C" int aldi_stem_pool_forward(const aldi_stem_args* a, const void* w_packed, void* y_pool, aldi_stream_t stream) {
+    if (!a || !a->img || !w_packed || !y_pool || !a->scale || !a->shift || a->N < 1 || a->N > ALDI_MAX_IMAGES || a->dtype != ALDI_BF16)
+        return aldi_set_error_msg(ALDI_ERR_ARG, "stem_pool_forward: bad args (bf16 only)");
+    StemPoolDev q;
+    StemDev& d = q.s;
+    d.img = a->img; d.w = a->w; d.scale = a->scale; d.shift = a->shift; d.y = nullptr;
+    d.N = a->N; d.Hs = a->Hs; d.Ws = a->Ws; d.Hc = a->Hc; d.Wc = a->Wc;
+    for (int i = 0; i < a->N; ++i) { d.h[i] = a->h[i]; d.wd[i] = a->w_img[i]; }
+    for (int c = 0; c < 3; ++c) { d.mean[c] = a->mean[c]; d.inv_std[c] = 1.0f / a->std[c]; }
+    q.wpk = static_cast<const bf16_t*>(w_packed);
+    q.yp = static_cast<bf16_t*>(y_pool);
+    q.Hp = (a->Hc - 1) / 2 + 1; q.Wp = (a->Wc - 1) / 2 + 1;
+    dim3 grid(cdiv(q.Wp, 7), cdiv(q.Hp, 7), a->N);
+    hipLaunchKernelGGL(stem_pool_mfma_kernel, grid, dim3(256), 0, static_cast<hipStream_t>(stream), q);
+    ALDI_CHECK_LAUNCH();
     return ALDI_OK;
 }
 

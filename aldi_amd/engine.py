@@ -85,6 +85,7 @@ class Weights:
         self._wt_keys: List[str] = []          # dgrad weights requested so far (re-derived in one launch per refresh)
         self._wt_plan = None
         self._neg1: Dict[int, torch.Tensor] = {}
+        self._stem_pk, self._stem_name = None, None
         self.lazy_wt = False             # True: sgd_step leaves the dgrad weights stale until someone asks / refreshes
         self._wt_dirty = False
 
@@ -151,6 +152,13 @@ class Weights:
         data-gradient contributions of a pixel to its KHxKW neighbourhood (sparse RPN backward)"""
         return self.wt(name + "@flat")
 
+    def stem_packed(self, name: str) -> torch.Tensor:
+        """the stem kernel in the fused stem+pool kernel's bf16 [64][200] layout; re-derived by refresh()"""
+        if self._stem_pk is None:
+            self._stem_pk = ops.stem_pack_weights(self.w_master(name))
+            self._stem_name = name
+        return self._stem_pk
+
     def _wt_source(self, key: str):
         """(fp32 master view, per-Cout scale) a dgrad-weight key is derived from"""
         neg = key.endswith("-")
@@ -202,6 +210,8 @@ class Weights:
                         self.master[b + 3 * c:b + 4 * c], self.bn_scale, self.bn_shift, c)
         if self.dtype != torch.float32:
             ops.cast_from_f32(self.master[:L.n_weights], self.dtype, out=self.compute)
+        if self._stem_pk is not None:
+            ops.stem_pack_weights(self.w_master(self._stem_name), out=self._stem_pk)
         self._refresh_wt()
 
     def zero_grad(self):
@@ -274,6 +284,7 @@ class RCNN:
         self.img_da_layers = sorted((n for n in names if n.startswith("img_align.model.")), key=idx)
         self.ins_da_layers = sorted((n for n in names if n.startswith("ins_align.model.")), key=idx)
         self.has_img_da, self.has_ins_da = bool(self.img_da_layers), bool(self.ins_da_layers)
+        self.fused_stem = os.environ.get("ALDI_FUSED_STEM", "1") == "1"                  # bf16: stem conv + max-pool in one kernel
         self.group_wgrad = os.environ.get("ALDI_WGRAD_GROUP", "1") == "1"                # bf16: a layer group's weight gradients in one launch
         self._wg_queue: list = []
         self.sparse_rpn_backward = os.environ.get("ALDI_RPN_SPARSE_BWD", "1") == "1"      # tests flip the attribute to compare with the dense form
@@ -411,10 +422,14 @@ class RCNN:
         W = self.wts
         c = Ctx()
         bu = "backbone.bottom_up."
-        stem = ops.stem_forward(st_u8, sizes, W.w_master(bu + "stem.conv1"), W.scale(bu + "stem.conv1"), W.shift(bu + "stem.conv1"),
-                                PIXEL_MEAN, PIXEL_STD, self.dtype)
-        x = ops.maxpool3s2(stem)
-        del stem
+        if self.dtype == torch.bfloat16 and self.fused_stem:
+            x = ops.stem_pool_forward(st_u8, sizes, W.stem_packed(bu + "stem.conv1"), W.scale(bu + "stem.conv1"), W.shift(bu + "stem.conv1"),
+                                      PIXEL_MEAN, PIXEL_STD)
+        else:
+            stem = ops.stem_forward(st_u8, sizes, W.w_master(bu + "stem.conv1"), W.scale(bu + "stem.conv1"), W.shift(bu + "stem.conv1"),
+                                    PIXEL_MEAN, PIXEL_STD, self.dtype)
+            x = ops.maxpool3s2(stem)
+            del stem
         blocks = []
         cs = []
         for si, nb in enumerate(STAGE_BLOCKS):

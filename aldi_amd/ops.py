@@ -210,6 +210,32 @@ def stem_forward(img_u8: torch.Tensor, sizes: Sequence[Sequence[int]], w: torch.
     return y
 
 
+def stem_pack_weights(w: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """fp32 [64,7,7,3] stem kernel -> bf16 [64,200] in the MFMA reduction order (aldi_stem_pack_weights)"""
+    if out is None:
+        out = torch.empty((64, 200), dtype=torch.bfloat16, device=w.device)
+    L.call("aldi_stem_pack_weights", _p(w), _p(out), stream_ptr())
+    return out
+
+
+def stem_pool_forward(img_u8: torch.Tensor, sizes: Sequence[Sequence[int]], w_packed: torch.Tensor, scale: torch.Tensor, shift: torch.Tensor,
+                      mean: Sequence[float], std: Sequence[float]) -> torch.Tensor:
+    """stem conv + FrozenBN + ReLU + max_pool2d(3, 2, 1) in one launch (bf16): [N,3,Hs,Ws] uint8 -> [N,Hs/4,Ws/4,64]"""
+    N, _, Hs, Ws = img_u8.shape
+    Hc, Wc = Hs // 2, Ws // 2
+    y = torch.empty((N, (Hc - 1) // 2 + 1, (Wc - 1) // 2 + 1, 64), dtype=torch.bfloat16, device=img_u8.device)
+    a = L.StemArgs()
+    a.img, a.w, a.scale, a.shift, a.y = _p(img_u8), None, _p(scale), _p(shift), None
+    a.N, a.Hs, a.Ws, a.Hc, a.Wc = N, Hs, Ws, Hc, Wc
+    for i, (h, w_) in enumerate(sizes):
+        a.h[i], a.w_img[i] = int(h), int(w_)
+    for c in range(3):
+        a.mean[c], a.std[c] = float(mean[c]), float(std[c])
+    a.dtype = L.BF16
+    L.call("aldi_stem_pool_forward", C.byref(a), _p(w_packed), _p(y), stream_ptr())
+    return y
+
+
 def maxpool3s2(x: torch.Tensor) -> torch.Tensor:
     N, H, W_, Cc = x.shape
     y = torch.empty((N, (H - 1) // 2 + 1, (W_ - 1) // 2 + 1, Cc), dtype=x.dtype, device=x.device)

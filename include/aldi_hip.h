@@ -153,6 +153,11 @@ typedef struct {
     int dtype;
 } aldi_stem_args;
 int aldi_stem_forward(const aldi_stem_args* a, aldi_stream_t stream);
+/* Stem + max_pool2d(k3,s2,p1) in one kernel (bf16): y_pool [N][(Hc-1)/2+1][(Wc-1)/2+1][64] == aldi_maxpool3s2(aldi_stem_forward(a))
+ * bit for bit, without the 64-channel half-resolution map ever reaching HBM.  w_packed = aldi_stem_pack_weights(a->w): the fp32
+ * [64][7][7][3] kernel re-laid as bf16 [64][200] in the MFMA reduction order (once per weight refresh).  a->y is not used. */
+int aldi_stem_pack_weights(const float* w, void* w_packed, aldi_stream_t stream);
+int aldi_stem_pool_forward(const aldi_stem_args* a, const void* w_packed, void* y_pool, aldi_stream_t stream);
 
 /* max_pool2d(k3,s2,p1) NHWC; y is [N][(H-1)/2+1][(W-1)/2+1][C]. */
 int aldi_maxpool3s2(const void* x, void* y, int N, int H, int W, int C, int dtype, aldi_stream_t stream);

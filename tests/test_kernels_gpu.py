@@ -467,3 +467,26 @@ def test_detections_and_pseudolabel_filter_vs_oracle():
         assert torch.equal(out["pc"][n, :m].cpu().long(), pl["gt_classes"])
         assert (out["pb"][n, :m].cpu() - pl["gt_boxes"]).abs().max() < 1e-3
         assert bool((out["ps"][n, :m] > thr).all())
+
+
+@pytest.mark.parametrize("sizes", [[(64, 96), (64, 96)], [(61, 93), (37, 50)], [(250, 333)], [(800, 1333), (800, 1333)]])
+def test_fused_stem_pool_equals_stem_then_maxpool(sizes):
+    """stem conv + FrozenBN + ReLU + max_pool2d(3,2,1) in one kernel == the two kernels, bit for bit (ragged images in one padded batch,
+    odd conv-map sizes, the benchmark size)"""
+    from aldi_amd import ops
+    from aldi_amd.arch import pad_to
+    gen = torch.Generator().manual_seed(len(sizes) + sizes[0][0])
+    Hs, Ws = pad_to(max(s[0] for s in sizes), 32), pad_to(max(s[1] for s in sizes), 32)
+    img = torch.zeros(len(sizes), 3, Hs, Ws, dtype=torch.uint8)
+    for i, (h, w) in enumerate(sizes):
+        img[i, :, :h, :w] = torch.randint(0, 256, (3, h, w), generator=gen, dtype=torch.uint8)
+    w = (torch.randn(64, 7, 7, 3, generator=gen) * 0.05).to(DEV)
+    scale = (0.5 + torch.rand(64, generator=gen)).to(DEV)
+    shift = (torch.randn(64, generator=gen) * 0.3).to(DEV)
+    mean, std = (103.53, 116.28, 123.675), (1.0, 1.0, 1.0)
+    imgd = img.to(DEV)
+    ref = ops.maxpool3s2(ops.stem_forward(imgd, sizes, w, scale, shift, mean, std, torch.bfloat16))
+    got = ops.stem_pool_forward(imgd, sizes, ops.stem_pack_weights(w), scale, shift, mean, std)
+    torch.cuda.synchronize()
+    assert got.shape == ref.shape and float(ref.float().abs().max()) > 0
+    assert torch.equal(got, ref)
