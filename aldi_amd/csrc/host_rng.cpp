@@ -104,9 +104,62 @@ void seed_mt(Mt& mt, uint64_t seed) {
     mt.next = 0;
 }
 
-// first k entries of torch.randperm(n) from `mt`, which ends where torch's generator would
-template <typename OutT>
-void randperm_prefix(Mt& mt, long n, long k, OutT* out) {
+// A pre-generated Mersenne stream (aldi_torch_rng_prefetch): the raw state words of consecutive refills, block 0 = the start
+// state as it was.  Draw t of the consumer is word `origin + t`; skipping n draws is an addition, which is what takes the
+// 268k-entry negative lists off the critical path between the step's two device phases.
+struct Stream {
+    bool seeded = false;
+    uint64_t seed = 0;
+    Mt start;
+    long origin = 0, capacity = 0;          // position of the first draw in block 0; draws available
+    std::vector<uint32_t> raw;
+    void fill(long max_draws) {
+        // a seeded engine (left == 1) refills before its first draw; otherwise next + left == 625 and the next draw is s[next]
+        origin = start.left == 1 ? MT_N : (long)start.next;
+        const long nb = (origin + max_draws) / MT_N + 2;
+        raw.resize((size_t)nb * MT_N);
+        memcpy(raw.data(), start.s, sizeof(start.s));
+        Mt t = start;
+        for (long b = 1; b < nb; ++b) {
+            t.regen();
+            memcpy(raw.data() + (size_t)b * MT_N, t.s, sizeof(t.s));
+        }
+        capacity = nb * MT_N - origin;
+    }
+};
+struct Cursor {
+    const Stream* st;
+    long pos;
+    uint32_t draw() {
+        uint32_t y = st->raw[(size_t)(st->origin + pos++)];
+        y ^= (y >> 11);
+        y ^= (y << 7) & 0x9d2c5680u;
+        y ^= (y << 15) & 0xefc60000u;
+        y ^= (y >> 18);
+        return y;
+    }
+    void discard(long d) { pos += d; }
+    // the engine a sequential consumer would be left with
+    void leave(Mt& mt) const {
+        if (pos == 0) { mt = st->start; return; }
+        const long p = st->origin + pos - 1, b = p / MT_N, i = p % MT_N;
+        memcpy(mt.s, st->raw.data() + (size_t)b * MT_N, sizeof(mt.s));
+        mt.next = (uint64_t)(i + 1);
+        mt.left = (int)(MT_N - i);
+    }
+};
+
+std::vector<Stream> g_streams;
+long g_stream_hits = 0;
+std::vector<std::thread> g_fillers;
+void join_fillers() {
+    for (auto& t : g_fillers) t.join();
+    g_fillers.clear();
+}
+
+// first k entries of torch.randperm(n) from `mt` (an engine or a stream cursor), which ends where torch's generator would
+template <typename OutT, typename Gen>
+void randperm_prefix(Gen& mt, long n, long k, OutT* out) {
     if (k > n) k = n;
     // sparse image of the permutation array: position -> value for the <= 2k positions touched so far (open addressing;
     // a node-based map costs more than the shuffle itself for the small lists)
@@ -168,9 +221,8 @@ extern "C" int aldi_torch_rng_script(unsigned char* state, const long* script, i
         }
     }
     segs.back().end = nops;
-    auto run = [&](Seg& sg) {
-        if (sg.seeded) seed_mt(sg.mt, sg.seed);
-        else load_blob(state, sg.mt);
+    join_fillers();
+    auto ops = [&](Seg& sg, auto& gen) {
         static thread_local std::vector<int> scratch;
         for (int i = sg.begin; i < sg.end; ++i) {
             const long n = script[4 * i + 1], k = script[4 * i + 2], off = script[4 * i + 3];
@@ -179,16 +231,41 @@ extern "C" int aldi_torch_rng_script(unsigned char* state, const long* script, i
                 scratch.resize((size_t)(k < n ? k : n) + 1);
                 dst = scratch.data();
             }
-            randperm_prefix<int>(sg.mt, n, k, dst);
+            randperm_prefix<int>(gen, n, k, dst);
         }
     };
-    if (threads > 1 && segs.size() > 1) {
+    auto run = [&](Seg& sg) { ops(sg, sg.mt); };
+    // segments whose stream was pre-generated (same seed / same engine state, long enough) cost a few hundred draws each and
+    // run here; the others skip through their Mersenne refills, on their own threads when there are several
+    std::vector<Seg*> slow;
+    for (auto& sg : segs) {
+        if (sg.seeded) seed_mt(sg.mt, sg.seed);
+        else load_blob(state, sg.mt);
+        long total = 0;
+        for (int i = sg.begin; i < sg.end; ++i) total += script[4 * i + 1] > 0 ? script[4 * i + 1] - 1 : 0;
+        const Stream* hit = nullptr;
+        for (const Stream& st : g_streams) {
+            const bool same = sg.seeded ? (st.seeded && st.seed == sg.seed)
+                                        : (!st.seeded && st.start.left == sg.mt.left && st.start.next == sg.mt.next &&
+                                           memcmp(st.start.s, sg.mt.s, sizeof(sg.mt.s)) == 0);
+            if (same && total <= st.capacity) { hit = &st; break; }
+        }
+        if (hit) {
+            Cursor cur{hit, 0};
+            ops(sg, cur);
+            cur.leave(sg.mt);
+            g_stream_hits++;
+        } else {
+            slow.push_back(&sg);
+        }
+    }
+    if (threads > 1 && slow.size() > 1) {
         std::vector<std::thread> pool;
-        for (size_t i = 1; i < segs.size(); ++i) pool.emplace_back(run, std::ref(segs[i]));
-        run(segs[0]);
+        for (size_t i = 1; i < slow.size(); ++i) pool.emplace_back(run, std::ref(*slow[i]));
+        run(*slow[0]);
         for (auto& t : pool) t.join();
     } else {
-        for (auto& sg : segs) run(sg);
+        for (Seg* sg : slow) run(*sg);
     }
     const Seg& last = segs.back();
     if (last.seeded) {                     // what torch.manual_seed(seed) + the draws leave in the blob
@@ -203,3 +280,36 @@ extern "C" int aldi_torch_rng_script(unsigned char* state, const long* script, i
     store_blob(state, last.mt);
     return ALDI_OK;
 }
+
+// Pre-generates, on background threads, the Mersenne streams the next aldi_torch_rng_script call will consume: the one that
+// continues `state` (the generator blob as it is NOW; NULL = none) and one per torch.manual_seed value in `seeds`, each
+// `max_draws` long.  The caller issues this while the device is busy with the phase whose results size the draws; the
+// script then only indexes into the streams.  A stream that does not match the script's actual engine state / seeds, or is
+// too short, is ignored (the script falls back to skipping through the refills itself).
+extern "C" int aldi_torch_rng_prefetch(const unsigned char* state, const long* seeds, int nseeds, long max_draws) {
+    if (nseeds < 0 || (nseeds > 0 && !seeds) || max_draws < 0 || max_draws > (1L << 28))
+        return aldi_set_error_msg(ALDI_ERR_ARG, "torch_rng_prefetch: bad args");
+    join_fillers();
+    g_streams.clear();
+    g_streams.resize((size_t)nseeds + (state ? 1 : 0));
+    size_t j = 0;
+    if (state) {
+        Stream& st = g_streams[j++];
+        load_blob(state, st.start);
+        if (st.start.left < 1 || st.start.left > MT_N || (st.start.left > 1 && (long)st.start.next + st.start.left != MT_N + 1)) {
+            g_streams.erase(g_streams.begin());            // not an engine state this code knows how to continue
+            j = 0;
+        }
+    }
+    for (int i = 0; i < nseeds; ++i) {
+        Stream& st = g_streams[j++];
+        st.seeded = true;
+        st.seed = (uint64_t)seeds[i];
+        seed_mt(st.start, st.seed);
+    }
+    for (Stream& st : g_streams) g_fillers.emplace_back([&st, max_draws] { st.fill(max_draws); });
+    return ALDI_OK;
+}
+
+// how many script segments were served from a pre-generated stream since the library was loaded (tests, bench stats)
+extern "C" int aldi_torch_rng_prefetch_hits(void) { return (int)(g_stream_hits & 0x7fffffff); }

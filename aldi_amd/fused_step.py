@@ -21,6 +21,7 @@ backward launches the overlapped gradient exchange, reduce.BucketedReducer)."""
 from __future__ import annotations
 
 import os
+import time
 from types import SimpleNamespace
 from typing import Dict, List, Optional
 
@@ -50,7 +51,11 @@ class _Packed:
             off += (nb + 15) // 16 * 16
         self.host = _pinned(off)
         self.host.zero_()
+        self.words = self.host.numpy().view("int32")         # same storage: scalar stores without a tensor op each
         self.dev = torch.zeros(self.host.numel(), dtype=torch.uint8, device=device)
+
+    def word0(self, name) -> int:
+        return self.spec[name][0] // 4
 
     def h(self, name) -> torch.Tensor:
         o, nb, shape, dt = self.spec[name]
@@ -226,6 +231,32 @@ class FusedStep:
                 return False
         return True
 
+    def _scripted(self) -> bool:
+        """the host phase as one C call (aldi_torch_rng_script) instead of Python hooks + torch.randperm"""
+        from . import engine as E
+        if E._FAST_RANDPERM is None:
+            E.randperm_prefix(1, 1)                            # (first use verifies the C generator against torch.randperm; draws nothing)
+        return self._hooks_are_standard() and bool(E._FAST_RANDPERM) and os.environ.get("ALDI_HOST_RNG_SCRIPT", "1") == "1"
+
+    def _prefetch_draws(self, S, n_anchors: int):
+        """While the device runs phase A: pre-generate the Mersenne streams the draws will come from -- the one continuing the
+        global CPU generator, the seeder's current seed, and the seed it will draw next (aldi/distill.py:148-150; Python's
+        `random` is peeked, not advanced).  The list lengths are not known yet, only the streams they index into; with them the
+        host phase between the two device phases no longer skips through ~430 state refills per 268k-entry negative list."""
+        if not self._scripted() or os.environ.get("ALDI_HOST_RNG_PREFETCH", "1") != "1":
+            return
+        import ctypes as C
+        import random
+        from . import _lib as L
+        seeds = [int(self.tr.distiller.seeder.seed)]
+        if S.distill:
+            keep = random.getstate()
+            seeds.append(random.randint(0, 2**32 - 1))          # what ManualSeed.reset_seed will draw (aldi/helpers.py:21-23)
+            random.setstate(keep)
+        depth = S.N * (n_anchors + 2 * 4096)                   # every image's RPN lists + ROI lists in ONE segment: an upper bound
+        st = torch.get_rng_state()
+        L.call("aldi_torch_rng_prefetch", st.data_ptr(), (C.c_long * len(seeds))(*seeds), len(seeds), depth)
+
     def _host_draws(self, S, A):
         """every sampling draw of the iteration on the global CPU generator, in the reference's order:
         per micro-step the RPN sample (two randperm per image), `torch.manual_seed(seed)` by the roi_heads pre-hook, the ROI
@@ -239,28 +270,29 @@ class FusedStep:
         roi_counts = [both[2 * N + 2 * i: 2 * N + 2 * i + 2] for i in range(N)]
         U = S.up
         from . import engine as E
-        E.randperm_prefix(1, 1)                            # (first use verifies the C generator against torch.randperm; draws nothing)
-        scripted = self._hooks_are_standard() and bool(E._FAST_RANDPERM) and os.environ.get("ALDI_HOST_RNG_SCRIPT", "1") == "1"
+        scripted = self._scripted()
         script: List[int] = []
+        hw = U.words
 
         def sample(name, nname, row0, counts, batch, frac):
             """subsample_labels for the images `row0 ...`: positives then negatives, two randperm per image"""
-            o0 = U.spec[name][0] // 4 if name != "-" else 0
-            nsel = U.h(nname) if nname else None
             per = []
             if not scripted:
                 a, b, hh = eng._sample_host(counts, batch, frac)
                 if name != "-":
-                    U.h(name)[row0:row0 + len(counts)], nsel[row0:row0 + len(counts)] = a, b
+                    U.h(name)[row0:row0 + len(counts)], U.h(nname)[row0:row0 + len(counts)] = a, b
                 return hh
+            keep = name != "-"
+            o0 = U.word0(name) if keep else 0
+            n0_ = U.word0(nname) if keep else 0
             for i, (npos, nneg) in enumerate(counts):
                 num_pos = min(npos, int(batch * frac))
                 num_neg = min(nneg, batch - num_pos)
-                keep = name != "-"
                 base = o0 + (row0 + i) * 2 * batch
                 script.extend((0, npos, num_pos, base if keep else -1, 0, nneg, num_neg, base + batch if keep else -1))
                 if keep:
-                    nsel[row0 + i, 0], nsel[row0 + i, 1] = num_pos, num_neg
+                    hw[n0_ + 2 * (row0 + i)] = num_pos
+                    hw[n0_ + 2 * (row0 + i) + 1] = num_neg
                 per.append([num_pos, num_neg])
             return per
 
@@ -286,10 +318,9 @@ class FusedStep:
             oh = sample("osel", "onsel", n0, roi_counts[n0:n1], ROI_BATCH, ROI_POS_FRAC)
             rows += [x + y for x, y in oh]
             ch["rpn_counts"], ch["roi_counts"] = rpn_counts[n0:n1], roi_counts[n0:n1]
-        off = 0
-        ro = U.h("row_off")
+        off, ro = 0, U.word0("row_off")
         for i, r in enumerate(rows):
-            ro[i] = off
+            hw[ro + i] = off
             off += r
         r0 = 0
         for ch in S.chunks:
@@ -304,8 +335,7 @@ class FusedStep:
             dh = sample("dsel", "dnsel", 0, ch["rpn_counts"], RPN_BATCH, RPN_POS_FRAC)     # fresh sample of get_rpn_losses (aldi/distill.py:200-202)
             n_fg = sum(x for x, _ in dh)
             n_valid = sum(x + y for x, y in dh)
-            nvf = U.h("nvf")
-            nvf[0], nvf[1] = n_valid, n_fg
+            hw[U.word0("nvf")], hw[U.word0("nvf") + 1] = n_valid, n_fg
         if scripted and script:
             import ctypes as C
             from . import _lib as L
@@ -483,6 +513,7 @@ class FusedStep:
         # (the ViTDet / ConvNeXt trunks draw their stochastic-depth masks on the host every step: their launches are not replayable as recorded)
         use_graph = self.graph_enabled and self.steps_done >= self.warmup and type(eng) is RCNN
         # ---- phase A
+        t0 = time.perf_counter()
         if use_graph:
             if S.graph_a is None:
                 S.graph_a, S.A = self._capture(lambda: self._phase_a(S))
@@ -492,9 +523,15 @@ class FusedStep:
         else:
             A = self._phase_a(S)
         c, tc = A.c, A.tc
+        self._prefetch_draws(S, int(c.anchors.shape[0]))
+        t1 = time.perf_counter()
         torch.cuda.current_stream().synchronize()                  # the ONE device->host sync: list lengths for the host RNG
+        t2 = time.perf_counter()
         # ---- host: all sampling draws
         Hst = self._host_draws(S, A)
+        t3 = time.perf_counter()
+        from . import _lib as L_
+        self.stats["rng_stream_hits"] = int(L_.lib.aldi_torch_rng_prefetch_hits())
         # ---- phase B
         graph_b = use_graph and getattr(eng, "grad_ready", None) is None and os.environ.get("ALDI_STEP_GRAPH_B", "1") == "1"
         if graph_b:
@@ -517,6 +554,9 @@ class FusedStep:
             B = self._phase_b(S, A, Hst)
             if not use_graph:
                 self.stats["eager"] += 1
+        t4 = time.perf_counter()
+        for k_, v_ in (("host_us_issue_a", t1 - t0), ("host_us_wait_a", t2 - t1), ("host_us_draws", t3 - t2), ("host_us_issue_b", t4 - t3)):
+            self.stats[k_] = round(0.8 * self.stats.get(k_, (v_ * 1e6)) + 0.2 * v_ * 1e6, 1)       # running mean, microseconds
         self.steps_done += 1
         if do_distill:
             teacher._last_inference = tc

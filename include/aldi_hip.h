@@ -318,6 +318,12 @@ int aldi_torch_randperm_prefix(unsigned char* state, long n, long k, long* out);
  * min(b, a) entries of torch.randperm(a) -> out[out_off ...] (int32; out_off < 0: discarded), kind 1 = torch.manual_seed(a).
  * Segments between seeds are independent and run on `threads` host threads; the state blob ends as torch would leave it. */
 int aldi_torch_rng_script(unsigned char* state, const long* script, int nops, int* out, int threads);
+/* Pre-generates on background threads the Mersenne streams the NEXT aldi_torch_rng_script call will consume: the one that
+ * continues `state` (NULL: none) and one per torch.manual_seed value of `seeds`, max_draws long each.  Issued while the
+ * device runs the phase whose results size the draws; the script then indexes into the streams instead of skipping through
+ * ~430 state refills per 268k-entry list.  Streams that do not match the script's engine state / seeds are ignored. */
+int aldi_torch_rng_prefetch(const unsigned char* state, const long* seeds, int nseeds, long max_draws);
+int aldi_torch_rng_prefetch_hits(void);       /* script segments served from a pre-generated stream so far */
 
 /* ---------------------------------------------------------------------------------------
  * Strong augmentation on the device (the step next to the hot path).  Images are HWC uint8 in HBM;

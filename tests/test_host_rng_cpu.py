@@ -75,3 +75,62 @@ def test_rng_script_equals_torch_sequence(threads):
     torch.set_rng_state(start)
     (b,) = _script([("draw", 5000, 40, True)], threads)
     assert torch.equal(a, b) and torch.equal(torch.get_rng_state(), s1)
+
+
+def _prefetch(seeds, max_draws, with_state=True):
+    import ctypes as C
+    from aldi_amd import _lib as L
+    st = torch.get_rng_state()
+    arr = (C.c_long * max(len(seeds), 1))(*seeds)
+    L.call("aldi_torch_rng_prefetch", st.data_ptr() if with_state else None, arr, len(seeds), max_draws)
+
+
+def _hits():
+    from aldi_amd import _lib as L
+    return L.lib.aldi_torch_rng_prefetch_hits()
+
+
+@pytest.mark.parametrize("case", ["all", "short", "wrong_seed", "stale_state", "mid_block", "no_draws"])
+def test_rng_script_from_prefetched_streams(case):
+    """the same script served from pre-generated Mersenne streams (aldi_torch_rng_prefetch): identical draws and final
+    generator state; streams that are too short / belong to another seed / another engine state are not used"""
+    ops_ = [("draw", 300, 128, True), ("draw", 268000, 128, True), ("draw", 17, 256, True), ("seed", 123456789), ("draw", 1100, 128, True),
+            ("draw", 900, 384, True), ("seed", 77), ("draw", 268569, 256, False), ("draw", 0, 10, True), ("draw", 1, 1, True),
+            ("seed", 77), ("draw", 70001, 300, True), ("draw", 5000, 300, True)]
+    if case == "no_draws":
+        ops_ = [("draw", 1, 5, True), ("seed", 123456789), ("draw", 0, 1, True), ("seed", 77)]
+    torch.manual_seed(4242)
+    if case == "mid_block":
+        torch.randperm(1000)                            # the engine sits in the middle of a state block
+    start = torch.get_rng_state()
+    ref = []
+    for op in ops_:
+        if op[0] == "seed":
+            torch.manual_seed(op[1])
+        else:
+            p = torch.randperm(op[1])[: op[2]]
+            if op[3]:
+                ref.append(p.to(torch.int32))
+    ref_state, ref_next = torch.get_rng_state(), torch.randperm(50)
+    torch.set_rng_state(start)
+    seeds, depth = [123456789, 77], 300000
+    if case == "short":
+        depth = 1000                                    # only the 1100 + 900 segment fits... not even that: (1099 + 899) > 1000
+    if case == "wrong_seed":
+        seeds = [5, 6]
+    _prefetch(seeds, depth)
+    if case == "stale_state":
+        torch.randperm(3)                               # the engine moved after the prefetch: its stream must be ignored
+        torch.set_rng_state(start)
+        torch.randperm(3)
+        ref = None
+    h0 = _hits()
+    got = _script(ops_, 2)
+    served = _hits() - h0
+    if case == "stale_state":
+        assert served == 3                              # the seeded segments only
+        return
+    assert len(got) == len(ref) and all(torch.equal(a, b) for a, b in zip(got, ref))
+    assert torch.equal(torch.get_rng_state(), ref_state)
+    assert torch.equal(torch.randperm(50), ref_next)
+    assert served == {"all": 4, "mid_block": 4, "short": 0, "wrong_seed": 1, "no_draws": 3}[case]
