@@ -282,36 +282,94 @@ __global__ __launch_bounds__(256) void roialign_fwd_vec_kernel(Feats ft, const f
 //   colc[px][pw]  = the same along x for every pixel of the segment                           (32 x 7)
 // with the forward's own bilin_prep (same clamps, same dead samples), so that
 //   dG[py][px][c] = sum_roi 1/count * sum_pw colc[px][pw] * ( sum_ph rowc[ph] * g_pooled[roi][ph][pw][c] ).
-// Thread = channel; the 32 pixel accumulators stay in registers; every gradient element is written exactly once
-// (the scatter form issues ~880 MB of fp32 atomics per step and is bound by them).
+// Every gradient element is written exactly once (the scatter form issues ~880 MB of fp32 atomics per step and is bound by
+// them).  The benchmark step's ROIs are small (512 per image, nearly all on P2, ~19 x 10 pixels there: ~5 candidates per
+// segment, 48 k (segment, ROI) pairs), so the kernel is bound by instruction issue and L2 round trips per pair, not by bytes:
+//   * two thread roles per pair.  Row reduction: thread = (bin column, 8 channels), three 16-byte loads (the run of bin rows
+//     with weight on this row; 2-byte loads per channel cost 7x the load instructions) -> gsum[pw][c] in LDS.
+//     Column spread: thread = (pixel, 4-channel groups), only the bins with weight on ITS pixel (2-3 of 7).
+//   * the candidate's geometry (divisions, ceilings) is computed once by the scanning thread and parked in LDS;
+//   * a software pipeline with ONE barrier per pair: iteration q reduces the rows it loaded an iteration ago, issues the
+//     loads of q + 1, builds the tables of q + 2 and spreads q - 1.
 constexpr int kSeg = 32;
 struct GatherGeom { int blk_off[5]; int segs[4]; int N; };
 
+template <typename T> struct Raw8;                      // 8 consecutive channels as loaded; unpacked when consumed
+template <> struct Raw8<bf16_t> {
+    uint4 v;
+    __device__ __forceinline__ void load(const bf16_t* p) { v = *reinterpret_cast<const uint4*>(p); }
+    __device__ __forceinline__ void unpack(float* o) const {
+        o[0] = __uint_as_float(v.x << 16); o[1] = __uint_as_float(v.x & 0xffff0000u);
+        o[2] = __uint_as_float(v.y << 16); o[3] = __uint_as_float(v.y & 0xffff0000u);
+        o[4] = __uint_as_float(v.z << 16); o[5] = __uint_as_float(v.z & 0xffff0000u);
+        o[6] = __uint_as_float(v.w << 16); o[7] = __uint_as_float(v.w & 0xffff0000u);
+    }
+};
+template <> struct Raw8<float> {
+    float4 a, b;
+    __device__ __forceinline__ void load(const float* p) { a = *reinterpret_cast<const float4*>(p); b = *reinterpret_cast<const float4*>(p + 4); }
+    __device__ __forceinline__ void unpack(float* o) const { o[0] = a.x; o[1] = a.y; o[2] = a.z; o[3] = a.w; o[4] = b.x; o[5] = b.y; o[6] = b.z; o[7] = b.w; }
+};
+
 template <typename T>
-__global__ __launch_bounds__(256) void roialign_bwd_gather_kernel(Feats ft, GatherGeom gg, const float* __restrict__ rois, int R, int P,
+__global__ __launch_bounds__(256, 5) void roialign_bwd_gather_kernel(Feats ft, GatherGeom gg, const float* __restrict__ rois, int R, int P,
                                                                   const T* __restrict__ gp /*[R][P][P][C]*/, int sorted) {
     __shared__ int cand[256];
+    __shared__ float cx1[256], cy1[256], cbw[256], cbh[256], cinv[256];
+    __shared__ int cgw[256], cgh[256];
     __shared__ int range[2];
     __shared__ int sm[17];
-    __shared__ float rowc[8];
-    __shared__ float colc[kSeg][8];
-    __shared__ int pwlo[kSeg], pwhi[kSeg];
-    __shared__ float gsum[7][256];
-    const int tid = threadIdx.x, c = tid;
-    // coarse levels first: their segments see most of an image's large ROIs (hundreds of candidates each) and would otherwise
-    // start last, alone on the chip, after the thousands of light P2 segments
+    __shared__ __attribute__((aligned(16))) float rowc[4][8];
+    __shared__ __attribute__((aligned(16))) float colc[4][kSeg][8];
+    __shared__ __attribute__((aligned(16))) float gsum[2][7][256];
+    const int tid = threadIdx.x;
+    const int px = tid >> 3, cg = tid & 7;               // column spread: pixel of the segment, channels (j * 8 + cg) * 4 ... + 3
+    const int qw = tid >> 5, c8 = tid & 31;              // row reduction: bin column, channels c8 * 8 ... + 7
+    // coarse levels first: their segments see an image's large ROIs (many candidates each) and would otherwise start last,
+    // alone on the chip, after the thousands of light P2 segments
     const int bid = (int)(gridDim.x - 1 - blockIdx.x);
     int l = 0;
     while (l < 3 && bid >= gg.blk_off[l + 1]) ++l;
-    const int H = ft.H[l], W = ft.W[l];
+    const int H = ft.H[l], W = ft.W[l], C = ft.C;
     int t = bid - gg.blk_off[l];
     const int seg = t % gg.segs[l]; t /= gg.segs[l];
     const int py = t % H, b = t / H;
     const int px0 = seg * kSeg;
     const float sc = ft.scale[l];
-    float acc[kSeg];
+    float4 acc[8];
 #pragma unroll
-    for (int i = 0; i < kSeg; ++i) acc[i] = 0.f;
+    for (int j = 0; j < 8; ++j) acc[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+
+    // the separable footprint of candidate k on this row / these 32 pixels -> table `buf` (every thread fills one colc entry)
+    auto tables = [&](int k, int buf) {
+        const float x1 = cx1[k], y1 = cy1[k], bw = cbw[k], bh = cbh[k];
+        const int gw = cgw[k], gh = cgh[k];
+        if (tid < 8) {
+            float a = 0.f;
+            if (tid < P)
+                for (int iy = 0; iy < gh; ++iy) {
+                    const Bilin by = bilin_prep(y1 + (float)tid * bh + ((float)iy + 0.5f) * bh / (float)gh, H);
+                    if (by.dead) continue;
+                    if (by.lo == py) a += by.h;
+                    if (by.hi == py) a += by.l;
+                }
+            rowc[buf][tid] = a;
+        }
+        {
+            const int pw = tid & 7;
+            float a = 0.f;
+            if (pw < P) {
+                const int pxa = px0 + px;
+                for (int ix = 0; ix < gw; ++ix) {
+                    const Bilin bx = bilin_prep(x1 + (float)pw * bw + ((float)ix + 0.5f) * bw / (float)gw, W);
+                    if (bx.dead) continue;
+                    if (bx.lo == pxa) a += bx.h;
+                    if (bx.hi == pxa) a += bx.l;
+                }
+            }
+            colc[buf][px][pw] = a;
+        }
+    };
 
     // ROI rows are grouped by image (the engine concatenates the per-image samples): only this image's rows can hit the segment
     // -- a binary search instead of scanning all R rows in every one of the ~12 k workgroups
@@ -333,10 +391,13 @@ __global__ __launch_bounds__(256) void roialign_bwd_gather_kernel(Feats ft, Gath
         // ---- candidates of this chunk: same image, same level, footprint bounding box meets the segment
         const int r = base + tid;
         bool hit = false;
+        float x1 = 0.f, y1 = 0.f, rw = 0.f, rh = 0.f;
         if (r < r_hi) {
             const float* rp = rois + (long)r * 5;
             if ((int)rp[0] == b && roi_level(rp[1], rp[2], rp[3], rp[4]) == l) {
-                const float x1 = rp[1] * sc - 0.5f, y1 = rp[2] * sc - 0.5f, x2 = rp[3] * sc - 0.5f, y2 = rp[4] * sc - 0.5f;
+                x1 = rp[1] * sc - 0.5f; y1 = rp[2] * sc - 0.5f;
+                const float x2 = rp[3] * sc - 0.5f, y2 = rp[4] * sc - 0.5f;
+                rw = x2 - x1; rh = y2 - y1;
                 const int r0 = min(max((int)floorf(y1) - 1, 0), H - 1), r1 = min(max((int)floorf(y2) + 2, 0), H - 1);
                 const int c0 = min(max((int)floorf(x1) - 1, 0), W - 1), c1 = min(max((int)floorf(x2) + 2, 0), W - 1);
                 hit = py >= r0 && py <= r1 && c1 >= px0 && c0 < px0 + kSeg;
@@ -344,85 +405,104 @@ __global__ __launch_bounds__(256) void roialign_bwd_gather_kernel(Feats ft, Gath
         }
         int ncand;
         const int rank = block_rank(hit, sm, &ncand);
-        if (hit) cand[rank] = r;
-        __syncthreads();
-        for (int q = 0; q < ncand; ++q) {
-            const int rr = cand[q];
-            const float* rp = rois + (long)rr * 5;
-            const float x1 = rp[1] * sc - 0.5f, y1 = rp[2] * sc - 0.5f, x2 = rp[3] * sc - 0.5f, y2 = rp[4] * sc - 0.5f;
-            const float rw = x2 - x1, rh = y2 - y1;
-            const float bw = rw / (float)P, bh = rh / (float)P;
+        if (hit) {
             const int gh = (int)ceilf(rh / (float)P), gw = (int)ceilf(rw / (float)P);
-            const float inv_count = 1.f / (float)max(gh * gw, 1);
-            if (tid < 8) {
-                float a = 0.f;
-                if (tid < P)
-                    for (int iy = 0; iy < gh; ++iy) {
-                        const Bilin by = bilin_prep(y1 + (float)tid * bh + ((float)iy + 0.5f) * bh / (float)gh, H);
-                        if (by.dead) continue;
-                        if (by.lo == py) a += by.h;
-                        if (by.hi == py) a += by.l;
-                    }
-                rowc[tid] = a;
+            cand[rank] = r;
+            cx1[rank] = x1; cy1[rank] = y1; cbw[rank] = rw / (float)P; cbh[rank] = rh / (float)P;
+            cgw[rank] = gw; cgh[rank] = gh;
+            cinv[rank] = 1.f / (float)max(gh * gw, 1);
+        }
+        __syncthreads();
+        if (ncand > 0) tables(0, 0);
+        if (ncand > 1) tables(1, 1);
+        __syncthreads();
+
+        // state of the candidate whose pooled-gradient rows are in flight
+        Raw8<T> raw[3];
+        float rc[3] = {0.f, 0.f, 0.f};
+        int plo = 8, phi = -1;
+        bool live_c = false, live_p = false;
+        // bin rows with a non-zero weight on this feature row: a run of <= 3 unless the bins are thinner than a pixel or the
+        // samples clamp at the border (the rest of the run is then fetched when the rows are reduced); the margin rows of the
+        // candidate test have none at all
+        auto issue = [&](int k, int buf) {
+            plo = 8; phi = -1;
+#pragma unroll
+            for (int ph = 0; ph < 7; ++ph)
+                if (ph < P && rowc[buf][ph] != 0.f) { plo = min(plo, ph); phi = ph; }
+            live_c = phi >= 0;
+            if (!live_c) return;
+            const T* g0 = gp + (long)cand[k] * P * P * C + c8 * 8;
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const int pk = min(plo + j, P - 1);
+                rc[j] = plo + j <= phi ? rowc[buf][pk] : 0.f;
+                if (qw < P) raw[j].load(g0 + (long)(pk * P + qw) * C);
             }
-            if (tid < kSeg * 8) {
-                const int pxl = tid >> 3, pw = tid & 7;
-                float a = 0.f;
-                if (pw < P) {
-                    const int px = px0 + pxl;
-                    for (int ix = 0; ix < gw; ++ix) {
-                        const Bilin bx = bilin_prep(x1 + (float)pw * bw + ((float)ix + 0.5f) * bw / (float)gw, W);
-                        if (bx.dead) continue;
-                        if (bx.lo == px) a += bx.h;
-                        if (bx.hi == px) a += bx.l;
+        };
+        if (ncand > 0) issue(0, 0);
+        for (int q = 0; q <= ncand; ++q) {                  // (the last iteration only spreads the last candidate)
+            bool live_q = false;
+            if (q < ncand) {
+                live_q = live_c;
+                if (live_q && qw < P) {
+                    // sum_ph rowc[ph] * g[ph][qw][c], ascending ph, then 1 / (samples per bin)
+                    float g8[8], u[8];
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) g8[i] = 0.f;
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) {
+                        raw[j].unpack(u);
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) g8[i] += rc[j] * u[i];
+                    }
+                    if (phi - plo > 2) {
+                        const T* g0 = gp + (long)cand[q] * P * P * C + c8 * 8;
+                        for (int ph = plo + 3; ph <= phi; ++ph) {
+                            const float w = rowc[q & 3][ph];
+                            Raw8<T> x;
+                            x.load(g0 + (long)(ph * P + qw) * C);
+                            x.unpack(u);
+#pragma unroll
+                            for (int i = 0; i < 8; ++i) g8[i] += w * u[i];
+                        }
+                    }
+                    const float inv = cinv[q];
+                    float* gd = &gsum[q & 1][qw][c8 * 8];
+                    *reinterpret_cast<float4*>(gd) = make_float4(g8[0] * inv, g8[1] * inv, g8[2] * inv, g8[3] * inv);
+                    *reinterpret_cast<float4*>(gd + 4) = make_float4(g8[4] * inv, g8[5] * inv, g8[6] * inv, g8[7] * inv);
+                }
+                if (q + 1 < ncand) issue(q + 1, (q + 1) & 3);
+                if (q + 2 < ncand) tables(q + 2, (q + 2) & 3);
+            }
+            if (q > 0 && live_p) {
+                // this pixel's bins of candidate q - 1 (a run of 2-3 of the 7), four channels at a time from gsum
+                const int tb = (q - 1) & 3;
+                const float4 w0 = *reinterpret_cast<const float4*>(&colc[tb][px][0]);
+                const float4 w1 = *reinterpret_cast<const float4*>(&colc[tb][px][4]);
+                const float wv[7] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z};
+                const float* gsb = &gsum[(q - 1) & 1][0][cg * 4];
+#pragma unroll
+                for (int pw = 0; pw < 7; ++pw) {
+                    if (wv[pw] != 0.f) {
+                        const float w = wv[pw];
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) {
+                            const float4 g = *reinterpret_cast<const float4*>(gsb + pw * 256 + j * 32);
+                            acc[j].x = __builtin_fmaf(w, g.x, acc[j].x); acc[j].y = __builtin_fmaf(w, g.y, acc[j].y); acc[j].z = __builtin_fmaf(w, g.z, acc[j].z); acc[j].w = __builtin_fmaf(w, g.w, acc[j].w);
+                        }
                     }
                 }
-                colc[pxl][pw] = a;
             }
+            live_p = live_q;
             __syncthreads();
-            if (tid < kSeg) {                 // bins with a non-zero weight on this pixel (a contiguous run)
-                int lo = 8, hi = -1;
-                for (int pw = 0; pw < P; ++pw)
-                    if (colc[tid][pw] != 0.f) { lo = min(lo, pw); hi = pw; }
-                pwlo[tid] = lo; pwhi[tid] = hi;
-            }
-            // per-bin-column gradient of this ROI weighted onto this row
-            {
-                float gs[7];
-#pragma unroll
-                for (int pw = 0; pw < 7; ++pw) gs[pw] = 0.f;
-                const T* g0 = gp + (long)rr * P * P * ft.C + c;
-                // all P*P loads in flight at once (a `continue` on zero row weights would put one L2 round trip per bin row
-                // on the critical path of every candidate)
-                if (P == 7) {
-#pragma unroll
-                    for (int ph = 0; ph < 7; ++ph) {
-                        const float rc = rowc[ph];
-#pragma unroll
-                        for (int pw = 0; pw < 7; ++pw) gs[pw] += rc * Elem<T>::ld(g0 + (long)(ph * 7 + pw) * ft.C);
-                    }
-                } else {
-                    for (int ph = 0; ph < P; ++ph) {
-                        const float rc = rowc[ph];
-                        for (int pw = 0; pw < P; ++pw) gs[pw] += rc * Elem<T>::ld(g0 + (long)(ph * P + pw) * ft.C);
-                    }
-                }
-#pragma unroll
-                for (int pw = 0; pw < 7; ++pw) gsum[pw][c] = gs[pw] * inv_count;
-            }
-            __syncthreads();
-#pragma unroll
-            for (int i = 0; i < kSeg; ++i) {
-                const int lo = pwlo[i], hi = pwhi[i];
-                for (int pw = lo; pw <= hi; ++pw) acc[i] += colc[i][pw] * gsum[pw][c];
-            }
-            __syncthreads();                  // tables are rewritten by the next candidate
         }
     }
-    float* G = ft.g[l] + (((long)b * H + py) * W + px0) * ft.C + c;
+    if (px0 + px < W) {
+        float* G = ft.g[l] + (((long)b * H + py) * W + px0 + px) * C + cg * 4;
 #pragma unroll
-    for (int i = 0; i < kSeg; ++i)
-        if (px0 + i < W) G[(long)i * ft.C] = acc[i];
+        for (int j = 0; j < 8; ++j) *reinterpret_cast<float4*>(G + j * 32) = acc[j];
+    }
 }
 
 // FastRCNNOutputLayers.losses: CE(mean over R) + L1 on the gt-class deltas of fg rows / R
