@@ -31,28 +31,103 @@ __device__ __forceinline__ float iou_d2(const float4 g, const float4 a) {
 // ---------------------------------------------------------------------------------------
 // Matcher (detectron2 Matcher): per box max/argmax IoU over GT (first max wins), per-GT best
 // ---------------------------------------------------------------------------------------
-__global__ void match_iou_kernel(const float4* __restrict__ boxes, long box_stride_n, const int* __restrict__ box_count, int L,
-                                 const float4* __restrict__ gt, const int* __restrict__ gt_count, int Gmax,
-                                 float* __restrict__ best_iou, int* __restrict__ best_idx, unsigned* __restrict__ gt_best) {
+constexpr int kGtTile = 256;
+
+// The boxes of one workgroup are 256 neighbouring anchors (one strip of a feature row): only the GT boxes that meet the strip's
+// union box can overlap any of them.  Every thread tests one GT against the union, the hits are compacted IN GT ORDER into
+// LDS, and the per-box loop runs over that short list (with 100 pseudo-label boxes per image: ~7 instead of 100 iterations,
+// none of them a scalar-memory round trip).  Proposals are not spatially ordered: their union is the image, the list all GTs.
+struct UnionBox { float x0, y0, x1, y1; };
+__device__ __forceinline__ UnionBox block_union(const float4 b, bool active, float (*sbb)[4]) {
+    float x0 = active ? b.x : INFINITY, y0 = active ? b.y : INFINITY, x1 = active ? b.z : -INFINITY, y1 = active ? b.w : -INFINITY;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        x0 = fminf(x0, __shfl_xor(x0, o, 64)); y0 = fminf(y0, __shfl_xor(y0, o, 64));
+        x1 = fmaxf(x1, __shfl_xor(x1, o, 64)); y1 = fmaxf(y1, __shfl_xor(y1, o, 64));
+    }
+    const int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { sbb[w][0] = x0; sbb[w][1] = y0; sbb[w][2] = x1; sbb[w][3] = y1; }
+    __syncthreads();
+    UnionBox u{sbb[0][0], sbb[0][1], sbb[0][2], sbb[0][3]};
+    for (int k = 1; k < (int)(blockDim.x >> 6); ++k) {
+        u.x0 = fminf(u.x0, sbb[k][0]); u.y0 = fminf(u.y0, sbb[k][1]); u.x1 = fmaxf(u.x1, sbb[k][2]); u.y1 = fmaxf(u.y1, sbb[k][3]);
+    }
+    return u;
+}
+__device__ __forceinline__ bool meets(const float4 g, const UnionBox u) {
+    return fminf(g.z, u.x1) - fmaxf(g.x, u.x0) > 0.f && fminf(g.w, u.y1) - fmaxf(g.y, u.y0) > 0.f;
+}
+
+__global__ __launch_bounds__(1024) void match_iou_kernel(const float4* __restrict__ boxes, long box_stride_n, const int* __restrict__ box_count, int L,
+                                                        const float4* __restrict__ gt, const int* __restrict__ gt_count, int Gmax,
+                                                        float* __restrict__ best_iou, int* __restrict__ best_idx, unsigned* __restrict__ gt_best, int parts) {
+    __shared__ float4 sgt[kGtTile];
+    __shared__ int sidx[kGtTile];
+    __shared__ unsigned smax[kGtTile];
+    __shared__ float sbb[16][4];
+    __shared__ int sm[17];
+    __shared__ float pbest[4][64];
+    __shared__ int pidx[4][64];
+    // parts == 1: one box per thread.  parts == 4 (blockDim 256): 64 boxes, wave p walks the p-th quarter of the GT list -- the
+    // proposals' lists are all GTs, and one wave per 64 boxes walking 100 of them is a 50 us dependent chain on a near-empty chip
+    const int part = parts > 1 ? (int)(threadIdx.x >> 6) : 0;
+    const int per_wg = (int)blockDim.x / parts;
     const int n = blockIdx.y;
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int i = blockIdx.x * per_wg + (parts > 1 ? (int)(threadIdx.x & 63) : (int)threadIdx.x);
     const int cnt = box_count ? box_count[n] : L;
     const bool active = i < cnt;
     const int G = gt_count[n];
     const float4 b = active ? boxes[n * box_stride_n + i] : make_float4(0.f, 0.f, 0.f, 0.f);
-    float best = -1.f;
+    const UnionBox ub = block_union(b, active, sbb);
+    // (the first GT always takes the running maximum to >= 0 with index 0; later ones must be strictly greater)
+    float best = G > 0 ? 0.f : -1.f;
     int bi = 0;
     const int lane = threadIdx.x & 63;
-    for (int g = 0; g < G; ++g) {
-        float v = active ? iou_d2(gt[n * Gmax + g], b) : 0.f;
-        if (v > best) { best = v; bi = g; }
-        // per-GT best IoU: one atomic per wave that overlaps the GT at all (neighbouring anchors share a wave, most
-        // waves overlap no GT), not one per (anchor, GT) pair on a handful of addresses
-        if (__ballot(v > 0.f)) {
-            float wm = v;
+    const int tile = min((int)blockDim.x, kGtTile);
+    for (int g0 = 0; g0 < G; g0 += tile) {
+        const int gq = g0 + (int)threadIdx.x;
+        float4 gq_box = make_float4(0.f, 0.f, 0.f, 0.f);
+        bool hit = false;
+        if ((int)threadIdx.x < tile && gq < G) { gq_box = gt[n * Gmax + gq]; hit = meets(gq_box, ub); }
+        int nl;
+        const int rank = block_rank(hit, sm, &nl);          // (its barriers also fence the previous tile's readers)
+        if (hit) { sgt[rank] = gq_box; sidx[rank] = gq; smax[rank] = 0u; }
+        __syncthreads();
+        const int per = (nl + parts - 1) / parts;
+        for (int k = part * per; k < min(nl, (part + 1) * per); ++k) {
+            const float4 gb = sgt[k];
+            const bool ov = active && fminf(gb.z, b.z) - fmaxf(gb.x, b.x) > 0.f && fminf(gb.w, b.w) - fmaxf(gb.y, b.y) > 0.f;
+            if (!__ballot(ov)) continue;
+            const int g = sidx[k];
+            float v = ov ? iou_d2(gb, b) : 0.f;
+            if (v > best) { best = v; bi = g; }
+            // per-GT best IoU: wave maximum -> workgroup maximum in LDS -> ONE global atomic per (workgroup, GT it overlaps).  The
+            // few hundred gt_best words are all the atomics of the launch go to: one per wave was 2/3 of the kernel's time.
+            if (__ballot(v > 0.f)) {
+                float wm = v;
 #pragma unroll
-            for (int o = 32; o > 0; o >>= 1) wm = fmaxf(wm, __shfl_xor(wm, o, 64));
-            if (lane == 0) atomicMax(gt_best + n * Gmax + g, __float_as_uint(wm));
+                for (int o = 32; o > 0; o >>= 1) wm = fmaxf(wm, __shfl_xor(wm, o, 64));
+                if (lane == 0) atomicMax(&smax[k], __float_as_uint(wm));
+            }
+        }
+        __syncthreads();
+        if ((int)threadIdx.x < nl && smax[threadIdx.x] != 0u) {
+            // same-address device-scope atomics from all 8 XCDs serialise at the memory side (~1 us each, ~70 workgroups per GT):
+            // read first and only raise the maximum -- a stale read is lower than the truth, so skipping is always safe
+            unsigned* dst = gt_best + n * Gmax + sidx[threadIdx.x];
+            if (__hip_atomic_load(dst, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < smax[threadIdx.x]) atomicMax(dst, smax[threadIdx.x]);
+        }
+    }
+    if (parts > 1) {
+        // the quarters in GT order: a later one wins only if strictly greater (first maximum, as in one pass); part 0 starts
+        // from the (0, index 0) the first GT always establishes, the others from "nothing seen"
+        pbest[part][threadIdx.x & 63] = part == 0 || best > 0.f ? best : -2.f;
+        pidx[part][threadIdx.x & 63] = bi;
+        __syncthreads();
+        if (part != 0) return;
+        for (int p = 1; p < parts; ++p) {
+            const float v = pbest[p][threadIdx.x];
+            if (v > best) { best = v; bi = pidx[p][threadIdx.x]; }
         }
     }
     if (active) {
@@ -61,82 +136,139 @@ __global__ void match_iou_kernel(const float4* __restrict__ boxes, long box_stri
     }
 }
 
-__global__ void match_label_kernel(const float4* __restrict__ boxes, long box_stride_n, const int* __restrict__ box_count, int L,
-                                   const float4* __restrict__ gt, const int* __restrict__ gt_count, int Gmax,
-                                   const float* __restrict__ best_iou, const unsigned* __restrict__ gt_best,
-                                   float lo, float hi, int allow_low_quality, int* __restrict__ labels) {
+__global__ __launch_bounds__(256) void match_label_kernel(const float4* __restrict__ boxes, long box_stride_n, const int* __restrict__ box_count, int L,
+                                                          const float4* __restrict__ gt, const int* __restrict__ gt_count, int Gmax,
+                                                          const float* __restrict__ best_iou, const unsigned* __restrict__ gt_best,
+                                                          float lo, float hi, int allow_low_quality, int* __restrict__ labels) {
+    __shared__ float4 sgt[kGtTile];
+    __shared__ unsigned sbest[kGtTile];
+    __shared__ float sbb[4][4];
+    __shared__ int sm[17];
+    __shared__ int s_zero;
     const int n = blockIdx.y;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const int cnt = box_count ? box_count[n] : L;
-    if (i >= L) return;
-    if (i >= cnt) { labels[(long)n * L + i] = -2; return; }     // padding slot, never sampled
     const int G = gt_count[n];
-    int lab;
-    if (G == 0) lab = 0;
-    else {
-        float v = best_iou[(long)n * L + i];
-        lab = v < lo ? 0 : (v < hi ? -1 : 1);
-        if (allow_low_quality) {
-            const float4 b = boxes[n * box_stride_n + i];
-            for (int g = 0; g < G; ++g) {
-                float u = iou_d2(gt[n * Gmax + g], b);
-                if (__float_as_uint(u) == gt_best[n * Gmax + g]) { lab = 1; break; }
-            }
+    const bool active = i < cnt;
+    int lab = -2;                                               // padding slot, never sampled
+    if (active) {
+        if (G == 0) lab = 0;
+        else {
+            const float v = best_iou[(long)n * L + i];
+            lab = v < lo ? 0 : (v < hi ? -1 : 1);
         }
     }
-    labels[(long)n * L + i] = lab;
+    if (allow_low_quality && G > 0) {                           // (block uniform)
+        // low-quality rule: IoU == the GT's best over all boxes.  A GT nothing overlaps has best 0 and claims EVERY box (the
+        // reference's `match_quality_matrix == highest_quality_foreach_gt`); the others can only claim boxes they overlap.
+        const float4 b = active ? boxes[n * box_stride_n + i] : make_float4(0.f, 0.f, 0.f, 0.f);
+        const UnionBox ub = block_union(b, active, sbb);
+        if (threadIdx.x == 0) s_zero = 0;
+        __syncthreads();
+        bool done = false;
+        for (int g0 = 0; g0 < G; g0 += kGtTile) {
+            const int gq = g0 + (int)threadIdx.x;
+            float4 gq_box = make_float4(0.f, 0.f, 0.f, 0.f);
+            unsigned top = 1u;
+            bool hit = false;
+            if (gq < G) {
+                gq_box = gt[n * Gmax + gq];
+                top = gt_best[n * Gmax + gq];
+                hit = top != 0u && meets(gq_box, ub);
+                if (top == 0u) s_zero = 1;
+            }
+            int nl;
+            const int rank = block_rank(hit, sm, &nl);
+            if (hit) { sgt[rank] = gq_box; sbest[rank] = top; }
+            __syncthreads();
+            if (active && !done)
+                for (int k = 0; k < nl; ++k) {
+                    const float4 gb = sgt[k];
+                    if (fminf(gb.z, b.z) - fmaxf(gb.x, b.x) > 0.f && fminf(gb.w, b.w) - fmaxf(gb.y, b.y) > 0.f &&
+                        __float_as_uint(iou_d2(gb, b)) == sbest[k]) { lab = 1; done = true; break; }
+                }
+        }
+        if (active && s_zero) lab = 1;
+    }
+    if (i < L) labels[(long)n * L + i] = lab;
 }
 
 // ---------------------------------------------------------------------------------------
 // ordered lists for subsample_labels: pos = (v != -1 && v != bg && v != -2), neg = (v == bg)
-// grid (2, N): blockIdx.x = kind
 // ---------------------------------------------------------------------------------------
-// one workgroup per (kind, image).  Per pass a WAVE owns 1024 consecutive labels as 16 coalesced rows of 64: a ballot per
-// row gives the in-row rank, the 16 popcounts the wave total; one block scan of the 16 wave totals per pass (16K labels),
-// then lanes with the flag set write consecutive output slots (coalesced) straight to global memory.
-__global__ __launch_bounds__(1024) void compact_kernel(const int* __restrict__ labels, int L, int bg,
-                                                       int* __restrict__ lists /*[N][2][L]*/, int* __restrict__ counts /*[N][2]*/) {
-    constexpr int ROWS = 16;
-    __shared__ int wsum[16];
-    const int kind = blockIdx.x, n = blockIdx.y;
+// A WAVE owns 1024 consecutive labels as 16 coalesced rows of 64: a ballot per row gives the in-row rank, the 16 popcounts
+// the wave total; lanes with the flag set write consecutive output slots (coalesced) straight to global memory.
+// Two launches over (segment of 4096 labels, image) instead of one workgroup walking an image's 268 k labels in 16 serial
+// passes (114 us on the critical path of the step, 8 workgroups on the chip): count both kinds per segment, then every
+// segment adds up the counts before it and writes its part of both lists.
+constexpr int kSegLabels = 4096, kSegRows = 16;        // 4 waves x 16 rows of 64
+__device__ __forceinline__ void label_flags(int v, int bg, bool& pos, bool& neg) {
+    pos = v != -1 && v != -2 && v != bg;
+    neg = v == bg;
+}
+__global__ __launch_bounds__(256) void compact_count_kernel(const int* __restrict__ labels, int L, int bg, int segs, int* __restrict__ segcnt /*[N][2][segs]*/) {
+    __shared__ int wsum[2][4];
+    const int seg = blockIdx.x, n = blockIdx.y;
     const int* lab = labels + (long)n * L;
-    int* out = lists + ((long)n * 2 + kind) * L;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int i0 = seg * kSegLabels + w * (64 * kSegRows) + lane;
+    int cp = 0, cn = 0;
+#pragma unroll
+    for (int k = 0; k < kSegRows; ++k) {
+        const int i = i0 + k * 64;
+        bool fp = false, fn = false;
+        if (i < L) label_flags(lab[i], bg, fp, fn);
+        cp += __popcll(__ballot(fp));
+        cn += __popcll(__ballot(fn));
+    }
+    if (lane == 0) { wsum[0][w] = cp; wsum[1][w] = cn; }
+    __syncthreads();
+    if (tid < 2) segcnt[((long)n * 2 + tid) * segs + seg] = wsum[tid][0] + wsum[tid][1] + wsum[tid][2] + wsum[tid][3];
+}
+__global__ __launch_bounds__(256) void compact_write_kernel(const int* __restrict__ labels, int L, int bg, int segs, const int* __restrict__ segcnt,
+                                                            int* __restrict__ lists /*[N][2][L]*/, int* __restrict__ counts /*[N][2]*/) {
+    __shared__ int wsum[2][4];
+    __shared__ int sbase[2];
+    const int seg = blockIdx.x, n = blockIdx.y;
+    const int* lab = labels + (long)n * L;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const unsigned long long lt = (1ull << lane) - 1ull;
-    int base = 0;
-    for (int s = 0; s < L; s += 1024 * ROWS) {
-        const int i0 = s + w * (64 * ROWS) + lane;
-        unsigned long long m[ROWS];
-        int wtot = 0;
+    // list offsets of this segment: the counts of the segments before it (waves 0 / 1: kind 0 / 1)
+    if (w < 2) {
+        int a = 0;
+        for (int s_ = lane; s_ < seg; s_ += 64) a += segcnt[((long)n * 2 + w) * segs + s_];
 #pragma unroll
-        for (int k = 0; k < ROWS; ++k) {
-            const int i = i0 + k * 64;
-            bool f = false;
-            if (i < L) {
-                const int v = lab[i];
-                f = kind == 0 ? (v != -1 && v != -2 && v != bg) : (v == bg);
-            }
-            m[k] = __ballot(f);
-            wtot += __popcll(m[k]);
-        }
-        __syncthreads();                      // previous pass's wsum reads are done
-        if (lane == 0) wsum[w] = wtot;
-        __syncthreads();
-        int pos = base, tot = 0;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int c = wsum[i];
-            if (i < w) pos += c;
-            tot += c;
-        }
-#pragma unroll
-        for (int k = 0; k < ROWS; ++k) {
-            if ((m[k] >> lane) & 1ull) out[pos + __popcll(m[k] & lt)] = i0 + k * 64;
-            pos += __popcll(m[k]);
-        }
-        base += tot;
+        for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o, 64);
+        if (lane == 0) sbase[w] = a;
     }
-    if (tid == 0) counts[n * 2 + kind] = base;
+    const int i0 = seg * kSegLabels + w * (64 * kSegRows) + lane;
+    unsigned long long mp[kSegRows], mn[kSegRows];
+    int cp = 0, cn = 0;
+#pragma unroll
+    for (int k = 0; k < kSegRows; ++k) {
+        const int i = i0 + k * 64;
+        bool fp = false, fn = false;
+        if (i < L) label_flags(lab[i], bg, fp, fn);
+        mp[k] = __ballot(fp); mn[k] = __ballot(fn);
+        cp += __popcll(mp[k]); cn += __popcll(mn[k]);
+    }
+    if (lane == 0) { wsum[0][w] = cp; wsum[1][w] = cn; }
+    __syncthreads();
+    int pp = sbase[0], pn = sbase[1], tp = 0, tn = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        if (i < w) { pp += wsum[0][i]; pn += wsum[1][i]; }
+        tp += wsum[0][i]; tn += wsum[1][i];
+    }
+    int* outp = lists + ((long)n * 2 + 0) * L;
+    int* outn = lists + ((long)n * 2 + 1) * L;
+#pragma unroll
+    for (int k = 0; k < kSegRows; ++k) {
+        if ((mp[k] >> lane) & 1ull) outp[pp + __popcll(mp[k] & lt)] = i0 + k * 64;
+        if ((mn[k] >> lane) & 1ull) outn[pn + __popcll(mn[k] & lt)] = i0 + k * 64;
+        pp += __popcll(mp[k]); pn += __popcll(mn[k]);
+    }
+    if (seg == segs - 1 && tid == 0) { counts[n * 2 + 0] = sbase[0] + tp; counts[n * 2 + 1] = sbase[1] + tn; }
 }
 
 // labels.fill_(-1); labels[pos_list[sel_pos]] = 1; labels[neg_list[sel_neg]] = 0
@@ -555,8 +687,12 @@ extern "C" int aldi_box_match(const float* boxes, long box_stride_n, const int* 
     hipError_t e = hipMemsetAsync(gt_best_scratch, 0, sizeof(unsigned) * (size_t)N * Gmax, st);
     if (e != hipSuccess) return aldi_set_error(e, __FILE__, __LINE__);
     dim3 grid(cdiv(L, 256), N);
-    hipLaunchKernelGGL(match_iou_kernel, grid, dim3(256), 0, st, (const float4*)boxes, box_stride_n, box_count, L, (const float4*)gt_boxes, gt_count, Gmax,
-                       best_iou, best_idx, gt_best_scratch);
+    // anchors (spatially ordered, ~268 k per image): big workgroups = few global atomics per GT; proposals (a few thousand,
+    // unordered: every GT is on every workgroup's list): one wave per workgroup so that they spread over the chip
+    const bool big = (long)L * N >= (1 << 16);
+    const int parts = !big && Gmax <= kGtTile ? 4 : 1;       // (the split keeps GT order only within one list tile)
+    hipLaunchKernelGGL(match_iou_kernel, dim3(cdiv(L, big ? 1024 : 64), N), dim3(big ? 1024 : 64 * parts), 0, st, (const float4*)boxes, box_stride_n, box_count, L,
+                       (const float4*)gt_boxes, gt_count, Gmax, best_iou, best_idx, gt_best_scratch, parts);
     ALDI_CHECK_LAUNCH();
     hipLaunchKernelGGL(match_label_kernel, grid, dim3(256), 0, st, (const float4*)boxes, box_stride_n, box_count, L, (const float4*)gt_boxes, gt_count, Gmax,
                        best_iou, gt_best_scratch, lo, hi, allow_low_quality, labels);
@@ -564,9 +700,15 @@ extern "C" int aldi_box_match(const float* boxes, long box_stride_n, const int* 
     return ALDI_OK;
 }
 
-extern "C" int aldi_compact_labels(const int* labels, int L, int N, int bg_label, int* lists, int* counts, aldi_stream_t stream) {
-    if (!labels || !lists || !counts) return aldi_set_error_msg(ALDI_ERR_ARG, "compact_labels: null pointer");
-    hipLaunchKernelGGL(compact_kernel, dim3(2, N), dim3(1024), 0, static_cast<hipStream_t>(stream), labels, L, bg_label, lists, counts);
+extern "C" size_t aldi_compact_labels_workspace(int L, int N) { return (size_t)N * 2 * (size_t)cdiv(L > 0 ? L : 1, kSegLabels) * sizeof(int); }
+
+extern "C" int aldi_compact_labels(const int* labels, int L, int N, int bg_label, int* lists, int* counts, void* workspace, aldi_stream_t stream) {
+    if (!labels || !lists || !counts || !workspace || L <= 0 || N <= 0) return aldi_set_error_msg(ALDI_ERR_ARG, "compact_labels: null pointer / empty shape");
+    const int segs = cdiv(L, kSegLabels);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(compact_count_kernel, dim3(segs, N), dim3(256), 0, st, labels, L, bg_label, segs, (int*)workspace);
+    ALDI_CHECK_LAUNCH();
+    hipLaunchKernelGGL(compact_write_kernel, dim3(segs, N), dim3(256), 0, st, labels, L, bg_label, segs, (const int*)workspace, lists, counts);
     ALDI_CHECK_LAUNCH();
     return ALDI_OK;
 }

@@ -314,7 +314,8 @@ def box_match(boxes, box_stride_n, box_count, Lb, gt_boxes, gt_count, Gmax, N, l
 
 
 def compact_labels(labels, Lb, N, bg, lists, counts):
-    L.call("aldi_compact_labels", _p(labels), Lb, N, bg, _p(lists), _p(counts), stream_ptr())
+    ws = torch.empty(max(int(L.lib.aldi_compact_labels_workspace(Lb, N)), 16), dtype=torch.uint8, device=labels.device)
+    L.call("aldi_compact_labels", _p(labels), Lb, N, bg, _p(lists), _p(counts), _p(ws), stream_ptr())
 
 
 def rpn_apply_sample(labels, Lb, N, lists, sel, nsel, S):

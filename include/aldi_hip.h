@@ -203,8 +203,9 @@ int aldi_box_match(const float* boxes, long box_stride_n, const int* box_count, 
                    float lo, float hi, int allow_low_quality,
                    float* best_iou, int* best_idx, unsigned* gt_best_scratch, int* labels, aldi_stream_t stream);
 /* subsample_labels, step 1: ordered index lists. lists [N][2][L] (0: positives = not -1/-2/bg,
- * 1: negatives = bg), counts [N][2]. */
-int aldi_compact_labels(const int* labels, int L, int N, int bg_label, int* lists, int* counts, aldi_stream_t stream);
+ * 1: negatives = bg), counts [N][2].  workspace: aldi_compact_labels_workspace(L, N) bytes (per-segment counts). */
+size_t aldi_compact_labels_workspace(int L, int N);
+int aldi_compact_labels(const int* labels, int L, int N, int bg_label, int* lists, int* counts, void* workspace, aldi_stream_t stream);
 /* subsample_labels, step 2 (RPN): labels.fill(-1); labels[lists[0][sel[0]]] = 1; labels[lists[1][sel[1]]] = 0.
  * sel [N][2][S] are positions drawn by the host RNG (torch.randperm order), nsel [N][2]. */
 int aldi_rpn_apply_sample(int* labels, int L, int N, const int* lists, const int* sel, const int* nsel, int S, aldi_stream_t stream);

@@ -120,6 +120,25 @@ def phases(d):
         print("%8.2f ms  %s" % (v, k))
 
 
+def launches(d, pattern, delim="sgd_kernel"):
+    """every launch of the kernels matching `pattern` (regex) in the last step: start offset from the previous optimizer step's end, duration"""
+    import re
+    dbs = glob.glob(d + "/**/*_results.db", recursive=True)
+    cur = sqlite3.connect(dbs[0]).cursor()
+    tabs = [r[0] for r in cur.execute("select name from sqlite_master where type in ('table','view')")]
+    kt = "kernels" if "kernels" in tabs else [t for t in tabs if "kernel_dispatch" in t][0]
+    cols = [r[1] for r in cur.execute(f"pragma table_info({kt})")]
+    name = "name" if "name" in cols else "kernel_name"
+    rows = list(cur.execute(f"select {name}, start, end from {kt} order by start"))
+    sgd = [i for i, r in enumerate(rows) if delim in r[0]]
+    a, b = sgd[-2], sgd[-1]
+    t0 = rows[a][2]
+    rx = re.compile(pattern)
+    for n, s_, e in rows[a + 1:b + 1]:
+        if rx.search(n):
+            print("%8.3f ms  %8.1f us  %s" % ((s_ - t0) / 1e6, (e - s_) / 1e3, n[:110]))
+
+
 def window(d, first="compact_kernel", last="wgrad_"):
     """kernel sequence between the last `first` kernel and the first `last` kernel of a step (the latency-bound middle)"""
     dbs = glob.glob(d + "/**/*_results.db", recursive=True)
@@ -162,4 +181,4 @@ def pmc(fetch_dir, write_dir, source_sha="", git_sha=""):
 
 
 if __name__ == "__main__":
-    {"stats": stats, "pmc": pmc, "gaps": gaps, "overlap": overlap, "phases": phases, "window": window}[sys.argv[1]](*sys.argv[2:])
+    {"stats": stats, "pmc": pmc, "gaps": gaps, "overlap": overlap, "phases": phases, "window": window, "launches": launches}[sys.argv[1]](*sys.argv[2:])
