@@ -31,6 +31,7 @@ const Knob kKnobs[] = {
     {"igemm_lintile_min", &AldiTuning::igemm_lintile_min, 768},
     {"igemm_halo", &AldiTuning::igemm_halo, 1},
     {"igemm_force", &AldiTuning::igemm_force, 0},
+    {"igemm_k64_min", &AldiTuning::igemm_k64_min, 1024},
     {"igemm_group", &AldiTuning::igemm_group, 1},
     {"wgrad_lean", &AldiTuning::wgrad_lean, 1},
     {"wgrad_big_min", &AldiTuning::wgrad_big_min, 28},

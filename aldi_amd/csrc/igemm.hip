@@ -316,7 +316,7 @@ __device__ __forceinline__ void igemm_body(const ConvDev& p, int bid, const int 
     //   issue the DMA of slab s+3 into the buffer slab s just vacated -> 16 MFMAs on slab s from registers -> lgkmcnt wait.
     // So the LDS read latency and the DMA both run under the MFMAs of the same wave, not only under other waves'.
     // __syncthreads() would drain the DMA queue (vmcnt(0)) at every slab (cdna_hip_programming.md section 5).
-    static_assert(KC == 4, "the register-pipelined loop reads one k-step (4 chunks) per slab");
+    static_assert(KC == 4 || !PIPE, "the register-pipelined loop reads one k-step (4 chunks) per slab");
     constexpr int N_DMA = A_IT + (BN * KC) / NT;   // DMA instructions per slab of the wave that issues the fewest
     const int S = (p.dbg & 8) ? 1 : (p.K + BK - 1) / BK;
     issue_slab(0, 0);
@@ -370,14 +370,19 @@ __device__ __forceinline__ void igemm_body(const ConvDev& p, int bid, const int 
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
         if (s + 2 < S) issue_slab(s + 2, nbuf);
-        u32x4_t xf[TM], wf[TN];
-        frag_read_all<TM, KC * 16>(xf, x_rd0 + (unsigned)buf * SLAB_BYTES);
-        frag_read_all<TN, KC * 16>(wf, w_rd0 + (unsigned)buf * SLAB_BYTES);
-        frag_wait<TM, TN>(xf, wf);
 #pragma unroll
-        for (int i = 0; i < TM; ++i)
+        for (int h = 0; h < KC / 4; ++h) {            // KC == 8: two MFMA k-steps per 128-byte slab row
+            u32x4_t xf[TM], wf[TN];
+            const unsigned xa = h == 0 ? x_rd0 : lds_addr(&lds[0][0]) + (unsigned)(xrow * KC + swz<KC>(xrow, fq + 4)) * 16u;
+            const unsigned wa = h == 0 ? w_rd0 : lds_addr(&lds[0][0]) + (unsigned)((BM + wrow) * KC + swz<KC>(wrow, fq + 4)) * 16u;
+            frag_read_all<TM, KC * 16>(xf, xa + (unsigned)buf * SLAB_BYTES);
+            frag_read_all<TN, KC * 16>(wf, wa + (unsigned)buf * SLAB_BYTES);
+            frag_wait<TM, TN>(xf, wf);
 #pragma unroll
-            for (int j = 0; j < TN; ++j) acc[i][j] = Mma<T>::run(wf[j], xf[i], acc[i][j]);
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[i][j] = Mma<T>::run(wf[j], xf[i], acc[i][j]);
+        }
         buf = buf == NBUF - 1 ? 0 : buf + 1;
         nbuf = nbuf == NBUF - 1 ? 0 : nbuf + 1;
     }
@@ -611,7 +616,8 @@ int launch(const ConvDev& d, hipStream_t st) {
         hipLaunchKernelGGL((igemm_group_kernel<T, BM, BN, WM, WN, KC, PIPE, HALO>), dim3(wg), dim3(WM * WN * 64), 0, st, G);
         ALDI_CHECK_LAUNCH();
         char name[112];
-        snprintf(name, sizeof(name), "igemm_group%d<%s,%d,%d,%d,%d,%s,%s>", G.n, sizeof(T) == 2 ? "bf16" : "f32", BM, BN, WM, WN, PIPE ? "pipe" : "flat", HALO ? "halo" : "tap");
+        snprintf(name, sizeof(name), "igemm_group%d<%s,%d,%d,%d,%d,%s,%s%s>", G.n, sizeof(T) == 2 ? "bf16" : "f32", BM, BN, WM, WN, PIPE ? "pipe" : "flat", HALO ? "halo" : "tap",
+                 KC == 8 ? ",k64" : "");
         aldi_note_dispatch(name);
         return ALDI_OK;
     }
@@ -619,7 +625,8 @@ int launch(const ConvDev& d, hipStream_t st) {
     hipLaunchKernelGGL((igemm_kernel<T, BM, BN, WM, WN, KC, PIPE, HALO>), grid, dim3(WM * WN * 64), 0, st, d);
     ALDI_CHECK_LAUNCH();
     char name[96];
-    snprintf(name, sizeof(name), "igemm<%s,%d,%d,%d,%d,%s,%s>", sizeof(T) == 2 ? "bf16" : "f32", BM, BN, WM, WN, PIPE ? "pipe" : "flat", HALO ? "halo" : "tap");
+    snprintf(name, sizeof(name), "igemm<%s,%d,%d,%d,%d,%s,%s%s>", sizeof(T) == 2 ? "bf16" : "f32", BM, BN, WM, WN, PIPE ? "pipe" : "flat", HALO ? "halo" : "tap",
+             KC == 8 ? ",k64" : "");
     aldi_note_dispatch(name);
     return ALDI_OK;
 }
@@ -662,6 +669,17 @@ int dispatch(ConvDev& d, hipStream_t st) {
     if (force == 2) return launch<T, 128, 64, 4, 1, 4>(d, st);
     if (force == 3) return launch<T, 64, 64, 2, 2, 4>(d, st);
     if (force == 4) return launch<T, 256, 128, 4, 2, 4, false>(d, st);
+    if constexpr (sizeof(T) == 2) {
+        // 128-byte K slabs (64 channels: a full cache line per pixel row and k-step, half the barriers): plain 1x1 / linear
+        // layers only (a ragged K tail is handled for those).  igemm_k64_min: long-K layers (res4/res5 reductions, their dgrads,
+        // the box head's FCs) run 10-18 % faster on the 64x64 form than on any 32-channel tile (tools/igemm_sweep.py);
+        // short-K layers (4 slabs) lose more to the shallower pipeline than they gain.
+        const bool plain = d.KH * d.KW == 1 && d.stride == 1 && d.pad == 0;
+        if (plain && force == 6) return launch<T, 128, 128, 2, 2, 8, false>(d, st);
+        if (plain && force == 7) return launch<T, 128, 64, 4, 1, 8, false>(d, st);
+        const bool lin256 = tn.igemm_tile != 9 && big >= tn.igemm_lintile_min && d.K >= tn.igemm_bigtile_k;     // (the token-GEMM rule below wins)
+        if (plain && (force == 8 || (force == 0 && !lin256 && d.Cout > 64 && d.K % 64 == 0 && d.K >= tn.igemm_k64_min))) return launch<T, 64, 64, 2, 2, 8, false>(d, st);
+    }
     if (d.Cout <= 64) return launch<T, 128, 64, 4, 1, 4>(d, st);
     if (tn.igemm_tile != 9 && big >= tn.igemm_lintile_min && d.K >= tn.igemm_bigtile_k) return launch<T, 256, 128, 4, 2, 4, false>(d, st);
     if (big < 200) return launch<T, 64, 64, 2, 2, 4>(d, st);

@@ -513,6 +513,13 @@ class FusedStep:
         # (the ViTDet / ConvNeXt trunks draw their stochastic-depth masks on the host every step: their launches are not replayable as recorded)
         use_graph = self.graph_enabled and self.steps_done >= self.warmup and type(eng) is RCNN
         # ---- phase A
+        # device-side phase times of the PREVIOUS step (its events have completed by now: no extra synchronisation)
+        evs = getattr(self, "_phase_events", None)
+        if evs is not None and evs[3].query():
+            for k_, (x, y) in (("gpu_ms_phase_a", (0, 1)), ("gpu_ms_host_gap", (1, 2)), ("gpu_ms_phase_b", (2, 3))):
+                self.stats[k_] = round(evs[x].elapsed_time(evs[y]), 3)
+        evs = self._phase_events = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+        evs[0].record()
         t0 = time.perf_counter()
         if use_graph:
             if S.graph_a is None:
@@ -523,6 +530,7 @@ class FusedStep:
         else:
             A = self._phase_a(S)
         c, tc = A.c, A.tc
+        evs[1].record()
         self._prefetch_draws(S, int(c.anchors.shape[0]))
         t1 = time.perf_counter()
         torch.cuda.current_stream().synchronize()                  # the ONE device->host sync: list lengths for the host RNG
@@ -534,6 +542,7 @@ class FusedStep:
         self.stats["rng_stream_hits"] = int(L_.lib.aldi_torch_rng_prefetch_hits())
         # ---- phase B
         graph_b = use_graph and getattr(eng, "grad_ready", None) is None and os.environ.get("ALDI_STEP_GRAPH_B", "1") == "1"
+        evs[2].record()
         if graph_b:
             ent = S.graphs_b.get(Hst.key)
             if ent is None:
@@ -554,6 +563,7 @@ class FusedStep:
             B = self._phase_b(S, A, Hst)
             if not use_graph:
                 self.stats["eager"] += 1
+        evs[3].record()
         t4 = time.perf_counter()
         for k_, v_ in (("host_us_issue_a", t1 - t0), ("host_us_wait_a", t2 - t1), ("host_us_draws", t3 - t2), ("host_us_issue_b", t4 - t3)):
             self.stats[k_] = round(0.8 * self.stats.get(k_, (v_ * 1e6)) + 0.2 * v_ * 1e6, 1)       # running mean, microseconds

@@ -32,7 +32,9 @@ int aldi_version(void);
 
 /* Tuning knobs of the kernel dispatchers (test / experiment surface; the defaults are what the benchmark runs).
  * Each knob can also be preset from the environment as ALDI_<UPPER-CASE NAME>, read once at first use.
- *   igemm_force          0 heuristics | 1 128x128 | 2 128x64 | 3 64x64 | 4 256x128 | 5 128x16 tile of aldi_conv_igemm
+ *   igemm_force          0 heuristics | 1 128x128 | 2 128x64 | 3 64x64 | 4 256x128 | 5 128x16 tile of aldi_conv_igemm |
+ *                        6 / 7 / 8: the 128x128 / 128x64 / 64x64 tile with 128-byte K slabs (plain 1x1 / linear layers)
+ *   igemm_k64_min        plain 1x1 / linear layers with K >= this (and K % 64 == 0) take the 64x64 128-byte-slab form (1024)
  *   igemm_group          1 = aldi_conv_igemm_group shares one launch (0: always n single launches)
  *   igemm_halo           1 = 3x3/stride-1/pad-1 bf16 convs use the halo form (one pixel slab per three taps)
  *   igemm_bigtile_min    128x128-tile count from which a 3x3 conv takes the 256x128 halo tile (1024)

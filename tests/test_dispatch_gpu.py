@@ -146,7 +146,7 @@ FULL_FWD = [
     ((4, 200, 336, 256, 512, 1, 2, 0), "igemm<bf16,128,128,2,2,pipe,tap>"),       # res3 shortcut (stride 2)
     ((4, 200, 336, 256, 16, 1, 1, 0), "igemm<bf16,128,16,4,1,pipe,tap>"),         # RPN objectness + deltas
     ((1, 120, 140, 3072, 768, 1, 1, 0), "igemm<bf16,256,128,4,2,flat,tap>"),      # 16800 x 3072 -> 768 (ViT MLP fc2)
-    ((2048, 1, 1, 12544, 1024, 1, 1, 0), "igemm<bf16,64,64,2,2,pipe,tap>"),       # box head FC1
+    ((2048, 1, 1, 12544, 1024, 1, 1, 0), "igemm<bf16,64,64,2,2,flat,tap,k64>"),   # box head FC1 (long K: 128-byte slabs)
     ((4, 25, 42, 512, 2048, 1, 1, 0), "igemm<bf16,128,128,2,2,pipe,tap>"),        # res5 conv3
     ((2, 25, 42, 512, 512, 3, 1, 1), "igemm<bf16,128,64,4,1,flat,halo>"),         # res5 conv2, teacher
 ]
@@ -195,6 +195,25 @@ def test_forward_forced_templates_bf16(case, force):
     _check_forward(case, torch.bfloat16, expect, force=force, full=False)
 
 
+K64 = [(2, 24, 40, 256, 72, 1, 1, 0), (5, 1, 1, 1032, 48, 1, 1, 0), (3, 7, 9, 64, 200, 1, 1, 0), (130, 1, 1, 2048, 136, 1, 1, 0)]
+
+
+@pytest.mark.parametrize("force", [6, 7, 8])
+@pytest.mark.parametrize("case", K64)
+def test_forward_forced_k64_templates_bf16(case, force):
+    """the 128-byte K-slab forms (64 bf16 channels per LDS row, two MFMA k-steps per slab) of the plain 1x1 / linear layers:
+    ragged M and Cout, a ragged K tail (1032 = 16 * 64 + 8), a single slab (K = 64)"""
+    expect = "igemm<bf16,%s,flat,tap,k64>" % NAMES[force - 5]
+    _check_forward(case, torch.bfloat16, expect, force=force, full=False)
+
+
+def test_long_k_linear_takes_k64_by_default():
+    from aldi_amd import _lib as L
+    L.reset_tuning()
+    assert _check_forward((130, 1, 1, 2048, 136, 1, 1, 0), torch.bfloat16, "igemm<bf16,64,64,2,2,flat,tap,k64>", full=False)
+    assert _check_forward((130, 1, 1, 512, 136, 1, 1, 0), torch.bfloat16, "igemm<bf16,64,64,2,2,pipe,tap>", full=False)
+
+
 @pytest.mark.parametrize("force", [1, 2, 3, 4, 5])
 @pytest.mark.parametrize("case", SMALL[:2] + SMALL[3:7])
 def test_forward_forced_templates_fp32(case, force):
@@ -221,7 +240,7 @@ def test_halo_off_equals_halo_on():
 @pytest.mark.parametrize("case,expect", [
     ((4, 200, 336, 256, 256, 3, 1, 1), "igemm<bf16,256,128,4,2,flat,halo>"),      # RPN conv / FPN output dgrad on p2
     ((4, 50, 84, 256, 256, 3, 1, 1), "igemm<bf16,128,64,4,1,flat,halo>"),         # res4 conv2 dgrad with ReLU mask
-    ((4, 50, 84, 1024, 256, 1, 1, 0), "igemm<bf16,128,128,2,2,pipe,tap>"),        # res4 conv3 dgrad (g: 1024 -> 256)
+    ((4, 50, 84, 1024, 256, 1, 1, 0), "igemm<bf16,64,64,2,2,flat,tap,k64>"),      # res4 conv3 dgrad (g: 1024 -> 256)
 ])
 def test_dgrad_fullsize_default_dispatch(case, expect):
     """dgrad = conv of g with the rotated / transposed weights + ReLU-backward mask (+ residual), at benchmark scale"""
@@ -445,7 +464,7 @@ GROUP_CASES = [
     ((50, 84, 256, 256, 3, 1, 1), (4, 2), "igemm_group2<bf16,128,64,4,1,flat,halo>"),
     ((200, 336, 256, 256, 3, 1, 1), (4, 2), "igemm_group2<bf16,256,128,4,2,flat,halo>"),
     ((100, 168, 256, 256, 3, 1, 1), (4, 2), "igemm_group2<bf16,256,128,4,2,flat,halo>"),       # 1575 tiles together
-    ((50, 84, 1024, 256, 1, 1, 0), (4, 2), "igemm_group2<bf16,128,128,2,2,pipe,tap>"),
+    ((50, 84, 1024, 256, 1, 1, 0), (4, 2), "igemm_group2<bf16,64,64,2,2,flat,tap,k64>"),
     ((25, 42, 1024, 2048, 1, 2, 0), (4, 2), "igemm_group2<bf16,128,128,2,2,pipe,tap>"),         # strided shortcut
     ((13, 21, 256, 16, 1, 1, 0), (4, 2), "igemm_group2<bf16,128,16,4,1,pipe,tap>"),             # RPN heads on p6: ragged, tiny
     ((19, 23, 64, 96, 3, 1, 1), (3, 1, 2), "igemm_group3<bf16,128,64,4,1,flat,halo>"),

@@ -19,7 +19,7 @@ for (N, H, W, Cin, Cout, k, res, relu, mask) in SHAPES:
     sc = torch.rand(Cout, device="cuda") + 0.5
     row = []
     nby = 2 * (x.numel() + w.numel() + y.numel() + (r.numel() if res else 0) + (m.numel() if mask else 0))
-    for force in (0, 1, 2, 3, 4):
+    for force in [int(v) for v in os.environ.get("SWEEP_FORCE", "0,1,2,3,4").split(",")]:
         L.reset_tuning(); L.set_tuning("igemm_force", force)
         run = lambda: ops.conv2d(x, w, pad=k // 2, out=y, relu=bool(relu), res=r, res_mode=res, mask=m, scale=sc, shift=sc)
         run(); which = L.last_dispatch()
