@@ -311,7 +311,7 @@ template <> struct Raw8<float> {
     __device__ __forceinline__ void unpack(float* o) const { o[0] = a.x; o[1] = a.y; o[2] = a.z; o[3] = a.w; o[4] = b.x; o[5] = b.y; o[6] = b.z; o[7] = b.w; }
 };
 
-template <typename T>
+template <typename T, typename GT>      // GT: type of the gradient maps (float, or bf16 = what the FPN backward consumes: no cast pass)
 __global__ __launch_bounds__(256, 5) void roialign_bwd_gather_kernel(Feats ft, GatherGeom gg, const float* __restrict__ rois, int R, int P,
                                                                   const T* __restrict__ gp /*[R][P][P][C]*/, int sorted) {
     __shared__ int cand[256];
@@ -499,9 +499,20 @@ __global__ __launch_bounds__(256, 5) void roialign_bwd_gather_kernel(Feats ft, G
         }
     }
     if (px0 + px < W) {
-        float* G = ft.g[l] + (((long)b * H + py) * W + px0 + px) * C + cg * 4;
+        const long o = (((long)b * H + py) * W + px0 + px) * C + cg * 4;
+        if constexpr (sizeof(GT) == 2) {
+            bf16_t* G = reinterpret_cast<bf16_t*>(ft.g[l]) + o;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) *reinterpret_cast<float4*>(G + j * 32) = acc[j];
+            for (int j = 0; j < 8; ++j) {
+                uint2 v;
+                v.x = pack2_bf16(acc[j].x, acc[j].y); v.y = pack2_bf16(acc[j].z, acc[j].w);
+                *reinterpret_cast<uint2*>(G + j * 32) = v;
+            }
+        } else {
+            float* G = ft.g[l] + o;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) *reinterpret_cast<float4*>(G + j * 32) = acc[j];
+        }
     }
 }
 
@@ -703,8 +714,10 @@ extern "C" int aldi_roialign(const aldi_roi_feats* f, const float* rois, int R, 
 }
 
 extern "C" int aldi_roialign_backward(const aldi_roi_feats* f, const float* rois, int R, int P, const void* g_pooled, int N, int rois_sorted,
-                                      int dtype, aldi_stream_t stream) {
+                                      int dtype, int grad_dtype, aldi_stream_t stream) {
     if (!f || !rois || !g_pooled || f->C != 256 || P > 7 || N < 1) return aldi_set_error_msg(ALDI_ERR_ARG, "roialign_backward: bad args (C must be 256, P <= 7)");
+    if (grad_dtype != ALDI_F32 && !(grad_dtype == ALDI_BF16 && dtype == ALDI_BF16))
+        return aldi_set_error_msg(ALDI_ERR_ARG, "roialign_backward: gradient maps are fp32, or bf16 with bf16 pooled gradients");
     Feats ft = make_feats(f, true);
     GatherGeom gg;
     gg.N = N;
@@ -717,8 +730,12 @@ extern "C" int aldi_roialign_backward(const aldi_roi_feats* f, const float* rois
     }
     gg.blk_off[4] = off;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    if (dtype == ALDI_BF16) hipLaunchKernelGGL((roialign_bwd_gather_kernel<bf16_t>), dim3(off), dim3(256), 0, st, ft, gg, rois, R, P, (const bf16_t*)g_pooled, rois_sorted);
-    else if (dtype == ALDI_F32) hipLaunchKernelGGL((roialign_bwd_gather_kernel<float>), dim3(off), dim3(256), 0, st, ft, gg, rois, R, P, (const float*)g_pooled, rois_sorted);
+    if (dtype == ALDI_BF16 && grad_dtype == ALDI_BF16)
+        hipLaunchKernelGGL((roialign_bwd_gather_kernel<bf16_t, bf16_t>), dim3(off), dim3(256), 0, st, ft, gg, rois, R, P, (const bf16_t*)g_pooled, rois_sorted);
+    else if (dtype == ALDI_BF16)
+        hipLaunchKernelGGL((roialign_bwd_gather_kernel<bf16_t, float>), dim3(off), dim3(256), 0, st, ft, gg, rois, R, P, (const bf16_t*)g_pooled, rois_sorted);
+    else if (dtype == ALDI_F32)
+        hipLaunchKernelGGL((roialign_bwd_gather_kernel<float, float>), dim3(off), dim3(256), 0, st, ft, gg, rois, R, P, (const float*)g_pooled, rois_sorted);
     else return aldi_set_error_msg(ALDI_ERR_ARG, "roialign_backward: bad dtype");
     ALDI_CHECK_LAUNCH();
     return ALDI_OK;

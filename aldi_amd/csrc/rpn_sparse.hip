@@ -99,6 +99,31 @@ __global__ __launch_bounds__(256) void sparse_gather_kernel(SGeom g, int Ch, int
     }
 }
 
+// bf16 gradient maps (the compute dtype's own: what the reference's autocast sums, aldi/trainer.py:79): packed two-channel atomics
+typedef short s16x2_t __attribute__((ext_vector_type(2)));
+__global__ __launch_bounds__(256) void sparse_scatter_bf16_kernel(SGeom g, int Cf, int cap, const int* __restrict__ idx, const int* __restrict__ count,
+                                                                  const bf16_t* __restrict__ Y) {
+    const int s = blockIdx.x;
+    if (s >= min(*count, cap)) return;
+    const int row = idx[s];
+    const int l = level_of(g, row);
+    const long pix = row - g.row0[l];
+    const int hw = g.H[l] * g.W[l];
+    const int n = (int)(pix / hw);
+    const int r = (int)(pix - (long)n * hw);
+    const int h = r / g.W[l], w = r - h * g.W[l];
+    const int half = Cf / 2;
+    for (int e = threadIdx.x; e < 9 * half; e += blockDim.x) {
+        const int tap = e / half, c2 = e - tap * half;
+        const int hh = h + tap / 3 - 1, ww = w + tap % 3 - 1;
+        if ((unsigned)hh >= (unsigned)g.H[l] || (unsigned)ww >= (unsigned)g.W[l]) continue;
+        const unsigned v = *reinterpret_cast<const unsigned*>(Y + (long)s * 9 * Cf + tap * Cf + c2 * 2);
+        if ((v & 0x7fff7fffu) == 0u) continue;
+        bf16_t* dst = reinterpret_cast<bf16_t*>(g.gfeat[l]) + (((long)n * g.H[l] + hh) * g.W[l] + ww) * Cf + c2 * 2;
+        __builtin_amdgcn_global_atomic_fadd_v2bf16((__attribute__((address_space(1))) s16x2_t*)dst, __builtin_bit_cast(s16x2_t, v));
+    }
+}
+
 // block s: gfeat[l][pixel + (tap - centre)][ci] += Y[s][tap][ci] for the nine taps (fp32 atomics: neighbouring active pixels overlap)
 template <typename T>
 __global__ __launch_bounds__(256) void sparse_scatter_kernel(SGeom g, int Cf, int cap, const int* __restrict__ idx, const int* __restrict__ count,
@@ -169,17 +194,21 @@ extern "C" int aldi_rpn_sparse_gather(const aldi_rpn_geom* gm, float* const* ghe
     return ALDI_OK;
 }
 
-extern "C" int aldi_rpn_sparse_scatter(const aldi_rpn_geom* gm, float* const* gfeat, const void* Y, int N, int Cf, int cap, const int* idx,
-                                       const int* count, int dtype, aldi_stream_t stream) {
+extern "C" int aldi_rpn_sparse_scatter(const aldi_rpn_geom* gm, void* const* gfeat, const void* Y, int N, int Cf, int cap, const int* idx,
+                                       const int* count, int dtype, int grad_dtype, aldi_stream_t stream) {
     if (!gfeat || !Y || !idx || !count) return aldi_set_error_msg(ALDI_ERR_ARG, "rpn_sparse_scatter: null pointer");
     SGeom g;
     if (int rc = fill_geom(g, gm, N)) return rc;
     for (int l = 0; l < g.nl; ++l) {
         if (!gfeat[l]) return aldi_set_error_msg(ALDI_ERR_ARG, "rpn_sparse_scatter: null level gradient");
-        g.gfeat[l] = gfeat[l];
+        g.gfeat[l] = static_cast<float*>(gfeat[l]);
     }
     hipStream_t st = static_cast<hipStream_t>(stream);
-    if (dtype == ALDI_BF16) hipLaunchKernelGGL(sparse_scatter_kernel<bf16_t>, dim3(cap), dim3(256), 0, st, g, Cf, cap, idx, count, (const bf16_t*)Y);
+    if (grad_dtype == ALDI_BF16) {
+        if (dtype != ALDI_BF16 || Cf % 2) return aldi_set_error_msg(ALDI_ERR_ARG, "rpn_sparse_scatter: bf16 gradient maps take bf16 rows, even channel count");
+        hipLaunchKernelGGL(sparse_scatter_bf16_kernel, dim3(cap), dim3(256), 0, st, g, Cf, cap, idx, count, (const bf16_t*)Y);
+    } else if (grad_dtype != ALDI_F32) return aldi_set_error_msg(ALDI_ERR_ARG, "rpn_sparse_scatter: bad gradient dtype");
+    else if (dtype == ALDI_BF16) hipLaunchKernelGGL(sparse_scatter_kernel<bf16_t>, dim3(cap), dim3(256), 0, st, g, Cf, cap, idx, count, (const bf16_t*)Y);
     else if (dtype == ALDI_F32) hipLaunchKernelGGL(sparse_scatter_kernel<float>, dim3(cap), dim3(256), 0, st, g, Cf, cap, idx, count, (const float*)Y);
     else return aldi_set_error_msg(ALDI_ERR_ARG, "rpn_sparse_scatter: bad dtype");
     ALDI_CHECK_LAUNCH();

@@ -999,7 +999,11 @@ class RCNN:
         T = self.dtype
         dev = self.device
         # ---- box head (+ instance-level discriminator behind the gradient-reversal layer)
-        gP_roi = [(torch.empty if c.R > 0 else torch.zeros)(f.shape, dtype=torch.float32, device=dev) for f in c.P[:4]]
+        # ROIAlign's share of d(loss)/d(P_l).  With the sparse RPN-head backward these maps ARE the FPN backward's input, so in bf16
+        # mode they are written in bf16 directly (no fp32 map + cast pass): the ROI part rounded once, the RPN head's few thousand
+        # active pixels added on top in bf16 -- the two bf16 gradients the reference's autocast sums (aldi/trainer.py:79)
+        g_dt = T if (self.sparse_rpn_backward and T == torch.bfloat16) else torch.float32
+        gP_roi = [(torch.empty if c.R > 0 else torch.zeros)(f.shape, dtype=g_dt, device=dev) for f in c.P[:4]]
         if c.R > 0:
             g_extra = None
             for al in align_list:
@@ -1024,7 +1028,7 @@ class RCNN:
             x = c.pooled.view(c.R, 1, 1, POOL * POOL * FPN_C)
             self._wgrad("roi_heads.box_head.fc1", x, g_fc1)
             g_pooled = ops.conv2d(g_fc1, W.wt("roi_heads.box_head.fc1")).view(c.R, POOL, POOL, FPN_C)
-            ops.roialign_backward(self.roi_feats(c, gP_roi), c.rois, c.R, POOL, g_pooled, c.N, rois_sorted=True)
+            ops.roialign_backward(self.roi_feats(c, gP_roi), c.rois, c.R, POOL, g_pooled, c.N, rois_sorted=True, grad_dtype=g_dt)
         self._grads_final(["box_pred", "roi_heads.box_head.fc2", "roi_heads.box_head.fc1"])
         # ---- RPN head (shared weights over 5 levels)
         if self.sparse_rpn_backward:
@@ -1107,7 +1111,7 @@ class RCNN:
         """RPN head backward over the ACTIVE pixels only (csrc/rpn_sparse.hip): d(loss)/d(head outputs) is non-zero at the sampled
         anchors' pixels (the RPN losses' sample + the positions the distillation losses' fresh sample selects), i.e. at
         <= 4 * 256 * N of the 358 k pixel positions.  Returns d(loss)/d(P_l) in the compute dtype, ROIAlign's contribution
-        (gP_roi, fp32) included -- summed in fp32 and rounded once."""
+        (gP_roi) included: fp32 maps are summed in fp32 and rounded once, bf16 maps take the rows by packed bf16 atomics."""
         W, T, dev = self.wts, self.dtype, self.device
         N, Cf, Ch = c.N, FPN_C, self.Ch
         # bound on the active pixels of one image: RPN_BATCH sampled anchors of the RPN losses + RPN_BATCH mask positions of the
@@ -1126,9 +1130,9 @@ class RCNN:
         g_t = ops.conv2d(G, W.wt("rpn_head_out"), mask=Tm)
         self._wgrad("proposal_generator.rpn_head.conv", X9, g_t, flat=True, temp_x=True)
         Y = ops.conv2d(g_t, W.wt_flat("proposal_generator.rpn_head.conv"))           # [cap][9][Cf]: contributions to the 3x3 neighbourhood
-        g32 = list(gP_roi) + [torch.zeros(c.P[4].shape, dtype=torch.float32, device=dev)]
+        g32 = list(gP_roi) + [torch.zeros(c.P[4].shape, dtype=gP_roi[0].dtype, device=dev)]
         ops.rpn_sparse_scatter(c.geom, g32, Y, N, Cf, cap, idx, count)
-        return [ops.cast_from_f32(g, T) for g in g32]
+        return g32 if g32[0].dtype == T else [ops.cast_from_f32(g, T) for g in g32]
 
     def _grads_final(self, names: List[str]):
         """tell the gradient exchange (if one is attached: data-parallel fused step) that these layers' gradients are

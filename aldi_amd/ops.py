@@ -346,7 +346,8 @@ def rpn_sparse_gather(geom, ghead, hidden, feat, N, Cf, cap, idx, count, G, Tm, 
 
 
 def rpn_sparse_scatter(geom, gfeat, Y, N, Cf, cap, idx, count):
-    L.call("aldi_rpn_sparse_scatter", C.byref(geom), ptrs(gfeat), _p(Y), N, Cf, cap, _p(idx), _p(count), dtype_code(Y.dtype), stream_ptr())
+    L.call("aldi_rpn_sparse_scatter", C.byref(geom), ptrs(gfeat), _p(Y), N, Cf, cap, _p(idx), _p(count), dtype_code(Y.dtype),
+           dtype_code(gfeat[0].dtype), stream_ptr())
 
 
 # ------------------------------------------------------------------------------- ROI heads
@@ -379,9 +380,10 @@ def roialign(feats: L.RoiFeats, rois, R, P, pooled, backward: bool):
     L.call("aldi_roialign", C.byref(feats), _p(rois), R, P, _p(pooled), int(backward), dtype_code(pooled.dtype), stream_ptr())
 
 
-def roialign_backward(feats: L.RoiFeats, rois, R, P, g_pooled, N, rois_sorted: bool = False):
-    """gather form: overwrites the fp32 gradient maps of `feats` (each element written once, no atomics)"""
-    L.call("aldi_roialign_backward", C.byref(feats), _p(rois), R, P, _p(g_pooled), N, int(rois_sorted), dtype_code(g_pooled.dtype), stream_ptr())
+def roialign_backward(feats: L.RoiFeats, rois, R, P, g_pooled, N, rois_sorted: bool = False, grad_dtype=torch.float32):
+    """gather form: overwrites the gradient maps of `feats` (fp32, or bf16 with bf16 pooled gradients; each element written once, no atomics)"""
+    L.call("aldi_roialign_backward", C.byref(feats), _p(rois), R, P, _p(g_pooled), N, int(rois_sorted), dtype_code(g_pooled.dtype),
+           dtype_code(grad_dtype), stream_ptr())
 
 
 def box_loss(pred, Cp, K, R, rois, cls, gt_boxes, weights4, gs_cls, gs_box, grad, loss2):

@@ -230,13 +230,14 @@ int aldi_rpn_proposals(const aldi_rpn_geom* gm, float* const* head, const float*
  *                            err_flag |= 2 when more than `cap` pixels are active.  Order of the list is unspecified.
  *   aldi_rpn_sparse_gather   rows s < min(*count, cap): G[s][C] = grad_head (in dtype), Tm[s][Cf] = hidden[l][pixel],
  *                            X9[s][tap][Cf] = feat[l][pixel + (tap/3-1, tap%3-1)] (zero outside the image); rows >= count zero.
- *   aldi_rpn_sparse_scatter  gfeat[l][pixel + (tap/3-1, tap%3-1)][ci] += Y[s][tap][ci] (fp32 atomics), Y in dtype [cap][9][Cf]. */
+ *   aldi_rpn_sparse_scatter  gfeat[l][pixel + (tap/3-1, tap%3-1)][ci] += Y[s][tap][ci], Y in dtype [cap][9][Cf]; gfeat maps in grad_dtype
+ *                            (fp32 atomics, or packed bf16 atomics on bf16 maps: the sum the reference's autocast forms). */
 int aldi_rpn_active_pixels(const aldi_rpn_geom* gm, float* const* grad_head, int N, int cap, int* idx, int* count, int* err_flag,
                            aldi_stream_t stream);
 int aldi_rpn_sparse_gather(const aldi_rpn_geom* gm, float* const* grad_head, const void* const* hidden, const void* const* feat, int N, int Cf,
                            int cap, const int* idx, const int* count, void* G, void* Tm, void* X9, int dtype, aldi_stream_t stream);
-int aldi_rpn_sparse_scatter(const aldi_rpn_geom* gm, float* const* gfeat, const void* Y, int N, int Cf, int cap, const int* idx,
-                            const int* count, int dtype, aldi_stream_t stream);
+int aldi_rpn_sparse_scatter(const aldi_rpn_geom* gm, void* const* gfeat, const void* Y, int N, int Cf, int cap, const int* idx,
+                            const int* count, int dtype, int grad_dtype, aldi_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------
  * ROI heads.  Replaces detectron2 StandardROIHeads.label_and_sample_proposals, ROIPooler +
@@ -269,10 +270,11 @@ int aldi_rois_from_proposals(const float* props, const int* pcount, int P, int N
 int aldi_roialign(const aldi_roi_feats* f, const float* rois, int R, int P, void* pooled, int backward, int dtype, aldi_stream_t stream);
 /* ROIAlign backward as a gather: OVERWRITES the four fp32 gradient maps f->grad[l] ([N][H_l][W_l][C], no zero-fill needed) with
  * d(loss)/d(feature) given g_pooled [R][P][P][C] in `dtype`; every element is written exactly once (deterministic, no atomics).
+ * grad_dtype = ALDI_BF16 (with dtype = ALDI_BF16): f->grad[l] point to bf16 maps, each element rounded once from the fp32 sum.
  * `aldi_roialign(..., backward=1)` is the accumulating scatter form of the same operator.  rois_sorted = 1 promises that the ROI
  * rows are grouped by ascending image index (what label_and_sample_proposals produces): each workgroup then scans its image's rows only. */
 int aldi_roialign_backward(const aldi_roi_feats* f, const float* rois, int R, int P, const void* g_pooled, int N, int rois_sorted, int dtype,
-                           aldi_stream_t stream);
+                           int grad_dtype, aldi_stream_t stream);
 
 /* pred fp32 [R][Cp]: [0,K] class logits, then 4K class-specific deltas. loss2 += {CE mean, L1 sum/R};
  * grad (fp32 [R][Cp], nullable) += d(scale_cls*loss_cls + scale_box*loss_box_reg)/d(pred). */

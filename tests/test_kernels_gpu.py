@@ -355,6 +355,11 @@ def test_roialign_fwd_bwd_vs_oracle(dtype, tol):
     srt = [torch.empty_like(t) for t in grads2]
     ops.roialign_backward(ops.make_roi_feats(fd, srt, [1 / 4, 1 / 8, 1 / 16, 1 / 32]), rois, R, 7, gd, N, rois_sorted=True)
     assert all(torch.equal(a, b) for a, b in zip(srt, grads2))
+    if dtype == torch.bfloat16:
+        # bf16 gradient maps (what the bf16 step's FPN backward consumes): the same fp32 sums, rounded once
+        lo = [torch.full(f.shape, float("nan"), dtype=torch.bfloat16, device=DEV) for f in fd]
+        ops.roialign_backward(ops.make_roi_feats(fd, lo, [1 / 4, 1 / 8, 1 / 16, 1 / 32]), rois, R, 7, gd, N, rois_sorted=True, grad_dtype=torch.bfloat16)
+        assert all(torch.equal(a, b.to(torch.bfloat16)) for a, b in zip(lo, grads2))
     # property: pooling a constant map returns the constant wherever the ROI lies inside the map
     const = [torch.full(f.shape, 3.0, dtype=dtype, device=DEV) for f in fd]
     inside = ((rois[:, 1] >= 0) & (rois[:, 2] >= 0) & (rois[:, 3] <= 640) & (rois[:, 4] <= 448)).nonzero().squeeze(1)

@@ -19,7 +19,7 @@ grads = [torch.zeros((N, Hs[l], Ws[l], 256), dtype=torch.float32, device=dev) fo
 gp = torch.randn((R, 7, 7, 256), device=dev).to(torch.bfloat16)
 rf = ops.make_roi_feats(feats, grads, [1 / 4, 1 / 8, 1 / 16, 1 / 32])
 def run(flags):
-    L.call("aldi_roialign_backward", C.byref(rf), ops._p(rois), R, 7, ops._p(gp), N, flags, ops.dtype_code(gp.dtype), ops.stream_ptr())
+    L.call("aldi_roialign_backward", C.byref(rf), ops._p(rois), R, 7, ops._p(gp), N, flags, ops.dtype_code(gp.dtype), ops.dtype_code(grads[0].dtype), ops.stream_ptr())
 for flags in (1, 0):
     for _ in range(3): run(flags)
     torch.cuda.synchronize()
