@@ -40,7 +40,8 @@ const Knob kKnobs[] = {
     {"wgrad_xcd", &AldiTuning::wgrad_xcd, 1},
     {"wgrad_dma", &AldiTuning::wgrad_dma, 0},
     {"wgrad_dbg", &AldiTuning::wgrad_dbg, 0},
-    {"wgrad_group_slots", &AldiTuning::wgrad_group_slots, 384},
+    {"wgrad_group_slots", &AldiTuning::wgrad_group_slots, 0},
+    {"wgrad_group_epi", &AldiTuning::wgrad_group_epi, 24},
     {"colsum_blocks", &AldiTuning::colsum_blocks, 256},
     {"colsum_minrows", &AldiTuning::colsum_minrows, 16},
     {"colsum_nt", &AldiTuning::colsum_nt, 1024},

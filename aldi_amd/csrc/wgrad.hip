@@ -788,7 +788,23 @@ extern "C" int aldi_conv_wgrad_group(const aldi_wgrad_args* args, int n, aldi_st
     };
     long T = (maxM + 63) / 64 * 64;
     const long target = tn.wgrad_group_slots;
-    while (T > 256 && wgs_for(T) < target) T = (T / 2 + 63) / 64 * 64;       // >= 4 slabs behind every epilogue
+    if (target > 0) {
+        while (T > 256 && wgs_for(T) < target) T = (T / 2 + 63) / 64 * 64;   // >= 4 slabs behind every epilogue
+    } else {
+        // wgrad_group_slots = 0: pick the split count by a round model.  Three of these workgroups are resident per CU (168
+        // VGPRs) and need each other to hide their LDS / DMA latency, so the chip works through the launch in rounds of 768, a
+        // round lasting (T / 32 slab steps + one epilogue, ~wgrad_group_epi slab steps of 16 K atomics).  Measured on the step's
+        // groups: 392 unsplit res4 tiles 603 us, three splits (1176 workgroups) 544 us; one 256-workgroup round of res3 553 us
+        // against 432 us for 512 half-length workgroups.
+        long best = -1;
+        for (int sp = 1; sp <= 4096; ++sp) {
+            const long Ts = ((maxM + sp - 1) / sp + 63) / 64 * 64;
+            if (Ts < 256 && sp > 1) break;
+            const long rounds = (wgs_for(Ts) + 767) / 768;
+            const long cost = rounds * (Ts / 32 + tn.wgrad_group_epi);
+            if (best < 0 || cost < best) { best = cost; T = Ts; }
+        }
+    }
     // longest-running problems first (K x K convs before 1x1: more k-steps per pixel do not matter, pixels per workgroup do)
     for (int i = 1; i < ng; ++i)
         for (int j = i; j > 0 && G.p[order[j]].M > G.p[order[j - 1]].M; --j) { int t_ = order[j]; order[j] = order[j - 1]; order[j - 1] = t_; }

@@ -46,7 +46,9 @@ int aldi_version(void);
  *   wgrad_big_min        slabs (64 pixels) per workgroup from which the 256x256 tile is used (28; 0 = never)
  *   wgrad_big_slots, wgrad_slots   target workgroup counts of the 256x256 / 128x128 forms (256, 384)
  *   wgrad_xcd            1 = XCD-aware order
- *   wgrad_group_slots    minimum workgroup count of an aldi_conv_wgrad_group launch before it stops splitting pixel ranges (384)
+ *   wgrad_group_slots    > 0: minimum workgroup count of an aldi_conv_wgrad_group launch before it stops splitting pixel ranges;
+ *                        0 (default): the pixel split of the group is chosen by a model of 256-workgroup rounds
+ *   wgrad_group_epi      cost of one atomic epilogue in that model, in 32-pixel slab steps (24)
  *   wgrad_dbg            ablation bits (1 = skip the atomic epilogue): results are WRONG when set
  *   wgrad_dma            LDS-DMA + ds_read_b64_tr_b16 weight-gradient kernel: 0 off, 1 in place of the lean kernel, 2 also of the 256x256
  *   colsum_blocks, colsum_minrows, colsum_nt, colsum_block_kb   aldi_bias_grad launch geometry
@@ -111,7 +113,7 @@ int aldi_conv_wgrad(const aldi_wgrad_args* a, aldi_stream_t stream);
  * gradient before the optimizer, so a stage's layers -- small GEMMs over the same pixels -- are launched together: hundreds
  * of output tiles fill the chip without the 11-24-way pixel splits (and their float-atomic epilogues) each layer needs alone.
  * Problems the lean bf16 kernel cannot take (fp32, strided, unpadded KxK) are forwarded to aldi_conv_wgrad one by one.
- * Knob wgrad_group_slots (384): workgroups the launch should at least have before pixel ranges stop being split. */
+ * Knobs wgrad_group_slots / wgrad_group_epi: how far the group's pixel ranges are split (see the knob table above). */
 int aldi_conv_wgrad_group(const aldi_wgrad_args* args, int n, aldi_stream_t stream);
 
 /* db[c] += sum_m g[m][c] (bias gradients), g is [M][C] in `dtype`. */

@@ -436,10 +436,10 @@ def test_wgrad_group_equals_single_launches():
         assert e <= 2e-5 * max(1.0, ref.abs().max().item()) * max(1.0, (x.shape[0] * x.shape[1] * x.shape[2] / 1024) ** 0.5), (case, e)
     # fewer pixel splits than the single launches: the whole group fits ~one wave of workgroups
     wgs = int(name.split("wgs=")[1].split()[0])
-    assert 300 <= wgs <= 1200, name
+    assert 300 <= wgs <= 2400, name
 
 
-@pytest.mark.parametrize("slots", [1, 4000])
+@pytest.mark.parametrize("slots", [0, 1, 4000])
 def test_wgrad_group_split_policy(slots):
     from aldi_amd import _lib as L
     from aldi_amd import ops
