@@ -117,7 +117,7 @@ struct Stream {
         // a seeded engine (left == 1) refills before its first draw; otherwise next + left == 625 and the next draw is s[next]
         origin = start.left == 1 ? MT_N : (long)start.next;
         const long nb = (origin + max_draws) / MT_N + 2;
-        raw.resize((size_t)nb * MT_N);
+        if (raw.size() < (size_t)nb * MT_N) raw.resize((size_t)nb * MT_N);      // (kept across calls: fresh pages cost more than the refills)
         memcpy(raw.data(), start.s, sizeof(start.s));
         Mt t = start;
         for (long b = 1; b < nb; ++b) {
@@ -149,7 +149,9 @@ struct Cursor {
     }
 };
 
-std::vector<Stream> g_streams;
+constexpr int kMaxStreams = 8;
+Stream g_streams[kMaxStreams];          // buffers persist; the first g_nstreams are valid for the next script
+int g_nstreams = 0;
 long g_stream_hits = 0;
 std::vector<std::thread> g_fillers;
 void join_fillers() {
@@ -161,11 +163,29 @@ void join_fillers() {
 template <typename OutT, typename Gen>
 void randperm_prefix(Gen& mt, long n, long k, OutT* out) {
     if (k > n) k = n;
-    // sparse image of the permutation array: position -> value for the <= 2k positions touched so far (open addressing;
-    // a node-based map costs more than the shuffle itself for the small lists)
+    const long iters = n > 0 ? n - 1 : 0;           // the reference loop: for (i = 0; i < n - 1; i++)
+    const long run = k < iters ? k : iters;
+    if (n <= 16384) {
+        // short lists (the ROI samples: a few thousand candidates): the permutation array itself, swapped in place
+        static thread_local std::vector<int> perm;
+        if ((long)perm.size() < n) perm.resize((size_t)n);
+        for (long i = 0; i < n; ++i) perm[(size_t)i] = (int)i;
+        for (long i = 0; i < run; ++i) {
+            const long j = (long)(mt.draw() % (uint64_t)(n - i)) + i;
+            const int t = perm[(size_t)i]; perm[(size_t)i] = perm[(size_t)j]; perm[(size_t)j] = t;
+        }
+        mt.discard(iters - run);
+        for (long i = 0; i < k; ++i) out[i] = (OutT)perm[(size_t)i];
+        return;
+    }
+    // sparse image of the permutation array: position -> value for the <= 2k positions touched so far (open addressing in a
+    // table kept per thread and wiped slot by slot afterwards; a node-based map costs more than the shuffle itself)
     size_t cap = 64;
     while (cap < (size_t)(4 * k + 16)) cap <<= 1;
-    std::vector<long> keys(cap, -1), vals(cap);
+    static thread_local std::vector<long> keys, vals;
+    static thread_local std::vector<uint32_t> used;
+    if (keys.size() < cap) { keys.assign(cap, -1); vals.resize(cap); }
+    used.clear();
     const size_t hmask = cap - 1;
     auto slot = [&](long pos) {
         size_t h = ((uint64_t)pos * 0x9E3779B97F4A7C15ull >> 20) & hmask;
@@ -173,9 +193,7 @@ void randperm_prefix(Gen& mt, long n, long k, OutT* out) {
         return h;
     };
     auto get = [&](long pos) { size_t h = slot(pos); return keys[h] == pos ? vals[h] : pos; };
-    auto put = [&](long pos, long v) { size_t h = slot(pos); keys[h] = pos; vals[h] = v; };
-    const long iters = n > 0 ? n - 1 : 0;           // the reference loop: for (i = 0; i < n - 1; i++)
-    const long run = k < iters ? k : iters;
+    auto put = [&](long pos, long v) { size_t h = slot(pos); if (keys[h] == -1) used.push_back((uint32_t)h); keys[h] = pos; vals[h] = v; };
     for (long i = 0; i < run; ++i) {
         long z = (long)(mt.draw() % (uint64_t)(n - i));
         long j = z + i;
@@ -185,6 +203,7 @@ void randperm_prefix(Gen& mt, long n, long k, OutT* out) {
     }
     mt.discard(iters - run);
     for (long i = 0; i < k; ++i) out[i] = (OutT)get(i);
+    for (uint32_t h : used) keys[h] = -1;
 }
 
 }  // namespace
@@ -206,8 +225,7 @@ extern "C" int aldi_torch_randperm_prefix(unsigned char* state, long n, long k, 
 // The generator state after a manual_seed does not depend on anything before it, so the script splits into segments at the
 // seeds and the segments run on `threads` host threads (the cost is the Mersenne-Twister skip-ahead of the 268k-entry negative
 // lists: ~80 us each, six per iteration); the blob ends as the sequential execution leaves it.
-extern "C" int aldi_torch_rng_script(unsigned char* state, const long* script, int nops, int* out, int threads) {
-    if (!state || !script || nops < 0 || (!out && nops > 0)) return aldi_set_error_msg(ALDI_ERR_ARG, "torch_rng_script: bad args");
+static int run_script(unsigned char* state, const long* script, int nops, int* out, int threads) {
     struct Seg { int begin, end; bool seeded; uint64_t seed; Mt mt; };
     std::vector<Seg> segs;
     segs.push_back(Seg{0, 0, false, 0, Mt()});
@@ -244,7 +262,8 @@ extern "C" int aldi_torch_rng_script(unsigned char* state, const long* script, i
         long total = 0;
         for (int i = sg.begin; i < sg.end; ++i) total += script[4 * i + 1] > 0 ? script[4 * i + 1] - 1 : 0;
         const Stream* hit = nullptr;
-        for (const Stream& st : g_streams) {
+        for (int si = 0; si < g_nstreams; ++si) {
+            const Stream& st = g_streams[si];
             const bool same = sg.seeded ? (st.seeded && st.seed == sg.seed)
                                         : (!st.seeded && st.start.left == sg.mt.left && st.start.next == sg.mt.next &&
                                            memcmp(st.start.s, sg.mt.s, sizeof(sg.mt.s)) == 0);
@@ -281,6 +300,76 @@ extern "C" int aldi_torch_rng_script(unsigned char* state, const long* script, i
     return ALDI_OK;
 }
 
+extern "C" int aldi_torch_rng_script(unsigned char* state, const long* script, int nops, int* out, int threads) {
+    if (!state || !script || nops < 0 || (!out && nops > 0)) return aldi_set_error_msg(ALDI_ERR_ARG, "torch_rng_script: bad args");
+    return run_script(state, script, nops, out, threads);
+}
+
+// The whole host phase of one fused ALDI iteration in one call: from the device's list lengths to the sampling positions,
+// their counts, the ROI row offsets and the distillation normalisers, written into the pinned upload buffer.  Order of the
+// draws on the global CPU generator (aldi/distill.py:148-162,200-202, aldi/helpers.py:17-26):
+//   per chunk: [distillation chunk: manual_seed(seed_old) by the teacher's eval pass] RPN sample (positives, negatives per
+//   image), manual_seed(seed of the student's roi_heads hook: seed_old before the seeder was reset, seed_new after), ROI sample;
+//   then for the distillation chunk manual_seed(seed_new), the teacher's identical ROI draws (discarded) and the fresh RPN
+//   sample of get_rpn_losses.
+// counts: [N][2] RPN (positives, negatives) then [N][2] ROI.  chunks: nch rows {kind (1 = distillation), n0, n1}.
+// word0: int32 word offsets into `words` of {rsel [N][2][rpn_batch], rnsel [N][2], osel [N][2][roi_batch], onsel [N][2],
+// row_off [N], dsel [nd][2][rpn_batch], dnsel [nd][2], nvf [2]}.  rows_out [N]: sampled ROI rows per image.
+extern "C" int aldi_step_draws(unsigned char* state, const int* counts, int N, const int* chunks, int nch, long seed_old, long seed_new,
+                               int rpn_batch, int rpn_pos_cap, int roi_batch, int roi_pos_cap, int* words, const int* word0, int* rows_out,
+                               int threads) {
+    if (!state || !counts || !chunks || !words || !word0 || !rows_out || N < 1 || nch < 1)
+        return aldi_set_error_msg(ALDI_ERR_ARG, "step_draws: bad args");
+    std::vector<long> sc;
+    sc.reserve(64 * (size_t)N);
+    auto sample = [&](int o_sel, int o_nsel, int row0, const int* cnt, int nimg, int batch, int pos_cap, int* sums) {
+        for (int i = 0; i < nimg; ++i) {
+            const int npos = cnt[2 * i], nneg = cnt[2 * i + 1];
+            const int num_pos = npos < pos_cap ? npos : pos_cap;
+            const int num_neg = nneg < batch - num_pos ? nneg : batch - num_pos;
+            const long base = o_sel < 0 ? -1 : (long)o_sel + (long)(row0 + i) * 2 * batch;
+            sc.insert(sc.end(), {0, (long)npos, (long)num_pos, base, 0, (long)nneg, (long)num_neg, base < 0 ? -1 : base + batch});
+            if (o_nsel >= 0) { words[o_nsel + 2 * (row0 + i)] = num_pos; words[o_nsel + 2 * (row0 + i) + 1] = num_neg; }
+            if (sums) { sums[2 * i] = num_pos; sums[2 * i + 1] = num_neg; }
+        }
+    };
+    const int* rpn = counts;
+    const int* roi = counts + 2 * N;
+    bool reset = false;
+    int distill = -1;
+    std::vector<int> pn(2 * (size_t)N);
+    for (int c = 0; c < nch; ++c) {
+        const int kind = chunks[3 * c], n0 = chunks[3 * c + 1], n1 = chunks[3 * c + 2];
+        if (n0 < 0 || n1 > N || n1 <= n0) return aldi_set_error_msg(ALDI_ERR_ARG, "step_draws: bad chunk");
+        if (kind == 1) {
+            sc.insert(sc.end(), {1, seed_old, 0, 0});
+            reset = true;
+            distill = c;
+        }
+        sample(word0[0], word0[1], n0, rpn + 2 * n0, n1 - n0, rpn_batch, rpn_pos_cap, nullptr);
+        sc.insert(sc.end(), {1, reset ? seed_new : seed_old, 0, 0});
+        sample(word0[2], word0[3], n0, roi + 2 * n0, n1 - n0, roi_batch, roi_pos_cap, pn.data() + 2 * n0);
+    }
+    int off = 0;
+    for (int i = 0; i < N; ++i) {
+        rows_out[i] = pn[2 * i] + pn[2 * i + 1];
+        words[word0[4] + i] = off;
+        off += rows_out[i];
+    }
+    if (distill >= 0) {
+        const int n0 = chunks[3 * distill + 1], n1 = chunks[3 * distill + 2];
+        sc.insert(sc.end(), {1, seed_new, 0, 0});
+        sample(-1, -1, 0, roi + 2 * n0, n1 - n0, roi_batch, roi_pos_cap, nullptr);
+        std::vector<int> dn(2 * (size_t)(n1 - n0));
+        sample(word0[5], word0[6], 0, rpn + 2 * n0, n1 - n0, rpn_batch, rpn_pos_cap, dn.data());
+        int n_valid = 0, n_fg = 0;
+        for (int i = 0; i < n1 - n0; ++i) { n_fg += dn[2 * i]; n_valid += dn[2 * i] + dn[2 * i + 1]; }
+        words[word0[7]] = n_valid;
+        words[word0[7] + 1] = n_fg;
+    }
+    return run_script(state, sc.data(), (int)(sc.size() / 4), words, threads);
+}
+
 // Pre-generates, on background threads, the Mersenne streams the next aldi_torch_rng_script call will consume: the one that
 // continues `state` (the generator blob as it is NOW; NULL = none) and one per torch.manual_seed value in `seeds`, each
 // `max_draws` long.  The caller issues this while the device is busy with the phase whose results size the draws; the
@@ -290,16 +379,14 @@ extern "C" int aldi_torch_rng_prefetch(const unsigned char* state, const long* s
     if (nseeds < 0 || (nseeds > 0 && !seeds) || max_draws < 0 || max_draws > (1L << 28))
         return aldi_set_error_msg(ALDI_ERR_ARG, "torch_rng_prefetch: bad args");
     join_fillers();
-    g_streams.clear();
-    g_streams.resize((size_t)nseeds + (state ? 1 : 0));
-    size_t j = 0;
+    if (nseeds + (state ? 1 : 0) > kMaxStreams) return aldi_set_error_msg(ALDI_ERR_ARG, "torch_rng_prefetch: too many streams");
+    int j = 0;
     if (state) {
-        Stream& st = g_streams[j++];
+        Stream& st = g_streams[j];
+        st.seeded = false;
         load_blob(state, st.start);
-        if (st.start.left < 1 || st.start.left > MT_N || (st.start.left > 1 && (long)st.start.next + st.start.left != MT_N + 1)) {
-            g_streams.erase(g_streams.begin());            // not an engine state this code knows how to continue
-            j = 0;
-        }
+        // (an engine state this code knows how to continue: seeded-and-untouched, or in the middle of a block)
+        if (st.start.left >= 1 && st.start.left <= MT_N && (st.start.left == 1 || (long)st.start.next + st.start.left == MT_N + 1)) ++j;
     }
     for (int i = 0; i < nseeds; ++i) {
         Stream& st = g_streams[j++];
@@ -307,7 +394,11 @@ extern "C" int aldi_torch_rng_prefetch(const unsigned char* state, const long* s
         st.seed = (uint64_t)seeds[i];
         seed_mt(st.start, st.seed);
     }
-    for (Stream& st : g_streams) g_fillers.emplace_back([&st, max_draws] { st.fill(max_draws); });
+    g_nstreams = j;
+    for (int i = 0; i < j; ++i) {
+        Stream* st = &g_streams[i];
+        g_fillers.emplace_back([st, max_draws] { st->fill(max_draws); });
+    }
     return ALDI_OK;
 }
 

@@ -81,6 +81,7 @@ class FusedStep:
         # latency-bound proposal / box-head / detection chain then runs alone after the paired trunk, and the EMA tick before it)
         self.pair_forward = os.environ.get("ALDI_PAIR_FORWARD", "0") == "1"
         self.teacher_first = os.environ.get("ALDI_TEACHER_FIRST", "0") == "1"
+        self.spin_wait = os.environ.get("ALDI_SPIN_WAIT", "1") == "1"
         self.warmup = 3                     # eager steps before capturing (lazy initialisation: anchors, dgrad weights, workspaces)
         self.stats = dict(captures=0, replays_a=0, replays_b=0, eager=0)
 
@@ -231,6 +232,20 @@ class FusedStep:
                 return False
         return True
 
+    def _wait_counts(self, S):
+        """block until phase A's last operation -- the copy of the list lengths into pinned memory -- has landed.  The host polls
+        the buffer itself (the lengths overwrite a -1 fill; a stream synchronize wakes up tens of microseconds later, with the
+        device idle meanwhile); anything unexpected falls back to the synchronize, which also surfaces device errors."""
+        cnt = getattr(S, "h_counts_np", None)
+        if cnt is not None and self.spin_wait:
+            t_end = time.perf_counter() + 2.0
+            while (cnt < 0).any():
+                if time.perf_counter() > t_end:
+                    break
+            else:
+                return
+        torch.cuda.current_stream().synchronize()
+
     def _scripted(self) -> bool:
         """the host phase as one C call (aldi_torch_rng_script) instead of Python hooks + torch.randperm"""
         from . import engine as E
@@ -273,6 +288,37 @@ class FusedStep:
         scripted = self._scripted()
         script: List[int] = []
         hw = U.words
+        if scripted and os.environ.get("ALDI_HOST_DRAWS_C", "1") == "1" and all(ch["kind"] != "distill" for ch in S.chunks[:-1]):
+            # the whole host phase as ONE native call (aldi_step_draws): same draws, same order, none of the Python below
+            import ctypes as C
+            from . import _lib as L
+            seeder = dist_.seeder
+            old = int(seeder.seed)
+            if S.distill:
+                seeder.reset_seed()                         # aldi/distill.py:148-150 (Python's `random` advances here, as in the reference)
+            new = int(seeder.seed)
+            if getattr(S, "chunk_arr", None) is None:
+                flat = []
+                for ch in S.chunks:
+                    flat += [1 if ch["kind"] == "distill" else 0, ch["n0"], ch["n1"]]
+                S.chunk_arr = (C.c_int * len(flat))(*flat)
+                S.word0_arr = (C.c_int * 8)(*[U.word0(k) for k in ("rsel", "rnsel", "osel", "onsel", "row_off", "dsel", "dnsel", "nvf")])
+                S.rows_arr = (C.c_int * N)()
+            st = torch.get_rng_state()
+            L.call("aldi_step_draws", st.data_ptr(), S.h_counts.data_ptr(), N, S.chunk_arr, len(S.chunks), old, new, RPN_BATCH,
+                   int(RPN_BATCH * RPN_POS_FRAC), ROI_BATCH, int(ROI_BATCH * ROI_POS_FRAC), U.host.data_ptr(), S.word0_arr, S.rows_arr, 4)
+            torch.set_rng_state(st)
+            rows = list(S.rows_arr)
+            r0 = 0
+            for ch in S.chunks:
+                n0, n1 = ch["n0"], ch["n1"]
+                r1 = r0 + sum(rows[n0:n1])
+                ch["r0"], ch["r1"] = r0, r1
+                ch["rpn_counts"], ch["roi_counts"] = rpn_counts[n0:n1], roi_counts[n0:n1]
+                r0 = r1
+            nv = U.word0("nvf")
+            return SimpleNamespace(rows=rows, R=sum(rows), n_valid=int(hw[nv]) if S.distill else 0, n_fg=int(hw[nv + 1]) if S.distill else 0,
+                                   key=tuple(rows))
 
         def sample(name, nname, row0, counts, batch, frac):
             """subsample_labels for the images `row0 ...`: positives then negatives, two randperm per image"""
@@ -510,6 +556,8 @@ class FusedStep:
                             ("onsel", (N, 2), torch.int32), ("row_off", (N,), torch.int32), ("dsel", (nd, 2, RPN_BATCH), torch.int32),
                             ("dnsel", (nd, 2), torch.int32), ("nvf", (2,), torch.int32)], dev)
             S.h_counts = _pinned(4 * N * 4)
+            S.h_counts_np = S.h_counts.numpy().view("int32")[: 4 * N]
+        S.h_counts_np.fill(-1)                                    # (phase A's last copy overwrites every word with a length >= 0)
         # (the ViTDet / ConvNeXt trunks draw their stochastic-depth masks on the host every step: their launches are not replayable as recorded)
         use_graph = self.graph_enabled and self.steps_done >= self.warmup and type(eng) is RCNN
         # ---- phase A
@@ -533,7 +581,7 @@ class FusedStep:
         evs[1].record()
         self._prefetch_draws(S, int(c.anchors.shape[0]))
         t1 = time.perf_counter()
-        torch.cuda.current_stream().synchronize()                  # the ONE device->host sync: list lengths for the host RNG
+        self._wait_counts(S)                                       # the ONE device->host sync: list lengths for the host RNG
         t2 = time.perf_counter()
         # ---- host: all sampling draws
         Hst = self._host_draws(S, A)

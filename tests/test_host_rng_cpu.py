@@ -134,3 +134,76 @@ def test_rng_script_from_prefetched_streams(case):
     assert torch.equal(torch.get_rng_state(), ref_state)
     assert torch.equal(torch.randperm(50), ref_next)
     assert served == {"all": 4, "mid_block": 4, "short": 0, "wrong_seed": 1, "no_draws": 3}[case]
+
+
+@pytest.mark.parametrize("distill", [True, False])
+def test_step_draws_equals_the_reference_sequence(distill):
+    """aldi_step_draws (the fused step's host phase as one native call) == the reference's sequence of torch.manual_seed /
+    torch.randperm calls: sampled positions, counts, ROI row offsets, normalisers, generator state"""
+    import ctypes as C
+    from aldi_amd import _lib as L
+    N = 4 if distill else 2
+    RB, RP, OB, OP = 256, 128, 512, 128
+    gen = torch.Generator().manual_seed(11)
+    rpn = [[int(torch.randint(0, 300, (1,), generator=gen)), int(torch.randint(100, 250000, (1,), generator=gen))] for _ in range(N)]
+    roi = [[int(torch.randint(0, 200, (1,), generator=gen)), int(torch.randint(0, 2100, (1,), generator=gen))] for _ in range(N)]
+    rpn[0][0] = 0                                                           # an image without positives
+    chunks = [(0, 0, 2), (1, 2, 4)] if distill else [(0, 0, 2)]
+    old, new = 1234567, 4000000001
+    nd = 2 if distill else 1
+    # word layout of the upload buffer
+    names = [("rsel", N * 2 * RB), ("rnsel", N * 2), ("osel", N * 2 * OB), ("onsel", N * 2), ("row_off", N), ("dsel", nd * 2 * RB), ("dnsel", nd * 2), ("nvf", 2)]
+    w0, off = {}, 0
+    for k, n in names:
+        w0[k] = off
+        off += (n + 3) // 4 * 4
+    # ---- reference: torch calls in the reference's order
+    torch.manual_seed(77)
+    torch.randperm(500)
+    start = torch.get_rng_state()
+    ref = torch.full((off,), -7, dtype=torch.int32)
+
+    def sample(dst, ndst, row0, cnts, batch, cap):
+        sums = []
+        for i, (npos, nneg) in enumerate(cnts):
+            num_pos = min(npos, cap)
+            num_neg = min(nneg, batch - num_pos)
+            p1, p2 = torch.randperm(npos)[:num_pos], torch.randperm(nneg)[:num_neg]
+            if dst is not None:
+                b = w0[dst] + (row0 + i) * 2 * batch
+                ref[b: b + num_pos] = p1.to(torch.int32)
+                ref[b + batch: b + batch + num_neg] = p2.to(torch.int32)
+                ref[w0[ndst] + 2 * (row0 + i)], ref[w0[ndst] + 2 * (row0 + i) + 1] = num_pos, num_neg
+            sums.append((num_pos, num_neg))
+        return sums
+    rows, seed = [], old
+    for kind, n0, n1 in chunks:
+        if kind == 1:
+            torch.manual_seed(old)
+            seed = new
+        sample("rsel", "rnsel", n0, rpn[n0:n1], RB, RP)
+        torch.manual_seed(seed)
+        rows += [a + b for a, b in sample("osel", "onsel", n0, roi[n0:n1], OB, OP)]
+    o = 0
+    for i, r in enumerate(rows):
+        ref[w0["row_off"] + i] = o
+        o += r
+    if distill:
+        torch.manual_seed(new)
+        sample(None, None, 0, roi[2:4], OB, OP)
+        dh = sample("dsel", "dnsel", 0, rpn[2:4], RB, RP)
+        ref[w0["nvf"]], ref[w0["nvf"] + 1] = sum(a + b for a, b in dh), sum(a for a, _ in dh)
+    ref_state = torch.get_rng_state()
+    # ---- the native call
+    torch.set_rng_state(start)
+    got = torch.full((off,), -7, dtype=torch.int32)
+    counts = torch.tensor([v for p in rpn for v in p] + [v for p in roi for v in p], dtype=torch.int32)
+    carr = (C.c_int * (3 * len(chunks)))(*[v for c in chunks for v in c])
+    warr = (C.c_int * 8)(*[w0[k] for k, _ in names])
+    rarr = (C.c_int * N)()
+    st = torch.get_rng_state()
+    L.call("aldi_step_draws", st.data_ptr(), counts.data_ptr(), N, carr, len(chunks), old, new, RB, RP, OB, OP, got.data_ptr(), warr, rarr, 4)
+    torch.set_rng_state(st)
+    assert list(rarr) == rows
+    assert torch.equal(got, ref)
+    assert torch.equal(torch.get_rng_state(), ref_state)
