@@ -630,27 +630,30 @@ __global__ void det_finish_kernel(const float4* __restrict__ boxes, const float*
                                   const int* __restrict__ keep, const int* __restrict__ keep_count, int topk, float pl_thresh,
                                   float4* __restrict__ det_boxes, float* __restrict__ det_scores, int* __restrict__ det_cls, int* __restrict__ det_count,
                                   float4* __restrict__ pl_boxes, int* __restrict__ pl_cls, float* __restrict__ pl_scores, int* __restrict__ pl_count) {
-    const int n = blockIdx.x;
-    if (threadIdx.x != 0) return;
+    // one wave per image, 64 detections per round (a single thread walking `topk` dependent loads was a 27 us chain)
+    const int n = blockIdx.x, lane = threadIdx.x;
     const int kc = min(keep_count[n], topk);
     int np = 0;
-    for (int j = 0; j < topk; ++j) {
+    for (int j0 = 0; j0 < topk; j0 += 64) {
+        const int j = j0 + lane;
         float4 b = make_float4(0, 0, 0, 0);
         float s = 0.f;
         int c = -1;
         if (j < kc) {
-            long slot = (long)n * kDetCap + keep[(long)n * kDetCap + j];
+            const long slot = (long)n * kDetCap + keep[(long)n * kDetCap + j];
             b = boxes[slot]; s = scores[slot]; c = cats[slot];
-            if (s > pl_thresh) {
-                pl_boxes[(long)n * topk + np] = b; pl_cls[n * topk + np] = c; pl_scores[n * topk + np] = s;
-                ++np;
-            }
         }
-        det_boxes[(long)n * topk + j] = b; det_scores[n * topk + j] = s; det_cls[n * topk + j] = c;
+        const bool pl = j < kc && s > pl_thresh;                     // pseudo-label: order of the detections kept
+        const unsigned long long m = __ballot(pl);
+        if (pl) {
+            const int q = np + __popcll(m & ((1ull << lane) - 1ull));
+            pl_boxes[(long)n * topk + q] = b; pl_cls[n * topk + q] = c; pl_scores[n * topk + q] = s;
+        }
+        np += __popcll(m);
+        if (j < topk) { det_boxes[(long)n * topk + j] = b; det_scores[n * topk + j] = s; det_cls[n * topk + j] = c; }
     }
-    for (int j = np; j < topk; ++j) { pl_boxes[(long)n * topk + j] = make_float4(0, 0, 0, 0); pl_cls[n * topk + j] = -1; pl_scores[n * topk + j] = 0.f; }
-    det_count[n] = kc;
-    pl_count[n] = np;
+    for (int j = np + lane; j < topk; j += 64) { pl_boxes[(long)n * topk + j] = make_float4(0, 0, 0, 0); pl_cls[n * topk + j] = -1; pl_scores[n * topk + j] = 0.f; }
+    if (lane == 0) { det_count[n] = kc; pl_count[n] = np; }
 }
 
 Feats make_feats(const aldi_roi_feats* f, bool bwd) {

@@ -526,16 +526,29 @@ __global__ __launch_bounds__(1024) void topk_collect_kernel(Geom g, const unsign
     const unsigned* kp = keys_all + (long)n * g.sumA + g.off[l] + (long)c * kTopkChunk;
     const int cnt = min(kTopkChunk, nel - c * kTopkChunk);
     unsigned long long* out = cand + (long)bl * kTopkCap;
-    const int lane = threadIdx.x & 63;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // ONE returning atomic per workgroup: count the chunk's winners first (wave ballots), reserve their slots together, then
+    // write.  A returning atomic per wave and key row put ~1800 serialised round trips on each (level, image) counter -- 90 us
+    // of the student's proposal chain.
+    int mine = 0;
+    for_each_key(kp, cnt, [&](unsigned key, int, bool ok) {
+        mine += __popcll(__ballot(ok && (key > kth || (take_all_eq && key == kth))));
+    });
+    __syncthreads();                                  // (find_bucket's readers of sm are done)
+    if (lane == 0) sm[wave] = mine;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int tot = 0;
+        for (int w = 0; w < 16; ++w) { const int v = sm[w]; sm[w] = tot; tot += v; }
+        sm[16] = tot ? atomicAdd(fill + bl, tot) : 0;
+    }
+    __syncthreads();
+    int pos = sm[16] + sm[wave];
     for_each_key(kp, cnt, [&](unsigned key, int i, bool ok) {
         const bool win = ok && (key > kth || (take_all_eq && key == kth));
         const unsigned long long m = __ballot(win);
-        if (m) {                                      // one global atomic per wave
-            int base = 0;
-            if (lane == 0) base = atomicAdd(fill + bl, __popcll(m));
-            base = __shfl(base, 0, 64);
-            if (win) out[base + __popcll(m & ((1ull << lane) - 1ull))] = ((unsigned long long)(~key) << 32) | (unsigned)(c * kTopkChunk + i);
-        }
+        if (win) out[pos + __popcll(m & ((1ull << lane) - 1ull))] = ((unsigned long long)(~key) << 32) | (unsigned)(c * kTopkChunk + i);
+        pos += __popcll(m);
     });
 }
 
