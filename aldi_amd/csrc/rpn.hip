@@ -809,7 +809,9 @@ extern "C" int aldi_rpn_proposals(const aldi_rpn_geom* gm, float* const* head, c
     ALDI_CHECK_LAUNCH();
     hipLaunchKernelGGL(nms_mask_kernel, dim3(cap / 64, cap / 64, (unsigned)B), dim3(64), 0, st, boxes, valid, (const int*)nullptr, cand_count, (int)cap, nms_thresh, mask);
     ALDI_CHECK_LAUNCH();
-    if (!nms_scan_launch(st, (int)B, mask, valid, cand_count, (int)cap, (int)cap, keep, keep_count)) return aldi_set_error_msg(ALDI_ERR_ARG, "rpn_proposals: NMS capacity too large");
+    // (a level can place at most post_nms_topk boxes in the image's merged list: its scan stops there)
+    if (!nms_scan_launch(st, (int)B, mask, valid, cand_count, (int)cap, post_nms_topk < (int)cap ? post_nms_topk : (int)cap, keep, keep_count))
+        return aldi_set_error_msg(ALDI_ERR_ARG, "rpn_proposals: NMS capacity too large");
     ALDI_CHECK_LAUNCH();
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(rpn_merge_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kMergeCap * 4);
     hipLaunchKernelGGL(rpn_merge_kernel, dim3(N), dim3(1024), kMergeCap * 4, st, g.nl, boxes, scores, keep, keep_count, post_nms_topk, (float4*)out_boxes, out_scores, out_count);
