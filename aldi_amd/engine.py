@@ -361,12 +361,12 @@ class RCNN:
         return t
 
     # ------------------------------------------------------------------ trunk
-    def _conv_call(self, x, name, *, relu=False, res=None, res_mode=0, want_f32=False):
+    def _conv_call(self, x, name, *, relu=False, res=None, res_mode=0, want_f32=False, out=None):
         """(x, weight, conv2d kwargs) of layer `name` applied to x"""
         W = self.wts
         p = W.layout.t[name]
         return x, W.w(name), dict(stride=p.stride, pad=p.pad, scale=W.scale(name), shift=W.shift(name), res=res, res_mode=res_mode, relu=relu,
-                                  want_f32=want_f32)
+                                  want_f32=want_f32, out=out)
 
     def conv(self, x, name, **kw):
         x, w, kw = self._conv_call(x, name, **kw)
@@ -460,12 +460,21 @@ class RCNN:
         self._drive(self.rpn_head_steps(c, save))
 
     def rpn_head_steps(self, c: Ctx, save: bool):
-        heads, ts = [], []
-        for f in c.P:
-            t = yield f, "proposal_generator.rpn_head.conv", dict(relu=True)
-            heads.append((yield t, "rpn_head_out", dict(want_f32=True)))
-            if save:
-                ts.append(t)
+        # The hidden maps of the five levels live in ONE buffer, level after level: the 1x1 objectness / delta heads (shared
+        # weights, pixel-wise) then run as a single launch over all 358 k pixel positions instead of five (the p2 one alone on
+        # the chip, the others far below one round of workgroups) on the student's serial proposal chain.
+        px = [f.shape[0] * f.shape[1] * f.shape[2] for f in c.P]
+        flat = torch.empty((1, sum(px), 1, FPN_C), dtype=self.dtype, device=self.device)
+        ts, o = [], 0
+        for f, n in zip(c.P, px):
+            view = flat[0, o:o + n, 0].view(f.shape[0], f.shape[1], f.shape[2], FPN_C)
+            ts.append((yield f, "proposal_generator.rpn_head.conv", dict(relu=True, out=view)))
+            o += n
+        hf = yield flat, "rpn_head_out", dict(want_f32=True)
+        heads, o = [], 0
+        for f, n in zip(c.P, px):
+            heads.append(hf[0, o:o + n, 0].view(f.shape[0], f.shape[1], f.shape[2], hf.shape[3]))
+            o += n
         c.head = heads
         if save:
             c.rpn_t = ts
