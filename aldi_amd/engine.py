@@ -475,7 +475,7 @@ class RCNN:
         for f, n in zip(c.P, px):
             heads.append(hf[0, o:o + n, 0].view(f.shape[0], f.shape[1], f.shape[2], hf.shape[3]))
             o += n
-        c.head = heads
+        c.head, c.head_flat = heads, hf
         if save:
             c.rpn_t = ts
 
@@ -712,11 +712,14 @@ class RCNN:
             acts.append(self.conv(acts[-1], name, relu=True))
         return acts, self.conv(acts[-1], self.ins_da_layers[-1], want_f32=True)
 
-    def distill_forward_chunk(self, c: Ctx, ch: dict, teacher_head, teacher_pred, labels, n_valid, n_fg, **kw):
-        """distillation losses of one chunk of a fused forward (teacher tensors cover exactly that chunk)"""
+    def distill_forward_chunk(self, c: Ctx, ch: dict, teacher_head, teacher_pred, labels, n_valid, n_fg, values=True, **kw):
+        """distillation losses of one chunk of a fused forward (teacher tensors cover exactly that chunk).  values = False: only
+        describe the losses; `backward_fused` then writes their values while it computes their gradients (ch["values_in_backward"])."""
         dev = self.device
         n0, n1, r0, r1 = ch["n0"], ch["n1"], ch["r0"], ch["r1"]
         ch["distill"] = dict(t_head=teacher_head, t_pred=teacher_pred, labels=labels, n_valid=n_valid, n_fg=n_fg, **kw)
+        if not values:
+            return
         ch["loss_dist_rpn"] = torch.zeros(2, dtype=torch.float32, device=dev)
         ch["loss_dist_roi"] = torch.zeros(2, dtype=torch.float32, device=dev)
         ops.rpn_distill_loss(c.geom, [h[n0:n1] for h in c.head], teacher_head, None, labels, n1 - n0, kw["obj_T"], n_valid, n_fg,
@@ -751,29 +754,49 @@ class RCNN:
         """backward of forward_train_fused: per-chunk loss gradients (scales[i] for chunk i) into the shared head-gradient
         buffers, then ONE pass heads -> FPN -> res5..res3 over all images."""
         T, dev = self.dtype, self.device
-        scratch = torch.zeros(2, dtype=torch.float32, device=dev)
-        c.ghead = [torch.zeros_like(h) for h in c.head]
+        # The loss kernels produce value AND gradient in one pass.  Chunks flagged `values_in_backward` (the fused step) take their
+        # loss values from THIS pass -- no separate value launches on the chain between the box head and the backward -- and all
+        # their small zero-initialised outputs come out of one arena (one fill instead of one per tensor).
+        arena = torch.zeros(2 + 8 * len(c.chunks), dtype=torch.float32, device=dev)
+        scratch = arena[:2]
+        hf = c.get("head_flat")
+        if hf is not None:                                   # one fill for the five levels' head gradients (views like c.head)
+            gf, o = torch.zeros_like(hf), 0
+            c.ghead = []
+            for h in c.head:
+                n = h.shape[0] * h.shape[1] * h.shape[2]
+                c.ghead.append(gf[0, o:o + n, 0].view(h.shape))
+                o += n
+        else:
+            c.ghead = [torch.zeros_like(h) for h in c.head]
         c.gpred = torch.zeros((max(c.R, 1), self.Cp), dtype=torch.float32, device=dev)
         gt = c.gt
         align_list = []
-        for ch, sc_ in zip(c.chunks, scales):
+        for ci, (ch, sc_) in enumerate(zip(c.chunks, scales)):
             sc = lambda k: float(sc_.get(k, 0.0))
             n0, n1, r0, r1 = ch["n0"], ch["n1"], ch["r0"], ch["r1"]
             nc = n1 - n0
             heads = [h[n0:n1] for h in c.head]
             gheads = [g[n0:n1] for g in c.ghead]
+            l_rpn = l_box = l_drpn = l_droi = scratch
+            if ch.get("values_in_backward"):
+                base = 2 + 8 * ci
+                l_rpn, l_box, l_drpn, l_droi = (arena[base + 2 * j: base + 2 * j + 2] for j in range(4))
+                ch["loss_rpn"], ch["loss_box"] = l_rpn, l_box
+                if ch["distill"] is not None:
+                    ch["loss_dist_rpn"], ch["loss_dist_roi"] = l_drpn, l_droi
             ops.rpn_loss(c.geom, heads, gheads, c.anchors, c.rpn_labels[n0:n1], c.rpn_matched[n0:n1], gt["boxes"][n0:n1], gt["count"][n0:n1],
-                         GMAX, nc, 1.0 / (RPN_BATCH * nc), sc("loss_rpn_cls"), sc("loss_rpn_loc"), scratch)
+                         GMAX, nc, 1.0 / (RPN_BATCH * nc), sc("loss_rpn_cls"), sc("loss_rpn_loc"), l_rpn)
             ops.box_loss(c.pred[r0:r1], self.Cp, self.K, r1 - r0, c.rois[r0:r1], c.r_cls[r0:r1], c.r_gt[r0:r1], ROI_WEIGHTS,
-                         sc("loss_cls"), sc("loss_box_reg"), c.gpred[r0:r1], scratch)
+                         sc("loss_cls"), sc("loss_box_reg"), c.gpred[r0:r1], l_box)
             d = ch["distill"]
             if d is not None:
                 def rpn_d(do_obj, do_reg, s_):
-                    ops.rpn_distill_loss(c.geom, heads, d["t_head"], gheads, d["labels"], nc, d["obj_T"], d["n_valid"], d["n_fg"], do_obj, do_reg, s_, scratch,
+                    ops.rpn_distill_loss(c.geom, heads, d["t_head"], gheads, d["labels"], nc, d["obj_T"], d["n_valid"], d["n_fg"], do_obj, do_reg, s_, l_drpn,
                                          counts_dev=d.get("counts_dev"))
 
                 def roi_d(do_cls, do_reg, s_):
-                    ops.roih_distill_loss(c.pred[r0:r1], d["t_pred"], self.Cp, self.K, r1 - r0, d["cls_T"], d["kl"], do_cls, do_reg, s_, c.gpred[r0:r1], scratch)
+                    ops.roih_distill_loss(c.pred[r0:r1], d["t_pred"], self.Cp, self.K, r1 - r0, d["cls_T"], d["kl"], do_cls, do_reg, s_, c.gpred[r0:r1], l_droi)
                 if sc("loss_obj_bce") == sc("loss_rpn_l1"):
                     rpn_d(d["do_obj"], d["do_rpn_reg"], sc("loss_obj_bce"))
                 else:

@@ -423,19 +423,18 @@ class FusedStep:
                     t_pred = teng.box_head_on(tc, rois_t, r1 - r0)
         eng.roi_forward(c)
         accum = S.accum
-        entries, scales = [], []
+        # ---- describe every chunk's losses and their gradient scales (host only), then ONE pass of loss kernels that yields
+        # values and gradients (engine.backward_fused) and the backward; the loss-dict arithmetic comes last, off the chain
+        LOSS_KEYS = ("loss_cls", "loss_box_reg", "loss_rpn_cls", "loss_rpn_loc")
+        scales = []
         for ch in S.chunks:
-            n0, n1, r0, r1 = ch["n0"], ch["n1"], ch["r0"], ch["r1"]
+            n0, n1 = ch["n0"], ch["n1"]
             nc = n1 - n0
-            ch["loss_rpn"] = torch.zeros(2, dtype=torch.float32, device=dev)
-            ch["loss_box"] = torch.zeros(2, dtype=torch.float32, device=dev)
-            ops.rpn_loss(c.geom, [h[n0:n1] for h in c.head], None, c.anchors, labels[n0:n1], c.rpn_matched[n0:n1], c.gt["boxes"][n0:n1],
-                         c.gt["count"][n0:n1], GMAX, nc, 1.0 / (RPN_BATCH * nc), 0.0, 0.0, ch["loss_rpn"])
-            ops.box_loss(c.pred[r0:r1], eng.Cp, eng.K, r1 - r0, c.rois[r0:r1], c.r_cls[r0:r1], c.r_gt[r0:r1], ROI_WEIGHTS, 0.0, 0.0, None, ch["loss_box"])
+            ch["values_in_backward"] = True
             ch["align"], ch["distill"] = {}, None
             if ch["do_align"]:
                 eng._align_forward_chunk(c, ch)
-            losses = eng.chunk_loss_dict(ch)
+            keys = list(LOSS_KEYS) + [k for k in ("loss_da_img", "loss_da_ins") if k[8:] in ch["align"]]
             keep = ch["keep"]
             if ch["kind"] == "distill":
                 hard = {"loss_cls": dist_.do_hard_cls, "loss_rpn_cls": dist_.do_hard_obj, "loss_rpn_loc": dist_.do_hard_rpn_reg,
@@ -444,27 +443,41 @@ class FusedStep:
                     main.wait_stream(S.tside)
                 dl = torch.empty((nc, sumA), dtype=torch.int32, device=dev)
                 ops.rpn_apply_sample(dl, sumA, nc, c.rpn_lists[n0:n1], U.d("dsel"), U.d("dnsel"), RPN_BATCH)
-                eng.distill_forward_chunk(c, ch, tc.head, t_pred, dl, Hst.n_valid, Hst.n_fg, obj_T=float(dist_.obj_temperature),
+                eng.distill_forward_chunk(c, ch, tc.head, t_pred, dl, Hst.n_valid, Hst.n_fg, values=False, obj_T=float(dist_.obj_temperature),
                                           cls_T=float(dist_.cls_temperature), kl=dist_.cls_loss_type == "KL", do_obj=dist_.do_obj_dst,
                                           do_rpn_reg=dist_.do_rpn_reg_dst, do_cls=dist_.do_cls_dst, do_roih_reg=dist_.do_roih_reg_dst,
                                           counts_dev=U.d("nvf"))
-                out, sc = {}, {}
+                ch["hard"] = hard
+                sc = {k: (1.0 if hard.get(k, False) else 0.0) / accum for k in keys}
+                k_ = ch["distill"]
+                for k, on in (("loss_obj_bce", k_["do_obj"]), ("loss_rpn_l1", k_["do_rpn_reg"]), ("loss_cls_ce", k_["do_cls"]), ("loss_roih_l1", k_["do_roih_reg"])):
+                    if on:
+                        sc[k] = 1.0 / accum
+            else:
+                sc = {k: (1.0 / accum if keep(k) else 0.0) for k in keys}
+            scales.append(sc)
+        c.chunks = S.chunks
+        c.align, c.distill = {}, None
+        eng.backward_fused(c, scales)
+        # ---- the logged loss dict (values written by the pass above): `v * 0.0`, `/ accum` for all entries in a handful of launches
+        entries = []
+        for ch in S.chunks:
+            losses = eng.chunk_loss_dict(ch)
+            keep = ch["keep"]
+            if ch["kind"] == "distill":
+                hard = ch["hard"]
+                out = {}
                 for k, v in losses.items():
                     out[k] = v if hard.get(k, False) else (v, 0.0)      # the reference's `v * 0.0` (aldi/distill.py:181-186)
-                    sc[k] = (1.0 if hard.get(k, False) else 0.0) / accum
                 if S.has_disc:
                     out["_da"] = torch.zeros((), device=dev)
                 for k, v in eng.chunk_distill_loss_dict(ch).items():
                     out[k] = v
-                    sc[k] = 1.0 / accum
             else:
                 out = losses
-                sc = {k: (1.0 / accum if keep(k) else 0.0) for k in losses}
-            scales.append(sc)
             for k, v in out.items():
                 if keep(k):
                     entries.append((f"{k}_{ch['name']}", v))
-        # loss-dict arithmetic (`v * 0.0`, `/ accum`) for all entries in a handful of launches
         kept = [(n_, v) for n_, v in entries if not isinstance(v, tuple)]
         masked = [(n_, v[0]) for n_, v in entries if isinstance(v, tuple)]
         vals = {}
@@ -477,9 +490,6 @@ class FusedStep:
         loss_dict = {}
         for n_, _ in entries:                                  # original key order
             loss_dict[n_] = loss_dict[n_] + vals[n_] if n_ in loss_dict else vals[n_]
-        c.chunks = S.chunks
-        c.align, c.distill = {}, None
-        eng.backward_fused(c, scales)
         fields = {k: c[k] for k in ("rpn_labels", "R", "rows", "rois", "r_cls", "r_gt", "r_idx", "pred", "pooled", "fc1", "fc2", "ghead", "gpred") if k in c}
         return SimpleNamespace(loss_dict=loss_dict, fields=fields, chunks=[dict(ch) for ch in S.chunks])
 

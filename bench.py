@@ -204,10 +204,10 @@ def cpu_baseline(cfg, height, width):
 
 
 def profile_insitu(step_fn, table_path=None):
-    """One step with a HIP-event pair around EVERY dense launch, recorded on the stream the kernel is launched on (the
-    engine runs three streams: torch's current stream at the call IS the launch stream).  Durations are what the kernel
-    took inside the real step -- other streams' kernels sharing the chip included -- not warm back-to-back replays.
-    -> per-family {launches, flops, ms, bytes}."""
+    """One step with a HIP-event pair around EVERY dense launch, recorded on the stream the kernel is launched on (torch's
+    current stream at the call IS the launch stream; the caller runs the step on one stream so that a kernel's duration is
+    its own).  Durations are what the kernel took inside the real step -- real inputs, cold caches -- not warm back-to-back
+    replays.  -> per-family {launches, flops, ms, bytes}."""
     from aldi_amd import ops
     rec = []
     orig_conv, orig_wg = ops.conv2d, ops.conv_wgrad
@@ -411,7 +411,23 @@ def main():
         graph_was = fs.graph_enabled if fs is not None else False
         if fs is not None:
             fs.graph_enabled = False                # the profiled step issues every launch from Python so that each one can be bracketed
-        prof = profile_insitu(one_step, os.path.join(ROOT, "gpurun_out", "dense_profile_insitu.txt"))
+        # ... and on ONE stream: a kernel's duration is then its own (alone on the chip, as rocprofv3 --kernel-trace, which
+        # serialises the step's three branches, reports it in profiles/), not inflated by whatever the other two streams run beside it
+        import aldi_amd.trainer as _T
+        engines = [tr.model.engine] + ([tr.ema.model.engine] if getattr(tr, "ema", None) is not None else [])
+        saved = [(e, e.__dict__.get("_wg_side", "absent")) for e in engines]
+        for e in engines:
+            e._wg_side, e._wgrad_pending = None, False
+        ts_fn, _T._teacher_stream = _T._teacher_stream, (lambda device: None)
+        try:
+            prof = profile_insitu(one_step, os.path.join(ROOT, "gpurun_out", "dense_profile_insitu.txt"))
+        finally:
+            _T._teacher_stream = ts_fn
+            for e, v in saved:
+                if v == "absent":
+                    e.__dict__.pop("_wg_side", None)
+                else:
+                    e._wg_side = v
         if fs is not None:
             fs.graph_enabled = graph_was
         if args.replay_profile:
@@ -425,7 +441,7 @@ def main():
                            "traffic": round(tj["igemm"]["hbm_bytes_per_launch"]) if tj else None,
                            "traffic_unit": "HBM bytes per igemm launch, rocprofv3 PMC passes of this command (FETCH_SIZE x2 + WRITE_SIZE)",
                            "traffic_source": tfile if tj else "no profiles/r*_pmc_traffic.json matches this source tree (tools/source_hash.py)",
-                           "timing": "HIP events on the launch stream around every launch of one in-situ step (three streams active)",
+                           "timing": "HIP events around every dense launch of one extra step issued eagerly on one stream (each kernel alone on the chip, as in the rocprofv3 kernel trace under profiles/)",
                            "algorithmic_bytes_per_launch": round(ig["bytes"] / max(ig["launches"], 1)),
                            "launches_per_step": ig["launches"], "kernel_ms_per_step": round(ig["ms"], 3),
                            "avg_launch_us": round(ig["ms"] * 1e3 / max(ig["launches"], 1), 2),

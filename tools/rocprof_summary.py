@@ -112,7 +112,7 @@ def phases(d):
         return v
     marks = [("first stem (forward starts)", first("stem_")), ("last stem start", max((s - t0) / 1e6 for n, s, e in step if "stem_" in n)),
              ("first topk_hist (proposals)", first("topk_hist")), ("det_finish end (teacher inference done)", last("det_finish")),
-             ("match_iou first", first("match_iou")), ("compact end (counts ready -> host sync)", last("compact_kernel")),
+             ("match_iou first", first("match_iou")), ("compact end (counts ready -> host sync)", last("compact_write")),
              ("sample_scatter first (host sampling done)", first("sample_scatter")), ("roi_gather", first("roi_gather")),
              ("first wgrad (backward running)", first("wgrad_")), ("roialign bwd start", first("roialign_bwd")), ("roialign bwd end", last("roialign_bwd")),
              ("last igemm end", last("igemm_kernel")), ("last wgrad end", last("wgrad_")), ("sgd start", (rows[b][1] - t0) / 1e6), ("sgd end", (rows[b][2] - t0) / 1e6)]
