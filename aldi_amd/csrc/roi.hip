@@ -627,7 +627,7 @@ __global__ __launch_bounds__(1024) void det_sort_kernel(const float* __restrict_
 
 // first `keep_count` survivors -> detections; detections with score > thr -> pseudo-labels (order preserved)
 __global__ void det_finish_kernel(const float4* __restrict__ boxes, const float* __restrict__ scores, const int* __restrict__ cats,
-                                  const int* __restrict__ keep, const int* __restrict__ keep_count, int topk, float pl_thresh,
+                                  const int* __restrict__ keep, const int* __restrict__ keep_count, int topk, int pl_rows, float pl_thresh,
                                   float4* __restrict__ det_boxes, float* __restrict__ det_scores, int* __restrict__ det_cls, int* __restrict__ det_count,
                                   float4* __restrict__ pl_boxes, int* __restrict__ pl_cls, float* __restrict__ pl_scores, int* __restrict__ pl_count) {
     // one wave per image, 64 detections per round (a single thread walking `topk` dependent loads was a 27 us chain)
@@ -647,12 +647,16 @@ __global__ void det_finish_kernel(const float4* __restrict__ boxes, const float*
         const unsigned long long m = __ballot(pl);
         if (pl) {
             const int q = np + __popcll(m & ((1ull << lane) - 1ull));
-            pl_boxes[(long)n * topk + q] = b; pl_cls[n * topk + q] = c; pl_scores[n * topk + q] = s;
+            pl_boxes[(long)n * pl_rows + q] = b; pl_cls[n * pl_rows + q] = c; pl_scores[n * pl_rows + q] = s;
         }
         np += __popcll(m);
         if (j < topk) { det_boxes[(long)n * topk + j] = b; det_scores[n * topk + j] = s; det_cls[n * topk + j] = c; }
     }
-    for (int j = np + lane; j < topk; j += 64) { pl_boxes[(long)n * topk + j] = make_float4(0, 0, 0, 0); pl_cls[n * topk + j] = -1; pl_scores[n * topk + j] = 0.f; }
+    // (rows of pl_rows >= topk entries -- the caller's ground-truth slots; the class of an unused slot is -1 up to topk, 0 beyond, as
+    // a zero-filled buffer with a [topk] block copied in would read)
+    for (int j = np + lane; j < pl_rows; j += 64) {
+        pl_boxes[(long)n * pl_rows + j] = make_float4(0, 0, 0, 0); pl_cls[n * pl_rows + j] = j < topk ? -1 : 0; pl_scores[n * pl_rows + j] = 0.f;
+    }
     if (lane == 0) { det_count[n] = kc; pl_count[n] = np; }
 }
 
@@ -767,8 +771,9 @@ extern "C" size_t aldi_detections_workspace(int N) {
 extern "C" int aldi_detections(const float* pred, int Cp, int K, const float* props, const int* pcount, int P, int N, const int* img_hw,
                                const float* weights4, float score_thresh, float nms_thresh, int topk, float pl_thresh, void* workspace,
                                float* det_boxes, float* det_scores, int* det_cls, int* det_count,
-                               float* pl_boxes, int* pl_cls, float* pl_scores, int* pl_count, int* err_flag, aldi_stream_t stream) {
+                               float* pl_boxes, int* pl_cls, float* pl_scores, int* pl_count, int pl_rows, int* err_flag, aldi_stream_t stream) {
     if (!pred || !props || !pcount || !img_hw || !workspace || !weights4) return aldi_set_error_msg(ALDI_ERR_ARG, "detections: null pointer");
+    if (pl_rows < topk) return aldi_set_error_msg(ALDI_ERR_ARG, "detections: pl_rows < topk");
     hipStream_t st = static_cast<hipStream_t>(stream);
     const size_t cap = kDetCap;
     char* w = static_cast<char*>(workspace);
@@ -794,7 +799,7 @@ extern "C" int aldi_detections(const float* pred, int Cp, int K, const float* pr
     ALDI_CHECK_LAUNCH();
     if (!nms_scan_launch(st, N, mask, valid, cnt, (int)cap, topk, keep, keep_count)) return aldi_set_error_msg(ALDI_ERR_ARG, "detections: NMS capacity too large");
     ALDI_CHECK_LAUNCH();
-    hipLaunchKernelGGL(det_finish_kernel, dim3(N), dim3(64), 0, st, boxes, scores, cats, keep, keep_count, topk, pl_thresh,
+    hipLaunchKernelGGL(det_finish_kernel, dim3(N), dim3(64), 0, st, boxes, scores, cats, keep, keep_count, topk, pl_rows, pl_thresh,
                        (float4*)det_boxes, det_scores, det_cls, det_count, (float4*)pl_boxes, pl_cls, pl_scores, pl_count);
     ALDI_CHECK_LAUNCH();
     return ALDI_OK;

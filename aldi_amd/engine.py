@@ -931,16 +931,18 @@ class RCNN:
         return pred
 
     # ------------------------------------------------------------------ inference (teacher)
-    def inference(self, images, pl_thresh: float, keep_ctx: bool = True, staged=None) -> Ctx:
+    def inference(self, images, pl_thresh: float, keep_ctx: bool = True, staged=None, pl_out=None) -> Ctx:
         """GeneralizedRCNN.inference(do_postprocess=False) + process_pseudo_label threshold
         (aldi/pseudolabeler.py:15-67).  Everything stays on device.  `staged` = (uint8 batch, sizes, hw) already in HBM."""
         st, sizes, hw = staged if staged is not None else self.stage_images(images)
         c = self.trunk(st, sizes, save=False)
         self.rpn_head(c, save=False)
-        return self.inference_heads(c, st, sizes, hw, pl_thresh)
+        return self.inference_heads(c, st, sizes, hw, pl_thresh, pl_out=pl_out)
 
-    def inference_heads(self, c: Ctx, st, sizes, hw, pl_thresh: float) -> Ctx:
-        """everything of the inference pass after the trunk and the RPN head (which may have run paired with another model's)"""
+    def inference_heads(self, c: Ctx, st, sizes, hw, pl_thresh: float, pl_out=None) -> Ctx:
+        """everything of the inference pass after the trunk and the RPN head (which may have run paired with another model's).
+        pl_out = (boxes [N][GMAX][4], classes [N][GMAX], count [N]): write the pseudo-labels straight into the caller's
+        ground-truth slots (the fused step's: no copies / concatenations between the detections and the anchor matcher)."""
         N = st.shape[0]
         shapes, geom, anchors = self.geometry(st.shape[2], st.shape[3])
         c.N, c.sizes, c.hw, c.geom, c.anchors, c.shapes = N, sizes, hw, geom, anchors, shapes
@@ -958,19 +960,16 @@ class RCNN:
         d.scores = torch.empty((N, DETS), dtype=torch.float32, device=dev)
         d.classes = torch.empty((N, DETS), dtype=torch.int32, device=dev)
         d.count = torch.empty((N,), dtype=torch.int32, device=dev)
-        pl_boxes = torch.zeros((N, GMAX, 4), dtype=torch.float32, device=dev)
-        pl_cls = torch.zeros((N, GMAX), dtype=torch.int32, device=dev)
-        pl_scores = torch.zeros((N, GMAX), dtype=torch.float32, device=dev)
-        pl_count = torch.empty((N,), dtype=torch.int32, device=dev)
-        # pl_* rows are [N][DETS] inside the kernel; allocate exact views
-        plb = torch.empty((N, DETS, 4), dtype=torch.float32, device=dev)
-        plc = torch.empty((N, DETS), dtype=torch.int32, device=dev)
-        pls = torch.empty((N, DETS), dtype=torch.float32, device=dev)
+        if pl_out is not None:
+            pl_boxes, pl_cls, pl_count = pl_out
+        else:
+            pl_boxes = torch.empty((N, GMAX, 4), dtype=torch.float32, device=dev)
+            pl_cls = torch.empty((N, GMAX), dtype=torch.int32, device=dev)
+            pl_count = torch.empty((N,), dtype=torch.int32, device=dev)
+        pl_scores = torch.empty((N, GMAX), dtype=torch.float32, device=dev)
+        # the kernel writes rows of GMAX entries and clears what it does not fill
         ops.detections(pred, self.Cp, self.K, props, pcount, P, N, hw, ROI_WEIGHTS, SCORE_THRESH, NMS_TEST, DETS, pl_thresh, ws,
-                       d.boxes, d.scores, d.classes, d.count, plb, plc, pls, pl_count, self.err)
-        pl_boxes[:, :DETS] = plb
-        pl_cls[:, :DETS] = plc
-        pl_scores[:, :DETS] = pls
+                       d.boxes, d.scores, d.classes, d.count, pl_boxes, pl_cls, pl_scores, pl_count, self.err)
         c.det = d
         c.pseudo = {"boxes": pl_boxes, "classes": pl_cls, "count": pl_count, "scores": pl_scores}
         c.props, c.prop_count, c.pred_all = props, pcount, pred

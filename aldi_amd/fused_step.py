@@ -106,16 +106,17 @@ class FusedStep:
             st.img[i, :, : sizes[i][0], : sizes[i][1]].copy_(im, non_blocking=True)
         return st
 
-    def _stage_gt(self, S, insts: List[dict]):
-        """ground truth of the labeled chunks (host records) -> static device buffers through one pinned upload"""
-        n = len(insts)
-        if S.gt_pack is None or S.gt_pack.n != n:
-            S.gt_pack = _Packed([("boxes", (n, GMAX, 4), torch.float32), ("classes", (n, GMAX), torch.int32), ("count", (n,), torch.int32)], self.eng.device)
-            S.gt_pack.n = n
+    def _stage_gt(self, S, rows, N: int):
+        """ground truth of ALL N images of the fused batch in static device buffers through one pinned upload: the labeled images'
+        records (rows = [(image index, record)]), zero rows for the others -- the distillation chunk's rows are then written by
+        the teacher's detection kernel itself (its pseudo-labels), so the matcher reads one buffer and nothing is concatenated"""
+        if S.gt_pack is None or S.gt_pack.n != N:
+            S.gt_pack = _Packed([("boxes", (N, GMAX, 4), torch.float32), ("classes", (N, GMAX), torch.int32), ("count", (N,), torch.int32)], self.eng.device)
+            S.gt_pack.n = N
         P = S.gt_pack
         gb, gc, cnt = P.h("boxes"), P.h("classes"), P.h("count")
-        gb.zero_(); gc.zero_()
-        for i, inst in enumerate(insts):
+        gb.zero_(); gc.zero_(); cnt.zero_()
+        for i, inst in rows:
             b = inst["gt_boxes"]
             b = b.tensor if hasattr(b, "tensor") else b
             g = int(b.shape[0])
@@ -157,7 +158,7 @@ class FusedStep:
                 with torch.cuda.stream(tside), torch.no_grad():
                     if S.ema_mode is not None:
                         teng.wts.ema_from(eng.wts, S.ema_alpha, copy_only=S.ema_mode == "copy")
-                    tc_early = teng.inference(None, dist_.pseudo_label_threshold, staged=(tea.img, tea.sizes, tea.hw))
+                    tc_early = teng.inference(None, dist_.pseudo_label_threshold, staged=(tea.img, tea.sizes, tea.hw), pl_out=S.pl_out)
             c = eng.trunk(stu.img, stu.sizes, save=True)
             eng.rpn_head(c, save=True)
         c.N, c.sizes, c.hw, c.geom, c.anchors, c.shapes = N, stu.sizes, stu.hw, geom, anchors, shapes
@@ -179,10 +180,10 @@ class FusedStep:
             # and is ENQUEUED after it (issued first its launches would run alone while the student's are still being queued).
             def teacher_pass():
                 if pair:
-                    return teng.inference_heads(tcx, tea.img, tea.sizes, tea.hw, dist_.pseudo_label_threshold)
+                    return teng.inference_heads(tcx, tea.img, tea.sizes, tea.hw, dist_.pseudo_label_threshold, pl_out=S.pl_out)
                 if S.ema_mode is not None:                   # the EMA tick of this iteration (aldi/trainer.py:242-246), beside the student's forward
                     teng.wts.ema_from(eng.wts, S.ema_alpha, copy_only=S.ema_mode == "copy")
-                return teng.inference(None, dist_.pseudo_label_threshold, staged=(tea.img, tea.sizes, tea.hw))
+                return teng.inference(None, dist_.pseudo_label_threshold, staged=(tea.img, tea.sizes, tea.hw), pl_out=S.pl_out)
             if tside is not None and self.teacher_first and not pair:
                 tc = tc_early
                 main.wait_stream(tside)
@@ -197,18 +198,9 @@ class FusedStep:
             else:
                 with torch.no_grad():
                     tc = teacher_pass()
-        # ground truth per chunk: uploaded labels | none (target-weak alignment rows) | the teacher's pseudo-labels
-        parts, lab0 = [], 0
-        for ch in S.chunks:
-            n = ch["n1"] - ch["n0"]
-            if ch["kind"] == "distill":
-                parts.append({k: tc.pseudo[k] for k in ("boxes", "classes", "count")})
-            elif ch["kind"] == "labeled":
-                parts.append({k: S.gt_lab[k][lab0:lab0 + n] for k in ("boxes", "classes", "count")})
-                lab0 += n
-            else:
-                parts.append(S.gt_none(n))
-        gt = {k: torch.cat([p[k] for p in parts]) for k in ("boxes", "classes", "count")}
+        # ground truth of all chunks: the staged buffers (labels uploaded in phase 0, zero rows for unlabeled chunks, the
+        # distillation chunk's rows written by the teacher's detection kernel above)
+        gt = S.gt_all
         c.gt = gt
         _, matched, lists, counts = eng.rpn_match(geom, anchors, gt, N)
         c.rpn_matched, c.rpn_lists, c.rpn_counts = matched, lists, counts
@@ -499,7 +491,7 @@ class FusedStep:
         if S is None:
             if len(self.static) >= 4:                          # multi-scale input: keep the most recent shapes only
                 self.static.pop(next(iter(self.static)))
-            S = SimpleNamespace(bufs={}, gt_pack=None, up=None, h_counts=None, graph_a=None, A=None, graphs_b={}, none_gt={})
+            S = SimpleNamespace(bufs={}, gt_pack=None, up=None, h_counts=None, graph_a=None, A=None, graphs_b={})
             self.static[key] = S
         else:
             self.static[key] = self.static.pop(key)
@@ -521,7 +513,7 @@ class FusedStep:
         self.teng = teacher.engine if teacher is not None else None
         dev = eng.device
         # ---- phase 0: describe the chunks, stage the inputs into their fixed buffers
-        images, lab_insts, chunks, n0 = [], [], [], 0
+        images, lab_rows, chunks, n0 = [], [], [], 0
         da = model.cfg.DOMAIN_ADAPT.ALIGN
         for row in plan:
             n1 = n0 + len(row.data)
@@ -531,7 +523,7 @@ class FusedStep:
                                keep=row.keep))
             images += [d["image"] for d in row.data]
             if kind == "labeled":
-                lab_insts += [as_record(d["instances"]) for d in row.data]
+                lab_rows += [(n0 + j, as_record(d["instances"])) for j, d in enumerate(row.data)]
             n0 = n1
         N = n0
         # the EMA tick handed over by ALDITrainer.before_step: copy while iter <= start_iter, else lerp (aldi/ema.py:52-57)
@@ -552,14 +544,11 @@ class FusedStep:
         S.tside = _teacher_stream(dev) if do_distill else None
         S.stu = self._stage_images(S, "student", images)
         S.tea = self._stage_images(S, "teacher", [d["image"] for d in unlabeled_weak]) if do_distill else None
-        S.gt_lab = self._stage_gt(S, lab_insts) if lab_insts else None
-
-        def gt_none(n):
-            if n not in S.none_gt:
-                S.none_gt[n] = {"boxes": torch.zeros((n, GMAX, 4), dtype=torch.float32, device=dev),
-                                "classes": torch.zeros((n, GMAX), dtype=torch.int32, device=dev), "count": torch.zeros((n,), dtype=torch.int32, device=dev)}
-            return S.none_gt[n]
-        S.gt_none = gt_none
+        S.gt_all = self._stage_gt(S, lab_rows, N)
+        S.pl_out = None
+        if do_distill:
+            d0, d1 = chunks[-1]["n0"], chunks[-1]["n1"]
+            S.pl_out = tuple(S.gt_all[k][d0:d1] for k in ("boxes", "classes", "count"))
         if S.up is None:
             nd = (chunks[-1]["n1"] - chunks[-1]["n0"]) if do_distill else 1
             S.up = _Packed([("rsel", (N, 2, RPN_BATCH), torch.int32), ("rnsel", (N, 2), torch.int32), ("osel", (N, 2, ROI_BATCH), torch.int32),

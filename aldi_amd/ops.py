@@ -400,7 +400,7 @@ def detections(pred, Cp, K, props, pcount, P, N, img_hw, weights4, score_thresh,
     w = (C.c_float * 4)(*weights4)
     L.call("aldi_detections", _p(pred), Cp, K, _p(props), _p(pcount), P, N, _p(img_hw), w, score_thresh, nms_thresh, topk, pl_thresh,
            _p(workspace), _p(det_boxes), _p(det_scores), _p(det_cls), _p(det_count), _p(pl_boxes), _p(pl_cls), _p(pl_scores), _p(pl_count),
-           _p(err), stream_ptr())
+           pl_boxes.shape[1], _p(err), stream_ptr())
 
 
 # ------------------------------------------------------------------------------- ALDI losses

@@ -284,11 +284,12 @@ int aldi_box_loss(const float* pred, int Cp, int K, int R, const float* rois, co
                   const float* weights4, float grad_scale_cls, float grad_scale_box, float* grad, float* loss2, aldi_stream_t stream);
 size_t aldi_detections_workspace(int N);
 /* fast_rcnn_inference + pseudo-label filter. pred fp32 [N*P][Cp] for all proposals.
- * det_* [N][topk], pl_* [N][topk] (detections with score > pl_thresh, order kept), counts [N]. */
+ * det_* [N][topk], pl_* [N][pl_rows >= topk] (detections with score > pl_thresh, order kept, the rest of each row cleared: the
+ * rows can be the ground-truth slots the matcher reads), counts [N]. */
 int aldi_detections(const float* pred, int Cp, int K, const float* props, const int* pcount, int P, int N, const int* img_hw,
                     const float* weights4, float score_thresh, float nms_thresh, int topk, float pl_thresh, void* workspace,
                     float* det_boxes, float* det_scores, int* det_cls, int* det_count,
-                    float* pl_boxes, int* pl_cls, float* pl_scores, int* pl_count, int* err_flag, aldi_stream_t stream);
+                    float* pl_boxes, int* pl_cls, float* pl_scores, int* pl_count, int pl_rows, int* err_flag, aldi_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------
  * ALDI-owned losses (forward + backward fused).
