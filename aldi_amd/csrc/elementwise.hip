@@ -575,6 +575,47 @@ extern "C" int aldi_maxpool3s2(const void* x, void* y, int N, int H, int W, int 
     return ALDI_OK;
 }
 
+// Input staging: up to 16 uint8 CHW images of their own sizes -> rows [n][c][0..h)[0..w) of the padded batch buffer, ONE launch
+// (the reference's ImageList.from_tensors, detectron2 via aldi/trainer.py:28; per-image strided copies were 6 launches on the
+// chain before the step's first graph).  The padding of the buffer is not touched.
+constexpr int kMaxStage = 16;
+struct StageDev { const unsigned char* src[kMaxStage]; int h[kMaxStage], w[kMaxStage]; int n, C, Hs, Ws; };
+__global__ __launch_bounds__(256) void stage_images_kernel(StageDev p, unsigned char* __restrict__ dst) {
+    const int i = blockIdx.z, c = blockIdx.y;
+    const int h = p.h[i], w = p.w[i];
+    const unsigned char* s = p.src[i] + (long)c * h * w;
+    unsigned char* d = dst + ((long)i * p.C + c) * p.Hs * p.Ws;
+    for (int row = blockIdx.x; row < h; row += gridDim.x) {
+        const unsigned char* sr = s + (long)row * w;
+        unsigned char* dr = d + (long)row * p.Ws;
+        // 4-byte body when both rows start aligned, bytes otherwise / for the tail
+        if ((((uintptr_t)sr | (uintptr_t)dr) & 3) == 0) {
+            const int w4 = w >> 2;
+            for (int x = threadIdx.x; x < w4; x += blockDim.x) reinterpret_cast<unsigned*>(dr)[x] = reinterpret_cast<const unsigned*>(sr)[x];
+            for (int x = (w4 << 2) + threadIdx.x; x < w; x += blockDim.x) dr[x] = sr[x];
+        } else {
+            for (int x = threadIdx.x; x < w; x += blockDim.x) dr[x] = sr[x];
+        }
+    }
+}
+
+extern "C" int aldi_stage_images(const void* const* images, const int* heights, const int* widths, int n, int C, int Hs, int Ws, void* batch,
+                                 aldi_stream_t stream) {
+    if (!images || !heights || !widths || !batch || n < 1 || n > kMaxStage || C < 1) return aldi_set_error_msg(ALDI_ERR_ARG, "stage_images: bad args (1..16 images)");
+    StageDev p;
+    p.n = n; p.C = C; p.Hs = Hs; p.Ws = Ws;
+    int hmax = 1;
+    for (int i = 0; i < kMaxStage; ++i) {
+        p.src[i] = i < n ? static_cast<const unsigned char*>(images[i]) : nullptr;
+        p.h[i] = i < n ? heights[i] : 0; p.w[i] = i < n ? widths[i] : 0;
+        if (i < n && (!images[i] || heights[i] < 0 || widths[i] < 0 || heights[i] > Hs || widths[i] > Ws)) return aldi_set_error_msg(ALDI_ERR_ARG, "stage_images: image larger than the batch");
+        if (p.h[i] > hmax) hmax = p.h[i];
+    }
+    hipLaunchKernelGGL(stage_images_kernel, dim3(hmax < 256 ? hmax : 256, C, n), dim3(256), 0, static_cast<hipStream_t>(stream), p, static_cast<unsigned char*>(batch));
+    ALDI_CHECK_LAUNCH();
+    return ALDI_OK;
+}
+
 extern "C" int aldi_subsample2(const void* x, void* y, int N, int H, int W, int C, int backward, int dtype, aldi_stream_t stream) {
     int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
     long total = (long)N * Ho * Wo * (C / 4);

@@ -102,8 +102,11 @@ class FusedStep:
                 st.img.zero_()                               # smaller images than last step: the padding must read zero
             st.hw.copy_(torch.tensor(sizes, dtype=torch.int32))
             st.sizes = sizes
-        for i, im in enumerate(images):
-            st.img[i, :, : sizes[i][0], : sizes[i][1]].copy_(im, non_blocking=True)
+        if all(im.is_cuda and im.dtype == torch.uint8 and im.is_contiguous() for im in images) and len(images) <= 16:
+            ops.stage_images(images, st.img)                 # one launch for the batch
+        else:
+            for i, im in enumerate(images):
+                st.img[i, :, : sizes[i][0], : sizes[i][1]].copy_(im, non_blocking=True)
         return st
 
     def _stage_gt(self, S, rows, N: int):
@@ -170,10 +173,14 @@ class FusedStep:
                 c.props, c.prop_scores, c.prop_count = eng.proposals(c, geom, anchors, stu.hw, N, training=True)
                 if S.lazy_wt:
                     eng.wts._refresh_wt()                   # the backward's dgrad weights of the weights SGD just wrote: off the critical path
+                if S.zero_grad:
+                    eng.wts.grad.zero_()                    # 164 MB: nothing reads or adds to it before phase B
         else:
             c.props, c.prop_scores, c.prop_count = eng.proposals(c, geom, anchors, stu.hw, N, training=True)
             if S.lazy_wt:
                 eng.wts._refresh_wt()
+            if S.zero_grad:
+                eng.wts.grad.zero_()
         tc = None
         if S.distill:
             # The teacher's inference (N = 2, mostly small launches) runs on its own stream beside the student's label-free work
@@ -497,7 +504,7 @@ class FusedStep:
             self.static[key] = self.static.pop(key)
         return S
 
-    def run(self, labeled_weak, labeled_strong, unlabeled_weak, unlabeled_strong, ema=None):
+    def run(self, labeled_weak, labeled_strong, unlabeled_weak, unlabeled_strong, ema=None, zero_grad=False):
         from .model import DevicePseudoLabels
         from .trainer import _schedule_flags, _teacher_stream, plan_micro_steps
         tr = self.tr
@@ -534,10 +541,13 @@ class FusedStep:
             else:
                 ema[0].update_weights(model, ema[1])               # not the teacher of this step's distiller: nothing to overlap with
         key = (tuple((ch["name"], ch["n1"] - ch["n0"]) for ch in chunks), tuple(tuple(im.shape[1:]) for im in images),
-               tuple(tuple(d["image"].shape[1:]) for d in (unlabeled_weak or [])) if do_distill else (), ema_mode)
+               tuple(tuple(d["image"].shape[1:]) for d in (unlabeled_weak or [])) if do_distill else (), ema_mode, bool(zero_grad))
         S = self._static_for(key)
         S.N, S.chunks, S.accum, S.distill, S.has_disc = N, chunks, accum, do_distill, do_align
         S.ema_mode, S.ema_alpha = ema_mode, (ema[0].alpha if ema is not None else None)
+        S.zero_grad = bool(zero_grad)                              # clear the gradient buffer inside phase A, beside the forward
+        if zero_grad:
+            eng.wts._gscale = 1.0                                  # (the host half of Weights.zero_grad: a replayed graph does not run it)
         S.lazy_wt = hasattr(eng.wts, "_refresh_wt")               # (the flat-container models re-derive theirs inside adamw_step)
         if S.lazy_wt:
             eng.wts.lazy_wt = True

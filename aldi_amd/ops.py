@@ -313,6 +313,15 @@ def box_match(boxes, box_stride_n, box_count, Lb, gt_boxes, gt_count, Gmax, N, l
            _p(best_iou), _p(best_idx), _p(scratch), _p(labels), stream_ptr())
 
 
+def stage_images(images, batch: torch.Tensor) -> None:
+    """uint8 CHW device images (their own sizes) -> batch[i, :, :h, :w], one launch (aldi_stage_images)"""
+    n = len(images)
+    ptr = (C.c_void_p * n)(*[_p(im) for im in images])
+    hs = (C.c_int * n)(*[int(im.shape[1]) for im in images])
+    ws = (C.c_int * n)(*[int(im.shape[2]) for im in images])
+    L.call("aldi_stage_images", ptr, hs, ws, n, batch.shape[1], batch.shape[2], batch.shape[3], _p(batch), stream_ptr())
+
+
 def compact_labels(labels, Lb, N, bg, lists, counts):
     ws = torch.empty(max(int(L.lib.aldi_compact_labels_workspace(Lb, N)), 16), dtype=torch.uint8, device=labels.device)
     L.call("aldi_compact_labels", _p(labels), Lb, N, bg, _p(lists), _p(counts), _p(ws), stream_ptr())

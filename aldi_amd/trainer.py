@@ -360,7 +360,10 @@ class SimpleTrainer:
         data = next(self._data_loader_iter)
         data_time = time.perf_counter() - start
         if self.zero_grad_before_forward:
-            self.optimizer.zero_grad()
+            if self._defers_zero_grad():
+                self._zero_pending = True            # run_model clears the gradients itself (fused step: beside its forward)
+            else:
+                self.optimizer.zero_grad()
         loss_dict = self.run_model(data)
         if isinstance(loss_dict, torch.Tensor):
             losses = loss_dict
@@ -376,6 +379,10 @@ class SimpleTrainer:
 
     def run_model(self, data):
         return self.model(data)
+
+    def _defers_zero_grad(self) -> bool:
+        """True when run_model clears the gradients itself (the fused step does it on a side stream beside its forward)"""
+        return False
 
     def do_backward(self, losses):
         losses.backward()
@@ -426,16 +433,29 @@ class _ALDITrainer:
                 return False
         return True
 
+    def _defers_zero_grad(self) -> bool:
+        from .engine import RCNN
+        model = self.model.module if hasattr(self.model, "module") else self.model
+        # (only the flat R50 weight container: the ViTDet / ConvNeXt models keep their trunk's gradients in a second buffer)
+        return bool(self.fused) and os.environ.get("ALDI_FUSED_LEGACY", "0") != "1" and type(getattr(model, "engine", None)) is RCNN
+
     def run_model(self, data):
         self._fused_done = False
         pending_ema = self.__dict__.pop("_pending_ema", None)       # the EMA tick `before_step` left for the fused step to run
         if pending_ema is not None and not self._can_fuse(data):
             pending_ema[0].update_weights(self.model, pending_ema[1])
             pending_ema = None
+        defer = self.__dict__.pop("_zero_pending", False)          # run_step left the zero_grad of this iteration to this method
+        if defer and not self._can_fuse(data):
+            self.optimizer.zero_grad()               # (this batch takes the unfused path)
+            defer = False
         if self._can_fuse(data):
             self._fused_done = True
-            if not self.zero_grad_before_forward:
-                self.optimizer.zero_grad()           # the fused driver runs its backward inside run_model
+            if not self.zero_grad_before_forward:    # the fused driver runs its backward inside run_model
+                if self._defers_zero_grad():
+                    defer = True
+                else:
+                    self.optimizer.zero_grad()
             eng = self.model.engine
             if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
                 from .reduce import BucketedReducer
@@ -447,7 +467,7 @@ class _ALDITrainer:
                 if getattr(self, "_fused_step", None) is None:
                     from .fused_step import FusedStep
                     self._fused_step = FusedStep(self)
-                return self._fused_step.run(*data, ema=pending_ema)
+                return self._fused_step.run(*data, ema=pending_ema, zero_grad=defer)
             finally:
                 eng.grad_ready = None
         return run_model_labeled_unlabeled(self, *data)

@@ -165,6 +165,10 @@ int aldi_stem_pool_forward(const aldi_stem_args* a, const void* w_packed, void* 
 
 /* max_pool2d(k3,s2,p1) NHWC; y is [N][(H-1)/2+1][(W-1)/2+1][C]. */
 int aldi_maxpool3s2(const void* x, void* y, int N, int H, int W, int C, int dtype, aldi_stream_t stream);
+/* Input staging (ImageList.from_tensors): n <= 16 uint8 CHW device images of sizes heights[i] x widths[i] (host arrays) -> rows
+ * [i][c][0..h)[0..w) of the padded uint8 batch [n][C][Hs][Ws] in one launch; the buffer's padding is left as it is. */
+int aldi_stage_images(const void* const* images, const int* heights, const int* widths, int n, int C, int Hs, int Ws, void* batch,
+                      aldi_stream_t stream);
 /* LastLevelMaxPool (k1,s2): forward y = x[:, ::2, ::2]; backward (x = grad small, y = grad big) y[::2,::2] += x. */
 int aldi_subsample2(const void* x, void* y, int N, int H, int W, int C, int backward, int dtype, aldi_stream_t stream);
 /* backward of FPN nearest-upsample-x2 + add: out[N][Hc][Wc][C] (=|+=) 2x2 block sums of g[N][2Hc][2Wc][C]. */

@@ -495,3 +495,18 @@ def test_fused_stem_pool_equals_stem_then_maxpool(sizes):
     torch.cuda.synchronize()
     assert got.shape == ref.shape and float(ref.float().abs().max()) > 0
     assert torch.equal(got, ref)
+
+
+def test_stage_images_equals_per_image_copies():
+    """aldi_stage_images: images of different sizes (odd widths: unaligned rows) into one padded batch; padding untouched"""
+    from aldi_amd import ops
+    g = torch.Generator().manual_seed(0)
+    sizes = [(37, 61), (40, 64), (1, 5), (33, 63)]
+    imgs = [torch.randint(0, 256, (3, h, w), dtype=torch.uint8, generator=g).to(DEV) for h, w in sizes]
+    batch = torch.full((len(imgs), 3, 64, 64), 7, dtype=torch.uint8, device=DEV)
+    ref = batch.clone()
+    for i, im in enumerate(imgs):
+        ref[i, :, : im.shape[1], : im.shape[2]] = im
+    ops.stage_images(imgs, batch)
+    torch.cuda.synchronize()
+    assert torch.equal(batch, ref)
