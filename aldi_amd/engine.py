@@ -750,7 +750,7 @@ class RCNN:
             d["loss_roih_l1"] = ch["loss_dist_roi"][1]
         return d
 
-    def backward_fused(self, c: Ctx, scales: List[Dict[str, float]]):
+    def backward_fused(self, c: Ctx, scales: List[Dict[str, float]], after_losses=None):
         """backward of forward_train_fused: per-chunk loss gradients (scales[i] for chunk i) into the shared head-gradient
         buffers, then ONE pass heads -> FPN -> res5..res3 over all images."""
         T, dev = self.dtype, self.device
@@ -821,6 +821,8 @@ class RCNN:
                 al["ins"] = (acts, glog)
             if "img" in al or "ins" in al:
                 align_list.append(al)
+        if after_losses is not None:
+            after_losses()                                   # (the loss values are final here: the caller's logging branches off)
         self._backward_trunk(c, align_list)
 
     def align_forward(self, c: Ctx, labeled: bool, da_weights):

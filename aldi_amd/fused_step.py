@@ -20,6 +20,7 @@ unless an image has fewer candidates): one graph per distinct row tuple.  Under 
 backward launches the overlapped gradient exchange, reduce.BucketedReducer)."""
 from __future__ import annotations
 
+import contextlib
 import os
 import time
 from types import SimpleNamespace
@@ -457,8 +458,25 @@ class FusedStep:
             scales.append(sc)
         c.chunks = S.chunks
         c.align, c.distill = {}, None
-        eng.backward_fused(c, scales)
-        # ---- the logged loss dict (values written by the pass above): `v * 0.0`, `/ accum` for all entries in a handful of launches
+        holder = {}
+        eng.backward_fused(c, scales, after_losses=lambda: holder.update(loss_dict=self._loss_dict(S, accum, main)))
+        loss_dict = holder["loss_dict"]
+        if S.tside is not None:
+            main.wait_stream(S.tside)
+        fields = {k: c[k] for k in ("rpn_labels", "R", "rows", "rois", "r_cls", "r_gt", "r_idx", "pred", "pooled", "fc1", "fc2", "ghead", "gpred") if k in c}
+        return SimpleNamespace(loss_dict=loss_dict, fields=fields, chunks=[dict(ch) for ch in S.chunks])
+
+    def _loss_dict(self, S, accum, main):
+        """the logged loss dict from the values the loss pass just wrote (`v * 0.0`, `/ accum` for all entries in a handful of
+        launches) -- on the teacher's stream, idle by now, so that these launches are not on the chain into the backward"""
+        eng, dev = self.eng, self.eng.device
+        side = S.tside
+        if side is not None:
+            side.wait_stream(main)
+        with torch.cuda.stream(side) if side is not None else contextlib.nullcontext():
+            return self._loss_dict_body(S, accum, dev, eng)
+
+    def _loss_dict_body(self, S, accum, dev, eng):
         entries = []
         for ch in S.chunks:
             losses = eng.chunk_loss_dict(ch)
@@ -489,8 +507,7 @@ class FusedStep:
         loss_dict = {}
         for n_, _ in entries:                                  # original key order
             loss_dict[n_] = loss_dict[n_] + vals[n_] if n_ in loss_dict else vals[n_]
-        fields = {k: c[k] for k in ("rpn_labels", "R", "rows", "rois", "r_cls", "r_gt", "r_idx", "pred", "pooled", "fc1", "fc2", "ghead", "gpred") if k in c}
-        return SimpleNamespace(loss_dict=loss_dict, fields=fields, chunks=[dict(ch) for ch in S.chunks])
+        return loss_dict
 
     # ------------------------------------------------------------------------------------------------ driver
     def _static_for(self, key):

@@ -368,7 +368,9 @@ class SimpleTrainer:
         if isinstance(loss_dict, torch.Tensor):
             losses = loss_dict
             loss_dict = {"total_loss": loss_dict}
-        else:
+        elif getattr(self, "_fused_done", False):
+            losses = None                            # the fused driver ran its backward inside run_model: no total to differentiate
+        else:                                        # (summing the entries here would put a dozen tiny launches in front of the optimizer)
             losses = sum(loss_dict.values())
         if not self.zero_grad_before_forward and not getattr(self, "_fused_done", False):
             self.optimizer.zero_grad()
