@@ -42,6 +42,7 @@ const Knob kKnobs[] = {
     {"wgrad_dbg", &AldiTuning::wgrad_dbg, 0},
     {"wgrad_group_slots", &AldiTuning::wgrad_group_slots, 0},
     {"wgrad_group_epi", &AldiTuning::wgrad_group_epi, 24},
+    {"roialign_sep", &AldiTuning::roialign_sep, 1},
     {"colsum_blocks", &AldiTuning::colsum_blocks, 256},
     {"colsum_minrows", &AldiTuning::colsum_minrows, 16},
     {"colsum_nt", &AldiTuning::colsum_nt, 1024},

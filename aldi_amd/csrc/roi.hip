@@ -276,6 +276,154 @@ __global__ __launch_bounds__(256) void roialign_fwd_vec_kernel(Feats ft, const f
     }
 }
 
+template <typename T> struct Raw8;                      // 8 consecutive channels as loaded; unpacked when consumed
+template <> struct Raw8<bf16_t> {
+    uint4 v;
+    __device__ __forceinline__ void load(const bf16_t* p) { v = *reinterpret_cast<const uint4*>(p); }
+    static __device__ __forceinline__ void store_zero(bf16_t* p) { *reinterpret_cast<uint4*>(p) = make_uint4(0, 0, 0, 0); }
+    static __device__ __forceinline__ void store(bf16_t* p, const float* o) {
+        *reinterpret_cast<uint4*>(p) = make_uint4(pack2_bf16(o[0], o[1]), pack2_bf16(o[2], o[3]), pack2_bf16(o[4], o[5]), pack2_bf16(o[6], o[7]));
+    }
+    __device__ __forceinline__ void unpack(float* o) const {
+        o[0] = __uint_as_float(v.x << 16); o[1] = __uint_as_float(v.x & 0xffff0000u);
+        o[2] = __uint_as_float(v.y << 16); o[3] = __uint_as_float(v.y & 0xffff0000u);
+        o[4] = __uint_as_float(v.z << 16); o[5] = __uint_as_float(v.z & 0xffff0000u);
+        o[6] = __uint_as_float(v.w << 16); o[7] = __uint_as_float(v.w & 0xffff0000u);
+    }
+};
+template <> struct Raw8<float> {
+    float4 a, b;
+    __device__ __forceinline__ void load(const float* p) { a = *reinterpret_cast<const float4*>(p); b = *reinterpret_cast<const float4*>(p + 4); }
+    static __device__ __forceinline__ void store_zero(float* p) {
+        *reinterpret_cast<float4*>(p) = make_float4(0.f, 0.f, 0.f, 0.f); *reinterpret_cast<float4*>(p + 4) = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    static __device__ __forceinline__ void store(float* p, const float* o) {
+        *reinterpret_cast<float4*>(p) = make_float4(o[0], o[1], o[2], o[3]); *reinterpret_cast<float4*>(p + 4) = make_float4(o[4], o[5], o[6], o[7]);
+    }
+    __device__ __forceinline__ void unpack(float* o) const { o[0] = a.x; o[1] = a.y; o[2] = a.z; o[3] = a.w; o[4] = b.x; o[5] = b.y; o[6] = b.z; o[7] = b.w; }
+};
+
+// Forward, separable form (what aldi_roialign runs): the adaptive sample grid of a bin is a product grid, so
+//   out[ph][pw][c] = 1/count * sum_yy rowc[ph][yy] * ( sum_xx colc[pw][xx] * f[yy][xx][c] )
+// with rowc / colc the summed bilinear weights the bin's sample rows / columns put on feature row yy / column xx (the same
+// bilin_prep, clamps and dead samples as above: a sample is dead when either coordinate is).  One workgroup per ROI; a thread
+// owns (bin column pw, 8 channels) and walks the footprint rows once: per row it reads the ~bw + 2 pixels under its bin column
+// (16 B each) instead of 4 corners per sample -- a 19 x 10-pixel ROI reads ~215 KB instead of ~600 KB, and the bilinear
+// bookkeeping is done once per ROI in LDS tables instead of once per (sample, 16 B).  Sums associate differently from the
+// sample-by-sample form (same terms; fp32 differences of a few ulps).
+constexpr int kSepMaxH = 208, kSepMaxW = 344;      // footprint bounds: the p2 map of a 1333 x 800 image is 200 x 336
+template <typename T>
+__global__ __launch_bounds__(256) void roialign_fwd_sep_kernel(Feats ft, const float* __restrict__ rois, int P, T* __restrict__ pooled /*[R][P][P][C]*/) {
+    __shared__ float rowc[7][kSepMaxH];
+    __shared__ float colc[7][kSepMaxW];
+    __shared__ int xlo_s[8], xhi_s[8];
+    const int r = blockIdx.x, tid = threadIdx.x;
+    const int pw = tid >> 5, c8 = tid & 31;            // bin column (7 = idle), channels c8 * 8 ... + 7
+    const int C = ft.C;
+    const float* rp = rois + (long)r * 5;
+    const int b = (int)rp[0];
+    T* out_base = pooled + (long)r * P * P * C + c8 * 8;
+    if (b < 0) {
+        if (pw < P)
+            for (int ph = 0; ph < P; ++ph) Raw8<T>::store_zero(out_base + (long)(ph * P + pw) * C);
+        return;
+    }
+    const int l = roi_level(rp[1], rp[2], rp[3], rp[4]);
+    const int H = ft.H[l], W = ft.W[l];
+    const float sc = ft.scale[l];
+    const float x1 = rp[1] * sc - 0.5f, y1 = rp[2] * sc - 0.5f, x2 = rp[3] * sc - 0.5f, y2 = rp[4] * sc - 0.5f;
+    const float rw = x2 - x1, rh = y2 - y1;
+    const float bw = rw / (float)P, bh = rh / (float)P;
+    const int gh = (int)ceilf(rh / (float)P), gw = (int)ceilf(rw / (float)P);
+    const float inv_count = 1.f / (float)max(gh * gw, 1);
+    // footprint (every live sample's two taps lie inside it)
+    const int fy0 = min(max((int)floorf(y1) - 1, 0), H - 1), fy1 = min(max((int)floorf(y2) + 2, 0), H - 1);
+    const int fx0 = min(max((int)floorf(x1) - 1, 0), W - 1), fx1 = min(max((int)floorf(x2) + 2, 0), W - 1);
+    const int nrow = fy1 - fy0 + 1, ncol = fx1 - fx0 + 1;
+    for (int e = tid; e < 7 * nrow; e += 256) {
+        const int ph = e / nrow, yy = fy0 + e - ph * nrow;
+        float a = 0.f;
+        if (ph < P)
+            for (int iy = 0; iy < gh; ++iy) {
+                const Bilin by = bilin_prep(y1 + (float)ph * bh + ((float)iy + 0.5f) * bh / (float)gh, H);
+                if (by.dead) continue;
+                if (by.lo == yy) a += by.h;
+                if (by.hi == yy) a += by.l;
+            }
+        rowc[ph][yy - fy0] = a;
+    }
+    for (int e = tid; e < 7 * ncol; e += 256) {
+        const int q = e / ncol, xx = fx0 + e - q * ncol;
+        float a = 0.f;
+        if (q < P)
+            for (int ix = 0; ix < gw; ++ix) {
+                const Bilin bx = bilin_prep(x1 + (float)q * bw + ((float)ix + 0.5f) * bw / (float)gw, W);
+                if (bx.dead) continue;
+                if (bx.lo == xx) a += bx.h;
+                if (bx.hi == xx) a += bx.l;
+            }
+        colc[q][xx - fx0] = a;
+    }
+    __syncthreads();
+    if (tid < 7) {                                     // pixels with weight under bin column `tid`: a contiguous run
+        int lo = ncol, hi = -1;
+        for (int x = 0; x < ncol; ++x)
+            if (colc[tid][x] != 0.f) { lo = min(lo, x); hi = x; }
+        xlo_s[tid] = lo; xhi_s[tid] = hi;
+    }
+    __syncthreads();
+    if (pw >= P) return;
+    const int xlo = xlo_s[pw], xhi = xhi_s[pw];
+    float acc[7][8];
+#pragma unroll
+    for (int ph = 0; ph < 7; ++ph)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc[ph][i] = 0.f;
+    const T* F = static_cast<const T*>(ft.f[l]) + (long)b * H * W * C + c8 * 8;
+    for (int y = 0; y < nrow; ++y) {
+        float wr[7];
+        bool any = false;
+#pragma unroll
+        for (int ph = 0; ph < 7; ++ph) { wr[ph] = rowc[ph][y]; any = any || wr[ph] != 0.f; }
+        if (!any) continue;                            // (uniform: margin rows of the footprint)
+        float t[8], u[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) t[i] = 0.f;
+        const T* Fr = F + ((long)(fy0 + y) * W + fx0) * C;
+        constexpr int XB = 4;       // pixels whose loads are in flight together (past the run: the last pixel again, weight 0; 8 measured slower: runs are 4-5 px)
+        for (int x = xlo; x <= xhi; x += XB) {
+            Raw8<T> q[XB];
+            float wc[XB];
+#pragma unroll
+            for (int k = 0; k < XB; ++k) {
+                const int xk = min(x + k, xhi);
+                q[k].load(Fr + (long)xk * C);
+                wc[k] = x + k <= xhi ? colc[pw][xk] : 0.f;
+            }
+#pragma unroll
+            for (int k = 0; k < XB; ++k) {
+                q[k].unpack(u);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) t[i] += wc[k] * u[i];
+            }
+        }
+#pragma unroll
+        for (int ph = 0; ph < 7; ++ph)
+            if (wr[ph] != 0.f) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) acc[ph][i] += wr[ph] * t[i];
+            }
+    }
+#pragma unroll
+    for (int ph = 0; ph < 7; ++ph)
+        if (ph < P) {
+            float o[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) o[i] = acc[ph][i] * inv_count;
+            Raw8<T>::store(out_base + (long)(ph * P + pw) * C, o);
+        }
+}
+
 // Backward as a GATHER (no atomics, deterministic): one workgroup owns a 32-pixel segment of one feature-map row of one
 // (level, image), finds the ROIs that can touch it, and for each of them builds the separable bilinear footprint
 //   rowc[ph]      = sum over the bin's sample rows of the weight they put on THIS row        (7 values)
@@ -293,23 +441,6 @@ __global__ __launch_bounds__(256) void roialign_fwd_vec_kernel(Feats ft, const f
 //     loads of q + 1, builds the tables of q + 2 and spreads q - 1.
 constexpr int kSeg = 32;
 struct GatherGeom { int blk_off[5]; int segs[4]; int N; };
-
-template <typename T> struct Raw8;                      // 8 consecutive channels as loaded; unpacked when consumed
-template <> struct Raw8<bf16_t> {
-    uint4 v;
-    __device__ __forceinline__ void load(const bf16_t* p) { v = *reinterpret_cast<const uint4*>(p); }
-    __device__ __forceinline__ void unpack(float* o) const {
-        o[0] = __uint_as_float(v.x << 16); o[1] = __uint_as_float(v.x & 0xffff0000u);
-        o[2] = __uint_as_float(v.y << 16); o[3] = __uint_as_float(v.y & 0xffff0000u);
-        o[4] = __uint_as_float(v.z << 16); o[5] = __uint_as_float(v.z & 0xffff0000u);
-        o[6] = __uint_as_float(v.w << 16); o[7] = __uint_as_float(v.w & 0xffff0000u);
-    }
-};
-template <> struct Raw8<float> {
-    float4 a, b;
-    __device__ __forceinline__ void load(const float* p) { a = *reinterpret_cast<const float4*>(p); b = *reinterpret_cast<const float4*>(p + 4); }
-    __device__ __forceinline__ void unpack(float* o) const { o[0] = a.x; o[1] = a.y; o[2] = a.z; o[3] = a.w; o[4] = b.x; o[5] = b.y; o[6] = b.z; o[7] = b.w; }
-};
 
 template <typename T, typename GT>      // GT: type of the gradient maps (float, or bf16 = what the FPN backward consumes: no cast pass)
 __global__ __launch_bounds__(256, 5) void roialign_bwd_gather_kernel(Feats ft, GatherGeom gg, const float* __restrict__ rois, int R, int P,
@@ -709,11 +840,16 @@ extern "C" int aldi_roialign(const aldi_roi_feats* f, const float* rois, int R, 
     Feats ft = make_feats(f, backward != 0);
     hipStream_t st = static_cast<hipStream_t>(stream);
     dim3 grid(R, P);
+    // forward: separable form when every level's map fits its footprint tables (roialign_sep knob: 0 = the sample-by-sample form)
+    bool sep = aldi_tuning().roialign_sep != 0 && P <= 7;
+    for (int l = 0; l < 4; ++l) sep = sep && ft.H[l] <= kSepMaxH && ft.W[l] <= kSepMaxW;
     if (dtype == ALDI_BF16) {
         if (backward) hipLaunchKernelGGL((roialign_kernel<bf16_t, true>), grid, dim3(256), 0, st, ft, rois, P, (bf16_t*)pooled);
+        else if (sep) hipLaunchKernelGGL((roialign_fwd_sep_kernel<bf16_t>), dim3(R), dim3(256), 0, st, ft, rois, P, (bf16_t*)pooled);
         else hipLaunchKernelGGL((roialign_fwd_vec_kernel<bf16_t>), grid, dim3(256), 0, st, ft, rois, P, (bf16_t*)pooled);
     } else {
         if (backward) hipLaunchKernelGGL((roialign_kernel<float, true>), grid, dim3(256), 0, st, ft, rois, P, (float*)pooled);
+        else if (sep) hipLaunchKernelGGL((roialign_fwd_sep_kernel<float>), dim3(R), dim3(256), 0, st, ft, rois, P, (float*)pooled);
         else hipLaunchKernelGGL((roialign_fwd_vec_kernel<float>), grid, dim3(256), 0, st, ft, rois, P, (float*)pooled);
     }
     ALDI_CHECK_LAUNCH();

@@ -49,6 +49,7 @@ int aldi_version(void);
  *   wgrad_group_slots    > 0: minimum workgroup count of an aldi_conv_wgrad_group launch before it stops splitting pixel ranges;
  *                        0 (default): the pixel split of the group is chosen by a model of 256-workgroup rounds
  *   wgrad_group_epi      cost of one atomic epilogue in that model, in 32-pixel slab steps (24)
+ *   roialign_sep         1 = aldi_roialign forward in the separable form (row / column weight tables, one workgroup per ROI); 0 = per sample
  *   wgrad_dbg            ablation bits (1 = skip the atomic epilogue): results are WRONG when set
  *   wgrad_dma            LDS-DMA + ds_read_b64_tr_b16 weight-gradient kernel: 0 off, 1 in place of the lean kernel, 2 also of the 256x256
  *   colsum_blocks, colsum_minrows, colsum_nt, colsum_block_kb   aldi_bias_grad launch geometry
