@@ -54,6 +54,14 @@ static __device__ __forceinline__ unsigned wave_or_u32(unsigned v) {
     x |= __builtin_amdgcn_update_dpp(0, x, 0x143, 0xc, 0xf, false);     // row_bcast:31 -> rows 2, 3
     return (unsigned)__builtin_amdgcn_readlane(x, 63);
 }
+// max over the 64 lanes of unsigned values (bit patterns of non-negative floats order like the floats), same DPP ladder
+static __device__ __forceinline__ unsigned wave_max_u32(unsigned v) {
+    int x = (int)v;
+#define ALDI_DPP_MAX(ctrl, rows) { const unsigned o_ = (unsigned)__builtin_amdgcn_update_dpp(0, x, ctrl, rows, 0xf, false); x = (int)((unsigned)x > o_ ? (unsigned)x : o_); }
+    ALDI_DPP_MAX(0xb1, 0xf) ALDI_DPP_MAX(0x4e, 0xf) ALDI_DPP_MAX(0x124, 0xf) ALDI_DPP_MAX(0x128, 0xf) ALDI_DPP_MAX(0x142, 0xa) ALDI_DPP_MAX(0x143, 0xc)
+#undef ALDI_DPP_MAX
+    return (unsigned)__builtin_amdgcn_readlane(x, 63);
+}
 static __device__ __forceinline__ unsigned long long wave_or_u64(unsigned long long v) {
     return ((unsigned long long)wave_or_u32((unsigned)(v >> 32)) << 32) | wave_or_u32((unsigned)v);
 }

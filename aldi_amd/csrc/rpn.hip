@@ -104,10 +104,8 @@ __global__ __launch_bounds__(1024) void match_iou_kernel(const float4* __restric
             // per-GT best IoU: wave maximum -> workgroup maximum in LDS -> ONE global atomic per (workgroup, GT it overlaps).  The
             // few hundred gt_best words are all the atomics of the launch go to: one per wave was 2/3 of the kernel's time.
             if (__ballot(v > 0.f)) {
-                float wm = v;
-#pragma unroll
-                for (int o = 32; o > 0; o >>= 1) wm = fmaxf(wm, __shfl_xor(wm, o, 64));
-                if (lane == 0) atomicMax(&smax[k], __float_as_uint(wm));
+                const unsigned wm = wave_max_u32(__float_as_uint(v));       // (IoUs are >= 0: their bit patterns order like the values)
+                if (lane == 0) atomicMax(&smax[k], wm);
             }
         }
         __syncthreads();
