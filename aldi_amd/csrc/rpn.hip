@@ -473,7 +473,7 @@ __global__ __launch_bounds__(1024) void topk_hist_kernel(Geom g, const unsigned*
     TopkState s;
     s.prefix = 0; s.mask = 0; s.need = min(pre_nms_topk, nel); s.bucket_count = 0;      // chain start (passes 0 and 1)
     if (pass > 0) {
-        if (pass > 1) s = state[bl];
+        if (pass > 1) s = state[B + bl];                   // what pass 1 left (slot 1); this pass writes slot 0, which the collect reads
         int b, above, bc;
         find_bucket(hists + ((long)(pass - 1) * B + bl) * 4096, 1 << widths[pass - 1], s.need, sm, &b, &above, &bc);
         s.prefix |= (unsigned)b << shifts[pass - 1];
@@ -495,15 +495,9 @@ __global__ __launch_bounds__(1024) void topk_hist_kernel(Geom g, const unsigned*
         const int v = hist[i];
         if (v) atomicAdd(out + i, v);
     }
-    // the next launch reads the state this launch started from (+ this launch's bucket): written by a workgroup that
-    // only reads its own copy, after everyone in THIS launch can only have read the previous launch's value
-    if (c == 0 && threadIdx.x == 0 && pass > 0) state[B + bl] = s;   // staging slot, promoted below
-}
-
-// promote the staged chain state (a launch boundary separates it from the readers)
-__global__ void topk_promote_kernel(TopkState* __restrict__ state, int B) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < B) state[i] = state[B + i];
+    // the next launch reads the state this launch started from (+ this launch's bucket).  The two slots alternate (pass 1 writes
+    // slot 1, pass 2 reads slot 1 and writes slot 0), so no workgroup of a launch reads the slot another one writes
+    if (c == 0 && threadIdx.x == 0 && pass > 0) state[(pass == 1 ? B : 0) + bl] = s;
 }
 
 // final: k-th key from the last histogram, collect the winners of this chunk (unordered append)
@@ -796,7 +790,6 @@ extern "C" int aldi_rpn_proposals(const aldi_rpn_geom* gm, float* const* head, c
         for (int pass = 0; pass < 3; ++pass) {
             hipLaunchKernelGGL(topk_hist_kernel, grid, dim3(1024), 0, st, g, okeys, pre_nms_topk, pass, hists, tstate);
             ALDI_CHECK_LAUNCH();
-            if (pass > 0) { hipLaunchKernelGGL(topk_promote_kernel, dim3(cdiv((long)B, 64)), dim3(64), 0, st, tstate, (int)B); ALDI_CHECK_LAUNCH(); }
         }
         hipLaunchKernelGGL(topk_collect_kernel, grid, dim3(1024), 0, st, g, okeys, hists, tstate, cand, fill, tstate + 2 * B);
         ALDI_CHECK_LAUNCH();

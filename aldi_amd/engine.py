@@ -1031,6 +1031,17 @@ class RCNN:
         W = self.wts
         T = self.dtype
         dev = self.device
+        # The stride-2 stages scatter their input gradient into every other pixel of a zero map (res5 -> c4, res4 -> c3): clear
+        # those maps NOW on the side stream, beside the box head's backward, instead of in the middle of the data-gradient chain
+        gx_pre, gx_ev = {}, None
+        side0 = self._wgrad_stream()
+        if side0 is not None and "cs" in c:
+            side0.wait_stream(torch.cuda.current_stream())     # (fork: inside a graph capture the side stream must descend from the captured one)
+            with torch.cuda.stream(side0):
+                for si_, ci_ in ((3, 2), (2, 1)):
+                    gx_pre[si_] = torch.zeros_like(c.cs[ci_])
+                gx_ev = torch.cuda.Event()
+                gx_ev.record(side0)
         # ---- box head (+ instance-level discriminator behind the gradient-reversal layer)
         # ROIAlign's share of d(loss)/d(P_l).  With the sparse RPN-head backward these maps ARE the FPN backward's input, so in bf16
         # mode they are written in bf16 directly (no fp32 map + cast pass): the ROI part rounded once, the RPN head's few thousand
@@ -1131,7 +1142,12 @@ class RCNN:
                         break                                           # stage input (res2 output) needs no gradient
                     stride = W.layout.t[p + "conv1"].stride
                     Hin, Win = xin.shape[1], xin.shape[2]
-                    gx = torch.zeros_like(xin)
+                    gx = gx_pre.pop(si, None)
+                    if gx is None or gx.shape != xin.shape:
+                        gx = torch.zeros_like(xin)
+                    else:
+                        torch.cuda.current_stream().wait_event(gx_ev)
+                        gx.record_stream(torch.cuda.current_stream())
                     ops.conv2d(g, W.wt(p + "shortcut"), out=gx, out_scale=stride, out_hw=(Hin, Win))
                     ops.conv2d(g1, W.wt(p + "conv1"), out=gx, out_scale=stride, out_hw=(Hin, Win), res=gx, res_mode=1)
                     lvl = si + 1                                        # this stage's input is C_{lvl}
