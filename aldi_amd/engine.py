@@ -1042,6 +1042,15 @@ class RCNN:
                     gx_pre[si_] = torch.zeros_like(c.cs[ci_])
                 gx_ev = torch.cuda.Event()
                 gx_ev.record(side0)
+        # The sparse RPN-head backward up to its scatter needs the head gradients only: on an auxiliary stream, beside the box head's
+        # backward and ROIAlign's (it was ~0.12 ms of small launches between ROIAlign's backward and the FPN's)
+        sp_pre, aux = None, None
+        if self.sparse_rpn_backward:
+            aux = self._aux_stream()
+            if aux is not None:
+                aux.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(aux):
+                    sp_pre = self._rpn_sparse_prepare(c)
         # ---- box head (+ instance-level discriminator behind the gradient-reversal layer)
         # ROIAlign's share of d(loss)/d(P_l).  With the sparse RPN-head backward these maps ARE the FPN backward's input, so in bf16
         # mode they are written in bf16 directly (no fp32 map + cast pass): the ROI part rounded once, the RPN head's few thousand
@@ -1076,7 +1085,15 @@ class RCNN:
         self._grads_final(["box_pred", "roi_heads.box_head.fc2", "roi_heads.box_head.fc1"])
         # ---- RPN head (shared weights over 5 levels)
         if self.sparse_rpn_backward:
-            gP = self._rpn_head_backward_sparse(c, gP_roi)
+            if sp_pre is not None:
+                main_ = torch.cuda.current_stream()
+                main_.wait_stream(aux)
+                for t_ in sp_pre.values():
+                    if isinstance(t_, torch.Tensor):
+                        t_.record_stream(main_)
+                gP = self._rpn_sparse_finish(c, gP_roi, sp_pre)
+            else:
+                gP = self._rpn_head_backward_sparse(c, gP_roi)
         else:
             gP = []
             for l in range(5):
@@ -1156,11 +1173,11 @@ class RCNN:
                     g = ops.conv2d(g1, W.wt(p + "conv1"), res=g, res_mode=1, mask=xin)
         self._join_wgrads()
 
-    def _rpn_head_backward_sparse(self, c: Ctx, gP_roi: List[torch.Tensor]) -> List[torch.Tensor]:
-        """RPN head backward over the ACTIVE pixels only (csrc/rpn_sparse.hip): d(loss)/d(head outputs) is non-zero at the sampled
-        anchors' pixels (the RPN losses' sample + the positions the distillation losses' fresh sample selects), i.e. at
-        <= 4 * 256 * N of the 358 k pixel positions.  Returns d(loss)/d(P_l) in the compute dtype, ROIAlign's contribution
-        (gP_roi) included: fp32 maps are summed in fp32 and rounded once, bf16 maps take the rows by packed bf16 atomics."""
+    def _rpn_sparse_prepare(self, c: Ctx):
+        """RPN head backward over the ACTIVE pixels only (csrc/rpn_sparse.hip), everything up to the scatter: d(loss)/d(head
+        outputs) is non-zero at the sampled anchors' pixels (the RPN losses' sample + the positions the distillation losses' fresh
+        sample selects), i.e. at <= 4 * 256 * N of the 358 k pixel positions.  Needs only c.ghead, so `_backward_trunk` runs it
+        on an auxiliary stream beside the box head's backward."""
         W, T, dev = self.wts, self.dtype, self.device
         N, Cf, Ch = c.N, FPN_C, self.Ch
         # bound on the active pixels of one image: RPN_BATCH sampled anchors of the RPN losses + RPN_BATCH mask positions of the
@@ -1175,13 +1192,27 @@ class RCNN:
         Tm = torch.empty((cap, 1, 1, Cf), dtype=T, device=dev)
         X9 = torch.empty((cap, 1, 1, 9 * Cf), dtype=T, device=dev)
         ops.rpn_sparse_gather(c.geom, c.ghead, c.rpn_t, c.P, N, Cf, cap, idx, count, G, Tm, X9)
-        self._wgrad("rpn_head_out", Tm, G, temp_x=True)
         g_t = ops.conv2d(G, W.wt("rpn_head_out"), mask=Tm)
-        self._wgrad("proposal_generator.rpn_head.conv", X9, g_t, flat=True, temp_x=True)
         Y = ops.conv2d(g_t, W.wt_flat("proposal_generator.rpn_head.conv"))           # [cap][9][Cf]: contributions to the 3x3 neighbourhood
+        return dict(cap=cap, idx=idx, count=count, G=G, Tm=Tm, X9=X9, g_t=g_t, Y=Y)
+
+    def _rpn_sparse_finish(self, c: Ctx, gP_roi: List[torch.Tensor], sp: dict) -> List[torch.Tensor]:
+        """queue the two weight gradients and scatter the rows into d(loss)/d(P_l) (ROIAlign's contribution gP_roi included: fp32
+        maps are summed in fp32 and rounded once, bf16 maps take the rows by packed bf16 atomics)"""
+        T, dev = self.dtype, self.device
+        self._wgrad("rpn_head_out", sp["Tm"], sp["G"], temp_x=True)
+        self._wgrad("proposal_generator.rpn_head.conv", sp["X9"], sp["g_t"], flat=True, temp_x=True)
         g32 = list(gP_roi) + [torch.zeros(c.P[4].shape, dtype=gP_roi[0].dtype, device=dev)]
-        ops.rpn_sparse_scatter(c.geom, g32, Y, N, Cf, cap, idx, count)
+        ops.rpn_sparse_scatter(c.geom, g32, sp["Y"], c.N, FPN_C, sp["cap"], sp["idx"], sp["count"])
         return g32 if g32[0].dtype == T else [ops.cast_from_f32(g, T) for g in g32]
+
+    def _rpn_head_backward_sparse(self, c: Ctx, gP_roi: List[torch.Tensor]) -> List[torch.Tensor]:
+        return self._rpn_sparse_finish(c, gP_roi, self._rpn_sparse_prepare(c))
+
+    def _aux_stream(self):
+        if not hasattr(self, "_aux_side"):
+            self._aux_side = torch.cuda.Stream(device=self.device) if os.environ.get("ALDI_AUX_STREAM", "1") == "1" and torch.device(self.device).type == "cuda" else None
+        return self._aux_side
 
     def _grads_final(self, names: List[str]):
         """tell the gradient exchange (if one is attached: data-parallel fused step) that these layers' gradients are
