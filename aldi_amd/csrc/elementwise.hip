@@ -486,12 +486,32 @@ __global__ void sgd_kernel(float* __restrict__ p, const float* __restrict__ g, f
 }
 
 // reference aldi/ema.py:43-46:  t = s*(1-alpha) + t*alpha   (copy_only: t = s, aldi/ema.py:29-30)
+// tc (nullable): the compute-dtype copy of the first nc elements (the weights), written in the same pass
 template <typename T>
-__global__ void ema_kernel(float* __restrict__ t, const float* __restrict__ s, T* __restrict__ tc, long n, float one_minus_alpha, float alpha, int copy_only) {
-    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+__global__ void ema_kernel(float* __restrict__ t, const float* __restrict__ s, T* __restrict__ tc, long n, long nc, float one_minus_alpha, float alpha,
+                           int copy_only) {
+    const long n4 = ((reinterpret_cast<uintptr_t>(t) | reinterpret_cast<uintptr_t>(s)) & 15) == 0 ? n >> 2 : 0;      // 16-byte body
+    for (long q = blockIdx.x * (long)blockDim.x + threadIdx.x; q < n4; q += (long)gridDim.x * blockDim.x) {
+        const float4 sv = reinterpret_cast<const float4*>(s)[q];
+        float4 v = sv;
+        if (!copy_only) {
+            const float4 tv = reinterpret_cast<const float4*>(t)[q];
+            v.x = sv.x * one_minus_alpha + tv.x * alpha; v.y = sv.y * one_minus_alpha + tv.y * alpha;
+            v.z = sv.z * one_minus_alpha + tv.z * alpha; v.w = sv.w * one_minus_alpha + tv.w * alpha;
+        }
+        reinterpret_cast<float4*>(t)[q] = v;
+        if (tc) {
+            const long i = q << 2;
+            if (i < nc) Elem<T>::st(tc + i, v.x);
+            if (i + 1 < nc) Elem<T>::st(tc + i + 1, v.y);
+            if (i + 2 < nc) Elem<T>::st(tc + i + 2, v.z);
+            if (i + 3 < nc) Elem<T>::st(tc + i + 3, v.w);
+        }
+    }
+    for (long i = (n4 << 2) + blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
         float v = copy_only ? s[i] : s[i] * one_minus_alpha + t[i] * alpha;
         t[i] = v;
-        if (tc) Elem<T>::st(tc + i, v);
+        if (tc && i < nc) Elem<T>::st(tc + i, v);
     }
 }
 
@@ -667,14 +687,16 @@ extern "C" int aldi_sgd_step(float* p, const float* g, float* buf, void* p_compu
     return ALDI_OK;
 }
 
-extern "C" int aldi_ema_update(float* teacher, const float* student, void* teacher_compute, long n, double alpha, int copy_only, int dtype, aldi_stream_t stream) {
+extern "C" int aldi_ema_update(float* teacher, const float* student, void* teacher_compute, long n, long n_compute, double alpha, int copy_only, int dtype,
+                               aldi_stream_t stream) {
     if (!teacher || !student) return aldi_set_error_msg(ALDI_ERR_ARG, "ema_update: null pointer");
     hipStream_t st = static_cast<hipStream_t>(stream);
     // python computes (1 - alpha) in DOUBLE; torch then casts each scalar to fp32 for the fp32 tensor multiply
     const float oma = (float)(1.0 - alpha);
     const float alpha_f = (float)alpha;
-    if (dtype == ALDI_BF16) hipLaunchKernelGGL(ema_kernel<bf16_t>, dim3(nblocks(n)), dim3(256), 0, st, teacher, student, (bf16_t*)teacher_compute, n, oma, alpha_f, copy_only);
-    else hipLaunchKernelGGL(ema_kernel<float>, dim3(nblocks(n)), dim3(256), 0, st, teacher, student, (float*)nullptr, n, oma, alpha_f, copy_only);
+    const long nc = teacher_compute ? (n_compute < n ? n_compute : n) : 0;
+    if (dtype == ALDI_BF16) hipLaunchKernelGGL(ema_kernel<bf16_t>, dim3(nblocks(n / 4 + 1)), dim3(256), 0, st, teacher, student, (bf16_t*)teacher_compute, n, nc, oma, alpha_f, copy_only);
+    else hipLaunchKernelGGL(ema_kernel<float>, dim3(nblocks(n / 4 + 1)), dim3(256), 0, st, teacher, student, (float*)nullptr, n, 0L, oma, alpha_f, copy_only);
     ALDI_CHECK_LAUNCH();
     return ALDI_OK;
 }

@@ -200,7 +200,7 @@ class Weights:
     def state_dict(self) -> "OrderedDict[str, torch.Tensor]":
         return self.layout.unpack(self.master)
 
-    def refresh(self):
+    def refresh(self, cast: bool = True):
         """re-derive everything computed from the master state (after load / optimizer step / EMA)."""
         L = self.layout
         if L.bn_channels:
@@ -208,7 +208,7 @@ class Weights:
             c = L.bn_channels
             ops.bn_fold(self.master[b:b + c], self.master[b + c:b + 2 * c], self.master[b + 2 * c:b + 3 * c],
                         self.master[b + 3 * c:b + 4 * c], self.bn_scale, self.bn_shift, c)
-        if self.dtype != torch.float32:
+        if self.dtype != torch.float32 and cast:
             ops.cast_from_f32(self.master[:L.n_weights], self.dtype, out=self.compute)
         if self._stem_pk is not None:
             ops.stem_pack_weights(self.w_master(self._stem_name), out=self._stem_pk)
@@ -235,8 +235,12 @@ class Weights:
     def ema_from(self, student: "Weights", alpha: float, copy_only: bool):
         """reference aldi/ema.py:29-57 over the whole state (params AND buffers)."""
         n = self.layout.n_total
-        ops.ema_update(self.master, student.master, None, n, alpha, copy_only, torch.float32)
-        self.refresh()
+        if self.dtype == torch.bfloat16:                     # the bf16 compute copy of the weights in the same pass (no cast pass)
+            ops.ema_update(self.master, student.master, self.compute, n, alpha, copy_only, self.dtype, n_compute=self.layout.n_weights)
+            self.refresh(cast=False)
+        else:
+            ops.ema_update(self.master, student.master, None, n, alpha, copy_only, torch.float32)
+            self.refresh()
 
 
 def make_anchors(shapes: Sequence[Tuple[int, int]], device, sizes: Sequence[float] = ANCHOR_SIZES) -> torch.Tensor:

@@ -278,8 +278,9 @@ def sgd_step(p, g, buf, p_compute, n, lr, momentum, weight_decay, grad_scale, fi
            dtype_code(dtype), stream_ptr())
 
 
-def ema_update(teacher, student, teacher_compute, n, alpha, copy_only, dtype) -> None:
-    L.call("aldi_ema_update", _p(teacher), _p(student), _p(teacher_compute), n, alpha, int(copy_only), dtype_code(dtype), stream_ptr())
+def ema_update(teacher, student, teacher_compute, n, alpha, copy_only, dtype, n_compute=None) -> None:
+    nc = 0 if teacher_compute is None else (teacher_compute.numel() if n_compute is None else n_compute)
+    L.call("aldi_ema_update", _p(teacher), _p(student), _p(teacher_compute), n, nc, alpha, int(copy_only), dtype_code(dtype), stream_ptr())
 
 
 def bn_fold(w, b, mean, var, scale, shift, Cc) -> None:

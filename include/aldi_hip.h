@@ -182,8 +182,10 @@ int aldi_cast_from_f32(const float* src, void* dst, long n, int dtype, aldi_stre
  * applied at aldi/dropin.py:121); refreshes the compute-dtype copy when dtype is bf16. */
 int aldi_sgd_step(float* p, const float* g, float* buf, void* p_compute, long n, float lr, float momentum, float weight_decay,
                   float grad_scale, int first_step, int dtype, aldi_stream_t stream);
-/* EMA teacher update over the flat state (aldi/ema.py:32-57): t = s*(1-alpha) + t*alpha, or t = s. */
-int aldi_ema_update(float* teacher, const float* student, void* teacher_compute, long n, double alpha, int copy_only, int dtype, aldi_stream_t stream);
+/* EMA teacher update over the flat state (aldi/ema.py:32-57): t = s*(1-alpha) + t*alpha, or t = s.  teacher_compute (nullable,
+ * dtype bf16): the compute copy of the first n_compute elements, written in the same pass. */
+int aldi_ema_update(float* teacher, const float* student, void* teacher_compute, long n, long n_compute, double alpha, int copy_only, int dtype,
+                    aldi_stream_t stream);
 /* FrozenBatchNorm2d fold (detectron2): scale = w*rsqrt(var+1e-5), shift = b - mean*scale. */
 int aldi_bn_fold(const float* w, const float* b, const float* mean, const float* var, float* scale, float* shift, int C, aldi_stream_t stream);
 

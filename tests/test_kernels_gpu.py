@@ -510,3 +510,21 @@ def test_stage_images_equals_per_image_copies():
     ops.stage_images(imgs, batch)
     torch.cuda.synchronize()
     assert torch.equal(batch, ref)
+
+
+def test_ema_update_writes_the_compute_copy_in_the_same_pass():
+    """aldi_ema_update with a bf16 compute copy of the first n_compute elements == the update followed by a cast; unaligned
+    tails and the copy-only form included"""
+    from aldi_amd import ops
+    g = torch.Generator().manual_seed(5)
+    n, nc = 100003, 70001
+    for copy_only in (False, True):
+        t = torch.randn(n, generator=g).to(DEV)
+        s = torch.randn(n, generator=g).to(DEV)
+        ref = t.clone()
+        ops.ema_update(ref, s, None, n, 0.9996, copy_only, torch.float32)
+        comp = torch.full((nc,), 7.0, dtype=torch.bfloat16, device=DEV)
+        ops.ema_update(t, s, comp, n, 0.9996, copy_only, torch.bfloat16, n_compute=nc)
+        torch.cuda.synchronize()
+        assert torch.equal(t, ref)
+        assert torch.equal(comp, ops.cast_from_f32(ref[:nc], torch.bfloat16))
