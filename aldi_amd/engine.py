@@ -1252,6 +1252,19 @@ class RCNN:
         p = W.layout.t[name]
         geo = dict(KH=1, KW=1, stride=1, pad=0) if flat else dict(KH=p.kk, KW=p.kk, stride=p.stride, pad=p.pad)
         geo["scale"] = W.scale(name)
+        if (not flat and p.kk == 1 and p.stride == 2 and p.pad == 0 and self.dtype == torch.bfloat16 and getattr(self, "group_wgrad", False)
+                and os.environ.get("ALDI_WGRAD_SUBSAMPLE", "1") == "1"):
+            # a stride-2 1x1 conv (first block of res3..res5: conv1 and the shortcut read the same input) sees every other pixel:
+            # gather those ONCE into a dense map and its weight gradient is a plain GEMM that joins the stage's grouped launch,
+            # instead of two launches of the generic gather kernel per stage (6 x ~60 us)
+            cache = self.__dict__.setdefault("_sub_cache", {})
+            hit = cache.get(id(x))
+            if hit is None or hit[0] is not x:
+                hit = (x, ops.subsample2(x))
+                cache.clear()
+                cache[id(x)] = hit
+            x, temp_x = hit[1], True
+            geo.update(stride=1)
         if getattr(self, "group_wgrad", False) and self.dtype == torch.bfloat16:
             self._wg_queue.append((x, g, W.gw(name), geo, W.gb(name) if p.bias else None, temp_x))
             return

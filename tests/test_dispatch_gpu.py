@@ -526,3 +526,28 @@ def test_conv_group_of_different_layers_falls_back():
     assert not L.last_dispatch().startswith("igemm_group")
     torch.cuda.synchronize()
     assert torch.equal(a, ops.conv2d(x1, w, pad=1)) and torch.equal(b, ops.conv2d(x2, w, pad=1))
+
+
+@pytest.mark.parametrize("shape", [(2, 50, 84, 256, 512), (1, 25, 41, 128, 64), (3, 13, 21, 64, 256)])
+def test_strided_1x1_wgrad_equals_gemm_on_subsampled_input(shape):
+    """the engine turns the weight gradient of a stride-2 1x1 conv into a plain GEMM over the subsampled input
+    (ops.subsample2) so that it can join a grouped launch: same numbers as the strided gather kernel, odd sizes included"""
+    from aldi_amd import _lib as L
+    from aldi_amd import ops
+    L.reset_tuning()
+    N, H, W_, Cin, Cout = shape
+    gen = torch.Generator().manual_seed(sum(shape))
+    x = torch.randn(N, H, W_, Cin, generator=gen).to("cuda", torch.bfloat16)
+    Ho, Wo = (H - 1) // 2 + 1, (W_ - 1) // 2 + 1
+    g = (torch.randn(N, Ho, Wo, Cout, generator=gen) * 0.1).to("cuda", torch.bfloat16)
+    a = torch.zeros(Cout, 1, 1, Cin, device="cuda")
+    b = torch.zeros(Cout, 1, 1, Cin, device="cuda")
+    ops.conv_wgrad(x, g, a, KH=1, KW=1, stride=2, pad=0)
+    xs = ops.subsample2(x)
+    assert torch.equal(xs, x[:, ::2, ::2].contiguous())
+    ops.conv_wgrad(xs, g, b, KH=1, KW=1, stride=1, pad=0)
+    torch.cuda.synchronize()
+    ref = _wgrad_ref(x, g, 1, 2, 0)
+    scale = max(1.0, ref.abs().max().item()) * max(1.0, (N * Ho * Wo / 1024) ** 0.5)
+    assert (a.double().view_as(ref) - ref).abs().max().item() <= 2e-5 * scale
+    assert (b.double().view_as(ref) - ref).abs().max().item() <= 2e-5 * scale
