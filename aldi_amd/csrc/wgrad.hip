@@ -365,7 +365,7 @@ constexpr int kMaxGroup = 24;
 struct WgGroup {
     int n;
     int wg_begin[kMaxGroup + 1];      // first workgroup of each problem; wg_begin[n] = grid size
-    int gx[kMaxGroup], gy[kMaxGroup]; // output tiles of each problem (its workgroups: tile-fastest, then split)
+    int gx[kMaxGroup], gy[kMaxGroup], gz[kMaxGroup]; // output tiles and pixel splits of each problem (its workgroups: tile-fastest, then split)
     WgDev p[kMaxGroup];
 };
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void wgrad_bf16_lean_group_kernel(WgGroup G) {
@@ -376,8 +376,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void w
     for (int k = 1; k < G.n; ++k)
         if (bid >= G.wg_begin[k]) i = k;
     i = __builtin_amdgcn_readfirstlane(i);
-    const int local = bid - G.wg_begin[i];
+    int local = bid - G.wg_begin[i];
     const int tiles = G.gx[i] * G.gy[i];
+    const int n_local = tiles * G.gz[i];
+    if (local >= n_local) return;                    // (a problem's workgroup range is padded to a multiple of 8)
+    if (G.p[i].xcd) {
+        // XCD-aware order inside the problem (workgroup b runs on XCD b % 8 and ranges start at multiples of 8): every XCD gets
+        // a contiguous range of (split, tile) pairs, tile fastest, so the tiles that re-read the same x / g rows share one L2
+        const int q = n_local >> 3, r = n_local & 7, xcd = local & 7, idx = local >> 3;
+        local = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
     const int t = local % tiles, bz = local / tiles;
     wgrad_bf16_lean_tile<128, 128, 2, 2>(G.p[i], lds, t % G.gx[i], t / G.gx[i], bz);
 }
@@ -768,6 +776,7 @@ extern "C" int aldi_conv_wgrad_group(const aldi_wgrad_args* args, int n, aldi_st
             continue;
         }
         d.dbg = tn.wgrad_dbg;
+        d.xcd = tn.wgrad_xcd;
         G.p[ng] = d;
         order[ng] = ng;
         ++ng;
@@ -817,8 +826,9 @@ extern "C" int aldi_conv_wgrad_group(const aldi_wgrad_args* args, int n, aldi_st
         L_.p[k] = d;
         L_.gx[k] = cdiv(d.Cout, 128);
         L_.gy[k] = cdiv(d.K, 128);
+        L_.gz[k] = cdiv(d.M, d.pix_per_split);
         L_.wg_begin[k] = wg;
-        wg += L_.gx[k] * L_.gy[k] * cdiv(d.M, d.pix_per_split);
+        wg += (L_.gx[k] * L_.gy[k] * L_.gz[k] + 7) / 8 * 8;
     }
     for (int k = ng; k <= kMaxGroup; ++k) L_.wg_begin[k] = wg;
     hipLaunchKernelGGL(wgrad_bf16_lean_group_kernel, dim3(wg), dim3(256), 0, st, L_);

@@ -291,6 +291,18 @@ def matching_traffic():
     return None, None
 
 
+def _traffic_per_launch(tj, family, launches):
+    """PMC bytes of one step's kernels of `family` divided by the launches THIS run's in-situ profile counts for it (a grouped
+    weight-gradient call is one launch here and several kernels in the counter file), so that it compares with
+    algorithmic_bytes_per_launch; files without per-step totals fall back to their per-kernel mean"""
+    if not tj or family not in tj:
+        return None
+    f = tj[family]
+    if f.get("hbm_bytes_per_step") and launches:
+        return round(f["hbm_bytes_per_step"] / launches)
+    return round(f["hbm_bytes_per_launch"])
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -438,7 +450,7 @@ def main():
         tj, tfile = matching_traffic()
         out["roofline"] = {"bound": "mfma", "kernel": "igemm_kernel<bf16> (conv fwd + dgrad + FC)", "achieved": round(ach, 2), "peak": PEAK_BF16_TFLOPS,
                            "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4),
-                           "traffic": round(tj["igemm"]["hbm_bytes_per_launch"]) if tj else None,
+                           "traffic": _traffic_per_launch(tj, "igemm", ig["launches"]),
                            "traffic_unit": "HBM bytes per igemm launch, rocprofv3 PMC passes of this command (FETCH_SIZE x2 + WRITE_SIZE)",
                            "traffic_source": tfile if tj else "no profiles/r*_pmc_traffic.json matches this source tree (tools/source_hash.py)",
                            "timing": "HIP events around every dense launch of one extra step issued eagerly on one stream (each kernel alone on the chip, as in the rocprofv3 kernel trace under profiles/)",
@@ -451,7 +463,7 @@ def main():
                                             "kernel_ms_per_step": round(wg["ms"], 3), "launches_per_step": wg["launches"],
                                             "avg_launch_us": round(wg["ms"] * 1e3 / max(wg["launches"], 1), 2),
                                             "algorithmic_bytes_per_launch": round(wg["bytes"] / max(wg["launches"], 1)),
-                                            "traffic": round(tj["wgrad"]["hbm_bytes_per_launch"]) if tj and "wgrad" in tj else None},
+                                            "traffic": _traffic_per_launch(tj, "wgrad", wg["launches"])},
                            "step_algorithmic_tflop": step_tflop if not args.align else None,
                            "step_frac_of_mfma_peak": round(step_tflop / (ms * 1e-3) / PEAK_BF16_TFLOPS, 4) if not args.align else None}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

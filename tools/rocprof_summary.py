@@ -158,17 +158,32 @@ def window(d, first="compact_kernel", last="wgrad_"):
 
 
 def pmc(fetch_dir, write_dir, source_sha="", git_sha=""):
-    res = {}
+    """HBM-side traffic of the dense kernel families from the two PMC passes: mean per kernel launch, and the totals of the LAST
+    complete step (between two optimizer launches) with that step's kernel-launch count -- bench.py divides the per-step total by
+    the number of launches ITS in-situ profile counts (a grouped weight-gradient call is one launch there, several kernels here)"""
+    res, step = {}, {}
     for key, d, ctr in (("fetch", fetch_dir, "FETCH_SIZE"), ("write", write_dir, "WRITE_SIZE")):
         per = collections.defaultdict(list)
+        rows = []
         for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
             for r in csv.DictReader(open(f)):
                 if r["Counter_Name"] != ctr:
                     continue
-                k = "igemm" if "igemm_kernel" in r["Kernel_Name"] else "wgrad" if "wgrad_bf16" in r["Kernel_Name"] else None
+                name = r["Kernel_Name"]
+                k = "igemm" if "igemm_kernel" in name else "wgrad" if "wgrad_bf16" in name else "sgd" if "sgd_kernel" in name else None
                 if k:
-                    per[k].append(float(r["Counter_Value"]))
+                    rows.append((int(r["Dispatch_Id"]), k, float(r["Counter_Value"])))
+                    if k != "sgd":
+                        per[k].append(float(r["Counter_Value"]))
         res[key] = {k: (sum(v) / len(v), len(v)) for k, v in per.items()}
+        rows.sort()
+        cuts = [i for i, r in enumerate(rows) if r[1] == "sgd"]
+        tot = collections.defaultdict(lambda: [0.0, 0])
+        if len(cuts) >= 2:
+            for _, k, v in rows[cuts[-2] + 1:cuts[-1]]:
+                tot[k][0] += v
+                tot[k][1] += 1
+        step[key] = tot
     out = {"source_sha256": source_sha, "git_sha": git_sha}
     for k in ("igemm", "wgrad"):
         f, nf = res["fetch"].get(k, (0, 0))
@@ -176,7 +191,9 @@ def pmc(fetch_dir, write_dir, source_sha="", git_sha=""):
         # rocprofv3 reports FETCH_SIZE / WRITE_SIZE in KiB-like units of 1 KB on this stack; gfx950 FETCH_SIZE counts 128-B
         # requests at 64 B (MI355X_MICROARCH.md "HBM"): double it.  WRITE_SIZE is used as reported (uncalibrated).
         out[k] = {"fetch_size_raw_kb_per_launch": f, "write_size_raw_kb_per_launch": w, "launches_fetch_pass": nf, "launches_write_pass": nw,
-                  "hbm_bytes_per_launch": (2.0 * f + w) * 1024.0}
+                  "hbm_bytes_per_launch": (2.0 * f + w) * 1024.0,
+                  "hbm_bytes_per_step": (2.0 * step["fetch"][k][0] + step["write"][k][0]) * 1024.0,
+                  "kernel_launches_per_step": step["fetch"][k][1]}
     print(json.dumps(out, indent=1))
 
 
