@@ -169,6 +169,38 @@ __global__ __launch_bounds__(256) void avgpool_kernel(const T* __restrict__ x, T
     if (w == 0 && c < C) Elem<T>::st(y + (long)n * C + c, (red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]) / (float)HW);
 }
 
+// The same in two launches over pixel ranges (the image discriminator pools a 196 x 332 map: eight workgroups walking 65 k pixels
+// each took 4.4 ms): part[n][s][c] = sum over the s-th pixel range (fp32), then y = sum_s part / HW.  Deterministic.
+constexpr int kPoolSplits = 128;
+template <typename T>
+__global__ __launch_bounds__(256) void avgpool_part_kernel(const T* __restrict__ x, float* __restrict__ part, int HW, int C) {
+    __shared__ float red[4][64];
+    const int n = blockIdx.z, sp = blockIdx.y, c = blockIdx.x * 64 + (threadIdx.x & 63), w = threadIdx.x >> 6;
+    const int per = (HW + kPoolSplits - 1) / kPoolSplits, p0 = sp * per, p1 = min(HW, p0 + per);
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    if (c < C) {
+        const T* xp = x + (long)n * HW * C + c;
+        int p = p0 + w;
+        for (; p + 12 < p1; p += 16) {                 // four independent loads in flight per lane
+            s0 += Elem<T>::ld(xp + (long)p * C); s1 += Elem<T>::ld(xp + (long)(p + 4) * C);
+            s2 += Elem<T>::ld(xp + (long)(p + 8) * C); s3 += Elem<T>::ld(xp + (long)(p + 12) * C);
+        }
+        for (; p < p1; p += 4) s0 += Elem<T>::ld(xp + (long)p * C);
+    }
+    red[w][threadIdx.x & 63] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (w == 0 && c < C) part[((long)n * kPoolSplits + sp) * C + c] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+template <typename T>
+__global__ void avgpool_finish_kernel(const float* __restrict__ part, T* __restrict__ y, int N, int HW, int C) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N * C) return;
+    const int n = i / C, c = i - n * C;
+    float s = 0.f;
+    for (int sp = 0; sp < kPoolSplits; ++sp) s += part[((long)n * kPoolSplits + sp) * C + c];
+    Elem<T>::st(y + i, s / (float)HW);
+}
+
 // backward of ReLU -> avgpool: gx[n][p][c] = act[n][p][c] > 0 ? gy[n][c] / HW : 0
 template <typename T>
 __global__ void avgpool_bwd_kernel(const T* __restrict__ gy, const T* __restrict__ act, T* __restrict__ gx, int N, int HW, int C) {
@@ -228,8 +260,23 @@ extern "C" int aldi_domain_bce(const float* pred, int ld, int R, float label, fl
     return ALDI_OK;
 }
 
-extern "C" int aldi_avgpool(const void* x, void* y, int N, int HW, int C, int dtype, aldi_stream_t stream) {
+extern "C" size_t aldi_avgpool_workspace(int N, int C) { return (size_t)N * kPoolSplits * (size_t)C * sizeof(float); }
+
+extern "C" int aldi_avgpool(const void* x, void* y, int N, int HW, int C, int dtype, void* workspace, aldi_stream_t stream) {
     hipStream_t st = static_cast<hipStream_t>(stream);
+    if (workspace && HW >= 4 * kPoolSplits) {            // large maps: pixel ranges in parallel, then the sum of the partial sums
+        float* part = static_cast<float*>(workspace);
+        dim3 g2(cdiv(C, 64), kPoolSplits, N);
+        if (dtype == ALDI_BF16) {
+            hipLaunchKernelGGL(avgpool_part_kernel<bf16_t>, g2, dim3(256), 0, st, (const bf16_t*)x, part, HW, C);
+            hipLaunchKernelGGL(avgpool_finish_kernel<bf16_t>, dim3(cdiv(N * C, 256)), dim3(256), 0, st, part, (bf16_t*)y, N, HW, C);
+        } else {
+            hipLaunchKernelGGL(avgpool_part_kernel<float>, g2, dim3(256), 0, st, (const float*)x, part, HW, C);
+            hipLaunchKernelGGL(avgpool_finish_kernel<float>, dim3(cdiv(N * C, 256)), dim3(256), 0, st, part, (float*)y, N, HW, C);
+        }
+        ALDI_CHECK_LAUNCH();
+        return ALDI_OK;
+    }
     dim3 grid(cdiv(C, 64), N);
     if (dtype == ALDI_BF16) hipLaunchKernelGGL(avgpool_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)x, (bf16_t*)y, HW, C);
     else hipLaunchKernelGGL(avgpool_kernel<float>, grid, dim3(256), 0, st, (const float*)x, (float*)y, HW, C);

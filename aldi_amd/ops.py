@@ -433,7 +433,8 @@ def domain_bce(pred, ld, R, label, weight, grad_scale, grad, loss):
 def avgpool(x: torch.Tensor) -> torch.Tensor:
     N, H, W_, Cc = x.shape
     y = torch.empty((N, 1, 1, Cc), dtype=x.dtype, device=x.device)
-    L.call("aldi_avgpool", _p(x), _p(y), N, H * W_, Cc, dtype_code(x.dtype), stream_ptr())
+    ws = torch.empty(max(int(L.lib.aldi_avgpool_workspace(N, Cc)), 16), dtype=torch.uint8, device=x.device)
+    L.call("aldi_avgpool", _p(x), _p(y), N, H * W_, Cc, dtype_code(x.dtype), _p(ws), stream_ptr())
     return y
 
 

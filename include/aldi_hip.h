@@ -320,7 +320,8 @@ int aldi_domain_bce(const float* pred, int ld, int R, float label, float weight,
                     int dtype, aldi_stream_t stream);
 /* ConvDiscriminator's AdaptiveAvgPool2d(1) (aldi/align.py:114): x [N][HW][C] -> y [N][C]; and the
  * backward through ReLU + pool: gx = act > 0 ? gy / HW : 0. */
-int aldi_avgpool(const void* x, void* y, int N, int HW, int C, int dtype, aldi_stream_t stream);
+size_t aldi_avgpool_workspace(int N, int C);      /* bytes of fp32 partial sums aldi_avgpool may use (nullable workspace: one workgroup per 64 channels) */
+int aldi_avgpool(const void* x, void* y, int N, int HW, int C, int dtype, void* workspace, aldi_stream_t stream);
 int aldi_avgpool_bwd(const void* gy, const void* act, void* gx, int N, int HW, int C, int dtype, aldi_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------

@@ -528,3 +528,17 @@ def test_ema_update_writes_the_compute_copy_in_the_same_pass():
         torch.cuda.synchronize()
         assert torch.equal(t, ref)
         assert torch.equal(comp, ops.cast_from_f32(ref[:nc], torch.bfloat16))
+
+
+@pytest.mark.parametrize("shape", [(2, 196, 332, 256), (1, 9, 11, 256), (3, 40, 50, 64)])
+def test_avgpool_large_and_small_maps(shape):
+    """AdaptiveAvgPool2d(1) of the image discriminator (aldi/align.py:113): the split form (large maps) and the one-pass form"""
+    from aldi_amd import ops
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(*shape, generator=g).to(DEV, torch.bfloat16)
+    y = ops.avgpool(x)
+    ref = x.float().mean(dim=(1, 2)).view(shape[0], 1, 1, shape[3])
+    assert (y.float() - ref).abs().max().item() <= 1e-2 * max(1.0, ref.abs().max().item())
+    xf = x.float()
+    yf = ops.avgpool(xf)
+    assert (yf - ref).abs().max().item() <= 1e-5
