@@ -137,11 +137,14 @@ def get_cfg() -> CfgNode:
         "ANCHOR_GENERATOR": {"SIZES": [[32], [64], [128], [256], [512]], "ASPECT_RATIOS": [[0.5, 1.0, 2.0]]},
         "RPN": {"IN_FEATURES": ["p2", "p3", "p4", "p5", "p6"], "PRE_NMS_TOPK_TRAIN": 2000, "PRE_NMS_TOPK_TEST": 1000,
                 "POST_NMS_TOPK_TRAIN": 1000, "POST_NMS_TOPK_TEST": 1000, "NMS_THRESH": 0.7, "BATCH_SIZE_PER_IMAGE": 256,
-                "POSITIVE_FRACTION": 0.5, "IOU_THRESHOLDS": [0.3, 0.7], "CONV_DIMS": [-1]},
+                "POSITIVE_FRACTION": 0.5, "IOU_THRESHOLDS": [0.3, 0.7], "CONV_DIMS": [-1], "BBOX_REG_WEIGHTS": [1.0, 1.0, 1.0, 1.0],
+                "SMOOTH_L1_BETA": 0.0, "BBOX_REG_LOSS_TYPE": "smooth_l1", "LOSS_WEIGHT": 1.0, "BBOX_REG_LOSS_WEIGHT": 1.0},
         "ROI_HEADS": {"NAME": "StandardROIHeads", "NUM_CLASSES": 80, "IN_FEATURES": ["p2", "p3", "p4", "p5"], "BATCH_SIZE_PER_IMAGE": 512,
-                      "POSITIVE_FRACTION": 0.25, "IOU_THRESHOLDS": [0.5], "SCORE_THRESH_TEST": 0.05, "NMS_THRESH_TEST": 0.5},
+                      "POSITIVE_FRACTION": 0.25, "IOU_THRESHOLDS": [0.5], "SCORE_THRESH_TEST": 0.05, "NMS_THRESH_TEST": 0.5,
+                      "PROPOSAL_APPEND_GT": True},
         "ROI_BOX_HEAD": {"NAME": "FastRCNNConvFCHead", "NUM_FC": 2, "POOLER_RESOLUTION": 7, "FC_DIM": 1024, "NUM_CONV": 0, "CONV_DIM": 256,
-                         "NORM": ""},
+                         "NORM": "", "BBOX_REG_WEIGHTS": [10.0, 10.0, 5.0, 5.0], "SMOOTH_L1_BETA": 0.0, "BBOX_REG_LOSS_TYPE": "smooth_l1",
+                         "POOLER_SAMPLING_RATIO": 0, "POOLER_TYPE": "ROIAlignV2", "CLS_AGNOSTIC_BBOX_REG": False},
     })
     _C.INPUT = CN({"FORMAT": "BGR", "MIN_SIZE_TRAIN": (800,), "MAX_SIZE_TRAIN": 1333, "MIN_SIZE_TEST": 800, "MAX_SIZE_TEST": 1333})
     _C.DATASETS = CN({"TRAIN": (), "TEST": ()})

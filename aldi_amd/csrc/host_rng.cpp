@@ -11,6 +11,7 @@
 #include "../../include/aldi_hip.h"
 int aldi_set_error_msg(int code, const char* msg);   // core.hip
 #include <string.h>
+#include <mutex>
 #include <thread>
 #include <vector>
 
@@ -150,14 +151,29 @@ struct Cursor {
 };
 
 constexpr int kMaxStreams = 8;
-Stream g_streams[kMaxStreams];          // buffers persist; the first g_nstreams are valid for the next script
-int g_nstreams = 0;
-long g_stream_hits = 0;
-std::vector<std::thread> g_fillers;
-void join_fillers() {
-    for (auto& t : g_fillers) t.join();
-    g_fillers.clear();
-}
+// The pre-generated streams and their filler threads are one object: `mu` serialises the entry points that touch it (two
+// Python threads may call into the library), and the destructor joins -- a process that exits between a prefetch and the
+// script that would have joined it (an exception in the caller, the last step of a run) would otherwise leave joinable
+// std::threads in static storage and die in std::terminate, masking the real error.
+struct StreamSet {
+    std::mutex mu;
+    Stream streams[kMaxStreams];        // buffers persist; the first `n` are valid for the next script
+    int n = 0;
+    long hits = 0;
+    std::vector<std::thread> fillers;
+    void join() {
+        for (auto& t : fillers)
+            if (t.joinable()) t.join();
+        fillers.clear();
+    }
+    ~StreamSet() { join(); }
+};
+StreamSet g_set;
+Stream* const g_streams = g_set.streams;
+int& g_nstreams = g_set.n;
+long& g_stream_hits = g_set.hits;
+std::vector<std::thread>& g_fillers = g_set.fillers;
+void join_fillers() { g_set.join(); }
 
 // first k entries of torch.randperm(n) from `mt` (an engine or a stream cursor), which ends where torch's generator would
 template <typename OutT, typename Gen>
@@ -239,6 +255,7 @@ static int run_script(unsigned char* state, const long* script, int nops, int* o
         }
     }
     segs.back().end = nops;
+    std::lock_guard<std::mutex> lock(g_set.mu);
     join_fillers();
     auto ops = [&](Seg& sg, auto& gen) {
         static thread_local std::vector<int> scratch;
@@ -378,6 +395,7 @@ extern "C" int aldi_step_draws(unsigned char* state, const int* counts, int N, c
 extern "C" int aldi_torch_rng_prefetch(const unsigned char* state, const long* seeds, int nseeds, long max_draws) {
     if (nseeds < 0 || (nseeds > 0 && !seeds) || max_draws < 0 || max_draws > (1L << 28))
         return aldi_set_error_msg(ALDI_ERR_ARG, "torch_rng_prefetch: bad args");
+    std::lock_guard<std::mutex> lock(g_set.mu);
     join_fillers();
     if (nseeds + (state ? 1 : 0) > kMaxStreams) return aldi_set_error_msg(ALDI_ERR_ARG, "torch_rng_prefetch: too many streams");
     int j = 0;
@@ -403,4 +421,7 @@ extern "C" int aldi_torch_rng_prefetch(const unsigned char* state, const long* s
 }
 
 // how many script segments were served from a pre-generated stream since the library was loaded (tests, bench stats)
-extern "C" int aldi_torch_rng_prefetch_hits(void) { return (int)(g_stream_hits & 0x7fffffff); }
+extern "C" int aldi_torch_rng_prefetch_hits(void) {
+    std::lock_guard<std::mutex> lock(g_set.mu);
+    return (int)(g_stream_hits & 0x7fffffff);
+}

@@ -12,22 +12,29 @@ from . import synthetic
 WEAK_IMG_KEY = "img_weak"
 
 
+def _weak_view(batch):
+    """independent copy of a batch whose "image" is the weakly augmented view (when the mapper attached one)"""
+    out = []
+    for rec in batch:
+        rec = copy.deepcopy(rec)
+        weak = rec.get(WEAK_IMG_KEY)
+        if weak is not None:
+            rec["image"] = weak
+        out.append(rec)
+    return out
+
+
 def unpack_data_weak_strong(labeled, unlabeled, batch_contents=("labeled_weak", "labeled_strong", "unlabeled_strong")):
-    labeled_weak = None
-    if "labeled_weak" in batch_contents and labeled is not None:
-        labeled_weak = copy.deepcopy(labeled)
-        for img in labeled_weak:
-            if WEAK_IMG_KEY in img:
-                img["image"] = img[WEAK_IMG_KEY]
-    labeled_strong = labeled if "labeled_strong" in batch_contents else None
-    unlabeled_weak = None
-    if ("unlabeled_weak" in batch_contents or "unlabeled_strong" in batch_contents) and unlabeled is not None:
-        unlabeled_weak = copy.deepcopy(unlabeled)
-        for img in unlabeled_weak:
-            if WEAK_IMG_KEY in img:
-                img["image"] = img[WEAK_IMG_KEY]
-    unlabeled_strong = unlabeled if "unlabeled_strong" in batch_contents else None
-    return labeled_weak, labeled_strong, unlabeled_weak, unlabeled_strong
+    """-> (labeled_weak, labeled_strong, unlabeled_weak, unlabeled_strong), None for what `batch_contents` does not ask for
+    (reference aldi/dataloader.py:57-80; pinned by golden g7).  The strong entries are the incoming lists themselves; the weak
+    ones are copies.  The unlabeled weak view also exists whenever the strong one is requested: the teacher labels it."""
+    wanted = set(batch_contents)
+    views = {"labeled": (labeled, {"labeled_weak"}), "unlabeled": (unlabeled, {"unlabeled_weak", "unlabeled_strong"})}
+    out = {}
+    for prefix, (batch, weak_triggers) in views.items():
+        out[prefix + "_weak"] = _weak_view(batch) if batch is not None and wanted & weak_triggers else None
+        out[prefix + "_strong"] = batch if prefix + "_strong" in wanted else None
+    return out["labeled_weak"], out["labeled_strong"], out["unlabeled_weak"], out["unlabeled_strong"]
 
 
 class WeakStrongDataloader:

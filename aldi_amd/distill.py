@@ -18,7 +18,6 @@ from __future__ import annotations
 
 import torch
 
-from .engine import RPN_BATCH, RPN_POS_FRAC, ROI_BATCH, ROI_POS_FRAC
 from .helpers import ManualSeed, ReplaceProposalsOnce, SaveIO, set_attributes
 from .model import GeneralizedRCNN, wire_losses
 from .pseudolabeler import PseudoLabeler
@@ -145,7 +144,7 @@ class ALDIDistiller(Distiller):
         # 3) teacher "train-mode forward" on the weak views with the student's proposals:
         #    trunk + RPN head are the ones computed in (1); RNG advanced as the reference would
         torch.manual_seed(self.seeder.seed)
-        student.engine._sample(c.roi_host_counts, ROI_BATCH, ROI_POS_FRAC)        # the teacher's identical ROI draws
+        student.engine._sample(c.roi_host_counts, student.engine.p.roi_batch, student.engine.p.roi_pos_frac)        # the teacher's identical ROI draws
         t_pred = teacher.engine.box_head_on(tc, c.rois, c.R)
         teacher.proposal_generator.rpn_head.fire(None, tc.head)
         teacher.roi_heads.box_predictor.fire(None, t_pred)

@@ -9,6 +9,7 @@ aldi/distill.py:157,162 and aldi/pseudolabeler.py:21, and autograd's backward at
 """
 from __future__ import annotations
 
+import dataclasses
 import inspect
 import math
 import os
@@ -84,6 +85,7 @@ class Weights:
         self._wt: Dict[str, torch.Tensor] = {}
         self._wt_keys: List[str] = []          # dgrad weights requested so far (re-derived in one launch per refresh)
         self._wt_plan = None
+        self.wt_epoch = 0
         self._neg1: Dict[int, torch.Tensor] = {}
         self._stem_pk, self._stem_name = None, None
         self.lazy_wt = False             # True: sgd_step leaves the dgrad weights stale until someone asks / refreshes
@@ -144,6 +146,8 @@ class Weights:
             self._wt[key] = ops.dgrad_weights(*self._wt_source(key), self.dtype)
             if key not in self._wt_keys:
                 self._wt_keys.append(key)
+                if self._wt_plan is not None:
+                    self.wt_epoch += 1      # recorded graphs hold the old plan's buffers (fused_step drops them)
                 self._wt_plan = None
         return self._wt[key]
 
@@ -262,6 +266,80 @@ def make_anchors(shapes: Sequence[Tuple[int, int]], device, sizes: Sequence[floa
     return torch.cat(out).contiguous().to(device)
 
 
+@dataclasses.dataclass(frozen=True)
+class D2Params:
+    """The Detectron2 config keys the engine's arithmetic depends on (defaults = detectron2's own; the module
+    constants above).  `from_cfg` reads them from the config node the reference hands to `build_model` (configs/detectron2/
+    Base-RCNN-FPN.yaml + overrides) and REJECTS values the kernels do not implement instead of silently ignoring them."""
+    pixel_mean: Tuple[float, ...] = PIXEL_MEAN
+    pixel_std: Tuple[float, ...] = PIXEL_STD
+    anchor_sizes: Tuple[float, ...] = ANCHOR_SIZES
+    rpn_batch: int = RPN_BATCH
+    rpn_pos_frac: float = RPN_POS_FRAC
+    rpn_iou: Tuple[float, float] = (0.3, 0.7)
+    rpn_pre: Tuple[int, int] = RPN_PRE          # (train, test)
+    rpn_post: Tuple[int, int] = RPN_POST
+    rpn_nms: float = RPN_NMS
+    roi_batch: int = ROI_BATCH
+    roi_pos_frac: float = ROI_POS_FRAC
+    roi_iou: float = 0.5
+    roi_weights: Tuple[float, float, float, float] = ROI_WEIGHTS
+    score_thresh: float = SCORE_THRESH
+    nms_test: float = NMS_TEST
+    dets: int = DETS
+
+    @classmethod
+    def from_cfg(cls, cfg) -> "D2Params":
+        M = cfg.MODEL
+
+        def get(node, key, default):
+            return node.get(key, default) if hasattr(node, "get") else getattr(node, key, default)
+
+        def need(cond, what):
+            if not cond:
+                raise ValueError(f"aldi_amd R50-FPN engine: unsupported config value: {what}")
+        rpn, roi, box, ag = M.RPN, M.ROI_HEADS, get(M, "ROI_BOX_HEAD", {}), M.ANCHOR_GENERATOR
+        sizes = [list(s_) for s_ in ag.SIZES]
+        need(len(sizes) == 5 and all(len(s_) == 1 for s_ in sizes), f"ANCHOR_GENERATOR.SIZES {sizes} (one size per level p2..p6)")
+        ratios = [list(r_) for r_ in ag.ASPECT_RATIOS]
+        need(all(tuple(float(v) for v in r_) == ANCHOR_RATIOS for r_ in ratios), f"ANCHOR_GENERATOR.ASPECT_RATIOS {ratios} (kernels: {ANCHOR_RATIOS})")
+        need(len(M.PIXEL_MEAN) == 3 and len(M.PIXEL_STD) == 3, "PIXEL_MEAN / PIXEL_STD must have 3 entries")
+        need(list(get(rpn, "IN_FEATURES", ["p2", "p3", "p4", "p5", "p6"])) == ["p2", "p3", "p4", "p5", "p6"], "RPN.IN_FEATURES")
+        need(list(get(roi, "IN_FEATURES", ["p2", "p3", "p4", "p5"])) == ["p2", "p3", "p4", "p5"], "ROI_HEADS.IN_FEATURES")
+        need(tuple(get(rpn, "BBOX_REG_WEIGHTS", (1.0, 1.0, 1.0, 1.0))) == (1.0, 1.0, 1.0, 1.0), "RPN.BBOX_REG_WEIGHTS != (1, 1, 1, 1)")
+        need(float(get(rpn, "SMOOTH_L1_BETA", 0.0)) == 0.0 and float(get(box, "SMOOTH_L1_BETA", 0.0)) == 0.0, "SMOOTH_L1_BETA != 0 (the losses are pure L1)")
+        need(get(rpn, "BBOX_REG_LOSS_TYPE", "smooth_l1") == "smooth_l1" and get(box, "BBOX_REG_LOSS_TYPE", "smooth_l1") == "smooth_l1", "BBOX_REG_LOSS_TYPE")
+        need(float(get(rpn, "LOSS_WEIGHT", 1.0)) == 1.0 and float(get(rpn, "BBOX_REG_LOSS_WEIGHT", 1.0)) == 1.0, "RPN loss weights != 1")
+        need(int(get(box, "POOLER_RESOLUTION", POOL)) == POOL and int(get(box, "POOLER_SAMPLING_RATIO", 0)) == 0 and
+             get(box, "POOLER_TYPE", "ROIAlignV2") == "ROIAlignV2", "ROI_BOX_HEAD pooler (kernels: ROIAlignV2, 7x7, adaptive sampling)")
+        need(not get(box, "CLS_AGNOSTIC_BBOX_REG", False), "CLS_AGNOSTIC_BBOX_REG")
+        need(get(roi, "PROPOSAL_APPEND_GT", True), "ROI_HEADS.PROPOSAL_APPEND_GT False")
+        need(len(rpn.IOU_THRESHOLDS) == 2 and len(roi.IOU_THRESHOLDS) == 1, "IOU_THRESHOLDS (RPN: two, ROI heads: one)")
+        pre = (int(rpn.PRE_NMS_TOPK_TRAIN), int(rpn.PRE_NMS_TOPK_TEST))
+        post = (int(rpn.POST_NMS_TOPK_TRAIN), int(rpn.POST_NMS_TOPK_TEST))
+        need(max(pre) <= 2048 and min(pre + post) >= 1, f"RPN.PRE_NMS_TOPK {pre} (the NMS workspace holds 2048 boxes per level and image)")
+        dets = int(get(get(cfg, "TEST", {}), "DETECTIONS_PER_IMAGE", DETS))
+        need(1 <= dets <= GMAX, f"TEST.DETECTIONS_PER_IMAGE {dets} (<= {GMAX}: pseudo-label rows)")
+        need(int(rpn.BATCH_SIZE_PER_IMAGE) >= 1 and int(roi.BATCH_SIZE_PER_IMAGE) >= 1, "BATCH_SIZE_PER_IMAGE")
+        return cls(pixel_mean=tuple(float(v) for v in M.PIXEL_MEAN), pixel_std=tuple(float(v) for v in M.PIXEL_STD),
+                   anchor_sizes=tuple(float(s_[0]) for s_ in sizes), rpn_batch=int(rpn.BATCH_SIZE_PER_IMAGE), rpn_pos_frac=float(rpn.POSITIVE_FRACTION),
+                   rpn_iou=(float(rpn.IOU_THRESHOLDS[0]), float(rpn.IOU_THRESHOLDS[1])), rpn_pre=pre, rpn_post=post, rpn_nms=float(rpn.NMS_THRESH),
+                   roi_batch=int(roi.BATCH_SIZE_PER_IMAGE), roi_pos_frac=float(roi.POSITIVE_FRACTION), roi_iou=float(roi.IOU_THRESHOLDS[0]),
+                   roi_weights=tuple(float(v) for v in get(box, "BBOX_REG_WEIGHTS", ROI_WEIGHTS)), score_thresh=float(roi.SCORE_THRESH_TEST),
+                   nms_test=float(roi.NMS_THRESH_TEST), dets=dets)
+
+
+def raise_on_error(code: int, who: str = "engine"):
+    """decode an engine's device error word (RCNN.err; the kernels OR bits into it, nothing on the device stops)"""
+    if code & 1:       # detectron2's find_top_rpn_proposals raises the same way
+        raise FloatingPointError(f"{who}: predicted boxes or scores contain Inf/NaN. Training has diverged.")
+    if code & 2:
+        raise RuntimeError(f"{who}: sparse RPN-head backward: more active pixels than (2 * BATCH_SIZE_PER_IMAGE + 4 * positives) per image; "
+                           "the excess was dropped, gradients of this step are wrong")
+    if code:
+        raise RuntimeError(f"{who}: device error word {code}")
+
+
 class Ctx(dict):
     """Saved tensors / intermediates of one forward (what the reference reads through forward hooks)."""
     __getattr__ = dict.__getitem__
@@ -269,8 +347,12 @@ class Ctx(dict):
 
 
 class RCNN:
-    def __init__(self, weights: Weights, num_classes: int):
+    p = D2Params()          # (subclasses that do not go through this constructor run on detectron2's defaults)
+
+    def __init__(self, weights: Weights, num_classes: int, params: Optional[D2Params] = None):
         self.wts = weights
+        if params is not None:
+            self.p = params
         self.K = num_classes
         self.device, self.dtype = weights.device, weights.dtype
         self.Cp = weights.layout.t["box_pred"].rows
@@ -349,7 +431,7 @@ class RCNN:
                     h, w = h // 2, w // 2
             shapes.append(((shapes[3][0] - 1) // 2 + 1, (shapes[3][1] - 1) // 2 + 1))
             geom = ops.make_geom(shapes, NUM_ANCHORS, self.Ch)
-            anchors = make_anchors(shapes, self.device, getattr(self, "anchor_sizes", ANCHOR_SIZES))
+            anchors = make_anchors(shapes, self.device, getattr(self, "anchor_sizes", self.p.anchor_sizes))
             self._anchor_cache[key] = (shapes, geom, anchors)
             while len(self._anchor_cache) > 16:               # multi-scale training: keep the most recent padded sizes only (4 MB of anchors each)
                 self._anchor_cache.pop(next(iter(self._anchor_cache)))
@@ -428,10 +510,10 @@ class RCNN:
         bu = "backbone.bottom_up."
         if self.dtype == torch.bfloat16 and self.fused_stem:
             x = ops.stem_pool_forward(st_u8, sizes, W.stem_packed(bu + "stem.conv1"), W.scale(bu + "stem.conv1"), W.shift(bu + "stem.conv1"),
-                                      PIXEL_MEAN, PIXEL_STD)
+                                      self.p.pixel_mean, self.p.pixel_std)
         else:
             stem = ops.stem_forward(st_u8, sizes, W.w_master(bu + "stem.conv1"), W.scale(bu + "stem.conv1"), W.shift(bu + "stem.conv1"),
-                                    PIXEL_MEAN, PIXEL_STD, self.dtype)
+                                    self.p.pixel_mean, self.p.pixel_std, self.dtype)
             x = ops.maxpool3s2(stem)
             del stem
         blocks = []
@@ -526,7 +608,7 @@ class RCNN:
         best_idx = torch.empty((N, sumA), dtype=torch.int32, device=dev)
         labels = torch.empty((N, sumA), dtype=torch.int32, device=dev)
         scratch = torch.empty((N, GMAX), dtype=torch.int32, device=dev)
-        ops.box_match(anchors, 0, None, sumA, gt["boxes"], gt["count"], GMAX, N, 0.3, 0.7, True, best_iou, best_idx, scratch, labels)
+        ops.box_match(anchors, 0, None, sumA, gt["boxes"], gt["count"], GMAX, N, self.p.rpn_iou[0], self.p.rpn_iou[1], True, best_iou, best_idx, scratch, labels)
         lists = torch.empty((N, 2, sumA), dtype=torch.int32, device=dev)
         counts = torch.empty((N, 2), dtype=torch.int32, device=dev)
         ops.compact_labels(labels, sumA, N, 0, lists, counts)
@@ -535,12 +617,14 @@ class RCNN:
     def rpn_sample(self, lists, counts, N, host_counts=None):
         """host draws (2 randperm per image) -> NEW label tensor in {-1,0,1}; returns (labels, n_valid, n_fg, host_counts)."""
         if host_counts is None:
-            host_counts = counts.cpu().tolist()             # device->host sync: the RNG needs the list lengths
+            both = torch.cat([counts.view(-1), self.err.view(-1)]).cpu().tolist()   # device->host sync: the RNG needs the list lengths
+            raise_on_error(both[-1])
+            host_counts = [both[2 * i: 2 * i + 2] for i in range(N)]
         lists = lists.contiguous()
-        sel, nsel, nsel_h = self._sample(host_counts, RPN_BATCH, RPN_POS_FRAC)
+        sel, nsel, nsel_h = self._sample(host_counts, self.p.rpn_batch, self.p.rpn_pos_frac)
         L_ = lists.shape[2]
         labels = torch.empty((N, L_), dtype=torch.int32, device=self.device)
-        ops.rpn_apply_sample(labels, L_, N, lists, sel, nsel, RPN_BATCH)
+        ops.rpn_apply_sample(labels, L_, N, lists, sel, nsel, self.p.rpn_batch)
         n_fg = sum(a for a, _ in nsel_h)
         n_valid = sum(a + b for a, b in nsel_h)
         return labels, n_valid, n_fg, host_counts
@@ -548,11 +632,11 @@ class RCNN:
     def proposals(self, c: Ctx, geom, anchors, hw, N, training: bool):
         nl = 5
         ws = self.workspace("rpn", ops.rpn_proposals_workspace(N, nl))
-        post = RPN_POST[0 if training else 1]
+        post = self.p.rpn_post[0 if training else 1]
         boxes = torch.empty((N, post, 4), dtype=torch.float32, device=self.device)
         scores = torch.empty((N, post), dtype=torch.float32, device=self.device)
         count = torch.empty((N,), dtype=torch.int32, device=self.device)
-        ops.rpn_proposals(geom, c.head, anchors, hw, N, RPN_PRE[0 if training else 1], post, RPN_NMS, ws, boxes, scores, count, self.err)
+        ops.rpn_proposals(geom, c.head, anchors, hw, N, self.p.rpn_pre[0 if training else 1], post, self.p.rpn_nms, ws, boxes, scores, count, self.err)
         return boxes, scores, count
 
     # ------------------------------------------------------------------ training forward
@@ -574,7 +658,7 @@ class RCNN:
         labels, _, _, c.rpn_host_counts = self.rpn_sample(lists, counts, N)
         c.rpn_labels, c.rpn_matched, c.rpn_lists, c.rpn_counts = labels, matched, lists, counts
         c.loss_rpn = torch.zeros(2, dtype=torch.float32, device=dev)
-        ops.rpn_loss(geom, c.head, None, anchors, labels, matched, gt["boxes"], gt["count"], GMAX, N, 1.0 / (RPN_BATCH * N), 0.0, 0.0, c.loss_rpn)
+        ops.rpn_loss(geom, c.head, None, anchors, labels, matched, gt["boxes"], gt["count"], GMAX, N, 1.0 / (self.p.rpn_batch * N), 0.0, 0.0, c.loss_rpn)
         # --- proposals (detached)
         c.props, c.prop_scores, c.prop_count = self.proposals(c, geom, anchors, hw, N, training=True)
         # --- ROI heads
@@ -585,7 +669,7 @@ class RCNN:
         self.roi_sample(c, c.props, c.prop_count, gt, N)
         self.roi_forward(c)
         c.loss_box = torch.zeros(2, dtype=torch.float32, device=dev)
-        ops.box_loss(c.pred, self.Cp, self.K, c.R, c.rois, c.r_cls, c.r_gt, ROI_WEIGHTS, 0.0, 0.0, None, c.loss_box)
+        ops.box_loss(c.pred, self.Cp, self.K, c.R, c.rois, c.r_cls, c.r_gt, self.p.roi_weights, 0.0, 0.0, None, c.loss_box)
         c.align = {}
         c.distill = None
         c.labeled, c.da_weights = labeled, da_weights
@@ -632,7 +716,8 @@ class RCNN:
         if side is not None:
             torch.cuda.current_stream().wait_stream(side)
         prep = self._roi_prepare(c.props, c.prop_count, gt, N)
-        both = torch.cat([counts.view(-1), prep["counts"].view(-1)]).cpu().tolist()      # the ONE device->host sync of the student pass
+        both = torch.cat([counts.view(-1), prep["counts"].view(-1), self.err.view(-1)]).cpu().tolist()      # the ONE device->host sync of the student pass
+        raise_on_error(both[-1], "student")
         rpn_counts = [both[2 * i: 2 * i + 2] for i in range(N)]
         roi_counts = [both[2 * N + 2 * i: 2 * N + 2 * i + 2] for i in range(N)]
         # host draws, chunk by chunk, in the sequential schedule's order
@@ -643,18 +728,18 @@ class RCNN:
             n1 = n0 + len(sp["images"])
             if sp.get("pre_rpn"):
                 sp["pre_rpn"]()
-            a, b, h_ = self._sample_host(rpn_counts[n0:n1], RPN_BATCH, RPN_POS_FRAC)
+            a, b, h_ = self._sample_host(rpn_counts[n0:n1], self.p.rpn_batch, self.p.rpn_pos_frac)
             rsel.append(a); rnsel.append(b); rh += h_
             if sp.get("pre_roi"):
                 sp["pre_roi"]()
-            a, b, h2 = self._sample_host(roi_counts[n0:n1], ROI_BATCH, ROI_POS_FRAC)
+            a, b, h2 = self._sample_host(roi_counts[n0:n1], self.p.roi_batch, self.p.roi_pos_frac)
             osel.append(a); onsel.append(b); oh += h2
             chunks.append(dict(n0=n0, n1=n1, labeled=sp.get("labeled", True), do_align=sp.get("do_align", False),
                                da_weights=sp.get("da_weights", (0.0, 0.0)), rpn_counts=rpn_counts[n0:n1], roi_counts=roi_counts[n0:n1]))
             n0 = n1
         labels = torch.empty((N, anchors.shape[0]), dtype=torch.int32, device=dev)
         rsel_d, rnsel_d, osel_d, onsel_d = ops.upload_packed([torch.cat(rsel), torch.cat(rnsel), torch.cat(osel), torch.cat(onsel)], dev)
-        ops.rpn_apply_sample(labels, anchors.shape[0], N, lists, rsel_d, rnsel_d, RPN_BATCH)
+        ops.rpn_apply_sample(labels, anchors.shape[0], N, lists, rsel_d, rnsel_d, self.p.rpn_batch)
         c.rpn_labels, c.rpn_matched, c.rpn_lists, c.rpn_counts = labels, matched, lists, counts
         self._roi_gather(c, prep, osel_d, onsel_d, oh, gt, N)
         r0 = 0
@@ -674,8 +759,8 @@ class RCNN:
             ch["loss_box"] = torch.zeros(2, dtype=torch.float32, device=dev)
             nc = n1 - n0
             ops.rpn_loss(geom, [h[n0:n1] for h in c.head], None, anchors, labels[n0:n1], matched[n0:n1], gt["boxes"][n0:n1], gt["count"][n0:n1],
-                         GMAX, nc, 1.0 / (RPN_BATCH * nc), 0.0, 0.0, ch["loss_rpn"])
-            ops.box_loss(c.pred[r0:r1], self.Cp, self.K, r1 - r0, c.rois[r0:r1], c.r_cls[r0:r1], c.r_gt[r0:r1], ROI_WEIGHTS, 0.0, 0.0, None, ch["loss_box"])
+                         GMAX, nc, 1.0 / (self.p.rpn_batch * nc), 0.0, 0.0, ch["loss_rpn"])
+            ops.box_loss(c.pred[r0:r1], self.Cp, self.K, r1 - r0, c.rois[r0:r1], c.r_cls[r0:r1], c.r_gt[r0:r1], self.p.roi_weights, 0.0, 0.0, None, ch["loss_box"])
             ch["align"] = {}
             ch["distill"] = None
             if ch["do_align"]:
@@ -790,8 +875,8 @@ class RCNN:
                 if ch["distill"] is not None:
                     ch["loss_dist_rpn"], ch["loss_dist_roi"] = l_drpn, l_droi
             ops.rpn_loss(c.geom, heads, gheads, c.anchors, c.rpn_labels[n0:n1], c.rpn_matched[n0:n1], gt["boxes"][n0:n1], gt["count"][n0:n1],
-                         GMAX, nc, 1.0 / (RPN_BATCH * nc), sc("loss_rpn_cls"), sc("loss_rpn_loc"), l_rpn)
-            ops.box_loss(c.pred[r0:r1], self.Cp, self.K, r1 - r0, c.rois[r0:r1], c.r_cls[r0:r1], c.r_gt[r0:r1], ROI_WEIGHTS,
+                         GMAX, nc, 1.0 / (self.p.rpn_batch * nc), sc("loss_rpn_cls"), sc("loss_rpn_loc"), l_rpn)
+            ops.box_loss(c.pred[r0:r1], self.Cp, self.K, r1 - r0, c.rois[r0:r1], c.r_cls[r0:r1], c.r_gt[r0:r1], self.p.roi_weights,
                          sc("loss_cls"), sc("loss_box_reg"), c.gpred[r0:r1], l_box)
             d = ch["distill"]
             if d is not None:
@@ -892,7 +977,7 @@ class RCNN:
         labels = torch.empty((N, Lc), dtype=torch.int32, device=dev)
         cls = torch.empty((N, Lc), dtype=torch.int32, device=dev)
         scratch = torch.empty((N, GMAX), dtype=torch.int32, device=dev)
-        ops.roi_prepare(props, prop_count, P, gt["boxes"], gt["classes"], gt["count"], GMAX, N, self.K, 0.5, cand, ccount, best_iou, best_idx,
+        ops.roi_prepare(props, prop_count, P, gt["boxes"], gt["classes"], gt["count"], GMAX, N, self.K, self.p.roi_iou, cand, ccount, best_iou, best_idx,
                         scratch, labels, cls)
         lists = torch.empty((N, 2, Lc), dtype=torch.int32, device=dev)
         counts = torch.empty((N, 2), dtype=torch.int32, device=dev)
@@ -913,14 +998,14 @@ class RCNN:
         c.r_idx = torch.empty((max(R, 1),), dtype=torch.int32, device=dev)
         if row_off_dev is None:
             row_off_dev = torch.tensor(row_off, dtype=torch.int32).to(dev)
-        ops.roi_gather(prep["cand"], prep["cls"], prep["best_idx"], prep["Lc"], prep["lists"], sel, nsel, ROI_BATCH,
+        ops.roi_gather(prep["cand"], prep["cls"], prep["best_idx"], prep["Lc"], prep["lists"], sel, nsel, self.p.roi_batch,
                        row_off_dev, gt["boxes"], gt["count"], GMAX, N, c.rois, c.r_cls, c.r_gt, c.r_idx)
 
     def roi_sample(self, c: Ctx, props, prop_count, gt, N):
         prep = self._roi_prepare(props, prop_count, gt, N)
         host_counts = prep["counts"].cpu().tolist()          # device->host sync (RNG needs the list lengths)
         c.roi_host_counts = host_counts
-        sel, nsel, nsel_h = self._sample(host_counts, ROI_BATCH, ROI_POS_FRAC)
+        sel, nsel, nsel_h = self._sample(host_counts, self.p.roi_batch, self.p.roi_pos_frac)
         self._roi_gather(c, prep, sel, nsel, nsel_h, gt, N)
 
     def roi_forward(self, c: Ctx):
@@ -962,9 +1047,9 @@ class RCNN:
         dev = self.device
         ws = self.workspace("det", ops.detections_workspace(N))
         d = Ctx()
-        d.boxes = torch.empty((N, DETS, 4), dtype=torch.float32, device=dev)
-        d.scores = torch.empty((N, DETS), dtype=torch.float32, device=dev)
-        d.classes = torch.empty((N, DETS), dtype=torch.int32, device=dev)
+        d.boxes = torch.empty((N, self.p.dets, 4), dtype=torch.float32, device=dev)
+        d.scores = torch.empty((N, self.p.dets), dtype=torch.float32, device=dev)
+        d.classes = torch.empty((N, self.p.dets), dtype=torch.int32, device=dev)
         d.count = torch.empty((N,), dtype=torch.int32, device=dev)
         if pl_out is not None:
             pl_boxes, pl_cls, pl_count = pl_out
@@ -974,7 +1059,7 @@ class RCNN:
             pl_count = torch.empty((N,), dtype=torch.int32, device=dev)
         pl_scores = torch.empty((N, GMAX), dtype=torch.float32, device=dev)
         # the kernel writes rows of GMAX entries and clears what it does not fill
-        ops.detections(pred, self.Cp, self.K, props, pcount, P, N, hw, ROI_WEIGHTS, SCORE_THRESH, NMS_TEST, DETS, pl_thresh, ws,
+        ops.detections(pred, self.Cp, self.K, props, pcount, P, N, hw, self.p.roi_weights, self.p.score_thresh, self.p.nms_test, self.p.dets, pl_thresh, ws,
                        d.boxes, d.scores, d.classes, d.count, pl_boxes, pl_cls, pl_scores, pl_count, self.err)
         c.det = d
         c.pseudo = {"boxes": pl_boxes, "classes": pl_cls, "count": pl_count, "scores": pl_scores}
@@ -995,8 +1080,8 @@ class RCNN:
         c.gpred = torch.zeros((max(c.R, 1), self.Cp), dtype=torch.float32, device=dev)
         gt = c.gt
         ops.rpn_loss(c.geom, c.head, c.ghead, c.anchors, c.rpn_labels, c.rpn_matched, gt["boxes"], gt["count"], GMAX, c.N,
-                     1.0 / (RPN_BATCH * c.N), sc("loss_rpn_cls"), sc("loss_rpn_loc"), scratch)
-        ops.box_loss(c.pred, self.Cp, self.K, c.R, c.rois, c.r_cls, c.r_gt, ROI_WEIGHTS, sc("loss_cls"), sc("loss_box_reg"), c.gpred, scratch)
+                     1.0 / (self.p.rpn_batch * c.N), sc("loss_rpn_cls"), sc("loss_rpn_loc"), scratch)
+        ops.box_loss(c.pred, self.Cp, self.K, c.R, c.rois, c.r_cls, c.r_gt, self.p.roi_weights, sc("loss_cls"), sc("loss_box_reg"), c.gpred, scratch)
         if c.distill is not None:
             d = c.distill
             # each kernel handles a loss pair with ONE scale: split the call when the two scales differ
@@ -1185,13 +1270,14 @@ class RCNN:
         W, T, dev = self.wts, self.dtype, self.device
         N, Cf, Ch = c.N, FPN_C, self.Ch
         # bound on the active pixels of one image: RPN_BATCH sampled anchors of the RPN losses + RPN_BATCH mask positions of the
-        # distillation objectness loss + 4 per foreground position (<= RPN_BATCH / 2) of the distillation L1: the reference's
+        # distillation objectness loss + 4 per foreground position (<= RPN_BATCH * POSITIVE_FRACTION) of the distillation L1: the reference's
         # `repeat_interleave(fg, 4)` mask lands on four consecutive positions of the RAW (N, 4A, H, W) layout, i.e. on four
         # different pixels
-        cap = 4 * RPN_BATCH * N
+        cap = (2 * self.p.rpn_batch + 4 * int(self.p.rpn_batch * self.p.rpn_pos_frac)) * N
         idx = torch.empty(cap, dtype=torch.int32, device=dev)
         count = torch.empty(1, dtype=torch.int32, device=dev)
-        ops.rpn_active_pixels(c.geom, c.ghead, N, cap, idx, count, self.err)
+        ws = torch.empty(ops.rpn_active_pixels_workspace(c.geom, N), dtype=torch.uint8, device=dev)
+        ops.rpn_active_pixels(c.geom, c.ghead, N, cap, idx, count, ws, self.err)
         G = torch.empty((cap, 1, 1, Ch), dtype=T, device=dev)
         Tm = torch.empty((cap, 1, 1, Cf), dtype=T, device=dev)
         X9 = torch.empty((cap, 1, 1, 9 * Cf), dtype=T, device=dev)

@@ -30,7 +30,7 @@ import torch
 
 from . import ops
 from .arch import pad_to
-from .engine import GMAX, RCNN, ROI_BATCH, ROI_POS_FRAC, ROI_WEIGHTS, RPN_BATCH, RPN_POS_FRAC, Ctx
+from .engine import GMAX, RCNN, Ctx
 from .structures import as_record
 
 
@@ -215,7 +215,10 @@ class FusedStep:
         if side is not None:
             main.wait_stream(side)
         prep = eng._roi_prepare(c.props, c.prop_count, gt, N)
-        S.h_counts.copy_(torch.cat([counts.view(-1), prep["counts"].view(-1)]).view(torch.uint8), non_blocking=True)
+        # ... and the two engines' error words ride along (bits set by this phase, or by the previous step's phase B): the host
+        # raises on them right after the hand-over instead of training on silently wrong gradients
+        errs = [eng.err.view(-1), (teng if teng is not None else eng).err.view(-1)]
+        S.h_counts.copy_(torch.cat([counts.view(-1), prep["counts"].view(-1)] + errs).view(torch.uint8), non_blocking=True)
         return SimpleNamespace(c=c, tc=tc, prep=prep)
 
     # ------------------------------------------------------------------------------------------------ host phase
@@ -280,6 +283,8 @@ class FusedStep:
         same seed and `get_rpn_losses` draws a fresh RPN sample (aldi/distill.py:160-162,200-202)."""
         eng, dist_, model = self.eng, self.tr.distiller, self.tr.model
         N = S.N
+        P_ = eng.p
+        RPN_BATCH, RPN_POS_FRAC, ROI_BATCH, ROI_POS_FRAC = P_.rpn_batch, P_.rpn_pos_frac, P_.roi_batch, P_.roi_pos_frac
         both = S.h_counts.view(torch.int32).tolist()
         rpn_counts = [both[2 * i: 2 * i + 2] for i in range(N)]
         roi_counts = [both[2 * N + 2 * i: 2 * N + 2 * i + 2] for i in range(N)]
@@ -305,8 +310,8 @@ class FusedStep:
                 S.word0_arr = (C.c_int * 8)(*[U.word0(k) for k in ("rsel", "rnsel", "osel", "onsel", "row_off", "dsel", "dnsel", "nvf")])
                 S.rows_arr = (C.c_int * N)()
             st = torch.get_rng_state()
-            L.call("aldi_step_draws", st.data_ptr(), S.h_counts.data_ptr(), N, S.chunk_arr, len(S.chunks), old, new, RPN_BATCH,
-                   int(RPN_BATCH * RPN_POS_FRAC), ROI_BATCH, int(ROI_BATCH * ROI_POS_FRAC), U.host.data_ptr(), S.word0_arr, S.rows_arr, 4)
+            L.call("aldi_step_draws", st.data_ptr(), S.h_counts.data_ptr(), N, S.chunk_arr, len(S.chunks), old, new, P_.rpn_batch,
+                   int(P_.rpn_batch * P_.rpn_pos_frac), P_.roi_batch, int(P_.roi_batch * P_.roi_pos_frac), U.host.data_ptr(), S.word0_arr, S.rows_arr, 4)
             torch.set_rng_state(st)
             rows = list(S.rows_arr)
             r0 = 0
@@ -402,6 +407,7 @@ class FusedStep:
         U.upload()
         sumA = c.anchors.shape[0]
         labels = torch.empty((N, sumA), dtype=torch.int32, device=dev)
+        RPN_BATCH = eng.p.rpn_batch
         ops.rpn_apply_sample(labels, sumA, N, c.rpn_lists, U.d("rsel"), U.d("rnsel"), RPN_BATCH)
         c.rpn_labels = labels
         oh = [[0, r] for r in Hst.rows]                       # only the row sums are used downstream
@@ -578,14 +584,22 @@ class FusedStep:
             S.pl_out = tuple(S.gt_all[k][d0:d1] for k in ("boxes", "classes", "count"))
         if S.up is None:
             nd = (chunks[-1]["n1"] - chunks[-1]["n0"]) if do_distill else 1
+            RPN_BATCH, ROI_BATCH = eng.p.rpn_batch, eng.p.roi_batch
             S.up = _Packed([("rsel", (N, 2, RPN_BATCH), torch.int32), ("rnsel", (N, 2), torch.int32), ("osel", (N, 2, ROI_BATCH), torch.int32),
                             ("onsel", (N, 2), torch.int32), ("row_off", (N,), torch.int32), ("dsel", (nd, 2, RPN_BATCH), torch.int32),
                             ("dnsel", (nd, 2), torch.int32), ("nvf", (2,), torch.int32)], dev)
-            S.h_counts = _pinned(4 * N * 4)
-            S.h_counts_np = S.h_counts.numpy().view("int32")[: 4 * N]
+            S.h_counts = _pinned((4 * N + 2) * 4)
+            S.h_counts_np = S.h_counts.numpy().view("int32")[: 4 * N + 2]
         S.h_counts_np.fill(-1)                                    # (phase A's last copy overwrites every word with a length >= 0)
         # (the ViTDet / ConvNeXt trunks draw their stochastic-depth masks on the host every step: their launches are not replayable as recorded)
         use_graph = self.graph_enabled and self.steps_done >= self.warmup and type(eng) is RCNN
+        # captured graphs read the dgrad-weight buffers of the plan they were recorded with: a layer first requested later rebuilds
+        # that plan (new buffers), so everything recorded before is dropped
+        epoch = getattr(eng.wts, "wt_epoch", 0)
+        if getattr(S, "wt_epoch", epoch) != epoch:
+            S.graph_a, S.A = None, None
+            S.graphs_b.clear()
+        S.wt_epoch = epoch
         # ---- phase A
         # device-side phase times of the PREVIOUS step (its events have completed by now: no extra synchronisation)
         evs = getattr(self, "_phase_events", None)
@@ -601,16 +615,26 @@ class FusedStep:
             S.graph_a.replay()
             self.stats["replays_a"] += 1
             A = S.A
+            if S.lazy_wt:
+                eng.wts._wt_dirty = False                          # (the replayed graph re-derived the dgrad weights on the device)
         else:
             A = self._phase_a(S)
         c, tc = A.c, A.tc
         evs[1].record()
         self._prefetch_draws(S, int(c.anchors.shape[0]))
-        t1 = time.perf_counter()
-        self._wait_counts(S)                                       # the ONE device->host sync: list lengths for the host RNG
-        t2 = time.perf_counter()
-        # ---- host: all sampling draws
-        Hst = self._host_draws(S, A)
+        try:
+            t1 = time.perf_counter()
+            self._wait_counts(S)                                   # the ONE device->host sync: list lengths for the host RNG
+            t2 = time.perf_counter()
+            from .engine import raise_on_error
+            raise_on_error(int(S.h_counts_np[4 * N]), "student")
+            raise_on_error(int(S.h_counts_np[4 * N + 1]), "teacher")
+            # ---- host: all sampling draws
+            Hst = self._host_draws(S, A)
+        except BaseException:
+            from . import _lib as L_
+            L_.call("aldi_torch_rng_prefetch", None, None, 0, 0)   # joins the background stream fillers of _prefetch_draws
+            raise
         t3 = time.perf_counter()
         from . import _lib as L_
         self.stats["rng_stream_hits"] = int(L_.lib.aldi_torch_rng_prefetch_hits())
@@ -649,6 +673,11 @@ class FusedStep:
                 dw["instances"] = lab
                 ds["instances"] = lab
         model._last_fused = c
+        if use_graph and B.loss_dict:
+            # the values are views into the graphs' pool, overwritten by the next replay: hand out a private copy (one launch), as
+            # the eager path does by construction (loggers / DEBUG dumps read them after the next run_step)
+            vec = torch.stack(list(B.loss_dict.values()))
+            return {k: vec[i] for i, k in enumerate(B.loss_dict)}
         return dict(B.loss_dict)
 
     def _capture(self, fn):

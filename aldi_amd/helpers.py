@@ -5,30 +5,34 @@ import torch
 
 
 class SaveIO:
-    """Stash of a sub-module's input / output (reference: a torch forward hook; here filled by the engine)."""
-    def __init__(self):
-        self.input = None
-        self.output = None
+    """Forward hook that remembers the most recent (input, output) pair of the module it is registered on -- how the distiller
+    reads the RPN / box-head tensors of student and teacher (reference aldi/helpers.py:7-15; here the engine fires it)."""
+    input = None
+    output = None
 
     def __call__(self, module, module_in, module_out):
-        self.input = module_in
-        self.output = module_out
+        self.input, self.output = module_in, module_out
 
 
 class ManualSeed:
-    """Forward pre-hook that re-seeds the GLOBAL torch RNG (aldi/helpers.py:17-26); seed drawn from Python's `random`."""
+    """Forward pre-hook: `torch.manual_seed(self.seed)` on the GLOBAL generator every time the hooked module runs, so that student
+    and teacher draw the same ROI samples (aldi/helpers.py:17-26).  `reset_seed` takes a fresh 32-bit seed from Python's `random`."""
+    SEED_RANGE = (0, 2**32 - 1)
+
     def __init__(self):
+        self.seed = None
         self.reset_seed()
 
     def reset_seed(self):
-        self.seed = random.randint(0, 2**32 - 1)
+        self.seed = random.randint(*self.SEED_RANGE)
 
     def __call__(self, module, args):
         torch.manual_seed(self.seed)
 
 
 class ReplaceProposalsOnce:
-    """Swap the `proposals` argument of roi_heads once, training only (aldi/helpers.py:28-42)."""
+    """Forward pre-hook on roi_heads: the next TRAINING-mode call sees `proposals` in place of its own third positional argument;
+    the replacement is consumed by that call (aldi/helpers.py:28-42).  Eval-mode calls pass through and leave it pending."""
     def __init__(self):
         self.proposals = None
 
@@ -36,19 +40,20 @@ class ReplaceProposalsOnce:
         self.proposals = proposals
 
     def __call__(self, module, args):
-        ret = None
-        if self.proposals is not None and module.training:
-            images, features, proposals, gt_instances = args
-            ret = (images, features, self.proposals, gt_instances)
-            self.proposals = None
-        return ret
+        pending = self.proposals
+        if pending is None or not module.training:
+            return None
+        self.proposals = None
+        images, features, _own, gt_instances = args
+        return images, features, pending, gt_instances
 
 
 def set_attributes(obj, params):
-    if params:
-        for k, v in params.items():
-            if k != "self" and not k.startswith("_"):
-                setattr(obj, k, v)
+    """`set_attributes(self, locals())` in a constructor: every public local becomes an attribute (aldi/helpers.py:44-49)"""
+    for name, value in (params or {}).items():
+        if name == "self" or name.startswith("_"):
+            continue
+        setattr(obj, name, value)
 
 
 class HookPoint:

@@ -19,7 +19,7 @@ import torch
 
 from . import synthetic
 from .arch import ParamLayout
-from .engine import RCNN, Ctx, Weights
+from .engine import RCNN, Ctx, D2Params, Weights
 from .helpers import HookPoint
 from .registry import Registry
 from .structures import Boxes, Instances, as_record
@@ -124,7 +124,7 @@ class GeneralizedRCNN:
         else:
             self.layout = ParamLayout(self.num_classes, self._img_da, self._ins_da)
             self.weights = Weights(self.layout, self.device, self.dtype, trainable=True)
-            self.engine = RCNN(self.weights, self.num_classes)
+            self.engine = RCNN(self.weights, self.num_classes, D2Params.from_cfg(cfg))
         self.training = True
         self._anchor = torch.zeros((), device=self.device, requires_grad=True)
         self._last: _Holder = None
@@ -136,9 +136,9 @@ class GeneralizedRCNN:
         self.roi_heads = HookPoint(self, "roi_heads")
         self.roi_heads.box_predictor = HookPoint(self, "box_predictor")
         self.roi_heads.box_head = HookPoint(self, "box_head")
-        if cfg.MODEL.WEIGHTS:
-            self._load_file(cfg.MODEL.WEIGHTS)
-        elif self.vitdet or self.convnext:
+        # Construction initialises; cfg.MODEL.WEIGHTS is read by the checkpointer (`Trainer.resume_or_load`, reference
+        # tools/train_net.py:84 / detectron2 build_model), with its key matching and `ema` handling -- not here.
+        if self.vitdet or self.convnext:
             self.weights.init_random(seed)
         else:
             self.load_state_dict(synthetic.init_state_dict(self.num_classes, seed=seed, img_da=self._img_da, ins_da=self._ins_da))
@@ -203,11 +203,6 @@ class GeneralizedRCNN:
     def load_state_dict(self, sd, strict: bool = True):
         self.weights.load_state_dict(sd)
 
-    def _load_file(self, path):
-        ckpt = torch.load(path, map_location="cpu")
-        sd = ckpt.get("model", ckpt)
-        self.load_state_dict({k: torch.as_tensor(v) for k, v in sd.items()})
-
     def parameters(self):
         return iter([self.weights.master[: self.layout.n_train]])
 
@@ -223,7 +218,7 @@ class GeneralizedRCNN:
             new._build_convnext(1)
         else:
             new.weights = Weights(self.layout, self.device, self.dtype, trainable=True)
-            new.engine = RCNN(new.weights, self.num_classes)
+            new.engine = RCNN(new.weights, self.num_classes, self.engine.p)
         new.weights.master.copy_(self.weights.master)
         new.weights.refresh()
         new._anchor = torch.zeros((), device=self.device, requires_grad=True)

@@ -346,8 +346,12 @@ def rpn_proposals(geom, head, anchors, img_hw, N, pre, post, thr, workspace, out
            _p(out_boxes), _p(out_scores), _p(out_count), _p(err), stream_ptr())
 
 
-def rpn_active_pixels(geom, ghead, N, cap, idx, count, err):
-    L.call("aldi_rpn_active_pixels", C.byref(geom), ptrs(ghead), N, cap, _p(idx), _p(count), _p(err), stream_ptr())
+def rpn_active_pixels_workspace(geom, N) -> int:
+    return int(L.lib.aldi_rpn_active_pixels_workspace(C.byref(geom), N))
+
+
+def rpn_active_pixels(geom, ghead, N, cap, idx, count, workspace, err):
+    L.call("aldi_rpn_active_pixels", C.byref(geom), ptrs(ghead), N, cap, _p(idx), _p(count), _p(workspace), _p(err), stream_ptr())
 
 
 def rpn_sparse_gather(geom, ghead, hidden, feat, N, Cf, cap, idx, count, G, Tm, X9):

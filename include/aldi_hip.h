@@ -235,14 +235,19 @@ int aldi_rpn_proposals(const aldi_rpn_geom* gm, float* const* head, const float*
 /* Sparse backward of the RPN head (what autograd runs as dense convolutions over all five levels, reached from
  * aldi/trainer.py:79): d(loss)/d(head outputs) is non-zero only at the sampled anchors' pixels (<= 256 per image and sample).
  *   aldi_rpn_active_pixels   idx[0..*count) = global row (level-major pixel position, row = N*sum_{k<l}H_k W_k + (n*H_l+h)*W_l+w)
- *                            of every pixel whose C head-gradient channels are not all zero; *count (device) is reset first;
- *                            err_flag |= 2 when more than `cap` pixels are active.  Order of the list is unspecified.
+ *                            of every pixel whose C head-gradient channels are not all zero, in ASCENDING row order (two-launch
+ *                            ordered compaction: the list, and with it every sum downstream, is run-to-run reproducible);
+ *                            *count (device) = number of active pixels; err_flag |= 2 when more than `cap` are active (the
+ *                            excess is dropped).  workspace: aldi_rpn_active_pixels_workspace(gm, N) bytes.
  *   aldi_rpn_sparse_gather   rows s < min(*count, cap): G[s][C] = grad_head (in dtype), Tm[s][Cf] = hidden[l][pixel],
  *                            X9[s][tap][Cf] = feat[l][pixel + (tap/3-1, tap%3-1)] (zero outside the image); rows >= count zero.
- *   aldi_rpn_sparse_scatter  gfeat[l][pixel + (tap/3-1, tap%3-1)][ci] += Y[s][tap][ci], Y in dtype [cap][9][Cf]; gfeat maps in grad_dtype
- *                            (fp32 atomics, or packed bf16 atomics on bf16 maps: the sum the reference's autocast forms). */
-int aldi_rpn_active_pixels(const aldi_rpn_geom* gm, float* const* grad_head, int N, int cap, int* idx, int* count, int* err_flag,
-                           aldi_stream_t stream);
+ *   aldi_rpn_sparse_scatter  gfeat[l][pixel + (tap/3-1, tap%3-1)][ci] += Y[s][tap][ci], Y in dtype [cap][9][Cf]; gfeat maps in grad_dtype.
+ *                            No atomics: every target pixel is finished by one workgroup, which adds its (<= 9) contributions in tap
+ *                            order in fp32 and updates the map once (bf16 maps: previous content + sum, rounded once); needs the
+ *                            sorted list of aldi_rpn_active_pixels. */
+size_t aldi_rpn_active_pixels_workspace(const aldi_rpn_geom* gm, int N);
+int aldi_rpn_active_pixels(const aldi_rpn_geom* gm, float* const* grad_head, int N, int cap, int* idx, int* count, void* workspace,
+                           int* err_flag, aldi_stream_t stream);
 int aldi_rpn_sparse_gather(const aldi_rpn_geom* gm, float* const* grad_head, const void* const* hidden, const void* const* feat, int N, int Cf,
                            int cap, const int* idx, const int* count, void* G, void* Tm, void* X9, int dtype, aldi_stream_t stream);
 int aldi_rpn_sparse_scatter(const aldi_rpn_geom* gm, void* const* gfeat, const void* Y, int N, int Cf, int cap, const int* idx,

@@ -607,3 +607,87 @@ def test_sparse_rpn_head_backward_equals_dense(dtype, tol):
         grads[sparse] = wts.grad.clone()
     a, b = grads[True], grads[False]
     assert float(b.abs().max()) > 0 and float((a - b).abs().max()) <= tol * float(b.abs().max())
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_sparse_rpn_head_backward_is_reproducible(dtype):
+    """the active-pixel list is an ordered compaction and the scatter is an owner gather (no atomics): the sparse part of two
+    backward passes from the same forward is bit-identical -- list, gathered rows and the level gradients they are added into"""
+    from aldi_amd import ops, synthetic as syn
+    sd = syn.init_state_dict(K, seed=1)
+    _, data, _, _ = syn.make_batch(2, 0, H, W, K, seed=0, boxes_per_image=(3, 6))
+    lay, wts, m = _engine(dtype, sd)
+    torch.manual_seed(5)
+    c = m.forward_train([d["image"] for d in data], [d["instances"] for d in data], roi_seed=9)
+    wts.zero_grad()
+    m.backward(c, {"loss_cls": 1.0, "loss_box_reg": 1.0, "loss_rpn_cls": 1.0, "loss_rpn_loc": 1.0})      # fills c.ghead
+    runs = []
+    for _ in range(3):
+        sp = m._rpn_sparse_prepare(c)
+        n = int(sp["count"])
+        idx = sp["idx"][:n].clone()
+        assert n > 0 and bool((idx[1:] > idx[:-1]).all()), "ascending row order"
+        base = [torch.randn(f.shape, device="cuda", generator=torch.Generator(device="cuda").manual_seed(3)).to(
+            dtype if dtype == torch.bfloat16 else torch.float32) for f in c.P]
+        ops.rpn_sparse_scatter(c.geom, base, sp["Y"], c.N, 256, sp["cap"], sp["idx"], sp["count"])
+        torch.cuda.synchronize()
+        runs.append((idx, sp["G"].clone(), sp["X9"].clone(), [b.clone() for b in base]))
+    for r in runs[1:]:
+        assert torch.equal(r[0], runs[0][0]) and torch.equal(r[1], runs[0][1]) and torch.equal(r[2], runs[0][2])
+        assert all(torch.equal(a, b) for a, b in zip(r[3], runs[0][3]))
+    # ... and the scatter equals the plain definition: map[t] += sum of the rows that reach t (fp32 reference on the host)
+    idx, Y = runs[0][0].cpu().tolist(), sp["Y"].float().cpu().view(sp["cap"], 9, 256)
+    ref = [torch.randn(f.shape, device="cuda", generator=torch.Generator(device="cuda").manual_seed(3)).to(
+        dtype if dtype == torch.bfloat16 else torch.float32).float().cpu() for f in c.P]
+    row0 = [0]
+    for f in c.P:
+        row0.append(row0[-1] + f.shape[0] * f.shape[1] * f.shape[2])
+    add = [torch.zeros_like(r) for r in ref]
+    for s_, row in enumerate(idx):
+        l = max(k for k in range(5) if row >= row0[k])
+        Hl, Wl = c.P[l].shape[1], c.P[l].shape[2]
+        pix = row - row0[l]
+        n_, r_ = divmod(pix, Hl * Wl)
+        h, w = divmod(r_, Wl)
+        for tap in range(9):
+            hh, ww = h + tap // 3 - 1, w + tap % 3 - 1
+            if 0 <= hh < Hl and 0 <= ww < Wl:
+                add[l][n_, hh, ww] += Y[s_, tap]
+    for l in range(5):
+        want = ref[l] + add[l]
+        got = runs[0][3][l].float().cpu()
+        tol = 1e-5 if dtype == torch.float32 else 1e-2
+        assert float((got - want).abs().max()) <= tol * max(1.0, float(want.abs().max())), (l, float((got - want).abs().max()))
+
+
+def test_engine_reads_detectron2_keys_from_cfg():
+    """the R50 engine takes its Detectron2 constants from the config node (engine.D2Params.from_cfg): overrides change what the
+    kernels are launched with, unsupported values raise instead of being ignored"""
+    from aldi_amd import synthetic as syn
+    from aldi_amd.config import add_aldi_config, get_cfg
+    from aldi_amd.model import build_aldi
+    cfg = get_cfg()
+    add_aldi_config(cfg)
+    cfg.merge_from_list(["MODEL.ROI_HEADS.NUM_CLASSES", K, "SEED", 1, "TEST.DETECTIONS_PER_IMAGE", 7, "MODEL.ROI_HEADS.SCORE_THRESH_TEST", 0.0,
+                         "MODEL.RPN.POST_NMS_TOPK_TEST", 300, "MODEL.ROI_HEADS.BATCH_SIZE_PER_IMAGE", 64, "MODEL.RPN.BATCH_SIZE_PER_IMAGE", 32])
+    model = build_aldi(cfg)
+    p = model.engine.p
+    assert (p.dets, p.score_thresh, p.rpn_post[1], p.roi_batch, p.rpn_batch) == (7, 0.0, 300, 64, 32)
+    _, data, _, _ = syn.make_batch(2, 0, H, W, K, seed=0, boxes_per_image=(3, 6))
+    model.eval()
+    out = model.inference(data)
+    assert all(len(o.scores) == 7 for o in out), [len(o.scores) for o in out]      # threshold 0: every image fills its 7 slots
+    model.train()
+    torch.manual_seed(0)
+    losses = model(data)
+    c = model._last.ctx
+    assert c.R <= 2 * 64 and max(c.rows) <= 64
+    assert int((c.rpn_labels >= 0).sum()) <= 2 * 32
+    sum(losses.values()).backward()
+    torch.cuda.synchronize()
+    assert int(model.engine.err) == 0 and float(model.weights.grad.abs().max()) > 0
+    bad = get_cfg()
+    add_aldi_config(bad)
+    bad.merge_from_list(["MODEL.ANCHOR_GENERATOR.ASPECT_RATIOS", [[0.5, 1.0]]])
+    with pytest.raises(ValueError):
+        build_aldi(bad)

@@ -206,3 +206,28 @@ def test_vit_layerwise_lr_decay_groups():
         lo = P.off[name]
         (piece,) = [x for x in g if x[0] <= lo < x[1]]
         assert piece[2] == (lo < P.n_decay) and abs(piece[3] - P.lr_factor(name, 0.7, 12)) < 1e-15, name
+
+
+def test_d2params_from_cfg_reads_and_validates():
+    """engine.D2Params.from_cfg: the Detectron2 keys of the R50 engine come from the config; what the kernels do not implement raises"""
+    from aldi_amd.config import add_aldi_config, get_cfg
+    from aldi_amd.engine import D2Params
+    cfg = get_cfg()
+    add_aldi_config(cfg)
+    assert D2Params.from_cfg(cfg) == D2Params()                    # detectron2's defaults are the engine's defaults
+    cfg.merge_from_list(["MODEL.PIXEL_MEAN", [1.0, 2.0, 3.0], "MODEL.PIXEL_STD", [4.0, 5.0, 6.0], "MODEL.RPN.NMS_THRESH", 0.6,
+                         "MODEL.RPN.PRE_NMS_TOPK_TRAIN", 1500, "MODEL.ROI_HEADS.POSITIVE_FRACTION", 0.5, "MODEL.RPN.IOU_THRESHOLDS", [0.2, 0.8],
+                         "MODEL.ROI_HEADS.IOU_THRESHOLDS", [0.6], "MODEL.ROI_HEADS.NMS_THRESH_TEST", 0.4, "TEST.DETECTIONS_PER_IMAGE", 50,
+                         "MODEL.ANCHOR_GENERATOR.SIZES", [[16], [32], [64], [128], [256]], "MODEL.ROI_BOX_HEAD.BBOX_REG_WEIGHTS", [5.0, 5.0, 2.0, 2.0]])
+    p = D2Params.from_cfg(cfg)
+    assert p.pixel_mean == (1.0, 2.0, 3.0) and p.pixel_std == (4.0, 5.0, 6.0) and p.rpn_nms == 0.6 and p.rpn_pre == (1500, 1000)
+    assert p.roi_pos_frac == 0.5 and p.rpn_iou == (0.2, 0.8) and p.roi_iou == 0.6 and p.nms_test == 0.4 and p.dets == 50
+    assert p.anchor_sizes == (16.0, 32.0, 64.0, 128.0, 256.0) and p.roi_weights == (5.0, 5.0, 2.0, 2.0)
+    import pytest
+    for bad in (["MODEL.ANCHOR_GENERATOR.ASPECT_RATIOS", [[1.0]]], ["MODEL.RPN.PRE_NMS_TOPK_TRAIN", 4000], ["TEST.DETECTIONS_PER_IMAGE", 500],
+                ["MODEL.RPN.SMOOTH_L1_BETA", 0.1], ["MODEL.ROI_BOX_HEAD.POOLER_RESOLUTION", 14], ["MODEL.RPN.BBOX_REG_WEIGHTS", [2.0, 2.0, 1.0, 1.0]]):
+        c2 = get_cfg()
+        add_aldi_config(c2)
+        c2.merge_from_list(bad)
+        with pytest.raises(ValueError):
+            D2Params.from_cfg(c2)
