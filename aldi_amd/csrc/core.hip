@@ -27,6 +27,7 @@ const Knob kKnobs[] = {
     {"igemm_tile", &AldiTuning::igemm_tile, 0},
     {"igemm_dbg", &AldiTuning::igemm_dbg, 0},
     {"igemm_bigtile_min", &AldiTuning::igemm_bigtile_min, 1024},
+    {"igemm_bigtile", &AldiTuning::igemm_bigtile, 4},
     {"igemm_bigtile_k", &AldiTuning::igemm_bigtile_k, 768},
     {"igemm_lintile_min", &AldiTuning::igemm_lintile_min, 768},
     {"igemm_halo", &AldiTuning::igemm_halo, 1},

@@ -96,6 +96,195 @@ template <> struct Mma<float> {
     }
 };
 
+// ---- epilogue of a BM x BN tile: lane owns pixel (lane&15), channels (lane>>4)*4 .. +3 of each 16x16 accumulator fragment.
+// `stg`: the workgroup's LDS (LDS_BYTES of it), free for staging once every wave is past its last fragment read.
+template <typename T, int BM, int BN, int WM, int WN, int LDS_BYTES>
+__device__ __forceinline__ void igemm_epilogue(const ConvDev& p, f32x4_t (&acc)[BM / WM / 16][BN / WN / 16], const int m0, const int n0, unsigned char* stg) {
+    constexpr int NT = WM * WN * 64;
+    constexpr int TM = BM / WM / 16, TN = BN / WN / 16;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int fr = lane & 15, fq = lane >> 4;
+    if (p.dbg & 4) return;
+    T* __restrict__ Y = static_cast<T*>(p.y);
+    const T* __restrict__ R = static_cast<const T*>(p.res);
+    const T* __restrict__ Mk = static_cast<const T*>(p.mask);
+    if constexpr (sizeof(T) == 2) {
+        // bf16 fast path: the accumulator fragment gives every lane 8 B per pixel (32-B runs per pixel row) -- poor store /
+        // residual-load granularity for what are mostly HBM-bound layers.  Stage scale*acc+shift through LDS (padded rows,
+        // conflict-free 8-B writes) and let every lane finish 16 B of one pixel row: 256-B coalesced residual / mask
+        // loads and stores.  (conv*scale+shift is rounded to bf16 before the residual add; the fp32 parity mode keeps
+        // the single-rounding direct path below.)
+        constexpr int ROWB = BN * 2 + 16;
+        constexpr bool kStageFits = BM * ROWB <= LDS_BYTES;              // staging tile reuses the pipeline buffers
+        if (kStageFits && Y && !p.y_f32 && (p.Cout & 7) == 0) {
+            // The epilogue is instruction-bound if written naively (wave64 VALU ops cost 4 cycles each and a block only
+            // moves 32 KB): hardware bf16 packing, per-column scale/shift hoisted, immediate LDS offsets, and packed
+            // 16-bit integer ops for ReLU / mask when there is no residual to add.
+            __syncthreads();                    // every wave is done reading the last slab
+            {
+                unsigned char* wr = stg + (wm * (BM / WM) + fr) * ROWB + (wn * (BN / WN) + fq * 4) * 2;
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    const int c = n0 + wn * (BN / WN) + j * 16 + fq * 4;
+                    float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (c < p.Cout) {
+                        if (p.scale) sc = *reinterpret_cast<const float4*>(p.scale + c);
+                        if (p.shift) sh = *reinterpret_cast<const float4*>(p.shift + c);
+                    }
+#pragma unroll
+                    for (int i = 0; i < TM; ++i) {
+                        uint2 t;
+                        if (p.scale || p.shift) {
+                            t.x = pack2_bf16(acc[i][j][0] * sc.x + sh.x, acc[i][j][1] * sc.y + sh.y);
+                            t.y = pack2_bf16(acc[i][j][2] * sc.z + sh.z, acc[i][j][3] * sc.w + sh.w);
+                        } else {
+                            t.x = pack2_bf16(acc[i][j][0], acc[i][j][1]);
+                            t.y = pack2_bf16(acc[i][j][2], acc[i][j][3]);
+                        }
+                        *reinterpret_cast<uint2*>(wr + i * 16 * ROWB + j * 32) = t;
+                    }
+                }
+            }
+            __syncthreads();
+            constexpr int CPR = BN / 8;          // 16-B chunks per tile row
+            constexpr int RPI = NT / CPR;        // tile rows covered per iteration
+            const int rowl0 = tid / CPR, ch8 = tid % CPR;
+            const int c = n0 + ch8 * 8;
+            if (c >= p.Cout) return;
+            const bool plain = p.out_scale == 1 && p.res_mode != 2;
+            const unsigned char* rd = stg + rowl0 * ROWB + ch8 * 16;
+            typedef short s16x2_t __attribute__((ext_vector_type(2)));
+            // Branch-free and latency-flat: byte offsets (out-of-tile rows -> the dropped/zero-filled range), then ALL the
+            // residual / mask loads of this lane in flight at once, then the arithmetic and the stores.  (A load next to a
+            // store inside one loop body is serialised behind it: Y and R may alias as far as the compiler knows.)
+            constexpr int NI = BM / RPI;
+            constexpr unsigned OOBX = 0x80000000u;
+            const __amdgpu_buffer_rsrc_t ry = make_rsrc_uniform(Y, 0x7fffffffu);
+            unsigned ooff[NI], roff[NI];
+#pragma unroll
+            for (int it = 0; it < NI; ++it) {
+                const int m = m0 + rowl0 + it * RPI;
+                const bool ok = m < p.M;
+                unsigned oidx, ridx;
+                if (plain) {
+                    oidx = (unsigned)m * (unsigned)p.Cout;
+                    ridx = oidx;
+                } else {
+                    const int mm = ok ? m : 0;
+                    const int n = mm / (p.Ho * p.Wo);
+                    const int r = mm - n * (p.Ho * p.Wo);
+                    const int ho = r / p.Wo, wo = r - ho * p.Wo;
+                    if (p.out_scale == 1) oidx = (unsigned)mm * (unsigned)p.Cout;
+                    else oidx = (unsigned)((((long)n * p.OH + ho * p.out_scale) * p.OW + wo * p.out_scale) * p.Cout);
+                    if (p.res_mode == 2) ridx = (unsigned)((((long)n * (p.Ho >> 1) + (ho >> 1)) * (p.Wo >> 1) + (wo >> 1)) * p.Cout);
+                    else ridx = oidx;
+                }
+                ooff[it] = ok ? (oidx + (unsigned)c) * 2u : OOBX;
+                roff[it] = ok ? (ridx + (unsigned)c) * 2u : OOBX;
+            }
+            u32x4_t rres[NI], rmsk[NI];
+            if (p.res_mode) {
+                const __amdgpu_buffer_rsrc_t rr_ = make_rsrc_uniform(R, 0x7fffffffu);
+#pragma unroll
+                for (int it = 0; it < NI; ++it) rres[it] = __builtin_amdgcn_raw_buffer_load_b128(rr_, roff[it], 0, 0);
+            }
+            if (Mk) {
+                const __amdgpu_buffer_rsrc_t rm_ = make_rsrc_uniform(Mk, 0x7fffffffu);
+#pragma unroll
+                for (int it = 0; it < NI; ++it) rmsk[it] = __builtin_amdgcn_raw_buffer_load_b128(rm_, ooff[it], 0, 0);
+            }
+#pragma unroll
+            for (int it = 0; it < NI; ++it) {
+                const uint4 raw4 = *reinterpret_cast<const uint4*>(rd + it * RPI * ROWB);
+                uint32_t raw[4] = {raw4.x, raw4.y, raw4.z, raw4.w};
+                if (p.res_mode) {
+                    const uint32_t rs[4] = {rres[it].x, rres[it].y, rres[it].z, rres[it].w};
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        float lo = __uint_as_float(raw[q] << 16) + __uint_as_float(rs[q] << 16);
+                        float hi = __uint_as_float(raw[q] & 0xffff0000u) + __uint_as_float(rs[q] & 0xffff0000u);
+                        if (p.relu) { lo = fmaxf(lo, 0.f); hi = fmaxf(hi, 0.f); }
+                        raw[q] = pack2_bf16(lo, hi);
+                    }
+                } else if (p.relu) {
+                    // bf16 as int16: negative floats (and -0) are negative integers
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        s16x2_t v = *reinterpret_cast<s16x2_t*>(&raw[q]);
+                        v = __builtin_elementwise_max(v, s16x2_t{0, 0});
+                        raw[q] = *reinterpret_cast<uint32_t*>(&v);
+                    }
+                }
+                if (Mk) {
+                    // keep where the forward activation (a ReLU output, so >= 0) is > 0: multiply the bit patterns by 0 / 1
+                    const uint32_t ms[4] = {rmsk[it].x, rmsk[it].y, rmsk[it].z, rmsk[it].w};
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        s16x2_t k = *reinterpret_cast<const s16x2_t*>(&ms[q]);
+                        k = __builtin_elementwise_min(__builtin_elementwise_max(k, s16x2_t{0, 0}), s16x2_t{1, 1});
+                        s16x2_t v = *reinterpret_cast<s16x2_t*>(&raw[q]);
+                        v = v * k;
+                        raw[q] = *reinterpret_cast<uint32_t*>(&v);
+                    }
+                }
+                const u32x4_t ov = {raw[0], raw[1], raw[2], raw[3]};
+                __builtin_amdgcn_raw_buffer_store_b128(ov, ry, ooff[it], 0, 0);
+            }
+            return;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        int m = m0 + wm * (BM / WM) + i * 16 + fr;
+        if (m >= p.M) continue;
+        long oidx, ridx = 0;
+        if (p.out_scale == 1 && p.res_mode != 2) {
+            oidx = (long)m * p.Cout;
+            ridx = oidx;
+        } else {
+            int n = m / (p.Ho * p.Wo);
+            int r = m - n * (p.Ho * p.Wo);
+            int ho = r / p.Wo, wo = r - ho * p.Wo;
+            if (p.out_scale == 1) oidx = (long)m * p.Cout;
+            else oidx = (((long)n * p.OH + ho * p.out_scale) * p.OW + wo * p.out_scale) * p.Cout;
+            if (p.res_mode == 2) ridx = (((long)n * (p.Ho >> 1) + (ho >> 1)) * (p.Wo >> 1) + (wo >> 1)) * p.Cout;
+            else ridx = oidx;
+        }
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            int c = n0 + wn * (BN / WN) + j * 16 + fq * 4;
+            if (c >= p.Cout) continue;
+            float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+            if (p.scale) {
+                float4 sc = *reinterpret_cast<const float4*>(p.scale + c);
+                v[0] *= sc.x; v[1] *= sc.y; v[2] *= sc.z; v[3] *= sc.w;
+            }
+            if (p.shift) {
+                float4 sh = *reinterpret_cast<const float4*>(p.shift + c);
+                v[0] += sh.x; v[1] += sh.y; v[2] += sh.z; v[3] += sh.w;
+            }
+            if (p.res_mode) {
+                float r4[4];
+                load4(R + ridx + c, r4);
+                v[0] += r4[0]; v[1] += r4[1]; v[2] += r4[2]; v[3] += r4[3];
+            }
+            if (p.relu) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = v[r] > 0.f ? v[r] : 0.f;
+            }
+            if (Mk) {
+                float k4[4];
+                load4(Mk + oidx + c, k4);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = k4[r] > 0.f ? v[r] : 0.f;
+            }
+            if (Y) store4(Y + oidx + c, v);
+            if (p.y_f32) store4(p.y_f32 + oidx + c, v);
+        }
+    }
+}
+
 // body of one workgroup: tile `bid` of an nmt x nnt tile grid of problem p (launched alone: igemm_kernel; as one of several
 // problems of the same layer shape sharing a launch: igemm_group_kernel)
 template <typename T, int BM, int BN, int WM, int WN, int KC, bool PIPE, bool HALO = false>
@@ -107,7 +296,7 @@ __device__ __forceinline__ void igemm_body(const ConvDev& p, int bid, const int 
     constexpr int A_IT = (BM * KC) / NT;           // pixel-tile chunks per thread
     constexpr int B_IT = (BN * KC + NT - 1) / NT;  // weight-tile chunks per thread
     constexpr int TM = BM / WM / 16, TN = BN / WN / 16;
-    static_assert((BM * KC) % NT == 0, "tile/threads mismatch");
+    static_assert(HALO || (BM * KC) % NT == 0, "tile/threads mismatch");
 
     constexpr int NBUF = 3;                        // LDS ring: two slabs of DMA in flight across the barrier
     constexpr int SLOTS = HALO ? ((BM + 2) * KC + 63) / 64 * 64 + 3 * BN * KC : (BM + BN) * KC;     // per ring stage
@@ -390,190 +579,223 @@ __device__ __forceinline__ void igemm_body(const ConvDev& p, int bid, const int 
 
     }
 
-    if (p.dbg & 4) return;
-    // ---- epilogue: lane owns pixel (lane&15), channels (lane>>4)*4 .. +3 of each 16x16 tile
-    T* __restrict__ Y = static_cast<T*>(p.y);
-    const T* __restrict__ R = static_cast<const T*>(p.res);
-    const T* __restrict__ Mk = static_cast<const T*>(p.mask);
-    if constexpr (sizeof(T) == 2) {
-        // bf16 fast path: the accumulator fragment gives every lane 8 B per pixel (32-B runs per pixel row) -- poor store /
-        // residual-load granularity for what are mostly HBM-bound layers.  Stage scale*acc+shift through LDS (padded rows,
-        // conflict-free 8-B writes) and let every lane finish 16 B of one pixel row: 256-B coalesced residual / mask
-        // loads and stores.  (conv*scale+shift is rounded to bf16 before the residual add; the fp32 parity mode keeps
-        // the single-rounding direct path below.)
-        constexpr int ROWB = BN * 2 + 16;
-        constexpr bool kStageFits = BM * ROWB <= NSTAGE * SLOTS * 16;   // staging tile reuses the pipeline buffers
-        if (kStageFits && Y && !p.y_f32 && (p.Cout & 7) == 0) {
-            // The epilogue is instruction-bound if written naively (wave64 VALU ops cost 4 cycles each and a block only
-            // moves 32 KB): hardware bf16 packing, per-column scale/shift hoisted, immediate LDS offsets, and packed
-            // 16-bit integer ops for ReLU / mask when there is no residual to add.
-            unsigned char* stg = reinterpret_cast<unsigned char*>(&lds[0][0]);
-            __syncthreads();                    // every wave is done reading the last slab
-            {
-                unsigned char* wr = stg + (wm * (BM / WM) + fr) * ROWB + (wn * (BN / WN) + fq * 4) * 2;
-#pragma unroll
-                for (int j = 0; j < TN; ++j) {
-                    const int c = n0 + wn * (BN / WN) + j * 16 + fq * 4;
-                    float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
-                    if (c < p.Cout) {
-                        if (p.scale) sc = *reinterpret_cast<const float4*>(p.scale + c);
-                        if (p.shift) sh = *reinterpret_cast<const float4*>(p.shift + c);
-                    }
-#pragma unroll
-                    for (int i = 0; i < TM; ++i) {
-                        uint2 t;
-                        if (p.scale || p.shift) {
-                            t.x = pack2_bf16(acc[i][j][0] * sc.x + sh.x, acc[i][j][1] * sc.y + sh.y);
-                            t.y = pack2_bf16(acc[i][j][2] * sc.z + sh.z, acc[i][j][3] * sc.w + sh.w);
-                        } else {
-                            t.x = pack2_bf16(acc[i][j][0], acc[i][j][1]);
-                            t.y = pack2_bf16(acc[i][j][2], acc[i][j][3]);
-                        }
-                        *reinterpret_cast<uint2*>(wr + i * 16 * ROWB + j * 32) = t;
-                    }
-                }
-            }
-            __syncthreads();
-            constexpr int CPR = BN / 8;          // 16-B chunks per tile row
-            constexpr int RPI = NT / CPR;        // tile rows covered per iteration
-            const int rowl0 = tid / CPR, ch8 = tid % CPR;
-            const int c = n0 + ch8 * 8;
-            if (c >= p.Cout) return;
-            const bool plain = p.out_scale == 1 && p.res_mode != 2;
-            const unsigned char* rd = stg + rowl0 * ROWB + ch8 * 16;
-            typedef short s16x2_t __attribute__((ext_vector_type(2)));
-            // Branch-free and latency-flat: byte offsets (out-of-tile rows -> the dropped/zero-filled range), then ALL the
-            // residual / mask loads of this lane in flight at once, then the arithmetic and the stores.  (A load next to a
-            // store inside one loop body is serialised behind it: Y and R may alias as far as the compiler knows.)
-            constexpr int NI = BM / RPI;
-            constexpr unsigned OOBX = 0x80000000u;
-            const __amdgpu_buffer_rsrc_t ry = make_rsrc_uniform(Y, 0x7fffffffu);
-            unsigned ooff[NI], roff[NI];
-#pragma unroll
-            for (int it = 0; it < NI; ++it) {
-                const int m = m0 + rowl0 + it * RPI;
-                const bool ok = m < p.M;
-                unsigned oidx, ridx;
-                if (plain) {
-                    oidx = (unsigned)m * (unsigned)p.Cout;
-                    ridx = oidx;
-                } else {
-                    const int mm = ok ? m : 0;
-                    const int n = mm / (p.Ho * p.Wo);
-                    const int r = mm - n * (p.Ho * p.Wo);
-                    const int ho = r / p.Wo, wo = r - ho * p.Wo;
-                    if (p.out_scale == 1) oidx = (unsigned)mm * (unsigned)p.Cout;
-                    else oidx = (unsigned)((((long)n * p.OH + ho * p.out_scale) * p.OW + wo * p.out_scale) * p.Cout);
-                    if (p.res_mode == 2) ridx = (unsigned)((((long)n * (p.Ho >> 1) + (ho >> 1)) * (p.Wo >> 1) + (wo >> 1)) * p.Cout);
-                    else ridx = oidx;
-                }
-                ooff[it] = ok ? (oidx + (unsigned)c) * 2u : OOBX;
-                roff[it] = ok ? (ridx + (unsigned)c) * 2u : OOBX;
-            }
-            u32x4_t rres[NI], rmsk[NI];
-            if (p.res_mode) {
-                const __amdgpu_buffer_rsrc_t rr_ = make_rsrc_uniform(R, 0x7fffffffu);
-#pragma unroll
-                for (int it = 0; it < NI; ++it) rres[it] = __builtin_amdgcn_raw_buffer_load_b128(rr_, roff[it], 0, 0);
-            }
-            if (Mk) {
-                const __amdgpu_buffer_rsrc_t rm_ = make_rsrc_uniform(Mk, 0x7fffffffu);
-#pragma unroll
-                for (int it = 0; it < NI; ++it) rmsk[it] = __builtin_amdgcn_raw_buffer_load_b128(rm_, ooff[it], 0, 0);
-            }
-#pragma unroll
-            for (int it = 0; it < NI; ++it) {
-                const uint4 raw4 = *reinterpret_cast<const uint4*>(rd + it * RPI * ROWB);
-                uint32_t raw[4] = {raw4.x, raw4.y, raw4.z, raw4.w};
-                if (p.res_mode) {
-                    const uint32_t rs[4] = {rres[it].x, rres[it].y, rres[it].z, rres[it].w};
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        float lo = __uint_as_float(raw[q] << 16) + __uint_as_float(rs[q] << 16);
-                        float hi = __uint_as_float(raw[q] & 0xffff0000u) + __uint_as_float(rs[q] & 0xffff0000u);
-                        if (p.relu) { lo = fmaxf(lo, 0.f); hi = fmaxf(hi, 0.f); }
-                        raw[q] = pack2_bf16(lo, hi);
-                    }
-                } else if (p.relu) {
-                    // bf16 as int16: negative floats (and -0) are negative integers
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        s16x2_t v = *reinterpret_cast<s16x2_t*>(&raw[q]);
-                        v = __builtin_elementwise_max(v, s16x2_t{0, 0});
-                        raw[q] = *reinterpret_cast<uint32_t*>(&v);
-                    }
-                }
-                if (Mk) {
-                    // keep where the forward activation (a ReLU output, so >= 0) is > 0: multiply the bit patterns by 0 / 1
-                    const uint32_t ms[4] = {rmsk[it].x, rmsk[it].y, rmsk[it].z, rmsk[it].w};
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        s16x2_t k = *reinterpret_cast<const s16x2_t*>(&ms[q]);
-                        k = __builtin_elementwise_min(__builtin_elementwise_max(k, s16x2_t{0, 0}), s16x2_t{1, 1});
-                        s16x2_t v = *reinterpret_cast<s16x2_t*>(&raw[q]);
-                        v = v * k;
-                        raw[q] = *reinterpret_cast<uint32_t*>(&v);
-                    }
-                }
-                const u32x4_t ov = {raw[0], raw[1], raw[2], raw[3]};
-                __builtin_amdgcn_raw_buffer_store_b128(ov, ry, ooff[it], 0, 0);
-            }
-            return;
-        }
-    }
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-        int m = m0 + wm * (BM / WM) + i * 16 + fr;
-        if (m >= p.M) continue;
-        long oidx, ridx = 0;
-        if (p.out_scale == 1 && p.res_mode != 2) {
-            oidx = (long)m * p.Cout;
-            ridx = oidx;
-        } else {
-            int n = m / (p.Ho * p.Wo);
-            int r = m - n * (p.Ho * p.Wo);
-            int ho = r / p.Wo, wo = r - ho * p.Wo;
-            if (p.out_scale == 1) oidx = (long)m * p.Cout;
-            else oidx = (((long)n * p.OH + ho * p.out_scale) * p.OW + wo * p.out_scale) * p.Cout;
-            if (p.res_mode == 2) ridx = (((long)n * (p.Ho >> 1) + (ho >> 1)) * (p.Wo >> 1) + (wo >> 1)) * p.Cout;
-            else ridx = oidx;
-        }
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            int c = n0 + wn * (BN / WN) + j * 16 + fq * 4;
-            if (c >= p.Cout) continue;
-            float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
-            if (p.scale) {
-                float4 sc = *reinterpret_cast<const float4*>(p.scale + c);
-                v[0] *= sc.x; v[1] *= sc.y; v[2] *= sc.z; v[3] *= sc.w;
-            }
-            if (p.shift) {
-                float4 sh = *reinterpret_cast<const float4*>(p.shift + c);
-                v[0] += sh.x; v[1] += sh.y; v[2] += sh.z; v[3] += sh.w;
-            }
-            if (p.res_mode) {
-                float r4[4];
-                load4(R + ridx + c, r4);
-                v[0] += r4[0]; v[1] += r4[1]; v[2] += r4[2]; v[3] += r4[3];
-            }
-            if (p.relu) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = v[r] > 0.f ? v[r] : 0.f;
-            }
-            if (Mk) {
-                float k4[4];
-                load4(Mk + oidx + c, k4);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = k4[r] > 0.f ? v[r] : 0.f;
-            }
-            if (Y) store4(Y + oidx + c, v);
-            if (p.y_f32) store4(p.y_f32 + oidx + c, v);
-        }
+    igemm_epilogue<T, BM, BN, WM, WN, NSTAGE * SLOTS * 16>(p, acc, m0, n0, reinterpret_cast<unsigned char*>(&lds[0][0]));
+}
+
+// ---- 3x3 / stride 1 / pad 1, halo form, with the two halves of an 8-wave workgroup in ALTERNATING ROLES ------------------------
+// The plain halo loop above runs its waves in lockstep: barrier -> everyone issues DMA and fragment reads -> everyone issues
+// MFMAs; on a SIMD the two resident waves want the matrix pipe at the same time and leave it idle at the same time (rocprofv3
+// on the p2 conv: MFMA pipe busy 45 % of the cycles, waves parked at barriers / waitcnt 36 %, profiles/r03_pmc_conv.txt).
+// Here a K step ("phase" = one horizontal tap of one (kh, 32-channel) group) is split into a LOAD segment (fragment reads of
+// this phase, two DMA pieces of the group two ahead, edge fix-up) and a COMPUTE segment (16 MFMAs at raised priority) with a
+// barrier after each, and waves 4..7 run ONE BARRIER BEHIND waves 0..3: while one half computes phase p its SIMD partners of the
+// other half do their load segment -- matrix work beside memory work on every SIMD at all times (MI355X_MICROARCH.md
+// "Two waves per SIMD", cdna_hip_programming.md T3+T4/T5).  Three LDS stages (groups g, g+1, g+2), DMA never drained inside
+// the loop: the counted vmcnt in the last load segment of group g retires group g+1's pieces only.
+//   RAW: a group's pieces are waited for (vmcnt) in a load segment and first read in the NEXT phase's load segment, two barriers
+//        later -- one more than the lag between the halves.
+//   WAR: a phase's fragment reads are retired (lgkmcnt(0)) right behind the barrier that ends its load segment, i.e. before the
+//        barrier that ends its compute segment; a stage is re-targeted by DMA two phases after its last read, which for the
+//        leading half is one full barrier interval after the lagging half retired its reads.
+template <int N, int ROWB, int I = 0>
+__device__ __forceinline__ void frag_read_each(u32x4_t* f, const unsigned* addr) {   // fragment I at addr[I] + I * 16 rows
+    if constexpr (I < N) {
+        f[I] = frag_read<I * 16 * ROWB>(addr[I]);
+        frag_read_each<N, ROWB, I + 1>(f, addr);
     }
 }
 
+template <typename T, int BN>
+__device__ __forceinline__ void igemm_halo_rs_body(const ConvDev& p, int bid, const int nmt, const int nnt) {
+    static_assert(sizeof(T) == 2, "bf16 only");
+    constexpr int BM = 256, WM = 4, WN = BN / 64, NT = WM * WN * 64, KC = 4, EP = 8, BK = 32;
+    static_assert(NT == 512, "eight waves: two halves of four");
+    constexpr int TM = BM / WM / 16, TN = BN / WN / 16;            // 4 x 4 fragments per wave
+    constexpr int AS = ((BM + 2) * KC + 63) / 64 * 64;             // 1088 halo slots (16 B each)
+    constexpr int WS = 3 * BN * KC;                                // three taps of weights
+    constexpr int STAGE = AS + WS, NS = 3;
+    constexpr int AH_IT = (AS + NT - 1) / NT, WH_IT = WS / NT;
+    static_assert(AH_IT == 3 && WH_IT == 3 && WS % NT == 0, "six DMA pieces per thread and group: two per phase");
+    __shared__ __attribute__((aligned(128))) uint4 lds[NS * STAGE + 4];          // (+ one all-zero 64-B row)
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    if (p.xcd) {
+        const int total = nmt * nnt, q = total >> 3, r = total & 7, xcd = bid & 7, idx = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int m0 = (bid / nnt) * BM, n0 = (bid % nnt) * BN;
+    const T* __restrict__ X = static_cast<const T*>(p.x);
+    const T* __restrict__ Wt = static_cast<const T*>(p.w);
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(X), 0, p.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(Wt), 0, p.w_bytes, 0x00020000);
+    constexpr unsigned OOB = 0x80000000u;
+    const int wbase = __builtin_amdgcn_readfirstlane(tid & ~63);
+    const bool half_b = __builtin_amdgcn_readfirstlane(wave) >= 4;               // the lagging half
+    const bool third_pix = wbase + 2 * NT < AS;                                  // this wave owns a piece of the halo slab's tail (wave 0)
+    f32x4_t acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    const int fr = lane & 15, fq = lane >> 4;
+    if (tid < 4) lds[NS * STAGE + tid] = make_uint4(0u, 0u, 0u, 0u);             // (visible after the prologue's barrier)
+
+    unsigned ha_voff[AH_IT], ha_mask[AH_IT];
+#pragma unroll
+    for (int it = 0; it < AH_IT; ++it) {
+        const int c = tid + it * NT, row = c >> 2, kce = swz<KC>(row, c & 3);
+        const int q0 = m0 - 1 + row;
+        const bool ok = row < BM + 2 && q0 >= 0 && q0 < p.M;
+        const int qq = ok ? q0 : 0;
+        const int h0 = (qq / p.W) % p.H;
+        ha_voff[it] = ((unsigned)qq * (unsigned)p.Cin + (unsigned)(kce * EP)) * (unsigned)sizeof(T);
+        ha_mask[it] = ok ? ((h0 >= 1 ? 1u : 0u) | 2u | (h0 <= p.H - 2 ? 4u : 0u)) : 0u;
+    }
+    unsigned hw_voff[WH_IT];
+#pragma unroll
+    for (int it = 0; it < WH_IT; ++it) {
+        const int c = tid + it * NT, kwi = c / (BN * KC), rem = c - kwi * (BN * KC), row = rem >> 2, kce = swz<KC>(row, rem & 3);
+        const int co = n0 + row;
+        hw_voff[it] = co < p.Cout ? ((unsigned)co * (unsigned)p.K + (unsigned)(kwi * p.Cin + kce * EP)) * (unsigned)sizeof(T) : OOB;
+    }
+    // Left / right image border: the neighbouring LDS row holds the previous / next image row's pixel, the tap must read zeros
+    // instead.  The fragment's ADDRESS is redirected to the all-zero row (one select per fragment, before the read is issued)
+    // rather than zeroing the fragment's four registers behind the read.
+    const int xrow = wm * (BM / WM) + fr, wrow = wn * (BN / WN) + fr;
+    const unsigned lbase = lds_addr(&lds[0]);
+    const unsigned zrow = lbase + (unsigned)(NS * STAGE) * 16u + (unsigned)fq * 16u;
+    bool edge_l[TM], edge_r[TM];
+    unsigned zaddr[TM];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int m = m0 + wm * (BM / WM) + i * 16 + fr;
+        const int wo = m % p.W;
+        edge_l[i] = wo == 0;
+        edge_r[i] = wo == p.W - 1;
+        zaddr[i] = zrow - (unsigned)(i * 16 * KC * 16);            // frag_read_each adds i * 16 rows back
+    }
+    unsigned x_rd[3];
+#pragma unroll
+    for (int kw = 0; kw < 3; ++kw) x_rd[kw] = lbase + (unsigned)((xrow + kw) * KC + swz<KC>(xrow + kw, fq)) * 16u;
+    const unsigned w_rd = lbase + (unsigned)((AS + wrow * KC) + swz<KC>(wrow, fq)) * 16u;
+    constexpr unsigned STAGE_BYTES = STAGE * 16;
+    const int G = 3 * (p.Cin / BK);
+
+    // DMA pieces of one group (six per thread: halo slab 0, 1, [2: wave 0 only], weights of taps 0, 1, 2) go out as three pairs:
+    //   pair 0 = slab pieces 0, 1    pair 1 = weight taps 0, 1    pair 2 = weight tap 2 (+ the slab's tail piece)
+    unsigned a_off = 0, w_off = 0, ikh = 0;                        // offsets / kh of the group being issued
+    int gkh = 0, gci = 0;
+    auto next_group = [&]() {
+        a_off = (unsigned)(((gkh - 1) * p.W * p.Cin + gci) * (int)sizeof(T));
+        w_off = (unsigned)((gkh * 3 * p.Cin + gci) * (int)sizeof(T));
+        ikh = (unsigned)gkh;
+        gci += BK;
+        if (gci >= p.Cin) { gci = 0; ++gkh; }
+    };
+    const unsigned dmask = (p.dbg & 16) ? 0xfffu : 0xffffffffu;   // ablation (igemm_dbg): 16 = all DMA sources inside one 4-KB window,
+    const bool no_dma = p.dbg & 32, no_mfma = p.dbg & 64;          //   32 = no DMA inside the K loop, 64 = no MFMAs, 4 = no epilogue
+    auto issue_pair = [&](int pair, int st) {
+        uint4* base = &lds[st * STAGE];
+        if (no_dma) return;
+        if (pair == 0) {
+            glds16(rx, base + wbase, ((ha_mask[0] >> ikh) & 1u) ? (ha_voff[0] + a_off) & dmask : OOB);
+            glds16(rx, base + wbase + NT, ((ha_mask[1] >> ikh) & 1u) ? (ha_voff[1] + a_off) & dmask : OOB);
+        } else if (pair == 1) {
+            glds16(rw, base + AS + wbase, hw_voff[0] == OOB ? OOB : (hw_voff[0] + w_off) & dmask);
+            glds16(rw, base + AS + wbase + NT, hw_voff[1] == OOB ? OOB : (hw_voff[1] + w_off) & dmask);
+        } else {
+            glds16(rw, base + AS + wbase + 2 * NT, hw_voff[2] == OOB ? OOB : (hw_voff[2] + w_off) & dmask);
+            if (third_pix) glds16(rx, base + wbase + 2 * NT, ((ha_mask[2] >> ikh) & 1u) ? (ha_voff[2] + a_off) & dmask : OOB);
+        }
+    };
+    // Issue schedule (phase = (group g, tap t)):  (g, 0): pair 2 of group g+1   (g, 1): pair 0 of group g+2   (g, 2): pair 1 of g+2.
+    // A stage is re-targeted two phases after its last fragment read ((g-1, 2) -> (g, 1)), and at (g, 2) exactly four pieces are
+    // younger than group g+1's last one: `vmcnt(4)` there retires group g+1, which is first read one phase later.
+    next_group();                                      // group 0
+    issue_pair(0, 0); issue_pair(1, 0); issue_pair(2, 0);
+    next_group();                                      // group 1: pairs 0, 1 now, pair 2 in phase (0, 0)
+    issue_pair(0, 1); issue_pair(1, 1);
+    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   // group 0 has landed
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    if (half_b) {                                      // stagger: the lagging half sits out one barrier interval
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    int rs = 0, s1 = 1, s2 = 2;                        // stages of groups g, g + 1, g + 2
+    for (int g = 0; g < G; ++g) {
+        const unsigned gb = (unsigned)rs * STAGE_BYTES;
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+            // ---- load segment: this phase's fragment reads go out first, then the DMA pair
+            u32x4_t xf[TM], wf[TN];
+            if (t == 1) {
+                frag_read_all<TM, KC * 16>(xf, x_rd[1] + gb);
+            } else {
+                unsigned xa[TM];
+#pragma unroll
+                for (int i = 0; i < TM; ++i) xa[i] = (t == 0 ? edge_l[i] : edge_r[i]) ? zaddr[i] : x_rd[t] + gb;
+                frag_read_each<TM, KC * 16>(xf, xa);
+            }
+            frag_read_all<TN, KC * 16>(wf, w_rd + gb + (unsigned)(t * BN * KC * 16));
+            if (t == 0) {
+                if (g + 1 < G) issue_pair(2, s1);
+            } else if (g + 2 < G) {
+                if (t == 1) next_group();
+                issue_pair(t - 1, s2);
+            }
+            if (t == 2 && g + 1 < G) {
+                if (g + 2 < G && !no_dma) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            // ---- compute segment
+            frag_wait<TM, TN>(xf, wf);
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_setprio(1);
+            if (!no_mfma) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) acc[i][j] = Mma<T>::run(wf[j], xf[i], acc[i][j]);
+            }
+            __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        const int o = rs; rs = s1; s1 = s2; s2 = o;
+    }
+    if (!half_b) {                                     // the leading half's matching extra barrier
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    igemm_epilogue<T, BM, BN, WM, WN, NS * STAGE * 16>(p, acc, m0, n0, reinterpret_cast<unsigned char*>(&lds[0]));
+}
+
+template <typename T, int BN>
+__global__ __launch_bounds__(512) void igemm_halo_rs_kernel(ConvDev p) {
+    igemm_halo_rs_body<T, BN>(p, (int)(blockIdx.y * gridDim.x + blockIdx.x), (int)gridDim.x, (int)gridDim.y);
+}
+
+template <typename T, int BN>
+int launch_halo_rs(const ConvDev& d, hipStream_t st) {
+    dim3 grid(cdiv(d.M, 256), cdiv(d.Cout, BN));
+    hipLaunchKernelGGL((igemm_halo_rs_kernel<T, BN>), grid, dim3(512), 0, st, d);
+    ALDI_CHECK_LAUNCH();
+    char name[96];
+    snprintf(name, sizeof(name), "igemm<bf16,256,%d,4,2,roles,halo>", BN);
+    aldi_note_dispatch(name);
+    return ALDI_OK;
+}
+
+// (the 240-pixel halo tile is sized for TWO workgroups per CU: 6 waves each = 3 waves per SIMD, 80 KB of LDS each)
+template <int BM, int NT, bool HALO> constexpr int min_waves_per_simd() { return HALO && BM == 240 ? 2 * NT / 256 : 1; }
 template <typename T, int BM, int BN, int WM, int WN, int KC, bool PIPE, bool HALO = false>
-__global__ __launch_bounds__(WM* WN * 64) void igemm_kernel(ConvDev p) {
+__global__ __launch_bounds__(WM* WN * 64, (min_waves_per_simd<BM, WM * WN * 64, HALO>())) void igemm_kernel(ConvDev p) {
     igemm_body<T, BM, BN, WM, WN, KC, PIPE, HALO>(p, (int)(blockIdx.y * gridDim.x + blockIdx.x), (int)gridDim.x, (int)gridDim.y);
 }
 
@@ -588,7 +810,7 @@ struct ConvGroup {
     ConvDev p[kMaxConvGroup];
 };
 template <typename T, int BM, int BN, int WM, int WN, int KC, bool PIPE, bool HALO = false>
-__global__ __launch_bounds__(WM* WN * 64) void igemm_group_kernel(ConvGroup G) {
+__global__ __launch_bounds__(WM* WN * 64, (min_waves_per_simd<BM, WM * WN * 64, HALO>())) void igemm_group_kernel(ConvGroup G) {
     const int bid = (int)blockIdx.x;
     int i = 0;
     for (int k = 1; k < G.n; ++k)
@@ -654,9 +876,15 @@ int dispatch(ConvDev& d, hipStream_t st) {
             if (force == 1) return launch<T, 128, 128, 2, 2, 4, false, true>(d, st);
             if (force == 2) return launch<T, 128, 64, 4, 1, 4, false, true>(d, st);
             if (force == 4) return launch<T, 256, 128, 4, 2, 4, false, true>(d, st);
+            if (force == 9) return launch<T, 240, 128, 3, 2, 4, false, true>(d, st);
+            if (force == 10 && !g_group) return launch_halo_rs<T, 128>(d, st);
             if (force == 0 || force == 3) {      // (no 64x64 halo form; 5 = the 128x16 tap form)
                 if (d.Cout <= 64) return launch<T, 128, 64, 4, 1, 4, false, true>(d, st);
-                if (big >= tn.igemm_bigtile_min) return launch<T, 256, 128, 4, 2, 4, false, true>(d, st);
+                if (big >= tn.igemm_bigtile_min) {
+                    if (tn.igemm_bigtile == 1) return launch<T, 128, 128, 2, 2, 4, false, true>(d, st);
+                    if (tn.igemm_bigtile == 10 && !g_group) return launch_halo_rs<T, 128>(d, st);
+                    return launch<T, 256, 128, 4, 2, 4, false, true>(d, st);
+                }
                 // below ~1000 128x128 tiles the tile count of this network sits just above a multiple of the 256 CUs (16800 pixels =
                 // 131.25 row tiles: 264 / 528 tiles) and the last partial round costs as much as a full one; half-width tiles halve that
                 // tail (measured 8-25 % faster on every res3..res5 / FPN p3..p6 3x3 at N = 2 and 4)

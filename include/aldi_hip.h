@@ -33,11 +33,13 @@ int aldi_version(void);
 /* Tuning knobs of the kernel dispatchers (test / experiment surface; the defaults are what the benchmark runs).
  * Each knob can also be preset from the environment as ALDI_<UPPER-CASE NAME>, read once at first use.
  *   igemm_force          0 heuristics | 1 128x128 | 2 128x64 | 3 64x64 | 4 256x128 | 5 128x16 tile of aldi_conv_igemm |
- *                        6 / 7 / 8: the 128x128 / 128x64 / 64x64 tile with 128-byte K slabs (plain 1x1 / linear layers)
+ *                        6 / 7 / 8: the 128x128 / 128x64 / 64x64 tile with 128-byte K slabs (plain 1x1 / linear layers) |
+ *                        9 / 10 (3x3 halo form only): 240x128 on six waves, two workgroups per CU / 256x128 role-split
  *   igemm_k64_min        plain 1x1 / linear layers with K >= this (and K % 64 == 0) take the 64x64 128-byte-slab form (1024)
  *   igemm_group          1 = aldi_conv_igemm_group shares one launch (0: always n single launches)
  *   igemm_halo           1 = 3x3/stride-1/pad-1 bf16 convs use the halo form (one pixel slab per three taps)
- *   igemm_bigtile_min    128x128-tile count from which a 3x3 conv takes the 256x128 halo tile (1024)
+ *   igemm_bigtile_min    128x128-tile count from which a 3x3 conv takes the big halo tile (1024)
+ *   igemm_bigtile        which one: 4 = 256x128 lockstep (default), 1 = 128x128, 10 = 256x128 with the two wave halves in alternating roles
  *   igemm_lintile_min, igemm_bigtile_k   tile count / K from which a 1x1 conv or linear takes the 256x128 tile (768, 768)
  *   igemm_tile           9 = never use the 256x128 tile for 1x1 / linear
  *   igemm_xcd            1 = XCD-aware workgroup -> tile order
