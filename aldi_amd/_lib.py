@@ -140,6 +140,16 @@ class DgwItem(C.Structure):
                 ("Cout", c_int), ("KH", c_int), ("KW", c_int), ("Cin", c_int), ("tile_begin", c_int), ("reserved", c_int)]
 
 
+class FoldItem(C.Structure):
+    _fields_ = [("w", c_void_p), ("scale", c_void_p), ("out", c_void_p), ("rows", c_int), ("cols", c_int), ("chunk_begin", c_int), ("reserved", c_int)]
+
+
+class BottleneckArgs(C.Structure):
+    _fields_ = [("x", c_void_p), ("res", c_void_p), ("y", c_void_p), ("w1", c_void_p), ("w2", c_void_p), ("w3", c_void_p),
+                ("b1", c_void_p), ("b2", c_void_p), ("b3", c_void_p),
+                ("N", c_int), ("H", c_int), ("W", c_int), ("Cin", c_int), ("mid", c_int), ("Cout", c_int)]
+
+
 class AttnArgs(C.Structure):
     _fields_ = [
         ("qkv", c_void_p), ("rel_h", c_void_p), ("rel_w", c_void_p),

@@ -90,6 +90,8 @@ class Weights:
         self._stem_pk, self._stem_name = None, None
         self.lazy_wt = False             # True: sgd_step leaves the dgrad weights stale until someone asks / refreshes
         self._wt_dirty = False
+        self._fold_names: List[str] = []    # layers whose scale-folded bf16 weights the fused bottleneck kernel reads
+        self._fold_plan = None
 
     @property
     def grad(self) -> torch.Tensor:
@@ -156,6 +158,16 @@ class Weights:
         data-gradient contributions of a pixel to its KHxKW neighbourhood (sparse RPN backward)"""
         return self.wt(name + "@flat")
 
+    def folded(self, names: Sequence[str]) -> List[torch.Tensor]:
+        """bf16 weights of `names` with their FrozenBN scale folded in (the fused bottleneck's operands), re-derived by refresh().
+        The set of names is fixed by the first call (one launch re-derives them all)."""
+        if self._fold_plan is None:
+            self._fold_names = list(names) if not self._fold_names else self._fold_names
+            self._fold_plan = ops.FoldWeightsPlan([(self.w_master(n), self.scale(n)) for n in self._fold_names])
+            self._fold_plan.run()
+        idx = [self._fold_names.index(n) for n in names]
+        return [self._fold_plan.out[i] for i in idx]
+
     def stem_packed(self, name: str) -> torch.Tensor:
         """the stem kernel in the fused stem+pool kernel's bf16 [64][200] layout; re-derived by refresh()"""
         if self._stem_pk is None:
@@ -216,6 +228,8 @@ class Weights:
             ops.cast_from_f32(self.master[:L.n_weights], self.dtype, out=self.compute)
         if self._stem_pk is not None:
             ops.stem_pack_weights(self.w_master(self._stem_name), out=self._stem_pk)
+        if self._fold_plan is not None:
+            self._fold_plan.run()
         self._refresh_wt()
 
     def zero_grad(self):
@@ -372,6 +386,7 @@ class RCNN:
         self.has_img_da, self.has_ins_da = bool(self.img_da_layers), bool(self.ins_da_layers)
         self.fused_stem = os.environ.get("ALDI_FUSED_STEM", "1") == "1"                  # bf16: stem conv + max-pool in one kernel
         self.group_wgrad = os.environ.get("ALDI_WGRAD_GROUP", "1") == "1"                # bf16: a layer group's weight gradients in one launch
+        self.fused_res2 = os.environ.get("ALDI_FUSED_RES2", "1") == "1"                  # bf16: a res2 bottleneck (no saved activations) in one kernel
         self._wg_queue: list = []
         self.sparse_rpn_backward = os.environ.get("ALDI_RPN_SPARSE_BWD", "1") == "1"      # tests flip the attribute to compare with the dense form
         spec = getattr(weights.layout, "img_da", None)
@@ -518,10 +533,20 @@ class RCNN:
             del stem
         blocks = []
         cs = []
+        # res2 keeps nothing for the backward (FREEZE_AT = 2; `blocks` below starts at res3): each of its bottlenecks is ONE kernel
+        # whose two 64-channel intermediate maps stay in the LDS (csrc/bneck.hip)
+        fuse2 = self.dtype == torch.bfloat16 and self.fused_res2
+        if fuse2:
+            res2 = [f"{bu}res2.{b}.conv{k}" for b in range(STAGE_BLOCKS[0]) for k in (1, 2, 3)]
+            fw = dict(zip(res2, W.folded(res2)))
         for si, nb in enumerate(STAGE_BLOCKS):
             for b in range(nb):
                 p = f"{bu}res{si + 2}.{b}."
                 sc = (yield x, p + "shortcut", {}) if b == 0 else x
+                if si == 0 and fuse2:
+                    x = ops.bottleneck_fused(x, sc, fw[p + "conv1"], fw[p + "conv2"], fw[p + "conv3"], W.shift(p + "conv1"), W.shift(p + "conv2"),
+                                             W.shift(p + "conv3"))
+                    continue
                 h1 = yield x, p + "conv1", dict(relu=True)
                 h2 = yield h1, p + "conv2", dict(relu=True)
                 out = yield h2, p + "conv3", dict(relu=True, res=sc, res_mode=1)

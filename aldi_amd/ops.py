@@ -191,6 +191,52 @@ class DgradWeightsPlan:
         L.call("aldi_dgrad_weights_batch", _p(self.items), self.n, self.total_tiles, dtype_code(self.dtype), stream_ptr())
 
 
+class FoldWeightsPlan:
+    """bf16 copies of conv weights with the FrozenBN scale folded into their rows, all in one launch (aldi_fold_weights_batch).
+    `entries` = [(w_master fp32 view [Cout, ...], scale [Cout] | None)]; `out[i]` has w_master's shape.  Inputs keep their storage."""
+
+    def __init__(self, entries):
+        dev = entries[0][0].device
+        self.keep = list(entries)
+        sizes = [w.numel() for w, _ in entries]
+        offs, tot = [], 0
+        for n in sizes:
+            assert n % 8 == 0
+            offs.append(tot)
+            tot += (n + 63) // 64 * 64
+        self.buf = torch.empty(tot, dtype=torch.bfloat16, device=dev)
+        self.out = []
+        items = (L.FoldItem * len(entries))()
+        chunk = 0
+        for i, (w, sc) in enumerate(entries):
+            assert w.dtype == torch.float32 and w.is_contiguous() and w.data_ptr() % 16 == 0, "fold_weights: fp32, contiguous, 16-byte aligned"
+            o = self.buf[offs[i]:offs[i] + sizes[i]].view(w.shape)
+            self.out.append(o)
+            it = items[i]
+            it.w, it.scale, it.out = w.data_ptr(), (sc.data_ptr() if sc is not None else None), o.data_ptr()
+            it.rows, it.cols, it.chunk_begin, it.reserved = w.shape[0], sizes[i] // w.shape[0], chunk, 0
+            chunk += sizes[i] // 8
+        self.total_chunks, self.n = chunk, len(entries)
+        self.items = torch.frombuffer(bytearray(bytes(items)), dtype=torch.uint8).to(dev)
+
+    def run(self):
+        L.call("aldi_fold_weights_batch", _p(self.items), self.n, self.total_chunks, stream_ptr())
+
+
+def bottleneck_fused(x: torch.Tensor, res: torch.Tensor, w1, w2, w3, b1, b2, b3, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """one ResNet bottleneck without saved activations in one kernel (aldi_bottleneck_fused): x [N,H,W,Cin] bf16, res [N,H,W,Cout]
+    (x itself for an identity block), folded bf16 weights w1 [mid,1,1,Cin], w2 [mid,3,3,mid], w3 [Cout,1,1,mid], fp32 shifts"""
+    N, H, W_, Cin = x.shape
+    mid, Cout = w1.shape[0], w3.shape[0]
+    assert x.dtype == torch.bfloat16 and x.is_contiguous() and res.is_contiguous() and res.shape == (N, H, W_, Cout), (x.shape, res.shape)
+    assert w1.numel() == mid * Cin and w2.numel() == mid * 9 * mid and w3.numel() == Cout * mid and w1.dtype == torch.bfloat16
+    if out is None:
+        out = torch.empty((N, H, W_, Cout), dtype=x.dtype, device=x.device)
+    a = L.BottleneckArgs(_p(x), _p(res), _p(out), _p(w1), _p(w2), _p(w3), _p(b1), _p(b2), _p(b3), N, H, W_, Cin, mid, Cout)
+    L.call("aldi_bottleneck_fused", C.byref(a), stream_ptr())
+    return out
+
+
 # ------------------------------------------------------------------------------- stem / glue
 def stem_forward(img_u8: torch.Tensor, sizes: Sequence[Sequence[int]], w: torch.Tensor, scale: torch.Tensor, shift: torch.Tensor,
                  mean: Sequence[float], std: Sequence[float], dtype: torch.dtype) -> torch.Tensor:

@@ -141,6 +141,30 @@ typedef struct aldi_dgw_item {
 } aldi_dgw_item;
 int aldi_dgrad_weights_batch(const aldi_dgw_item* items, int n_items, int total_tiles, int dtype, aldi_stream_t stream);
 
+/* A whole ResNet bottleneck (1x1 reduce -> 3x3 -> 1x1 expand, FrozenBN folded, ReLUs, residual add) in ONE kernel, bf16, for
+ * blocks that keep no activations for a backward pass -- res2 of the student (BACKBONE.FREEZE_AT = 2) and of the EMA teacher:
+ * the two 64-channel intermediate maps stay in the LDS (csrc/bneck.hip).  Replaces detectron2 BottleneckBlock.forward for res2
+ * (three aldi_conv_igemm launches per block, 2048 -> 1024 B of HBM traffic per pixel).
+ *   y = relu( w3 . relu( w2 (*) relu( w1 . x + b1 ) + b2 ) + b3 + res ),   res = x for an identity block (Cin == Cout), the shortcut
+ *   conv's output for the first block of the stage.  w1 [mid][Cin], w2 [mid][3][3][mid], w3 [Cout][mid] are bf16 WITH the FrozenBN
+ *   scales folded in (aldi_fold_weights_batch), b1 / b2 / b3 the folded shifts (fp32).  Built for Cin in {64, 256}, mid 64, Cout 256. */
+typedef struct aldi_bottleneck_args {
+    const void* x;            /* [N][H][W][Cin] bf16 */
+    const void* res;          /* [N][H][W][Cout] bf16 */
+    void* y;                  /* [N][H][W][Cout] bf16 */
+    const void* w1; const void* w2; const void* w3;
+    const float* b1; const float* b2; const float* b3;
+    int N, H, W, Cin, mid, Cout;
+} aldi_bottleneck_args;
+int aldi_bottleneck_fused(const aldi_bottleneck_args* a, aldi_stream_t stream);
+/* out[r][c] = bf16(w[r][c] * scale[r]) for a DEVICE table of fp32 matrices (rows * cols a multiple of 8, 16-byte aligned);
+ * matrix i owns the 8-element chunks [chunk_begin_i, chunk_begin_{i+1}) of the launch. */
+typedef struct aldi_fold_item {
+    const float* w; const float* scale; void* out;
+    int rows, cols, chunk_begin, reserved;
+} aldi_fold_item;
+int aldi_fold_weights_batch(const aldi_fold_item* items, int n_items, int total_chunks, aldi_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------
  * Stem and glue (bandwidth-bound).
  * ------------------------------------------------------------------------------------- */
