@@ -324,18 +324,21 @@ extern "C" int aldi_torch_rng_script(unsigned char* state, const long* script, i
 
 // The whole host phase of one fused ALDI iteration in one call: from the device's list lengths to the sampling positions,
 // their counts, the ROI row offsets and the distillation normalisers, written into the pinned upload buffer.  Order of the
-// draws on the global CPU generator (aldi/distill.py:148-162,200-202, aldi/helpers.py:17-26):
-//   per chunk: [distillation chunk: manual_seed(seed_old) by the teacher's eval pass] RPN sample (positives, negatives per
-//   image), manual_seed(seed of the student's roi_heads hook: seed_old before the seeder was reset, seed_new after), ROI sample;
-//   then for the distillation chunk manual_seed(seed_new), the teacher's identical ROI draws (discarded) and the fresh RPN
-//   sample of get_rpn_losses.
+// draws on the global CPU generator (aldi/distill.py:148-162,200-202, aldi/helpers.py:17-26), chunk by chunk
+// (= micro-step by micro-step of the reference schedule, aldi/trainer.py:51-52,86-89):
+//   [distillation chunk: manual_seed(current seed) by the teacher's eval pass, then the seeder is reset: next seed] RPN sample
+//   (positives, negatives per image), manual_seed(current seed) by the student's roi_heads hook, ROI sample; a distillation
+//   chunk continues with manual_seed(current seed), the teacher's identical ROI draws (discarded) and the fresh RPN sample of
+//   get_rpn_losses.
 // counts: [N][2] RPN (positives, negatives) then [N][2] ROI.  chunks: nch rows {kind (1 = distillation), n0, n1}.
+// seeds: the ManualSeed hook's seed before the iteration, then after each distillation chunk's reset_seed (1 + #distillation chunks).
 // word0: int32 word offsets into `words` of {rsel [N][2][rpn_batch], rnsel [N][2], osel [N][2][roi_batch], onsel [N][2],
-// row_off [N], dsel [nd][2][rpn_batch], dnsel [nd][2], nvf [2]}.  rows_out [N]: sampled ROI rows per image.
-extern "C" int aldi_step_draws(unsigned char* state, const int* counts, int N, const int* chunks, int nch, long seed_old, long seed_new,
+// row_off [N], dsel [Nd][2][rpn_batch], dnsel [Nd][2], nvf [#distillation chunks][2]} (Nd = images of the distillation chunks,
+// in chunk order).  rows_out [N]: sampled ROI rows per image.
+extern "C" int aldi_step_draws(unsigned char* state, const int* counts, int N, const int* chunks, int nch, const long* seeds, int nseeds,
                                int rpn_batch, int rpn_pos_cap, int roi_batch, int roi_pos_cap, int* words, const int* word0, int* rows_out,
                                int threads) {
-    if (!state || !counts || !chunks || !words || !word0 || !rows_out || N < 1 || nch < 1)
+    if (!state || !counts || !chunks || !seeds || !words || !word0 || !rows_out || N < 1 || nch < 1 || nseeds < 1)
         return aldi_set_error_msg(ALDI_ERR_ARG, "step_draws: bad args");
     std::vector<long> sc;
     sc.reserve(64 * (size_t)N);
@@ -352,37 +355,36 @@ extern "C" int aldi_step_draws(unsigned char* state, const int* counts, int N, c
     };
     const int* rpn = counts;
     const int* roi = counts + 2 * N;
-    bool reset = false;
-    int distill = -1;
-    std::vector<int> pn(2 * (size_t)N);
+    int k = 0, d0 = 0;                              // resets so far / distillation images so far
+    std::vector<int> pn(2 * (size_t)N), dn;
     for (int c = 0; c < nch; ++c) {
         const int kind = chunks[3 * c], n0 = chunks[3 * c + 1], n1 = chunks[3 * c + 2];
         if (n0 < 0 || n1 > N || n1 <= n0) return aldi_set_error_msg(ALDI_ERR_ARG, "step_draws: bad chunk");
         if (kind == 1) {
-            sc.insert(sc.end(), {1, seed_old, 0, 0});
-            reset = true;
-            distill = c;
+            if (k + 1 >= nseeds) return aldi_set_error_msg(ALDI_ERR_ARG, "step_draws: one seed per distillation chunk (+ the initial one)");
+            sc.insert(sc.end(), {1, seeds[k], 0, 0});
+            ++k;
         }
         sample(word0[0], word0[1], n0, rpn + 2 * n0, n1 - n0, rpn_batch, rpn_pos_cap, nullptr);
-        sc.insert(sc.end(), {1, reset ? seed_new : seed_old, 0, 0});
+        sc.insert(sc.end(), {1, seeds[k], 0, 0});
         sample(word0[2], word0[3], n0, roi + 2 * n0, n1 - n0, roi_batch, roi_pos_cap, pn.data() + 2 * n0);
+        if (kind == 1) {
+            sc.insert(sc.end(), {1, seeds[k], 0, 0});
+            sample(-1, -1, 0, roi + 2 * n0, n1 - n0, roi_batch, roi_pos_cap, nullptr);
+            dn.assign(2 * (size_t)(n1 - n0), 0);
+            sample(word0[5], word0[6], d0, rpn + 2 * n0, n1 - n0, rpn_batch, rpn_pos_cap, dn.data());
+            int n_valid = 0, n_fg = 0;
+            for (int i = 0; i < n1 - n0; ++i) { n_fg += dn[2 * i]; n_valid += dn[2 * i] + dn[2 * i + 1]; }
+            words[word0[7] + 2 * (k - 1)] = n_valid;
+            words[word0[7] + 2 * (k - 1) + 1] = n_fg;
+            d0 += n1 - n0;
+        }
     }
     int off = 0;
     for (int i = 0; i < N; ++i) {
         rows_out[i] = pn[2 * i] + pn[2 * i + 1];
         words[word0[4] + i] = off;
         off += rows_out[i];
-    }
-    if (distill >= 0) {
-        const int n0 = chunks[3 * distill + 1], n1 = chunks[3 * distill + 2];
-        sc.insert(sc.end(), {1, seed_new, 0, 0});
-        sample(-1, -1, 0, roi + 2 * n0, n1 - n0, roi_batch, roi_pos_cap, nullptr);
-        std::vector<int> dn(2 * (size_t)(n1 - n0));
-        sample(word0[5], word0[6], 0, rpn + 2 * n0, n1 - n0, rpn_batch, rpn_pos_cap, dn.data());
-        int n_valid = 0, n_fg = 0;
-        for (int i = 0; i < n1 - n0; ++i) { n_fg += dn[2 * i]; n_valid += dn[2 * i] + dn[2 * i + 1]; }
-        words[word0[7]] = n_valid;
-        words[word0[7] + 1] = n_fg;
     }
     return run_script(state, sc.data(), (int)(sc.size() / 4), words, threads);
 }

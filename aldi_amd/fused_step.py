@@ -269,18 +269,20 @@ class FusedStep:
         seeds = [int(self.tr.distiller.seeder.seed)]
         if S.distill:
             keep = random.getstate()
-            seeds.append(random.randint(0, 2**32 - 1))          # what ManualSeed.reset_seed will draw (aldi/helpers.py:21-23)
+            for _ in range(min(S.nk, 6)):                       # what ManualSeed.reset_seed will draw, once per distillation micro-step
+                seeds.append(random.randint(0, 2**32 - 1))      # (aldi/helpers.py:21-23; the library keeps at most 8 streams)
             random.setstate(keep)
         depth = S.N * (n_anchors + 2 * 4096)                   # every image's RPN lists + ROI lists in ONE segment: an upper bound
         st = torch.get_rng_state()
         L.call("aldi_torch_rng_prefetch", st.data_ptr(), (C.c_long * len(seeds))(*seeds), len(seeds), depth)
 
     def _host_draws(self, S, A):
-        """every sampling draw of the iteration on the global CPU generator, in the reference's order:
-        per micro-step the RPN sample (two randperm per image), `torch.manual_seed(seed)` by the roi_heads pre-hook, the ROI
-        sample; for the distillation micro-step first the teacher's eval inference re-seeds with the OLD seed and the seeder
-        draws a new one (aldi/distill.py:148-150), afterwards the teacher's train-mode forward repeats the ROI draws under the
-        same seed and `get_rpn_losses` draws a fresh RPN sample (aldi/distill.py:160-162,200-202)."""
+        """every sampling draw of the iteration on the global CPU generator, in the reference's order, chunk by chunk =
+        micro-step by micro-step of the reference schedule (aldi/trainer.py:51-52,86-89):
+        the RPN sample (two randperm per image), `torch.manual_seed(seed)` by the roi_heads pre-hook, the ROI sample; a distillation
+        micro-step starts with the teacher's eval inference re-seeding with the CURRENT seed and the seeder drawing a new one
+        (aldi/distill.py:148-150), and ends with the teacher's train-mode forward repeating the ROI draws under the same seed and
+        `get_rpn_losses` drawing a fresh RPN sample (aldi/distill.py:160-162,200-202)."""
         eng, dist_, model = self.eng, self.tr.distiller, self.tr.model
         N = S.N
         P_ = eng.p
@@ -293,15 +295,27 @@ class FusedStep:
         scripted = self._scripted()
         script: List[int] = []
         hw = U.words
-        if scripted and os.environ.get("ALDI_HOST_DRAWS_C", "1") == "1" and all(ch["kind"] != "distill" for ch in S.chunks[:-1]):
+        nv = U.word0("nvf")
+
+        def finish(rows):
+            r0 = 0
+            for ch in S.chunks:
+                n0, n1 = ch["n0"], ch["n1"]
+                r1 = r0 + sum(rows[n0:n1])
+                ch["r0"], ch["r1"] = r0, r1
+                ch["rpn_counts"], ch["roi_counts"] = rpn_counts[n0:n1], roi_counts[n0:n1]
+                r0 = r1
+            nvf = [(int(hw[nv + 2 * k]), int(hw[nv + 2 * k + 1])) for k in range(S.nk)]
+            return SimpleNamespace(rows=rows, R=sum(rows), nvf=nvf, key=tuple(rows))
+        if scripted and os.environ.get("ALDI_HOST_DRAWS_C", "1") == "1":
             # the whole host phase as ONE native call (aldi_step_draws): same draws, same order, none of the Python below
             import ctypes as C
             from . import _lib as L
             seeder = dist_.seeder
-            old = int(seeder.seed)
-            if S.distill:
+            seeds = [int(seeder.seed)]
+            for _ in range(S.nk):
                 seeder.reset_seed()                         # aldi/distill.py:148-150 (Python's `random` advances here, as in the reference)
-            new = int(seeder.seed)
+                seeds.append(int(seeder.seed))
             if getattr(S, "chunk_arr", None) is None:
                 flat = []
                 for ch in S.chunks:
@@ -310,20 +324,11 @@ class FusedStep:
                 S.word0_arr = (C.c_int * 8)(*[U.word0(k) for k in ("rsel", "rnsel", "osel", "onsel", "row_off", "dsel", "dnsel", "nvf")])
                 S.rows_arr = (C.c_int * N)()
             st = torch.get_rng_state()
-            L.call("aldi_step_draws", st.data_ptr(), S.h_counts.data_ptr(), N, S.chunk_arr, len(S.chunks), old, new, P_.rpn_batch,
-                   int(P_.rpn_batch * P_.rpn_pos_frac), P_.roi_batch, int(P_.roi_batch * P_.roi_pos_frac), U.host.data_ptr(), S.word0_arr, S.rows_arr, 4)
+            L.call("aldi_step_draws", st.data_ptr(), S.h_counts.data_ptr(), N, S.chunk_arr, len(S.chunks), (C.c_long * len(seeds))(*seeds), len(seeds),
+                   P_.rpn_batch, int(P_.rpn_batch * P_.rpn_pos_frac), P_.roi_batch, int(P_.roi_batch * P_.roi_pos_frac), U.host.data_ptr(), S.word0_arr,
+                   S.rows_arr, 4)
             torch.set_rng_state(st)
-            rows = list(S.rows_arr)
-            r0 = 0
-            for ch in S.chunks:
-                n0, n1 = ch["n0"], ch["n1"]
-                r1 = r0 + sum(rows[n0:n1])
-                ch["r0"], ch["r1"] = r0, r1
-                ch["rpn_counts"], ch["roi_counts"] = rpn_counts[n0:n1], roi_counts[n0:n1]
-                r0 = r1
-            nv = U.word0("nvf")
-            return SimpleNamespace(rows=rows, R=sum(rows), n_valid=int(hw[nv]) if S.distill else 0, n_fg=int(hw[nv + 1]) if S.distill else 0,
-                                   key=tuple(rows))
+            return finish(list(S.rows_arr))
 
         def sample(name, nname, row0, counts, batch, frac):
             """subsample_labels for the images `row0 ...`: positives then negatives, two randperm per image"""
@@ -353,11 +358,13 @@ class FusedStep:
             else:
                 torch.manual_seed(dist_.seeder.seed)
         rows: List[int] = []
+        k = d0 = 0
         for ch in S.chunks:
             n0, n1 = ch["n0"], ch["n1"]
-            if ch["kind"] == "distill":
+            distill = ch["kind"] == "distill"
+            if distill:
                 if scripted:
-                    reseed()                               # the teacher's eval inference fired ManualSeed with the OLD seed
+                    reseed()                               # the teacher's eval inference fired ManualSeed with the current seed
                 else:
                     self.teacher.roi_heads.fire_pre()
                 dist_.seeder.reset_seed()
@@ -368,25 +375,17 @@ class FusedStep:
                 model.roi_heads.fire_pre()
             oh = sample("osel", "onsel", n0, roi_counts[n0:n1], ROI_BATCH, ROI_POS_FRAC)
             rows += [x + y for x, y in oh]
-            ch["rpn_counts"], ch["roi_counts"] = rpn_counts[n0:n1], roi_counts[n0:n1]
+            if distill:
+                reseed()
+                sample("-", None, 0, roi_counts[n0:n1], ROI_BATCH, ROI_POS_FRAC)            # the teacher's identical ROI draws (aldi/distill.py:160-162)
+                dh = sample("dsel", "dnsel", d0, rpn_counts[n0:n1], RPN_BATCH, RPN_POS_FRAC)     # fresh sample of get_rpn_losses (aldi/distill.py:200-202)
+                hw[nv + 2 * k], hw[nv + 2 * k + 1] = sum(x + y for x, y in dh), sum(x for x, _ in dh)
+                k += 1
+                d0 += n1 - n0
         off, ro = 0, U.word0("row_off")
         for i, r in enumerate(rows):
             hw[ro + i] = off
             off += r
-        r0 = 0
-        for ch in S.chunks:
-            r1 = r0 + sum(rows[ch["n0"]:ch["n1"]])
-            ch["r0"], ch["r1"] = r0, r1
-            r0 = r1
-        n_valid = n_fg = 0
-        if S.distill:
-            ch = S.chunks[-1]
-            reseed()
-            sample("-", None, 0, ch["roi_counts"], ROI_BATCH, ROI_POS_FRAC)            # the teacher's identical ROI draws (aldi/distill.py:160-162)
-            dh = sample("dsel", "dnsel", 0, ch["rpn_counts"], RPN_BATCH, RPN_POS_FRAC)     # fresh sample of get_rpn_losses (aldi/distill.py:200-202)
-            n_fg = sum(x for x, _ in dh)
-            n_valid = sum(x + y for x, y in dh)
-            hw[U.word0("nvf")], hw[U.word0("nvf") + 1] = n_valid, n_fg
         if scripted and script:
             import ctypes as C
             from . import _lib as L
@@ -394,7 +393,7 @@ class FusedStep:
             st = torch.get_rng_state()
             L.call("aldi_torch_rng_script", st.data_ptr(), arr, len(script) // 4, U.host.data_ptr(), 4)
             torch.set_rng_state(st)
-        return SimpleNamespace(rows=rows, R=sum(rows), n_valid=n_valid, n_fg=n_fg, key=tuple(rows))
+        return finish(rows)
 
     # ------------------------------------------------------------------------------------------------ phase B
     def _phase_b(self, S, A, Hst):
@@ -414,19 +413,21 @@ class FusedStep:
         eng._roi_gather(c, prep, U.d("osel"), U.d("onsel"), oh, c.gt, N, row_off_dev=U.d("row_off"))
         t_pred = None
         if S.distill:
-            ch = S.chunks[-1]
-            n0, r0, r1 = ch["n0"], ch["r0"], ch["r1"]
-            rois_t = c.rois[r0:r1].clone()
-            rois_t[:, 0] -= n0
+            # the teacher's box head on the student's sampled proposals of ALL distillation chunks (consecutive images d0 .. N of the
+            # student batch = images 0 .. of the teacher's), beside the student's own
+            dch = [ch for ch in S.chunks if ch["kind"] == "distill"]
+            tr0, tr1 = dch[0]["r0"], dch[-1]["r1"]
+            rois_t = c.rois[tr0:tr1].clone()
+            rois_t[:, 0] -= S.d0
             tside = S.tside
-            if tside is not None:                              # the teacher's box head on the student's sampled proposals, beside the student's own
+            if tside is not None:
                 tside.wait_stream(main)
                 rois_t.record_stream(tside)
                 with torch.cuda.stream(tside), torch.no_grad():
-                    t_pred = teng.box_head_on(tc, rois_t, r1 - r0)
+                    t_pred = teng.box_head_on(tc, rois_t, tr1 - tr0)
             else:
                 with torch.no_grad():
-                    t_pred = teng.box_head_on(tc, rois_t, r1 - r0)
+                    t_pred = teng.box_head_on(tc, rois_t, tr1 - tr0)
         eng.roi_forward(c)
         accum = S.accum
         # ---- describe every chunk's losses and their gradient scales (host only), then ONE pass of loss kernels that yields
@@ -447,12 +448,14 @@ class FusedStep:
                         "loss_box_reg": dist_.do_hard_roi_reg}
                 if S.tside is not None:
                     main.wait_stream(S.tside)
+                t0, t1, kd = n0 - S.d0, n1 - S.d0, ch["kd"]             # this chunk's images in the teacher's batch / its index among the distillation chunks
                 dl = torch.empty((nc, sumA), dtype=torch.int32, device=dev)
-                ops.rpn_apply_sample(dl, sumA, nc, c.rpn_lists[n0:n1], U.d("dsel"), U.d("dnsel"), RPN_BATCH)
-                eng.distill_forward_chunk(c, ch, tc.head, t_pred, dl, Hst.n_valid, Hst.n_fg, values=False, obj_T=float(dist_.obj_temperature),
+                ops.rpn_apply_sample(dl, sumA, nc, c.rpn_lists[n0:n1], U.d("dsel")[t0:t1], U.d("dnsel")[t0:t1], RPN_BATCH)
+                eng.distill_forward_chunk(c, ch, [h[t0:t1] for h in tc.head], t_pred[ch["r0"] - tr0: ch["r1"] - tr0], dl, Hst.nvf[kd][0], Hst.nvf[kd][1],
+                                          values=False, obj_T=float(dist_.obj_temperature),
                                           cls_T=float(dist_.cls_temperature), kl=dist_.cls_loss_type == "KL", do_obj=dist_.do_obj_dst,
                                           do_rpn_reg=dist_.do_rpn_reg_dst, do_cls=dist_.do_cls_dst, do_roih_reg=dist_.do_roih_reg_dst,
-                                          counts_dev=U.d("nvf"))
+                                          counts_dev=U.d("nvf")[2 * kd: 2 * kd + 2])
                 ch["hard"] = hard
                 sc = {k: (1.0 if hard.get(k, False) else 0.0) / accum for k in keys}
                 k_ = ch["distill"]
@@ -501,18 +504,22 @@ class FusedStep:
             for k, v in out.items():
                 if keep(k):
                     entries.append((f"{k}_{ch['name']}", v))
-        kept = [(n_, v) for n_, v in entries if not isinstance(v, tuple)]
-        masked = [(n_, v[0]) for n_, v in entries if isinstance(v, tuple)]
-        vals = {}
+        # (a row that spans several micro-batches contributes one entry per chunk under the SAME key: they add up, as the
+        # sequential driver's `metrics[key] = metrics.get(key, 0) + v` does)
+        kept = [i for i, (_, v) in enumerate(entries) if not isinstance(v, tuple)]
+        masked = [i for i, (_, v) in enumerate(entries) if isinstance(v, tuple)]
+        vals = [None] * len(entries)
         if kept:
-            kv = (torch.stack([v for _, v in kept]) / accum).detach()
-            vals.update({n_: kv[i] for i, (n_, _) in enumerate(kept)})
+            kv = (torch.stack([entries[i][1] for i in kept]) / accum).detach()
+            for j, i in enumerate(kept):
+                vals[i] = kv[j]
         if masked:
-            mv = ((torch.stack([v for _, v in masked]) * 0.0) / accum).detach()
-            vals.update({n_: mv[i] for i, (n_, _) in enumerate(masked)})
+            mv = ((torch.stack([entries[i][1][0] for i in masked]) * 0.0) / accum).detach()
+            for j, i in enumerate(masked):
+                vals[i] = mv[j]
         loss_dict = {}
-        for n_, _ in entries:                                  # original key order
-            loss_dict[n_] = loss_dict[n_] + vals[n_] if n_ in loss_dict else vals[n_]
+        for (n_, _), v in zip(entries, vals):                  # original key order
+            loss_dict[n_] = loss_dict[n_] + v if n_ in loss_dict else v
         return loss_dict
 
     # ------------------------------------------------------------------------------------------------ driver
@@ -546,15 +553,26 @@ class FusedStep:
         images, lab_rows, chunks, n0 = [], [], [], 0
         da = model.cfg.DOMAIN_ADAPT.ALIGN
         for row in plan:
-            n1 = n0 + len(row.data)
             kind = "distill" if row.teacher_data is not None else ("labeled" if row.kwargs.get("labeled", True) else "unlabeled")
-            chunks.append(dict(name=row.name, kind=kind, n0=n0, n1=n1, labeled=row.kwargs.get("labeled", True),
-                               do_align=row.kwargs.get("do_align", False) and kind != "distill", da_weights=(da.IMG_DA_WEIGHT, da.INS_DA_WEIGHT),
-                               keep=row.keep))
-            images += [d["image"] for d in row.data]
-            if kind == "labeled":
-                lab_rows += [(n0 + j, as_record(d["instances"])) for j, d in enumerate(row.data)]
-            n0 = n1
+            if row.teacher_data is not None:
+                assert len(row.teacher_data) == len(row.data), "Teacher and student data must be the same length."
+            # one chunk per IMS_PER_GPU-sized micro-batch of the row, in the sequential driver's order (aldi/trainer.py:51-52,86-89):
+            # the loss normalisers, the sampling draws and the `ManualSeed` resets are per micro-step
+            for lo in range(0, len(row.data), bs):
+                part = row.data[lo:lo + bs]
+                n1 = n0 + len(part)
+                chunks.append(dict(name=row.name, kind=kind, n0=n0, n1=n1, labeled=row.kwargs.get("labeled", True),
+                                   do_align=row.kwargs.get("do_align", False) and kind != "distill", da_weights=(da.IMG_DA_WEIGHT, da.INS_DA_WEIGHT),
+                                   keep=row.keep))
+                images += [d["image"] for d in part]
+                if kind == "labeled":
+                    lab_rows += [(n0 + j, as_record(d["instances"])) for j, d in enumerate(part)]
+                n0 = n1
+        kd = 0
+        for ch in chunks:
+            if ch["kind"] == "distill":
+                ch["kd"] = kd
+                kd += 1
         N = n0
         # the EMA tick handed over by ALDITrainer.before_step: copy while iter <= start_iter, else lerp (aldi/ema.py:52-57)
         ema_mode = None
@@ -567,6 +585,8 @@ class FusedStep:
                tuple(tuple(d["image"].shape[1:]) for d in (unlabeled_weak or [])) if do_distill else (), ema_mode, bool(zero_grad))
         S = self._static_for(key)
         S.N, S.chunks, S.accum, S.distill, S.has_disc = N, chunks, accum, do_distill, do_align
+        S.nk = kd                                                  # distillation micro-steps; their images are the last ones: d0 .. N
+        S.d0 = min([ch["n0"] for ch in chunks if ch["kind"] == "distill"], default=N)
         S.ema_mode, S.ema_alpha = ema_mode, (ema[0].alpha if ema is not None else None)
         S.zero_grad = bool(zero_grad)                              # clear the gradient buffer inside phase A, beside the forward
         if zero_grad:
@@ -580,14 +600,13 @@ class FusedStep:
         S.gt_all = self._stage_gt(S, lab_rows, N)
         S.pl_out = None
         if do_distill:
-            d0, d1 = chunks[-1]["n0"], chunks[-1]["n1"]
-            S.pl_out = tuple(S.gt_all[k][d0:d1] for k in ("boxes", "classes", "count"))
+            S.pl_out = tuple(S.gt_all[k][S.d0:N] for k in ("boxes", "classes", "count"))
         if S.up is None:
-            nd = (chunks[-1]["n1"] - chunks[-1]["n0"]) if do_distill else 1
+            nd = max(N - S.d0, 1)
             RPN_BATCH, ROI_BATCH = eng.p.rpn_batch, eng.p.roi_batch
             S.up = _Packed([("rsel", (N, 2, RPN_BATCH), torch.int32), ("rnsel", (N, 2), torch.int32), ("osel", (N, 2, ROI_BATCH), torch.int32),
                             ("onsel", (N, 2), torch.int32), ("row_off", (N,), torch.int32), ("dsel", (nd, 2, RPN_BATCH), torch.int32),
-                            ("dnsel", (nd, 2), torch.int32), ("nvf", (2,), torch.int32)], dev)
+                            ("dnsel", (nd, 2), torch.int32), ("nvf", (2 * max(S.nk, 1),), torch.int32)], dev)
             S.h_counts = _pinned((4 * N + 2) * 4)
             S.h_counts_np = S.h_counts.numpy().view("int32")[: 4 * N + 2]
         S.h_counts_np.fill(-1)                                    # (phase A's last copy overwrites every word with a length >= 0)

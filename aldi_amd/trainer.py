@@ -200,7 +200,7 @@ def fused_run_model(trainer, labeled_weak, labeled_strong, unlabeled_weak, unlab
                     "loss_box_reg": dist_.do_hard_roi_reg}
             n0, n1, r0, r1 = ch["n0"], ch["n1"], ch["r0"], ch["r1"]
             torch.manual_seed(dist_.seeder.seed)
-            eng._sample_host(ch["roi_counts"], 512, 0.25)                    # the teacher's identical ROI draws
+            eng._sample_host(ch["roi_counts"], eng.p.roi_batch, eng.p.roi_pos_frac)   # the teacher's identical ROI draws
             if side is not None:
                 torch.cuda.current_stream().wait_stream(side)
             t_pred = t_out["pred"]
@@ -424,15 +424,31 @@ class _ALDITrainer:
         self.fused = False
 
     def _can_fuse(self, data):
+        """the fused driver takes the reference's FPN batch contents (labeled_strong [+ unlabeled weak / strong pairs]) in any whole
+        number of IMS_PER_GPU-sized micro-batches per part -- e.g. the shipped IMS_PER_BATCH 48 / IMS_PER_GPU 2 on 8 GPUs = three
+        source and three distillation micro-steps (reference configs/Base-RCNN-FPN.yaml:15-16, aldi/trainer.py:51-52) -- as long as
+        the whole iteration fits one student pass (16 images: the staging kernels' limit)"""
         lw, ls, uw, us = data
-        if not self.fused or lw is not None or ls is None or len(ls) != self.model_batch_size or hasattr(self.model, "module"):
+        bs = self.model_batch_size
+        if not self.fused or lw is not None or ls is None or len(ls) == 0 or len(ls) % bs or hasattr(self.model, "module"):
             return False
-        if self.distiller.distill_enabled():
+        do_align, do_distill = _schedule_flags(self)
+        total = len(ls)
+        if do_distill:
             from .distill import ALDIDistiller
             if not isinstance(self.distiller, ALDIDistiller) or uw is None or us is None:
                 return False
-            if len(uw) != self.model_batch_size or len(us) != self.model_batch_size:
+            if len(uw) != len(us) or len(us) == 0 or len(us) % bs:
                 return False
+            total += len(us)
+        if do_align:
+            if uw is None or len(uw) == 0 or len(uw) % bs:
+                return False
+            total += len(uw)
+        if total > 16:
+            return False
+        if os.environ.get("ALDI_FUSED_LEGACY", "0") == "1" and (len(ls) != bs or (do_distill and len(us) != bs)):
+            return False                                     # (the older single-chunk driver, kept for A/B runs)
         return True
 
     def _defers_zero_grad(self) -> bool:

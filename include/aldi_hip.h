@@ -371,10 +371,12 @@ int aldi_torch_rng_script(unsigned char* state, const long* script, int nops, in
  * ~430 state refills per 268k-entry list.  Streams that do not match the script's engine state / seeds are ignored. */
 /* The host phase of one fused iteration in one call: device list lengths (counts: [N][2] RPN positives / negatives, then [N][2]
  * ROI) -> sampling positions, their counts, ROI row offsets and the distillation normalisers in the pinned upload buffer `words`
- * (int32 word offsets word0[8] = rsel, rnsel, osel, onsel, row_off, dsel, dnsel, nvf), in the reference's draw order
- * (aldi/distill.py:148-162,200-202; aldi/helpers.py:17-26).  chunks: nch rows {kind (1 = distillation), n0, n1}; seed_old / seed_new:
- * the ManualSeed hook's seed before / after this iteration's reset_seed.  rows_out [N]: sampled ROI rows per image. */
-int aldi_step_draws(unsigned char* state, const int* counts, int N, const int* chunks, int nch, long seed_old, long seed_new,
+ * (int32 word offsets word0[8] = rsel, rnsel, osel, onsel, row_off, dsel, dnsel, nvf), in the reference's draw order, micro-step by
+ * micro-step (aldi/trainer.py:51-52,86-89; aldi/distill.py:148-162,200-202; aldi/helpers.py:17-26).  chunks: nch rows {kind (1 =
+ * distillation), n0, n1}, any number of distillation chunks; seeds[nseeds]: the ManualSeed hook's seed before the iteration, then
+ * after each distillation chunk's reset_seed; dsel / dnsel rows and the nvf pairs follow the distillation chunks in order.
+ * rows_out [N]: sampled ROI rows per image. */
+int aldi_step_draws(unsigned char* state, const int* counts, int N, const int* chunks, int nch, const long* seeds, int nseeds,
                     int rpn_batch, int rpn_pos_cap, int roi_batch, int roi_pos_cap, int* words, const int* word0, int* rows_out, int threads);
 int aldi_torch_rng_prefetch(const unsigned char* state, const long* seeds, int nseeds, long max_draws);
 int aldi_torch_rng_prefetch_hits(void);       /* script segments served from a pre-generated stream so far */

@@ -691,3 +691,48 @@ def test_engine_reads_detectron2_keys_from_cfg():
     bad.merge_from_list(["MODEL.ANCHOR_GENERATOR.ASPECT_RATIOS", [[0.5, 1.0]]])
     with pytest.raises(ValueError):
         build_aldi(bad)
+
+
+@pytest.mark.parametrize("ims,align", [(12, False), (8, True)])
+def test_fused_step_with_several_micro_batches_equals_sequential(ims, align):
+    """the reference's shipped batch shape is several IMS_PER_GPU-sized micro-steps per part and iteration (IMS_PER_BATCH 48,
+    IMS_PER_GPU 2 on 8 GPUs = three source + three distillation micro-steps, configs/Base-RCNN-FPN.yaml:15-16, aldi/trainer.py:51-52).
+    The fused driver runs them as ONE student pass (here 12 images) with per-micro-step normalisers, draws and seeder resets:
+    same loss dict, same host RNG consumption (torch and Python's `random`), same gradients as the sequential driver -- eagerly
+    and replayed from the two captured graphs."""
+    from aldi_amd.trainer import ALDITrainer
+    out = []
+    for fused, graph in ((False, False), (True, False), (True, True)):
+        cfg = _cfg(align)
+        cfg.merge_from_list(["SOLVER.IMS_PER_BATCH", ims])
+        cfg.SOLVER.FUSED_STEP = fused
+        cfg.SOLVER.STEP_GRAPH = graph
+        random.seed(0)
+        torch.manual_seed(11)
+        tr = ALDITrainer(cfg)
+        t = tr._trainer
+        its = 6 if graph else 1                     # (three eager warm-up steps, the capture, two replays)
+        for it in range(its):
+            tr.iter = it
+            tr.before_step()
+            if it == its - 1:
+                data = next(t._data_loader_iter)
+                assert len(data[1]) == ims // 2 and (data[3] is None or len(data[3]) == ims // 2)
+                t.optimizer.zero_grad()
+                ld = t.run_model(data)
+                torch.cuda.synchronize()
+                assert t._fused_done == fused
+                rec = ({k: float(v) for k, v in ld.items()}, tr.model.weights.grad.clone(), torch.get_rng_state(), random.getstate())
+            else:
+                tr.run_step()
+                tr.after_step()
+        if graph:
+            assert t._fused_step.stats["replays_b"] >= 1 and t._fused_step.stats["replays_a"] >= 1
+        else:
+            out.append(rec)
+    (l0, g0, r0, p0), (l1, g1, r1, p1) = out
+    assert list(l0.keys()) == list(l1.keys())
+    for k in l0:
+        assert abs(l0[k] - l1[k]) < 2e-5 * max(1.0, abs(l0[k])), (k, l0[k], l1[k])
+    assert torch.equal(r0, r1) and p0 == p1                      # identical host RNG consumption
+    assert (g0 - g1).abs().max() < 2e-4 * g0.abs().max()

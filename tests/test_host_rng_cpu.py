@@ -136,23 +136,28 @@ def test_rng_script_from_prefetched_streams(case):
     assert served == {"all": 4, "mid_block": 4, "short": 0, "wrong_seed": 1, "no_draws": 3}[case]
 
 
-@pytest.mark.parametrize("distill", [True, False])
-def test_step_draws_equals_the_reference_sequence(distill):
+@pytest.mark.parametrize("layout", ["source_only", "one_each", "three_each"])
+def test_step_draws_equals_the_reference_sequence(layout):
     """aldi_step_draws (the fused step's host phase as one native call) == the reference's sequence of torch.manual_seed /
-    torch.randperm calls: sampled positions, counts, ROI row offsets, normalisers, generator state"""
+    torch.randperm calls, micro-step by micro-step (aldi/trainer.py:51-52,86-89 with IMS_PER_GPU-sized chunks):
+    sampled positions, counts, ROI row offsets, normalisers, generator state.  "three_each" = the reference's shipped shape on
+    8 GPUs (IMS_PER_BATCH 48, IMS_PER_GPU 2: three source and three distillation micro-steps per iteration)."""
     import ctypes as C
     from aldi_amd import _lib as L
-    N = 4 if distill else 2
+    chunks = {"source_only": [(0, 0, 2)], "one_each": [(0, 0, 2), (1, 2, 4)],
+              "three_each": [(0, 0, 2), (0, 2, 4), (0, 4, 6), (1, 6, 8), (1, 8, 10), (1, 10, 12)]}[layout]
+    N = chunks[-1][2]
     RB, RP, OB, OP = 256, 128, 512, 128
     gen = torch.Generator().manual_seed(11)
     rpn = [[int(torch.randint(0, 300, (1,), generator=gen)), int(torch.randint(100, 250000, (1,), generator=gen))] for _ in range(N)]
     roi = [[int(torch.randint(0, 200, (1,), generator=gen)), int(torch.randint(0, 2100, (1,), generator=gen))] for _ in range(N)]
     rpn[0][0] = 0                                                           # an image without positives
-    chunks = [(0, 0, 2), (1, 2, 4)] if distill else [(0, 0, 2)]
-    old, new = 1234567, 4000000001
-    nd = 2 if distill else 1
+    nk = sum(1 for c in chunks if c[0] == 1)
+    seeds = [1234567, 4000000001, 17, 3999999999][: nk + 1]
+    nd = max(sum(c[2] - c[1] for c in chunks if c[0] == 1), 1)
     # word layout of the upload buffer
-    names = [("rsel", N * 2 * RB), ("rnsel", N * 2), ("osel", N * 2 * OB), ("onsel", N * 2), ("row_off", N), ("dsel", nd * 2 * RB), ("dnsel", nd * 2), ("nvf", 2)]
+    names = [("rsel", N * 2 * RB), ("rnsel", N * 2), ("osel", N * 2 * OB), ("onsel", N * 2), ("row_off", N), ("dsel", nd * 2 * RB), ("dnsel", nd * 2),
+             ("nvf", 2 * max(nk, 1))]
     w0, off = {}, 0
     for k, n in names:
         w0[k] = off
@@ -176,33 +181,35 @@ def test_step_draws_equals_the_reference_sequence(distill):
                 ref[w0[ndst] + 2 * (row0 + i)], ref[w0[ndst] + 2 * (row0 + i) + 1] = num_pos, num_neg
             sums.append((num_pos, num_neg))
         return sums
-    rows, seed = [], old
+    rows, k, d0 = [], 0, 0
     for kind, n0, n1 in chunks:
         if kind == 1:
-            torch.manual_seed(old)
-            seed = new
-        sample("rsel", "rnsel", n0, rpn[n0:n1], RB, RP)
-        torch.manual_seed(seed)
+            torch.manual_seed(seeds[k])            # the teacher's eval inference fires ManualSeed with the current seed ...
+            k += 1                                 # ... then the distiller resets the seeder (aldi/distill.py:148-150)
+        sample("rsel", "rnsel", n0, rpn[n0:n1], RB, RP)          # student RPN sampling
+        torch.manual_seed(seeds[k])                # ManualSeed on the student's roi_heads
         rows += [a + b for a, b in sample("osel", "onsel", n0, roi[n0:n1], OB, OP)]
+        if kind == 1:
+            torch.manual_seed(seeds[k])            # the teacher's train-mode roi_heads: identical ROI draws (aldi/distill.py:160-162)
+            sample(None, None, 0, roi[n0:n1], OB, OP)
+            dh = sample("dsel", "dnsel", d0, rpn[n0:n1], RB, RP)  # get_rpn_losses' fresh sample (aldi/distill.py:200-202)
+            ref[w0["nvf"] + 2 * (k - 1)], ref[w0["nvf"] + 2 * (k - 1) + 1] = sum(a + b for a, b in dh), sum(a for a, _ in dh)
+            d0 += n1 - n0
     o = 0
     for i, r in enumerate(rows):
         ref[w0["row_off"] + i] = o
         o += r
-    if distill:
-        torch.manual_seed(new)
-        sample(None, None, 0, roi[2:4], OB, OP)
-        dh = sample("dsel", "dnsel", 0, rpn[2:4], RB, RP)
-        ref[w0["nvf"]], ref[w0["nvf"] + 1] = sum(a + b for a, b in dh), sum(a for a, _ in dh)
     ref_state = torch.get_rng_state()
     # ---- the native call
     torch.set_rng_state(start)
     got = torch.full((off,), -7, dtype=torch.int32)
     counts = torch.tensor([v for p in rpn for v in p] + [v for p in roi for v in p], dtype=torch.int32)
     carr = (C.c_int * (3 * len(chunks)))(*[v for c in chunks for v in c])
-    warr = (C.c_int * 8)(*[w0[k] for k, _ in names])
+    warr = (C.c_int * 8)(*[w0[k_] for k_, _ in names])
     rarr = (C.c_int * N)()
+    sarr = (C.c_long * len(seeds))(*seeds)
     st = torch.get_rng_state()
-    L.call("aldi_step_draws", st.data_ptr(), counts.data_ptr(), N, carr, len(chunks), old, new, RB, RP, OB, OP, got.data_ptr(), warr, rarr, 4)
+    L.call("aldi_step_draws", st.data_ptr(), counts.data_ptr(), N, carr, len(chunks), sarr, len(seeds), RB, RP, OB, OP, got.data_ptr(), warr, rarr, 4)
     torch.set_rng_state(st)
     assert list(rarr) == rows
     assert torch.equal(got, ref)
