@@ -225,6 +225,7 @@ def add_aldi_config(cfg: CfgNode):
     # (numerically the sequential schedule; see aldi_amd.trainer.fused_run_model)
     _C.SOLVER.FUSED_STEP = False
     _C.SOLVER.STEP_GRAPH = False          # replay the fused step's two device phases as hipGraphs (aldi_amd/fused_step.py)
+    _C.SOLVER.GRAD_PAYLOAD = "fp32"       # data-parallel gradient exchange: "fp32" (exact) or "bf16" (half the bytes per xGMI link)
 
     _C.MODEL.CONVNEXT = CN()
     _C.MODEL.CONVNEXT.DEPTHS = [3, 3, 9, 3]

@@ -84,6 +84,7 @@ class FusedStep:
         self.teacher_first = os.environ.get("ALDI_TEACHER_FIRST", "0") == "1"
         self.spin_wait = os.environ.get("ALDI_SPIN_WAIT", "1") == "1"
         self.warmup = 3                     # eager steps before capturing (lazy initialisation: anchors, dgrad weights, workspaces)
+        self.dp_graph_ok = True             # cleared if recording phase B together with its collectives ever fails
         self.stats = dict(captures=0, replays_a=0, replays_b=0, eager=0)
 
     # ------------------------------------------------------------------------------------------------ phase 0: inputs
@@ -534,7 +535,7 @@ class FusedStep:
             self.static[key] = self.static.pop(key)
         return S
 
-    def run(self, labeled_weak, labeled_strong, unlabeled_weak, unlabeled_strong, ema=None, zero_grad=False):
+    def run(self, labeled_weak, labeled_strong, unlabeled_weak, unlabeled_strong, ema=None, zero_grad=False, reducer=None):
         from .model import DevicePseudoLabels
         from .trainer import _schedule_flags, _teacher_stream, plan_micro_steps
         tr = self.tr
@@ -658,16 +659,43 @@ class FusedStep:
         from . import _lib as L_
         self.stats["rng_stream_hits"] = int(L_.lib.aldi_torch_rng_prefetch_hits())
         # ---- phase B
-        graph_b = use_graph and getattr(eng, "grad_ready", None) is None and os.environ.get("ALDI_STEP_GRAPH_B", "1") == "1"
+        # Under data parallelism the backward launches the gradient exchange (reduce.BucketedReducer: collectives on a launch stream
+        # behind the producers' events).  With RCCL those launches are stream-ordered kernels, so the whole of phase B -- backward,
+        # collectives, their join -- is recorded and replayed like the single-GPU one; a host-driven backend (gloo) keeps phase B eager.
+        dp = getattr(eng, "grad_ready", None) is not None
+        dp_graph = dp and reducer is not None and self.dp_graph_ok and reducer.capturable()
+        graph_b = use_graph and (not dp or dp_graph) and os.environ.get("ALDI_STEP_GRAPH_B", "1") == "1"
         evs[2].record()
+        ent = None
         if graph_b:
             ent = S.graphs_b.get(Hst.key)
             if ent is None:
                 if len(S.graphs_b) >= 4:
                     S.graphs_b.pop(next(iter(S.graphs_b)))
-                ent = self._capture(lambda: self._phase_b(S, A, Hst))
-                S.graphs_b[Hst.key] = ent
+
+                def phase_b_recorded():
+                    out = self._phase_b(S, A, Hst)
+                    if dp_graph:
+                        reducer.finish()                       # inside the recording: launch stream and collectives join the main stream
+                    return out
+                try:
+                    ent = self._capture(phase_b_recorded)
+                    S.graphs_b[Hst.key] = ent
+                except Exception:
+                    if not dp_graph:
+                        raise
+                    # the collectives of this stack cannot be recorded: say so once, keep phase B eager under DP from here on
+                    import logging
+                    logging.getLogger(__name__).warning("phase B with its collectives could not be captured; data-parallel phase B stays eager", exc_info=True)
+                    self.dp_graph_ok = False
+                    torch.cuda.synchronize()
+                    reducer.__init__(reducer.grad, reducer.group, reducer.payload)
+                    ent = None
+        if ent is not None:
             ent[0].replay()
+            if dp_graph:
+                reducer.finished = True                        # the replayed graph contains the whole exchange
+                self.stats["replays_b_dp"] = self.stats.get("replays_b_dp", 0) + 1
             self.stats["replays_b"] += 1
             B = ent[1]
             c.update(B.fields)

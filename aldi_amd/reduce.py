@@ -44,12 +44,19 @@ class BucketedReducer:
 
     _LAUNCH_STREAMS = {}
 
-    def __init__(self, grad: torch.Tensor, group=None):
-        self.grad, self.group = grad, group
+    def __init__(self, grad: torch.Tensor, group=None, payload: str = "fp32"):
+        """payload "bf16": a piece travels as bf16 (half the bytes per xGMI link: the ring all-reduce over 8 GPUs is per-link
+        bound, SURVEY 5.8) -- rounded once before the exchange, summed by the collective, written back into the fp32 buffer;
+        the reference's DDP exchanges what autocast produced, i.e. fp32 master gradients: "fp32" (default) is the exact form."""
+        if payload not in ("fp32", "bf16"):
+            raise ValueError("gradient payload must be fp32 or bf16")
+        self.grad, self.group, self.payload = grad, group, payload
         self.done: List[Tuple[int, int]] = []
         self.pending: List[Tuple[int, int]] = []
         self.works = []
+        self.post = []                   # bf16 payload: (lo, hi, buffer) to widen back after the collective
         self.events = []                 # producer events of the pieces not launched yet
+        self.finished = False
         # Collectives are issued from a stream of their own that waits only on the PRODUCERS' events (the weight-gradient
         # side stream and the point of the main stream where the group was reported): the main stream never joins the
         # side stream in the middle of the backward, so the dgrad chain and the wgrad kernels keep overlapping under DP.
@@ -60,14 +67,45 @@ class BucketedReducer:
                 BucketedReducer._LAUNCH_STREAMS[key] = torch.cuda.Stream(device=grad.device)
             self.launch_stream = BucketedReducer._LAUNCH_STREAMS[key]
 
+    def capturable(self) -> bool:
+        """True when the collectives may be recorded into the fused step's phase-B hipGraph: RCCL (backend "nccl") launches are
+        stream-ordered kernels; gloo's are host calls.  ALDI_DP_GRAPH=0 keeps phase B eager under data parallelism."""
+        import os
+        if os.environ.get("ALDI_DP_GRAPH", "1") != "1" or not self.grad.is_cuda:
+            return False
+        return self._stream_ordered()
+
+    def _exchange(self, lo: int, hi: int):
+        piece = self.grad[lo:hi]
+        if self.payload == "bf16":
+            buf = piece.to(torch.bfloat16)
+            self.post.append((lo, hi, buf))
+            piece = buf
+        # RCCL: the plain (async_op = False) call is already asynchronous for the host -- it orders itself on the stream it is issued
+        # from (here the launch stream) -- and it is the form a hipGraph can record: an async work handle's wait() inside a capture
+        # segfaults in capture_end on this stack (torch 2.10 + RCCL 2.26.6; tools/probes/rccl_capture_probe.py).  gloo's plain call
+        # would block the host until the exchange is done, so it keeps the work handle.
+        if self._stream_ordered():
+            dist.all_reduce(piece, op=dist.ReduceOp.SUM, group=self.group)
+            return None
+        return dist.all_reduce(piece, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+
+    def _stream_ordered(self) -> bool:
+        if not hasattr(self, "_nccl"):
+            try:
+                self._nccl = self.grad.is_cuda and dist.get_backend(self.group) == "nccl"
+            except Exception:
+                self._nccl = False
+        return self._nccl
+
     def _launch(self, lo: int, hi: int):
         if self.launch_stream is not None:
             for ev in self.events:
                 self.launch_stream.wait_event(ev)
             with torch.cuda.stream(self.launch_stream):
-                w = dist.all_reduce(self.grad[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+                w = self._exchange(lo, hi)
         else:
-            w = dist.all_reduce(self.grad[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            w = self._exchange(lo, hi)
         self.works.append(w)
         self.done.append((lo, hi))
 
@@ -92,15 +130,34 @@ class BucketedReducer:
         self.pending = keep
 
     def finish(self):
-        """reduce everything not reduced yet, then make the current stream wait for every collective."""
+        """reduce everything not reduced yet, then make the current stream wait for every collective (idempotent: the fused step
+        calls it at the end of a captured phase B, the trainer's `after_backward` again afterwards)."""
+        if self.finished:
+            return
         if self.launch_stream is not None:
             ev = torch.cuda.Event()
             ev.record()                                  # everything the step has enqueued on the current stream
             self.events.append(ev)
         for lo, hi in complement(self.done, self.grad.numel()):
             self._launch(lo, hi)
+        ctx = torch.cuda.stream(self.launch_stream) if self.launch_stream is not None else _Null()
         for w in self.works:
-            w.wait()
+            if w is not None:
+                with ctx:
+                    w.wait()                             # (the collective's own stream -> the launch stream)
+        if self.post:
+            with ctx:
+                for lo, hi, buf in self.post:
+                    self.grad[lo:hi].copy_(buf)          # bf16 -> fp32, behind the collectives on the launch stream
         if self.launch_stream is not None:
             torch.cuda.current_stream().wait_stream(self.launch_stream)
-        self.done, self.pending, self.works, self.events = [], [], [], []
+        self.done, self.pending, self.works, self.events, self.post = [], [], [], [], []
+        self.finished = True
+
+
+class _Null:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        return False

@@ -96,6 +96,14 @@ def run_model_labeled_unlabeled(trainer, labeled_weak, labeled_strong, unlabeled
     return metrics
 
 
+def _data_parallel() -> bool:
+    """more than one rank -- or ALDI_DP_FORCE=1 with an initialised process group of any size: the data-parallel code path (bucketed
+    exchange, its stream plumbing, the captured collectives) on a single GPU, which is how the RCCL path is exercised on a 1-GPU box"""
+    if not (dist.is_available() and dist.is_initialized()):
+        return False
+    return dist.get_world_size() > 1 or os.environ.get("ALDI_DP_FORCE", "0") == "1"
+
+
 _TEACHER_STREAMS = {}
 
 
@@ -392,7 +400,7 @@ class SimpleTrainer:
     def after_backward(self):
         """One all-reduce of the student gradients per step (the reference's DDP reduces on every
         micro-step backward, aldi/dropin.py:53; the sum is linear so one reduction at the end is equivalent)."""
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        if _data_parallel():
             red = getattr(self, "_reducer", None)
             if red is not None:                  # fused step: most of the exchange already ran under the backward
                 red.finish()
@@ -475,17 +483,18 @@ class _ALDITrainer:
                 else:
                     self.optimizer.zero_grad()
             eng = self.model.engine
-            if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            reducer = None
+            if _data_parallel():
                 from .reduce import BucketedReducer
-                self._reducer = BucketedReducer(self.model.weights.grad)
-                eng.grad_ready = self._reducer.ready
+                reducer = self._reducer = BucketedReducer(self.model.weights.grad, payload=str(self.model.cfg.SOLVER.get("GRAD_PAYLOAD", "fp32")))
+                eng.grad_ready = reducer.ready
             try:
                 if os.environ.get("ALDI_FUSED_LEGACY", "0") == "1":
                     return fused_run_model(self, *data)
                 if getattr(self, "_fused_step", None) is None:
                     from .fused_step import FusedStep
                     self._fused_step = FusedStep(self)
-                return self._fused_step.run(*data, ema=pending_ema, zero_grad=defer)
+                return self._fused_step.run(*data, ema=pending_ema, zero_grad=defer, reducer=reducer)
             finally:
                 eng.grad_ready = None
         return run_model_labeled_unlabeled(self, *data)

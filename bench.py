@@ -415,7 +415,7 @@ def main():
                                   "%d labeled_strong + %d unlabeled (weak+strong) images per GPU" % ({"vitdet_b": 3, "convnext_l": -1}.get(args.workload, 2 if args.align else 1), arch_name, args.width,
                                                                                                    args.height, "on" if args.align else "off", per, per),
                       "global_batch": imgs_per_step, "parallelism": f"dp{world}", "pseudo_label_threshold": cfg.DOMAIN_ADAPT.TEACHER.THRESHOLD,
-                      "pseudo_labels_per_image": pl_count, "schedule": "sequential micro-steps" if args.sequential else "fused source+target student pass" + ("" if args.no_graph or world > 1 else ", two hipGraph replays per step"), "weights": f"random-init {arch_name} (synthetic)", "error_flag": err, "init_steps": init_steps,
+                      "pseudo_labels_per_image": pl_count, "schedule": "sequential micro-steps" if args.sequential else "fused source+target student pass" + ("" if args.no_graph else ", two hipGraph replays per step" + (" (RCCL collectives inside the second)" if world > 1 else "")), "weights": f"random-init {arch_name} (synthetic)", "error_flag": err, "init_steps": init_steps,
                       "step_graphs": dict(getattr(getattr(tr._trainer, "_fused_step", None), "stats", {}))},
            "final_losses": {k: round(v, 5) for k, v in losses.items()}}
     if rank == 0 and world == 1 and not args.no_profile:

@@ -71,7 +71,15 @@ def _worker_bucketed(rank, world, port, q):
     red.ready([(100, 200)])
     red.ready([(500_000, 1_200_000), (1_100_000, 1_500_000), (200, 300_000)])
     red.finish()
-    q.put((rank, bool(torch.equal(grad, ref)), float((grad - ref).abs().max())))
+    red.finish()                                                       # idempotent (fused step + after_backward both call it)
+    exact = bool(torch.equal(grad, ref))
+    # bf16 payload (SOLVER.GRAD_PAYLOAD): every piece is rounded to bf16 once, summed, written back into the fp32 buffer
+    grad2 = torch.randn(n, generator=torch.Generator().manual_seed(7 + rank))
+    red2 = BucketedReducer(grad2, payload="bf16")
+    red2.ready([(2_000_000, 2_900_000)])
+    red2.finish()
+    rel = float((grad2 - ref).abs().max() / ref.abs().max())
+    q.put((rank, exact and 0 < rel < 2e-2, float((grad - ref).abs().max()) + rel))
     dist.destroy_process_group()
 
 
