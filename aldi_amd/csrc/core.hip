@@ -16,6 +16,14 @@ int aldi_set_error_msg(int code, const char* msg) {
 extern "C" const char* aldi_last_error(void) { return g_err; }
 extern "C" int aldi_version(void) { return 1; }
 
+// an empty one-workgroup launch: what timing harnesses calibrate the cost of a launch / an event pair with
+namespace { __global__ void noop_kernel() {} }
+extern "C" int aldi_noop(aldi_stream_t stream) {
+    hipLaunchKernelGGL(noop_kernel, dim3(1), dim3(64), 0, static_cast<hipStream_t>(stream));
+    ALDI_CHECK_LAUNCH();
+    return ALDI_OK;
+}
+
 // ---- tuning knobs (include/aldi_hip.h: aldi_set_tuning) -------------------------------------------------------------
 // One table; the defaults can be overridden once from the environment (ALDI_<UPPER-CASE NAME>) and at any time through
 // the C ABI, so a single test process can select every dispatch arm.

@@ -25,6 +25,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_BF16_TFLOPS = 2500.0      # dense MFMA bf16 peak, MI355X_MICROARCH.md
+PEAK_HBM_GBS = 8000.0          # HBM3E peak (spec), same guide; ~6300 GB/s is what a streaming copy achieves
 # algorithmic conv/FC work of one cfg-2 step per GPU with the teacher trunk computed once (SURVEY.md 8d / BASELINE.md 4)
 STEP_TFLOP_FUSED = 5.49
 # ... minus the RPN head's backward, which the sparse form (csrc/rpn_sparse.hip) no longer executes as dense convolutions:
@@ -249,17 +250,72 @@ def profile_insitu(step_fn, table_path=None):
         fl = sum(2.0 * g.numel() * kw["KH"] * kw["KW"] * x.shape[3] for x, g, dw, kw in problems)
         nby = sum(x.element_size() * (x.numel() + g.numel()) + 8 * dw.numel() for x, g, dw, kw in problems)
         rec.append((("wgrad", "group of %d" % len(problems)) + tuple(sorted({tuple(x.shape) for x, _, _, _ in problems}))[:3], fl, nby, e0, e1))
+    # ... the fused res2 bottleneck (MFMA work, HBM-bound) and the streaming kernels whose roofline is the HBM's:
+    # algorithmic bytes = every operand read once and every result written once
+    orig_bn, orig_sgd, orig_ema, orig_ra, orig_rab = ops.bottleneck_fused, ops.sgd_step, ops.ema_update, ops.roialign, ops.roialign_backward
+
+    def timed(fam, key, fl, nby, fn, *a, **kw):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        r = fn(*a, **kw)
+        e1.record()
+        rec.append(((fam,) + key, fl, nby, e0, e1))
+        return r
+
+    def bottleneck_fused(x, res, w1, w2, w3, *a, **kw):
+        N, H, W_, Cin = x.shape
+        mid, Cout = w1.shape[0], w3.shape[0]
+        px = N * H * W_
+        nby = 2 * (x.numel() + (0 if res.data_ptr() == x.data_ptr() else res.numel()) + px * Cout + w1.numel() + w2.numel() + w3.numel())
+        return timed("bneck", (N, H, W_, Cin, mid, Cout), 2.0 * px * (Cin * mid + 9 * mid * mid + mid * Cout), nby, orig_bn, x, res, w1, w2, w3, *a, **kw)
+
+    def sgd_step(p_, g, buf, p_compute, n, *a, **kw):     # reads master, gradient, momentum; writes master, momentum, the bf16 compute copy
+        return timed("sgd", (n,), 0.0, n * (20 + (2 if p_compute is not None else 0)), orig_sgd, p_, g, buf, p_compute, n, *a, **kw)
+
+    def ema_update(teacher, student, teacher_compute, n, *a, **kw):   # reads teacher + student state, writes the teacher's (+ its bf16 weights)
+        nc = kw.get("n_compute") or (teacher_compute.numel() if teacher_compute is not None else 0)
+        return timed("ema", (n,), 0.0, n * 12 + 2 * nc, orig_ema, teacher, student, teacher_compute, n, *a, **kw)
+
+    def roialign(feats, rois, R, P, pooled, backward):
+        return timed("roialign_fwd", (R,), 0.0, pooled.numel() * pooled.element_size(), orig_ra, feats, rois, R, P, pooled, backward)
+
+    def roialign_backward(feats, rois, R, P, g_pooled, N, **kw):
+        return timed("roialign_bwd", (R,), 0.0, g_pooled.numel() * g_pooled.element_size(), orig_rab, feats, rois, R, P, g_pooled, N, **kw)
     ops.conv2d, ops.conv_wgrad, ops.conv_wgrad_group = conv2d, conv_wgrad, conv_wgrad_group
+    ops.bottleneck_fused, ops.sgd_step, ops.ema_update, ops.roialign, ops.roialign_backward = bottleneck_fused, sgd_step, ema_update, roialign, roialign_backward
     try:
         step_fn()
         torch.cuda.synchronize()
     finally:
         ops.conv2d, ops.conv_wgrad, ops.conv_wgrad_group = orig_conv, orig_wg, orig_group
+        ops.bottleneck_fused, ops.sgd_step, ops.ema_update, ops.roialign, ops.roialign_backward = orig_bn, orig_sgd, orig_ema, orig_ra, orig_rab
+    # What an event pair adds to the kernel it brackets (marker latency): with t1 = a pair around ONE launch of a small conv (T + o)
+    # and t2 = a pair around TWO back-to-back launches of it (2 T + g + o), o = 2 t1 - t2 + g, where g is the dependent-kernel
+    # boundary of MI355X_MICROARCH.md's price list (1.45 us).  It is subtracted from every measurement so that a launch's figure is
+    # the kernel's own duration as rocprofv3 --kernel-trace reports it (profiles/r03_kernel_stats_single_stream.txt: the
+    # uncorrected sum over the igemm launches read 7 % above the trace's, 2.7 us per launch).
+    cx = torch.randn(1, 64, 64, 256, device="cuda").to(torch.bfloat16)
+    cw = torch.randn(256, 1, 1, 256, device="cuda").to(torch.bfloat16)
+    cy = torch.empty(1, 64, 64, 256, device="cuda", dtype=torch.bfloat16)
+    t12 = []
+    for reps in (1, 2):
+        pairs = []
+        for _ in range(100):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(reps):
+                orig_conv(cx, cw, out=cy)
+            e1.record()
+            pairs.append((e0, e1))
+        torch.cuda.synchronize()
+        t12.append(sorted(a.elapsed_time(b) * 1e3 for a, b in pairs)[len(pairs) // 2])
+    empty = min(max(2 * t12[0] - t12[1] + 1.45, 0.0), 5.0)
     shapes, out = {}, {}
-    for fam in ("igemm", "wgrad"):
+    for fam in ("igemm", "wgrad", "bneck", "sgd", "ema", "roialign_fwd", "roialign_bwd"):
         out[fam] = {"launches": 0, "flops": 0.0, "ms": 0.0, "bytes": 0}
+    out["event_pair_us"] = round(empty, 2)
     for key, fl, nby, e0, e1 in rec:
-        us = e0.elapsed_time(e1) * 1e3
+        us = max(e0.elapsed_time(e1) * 1e3 - empty, 0.5)
         f = out[key[0]]
         f["launches"] += 1; f["flops"] += fl; f["ms"] += us / 1e3; f["bytes"] += nby
         e = shapes.setdefault(key, {"count": 0, "flops": fl, "us": 0.0})
@@ -428,8 +484,10 @@ def main():
         import aldi_amd.trainer as _T
         engines = [tr.model.engine] + ([tr.ema.model.engine] if getattr(tr, "ema", None) is not None else [])
         saved = [(e, e.__dict__.get("_wg_side", "absent")) for e in engines]
+        saved_aux = [(e, e.__dict__.get("_aux_side", "absent")) for e in engines]
         for e in engines:
             e._wg_side, e._wgrad_pending = None, False
+            e._aux_side = None
         ts_fn, _T._teacher_stream = _T._teacher_stream, (lambda device: None)
         try:
             prof = profile_insitu(one_step, os.path.join(ROOT, "gpurun_out", "dense_profile_insitu.txt"))
@@ -440,6 +498,11 @@ def main():
                     e.__dict__.pop("_wg_side", None)
                 else:
                     e._wg_side = v
+            for e, v in saved_aux:
+                if v == "absent":
+                    e.__dict__.pop("_aux_side", None)
+                else:
+                    e._aux_side = v
         if fs is not None:
             fs.graph_enabled = graph_was
         if args.replay_profile:
@@ -453,9 +516,9 @@ def main():
                            "traffic": _traffic_per_launch(tj, "igemm", ig["launches"]),
                            "traffic_unit": "HBM bytes per igemm launch, rocprofv3 PMC passes of this command (FETCH_SIZE x2 + WRITE_SIZE)",
                            "traffic_source": tfile if tj else "no profiles/r*_pmc_traffic.json matches this source tree (tools/source_hash.py)",
-                           "timing": "HIP events around every dense launch of one extra step issued eagerly on one stream (each kernel alone on the chip, as in the rocprofv3 kernel trace under profiles/)",
+                           "timing": "HIP events around every dense launch of ONE extra step issued eagerly on ONE stream (ALDI_WGRAD_STREAM / TEACHER_STREAM / AUX_STREAM off), i.e. each kernel alone on the chip; the matching rocprofv3 --kernel-trace --stats summary of the same single-stream step is profiles/r03_kernel_stats_single_stream.txt (the multi-stream step's is profiles/r03_kernel_stats.txt: co-resident kernels run longer there)",
                            "algorithmic_bytes_per_launch": round(ig["bytes"] / max(ig["launches"], 1)),
-                           "launches_per_step": ig["launches"], "kernel_ms_per_step": round(ig["ms"], 3),
+                           "launches_per_step": ig["launches"], "kernel_ms_per_step": round(ig["ms"], 3), "event_pair_us_subtracted": prof.get("event_pair_us"),
                            "avg_launch_us": round(ig["ms"] * 1e3 / max(ig["launches"], 1), 2),
                            "algorithmic_tflop_per_step_in_kernel": round(ig["flops"] / 1e12, 3),
                            "wgrad_kernel": {"achieved": round(wg["flops"] / max(wg["ms"], 1e-9) / 1e9, 2), "unit": "TFLOP/s",
@@ -464,6 +527,19 @@ def main():
                                             "avg_launch_us": round(wg["ms"] * 1e3 / max(wg["launches"], 1), 2),
                                             "algorithmic_bytes_per_launch": round(wg["bytes"] / max(wg["launches"], 1)),
                                             "traffic": _traffic_per_launch(tj, "wgrad", wg["launches"])},
+                           "bottleneck_kernel": None if not prof["bneck"]["launches"] else {
+                               "kernel": "bneck_kernel (one launch per res2 bottleneck: 1x1 -> 3x3 -> 1x1 + residual, intermediates in LDS)",
+                               "achieved": round(prof["bneck"]["flops"] / prof["bneck"]["ms"] / 1e9, 2), "unit": "TFLOP/s",
+                               "hbm_achieved": round(prof["bneck"]["bytes"] / prof["bneck"]["ms"] / 1e6, 1), "hbm_unit": "GB/s", "hbm_peak": PEAK_HBM_GBS,
+                               "hbm_frac": round(prof["bneck"]["bytes"] / prof["bneck"]["ms"] / 1e6 / PEAK_HBM_GBS, 4), "bound": "hbm",
+                               "kernel_ms_per_step": round(prof["bneck"]["ms"], 3), "launches_per_step": prof["bneck"]["launches"],
+                               "algorithmic_bytes_per_launch": round(prof["bneck"]["bytes"] / prof["bneck"]["launches"])},
+                           "hbm_kernels": {fam: {"achieved": round(prof[fam]["bytes"] / prof[fam]["ms"] / 1e6, 1), "unit": "GB/s", "peak": PEAK_HBM_GBS,
+                                                 "frac": round(prof[fam]["bytes"] / prof[fam]["ms"] / 1e6 / PEAK_HBM_GBS, 4),
+                                                 "us_per_step": round(prof[fam]["ms"] * 1e3, 1), "launches_per_step": prof[fam]["launches"],
+                                                 "algorithmic_bytes_per_step": prof[fam]["bytes"]}
+                                           for fam in ("sgd", "ema", "roialign_fwd", "roialign_bwd") if prof[fam]["launches"] and prof[fam]["ms"] > 0},
+                           "hbm_kernels_note": "sgd / ema: every state word read and written once; roialign_*: the pooled tensor's bytes only (the gather side is data dependent), so a lower bound of their traffic",
                            "step_algorithmic_tflop": step_tflop if not args.align else None,
                            "step_frac_of_mfma_peak": round(step_tflop / (ms * 1e-3) / PEAK_BF16_TFLOPS, 4) if not args.align else None}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

@@ -29,6 +29,8 @@ enum { ALDI_OK = 0, ALDI_ERR_HIP = -1, ALDI_ERR_ARG = -2 };
 
 const char* aldi_last_error(void);
 int aldi_version(void);
+/* an empty launch (one workgroup that returns): calibration of timing harnesses (bench.py subtracts what an event pair around it reads) */
+int aldi_noop(aldi_stream_t stream);
 
 /* Tuning knobs of the kernel dispatchers (test / experiment surface; the defaults are what the benchmark runs).
  * Each knob can also be preset from the environment as ALDI_<UPPER-CASE NAME>, read once at first use.

@@ -202,3 +202,65 @@ def test_benchmark_step_bf16_vs_fp32_parity_mode():
         # the ROI samples differ (proposals are discontinuous in the scores), so this is a statistical agreement, not a rounding bound
         print("grad cosine bf16 vs fp32:", gname, round(cos, 4))
         assert cos > 0.5, (gname, cos)
+
+
+def test_cfg2_fullsize_alignment_bf16_properties():
+    """BASELINE configs[2]'s per-GPU workload at full size: ALDI++ with image- and instance-level alignment on, 1333x800, 2 labeled +
+    2 unlabeled images, benchmark dtype, fused + graph-replayed schedule (three eager steps, the capture, replays).  Size-independent
+    properties: loss-dict keys of all three rows incl. the discriminator losses (reference aldi/trainer.py:99-111: target_weak keeps
+    only "_da_" keys; aldi/align.py:84-100), per-micro-step normalisers, the gradient reaches both discriminators and -- reversed --
+    the trunk, the teacher stays an EMA of the student, frozen layers do not move."""
+    from aldi_amd import synthetic as syn
+    from aldi_amd.config import add_aldi_config, get_cfg
+    from aldi_amd.trainer import ALDITrainer
+    cfg = get_cfg()
+    add_aldi_config(cfg)
+    cfg.merge_from_file(os.path.join(ROOT, "configs", "cityscapes", "ALDI-Best-Cityscapes.yaml"))
+    cfg.merge_from_list(["SOLVER.IMS_PER_BATCH", 4, "SEED", 1, "SYNTHETIC.HEIGHT", 800, "SYNTHETIC.WIDTH", 1333, "SOLVER.BASE_LR", 1e-4,
+                         "SOLVER.AMP.ENABLED", True, "DOMAIN_ADAPT.ALIGN.IMG_DA_ENABLED", True, "DOMAIN_ADAPT.ALIGN.INS_DA_ENABLED", True])
+    cfg.SOLVER.FUSED_STEP = True
+    cfg.SOLVER.STEP_GRAPH = True
+    random.seed(1234)
+    torch.manual_seed(100)
+    tr = ALDITrainer(cfg)
+    t = tr._trainer
+    w0 = tr.model.weights.master.clone()
+    for it in range(6):
+        tr.iter = it
+        tr.before_step()
+        tr.run_step()
+        tr.after_step()
+        assert t._fused_done
+    torch.cuda.synchronize()
+    st = t._fused_step.stats
+    assert st["replays_a"] >= 2 and st["replays_b"] >= 2, st
+    ld = {k: float(v) for k, v in t.last_loss_dict.items()}
+    src = [f"{k}_source_strong" for k in ("loss_cls", "loss_box_reg", "loss_rpn_cls", "loss_rpn_loc", "loss_da_img", "loss_da_ins")]
+    tgt = ["loss_da_img_target_weak", "loss_da_ins_target_weak"]
+    dst = [f"{k}_distill" for k in ("loss_cls", "loss_box_reg", "loss_rpn_cls", "loss_rpn_loc", "_da", "loss_obj_bce", "loss_rpn_l1", "loss_cls_ce", "loss_roih_l1")]
+    assert list(ld) == src + tgt + dst, list(ld)
+    assert all(v == v and 0.0 <= v < 1e3 for v in ld.values()), ld
+    # a discriminator that cannot tell the domains yet: BCE of a near-zero logit = ln 2, times the 0.01 loss weight, over accum = 3
+    for k in ("loss_da_img_source_strong", "loss_da_ins_source_strong", "loss_da_img_target_weak", "loss_da_ins_target_weak"):
+        assert 0.0005 < ld[k] < 0.02, (k, ld[k])
+    assert ld["_da_distill"] == 0.0 and ld["loss_cls_distill"] == 0.0        # masked hard losses are reported as zeros (aldi/distill.py:181-186)
+    c = tr.model._last_fused
+    assert c.N == 6 and [ch["name"] for ch in c.chunks] == ["source_strong", "target_weak", "distill"]
+    assert c.R == 3 * 1024 and list(c.rows) == [512] * 6
+    assert [tuple(p.shape[1:3]) for p in c.P] == [(200, 336), (100, 168), (50, 84), (25, 42), (13, 21)]
+    lay = tr.model.layout
+    g = tr.model.weights.grad
+    for name in [n for n in lay.t if n.startswith(("img_align", "ins_align"))] + ["backbone.fpn_output2", "backbone.bottom_up.res3.0.conv2", "roi_heads.box_head.fc2"]:
+        for lo, hi in lay.ranges([name]):
+            assert torch.isfinite(g[lo:hi]).all() and float(g[lo:hi].abs().max()) > 0, name
+    w1 = tr.model.weights.master
+    assert torch.isfinite(w1).all()
+    assert not torch.equal(w1[: lay.n_train], w0[: lay.n_train]) and torch.equal(w1[lay.n_train:], w0[lay.n_train:])
+    # the teacher (incl. its own, unused discriminators: SURVEY B.9) trails the student: |teacher - initial| < |student - initial|
+    tw = tr.ema.model.weights.master
+    n = lay.n_train
+    ds, dt = (w1[:n] - w0[:n]).norm(), (tw[:n] - w0[:n]).norm()
+    assert 0 < float(dt) < float(ds)
+    assert int(tr.model.engine.err) == 0 and int(tr.ema.model.engine.err) == 0
+    pl = tr.ema.model._last_inference.pseudo["count"].tolist()
+    assert len(pl) == 2 and all(0 <= v <= 100 for v in pl)

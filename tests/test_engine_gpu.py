@@ -189,6 +189,7 @@ def test_full_aldi_iterations_vs_oracle(align):
         orc_idx.append(torch.cat([s_["sampled_idxs"] for s_ in orc.last["student_cap"]["sampled"]]).to(torch.int32))
         return out
     orc.model = omodel_rec
+    prop_diffs, prop_noise = [], []
     try:
         for it in range(2):
             hip_idx.clear()
@@ -240,6 +241,13 @@ def test_full_aldi_iterations_vs_oracle(align):
                 m_ = min(len(a_), len(b_))
                 close = ((a_[:m_] - b_[:m_]).abs().max(1)[0] < 1e-2).float().mean()
                 assert float(close) > 0.9, float(close)
+                # the exact count of proposals that are DIFFERENT boxes in the two lists (rank by rank, >= 0.5 px apart: a flipped
+                # NMS / top-k decision replaces a box or shifts every later rank; fp32 noise of the two trunks moves a decoded
+                # coordinate by up to a few 1e-2 px on boxes hundreds of pixels wide), and the largest coordinate difference among
+                # the boxes that are the same
+                d_ = (a_[:m_] - b_[:m_]).abs().max(1)[0]
+                prop_diffs.append(abs(len(a_) - len(b_)) + int((d_ >= 0.5).sum()))
+                prop_noise.append(float(d_[d_ < 0.5].max()) if bool((d_ < 0.5).any()) else 0.0)
             for k in ref:
                 assert abs(ref[k] - hip[k]) < tol * max(1.0, abs(ref[k])), (it, k, ref[k], hip[k], ndiff)
             own = orc.last["pseudo_own"]
@@ -264,6 +272,15 @@ def test_full_aldi_iterations_vs_oracle(align):
         type(pl).__call__ = orig
         type(tr.model).forward = mfwd
     assert int(tr.model.engine.err) == 0 and int(tr.ema.model.engine.err) == 0
+    # proposals from the oracle's OWN trunk vs the device's: identical lists (count and every box to 1e-2 px) for at least one image
+    # and iteration, i.e. where no NMS / top-k decision sat on an fp32 near-tie
+    print("different proposals per (iteration, image):", prop_diffs, "largest coordinate noise among equal ones [px]:", [round(v, 4) for v in prop_noise])
+    # measured: [6, 6, 0, 0] (align off), [6, 6, 2, 0] (on), [6, 6, 4, 2] ("deep") of ~1000 proposals per image, the equal ones to
+    # 6e-4 px: ONE decision flipped near the post-NMS cut of an image (a score pair within fp32 noise of the two trunks) shows up as
+    # the tail behind it; no image differs by more than 1 %, and where no such pair exists the lists are identical
+    assert len(prop_diffs) == 4 and max(prop_diffs) <= 10 and max(prop_noise) < 5e-3, (prop_diffs, prop_noise)
+    if align != "deep":
+        assert min(prop_diffs) == 0, prop_diffs
 
 
 def test_backward_at_end_equals_early_backward():
