@@ -35,6 +35,7 @@ struct ConvDev {
     int relu, res_mode, out_scale, OH, OW;
     int M, K, xcd, dbg;
     unsigned x_bytes, w_bytes;
+    int ksplit, slabs_per_split;     // split-K (plain 1x1 / linear): blockIdx.z = slice, slabs_per_split K slabs each
 };
 
 // ---- epilogue of a BM x BN tile: lane owns pixel (lane&15), channels (lane>>4)*4 .. +3 of each 16x16 accumulator fragment.
@@ -448,15 +449,19 @@ __device__ __forceinline__ void igemm_body(const ConvDev& p, int bid, const int 
     // __syncthreads() would drain the DMA queue (vmcnt(0)) at every slab (cdna_hip_programming.md section 5).
     static_assert(KC == 4 || !PIPE, "the register-pipelined loop reads one k-step (4 chunks) per slab");
     constexpr int N_DMA = A_IT + (BN * KC) / NT;   // DMA instructions per slab of the wave that issues the fewest
-    const int S = (p.dbg & 8) ? 1 : (p.K + BK - 1) / BK;
-    issue_slab(0, 0);
-    if (S > 1) issue_slab(1, 1);
+    const int S_all = (p.dbg & 8) ? 1 : (p.K + BK - 1) / BK;
+    // split-K: this workgroup's slice of the K slabs (plain 1x1 only: the running channel offset is the slab index)
+    const int s_first = p.ksplit > 1 ? (int)blockIdx.z * p.slabs_per_split : 0;
+    const int S = p.ksplit > 1 ? min(S_all - s_first, p.slabs_per_split) : S_all;
+    ci0 = s_first * BK;
+    issue_slab(s_first, 0);
+    if (S > 1) issue_slab(s_first + 1, 1);
     constexpr unsigned SLAB_BYTES = (BM + BN) * KC * 16;
     const int xrow = wm * (BM / WM) + fr, wrow = wn * (BN / WN) + fr;
     const unsigned x_rd0 = lds_addr(&lds[0][0]) + (unsigned)(xrow * KC + swz<KC>(xrow, fq)) * 16u;
     const unsigned w_rd0 = lds_addr(&lds[0][0]) + (unsigned)((BM + wrow) * KC + swz<KC>(wrow, fq)) * 16u;
     if constexpr (PIPE) {
-    if (S > 2) issue_slab(2, 2);
+    if (S > 2) issue_slab(s_first + 2, 2);
     u32x4_t xf0[TM], wf0[TN], xf1[TM], wf1[TN];
     if (S > 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * N_DMA) : "memory");
     else if (S > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N_DMA) : "memory");
@@ -476,7 +481,7 @@ __device__ __forceinline__ void igemm_body(const ConvDev& p, int bid, const int 
             __builtin_amdgcn_sched_barrier(0);
             frag_read_all<TM, KC * 16>(xn, x_rd0 + (unsigned)rbuf * SLAB_BYTES);
             frag_read_all<TN, KC * 16>(wn_, w_rd0 + (unsigned)rbuf * SLAB_BYTES);
-            if (s + 3 < S) issue_slab(s + 3, ibuf);
+            if (s + 3 < S) issue_slab(s_first + s + 3, ibuf);
         }
 #pragma unroll
         for (int i = 0; i < TM; ++i)
@@ -499,7 +504,7 @@ __device__ __forceinline__ void igemm_body(const ConvDev& p, int bid, const int 
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
-        if (s + 2 < S) issue_slab(s + 2, nbuf);
+        if (s + 2 < S) issue_slab(s_first + s + 2, nbuf);
 #pragma unroll
         for (int h = 0; h < KC / 4; ++h) {            // KC == 8: two MFMA k-steps per 128-byte slab row
             u32x4_t xf[TM], wf[TN];
@@ -520,6 +525,12 @@ __device__ __forceinline__ void igemm_body(const ConvDev& p, int bid, const int 
 
     }
 
+    if (p.ksplit > 1) {                              // this slice's partial tile, raw fp32, into its own slab of the workspace
+        ConvDev q = p;
+        q.y_f32 = p.y_f32 + (long)blockIdx.z * p.M * p.Cout;
+        igemm_epilogue<T, BM, BN, WM, WN, NSTAGE * SLOTS * 16>(q, acc, m0, n0, reinterpret_cast<unsigned char*>(&lds[0][0]));
+        return;
+    }
     igemm_epilogue<T, BM, BN, WM, WN, NSTAGE * SLOTS * 16>(p, acc, m0, n0, reinterpret_cast<unsigned char*>(&lds[0][0]));
 }
 
@@ -784,12 +795,12 @@ int launch(const ConvDev& d, hipStream_t st) {
         aldi_note_dispatch(name);
         return ALDI_OK;
     }
-    dim3 grid(cdiv(d.M, BM), cdiv(d.Cout, BN));
+    dim3 grid(cdiv(d.M, BM), cdiv(d.Cout, BN), d.ksplit > 1 ? d.ksplit : 1);
     hipLaunchKernelGGL((igemm_kernel<T, BM, BN, WM, WN, KC, PIPE, HALO>), grid, dim3(WM * WN * 64), 0, st, d);
     ALDI_CHECK_LAUNCH();
-    char name[96];
-    snprintf(name, sizeof(name), "igemm<%s,%d,%d,%d,%d,%s,%s%s>", sizeof(T) == 2 ? "bf16" : "f32", BM, BN, WM, WN, PIPE ? "pipe" : "flat", HALO ? "halo" : "tap",
-             KC == 8 ? ",k64" : "");
+    char name[112];
+    snprintf(name, sizeof(name), "igemm<%s,%d,%d,%d,%d,%s,%s%s>%s", sizeof(T) == 2 ? "bf16" : "f32", BM, BN, WM, WN, PIPE ? "pipe" : "flat", HALO ? "halo" : "tap",
+             KC == 8 ? ",k64" : "", d.ksplit > 1 ? " splitk" : "");
     aldi_note_dispatch(name);
     return ALDI_OK;
 }
@@ -887,6 +898,45 @@ int fill_convdev(const aldi_conv_args* a, ConvDev& d) {
     d.x_bytes = (unsigned)xb;
     d.w_bytes = (unsigned)wb;
     d.xcd = 0; d.dbg = 0;
+    d.ksplit = 0; d.slabs_per_split = 0;
+    return ALDI_OK;
+}
+}  // namespace
+
+namespace {
+// y[m][c] = act(scale[c] * sum_z ws[z][m][c] + shift[c]) -> bf16: the slices are added in slice order (deterministic)
+__global__ __launch_bounds__(256) void splitk_finalize_kernel(const float* __restrict__ ws, int ks, long mc, int C, const float* __restrict__ scale,
+                                                              const float* __restrict__ shift, int relu, bf16_t* __restrict__ y) {
+    const long e = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (e >= mc) return;
+    float4 a = *reinterpret_cast<const float4*>(ws + e);
+    for (int z = 1; z < ks; ++z) {
+        const float4 b = *reinterpret_cast<const float4*>(ws + z * mc + e);
+        a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+    }
+    const int c = (int)(e % C);
+    if (scale) { const float4 s4 = *reinterpret_cast<const float4*>(scale + c); a.x *= s4.x; a.y *= s4.y; a.z *= s4.z; a.w *= s4.w; }
+    if (shift) { const float4 s4 = *reinterpret_cast<const float4*>(shift + c); a.x += s4.x; a.y += s4.y; a.z += s4.z; a.w += s4.w; }
+    if (relu) { a.x = fmaxf(a.x, 0.f); a.y = fmaxf(a.y, 0.f); a.z = fmaxf(a.z, 0.f); a.w = fmaxf(a.w, 0.f); }
+    uint2 o;
+    o.x = pack2_bf16(a.x, a.y); o.y = pack2_bf16(a.z, a.w);
+    *reinterpret_cast<uint2*>(y + e) = o;
+}
+
+int conv_splitk(const aldi_conv_args* a, ConvDev& d, hipStream_t st) {
+    const int ks = a->ksplit;
+    if (a->dtype != ALDI_BF16 || a->KH * a->KW != 1 || a->stride != 1 || a->pad != 0 || a->res_mode || a->mask || a->y_f32 || !a->y || !a->ws ||
+        (a->out_scale > 1) || d.K % (64 * ks) != 0 || ks > 64)
+        return aldi_set_error_msg(ALDI_ERR_ARG, "conv_igemm: split-K takes bf16 plain 1x1 / linear layers with K % (64 * ksplit) == 0, a workspace, no res / mask / fp32 output");
+    ConvDev s = d;
+    s.y = nullptr; s.y_f32 = static_cast<float*>(a->ws); s.scale = nullptr; s.shift = nullptr; s.relu = 0;
+    s.ksplit = ks; s.slabs_per_split = d.K / 64 / ks;
+    s.xcd = aldi_tuning().igemm_xcd; s.dbg = aldi_tuning().igemm_dbg;
+    if (int rc = launch<bf16_t, 128, 128, 2, 2, 8, false>(s, st)) return rc;
+    const long mc = (long)d.M * d.Cout;
+    hipLaunchKernelGGL(splitk_finalize_kernel, dim3(cdiv(mc / 4, 256)), dim3(256), 0, st, static_cast<const float*>(a->ws), ks, mc, d.Cout, d.scale, d.shift,
+                       d.relu, static_cast<bf16_t*>(a->y));
+    ALDI_CHECK_LAUNCH();
     return ALDI_OK;
 }
 }  // namespace
@@ -895,6 +945,7 @@ extern "C" int aldi_conv_igemm(const aldi_conv_args* a, aldi_stream_t stream) {
     ConvDev d;
     if (int rc = fill_convdev(a, d)) return rc;
     hipStream_t st = static_cast<hipStream_t>(stream);
+    if (a->ksplit > 1) return conv_splitk(a, d, st);
     if (a->dtype == ALDI_BF16) return dispatch<bf16_t>(d, st);
     return dispatch<float>(d, st);
 }

@@ -6,6 +6,7 @@ libaldi_hip.so on torch's current HIP stream.
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import List, Optional, Sequence
 
 import torch
@@ -57,9 +58,10 @@ def conv2d(x: torch.Tensor, w: torch.Tensor, *, stride: int = 1, pad: int = 0,
            res: Optional[torch.Tensor] = None, res_mode: int = 0, relu: bool = False,
            mask: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None,
            out_f32: Optional[torch.Tensor] = None, want_f32: bool = False,
-           out_scale: int = 1, out_hw=None) -> torch.Tensor:
+           out_scale: int = 1, out_hw=None, ksplit: Optional[int] = None) -> torch.Tensor:
     """x [N,H,W,Cin] (NHWC), w [Cout,KH,KW,Cin] -> y [N,Ho,Wo,Cout] (or the scattered
-    [N,OH,OW,Cout] tensor when out_scale > 1, which must be pre-zeroed by the caller)."""
+    [N,OH,OW,Cout] tensor when out_scale > 1, which must be pre-zeroed by the caller).
+    ksplit: K slices of a long-K linear layer (None: chosen here -- the box head's FC1 is 128 tiles of 128 x 128 over K = 12544)."""
     N, H, W_, Cin = x.shape
     Cout, KH, KW, Cin2 = w.shape
     assert Cin == Cin2 and x.is_contiguous() and w.is_contiguous() and x.dtype == w.dtype, (x.shape, w.shape, x.dtype, w.dtype)
@@ -75,11 +77,30 @@ def conv2d(x: torch.Tensor, w: torch.Tensor, *, stride: int = 1, pad: int = 0,
         out = torch.empty(shape, dtype=x.dtype, device=x.device)
     if want_f32 and out_f32 is None:
         out_f32 = torch.empty(shape, dtype=torch.float32, device=x.device)
+    ws = None
+    if ksplit is None:
+        ksplit = _auto_ksplit(x, N * Ho * Wo, Cout, KH * KW * Cin, KH * KW == 1 and stride == 1 and pad == 0 and res is None and mask is None
+                              and not want_f32 and out_f32 is None and out_scale == 1)
+    if ksplit and ksplit > 1:
+        ws = torch.empty(ksplit * N * Ho * Wo * Cout, dtype=torch.float32, device=x.device)
     a = L.ConvArgs(_p(x), _p(w), _p(out), _p(out_f32), _p(scale), _p(shift), _p(res), _p(mask),
                    N, H, W_, Cin, Cout, KH, KW, stride, pad, Ho, Wo,
-                   int(relu), res_mode, out_scale, OH, OW, dtype_code(x.dtype))
+                   int(relu), res_mode, out_scale, OH, OW, dtype_code(x.dtype), _p(ws), int(ksplit or 0))
     L.call("aldi_conv_igemm", C.byref(a), stream_ptr())
     return out_f32 if want_f32 and out is None else out
+
+
+def _auto_ksplit(x, M, Cout, K, plain: bool) -> int:
+    """four K slices for a bf16 linear layer with a very long K and fewer 128 x 128 output tiles than CUs (ALDI_SPLITK=0: never)"""
+    if not plain or x.dtype != torch.bfloat16 or K < 4096 or K % 256 or os.environ.get("ALDI_SPLITK", "1") != "1":
+        return 0
+    tiles = ((M + 127) // 128) * ((Cout + 127) // 128)
+    if not (16 <= tiles <= 160) or Cout % 4:
+        return 0
+    for ks in (2, 4):                       # as many slices as it takes to give every CU a workgroup (measured on FC1: M = 2048: 111 -> 95 us
+        if tiles * ks >= 256:               # with 2 slices, 100 with 4; M = 1024: 81 -> 52 us with 4)
+            return ks
+    return 4
 
 
 def _conv_args(x, w, *, stride=1, pad=0, scale=None, shift=None, res=None, res_mode=0, relu=False, mask=None, out=None, out_f32=None,

@@ -92,6 +92,12 @@ typedef struct {
                            a stride-s 1x1 conv); res/mask use the same scattered index       */
     int OH, OW;         /* only for out_scale > 1                                          */
     int dtype;          /* ALDI_F32 or ALDI_BF16                                           */
+    /* split-K for long-K linear layers with few output tiles (the box head's FC1: 2048 x 1024 x 12544 is 128 tiles of 128 x 128):
+     * ksplit > 1 runs the K range in `ksplit` slices on ksplit times the workgroups, every slice writing its fp32 partial tile
+     * to ws[slice][M][Cout] with plain stores, and a second launch sums the slices in slice order (deterministic, no atomics),
+     * applies scale / shift / ReLU and writes y.  bf16, plain 1x1 / linear, K % (64 * ksplit) == 0, no res / mask / y_f32. */
+    void* ws;           /* ksplit * M * Cout floats (only read / written when ksplit > 1)   */
+    int ksplit;         /* 0 / 1 = off                                                       */
 } aldi_conv_args;
 
 int aldi_conv_igemm(const aldi_conv_args* a, aldi_stream_t stream);

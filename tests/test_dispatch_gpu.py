@@ -551,3 +551,35 @@ def test_strided_1x1_wgrad_equals_gemm_on_subsampled_input(shape):
     scale = max(1.0, ref.abs().max().item()) * max(1.0, (N * Ho * Wo / 1024) ** 0.5)
     assert (a.double().view_as(ref) - ref).abs().max().item() <= 2e-5 * scale
     assert (b.double().view_as(ref) - ref).abs().max().item() <= 2e-5 * scale
+
+
+@pytest.mark.parametrize("M,Cout,K,ks", [(2048, 1024, 12544, 4), (1000, 1024, 12544, 4), (300, 256, 4096, 2), (2048, 1024, 12544, 7)])
+def test_splitk_linear_equals_plain(M, Cout, K, ks):
+    """split-K for long-K linear layers (the box head's FC1): K slices on ksplit times the workgroups, fp32 partial tiles summed in
+    slice order by a second launch -- against the unsplit kernel and an fp64 evaluation; two runs are bit-identical (no atomics)"""
+    from aldi_amd import _lib as L, ops
+    g = torch.Generator(device="cuda").manual_seed(M + K)
+    x = torch.randn(M, 1, 1, K, device="cuda", generator=g).to(torch.bfloat16)
+    w = (torch.randn(Cout, 1, 1, K, device="cuda", generator=g) / K ** 0.5).to(torch.bfloat16)
+    sc, sh = torch.rand(Cout, device="cuda") + 0.5, torch.randn(Cout, device="cuda")
+    L.reset_tuning()
+    y0 = ops.conv2d(x, w, scale=sc, shift=sh, relu=True, ksplit=0)
+    name0 = L.last_dispatch()
+    if K % (64 * ks):
+        with pytest.raises(L.AldiHipError):
+            ops.conv2d(x, w, scale=sc, shift=sh, relu=True, ksplit=ks)
+        return
+    y1 = ops.conv2d(x, w, scale=sc, shift=sh, relu=True, ksplit=ks)
+    name1 = L.last_dispatch()
+    y2 = ops.conv2d(x, w, scale=sc, shift=sh, relu=True, ksplit=ks)
+    torch.cuda.synchronize()
+    assert "splitk" in name1 and "splitk" not in name0, (name0, name1)
+    assert torch.equal(y1, y2)
+    rows = torch.arange(0, M, max(M // 64, 1), device="cuda")
+    ref = torch.relu((x.view(M, K)[rows].double() @ w.view(Cout, K).double().t()) * sc.double() + sh.double())
+    for y in (y0, y1):
+        assert float((y.view(M, Cout)[rows].double() - ref).abs().max()) <= 2e-2 * float(ref.abs().max())
+    assert float((y0.float() - y1.float()).abs().max()) <= 1e-2 * float(y0.float().abs().max())
+    # the heuristic takes FC1's shape and leaves a short-K layer alone
+    ops.conv2d(x, w, relu=True)
+    assert ("splitk" in L.last_dispatch()) == (K >= 4096 and K % 256 == 0 and 16 <= ((M + 127) // 128) * ((Cout + 127) // 128) <= 160)
