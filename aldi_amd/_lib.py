@@ -108,7 +108,7 @@ class WgradArgs(C.Structure):
     _fields_ = [
         ("x", c_void_p), ("g", c_void_p), ("dw", c_void_p), ("scale", c_void_p),
         ("N", c_int), ("H", c_int), ("W", c_int), ("Cin", c_int), ("Cout", c_int), ("KH", c_int), ("KW", c_int),
-        ("stride", c_int), ("pad", c_int), ("Ho", c_int), ("Wo", c_int), ("dtype", c_int),
+        ("stride", c_int), ("pad", c_int), ("Ho", c_int), ("Wo", c_int), ("dtype", c_int), ("db", c_void_p),
     ]
 
 

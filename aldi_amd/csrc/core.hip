@@ -51,6 +51,7 @@ const Knob kKnobs[] = {
     {"wgrad_dbg", &AldiTuning::wgrad_dbg, 0},
     {"wgrad_group_slots", &AldiTuning::wgrad_group_slots, 0},
     {"wgrad_group_epi", &AldiTuning::wgrad_group_epi, 24},
+    {"wgrad_db", &AldiTuning::wgrad_db, 0},
     {"roialign_sep", &AldiTuning::roialign_sep, 1},
     {"colsum_blocks", &AldiTuning::colsum_blocks, 256},
     {"colsum_minrows", &AldiTuning::colsum_minrows, 16},

@@ -24,7 +24,7 @@
 namespace {
 
 struct WgDev {
-    const void* x; const void* g; float* dw; const float* scale;
+    const void* x; const void* g; float* dw; const float* scale; float* db;
     int N, H, W, Cin, Cout, KH, KW, stride, pad, Ho, Wo;
     int M, K, pix_per_split, ident, xcd, dbg;
     unsigned x_bytes, g_bytes, dw_bytes;
@@ -176,10 +176,10 @@ __global__ __launch_bounds__(256) void wgrad_bf16_kernel(WgDev p) {
 //   * the 8x8 16-bit transposes are v_perm_b32, one per output register.
 // TCO x TKK output tile (channels of g x (tap, channel) of x), 64 pixels per slab; (TCO + TKK) / 64 waves, each loading 64
 // channels of one operand and owning a (TCO / WM) x (TKK / WN) piece of the accumulator.
-template <int TCO, int TKK, int WM, int WN>
+template <int TCO, int TKK, int WM, int WN, bool DB = false>
 __device__ __forceinline__ void wgrad_bf16_lean_tile(const WgDev& p, uint4* lds, int bx, int by, int bz);
 
-template <int TCO, int TKK, int WM, int WN>
+template <int TCO, int TKK, int WM, int WN, bool DB = false>
 __device__ __forceinline__ void wgrad_bf16_lean_body(const WgDev& p, uint4* lds) {
     // XCD-aware order: workgroup b runs on XCD b % 8; give every XCD a contiguous range of (split, tile) pairs, tile
     // fastest, so the tiles of one pixel range (which re-read the same x / g rows) share one L2.
@@ -194,10 +194,12 @@ __device__ __forceinline__ void wgrad_bf16_lean_body(const WgDev& p, uint4* lds)
         bx = bid % gx; bid /= gx;
         by = bid % gy; bz = bid / gy;
     }
-    wgrad_bf16_lean_tile<TCO, TKK, WM, WN>(p, lds, bx, by, bz);
+    wgrad_bf16_lean_tile<TCO, TKK, WM, WN, DB>(p, lds, bx, by, bz);
 }
 
-template <int TCO, int TKK, int WM, int WN>
+// DB: two LDS images (slab s in image s & 1) and ONE barrier per slab: a wave writes slab s + 1 while others still read slab s; the
+// image it overwrites was last read two slabs ago, i.e. before everybody's previous barrier.
+template <int TCO, int TKK, int WM, int WN, bool DB>
 __device__ __forceinline__ void wgrad_bf16_lean_tile(const WgDev& p, uint4* lds, int bx, int by, int bz) {
     static_assert(WM * WN * 64 == TCO + TKK, "one loader wave per 64 channels");
     constexpr int NGW = TCO / 64;                    // g-loader waves
@@ -279,6 +281,14 @@ __device__ __forceinline__ void wgrad_bf16_lean_tile(const WgDev& p, uint4* lds,
     for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    // Bias gradient db[co] = sum over pixels of g[p][co] in the same pass: it is the product of the g tile with a column of ONES,
+    // i.e. TM more MFMAs per k-step whose B fragment is a constant register (no LDS read), in the waves of the first kk tile's first
+    // column only -- instead of a separate column-sum launch that reads g again (13 launches per step).
+    const bool do_bias = p.db != nullptr && by == 0 && wn == 0;
+    f32x4_t accb[TM];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) accb[i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    const uint4 ones4 = make_uint4(0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u);      // eight bf16 1.0
     const int fr = lane & 15, fq = lane >> 4;
     // LDS slots are loop invariant and differ only by immediates / one XOR: fragment rows i*16 apart share the swizzle
     // term ((row>>1)&7 sees only fr), the second k-step flips chunk bit 2; write rows c share pg ^ (cc&1)*4 up to c>>1.
@@ -302,9 +312,10 @@ __device__ __forceinline__ void wgrad_bf16_lean_tile(const WgDev& p, uint4* lds,
                     oo[(2 * d + 1) * 4 + j] = __builtin_amdgcn_perm(b, a, 0x07060302u);   // (a >> 16) | (b & 0xffff0000)
                 }
         }
-        __syncthreads();   // previous slab's fragment reads are done
+        if constexpr (!DB) __syncthreads();   // previous slab's fragment reads are done
+        uint4* img = DB ? lds + ((p0 - pbeg) / BP & 1) * ((TCO + TKK) * 8) : lds;
 #pragma unroll
-        for (int c = 0; c < 8; ++c) lds[iw + c * 8 + (wu ^ (c >> 1))] = out[c];
+        for (int c = 0; c < 8; ++c) img[iw + c * 8 + (wu ^ (c >> 1))] = out[c];
         if (p0 + BP < pend) load_slab();   // next slab's global loads fly under this slab's MFMAs
         __syncthreads();
 #pragma unroll
@@ -312,16 +323,30 @@ __device__ __forceinline__ void wgrad_bf16_lean_tile(const WgDev& p, uint4* lds,
             uint4 af[TM], bfr[TN];
             const int ia = ia0 ^ (ks * 4), ib = ib0 ^ (ks * 4);
 #pragma unroll
-            for (int i = 0; i < TM; ++i) af[i] = lds[ia + i * 128];
+            for (int i = 0; i < TM; ++i) af[i] = img[ia + i * 128];
 #pragma unroll
-            for (int j = 0; j < TN; ++j) bfr[j] = lds[ib + j * 128];
+            for (int j = 0; j < TN; ++j) bfr[j] = img[ib + j * 128];
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<bf16x8_t*>(&af[i]),
                                                                          *reinterpret_cast<bf16x8_t*>(&bfr[j]), acc[i][j], 0, 0, 0);
+            if (do_bias) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+                    accb[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<bf16x8_t*>(&af[i]), *reinterpret_cast<const bf16x8_t*>(&ones4), accb[i], 0, 0, 0);
+            }
         }
+    }
+    if (do_bias && fr == 0) {     // every column of the ones product holds the sum: column 0's lanes add it to the bias gradient
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int co = co0 + wm * (TCO / WM) + i * 16 + fq * 4 + r;
+                if (co < p.Cout) unsafeAtomicAdd(p.db + co, accb[i][r]);
+            }
     }
     if (p.dbg & 1) {     // ablation (wgrad_dbg): no atomics -- every accumulator stays live through one sum
         float t = 0.f;
@@ -388,6 +413,26 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void w
     }
     const int t = local % tiles, bz = local / tiles;
     wgrad_bf16_lean_tile<128, 128, 2, 2>(G.p[i], lds, t % G.gx[i], t / G.gx[i], bz);
+}
+
+// the same with two LDS images and one barrier per slab (64 KB: two workgroups per CU)
+__global__ __launch_bounds__(256) void wgrad_bf16_lean_group_db_kernel(WgGroup G) {
+    __shared__ uint4 lds[2 * 2 * 128 * 8];
+    const int bid = (int)blockIdx.x;
+    int i = 0;
+    for (int k = 1; k < G.n; ++k)
+        if (bid >= G.wg_begin[k]) i = k;
+    i = __builtin_amdgcn_readfirstlane(i);
+    int local = bid - G.wg_begin[i];
+    const int tiles = G.gx[i] * G.gy[i];
+    const int n_local = tiles * G.gz[i];
+    if (local >= n_local) return;
+    if (G.p[i].xcd) {
+        const int q = n_local >> 3, r = n_local & 7, xcd = local & 7, idx = local >> 3;
+        local = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int t = local % tiles, bz = local / tiles;
+    wgrad_bf16_lean_tile<128, 128, 2, 2, true>(G.p[i], lds, t % G.gx[i], t / G.gx[i], bz);
 }
 
 // 256 x 256 tile, 8 waves (128 x 64 each), one workgroup per CU: half the L2 -> CU bytes per FLOP, for layers whose
@@ -727,7 +772,7 @@ int fill_wgdev(const aldi_wgrad_args* a, WgDev& d) {
     if (!a || !a->x || !a->g || !a->dw) return aldi_set_error_msg(ALDI_ERR_ARG, "conv_wgrad: null pointer");
     const int ep = a->dtype == ALDI_BF16 ? 8 : 4;
     if (a->Cin % ep || a->Cout % ep) return aldi_set_error_msg(ALDI_ERR_ARG, "conv_wgrad: Cin/Cout must be multiples of a 16-B chunk");
-    d.x = a->x; d.g = a->g; d.dw = a->dw; d.scale = a->scale;
+    d.x = a->x; d.g = a->g; d.dw = a->dw; d.scale = a->scale; d.db = a->db;
     d.N = a->N; d.H = a->H; d.W = a->W; d.Cin = a->Cin; d.Cout = a->Cout; d.KH = a->KH; d.KW = a->KW;
     d.stride = a->stride; d.pad = a->pad; d.Ho = a->Ho; d.Wo = a->Wo;
     long M = (long)a->N * a->Ho * a->Wo;
@@ -831,11 +876,12 @@ extern "C" int aldi_conv_wgrad_group(const aldi_wgrad_args* args, int n, aldi_st
         wg += (L_.gx[k] * L_.gy[k] * L_.gz[k] + 7) / 8 * 8;
     }
     for (int k = ng; k <= kMaxGroup; ++k) L_.wg_begin[k] = wg;
-    hipLaunchKernelGGL(wgrad_bf16_lean_group_kernel, dim3(wg), dim3(256), 0, st, L_);
+    if (tn.wgrad_db) hipLaunchKernelGGL(wgrad_bf16_lean_group_db_kernel, dim3(wg), dim3(256), 0, st, L_);
+    else hipLaunchKernelGGL(wgrad_bf16_lean_group_kernel, dim3(wg), dim3(256), 0, st, L_);
     ALDI_CHECK_LAUNCH();
     {
         char name[96];
-        snprintf(name, sizeof(name), "wgrad_bf16_lean_group n=%d wgs=%d pix=%ld", ng, wg, T);
+        snprintf(name, sizeof(name), "wgrad_bf16_lean_group%s n=%d wgs=%d pix=%ld", tn.wgrad_db ? "_db" : "", ng, wg, T);
         aldi_note_dispatch(name);
     }
     return ALDI_OK;
@@ -893,6 +939,8 @@ extern "C" int aldi_conv_wgrad(const aldi_wgrad_args* a, aldi_stream_t stream) {
     else if (a->dtype == ALDI_F32) { hipLaunchKernelGGL(wgrad_f32_kernel, grid, dim3(256), 0, st, d); which = "wgrad_f32"; }
     else return aldi_set_error_msg(ALDI_ERR_ARG, "conv_wgrad: bad dtype");
     ALDI_CHECK_LAUNCH();
+    if (a->db && (dma || !(big || lean)))           // only the lean / 256x256 kernels add the bias gradient themselves
+        if (int rc = aldi_bias_grad(a->g, a->db, d.M, d.Cout, a->dtype, stream)) return rc;
     {
         char name[96];
         snprintf(name, sizeof(name), "%s splits=%d", which, splits);

@@ -1377,13 +1377,16 @@ class RCNN:
             x, temp_x = hit[1], True
             geo.update(stride=1)
         if getattr(self, "group_wgrad", False) and self.dtype == torch.bfloat16:
-            self._wg_queue.append((x, g, W.gw(name), geo, W.gb(name) if p.bias else None, temp_x))
+            fused_bias = p.bias and os.environ.get("ALDI_WGRAD_BIAS_FUSED", "1") == "1"    # (0: the separate column-sum launches, for A/B runs)
+            if fused_bias:
+                geo["db"] = W.gb(name)
+            self._wg_queue.append((x, g, W.gw(name), geo, W.gb(name) if p.bias and not fused_bias else None, temp_x))
             return
         side = self._wgrad_stream()
+        if p.bias:
+            geo["db"] = W.gb(name)                   # the bias gradient rides in the same launch (ones column; csrc/wgrad.hip)
         if side is None:
             ops.conv_wgrad(x, g, W.gw(name), **geo)
-            if p.bias:
-                ops.bias_grad(g, W.gb(name))
             return
         ev = torch.cuda.Event()
         ev.record()                                  # g (and x) are complete once the main stream gets here
@@ -1393,8 +1396,6 @@ class RCNN:
             x.record_stream(side)                    # x is a temporary too (gathered rows), not a saved activation
         with torch.cuda.stream(side):
             ops.conv_wgrad(x, g, W.gw(name), **geo)
-            if p.bias:
-                ops.bias_grad(g, W.gb(name))
         self._wgrad_pending = True
 
     def _flush_wgrads(self):

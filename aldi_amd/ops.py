@@ -140,12 +140,12 @@ def conv2d_group(calls) -> List[torch.Tensor]:
 
 
 def conv_wgrad(x: torch.Tensor, g: torch.Tensor, dw: torch.Tensor, *, KH: int, KW: int, stride: int = 1, pad: int = 0,
-               scale: Optional[torch.Tensor] = None) -> None:
-    """dw [Cout,KH,KW,Cin] fp32 += scale * (g^T . im2col(x)); x [N,H,W,Cin], g [N,Ho,Wo,Cout]."""
+               scale: Optional[torch.Tensor] = None, db: Optional[torch.Tensor] = None) -> None:
+    """dw [Cout,KH,KW,Cin] fp32 += scale * (g^T . im2col(x)); x [N,H,W,Cin], g [N,Ho,Wo,Cout]; db [Cout] fp32 += column sums of g."""
     N, H, W_, Cin = x.shape
     _, Ho, Wo, Cout = g.shape
     assert dw.dtype == torch.float32 and dw.numel() == Cout * KH * KW * Cin and x.dtype == g.dtype, (dw.shape, x.shape, g.shape)
-    a = L.WgradArgs(_p(x), _p(g), _p(dw), _p(scale), N, H, W_, Cin, Cout, KH, KW, stride, pad, Ho, Wo, dtype_code(x.dtype))
+    a = L.WgradArgs(_p(x), _p(g), _p(dw), _p(scale), N, H, W_, Cin, Cout, KH, KW, stride, pad, Ho, Wo, dtype_code(x.dtype), _p(db))
     L.call("aldi_conv_wgrad", C.byref(a), stream_ptr())
 
 
@@ -158,7 +158,7 @@ def conv_wgrad_group(problems) -> None:
         KH, KW = kw["KH"], kw["KW"]
         assert dw.dtype == torch.float32 and dw.numel() == Cout * KH * KW * Cin and x.dtype == g.dtype, (dw.shape, x.shape, g.shape)
         arr[i] = L.WgradArgs(_p(x), _p(g), _p(dw), _p(kw.get("scale")), N, H, W_, Cin, Cout, KH, KW, kw.get("stride", 1), kw.get("pad", 0), Ho, Wo,
-                             dtype_code(x.dtype))
+                             dtype_code(x.dtype), _p(kw.get("db")))
     L.call("aldi_conv_wgrad_group", arr, len(problems), stream_ptr())
 
 

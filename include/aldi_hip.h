@@ -53,6 +53,7 @@ int aldi_noop(aldi_stream_t stream);
  *   wgrad_group_slots    > 0: minimum workgroup count of an aldi_conv_wgrad_group launch before it stops splitting pixel ranges;
  *                        0 (default): the pixel split of the group is chosen by a model of 256-workgroup rounds
  *   wgrad_group_epi      cost of one atomic epilogue in that model, in 32-pixel slab steps (24)
+ *   wgrad_db             1 = grouped weight gradients with two LDS images and one barrier per 64-pixel slab (64 KB, two workgroups per CU)
  *   roialign_sep         1 = aldi_roialign forward in the separable form (row / column weight tables, one workgroup per ROI); 0 = per sample
  *   wgrad_dbg            ablation bits (1 = skip the atomic epilogue): results are WRONG when set
  *   wgrad_dma            LDS-DMA + ds_read_b64_tr_b16 weight-gradient kernel: 0 off, 1 in place of the lean kernel, 2 also of the 256x256
@@ -117,6 +118,9 @@ typedef struct {
     const float* scale; /* per-Cout multiplier (FrozenBN fold), nullable     */
     int N, H, W, Cin, Cout, KH, KW, stride, pad, Ho, Wo;
     int dtype;
+    float* db;          /* nullable: db[co] += sum over pixels of g[p][co] (the layer's bias gradient) in the same call: the lean /
+                           256x256 bf16 kernels add it as one more MFMA column (a constant ones fragment) instead of re-reading g in
+                           aldi_bias_grad; the other kernels fall back to that launch */
 } aldi_wgrad_args;
 int aldi_conv_wgrad(const aldi_wgrad_args* a, aldi_stream_t stream);
 

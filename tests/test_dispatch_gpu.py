@@ -583,3 +583,38 @@ def test_splitk_linear_equals_plain(M, Cout, K, ks):
     # the heuristic takes FC1's shape and leaves a short-K layer alone
     ops.conv2d(x, w, relu=True)
     assert ("splitk" in L.last_dispatch()) == (K >= 4096 and K % 256 == 0 and 16 <= ((M + 127) // 128) * ((Cout + 127) // 128) <= 160)
+
+
+@pytest.mark.parametrize("case", ["lean_1x1", "lean_3x3", "big_3x3", "generic_stride2", "fp32", "group"])
+def test_bias_gradient_rides_in_the_wgrad_launch(case):
+    """aldi_wgrad_args.db: db[co] += sum over pixels of g[p][co] in the weight-gradient call itself -- as one more MFMA column
+    (a constant ones fragment) in the lean / 256x256 bf16 kernels, through the column-sum launch behind the others -- against a
+    float64 column sum; the weight gradient itself must not change."""
+    from aldi_amd import _lib as L, ops
+    torch.manual_seed(3)
+    dt = torch.float32 if case == "fp32" else torch.bfloat16
+    N, H, W, Cin, Cout, k, s = {"lean_1x1": (2, 50, 84, 256, 512, 1, 1), "lean_3x3": (2, 25, 42, 128, 128, 3, 1), "big_3x3": (2, 200, 336, 256, 256, 3, 1),
+                                "generic_stride2": (2, 50, 84, 256, 512, 1, 2), "fp32": (1, 25, 42, 64, 64, 3, 1), "group": (2, 50, 84, 256, 256, 1, 1)}[case]
+    Ho, Wo = (H - 1) // s + 1, (W - 1) // s + 1
+    x = torch.randn(N, H, W, Cin, device="cuda").to(dt)
+    g = torch.randn(N, Ho, Wo, Cout, device="cuda").to(dt)
+    ref = g.double().sum((0, 1, 2))
+    L.reset_tuning()
+    dw0 = torch.zeros(Cout, k, k, Cin, device="cuda")
+    dw1 = torch.zeros_like(dw0)
+    db = torch.full((Cout,), 0.5, device="cuda")                       # (accumulates: starts from a non-zero value)
+    geo = dict(KH=k, KW=k, stride=s, pad=k // 2)
+    ops.conv_wgrad(x, g, dw0, **geo)
+    if case == "group":
+        x2 = torch.randn(N, H, W, 128, device="cuda").to(dt)
+        dw2, db2 = torch.zeros(Cout, 1, 1, 128, device="cuda"), torch.zeros(Cout, device="cuda")
+        ops.conv_wgrad_group([(x, g, dw1, dict(geo, db=db)), (x2, g, dw2, dict(geo, db=db2))])
+        assert "group" in L.last_dispatch()
+        assert float((db2.double() - ref).abs().max()) <= 1e-3 * float(ref.abs().max()) + 1e-2
+    else:
+        ops.conv_wgrad(x, g, dw1, db=db, **geo)
+        want = {"lean_1x1": "wgrad_bf16_lean", "lean_3x3": "wgrad_bf16_lean", "big_3x3": "wgrad_bf16_big", "generic_stride2": "wgrad_bf16_generic", "fp32": "wgrad_f32"}[case]
+        assert L.last_dispatch().startswith(want), L.last_dispatch()
+    torch.cuda.synchronize()
+    assert float((db.double() - 0.5 - ref).abs().max()) <= 1e-3 * float(ref.abs().max()) + 1e-2, float((db.double() - 0.5 - ref).abs().max())
+    assert float((dw0 - dw1).abs().max()) <= 1e-4 * float(dw0.abs().max())      # (fp32 atomics: summation order only)
