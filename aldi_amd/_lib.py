@@ -46,11 +46,11 @@ def parse_header(path: str = HEADER_PATH):
     src = open(path).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
     protos = {}
-    for m in re.finditer(r"\b(int|size_t|const char\*)\s+(aldi_\w+)\s*\(([^;{}]*?)\)\s*;", src, flags=re.S):
+    for m in re.finditer(r"\b(int|long|size_t|const char\*)\s+(aldi_\w+)\s*\(([^;{}]*?)\)\s*;", src, flags=re.S):
         ret, name, args = m.group(1), m.group(2), m.group(3)
         args = " ".join(args.split())
         argtypes = [] if args in ("void", "") else [_ctype(a) for a in args.split(",")]
-        restype = {"int": C.c_int, "size_t": C.c_size_t, "const char*": C.c_char_p}[ret]
+        restype = {"int": C.c_int, "long": C.c_long, "size_t": C.c_size_t, "const char*": C.c_char_p}[ret]
         protos[name] = (restype, argtypes)
     return protos
 
@@ -109,6 +109,7 @@ class WgradArgs(C.Structure):
         ("x", c_void_p), ("g", c_void_p), ("dw", c_void_p), ("scale", c_void_p),
         ("N", c_int), ("H", c_int), ("W", c_int), ("Cin", c_int), ("Cout", c_int), ("KH", c_int), ("KW", c_int),
         ("stride", c_int), ("pad", c_int), ("Ho", c_int), ("Wo", c_int), ("dtype", c_int), ("db", c_void_p),
+        ("ws", c_void_p), ("ws_bytes", C.c_long),
     ]
 
 

@@ -52,6 +52,10 @@ const Knob kKnobs[] = {
     {"wgrad_group_slots", &AldiTuning::wgrad_group_slots, 0},
     {"wgrad_group_epi", &AldiTuning::wgrad_group_epi, 24},
     {"wgrad_db", &AldiTuning::wgrad_db, 0},
+    {"wgrad_ordered", &AldiTuning::wgrad_ordered, 1},
+    {"wgrad_big_group", &AldiTuning::wgrad_big_group, 1},
+    {"wgrad_big_epi", &AldiTuning::wgrad_big_epi, 12},
+    {"wgrad_big_group_min", &AldiTuning::wgrad_big_group_min, 64},
     {"roialign_sep", &AldiTuning::roialign_sep, 1},
     {"colsum_blocks", &AldiTuning::colsum_blocks, 256},
     {"colsum_minrows", &AldiTuning::colsum_minrows, 16},
@@ -74,7 +78,7 @@ AldiTuning make_tuning() {
     }
     return t;
 }
-thread_local char g_dispatch[160] = "";
+thread_local char g_dispatch[224] = "";
 }  // namespace
 
 AldiTuning& aldi_tuning() {

@@ -752,9 +752,10 @@ __global__ __launch_bounds__(WM* WN * 64, (min_waves_per_simd<BM, WM * WN * 64, 
 }
 
 // Several problems of ONE layer shape in one launch -- the student's and the teacher's pass through the same layer (different
-// weights, different images): the two launches' fixed costs (ramp-up, partial last wave of tiles, dependent-launch gap: ~10 us
-// per 3x3 layer at these sizes) are paid once, and the smaller problem's tiles fill the larger one's tail.
-constexpr int kMaxConvGroup = 4;
+// weights, different images), and the same kind of layer on the maps of several pyramid levels (the four FPN output convs, the
+// RPN conv on p2..p6: same channels and taps, different H x W): the launches' fixed costs (ramp-up, partial last wave of tiles,
+// dependent-launch gap: ~10 us per 3x3 layer at these sizes) are paid once, and the small problems' tiles fill the large one's tail.
+constexpr int kMaxConvGroup = 12;
 struct ConvGroup {
     int n;
     int wg_begin[kMaxConvGroup + 1];          // first workgroup of each problem (multiples of 8: the XCD-aware tile order assumes it)
@@ -955,9 +956,10 @@ extern "C" int aldi_conv_igemm_group(const aldi_conv_args* args, int n, aldi_str
     bool same = n <= kMaxConvGroup && aldi_tuning().igemm_group;
     for (int i = 1; i < n && same; ++i) {
         const aldi_conv_args &a = args[0], &b = args[i];
-        // one layer shape: everything that selects code paths inside the kernel template is equal, only N (and the tensors) differ
-        same = a.dtype == b.dtype && a.H == b.H && a.W == b.W && a.Cin == b.Cin && a.Cout == b.Cout && a.KH == b.KH && a.KW == b.KW &&
-               a.stride == b.stride && a.pad == b.pad && a.Ho == b.Ho && a.Wo == b.Wo && a.out_scale == b.out_scale &&
+        // one layer shape: everything that selects code paths inside the kernel template is equal; N, H x W (pyramid levels) and the
+        // tensors differ -- the tile heuristics look at the pixel count, Cout, K and the conv geometry ("same" padding or not) only
+        same = a.dtype == b.dtype && a.Cin == b.Cin && a.Cout == b.Cout && a.KH == b.KH && a.KW == b.KW &&
+               a.stride == b.stride && a.pad == b.pad && (a.Ho == a.H) == (b.Ho == b.H) && (a.Wo == a.W) == (b.Wo == b.W) && a.out_scale == b.out_scale &&
                (a.y != nullptr) == (b.y != nullptr) && (a.y_f32 != nullptr) == (b.y_f32 != nullptr);
     }
     if (!same || n == 1) {
@@ -972,6 +974,8 @@ extern "C" int aldi_conv_igemm_group(const aldi_conv_args* args, int n, aldi_str
         if (int rc = fill_convdev(&args[i], G.p[i])) return rc;
         Msum += G.p[i].M;
     }
+    for (int i = 1; i < n; ++i)         // largest problem first: the small ones' tiles fill its tail
+        for (int j = i; j > 0 && G.p[j].M > G.p[j - 1].M; --j) { const ConvDev t_ = G.p[j]; G.p[j] = G.p[j - 1]; G.p[j - 1] = t_; }
     // the tile template is chosen for the COMBINED pixel count (the heuristics look at M, Cout, K and the conv geometry only)
     ConvDev d = G.p[0];
     d.M = (int)(Msum > 0x7fffffffL ? 0x7fffffffL : Msum);

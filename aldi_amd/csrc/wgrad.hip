@@ -28,6 +28,11 @@ struct WgDev {
     int N, H, W, Cin, Cout, KH, KW, stride, pad, Ho, Wo;
     int M, K, pix_per_split, ident, xcd, dbg;
     unsigned x_bytes, g_bytes, dw_bytes;
+    // ordered epilogue (no float atomics): a pixel split writes its partial tile to `ws` (fragment order, 16 B per lane) and its
+    // partial bias sums to `wsb`; wgrad_finalize_kernel adds the splits IN ORDER to dw / db.  splits == 1: the only owner of a tile
+    // adds to dw with plain loads and stores.  ordered == 0: the float-atomic epilogue (callers without a workspace).
+    float* ws; float* wsb;
+    int splits, ordered;
 };
 
 __device__ __forceinline__ int swz8(int row, int c) { return c ^ ((row >> 1) & 7); }
@@ -176,6 +181,96 @@ __global__ __launch_bounds__(256) void wgrad_bf16_kernel(WgDev p) {
 //   * the 8x8 16-bit transposes are v_perm_b32, one per output register.
 // TCO x TKK output tile (channels of g x (tap, channel) of x), 64 pixels per slab; (TCO + TKK) / 64 waves, each loading 64
 // channels of one operand and owning a (TCO / WM) x (TKK / WN) piece of the accumulator.
+// What a workgroup does with its finished TCO x TKK partial tile (acc: the MFMA accumulators of this wave, accb: the ones-column
+// product = the bias gradient, valid where do_bias).  D[row = co][col = kk]; lane (fr, fq) of fragment (i, j) holds rows
+// 4 fq .. 4 fq + 3 of column fr.
+template <int TCO, int TKK, int WM, int WN>
+__device__ __forceinline__ void wgrad_finish_tile(const WgDev& p, const f32x4_t (&acc)[TCO / WM / 16][TKK / WN / 16], const f32x4_t (&accb)[TCO / WM / 16],
+                                                  bool do_bias, int bx, int by, int bz, int wave, int lane) {
+    constexpr int TM = TCO / WM / 16, TN = TKK / WN / 16, NW = WM * WN;
+    const int wm = wave / WN, wn = wave % WN, fr = lane & 15, fq = lane >> 4;
+    const int co0 = bx * TCO, kk0 = by * TKK;
+    if (p.dbg & 1) {     // ablation (wgrad_dbg): no epilogue -- every accumulator stays live through one sum
+        float t = 0.f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) t += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
+        if (t == 123.456f) p.dw[0] = t;
+        return;
+    }
+    if (p.ordered && p.splits > 1) {
+        // partial tile -> workspace, one 1-KB wave store per fragment: [tile][split][wave][fragment][lane] x 16 B
+        const int gx = (p.Cout + TCO - 1) / TCO;
+        const long t = (long)by * gx + bx;
+        float4* dst = reinterpret_cast<float4*>(p.ws) + ((t * p.splits + bz) * NW + wave) * (long)(TM * TN * 64) + lane;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) dst[(i * TN + j) * 64] = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+        if (do_bias && fr == 0) {       // [co tile][split][TCO] floats
+            float* b = p.wsb + ((long)bx * p.splits + bz) * TCO + wm * (TCO / WM) + fq * 4;
+#pragma unroll
+            for (int i = 0; i < TM; ++i) *reinterpret_cast<float4*>(b + i * 16) = make_float4(accb[i][0], accb[i][1], accb[i][2], accb[i][3]);
+        }
+        return;
+    }
+    if (do_bias && fr == 0) {     // every column of the ones product holds the sum: column 0's lanes add it to the bias gradient
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int co = co0 + wm * (TCO / WM) + i * 16 + fq * 4 + r;
+                if (co < p.Cout) {
+                    if (p.ordered) p.db[co] += accb[i][r];          // the only pixel range of this co tile
+                    else unsafeAtomicAdd(p.db + co, accb[i][r]);
+                }
+            }
+    }
+    const __amdgpu_buffer_rsrc_t rdw = make_rsrc_uniform(p.dw, p.dw_bytes);
+    if (p.ordered) {   // sole owner of the tile: plain read-modify-write (out-of-tile lanes read zeros and drop their store)
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            float old_[4][TN];
+            unsigned off[4][TN];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int co = co0 + wm * (TCO / WM) + i * 16 + fq * 4 + r;
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    const int kk = kk0 + wn * (TKK / WN) + j * 16 + fr;
+                    off[r][j] = (co < p.Cout && kk < p.K) ? ((unsigned)co * (unsigned)p.K + (unsigned)kk) * 4u : kBufOOB;
+                    old_[r][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rdw, off[r][j], 0, 0));
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int co = co0 + wm * (TCO / WM) + i * 16 + fq * 4 + r;
+                const float sc = p.scale ? p.scale[co < p.Cout ? co : 0] : 1.f;
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, old_[r][j] + acc[i][j][r] * sc), rdw, off[r][j], 0, 0);
+            }
+        }
+        return;
+    }
+    // split-K partial tile -> fp32 gradient: fire-and-forget buffer atomics, out-of-tile lanes dropped
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int co = co0 + wm * (TCO / WM) + i * 16 + fq * 4 + r;
+            const bool cok = co < p.Cout;
+            const float sc = p.scale ? p.scale[cok ? co : 0] : 1.f;
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int kk = kk0 + wn * (TKK / WN) + j * 16 + fr;
+                const unsigned off = (cok && kk < p.K) ? ((unsigned)co * (unsigned)p.K + (unsigned)kk) * 4u : kBufOOB;
+                buf_atomic_add_f32(rdw, off, acc[i][j][r] * sc);
+            }
+        }
+}
+
 template <int TCO, int TKK, int WM, int WN, bool DB = false>
 __device__ __forceinline__ void wgrad_bf16_lean_tile(const WgDev& p, uint4* lds, int bx, int by, int bz);
 
@@ -339,41 +434,7 @@ __device__ __forceinline__ void wgrad_bf16_lean_tile(const WgDev& p, uint4* lds,
             }
         }
     }
-    if (do_bias && fr == 0) {     // every column of the ones product holds the sum: column 0's lanes add it to the bias gradient
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int co = co0 + wm * (TCO / WM) + i * 16 + fq * 4 + r;
-                if (co < p.Cout) unsafeAtomicAdd(p.db + co, accb[i][r]);
-            }
-    }
-    if (p.dbg & 1) {     // ablation (wgrad_dbg): no atomics -- every accumulator stays live through one sum
-        float t = 0.f;
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int j = 0; j < TN; ++j) t += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
-        if (t == 123.456f) p.dw[0] = t;
-        return;
-    }
-    {   // split-K partial tile -> fp32 gradient: 64 fire-and-forget buffer atomics per lane, out-of-tile lanes dropped
-        const __amdgpu_buffer_rsrc_t rdw = make_rsrc_uniform(p.dw, p.dw_bytes);
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int co = co0 + wm * (TCO / WM) + i * 16 + fq * 4 + r;
-                const bool cok = co < p.Cout;
-                const float sc = p.scale ? p.scale[cok ? co : 0] : 1.f;
-#pragma unroll
-                for (int j = 0; j < TN; ++j) {
-                    const int kk = kk0 + wn * (TKK / WN) + j * 16 + fr;
-                    const unsigned off = (cok && kk < p.K) ? ((unsigned)co * (unsigned)p.K + (unsigned)kk) * 4u : kBufOOB;
-                    buf_atomic_add_f32(rdw, off, acc[i][j][r] * sc);
-                }
-            }
-    }
+    wgrad_finish_tile<TCO, TKK, WM, WN>(p, acc, accb, do_bias, bx, by, bz, wave, lane);
 }
 
 // <= 168 VGPRs: three workgroups per CU
@@ -440,6 +501,87 @@ __global__ __launch_bounds__(256) void wgrad_bf16_lean_group_db_kernel(WgGroup G
 __global__ __launch_bounds__(512) void wgrad_bf16_big_kernel(WgDev p) {
     __shared__ uint4 lds[2 * 256 * 8];
     wgrad_bf16_lean_body<256, 256, 2, 4>(p, lds);
+}
+// Grouped form of the 256 x 256 tile: a stage's layers whose Cout and K are multiples of 256 in ONE launch of (about) one
+// workgroup per CU.  The 128 x 128 kernel stages twice the operand bytes per MFMA through registers and LDS and is bound by
+// that (~450 TFLOP/s in its loop against ~850 for this tile); alone, a res4 / res5 layer has 4-36 tiles of this size and
+// would need a 7-60-way pixel split to occupy the chip, together they are 100-240 tiles: one or two pixel ranges each.
+__global__ __launch_bounds__(512) void wgrad_bf16_big_group_kernel(WgGroup G) {
+    __shared__ uint4 lds[2 * 256 * 8];
+    const int bid = (int)blockIdx.x;
+    int i = 0;
+    for (int k = 1; k < G.n; ++k)
+        if (bid >= G.wg_begin[k]) i = k;
+    i = __builtin_amdgcn_readfirstlane(i);
+    const int local = bid - G.wg_begin[i];
+    const int tiles = G.gx[i] * G.gy[i];
+    if (local >= tiles * G.gz[i]) return;
+    const int t = local % tiles, bz = local / tiles;      // tile fastest: the tiles of one pixel range re-read the same x / g rows
+    wgrad_bf16_lean_tile<256, 256, 2, 4>(G.p[i], lds, t % G.gx[i], t / G.gx[i], bz);
+}
+
+// Second pass of the ordered epilogue: dw += scale * (split 0 + split 1 + ...), db += (...), the splits in index order -- the
+// same bits on every run, and plain loads / stores.  One 256-thread workgroup per (tile, fragment, 4 waves of the producer).
+struct WgFinItem {
+    const float* ws; const float* wsb; float* dw; float* db; const float* scale;
+    int Cout, K, gx, gy, S, big;
+};
+struct WgFin {
+    int n;
+    int wg_begin[kMaxGroup + 1];
+    WgFinItem it[kMaxGroup];
+};
+template <int TCO, int TKK, int WM, int WN>
+__device__ __forceinline__ void wgrad_finalize_part(const WgFinItem& it, int local) {
+    constexpr int TM = TCO / WM / 16, TN = TKK / WN / 16, NW = WM * WN, NF = TM * TN, HALVES = NW / 4;
+    const int S = it.S;
+    const int nblk = it.gx * it.gy * NF * HALVES;
+    if (local >= nblk) {        // the item's last workgroup: bias gradient
+        if (!it.db || local > nblk) return;
+        for (int co = threadIdx.x; co < it.Cout; co += 256) {
+            const float* b = it.wsb + (long)(co / TCO) * S * TCO + co % TCO;
+            float sum = 0.f;
+            for (int k = 0; k < S; ++k) sum += b[(long)k * TCO];
+            it.db[co] += sum;
+        }
+        return;
+    }
+    const int h = local % HALVES, f = (local / HALVES) % NF, t = local / (HALVES * NF);
+    const int wave = h * 4 + (int)(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const float4* src = reinterpret_cast<const float4*>(it.ws) + (((long)t * S) * NW + wave) * (long)(NF * 64) + f * 64 + lane;
+    float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
+    int k = 0;
+    for (; k + 4 <= S; k += 4) {      // four loads in flight, added in split order
+        const float4 v0 = src[(long)(k + 0) * NW * NF * 64], v1 = src[(long)(k + 1) * NW * NF * 64];
+        const float4 v2 = src[(long)(k + 2) * NW * NF * 64], v3 = src[(long)(k + 3) * NW * NF * 64];
+        sum.x += v0.x; sum.y += v0.y; sum.z += v0.z; sum.w += v0.w;
+        sum.x += v1.x; sum.y += v1.y; sum.z += v1.z; sum.w += v1.w;
+        sum.x += v2.x; sum.y += v2.y; sum.z += v2.z; sum.w += v2.w;
+        sum.x += v3.x; sum.y += v3.y; sum.z += v3.z; sum.w += v3.w;
+    }
+    for (; k < S; ++k) {
+        const float4 v = src[(long)k * NW * NF * 64];
+        sum.x += v.x; sum.y += v.y; sum.z += v.z; sum.w += v.w;
+    }
+    const int bx = t % it.gx, by = t / it.gx, wm = wave / WN, wn = wave % WN, i = f / TN, j = f % TN, fr = lane & 15, fq = lane >> 4;
+    const int kk = by * TKK + wn * (TKK / WN) + j * 16 + fr;
+    if (kk >= it.K) return;
+    const float v[4] = {sum.x, sum.y, sum.z, sum.w};
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int co = bx * TCO + wm * (TCO / WM) + i * 16 + fq * 4 + r;
+        if (co < it.Cout) it.dw[(long)co * it.K + kk] += v[r] * (it.scale ? it.scale[co] : 1.f);
+    }
+}
+__global__ __launch_bounds__(256) void wgrad_finalize_kernel(WgFin F) {
+    const int bid = (int)blockIdx.x;
+    int i = 0;
+    for (int k = 1; k < F.n; ++k)
+        if (bid >= F.wg_begin[k]) i = k;
+    i = __builtin_amdgcn_readfirstlane(i);
+    const int local = bid - F.wg_begin[i];
+    if (F.it[i].big) wgrad_finalize_part<256, 256, 2, 4>(F.it[i], local);
+    else wgrad_finalize_part<128, 128, 2, 2>(F.it[i], local);
 }
 
 // ------------------------------------------------------------------------------------ bf16, LDS-DMA + transpose reads
@@ -790,6 +932,7 @@ int fill_wgdev(const aldi_wgrad_args* a, WgDev& d) {
     d.dw_bytes = (unsigned)wb;
     d.ident = (a->KH == 1 && a->KW == 1 && a->stride == 1 && a->pad == 0 && a->Ho == a->H && a->Wo == a->W) ? 1 : 0;
     d.pix_per_split = d.M; d.xcd = 0; d.dbg = 0;
+    d.ws = d.wsb = nullptr; d.splits = 1; d.ordered = 0;
     return ALDI_OK;
 }
 bool lean_eligible(const aldi_wgrad_args* a, const WgDev& d) {
@@ -805,110 +948,70 @@ bool wants_big_tile(const WgDev& d, const AldiTuning& tn) {
 }
 }  // namespace
 
-extern "C" int aldi_conv_wgrad_group(const aldi_wgrad_args* args, int n, aldi_stream_t stream) {
-    if (!args || n < 1) return aldi_set_error_msg(ALDI_ERR_ARG, "conv_wgrad_group: no problems");
-    const AldiTuning& tn = aldi_tuning();
-    hipStream_t st = static_cast<hipStream_t>(stream);
-    // problems the lean 128x128 kernel cannot take (fp32, strided, unpadded ...) go through the single-problem dispatcher
-    static thread_local WgGroup G;
-    int order[kMaxGroup];
-    int ng = 0;
-    for (int i = 0; i < n; ++i) {
-        WgDev d;
-        if (int rc = fill_wgdev(&args[i], d)) return rc;
-        if (!lean_eligible(&args[i], d) || !tn.wgrad_lean || ng == kMaxGroup || wants_big_tile(d, tn)) {      // (the big tile has its own launch)
-            if (int rc = aldi_conv_wgrad(&args[i], stream)) return rc;
-            continue;
-        }
-        d.dbg = tn.wgrad_dbg;
-        d.xcd = tn.wgrad_xcd;
-        G.p[ng] = d;
-        order[ng] = ng;
-        ++ng;
+namespace {
+// Workspace of the ordered epilogue, carved in 256-B units.  dry: count only (aldi_conv_wgrad_group_workspace).
+struct WsCarver {
+    float* base; size_t cap, used; bool dry;
+    float* take(size_t n_floats) {
+        n_floats = (n_floats + 63) / 64 * 64;
+        float* r = dry ? nullptr : base + used;
+        used += n_floats;
+        return r;
     }
-    if (ng == 0) return ALDI_OK;
-    // Pixels per workgroup: ONE value T for the whole group (workgroups of equal length), the largest for which the launch
-    // still has wgrad_group_slots workgroups -- i.e. as few pixel splits (atomic epilogues) as filling the chip allows.
-    long tiles_of[kMaxGroup];
-    long maxM = 0;
-    for (int i = 0; i < ng; ++i) {
-        tiles_of[i] = (long)cdiv(G.p[i].Cout, 128) * cdiv(G.p[i].K, 128);
-        if (G.p[i].M > maxM) maxM = G.p[i].M;
+    bool fits() const { return dry || used <= cap; }
+};
+// the problems of one call that need the second pass; flushed in batches of kMaxGroup
+struct FinBuilder {
+    WgFin F; int wg; bool dry; hipStream_t st;
+    FinBuilder(hipStream_t s, bool d) : wg(0), dry(d), st(s) { F.n = 0; }
+    void add(const WgDev& d, int big) {
+        if (dry) return;
+        if (F.n == kMaxGroup) flush();
+        const int tile = big ? 256 : 128, gx = cdiv(d.Cout, tile), gy = cdiv(d.K, tile);
+        WgFinItem& it = F.it[F.n];
+        it.ws = d.ws; it.wsb = d.wsb; it.dw = d.dw; it.db = d.db; it.scale = d.scale;
+        it.Cout = d.Cout; it.K = d.K; it.gx = gx; it.gy = gy; it.S = d.splits; it.big = big;
+        F.wg_begin[F.n] = wg;
+        wg += gx * gy * (big ? 32 * 2 : 16) + 1;           // (tile, fragment, four producer waves) + the bias workgroup
+        ++F.n;
     }
-    auto wgs_for = [&](long T) {
-        long w = 0;
-        for (int i = 0; i < ng; ++i) w += tiles_of[i] * cdiv(G.p[i].M, T);
-        return w;
-    };
-    long T = (maxM + 63) / 64 * 64;
-    const long target = tn.wgrad_group_slots;
-    if (target > 0) {
-        while (T > 256 && wgs_for(T) < target) T = (T / 2 + 63) / 64 * 64;   // >= 4 slabs behind every epilogue
-    } else {
-        // wgrad_group_slots = 0: pick the split count by a round model.  Three of these workgroups are resident per CU (168
-        // VGPRs) and need each other to hide their LDS / DMA latency, so the chip works through the launch in rounds of 768, a
-        // round lasting (T / 32 slab steps + one epilogue, ~wgrad_group_epi slab steps of 16 K atomics).  Measured on the step's
-        // groups: 392 unsplit res4 tiles 603 us, three splits (1176 workgroups) 544 us; one 256-workgroup round of res3 553 us
-        // against 432 us for 512 half-length workgroups.
-        long best = -1;
-        for (int sp = 1; sp <= 4096; ++sp) {
-            const long Ts = ((maxM + sp - 1) / sp + 63) / 64 * 64;
-            if (Ts < 256 && sp > 1) break;
-            const long rounds = (wgs_for(Ts) + 767) / 768;
-            const long cost = rounds * (Ts / 32 + tn.wgrad_group_epi);
-            if (best < 0 || cost < best) { best = cost; T = Ts; }
-        }
+    void flush() {
+        if (dry || F.n == 0) return;
+        for (int k = F.n; k <= kMaxGroup; ++k) F.wg_begin[k] = wg;
+        hipLaunchKernelGGL(wgrad_finalize_kernel, dim3(wg), dim3(256), 0, st, F);
+        F.n = 0; wg = 0;
     }
-    // longest-running problems first (K x K convs before 1x1: more k-steps per pixel do not matter, pixels per workgroup do)
-    for (int i = 1; i < ng; ++i)
-        for (int j = i; j > 0 && G.p[order[j]].M > G.p[order[j - 1]].M; --j) { int t_ = order[j]; order[j] = order[j - 1]; order[j - 1] = t_; }
-    static thread_local WgGroup L_;
-    L_.n = ng;
-    int wg = 0;
-    for (int k = 0; k < ng; ++k) {
-        WgDev d = G.p[order[k]];
-        d.pix_per_split = (int)(T < d.M ? T : (d.M + 63) / 64 * 64);
-        L_.p[k] = d;
-        L_.gx[k] = cdiv(d.Cout, 128);
-        L_.gy[k] = cdiv(d.K, 128);
-        L_.gz[k] = cdiv(d.M, d.pix_per_split);
-        L_.wg_begin[k] = wg;
-        wg += (L_.gx[k] * L_.gy[k] * L_.gz[k] + 7) / 8 * 8;
-    }
-    for (int k = ng; k <= kMaxGroup; ++k) L_.wg_begin[k] = wg;
-    if (tn.wgrad_db) hipLaunchKernelGGL(wgrad_bf16_lean_group_db_kernel, dim3(wg), dim3(256), 0, st, L_);
-    else hipLaunchKernelGGL(wgrad_bf16_lean_group_kernel, dim3(wg), dim3(256), 0, st, L_);
-    ALDI_CHECK_LAUNCH();
-    {
-        char name[96];
-        snprintf(name, sizeof(name), "wgrad_bf16_lean_group%s n=%d wgs=%d pix=%ld", tn.wgrad_db ? "_db" : "", ng, wg, T);
-        aldi_note_dispatch(name);
-    }
-    return ALDI_OK;
+};
+// ordered epilogue of problem d (tile x tile output tiles, d.splits pixel ranges): workspace + second pass when split
+void plan_ordered(WgDev& d, int big, WsCarver& ws, FinBuilder& fin) {
+    d.ordered = 1;
+    d.ws = d.wsb = nullptr;
+    if (d.splits <= 1) return;
+    const int tile = big ? 256 : 128;
+    const size_t gx = cdiv(d.Cout, tile), gy = cdiv(d.K, tile);
+    d.ws = ws.take(gx * gy * (size_t)d.splits * tile * tile);
+    if (d.db) d.wsb = ws.take(gx * (size_t)d.splits * tile);
+    fin.add(d, big);
 }
 
-extern "C" int aldi_conv_wgrad(const aldi_wgrad_args* a, aldi_stream_t stream) {
+int wgrad_single(const aldi_wgrad_args* a, hipStream_t st, WsCarver& ws, FinBuilder& fin, bool ordered, bool dry) {
     WgDev d;
     if (int rc = fill_wgdev(a, d)) return rc;
-    long M = d.M;
-    (void)M;
-    hipStream_t st = static_cast<hipStream_t>(stream);
     const AldiTuning& tn = aldi_tuning();
-    const int lean_env = tn.wgrad_lean, big_min_env = tn.wgrad_big_min, big_slots_env = tn.wgrad_big_slots;
+    const int lean_env = tn.wgrad_lean, big_slots_env = tn.wgrad_big_slots;
     const bool same = a->stride == 1 && a->Ho == a->H && a->Wo == a->W && 2 * a->pad == a->KH - 1 && a->KH == a->KW && a->Cin % 64 == 0;
     const bool lean = a->dtype == ALDI_BF16 && lean_env && (d.ident || same);
     const int bp = a->dtype == ALDI_BF16 ? 64 : 16;
     int slabs = cdiv(d.M, bp);
     const bool big = lean && wants_big_tile(d, tn);
-    (void)big_min_env;
     const int tile = big ? 256 : (a->dtype == ALDI_BF16 ? 128 : 64);
     int tiles = cdiv(d.Cout, tile) * cdiv(d.K, tile);
     const int slots_env_ = tn.wgrad_slots;
     const int slots_env = big ? big_slots_env : slots_env_;
     // the kernel is bound per CU (L2 -> CU path, LDS), not by latency: few, long splits (1-2 workgroups per CU) beat
-    // many short ones, whose 16K-atomic epilogues also contend on the same dW lines
+    // many short ones, whose epilogues also contend on the same dW lines
     int splits = big ? slots_env / tiles : cdiv(slots_env, tiles);
-    if (splits > slabs / 4) splits = slabs / 4;    // ... but at least 4 slabs of work behind every 16K-atomic epilogue
+    if (splits > slabs / 4) splits = slabs / 4;    // ... but at least 4 slabs of work behind every epilogue
     if (splits < 1) splits = 1;
     if (splits > 512) splits = 512;
     int slabs_per = cdiv(slabs, splits);
@@ -917,6 +1020,7 @@ extern "C" int aldi_conv_wgrad(const aldi_wgrad_args* a, aldi_stream_t stream) {
     dim3 grid(cdiv(d.Cout, tile), cdiv(d.K, tile), splits);
     d.xcd = tn.wgrad_xcd;
     d.dbg = tn.wgrad_dbg;
+    d.splits = splits;
     const char* which;
     // LDS-DMA + transpose-read form (wgrad_dma: 0 off, 1 = 128x128 tile in place of the lean kernel, 2 = also in place of the 256x256 one)
     const bool dma = lean && tn.wgrad_dma > 0 && (d.ident ? a->Cin % 8 == 0 : a->Cin % 16 == 0) && a->KH * a->KW <= 25 && !(big && tn.wgrad_dma < 2);
@@ -931,21 +1035,173 @@ extern "C" int aldi_conv_wgrad(const aldi_wgrad_args* a, aldi_stream_t stream) {
             splits = cdiv(d.M, d.pix_per_split);
             grid = dim3(cdiv(d.Cout, 128), cdiv(d.K, 128), splits);
         }
-        hipLaunchKernelGGL((wgrad_bf16_dma_kernel<128, 128, 2, 2>), grid, dim3(256), 0, st, d);
+        if (!dry) hipLaunchKernelGGL((wgrad_bf16_dma_kernel<128, 128, 2, 2>), grid, dim3(256), 0, st, d);
         which = "wgrad_bf16_dma";
-    } else if (big) { hipLaunchKernelGGL(wgrad_bf16_big_kernel, grid, dim3(512), 0, st, d); which = "wgrad_bf16_big"; }
-    else if (lean) { hipLaunchKernelGGL(wgrad_bf16_lean_kernel, grid, dim3(256), 0, st, d); which = "wgrad_bf16_lean"; }
-    else if (a->dtype == ALDI_BF16) { hipLaunchKernelGGL(wgrad_bf16_kernel, grid, dim3(256), 0, st, d); which = "wgrad_bf16_generic"; }
-    else if (a->dtype == ALDI_F32) { hipLaunchKernelGGL(wgrad_f32_kernel, grid, dim3(256), 0, st, d); which = "wgrad_f32"; }
+    } else if (big || lean) {
+        if (ordered) plan_ordered(d, big, ws, fin);
+        if (!ws.fits()) return aldi_set_error_msg(ALDI_ERR_ARG, "conv_wgrad: workspace too small (aldi_conv_wgrad_group_workspace)");
+        if (!dry) {
+            if (big) hipLaunchKernelGGL(wgrad_bf16_big_kernel, grid, dim3(512), 0, st, d);
+            else hipLaunchKernelGGL(wgrad_bf16_lean_kernel, grid, dim3(256), 0, st, d);
+        }
+        which = big ? "wgrad_bf16_big" : "wgrad_bf16_lean";
+    }
+    else if (a->dtype == ALDI_BF16) { if (!dry) hipLaunchKernelGGL(wgrad_bf16_kernel, grid, dim3(256), 0, st, d); which = "wgrad_bf16_generic"; }
+    else if (a->dtype == ALDI_F32) { if (!dry) hipLaunchKernelGGL(wgrad_f32_kernel, grid, dim3(256), 0, st, d); which = "wgrad_f32"; }
     else return aldi_set_error_msg(ALDI_ERR_ARG, "conv_wgrad: bad dtype");
+    if (dry) return ALDI_OK;
     ALDI_CHECK_LAUNCH();
     if (a->db && (dma || !(big || lean)))           // only the lean / 256x256 kernels add the bias gradient themselves
-        if (int rc = aldi_bias_grad(a->g, a->db, d.M, d.Cout, a->dtype, stream)) return rc;
+        if (int rc = aldi_bias_grad(a->g, a->db, d.M, d.Cout, a->dtype, st)) return rc;
     {
         char name[96];
-        snprintf(name, sizeof(name), "%s splits=%d", which, splits);
+        snprintf(name, sizeof(name), "%s splits=%d%s", which, splits, d.ordered ? " ordered" : "");
         aldi_note_dispatch(name);
     }
+    return ALDI_OK;
+}
+
+// one grouped launch of the problems idx[0..ng) with a common pixel length per workgroup; big: 256x256 tiles, one workgroup per CU
+int launch_group(const WgDev* probs, int ng, bool big, hipStream_t st, WsCarver& ws, FinBuilder& fin, bool ordered, bool dry, char* name, size_t name_len) {
+    const AldiTuning& tn = aldi_tuning();
+    const int tile = big ? 256 : 128;
+    long tiles_of[kMaxGroup];
+    int order[kMaxGroup];
+    long maxM = 0;
+    for (int i = 0; i < ng; ++i) {
+        tiles_of[i] = (long)cdiv(probs[i].Cout, tile) * cdiv(probs[i].K, tile);
+        if (probs[i].M > maxM) maxM = probs[i].M;
+        order[i] = i;
+    }
+    auto wgs_for = [&](long T) {
+        long w = 0;
+        for (int i = 0; i < ng; ++i) w += tiles_of[i] * cdiv(probs[i].M, T);
+        return w;
+    };
+    // Pixels per workgroup: ONE value T for the whole group (workgroups of equal length), chosen by a round model.  128x128: three
+    // workgroups are resident per CU (168 VGPRs) and need each other to hide their LDS / DMA latency, so the chip works through
+    // the launch in rounds of 768, a round lasting (T / 32 slab steps + one epilogue of ~wgrad_group_epi slab steps).  Measured on
+    // the step's groups: 392 unsplit res4 tiles 603 us, three splits (1176 workgroups) 544 us; one 256-workgroup round of res3
+    // 553 us against 432 us for 512 half-length workgroups.  256x256: one workgroup per CU, rounds of wgrad_big_slots.
+    long T = (maxM + 63) / 64 * 64;
+    const long target = big ? 0 : tn.wgrad_group_slots;
+    if (target > 0) {
+        while (T > 256 && wgs_for(T) < target) T = (T / 2 + 63) / 64 * 64;   // >= 4 slabs behind every epilogue
+    } else {
+        const long slots = big ? (tn.wgrad_big_slots > 0 ? tn.wgrad_big_slots : 256) : 768;
+        const long epi = big ? tn.wgrad_big_epi : tn.wgrad_group_epi;
+        const long minT = big ? 512 : 256;
+        long best = -1;
+        for (int sp = 1; sp <= 4096; ++sp) {
+            const long Ts = ((maxM + sp - 1) / sp + 63) / 64 * 64;
+            if (Ts < minT && sp > 1) break;
+            const long rounds = (wgs_for(Ts) + slots - 1) / slots;
+            const long cost = rounds * (Ts / 32 + epi);
+            if (best < 0 || cost < best) { best = cost; T = Ts; }
+        }
+    }
+    // longest-running problems first (K x K convs before 1x1: more k-steps per pixel do not matter, pixels per workgroup do)
+    for (int i = 1; i < ng; ++i)
+        for (int j = i; j > 0 && probs[order[j]].M > probs[order[j - 1]].M; --j) { int t_ = order[j]; order[j] = order[j - 1]; order[j - 1] = t_; }
+    static thread_local WgGroup L_;
+    L_.n = ng;
+    int wg = 0;
+    for (int k = 0; k < ng; ++k) {
+        WgDev d = probs[order[k]];
+        d.pix_per_split = (int)(T < d.M ? T : (d.M + 63) / 64 * 64);
+        d.splits = cdiv(d.M, d.pix_per_split);
+        if (ordered && d.ordered >= 0) plan_ordered(d, big, ws, fin);
+        else d.ordered = 0;
+        L_.p[k] = d;
+        L_.gx[k] = cdiv(d.Cout, tile);
+        L_.gy[k] = cdiv(d.K, tile);
+        L_.gz[k] = d.splits;
+        L_.wg_begin[k] = wg;
+        const int w = L_.gx[k] * L_.gy[k] * L_.gz[k];
+        wg += big ? w : (w + 7) / 8 * 8;
+    }
+    if (!ws.fits()) return aldi_set_error_msg(ALDI_ERR_ARG, "conv_wgrad_group: workspace too small (aldi_conv_wgrad_group_workspace)");
+    for (int k = ng; k <= kMaxGroup; ++k) L_.wg_begin[k] = wg;
+    if (dry) return ALDI_OK;
+    if (big) hipLaunchKernelGGL(wgrad_bf16_big_group_kernel, dim3(wg), dim3(512), 0, st, L_);
+    else if (tn.wgrad_db) hipLaunchKernelGGL(wgrad_bf16_lean_group_db_kernel, dim3(wg), dim3(256), 0, st, L_);
+    else hipLaunchKernelGGL(wgrad_bf16_lean_group_kernel, dim3(wg), dim3(256), 0, st, L_);
+    ALDI_CHECK_LAUNCH();
+    snprintf(name, name_len, "wgrad_bf16_%s_group%s n=%d wgs=%d pix=%ld%s", big ? "big" : "lean", (!big && tn.wgrad_db) ? "_db" : "", ng, wg, T, ordered ? " ordered" : "");
+    return ALDI_OK;
+}
+
+int wgrad_group_impl(const aldi_wgrad_args* args, int n, hipStream_t st, bool dry, size_t* need) {
+    if (!args || n < 1) return aldi_set_error_msg(ALDI_ERR_ARG, "conv_wgrad_group: no problems");
+    const AldiTuning& tn = aldi_tuning();
+    const bool ordered = dry || (args[0].ws != nullptr && tn.wgrad_ordered);
+    WsCarver ws{static_cast<float*>(args[0].ws), dry ? 0 : (size_t)args[0].ws_bytes / 4, 0, dry};
+    FinBuilder fin(st, dry);
+    // problems the lean / 256x256 kernels cannot take (fp32, strided, unpadded ...) go through the single-problem dispatcher
+    static thread_local WgDev lean_p[kMaxGroup], big_p[kMaxGroup];
+    int nl = 0, nb = 0;
+    for (int i = 0; i < n; ++i) {
+        WgDev d;
+        if (int rc = fill_wgdev(&args[i], d)) return rc;
+        // layers that SHARE a gradient buffer inside one call (one conv applied to several pyramid levels) would race in the plain
+        // read-modify-write / second pass: those keep the float-atomic epilogue
+        bool shared = false;
+        for (int j = 0; j < n && !shared; ++j)
+            shared = j != i && (args[j].dw == args[i].dw || (args[i].db && args[j].db == args[i].db));
+        const bool elig = lean_eligible(&args[i], d) && tn.wgrad_lean;
+        const bool big_group = elig && tn.wgrad_big_group && d.Cout % 256 == 0 && d.K % 256 == 0 && d.M >= 512 && nb < kMaxGroup;
+        if (!elig || (!big_group && (nl == kMaxGroup || wants_big_tile(d, tn)))) {      // (alone, the big tile has its own launch)
+            if (int rc = wgrad_single(&args[i], st, ws, fin, ordered && !shared, dry)) return rc;
+            continue;
+        }
+        d.dbg = tn.wgrad_dbg;
+        d.xcd = tn.wgrad_xcd;
+        d.splits = 1; d.ordered = shared ? -1 : 0; d.ws = d.wsb = nullptr;
+        if (big_group) big_p[nb++] = d; else lean_p[nl++] = d;
+    }
+    if (nb) {
+        // a 256x256 launch wants a CU-count of workgroups with >= 1000 pixels each; a couple of tiles would be cut into hundreds of
+        // short pixel ranges (each ending in a 256-KB partial tile) just to occupy the chip: those layers stay with the 128x128 group
+        double tile_pixels = 0.0;
+        for (int i = 0; i < nb; ++i) tile_pixels += (double)(big_p[i].Cout / 256) * (big_p[i].K / 256) * big_p[i].M;
+        if (tile_pixels < 4096.0 * tn.wgrad_big_group_min && nl + nb <= kMaxGroup) {
+            for (int i = 0; i < nb; ++i) lean_p[nl++] = big_p[i];
+            nb = 0;
+        }
+    }
+    char nb_name[96] = "", nl_name[96] = "";
+    if (nb) if (int rc = launch_group(big_p, nb, true, st, ws, fin, ordered, dry, nb_name, sizeof(nb_name))) return rc;
+    if (nl) if (int rc = launch_group(lean_p, nl, false, st, ws, fin, ordered, dry, nl_name, sizeof(nl_name))) return rc;
+    fin.flush();
+    if (need) *need = ws.used * 4;
+    if (!dry && (nb || nl)) {
+        ALDI_CHECK_LAUNCH();
+        char name[200];
+        snprintf(name, sizeof(name), "%s%s%s", nl_name, (nb && nl) ? " | " : "", nb_name);
+        aldi_note_dispatch(name);
+    }
+    return ALDI_OK;
+}
+}  // namespace
+
+extern "C" int aldi_conv_wgrad_group(const aldi_wgrad_args* args, int n, aldi_stream_t stream) {
+    return wgrad_group_impl(args, n, static_cast<hipStream_t>(stream), false, nullptr);
+}
+extern "C" long aldi_conv_wgrad_group_workspace(const aldi_wgrad_args* args, int n) {
+    size_t need = 0;
+    if (wgrad_group_impl(args, n, nullptr, true, &need)) return -1;
+    return (long)need;
+}
+
+extern "C" int aldi_conv_wgrad(const aldi_wgrad_args* a, aldi_stream_t stream) {
+    if (!a) return aldi_set_error_msg(ALDI_ERR_ARG, "conv_wgrad: null pointer");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const bool ordered = a->ws != nullptr && aldi_tuning().wgrad_ordered;
+    WsCarver ws{static_cast<float*>(a->ws), (size_t)a->ws_bytes / 4, 0, false};
+    FinBuilder fin(st, false);
+    if (int rc = wgrad_single(a, st, ws, fin, ordered, false)) return rc;
+    fin.flush();
+    ALDI_CHECK_LAUNCH();
     return ALDI_OK;
 }
 

@@ -386,6 +386,7 @@ class RCNN:
         self.has_img_da, self.has_ins_da = bool(self.img_da_layers), bool(self.ins_da_layers)
         self.fused_stem = os.environ.get("ALDI_FUSED_STEM", "1") == "1"                  # bf16: stem conv + max-pool in one kernel
         self.group_wgrad = os.environ.get("ALDI_WGRAD_GROUP", "1") == "1"                # bf16: a layer group's weight gradients in one launch
+        self.level_groups = os.environ.get("ALDI_LEVEL_GROUPS", "1") == "1"              # one launch for a layer applied to several pyramid levels
         self.fused_res2 = os.environ.get("ALDI_FUSED_RES2", "1") == "1"                  # bf16: a res2 bottleneck (no saved activations) in one kernel
         self._wg_queue: list = []
         self.sparse_rpn_backward = os.environ.get("ALDI_RPN_SPARSE_BWD", "1") == "1"      # tests flip the attribute to compare with the dense form
@@ -476,11 +477,18 @@ class RCNN:
     # The trunk and the RPN head are written as generators that YIELD their convolutions ((x, layer name, flags) -> output): run
     # alone (`_drive`) each request is one launch; two models of the same architecture run in lockstep (`drive_pair`: the
     # student's N = 4 batch and the teacher's N = 2 batch through their own weights) share ONE launch per layer.
+    # A request may also be a LIST of such triples: independent convolutions of one layer shape (the output conv on the four
+    # pyramid levels, the RPN conv on five) that share one launch (aldi_conv_igemm_group) -- with the other model's list too.
+    def _serve(self, req):
+        if isinstance(req, list):
+            return ops.conv2d_group([self._conv_call(r[0], r[1], **r[2]) for r in req])
+        return self.conv(req[0], req[1], **req[2])
+
     def _drive(self, gen):
         try:
             req = next(gen)
             while True:
-                req = gen.send(self.conv(req[0], req[1], **req[2]))
+                req = gen.send(self._serve(req))
         except StopIteration as e:
             return e.value
 
@@ -498,11 +506,14 @@ class RCNN:
             rb, res[1] = None, e.value
         while ra is not None or rb is not None:
             if ra is not None and rb is not None:
-                ya, yb = ops.conv2d_group([eng_a._conv_call(ra[0], ra[1], **ra[2]), eng_b._conv_call(rb[0], rb[1], **rb[2])])
+                la, lb = (ra if isinstance(ra, list) else [ra]), (rb if isinstance(rb, list) else [rb])
+                ys = ops.conv2d_group([eng_a._conv_call(r[0], r[1], **r[2]) for r in la] + [eng_b._conv_call(r[0], r[1], **r[2]) for r in lb])
+                ya = ys[:len(la)] if isinstance(ra, list) else ys[0]
+                yb = ys[len(la):] if isinstance(rb, list) else ys[len(la)]
             elif ra is not None:
-                ya = eng_a.conv(ra[0], ra[1], **ra[2])
+                ya = eng_a._serve(ra)
             else:
-                yb = eng_b.conv(rb[0], rb[1], **rb[2])
+                yb = eng_b._serve(rb)
             if ra is not None:
                 try:
                     ra = gen_a.send(ya)
@@ -557,10 +568,18 @@ class RCNN:
         prev = {}
         P = {}
         prev[5] = yield cs[3], "backbone.fpn_lateral5", {}
-        P[5] = yield prev[5], "backbone.fpn_output5", {}
-        for lvl in (4, 3, 2):
-            prev[lvl] = yield cs[lvl - 2], f"backbone.fpn_lateral{lvl}", dict(res=prev[lvl + 1], res_mode=2)
-            P[lvl] = yield prev[lvl], f"backbone.fpn_output{lvl}", {}
+        if self.level_groups:
+            # the top-down sums first, then the four output convs (256 -> 256, 3x3, on 268800 / 67200 / 16800 / 4200 pixels at N = 4)
+            # as ONE launch: alone, the p4 / p5 ones are a fraction of a round of workgroups each
+            for lvl in (4, 3, 2):
+                prev[lvl] = yield cs[lvl - 2], f"backbone.fpn_lateral{lvl}", dict(res=prev[lvl + 1], res_mode=2)
+            outs = yield [(prev[lvl], f"backbone.fpn_output{lvl}", {}) for lvl in (2, 3, 4, 5)]
+            P.update(zip((2, 3, 4, 5), outs))
+        else:
+            P[5] = yield prev[5], "backbone.fpn_output5", {}
+            for lvl in (4, 3, 2):
+                prev[lvl] = yield cs[lvl - 2], f"backbone.fpn_lateral{lvl}", dict(res=prev[lvl + 1], res_mode=2)
+                P[lvl] = yield prev[lvl], f"backbone.fpn_output{lvl}", {}
         P[6] = ops.subsample2(P[5])
         c.P = [P[2], P[3], P[4], P[5], P[6]]
         if save:
@@ -576,11 +595,16 @@ class RCNN:
         # the chip, the others far below one round of workgroups) on the student's serial proposal chain.
         px = [f.shape[0] * f.shape[1] * f.shape[2] for f in c.P]
         flat = torch.empty((1, sum(px), 1, FPN_C), dtype=self.dtype, device=self.device)
-        ts, o = [], 0
+        ts, o, reqs = [], 0, []
         for f, n in zip(c.P, px):
             view = flat[0, o:o + n, 0].view(f.shape[0], f.shape[1], f.shape[2], FPN_C)
-            ts.append((yield f, "proposal_generator.rpn_head.conv", dict(relu=True, out=view)))
+            reqs.append((f, "proposal_generator.rpn_head.conv", dict(relu=True, out=view)))
             o += n
+        if self.level_groups:
+            ts = yield reqs             # the shared 3x3 conv on the five levels: one launch
+        else:
+            for r in reqs:
+                ts.append((yield r))
         hf = yield flat, "rpn_head_out", dict(want_f32=True)
         heads, o = [], 0
         for f, n in zip(c.P, px):
@@ -1244,7 +1268,12 @@ class RCNN:
         gprev = {}
         for i, lvl in enumerate((2, 3, 4, 5)):
             self._wgrad(f"backbone.fpn_output{lvl}", c.prev[lvl], gP[i])
-            gprev[lvl] = ops.conv2d(gP[i], W.wt(f"backbone.fpn_output{lvl}"), pad=1)
+        if self.level_groups:
+            gs = ops.conv2d_group([(gP[i], W.wt(f"backbone.fpn_output{lvl}"), dict(pad=1)) for i, lvl in enumerate((2, 3, 4, 5))])
+            gprev.update(zip((2, 3, 4, 5), gs))
+        else:
+            for i, lvl in enumerate((2, 3, 4, 5)):
+                gprev[lvl] = ops.conv2d(gP[i], W.wt(f"backbone.fpn_output{lvl}"), pad=1)
         for lvl in (3, 4, 5):
             ops.upsample2_bwd(gprev[lvl - 1], gprev[lvl], accumulate=True)
         for lvl in (2, 3, 4, 5):

@@ -139,14 +139,40 @@ def conv2d_group(calls) -> List[torch.Tensor]:
     return outs
 
 
+_WGRAD_WS = {}          # (device, stream handle) -> fp32 workspace of the ordered weight-gradient epilogue (grow only)
+WGRAD_ORDERED = os.environ.get("ALDI_WGRAD_ORDERED", "1") != "0"
+
+
+def _wgrad_workspace(arr, n: int, device) -> None:
+    """give the call's first problem the workspace its ordered epilogue needs (aldi_conv_wgrad_group_workspace); launches on one
+    stream are ordered, so one buffer per stream serves all of them"""
+    if not WGRAD_ORDERED:
+        return
+    need = L.lib.aldi_conv_wgrad_group_workspace(arr, n)
+    if need < 0:
+        raise RuntimeError("aldi_conv_wgrad_group_workspace: " + L.lib.aldi_last_error().decode())
+    if need == 0:
+        need = 256          # a non-NULL workspace selects the ordered epilogue (plain read-modify-write of unsplit tiles)
+    key = (device, stream_ptr())
+    buf = _WGRAD_WS.get(key)
+    if buf is None or buf.numel() * 4 < need:
+        buf = torch.empty((need + (need >> 2) + 3) // 4, dtype=torch.float32, device=device)
+        _WGRAD_WS[key] = buf
+    arr[0].ws = buf.data_ptr()
+    arr[0].ws_bytes = buf.numel() * 4
+
+
 def conv_wgrad(x: torch.Tensor, g: torch.Tensor, dw: torch.Tensor, *, KH: int, KW: int, stride: int = 1, pad: int = 0,
                scale: Optional[torch.Tensor] = None, db: Optional[torch.Tensor] = None) -> None:
     """dw [Cout,KH,KW,Cin] fp32 += scale * (g^T . im2col(x)); x [N,H,W,Cin], g [N,Ho,Wo,Cout]; db [Cout] fp32 += column sums of g."""
     N, H, W_, Cin = x.shape
     _, Ho, Wo, Cout = g.shape
     assert dw.dtype == torch.float32 and dw.numel() == Cout * KH * KW * Cin and x.dtype == g.dtype, (dw.shape, x.shape, g.shape)
-    a = L.WgradArgs(_p(x), _p(g), _p(dw), _p(scale), N, H, W_, Cin, Cout, KH, KW, stride, pad, Ho, Wo, dtype_code(x.dtype), _p(db))
-    L.call("aldi_conv_wgrad", C.byref(a), stream_ptr())
+    arr = (L.WgradArgs * 1)()
+    arr[0] = L.WgradArgs(_p(x), _p(g), _p(dw), _p(scale), N, H, W_, Cin, Cout, KH, KW, stride, pad, Ho, Wo, dtype_code(x.dtype), _p(db), None, 0)
+    if x.dtype == torch.bfloat16:
+        _wgrad_workspace(arr, 1, x.device)
+    L.call("aldi_conv_wgrad", arr, stream_ptr())
 
 
 def conv_wgrad_group(problems) -> None:
@@ -158,7 +184,8 @@ def conv_wgrad_group(problems) -> None:
         KH, KW = kw["KH"], kw["KW"]
         assert dw.dtype == torch.float32 and dw.numel() == Cout * KH * KW * Cin and x.dtype == g.dtype, (dw.shape, x.shape, g.shape)
         arr[i] = L.WgradArgs(_p(x), _p(g), _p(dw), _p(kw.get("scale")), N, H, W_, Cin, Cout, KH, KW, kw.get("stride", 1), kw.get("pad", 0), Ho, Wo,
-                             dtype_code(x.dtype), _p(kw.get("db")))
+                             dtype_code(x.dtype), _p(kw.get("db")), None, 0)
+    _wgrad_workspace(arr, len(problems), problems[0][0].device)
     L.call("aldi_conv_wgrad_group", arr, len(problems), stream_ptr())
 
 

@@ -53,6 +53,10 @@ int aldi_noop(aldi_stream_t stream);
  *   wgrad_group_slots    > 0: minimum workgroup count of an aldi_conv_wgrad_group launch before it stops splitting pixel ranges;
  *                        0 (default): the pixel split of the group is chosen by a model of 256-workgroup rounds
  *   wgrad_group_epi      cost of one atomic epilogue in that model, in 32-pixel slab steps (24)
+ *   wgrad_ordered        1 = ordered (atomic-free, deterministic) epilogue whenever the caller passes a workspace (default)
+ *   wgrad_big_group      1 = a group's layers with Cout % 256 == K % 256 == 0 run as ONE launch of 256x256 tiles (default)
+ *   wgrad_big_epi        cost of one 256x256 epilogue in the group's split model, in 32-pixel slab steps (12)
+ *   wgrad_big_group_min  (256x256 tiles x pixels) / 4096 a group needs for that launch (64); less: its layers join the 128x128 group
  *   wgrad_db             1 = grouped weight gradients with two LDS images and one barrier per 64-pixel slab (64 KB, two workgroups per CU)
  *   roialign_sep         1 = aldi_roialign forward in the separable form (row / column weight tables, one workgroup per ROI); 0 = per sample
  *   wgrad_dbg            ablation bits (1 = skip the atomic epilogue): results are WRONG when set
@@ -102,13 +106,14 @@ typedef struct {
 } aldi_conv_args;
 
 int aldi_conv_igemm(const aldi_conv_args* a, aldi_stream_t stream);
-/* n (<= 4) convolutions of ONE layer shape -- same geometry and channel counts, different tensors / batch sizes: the student's
- * and the teacher's pass through a layer (aldi/distill.py:157,162 run them as two model calls) -- in ONE launch; any other
- * combination (or igemm_group = 0) falls back to n single launches.  Same arithmetic as n aldi_conv_igemm calls. */
+/* n (<= 12) convolutions of ONE layer shape -- same channel counts, taps, stride and padding; different tensors, batch sizes and
+ * H x W: the student's and the teacher's pass through a layer (aldi/distill.py:157,162 run them as two model calls), and one layer
+ * applied to several pyramid levels (FPN output convs, the RPN conv on p2..p6) -- in ONE launch; any other combination (or
+ * igemm_group = 0) falls back to n single launches.  Same arithmetic as n aldi_conv_igemm calls. */
 int aldi_conv_igemm_group(const aldi_conv_args* args, int n, aldi_stream_t stream);
 
 /* Weight gradient: dw[Cout][KH][KW][Cin] (fp32) += scale[co] * sum_pixels g[p][co] * x[pix(p,kh,kw)][ci].
- * Accumulates with float atomics (split-K over pixels and over micro-steps); zero dw once
+ * Accumulates into dw (split-K over pixels -- ordered through `ws`, or float atomics without it -- and over micro-steps); zero dw once
  * per optimizer step.  Replaces cuDNN wgrad / Linear weight grad reached through autograd
  * from aldi/trainer.py:79. */
 typedef struct {
@@ -121,6 +126,11 @@ typedef struct {
     float* db;          /* nullable: db[co] += sum over pixels of g[p][co] (the layer's bias gradient) in the same call: the lean /
                            256x256 bf16 kernels add it as one more MFMA column (a constant ones fragment) instead of re-reading g in
                            aldi_bias_grad; the other kernels fall back to that launch */
+    void* ws;           /* nullable workspace of the ORDERED epilogue (bf16 lean / 256x256 kernels): pixel splits write their partial
+                           tiles here with plain stores and a second launch adds them to dw / db in split order (no float atomics, the
+                           same bits on every run); a tile with one pixel range adds to dw with plain loads and stores.  NULL (or knob
+                           wgrad_ordered = 0): float-atomic epilogue.  A group call reads ws / ws_bytes of args[0] only. */
+    long ws_bytes;      /* >= aldi_conv_wgrad_group_workspace(args, n) */
 } aldi_wgrad_args;
 int aldi_conv_wgrad(const aldi_wgrad_args* a, aldi_stream_t stream);
 
@@ -130,6 +140,10 @@ int aldi_conv_wgrad(const aldi_wgrad_args* a, aldi_stream_t stream);
  * Problems the lean bf16 kernel cannot take (fp32, strided, unpadded KxK) are forwarded to aldi_conv_wgrad one by one.
  * Knobs wgrad_group_slots / wgrad_group_epi: how far the group's pixel ranges are split (see the knob table above). */
 int aldi_conv_wgrad_group(const aldi_wgrad_args* args, int n, aldi_stream_t stream);
+/* Bytes of workspace the ordered epilogue of this call needs under the current knobs (n = 1: of aldi_conv_wgrad); < 0: bad arguments.
+ * Layers whose Cout and K are multiples of 256 (knob wgrad_big_group, default 1) are launched together as 256x256 tiles, about one
+ * workgroup per CU (knob wgrad_big_epi: cost of one epilogue in 32-pixel steps in the split model), the others as 128x128 tiles. */
+long aldi_conv_wgrad_group_workspace(const aldi_wgrad_args* args, int n);
 
 /* db[c] += sum_m g[m][c] (bias gradients), g is [M][C] in `dtype`. */
 int aldi_bias_grad(const void* g, float* db, int M, int C, int dtype, aldi_stream_t stream);

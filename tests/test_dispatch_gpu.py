@@ -405,9 +405,12 @@ def test_wgrad_dma_split_counts(slots):
 
 
 # ---------------------------------------------------------------------------------- grouped weight gradients (one launch per layer group)
-def test_wgrad_group_equals_single_launches():
-    """a res4-like stage (the small GEMMs over the same pixels), a p2 3x3 (goes to its own 256x256-tile launch), a strided 1x1 and
-    an fp32 problem (forwarded to the single-problem dispatcher) through aldi_conv_wgrad_group == one aldi_conv_wgrad each"""
+@pytest.mark.parametrize("knobs", [(), (("wgrad_big_group", 0),), (("wgrad_ordered", 0),), (("wgrad_big_group", 0), ("wgrad_ordered", 0))],
+                         ids=["default", "no-big-group", "atomics", "r02"])
+def test_wgrad_group_equals_single_launches(knobs):
+    """a res4-like stage (the small GEMMs over the same pixels), a p2 3x3, a strided 1x1 and an fp32-ineligible problem (forwarded to the
+    single-problem dispatcher) through aldi_conv_wgrad_group == one aldi_conv_wgrad each; default: the layers whose Cout and K are
+    multiples of 256 run as ONE launch of 256x256 tiles, the rest as 128x128 tiles, pixel splits summed in order by a second launch"""
     from aldi_amd import _lib as L
     from aldi_amd import ops
     gen = torch.Generator().manual_seed(3)
@@ -415,6 +418,8 @@ def test_wgrad_group_equals_single_launches():
     cases = [(4, 50, 84, 256, 256, 3, 1, 1), (4, 50, 84, 1024, 256, 1, 1, 0), (4, 50, 84, 256, 1024, 1, 1, 0), (4, 50, 84, 256, 256, 3, 1, 1),
              (4, 25, 42, 512, 512, 3, 1, 1), (2, 200, 336, 256, 256, 3, 1, 1), (4, 100, 168, 256, 512, 1, 2, 0), (4096, 1, 1, 2304, 256, 1, 1, 0),
              (4096, 1, 1, 256, 16, 1, 1, 0)]
+    for kn, v in knobs:
+        L.set_tuning(kn, v)
     probs, refs = [], []
     for (N, H, W_, Cin, Cout, k, stride, pad) in cases:
         Ho, Wo = (H + 2 * pad - k) // stride + 1, (W_ + 2 * pad - k) // stride + 1
@@ -422,21 +427,92 @@ def test_wgrad_group_equals_single_launches():
         g = (torch.randn(N, Ho, Wo, Cout, generator=gen) * 0.1).to(dev, torch.bfloat16)
         sc = (0.5 + torch.rand(Cout, generator=gen)).to(dev)
         dw0 = torch.randn(Cout, k, k, Cin, generator=gen).to(dev)
+        db0 = torch.randn(Cout, generator=gen).to(dev) if Cout >= 64 and stride == 1 else None
         geo = dict(KH=k, KW=k, stride=stride, pad=pad, scale=sc)
-        one = dw0.clone()
-        ops.conv_wgrad(x, g, one, **geo)
-        refs.append(one)
-        probs.append((x, g, dw0.clone(), geo))
+        one, one_b = dw0.clone(), (db0.clone() if db0 is not None else None)
+        ops.conv_wgrad(x, g, one, db=one_b, **geo)
+        refs.append((one, one_b))
+        probs.append((x, g, dw0.clone(), dict(geo, db=db0.clone() if db0 is not None else None)))
     ops.conv_wgrad_group(probs)
     name = L.last_dispatch()
     torch.cuda.synchronize()
-    assert name.startswith("wgrad_bf16_lean_group n=7"), name          # 9 problems: p2 3x3 -> big tile, strided -> generic, 7 grouped
-    for (x, g, dw, geo), ref, case in zip(probs, refs, cases):
+    kn = dict(knobs)
+    ordered = " ordered" if kn.get("wgrad_ordered", 1) else ""
+    if kn.get("wgrad_big_group", 1):     # 9 problems: strided -> generic, Cout 16 -> 128x128 group of one, 7 in the 256x256 group
+        assert name.startswith("wgrad_bf16_lean_group n=1") and "| wgrad_bf16_big_group n=7" in name and name.endswith(ordered or name[-1]), name
+        wgs = int(name.split("wgrad_bf16_big_group")[1].split("wgs=")[1].split()[0])
+        assert 128 <= wgs <= 1024, name         # one to four rounds of one workgroup per CU
+    else:                                # r02 form: p2 3x3 -> its own big-tile launch, strided -> generic, 7 grouped
+        assert name.startswith("wgrad_bf16_lean_group n=7") and (ordered in name), name
+        wgs = int(name.split("wgs=")[1].split()[0])
+        assert 300 <= wgs <= 2400, name          # fewer pixel splits than the single launches
+    for (x, g, dw, geo), (ref, ref_b), case in zip(probs, refs, cases):
         e = (dw - ref).abs().max().item()
         assert e <= 2e-5 * max(1.0, ref.abs().max().item()) * max(1.0, (x.shape[0] * x.shape[1] * x.shape[2] / 1024) ** 0.5), (case, e)
-    # fewer pixel splits than the single launches: the whole group fits ~one wave of workgroups
-    wgs = int(name.split("wgs=")[1].split()[0])
-    assert 300 <= wgs <= 2400, name
+        if ref_b is not None:
+            eb = (geo["db"] - ref_b).abs().max().item()
+            assert eb <= 2e-5 * max(1.0, ref_b.abs().max().item()) * max(1.0, (x.shape[0] * x.shape[1] * x.shape[2] / 1024) ** 0.5), (case, eb)
+
+
+def test_wgrad_ordered_epilogue_is_reproducible_and_equals_the_fp64_sum():
+    """the ordered epilogue (partials to a workspace, splits added in index order) gives the same BITS on every run -- the float-atomic
+    one does not promise that -- for a split single launch, an unsplit one, and a group; checked against the fp64 product too"""
+    from aldi_amd import _lib as L
+    from aldi_amd import ops
+    gen = torch.Generator().manual_seed(11)
+    dev = "cuda"
+    cases = [(4, 50, 84, 256, 256, 3), (4, 50, 84, 1024, 256, 1), (2, 100, 168, 128, 128, 3), (4, 25, 42, 2048, 512, 1), (300, 1, 1, 1024, 1024, 1)]
+    data = []
+    for (N, H, W_, Cin, Cout, k) in cases:
+        x = torch.randn(N, H, W_, Cin, generator=gen).to(dev, torch.bfloat16)
+        g = (torch.randn(N, H, W_, Cout, generator=gen) * 0.1).to(dev, torch.bfloat16)
+        data.append((x, g, k, torch.randn(Cout, k, k, Cin, generator=gen).to(dev), torch.randn(Cout, generator=gen).to(dev)))
+    def run(group):
+        outs = [(dw0.clone(), db0.clone()) for (_, _, _, dw0, db0) in data]
+        if group:
+            ops.conv_wgrad_group([(x, g, o[0], dict(KH=k, KW=k, stride=1, pad=k // 2, db=o[1])) for (x, g, k, _, _), o in zip(data, outs)])
+        else:
+            for (x, g, k, _, _), o in zip(data, outs):
+                ops.conv_wgrad(x, g, o[0], KH=k, KW=k, stride=1, pad=k // 2, db=o[1])
+                assert L.last_dispatch().endswith(" ordered"), L.last_dispatch()
+        torch.cuda.synchronize()
+        return outs
+    for group in (False, True):
+        a, b = run(group), run(group)
+        for (wa, ba), (wb, bb), (x, g, k, dw0, db0), case in zip(a, b, data, cases):
+            assert torch.equal(wa, wb) and torch.equal(ba, bb), (group, case)
+            ref = dw0.double() + _wgrad_ref(x, g, k, 1, k // 2)
+            M = x.shape[0] * x.shape[1] * x.shape[2]
+            assert (wa.double() - ref).abs().max().item() <= 3e-6 * max(1.0, ref.abs().max().item()) * max(1.0, (M / 1024) ** 0.5), (group, case)
+            refb = db0.double() + g.double().reshape(-1, g.shape[-1]).sum(0)
+            assert (ba.double() - refb).abs().max().item() <= 3e-6 * max(1.0, refb.abs().max().item()) * max(1.0, (M / 1024) ** 0.5), (group, case)
+
+
+def test_wgrad_group_layers_sharing_one_gradient_buffer():
+    """one conv applied to several pyramid levels (the RPN conv): the problems of the group accumulate into the SAME dw / db -- the
+    ordered epilogue's plain read-modify-write would race, those problems keep the atomic one; == the fp64 sum over levels"""
+    from aldi_amd import ops
+    gen = torch.Generator().manual_seed(21)
+    dw = torch.zeros(256, 3, 3, 256, device="cuda")
+    db = torch.zeros(256, device="cuda")
+    other = torch.zeros(256, 1, 1, 512, device="cuda")
+    ref = torch.zeros(256, 3, 3, 256, dtype=torch.float64, device="cuda")
+    refb = torch.zeros(256, dtype=torch.float64, device="cuda")
+    probs = []
+    for (N, H, W_) in [(2, 100, 168), (2, 50, 84), (2, 25, 42), (2, 13, 21)]:
+        x = torch.randn(N, H, W_, 256, generator=gen).to("cuda", torch.bfloat16)
+        g = (torch.randn(N, H, W_, 256, generator=gen) * 0.1).to("cuda", torch.bfloat16)
+        probs.append((x, g, dw, dict(KH=3, KW=3, stride=1, pad=1, db=db)))
+        ref += _wgrad_ref(x, g, 3, 1, 1)
+        refb += g.double().reshape(-1, 256).sum(0)
+    x = torch.randn(2, 50, 84, 512, generator=gen).to("cuda", torch.bfloat16)
+    g = (torch.randn(2, 50, 84, 256, generator=gen) * 0.1).to("cuda", torch.bfloat16)
+    probs.append((x, g, other, dict(KH=1, KW=1, stride=1, pad=0)))
+    ops.conv_wgrad_group(probs)
+    torch.cuda.synchronize()
+    assert (dw.double() - ref).abs().max().item() <= 3e-5 * ref.abs().max().item()
+    assert (db.double() - refb).abs().max().item() <= 3e-5 * refb.abs().max().item()
+    assert (other.double() - _wgrad_ref(x, g, 1, 1, 0)).abs().max().item() <= 3e-5 * other.abs().max().item()
 
 
 @pytest.mark.parametrize("slots", [0, 1, 4000])
@@ -520,12 +596,39 @@ def test_conv_group_of_different_layers_falls_back():
     from aldi_amd import _lib as L
     from aldi_amd import ops
     x1 = torch.randn(2, 20, 24, 64, device="cuda").bfloat16()
-    x2 = torch.randn(2, 10, 12, 64, device="cuda").bfloat16()
-    w = torch.randn(64, 3, 3, 64, device="cuda").bfloat16()
-    a, b = ops.conv2d_group([(x1, w, dict(pad=1)), (x2, w, dict(pad=1))])
+    x2 = torch.randn(2, 10, 12, 32, device="cuda").bfloat16()
+    w1 = torch.randn(64, 3, 3, 64, device="cuda").bfloat16()
+    w2 = torch.randn(64, 3, 3, 32, device="cuda").bfloat16()
+    a, b = ops.conv2d_group([(x1, w1, dict(pad=1)), (x2, w2, dict(pad=1))])          # different Cin: not one layer shape
     assert not L.last_dispatch().startswith("igemm_group")
     torch.cuda.synchronize()
-    assert torch.equal(a, ops.conv2d(x1, w, pad=1)) and torch.equal(b, ops.conv2d(x2, w, pad=1))
+    assert torch.equal(a, ops.conv2d(x1, w1, pad=1)) and torch.equal(b, ops.conv2d(x2, w2, pad=1))
+
+
+@pytest.mark.parametrize("k,pad", [(3, 1), (1, 0)])
+def test_conv_group_over_pyramid_levels(k, pad):
+    """one layer (shared or per-level weights of the same shape) on maps of DIFFERENT H x W and batch size -- the FPN output convs, the
+    RPN conv on p2..p6, student and teacher together -- is one launch (up to 12 problems), bit-identical to the single launches"""
+    from aldi_amd import _lib as L
+    from aldi_amd import ops
+    gen = torch.Generator().manual_seed(31)
+    calls = []
+    for (N, H, W_) in [(4, 100, 168), (4, 50, 84), (4, 25, 42), (4, 13, 21), (2, 100, 168), (2, 50, 84), (2, 25, 42), (2, 13, 21), (1, 7, 11)]:
+        x = torch.randn(N, H, W_, 256, generator=gen).to("cuda", torch.bfloat16)
+        w = (torch.randn(256, k, k, 256, generator=gen) * 0.05).to("cuda", torch.bfloat16)
+        sh = torch.randn(256, generator=gen).to("cuda")
+        calls.append((x, w, dict(pad=pad, shift=sh, relu=True)))
+    outs = ops.conv2d_group(calls)
+    name = L.last_dispatch()
+    torch.cuda.synchronize()
+    assert name.startswith("igemm_group9<"), name
+    for (x, w, kw), y in zip(calls, outs):
+        assert torch.equal(y, ops.conv2d(x, w, **kw)), (tuple(x.shape), name, L.last_dispatch())
+    outs13 = ops.conv2d_group(calls + calls[:4])            # more than 12: single launches
+    assert not L.last_dispatch().startswith("igemm_group")
+    torch.cuda.synchronize()
+    for a, b in zip(outs13, outs + outs[:4]):
+        assert torch.equal(a, b)
 
 
 @pytest.mark.parametrize("shape", [(2, 50, 84, 256, 512), (1, 25, 41, 128, 64), (3, 13, 21, 64, 256)])
