@@ -1125,7 +1125,7 @@ int launch_group(const WgDev* probs, int ng, bool big, hipStream_t st, WsCarver&
     if (dry) return ALDI_OK;
     if (big) hipLaunchKernelGGL(wgrad_bf16_big_group_kernel, dim3(wg), dim3(512), 0, st, L_);
     else if (tn.wgrad_db) hipLaunchKernelGGL(wgrad_bf16_lean_group_db_kernel, dim3(wg), dim3(256), 0, st, L_);
-    else hipLaunchKernelGGL(wgrad_bf16_lean_group_kernel, dim3(wg), dim3(256), 0, st, L_);
+    else hipLaunchKernelGGL(wgrad_bf16_lean_group_kernel, dim3(wg), dim3(256), (size_t)tn.wgrad_lds_pad_kb << 10, st, L_);
     ALDI_CHECK_LAUNCH();
     snprintf(name, name_len, "wgrad_bf16_%s_group%s n=%d wgs=%d pix=%ld%s", big ? "big" : "lean", (!big && tn.wgrad_db) ? "_db" : "", ng, wg, T, ordered ? " ordered" : "");
     return ALDI_OK;

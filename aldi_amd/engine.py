@@ -1456,7 +1456,8 @@ class RCNN:
 
     def _wgrad_stream(self):
         if not hasattr(self, "_wg_side"):
-            self._wg_side = torch.cuda.Stream(device=self.device) if os.environ.get("ALDI_WGRAD_STREAM", "1") == "1" else None
+            self._wg_side = (torch.cuda.Stream(device=self.device, priority=int(os.environ.get("ALDI_WGRAD_PRIO", "0")))
+                             if os.environ.get("ALDI_WGRAD_STREAM", "1") == "1" else None)
             self._wgrad_pending = False
         return self._wg_side
 

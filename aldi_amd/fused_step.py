@@ -734,7 +734,13 @@ class FusedStep:
             self.pool = torch.cuda.graph_pool_handle()
         torch.cuda.synchronize()
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g, pool=self.pool, capture_error_mode="thread_local"):
+        prio = int(os.environ.get("ALDI_MAIN_PRIO", "0"))
+        kw = {}
+        if prio:                      # the serial chain of the step on a high-priority stream: its small launches are not queued
+            if not hasattr(self, "_cap_stream"):      # behind the (long) workgroups of the weight-gradient stream
+                self._cap_stream = torch.cuda.Stream(device=self.eng.device, priority=prio)
+            kw["stream"] = self._cap_stream
+        with torch.cuda.graph(g, pool=self.pool, capture_error_mode="thread_local", **kw):
             out = fn()
         self.stats["captures"] += 1
         return g, out

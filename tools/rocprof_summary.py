@@ -62,6 +62,32 @@ def gaps(d, top="15"):
         print("%9.1f us   after %-60s before %s" % (us, n0, n1))
 
 
+def streams(d, t_from="0"):
+    """launch list of one step with the hardware queue of every kernel: which launches run beside which (the dgrad chain vs the
+    weight-gradient launches of the side stream)"""
+    import re
+    dbs = glob.glob(d + "/**/*_results.db", recursive=True)
+    cur = sqlite3.connect(dbs[0]).cursor()
+    rows = list(cur.execute("select name, start, end, queue_id, grid_x, workgroup_x from kernels order by start"))
+    sgd = [i for i, r in enumerate(rows) if delim in r[0]]
+    a, b = sgd[-1 - int(per_step)], sgd[-1]
+    t0 = rows[a][2]
+    def short(n):
+        n = n.replace("(anonymous namespace)::", "").replace("void ", "")
+        m = re.match(r"([A-Za-z0-9_:]+)(<[^(]*>)?", n)
+        s_ = m.group(1)
+        if "igemm" in s_ and m.group(2):
+            s_ += m.group(2).replace("unsigned short", "bf16").replace(" ", "")
+        return s_[:64]
+    step = rows[a + 1:b + 1]
+    qs = sorted({r[3] for r in step})
+    print("# one step, kernel launches by start time: start ms, end ms, hardware queue, duration, kernel, workgroups; busy per queue: " +
+          ", ".join("q%d %.2f ms" % (q, sum(r[2] - r[1] for r in step if r[3] == q) / 1e6) for q in qs))
+    for n, s_, e, q, gx, wx in step:
+        if (s_ - t0) / 1e6 >= float(t_from):
+            print("%8.3f %8.3f q%d %7.1fus %s wg=%d" % ((s_ - t0) / 1e6, (e - t0) / 1e6, q, (e - s_) / 1e3, short(n), gx // max(wx, 1)))
+
+
 def overlap(d):
     """multi-stream view of one step: union busy time, time with >= 2 kernels in flight, idle time"""
     dbs = glob.glob(d + "/**/*_results.db", recursive=True)
@@ -198,4 +224,4 @@ def pmc(fetch_dir, write_dir, source_sha="", git_sha=""):
 
 
 if __name__ == "__main__":
-    {"stats": stats, "pmc": pmc, "gaps": gaps, "overlap": overlap, "phases": phases, "window": window, "launches": launches}[sys.argv[1]](*sys.argv[2:])
+    {"stats": stats, "pmc": pmc, "gaps": gaps, "overlap": overlap, "phases": phases, "window": window, "launches": launches, "streams": streams}[sys.argv[1]](*sys.argv[2:])
