@@ -42,6 +42,7 @@ const Knob kKnobs[] = {
     {"igemm_force", &AldiTuning::igemm_force, 0},
     {"igemm_k64_min", &AldiTuning::igemm_k64_min, 1024},
     {"igemm_group", &AldiTuning::igemm_group, 1},
+    {"igemm_narrow_k", &AldiTuning::igemm_narrow_k, 512},
     {"wgrad_lean", &AldiTuning::wgrad_lean, 1},
     {"wgrad_big_min", &AldiTuning::wgrad_big_min, 28},
     {"wgrad_big_slots", &AldiTuning::wgrad_big_slots, 256},

@@ -485,6 +485,23 @@ __global__ void sgd_kernel(float* __restrict__ p, const float* __restrict__ g, f
     }
 }
 
+// the same update with its scalars read from device memory (hyper = lr, momentum, weight decay, gradient scale): the launch can sit
+// in a replayed hipGraph while the learning-rate schedule moves (the host refreshes the four floats before the replay)
+template <typename T>
+__global__ void sgd_dev_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ buf, T* __restrict__ pc,
+                               long n, const float* __restrict__ hyper) {
+    const float lr = hyper[0], mu = hyper[1], wd = hyper[2], gscale = hyper[3];
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        float w = p[i];
+        const float d = g[i] * gscale + wd * w;
+        const float b = mu * buf[i] + d;
+        buf[i] = b;
+        w = w - lr * b;
+        p[i] = w;
+        if (pc) Elem<T>::st(pc + i, w);
+    }
+}
+
 // reference aldi/ema.py:43-46:  t = s*(1-alpha) + t*alpha   (copy_only: t = s, aldi/ema.py:29-30)
 // tc (nullable): the compute-dtype copy of the first nc elements (the weights), written in the same pass
 template <typename T>
@@ -683,6 +700,15 @@ extern "C" int aldi_sgd_step(float* p, const float* g, float* buf, void* p_compu
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (dtype == ALDI_BF16) hipLaunchKernelGGL(sgd_kernel<bf16_t>, dim3(nblocks(n)), dim3(256), 0, st, p, g, buf, (bf16_t*)p_compute, n, lr, momentum, weight_decay, grad_scale, first_step);
     else hipLaunchKernelGGL(sgd_kernel<float>, dim3(nblocks(n)), dim3(256), 0, st, p, g, buf, (float*)nullptr, n, lr, momentum, weight_decay, grad_scale, first_step);
+    ALDI_CHECK_LAUNCH();
+    return ALDI_OK;
+}
+
+extern "C" int aldi_sgd_step_dev(float* p, const float* g, float* buf, void* p_compute, long n, const float* hyper, int dtype, aldi_stream_t stream) {
+    if (!p || !g || !buf || !hyper || n <= 0) return aldi_set_error_msg(ALDI_ERR_ARG, "sgd_step_dev: bad args");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (dtype == ALDI_BF16) hipLaunchKernelGGL(sgd_dev_kernel<bf16_t>, dim3(nblocks(n)), dim3(256), 0, st, p, g, buf, (bf16_t*)p_compute, n, hyper);
+    else hipLaunchKernelGGL(sgd_dev_kernel<float>, dim3(nblocks(n)), dim3(256), 0, st, p, g, buf, (float*)nullptr, n, hyper);
     ALDI_CHECK_LAUNCH();
     return ALDI_OK;
 }

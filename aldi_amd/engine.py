@@ -9,6 +9,7 @@ aldi/distill.py:157,162 and aldi/pseudolabeler.py:21, and autograd's backward at
 """
 from __future__ import annotations
 
+import contextlib
 import dataclasses
 import inspect
 import math
@@ -244,11 +245,21 @@ class Weights:
         n = self.layout.n_train
         ops.sgd_step(self.master, self.grad, self.mom, self.compute if self.dtype != torch.float32 else None, n, lr, momentum,
                      weight_decay, grad_scale * getattr(self, "_gscale", 1.0), self.first_step, self.dtype)
+        self._after_sgd()
+
+    def _after_sgd(self):
         self.first_step = False
         if self.lazy_wt:
             self._wt_dirty = True        # re-derived where the next backward needs them (the fused step does it beside its forward)
         else:
             self._refresh_wt()
+
+    def sgd_range_dev(self, lo: int, hi: int, hyper: torch.Tensor):
+        """the optimizer step of elements [lo, hi) with device-resident scalars (ops.sgd_step_dev): issued per layer group from
+        inside the backward by the fused step"""
+        hi = min(hi, self.layout.n_train)
+        if hi > lo:
+            ops.sgd_step_dev(self.master, self.grad, self.mom, self.compute if self.dtype != torch.float32 else None, lo, hi, hyper, self.dtype)
 
     def ema_from(self, student: "Weights", alpha: float, copy_only: bool):
         """reference aldi/ema.py:29-57 over the whole state (params AND buffers)."""
@@ -493,18 +504,41 @@ class RCNN:
             return e.value
 
     @staticmethod
-    def drive_pair(eng_a, gen_a, eng_b, gen_b):
-        """advance two engines' generators together, one grouped launch per pair of requests -> (result_a, result_b)"""
+    def drive_pair(eng_a, gen_a, eng_b, gen_b, streams=None):
+        """advance two engines' generators together, one grouped launch per pair of requests -> (result_a, result_b).
+        streams = (stream_a, stream_b): no grouping -- each model's launches go to its own stream, ISSUED alternately (a hipGraph
+        hands its nodes to the queues in capture order: a branch captured after the other one starts when the host has submitted
+        everything before it, 2 ms into the phase for the teacher's pass behind the student's trunk)"""
         res = [None, None]
+        ctx_a = torch.cuda.stream(streams[0]) if streams else contextlib.nullcontext()
+        ctx_b = torch.cuda.stream(streams[1]) if streams else contextlib.nullcontext()
         try:
-            ra = next(gen_a)
+            with ctx_a:
+                ra = next(gen_a)
         except StopIteration as e:
             ra, res[0] = None, e.value
         try:
-            rb = next(gen_b)
+            with ctx_b:
+                rb = next(gen_b)
         except StopIteration as e:
             rb, res[1] = None, e.value
         while ra is not None or rb is not None:
+            if streams:
+                if ra is not None:
+                    with ctx_a:
+                        ya = eng_a._serve(ra)
+                        try:
+                            ra = gen_a.send(ya)
+                        except StopIteration as e:
+                            ra, res[0] = None, e.value
+                if rb is not None:
+                    with ctx_b:
+                        yb = eng_b._serve(rb)
+                        try:
+                            rb = gen_b.send(yb)
+                        except StopIteration as e:
+                            rb, res[1] = None, e.value
+                continue
             if ra is not None and rb is not None:
                 la, lb = (ra if isinstance(ra, list) else [ra]), (rb if isinstance(rb, list) else [rb])
                 ys = ops.conv2d_group([eng_a._conv_call(r[0], r[1], **r[2]) for r in la] + [eng_b._conv_call(r[0], r[1], **r[2]) for r in lb])

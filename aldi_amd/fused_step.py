@@ -70,6 +70,48 @@ class _Packed:
         self.dev.copy_(self.host, non_blocking=True)
 
 
+class _GroupSGD:
+    """`grad_ready` receiver of the single-GPU fused step: SGD over the reported ranges of the flat parameter buffer, on its own
+    stream behind the producers' events; `finish` covers whatever was not reported and joins the main stream"""
+    def __init__(self, eng, hyper):
+        self.eng, self.hyper, self.done = eng, hyper, []
+        if getattr(eng, "_sgd_side", None) is None:          # (False: on the caller's stream -- ALDI_SGD_STREAM=0, single-stream profiles)
+            eng._sgd_side = torch.cuda.Stream(device=eng.device) if os.environ.get("ALDI_SGD_STREAM", "1") == "1" else False
+        self.stream = eng._sgd_side or torch.cuda.current_stream()
+
+    @staticmethod
+    def _merge(ranges):
+        out = []
+        for lo, hi in sorted((int(a), int(b)) for a, b in ranges):
+            if out and lo <= out[-1][1]:
+                out[-1][1] = max(out[-1][1], hi)
+            else:
+                out.append([lo, hi])
+        return out
+
+    def ready(self, ranges, evs):
+        for ev in evs:
+            self.stream.wait_event(ev)
+        with torch.cuda.stream(self.stream):
+            for lo, hi in self._merge(ranges):
+                self.eng.wts.sgd_range_dev(lo, hi, self.hyper)
+        self.done += [(int(a), int(b)) for a, b in ranges]
+
+    def finish(self):
+        main = torch.cuda.current_stream()
+        rest, at = [], 0
+        for lo, hi in self._merge(self.done) + [[self.eng.wts.layout.n_train, self.eng.wts.layout.n_train]]:
+            if lo > at:
+                rest.append((at, min(lo, self.eng.wts.layout.n_train)))
+            at = max(at, hi)
+        if rest:
+            self.stream.wait_stream(main)                  # (the backward has joined its weight-gradient stream by now)
+            with torch.cuda.stream(self.stream):
+                for lo, hi in rest:
+                    self.eng.wts.sgd_range_dev(lo, hi, self.hyper)
+        main.wait_stream(self.stream)
+
+
 class FusedStep:
     def __init__(self, trainer):
         self.tr = trainer
@@ -82,6 +124,7 @@ class FusedStep:
         # latency-bound proposal / box-head / detection chain then runs alone after the paired trunk, and the EMA tick before it)
         self.pair_forward = os.environ.get("ALDI_PAIR_FORWARD", "0") == "1"
         self.teacher_first = os.environ.get("ALDI_TEACHER_FIRST", "0") == "1"
+        self.interleave = os.environ.get("ALDI_INTERLEAVE", "1") == "1"
         self.spin_wait = os.environ.get("ALDI_SPIN_WAIT", "1") == "1"
         self.warmup = 3                     # eager steps before capturing (lazy initialisation: anchors, dgrad weights, workspaces)
         self.dp_graph_ok = True             # cleared if recording phase B together with its collectives ever fails
@@ -138,6 +181,8 @@ class FusedStep:
     def _phase_a(self, S):
         eng, teng, dist_ = self.eng, self.teng, self.tr.distiller
         main = torch.cuda.current_stream()
+        if os.environ.get("ALDI_PROBE_SPIN_CYCLES"):         # (probe: a busy-wait kernel in front of the fork)
+            torch.cuda._sleep(int(os.environ["ALDI_PROBE_SPIN_CYCLES"]))
         ev0 = torch.cuda.Event()
         ev0.record(main)                                     # the teacher may start here: beside the student's trunk
         N = S.N
@@ -145,8 +190,21 @@ class FusedStep:
         tea, tside = S.tea, S.tside
         shapes, geom, anchors = eng.geometry(stu.img.shape[2], stu.img.shape[3])
         pair = S.distill and self.pair_forward and type(eng) is RCNN and type(teng) is RCNN
+        inter = S.distill and self.interleave and not pair and tside is not None and type(eng) is RCNN and type(teng) is RCNN
         tcx = None
-        if pair:
+        if inter:
+            # Student on the main stream, teacher on its own, their launches ISSUED alternately layer by layer: both branches of the
+            # captured graph are fed from the first microsecond (captured one after the other, the second branch's first node
+            # reaches its queue when the host has submitted the whole first branch: the teacher's serial chain of small launches
+            # -- which the student's anchor matching waits for -- then starts 2 ms late and runs its last 1.5 ms alone)
+            tside.wait_event(ev0)
+            if S.ema_mode is not None:
+                with torch.cuda.stream(tside):
+                    teng.wts.ema_from(eng.wts, S.ema_alpha, copy_only=S.ema_mode == "copy")
+            with torch.no_grad():
+                c, tcx = RCNN.drive_pair(eng, eng.trunk_steps(stu.img, stu.sizes, True), teng, teng.trunk_steps(tea.img, tea.sizes, False), streams=(main, tside))
+                RCNN.drive_pair(eng, eng.rpn_head_steps(c, True), teng, teng.rpn_head_steps(tcx, False), streams=(main, tside))
+        elif pair:
             # Student (N = 4) and teacher (N = 2) go through the same layers with different weights: ONE launch per layer for both
             # (engine.RCNN.drive_pair -> aldi_conv_igemm_group) instead of two half-empty ones on two streams.  The EMA tick has
             # to come first then (the teacher's weights are read from the first layer on).
@@ -188,7 +246,7 @@ class FusedStep:
             # The teacher's inference (N = 2, mostly small launches) runs on its own stream beside the student's label-free work
             # and is ENQUEUED after it (issued first its launches would run alone while the student's are still being queued).
             def teacher_pass():
-                if pair:
+                if pair or inter:
                     return teng.inference_heads(tcx, tea.img, tea.sizes, tea.hw, dist_.pseudo_label_threshold, pl_out=S.pl_out)
                 if S.ema_mode is not None:                   # the EMA tick of this iteration (aldi/trainer.py:242-246), beside the student's forward
                     teng.wts.ema_from(eng.wts, S.ema_alpha, copy_only=S.ema_mode == "copy")
@@ -199,7 +257,7 @@ class FusedStep:
             elif tside is not None:
                 if pair:
                     tside.wait_stream(main)
-                else:
+                elif not inter:
                     tside.wait_event(ev0)
                 with torch.cuda.stream(tside), torch.no_grad():
                     tc = teacher_pass()
@@ -469,7 +527,20 @@ class FusedStep:
         c.chunks = S.chunks
         c.align, c.distill = {}, None
         holder = {}
-        eng.backward_fused(c, scales, after_losses=lambda: holder.update(loss_dict=self._loss_dict(S, accum, main)))
+        if S.sgd:
+            # The optimizer step rides inside the backward: a layer group's parameters are updated (on a third stream, behind the
+            # group's producer events) as soon as its weight gradients are complete -- box head first, res3 last -- so that the
+            # 0.9 GB the update streams through HBM overlaps the MFMA-bound rest of the backward instead of following it.
+            applier = _GroupSGD(eng, S.hyper)
+            prev_cb = getattr(eng, "grad_ready", None)
+            eng.grad_ready = applier.ready
+            try:
+                eng.backward_fused(c, scales, after_losses=lambda: holder.update(loss_dict=self._loss_dict(S, accum, main)))
+            finally:
+                eng.grad_ready = prev_cb
+            applier.finish()
+        else:
+            eng.backward_fused(c, scales, after_losses=lambda: holder.update(loss_dict=self._loss_dict(S, accum, main)))
         loss_dict = holder["loss_dict"]
         if S.tside is not None:
             main.wait_stream(S.tside)
@@ -535,7 +606,9 @@ class FusedStep:
             self.static[key] = self.static.pop(key)
         return S
 
-    def run(self, labeled_weak, labeled_strong, unlabeled_weak, unlabeled_strong, ema=None, zero_grad=False, reducer=None):
+    def run(self, labeled_weak, labeled_strong, unlabeled_weak, unlabeled_strong, ema=None, zero_grad=False, reducer=None, sgd=None):
+        """sgd = (lr, momentum, weight_decay): the optimizer step the caller would run right after this (EngineSGD.step), applied here
+        instead, layer group by layer group as the backward completes their gradients (sets eng.wts._sgd_applied)"""
         from .model import DevicePseudoLabels
         from .trainer import _schedule_flags, _teacher_stream, plan_micro_steps
         tr = self.tr
@@ -583,8 +656,14 @@ class FusedStep:
             else:
                 ema[0].update_weights(model, ema[1])               # not the teacher of this step's distiller: nothing to overlap with
         key = (tuple((ch["name"], ch["n1"] - ch["n0"]) for ch in chunks), tuple(tuple(im.shape[1:]) for im in images),
-               tuple(tuple(d["image"].shape[1:]) for d in (unlabeled_weak or [])) if do_distill else (), ema_mode, bool(zero_grad))
+               tuple(tuple(d["image"].shape[1:]) for d in (unlabeled_weak or [])) if do_distill else (), ema_mode, bool(zero_grad), sgd is not None)
         S = self._static_for(key)
+        S.sgd = sgd is not None
+        if S.sgd:
+            if getattr(S, "hyper_host", None) is None:
+                S.hyper_host = torch.zeros(4, dtype=torch.float32).pin_memory()
+                S.hyper = torch.zeros(4, dtype=torch.float32, device=dev)
+            S.hyper_vals = (float(sgd[0]), float(sgd[1]), float(sgd[2]))
         S.N, S.chunks, S.accum, S.distill, S.has_disc = N, chunks, accum, do_distill, do_align
         S.nk = kd                                                  # distillation micro-steps; their images are the last ones: d0 .. N
         S.d0 = min([ch["n0"] for ch in chunks if ch["kind"] == "distill"], default=N)
@@ -665,6 +744,9 @@ class FusedStep:
         dp = getattr(eng, "grad_ready", None) is not None
         dp_graph = dp and reducer is not None and self.dp_graph_ok and reducer.capturable()
         graph_b = use_graph and (not dp or dp_graph) and os.environ.get("ALDI_STEP_GRAPH_B", "1") == "1"
+        if S.sgd:                                                   # this iteration's learning rate etc. for the recorded optimizer launches
+            S.hyper_host[0], S.hyper_host[1], S.hyper_host[2], S.hyper_host[3] = S.hyper_vals + (float(getattr(eng.wts, "_gscale", 1.0)),)
+            S.hyper.copy_(S.hyper_host, non_blocking=True)
         evs[2].record()
         ent = None
         if graph_b:
@@ -708,6 +790,8 @@ class FusedStep:
             B = self._phase_b(S, A, Hst)
             if not use_graph:
                 self.stats["eager"] += 1
+        if S.sgd:
+            eng.wts._sgd_applied = True            # recorded or eager, phase B contained this iteration's optimizer step: EngineSGD.step skips its launch
         evs[3].record()
         t4 = time.perf_counter()
         for k_, v_ in (("host_us_issue_a", t1 - t0), ("host_us_wait_a", t2 - t1), ("host_us_draws", t3 - t2), ("host_us_issue_b", t4 - t3)):

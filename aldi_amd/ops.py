@@ -372,6 +372,12 @@ def sgd_step(p, g, buf, p_compute, n, lr, momentum, weight_decay, grad_scale, fi
            dtype_code(dtype), stream_ptr())
 
 
+def sgd_step_dev(p, g, buf, p_compute, lo: int, hi: int, hyper: torch.Tensor, dtype) -> None:
+    """SGD over elements [lo, hi) of the flat buffers, scalars (lr, momentum, weight decay, gradient scale) from the device tensor `hyper`"""
+    pc = None if p_compute is None else p_compute.data_ptr() + lo * p_compute.element_size()
+    L.call("aldi_sgd_step_dev", p.data_ptr() + 4 * lo, g.data_ptr() + 4 * lo, buf.data_ptr() + 4 * lo, pc, hi - lo, _p(hyper), dtype_code(dtype), stream_ptr())
+
+
 def ema_update(teacher, student, teacher_compute, n, alpha, copy_only, dtype, n_compute=None) -> None:
     nc = 0 if teacher_compute is None else (teacher_compute.numel() if n_compute is None else n_compute)
     L.call("aldi_ema_update", _p(teacher), _p(student), _p(teacher_compute), n, nc, alpha, int(copy_only), dtype_code(dtype), stream_ptr())

@@ -260,8 +260,13 @@ class EngineSGD:
         self.model.weights.zero_grad()
 
     def step(self):
+        W = self.model.weights
+        if getattr(W, "_sgd_applied", False):        # the fused step ran this iteration's update inside its backward (FusedStep.run(sgd=...))
+            W._sgd_applied = False
+            W._after_sgd()
+            return
         g = self.param_groups[0]
-        self.model.weights.sgd_step(g["lr"], g["momentum"], g["weight_decay"])
+        W.sgd_step(g["lr"], g["momentum"], g["weight_decay"])
 
     def state_dict(self):
         """checkpointable (detectron2 saves the optimizer through `trainer._trainer.optimizer`): the flat momentum buffer"""
@@ -372,7 +377,10 @@ class SimpleTrainer:
                 self._zero_pending = True            # run_model clears the gradients itself (fused step: beside its forward)
             else:
                 self.optimizer.zero_grad()
+        if self._defers_sgd():
+            self._sgd_pending = True                 # run_model may apply this iteration's optimizer step itself (fused step: inside its backward)
         loss_dict = self.run_model(data)
+        self.__dict__.pop("_sgd_pending", None)
         if isinstance(loss_dict, torch.Tensor):
             losses = loss_dict
             loss_dict = {"total_loss": loss_dict}
@@ -392,6 +400,10 @@ class SimpleTrainer:
 
     def _defers_zero_grad(self) -> bool:
         """True when run_model clears the gradients itself (the fused step does it on a side stream beside its forward)"""
+        return False
+
+    def _defers_sgd(self) -> bool:
+        """True when run_model may run this iteration's optimizer step itself (and then sets weights._sgd_applied for EngineSGD.step)"""
         return False
 
     def do_backward(self, losses):
@@ -465,6 +477,11 @@ class _ALDITrainer:
         # (only the flat R50 weight container: the ViTDet / ConvNeXt models keep their trunk's gradients in a second buffer)
         return bool(self.fused) and os.environ.get("ALDI_FUSED_LEGACY", "0") != "1" and type(getattr(model, "engine", None)) is RCNN
 
+    def _defers_sgd(self) -> bool:
+        W = getattr(self.model, "weights", None)
+        return (self._defers_zero_grad() and isinstance(self.optimizer, EngineSGD) and not _data_parallel() and W is not None
+                and not W.first_step and os.environ.get("ALDI_SGD_IN_STEP", "0") == "1")
+
     def run_model(self, data):
         self._fused_done = False
         pending_ema = self.__dict__.pop("_pending_ema", None)       # the EMA tick `before_step` left for the fused step to run
@@ -494,7 +511,11 @@ class _ALDITrainer:
                 if getattr(self, "_fused_step", None) is None:
                     from .fused_step import FusedStep
                     self._fused_step = FusedStep(self)
-                return self._fused_step.run(*data, ema=pending_ema, zero_grad=defer, reducer=reducer)
+                sgd = None
+                if self.__dict__.pop("_sgd_pending", False) and reducer is None:
+                    g_ = self.optimizer.param_groups[0]
+                    sgd = (g_["lr"], g_["momentum"], g_["weight_decay"])
+                return self._fused_step.run(*data, ema=pending_ema, zero_grad=defer, reducer=reducer, sgd=sgd)
             finally:
                 eng.grad_ready = None
         return run_model_labeled_unlabeled(self, *data)

@@ -232,6 +232,35 @@ def profile_insitu(step_fn, table_path=None):
         rec.append((key, 2.0 * N * Ho * Wo * Cout * KH * KW * Cin, nby, e0, e1))
         return y
 
+    def conv_cost(x, w, kw):
+        N, H, W_, Cin = x.shape
+        Cout, KH, KW, _ = w.shape
+        s, p = kw.get("stride", 1), kw.get("pad", 0)
+        Ho, Wo = (H + 2 * p - KH) // s + 1, (W_ + 2 * p - KW) // s + 1
+        esz = x.element_size()
+        osz = 4 if kw.get("want_f32") else esz
+        nby = esz * (x.numel() + w.numel()) + osz * N * Ho * Wo * Cout \
+            + (esz * N * Ho * Wo * Cout if kw.get("mask") is not None else 0) \
+            + (esz * N * Ho * Wo * Cout // (4 if kw.get("res_mode", 0) == 2 else 1) if kw.get("res_mode", 0) else 0)
+        return 2.0 * N * Ho * Wo * Cout * KH * KW * Cin, nby
+    orig_cgroup = ops.conv2d_group
+
+    def conv2d_group(calls):
+        """one layer on several pyramid levels (FPN output convs, the RPN conv, their dgrads) in one launch: timed as one, its
+        FLOPs / bytes are the sums"""
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        ys = orig_cgroup(calls)
+        e1.record()
+        fl = nby = 0
+        for x, w, kw in calls:
+            f, b = conv_cost(x, w, kw)
+            fl += f; nby += b
+        x0, w0, kw0 = calls[0]
+        rec.append((("igemm", "group of %d" % len(calls), sum(c[0].shape[0] * c[0].shape[1] * c[0].shape[2] for c in calls), x0.shape[3], w0.shape[0], w0.shape[1],
+                     kw0.get("stride", 1), kw0.get("pad", 0), bool(kw0.get("relu"))), fl, nby, e0, e1))
+        return ys
+
     def conv_wgrad(x, g, dw, **kw):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
@@ -272,6 +301,11 @@ def profile_insitu(step_fn, table_path=None):
     def sgd_step(p_, g, buf, p_compute, n, *a, **kw):     # reads master, gradient, momentum; writes master, momentum, the bf16 compute copy
         return timed("sgd", (n,), 0.0, n * (20 + (2 if p_compute is not None else 0)), orig_sgd, p_, g, buf, p_compute, n, *a, **kw)
 
+    orig_sgd_dev = ops.sgd_step_dev
+
+    def sgd_step_dev(p_, g, buf, p_compute, lo, hi, *a, **kw):       # the same update in per-layer-group pieces inside the backward
+        return timed("sgd", (hi - lo,), 0.0, (hi - lo) * (20 + (2 if p_compute is not None else 0)), orig_sgd_dev, p_, g, buf, p_compute, lo, hi, *a, **kw)
+
     def ema_update(teacher, student, teacher_compute, n, *a, **kw):   # reads teacher + student state, writes the teacher's (+ its bf16 weights)
         nc = kw.get("n_compute") or (teacher_compute.numel() if teacher_compute is not None else 0)
         return timed("ema", (n,), 0.0, n * 12 + 2 * nc, orig_ema, teacher, student, teacher_compute, n, *a, **kw)
@@ -281,14 +315,16 @@ def profile_insitu(step_fn, table_path=None):
 
     def roialign_backward(feats, rois, R, P, g_pooled, N, **kw):
         return timed("roialign_bwd", (R,), 0.0, g_pooled.numel() * g_pooled.element_size(), orig_rab, feats, rois, R, P, g_pooled, N, **kw)
-    ops.conv2d, ops.conv_wgrad, ops.conv_wgrad_group = conv2d, conv_wgrad, conv_wgrad_group
+    ops.conv2d, ops.conv_wgrad, ops.conv_wgrad_group, ops.conv2d_group = conv2d, conv_wgrad, conv_wgrad_group, conv2d_group
     ops.bottleneck_fused, ops.sgd_step, ops.ema_update, ops.roialign, ops.roialign_backward = bottleneck_fused, sgd_step, ema_update, roialign, roialign_backward
+    ops.sgd_step_dev = sgd_step_dev
     try:
         step_fn()
         torch.cuda.synchronize()
     finally:
-        ops.conv2d, ops.conv_wgrad, ops.conv_wgrad_group = orig_conv, orig_wg, orig_group
+        ops.conv2d, ops.conv_wgrad, ops.conv_wgrad_group, ops.conv2d_group = orig_conv, orig_wg, orig_group, orig_cgroup
         ops.bottleneck_fused, ops.sgd_step, ops.ema_update, ops.roialign, ops.roialign_backward = orig_bn, orig_sgd, orig_ema, orig_ra, orig_rab
+        ops.sgd_step_dev = orig_sgd_dev
     # What an event pair adds to the kernel it brackets (marker latency): with t1 = a pair around ONE launch of a small conv (T + o)
     # and t2 = a pair around TWO back-to-back launches of it (2 T + g + o), o = 2 t1 - t2 + g, where g is the dependent-kernel
     # boundary of MI355X_MICROARCH.md's price list (1.45 us).  It is subtracted from every measurement so that a launch's figure is
@@ -485,9 +521,11 @@ def main():
         engines = [tr.model.engine] + ([tr.ema.model.engine] if getattr(tr, "ema", None) is not None else [])
         saved = [(e, e.__dict__.get("_wg_side", "absent")) for e in engines]
         saved_aux = [(e, e.__dict__.get("_aux_side", "absent")) for e in engines]
+        saved_sgd = [(e, e.__dict__.get("_sgd_side", "absent")) for e in engines]
         for e in engines:
             e._wg_side, e._wgrad_pending = None, False
             e._aux_side = None
+            e._sgd_side = False
         ts_fn, _T._teacher_stream = _T._teacher_stream, (lambda device: None)
         try:
             prof = profile_insitu(one_step, os.path.join(ROOT, "gpurun_out", "dense_profile_insitu.txt"))
@@ -503,6 +541,11 @@ def main():
                     e.__dict__.pop("_aux_side", None)
                 else:
                     e._aux_side = v
+            for e, v in saved_sgd:
+                if v == "absent":
+                    e.__dict__.pop("_sgd_side", None)
+                else:
+                    e._sgd_side = v
         if fs is not None:
             fs.graph_enabled = graph_was
         if args.replay_profile:
@@ -511,7 +554,7 @@ def main():
         step_tflop = STEP_TFLOP_SPARSE_RPN if getattr(tr.model.engine, "sparse_rpn_backward", False) else STEP_TFLOP_FUSED
         ach = ig["flops"] / (ig["ms"] * 1e-3) / 1e12 if ig["ms"] > 0 else 0.0
         tj, tfile = matching_traffic()
-        out["roofline"] = {"bound": "mfma", "kernel": "igemm_kernel<bf16> (conv fwd + dgrad + FC)", "achieved": round(ach, 2), "peak": PEAK_BF16_TFLOPS,
+        out["roofline"] = {"bound": "mfma", "kernel": "igemm_kernel<bf16> + igemm_group_kernel<bf16> (conv fwd + dgrad + FC)", "achieved": round(ach, 2), "peak": PEAK_BF16_TFLOPS,
                            "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4),
                            "traffic": _traffic_per_launch(tj, "igemm", ig["launches"]),
                            "traffic_unit": "HBM bytes per igemm launch, rocprofv3 PMC passes of this command (FETCH_SIZE x2 + WRITE_SIZE)",

@@ -39,6 +39,7 @@ int aldi_noop(aldi_stream_t stream);
  *                        9 / 10 (3x3 halo form only): 240x128 on six waves, two workgroups per CU / 256x128 role-split
  *   igemm_k64_min        plain 1x1 / linear layers with K >= this (and K % 64 == 0) take the 64x64 128-byte-slab form (1024)
  *   igemm_group          1 = aldi_conv_igemm_group shares one launch (0: always n single launches)
+ *   igemm_narrow_k       bf16 layers with K up to this many channels x taps take 128x64 tiles instead of 128x128 (512; 0 = never)
  *   igemm_halo           1 = 3x3/stride-1/pad-1 bf16 convs use the halo form (one pixel slab per three taps)
  *   igemm_bigtile_min    128x128-tile count from which a 3x3 conv takes the big halo tile (1024)
  *   igemm_bigtile        which one: 4 = 256x128 lockstep (default), 1 = 128x128, 10 = 256x128 with the two wave halves in alternating roles
@@ -234,6 +235,11 @@ int aldi_cast_from_f32(const float* src, void* dst, long n, int dtype, aldi_stre
  * applied at aldi/dropin.py:121); refreshes the compute-dtype copy when dtype is bf16. */
 int aldi_sgd_step(float* p, const float* g, float* buf, void* p_compute, long n, float lr, float momentum, float weight_decay,
                   float grad_scale, int first_step, int dtype, aldi_stream_t stream);
+/* The same step (never the first one: the momentum buffer exists) over a RANGE of the flat buffers, with lr, momentum, weight decay and
+ * the gradient scale read from device memory (hyper[0..3]): a launch that can be recorded in a hipGraph and replayed while the
+ * learning-rate schedule moves.  The fused step issues one per layer group as soon as the group's weight gradients are complete,
+ * beside the rest of the backward, instead of one pass over all parameters after it. */
+int aldi_sgd_step_dev(float* p, const float* g, float* buf, void* p_compute, long n, const float* hyper, int dtype, aldi_stream_t stream);
 /* EMA teacher update over the flat state (aldi/ema.py:32-57): t = s*(1-alpha) + t*alpha, or t = s.  teacher_compute (nullable,
  * dtype bf16): the compute copy of the first n_compute elements, written in the same pass. */
 int aldi_ema_update(float* teacher, const float* student, void* teacher_compute, long n, long n_compute, double alpha, int copy_only, int dtype,

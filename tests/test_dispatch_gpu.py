@@ -141,13 +141,14 @@ FULL_FWD = [
     ((2, 100, 168, 256, 256, 3, 1, 1), "igemm<bf16,128,64,4,1,flat,halo>"),       # p3 3x3, teacher
     ((4, 50, 84, 256, 256, 3, 1, 1), "igemm<bf16,128,64,4,1,flat,halo>"),         # res4 conv2
     ((4, 200, 336, 64, 64, 3, 1, 1), "igemm<bf16,128,64,4,1,flat,halo>"),         # res2 conv2
-    ((4, 200, 336, 64, 256, 1, 1, 0), "igemm<bf16,128,128,2,2,pipe,tap>"),        # res2 conv3
+    ((4, 200, 336, 64, 256, 1, 1, 0), "igemm<bf16,128,64,4,1,pipe,tap>"),         # res2 conv3 (short K: half-width tiles)
     ((4, 200, 336, 256, 64, 1, 1, 0), "igemm<bf16,128,64,4,1,pipe,tap>"),         # res2 conv1
-    ((4, 200, 336, 256, 512, 1, 2, 0), "igemm<bf16,128,128,2,2,pipe,tap>"),       # res3 shortcut (stride 2)
+    ((4, 200, 336, 256, 512, 1, 2, 0), "igemm<bf16,128,64,4,1,pipe,tap>"),        # res3 shortcut (stride 2, K = 256)
+    ((4, 50, 84, 768, 1024, 1, 2, 0), "igemm<bf16,128,128,2,2,pipe,tap>"),        # a strided 1x1 with K > 512: full tiles
     ((4, 200, 336, 256, 16, 1, 1, 0), "igemm<bf16,128,16,4,1,pipe,tap>"),         # RPN objectness + deltas
     ((1, 120, 140, 3072, 768, 1, 1, 0), "igemm<bf16,256,128,4,2,flat,tap>"),      # 16800 x 3072 -> 768 (ViT MLP fc2)
     ((2048, 1, 1, 12544, 1024, 1, 1, 0), "igemm<bf16,64,64,2,2,flat,tap,k64>"),   # box head FC1 (long K: 128-byte slabs)
-    ((4, 25, 42, 512, 2048, 1, 1, 0), "igemm<bf16,128,128,2,2,pipe,tap>"),        # res5 conv3
+    ((4, 25, 42, 512, 2048, 1, 1, 0), "igemm<bf16,128,64,4,1,pipe,tap>"),         # res5 conv3
     ((2, 25, 42, 512, 512, 3, 1, 1), "igemm<bf16,128,64,4,1,flat,halo>"),         # res5 conv2, teacher
 ]
 

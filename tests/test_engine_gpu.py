@@ -363,6 +363,41 @@ def test_fused_step_equals_sequential(align):
     assert (g0 - g1).abs().max() < 2e-4 * g0.abs().max()
 
 
+def test_optimizer_step_inside_the_backward_equals_the_step_after_it(monkeypatch):
+    """ALDI_SGD_IN_STEP=1: the fused step applies the iteration's SGD update layer group by layer group from inside its backward
+    (aldi_sgd_step_dev, scalars in device memory, recorded in the phase-B graph) and EngineSGD.step skips its launch -- same weights,
+    momentum and losses as the optimizer launch after the backward, over eager and replayed iterations with a moving learning rate"""
+    from aldi_amd.trainer import ALDITrainer
+    out = []
+    for inside in ("0", "1"):
+        monkeypatch.setenv("ALDI_SGD_IN_STEP", inside)
+        cfg = _cfg(False, bf16=True)
+        cfg.SOLVER.FUSED_STEP = True
+        cfg.SOLVER.STEP_GRAPH = True
+        random.seed(0)
+        torch.manual_seed(11)
+        tr = ALDITrainer(cfg)
+        losses = []
+        for it in range(7):
+            tr.iter = it
+            tr._trainer.optimizer.param_groups[0]["lr"] = 0.0002 * (1 + it)  # a schedule: the recorded launches must follow it
+            tr.before_step(); tr.run_step(); tr.after_step()
+            losses.append({k: float(v) for k, v in tr._trainer.last_loss_dict.items()})
+        torch.cuda.synchronize()
+        fs = tr._trainer._fused_step
+        assert fs.stats["replays_b"] >= 2, fs.stats
+        W = tr.model.weights
+        assert not getattr(W, "_sgd_applied", False)
+        out.append((losses, W.master.clone(), W.mom.clone()))
+    (l0, w0, m0), (l1, w1, m1) = out
+    for a, b in zip(l0, l1):
+        for k in a:
+            assert abs(a[k] - b[k]) <= 1e-6 * max(1.0, abs(a[k])), (k, a[k], b[k])
+    # the weight-gradient sums are reproducible (ordered epilogue) except where layers share a buffer (float atomics): tiny differences
+    assert (w0 - w1).abs().max().item() <= 1e-5 * w0.abs().max().item()
+    assert (m0 - m1).abs().max().item() <= 1e-4 * m0.abs().max().item()
+
+
 @pytest.mark.parametrize("align", [False, True])
 def test_overlapped_exchange_hook_reports_final_gradients(align):
     """Data-parallel fused step: the engine reports layer groups to the gradient exchange while the backward is still

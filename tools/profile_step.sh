@@ -14,8 +14,8 @@ sha=$(python tools/source_hash.py)
 python tools/rocprof_summary.py stats $out/kt "rocprofv3 --kernel-trace --stats -- $cmd   ($tag, source_sha256 $sha, git ${GIT_SHA:-unknown})" > gpurun_out/${tag}_kernel_stats.txt
 python tools/rocprof_summary.py gaps $out/kt > gpurun_out/${tag}_gaps.txt 2>&1
 # the same step on ONE stream (every kernel alone on the chip): what bench.py's in-situ HIP-event profile of its roofline line measures
-ALDI_WGRAD_STREAM=0 ALDI_TEACHER_STREAM=0 ALDI_AUX_STREAM=0 rocprofv3 --kernel-trace --stats -d $out/kt1 -o kt -- $cmd > $out/kt1.log 2>&1
-python tools/rocprof_summary.py stats $out/kt1 "ALDI_WGRAD_STREAM=0 ALDI_TEACHER_STREAM=0 ALDI_AUX_STREAM=0 rocprofv3 --kernel-trace --stats -- $cmd   ($tag, single stream, source_sha256 $sha, git ${GIT_SHA:-unknown})" > gpurun_out/${tag}_kernel_stats_single_stream.txt
+ALDI_WGRAD_STREAM=0 ALDI_TEACHER_STREAM=0 ALDI_AUX_STREAM=0 ALDI_SGD_STREAM=0 rocprofv3 --kernel-trace --stats -d $out/kt1 -o kt -- $cmd > $out/kt1.log 2>&1
+python tools/rocprof_summary.py stats $out/kt1 "ALDI_WGRAD_STREAM=0 ALDI_TEACHER_STREAM=0 ALDI_AUX_STREAM=0 ALDI_SGD_STREAM=0 rocprofv3 --kernel-trace --stats -- $cmd   ($tag, single stream, source_sha256 $sha, git ${GIT_SHA:-unknown})" > gpurun_out/${tag}_kernel_stats_single_stream.txt
 rocprofv3 --pmc FETCH_SIZE -d $out/fetch -o p --output-format csv -- $cmd > $out/fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE -d $out/write -o p --output-format csv -- $cmd > $out/write.log 2>&1
 python tools/rocprof_summary.py pmc $out/fetch $out/write $sha "${GIT_SHA:-unknown}" > gpurun_out/${tag}_pmc_traffic.json

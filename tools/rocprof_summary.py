@@ -11,10 +11,10 @@ import sqlite3
 import sys
 
 
-delim, per_step = "sgd_kernel", "1"        # step-closing optimizer kernel (gaps / overlap / phases use the R50 defaults)
+delim, per_step = "stage_images_kernel", "2"   # step-opening kernels of the R50 step (student + teacher batches staged); the optimizer runs in pieces inside the backward
 
 
-def stats(d, title, delim="sgd_kernel", per_step="1"):
+def stats(d, title, delim="stage_images_kernel", per_step="2"):
     """per-kernel table of ONE step: the launches between the last two step-closing optimizer launches (`delim` kernel,
     `per_step` of them per step)"""
     dbs = glob.glob(d + "/**/*_results.db", recursive=True)
@@ -35,7 +35,7 @@ def stats(d, title, delim="sgd_kernel", per_step="1"):
         agg[n][1] += (e - s) / 1e3
     busy = sum(v[1] for v in agg.values())
     print(f"# {title}")
-    print(f"# one step (between two closing {delim} launches): wall {wall:.2f} ms (under the profiler), GPU kernel busy {busy / 1e3:.2f} ms, {len(step)} kernel launches")
+    print(f"# one step (between two {delim} launches, {per_step} per step): wall {wall:.2f} ms (under the profiler), GPU kernel busy {busy / 1e3:.2f} ms, {len(step)} kernel launches")
     print("%-100s %6s %10s %10s %6s" % ("kernel", "calls", "total_us", "avg_us", "pct"))
     for n, (c, t) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
         print("%-100s %6d %10.1f %10.1f %6.1f" % (n[:100], c, t, t / c, 100 * t / busy))
@@ -146,7 +146,7 @@ def phases(d):
         print("%8.2f ms  %s" % (v, k))
 
 
-def launches(d, pattern, delim="sgd_kernel"):
+def launches(d, pattern, delim="stage_images_kernel"):
     """every launch of the kernels matching `pattern` (regex) in the last step: start offset from the previous optimizer step's end, duration"""
     import re
     dbs = glob.glob(d + "/**/*_results.db", recursive=True)
@@ -185,7 +185,7 @@ def window(d, first="compact_kernel", last="wgrad_"):
 
 def pmc(fetch_dir, write_dir, source_sha="", git_sha=""):
     """HBM-side traffic of the dense kernel families from the two PMC passes: mean per kernel launch, and the totals of the LAST
-    complete step (between two optimizer launches) with that step's kernel-launch count -- bench.py divides the per-step total by
+    complete step (between the image-staging launches that open two steps) with that step's kernel-launch count -- bench.py divides the per-step total by
     the number of launches ITS in-situ profile counts (a grouped weight-gradient call is one launch there, several kernels here)"""
     res, step = {}, {}
     for key, d, ctr in (("fetch", fetch_dir, "FETCH_SIZE"), ("write", write_dir, "WRITE_SIZE")):
@@ -196,7 +196,8 @@ def pmc(fetch_dir, write_dir, source_sha="", git_sha=""):
                 if r["Counter_Name"] != ctr:
                     continue
                 name = r["Kernel_Name"]
-                k = "igemm" if "igemm_kernel" in name else "wgrad" if "wgrad_bf16" in name else "sgd" if "sgd_kernel" in name else None
+                k = ("igemm" if ("igemm_kernel" in name or "igemm_group_kernel" in name or "splitk_finalize" in name) else
+                     "wgrad" if ("wgrad_bf16" in name or "wgrad_finalize" in name) else "sgd" if "stage_images_kernel" in name else None)
                 if k:
                     rows.append((int(r["Dispatch_Id"]), k, float(r["Counter_Value"])))
                     if k != "sgd":
@@ -205,8 +206,8 @@ def pmc(fetch_dir, write_dir, source_sha="", git_sha=""):
         rows.sort()
         cuts = [i for i, r in enumerate(rows) if r[1] == "sgd"]
         tot = collections.defaultdict(lambda: [0.0, 0])
-        if len(cuts) >= 2:
-            for _, k, v in rows[cuts[-2] + 1:cuts[-1]]:
+        if len(cuts) >= 3:                  # two staging launches open every step: one step = from the second of step k - 1 to the second of step k
+            for _, k, v in rows[cuts[-3] + 1:cuts[-1]]:
                 tot[k][0] += v
                 tot[k][1] += 1
         step[key] = tot
