@@ -513,10 +513,17 @@ __global__ __launch_bounds__(512) void wgrad_bf16_big_group_kernel(WgGroup G) {
     for (int k = 1; k < G.n; ++k)
         if (bid >= G.wg_begin[k]) i = k;
     i = __builtin_amdgcn_readfirstlane(i);
-    const int local = bid - G.wg_begin[i];
+    int local = bid - G.wg_begin[i];
     const int tiles = G.gx[i] * G.gy[i];
-    if (local >= tiles * G.gz[i]) return;
-    const int t = local % tiles, bz = local / tiles;      // tile fastest: the tiles of one pixel range re-read the same x / g rows
+    const int n_local = tiles * G.gz[i];
+    if (local >= n_local) return;                    // (a problem's workgroup range is padded to a multiple of 8)
+    if (G.p[i].xcd) {
+        // XCD-aware order (workgroup b runs on XCD b % 8, ranges start at multiples of 8): a contiguous range of (split, tile) pairs
+        // per XCD, tile fastest -- the tiles of one pixel range re-read the same x / g rows out of ONE L2 instead of eight
+        const int q = n_local >> 3, r = n_local & 7, xcd = local & 7, idx = local >> 3;
+        local = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int t = local % tiles, bz = local / tiles;
     wgrad_bf16_lean_tile<256, 256, 2, 4>(G.p[i], lds, t % G.gx[i], t / G.gx[i], bz);
 }
 
@@ -1075,7 +1082,7 @@ int launch_group(const WgDev* probs, int ng, bool big, hipStream_t st, WsCarver&
     }
     auto wgs_for = [&](long T) {
         long w = 0;
-        for (int i = 0; i < ng; ++i) w += tiles_of[i] * cdiv(probs[i].M, T);
+        for (int i = 0; i < ng; ++i) w += (tiles_of[i] * cdiv(probs[i].M, T) + 7) / 8 * 8;      // (ranges are padded to multiples of 8: XCD order)
         return w;
     };
     // Pixels per workgroup: ONE value T for the whole group (workgroups of equal length), chosen by a round model.  128x128: three
@@ -1118,7 +1125,7 @@ int launch_group(const WgDev* probs, int ng, bool big, hipStream_t st, WsCarver&
         L_.gz[k] = d.splits;
         L_.wg_begin[k] = wg;
         const int w = L_.gx[k] * L_.gy[k] * L_.gz[k];
-        wg += big ? w : (w + 7) / 8 * 8;
+        wg += (w + 7) / 8 * 8;
     }
     if (!ws.fits()) return aldi_set_error_msg(ALDI_ERR_ARG, "conv_wgrad_group: workspace too small (aldi_conv_wgrad_group_workspace)");
     for (int k = ng; k <= kMaxGroup; ++k) L_.wg_begin[k] = wg;
