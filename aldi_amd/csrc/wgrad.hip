@@ -454,46 +454,41 @@ struct WgGroup {
     int gx[kMaxGroup], gy[kMaxGroup], gz[kMaxGroup]; // output tiles and pixel splits of each problem (its workgroups: tile-fastest, then split)
     WgDev p[kMaxGroup];
 };
+// Which (problem, tile, pixel split) does workgroup `bid` of a grouped launch work on.  XCD-aware order over the WHOLE group: workgroup b
+// runs on XCD b % 8 (observed dispatch); every XCD gets one contiguous range of the group's (problem, split, tile) list, tile fastest,
+// so the workgroups resident in an XCD at the same time are neighbours in that list -- the tiles of one pixel range, which re-read the
+// same x / g rows, out of ONE L2 -- also for the small problems (4-16 tiles) that a per-problem order would deal out one per XCD.
+__device__ __forceinline__ void wgrad_group_pick(const WgGroup& G, int& i, int& tx, int& ty, int& bz) {
+    const int W = G.wg_begin[G.n];
+    int g = (int)blockIdx.x;
+    if (G.p[0].xcd) {
+        const int q = W >> 3, r = W & 7, xcd = g & 7, idx = g >> 3;
+        g = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    i = 0;
+    for (int k = 1; k < G.n; ++k)
+        if (g >= G.wg_begin[k]) i = k;
+    i = __builtin_amdgcn_readfirstlane(i);
+    const int local = g - G.wg_begin[i];
+    const int tiles = G.gx[i] * G.gy[i];
+    const int t = local % tiles;
+    bz = local / tiles;
+    tx = t % G.gx[i]; ty = t / G.gx[i];
+}
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void wgrad_bf16_lean_group_kernel(WgGroup G) {
     __shared__ uint4 lds[2 * 128 * 8];
     // longest problems first in the launch order is the host's job; here: which problem does this workgroup belong to
-    const int bid = (int)blockIdx.x;
-    int i = 0;
-    for (int k = 1; k < G.n; ++k)
-        if (bid >= G.wg_begin[k]) i = k;
-    i = __builtin_amdgcn_readfirstlane(i);
-    int local = bid - G.wg_begin[i];
-    const int tiles = G.gx[i] * G.gy[i];
-    const int n_local = tiles * G.gz[i];
-    if (local >= n_local) return;                    // (a problem's workgroup range is padded to a multiple of 8)
-    if (G.p[i].xcd) {
-        // XCD-aware order inside the problem (workgroup b runs on XCD b % 8 and ranges start at multiples of 8): every XCD gets
-        // a contiguous range of (split, tile) pairs, tile fastest, so the tiles that re-read the same x / g rows share one L2
-        const int q = n_local >> 3, r = n_local & 7, xcd = local & 7, idx = local >> 3;
-        local = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-    }
-    const int t = local % tiles, bz = local / tiles;
-    wgrad_bf16_lean_tile<128, 128, 2, 2>(G.p[i], lds, t % G.gx[i], t / G.gx[i], bz);
+    int i, tx, ty, bz;
+    wgrad_group_pick(G, i, tx, ty, bz);
+    wgrad_bf16_lean_tile<128, 128, 2, 2>(G.p[i], lds, tx, ty, bz);
 }
 
 // the same with two LDS images and one barrier per slab (64 KB: two workgroups per CU)
 __global__ __launch_bounds__(256) void wgrad_bf16_lean_group_db_kernel(WgGroup G) {
     __shared__ uint4 lds[2 * 2 * 128 * 8];
-    const int bid = (int)blockIdx.x;
-    int i = 0;
-    for (int k = 1; k < G.n; ++k)
-        if (bid >= G.wg_begin[k]) i = k;
-    i = __builtin_amdgcn_readfirstlane(i);
-    int local = bid - G.wg_begin[i];
-    const int tiles = G.gx[i] * G.gy[i];
-    const int n_local = tiles * G.gz[i];
-    if (local >= n_local) return;
-    if (G.p[i].xcd) {
-        const int q = n_local >> 3, r = n_local & 7, xcd = local & 7, idx = local >> 3;
-        local = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-    }
-    const int t = local % tiles, bz = local / tiles;
-    wgrad_bf16_lean_tile<128, 128, 2, 2, true>(G.p[i], lds, t % G.gx[i], t / G.gx[i], bz);
+    int i, tx, ty, bz;
+    wgrad_group_pick(G, i, tx, ty, bz);
+    wgrad_bf16_lean_tile<128, 128, 2, 2, true>(G.p[i], lds, tx, ty, bz);
 }
 
 // 256 x 256 tile, 8 waves (128 x 64 each), one workgroup per CU: half the L2 -> CU bytes per FLOP, for layers whose
@@ -508,23 +503,9 @@ __global__ __launch_bounds__(512) void wgrad_bf16_big_kernel(WgDev p) {
 // would need a 7-60-way pixel split to occupy the chip, together they are 100-240 tiles: one or two pixel ranges each.
 __global__ __launch_bounds__(512) void wgrad_bf16_big_group_kernel(WgGroup G) {
     __shared__ uint4 lds[2 * 256 * 8];
-    const int bid = (int)blockIdx.x;
-    int i = 0;
-    for (int k = 1; k < G.n; ++k)
-        if (bid >= G.wg_begin[k]) i = k;
-    i = __builtin_amdgcn_readfirstlane(i);
-    int local = bid - G.wg_begin[i];
-    const int tiles = G.gx[i] * G.gy[i];
-    const int n_local = tiles * G.gz[i];
-    if (local >= n_local) return;                    // (a problem's workgroup range is padded to a multiple of 8)
-    if (G.p[i].xcd) {
-        // XCD-aware order (workgroup b runs on XCD b % 8, ranges start at multiples of 8): a contiguous range of (split, tile) pairs
-        // per XCD, tile fastest -- the tiles of one pixel range re-read the same x / g rows out of ONE L2 instead of eight
-        const int q = n_local >> 3, r = n_local & 7, xcd = local & 7, idx = local >> 3;
-        local = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-    }
-    const int t = local % tiles, bz = local / tiles;
-    wgrad_bf16_lean_tile<256, 256, 2, 4>(G.p[i], lds, t % G.gx[i], t / G.gx[i], bz);
+    int i, tx, ty, bz;
+    wgrad_group_pick(G, i, tx, ty, bz);
+    wgrad_bf16_lean_tile<256, 256, 2, 4>(G.p[i], lds, tx, ty, bz);
 }
 
 // Second pass of the ordered epilogue: dw += scale * (split 0 + split 1 + ...), db += (...), the splits in index order -- the
@@ -1082,7 +1063,7 @@ int launch_group(const WgDev* probs, int ng, bool big, hipStream_t st, WsCarver&
     }
     auto wgs_for = [&](long T) {
         long w = 0;
-        for (int i = 0; i < ng; ++i) w += (tiles_of[i] * cdiv(probs[i].M, T) + 7) / 8 * 8;      // (ranges are padded to multiples of 8: XCD order)
+        for (int i = 0; i < ng; ++i) w += tiles_of[i] * cdiv(probs[i].M, T);
         return w;
     };
     // Pixels per workgroup: ONE value T for the whole group (workgroups of equal length), chosen by a round model.  128x128: three
@@ -1124,8 +1105,7 @@ int launch_group(const WgDev* probs, int ng, bool big, hipStream_t st, WsCarver&
         L_.gy[k] = cdiv(d.K, tile);
         L_.gz[k] = d.splits;
         L_.wg_begin[k] = wg;
-        const int w = L_.gx[k] * L_.gy[k] * L_.gz[k];
-        wg += (w + 7) / 8 * 8;
+        wg += L_.gx[k] * L_.gy[k] * L_.gz[k];
     }
     if (!ws.fits()) return aldi_set_error_msg(ALDI_ERR_ARG, "conv_wgrad_group: workspace too small (aldi_conv_wgrad_group_workspace)");
     for (int k = ng; k <= kMaxGroup; ++k) L_.wg_begin[k] = wg;
