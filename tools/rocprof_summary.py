@@ -54,8 +54,11 @@ def gaps(d, top="15"):
     a, b = sgd[-1 - int(per_step)], sgd[-1]
     step = rows[a:b + 1]
     g = []
-    for (n0, s0, e0), (n1, s1, e1) in zip(step[:-1], step[1:]):
-        g.append(((s1 - e0) / 1e3, n0[:60], n1[:60]))
+    busy_until, last = step[0][2], step[0][0]          # true idle: nothing at all in flight (streams overlap: compare with the latest end so far)
+    for (n1, s1, e1) in step[1:]:
+        g.append(((s1 - busy_until) / 1e3, last[:60], n1[:60]))
+        if e1 > busy_until:
+            busy_until, last = e1, n1
     tot = sum(x[0] for x in g if x[0] > 0)
     print(f"# idle between kernels in one step: {tot / 1e3:.2f} ms over {len(g)} gaps; gaps > 20 us: {sum(x[0] for x in g if x[0] > 20) / 1e3:.2f} ms")
     for us, n0, n1 in sorted(g, reverse=True)[:int(top)]:
