@@ -935,9 +935,18 @@ int conv_splitk(const aldi_conv_args* a, ConvDev& d, hipStream_t st) {
         return aldi_set_error_msg(ALDI_ERR_ARG, "conv_igemm: split-K takes bf16 plain 1x1 / linear layers with K % (64 * ksplit) == 0, a workspace, no res / mask / fp32 output");
     ConvDev s = d;
     s.y = nullptr; s.y_f32 = static_cast<float*>(a->ws); s.scale = nullptr; s.shift = nullptr; s.relu = 0;
-    s.ksplit = ks; s.slabs_per_split = d.K / 64 / ks;
+    s.ksplit = ks;
     s.xcd = aldi_tuning().igemm_xcd; s.dbg = aldi_tuning().igemm_dbg;
-    if (int rc = launch<bf16_t, 128, 128, 2, 2, 8, false>(s, st)) return rc;
+    // igemm_splitk_tile: 0 = 128x128 tiles with 128-byte K slabs (4 waves); 1 = 256x128 tiles, 64-byte slabs (8 waves: two per SIMD
+    // also when the launch is one workgroup per CU: FC1 at 2048 rows 86 -> 72 us, at 2000 rows 94 -> 72 us, tools/fc1_splitk_sweep.py)
+    const int tile_knob = aldi_tuning().igemm_splitk_tile;       // 2 (default): 256x128 when its launch still has ~one workgroup per CU
+    if (tile_knob == 1 || (tile_knob == 2 && (long)cdiv(d.M, 256) * cdiv(d.Cout, 128) * ks >= 200)) {
+        s.slabs_per_split = d.K / 32 / ks;
+        if (int rc = launch<bf16_t, 256, 128, 4, 2, 4, false>(s, st)) return rc;
+    } else {
+        s.slabs_per_split = d.K / 64 / ks;
+        if (int rc = launch<bf16_t, 128, 128, 2, 2, 8, false>(s, st)) return rc;
+    }
     const long mc = (long)d.M * d.Cout;
     hipLaunchKernelGGL(splitk_finalize_kernel, dim3(cdiv(mc / 4, 256)), dim3(256), 0, st, static_cast<const float*>(a->ws), ks, mc, d.Cout, d.scale, d.shift,
                        d.relu, static_cast<bf16_t*>(a->y));

@@ -91,16 +91,19 @@ def conv2d(x: torch.Tensor, w: torch.Tensor, *, stride: int = 1, pad: int = 0,
 
 
 def _auto_ksplit(x, M, Cout, K, plain: bool) -> int:
-    """four K slices for a bf16 linear layer with a very long K and fewer 128 x 128 output tiles than CUs (ALDI_SPLITK=0: never)"""
+    """K slices for a bf16 linear layer with a very long K and fewer output tiles than CUs (ALDI_SPLITK=0: never): as many as give
+    the 256 x 128-tile launch about one 8-wave workgroup per CU (tools/fc1_splitk_sweep.py: FC1 at 2048 rows 98 us unsplit, 72 us with
+    4 slices; at 1024 rows 92 -> 49 us with 7)"""
     if not plain or x.dtype != torch.bfloat16 or K < 4096 or K % 256 or os.environ.get("ALDI_SPLITK", "1") != "1":
         return 0
     tiles = ((M + 127) // 128) * ((Cout + 127) // 128)
     if not (16 <= tiles <= 160) or Cout % 4:
         return 0
-    for ks in (2, 4):                       # as many slices as it takes to give every CU a workgroup (measured on FC1: M = 2048: 111 -> 95 us
-        if tiles * ks >= 256:               # with 2 slices, 100 with 4; M = 1024: 81 -> 52 us with 4)
+    tiles256 = ((M + 255) // 256) * ((Cout + 127) // 128)
+    for ks in (2, 4, 7, 8, 14, 16):
+        if K % (64 * ks) == 0 and tiles256 * ks >= 216:
             return ks
-    return 4
+    return 4 if K % 256 == 0 else 0
 
 
 def _conv_args(x, w, *, stride=1, pad=0, scale=None, shift=None, res=None, res_mode=0, relu=False, mask=None, out=None, out_f32=None,

@@ -39,6 +39,8 @@ int aldi_noop(aldi_stream_t stream);
  *                        9 / 10 (3x3 halo form only): 240x128 on six waves, two workgroups per CU / 256x128 role-split
  *   igemm_k64_min        plain 1x1 / linear layers with K >= this (and K % 64 == 0) take the 64x64 128-byte-slab form (1024)
  *   igemm_group          1 = aldi_conv_igemm_group shares one launch (0: always n single launches)
+ *   igemm_splitk_tile    tile of a split-K launch (aldi_conv_args.ksplit): 0 = 128x128, 1 = 256x128, 2 = 256x128 when that still gives about
+ *                        one workgroup per CU (default)
  *   igemm_narrow_k       bf16 layers with K up to this many channels x taps take 128x64 tiles instead of 128x128 (512; 0 = never)
  *   igemm_halo           1 = 3x3/stride-1/pad-1 bf16 convs use the halo form (one pixel slab per three taps)
  *   igemm_bigtile_min    128x128-tile count from which a 3x3 conv takes the big halo tile (1024)
