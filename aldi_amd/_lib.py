@@ -100,7 +100,7 @@ class ConvArgs(C.Structure):
         ("Cout", c_int), ("KH", c_int), ("KW", c_int), ("stride", c_int), ("pad", c_int),
         ("Ho", c_int), ("Wo", c_int),
         ("relu", c_int), ("res_mode", c_int), ("out_scale", c_int), ("OH", c_int), ("OW", c_int),
-        ("dtype", c_int), ("ws", c_void_p), ("ksplit", c_int),
+        ("dtype", c_int), ("ws", c_void_p), ("ksplit", c_int), ("mask_bits", c_void_p), ("bits_out", c_void_p),
     ]
 
 

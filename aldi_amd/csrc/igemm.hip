@@ -36,6 +36,9 @@ struct ConvDev {
     int M, K, xcd, dbg;
     unsigned x_bytes, w_bytes;
     int ksplit, slabs_per_split;     // split-K (plain 1x1 / linear): blockIdx.z = slice, slabs_per_split K slabs each
+    // ReLU masks as BITS (bf16, Cout % 8 == 0, plain output layout): [M][Cout / 8] bytes, bit c % 8 of byte c / 8 = (y[m][c] > 0).
+    // bits_out: written by the forward launch beside y; mask_bits: read by the backward launch instead of the 16x larger `mask` tensor.
+    const unsigned char* mask_bits; unsigned char* bits_out;
 };
 
 // ---- epilogue of a BM x BN tile: lane owns pixel (lane&15), channels (lane>>4)*4 .. +3 of each 16x16 accumulator fragment.
@@ -103,7 +106,7 @@ __device__ __forceinline__ void igemm_epilogue(const ConvDev& p, f32x4_t (&acc)[
             constexpr int NI = BM / RPI;
             constexpr unsigned OOBX = 0x80000000u;
             const __amdgpu_buffer_rsrc_t ry = make_rsrc_uniform(Y, 0x7fffffffu);
-            unsigned ooff[NI], roff[NI];
+            unsigned ooff[NI], roff[NI], boff[NI];
 #pragma unroll
             for (int it = 0; it < NI; ++it) {
                 const int m = m0 + rowl0 + it * RPI;
@@ -124,6 +127,7 @@ __device__ __forceinline__ void igemm_epilogue(const ConvDev& p, f32x4_t (&acc)[
                 }
                 ooff[it] = ok ? (oidx + (unsigned)c) * 2u : OOBX;
                 roff[it] = ok ? (ridx + (unsigned)c) * 2u : OOBX;
+                boff[it] = ok ? (oidx + (unsigned)c) >> 3 : OOBX;          // this lane's 8 channels = one byte of a bit mask
             }
             u32x4_t rres[NI], rmsk[NI];
             if (p.res_mode) {
@@ -136,6 +140,13 @@ __device__ __forceinline__ void igemm_epilogue(const ConvDev& p, f32x4_t (&acc)[
 #pragma unroll
                 for (int it = 0; it < NI; ++it) rmsk[it] = __builtin_amdgcn_raw_buffer_load_b128(rm_, ooff[it], 0, 0);
             }
+            unsigned rbits[NI];
+            if (p.mask_bits) {
+                const __amdgpu_buffer_rsrc_t rb_ = make_rsrc_uniform(p.mask_bits, 0x7fffffffu);
+#pragma unroll
+                for (int it = 0; it < NI; ++it) rbits[it] = __builtin_amdgcn_raw_buffer_load_b8(rb_, boff[it], 0, 0);
+            }
+            const __amdgpu_buffer_rsrc_t rbo = make_rsrc_uniform(p.bits_out, 0x7fffffffu);
 #pragma unroll
             for (int it = 0; it < NI; ++it) {
                 const uint4 raw4 = *reinterpret_cast<const uint4*>(rd + it * RPI * ROWB);
@@ -170,8 +181,28 @@ __device__ __forceinline__ void igemm_epilogue(const ConvDev& p, f32x4_t (&acc)[
                         raw[q] = *reinterpret_cast<uint32_t*>(&v);
                     }
                 }
+                if (p.mask_bits) {          // the same, the forward activation's sign from one bit per element
+                    const unsigned b = rbits[it];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const unsigned k32 = ((b >> (2 * q)) & 1u) | (((b >> (2 * q + 1)) & 1u) << 16);
+                        s16x2_t k = *reinterpret_cast<const s16x2_t*>(&k32);
+                        s16x2_t v = *reinterpret_cast<s16x2_t*>(&raw[q]);
+                        v = v * k;
+                        raw[q] = *reinterpret_cast<uint32_t*>(&v);
+                    }
+                }
                 const u32x4_t ov = {raw[0], raw[1], raw[2], raw[3]};
                 __builtin_amdgcn_raw_buffer_store_b128(ov, ry, ooff[it], 0, 0);
+                if (p.bits_out) {           // (y > 0) of this lane's 8 channels: bf16 as int16, positive floats are positive integers
+                    unsigned b = 0;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        b |= ((short)(raw[q] & 0xffffu) > 0 ? 1u : 0u) << (2 * q);
+                        b |= ((short)(raw[q] >> 16) > 0 ? 1u : 0u) << (2 * q + 1);
+                    }
+                    __builtin_amdgcn_raw_buffer_store_b8((unsigned char)b, rbo, boff[it], 0, 0);
+                }
             }
             return;
         }
@@ -904,6 +935,11 @@ int fill_convdev(const aldi_conv_args* a, ConvDev& d) {
     d.w_bytes = (unsigned)wb;
     d.xcd = 0; d.dbg = 0;
     d.ksplit = 0; d.slabs_per_split = 0;
+    d.mask_bits = static_cast<const unsigned char*>(a->mask_bits);
+    d.bits_out = static_cast<unsigned char*>(a->bits_out);
+    if ((a->mask_bits || a->bits_out) && (a->dtype != ALDI_BF16 || (a->Cout & 7) || d.out_scale != 1 || a->res_mode == 2 || !a->y || a->y_f32 || a->ksplit > 1))
+        return aldi_set_error_msg(ALDI_ERR_ARG, "conv_igemm: bit masks take bf16 outputs with Cout % 8 == 0 in the plain layout (no fp32 output, scatter, upsampled residual or split-K)");
+    if (a->mask_bits && a->mask) return aldi_set_error_msg(ALDI_ERR_ARG, "conv_igemm: mask and mask_bits are alternatives");
     return ALDI_OK;
 }
 }  // namespace

@@ -397,6 +397,7 @@ class RCNN:
         self.has_img_da, self.has_ins_da = bool(self.img_da_layers), bool(self.ins_da_layers)
         self.fused_stem = os.environ.get("ALDI_FUSED_STEM", "1") == "1"                  # bf16: stem conv + max-pool in one kernel
         self.group_wgrad = os.environ.get("ALDI_WGRAD_GROUP", "1") == "1"                # bf16: a layer group's weight gradients in one launch
+        self.mask_bits = os.environ.get("ALDI_MASK_BITS", "1") == "1"                    # ReLU masks of the block outputs as bits for the backward
         self.level_groups = os.environ.get("ALDI_LEVEL_GROUPS", "1") == "1"              # one launch for a layer applied to several pyramid levels
         self.fused_res2 = os.environ.get("ALDI_FUSED_RES2", "1") == "1"                  # bf16: a res2 bottleneck (no saved activations) in one kernel
         self._wg_queue: list = []
@@ -474,12 +475,12 @@ class RCNN:
         return t
 
     # ------------------------------------------------------------------ trunk
-    def _conv_call(self, x, name, *, relu=False, res=None, res_mode=0, want_f32=False, out=None):
+    def _conv_call(self, x, name, *, relu=False, res=None, res_mode=0, want_f32=False, out=None, bits_out=None):
         """(x, weight, conv2d kwargs) of layer `name` applied to x"""
         W = self.wts
         p = W.layout.t[name]
         return x, W.w(name), dict(stride=p.stride, pad=p.pad, scale=W.scale(name), shift=W.shift(name), res=res, res_mode=res_mode, relu=relu,
-                                  want_f32=want_f32, out=out)
+                                  want_f32=want_f32, out=out, bits_out=bits_out)
 
     def conv(self, x, name, **kw):
         x, w, kw = self._conv_call(x, name, **kw)
@@ -578,6 +579,7 @@ class RCNN:
             del stem
         blocks = []
         cs = []
+        out_bits = {}                          # data_ptr of a saved block output -> its ReLU bit mask
         # res2 keeps nothing for the backward (FREEZE_AT = 2; `blocks` below starts at res3): each of its bottlenecks is ONE kernel
         # whose two 64-channel intermediate maps stay in the LDS (csrc/bneck.hip)
         fuse2 = self.dtype == torch.bfloat16 and self.fused_res2
@@ -594,9 +596,15 @@ class RCNN:
                     continue
                 h1 = yield x, p + "conv1", dict(relu=True)
                 h2 = yield h1, p + "conv2", dict(relu=True)
-                out = yield h2, p + "conv3", dict(relu=True, res=sc, res_mode=1)
+                # the block output's ReLU mask as bits (1/16 of the tensor): what the NEXT block's conv1 / the lateral conv's data gradient
+                # multiplies by instead of reading this whole activation again (those launches are HBM-bound)
+                bits = (torch.empty(h2.shape[0] * h2.shape[1] * h2.shape[2] * (W.layout.t[p + "conv3"].wshape[0] // 8), dtype=torch.uint8, device=self.device)
+                        if save and si > 0 and self.mask_bits and self.dtype == torch.bfloat16 else None)
+                out = yield h2, p + "conv3", dict(relu=True, res=sc, res_mode=1, bits_out=bits)
                 if save and si > 0:
                     blocks.append((p, x, h1, h2, out, b == 0))
+                    if bits is not None:
+                        out_bits[out.data_ptr()] = bits
                 x = out
             cs.append(x)
         prev = {}
@@ -617,7 +625,7 @@ class RCNN:
         P[6] = ops.subsample2(P[5])
         c.P = [P[2], P[3], P[4], P[5], P[6]]
         if save:
-            c.blocks, c.cs, c.prev = blocks, cs, prev
+            c.blocks, c.cs, c.prev, c.out_bits = blocks, cs, prev, out_bits
         return c
 
     def rpn_head(self, c: Ctx, save: bool):
@@ -1315,7 +1323,7 @@ class RCNN:
         self._grads_final(["rpn_head_out", "proposal_generator.rpn_head.conv"] + [f"backbone.fpn_output{l}" for l in (2, 3, 4, 5)] +
                           [f"backbone.fpn_lateral{l}" for l in (2, 3, 4, 5)])
         # ---- res5 .. res3 (stem + res2 frozen: FREEZE_AT=2)
-        g = ops.conv2d(gprev[5], W.wt("backbone.fpn_lateral5"), mask=c.cs[3])
+        g = ops.conv2d(gprev[5], W.wt("backbone.fpn_lateral5"), **self._relu_mask(c, c.cs[3]))
         blocks = c.blocks
         bi = len(blocks) - 1
         for si in (3, 2, 1):
@@ -1345,10 +1353,16 @@ class RCNN:
                     ops.conv2d(g, W.wt(p + "shortcut"), out=gx, out_scale=stride, out_hw=(Hin, Win))
                     ops.conv2d(g1, W.wt(p + "conv1"), out=gx, out_scale=stride, out_hw=(Hin, Win), res=gx, res_mode=1)
                     lvl = si + 1                                        # this stage's input is C_{lvl}
-                    g = ops.conv2d(gprev[lvl], W.wt(f"backbone.fpn_lateral{lvl}"), res=gx, res_mode=1, mask=xin)
+                    g = ops.conv2d(gprev[lvl], W.wt(f"backbone.fpn_lateral{lvl}"), res=gx, res_mode=1, **self._relu_mask(c, xin))
                 else:
-                    g = ops.conv2d(g1, W.wt(p + "conv1"), res=g, res_mode=1, mask=xin)
+                    g = ops.conv2d(g1, W.wt(p + "conv1"), res=g, res_mode=1, **self._relu_mask(c, xin))
         self._join_wgrads()
+
+    @staticmethod
+    def _relu_mask(c: Ctx, act: torch.Tensor) -> dict:
+        """conv2d kwargs that mask a data gradient by (act > 0): the bit mask the forward wrote beside `act` when there is one"""
+        bits = (c.get("out_bits") or {}).get(act.data_ptr())
+        return dict(mask_bits=bits) if bits is not None else dict(mask=act)
 
     def _rpn_sparse_prepare(self, c: Ctx):
         """RPN head backward over the ACTIVE pixels only (csrc/rpn_sparse.hip), everything up to the scatter: d(loss)/d(head

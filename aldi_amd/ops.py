@@ -58,7 +58,8 @@ def conv2d(x: torch.Tensor, w: torch.Tensor, *, stride: int = 1, pad: int = 0,
            res: Optional[torch.Tensor] = None, res_mode: int = 0, relu: bool = False,
            mask: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None,
            out_f32: Optional[torch.Tensor] = None, want_f32: bool = False,
-           out_scale: int = 1, out_hw=None, ksplit: Optional[int] = None) -> torch.Tensor:
+           out_scale: int = 1, out_hw=None, ksplit: Optional[int] = None, mask_bits: Optional[torch.Tensor] = None,
+           bits_out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """x [N,H,W,Cin] (NHWC), w [Cout,KH,KW,Cin] -> y [N,Ho,Wo,Cout] (or the scattered
     [N,OH,OW,Cout] tensor when out_scale > 1, which must be pre-zeroed by the caller).
     ksplit: K slices of a long-K linear layer (None: chosen here -- the box head's FC1 is 128 tiles of 128 x 128 over K = 12544)."""
@@ -80,12 +81,12 @@ def conv2d(x: torch.Tensor, w: torch.Tensor, *, stride: int = 1, pad: int = 0,
     ws = None
     if ksplit is None:
         ksplit = _auto_ksplit(x, N * Ho * Wo, Cout, KH * KW * Cin, KH * KW == 1 and stride == 1 and pad == 0 and res is None and mask is None
-                              and not want_f32 and out_f32 is None and out_scale == 1)
+                              and not want_f32 and out_f32 is None and out_scale == 1 and mask_bits is None and bits_out is None)
     if ksplit and ksplit > 1:
         ws = torch.empty(ksplit * N * Ho * Wo * Cout, dtype=torch.float32, device=x.device)
     a = L.ConvArgs(_p(x), _p(w), _p(out), _p(out_f32), _p(scale), _p(shift), _p(res), _p(mask),
                    N, H, W_, Cin, Cout, KH, KW, stride, pad, Ho, Wo,
-                   int(relu), res_mode, out_scale, OH, OW, dtype_code(x.dtype), _p(ws), int(ksplit or 0))
+                   int(relu), res_mode, out_scale, OH, OW, dtype_code(x.dtype), _p(ws), int(ksplit or 0), _p(mask_bits), _p(bits_out))
     L.call("aldi_conv_igemm", C.byref(a), stream_ptr())
     return out_f32 if want_f32 and out is None else out
 
@@ -107,7 +108,7 @@ def _auto_ksplit(x, M, Cout, K, plain: bool) -> int:
 
 
 def _conv_args(x, w, *, stride=1, pad=0, scale=None, shift=None, res=None, res_mode=0, relu=False, mask=None, out=None, out_f32=None,
-               want_f32=False, out_scale=1, out_hw=None):
+               want_f32=False, out_scale=1, out_hw=None, mask_bits=None, bits_out=None):
     """(ConvArgs, result tensor) of one conv2d call -- shared by the single and the grouped launch"""
     N, H, W_, Cin = x.shape
     Cout, KH, KW, Cin2 = w.shape
@@ -126,7 +127,7 @@ def _conv_args(x, w, *, stride=1, pad=0, scale=None, shift=None, res=None, res_m
         out_f32 = torch.empty(shape, dtype=torch.float32, device=x.device)
     a = L.ConvArgs(_p(x), _p(w), _p(out), _p(out_f32), _p(scale), _p(shift), _p(res), _p(mask),
                    N, H, W_, Cin, Cout, KH, KW, stride, pad, Ho, Wo,
-                   int(relu), res_mode, out_scale, OH, OW, dtype_code(x.dtype))
+                   int(relu), res_mode, out_scale, OH, OW, dtype_code(x.dtype), None, 0, _p(mask_bits), _p(bits_out))
     return a, (out_f32 if want_f32 and out is None else out)
 
 

@@ -106,6 +106,12 @@ typedef struct {
      * applies scale / shift / ReLU and writes y.  bf16, plain 1x1 / linear, K % (64 * ksplit) == 0, no res / mask / y_f32. */
     void* ws;           /* ksplit * M * Cout floats (only read / written when ksplit > 1)   */
     int ksplit;         /* 0 / 1 = off                                                       */
+    /* ReLU masks as bits (bf16, Cout % 8 == 0, plain output layout): [M][Cout / 8] bytes, bit c % 8 of byte c / 8 = (y[m][c] > 0).
+     * bits_out (nullable): the forward launch writes the mask of its own output beside y; mask_bits (nullable, alternative to `mask`):
+     * the backward launch multiplies by it instead of reading the 16x larger activation -- the conv1 / lateral data-gradient launches of
+     * res3..res5 are HBM-bound and a quarter of their bytes was that read. */
+    const void* mask_bits;
+    void* bits_out;
 } aldi_conv_args;
 
 int aldi_conv_igemm(const aldi_conv_args* a, aldi_stream_t stream);

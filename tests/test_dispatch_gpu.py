@@ -593,6 +593,40 @@ def test_conv_group_equals_single_launches(geo, batches, expect):
         assert (a - b).abs().max().item() <= 2e-5 * max(1.0, b.abs().max().item())
 
 
+@pytest.mark.parametrize("case", [(2, 50, 84, 256, 1024, 1, 0), (1, 19, 23, 64, 72, 3, 1), (2, 25, 42, 512, 2048, 1, 0)])
+def test_relu_masks_as_bits(case):
+    """aldi_conv_args.bits_out / mask_bits: the forward launch writes (y > 0) of its output as one bit per element beside y, the backward
+    launch multiplies by those bits -- the same result, bit for bit, as masking by the bf16 activation itself; ragged M and a Cout that is
+    not a tile multiple included"""
+    from aldi_amd import ops
+    N, H, W_, Cin, Cout, k, pad = case
+    g = torch.Generator().manual_seed(sum(case))
+    x = torch.randn(N, H, W_, Cin, generator=g).to("cuda", torch.bfloat16)
+    w = (torch.randn(Cout, k, k, Cin, generator=g) / (Cin * k * k) ** 0.5).to("cuda", torch.bfloat16)
+    res = torch.randn(N, H, W_, Cout, generator=g).to("cuda", torch.bfloat16)
+    sh = torch.randn(Cout, generator=g).to("cuda")
+    M = N * H * W_
+    bits = torch.full((M * Cout // 8 + 64,), 0xA5, dtype=torch.uint8, device="cuda")          # (guard bytes behind the mask)
+    y = ops.conv2d(x, w, pad=pad, shift=sh, res=res, res_mode=1, relu=True, bits_out=bits)
+    y_plain = ops.conv2d(x, w, pad=pad, shift=sh, res=res, res_mode=1, relu=True)
+    torch.cuda.synchronize()
+    assert torch.equal(y, y_plain)
+    expect = (y.view(M, Cout // 8, 8).float() > 0).to(torch.uint8)
+    packed = (expect * (2 ** torch.arange(8, device="cuda", dtype=torch.uint8))).sum(-1).to(torch.uint8).view(-1)
+    assert torch.equal(bits[:M * Cout // 8], packed) and bool((bits[M * Cout // 8:] == 0xA5).all())
+    assert 0.2 < float(expect.float().mean()) < 0.8
+    # backward: a data-gradient launch masked by the bits == masked by the activation
+    gy = torch.randn(N, H, W_, Cin, generator=g).to("cuda", torch.bfloat16)
+    wt = (torch.randn(Cout, 1, 1, Cin, generator=g) / Cin ** 0.5).to("cuda", torch.bfloat16)
+    r2 = torch.randn(N, H, W_, Cout, generator=g).to("cuda", torch.bfloat16)
+    a = ops.conv2d(gy, wt, res=r2, res_mode=1, mask=y)
+    b = ops.conv2d(gy, wt, res=r2, res_mode=1, mask_bits=bits)
+    torch.cuda.synchronize()
+    assert torch.equal(a, b)
+    with pytest.raises(Exception):
+        ops.conv2d(gy, wt, mask=y, mask_bits=bits)
+
+
 def test_conv_group_of_different_layers_falls_back():
     from aldi_amd import _lib as L
     from aldi_amd import ops
