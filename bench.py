@@ -345,7 +345,9 @@ def profile_insitu(step_fn, table_path=None):
             pairs.append((e0, e1))
         torch.cuda.synchronize()
         t12.append(sorted(a.elapsed_time(b) * 1e3 for a, b in pairs)[len(pairs) // 2])
-    empty = min(max(2 * t12[0] - t12[1] + 1.45, 0.0), 5.0)
+    # (capped at 3 us: the estimate moves between 2.5 and 4.6 us from run to run, and an over-correction would OVERSTATE the achieved
+    # rate -- at 2.5 us the line agreed with the kernel trace of the same single-stream step to 1 %, at 4 us it read 5 % above it)
+    empty = min(max(2 * t12[0] - t12[1] + 1.45, 0.0), 3.0)
     shapes, out = {}, {}
     for fam in ("igemm", "wgrad", "bneck", "sgd", "ema", "roialign_fwd", "roialign_bwd"):
         out[fam] = {"launches": 0, "flops": 0.0, "ms": 0.0, "bytes": 0}
