@@ -319,8 +319,18 @@ def profile_insitu(step_fn, table_path=None):
     ops.bottleneck_fused, ops.sgd_step, ops.ema_update, ops.roialign, ops.roialign_backward = bottleneck_fused, sgd_step, ema_update, roialign, roialign_backward
     ops.sgd_step_dev = sgd_step_dev
     try:
-        step_fn()
-        torch.cuda.synchronize()
+        # THREE profiled steps, the one with the smallest total kept: issued eagerly from Python the GPU idles between launches, and on
+        # some boxes the first such step runs with the clocks still down (one run read every kernel 3.6x slower than the trace of the
+        # same tree; the timed region -- graph replays, back to back -- is not affected)
+        best = None
+        for _ in range(3):
+            del rec[:]
+            step_fn()
+            torch.cuda.synchronize()
+            tot = sum(e0.elapsed_time(e1) for _, _, _, e0, e1 in rec)
+            if best is None or tot < best[0]:
+                best = (tot, list(rec))
+        rec[:] = best[1]
     finally:
         ops.conv2d, ops.conv_wgrad, ops.conv_wgrad_group, ops.conv2d_group = orig_conv, orig_wg, orig_group, orig_cgroup
         ops.bottleneck_fused, ops.sgd_step, ops.ema_update, ops.roialign, ops.roialign_backward = orig_bn, orig_sgd, orig_ema, orig_ra, orig_rab
