@@ -526,6 +526,26 @@ int aldi_ms_deform_attn_backward(const float* value, const int* spatial_shapes, 
                                  const float* attn_weight, const float* grad_out, float* grad_value, float* grad_sampling_loc,
                                  float* grad_attn_weight, int N, int S, int M, int D, int Lq, int L, int P, aldi_stream_t stream);
 
+/* Deformable-DETR pieces around that op (csrc/detr.hip), fp32; the arithmetic follows oracle/deformable_detr.py.
+ * GroupNorm(G) over NHWC maps x [N][HW][C] (the input projections' normalisation): mean / rstd [N][G] are written for a backward
+ * pass; workspace: aldi_group_norm_workspace(N, HW, G) bytes.  Deterministic (two-stage sums in a fixed order). */
+size_t aldi_group_norm_workspace(int N, int HW, int G);
+int aldi_group_norm_forward(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd, void* workspace, int N, int HW,
+                            int C, int G, float eps, aldi_stream_t stream);
+/* From the outputs raw [T][M*L*P*3] of a deformable-attention layer's two linear maps (sampling offsets [M][L][P][2], then attention
+ * logits [M][L*P]) and the tokens' reference points ref [T][L][2]: sampling_loc [T][M][L][P][2] = ref + offset / (W_l, H_l) and
+ * attn_weight [T][M][L][P] = softmax over (l, p) -- the operands of aldi_ms_deform_attn_forward. */
+int aldi_msda_prepare(const float* raw, const float* ref, const int* spatial_shapes, float* sampling_loc, float* attn_weight, long T, int M, int L, int P,
+                      aldi_stream_t stream);
+/* softmax(q k^T * scale) v for a few hundred tokens (the decoder's self attention): q / k / v [B][Q][H*D] with row strides ldq / ldk / ldv
+ * floats, D = 16, 32 or 64; out [B][Q][H*D]; lse [B][H][Q] nullable. */
+int aldi_mha_small_forward(const float* q, const float* k, const float* v, float* out, float* lse, int B, int Q, int H, int D, int ldq, int ldk, int ldv,
+                           float scale, aldi_stream_t stream);
+/* x [T][C] in place: rows whose keep byte is 0 become zero (the value maps of padded pixels, MSDeformAttn's masked_fill) */
+int aldi_mask_rows(float* x, const unsigned char* keep, long T, int C, aldi_stream_t stream);
+/* boxes [R][4] = sigmoid(t [R][4] + (logit(ref [r % refs][0..1]), 0, 0)): the box head's last step (reference points in logit space) */
+int aldi_detr_box_finish(const float* t, const float* ref, float* boxes, long R, long refs, aldi_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------------------------------
  * ConvNeXt trunk (reference aldi/backbone.py:189-352).  Depthwise 7x7 / pad 3 convolution, NHWC, C % 8 == 0; wt is [7][7][C]
  * (the reference's [C][1][7][7] transposed), bias fp32.  flip != 0 mirrors the taps and ignores bias: the data gradient.

@@ -1,0 +1,99 @@
+"""The Deformable-DETR detector after its backbone on the HIP library (aldi_amd/detr/model.py: forward pass) against
+oracle/deformable_detr.py (pinned to transformers' implementation in tests/test_oracle_detr_cpu.py), at the reference configuration's
+widths (d_model 256, 8 heads x 32, 4 levels x 4 points, FFN 1024; configs/Base-DETR.yaml:13-26) on small maps, one image padded."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _params(gen, d=256, L=4, enc=2, dec=2, M=8, P=4, ffn=1024, Nq=100, K=20, chans=(512, 1024, 2048)):
+    def rn(*s, std=0.05):
+        return torch.randn(*s, generator=gen) * std
+    p = {}
+    for l in range(L):
+        cin = chans[l] if l < len(chans) else (chans[-1] if l == len(chans) else d)
+        k = 1 if l < len(chans) else 3
+        p[f"input_proj.{l}.0.weight"] = rn(d, cin, k, k, std=(cin * k * k) ** -0.5)
+        p[f"input_proj.{l}.0.bias"] = rn(d)
+        p[f"input_proj.{l}.1.weight"] = 1 + rn(d, std=0.1)
+        p[f"input_proj.{l}.1.bias"] = rn(d, std=0.1)
+    p["transformer.level_embed"] = rn(L, d, std=0.5)
+    def attn(pre):
+        p[pre + ".sampling_offsets.weight"] = rn(M * L * P * 2, d, std=0.02)
+        p[pre + ".sampling_offsets.bias"] = rn(M * L * P * 2, std=1.5)                 # offsets of a few pixels
+        p[pre + ".attention_weights.weight"] = rn(M * L * P, d)
+        p[pre + ".attention_weights.bias"] = rn(M * L * P, std=0.5)
+        for n in ("value_proj", "output_proj"):
+            p[pre + f".{n}.weight"] = rn(d, d, std=d ** -0.5)
+            p[pre + f".{n}.bias"] = rn(d)
+    def ffn_norms(pre, norms):
+        p[pre + ".linear1.weight"], p[pre + ".linear1.bias"] = rn(ffn, d, std=d ** -0.5), rn(ffn)
+        p[pre + ".linear2.weight"], p[pre + ".linear2.bias"] = rn(d, ffn, std=ffn ** -0.5), rn(d)
+        for n in norms:
+            p[pre + f".{n}.weight"], p[pre + f".{n}.bias"] = 1 + rn(d, std=0.1), rn(d, std=0.1)
+    for i in range(enc):
+        attn(f"transformer.encoder.layers.{i}.self_attn")
+        ffn_norms(f"transformer.encoder.layers.{i}", ("norm1", "norm2"))
+    for i in range(dec):
+        pre = f"transformer.decoder.layers.{i}"
+        attn(pre + ".cross_attn")
+        p[pre + ".self_attn.in_proj_weight"], p[pre + ".self_attn.in_proj_bias"] = rn(3 * d, d, std=d ** -0.5), rn(3 * d)
+        p[pre + ".self_attn.out_proj.weight"], p[pre + ".self_attn.out_proj.bias"] = rn(d, d, std=d ** -0.5), rn(d)
+        ffn_norms(pre, ("norm1", "norm2", "norm3"))
+    p["transformer.reference_points.weight"], p["transformer.reference_points.bias"] = rn(2, d, std=0.3), rn(2, std=0.3)
+    p["query_embed.weight"] = rn(Nq, 2 * d, std=1.0)
+    p["class_embed.weight"], p["class_embed.bias"] = rn(K, d, std=d ** -0.5), rn(K)
+    for j, (o, i) in enumerate(((d, d), (d, d), (4, d))):
+        p[f"bbox_embed.layers.{j}.weight"], p[f"bbox_embed.layers.{j}.bias"] = rn(o, i, std=i ** -0.5), rn(o, std=0.3)
+    return p
+
+
+def test_forward_matches_the_oracle():
+    from aldi_amd.detr.model import DeformableTransformer
+    from oracle import deformable_detr as D
+    gen = torch.Generator().manual_seed(0)
+    cfg = dict(d_model=256, num_levels=4, enc_layers=2, dec_layers=2, n_heads=8, enc_points=4, dec_points=4)
+    p = _params(gen)
+    B, H, W = 2, 192, 256
+    feats = [torch.randn(B, c, H // s, W // s, generator=gen) for c, s in ((512, 8), (1024, 16), (2048, 32))]
+    mask = torch.zeros(B, H, W, dtype=torch.bool)
+    mask[1, 160:, :] = True
+    mask[1, :, 200:] = True
+    ref_logits, ref_boxes = D.forward(p, feats, mask, **cfg)
+    model = DeformableTransformer(p, **cfg)
+    logits, boxes = model.forward([f.permute(0, 2, 3, 1).contiguous().cuda() for f in feats], mask)
+    torch.cuda.synchronize()
+    logits, boxes = logits.cpu(), boxes.cpu()
+    assert logits.shape == ref_logits.shape and boxes.shape == ref_boxes.shape
+    e_l = (logits - ref_logits).abs().max().item() / max(1.0, ref_logits.abs().max().item())
+    e_b = (boxes - ref_boxes).abs().max().item()
+    assert e_l <= 2e-3 and e_b <= 1e-3, (e_l, e_b)
+    # the padded image really exercised the masks, and the outputs are not degenerate
+    assert (ref_logits[:, 0] - ref_logits[:, 1]).abs().max().item() > 1e-2 and 0.05 < float(ref_boxes.std())
+    # a second call reuses the cached tables and gives the same bits
+    l2, b2 = model.forward([f.permute(0, 2, 3, 1).contiguous().cuda() for f in feats], mask)
+    assert torch.equal(l2.cpu(), logits) and torch.equal(b2.cpu(), boxes)
+
+
+def test_group_norm_and_small_attention_against_torch():
+    from aldi_amd import _lib as L
+    from aldi_amd.detr.model import group_norm
+    from aldi_amd.ops import _p, stream_ptr
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(2, 37, 53, 256, generator=g) * 3 + 1
+    gamma, beta = torch.randn(256, generator=g), torch.randn(256, generator=g)
+    y = group_norm(x.cuda(), gamma.cuda(), beta.cuda()).cpu()
+    ref = torch.nn.functional.group_norm(x.permute(0, 3, 1, 2), 32, gamma, beta, 1e-5).permute(0, 2, 3, 1)
+    assert (y - ref).abs().max().item() <= 2e-5 * ref.abs().max().item()
+    for (B, Q, H, Dh) in ((2, 300, 8, 32), (1, 77, 4, 16), (3, 64, 2, 64)):
+        q, k, v = (torch.randn(B, Q, H * Dh, generator=g) for _ in range(3))
+        out = torch.empty(B, Q, H * Dh, device="cuda")
+        lse = torch.empty(B, H, Q, device="cuda")
+        qc, kc, vc = q.cuda(), k.cuda(), v.cuda()
+        L.call("aldi_mha_small_forward", _p(qc), _p(kc), _p(vc), _p(out), _p(lse), B, Q, H, Dh, H * Dh, H * Dh, H * Dh, Dh ** -0.5, stream_ptr())
+        qh, kh, vh = (t.view(B, Q, H, Dh).transpose(1, 2).double() for t in (q, k, v))
+        s = qh @ kh.transpose(-1, -2) * Dh ** -0.5
+        ref = (torch.softmax(s, -1) @ vh).transpose(1, 2).reshape(B, Q, H * Dh)
+        assert (out.cpu().double() - ref).abs().max().item() <= 1e-5 * max(1.0, ref.abs().max().item())
+        assert (lse.cpu().double() - torch.logsumexp(s, -1)).abs().max().item() <= 1e-5 * max(1.0, s.abs().max().item())
