@@ -225,3 +225,303 @@ extern "C" int aldi_mask_rows(float* x, const unsigned char* keep, long T, int C
     ALDI_CHECK_LAUNCH();
     return ALDI_OK;
 }
+
+// ==================================================================================================== backward passes
+namespace {
+
+// msda_prepare backward: g_raw [T][M*L*P*3] (fully written) and g_ref [T][L][2] (fully written: the sum over heads and points of the
+// location gradients) from g_loc [T][M][L][P][2], g_aw [T][M][L][P] and the forward's attention weights aw.
+__global__ __launch_bounds__(256) void msda_prepare_bwd_kernel(const float* __restrict__ g_loc, const float* __restrict__ g_aw, const float* __restrict__ aw,
+                                                               const int* __restrict__ shapes, float* __restrict__ g_raw, long T, int M, int L, int P) {
+    const long i = blockIdx.x * (long)blockDim.x + threadIdx.x;          // (token, head)
+    if (i >= T * M) return;
+    const long t = i / M;
+    const int m = (int)(i % M);
+    const int LP = L * P;
+    float* o_off = g_raw + t * (long)(M * LP * 3) + (long)m * LP * 2;
+    float* o_lg = g_raw + t * (long)(M * LP * 3) + (long)M * LP * 2 + (long)m * LP;
+    const float* a = aw + i * LP;
+    const float* ga = g_aw + i * LP;
+    const float* gl = g_loc + i * LP * 2;
+    float dot = 0.f;
+    for (int k = 0; k < LP; ++k) dot += a[k] * ga[k];
+    for (int l = 0; l < L; ++l) {
+        const float iw = 1.f / (float)shapes[2 * l + 1], ih = 1.f / (float)shapes[2 * l];
+        for (int p = 0; p < P; ++p) {
+            const int k = l * P + p;
+            o_lg[k] = a[k] * (ga[k] - dot);
+            o_off[2 * k] = gl[2 * k] * iw;
+            o_off[2 * k + 1] = gl[2 * k + 1] * ih;
+        }
+    }
+}
+// g_ref [T][L][2] = sum over heads and points of g_loc (the reference point enters every location with weight 1)
+__global__ __launch_bounds__(256) void msda_ref_bwd_kernel(const float* __restrict__ g_loc, float* __restrict__ g_ref, long T, int M, int L, int P) {
+    const long i = blockIdx.x * (long)blockDim.x + threadIdx.x;          // (token, level)
+    if (i >= T * L) return;
+    const long t = i / L;
+    const int l = (int)(i % L);
+    float sx = 0.f, sy = 0.f;
+    for (int m = 0; m < M; ++m)
+        for (int p = 0; p < P; ++p) {
+            const float* g = g_loc + (((t * M + m) * L + l) * P + p) * 2;
+            sx += g[0]; sy += g[1];
+        }
+    g_ref[i * 2] = sx; g_ref[i * 2 + 1] = sy;
+}
+
+// small attention backward.  delta[b][h][i] = sum_d dO * O.  dq: one thread per query; dk, dv: one thread per key.
+template <int D>
+__global__ __launch_bounds__(64) void mha_small_bwd_q_kernel(const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v,
+                                                             const float* __restrict__ o, const float* __restrict__ d_o, const float* __restrict__ lse,
+                                                             float* __restrict__ dq, float* __restrict__ delta, int Q, int H, int ldq, int ldk, int ldv, int lddq,
+                                                             float scale) {
+    __shared__ float ks[64][D], vs[64][D];
+    const int bh = blockIdx.x, b = bh / H, h = bh % H;
+    const int qi = blockIdx.y * 64 + threadIdx.x;
+    const bool live = qi < Q;
+    float qr[D], gr[D], acc[D];
+    float dl = 0.f;
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+        qr[d] = live ? q[((long)b * Q + qi) * ldq + h * D + d] * scale : 0.f;
+        gr[d] = live ? d_o[((long)b * Q + qi) * (H * D) + h * D + d] : 0.f;
+        dl += live ? gr[d] * o[((long)b * Q + qi) * (H * D) + h * D + d] : 0.f;
+        acc[d] = 0.f;
+    }
+    const float ls = live ? lse[((long)b * H + h) * Q + qi] : 0.f;
+    for (int j0 = 0; j0 < Q; j0 += 64) {
+        __syncthreads();
+        const int j = j0 + threadIdx.x;
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            ks[threadIdx.x][d] = j < Q ? k[((long)b * Q + j) * ldk + h * D + d] : 0.f;
+            vs[threadIdx.x][d] = j < Q ? v[((long)b * Q + j) * ldv + h * D + d] : 0.f;
+        }
+        __syncthreads();
+        const int nj = min(64, Q - j0);
+        for (int jj = 0; jj < nj; ++jj) {
+            float s = 0.f, dp = 0.f;
+#pragma unroll
+            for (int d = 0; d < D; ++d) { s += qr[d] * ks[jj][d]; dp += gr[d] * vs[jj][d]; }
+            const float p = expf(s - ls);
+            const float ds = p * (dp - dl);
+#pragma unroll
+            for (int d = 0; d < D; ++d) acc[d] += ds * ks[jj][d];
+        }
+    }
+    if (!live) return;
+#pragma unroll
+    for (int d = 0; d < D; ++d) dq[((long)b * Q + qi) * lddq + h * D + d] = acc[d] * scale;
+    delta[((long)b * H + h) * Q + qi] = dl;
+}
+template <int D>
+__global__ __launch_bounds__(64) void mha_small_bwd_kv_kernel(const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v,
+                                                              const float* __restrict__ d_o, const float* __restrict__ lse, const float* __restrict__ delta,
+                                                              float* __restrict__ dk, float* __restrict__ dv, int Q, int H, int ldq, int ldk, int ldv, int lddk,
+                                                              int lddv, float scale) {
+    __shared__ float qs[64][D], gs[64][D], ls_[64], dl_[64];
+    const int bh = blockIdx.x, b = bh / H, h = bh % H;
+    const int kj = blockIdx.y * 64 + threadIdx.x;
+    const bool live = kj < Q;
+    float kr[D], vr[D], ak[D], av[D];
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+        kr[d] = live ? k[((long)b * Q + kj) * ldk + h * D + d] : 0.f;
+        vr[d] = live ? v[((long)b * Q + kj) * ldv + h * D + d] : 0.f;
+        ak[d] = av[d] = 0.f;
+    }
+    for (int i0 = 0; i0 < Q; i0 += 64) {
+        __syncthreads();
+        const int i = i0 + threadIdx.x;
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            qs[threadIdx.x][d] = i < Q ? q[((long)b * Q + i) * ldq + h * D + d] * scale : 0.f;
+            gs[threadIdx.x][d] = i < Q ? d_o[((long)b * Q + i) * (H * D) + h * D + d] : 0.f;
+        }
+        ls_[threadIdx.x] = i < Q ? lse[((long)b * H + h) * Q + i] : 0.f;
+        dl_[threadIdx.x] = i < Q ? delta[((long)b * H + h) * Q + i] : 0.f;
+        __syncthreads();
+        const int ni = min(64, Q - i0);
+        for (int ii = 0; ii < ni; ++ii) {
+            float s = 0.f, dp = 0.f;
+#pragma unroll
+            for (int d = 0; d < D; ++d) { s += qs[ii][d] * kr[d]; dp += gs[ii][d] * vr[d]; }
+            const float p = expf(s - ls_[ii]);
+            const float ds = p * (dp - dl_[ii]);
+#pragma unroll
+            for (int d = 0; d < D; ++d) { av[d] += p * gs[ii][d]; ak[d] += ds * qs[ii][d]; }
+        }
+    }
+    if (!live) return;
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+        dk[((long)b * Q + kj) * lddk + h * D + d] = ak[d];           // (qs already carries the scale)
+        dv[((long)b * Q + kj) * lddv + h * D + d] = av[d];
+    }
+}
+
+// GroupNorm backward.  Stage 1 per (image, pixel chunk): per channel sum(g) and sum(g * xhat) -> part [N][chunks][C][2]; stage 2 per image:
+// chunks added in order -> per-group sums ds, db (for dx) and per-channel sums accumulated into dgamma / dbeta over images in order.
+__global__ __launch_bounds__(256) void gn_bwd_partial_kernel(const float* __restrict__ g, const float* __restrict__ x, const float* __restrict__ mean,
+                                                             const float* __restrict__ rstd, float* __restrict__ part, int HW, int C, int G, int chunk_px) {
+    const int n = blockIdx.y, ch = blockIdx.x, chunks = gridDim.x;
+    const int p0 = ch * chunk_px, p1 = min(HW, p0 + chunk_px);
+    const int cpg = C / G;
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        const float m = mean[n * G + c / cpg], r = rstd[n * G + c / cpg];
+        float s = 0.f, q = 0.f;
+        const long base = ((long)n * HW + p0) * C + c;
+        for (int p = 0; p < p1 - p0; ++p) {
+            const float gv = g[base + (long)p * C];
+            s += gv;
+            q += gv * (x[base + (long)p * C] - m) * r;
+        }
+        float* o = part + (((long)n * chunks + ch) * C + c) * 2;
+        o[0] = s; o[1] = q;
+    }
+}
+// one workgroup per image: sums [C][2] over chunks (LDS), group sums, then this image's contribution to dgamma / dbeta
+__global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(const float* __restrict__ part, const float* __restrict__ gamma, float* __restrict__ gsum /*[N][G][2]*/,
+                                                            float* __restrict__ chan /*[N][C][2]*/, int chunks, int C, int G) {
+    extern __shared__ float sm[];                     // [C][2]
+    const int n = blockIdx.x, cpg = C / G;
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        float s = 0.f, q = 0.f;
+        for (int k = 0; k < chunks; ++k) {
+            const float* o = part + (((long)n * chunks + k) * C + c) * 2;
+            s += o[0]; q += o[1];
+        }
+        sm[2 * c] = s; sm[2 * c + 1] = q;
+        chan[((long)n * C + c) * 2] = s; chan[((long)n * C + c) * 2 + 1] = q;
+    }
+    __syncthreads();
+    for (int gi = threadIdx.x; gi < G; gi += blockDim.x) {
+        float a = 0.f, b = 0.f;                       // sum(g * gamma), sum(g * gamma * xhat) over the group
+        for (int k = 0; k < cpg; ++k) {
+            const int c = gi * cpg + k;
+            a += sm[2 * c] * gamma[c];
+            b += sm[2 * c + 1] * gamma[c];
+        }
+        gsum[((long)n * G + gi) * 2] = a; gsum[((long)n * G + gi) * 2 + 1] = b;
+    }
+}
+__global__ void gn_bwd_params_kernel(const float* __restrict__ chan, float* __restrict__ dgamma, float* __restrict__ dbeta, int N, int C) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    float s = 0.f, q = 0.f;
+    for (int n = 0; n < N; ++n) { s += chan[((long)n * C + c) * 2]; q += chan[((long)n * C + c) * 2 + 1]; }
+    dbeta[c] += s; dgamma[c] += q;
+}
+__global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const float* __restrict__ g, const float* __restrict__ x, const float* __restrict__ mean,
+                                                           const float* __restrict__ rstd, const float* __restrict__ gamma, const float* __restrict__ gsum,
+                                                           float* __restrict__ dx, long total, int HW, int C, int G) {
+    const int cpg = C / G;
+    const float inv_cnt = 1.f / ((float)HW * (float)cpg);
+    for (long i = (blockIdx.x * (long)blockDim.x + threadIdx.x) * 4; i < total; i += (long)gridDim.x * blockDim.x * 4) {
+        const int c = (int)(i % C);
+        const int n = (int)(i / ((long)HW * C));
+        const float4 gv = *reinterpret_cast<const float4*>(g + i), xv = *reinterpret_cast<const float4*>(x + i);
+        const float gg[4] = {gv.x, gv.y, gv.z, gv.w}, xx[4] = {xv.x, xv.y, xv.z, xv.w};
+        float o[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int gi = (c + k) / cpg;
+            const float m = mean[n * G + gi], r = rstd[n * G + gi];
+            const float a = gsum[((long)n * G + gi) * 2] * inv_cnt, b = gsum[((long)n * G + gi) * 2 + 1] * inv_cnt;
+            const float xh = (xx[k] - m) * r;
+            o[k] = r * (gg[k] * gamma[c + k] - a - xh * b);
+        }
+        *reinterpret_cast<float4*>(dx + i) = make_float4(o[0], o[1], o[2], o[3]);
+    }
+}
+
+// box head's last step backward: g_t [R][4] (fully written), g_ref [refs][2] accumulated over the rows that share a reference point
+__global__ void box_finish_bwd_kernel(const float* __restrict__ g_boxes, const float* __restrict__ boxes, const float* __restrict__ ref, float* __restrict__ g_t,
+                                      long R) {
+    const long r = blockIdx.x * (long)blockDim.x + threadIdx.x;
+    if (r >= R) return;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const float s = boxes[r * 4 + k];
+        g_t[r * 4 + k] = g_boxes[r * 4 + k] * s * (1.f - s);
+    }
+}
+// g_ref [refs][2] = sum over rows r with r % refs == j (in row order) of g_t[r][0..1] * d logit / d ref
+__global__ void box_ref_bwd_kernel(const float* __restrict__ g_t, const float* __restrict__ ref, float* __restrict__ g_ref, long R, long refs) {
+    const long j = blockIdx.x * (long)blockDim.x + threadIdx.x;
+    if (j >= refs) return;
+    float sx = 0.f, sy = 0.f;
+    for (long r = j; r < R; r += refs) { sx += g_t[r * 4]; sy += g_t[r * 4 + 1]; }
+    const float s[2] = {sx, sy};
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const float u = ref[j * 2 + k];
+        // logit(u) = log(max(u, eps)) - log(max(1 - u, eps)): each clamp switches its term's derivative off
+        float d = 0.f;
+        if (u >= 0.f && u <= 1.f) d = (u > 1e-5f ? 1.f / u : 0.f) + (1.f - u > 1e-5f ? 1.f / (1.f - u) : 0.f);
+        g_ref[j * 2 + k] += s[k] * d;
+    }
+}
+
+}  // namespace
+
+extern "C" int aldi_msda_prepare_backward(const float* g_loc, const float* g_aw, const float* attn_weight, const int* spatial_shapes, float* g_raw, float* g_ref, long T,
+                                          int M, int L, int P, aldi_stream_t stream) {
+    if (!g_loc || !g_aw || !attn_weight || !spatial_shapes || !g_raw || T <= 0) return aldi_set_error_msg(ALDI_ERR_ARG, "msda_prepare_backward: bad args");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(msda_prepare_bwd_kernel, dim3((unsigned)((T * M + 255) / 256)), dim3(256), 0, st, g_loc, g_aw, attn_weight, spatial_shapes, g_raw, T, M, L, P);
+    if (g_ref) hipLaunchKernelGGL(msda_ref_bwd_kernel, dim3((unsigned)((T * L + 255) / 256)), dim3(256), 0, st, g_loc, g_ref, T, M, L, P);
+    ALDI_CHECK_LAUNCH();
+    return ALDI_OK;
+}
+
+extern "C" int aldi_mha_small_backward(const float* q, const float* k, const float* v, const float* out, const float* d_out, const float* lse, float* dq, float* dk,
+                                       float* dv, float* delta, int B, int Q, int H, int D, int ldq, int ldk, int ldv, int lddq, int lddk, int lddv, float scale,
+                                       aldi_stream_t stream) {
+    if (!q || !k || !v || !out || !d_out || !lse || !dq || !dk || !dv || !delta) return aldi_set_error_msg(ALDI_ERR_ARG, "mha_small_backward: null pointer");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const dim3 grid(B * H, cdiv(Q, 64));
+#define ALDI_MHA_BWD(DD)                                                                                                                                         \
+    hipLaunchKernelGGL(mha_small_bwd_q_kernel<DD>, grid, dim3(64), 0, st, q, k, v, out, d_out, lse, dq, delta, Q, H, ldq, ldk, ldv, lddq, scale);               \
+    hipLaunchKernelGGL(mha_small_bwd_kv_kernel<DD>, grid, dim3(64), 0, st, q, k, v, d_out, lse, delta, dk, dv, Q, H, ldq, ldk, ldv, lddk, lddv, scale)
+    if (D == 32) { ALDI_MHA_BWD(32); }
+    else if (D == 16) { ALDI_MHA_BWD(16); }
+    else if (D == 64) { ALDI_MHA_BWD(64); }
+    else return aldi_set_error_msg(ALDI_ERR_ARG, "mha_small_backward: head width 16, 32 or 64");
+#undef ALDI_MHA_BWD
+    ALDI_CHECK_LAUNCH();
+    return ALDI_OK;
+}
+
+extern "C" size_t aldi_group_norm_backward_workspace(int N, int HW, int C, int G) {
+    return ((size_t)N * cdiv(HW, 256) * C * 2 + (size_t)N * G * 2 + (size_t)N * C * 2) * sizeof(float);
+}
+extern "C" int aldi_group_norm_backward(const float* g, const float* x, const float* gamma, const float* mean, const float* rstd, float* dx, float* dgamma,
+                                        float* dbeta, void* workspace, int N, int HW, int C, int G, aldi_stream_t stream) {
+    if (!g || !x || !gamma || !mean || !rstd || !dx || !dgamma || !dbeta || !workspace || C % G || C % 4 || C > 4096)
+        return aldi_set_error_msg(ALDI_ERR_ARG, "group_norm_backward: bad args");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int chunk = 256, chunks = cdiv(HW, chunk);
+    float* part = static_cast<float*>(workspace);
+    float* gsum = part + (size_t)N * chunks * C * 2;
+    float* chan = gsum + (size_t)N * G * 2;
+    hipLaunchKernelGGL(gn_bwd_partial_kernel, dim3(chunks, N), dim3(256), 0, st, g, x, mean, rstd, part, HW, C, G, chunk);
+    hipLaunchKernelGGL(gn_bwd_reduce_kernel, dim3(N), dim3(256), (size_t)C * 2 * sizeof(float), st, part, gamma, gsum, chan, chunks, C, G);
+    hipLaunchKernelGGL(gn_bwd_params_kernel, dim3(cdiv(C, 256)), dim3(256), 0, st, chan, dgamma, dbeta, N, C);
+    const long total = (long)N * HW * C;
+    hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3((unsigned)((total / 4 + 255) / 256 < 4096 ? (total / 4 + 255) / 256 : 4096)), dim3(256), 0, st, g, x, mean, rstd, gamma,
+                       gsum, dx, total, HW, C, G);
+    ALDI_CHECK_LAUNCH();
+    return ALDI_OK;
+}
+
+extern "C" int aldi_detr_box_finish_backward(const float* g_boxes, const float* boxes, const float* ref, float* g_t, float* g_ref, long R, long refs,
+                                             aldi_stream_t stream) {
+    if (!g_boxes || !boxes || !ref || !g_t || R <= 0 || refs <= 0) return aldi_set_error_msg(ALDI_ERR_ARG, "detr_box_finish_backward: bad args");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(box_finish_bwd_kernel, dim3((unsigned)((R + 255) / 256)), dim3(256), 0, st, g_boxes, boxes, ref, g_t, R);
+    if (g_ref) hipLaunchKernelGGL(box_ref_bwd_kernel, dim3((unsigned)((refs + 255) / 256)), dim3(256), 0, st, g_t, ref, g_ref, R, refs);
+    ALDI_CHECK_LAUNCH();
+    return ALDI_OK;
+}

@@ -541,6 +541,21 @@ int aldi_msda_prepare(const float* raw, const float* ref, const int* spatial_sha
  * floats, D = 16, 32 or 64; out [B][Q][H*D]; lse [B][H][Q] nullable. */
 int aldi_mha_small_forward(const float* q, const float* k, const float* v, float* out, float* lse, int B, int Q, int H, int D, int ldq, int ldk, int ldv,
                            float scale, aldi_stream_t stream);
+/* Backward passes of the three above.  msda_prepare: g_raw [T][M*L*P*3] fully written from the sampling op's gradients (g_loc, g_aw) and
+ * the forward's attention weights; g_ref [T][L][2] (nullable) = the reference points' gradient, fully written.  mha_small: dq / dk / dv with
+ * row strides lddq / lddk / lddv from out, d_out and the forward's lse; delta [B][H][Q] is scratch.  group_norm: dx fully written, dgamma /
+ * dbeta ACCUMULATE (deterministically: fixed summation orders); workspace aldi_group_norm_backward_workspace(N, HW, C, G) bytes. */
+int aldi_msda_prepare_backward(const float* g_loc, const float* g_aw, const float* attn_weight, const int* spatial_shapes, float* g_raw, float* g_ref, long T,
+                               int M, int L, int P, aldi_stream_t stream);
+int aldi_mha_small_backward(const float* q, const float* k, const float* v, const float* out, const float* d_out, const float* lse, float* dq, float* dk,
+                            float* dv, float* delta, int B, int Q, int H, int D, int ldq, int ldk, int ldv, int lddq, int lddk, int lddv, float scale,
+                            aldi_stream_t stream);
+size_t aldi_group_norm_backward_workspace(int N, int HW, int C, int G);
+int aldi_group_norm_backward(const float* g, const float* x, const float* gamma, const float* mean, const float* rstd, float* dx, float* dgamma,
+                             float* dbeta, void* workspace, int N, int HW, int C, int G, aldi_stream_t stream);
+/* g_t [R][4] = g_boxes * boxes * (1 - boxes); g_ref [refs][2] (nullable) ACCUMULATES the reference points' gradient through logit(). */
+int aldi_detr_box_finish_backward(const float* g_boxes, const float* boxes, const float* ref, float* g_t, float* g_ref, long R, long refs,
+                                  aldi_stream_t stream);
 /* x [T][C] in place: rows whose keep byte is 0 become zero (the value maps of padded pixels, MSDeformAttn's masked_fill) */
 int aldi_mask_rows(float* x, const unsigned char* keep, long T, int C, aldi_stream_t stream);
 /* boxes [R][4] = sigmoid(t [R][4] + (logit(ref [r % refs][0..1]), 0, 0)): the box head's last step (reference points in logit space) */

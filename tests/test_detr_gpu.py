@@ -97,3 +97,42 @@ def test_group_norm_and_small_attention_against_torch():
         ref = (torch.softmax(s, -1) @ vh).transpose(1, 2).reshape(B, Q, H * Dh)
         assert (out.cpu().double() - ref).abs().max().item() <= 1e-5 * max(1.0, ref.abs().max().item())
         assert (lse.cpu().double() - torch.logsumexp(s, -1)).abs().max().item() <= 1e-5 * max(1.0, s.abs().max().item())
+
+
+def test_backward_matches_the_oracles_autograd():
+    """d(loss)/d(every parameter) and d(loss)/d(backbone maps) of the taped backward == torch autograd through the oracle, for a random
+    linear functional of all decoder layers' logits and boxes (one image padded)"""
+    from aldi_amd.detr.model import DeformableTransformer
+    from oracle import deformable_detr as D
+    gen = torch.Generator().manual_seed(3)
+    cfg = dict(d_model=256, num_levels=4, enc_layers=2, dec_layers=2, n_heads=8, enc_points=4, dec_points=4)
+    p = _params(gen, Nq=60, K=12)
+    B, H, W = 2, 128, 160
+    feats = [torch.randn(B, c, H // s, W // s, generator=gen) for c, s in ((512, 8), (1024, 16), (2048, 32))]
+    mask = torch.zeros(B, H, W, dtype=torch.bool)
+    mask[1, 100:, :] = True
+    mask[1, :, 130:] = True
+    pr = {k: v.clone().double().requires_grad_(True) for k, v in p.items()}
+    fr = [f.clone().double().requires_grad_(True) for f in feats]
+    lo, bo = D.forward(pr, fr, mask, **cfg)
+    R1, R2 = torch.randn(lo.shape, generator=gen), torch.randn(bo.shape, generator=gen)
+    (lo * R1.double()).sum().add((bo * R2.double()).sum()).backward()
+    model = DeformableTransformer(p, **cfg)
+    model.P.zero_grad()
+    f_dev = [f.permute(0, 2, 3, 1).contiguous().cuda() for f in feats]
+    logits, boxes = model.forward(f_dev, mask, record=True, feats_need_grad=True)
+    gf = model.backward(R1.cuda(), R2.cuda())
+    torch.cuda.synchronize()
+    assert (logits.cpu().double() - lo.detach()).abs().max().item() <= 2e-3 * max(1.0, lo.abs().max().item())
+    got = model.P.state_dict(model.P.grad)
+    worst = []
+    for k, v in pr.items():
+        ref = v.grad
+        e = (got[k].cpu().double() - ref).abs().max().item() / max(ref.abs().max().item(), 1e-6)
+        worst.append((e, k))
+        assert ref.abs().max().item() > 0, k
+    worst.sort(reverse=True)
+    assert worst[0][0] <= 5e-3, worst[:8]
+    for g, f in zip(gf, fr):
+        ref = f.grad.permute(0, 2, 3, 1)
+        assert (g.cpu().double() - ref).abs().max().item() <= 5e-3 * ref.abs().max().item()
