@@ -525,3 +525,144 @@ extern "C" int aldi_detr_box_finish_backward(const float* g_boxes, const float* 
     ALDI_CHECK_LAUNCH();
     return ALDI_OK;
 }
+
+// ==================================================================================================== Hungarian cost and set loss
+namespace {
+
+__device__ __forceinline__ void cxcywh_to_xyxy(const float* b, float* o) {
+    o[0] = b[0] - 0.5f * b[2]; o[1] = b[1] - 0.5f * b[3]; o[2] = b[0] + 0.5f * b[2]; o[3] = b[1] + 0.5f * b[3];
+}
+// generalized IoU of two xyxy boxes; optionally its gradient with respect to box a's corners
+__device__ __forceinline__ float giou_xyxy(const float* a, const float* b, float* da) {
+    const float aw = a[2] - a[0], ah = a[3] - a[1];
+    const float area_a = aw * ah, area_b = (b[2] - b[0]) * (b[3] - b[1]);
+    const float ix0 = fmaxf(a[0], b[0]), iy0 = fmaxf(a[1], b[1]), ix1 = fminf(a[2], b[2]), iy1 = fminf(a[3], b[3]);
+    const float iw = fmaxf(ix1 - ix0, 0.f), ih = fmaxf(iy1 - iy0, 0.f);
+    const float inter = iw * ih, uni = area_a + area_b - inter;
+    const float hx0 = fminf(a[0], b[0]), hy0 = fminf(a[1], b[1]), hx1 = fmaxf(a[2], b[2]), hy1 = fmaxf(a[3], b[3]);
+    const float hw = fmaxf(hx1 - hx0, 0.f), hh = fmaxf(hy1 - hy0, 0.f);
+    const float hull = hw * hh;
+    const float g = inter / uni - (hull - uni) / hull;
+    if (da) {
+        // corner k of a: derivative of every piece
+        const float d_iw[4] = {(iw > 0.f && a[0] > b[0]) ? -1.f : 0.f, 0.f, (iw > 0.f && a[2] < b[2]) ? 1.f : 0.f, 0.f};
+        const float d_ih[4] = {0.f, (ih > 0.f && a[1] > b[1]) ? -1.f : 0.f, 0.f, (ih > 0.f && a[3] < b[3]) ? 1.f : 0.f};
+        const float d_aa[4] = {-ah, -aw, ah, aw};
+        const float d_hw[4] = {(a[0] < b[0]) ? -1.f : 0.f, 0.f, (a[2] > b[2]) ? 1.f : 0.f, 0.f};
+        const float d_hh[4] = {0.f, (a[1] < b[1]) ? -1.f : 0.f, 0.f, (a[3] > b[3]) ? 1.f : 0.f};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float d_inter = d_iw[k] * ih + iw * d_ih[k];
+            const float d_uni = d_aa[k] - d_inter;
+            const float d_hull = d_hw[k] * hh + hw * d_hh[k];
+            da[k] = (d_inter * uni - inter * d_uni) / (uni * uni) + (d_uni * hull - uni * d_hull) / (hull * hull);
+        }
+    }
+    return g;
+}
+
+// cost [LB][Nq][Gmax] of assigning query q to target g (focal-style class cost, L1, -GIoU); targets of image lb % B
+__global__ __launch_bounds__(256) void detr_cost_kernel(const float* __restrict__ logits, const float* __restrict__ boxes, const int* __restrict__ t_labels,
+                                                        const float* __restrict__ t_boxes, const int* __restrict__ t_count, float* __restrict__ cost, int LB, int B,
+                                                        int Nq, int K, int Gmax, float w_class, float w_bbox, float w_giou, float alpha) {
+    const long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
+    if (i >= (long)LB * Nq * Gmax) return;
+    const int g = (int)(i % Gmax);
+    const long r = i / Gmax;                          // (lb, q)
+    const int b = (int)((r / Nq) % B);
+    if (g >= t_count[b]) { cost[i] = 0.f; return; }
+    const int lab = t_labels[b * Gmax + g];
+    const float p = 1.f / (1.f + expf(-logits[r * K + lab]));
+    const float neg = (1.f - alpha) * p * p * -logf(1.f - p + 1e-8f);
+    const float pos = alpha * (1.f - p) * (1.f - p) * -logf(p + 1e-8f);
+    const float* pb = boxes + r * 4;
+    const float* tb = t_boxes + ((long)b * Gmax + g) * 4;
+    const float l1 = fabsf(pb[0] - tb[0]) + fabsf(pb[1] - tb[1]) + fabsf(pb[2] - tb[2]) + fabsf(pb[3] - tb[3]);
+    float pa[4], ta[4];
+    cxcywh_to_xyxy(pb, pa); cxcywh_to_xyxy(tb, ta);
+    cost[i] = w_bbox * l1 + w_class * (pos - neg) - w_giou * giou_xyxy(pa, ta, nullptr);
+}
+
+// One thread per (lb, q): the focal loss of its K logits (+ gradient), and, when the query is matched (match[lb][q] = target index or -1),
+// the L1 and GIoU terms of its box (+ gradient).  rows [LB*Nq][3] = this row's (focal, L1, 1 - GIoU) sums; gradients already carry
+// coefficient / num_boxes.
+__global__ __launch_bounds__(256) void detr_loss_kernel(const float* __restrict__ logits, const float* __restrict__ boxes, const int* __restrict__ match,
+                                                        const int* __restrict__ t_labels, const float* __restrict__ t_boxes, float* __restrict__ rows,
+                                                        float* __restrict__ g_logits, float* __restrict__ g_boxes, int LB, int B, int Nq, int K, int Gmax,
+                                                        float alpha, float c_ce, float c_bbox, float c_giou, float inv_num_boxes) {
+    const long r = blockIdx.x * (long)blockDim.x + threadIdx.x;
+    if (r >= (long)LB * Nq) return;
+    const int b = (int)((r / Nq) % B);
+    const int m = match[r];
+    const int lab = m >= 0 ? t_labels[b * Gmax + m] : -1;
+    float ce = 0.f;
+    for (int k = 0; k < K; ++k) {
+        const float x = logits[r * K + k];
+        const float p = 1.f / (1.f + expf(-x));
+        // binary cross entropy with logits, stable form; focal weight (1 - p_t)^2 and the alpha balance
+        const float t = k == lab ? 1.f : 0.f;
+        const float bce = fmaxf(x, 0.f) - x * t + log1pf(expf(-fabsf(x)));
+        const float pt = p * t + (1.f - p) * (1.f - t);
+        const float at = alpha * t + (1.f - alpha) * (1.f - t);
+        ce += at * (1.f - pt) * (1.f - pt) * bce;
+        float d;
+        if (k == lab) d = alpha * (1.f - p) * (1.f - p) * (2.f * p * logf(fmaxf(p, 1e-38f)) - (1.f - p));
+        else d = (1.f - alpha) * p * p * (p - 2.f * (1.f - p) * log1pf(-fminf(p, 1.f - 1e-7f)));
+        g_logits[r * K + k] = d * c_ce * inv_num_boxes;
+    }
+    float l1 = 0.f, gl = 0.f;
+    float gb[4] = {0.f, 0.f, 0.f, 0.f};
+    if (m >= 0) {
+        const float* pb = boxes + r * 4;
+        const float* tb = t_boxes + ((long)b * Gmax + m) * 4;
+        float pa[4], ta[4], da[4];
+        cxcywh_to_xyxy(pb, pa); cxcywh_to_xyxy(tb, ta);
+        const float g = giou_xyxy(pa, ta, da);
+        gl = 1.f - g;
+        // corners -> (cx, cy, w, h): x0 = cx - w/2, x1 = cx + w/2
+        const float dg[4] = {da[0] + da[2], da[1] + da[3], 0.5f * (da[2] - da[0]), 0.5f * (da[3] - da[1])};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float df = pb[k] - tb[k];
+            l1 += fabsf(df);
+            gb[k] = (c_bbox * (df > 0.f ? 1.f : (df < 0.f ? -1.f : 0.f)) - c_giou * dg[k]) * inv_num_boxes;
+        }
+    }
+    *reinterpret_cast<float4*>(g_boxes + r * 4) = make_float4(gb[0], gb[1], gb[2], gb[3]);
+    rows[r * 3] = ce; rows[r * 3 + 1] = l1; rows[r * 3 + 2] = gl;
+}
+// losses [LB / B][3]: per decoder layer, the rows of its B images added in row order, / num_boxes
+__global__ void detr_loss_reduce_kernel(const float* __restrict__ rows, float* __restrict__ losses, int rows_per_layer, float inv_num_boxes) {
+    const int l = blockIdx.x, k = threadIdx.x;
+    if (k >= 3) return;
+    float s = 0.f;
+    for (int r = 0; r < rows_per_layer; ++r) s += rows[((long)l * rows_per_layer + r) * 3 + k];
+    losses[l * 3 + k] = s * inv_num_boxes;
+}
+
+}  // namespace
+
+extern "C" int aldi_detr_match_cost(const float* logits, const float* boxes, const int* t_labels, const float* t_boxes, const int* t_count, float* cost, int LB, int B,
+                                    int Nq, int K, int Gmax, float w_class, float w_bbox, float w_giou, float alpha, aldi_stream_t stream) {
+    if (!logits || !boxes || !t_labels || !t_boxes || !t_count || !cost || LB <= 0 || B <= 0 || LB % B || Gmax <= 0)
+        return aldi_set_error_msg(ALDI_ERR_ARG, "detr_match_cost: bad args");
+    const long n = (long)LB * Nq * Gmax;
+    hipLaunchKernelGGL(detr_cost_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), logits, boxes, t_labels, t_boxes, t_count, cost,
+                       LB, B, Nq, K, Gmax, w_class, w_bbox, w_giou, alpha);
+    ALDI_CHECK_LAUNCH();
+    return ALDI_OK;
+}
+
+extern "C" int aldi_detr_set_loss(const float* logits, const float* boxes, const int* match, const int* t_labels, const float* t_boxes, float* rows, float* losses,
+                                  float* g_logits, float* g_boxes, int LB, int B, int Nq, int K, int Gmax, float alpha, float c_ce, float c_bbox, float c_giou,
+                                  float num_boxes, aldi_stream_t stream) {
+    if (!logits || !boxes || !match || !t_labels || !t_boxes || !rows || !losses || !g_logits || !g_boxes || LB <= 0 || B <= 0 || LB % B || num_boxes <= 0.f)
+        return aldi_set_error_msg(ALDI_ERR_ARG, "detr_set_loss: bad args");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const long n = (long)LB * Nq;
+    hipLaunchKernelGGL(detr_loss_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, logits, boxes, match, t_labels, t_boxes, rows, g_logits, g_boxes, LB, B, Nq, K,
+                       Gmax, alpha, c_ce, c_bbox, c_giou, 1.f / num_boxes);
+    hipLaunchKernelGGL(detr_loss_reduce_kernel, dim3(LB / B), dim3(64), 0, st, rows, losses, B * Nq, 1.f / num_boxes);
+    ALDI_CHECK_LAUNCH();
+    return ALDI_OK;
+}

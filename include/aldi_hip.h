@@ -556,6 +556,18 @@ int aldi_group_norm_backward(const float* g, const float* x, const float* gamma,
 /* g_t [R][4] = g_boxes * boxes * (1 - boxes); g_ref [refs][2] (nullable) ACCUMULATES the reference points' gradient through logit(). */
 int aldi_detr_box_finish_backward(const float* g_boxes, const float* boxes, const float* ref, float* g_t, float* g_ref, long R, long refs,
                                   aldi_stream_t stream);
+/* The set loss of LB = (decoder layers x B) prediction sets against the B images' targets (padded to Gmax; t_count [B]), as the authors
+ * compute it (oracle/deformable_detr.py; coefficients configs/Base-DETR.yaml:27-39).
+ * match_cost: cost [LB][Nq][Gmax] = w_bbox * L1 + w_class * focal class cost - w_giou * GIoU (columns >= t_count are 0): what the HOST's
+ *   Hungarian solver takes (scipy.optimize.linear_sum_assignment, as in the reference: a sequential algorithm on 300 x ~10 matrices).
+ * set_loss: match [LB][Nq] = index of the query's target or -1.  losses [LB / B][3] = (focal x 1, L1, 1 - GIoU) sums / num_boxes per
+ *   decoder layer (unweighted, rows added in order: deterministic); g_logits / g_boxes = gradients of sum_layers (c_ce * focal + c_bbox *
+ *   L1 + c_giou * (1 - GIoU)); rows [LB * Nq][3] is scratch. */
+int aldi_detr_match_cost(const float* logits, const float* boxes, const int* t_labels, const float* t_boxes, const int* t_count, float* cost, int LB, int B,
+                         int Nq, int K, int Gmax, float w_class, float w_bbox, float w_giou, float alpha, aldi_stream_t stream);
+int aldi_detr_set_loss(const float* logits, const float* boxes, const int* match, const int* t_labels, const float* t_boxes, float* rows, float* losses,
+                       float* g_logits, float* g_boxes, int LB, int B, int Nq, int K, int Gmax, float alpha, float c_ce, float c_bbox, float c_giou,
+                       float num_boxes, aldi_stream_t stream);
 /* x [T][C] in place: rows whose keep byte is 0 become zero (the value maps of padded pixels, MSDeformAttn's masked_fill) */
 int aldi_mask_rows(float* x, const unsigned char* keep, long T, int C, aldi_stream_t stream);
 /* boxes [R][4] = sigmoid(t [R][4] + (logit(ref [r % refs][0..1]), 0, 0)): the box head's last step (reference points in logit space) */

@@ -136,3 +136,41 @@ def test_backward_matches_the_oracles_autograd():
     for g, f in zip(gf, fr):
         ref = f.grad.permute(0, 2, 3, 1)
         assert (g.cpu().double() - ref).abs().max().item() <= 5e-3 * ref.abs().max().item()
+
+
+def test_set_criterion_matches_the_oracle():
+    """matching, the weighted loss entries of every decoder layer and d(total)/d(logits, boxes) == the oracle's criterion + autograd;
+    one image without targets"""
+    from aldi_amd.detr.criterion import SetCriterion
+    from oracle import deformable_detr as D
+    g = torch.Generator().manual_seed(9)
+    Ld, B, Nq, K = 3, 3, 50, 9
+    logits = torch.randn(Ld, B, Nq, K, generator=g) * 2
+    cxcy = torch.rand(Ld, B, Nq, 2, generator=g) * 0.6 + 0.2
+    wh = torch.rand(Ld, B, Nq, 2, generator=g) * 0.3 + 0.05
+    boxes = torch.cat([cxcy, wh], -1)
+    targets = []
+    for n in (4, 0, 7):
+        targets.append({"labels": torch.randint(0, K, (n,), generator=g), "boxes": torch.cat([torch.rand(n, 2, generator=g) * 0.6 + 0.2, torch.rand(n, 2, generator=g) * 0.3 + 0.05], -1)})
+    lr, br = logits.clone().double().requires_grad_(True), boxes.clone().double().requires_grad_(True)
+    tr = [{"labels": t["labels"], "boxes": t["boxes"].double()} for t in targets]
+    ref, total = D.criterion(lr, br, tr, weights=(2.0, 5.0, 2.0))
+    total.backward()
+    crit = SetCriterion()
+    out, gl, gb = crit(logits.cuda(), boxes.cuda(), targets)
+    torch.cuda.synchronize()
+    w = {"loss_ce": 2.0, "loss_bbox": 5.0, "loss_giou": 2.0}
+    assert list(out.keys()) == ["loss_ce_0", "loss_bbox_0", "loss_giou_0", "loss_ce_1", "loss_bbox_1", "loss_giou_1", "loss_ce", "loss_bbox", "loss_giou"]
+    for k, v in out.items():
+        base = k.split("_")[0] + "_" + k.split("_")[1]
+        assert abs(float(v) - w[base] * float(ref[k])) <= 1e-4 * max(1.0, abs(w[base] * float(ref[k]))), (k, float(v), float(ref[k]))
+    assert abs(sum(float(v) for v in out.values()) - float(total)) <= 1e-4 * float(total)
+    assert (gl.cpu().double() - lr.grad).abs().max().item() <= 1e-4 * lr.grad.abs().max().item()
+    assert (gb.cpu().double() - br.grad).abs().max().item() <= 1e-4 * br.grad.abs().max().item()
+    # the assignment: one query per target, the oracle's pairs
+    m = crit.last_match.cpu().view(Ld, B, Nq)
+    for l in range(Ld):
+        idx = D.hungarian_match(logits[l], boxes[l], targets)
+        for b, (qi, gi) in enumerate(idx):
+            got = {(int(q), int(m[l, b, q])) for q in range(Nq) if m[l, b, q] >= 0}
+            assert got == set(zip(qi.tolist(), gi.tolist())), (l, b)
