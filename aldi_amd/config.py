@@ -227,6 +227,49 @@ def add_aldi_config(cfg: CfgNode):
     _C.SOLVER.STEP_GRAPH = False          # replay the fused step's two device phases as hipGraphs (aldi_amd/fused_step.py)
     _C.SOLVER.GRAD_PAYLOAD = "fp32"       # data-parallel gradient exchange: "fp32" (exact) or "bf16" (half the bytes per xGMI link)
 
+    # Deformable-DETR (the reference's absent submodule adds these through its own add_deformable_detr_config; configs/Base-DETR.yaml)
+    _C.MODEL.DEFORMABLE_DETR = CN()
+    D = _C.MODEL.DEFORMABLE_DETR
+    D.NUM_CLASSES = 80
+    D.BACKBONE = "resnet50"
+    D.DILATION = False
+    D.POSITION_EMBEDDING = "sine"
+    D.POSITION_EMBEDDING_SCALE = 6.283185307179586
+    D.NUM_FEATURE_LEVELS = 4
+    D.WITH_BOX_REFINE = False
+    D.TWO_STAGE = False
+    D.FROZEN_WEIGHTS = False
+    D.TRANSFORMER = CN()
+    D.TRANSFORMER.NUM_QUERIES = 300
+    D.TRANSFORMER.ENC_LAYERS = 6
+    D.TRANSFORMER.DEC_LAYERS = 6
+    D.TRANSFORMER.NHEADS = 8
+    D.TRANSFORMER.DIM_FEEDFORWARD = 1024
+    D.TRANSFORMER.HIDDEN_DIM = 256
+    D.TRANSFORMER.DROPOUT = 0.1
+    D.TRANSFORMER.DEC_N_POINTS = 4
+    D.TRANSFORMER.ENC_N_POINTS = 4
+    D.LOSS = CN()
+    D.LOSS.AUX_LOSS = True
+    D.LOSS.MASK_LOSS_COEF = 1.0
+    D.LOSS.DICE_LOSS_COEF = 1.0
+    D.LOSS.CLS_LOSS_COEF = 2.0
+    D.LOSS.BBOX_LOSS_COEF = 5.0
+    D.LOSS.GIOU_LOSS_COEF = 2.0
+    D.LOSS.FOCAL_ALPHA = 0.25
+    D.MATCHER = CN()
+    D.MATCHER.SET_COST_CLASS = 2
+    D.MATCHER.SET_COST_BBOX = 5
+    D.MATCHER.SET_COST_GIOU = 2
+    if "CLIP_GRADIENTS" not in _C.SOLVER:                     # detectron2 defaults
+        _C.SOLVER.CLIP_GRADIENTS = CN({"ENABLED": False, "CLIP_TYPE": "value", "CLIP_VALUE": 1.0, "NORM_TYPE": 2.0})
+    if "CROP" not in _C.INPUT:
+        _C.INPUT.CROP = CN({"ENABLED": False, "TYPE": "relative_range", "SIZE": [0.9, 0.9]})
+    _C.SOLVER.BACKBONE_LR_MULTIPLIER = 0.1
+    _C.SOLVER.LR_BACKBONE_NAMES = ["backbone.0"]
+    _C.SOLVER.LR_LINEAR_PROJ_NAMES = ["reference_points", "sampling_offsets"]
+    _C.SOLVER.LR_LINEAR_PROJ_MULTIPLIER = 0.1
+
     _C.MODEL.CONVNEXT = CN()
     _C.MODEL.CONVNEXT.DEPTHS = [3, 3, 9, 3]
     _C.MODEL.CONVNEXT.DIMS = [96, 192, 384, 768]

@@ -36,7 +36,7 @@ class SetCriterion:
                 box[b, :n] = t["boxes"].to(torch.float32).cpu()
         return lab.to(device), box.to(device), cnt.to(device), Gmax
 
-    def __call__(self, logits: torch.Tensor, boxes: torch.Tensor, targets: List[Dict[str, torch.Tensor]], num_boxes: float = None):
+    def __call__(self, logits: torch.Tensor, boxes: torch.Tensor, targets: List[Dict[str, torch.Tensor]], num_boxes: float = None, match: torch.Tensor = None):
         """logits [Ld, B, Nq, K], boxes [Ld, B, Nq, 4] (device, fp32) -> (OrderedDict of WEIGHTED losses: loss_ce / loss_bbox / loss_giou and
         their `_i` copies for the earlier decoder layers, g_logits, g_boxes = gradients of the sum of the dict)"""
         from scipy.optimize import linear_sum_assignment
@@ -48,17 +48,18 @@ class SetCriterion:
         if num_boxes is None:
             num_boxes = max(float(sum(counts)), 1.0)
         LB = Ld * B
-        cost = torch.empty((LB, Nq, Gmax), dtype=torch.float32, device=dev)
-        L.call("aldi_detr_match_cost", _p(logits), _p(boxes), _p(lab), _p(tbox), _p(cnt), _p(cost), LB, B, Nq, K, Gmax, self.cost[0], self.cost[1], self.cost[2],
-               self.alpha, stream_ptr())
-        ch = cost.cpu().numpy()                                         # the step's one device -> host hand-over
-        match = torch.full((LB, Nq), -1, dtype=torch.int32)
-        for lb in range(LB):
-            n = counts[lb % B]
-            if n:
-                qi, gi = linear_sum_assignment(ch[lb, :, :n])
-                match[lb, torch.as_tensor(qi, dtype=torch.long)] = torch.as_tensor(gi, dtype=torch.int32)
-        match = match.to(dev)
+        if match is None:
+            cost = torch.empty((LB, Nq, Gmax), dtype=torch.float32, device=dev)
+            L.call("aldi_detr_match_cost", _p(logits), _p(boxes), _p(lab), _p(tbox), _p(cnt), _p(cost), LB, B, Nq, K, Gmax, self.cost[0], self.cost[1], self.cost[2],
+                   self.alpha, stream_ptr())
+            ch = cost.cpu().numpy()                                     # the step's one device -> host hand-over
+            match = torch.full((LB, Nq), -1, dtype=torch.int32)
+            for lb in range(LB):
+                n = counts[lb % B]
+                if n:
+                    qi, gi = linear_sum_assignment(ch[lb, :, :n])
+                    match[lb, torch.as_tensor(qi, dtype=torch.long)] = torch.as_tensor(gi, dtype=torch.int32)
+            match = match.to(dev)
         rows = torch.empty((LB * Nq, 3), dtype=torch.float32, device=dev)
         losses = torch.empty((Ld, 3), dtype=torch.float32, device=dev)
         g_logits, g_boxes = torch.empty_like(logits), torch.empty_like(boxes)

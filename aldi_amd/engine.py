@@ -565,7 +565,7 @@ class RCNN:
         """preprocess + ResNet-50 + FPN -> P2..P6.  `save` keeps the activations backward needs."""
         return self._drive(self.trunk_steps(st_u8, sizes, save))
 
-    def trunk_steps(self, st_u8: torch.Tensor, sizes, save: bool):
+    def trunk_steps(self, st_u8: torch.Tensor, sizes, save: bool, fpn: bool = True):
         W = self.wts
         c = Ctx()
         bu = "backbone.bottom_up."
@@ -607,6 +607,12 @@ class RCNN:
                         out_bits[out.data_ptr()] = bits
                 x = out
             cs.append(x)
+        if not fpn:                            # the bare trunk (the Deformable-DETR detector takes C3..C5 themselves)
+            if save:
+                c.blocks, c.cs, c.out_bits = blocks, cs, out_bits
+            else:
+                c.cs = cs
+            return c
         prev = {}
         P = {}
         prev[5] = yield cs[3], "backbone.fpn_lateral5", {}
@@ -1356,6 +1362,45 @@ class RCNN:
                     g = ops.conv2d(gprev[lvl], W.wt(f"backbone.fpn_lateral{lvl}"), res=gx, res_mode=1, **self._relu_mask(c, xin))
                 else:
                     g = ops.conv2d(g1, W.wt(p + "conv1"), res=g, res_mode=1, **self._relu_mask(c, xin))
+        self._join_wgrads()
+
+    def trunk_backward(self, c: Ctx, gC: Dict[int, Optional[torch.Tensor]]):
+        """backward of the bare trunk (trunk_steps(..., fpn=False), fp32): gC[lvl] = d(loss)/d(C_lvl) for lvl in 3, 4, 5 (the stage outputs,
+        post-ReLU; None = no gradient); weight gradients of res3..res5 accumulate as in `backward`, stem + res2 are frozen (FREEZE_AT = 2)"""
+        W = self.wts
+        assert self.dtype == torch.float32, "the bare-trunk backward runs in the fp32 mode (the DETR path's AMP is off)"
+        def masked(a, b, act):                     # (a + b) where act > 0; a, b nullable (not both)
+            if a is None and b is None:
+                return None
+            x, y = (a, b) if b is not None else (None, a)
+            return ops.add_f32(x, y, torch.empty_like(act), relu_src=act)
+        blocks = c.blocks
+        bi = len(blocks) - 1
+        g = masked(gC.get(5), None, c.cs[3])
+        for si in (3, 2, 1):
+            stage_names: List[str] = []
+            for b in range(STAGE_BLOCKS[si] - 1, -1, -1):
+                p, xin, h1, h2, out, first = blocks[bi]
+                bi -= 1
+                stage_names += [p + "conv3", p + "conv2", p + "conv1"] + ([p + "shortcut"] if first else [])
+                self._wgrad(p + "conv3", h2, g)
+                g2 = ops.conv2d(g, W.wt(p + "conv3"), mask=h2)
+                self._wgrad(p + "conv2", h1, g2)
+                g1 = ops.conv2d(g2, W.wt(p + "conv2"), pad=1, mask=h1)
+                self._wgrad(p + "conv1", xin, g1)
+                if first:
+                    self._wgrad(p + "shortcut", xin, g)
+                    self._grads_final(stage_names)
+                    if si == 1:
+                        break                                           # stage input (res2 output) needs no gradient
+                    stride = W.layout.t[p + "conv1"].stride
+                    Hin, Win = xin.shape[1], xin.shape[2]
+                    gx = torch.zeros_like(xin)
+                    ops.conv2d(g, W.wt(p + "shortcut"), out=gx, out_scale=stride, out_hw=(Hin, Win))
+                    ops.conv2d(g1, W.wt(p + "conv1"), out=gx, out_scale=stride, out_hw=(Hin, Win), res=gx, res_mode=1)
+                    g = masked(gC.get(si + 1), gx, xin)                # this stage's input is C_{si+1}: its own gradient joins here
+                else:
+                    g = ops.conv2d(g1, W.wt(p + "conv1"), res=g, res_mode=1, mask=xin)
         self._join_wgrads()
 
     @staticmethod

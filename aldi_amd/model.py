@@ -291,6 +291,8 @@ def build_aldi(cfg):
     """Add Align and Distill capabilities to any Meta Architecture dynamically (reference aldi/model.py:12-34)."""
     from .align import ALIGN_MIXIN_REGISTRY
     from .distill import DISTILL_MIXIN_REGISTRY
+    if cfg.MODEL.META_ARCHITECTURE == "DeformableDETR":
+        from . import detr  # noqa: F401  (registers the detector and its mixins, as importing aldi.detr does in the reference)
     base_cls = META_ARCH_REGISTRY.get(cfg.MODEL.META_ARCHITECTURE)
     align_mixin = ALIGN_MIXIN_REGISTRY.get(cfg.DOMAIN_ADAPT.ALIGN.MIXIN_NAME)
     distill_mixin = DISTILL_MIXIN_REGISTRY.get(cfg.DOMAIN_ADAPT.DISTILL.MIXIN_NAME)

@@ -323,6 +323,41 @@ class EngineAdamW:
         W.step_count = int(sd.get("step", 0))
 
 
+class EngineDetrAdamW:
+    """AdamW of the Deformable-DETR detector over its flat state: the parameter groups and the full-model gradient clip of
+    configs/Base-DETR.yaml:59-69 (DetrWeights.adamw_step)"""
+    def __init__(self, model, cfg):
+        S = cfg.SOLVER
+        self.model = model
+        self.param_groups = [{"lr": S.BASE_LR, "weight_decay": S.WEIGHT_DECAY, "betas": (0.9, 0.999)}]
+        cg = S.CLIP_GRADIENTS
+        self.clip = float(cg.CLIP_VALUE) if cg.ENABLED else 0.0
+        if cg.ENABLED and (cg.CLIP_TYPE != "full_model" or float(cg.NORM_TYPE) != 2.0):
+            raise ValueError("DeformableDETR: only CLIP_TYPE full_model with the L2 norm is implemented")
+        self.backbone_mult, self.proj_mult, self.proj_names = float(S.BACKBONE_LR_MULTIPLIER), float(S.LR_LINEAR_PROJ_MULTIPLIER), tuple(S.LR_LINEAR_PROJ_NAMES)
+
+    def zero_grad(self, set_to_none: bool = False):
+        self.model.weights.zero_grad()
+
+    def step(self):
+        g = self.param_groups[0]
+        self.model.weights.adamw_step(g["lr"], betas=g["betas"], weight_decay=g["weight_decay"], clip=self.clip, backbone_mult=self.backbone_mult,
+                                      proj_mult=self.proj_mult, proj_names=self.proj_names)
+
+    def state_dict(self):
+        W = self.model.weights
+        return {"format": "aldi_amd.detr_adamw", "param_groups": [dict(g) for g in self.param_groups], "step": int(W.step),
+                "exp_avg": None if W.m is None else W.m.detach().cpu().clone(), "exp_avg_sq": None if W.v is None else W.v.detach().cpu().clone()}
+
+    def load_state_dict(self, sd):
+        W = self.model.weights
+        if sd.get("format") != "aldi_amd.detr_adamw":
+            return
+        if sd.get("exp_avg") is not None:
+            W.m, W.v = sd["exp_avg"].to(W.master.device).clone(), sd["exp_avg_sq"].to(W.master.device).clone()
+        W.step = int(sd.get("step", 0))
+
+
 class WarmupMultiStepLR:
     """detectron2 WarmupMultiStepLR (linear warmup), stepped once per iteration."""
     def __init__(self, optimizer, base_lr, steps, gamma, warmup_factor, warmup_iters):
@@ -669,6 +704,8 @@ class ALDITrainer(DefaultTrainer):
             if getattr(model, "adamw", False):
                 raise ValueError("the ViTDet / ConvNeXt models are trained with SOLVER.OPTIMIZER ADAMW (their Base-RCNN-*.yaml)")
             return super(ALDITrainer, cls).build_optimizer(cfg, model)
+        if cfg.SOLVER.OPTIMIZER.upper() == "ADAMW" and getattr(model, "detr", False):
+            return EngineDetrAdamW(model, cfg)
         if cfg.SOLVER.OPTIMIZER.upper() == "ADAMW" and getattr(model, "adamw", False):       # reference aldi/trainer.py:200-209
             vitdet_b = cfg.MODEL.BACKBONE.NAME == "build_vitdet_b_backbone"          # include_vit_lr_decay of the reference
             return EngineAdamW(model, cfg.SOLVER.BASE_LR, lr_decay_rate=0.7 if vitdet_b else None, num_layers=12)

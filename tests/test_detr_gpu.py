@@ -174,3 +174,85 @@ def test_set_criterion_matches_the_oracle():
         for b, (qi, gi) in enumerate(idx):
             got = {(int(q), int(m[l, b, q])) for q in range(Nq) if m[l, b, q] >= 0}
             assert got == set(zip(qi.tolist(), gi.tolist())), (l, b)
+
+
+def _detr_cfg(**over):
+    import os
+    from aldi_amd.config import add_aldi_config, get_cfg
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cfg = get_cfg()
+    add_aldi_config(cfg)
+    cfg.merge_from_file(os.path.join(root, "configs", "Base-DETR.yaml"))
+    cfg.merge_from_list(["MODEL.DEFORMABLE_DETR.NUM_CLASSES", 8, "MODEL.DEFORMABLE_DETR.TRANSFORMER.NUM_QUERIES", 40, "MODEL.DEFORMABLE_DETR.TRANSFORMER.ENC_LAYERS", 2,
+                         "MODEL.DEFORMABLE_DETR.TRANSFORMER.DEC_LAYERS", 2, "SEED", 3])
+    for k, v in over.items():
+        cfg.merge_from_list([k, v])
+    return cfg
+
+
+def _detr_batch(gen, sizes=((160, 224), (128, 192)), counts=(3, 2), K=8):
+    from aldi_amd.structures import Boxes, Instances
+    data = []
+    for (h, w), n in zip(sizes, counts):
+        inst = Instances((h, w))
+        x0, y0 = torch.rand(n, generator=gen) * w * 0.5, torch.rand(n, generator=gen) * h * 0.5
+        bw, bh = 20 + torch.rand(n, generator=gen) * w * 0.4, 20 + torch.rand(n, generator=gen) * h * 0.4
+        inst.gt_boxes = Boxes(torch.stack([x0, y0, (x0 + bw).clamp(max=w), (y0 + bh).clamp(max=h)], -1))
+        inst.gt_classes = torch.randint(0, K, (n,), generator=gen)
+        data.append({"image": torch.randint(0, 256, (3, h, w), generator=gen, dtype=torch.uint8), "instances": inst, "height": h, "width": w})
+    return data
+
+
+def test_detector_training_forward_backward_vs_oracle():
+    """META_ARCHITECTURE DeformableDETR built from configs/Base-DETR.yaml (fewer layers / queries): the weighted loss dict of model(batch)
+    and, after `sum(losses).backward()`, gradients of the transformer AND of the R50 trunk == the oracle (its R50 + oracle/deformable_detr.py
+    + criterion, torch autograd); one image smaller than the other (padding mask)"""
+    from aldi_amd.model import build_aldi
+    from oracle import d2_rcnn as d2
+    from oracle import deformable_detr as D
+    cfg = _detr_cfg()
+    model = build_aldi(cfg)
+    gen = torch.Generator().manual_seed(5)
+    data = _detr_batch(gen)
+    # the authors' initial sampling offsets are whole pixels: in the encoder every same-level sample then sits exactly on a pixel centre,
+    # a kink of the bilinear interpolation where one-sided derivatives (and fp32 rounding of the location) decide the gradient -- jitter them
+    for k in model.weights.tr.spec:
+        if k.endswith("sampling_offsets.bias"):
+            model.weights.tr.p(k).add_(torch.randn(model.weights.tr.p(k).shape, generator=gen).cuda() * 0.11)
+    model.weights.zero_grad()
+    ld = model(data)
+    total = sum(ld.values())
+    total.backward()
+    torch.cuda.synchronize()
+    # ---- the oracle on the same weights
+    W = model.weights
+    sd_b = {k: v.detach().cpu().double() for k, v in W.backbone.state_dict().items()}
+    train_b = [k for k in sd_b if k.startswith(("backbone.bottom_up.res3", "backbone.bottom_up.res4", "backbone.bottom_up.res5")) and k.endswith(".weight") and ".norm." not in k]
+    for k in train_b:
+        sd_b[k].requires_grad_(True)
+    p_t = {k: v.detach().cpu().double().requires_grad_(True) for k, v in W.tr.state_dict().items()}
+    ocfg = d2.make_cfg(pixel_mean=list(cfg.MODEL.PIXEL_MEAN), pixel_std=list(cfg.MODEL.PIXEL_STD))
+    x, sizes = d2.preprocess(ocfg, [d["image"] for d in data])
+    stages = []
+    d2.resnet_fpn(ocfg, sd_b, x.double(), stages)
+    mask = torch.ones(len(data), x.shape[2], x.shape[3], dtype=torch.bool)
+    for i, (h, w) in enumerate(sizes):
+        mask[i, :h, :w] = False
+    dims = dict(d_model=256, num_levels=4, enc_layers=2, dec_layers=2, n_heads=8, enc_points=4, dec_points=4)
+    lo, bo = D.forward(p_t, stages[1:4], mask, **dims)
+    targets = [{"labels": t["labels"], "boxes": t["boxes"].double()} for t in model._targets([d["instances"] for d in data], sizes)]
+    ref, ref_total = D.criterion(lo, bo, targets, weights=(2.0, 5.0, 2.0))
+    ref_total.backward()
+    w = {"loss_ce": 2.0, "loss_bbox": 5.0, "loss_giou": 2.0}
+    assert set(ld.keys()) == set(ref.keys())
+    for k, v in ld.items():
+        base = "_".join(k.split("_")[:2])
+        assert abs(float(v) - w[base] * float(ref[k])) <= 2e-3 * max(1.0, abs(w[base] * float(ref[k]))), (k, float(v), w[base] * float(ref[k]))
+    got_t = W.tr.state_dict(W.tr.grad)
+    worst = sorted(((got_t[k].cpu().double() - v.grad).abs().max().item() / max(v.grad.abs().max().item(), 1e-9), k) for k, v in p_t.items() if v.grad is not None and v.grad.abs().max() > 0)
+    assert worst[-1][0] <= 2e-2, worst[-6:]
+    for k in ("backbone.bottom_up.res5.2.conv3.weight", "backbone.bottom_up.res4.0.conv1.weight", "backbone.bottom_up.res3.0.conv1.weight", "backbone.bottom_up.res3.3.conv2.weight"):
+        name = k[: -len(".weight")]
+        g = W.backbone.gw(name).view(W.backbone.layout.t[name].wshape).permute(0, 3, 1, 2).cpu().double()
+        r = sd_b[k].grad
+        assert (g - r).abs().max().item() <= 2e-2 * r.abs().max().item(), (k, (g - r).abs().max().item(), r.abs().max().item())
