@@ -308,6 +308,11 @@ class DeformableDETR:
             out.append({"labels": r["gt_classes"].to(torch.long).cpu().view(-1), "boxes": cxcywh})
         return out
 
+    def _check_labels(self, targets):
+        for t in targets:
+            if len(t["labels"]) and (int(t["labels"].min()) < 0 or int(t["labels"].max()) >= self.num_classes):
+                raise ValueError(f"ground-truth class outside [0, {self.num_classes}) for MODEL.DEFORMABLE_DETR.NUM_CLASSES = {self.num_classes}")
+
     def forward(self, batched_inputs: List[Dict], do_align: bool = False, labeled: bool = True):
         if not self.training:
             return self.inference(batched_inputs)
@@ -320,6 +325,7 @@ class DeformableDETR:
         if not self.aux_loss:
             logits, boxes = logits[-1:], boxes[-1:]
         targets = self._targets([b["instances"] for b in batched_inputs], sizes)
+        self._check_labels(targets)
         losses, gl, gb = self.criterion(logits, boxes, targets)
         if not self.aux_loss:                                     # gradients for the full stack of layers: zeros for the unused ones
             full_l, full_b = self.transformer._out[0].new_zeros(self.transformer._out[0].shape), self.transformer._out[1].new_zeros(self.transformer._out[1].shape)

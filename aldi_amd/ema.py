@@ -19,7 +19,7 @@ class EMA:
         for key in self.model.layout.state_dict_keys():
             if key not in skeys:
                 raise Exception("{} is not found in student model".format(key))
-            if any(k in key for k in self.exclude_keys) and not hasattr(self.model.weights, "off"):
+            if any(k in key for k in self.exclude_keys) and not hasattr(self.model.weights, "ranges"):
                 raise NotImplementedError("excluded (copied) keys are not part of the R50-FPN layout")
 
     def _init_ema_weights(self, model):

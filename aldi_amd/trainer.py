@@ -250,6 +250,13 @@ def fused_run_model(trainer, labeled_weak, labeled_strong, unlabeled_weak, unlab
     return loss_dict
 
 
+def _num_classes(cfg) -> int:
+    """the detector's class count: ROI_HEADS.NUM_CLASSES, or DEFORMABLE_DETR.NUM_CLASSES for that meta-architecture"""
+    if cfg.MODEL.META_ARCHITECTURE == "DeformableDETR":
+        return int(cfg.MODEL.DEFORMABLE_DETR.NUM_CLASSES)
+    return int(cfg.MODEL.ROI_HEADS.NUM_CLASSES)
+
+
 class EngineSGD:
     """torch.optim.SGD-shaped handle on the fused HIP optimizer (momentum / weight decay of detectron2's build_optimizer)."""
     def __init__(self, model, lr, momentum=0.9, weight_decay=1e-4):
@@ -729,7 +736,7 @@ class ALDITrainer(DefaultTrainer):
         unlabeled_bs = max(unlabeled_bs) if len(unlabeled_bs) else 0
         syn = cfg.get("SYNTHETIC", {})
         h, w = syn.get("HEIGHT", 800), syn.get("WIDTH", 1333)
-        K = cfg.MODEL.ROI_HEADS.NUM_CLASSES
+        K = _num_classes(cfg)
         fixed = bool(syn.get("FIXED", False))
         labeled_loader = SyntheticDetectionLoader(labeled_bs // world, h, w, K, 1000 + 17 * rank, True, fixed=fixed) if labeled_bs > 0 else None
         unlabeled_loader = SyntheticDetectionLoader(unlabeled_bs // world, h, w, K, 2000 + 17 * rank, False, fixed=fixed) if unlabeled_bs > 0 else None
@@ -752,7 +759,7 @@ class ALDITrainer(DefaultTrainer):
         """synthetic validation split: a finite list of batches of {image, image_id, height, width} + detectron2-format records"""
         syn_ = cfg.get("SYNTHETIC", {})
         h, w = syn_.get("HEIGHT", 800), syn_.get("WIDTH", 1333)
-        n, K = int(syn_.get("VAL_IMAGES", 8)), cfg.MODEL.ROI_HEADS.NUM_CLASSES
+        n, K = int(syn_.get("VAL_IMAGES", 8)), _num_classes(cfg)
         g = torch.Generator().manual_seed(4242)
         batches, records = [], []
         for i in range(n):
@@ -769,7 +776,7 @@ class ALDITrainer(DefaultTrainer):
         from .evaluation import Detectron2COCOEvaluatorAdapter
         if output_folder is None:
             output_folder = os.path.join(cfg.OUTPUT_DIR, "inference")
-        return Detectron2COCOEvaluatorAdapter(dataset_name, dataset_dicts or [], cfg.MODEL.ROI_HEADS.NUM_CLASSES, output_dir=output_folder)
+        return Detectron2COCOEvaluatorAdapter(dataset_name, dataset_dicts or [], _num_classes(cfg), output_dir=output_folder)
 
     @classmethod
     def test(cls, cfg, model, evaluators=None):
