@@ -56,6 +56,12 @@ def make_cfg(world, height, width, align, workload="r50_fpn"):
         cfg.merge_from_file(os.path.join(ROOT, "configs", "cityscapes", "ALDI-Best-ConvNeXt-Cityscapes.yaml"))
         cfg.merge_from_list(["SOLVER.IMS_PER_BATCH", 4 * world, "SOLVER.IMS_PER_GPU", 2, "SEED", 1, "SYNTHETIC.HEIGHT", height, "SYNTHETIC.WIDTH", width])
         return cfg
+    if workload == "detr":              # BASELINE configs[4]: Deformable-DETR ALDI++ (HardDistiller), fp32, 2 + 2 images per GPU here; pseudo-label
+        # threshold lowered so that the random-init teacher's detections become pseudo labels (the student's distillation step then has targets)
+        cfg.merge_from_file(os.path.join(ROOT, "configs", "cityscapes", "ALDI-Best-DETR-Cityscapes.yaml"))
+        cfg.merge_from_list(["SOLVER.IMS_PER_BATCH", 4 * world, "SOLVER.IMS_PER_GPU", 2, "SEED", 1, "SYNTHETIC.HEIGHT", height, "SYNTHETIC.WIDTH", width,
+                             "DOMAIN_ADAPT.TEACHER.THRESHOLD", 0.011])
+        return cfg
     if workload == "vitdet_b":          # BASELINE configs[3] (cfg 4): ViTDet-B, AdamW, one labeled + one unlabeled image per GPU and step
         cfg.merge_from_file(os.path.join(ROOT, "configs", "cityscapes", "ALDI-VitDetB-Cityscapes.yaml"))
         cfg.merge_from_list(["SOLVER.IMS_PER_BATCH", 2 * world, "SEED", 1, "SYNTHETIC.HEIGHT", height, "SYNTHETIC.WIDTH", width])
@@ -421,7 +427,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--replay-profile", action="store_true", help="additionally replay every dense shape back-to-back (isolated per-shape table for tuning)")
-    ap.add_argument("--workload", default="r50_fpn", choices=["r50_fpn", "vitdet_b", "convnext_l"],
+    ap.add_argument("--workload", default="r50_fpn", choices=["r50_fpn", "vitdet_b", "convnext_l", "detr"],
                     help="r50_fpn = the headline configuration (default); vitdet_b = BASELINE cfg 4 (SURVEY 8(f) rank 1), reported beside it")
     args = ap.parse_args()
     vitdet = args.workload == "vitdet_b"
@@ -470,7 +476,9 @@ def main():
     random.seed(1234)
     torch.manual_seed(100 + rank)
     tr = ALDITrainer(cfg)
-    K = cfg.MODEL.ROI_HEADS.NUM_CLASSES
+    K = cfg.MODEL.DEFORMABLE_DETR.NUM_CLASSES if args.workload == "detr" else cfg.MODEL.ROI_HEADS.NUM_CLASSES
+    if args.workload == "detr":
+        args.fp32 = True                                 # (the detector's precision: AMP is off in its config)
     per = 1 if vitdet else 2
     data = syn.make_batch(per, per, args.height, args.width, K, seed=100 + rank)
     tr._trainer.data_loader = FixedGpuLoader(data, dev)
@@ -507,19 +515,19 @@ def main():
     ms = dt / args.steps * 1e3
     imgs_per_step = 2 * per * world
     value = imgs_per_step * args.steps / dt
-    err = int(tr.model.engine.err) | int(tr.ema.model.engine.err)
+    err = int(getattr(tr.model.engine, "err", 0)) | int(getattr(tr.ema.model.engine, "err", 0))
     losses = {k: float(v) for k, v in tr._trainer.last_loss_dict.items()}
     pl_count = tr.ema.model._last_inference.pseudo["count"].tolist()
 
-    arch_name = {"vitdet_b": "ViTDet-B", "convnext_l": "ConvNeXt-L-FPN"}.get(args.workload, "R50-FPN")
+    arch_name = {"vitdet_b": "ViTDet-B", "convnext_l": "ConvNeXt-L-FPN", "detr": "Deformable-DETR-R50"}.get(args.workload, "R50-FPN")
     out = {"metric": f"images/sec (student+teacher ALDI step), {arch_name} 1333x800", "value": round(value, 3), "unit": "images/sec",
            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True,
            "scaling": "weak", "vs_baseline": None, "dtype": "fp32" if args.fp32 else "bf16", "data": "synthetic",
            "config": {"workload": "configs[%d]: ALDI++ %s Cityscapes->Foggy-shaped synthetic %dx%d, teacher EMA + distill on, align %s, "
-                                  "%d labeled_strong + %d unlabeled (weak+strong) images per GPU" % ({"vitdet_b": 3, "convnext_l": -1}.get(args.workload, 2 if args.align else 1), arch_name, args.width,
+                                  "%d labeled_strong + %d unlabeled (weak+strong) images per GPU" % ({"vitdet_b": 3, "convnext_l": -1, "detr": 4}.get(args.workload, 2 if args.align else 1), arch_name, args.width,
                                                                                                    args.height, "on" if args.align else "off", per, per),
                       "global_batch": imgs_per_step, "parallelism": f"dp{world}", "pseudo_label_threshold": cfg.DOMAIN_ADAPT.TEACHER.THRESHOLD,
-                      "pseudo_labels_per_image": pl_count, "schedule": "sequential micro-steps" if args.sequential else "fused source+target student pass" + ("" if args.no_graph else ", two hipGraph replays per step" + (" (RCCL collectives inside the second)" if world > 1 else "")), "weights": f"random-init {arch_name} (synthetic)", "error_flag": err, "init_steps": init_steps,
+                      "pseudo_labels_per_image": pl_count, "schedule": "sequential micro-steps, eager launches" if (args.sequential or args.workload == "detr") else "fused source+target student pass" + ("" if (args.no_graph or args.workload == "detr") else ", two hipGraph replays per step" + (" (RCCL collectives inside the second)" if world > 1 else "")), "weights": f"random-init {arch_name} (synthetic)", "error_flag": err, "init_steps": init_steps,
                       "step_graphs": dict(getattr(getattr(tr._trainer, "_fused_step", None), "stats", {}))},
            "final_losses": {k: round(v, 5) for k, v in losses.items()}}
     if rank == 0 and world == 1 and not args.no_profile:
