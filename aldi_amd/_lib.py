@@ -37,7 +37,7 @@ def _ctype(decl: str):
     if "*" in decl or decl.startswith("aldi_stream_t"):
         return C.c_void_p
     base = decl.rsplit(" ", 1)[0].replace("const", "").strip() if " " in decl else decl
-    return {"int": C.c_int, "long": C.c_long, "float": C.c_float, "size_t": C.c_size_t, "unsigned": C.c_uint,
+    return {"int": C.c_int, "long": C.c_long, "float": C.c_float, "size_t": C.c_size_t, "unsigned": C.c_uint, "unsigned long long": C.c_ulonglong,
             "double": C.c_double}[base]
 
 

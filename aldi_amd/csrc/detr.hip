@@ -13,6 +13,26 @@
 
 namespace {
 
+// ---------------------------------------------------------------------------------------------------- dropout
+// Stateless: element i of site `seed` is kept when a 64-bit mix of (seed, i) lands at or above p -- the backward pass recomputes the same
+// decision from the same (seed, i) instead of reading a stored mask.  (Not torch's generator: the reference's dropout draws from the CUDA
+// Philox stream, which no other implementation reproduces either; the statistics are the same.)
+__device__ __forceinline__ float drop_scale(unsigned long long seed, unsigned long long i, float p, float inv_keep) {
+    unsigned long long z = seed + 0x9E3779B97F4A7C15ull * (i + 1);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z ^= z >> 31;
+    const float u = (float)(z >> 40) * (1.0f / 16777216.0f);         // 24 bits -> [0, 1)
+    return u >= p ? inv_keep : 0.f;
+}
+// out = (res ? res : 0) + x * keep / (1 - p)
+__global__ __launch_bounds__(256) void dropout_add_kernel(const float* __restrict__ x, const float* __restrict__ res, float* __restrict__ out, long n, float p,
+                                                          unsigned long long seed) {
+    const float inv_keep = 1.f / (1.f - p);
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+        out[i] = (res ? res[i] : 0.f) + x[i] * drop_scale(seed, (unsigned long long)i, p, inv_keep);
+}
+
 // ---------------------------------------------------------------------------------------------------- GroupNorm
 // x [N][HW][C]; part [N][chunks][G][2] = (sum, sum of squares) of the chunk's pixels over the group's C / G channels
 __global__ __launch_bounds__(256) void gn_partial_kernel(const float* __restrict__ x, float* __restrict__ part, int HW, int C, int G, int chunk_px) {
@@ -103,10 +123,12 @@ __global__ __launch_bounds__(256) void msda_prepare_kernel(const float* __restri
 // q, k, v [B][Q][H*D] (row strides ldq / ldk / ldv floats); out [B][Q][H*D]; lse [B][H][Q] (for a backward pass).  One thread per query.
 template <int D>
 __global__ __launch_bounds__(64) void mha_small_kernel(const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v, float* __restrict__ out,
-                                                       float* __restrict__ lse, int Q, int H, int ldq, int ldk, int ldv, float scale) {
+                                                       float* __restrict__ lse, int Q, int H, int ldq, int ldk, int ldv, float scale, float drop_p,
+                                                       unsigned long long seed) {
     __shared__ float ks[64][D], vs[64][D];
     const int bh = blockIdx.x, b = bh / H, h = bh % H;
     const int qi = blockIdx.y * 64 + threadIdx.x;
+    const float inv_keep = 1.f / (1.f - drop_p);
     float qr[D], acc[D];
     const bool live = qi < Q;
 #pragma unroll
@@ -128,9 +150,10 @@ __global__ __launch_bounds__(64) void mha_small_kernel(const float* __restrict__
             for (int d = 0; d < D; ++d) s += qr[d] * ks[jj][d];
             const float nm = fmaxf(mx, s);
             const float c = expf(mx - nm), p = expf(s - nm);
-            l = l * c + p;
+            l = l * c + p;                  // (the softmax normalises over ALL keys; dropout acts on the normalised probabilities)
+            const float pk = drop_p > 0.f ? p * drop_scale(seed, ((unsigned long long)bh * Q + qi) * Q + (j0 + jj), drop_p, inv_keep) : p;
 #pragma unroll
-            for (int d = 0; d < D; ++d) acc[d] = acc[d] * c + p * vs[jj][d];
+            for (int d = 0; d < D; ++d) acc[d] = acc[d] * c + pk * vs[jj][d];
             mx = nm;
         }
     }
@@ -190,14 +213,22 @@ extern "C" int aldi_msda_prepare(const float* raw, const float* ref, const int* 
     return ALDI_OK;
 }
 
+extern "C" int aldi_dropout_add(const float* x, const float* res, float* out, long n, float p, unsigned long long seed, aldi_stream_t stream) {
+    if (!x || !out || n <= 0 || !(p >= 0.f && p < 1.f)) return aldi_set_error_msg(ALDI_ERR_ARG, "dropout_add: bad args (0 <= p < 1)");
+    const long blocks = (n + 255) / 256;
+    hipLaunchKernelGGL(dropout_add_kernel, dim3((unsigned)(blocks < 8192 ? blocks : 8192)), dim3(256), 0, static_cast<hipStream_t>(stream), x, res, out, n, p, seed);
+    ALDI_CHECK_LAUNCH();
+    return ALDI_OK;
+}
+
 extern "C" int aldi_mha_small_forward(const float* q, const float* k, const float* v, float* out, float* lse, int B, int Q, int H, int D, int ldq, int ldk, int ldv,
-                                      float scale, aldi_stream_t stream) {
-    if (!q || !k || !v || !out || B <= 0 || Q <= 0 || H <= 0) return aldi_set_error_msg(ALDI_ERR_ARG, "mha_small_forward: bad args");
+                                      float scale, float drop_p, unsigned long long seed, aldi_stream_t stream) {
+    if (!q || !k || !v || !out || B <= 0 || Q <= 0 || H <= 0 || !(drop_p >= 0.f && drop_p < 1.f)) return aldi_set_error_msg(ALDI_ERR_ARG, "mha_small_forward: bad args");
     hipStream_t st = static_cast<hipStream_t>(stream);
     const dim3 grid(B * H, cdiv(Q, 64));
-    if (D == 32) hipLaunchKernelGGL(mha_small_kernel<32>, grid, dim3(64), 0, st, q, k, v, out, lse, Q, H, ldq, ldk, ldv, scale);
-    else if (D == 16) hipLaunchKernelGGL(mha_small_kernel<16>, grid, dim3(64), 0, st, q, k, v, out, lse, Q, H, ldq, ldk, ldv, scale);
-    else if (D == 64) hipLaunchKernelGGL(mha_small_kernel<64>, grid, dim3(64), 0, st, q, k, v, out, lse, Q, H, ldq, ldk, ldv, scale);
+    if (D == 32) hipLaunchKernelGGL(mha_small_kernel<32>, grid, dim3(64), 0, st, q, k, v, out, lse, Q, H, ldq, ldk, ldv, scale, drop_p, seed);
+    else if (D == 16) hipLaunchKernelGGL(mha_small_kernel<16>, grid, dim3(64), 0, st, q, k, v, out, lse, Q, H, ldq, ldk, ldv, scale, drop_p, seed);
+    else if (D == 64) hipLaunchKernelGGL(mha_small_kernel<64>, grid, dim3(64), 0, st, q, k, v, out, lse, Q, H, ldq, ldk, ldv, scale, drop_p, seed);
     else return aldi_set_error_msg(ALDI_ERR_ARG, "mha_small_forward: head width 16, 32 or 64");
     ALDI_CHECK_LAUNCH();
     return ALDI_OK;
@@ -275,11 +306,12 @@ template <int D>
 __global__ __launch_bounds__(64) void mha_small_bwd_q_kernel(const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v,
                                                              const float* __restrict__ o, const float* __restrict__ d_o, const float* __restrict__ lse,
                                                              float* __restrict__ dq, float* __restrict__ delta, int Q, int H, int ldq, int ldk, int ldv, int lddq,
-                                                             float scale) {
+                                                             float scale, float drop_p, unsigned long long seed) {
     __shared__ float ks[64][D], vs[64][D];
     const int bh = blockIdx.x, b = bh / H, h = bh % H;
     const int qi = blockIdx.y * 64 + threadIdx.x;
     const bool live = qi < Q;
+    const float inv_keep = 1.f / (1.f - drop_p);
     float qr[D], gr[D], acc[D];
     float dl = 0.f;
 #pragma unroll
@@ -305,6 +337,7 @@ __global__ __launch_bounds__(64) void mha_small_bwd_q_kernel(const float* __rest
 #pragma unroll
             for (int d = 0; d < D; ++d) { s += qr[d] * ks[jj][d]; dp += gr[d] * vs[jj][d]; }
             const float p = expf(s - ls);
+            if (drop_p > 0.f) dp *= drop_scale(seed, ((unsigned long long)bh * Q + qi) * Q + (j0 + jj), drop_p, inv_keep);
             const float ds = p * (dp - dl);
 #pragma unroll
             for (int d = 0; d < D; ++d) acc[d] += ds * ks[jj][d];
@@ -319,11 +352,12 @@ template <int D>
 __global__ __launch_bounds__(64) void mha_small_bwd_kv_kernel(const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v,
                                                               const float* __restrict__ d_o, const float* __restrict__ lse, const float* __restrict__ delta,
                                                               float* __restrict__ dk, float* __restrict__ dv, int Q, int H, int ldq, int ldk, int ldv, int lddk,
-                                                              int lddv, float scale) {
+                                                              int lddv, float scale, float drop_p, unsigned long long seed) {
     __shared__ float qs[64][D], gs[64][D], ls_[64], dl_[64];
     const int bh = blockIdx.x, b = bh / H, h = bh % H;
     const int kj = blockIdx.y * 64 + threadIdx.x;
     const bool live = kj < Q;
+    const float inv_keep = 1.f / (1.f - drop_p);
     float kr[D], vr[D], ak[D], av[D];
 #pragma unroll
     for (int d = 0; d < D; ++d) {
@@ -348,9 +382,10 @@ __global__ __launch_bounds__(64) void mha_small_bwd_kv_kernel(const float* __res
 #pragma unroll
             for (int d = 0; d < D; ++d) { s += qs[ii][d] * kr[d]; dp += gs[ii][d] * vr[d]; }
             const float p = expf(s - ls_[ii]);
-            const float ds = p * (dp - dl_[ii]);
+            const float m = drop_p > 0.f ? drop_scale(seed, ((unsigned long long)bh * Q + (i0 + ii)) * Q + kj, drop_p, inv_keep) : 1.f;
+            const float ds = p * (dp * m - dl_[ii]);
 #pragma unroll
-            for (int d = 0; d < D; ++d) { av[d] += p * gs[ii][d]; ak[d] += ds * qs[ii][d]; }
+            for (int d = 0; d < D; ++d) { av[d] += p * m * gs[ii][d]; ak[d] += ds * qs[ii][d]; }
         }
     }
     if (!live) return;
@@ -478,13 +513,13 @@ extern "C" int aldi_msda_prepare_backward(const float* g_loc, const float* g_aw,
 
 extern "C" int aldi_mha_small_backward(const float* q, const float* k, const float* v, const float* out, const float* d_out, const float* lse, float* dq, float* dk,
                                        float* dv, float* delta, int B, int Q, int H, int D, int ldq, int ldk, int ldv, int lddq, int lddk, int lddv, float scale,
-                                       aldi_stream_t stream) {
+                                       float drop_p, unsigned long long seed, aldi_stream_t stream) {
     if (!q || !k || !v || !out || !d_out || !lse || !dq || !dk || !dv || !delta) return aldi_set_error_msg(ALDI_ERR_ARG, "mha_small_backward: null pointer");
     hipStream_t st = static_cast<hipStream_t>(stream);
     const dim3 grid(B * H, cdiv(Q, 64));
 #define ALDI_MHA_BWD(DD)                                                                                                                                         \
-    hipLaunchKernelGGL(mha_small_bwd_q_kernel<DD>, grid, dim3(64), 0, st, q, k, v, out, d_out, lse, dq, delta, Q, H, ldq, ldk, ldv, lddq, scale);               \
-    hipLaunchKernelGGL(mha_small_bwd_kv_kernel<DD>, grid, dim3(64), 0, st, q, k, v, d_out, lse, delta, dk, dv, Q, H, ldq, ldk, ldv, lddk, lddv, scale)
+    hipLaunchKernelGGL(mha_small_bwd_q_kernel<DD>, grid, dim3(64), 0, st, q, k, v, out, d_out, lse, dq, delta, Q, H, ldq, ldk, ldv, lddq, scale, drop_p, seed); \
+    hipLaunchKernelGGL(mha_small_bwd_kv_kernel<DD>, grid, dim3(64), 0, st, q, k, v, d_out, lse, delta, dk, dv, Q, H, ldq, ldk, ldv, lddk, lddv, scale, drop_p, seed)
     if (D == 32) { ALDI_MHA_BWD(32); }
     else if (D == 16) { ALDI_MHA_BWD(16); }
     else if (D == 64) { ALDI_MHA_BWD(64); }

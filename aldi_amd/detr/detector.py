@@ -7,7 +7,7 @@ fp32 state for the optimizer (AdamW + full-model gradient clip), the EMA teacher
 The reference registers its detector as `DETRDistillMixin(DeformableDETR)` / `DETRAlignMixin(DeformableDETR)` (aldi/detr/distill.py:6-7,
 aldi/detr/align.py:6-7) from an ABSENT submodule; the algorithm is restated from the published model and pinned through
 oracle/deformable_detr.py.  Differences, stated: the backbone is this repository's R50 (stride on the bottleneck's 1x1 conv, as in the
-reference's FPN models) rather than torchvision's (stride on the 3x3 conv); TRANSFORMER.DROPOUT must be 0 (no dropout kernels yet)."""
+reference's FPN models) rather than torchvision's (stride on the 3x3 conv); dropout draws from its own stateless generator."""
 from __future__ import annotations
 
 import copy
@@ -205,8 +205,6 @@ class DeformableDETR:
             raise RuntimeError("aldi_amd runs on the MI355X HIP path only (MODEL.DEVICE must be cuda); there is no CPU fallback")
         if cfg.SOLVER.AMP.ENABLED:
             raise ValueError("DeformableDETR runs in fp32 (SOLVER.AMP.ENABLED False, as configs/Base-DETR.yaml:56-58)")
-        if float(T.DROPOUT) != 0.0:
-            raise ValueError("MODEL.DEFORMABLE_DETR.TRANSFORMER.DROPOUT must be 0: dropout is not implemented on this path")
         if dd.WITH_BOX_REFINE or dd.TWO_STAGE or dd.BACKBONE != "resnet50" or dd.DILATION or dd.POSITION_EMBEDDING != "sine":
             raise ValueError("DeformableDETR: only the plain variant (ResNet-50, sine embedding, no box refinement / two-stage / dilation)")
         self.dtype = torch.float32
@@ -246,7 +244,7 @@ class DeformableDETR:
         self.weights.refresh()
         self.layout = self.weights
         self.bengine = RCNN(bw, self.num_classes, D2Params.from_cfg(self.cfg))
-        self.transformer = DeformableTransformer(P, device=self.device, **dims)
+        self.transformer = DeformableTransformer(P, device=self.device, dropout=float(T.DROPOUT), seed=seed, **dims)
         self.engine = _DetrEngine(self)
 
     # ---- nn.Module-like surface -------------------------------------------------------------

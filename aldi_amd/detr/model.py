@@ -10,7 +10,10 @@ The reference's own detector is an absent submodule (`aldi/detr/libs/DeformableD
 pinned against transformers' implementation) in tests/test_detr_gpu.py.
 
 No autograd: the forward records a tape of the launches it made and `backward` walks it in reverse (the ViT path's way, aldi_amd/vit.py).
-Dropout (TRANSFORMER.DROPOUT 0.1 in the reference's config) is not implemented: the layers are built with dropout 0."""
+Dropout (TRANSFORMER.DROPOUT, 0.1 in the reference's config) acts in recorded (training) forwards at the authors' sites -- after each
+attention / feed-forward block, inside the feed-forward block and on the decoder self attention's probabilities -- through
+aldi_dropout_add / aldi_mha_small_*: stateless keep decisions from (seed, element), recomputed by the backward; its own generator, not
+torch's random stream."""
 from __future__ import annotations
 
 import math
@@ -197,7 +200,7 @@ class _Grads:
 
 class DeformableTransformer:
     def __init__(self, params, *, d_model=256, num_levels=4, enc_layers=6, dec_layers=6, n_heads=8, enc_points=4, dec_points=4, device="cuda",
-                 trainable: bool = True):
+                 trainable: bool = True, dropout: float = 0.0, seed: int = 0):
         """params: a FlatParams, or a state dict in the authors' names (then a FlatParams is built from its shapes)"""
         if not torch.cuda.is_available():
             raise RuntimeError("the Deformable-DETR path runs on the MI355X HIP library only; there is no CPU fallback")
@@ -214,6 +217,8 @@ class DeformableTransformer:
         self.P = params
         self._tables = {}
         self.tape = None
+        self.dropout, self._seed0, self._fwd_count, self._drop_on = float(dropout), int(seed), 0, False
+        self.drop_sites = {}                   # site name -> (seed, shape) of the last recorded forward (tests rebuild the masks from it)
 
     # ------------------------------------------------------------------------------------------------ tape plumbing
     def _rec(self, fn):
@@ -272,6 +277,35 @@ class DeformableTransformer:
                 G.add(x, V.layernorm_backward(g.contiguous(), x, P.p(name + ".weight"), mean, rstd, P.g(name + ".weight"), P.g(name + ".bias")))
         self._rec(bwd)
         return y
+
+    def _site_seed(self, name: str, shape) -> int:
+        sd = ((self._seed0 * 1000003 + self._fwd_count) * 4099 + len(self.drop_sites) + 1) & ((1 << 63) - 1)
+        self.drop_sites[name] = (sd, tuple(shape))
+        return sd
+
+    def _dropout(self, name: str, x: torch.Tensor, res: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """res + dropout(x) (res nullable) at site `name`"""
+        p, sd = self.dropout, self._site_seed(name, x.shape)
+        out = torch.empty_like(x)
+        L.call("aldi_dropout_add", _p(x), _p(res), _p(out), x.numel(), p, sd, stream_ptr())
+
+        def bwd(G, x=x, res=res, out=out):
+            g = G.pop(out)
+            if g is None:
+                return
+            gx = torch.empty_like(x)
+            L.call("aldi_dropout_add", _p(g.contiguous()), None, _p(gx), x.numel(), p, sd, stream_ptr())
+            G.add(x, gx)
+            if res is not None:
+                G.add(res, g)
+        self._rec(bwd)
+        return out
+
+    def _lin_res(self, x: torch.Tensor, wname: str, res: torch.Tensor, site: str) -> torch.Tensor:
+        """res + dropout(linear(x)): the residual add stays in the linear map's epilogue when dropout is off"""
+        if not self._drop_on:
+            return self._lin(x, wname, res=res)
+        return self._dropout(site, self._lin(x, wname), res)
 
     def _add(self, a: torch.Tensor, b: torch.Tensor, b_const: bool = False) -> torch.Tensor:
         y = ops.add_f32(a, b, torch.empty_like(a))
@@ -393,7 +427,7 @@ class DeformableTransformer:
             if ref_grad is not None:
                 G.add(ref_grad, g_ref)
         self._rec(bwd)
-        return self._lin(out, pre + ".output_proj", res=res)
+        return self._lin_res(out, pre + ".output_proj", res, pre.rsplit(".", 1)[0] + ".dropout1")
 
     def _self_attn(self, pre: str, tgt: torch.Tensor, qpos: torch.Tensor, B: int, Nq: int) -> torch.Tensor:
         P, d, M = self.P, self.d, self.M
@@ -407,7 +441,9 @@ class DeformableTransformer:
         att = torch.empty((B * Nq, d), dtype=torch.float32, device=self.dev)
         lse = torch.empty((B, M, Nq), dtype=torch.float32, device=self.dev)
         scale = float(dh) ** -0.5
-        L.call("aldi_mha_small_forward", _p(qk), qk.data_ptr() + 4 * d, _p(v), _p(att), _p(lse), B, Nq, M, dh, 2 * d, 2 * d, d, scale, stream_ptr())
+        dp = self.dropout if self._drop_on else 0.0
+        sd = self._site_seed(pre + ".attn", (B, M, Nq, Nq)) if dp > 0 else 0
+        L.call("aldi_mha_small_forward", _p(qk), qk.data_ptr() + 4 * d, _p(v), _p(att), _p(lse), B, Nq, M, dh, 2 * d, 2 * d, d, scale, dp, sd, stream_ptr())
 
         def bwd(G, qk=qk, v=v, att=att, lse=lse):
             g = G.pop(att)
@@ -416,11 +452,11 @@ class DeformableTransformer:
             dqk, dv = torch.empty_like(qk), torch.empty_like(v)
             delta = torch.empty_like(lse)
             L.call("aldi_mha_small_backward", _p(qk), qk.data_ptr() + 4 * d, _p(v), _p(att), _p(g.contiguous()), _p(lse), _p(dqk), dqk.data_ptr() + 4 * d, _p(dv),
-                   _p(delta), B, Nq, M, dh, 2 * d, 2 * d, d, 2 * d, 2 * d, d, scale, stream_ptr())
+                   _p(delta), B, Nq, M, dh, 2 * d, 2 * d, d, 2 * d, 2 * d, d, scale, dp, sd, stream_ptr())
             G.add(qk, dqk)
             G.add(v, dv)
         self._rec(bwd)
-        return self._lin(att, pre + ".out_proj", res=tgt)
+        return self._lin_res(att, pre + ".out_proj", tgt, pre.rsplit(".", 1)[0] + ".dropout2")
 
     # ------------------------------------------------------------------------------------------------ forward / backward
     def forward(self, feats: List[torch.Tensor], image_mask: torch.Tensor, record: bool = False, feats_need_grad: bool = False):
@@ -428,6 +464,9 @@ class DeformableTransformer:
         -> (logits [dec_layers, B, Nq, K], boxes [dec_layers, B, Nq, 4] as (cx, cy, w, h) in [0, 1]).  record: keep the tape for `backward`."""
         P, d = self.P, self.d
         self.tape = [] if record else None
+        self._drop_on = bool(record) and self.dropout > 0.0          # training forwards only (the teacher's inference is in eval mode)
+        self.drop_sites = {}
+        self._fwd_count += 1
         B = feats[0].shape[0]
         for f in feats:
             f.requires_grad_flag = feats_need_grad                          # (plain attribute: does the backbone want d(loss)/d(feature map))
@@ -472,7 +511,9 @@ class DeformableTransformer:
             q = self._add(x, pos)
             x = self._ln(pre + ".norm1", self._deform_attn(pre + ".self_attn", q, t["ref_enc"].view(B * S, self.L, 2), x, x, t, B, self.pe))
             h = self._lin(x, pre + ".linear1", relu=True)
-            x = self._ln(pre + ".norm2", self._lin(h, pre + ".linear2", res=x))
+            if self._drop_on:
+                h = self._dropout(pre + ".dropout2", h)
+            x = self._ln(pre + ".norm2", self._lin_res(h, pre + ".linear2", x, pre + ".dropout3"))
         memory = x
         qe = P.p("query_embed.weight")
         Nq = qe.shape[0]
@@ -516,7 +557,9 @@ class DeformableTransformer:
             q = self._add(tgt, qpos)
             tgt = self._ln(pre + ".norm1", self._deform_attn(pre + ".cross_attn", q, ref_dec, memory, tgt, t, B, self.pd, ref_grad=ref_dec))
             h = self._lin(tgt, pre + ".linear1", relu=True)
-            tgt = self._ln(pre + ".norm3", self._lin(h, pre + ".linear2", res=tgt))
+            if self._drop_on:
+                h = self._dropout(pre + ".dropout3", h)
+            tgt = self._ln(pre + ".norm3", self._lin_res(h, pre + ".linear2", tgt, pre + ".dropout4"))
             hs.append(tgt)
         hs_all = torch.cat(hs)                                                     # [dec_layers * B * Nq, d]
         if record:

@@ -540,7 +540,12 @@ int aldi_msda_prepare(const float* raw, const float* ref, const int* spatial_sha
 /* softmax(q k^T * scale) v for a few hundred tokens (the decoder's self attention): q / k / v [B][Q][H*D] with row strides ldq / ldk / ldv
  * floats, D = 16, 32 or 64; out [B][Q][H*D]; lse [B][H][Q] nullable. */
 int aldi_mha_small_forward(const float* q, const float* k, const float* v, float* out, float* lse, int B, int Q, int H, int D, int ldq, int ldk, int ldv,
-                           float scale, aldi_stream_t stream);
+                           float scale, float drop_p, unsigned long long seed, aldi_stream_t stream);
+/* Dropout without a stored mask: out[i] = (res ? res[i] : 0) + x[i] * keep(seed, i) / (1 - p), keep decided by a 64-bit mix of (seed, i).
+ * The same call on a gradient is the backward pass.  aldi_mha_small_* with drop_p > 0 drop attention PROBABILITIES with index
+ * ((b * H + h) * Q + i) * Q + j of the same function (nn.MultiheadAttention(dropout=p)).  Not torch's random stream (TRANSFORMER.DROPOUT 0.1 of
+ * configs/Base-DETR.yaml:24 draws from CUDA Philox in the reference): same statistics, own generator. */
+int aldi_dropout_add(const float* x, const float* res, float* out, long n, float p, unsigned long long seed, aldi_stream_t stream);
 /* Backward passes of the three above.  msda_prepare: g_raw [T][M*L*P*3] fully written from the sampling op's gradients (g_loc, g_aw) and
  * the forward's attention weights; g_ref [T][L][2] (nullable) = the reference points' gradient, fully written.  mha_small: dq / dk / dv with
  * row strides lddq / lddk / lddv from out, d_out and the forward's lse; delta [B][H][Q] is scratch.  group_norm: dx fully written, dgamma /
@@ -549,7 +554,7 @@ int aldi_msda_prepare_backward(const float* g_loc, const float* g_aw, const floa
                                int M, int L, int P, aldi_stream_t stream);
 int aldi_mha_small_backward(const float* q, const float* k, const float* v, const float* out, const float* d_out, const float* lse, float* dq, float* dk,
                             float* dv, float* delta, int B, int Q, int H, int D, int ldq, int ldk, int ldv, int lddq, int lddk, int lddv, float scale,
-                            aldi_stream_t stream);
+                            float drop_p, unsigned long long seed, aldi_stream_t stream);
 size_t aldi_group_norm_backward_workspace(int N, int HW, int C, int G);
 int aldi_group_norm_backward(const float* g, const float* x, const float* gamma, const float* mean, const float* rstd, float* dx, float* dgamma,
                              float* dbeta, void* workspace, int N, int HW, int C, int G, aldi_stream_t stream);

@@ -85,14 +85,20 @@ def deformable_attention(p: Dict[str, torch.Tensor], pre: str, query, reference_
     return _linear(p, pre + ".output_proj", out)
 
 
-def multihead_self_attention(p, pre: str, q_in, k_in, v_in, n_heads: int):
+def _keep(drop, name, t):
+    """dropout hook of the restatement: `drop(site name, tensor) -> tensor` (None = evaluation mode / p = 0).  Sites carry the authors'
+    module names: <layer>.dropout1..4 and <layer>.self_attn.attn (the attention probabilities inside nn.MultiheadAttention)."""
+    return t if drop is None else drop(name, t)
+
+
+def multihead_self_attention(p, pre: str, q_in, k_in, v_in, n_heads: int, drop=None):
     """nn.MultiheadAttention (batch-first here) with its packed in_proj: q, k from (target + query position), v from target"""
     B, Q, d = q_in.shape
     w, b = p[pre + ".in_proj_weight"], p[pre + ".in_proj_bias"]
     q = F.linear(q_in, w[:d], b[:d]).view(B, Q, n_heads, d // n_heads).transpose(1, 2)
     k = F.linear(k_in, w[d:2 * d], b[d:2 * d]).view(B, Q, n_heads, d // n_heads).transpose(1, 2)
     v = F.linear(v_in, w[2 * d:], b[2 * d:]).view(B, Q, n_heads, d // n_heads).transpose(1, 2)
-    att = F.softmax((q * (d // n_heads) ** -0.5) @ k.transpose(-1, -2), -1)
+    att = _keep(drop, pre + ".attn", F.softmax((q * (d // n_heads) ** -0.5) @ k.transpose(-1, -2), -1))
     out = (att @ v).transpose(1, 2).reshape(B, Q, d)
     return F.linear(out, p[pre + ".out_proj.weight"], p[pre + ".out_proj.bias"])
 
@@ -138,17 +144,18 @@ def encoder_reference_points(shapes, valid_ratios):
     return ref[:, :, None] * valid_ratios[:, None]
 
 
-def encoder(p, src, pos, mask, shapes, valid_ratios, n_layers: int, n_heads: int, n_points: int):
+def encoder(p, src, pos, mask, shapes, valid_ratios, n_layers: int, n_heads: int, n_points: int, drop=None):
     ref = encoder_reference_points(shapes, valid_ratios)
     x = src
     for i in range(n_layers):
         pre = f"transformer.encoder.layers.{i}"
-        x = _layer_norm(p, pre + ".norm1", x + deformable_attention(p, pre + ".self_attn", x + pos, ref, x, shapes, mask, n_heads, n_points))
-        x = _layer_norm(p, pre + ".norm2", x + _linear(p, pre + ".linear2", F.relu(_linear(p, pre + ".linear1", x))))
+        x = _layer_norm(p, pre + ".norm1", x + _keep(drop, pre + ".dropout1", deformable_attention(p, pre + ".self_attn", x + pos, ref, x, shapes, mask, n_heads, n_points)))
+        h = _keep(drop, pre + ".dropout2", F.relu(_linear(p, pre + ".linear1", x)))
+        x = _layer_norm(p, pre + ".norm2", x + _keep(drop, pre + ".dropout3", _linear(p, pre + ".linear2", h)))
     return x
 
 
-def decoder(p, memory, mask, shapes, valid_ratios, n_layers: int, n_heads: int, n_points: int):
+def decoder(p, memory, mask, shapes, valid_ratios, n_layers: int, n_heads: int, n_points: int, drop=None):
     """-> hidden states of every layer (n_layers, B, Nq, d) and the (fixed: no box refinement) reference points (B, Nq, 2)"""
     B = memory.shape[0]
     qe = p["query_embed.weight"]
@@ -160,9 +167,10 @@ def decoder(p, memory, mask, shapes, valid_ratios, n_layers: int, n_heads: int, 
     for i in range(n_layers):
         pre = f"transformer.decoder.layers.{i}"
         q = tgt + query_pos
-        tgt = _layer_norm(p, pre + ".norm2", tgt + multihead_self_attention(p, pre + ".self_attn", q, q, tgt, n_heads))
-        tgt = _layer_norm(p, pre + ".norm1", tgt + deformable_attention(p, pre + ".cross_attn", tgt + query_pos, ref_in, memory, shapes, mask, n_heads, n_points))
-        tgt = _layer_norm(p, pre + ".norm3", tgt + _linear(p, pre + ".linear2", F.relu(_linear(p, pre + ".linear1", tgt))))
+        tgt = _layer_norm(p, pre + ".norm2", tgt + _keep(drop, pre + ".dropout2", multihead_self_attention(p, pre + ".self_attn", q, q, tgt, n_heads, drop)))
+        tgt = _layer_norm(p, pre + ".norm1", tgt + _keep(drop, pre + ".dropout1", deformable_attention(p, pre + ".cross_attn", tgt + query_pos, ref_in, memory, shapes, mask, n_heads, n_points)))
+        h = _keep(drop, pre + ".dropout3", F.relu(_linear(p, pre + ".linear1", tgt)))
+        tgt = _layer_norm(p, pre + ".norm3", tgt + _keep(drop, pre + ".dropout4", _linear(p, pre + ".linear2", h)))
         hs.append(tgt)
     return torch.stack(hs), reference
 
@@ -176,11 +184,11 @@ def heads(p, hs, reference):
     return logits, torch.sigmoid(t)
 
 
-def forward(p, feats, image_mask, *, d_model=256, num_levels=4, enc_layers=6, dec_layers=6, n_heads=8, enc_points=4, dec_points=4):
+def forward(p, feats, image_mask, *, d_model=256, num_levels=4, enc_layers=6, dec_layers=6, n_heads=8, enc_points=4, dec_points=4, drop=None):
     """feats: the backbone's C3..C5 maps (B, C_l, H_l, W_l); image_mask (B, H, W) True = padding -> (logits (L, B, Nq, K), boxes (L, B, Nq, 4))"""
     src, pos, mask, shapes, vr = prepare_levels(p, feats, image_mask, d_model, num_levels)
-    memory = encoder(p, src, pos, mask, shapes, vr, enc_layers, n_heads, enc_points)
-    hs, reference = decoder(p, memory, mask, shapes, vr, dec_layers, n_heads, dec_points)
+    memory = encoder(p, src, pos, mask, shapes, vr, enc_layers, n_heads, enc_points, drop)
+    hs, reference = decoder(p, memory, mask, shapes, vr, dec_layers, n_heads, dec_points, drop)
     return heads(p, hs, reference)
 
 

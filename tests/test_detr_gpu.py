@@ -91,7 +91,7 @@ def test_group_norm_and_small_attention_against_torch():
         out = torch.empty(B, Q, H * Dh, device="cuda")
         lse = torch.empty(B, H, Q, device="cuda")
         qc, kc, vc = q.cuda(), k.cuda(), v.cuda()
-        L.call("aldi_mha_small_forward", _p(qc), _p(kc), _p(vc), _p(out), _p(lse), B, Q, H, Dh, H * Dh, H * Dh, H * Dh, Dh ** -0.5, stream_ptr())
+        L.call("aldi_mha_small_forward", _p(qc), _p(kc), _p(vc), _p(out), _p(lse), B, Q, H, Dh, H * Dh, H * Dh, H * Dh, Dh ** -0.5, 0.0, 0, stream_ptr())
         qh, kh, vh = (t.view(B, Q, H, Dh).transpose(1, 2).double() for t in (q, k, v))
         s = qh @ kh.transpose(-1, -2) * Dh ** -0.5
         ref = (torch.softmax(s, -1) @ vh).transpose(1, 2).reshape(B, Q, H * Dh)
@@ -136,6 +136,96 @@ def test_backward_matches_the_oracles_autograd():
     for g, f in zip(gf, fr):
         ref = f.grad.permute(0, 2, 3, 1)
         assert (g.cpu().double() - ref).abs().max().item() <= 5e-3 * ref.abs().max().item()
+
+
+def _keep_mask(seed, shape, p):
+    """the keep/(1-p) factors aldi_dropout_add applies for (seed, element index)"""
+    from aldi_amd import _lib as L
+    from aldi_amd.ops import _p, stream_ptr
+    ones = torch.ones(shape, device="cuda")
+    out = torch.empty_like(ones)
+    L.call("aldi_dropout_add", _p(ones), None, _p(out), ones.numel(), p, seed, stream_ptr())
+    return out
+
+
+def test_dropout_add_keep_rate_scale_and_seeds():
+    from aldi_amd import _lib as L
+    from aldi_amd.ops import _p, stream_ptr
+    g = torch.Generator().manual_seed(2)
+    x, r = torch.randn(1 << 20, generator=g).cuda(), torch.randn(1 << 20, generator=g).cuda()
+    for p in (0.1, 0.5):
+        m = _keep_mask(77, x.shape, p)
+        kept = m != 0
+        assert abs(kept.float().mean().item() - (1 - p)) < 3e-3                                 # 1M draws: sigma < 5e-4
+        assert torch.allclose(m[kept], torch.full_like(m[kept], 1 / (1 - p)), rtol=1e-6)
+        out = torch.empty_like(x)
+        L.call("aldi_dropout_add", _p(x), _p(r), _p(out), x.numel(), p, 77, stream_ptr())
+        assert torch.allclose(out, r + x * m, rtol=1e-6, atol=1e-6)
+        assert torch.equal(m, _keep_mask(77, x.shape, p))                                       # stateless: the same seed, the same mask
+        m2 = _keep_mask(78, x.shape, p)
+        agree = ((m != 0) == (m2 != 0)).float().mean().item()
+        assert abs(agree - ((1 - p) ** 2 + p ** 2)) < 5e-3                                       # a different seed is an independent mask
+        # no structure along the index: neighbours are independent
+        k = kept.float()
+        assert abs(((k[1:] * k[:-1]).mean() - (1 - p) ** 2).item()) < 3e-3
+    out = torch.empty_like(x)
+    L.call("aldi_dropout_add", _p(x), None, _p(out), x.numel(), 0.0, 5, stream_ptr())
+    assert torch.equal(out, x)
+    with pytest.raises(Exception):
+        L.call("aldi_dropout_add", _p(x), None, _p(out), x.numel(), 1.0, 5, stream_ptr())
+
+
+def test_dropout_forward_backward_equals_the_oracle_with_the_same_masks():
+    """TRANSFORMER.DROPOUT 0.1 (the reference's shipped value, configs/Base-DETR.yaml): the recorded forward draws its masks from
+    (seed, element); the oracle run with exactly those masks at the authors' sites (dropout1..4 of every layer and the decoder self
+    attention's probabilities) gives the same outputs and the same gradients; an unrecorded forward (the teacher) has no dropout"""
+    from aldi_amd.detr.model import DeformableTransformer
+    from oracle import deformable_detr as D
+    gen = torch.Generator().manual_seed(13)
+    cfg = dict(d_model=256, num_levels=4, enc_layers=2, dec_layers=2, n_heads=8, enc_points=4, dec_points=4)
+    p = _params(gen, Nq=60, K=12)
+    B, H, W = 2, 128, 160
+    feats = [torch.randn(B, c, H // s, W // s, generator=gen) for c, s in ((512, 8), (1024, 16), (2048, 32))]
+    mask = torch.zeros(B, H, W, dtype=torch.bool)
+    mask[1, 100:, :] = True
+    model = DeformableTransformer(p, dropout=0.1, seed=4, **cfg)
+    model.P.zero_grad()
+    f_dev = [f.permute(0, 2, 3, 1).contiguous().cuda() for f in feats]
+    logits, boxes = model.forward(f_dev, mask, record=True, feats_need_grad=True)
+    sites = dict(model.drop_sites)
+    want = {f"transformer.encoder.layers.{i}.dropout{j}" for i in range(2) for j in (1, 2, 3)} | \
+           {f"transformer.decoder.layers.{i}.dropout{j}" for i in range(2) for j in (1, 2, 3, 4)} | \
+           {f"transformer.decoder.layers.{i}.self_attn.attn" for i in range(2)}
+    assert set(sites) == want and len({sd for sd, _ in sites.values()}) == len(sites)
+    R1, R2 = torch.randn(logits.shape, generator=gen), torch.randn(boxes.shape, generator=gen)
+    gf = model.backward(R1.cuda(), R2.cuda())
+    torch.cuda.synchronize()
+    masks = {k: _keep_mask(sd, shape, 0.1).cpu().double() for k, (sd, shape) in sites.items()}
+    used = set()
+
+    def drop(name, t):
+        used.add(name)
+        return t * masks[name].view(t.shape)
+    pr = {k: v.clone().double().requires_grad_(True) for k, v in p.items()}
+    fr = [f.clone().double().requires_grad_(True) for f in feats]
+    lo, bo = D.forward(pr, fr, mask, drop=drop, **cfg)
+    assert used == want
+    (lo * R1.double()).sum().add((bo * R2.double()).sum()).backward()
+    assert (logits.cpu().double() - lo.detach()).abs().max().item() <= 2e-3 * max(1.0, lo.abs().max().item())
+    assert (boxes.cpu().double() - bo.detach()).abs().max().item() <= 1e-3
+    got = model.P.state_dict(model.P.grad)
+    worst = sorted(((got[k].cpu().double() - v.grad).abs().max().item() / max(v.grad.abs().max().item(), 1e-6), k) for k, v in pr.items())[::-1]
+    assert worst[0][0] <= 5e-3, worst[:8]
+    for g, f in zip(gf, fr):
+        ref = f.grad.permute(0, 2, 3, 1)
+        assert (g.cpu().double() - ref).abs().max().item() <= 5e-3 * ref.abs().max().item()
+    # dropout really acted, the next recorded forward draws other masks, and evaluation has none
+    l_eval, _ = model.forward(f_dev, mask)
+    lo0, _ = D.forward(p, feats, mask, **cfg)
+    assert not model.drop_sites and (l_eval.cpu() - lo0).abs().max().item() <= 2e-3 * max(1.0, lo0.abs().max().item())
+    assert (logits.cpu() - lo0).abs().max().item() > 0.05
+    l2, _ = model.forward(f_dev, mask, record=True)
+    assert (l2 - logits).abs().max().item() > 0.05
 
 
 def test_set_criterion_matches_the_oracle():
@@ -210,7 +300,7 @@ def test_detector_training_forward_backward_vs_oracle():
     from aldi_amd.model import build_aldi
     from oracle import d2_rcnn as d2
     from oracle import deformable_detr as D
-    cfg = _detr_cfg()
+    cfg = _detr_cfg(**{"MODEL.DEFORMABLE_DETR.TRANSFORMER.DROPOUT": 0.0})       # dropout against the oracle: the transformer-level test above
     model = build_aldi(cfg)
     gen = torch.Generator().manual_seed(5)
     data = _detr_batch(gen)
