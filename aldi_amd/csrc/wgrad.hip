@@ -846,6 +846,96 @@ __global__ __launch_bounds__(256) void wgrad_f32_kernel(WgDev p) {
         }
 }
 
+// fp32, 128 (co) x 128 (kk) tile, BP (32) pixels per slab, 4 waves (2x2), wave tile 64x64 = 4x4 fragments of v_mfma_f32_16x16x4_f32.
+// The f32-input MFMA runs at 1/16 of the bf16 rate, so what matters is keeping it fed: per 4-pixel k-step a lane reads 4 + 4 floats
+// from LDS for 16 MFMAs (the 64x64 tile above: 2 + 2 for 4), the next slab's global loads are in flight during the current slab's
+// MFMAs (register staging, two LDS buffers, one barrier per slab; 16-pixel slabs left the loads exposed: 53 -> TF/s at short splits).  Row pitch 144 floats: the four k-rows of a fragment read land
+// on 64 different banks.
+template <int BP>
+__global__ __launch_bounds__(256) void wgrad_f32_t128_kernel(WgDev p) {
+    constexpr int LD = 128 + 16, HALF = BP * LD, NH = BP / 8;
+    __shared__ float lds[2 * 2 * HALF];              // [buffer][g | x][pixel][channel]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int co0 = blockIdx.x * 128, kk0 = blockIdx.y * 128;
+    const int pbeg = blockIdx.z * p.pix_per_split;
+    const int pend = min(p.M, pbeg + p.pix_per_split);
+    const float* __restrict__ X = static_cast<const float*>(p.x);
+    const float* __restrict__ G = static_cast<const float*>(p.g);
+    // a thread stages BP/8 4-float chunks of g and of x per slab: rows lrow + 8 h, chunk lch
+    const int lrow = tid >> 5, lch = (tid & 31) * 4;
+    const int co_l = co0 + lch, kk_l = kk0 + lch;
+    int ci = 0, kh = 0, kw = 0;
+    if (kk_l < p.K) { const int tap = kk_l / p.Cin; ci = kk_l - tap * p.Cin; kh = tap / p.KW; kw = tap - kh * p.KW; }
+    const int HoWo = p.Ho * p.Wo;
+    float4 gv[NH], xv[NH];
+    auto fetch = [&](int p0) {
+#pragma unroll
+        for (int h = 0; h < NH; ++h) {
+            const int px = p0 + lrow + 8 * h;
+            gv[h] = make_float4(0, 0, 0, 0); xv[h] = make_float4(0, 0, 0, 0);
+            if (px < pend) {
+                if (co_l < p.Cout) gv[h] = *reinterpret_cast<const float4*>(G + (long)px * p.Cout + co_l);
+                if (kk_l < p.K) {
+                    if (p.ident) xv[h] = *reinterpret_cast<const float4*>(X + (long)px * p.Cin + ci);
+                    else {
+                        const int n = px / HoWo, r = px - n * HoWo;
+                        const int ho = r / p.Wo, wo = r - ho * p.Wo;
+                        const int hi = ho * p.stride - p.pad + kh, wi = wo * p.stride - p.pad + kw;
+                        if ((unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W)
+                            xv[h] = *reinterpret_cast<const float4*>(X + (((long)n * p.H + hi) * p.W + wi) * p.Cin + ci);
+                    }
+                }
+            }
+        }
+    };
+    const int wm = wave >> 1, wn = wave & 1;
+    f32x4_t acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    const int fr = lane & 15, fq = lane >> 4;
+    int buf = 0;
+    if (pbeg < pend) fetch(pbeg);
+    for (int p0 = pbeg; p0 < pend; p0 += BP) {
+        float* Lg = lds + buf * 2 * HALF;
+        float* Lx = Lg + HALF;
+#pragma unroll
+        for (int h = 0; h < NH; ++h) {
+            *reinterpret_cast<float4*>(&Lg[(lrow + 8 * h) * LD + lch]) = gv[h];
+            *reinterpret_cast<float4*>(&Lx[(lrow + 8 * h) * LD + lch]) = xv[h];
+        }
+        __syncthreads();
+        if (p0 + BP < pend) fetch(p0 + BP);
+#pragma unroll
+        for (int st = 0; st < BP / 4; ++st) {
+            float af[4], bfv[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) af[i] = Lg[(st * 4 + fq) * LD + wm * 64 + i * 16 + fr];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) bfv[j] = Lx[(st * 4 + fq) * LD + wn * 64 + j * 16 + fr];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i], bfv[j], acc[i][j], 0, 0, 0);
+        }
+        buf ^= 1;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int co = co0 + wm * 64 + i * 16 + fq * 4 + r;
+            if (co >= p.Cout) continue;
+            const float sc = p.scale ? p.scale[co] : 1.f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int kk = kk0 + wn * 64 + j * 16 + fr;
+                if (kk < p.K) unsafeAtomicAdd(p.dw + (long)co * p.K + kk, acc[i][j][r] * sc);
+            }
+        }
+}
+
 // db[c] += sum_p g[p][c]  (bias gradients).  Rows are read as full contiguous lines: a thread owns one 16-B chunk of
 // channels (C/EP chunks per row), the block walks `rows_per_block` rows, partial sums are combined through LDS.
 template <typename T, int NT>
@@ -989,16 +1079,30 @@ int wgrad_single(const aldi_wgrad_args* a, hipStream_t st, WsCarver& ws, FinBuil
     const int lean_env = tn.wgrad_lean, big_slots_env = tn.wgrad_big_slots;
     const bool same = a->stride == 1 && a->Ho == a->H && a->Wo == a->W && 2 * a->pad == a->KH - 1 && a->KH == a->KW && a->Cin % 64 == 0;
     const bool lean = a->dtype == ALDI_BF16 && lean_env && (d.ident || same);
-    const int bp = a->dtype == ALDI_BF16 ? 64 : 16;
-    int slabs = cdiv(d.M, bp);
     const bool big = lean && wants_big_tile(d, tn);
-    const int tile = big ? 256 : (a->dtype == ALDI_BF16 ? 128 : 64);
+    const bool f32_t128 = a->dtype == ALDI_F32 && tn.wgrad_f32_tile128 && d.Cout >= 128 && d.K >= 128;
+    const int tile = big ? 256 : (a->dtype == ALDI_BF16 || f32_t128 ? 128 : 64);
+    const int bp = a->dtype == ALDI_BF16 ? 64 : (f32_t128 ? 32 : 16);
+    int slabs = cdiv(d.M, bp);
     int tiles = cdiv(d.Cout, tile) * cdiv(d.K, tile);
     const int slots_env_ = tn.wgrad_slots;
-    const int slots_env = big ? big_slots_env : slots_env_;
+    const int slots_env = big ? big_slots_env : (f32_t128 ? 512 : slots_env_);      // fp32 128x128: two workgroups per CU (VGPRs), MFMA-bound: whole rounds
     // the kernel is bound per CU (L2 -> CU path, LDS), not by latency: few, long splits (1-2 workgroups per CU) beat
     // many short ones, whose epilogues also contend on the same dW lines
     int splits = big ? slots_env / tiles : cdiv(slots_env, tiles);
+    if (f32_t128) {
+        // MFMA-bound, two workgroups per CU: the launch runs in rounds of 512 workgroups, a round lasting (slabs per split + an
+        // epilogue of ~6 slabs: 16 K float atomics per workgroup).  cdiv(512, tiles) splits put 576 workgroups = two rounds on
+        // res5's 3x3 (169 us against 150 for the 64x64 kernel)
+        long best = -1;
+        int best_sp = 1;
+        for (int sp = 1; sp <= 512 && sp <= (slabs + 3) / 4; ++sp) {
+            const long rounds = ((long)tiles * sp + 511) / 512;
+            const long cost = rounds * (cdiv(slabs, sp) + 6);
+            if (best < 0 || cost < best) { best = cost; best_sp = sp; }
+        }
+        splits = best_sp;
+    }
     if (splits > slabs / 4) splits = slabs / 4;    // ... but at least 4 slabs of work behind every epilogue
     if (splits < 1) splits = 1;
     if (splits > 512) splits = 512;
@@ -1035,6 +1139,7 @@ int wgrad_single(const aldi_wgrad_args* a, hipStream_t st, WsCarver& ws, FinBuil
         which = big ? "wgrad_bf16_big" : "wgrad_bf16_lean";
     }
     else if (a->dtype == ALDI_BF16) { if (!dry) hipLaunchKernelGGL(wgrad_bf16_kernel, grid, dim3(256), 0, st, d); which = "wgrad_bf16_generic"; }
+    else if (a->dtype == ALDI_F32 && f32_t128) { if (!dry) hipLaunchKernelGGL(wgrad_f32_t128_kernel<32>, grid, dim3(256), 0, st, d); which = "wgrad_f32_t128"; }
     else if (a->dtype == ALDI_F32) { if (!dry) hipLaunchKernelGGL(wgrad_f32_kernel, grid, dim3(256), 0, st, d); which = "wgrad_f32"; }
     else return aldi_set_error_msg(ALDI_ERR_ARG, "conv_wgrad: bad dtype");
     if (dry) return ALDI_OK;

@@ -25,6 +25,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_BF16_TFLOPS = 2500.0      # dense MFMA bf16 peak, MI355X_MICROARCH.md
+PEAK_F32_TFLOPS = 157.3        # dense MFMA f32-input peak (v_mfma_f32_16x16x4_f32: 1/16 of the bf16 rate), same guide
 PEAK_HBM_GBS = 8000.0          # HBM3E peak (spec), same guide; ~6300 GB/s is what a streaming copy achieves
 # algorithmic conv/FC work of one cfg-2 step per GPU with the teacher trunk computed once (SURVEY.md 8d / BASELINE.md 4)
 STEP_TFLOP_FUSED = 5.49
@@ -432,7 +433,7 @@ def main():
     args = ap.parse_args()
     vitdet = args.workload == "vitdet_b"
     if args.workload != "r50_fpn":
-        args.no_profile = args.no_cpu_baseline = True      # the roofline / CPU legs are defined for the headline workload
+        args.no_cpu_baseline = True      # the CPU leg is defined for the headline workload; the in-situ roofline of the shared dense kernels is reported for all
 
     # One process per GPU.  Launched by torch.distributed.run the ranks are already there (WORLD_SIZE set); a plain
     # `python bench.py --gpus N` spawns its own N ranks through the same launcher.  It never falls back to fewer GPUs.
@@ -571,21 +572,25 @@ def main():
         if args.replay_profile:
             profile_dense(tr, one_step, os.path.join(ROOT, "gpurun_out", "dense_profile.txt"))
         ig, wg = prof["igemm"], prof["wgrad"]
+        headline = args.workload == "r50_fpn"
         step_tflop = STEP_TFLOP_SPARSE_RPN if getattr(tr.model.engine, "sparse_rpn_backward", False) else STEP_TFLOP_FUSED
         ach = ig["flops"] / (ig["ms"] * 1e-3) / 1e12 if ig["ms"] > 0 else 0.0
-        tj, tfile = matching_traffic()
-        out["roofline"] = {"bound": "mfma", "kernel": "igemm_kernel<bf16> + igemm_group_kernel<bf16> (conv fwd + dgrad + FC)", "achieved": round(ach, 2), "peak": PEAK_BF16_TFLOPS,
-                           "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4),
+        tj, tfile = matching_traffic() if headline else (None, None)
+        PEAK = PEAK_F32_TFLOPS if args.fp32 else PEAK_BF16_TFLOPS
+        kname = "igemm_kernel<float> (conv fwd + dgrad + the transformer's linear maps; f32-input MFMA)" if args.fp32 else \
+            "igemm_kernel<bf16> + igemm_group_kernel<bf16> (conv fwd + dgrad + FC)"
+        out["roofline"] = {"bound": "mfma", "kernel": kname, "achieved": round(ach, 2), "peak": PEAK,
+                           "unit": "TFLOP/s", "frac": round(ach / PEAK, 4),
                            "traffic": _traffic_per_launch(tj, "igemm", ig["launches"]),
                            "traffic_unit": "HBM bytes per igemm launch, rocprofv3 PMC passes of this command (FETCH_SIZE x2 + WRITE_SIZE)",
-                           "traffic_source": tfile if tj else "no profiles/r*_pmc_traffic.json matches this source tree (tools/source_hash.py)",
-                           "timing": "HIP events around every dense launch of ONE extra step issued eagerly on ONE stream (ALDI_WGRAD_STREAM / TEACHER_STREAM / AUX_STREAM off), i.e. each kernel alone on the chip; the matching rocprofv3 --kernel-trace --stats summary of the same single-stream step is profiles/r03_kernel_stats_single_stream.txt (the multi-stream step's is profiles/r03_kernel_stats.txt: co-resident kernels run longer there)",
+                           "traffic_source": tfile if tj else ("no profiles/r*_pmc_traffic.json matches this source tree (tools/source_hash.py)" if headline else "counter passes are collected for the headline workload only"),
+                           "timing": "HIP events around every dense launch of ONE extra step issued eagerly on ONE stream (ALDI_WGRAD_STREAM / TEACHER_STREAM / AUX_STREAM off), i.e. each kernel alone on the chip" + ("" if not headline else "; the matching rocprofv3 --kernel-trace --stats summary of the same single-stream step is profiles/r03_kernel_stats_single_stream.txt (the multi-stream step's is profiles/r03_kernel_stats.txt: co-resident kernels run longer there)"),
                            "algorithmic_bytes_per_launch": round(ig["bytes"] / max(ig["launches"], 1)),
                            "launches_per_step": ig["launches"], "kernel_ms_per_step": round(ig["ms"], 3), "event_pair_us_subtracted": prof.get("event_pair_us"),
                            "avg_launch_us": round(ig["ms"] * 1e3 / max(ig["launches"], 1), 2),
                            "algorithmic_tflop_per_step_in_kernel": round(ig["flops"] / 1e12, 3),
                            "wgrad_kernel": {"achieved": round(wg["flops"] / max(wg["ms"], 1e-9) / 1e9, 2), "unit": "TFLOP/s",
-                                            "frac": round(wg["flops"] / max(wg["ms"], 1e-9) / 1e9 / PEAK_BF16_TFLOPS, 4),
+                                            "frac": round(wg["flops"] / max(wg["ms"], 1e-9) / 1e9 / PEAK, 4),
                                             "kernel_ms_per_step": round(wg["ms"], 3), "launches_per_step": wg["launches"],
                                             "avg_launch_us": round(wg["ms"] * 1e3 / max(wg["launches"], 1), 2),
                                             "algorithmic_bytes_per_launch": round(wg["bytes"] / max(wg["launches"], 1)),
@@ -603,8 +608,11 @@ def main():
                                                  "algorithmic_bytes_per_step": prof[fam]["bytes"]}
                                            for fam in ("sgd", "ema", "roialign_fwd", "roialign_bwd") if prof[fam]["launches"] and prof[fam]["ms"] > 0},
                            "hbm_kernels_note": "sgd / ema: every state word read and written once; roialign_*: the pooled tensor's bytes only (the gather side is data dependent), so a lower bound of their traffic",
-                           "step_algorithmic_tflop": step_tflop if not args.align else None,
-                           "step_frac_of_mfma_peak": round(step_tflop / (ms * 1e-3) / PEAK_BF16_TFLOPS, 4) if not args.align else None}
+                           "step_algorithmic_tflop": step_tflop if (headline and not args.align) else None,
+                           "step_frac_of_mfma_peak": round(step_tflop / (ms * 1e-3) / PEAK_BF16_TFLOPS, 4) if (headline and not args.align) else None}
+        if not headline:
+            out["roofline"]["dense_ms_per_step"] = round(ig["ms"] + wg["ms"], 3)
+            out["roofline"]["note"] = "the families timed are the dense kernels this workload shares with the headline step (ops.conv2d / conv_wgrad); its attention / normalisation kernels are in the kernel-trace summary under profiles/"
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(cfg, args.height, args.width)
     if rank == 0:

@@ -365,7 +365,8 @@ def test_wgrad_forced_big_and_generic_small(case):
     _check_wgrad(case, torch.bfloat16, "wgrad_bf16_big" if big_ok else "wgrad_bf16_lean", knobs=[("wgrad_big_min", 1), ("wgrad_big_slots", 2)])
     _check_wgrad(case, torch.bfloat16, "wgrad_bf16_lean", knobs=[("wgrad_big_min", 0)])
     _check_wgrad(case, torch.bfloat16, "wgrad_bf16_generic", knobs=[("wgrad_lean", 0)])
-    _check_wgrad(case, torch.float32, "wgrad_f32")
+    _check_wgrad(case, torch.float32, "wgrad_f32_t128")
+    _check_wgrad(case, torch.float32, "wgrad_f32", knobs=[("wgrad_f32_tile128", 0)])
 
 
 @pytest.mark.parametrize("slots", [1, 64, 1000])
@@ -377,7 +378,20 @@ def test_wgrad_split_count_does_not_change_the_result(slots):
 
 
 def test_wgrad_fp32_fullsize():
-    _check_wgrad((2, 100, 168, 256, 256, 3, 1, 1), torch.float32, "wgrad_f32")
+    _check_wgrad((2, 100, 168, 256, 256, 3, 1, 1), torch.float32, "wgrad_f32_t128")
+    _check_wgrad((2, 100, 168, 256, 256, 3, 1, 1), torch.float32, "wgrad_f32", knobs=[("wgrad_f32_tile128", 0)])
+
+
+@pytest.mark.parametrize("case,expect", [
+    ((44646, 1, 1, 256, 1024, 1, 1, 0), "wgrad_f32_t128"),        # the Deformable-DETR encoder's feed-forward maps at 1333 x 800 (2 images)
+    ((44646, 1, 1, 1024, 256, 1, 1, 0), "wgrad_f32_t128"),
+    ((600, 1, 1, 256, 92, 1, 1, 0), "wgrad_f32"),                 # class head: Cout < 128
+    ((2, 50, 84, 1024, 256, 1, 2, 0), "wgrad_f32_t128"),          # strided shortcut (gather addressing)
+    ((2, 23, 37, 132, 200, 3, 1, 1), "wgrad_f32_t128"),           # ragged channels and taps: Cin 132 (K = 1188), Cout 200
+    ((2, 200, 336, 64, 64, 3, 1, 1), "wgrad_f32"),
+])
+def test_wgrad_fp32_dispatch_and_values(case, expect):
+    _check_wgrad(case, torch.float32, expect)
 
 
 # ---------------------------------------------------------------------------------- LDS-DMA + transpose-read weight gradient
