@@ -14,6 +14,17 @@ from .. import _lib as L
 from ..ops import _p, stream_ptr
 
 
+def _world_mean(n: float, device) -> float:
+    """the authors' normaliser under data parallelism: the ranks' target counts summed, / world size, at least 1 (the pinned restatement,
+    transformers' DeformableDetrLoss.forward, and the authors' SetCriterion.forward do the same reduction)"""
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        t = torch.tensor([n], dtype=torch.float64, device=device)
+        dist.all_reduce(t)
+        n = float(t) / dist.get_world_size()
+    return max(n, 1.0)
+
+
 class SetCriterion:
     def __init__(self, *, cls_coef=2.0, bbox_coef=5.0, giou_coef=2.0, cost_class=2.0, cost_bbox=5.0, cost_giou=2.0, focal_alpha=0.25):
         self.coef = (float(cls_coef), float(bbox_coef), float(giou_coef))
@@ -46,7 +57,7 @@ class SetCriterion:
         lab, tbox, cnt, Gmax = self.pad_targets(targets, dev)
         counts = [len(t["labels"]) for t in targets]
         if num_boxes is None:
-            num_boxes = max(float(sum(counts)), 1.0)
+            num_boxes = _world_mean(float(sum(counts)), dev)
         LB = Ld * B
         if match is None:
             cost = torch.empty((LB, Nq, Gmax), dtype=torch.float32, device=dev)

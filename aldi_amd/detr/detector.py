@@ -244,7 +244,9 @@ class DeformableDETR:
         self.weights.refresh()
         self.layout = self.weights
         self.bengine = RCNN(bw, self.num_classes, D2Params.from_cfg(self.cfg))
-        self.transformer = DeformableTransformer(P, device=self.device, dropout=float(T.DROPOUT), seed=seed, **dims)
+        import torch.distributed as dist
+        rank = dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
+        self.transformer = DeformableTransformer(P, device=self.device, dropout=float(T.DROPOUT), seed=seed + 7919 * rank, **dims)    # (dropout masks differ by rank)
         self.engine = _DetrEngine(self)
 
     # ---- nn.Module-like surface -------------------------------------------------------------

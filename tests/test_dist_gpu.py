@@ -175,6 +175,86 @@ def test_two_ranks_equal_one_rank_with_both_batches(tmp_path, align):
     assert (w2[:n] - w0[:n]).abs().max().item() > 100 * max(d, 1e-9)
 
 
+def _detr_cfg():
+    from aldi_amd.config import add_aldi_config, get_cfg
+    cfg = get_cfg()
+    add_aldi_config(cfg)
+    cfg.merge_from_file(os.path.join(ROOT, "configs", "cityscapes", "ALDI-Best-DETR-Cityscapes.yaml"))
+    cfg.merge_from_list(["MODEL.DEFORMABLE_DETR.TRANSFORMER.NUM_QUERIES", 40, "MODEL.DEFORMABLE_DETR.TRANSFORMER.ENC_LAYERS", 2,
+                         "MODEL.DEFORMABLE_DETR.TRANSFORMER.DEC_LAYERS", 2, "SEED", 3, "SOLVER.IMS_PER_BATCH", 8, "SOLVER.IMS_PER_GPU", 2, "SOLVER.WARMUP_ITERS", 0,
+                         "SYNTHETIC.HEIGHT", 160, "SYNTHETIC.WIDTH", 224, "EMA.ALPHA", 0.9, "DOMAIN_ADAPT.TEACHER.THRESHOLD", 0.011, "SOLVER.BASE_LR", 1e-3])
+    return cfg
+
+
+def _detr_main(rank, world, port, out_path):
+    """one rank of the Deformable-DETR data-parallel run: ALDITrainer iterations (HardDistiller), each rank on its own batches"""
+    import torch.distributed as dist
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from aldi_amd import synthetic as syn
+    from aldi_amd.detr.criterion import SetCriterion
+    from aldi_amd.trainer import ALDITrainer
+    # the set criterion's normaliser: the ranks' target counts summed / world size (3 and 5 targets -> 4 on both ranks)
+    g = torch.Generator().manual_seed(40 + rank)
+    n = 3 if rank == 0 else 5
+    logits, boxes = torch.randn(2, 1, 30, 8, generator=g).cuda(), (torch.rand(2, 1, 30, 4, generator=g) * 0.4 + 0.2).cuda()
+    tg = [{"labels": torch.randint(0, 8, (n,), generator=g), "boxes": torch.rand(n, 4, generator=g) * 0.4 + 0.2}]
+    crit = SetCriterion()
+    l_dp = {k: float(v) for k, v in crit(logits, boxes, tg)[0].items()}
+    l_4 = {k: float(v) for k, v in crit(logits, boxes, tg, num_boxes=4.0)[0].items()}
+    random.seed(1234)
+    torch.manual_seed(9)
+    tr = ALDITrainer(_detr_cfg())
+    t = tr._trainer
+    t.data_loader = _ListLoader([syn.make_batch(2, 2, 160, 224, 8, seed=1000 * it + 31 * rank + 5) for it in range(ITERS)])
+    t._data_loader_iter_obj = None
+    w0 = tr.model.weights.master.cpu()
+    losses = []
+    for it in range(ITERS):
+        tr.iter = it
+        tr.before_step()
+        tr.run_step()
+        tr.after_step()
+        losses.append({k: float(v) for k, v in t.last_loss_dict.items()})
+    torch.cuda.synchronize()
+    torch.save(dict(student=tr.model.weights.master.cpu(), teacher=tr.ema.model.weights.master.cpu(), initial=w0, losses=losses, l_dp=l_dp, l_4=l_4), out_path)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_deformable_detr_two_ranks(tmp_path):
+    """BASELINE configs[4] under data parallelism (reference: DDP wrap aldi/dropin.py:53): two ranks with different batches end every
+    iteration with bit-identical student weights (one all-reduce of the flat gradient before the clip and the AdamW step) and
+    bit-identical teachers; the criterion normalises by the world's mean target count"""
+    port = _free_port()
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    procs, outs = [], []
+    for r in range(2):
+        outs.append(str(tmp_path / f"detr{r}.pt"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), "detr", str(r), "2", str(port), outs[-1]], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+    logs = []
+    for p in procs:
+        try:
+            o, _ = p.communicate(timeout=600)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        logs.append(o.decode(errors="replace")[-3000:])
+    assert all(p.returncode == 0 for p in procs), logs
+    res = [torch.load(o) for o in outs]
+    assert torch.equal(res[0]["student"], res[1]["student"]) and torch.equal(res[0]["teacher"], res[1]["teacher"])
+    assert torch.equal(res[0]["initial"], res[1]["initial"]) and not torch.equal(res[0]["student"], res[0]["initial"])
+    assert res[0]["losses"] != res[1]["losses"]                     # different batches per rank
+    assert all(v == v and abs(v) < 1e4 for r in res for d in r["losses"] for v in d.values())
+    for r in res:
+        assert r["l_dp"].keys() == r["l_4"].keys()
+        for k in r["l_dp"]:
+            assert abs(r["l_dp"][k] - r["l_4"][k]) <= 1e-6 * max(1.0, abs(r["l_4"][k])), (k, r["l_dp"][k], r["l_4"][k])
+
+
 def _bench(args, extra_env=None, timeout=900):
     env = dict(os.environ, **(extra_env or {}))
     env.pop("WORLD_SIZE", None)
@@ -281,3 +361,5 @@ if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "rank":
     _rank_main(int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), bool(int(sys.argv[5])), sys.argv[6])
 if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "rccl":
     _rccl_main(sys.argv[2], int(sys.argv[3]), sys.argv[4], sys.argv[5])
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "detr":
+    _detr_main(int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), sys.argv[5])
