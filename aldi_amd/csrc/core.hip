@@ -60,6 +60,8 @@ const Knob kKnobs[] = {
     {"wgrad_big_group_min", &AldiTuning::wgrad_big_group_min, 64},
     {"wgrad_lds_pad_kb", &AldiTuning::wgrad_lds_pad_kb, 0},
     {"wgrad_f32_tile128", &AldiTuning::wgrad_f32_tile128, 1},
+    {"msda_gather", &AldiTuning::msda_gather, 7},
+    {"msda_gather_list", &AldiTuning::msda_gather_list, 1500},
     {"roialign_sep", &AldiTuning::roialign_sep, 1},
     {"colsum_blocks", &AldiTuning::colsum_blocks, 256},
     {"colsum_minrows", &AldiTuning::colsum_minrows, 16},

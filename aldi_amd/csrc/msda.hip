@@ -20,6 +20,7 @@ struct MsdaDev {
     const int *shapes, *lstart;
     float *out, *gvalue, *gloc, *gattw;
     int N, S, M, Lq, L, P;
+    int gmask;          // gather form: bit l = target level l is gathered (the others take the atomic scatter)
 };
 
 // A (query, head) pair is D/4 consecutive lanes, each owning 4 channels (one 16-B load per corner; the D/4 lanes of a pair read
@@ -122,6 +123,185 @@ __global__ __launch_bounds__(256) void msda_bwd_value_kernel(MsdaDev a) {
     }
 }
 
+// ---- value gradient as a GATHER when the queries are the pyramid's positions (the encoder's self attention) ---------------------
+// The scatter above is bound by the float-add rate of the L2 atomic units (tools/probes/atomic_scope_probe.hip: 326 G adds/s at any
+// scope; 2 x 22 K queries x 8 heads x 64 corners x 32 channels = 730 M adds per encoder layer: 1.9 ms).  Here a workgroup OWNS a tile
+// of value pixels of one level and one head (8 x 8 on the fine levels, 4 x 4 / 2 x 2 on the coarse ones: every level receives the same
+// number of samples, so a coarse pixel collects ~1300 of them on a 13 x 21 map and its list is split over 4 / 16 threads).  It walks
+// the queries whose samples can reach the tile -- query (x, y) of level lq is expected at c = ((x + 0.5) W_l / W_lq - 0.5, ...) on the
+// target level and a sample counts as "near" when it lies within kGR pixels of c --, keeps those that touch the tile in an LDS list
+// (position, weight, query; slots reserved with one integer LDS atomic per wave), then every (pixel, 8-channel group) thread runs down
+// the list, takes the samples within one pixel of its own position with the bilinear weight (1 - |dx|)(1 - |dy|), reads the output
+// gradient's 32 bytes and writes its sum ONCE.  Samples that are not "near" (large learnt offsets, strongly padded images) go through a
+// second launch of the atomic scatter restricted to them; the predicate is the same float expression in both kernels, so every sample
+// is counted exactly once.  A tile whose list would not fit (kSCap) adds its own pixels with atomics instead.
+struct GatherTiles { int tile_begin[9]; int ts_log[8]; int L; };     // per TARGET level: first tile, log2 of the tile edge (8, 4 or 2 pixels)
+constexpr int kGR = 5, kSCap = 2048;
+
+__device__ __forceinline__ float msda_centre(int q, int Wt, int Wq) { return ((float)q + 0.5f) * ((float)Wt / (float)Wq) - 0.5f; }
+__device__ __forceinline__ bool msda_near(float x, float y, float cx, float cy) { return fabsf(x - cx) <= (float)kGR && fabsf(y - cy) <= (float)kGR; }
+
+// DIRECT = false: list the tile's samples in LDS; true: add them to the tile's pixels with atomics (the list overflowed)
+template <bool DIRECT>
+__device__ __forceinline__ void gather_walk(const MsdaDev& a, int n, int m, int l, int H, int W, int ty0, int tx0, int TS, float4* smp, int* count, float* gvl) {
+    const int tid = threadIdx.x, lane = tid & 63;
+    const long rowstride = (long)a.M * 32;
+    for (int lq = 0; lq < a.L; ++lq) {
+        const int Hq = a.shapes[2 * lq], Wq = a.shapes[2 * lq + 1];
+        // queries whose centre on level l lies within (tile - 1 - kGR, tile + TS + kGR): conservative integer bounds (+-1)
+        const float sx = (float)Wq / (float)W, sy = (float)Hq / (float)H;
+        int xa = (int)floorf(((float)(tx0 - 1 - kGR) + 0.5f) * sx - 0.5f) - 1, xb = (int)ceilf(((float)(tx0 + TS + kGR) + 0.5f) * sx - 0.5f) + 1;
+        int ya = (int)floorf(((float)(ty0 - 1 - kGR) + 0.5f) * sy - 0.5f) - 1, yb = (int)ceilf(((float)(ty0 + TS + kGR) + 0.5f) * sy - 0.5f) + 1;
+        xa = max(xa, 0); ya = max(ya, 0); xb = min(xb, Wq - 1); yb = min(yb, Hq - 1);
+        if (xa > xb || ya > yb) continue;
+        const int span = xb - xa + 1, cnt = span * (yb - ya + 1) * a.P;
+        // a trip's operands (location + weight of candidate base + tid) are requested one trip ahead: the walk is a chain of L2 round trips
+        const long lq0 = (long)n * a.Lq + a.lstart[lq];
+        auto fetch = [&](int idx, long& pair_, int& xq_, int& yq_, float2& lp_, float& w_) {
+            pair_ = -1;
+            if (idx < cnt) {
+                const int qq = idx / a.P, p_ = idx - qq * a.P;
+                yq_ = ya + qq / span; xq_ = xa + qq % span;
+                pair_ = (lq0 + (long)yq_ * Wq + xq_) * a.M + m;
+                const long e = (pair_ * a.L + l) * a.P + p_;
+                lp_ = *reinterpret_cast<const float2*>(a.loc + e * 2);
+                w_ = a.attw[e];
+            }
+        };
+        long pair_n; int xq_n = 0, yq_n = 0; float2 lp_n = make_float2(0.f, 0.f); float w_n = 0.f;
+        fetch(tid, pair_n, xq_n, yq_n, lp_n, w_n);
+        for (int base = 0; base < cnt; base += 256) {                    // (whole-workgroup trips: the slot reservation is a wave operation)
+            const long pair = pair_n; const int xq = xq_n, yq = yq_n; const float2 lp = lp_n; const float wgt_c = w_n;
+            if (base + 256 < cnt) fetch(base + 256 + tid, pair_n, xq_n, yq_n, lp_n, w_n);
+            bool hit = false;
+            float x = 0.f, y = 0.f;
+            if (pair >= 0) {
+                x = lp.x * W - 0.5f; y = lp.y * H - 0.5f;
+                if (y > -1.f && x > -1.f && y < (float)H && x < (float)W && msda_near(x, y, msda_centre(xq, W, Wq), msda_centre(yq, H, Hq))) {
+                    const int x0 = (int)floorf(x), y0 = (int)floorf(y);
+                    hit = x0 + 1 >= tx0 && x0 < tx0 + TS && y0 + 1 >= ty0 && y0 < ty0 + TS;
+                }
+            }
+            if (!DIRECT) {
+                const unsigned long long mask = __ballot(hit);
+                if (mask == 0) continue;
+                int slot0 = 0;
+                const int leader = __ffsll((long long)mask) - 1;
+                if (lane == leader) slot0 = atomicAdd(count, __popcll(mask));
+                slot0 = __shfl(slot0, leader, 64);
+                if (hit) {
+                    const int slot = slot0 + __popcll(mask & ((1ull << lane) - 1ull));
+                    if (slot < kSCap) smp[slot] = make_float4(x, y, wgt_c, __int_as_float((int)pair));
+                }
+            } else if (hit) {
+                const float wgt = wgt_c;
+                const float fx = floorf(x), fy = floorf(y), lx = x - fx, ly = y - fy, hx = 1.f - lx, hy = 1.f - ly;
+                const int x0 = (int)fx, y0 = (int)fy;
+                const float* g = a.gout + pair * 32;
+                for (int c = 0; c < 4; ++c) {
+                    const int xx = x0 + (c & 1), yy = y0 + (c >> 1);
+                    if (xx < tx0 || yy < ty0 || xx >= min(W, tx0 + TS) || yy >= min(H, ty0 + TS)) continue;
+                    const float v = wgt * ((c >> 1) ? ly : hy) * ((c & 1) ? lx : hx);
+                    float* dst = gvl + ((long)yy * W + xx) * rowstride;
+                    for (int d = 0; d < 32; ++d) unsafeAtomicAdd(dst + d, v * g[d]);
+                }
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void msda_bwd_value_gather_kernel(MsdaDev a, GatherTiles T) {
+    __shared__ float4 smp[kSCap];
+    __shared__ int count;
+    const int tid = threadIdx.x, m = blockIdx.y, n = blockIdx.z;
+    int l = 0;
+    while (l + 1 < T.L && (int)blockIdx.x >= T.tile_begin[l + 1]) ++l;
+    if (!((a.gmask >> l) & 1)) return;
+    const int ts_log = T.ts_log[l], TS = 1 << ts_log, NP = TS * TS, PARTS = 64 / NP;
+    const int H = a.shapes[2 * l], W = a.shapes[2 * l + 1];
+    const int tiles_x = (W + TS - 1) >> ts_log, tl = blockIdx.x - T.tile_begin[l];
+    const int ty0 = (tl / tiles_x) << ts_log, tx0 = (tl % tiles_x) << ts_log;
+    float* gvl = a.gvalue + ((long)n * a.S + a.lstart[l]) * (long)a.M * 32 + (long)m * 32;
+    if (tid == 0) count = 0;
+    __syncthreads();
+    gather_walk<false>(a, n, m, l, H, W, ty0, tx0, TS, smp, &count, gvl);
+    __syncthreads();
+    const int ns = count;
+    if (ns > kSCap) {                                  // (gvalue was zeroed by the caller; nobody else writes this tile's pixels in this launch)
+        gather_walk<true>(a, n, m, l, H, W, ty0, tx0, TS, smp, &count, gvl);
+        return;
+    }
+    // thread = (part of the list, pixel, 8-channel group)
+    const int cq = tid & 3, px = (tid >> 2) & (NP - 1), part = (tid >> 2) >> (2 * ts_log);
+    const int X = tx0 + (px & (TS - 1)), Y = ty0 + (px >> ts_log);
+    const float Xf = (float)X, Yf = (float)Y;
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int i = part; i < ns; i += PARTS) {
+        const float4 sp = smp[i];
+        const float wx = 1.f - fabsf(sp.x - Xf), wy = 1.f - fabsf(sp.y - Yf);
+        if (wx > 0.f && wy > 0.f) {
+            const float v = sp.z * wy * wx;
+            const float4* g = reinterpret_cast<const float4*>(a.gout + (long)__float_as_int(sp.w) * 32 + cq * 8);
+            const float4 g0 = g[0], g1 = g[1];
+            acc[0] += v * g0.x; acc[1] += v * g0.y; acc[2] += v * g0.z; acc[3] += v * g0.w;
+            acc[4] += v * g1.x; acc[5] += v * g1.y; acc[6] += v * g1.z; acc[7] += v * g1.w;
+        }
+    }
+    if (PARTS > 1) {                                   // the parts of a (pixel, channel group) meet in LDS (the list is consumed)
+        __syncthreads();
+        float* red = reinterpret_cast<float*>(smp);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) red[tid * 8 + k] = acc[k];
+        __syncthreads();
+        if (part) return;
+        for (int q = 1; q < PARTS; ++q)
+#pragma unroll
+            for (int k = 0; k < 8; ++k) acc[k] += red[(((q << (2 * ts_log)) + px) * 4 + cq) * 8 + k];
+    }
+    if (X >= W || Y >= H) return;
+    float4* dst = reinterpret_cast<float4*>(gvl + ((long)Y * W + X) * (long)a.M * 32 + cq * 8);
+    dst[0] = make_float4(acc[0], acc[1], acc[2], acc[3]);
+    dst[1] = make_float4(acc[4], acc[5], acc[6], acc[7]);
+}
+
+// the samples the gather does not take: not "near" their query's centre on the target level -> the atomic scatter (one lane per channel)
+__global__ __launch_bounds__(256) void msda_bwd_value_far_kernel(MsdaDev a) {
+    constexpr int D = 32;
+    const int lane = threadIdx.x & 63, d = lane % D;
+    const long pair = ((long)blockIdx.x * 4 + (threadIdx.x >> 6)) * 2 + lane / D;
+    if (pair >= (long)a.N * a.Lq * a.M) return;
+    const int m = (int)(pair % a.M), n = (int)(pair / ((long)a.M * a.Lq));
+    const int q = (int)((pair / a.M) % a.Lq);
+    int lq = 0;
+    while (lq + 1 < a.L && q >= a.lstart[lq + 1]) ++lq;
+    const int Hq = a.shapes[2 * lq], Wq = a.shapes[2 * lq + 1];
+    const int yq = (q - a.lstart[lq]) / Wq, xq = (q - a.lstart[lq]) - yq * Wq;
+    const long rowstride = (long)a.M * D;
+    const float* locp = a.loc + pair * a.L * a.P * 2;
+    const float* wp = a.attw + pair * a.L * a.P;
+    float g = 0.f;
+    bool have_g = false;
+    for (int l = 0; l < a.L; ++l) {
+        const int H = a.shapes[2 * l], W = a.shapes[2 * l + 1];
+        const float cx = msda_centre(xq, W, Wq), cy = msda_centre(yq, H, Hq);
+        float* gv = a.gvalue + ((long)n * a.S + a.lstart[l]) * rowstride + (long)m * D + d;
+        for (int p = 0; p < a.P; ++p) {
+            const float x = locp[(l * a.P + p) * 2] * W - 0.5f, y = locp[(l * a.P + p) * 2 + 1] * H - 0.5f;
+            if (!(y > -1.f && x > -1.f && y < (float)H && x < (float)W)) continue;
+            if (((a.gmask >> l) & 1) && msda_near(x, y, cx, cy)) continue;
+            if (!have_g) { g = a.gout[pair * D + d]; have_g = true; }
+            const float gw = g * wp[l * a.P + p];
+            const float fx = floorf(x), fy = floorf(y), lx = x - fx, ly = y - fy, hx = 1.f - lx, hy = 1.f - ly;
+            const int x0 = (int)fx, y0 = (int)fy;
+            const bool xa = x0 >= 0, xb = x0 + 1 < W, ya = y0 >= 0, yb = y0 + 1 < H;
+            if (ya && xa) unsafeAtomicAdd(gv + ((long)y0 * W + x0) * rowstride, gw * hy * hx);
+            if (ya && xb) unsafeAtomicAdd(gv + ((long)y0 * W + x0 + 1) * rowstride, gw * hy * lx);
+            if (yb && xa) unsafeAtomicAdd(gv + ((long)(y0 + 1) * W + x0) * rowstride, gw * ly * hx);
+            if (yb && xb) unsafeAtomicAdd(gv + ((long)(y0 + 1) * W + x0 + 1) * rowstride, gw * ly * lx);
+        }
+    }
+}
+
 template <bool BWD>
 int launch(const MsdaDev& a, int D, hipStream_t st) {
     const long npairs = (long)a.N * a.Lq * a.M;
@@ -129,6 +309,7 @@ int launch(const MsdaDev& a, int D, hipStream_t st) {
     else if (D == 64) hipLaunchKernelGGL((msda_kernel<64, BWD>), dim3(cdiv(npairs, 4 * 4)), dim3(256), 0, st, a);
     else return aldi_set_error_msg(ALDI_ERR_ARG, "ms_deform_attn: head dim must be 32 or 64");
     ALDI_CHECK_LAUNCH();
+    if (BWD && a.out) return ALDI_OK;                  // (the gather form finishes the value gradient itself; `out` is unused by the backward)
     if (BWD) {
         if (D == 32) hipLaunchKernelGGL(msda_bwd_value_kernel<32>, dim3(cdiv(npairs, 8)), dim3(256), 0, st, a);
         else hipLaunchKernelGGL(msda_bwd_value_kernel<64>, dim3(cdiv(npairs, 4)), dim3(256), 0, st, a);
@@ -162,5 +343,53 @@ extern "C" int aldi_ms_deform_attn_backward(const float* value, const int* spati
     a.value = value; a.loc = sampling_loc; a.attw = attn_weight; a.gout = grad_out; a.shapes = spatial_shapes; a.lstart = level_start_index;
     a.gvalue = grad_value; a.gloc = grad_sampling_loc; a.gattw = grad_attn_weight;
     a.N = N; a.S = S; a.M = M; a.Lq = Lq; a.L = L; a.P = P;
-    return launch<true>(a, D, (hipStream_t)stream);
+    if (int rc = launch<true>(a, D, (hipStream_t)stream)) return rc;
+    aldi_note_dispatch("msda_bwd_value_scatter");
+    return ALDI_OK;
+}
+
+extern "C" int aldi_ms_deform_attn_backward_self(const float* value, const int* spatial_shapes, const int* level_start_index, const int* spatial_shapes_host,
+                                                 const float* sampling_loc, const float* attn_weight, const float* grad_out, float* grad_value,
+                                                 float* grad_sampling_loc, float* grad_attn_weight, int N, int S, int M, int D, int L, int P, aldi_stream_t stream) {
+    if (!value || !spatial_shapes || !level_start_index || !spatial_shapes_host || !sampling_loc || !attn_weight || !grad_out || !grad_value ||
+        !grad_sampling_loc || !grad_attn_weight || N <= 0 || S <= 0 || M <= 0 || L <= 0 || L > 8 || P <= 0)
+        return aldi_set_error_msg(ALDI_ERR_ARG, "ms_deform_attn_backward_self: bad args (1 <= L <= 8)");
+    long sum = 0;
+    GatherTiles T{};
+    T.L = L;
+    for (int l = 0; l < L; ++l) {
+        const int H = spatial_shapes_host[2 * l], W = spatial_shapes_host[2 * l + 1];
+        if (H <= 0 || W <= 0) return aldi_set_error_msg(ALDI_ERR_ARG, "ms_deform_attn_backward_self: bad level shape");
+        sum += (long)H * W;
+    }
+    if (sum != S) return aldi_set_error_msg(ALDI_ERR_ARG, "ms_deform_attn_backward_self: the level shapes do not add up to S");
+    for (int l = 0; l < L; ++l) {
+        const int H = spatial_shapes_host[2 * l], W = spatial_shapes_host[2 * l + 1];
+        // every level receives S * P samples per head; a sample touches a T x T tile when its 2 x 2 footprint does: ~spp (T + 1)^2 list
+        // entries per tile for spp samples per pixel -- at most ~1500 (the list holds 2048)
+        const double spp = (double)S * P / ((double)H * W);
+        const double lim = aldi_tuning().msda_gather_list;
+        const int ts_log = spp * 81 <= lim ? 3 : (spp * 25 <= lim ? 2 : (spp * 9 <= lim ? 1 : 0));
+        T.ts_log[l] = ts_log;
+        T.tile_begin[l + 1] = T.tile_begin[l] + cdiv(H, 1 << ts_log) * cdiv(W, 1 << ts_log);
+    }
+    if (D != 32 || !aldi_tuning().msda_gather || M > 65535 || N > 65535 || (long)N * S * M > 0x7fffffffL)
+        return aldi_ms_deform_attn_backward(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, grad_out, grad_value, grad_sampling_loc,
+                                            grad_attn_weight, N, S, M, D, S, L, P, stream);
+    hipStream_t st = (hipStream_t)stream;
+    hipError_t e = hipMemsetAsync(grad_value, 0, (size_t)N * S * M * D * sizeof(float), st);
+    if (e != hipSuccess) return aldi_set_error(e, __FILE__, __LINE__);
+    MsdaDev a{};
+    a.value = value; a.loc = sampling_loc; a.attw = attn_weight; a.gout = grad_out; a.shapes = spatial_shapes; a.lstart = level_start_index;
+    a.gvalue = grad_value; a.gloc = grad_sampling_loc; a.gattw = grad_attn_weight;
+    a.N = N; a.S = S; a.M = M; a.Lq = S; a.L = L; a.P = P;
+    a.out = grad_value;                                 // marks "value gradient handled here" for launch<true>
+    a.gmask = aldi_tuning().msda_gather;
+    if (int rc = launch<true>(a, D, st)) return rc;
+    hipLaunchKernelGGL(msda_bwd_value_gather_kernel, dim3(T.tile_begin[L], M, N), dim3(256), 0, st, a, T);
+    ALDI_CHECK_LAUNCH();
+    hipLaunchKernelGGL(msda_bwd_value_far_kernel, dim3(cdiv((long)N * S * M, 8)), dim3(256), 0, st, a);
+    ALDI_CHECK_LAUNCH();
+    aldi_note_dispatch("msda_bwd_value_gather");
+    return ALDI_OK;
 }

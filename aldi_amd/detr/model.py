@@ -20,6 +20,7 @@ import math
 from collections import OrderedDict
 from typing import Dict, List, Optional, Sequence, Tuple
 
+import numpy as np
 import torch
 
 from .. import _lib as L
@@ -340,7 +341,7 @@ class DeformableTransformer:
         sh = torch.tensor([[h, w] for h, w in shapes], dtype=torch.int32)
         ls = torch.tensor([0] + list(torch.tensor([h * w for h, w in shapes]).cumsum(0)[:-1]), dtype=torch.int32)
         t = dict(pos=pos.to(self.dev).contiguous(), lvl_of=lvl_of.to(self.dev), keep=keep.to(self.dev).contiguous(), ref_enc=ref_enc.to(self.dev), vr=vr.to(self.dev),
-                 shapes=sh.to(self.dev), lstart=ls.to(self.dev), S=int(pos.shape[1]))
+                 shapes=sh.to(self.dev), lstart=ls.to(self.dev), S=int(pos.shape[1]), shapes_host=np.ascontiguousarray(sh.numpy().astype(np.int32)))
         self._tables[key] = t
         return t
 
@@ -416,8 +417,12 @@ class DeformableTransformer:
             if g is None:
                 return
             gv, gl, ga = torch.empty_like(value), torch.empty_like(loc), torch.empty_like(aw)
-            L.call("aldi_ms_deform_attn_backward", _p(value), _p(t["shapes"]), _p(t["lstart"]), _p(loc), _p(aw), _p(g.contiguous()), _p(gv), _p(gl), _p(ga),
-                   B, S, M, d // M, T // B, Lv, points, stream_ptr())
+            if pre.endswith(".self_attn") and T == B * S:    # the encoder's self attention: the queries are the pyramid's positions
+                L.call("aldi_ms_deform_attn_backward_self", _p(value), _p(t["shapes"]), _p(t["lstart"]), t["shapes_host"].ctypes.data, _p(loc), _p(aw),
+                       _p(g.contiguous()), _p(gv), _p(gl), _p(ga), B, S, M, d // M, Lv, points, stream_ptr())
+            else:
+                L.call("aldi_ms_deform_attn_backward", _p(value), _p(t["shapes"]), _p(t["lstart"]), _p(loc), _p(aw), _p(g.contiguous()), _p(gv), _p(gl), _p(ga),
+                       B, S, M, d // M, T // B, Lv, points, stream_ptr())
             L.call("aldi_mask_rows", _p(gv), _p(t["keep"]), gv.shape[0], d, stream_ptr())
             g_raw = torch.empty_like(raw)
             g_ref = torch.empty((T, Lv, 2), dtype=torch.float32, device=self.dev) if ref_grad is not None else None

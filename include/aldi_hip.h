@@ -526,6 +526,17 @@ int aldi_ms_deform_attn_backward(const float* value, const int* spatial_shapes, 
                                  const float* attn_weight, const float* grad_out, float* grad_value, float* grad_sampling_loc,
                                  float* grad_attn_weight, int N, int S, int M, int D, int Lq, int L, int P, aldi_stream_t stream);
 
+/* The same backward when the queries ARE the pyramid's positions (the encoder's self attention: Lq == S, query level_start[l] + y W_l + x
+ * at pixel (x, y) of level l); spatial_shapes_host = the same int[L][2] in host memory (launch geometry).  The value gradient is GATHERED:
+ * a workgroup owns an 8 x 8 tile of value pixels of one level and head, lists the (query, weight) pairs that reach each pixel and writes
+ * every gradient element once; samples farther than 5 pixels from their query's position on the target level go through the atomic
+ * scatter in a second launch (any offsets are handled; the sum is the same, the order of the float additions differs).
+ * Tuning msda_gather = bit mask of the target levels that are gathered (default 7: the three finest; the others keep the scatter),
+ * msda_gather_list = the list length the tile sizes aim at.  D != 32 or msda_gather = 0: the general form. */
+int aldi_ms_deform_attn_backward_self(const float* value, const int* spatial_shapes, const int* level_start_index, const int* spatial_shapes_host,
+                                      const float* sampling_loc, const float* attn_weight, const float* grad_out, float* grad_value,
+                                      float* grad_sampling_loc, float* grad_attn_weight, int N, int S, int M, int D, int L, int P, aldi_stream_t stream);
+
 /* Deformable-DETR pieces around that op (csrc/detr.hip), fp32; the arithmetic follows oracle/deformable_detr.py.
  * GroupNorm(G) over NHWC maps x [N][HW][C] (the input projections' normalisation): mean / rstd [N][G] are written for a backward
  * pass; workspace: aldi_group_norm_workspace(N, HW, G) bytes.  Deterministic (two-stage sums in a fixed order). */

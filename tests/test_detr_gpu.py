@@ -138,6 +138,57 @@ def test_backward_matches_the_oracles_autograd():
         assert (g.cpu().double() - ref).abs().max().item() <= 5e-3 * ref.abs().max().item()
 
 
+@pytest.mark.parametrize("offset_px,valid,cap_overflow", [(2.0, 1.0, False), (9.0, 1.0, False), (3.0, 0.8, False), (0.4, 1.0, True)])
+def test_self_attention_value_gradient_gathered(offset_px, valid, cap_overflow):
+    """aldi_ms_deform_attn_backward_self (queries = the pyramid's positions: a workgroup per 8 x 8 tile of value pixels gathers the samples
+    that reach it, the far ones go through the atomic scatter) == the general scatter kernel -- offsets inside the 5-pixel neighbourhood,
+    well outside it, reference points of a padded image (valid ratio 0.8: the queries' samples drift away from their pixel's position),
+    and samples piled onto few pixels (a tile's list overflows: its own atomic path); ragged level shapes (tiles cut by the border)"""
+    import numpy as np
+    from aldi_amd import _lib as L
+    from aldi_amd.ops import _p, stream_ptr
+    g = torch.Generator().manual_seed(21)
+    shapes = [(37, 53), (19, 27), (10, 14), (5, 7)]
+    N, M, D, Lv, P = 2, 8, 32, 4, 4
+    S = sum(h * w for h, w in shapes)
+    sh = torch.tensor(shapes, dtype=torch.int32)
+    ls = torch.tensor([0] + list(torch.tensor([h * w for h, w in shapes]).cumsum(0)[:-1]), dtype=torch.int32)
+    ref = torch.cat([torch.stack(torch.meshgrid((torch.arange(h) + 0.5) / h, (torch.arange(w) + 0.5) / w, indexing="ij"), -1).flip(-1).reshape(-1, 2) for h, w in shapes]) * valid
+    if cap_overflow:
+        ref = ref * 0 + 0.31                     # every query samples around one point: > 8192 (query, corner) pairs on a few pixels
+    off = torch.randn(N, S, M, Lv, P, 2, generator=g) * offset_px / torch.tensor([[w, h] for h, w in shapes]).view(1, 1, 1, Lv, 1, 2)
+    loc = (ref.view(1, S, 1, 1, 1, 2) + off).contiguous()
+    aw = torch.softmax(torch.randn(N, S, M, Lv * P, generator=g), -1).view(N, S, M, Lv, P).contiguous()
+    value, gout = torch.randn(N, S, M, D, generator=g), torch.randn(N, S, M * D, generator=g)
+    dev = [t.cuda() for t in (value, sh, ls, loc, aw, gout)]
+    host = np.ascontiguousarray(sh.numpy())
+    outs = []
+    # None: the general scatter; then the gather with its default level set (the three finest: the coarsest keeps the atomics), all four
+    # levels (1 x 1 tiles with the list split over 64 threads on the 5 x 7 map), the finest only, and switched off (the general form)
+    for mask in (None, -1, 15, 1, 0):
+        gv, gl, ga = torch.full_like(dev[0], 7.0), torch.empty_like(dev[3]), torch.empty_like(dev[4])
+        L.reset_tuning()
+        if mask is not None:
+            if mask >= 0:
+                L.set_tuning("msda_gather", mask)
+            L.call("aldi_ms_deform_attn_backward_self", _p(dev[0]), _p(dev[1]), _p(dev[2]), host.ctypes.data, _p(dev[3]), _p(dev[4]), _p(dev[5]),
+                   _p(gv), _p(gl), _p(ga), N, S, M, D, Lv, P, stream_ptr())
+            assert (L.last_dispatch() == "msda_bwd_value_gather") == (mask != 0), L.last_dispatch()
+        else:
+            L.call("aldi_ms_deform_attn_backward", _p(dev[0]), _p(dev[1]), _p(dev[2]), _p(dev[3]), _p(dev[4]), _p(dev[5]), _p(gv), _p(gl), _p(ga), N, S, M, D, S, Lv, P, stream_ptr())
+        torch.cuda.synchronize()
+        outs.append((gv.cpu(), gl.cpu(), ga.cpu()))
+    L.reset_tuning()
+    gv0, gl0, ga0 = outs[0]
+    assert gv0.abs().max().item() > 1.0
+    for gv1, gl1, ga1 in outs[1:]:
+        assert torch.equal(gl0, gl1) and torch.equal(ga0, ga1)
+        assert (gv0 - gv1).abs().max().item() <= 2e-5 * gv0.abs().max().item(), (gv0 - gv1).abs().max().item()
+    with pytest.raises(Exception):             # level shapes that do not add up to S
+        L.call("aldi_ms_deform_attn_backward_self", _p(dev[0]), _p(dev[1]), _p(dev[2]), host.ctypes.data, _p(dev[3]), _p(dev[4]), _p(dev[5]),
+               _p(gv), _p(gl), _p(ga), N, S - 1, M, D, Lv, P, stream_ptr())
+
+
 def _keep_mask(seed, shape, p):
     """the keep/(1-p) factors aldi_dropout_add applies for (seed, element index)"""
     from aldi_amd import _lib as L
