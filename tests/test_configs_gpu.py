@@ -264,3 +264,58 @@ def test_cfg2_fullsize_alignment_bf16_properties():
     assert int(tr.model.engine.err) == 0 and int(tr.ema.model.engine.err) == 0
     pl = tr.ema.model._last_inference.pseudo["count"].tolist()
     assert len(pl) == 2 and all(0 <= v <= 100 for v in pl)
+
+
+def test_cfg4_fullsize_deformable_detr_properties():
+    """BASELINE configs[4] at full size, as `bench.py --workload detr` runs it: configs/cityscapes/ALDI-Best-DETR-Cityscapes.yaml (6 + 6 layers,
+    300 queries, dropout 0.1, fp32), 1333 x 800, 2 labeled + 2 unlabeled images, HardDistiller through ALDITrainer.  Size-independent
+    properties: the loss-dict keys of the source and the pseudo-labelled target pass for every decoder layer (reference configs/Base-DETR.yaml
+    AUX_LOSS; aldi/distill.py:62-84 keeps the detector's own keys), finite values, the teacher's pseudo labels are consumed, trunk and
+    transformer step while the frozen stem / res2 do not, the teacher trails the student with `query_embed` copied (aldi/ema.py:17,39-41),
+    and the encoder's backward went through the gathered value gradient."""
+    from aldi_amd import _lib as L
+    from aldi_amd.config import add_aldi_config, get_cfg
+    from aldi_amd.trainer import ALDITrainer
+    cfg = get_cfg()
+    add_aldi_config(cfg)
+    cfg.merge_from_file(os.path.join(ROOT, "configs", "cityscapes", "ALDI-Best-DETR-Cityscapes.yaml"))
+    cfg.merge_from_list(["SOLVER.IMS_PER_BATCH", 4, "SOLVER.IMS_PER_GPU", 2, "SEED", 1, "SYNTHETIC.HEIGHT", 800, "SYNTHETIC.WIDTH", 1333,
+                         "DOMAIN_ADAPT.TEACHER.THRESHOLD", 0.011, "SOLVER.WARMUP_ITERS", 0])
+    assert cfg.MODEL.DEFORMABLE_DETR.TRANSFORMER.DROPOUT == 0.1 and cfg.MODEL.DEFORMABLE_DETR.TRANSFORMER.NUM_QUERIES == 300
+    random.seed(1234)
+    torch.manual_seed(100)
+    tr = ALDITrainer(cfg)
+    W, T = tr.model.weights, tr.ema.model.weights
+    w0 = W.master.clone()
+    seen = set()
+    orig = L.call
+
+    def spy(name, *a):
+        seen.add(name)
+        return orig(name, *a)
+    L.call = spy
+    try:
+        for it in range(2):
+            tr.iter = it
+            tr.before_step()
+            at_ema = W.master.clone()
+            tr.run_step()
+            tr.after_step()
+    finally:
+        L.call = orig
+    torch.cuda.synchronize()
+    assert "aldi_ms_deform_attn_backward_self" in seen and "aldi_dropout_add" in seen and "aldi_detr_set_loss" in seen
+    ld = {k: float(v) for k, v in tr._trainer.last_loss_dict.items()}
+    base = [f"{k}_{i}" for i in range(5) for k in ("loss_ce", "loss_bbox", "loss_giou")] + ["loss_ce", "loss_bbox", "loss_giou"]
+    assert set(ld) == {f"{k}_source_strong" for k in base} | {f"{k}_distill" for k in base}, sorted(ld)
+    assert all(v == v and 0.0 <= v < 1e3 for v in ld.values()), ld
+    assert int(tr.ema.model._last_inference.pseudo["count"].sum()) > 0
+    moved = (W.master - w0).abs()
+    nb = W.nb
+    assert torch.isfinite(W.master).all() and float(moved[nb:].max()) > 0 and float(moved[:nb].max()) > 0
+    frozen = W.backbone.layout.ranges(["backbone.bottom_up.stem.conv1", "backbone.bottom_up.res2.0.conv1"])
+    assert all(float(moved[a:b].max()) == 0.0 for a, b in frozen)
+    (a, b), = W.ranges(["query_embed.weight"])
+    assert torch.equal(T.master[a:b], at_ema[a:b])
+    (a, b), = W.ranges(["class_embed.weight"])
+    assert not torch.equal(T.master[a:b], at_ema[a:b])
