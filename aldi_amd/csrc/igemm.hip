@@ -854,19 +854,29 @@ int dispatch(ConvDev& d, hipStream_t st) {
     // the R50 trunk are HBM-bound and stay on 128x128.
     // igemm_halo: 3x3 / stride 1 / pad 1 (every 3x3 of the network): halo form, the pixel tile is loaded once per three taps.
     const int force = tn.igemm_force;     // 0 = heuristics; 1 = 128x128, 2 = 128x64, 3 = 64x64, 4 = 256x128, 5 = 128x16
-    if constexpr (sizeof(T) == 2) {
+    {
+        // (fp32 -- the parity mode and the Deformable-DETR step's trunk: the halo form is the same code, 16 channels per group; igemm_halo_f32)
         const bool same3 = d.KH == 3 && d.KW == 3 && d.stride == 1 && d.pad == 1 && d.Ho == d.H && d.Wo == d.W && d.Cin % 32 == 0 && d.out_scale == 1;
-        if (tn.igemm_halo && same3) {
+        // fp32: OFF by default (igemm_halo_f32 = 0).  From ~400 half-width tiles on the halo form is faster alone (tools/halo_f32_sweep.py:
+        // 33 600 px x 256 -> 256 324 -> 228 us, 33 600 x 128 -> 128 162 -> 115; below, the 64 x 64 tap form's four-fold workgroup count wins:
+        // 8400 x 256 -> 256 148 vs 158, 2100 x 2048 -> 256 488 vs 647), but it sums K in another order (kh, channels, kw) than the tap form, so
+        // a layer would round differently at N = 2 and at N = 6 -- the parity mode's fused-vs-sequential comparison flips discrete decisions --
+        // and the Deformable-DETR step (N = 2 maps, few eligible layers) did not move (138 vs 140 ms)
+        const bool f32_halo = sizeof(T) == 4 && tn.igemm_halo_f32 > 0 && (long)cdiv(d.M, 128) * cdiv(d.Cout, 64) >= tn.igemm_halo_f32;
+        if (tn.igemm_halo && (sizeof(T) == 2 || f32_halo) && same3) {
             if (force == 1) return launch<T, 128, 128, 2, 2, 4, false, true>(d, st);
             if (force == 2) return launch<T, 128, 64, 4, 1, 4, false, true>(d, st);
             if (force == 4) return launch<T, 256, 128, 4, 2, 4, false, true>(d, st);
-            if (force == 9) return launch<T, 240, 128, 3, 2, 4, false, true>(d, st);
-            if (force == 10 && !g_group) return launch_halo_rs<T, 128>(d, st);
+            if constexpr (sizeof(T) == 2) {
+                if (force == 9) return launch<T, 240, 128, 3, 2, 4, false, true>(d, st);
+                if (force == 10 && !g_group) return launch_halo_rs<T, 128>(d, st);
+            }
             if (force == 0 || force == 3) {      // (no 64x64 halo form; 5 = the 128x16 tap form)
                 if (d.Cout <= 64) return launch<T, 128, 64, 4, 1, 4, false, true>(d, st);
                 if (big >= tn.igemm_bigtile_min) {
                     if (tn.igemm_bigtile == 1) return launch<T, 128, 128, 2, 2, 4, false, true>(d, st);
-                    if (tn.igemm_bigtile == 10 && !g_group) return launch_halo_rs<T, 128>(d, st);
+                    if constexpr (sizeof(T) == 2)
+                        if (tn.igemm_bigtile == 10 && !g_group) return launch_halo_rs<T, 128>(d, st);
                     return launch<T, 256, 128, 4, 2, 4, false, true>(d, st);
                 }
                 // below ~1000 128x128 tiles the tile count of this network sits just above a multiple of the 256 CUs (16800 pixels =

@@ -164,6 +164,16 @@ def test_forward_default_dispatch_fullsize_fp32():
     _check_forward((2, 200, 336, 64, 256, 1, 1, 0), torch.float32, "igemm<f32,128,128,2,2,pipe,tap>")
     _check_forward((2, 200, 336, 64, 64, 3, 1, 1), torch.float32, "igemm<f32,128,64,4,1,pipe,tap>")
     _check_forward((2, 25, 42, 512, 512, 3, 1, 1), torch.float32, "igemm<f32,64,64,2,2,pipe,tap>")
+    # the fp32 halo arms (igemm_halo_f32 = least number of half-width tiles; off by default: another summation order than the tap form)
+    from aldi_amd import _lib as L
+    L.set_tuning("igemm_halo_f32", 400)
+    try:
+        _check_forward((2, 200, 336, 256, 256, 3, 1, 1), torch.float32, "igemm<f32,256,128,4,2,flat,halo>")
+        _check_forward((2, 200, 336, 64, 64, 3, 1, 1), torch.float32, "igemm<f32,128,64,4,1,flat,halo>")
+        _check_forward((2, 100, 168, 128, 128, 3, 1, 1), torch.float32, "igemm<f32,128,64,4,1,flat,halo>")      # 526 tiles
+        _check_forward((2, 25, 42, 512, 512, 3, 1, 1), torch.float32, "igemm<f32,64,64,2,2,pipe,tap>")          # 136 tiles
+    finally:
+        L.reset_tuning()
 
 
 # ---------------------------------------------------------------------------------- every template forced onto small ragged shapes
