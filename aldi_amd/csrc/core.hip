@@ -63,6 +63,8 @@ const Knob kKnobs[] = {
     {"wgrad_f32_tile128", &AldiTuning::wgrad_f32_tile128, 1},
     {"msda_gather", &AldiTuning::msda_gather, 7},
     {"msda_gather_list", &AldiTuning::msda_gather_list, 1500},
+    {"msda_bin", &AldiTuning::msda_bin, 1},
+    {"msda_bin_list", &AldiTuning::msda_bin_list, 512},
     {"roialign_sep", &AldiTuning::roialign_sep, 1},
     {"colsum_blocks", &AldiTuning::colsum_blocks, 256},
     {"colsum_minrows", &AldiTuning::colsum_minrows, 16},

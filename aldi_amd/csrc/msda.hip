@@ -302,6 +302,166 @@ __global__ __launch_bounds__(256) void msda_bwd_value_far_kernel(MsdaDev a) {
     }
 }
 
+// ---- the same gather with the lists built in HBM by ONE pass over the samples ("binned" form; needs a workspace) -----------------
+// The walk above finds a tile's samples by scanning every query that could reach it (5.6x the samples on an 8 x 8 tile, 42x on a 2 x 2
+// one) and needs the "near" predicate plus a second launch for the rest.  Here every sample is visited once: a thread per (query,
+// head, level, point) computes the 1..4 tiles its 2 x 2 footprint touches and appends (x, y, weight, query) to each tile's list in the
+// workspace (one returning integer atomic per tile touched); the second kernel is a workgroup per tile that streams its list through
+// LDS and sums as before.  No predicate, no second launch, any offsets; small tiles cost nothing to find, so every level is gathered
+// with tiles sized for ~128+ entries.  A list that overflows its capacity sends the extra samples through the atomic scatter, tile by
+// tile (the accumulate kernel ADDS to what those atomics left).
+constexpr int kCntPad = 32;        // one list counter per 128-B line: counters of neighbouring tiles on one line serialise in the L2 atomic unit
+struct BinTiles { int tile_begin[9]; int ts_log[8]; int cap[8]; long ent_begin[9]; int L; };      // per level: first tile, tile edge, list capacity, first entry (per (n, m) slice)
+
+// grid (64-query chunk, head, image); a wave takes four of the L * P (level, point) pairs in turn, lane = query of the chunk: the 64
+// neighbouring queries' samples of one (level, point) fall into a handful of tiles, so the lanes that hit the same tile reserve their
+// slots with ONE returning atomic (743 us with one atomic per sample and tile, 558 with one per group but a round trip per group, 322 with all groups of a (level, point) at once)
+__global__ __launch_bounds__(256) void msda_bin_kernel(MsdaDev a, BinTiles T, int* __restrict__ cnt, float4* __restrict__ ent) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int q = blockIdx.x * 64 + lane, m = blockIdx.y, n = blockIdx.z;
+    const bool live = q < a.Lq;
+    const long pair = ((long)n * a.Lq + (live ? q : 0)) * a.M + m;
+    const int lp = a.L * a.P;
+    const long slice = (long)n * a.M + m;
+    const long ent_slice = T.ent_begin[T.L];
+    int* cnt_s = cnt + slice * T.tile_begin[T.L] * kCntPad;
+    for (int r = wave; r < lp; r += 4) {
+        const int l = r / a.P;
+        const int H = a.shapes[2 * l], W = a.shapes[2 * l + 1];
+        const int ts = T.ts_log[l], tiles_x = (W + (1 << ts) - 1) >> ts, cap = T.cap[l];
+        float x = 0.f, y = 0.f, wgt = 0.f;
+        bool ok = false;
+        if (live) {
+            const float2 lc = *reinterpret_cast<const float2*>(a.loc + (pair * lp + r) * 2);
+            x = lc.x * W - 0.5f; y = lc.y * H - 0.5f;
+            ok = y > -1.f && x > -1.f && y < (float)H && x < (float)W;
+            if (ok) wgt = a.attw[pair * lp + r];
+        }
+        const int x0 = (int)floorf(x), y0 = (int)floorf(y);
+        const int txa = x0 >= 0 ? x0 >> ts : -1, txb = x0 + 1 < W ? (x0 + 1) >> ts : -1;
+        const int tya = y0 >= 0 ? y0 >> ts : -1, tyb = y0 + 1 < H ? (y0 + 1) >> ts : -1;
+        // per corner: the tile, and among the lanes that hit the same tile a leader, this lane's rank and the group's size (register work
+        // only); then ALL leaders of all four corners reserve their groups' slots at once -- one atomic round trip per (level, point)
+        bool hit4[4]; int t4[4], leader4[4], rank4[4], base4[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int tx = (c & 1) ? txb : txa, ty = (c >> 1) ? tyb : tya;
+            bool hit = ok && tx >= 0 && ty >= 0;
+            if ((c & 1) && txb == txa) hit = false;      // the same tile as the left / upper corner
+            if ((c >> 1) && tyb == tya) hit = false;
+            const int t = hit ? T.tile_begin[l] + ty * tiles_x + tx : -1;
+            int leader = -1, rank = 0, count = 0;
+            unsigned long long todo = __ballot(hit);
+            while (todo) {
+                const int ld = __ffsll((long long)todo) - 1;
+                const int tl = __shfl(t, ld, 64);
+                const unsigned long long same = __ballot(hit && t == tl);
+                if (hit && t == tl) { leader = ld; rank = __popcll(same & ((1ull << lane) - 1ull)); count = __popcll(same); }
+                todo &= ~same;
+            }
+            hit4[c] = hit; t4[c] = t; leader4[c] = leader; rank4[c] = rank;
+            base4[c] = 0;
+            if (hit && lane == leader) base4[c] = atomicAdd(cnt_s + (long)t * kCntPad, count);
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int tx = (c & 1) ? txb : txa, ty = (c >> 1) ? tyb : tya;
+            const bool hit = hit4[c];
+            const int t = t4[c];
+            const int slot = __shfl(base4[c], leader4[c] < 0 ? lane : leader4[c], 64) + rank4[c];
+            if (!hit) continue;
+            if (slot < cap) {
+                ent[slice * ent_slice + T.ent_begin[l] + (long)(t - T.tile_begin[l]) * cap + slot] = make_float4(x, y, wgt, __int_as_float((int)pair));
+            } else {                                     // list full: this sample's corners inside the tile, with atomics
+                const float lx = x - (float)x0, ly = y - (float)y0, hx = 1.f - lx, hy = 1.f - ly;
+                const float* g = a.gout + pair * 32;
+                float* gvl = a.gvalue + ((long)n * a.S + a.lstart[l]) * (long)a.M * 32 + (long)m * 32;
+                for (int k = 0; k < 4; ++k) {
+                    const int xx = x0 + (k & 1), yy = y0 + (k >> 1);
+                    if (xx < 0 || yy < 0 || xx >= W || yy >= H || (xx >> ts) != tx || (yy >> ts) != ty) continue;
+                    const float v = wgt * ((k >> 1) ? ly : hy) * ((k & 1) ? lx : hx);
+                    float* dst = gvl + ((long)yy * W + xx) * (long)a.M * 32;
+                    for (int d = 0; d < 32; ++d) unsafeAtomicAdd(dst + d, v * g[d]);
+                }
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void msda_bin_accumulate_kernel(MsdaDev a, BinTiles T, const int* __restrict__ cnt, const float4* __restrict__ ent) {
+    constexpr int CH = 1024;
+    __shared__ float4 smp[CH];
+    const int tid = threadIdx.x, m = blockIdx.y, n = blockIdx.z;
+    int l = 0;
+    while (l + 1 < T.L && (int)blockIdx.x >= T.tile_begin[l + 1]) ++l;
+    const int ts_log = T.ts_log[l], TS = 1 << ts_log, NP = TS * TS, PARTS = 64 / NP;
+    const int H = a.shapes[2 * l], W = a.shapes[2 * l + 1];
+    const int tiles_x = (W + TS - 1) >> ts_log, tl = blockIdx.x - T.tile_begin[l];
+    const int ty0 = (tl / tiles_x) << ts_log, tx0 = (tl % tiles_x) << ts_log;
+    const long slice = (long)n * a.M + m;
+    const int ns = min(cnt[(slice * T.tile_begin[T.L] + blockIdx.x) * kCntPad], T.cap[l]);
+    const float4* list = ent + slice * T.ent_begin[T.L] + T.ent_begin[l] + (long)tl * T.cap[l];
+    const int cq = tid & 3, px = (tid >> 2) & (NP - 1), part = (tid >> 2) >> (2 * ts_log);
+    const int X = tx0 + (px & (TS - 1)), Y = ty0 + (px >> ts_log);
+    const float Xf = (float)X, Yf = (float)Y;
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int base = 0; base < ns; base += CH) {
+        const int nc = min(CH, ns - base);
+        if (base) __syncthreads();
+        for (int i = tid; i < nc; i += 256) smp[i] = list[base + i];
+        __syncthreads();
+        for (int i = part; i < nc; i += PARTS) {
+            const float4 sp = smp[i];
+            const float wx = 1.f - fabsf(sp.x - Xf), wy = 1.f - fabsf(sp.y - Yf);
+            if (wx > 0.f && wy > 0.f) {
+                const float v = sp.z * wy * wx;
+                const float4* g = reinterpret_cast<const float4*>(a.gout + (long)__float_as_int(sp.w) * 32 + cq * 8);
+                const float4 g0 = g[0], g1 = g[1];
+                acc[0] += v * g0.x; acc[1] += v * g0.y; acc[2] += v * g0.z; acc[3] += v * g0.w;
+                acc[4] += v * g1.x; acc[5] += v * g1.y; acc[6] += v * g1.z; acc[7] += v * g1.w;
+            }
+        }
+    }
+    if (PARTS > 1) {
+        __syncthreads();
+        float* red = reinterpret_cast<float*>(smp);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) red[tid * 8 + k] = acc[k];
+        __syncthreads();
+        if (part) return;
+        for (int q = 1; q < PARTS; ++q)
+#pragma unroll
+            for (int k = 0; k < 8; ++k) acc[k] += red[(((q << (2 * ts_log)) + px) * 4 + cq) * 8 + k];
+    }
+    if (X >= W || Y >= H) return;
+    float4* dst = reinterpret_cast<float4*>(a.gvalue + (((long)n * a.S + a.lstart[l] + (long)Y * W + X) * a.M + m) * 32 + cq * 8);
+    float4 d0 = dst[0], d1 = dst[1];                    // (zero, or what an overflowing list's atomics left)
+    d0.x += acc[0]; d0.y += acc[1]; d0.z += acc[2]; d0.w += acc[3];
+    d1.x += acc[4]; d1.y += acc[5]; d1.z += acc[6]; d1.w += acc[7];
+    dst[0] = d0; dst[1] = d1;
+}
+
+// tile sizes / capacities of the binned form: the smallest tile with >= `want` expected entries, capacity 2x the expectation + 256
+int bin_plan(const int* shapes_host, int S, int L, int P, BinTiles& T) {
+    T = BinTiles{};
+    T.L = L;
+    const double want = aldi_tuning().msda_bin_list;
+    for (int l = 0; l < L; ++l) {
+        const int H = shapes_host[2 * l], W = shapes_host[2 * l + 1];
+        const double spp = (double)S * P / ((double)H * W);
+        int ts_log = 3;
+        for (int t = 0; t <= 3; ++t)
+            if (spp * ((1 << t) + 1) * ((1 << t) + 1) >= want) { ts_log = t; break; }
+        T.ts_log[l] = ts_log;
+        const double expect = spp * ((1 << ts_log) + 1) * ((1 << ts_log) + 1);
+        T.cap[l] = ((int)(2.0 * expect) + 256 + 255) / 256 * 256;
+        const int tiles = cdiv(H, 1 << ts_log) * cdiv(W, 1 << ts_log);
+        T.tile_begin[l + 1] = T.tile_begin[l] + tiles;
+        T.ent_begin[l + 1] = T.ent_begin[l] + (long)tiles * T.cap[l];
+    }
+    return ALDI_OK;
+}
+
 template <bool BWD>
 int launch(const MsdaDev& a, int D, hipStream_t st) {
     const long npairs = (long)a.N * a.Lq * a.M;
@@ -348,9 +508,18 @@ extern "C" int aldi_ms_deform_attn_backward(const float* value, const int* spati
     return ALDI_OK;
 }
 
+extern "C" size_t aldi_ms_deform_attn_backward_self_workspace(const int* spatial_shapes_host, int N, int S, int M, int L, int P) {
+    if (!spatial_shapes_host || N <= 0 || S <= 0 || M <= 0 || L <= 0 || L > 8 || P <= 0) return 0;
+    BinTiles T;
+    bin_plan(spatial_shapes_host, S, L, P, T);
+    const size_t slices = (size_t)N * M;
+    return slices * T.tile_begin[L] * kCntPad * sizeof(int) + slices * (size_t)T.ent_begin[L] * sizeof(float4);
+}
+
 extern "C" int aldi_ms_deform_attn_backward_self(const float* value, const int* spatial_shapes, const int* level_start_index, const int* spatial_shapes_host,
                                                  const float* sampling_loc, const float* attn_weight, const float* grad_out, float* grad_value,
-                                                 float* grad_sampling_loc, float* grad_attn_weight, int N, int S, int M, int D, int L, int P, aldi_stream_t stream) {
+                                                 float* grad_sampling_loc, float* grad_attn_weight, void* workspace, size_t workspace_bytes,
+                                                 int N, int S, int M, int D, int L, int P, aldi_stream_t stream) {
     if (!value || !spatial_shapes || !level_start_index || !spatial_shapes_host || !sampling_loc || !attn_weight || !grad_out || !grad_value ||
         !grad_sampling_loc || !grad_attn_weight || N <= 0 || S <= 0 || M <= 0 || L <= 0 || L > 8 || P <= 0)
         return aldi_set_error_msg(ALDI_ERR_ARG, "ms_deform_attn_backward_self: bad args (1 <= L <= 8)");
@@ -386,6 +555,23 @@ extern "C" int aldi_ms_deform_attn_backward_self(const float* value, const int* 
     a.out = grad_value;                                 // marks "value gradient handled here" for launch<true>
     a.gmask = aldi_tuning().msda_gather;
     if (int rc = launch<true>(a, D, st)) return rc;
+    if (workspace && aldi_tuning().msda_bin) {           // the binned form: lists built in the workspace by one pass over the samples
+        BinTiles B;
+        bin_plan(spatial_shapes_host, S, L, P, B);
+        if (workspace_bytes < aldi_ms_deform_attn_backward_self_workspace(spatial_shapes_host, N, S, M, L, P))
+            return aldi_set_error_msg(ALDI_ERR_ARG, "ms_deform_attn_backward_self: workspace too small (aldi_ms_deform_attn_backward_self_workspace)");
+        const size_t slices = (size_t)N * M, cnt_bytes = slices * B.tile_begin[L] * kCntPad * sizeof(int);
+        int* cnt = static_cast<int*>(workspace);
+        float4* ent = reinterpret_cast<float4*>(static_cast<char*>(workspace) + cnt_bytes);
+        e = hipMemsetAsync(cnt, 0, cnt_bytes, st);
+        if (e != hipSuccess) return aldi_set_error(e, __FILE__, __LINE__);
+        hipLaunchKernelGGL(msda_bin_kernel, dim3(cdiv(S, 64), M, N), dim3(256), 0, st, a, B, cnt, ent);
+        ALDI_CHECK_LAUNCH();
+        hipLaunchKernelGGL(msda_bin_accumulate_kernel, dim3(B.tile_begin[L], M, N), dim3(256), 0, st, a, B, cnt, ent);
+        ALDI_CHECK_LAUNCH();
+        aldi_note_dispatch("msda_bwd_value_binned");
+        return ALDI_OK;
+    }
     hipLaunchKernelGGL(msda_bwd_value_gather_kernel, dim3(T.tile_begin[L], M, N), dim3(256), 0, st, a, T);
     ALDI_CHECK_LAUNCH();
     hipLaunchKernelGGL(msda_bwd_value_far_kernel, dim3(cdiv((long)N * S * M, 8)), dim3(256), 0, st, a);

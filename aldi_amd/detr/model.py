@@ -390,6 +390,14 @@ class DeformableTransformer:
         self._rec(bwd)
         return y
 
+    def _msda_workspace(self, t: dict, B: int, S: int, M: int, Lv: int, points: int) -> torch.Tensor:
+        """the sample lists of the encoder's gathered value gradient (one buffer per forward geometry, reused by every layer)"""
+        need = int(L.lib.aldi_ms_deform_attn_backward_self_workspace(t["shapes_host"].ctypes.data, B, S, M, Lv, points))
+        ws = t.get("msda_ws")
+        if ws is None or ws.numel() < need:
+            ws = t["msda_ws"] = torch.empty(need, dtype=torch.uint8, device=self.dev)
+        return ws
+
     def _deform_attn(self, pre: str, query: torch.Tensor, ref: torch.Tensor, value_in: torch.Tensor, res: torch.Tensor, t: dict, B: int, points: int,
                      ref_grad: Optional[torch.Tensor] = None):
         """query [B*Q, d] (already + position), ref [B*Q, L, 2], value_in [B*S, d]; -> output_proj(attention) + res.
@@ -418,8 +426,9 @@ class DeformableTransformer:
                 return
             gv, gl, ga = torch.empty_like(value), torch.empty_like(loc), torch.empty_like(aw)
             if pre.endswith(".self_attn") and T == B * S:    # the encoder's self attention: the queries are the pyramid's positions
+                ws = self._msda_workspace(t, B, S, M, Lv, points)
                 L.call("aldi_ms_deform_attn_backward_self", _p(value), _p(t["shapes"]), _p(t["lstart"]), t["shapes_host"].ctypes.data, _p(loc), _p(aw),
-                       _p(g.contiguous()), _p(gv), _p(gl), _p(ga), B, S, M, d // M, Lv, points, stream_ptr())
+                       _p(g.contiguous()), _p(gv), _p(gl), _p(ga), _p(ws), ws.numel(), B, S, M, d // M, Lv, points, stream_ptr())
             else:
                 L.call("aldi_ms_deform_attn_backward", _p(value), _p(t["shapes"]), _p(t["lstart"]), _p(loc), _p(aw), _p(g.contiguous()), _p(gv), _p(gl), _p(ga),
                        B, S, M, d // M, T // B, Lv, points, stream_ptr())

@@ -535,7 +535,12 @@ int aldi_ms_deform_attn_backward(const float* value, const int* spatial_shapes, 
  * msda_gather_list = the list length the tile sizes aim at.  D != 32 or msda_gather = 0: the general form. */
 int aldi_ms_deform_attn_backward_self(const float* value, const int* spatial_shapes, const int* level_start_index, const int* spatial_shapes_host,
                                       const float* sampling_loc, const float* attn_weight, const float* grad_out, float* grad_value,
-                                      float* grad_sampling_loc, float* grad_attn_weight, int N, int S, int M, int D, int L, int P, aldi_stream_t stream);
+                                      float* grad_sampling_loc, float* grad_attn_weight, void* workspace, size_t workspace_bytes,
+                                      int N, int S, int M, int D, int L, int P, aldi_stream_t stream);
+/* With a workspace of aldi_ms_deform_attn_backward_self_workspace(...) bytes (tuning msda_bin = 1) the lists are built by ONE pass over the
+ * samples: a thread per sample appends it to the 1..4 tiles its footprint touches (tiles sized for >= msda_bin_list (512) expected entries on
+ * every level), a workgroup per tile sums its list; no neighbourhood predicate, any offsets, all levels.  workspace NULL: the walk form. */
+size_t aldi_ms_deform_attn_backward_self_workspace(const int* spatial_shapes_host, int N, int S, int M, int L, int P);
 
 /* Deformable-DETR pieces around that op (csrc/detr.hip), fp32; the arithmetic follows oracle/deformable_detr.py.
  * GroupNorm(G) over NHWC maps x [N][HW][C] (the input projections' normalisation): mean / rstd [N][G] are written for a backward

@@ -165,14 +165,33 @@ def test_self_attention_value_gradient_gathered(offset_px, valid, cap_overflow):
     outs = []
     # None: the general scatter; then the gather with its default level set (the three finest: the coarsest keeps the atomics), all four
     # levels (1 x 1 tiles with the list split over 64 threads on the 5 x 7 map), the finest only, and switched off (the general form)
-    for mask in (None, -1, 15, 1, 0):
+    need = int(L.lib.aldi_ms_deform_attn_backward_self_workspace(host.ctypes.data, N, S, M, Lv, P))
+    ws = torch.empty(need, dtype=torch.uint8, device="cuda")
+    # None: the general scatter; "bin": the lists built by one pass over the samples (workspace), also with tiny lists (capacity overflow ->
+    # atomics for the surplus); then the walk form (no workspace) with its default level set (the three finest: the coarsest keeps the
+    # atomics), all four levels (1 x 1 tiles, the list split over 64 threads on the 5 x 7 map), the finest only, and switched off
+    for mask in (None, "bin", "bin-small", -1, 15, 1, 0):
         gv, gl, ga = torch.full_like(dev[0], 7.0), torch.empty_like(dev[3]), torch.empty_like(dev[4])
         L.reset_tuning()
-        if mask is not None:
+        if isinstance(mask, str):
+            if mask == "bin-small":
+                L.set_tuning("msda_bin_list", 8)
+                need2 = int(L.lib.aldi_ms_deform_attn_backward_self_workspace(host.ctypes.data, N, S, M, Lv, P))
+                assert need2 != need
+                ws2 = torch.empty(need2, dtype=torch.uint8, device="cuda")
+            else:
+                ws2 = ws
+            L.call("aldi_ms_deform_attn_backward_self", _p(dev[0]), _p(dev[1]), _p(dev[2]), host.ctypes.data, _p(dev[3]), _p(dev[4]), _p(dev[5]),
+                   _p(gv), _p(gl), _p(ga), _p(ws2), ws2.numel(), N, S, M, D, Lv, P, stream_ptr())
+            assert L.last_dispatch() == "msda_bwd_value_binned", L.last_dispatch()
+            with pytest.raises(Exception):         # a workspace that is too small is refused
+                L.call("aldi_ms_deform_attn_backward_self", _p(dev[0]), _p(dev[1]), _p(dev[2]), host.ctypes.data, _p(dev[3]), _p(dev[4]), _p(dev[5]),
+                       _p(gv.clone()), _p(gl), _p(ga), _p(ws2), 1024, N, S, M, D, Lv, P, stream_ptr())
+        elif mask is not None:
             if mask >= 0:
                 L.set_tuning("msda_gather", mask)
             L.call("aldi_ms_deform_attn_backward_self", _p(dev[0]), _p(dev[1]), _p(dev[2]), host.ctypes.data, _p(dev[3]), _p(dev[4]), _p(dev[5]),
-                   _p(gv), _p(gl), _p(ga), N, S, M, D, Lv, P, stream_ptr())
+                   _p(gv), _p(gl), _p(ga), None, 0, N, S, M, D, Lv, P, stream_ptr())
             assert (L.last_dispatch() == "msda_bwd_value_gather") == (mask != 0), L.last_dispatch()
         else:
             L.call("aldi_ms_deform_attn_backward", _p(dev[0]), _p(dev[1]), _p(dev[2]), _p(dev[3]), _p(dev[4]), _p(dev[5]), _p(gv), _p(gl), _p(ga), N, S, M, D, S, Lv, P, stream_ptr())
@@ -186,7 +205,7 @@ def test_self_attention_value_gradient_gathered(offset_px, valid, cap_overflow):
         assert (gv0 - gv1).abs().max().item() <= 2e-5 * gv0.abs().max().item(), (gv0 - gv1).abs().max().item()
     with pytest.raises(Exception):             # level shapes that do not add up to S
         L.call("aldi_ms_deform_attn_backward_self", _p(dev[0]), _p(dev[1]), _p(dev[2]), host.ctypes.data, _p(dev[3]), _p(dev[4]), _p(dev[5]),
-               _p(gv), _p(gl), _p(ga), N, S - 1, M, D, Lv, P, stream_ptr())
+               _p(gv), _p(gl), _p(ga), None, 0, N, S - 1, M, D, Lv, P, stream_ptr())
 
 
 def _keep_mask(seed, shape, p):

@@ -25,12 +25,16 @@ for px in (0.0, 2.0, 4.0, 8.0):
     gv, gl, ga = torch.empty_like(value), torch.empty_like(loc), torch.empty_like(aw)
     host = np.ascontiguousarray(sh.numpy())
     res, keep = [], []
-    for form in (0, 1500, 1500, 1500, 1500):
-        L.set_tuning("msda_gather", 7)
-        L.set_tuning("msda_gather_list", form if form else 1500)
+    for form in (0, "walk", 128, 512, 1024, 2048):
+        L.reset_tuning()
+        ws = None
+        if form not in (0, "walk"):
+            L.set_tuning("msda_bin_list", form)
+            ws = torch.empty(int(L.lib.aldi_ms_deform_attn_backward_self_workspace(host.ctypes.data, N, S, M, Lv, P)), dtype=torch.uint8, device="cuda")
         def run():
             if form:
-                L.call("aldi_ms_deform_attn_backward_self", _p(value), _p(shd), _p(lsd), host.ctypes.data, _p(loc), _p(aw), _p(gout), _p(gv), _p(gl), _p(ga), N, S, M, D, Lv, P, stream_ptr())
+                L.call("aldi_ms_deform_attn_backward_self", _p(value), _p(shd), _p(lsd), host.ctypes.data, _p(loc), _p(aw), _p(gout), _p(gv), _p(gl), _p(ga),
+                       _p(ws) if ws is not None else None, ws.numel() if ws is not None else 0, N, S, M, D, Lv, P, stream_ptr())
             else:
                 L.call("aldi_ms_deform_attn_backward", _p(value), _p(shd), _p(lsd), _p(loc), _p(aw), _p(gout), _p(gv), _p(gl), _p(ga), N, S, M, D, S, Lv, P, stream_ptr())
         for _ in range(2):
@@ -44,4 +48,4 @@ for px in (0.0, 2.0, 4.0, 8.0):
         res.append(e0.elapsed_time(e1) * 200)
         keep.append(gv.clone())
     err = max((keep[0] - k).abs().max().item() for k in keep[1:]) / keep[0].abs().max().item()
-    print("offsets %s: scatter %.0f us; gather of levels {0,1,2} with lists <= 1500 %.0f, 600 %.0f, 300 %.0f, 150 %.0f us (whole backward); max rel diff %.1e" % (("initial" if px == 0 else "sigma %.0f px" % px,) + tuple(res) + (err,)))
+    print("offsets %s: scatter %.0f us; walk form %.0f; binned form with lists >= 128 %.0f, 512 %.0f, 1024 %.0f, 2048 %.0f us (whole backward); max rel diff %.1e" % (("initial" if px == 0 else "sigma %.0f px" % px,) + tuple(res) + (err,)))
