@@ -551,6 +551,8 @@ def main():
         # serialises the step's three branches, reports it in profiles/), not inflated by whatever the other two streams run beside it
         import aldi_amd.trainer as _T
         engines = [tr.model.engine] + ([tr.ema.model.engine] if getattr(tr, "ema", None) is not None else [])
+        # (the Deformable-DETR detector drives its R50 trunk through an engine of its own: its side streams are switched off as well)
+        engines += [m.bengine for m in (tr.model, getattr(getattr(tr, "ema", None), "model", None)) if m is not None and hasattr(m, "bengine")]
         saved = [(e, e.__dict__.get("_wg_side", "absent")) for e in engines]
         saved_aux = [(e, e.__dict__.get("_aux_side", "absent")) for e in engines]
         saved_sgd = [(e, e.__dict__.get("_sgd_side", "absent")) for e in engines]

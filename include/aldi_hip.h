@@ -64,6 +64,13 @@ int aldi_noop(aldi_stream_t stream);
  *   roialign_sep         1 = aldi_roialign forward in the separable form (row / column weight tables, one workgroup per ROI); 0 = per sample
  *   wgrad_dbg            ablation bits (1 = skip the atomic epilogue): results are WRONG when set
  *   wgrad_dma            LDS-DMA + ds_read_b64_tr_b16 weight-gradient kernel: 0 off, 1 in place of the lean kernel, 2 also of the 256x256
+ *   wgrad_f32_tile128    1 = fp32 weight gradients with Cout, K >= 128 on the 128x128 f32-MFMA tile (0: the 64x64 kernel)
+ *   igemm_halo_f32       > 0: fp32 3x3/stride-1/pad-1 convs with at least this many 128x64 tiles take the halo form too (0 = off, the
+ *                        default: it sums K in another order than the tap form)
+ *   msda_bin             1 = aldi_ms_deform_attn_backward_self with a workspace bins the samples into per-tile lists (0: the walk form)
+ *   msda_bin_list        expected list entries per tile the binned form sizes its tiles for (512)
+ *   msda_gather          walk form (no workspace): bit mask of the target levels that are gathered (7); 0 = the general scatter
+ *   msda_gather_list     walk form: list length the tile sizes aim at (1500)
  *   colsum_blocks, colsum_minrows, colsum_nt, colsum_block_kb   aldi_bias_grad launch geometry
  *   stem_mfma            1 = MFMA stem kernel in bf16 mode
  *   sab_blocks, ln_bwd_blocks, ln_bwd_blocks_narrow   ConvNeXt scale-and-bias / LayerNorm backward launch geometry
