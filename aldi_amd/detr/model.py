@@ -342,6 +342,8 @@ class DeformableTransformer:
         ls = torch.tensor([0] + list(torch.tensor([h * w for h, w in shapes]).cumsum(0)[:-1]), dtype=torch.int32)
         t = dict(pos=pos.to(self.dev).contiguous(), lvl_of=lvl_of.to(self.dev), keep=keep.to(self.dev).contiguous(), ref_enc=ref_enc.to(self.dev), vr=vr.to(self.dev),
                  shapes=sh.to(self.dev), lstart=ls.to(self.dev), S=int(pos.shape[1]), shapes_host=np.ascontiguousarray(sh.numpy().astype(np.int32)))
+        if len(self._tables) >= 16:                 # (batches of varying sizes / paddings: keep the most recent geometries only)
+            self._tables.pop(next(iter(self._tables)))
         self._tables[key] = t
         return t
 
@@ -391,11 +393,11 @@ class DeformableTransformer:
         return y
 
     def _msda_workspace(self, t: dict, B: int, S: int, M: int, Lv: int, points: int) -> torch.Tensor:
-        """the sample lists of the encoder's gathered value gradient (one buffer per forward geometry, reused by every layer)"""
+        """the sample lists of the encoder's gathered value gradient (reused by every layer and every geometry)"""
         need = int(L.lib.aldi_ms_deform_attn_backward_self_workspace(t["shapes_host"].ctypes.data, B, S, M, Lv, points))
-        ws = t.get("msda_ws")
+        ws = getattr(self, "_msda_ws", None)
         if ws is None or ws.numel() < need:
-            ws = t["msda_ws"] = torch.empty(need, dtype=torch.uint8, device=self.dev)
+            ws = self._msda_ws = torch.empty(need, dtype=torch.uint8, device=self.dev)       # ONE buffer, grown to the largest geometry seen
         return ws
 
     def _deform_attn(self, pre: str, query: torch.Tensor, ref: torch.Tensor, value_in: torch.Tensor, res: torch.Tensor, t: dict, B: int, points: int,

@@ -329,6 +329,26 @@ def profile_insitu(step_fn, table_path=None):
     ops.conv2d, ops.conv_wgrad, ops.conv_wgrad_group, ops.conv2d_group = conv2d, conv_wgrad, conv_wgrad_group, conv2d_group
     ops.bottleneck_fused, ops.sgd_step, ops.ema_update, ops.roialign, ops.roialign_backward = bottleneck_fused, sgd_step, ema_update, roialign, roialign_backward
     ops.sgd_step_dev = sgd_step_dev
+    # ... and the multi-scale deformable attention of the Deformable-DETR workload (called through the C ABI directly): compulsory HBM bytes
+    # = value, locations, weights (+ the output gradient) read once, the output (or the three gradients) written once
+    from aldi_amd import _lib as _L
+    orig_call = _L.call
+
+    def lib_call(name, *a):
+        if name == "aldi_ms_deform_attn_forward":
+            N, S, M, D, Lq, Lv, P = a[-8:-1]
+            nby = 4 * (N * S * M * D + N * Lq * M * Lv * P * 3 + N * Lq * M * D)
+            return timed("msda_fwd", (N, S, Lq), 0.0, nby, orig_call, name, *a)
+        if name in ("aldi_ms_deform_attn_backward", "aldi_ms_deform_attn_backward_self"):
+            if name.endswith("_self"):
+                N, S, M, D, Lv, P = a[-7:-1]
+                Lq = S
+            else:
+                N, S, M, D, Lq, Lv, P = a[-8:-1]
+            nby = 4 * (2 * N * S * M * D + 2 * N * Lq * M * Lv * P * 3 + N * Lq * M * D)
+            return timed("msda_bwd_self" if name.endswith("_self") else "msda_bwd", (N, S, Lq), 0.0, nby, orig_call, name, *a)
+        return orig_call(name, *a)
+    _L.call = lib_call
     try:
         # THREE profiled steps, the one with the smallest total kept: issued eagerly from Python the GPU idles between launches, and on
         # some boxes the first such step runs with the clocks still down (one run read every kernel 3.6x slower than the trace of the
@@ -346,6 +366,7 @@ def profile_insitu(step_fn, table_path=None):
         ops.conv2d, ops.conv_wgrad, ops.conv_wgrad_group, ops.conv2d_group = orig_conv, orig_wg, orig_group, orig_cgroup
         ops.bottleneck_fused, ops.sgd_step, ops.ema_update, ops.roialign, ops.roialign_backward = orig_bn, orig_sgd, orig_ema, orig_ra, orig_rab
         ops.sgd_step_dev = orig_sgd_dev
+        _L.call = orig_call
     # What an event pair adds to the kernel it brackets (marker latency): with t1 = a pair around ONE launch of a small conv (T + o)
     # and t2 = a pair around TWO back-to-back launches of it (2 T + g + o), o = 2 t1 - t2 + g, where g is the dependent-kernel
     # boundary of MI355X_MICROARCH.md's price list (1.45 us).  It is subtracted from every measurement so that a launch's figure is
@@ -370,7 +391,7 @@ def profile_insitu(step_fn, table_path=None):
     # rate -- at 2.5 us the line agreed with the kernel trace of the same single-stream step to 1 %, at 4 us it read 5 % above it)
     empty = min(max(2 * t12[0] - t12[1] + 1.45, 0.0), 3.0)
     shapes, out = {}, {}
-    for fam in ("igemm", "wgrad", "bneck", "sgd", "ema", "roialign_fwd", "roialign_bwd"):
+    for fam in ("igemm", "wgrad", "bneck", "sgd", "ema", "roialign_fwd", "roialign_bwd", "msda_fwd", "msda_bwd", "msda_bwd_self"):
         out[fam] = {"launches": 0, "flops": 0.0, "ms": 0.0, "bytes": 0}
     out["event_pair_us"] = round(empty, 2)
     for key, fl, nby, e0, e1 in rec:
@@ -623,6 +644,14 @@ def main():
                            "hbm_kernels_note": "sgd / ema: every state word read and written once; roialign_*: the pooled tensor's bytes only (the gather side is data dependent), so a lower bound of their traffic",
                            "step_algorithmic_tflop": step_tflop if (headline and not args.align) else None,
                            "step_frac_of_mfma_peak": round(step_tflop / (ms * 1e-3) / PEAK_BF16_TFLOPS, 4) if (headline and not args.align) else None}
+        if any(prof[f]["launches"] for f in ("msda_fwd", "msda_bwd", "msda_bwd_self")):
+            out["roofline"]["msda_kernels"] = {fam: {"achieved": round(prof[fam]["bytes"] / prof[fam]["ms"] / 1e6, 1), "unit": "GB/s", "peak": PEAK_HBM_GBS,
+                                                     "frac": round(prof[fam]["bytes"] / prof[fam]["ms"] / 1e6 / PEAK_HBM_GBS, 4), "ms_per_step": round(prof[fam]["ms"], 3),
+                                                     "launches_per_step": prof[fam]["launches"], "algorithmic_bytes_per_step": prof[fam]["bytes"]}
+                                               for fam in ("msda_fwd", "msda_bwd_self", "msda_bwd") if prof[fam]["launches"] and prof[fam]["ms"] > 0}
+            out["roofline"]["msda_kernels_note"] = ("multi-scale deformable attention (aldi_ms_deform_attn_*): compulsory bytes = every operand read once and every result "
+                                                    "written once, against the HBM peak; msda_bwd_self = the encoder's backward (value gradient gathered per tile from binned "
+                                                    "lists: bound by the gather, not by these bytes), msda_bwd = the decoder's (atomic scatter: bound by the L2 float-add rate)")
         if not headline:
             out["roofline"]["dense_ms_per_step"] = round(ig["ms"] + wg["ms"], 3)
             out["roofline"]["note"] = "the families timed are the dense kernels this workload shares with the headline step (ops.conv2d / conv_wgrad); its attention / normalisation kernels are in the kernel-trace summary under profiles/"
