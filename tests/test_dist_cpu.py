@@ -237,3 +237,33 @@ def test_distributed_evaluation_equals_single_process():
     assert res[1] == {}                                           # only the main process reports
     for k in ("AP", "AP50", "AP75"):
         assert abs(res[0][k] - ref[k]) < 1e-9, (k, res[0][k], ref[k])
+
+
+def _worker_detr_norm(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from aldi_amd.detr.criterion import _world_mean
+    dev = torch.device("cpu")
+    q.put((rank, _world_mean(3.0 if rank == 0 else 5.0, dev), _world_mean(0.0, dev), _world_mean(1.0 if rank == 0 else 0.0, dev)))
+    dist.destroy_process_group()
+
+
+def test_detr_target_count_is_the_world_mean_gloo():
+    """the Deformable-DETR set criterion's normaliser under data parallelism: the ranks' target counts summed / world size, at least 1
+    (3 and 5 targets -> 4 on both ranks; none anywhere -> 1; one target on one rank -> 0.5 -> 1)"""
+    from aldi_amd.detr.criterion import _world_mean
+    assert _world_mean(7.0, torch.device("cpu")) == 7.0 and _world_mean(0.0, torch.device("cpu")) == 1.0       # no process group: this rank's count
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_worker_detr_norm, args=(r, 2, port, q)) for r in range(2)]
+    for p in ps:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(2))
+    for p in ps:
+        p.join(timeout=60)
+    assert [r[1:] for r in res] == [(4.0, 1.0, 1.0), (4.0, 1.0, 1.0)], res

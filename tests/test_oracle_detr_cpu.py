@@ -77,3 +77,69 @@ def test_live_transformers_run_on_fresh_inputs():
     targets = [{"labels": t["class_labels"], "boxes": t["boxes"]} for t in labels]
     _, total = D.criterion(lo, bo, targets, weights=(1.0, 5.0, 2.0))
     assert abs(float(total) - float(out.loss)) <= 1e-4 * float(out.loss)
+
+
+def test_dropout_sites_and_order_against_live_transformers():
+    """the oracle's dropout hook (`drop(site, tensor)`: <layer>.dropout1..4 and the decoder self attention's probabilities) sits where
+    transformers' layers call nn.functional.dropout, in the same order: both runs take their keep masks from one call counter and must
+    agree.  (transformers' layers carry `dropout` / `activation_dropout` / the attention's `dropout`; the authors use one rate for all, as
+    configs/Base-DETR.yaml's TRANSFORMER.DROPOUT.  Its encoder's extra dropout on the input embeddings -- not in the authors' code --
+    stays at p = 0.)"""
+    pytest.importorskip("transformers")
+    import importlib.util
+    import torch.nn.functional as F
+    spec = importlib.util.spec_from_file_location("make_detr_golden", os.path.join(ROOT, "tests", "golden", "make_detr_golden.py"))
+    G = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(G)
+    from oracle import deformable_detr as D
+    m, cfg = G.build(seed=11)
+    m.config._attn_implementation = "eager"                       # (the fused attention paths draw their own masks)
+    for layer in list(m.model.encoder.layers) + list(m.model.decoder.layers):
+        layer.training = True
+        layer.dropout, layer.activation_dropout = 0.3, 0.3
+        mlp = getattr(layer, "mlp", None)                         # (newer transformers keep the feed-forward block's two rates on a sub-module)
+        if mlp is not None:
+            mlp.training = True
+            mlp.dropout, mlp.activation_dropout = 0.3, 0.3
+        att = layer.self_attn                                     # the decoder's multi-head attention (the deformable attention has no dropout)
+        for name in ("attention_dropout", "dropout"):
+            if isinstance(getattr(att, name, None), float):
+                att.training = True
+                setattr(att, name, 0.3)
+                if hasattr(att, "config"):
+                    att.config._attn_implementation = "eager"
+
+    def mask_of(i, shape):
+        n = 1
+        for s_ in shape:
+            n *= s_
+        return ((torch.rand(n, generator=torch.Generator().manual_seed(1000 + i)) > 0.3).float() / 0.7).view(shape)
+    calls = []
+    orig = F.dropout
+
+    def fake(x, p=0.5, training=True, inplace=False):
+        if not training or p == 0.0:
+            return x
+        calls.append(tuple(x.shape))
+        return x * mask_of(len(calls) - 1, x.shape)
+    F.dropout = fake
+    try:
+        x, pixel_mask, labels, fmaps, logits, boxes, out = G.run(m, seed=13)
+    finally:
+        F.dropout = orig
+    assert len(calls) == 2 * 3 + 3 * 5, calls
+    p = G.rename({k: v.detach() for k, v in m.state_dict().items()})
+    sites = []
+
+    def drop(name, t):
+        sites.append(name)
+        return t * mask_of(len(sites) - 1, t.shape)
+    lo, bo = D.forward(p, fmaps, pixel_mask == 0, drop=drop, **CFG)
+    assert len(sites) == len(calls)
+    assert sites[:3] == ["transformer.encoder.layers.0.dropout1", "transformer.encoder.layers.0.dropout2", "transformer.encoder.layers.0.dropout3"]
+    assert sites[6:11] == ["transformer.decoder.layers.0.self_attn.attn", "transformer.decoder.layers.0.dropout2", "transformer.decoder.layers.0.dropout1",
+                           "transformer.decoder.layers.0.dropout3", "transformer.decoder.layers.0.dropout4"]
+    assert (lo - logits).abs().max().item() <= 2e-4 * max(1.0, logits.abs().max().item())
+    assert (bo - boxes).abs().max().item() <= 1e-5
+    lo0, _ = D.forward(p, fmaps, pixel_mask == 0, **CFG)
+    assert (lo0 - logits).abs().max().item() > 1e-2              # the masks really changed the result
