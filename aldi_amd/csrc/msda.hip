@@ -48,6 +48,11 @@ __global__ __launch_bounds__(256) void msda_kernel(MsdaDev a) {
     const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
     float4 g = zero, acc = zero;
     if (BWD && live) g = *reinterpret_cast<const float4*>(a.gout + pr * D + d);
+    // backward: the pair's L * P results are kept spread over its lanes (lane j holds samples j and j + LANES) and written as contiguous
+    // runs at the end -- one lane storing three scattered words per sample was a third of this kernel
+    const int lp = a.L * a.P, sub = lane % LANES;
+    const bool spread = BWD && lp <= 2 * LANES;
+    float rw0 = 0.f, rw1 = 0.f, rx0 = 0.f, rx1 = 0.f, ry0 = 0.f, ry1 = 0.f;
     for (int l = 0; l < a.L; ++l) {
         const int H = a.shapes[2 * l], W = a.shapes[2 * l + 1];
         const long base = ((long)n * a.S + a.lstart[l]) * rowstride + (long)m * D + d;
@@ -82,15 +87,29 @@ __global__ __launch_bounds__(256) void msda_kernel(MsdaDev a) {
                 const float t_w = group_sum<LANES>(w00 * d00 + w01 * d01 + w10 * d10 + w11 * d11);
                 const float t_x = group_sum<LANES>(w * (hy * (d01 - d00) + ly * (d11 - d10))) * (float)W;
                 const float t_y = group_sum<LANES>(w * (hx * (d10 - d00) + lx * (d11 - d01))) * (float)H;
-                if (live && d == 0) {
-                    a.gattw[pr * a.L * a.P + l * a.P + p] = t_w;
-                    a.gloc[(pr * a.L * a.P + l * a.P + p) * 2] = t_x;
-                    a.gloc[(pr * a.L * a.P + l * a.P + p) * 2 + 1] = t_y;
+                const int idx = l * a.P + p;
+                if (spread) {
+                    if (idx == sub) { rw0 = t_w; rx0 = t_x; ry0 = t_y; }
+                    if (idx == sub + LANES) { rw1 = t_w; rx1 = t_x; ry1 = t_y; }
+                } else if (live && d == 0) {
+                    a.gattw[pr * lp + idx] = t_w;
+                    a.gloc[(pr * lp + idx) * 2] = t_x;
+                    a.gloc[(pr * lp + idx) * 2 + 1] = t_y;
                 }
             }
         }
     }
     if (!BWD && live) *reinterpret_cast<float4*>(a.out + pr * D + d) = acc;
+    if (spread && live) {
+        if (sub < lp) {
+            a.gattw[pr * lp + sub] = rw0;
+            *reinterpret_cast<float2*>(a.gloc + (pr * lp + sub) * 2) = make_float2(rx0, ry0);
+        }
+        if (sub + LANES < lp) {
+            a.gattw[pr * lp + sub + LANES] = rw1;
+            *reinterpret_cast<float2*>(a.gloc + (pr * lp + sub + LANES) * 2) = make_float2(rx1, ry1);
+        }
+    }
 }
 
 // value gradient: one lane per channel (a pair = D consecutive lanes), so every atomic instruction of a pair covers one
@@ -410,15 +429,34 @@ __global__ __launch_bounds__(256) void msda_bin_accumulate_kernel(MsdaDev a, Bin
         if (base) __syncthreads();
         for (int i = tid; i < nc; i += 256) smp[i] = list[base + i];
         __syncthreads();
-        for (int i = part; i < nc; i += PARTS) {
-            const float4 sp = smp[i];
-            const float wx = 1.f - fabsf(sp.x - Xf), wy = 1.f - fabsf(sp.y - Yf);
-            if (wx > 0.f && wy > 0.f) {
-                const float v = sp.z * wy * wx;
-                const float4* g = reinterpret_cast<const float4*>(a.gout + (long)__float_as_int(sp.w) * 32 + cq * 8);
-                const float4 g0 = g[0], g1 = g[1];
-                acc[0] += v * g0.x; acc[1] += v * g0.y; acc[2] += v * g0.z; acc[3] += v * g0.w;
-                acc[4] += v * g1.x; acc[5] += v * g1.y; acc[6] += v * g1.z; acc[7] += v * g1.w;
+        // a thread's entries in windows of 32: first the window's hits as a bit mask (LDS reads and compares only), then the hits two at
+        // a time -- four independent 16-byte loads of the output gradient in flight instead of one dependent pair per hit
+        for (int w0 = part; w0 < nc; w0 += 32 * PARTS) {
+            unsigned hits = 0;
+#pragma unroll 8
+            for (int k = 0; k < 32; ++k) {
+                const int i = w0 + k * PARTS;
+                if (i < nc) {
+                    const float4 sp = smp[i];
+                    if (1.f - fabsf(sp.x - Xf) > 0.f && 1.f - fabsf(sp.y - Yf) > 0.f) hits |= 1u << k;
+                }
+            }
+            while (hits) {
+                const int k0 = __ffs(hits) - 1;
+                hits &= hits - 1;
+                const int k1 = hits ? __ffs(hits) - 1 : k0;
+                const bool two = hits != 0;
+                hits &= hits - 1 + (two ? 0u : 1u);            // (clear the second bit only when there is one)
+                const float4 s0 = smp[w0 + k0 * PARTS], s1 = smp[w0 + k1 * PARTS];
+                const float4* g0p = reinterpret_cast<const float4*>(a.gout + (long)__float_as_int(s0.w) * 32 + cq * 8);
+                const float4* g1p = reinterpret_cast<const float4*>(a.gout + (long)__float_as_int(s1.w) * 32 + cq * 8);
+                const float4 a0 = g0p[0], a1 = g0p[1], b0 = g1p[0], b1 = g1p[1];
+                const float v0 = s0.z * (1.f - fabsf(s0.y - Yf)) * (1.f - fabsf(s0.x - Xf));
+                const float v1 = two ? s1.z * (1.f - fabsf(s1.y - Yf)) * (1.f - fabsf(s1.x - Xf)) : 0.f;
+                acc[0] += v0 * a0.x; acc[1] += v0 * a0.y; acc[2] += v0 * a0.z; acc[3] += v0 * a0.w;
+                acc[4] += v0 * a1.x; acc[5] += v0 * a1.y; acc[6] += v0 * a1.z; acc[7] += v0 * a1.w;
+                acc[0] += v1 * b0.x; acc[1] += v1 * b0.y; acc[2] += v1 * b0.z; acc[3] += v1 * b0.w;
+                acc[4] += v1 * b1.x; acc[5] += v1 * b1.y; acc[6] += v1 * b1.z; acc[7] += v1 * b1.w;
             }
         }
     }
