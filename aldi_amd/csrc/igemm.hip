@@ -902,6 +902,11 @@ int dispatch(ConvDev& d, hipStream_t st) {
         const bool lin256 = tn.igemm_tile != 9 && big >= tn.igemm_lintile_min && d.K >= tn.igemm_bigtile_k;     // (the token-GEMM rule below wins)
         if (plain && (force == 8 || (force == 0 && !lin256 && d.Cout > 64 && d.K % 64 == 0 && d.K >= tn.igemm_k64_min))) return launch<T, 64, 64, 2, 2, 8, false>(d, st);
     }
+    // fp32 (the parity mode; the Deformable-DETR step's arithmetic): the f32-input MFMA runs at 1/16 of the bf16 rate, so a tile's K loop is
+    // long and what pays is workgroups, not bytes per flop -- 64 x 64 tiles are as fast or faster than every larger tile on all of that
+    // step's shapes (tools/f32_tile_sweep.py: 33 600 px x 128 -> 128 3x3 161 -> 110 us, 16 800 x 512 -> 128 77 -> 52, 44 646 x 256 -> 384
+    // 100 -> 85, 44 646 x 1024 -> 256 205 -> 201); same K order per output element as the other tap-form tiles (bit-identical results)
+    if (sizeof(T) == 4 && force == 0 && big < tn.igemm_f32_tile64_max) return launch<T, 64, 64, 2, 2, 4>(d, st);
     if (d.Cout <= 64) return launch<T, 128, 64, 4, 1, 4>(d, st);
     if (tn.igemm_tile != 9 && big >= tn.igemm_lintile_min && d.K >= tn.igemm_bigtile_k) return launch<T, 256, 128, 4, 2, 4, false>(d, st);
     if (big < 200) return launch<T, 64, 64, 2, 2, 4>(d, st);

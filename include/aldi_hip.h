@@ -67,6 +67,7 @@ int aldi_noop(aldi_stream_t stream);
  *   wgrad_f32_tile128    1 = fp32 weight gradients with Cout, K >= 128 on the 128x128 f32-MFMA tile (0: the 64x64 kernel)
  *   igemm_halo_f32       > 0: fp32 3x3/stride-1/pad-1 convs with at least this many 128x64 tiles take the halo form too (0 = off, the
  *                        default: it sums K in another order than the tap form)
+ *   igemm_f32_tile64_max fp32 layers with fewer 128x128-tile equivalents than this run on 64x64 tiles (4096; 0 = the bf16 rules)
  *   msda_bin             1 = aldi_ms_deform_attn_backward_self with a workspace bins the samples into per-tile lists (0: the walk form)
  *   msda_bin_list        expected list entries per tile the binned form sizes its tiles for (512)
  *   msda_gather          walk form (no workspace): bit mask of the target levels that are gathered (7); 0 = the general scatter

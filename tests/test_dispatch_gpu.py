@@ -160,12 +160,18 @@ def test_forward_default_dispatch_fullsize(case, expect):
 
 def test_forward_default_dispatch_fullsize_fp32():
     """parity mode at benchmark scale (the fp32 arms: direct epilogue, 16x16x4 MFMA)"""
-    _check_forward((2, 200, 336, 256, 256, 3, 1, 1), torch.float32, "igemm<f32,256,128,4,2,flat,tap>")
-    _check_forward((2, 200, 336, 64, 256, 1, 1, 0), torch.float32, "igemm<f32,128,128,2,2,pipe,tap>")
-    _check_forward((2, 200, 336, 64, 64, 3, 1, 1), torch.float32, "igemm<f32,128,64,4,1,pipe,tap>")
-    _check_forward((2, 25, 42, 512, 512, 3, 1, 1), torch.float32, "igemm<f32,64,64,2,2,pipe,tap>")
-    # the fp32 halo arms (igemm_halo_f32 = least number of half-width tiles; off by default: another summation order than the tap form)
+    # fp32 runs on 64 x 64 tiles by default (igemm_f32_tile64_max: the f32-input MFMA is slow enough that workgroups pay, not bytes per flop)
+    for case in ((2, 200, 336, 256, 256, 3, 1, 1), (2, 200, 336, 64, 256, 1, 1, 0), (2, 200, 336, 64, 64, 3, 1, 1), (2, 25, 42, 512, 512, 3, 1, 1)):
+        _check_forward(case, torch.float32, "igemm<f32,64,64,2,2,pipe,tap>")
     from aldi_amd import _lib as L
+    L.set_tuning("igemm_f32_tile64_max", 0)                # ... the bf16 tile rules
+    try:
+        _check_forward((2, 200, 336, 256, 256, 3, 1, 1), torch.float32, "igemm<f32,256,128,4,2,flat,tap>")
+        _check_forward((2, 200, 336, 64, 256, 1, 1, 0), torch.float32, "igemm<f32,128,128,2,2,pipe,tap>")
+        _check_forward((2, 200, 336, 64, 64, 3, 1, 1), torch.float32, "igemm<f32,128,64,4,1,pipe,tap>")
+    finally:
+        L.reset_tuning()
+    # the fp32 halo arms (igemm_halo_f32 = least number of half-width tiles; off by default: another summation order than the tap form)
     L.set_tuning("igemm_halo_f32", 400)
     try:
         _check_forward((2, 200, 336, 256, 256, 3, 1, 1), torch.float32, "igemm<f32,256,128,4,2,flat,halo>")
