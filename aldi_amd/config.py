@@ -221,11 +221,14 @@ def add_aldi_config(cfg: CfgNode):
     _C.SOLVER.IMS_PER_GPU = 2
     _C.SOLVER.BACKWARD_AT_END = True
     _C.SOLVER.OPTIMIZER = "SGD"
-    # aldi_amd extension (not in the reference): run the step's student passes as one fused launch sequence
-    # (numerically the sequential schedule; see aldi_amd.trainer.fused_run_model)
-    _C.SOLVER.FUSED_STEP = False
-    _C.SOLVER.STEP_GRAPH = False          # replay the fused step's two device phases as hipGraphs (aldi_amd/fused_step.py)
-    _C.SOLVER.GRAD_PAYLOAD = "fp32"       # data-parallel gradient exchange: "fp32" (exact) or "bf16" (half the bytes per xGMI link)
+    # aldi_amd extensions (not in the reference).  Both are ON by default, so `ALDITrainer(cfg)` built from the reference's own
+    # YAML runs the step the benchmark measures; whenever a batch does not fit the fused driver (`_ALDITrainer._can_fuse`: other
+    # batch contents, another distiller, a detector without the R-CNN engine) the reference's sequential schedule runs instead.
+    # Turn them off with these keys or ALDI_FUSED_STEP=0 / ALDI_STEP_GRAPH=0.
+    _C.SOLVER.FUSED_STEP = True           # the step's student passes as one fused launch sequence (numerically the sequential schedule)
+    _C.SOLVER.STEP_GRAPH = True           # replay the fused step's two device phases as hipGraphs (aldi_amd/fused_step.py)
+    _C.SOLVER.GRAD_PAYLOAD = "fp32"       # data-parallel gradient exchange: "fp32" (exact) or "bf16" (half the bytes per xGMI link; sums in bf16)
+    _C.SOLVER.GRAD_EXCHANGE = "all_reduce"  # per bucket: "all_reduce" or "rs_ag" (reduce_scatter_tensor + all_gather_into_tensor, aldi_amd/reduce.py)
 
     # Deformable-DETR (the reference's absent submodule adds these through its own add_deformable_detr_config; configs/Base-DETR.yaml)
     _C.MODEL.DEFORMABLE_DETR = CN()

@@ -84,4 +84,5 @@ class SetCriterion:
             for j, k in enumerate(("loss_ce", "loss_bbox", "loss_giou")):
                 out[k + suffix] = weighted[l, j]
         self.last_match = match
+        self.last_num_boxes = float(num_boxes)                           # the normaliser this call USED (the world mean under data parallelism)
         return out, g_logits, g_boxes

@@ -106,11 +106,23 @@ class DetrWeights:
         return sd
 
     def load_state_dict(self, sd, strict: bool = True):
+        """strict: every key of this detector must be present (KeyError lists the missing ones).  strict=False loads the intersection --
+        e.g. a backbone-only R50 pretrain, the usual Deformable-DETR initialisation -- and returns (missing, unexpected) like torch does"""
         full = self.backbone.state_dict()
+        mine = [k for k in full if k.startswith("backbone.bottom_up.")] + list(self.tr.spec)
+        missing = [k for k in mine if k not in sd]
+        unexpected = [k for k in sd if k not in full and k not in self.tr.spec]
+        if strict and missing:
+            raise KeyError(f"missing keys in state_dict: {missing[:5]}{'...' if len(missing) > 5 else ''}")
         full.update({k: v for k, v in sd.items() if k in full})
         self.backbone.load_state_dict(full)
-        self.tr.load({k: sd[k] for k in self.tr.spec})
+        cur = self.tr.state_dict() if missing else {}
+        self.tr.load({k: sd[k] if k in sd else cur[k] for k in self.tr.spec})
         self.refresh()
+        if missing:
+            import logging
+            logging.getLogger(__name__).warning("DetrWeights.load_state_dict: %d keys kept at their current values (e.g. %s)", len(missing), missing[0])
+        return missing, unexpected
 
     def refresh(self, cast: bool = True):
         self.backbone.refresh()
@@ -173,6 +185,10 @@ class _DetrEngine:
 
     def backward(self, c: Ctx, scales: Dict[str, float]):
         m = self.m
+        if m._last is None or m._last.ctx is not c:
+            # the detector keeps ONE tape (transformer.tape, the trunk's saved activations): only the most recent forward can be differentiated
+            raise RuntimeError("DeformableDETR: backward of an earlier forward (SOLVER.BACKWARD_AT_END True with several micro-steps); "
+                               "set SOLVER.BACKWARD_AT_END False as configs/Base-DETR.yaml does")
         per = {}
         for k, v in scales.items():                               # one upstream factor per loss TYPE (the layers' copies share it)
             base = "_".join(k.split("_")[:2])
@@ -187,7 +203,7 @@ class _DetrEngine:
             saved = crit.coef
             crit.coef = tuple(a * b for a, b in zip(saved, s))
             try:
-                _, gl, gb = crit(c.logits, c.boxes, c.targets, num_boxes=c.num_boxes, match=crit.last_match)
+                _, gl, gb = crit(c.logits, c.boxes, c.targets, num_boxes=c.num_boxes, match=c.match)
             finally:
                 crit.coef = saved
         gfeats = m.transformer.backward(gl, gb)
@@ -335,7 +351,10 @@ class DeformableDETR:
             gl, gb = full_l, full_b
         c = Ctx()
         c.trunk, c.logits, c.boxes, c.targets, c.g_logits, c.g_boxes = ctr, logits, boxes, targets, gl, gb
-        c.num_boxes = max(float(sum(len(t["labels"]) for t in targets)), 1.0)
+        # the normaliser and the assignment the forward's losses were computed with: a re-run of the loss kernel in the backward (gradient
+        # accumulation / masked losses: a scale != 1) must divide by the SAME count -- the world mean under data parallelism, not this
+        # rank's -- and needs no second collective
+        c.num_boxes, c.match = self.criterion.last_num_boxes, self.criterion.last_match
         h = _Holder(self, c)
         h.root = _Root.apply(self._anchor, h)
         self._last = h

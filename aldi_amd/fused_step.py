@@ -118,7 +118,7 @@ class FusedStep:
         self.static: Dict[tuple, SimpleNamespace] = {}
         self.steps_done = 0
         self.pool = None
-        self.graph_enabled = bool(trainer.model.cfg.SOLVER.get("STEP_GRAPH", False)) and os.environ.get("ALDI_STEP_GRAPH", "1") == "1"
+        self.graph_enabled = bool(trainer.model.cfg.SOLVER.get("STEP_GRAPH", True)) and os.environ.get("ALDI_STEP_GRAPH", "1") == "1"
         # student + teacher trunk / RPN head as ONE launch per layer.  Off by default: measured 11.98 vs 11.20 ms/step -- what the
         # shared launches save (~0.5 ms of fixed per-launch cost) is less than what the lost concurrency costs (the teacher's
         # latency-bound proposal / box-head / detection chain then runs alone after the paired trunk, and the EMA tick before it)
@@ -269,6 +269,14 @@ class FusedStep:
         # distillation chunk's rows written by the teacher's detection kernel above)
         gt = S.gt_all
         c.gt = gt
+        hook = getattr(self, "discrete_inputs_hook", None)
+        if hook is not None:
+            # parity tooling (tests/test_configs_gpu.py): called with everything the DISCRETE stages below read -- the student's proposals
+            # and the ground truth incl. the teacher's pseudo-label rows -- so that a run in another arithmetic mode can be given the same
+            # ones (matching / sampling are discontinuous in them); eager steps only, nothing on the product path sets it
+            if side is not None:
+                main.wait_stream(side)
+            hook(S, c, tc)
         _, matched, lists, counts = eng.rpn_match(geom, anchors, gt, N)
         c.rpn_matched, c.rpn_lists, c.rpn_counts = matched, lists, counts
         if side is not None:

@@ -44,13 +44,22 @@ class BucketedReducer:
 
     _LAUNCH_STREAMS = {}
 
-    def __init__(self, grad: torch.Tensor, group=None, payload: str = "fp32"):
+    def __init__(self, grad: torch.Tensor, group=None, payload: str = "fp32", exchange: str = "all_reduce"):
         """payload "bf16": a piece travels as bf16 (half the bytes per xGMI link: the ring all-reduce over 8 GPUs is per-link
-        bound, SURVEY 5.8) -- rounded once before the exchange, summed by the collective, written back into the fp32 buffer;
-        the reference's DDP exchanges what autocast produced, i.e. fp32 master gradients: "fp32" (default) is the exact form."""
+        bound) and is written back into the fp32 buffer afterwards.  The collective then ADDS in bf16: every
+        partial sum of the ring (world - 1 of them per element) is rounded to 8 mantissa bits, so the error of an element is up to
+        ~(world - 1) * 2^-9 of the partial sums' magnitude, not the single rounding of the payload -- an approximation to opt into;
+        the reference's DDP exchanges fp32 master gradients: "fp32" (default) is the exact form.
+        exchange "rs_ag": every piece as reduce_scatter_tensor + all_gather_into_tensor on the flat buffer (in place: rank r owns
+        the r-th slice of the piece) instead of one all_reduce -- the two halves of the exchange as separate collectives, the form
+        SURVEY 5.8 / 8(e) prefers on the fully connected xGMI mesh (each rank talks to its 7 peers at once: 2 * 7/8 of the piece
+        over 7 links, against a ring that moves the same bytes over one link at a time); a tail shorter than the world size goes
+        through all_reduce.  Same sums (the same pairs are added; the order inside the collective is the library's)."""
         if payload not in ("fp32", "bf16"):
             raise ValueError("gradient payload must be fp32 or bf16")
-        self.grad, self.group, self.payload = grad, group, payload
+        if exchange not in ("all_reduce", "rs_ag"):
+            raise ValueError("gradient exchange must be all_reduce or rs_ag")
+        self.grad, self.group, self.payload, self.exchange = grad, group, payload, exchange
         self.done: List[Tuple[int, int]] = []
         self.pending: List[Tuple[int, int]] = []
         self.works = []
@@ -85,7 +94,21 @@ class BucketedReducer:
         # from (here the launch stream) -- and it is the form a hipGraph can record: an async work handle's wait() inside a capture
         # segfaults in capture_end on this stack (torch 2.10 + RCCL 2.26.6; tools/probes/rccl_capture_probe.py).  gloo's plain call
         # would block the host until the exchange is done, so it keeps the work handle.
-        if self._stream_ordered():
+        ordered = self._stream_ordered()
+        if self.exchange == "rs_ag":
+            world, rank = dist.get_world_size(self.group), dist.get_rank(self.group)
+            m = piece.numel() // world * world
+            w = None
+            if m:
+                body = piece[:m]
+                shard = body[rank * (m // world): (rank + 1) * (m // world)]
+                dist.reduce_scatter_tensor(shard, body, op=dist.ReduceOp.SUM, group=self.group)
+                # (RCCL takes the in-place form -- the input is the rank's own slice of the output; gloo gets a copy)
+                w = dist.all_gather_into_tensor(body, shard if ordered else shard.clone(), group=self.group, async_op=not ordered)
+            if m < piece.numel():
+                dist.all_reduce(piece[m:], op=dist.ReduceOp.SUM, group=self.group)
+            return None if ordered else w
+        if ordered:
             dist.all_reduce(piece, op=dist.ReduceOp.SUM, group=self.group)
             return None
         return dist.all_reduce(piece, op=dist.ReduceOp.SUM, group=self.group, async_op=True)

@@ -410,31 +410,34 @@ class SimpleTrainer:
         return self._data_loader_iter_obj
 
     def run_step(self):
-        assert self.model.training, "[SimpleTrainer] model was changed to eval mode!"
-        start = time.perf_counter()
-        data = next(self._data_loader_iter)
-        data_time = time.perf_counter() - start
-        if self.zero_grad_before_forward:
-            if self._defers_zero_grad():
-                self._zero_pending = True            # run_model clears the gradients itself (fused step: beside its forward)
-            else:
-                self.optimizer.zero_grad()
-        if self._defers_sgd():
-            self._sgd_pending = True                 # run_model may apply this iteration's optimizer step itself (fused step: inside its backward)
-        loss_dict = self.run_model(data)
-        self.__dict__.pop("_sgd_pending", None)
-        if isinstance(loss_dict, torch.Tensor):
-            losses = loss_dict
-            loss_dict = {"total_loss": loss_dict}
-        elif getattr(self, "_fused_done", False):
-            losses = None                            # the fused driver ran its backward inside run_model: no total to differentiate
-        else:                                        # (summing the entries here would put a dozen tiny launches in front of the optimizer)
-            losses = sum(loss_dict.values())
-        if not self.zero_grad_before_forward and not getattr(self, "_fused_done", False):
+        """One optimizer step = fetch a batch, run the model (which may already contain its backward), reduce gradients across ranks,
+        apply the update.  Same order of effects as the reference's step (aldi/dropin.py:94-121), organised around what THIS engine
+        can take over: `run_model` may clear the gradients itself, run the backward itself (`_fused_done`) and even the update."""
+        if not self.model.training:
+            raise AssertionError("[SimpleTrainer] model was changed to eval mode!")
+        t0 = time.perf_counter()
+        batch = next(self._data_loader_iter)
+        fetch_s = time.perf_counter() - t0
+        clear_first = self.zero_grad_before_forward
+        if clear_first and self._defers_zero_grad():
+            self._zero_pending = True                # the fused step clears them on a side stream beside its forward
+        elif clear_first:
             self.optimizer.zero_grad()
-        self.do_backward(losses)
+        if self._defers_sgd():
+            self._sgd_pending = True                 # the fused step may apply this iteration's update inside its backward
+        result = self.run_model(batch)
+        self.__dict__.pop("_sgd_pending", None)
+        fused = bool(getattr(self, "_fused_done", False))
+        if isinstance(result, torch.Tensor):
+            loss_dict, total = {"total_loss": result}, result
+        else:
+            # (a fused step has nothing left to differentiate; summing its entries would only put a dozen tiny launches before the update)
+            loss_dict, total = result, (None if fused else sum(result.values()))
+        if not clear_first and not fused:
+            self.optimizer.zero_grad()
+        self.do_backward(total)
         self.after_backward()
-        self._write_metrics(loss_dict, data_time)
+        self._write_metrics(loss_dict, fetch_s)
         self.optimizer.step()
 
     def run_model(self, data):
@@ -492,6 +495,9 @@ class _ALDITrainer:
         the whole iteration fits one student pass (16 images: the staging kernels' limit)"""
         lw, ls, uw, us = data
         bs = self.model_batch_size
+        from .engine import RCNN
+        if not isinstance(getattr(self.model, "engine", None), RCNN):        # (e.g. the Deformable-DETR detector: sequential driver)
+            return False
         if not self.fused or lw is not None or ls is None or len(ls) == 0 or len(ls) % bs or hasattr(self.model, "module"):
             return False
         do_align, do_distill = _schedule_flags(self)
@@ -545,11 +551,15 @@ class _ALDITrainer:
             reducer = None
             if _data_parallel():
                 from .reduce import BucketedReducer
-                reducer = self._reducer = BucketedReducer(self.model.weights.grad, payload=str(self.model.cfg.SOLVER.get("GRAD_PAYLOAD", "fp32")))
+                reducer = self._reducer = BucketedReducer(self.model.weights.grad, payload=str(self.model.cfg.SOLVER.get("GRAD_PAYLOAD", "fp32")),
+                                                          exchange=str(self.model.cfg.SOLVER.get("GRAD_EXCHANGE", "all_reduce")))
                 eng.grad_ready = reducer.ready
+            ok = False
             try:
                 if os.environ.get("ALDI_FUSED_LEGACY", "0") == "1":
-                    return fused_run_model(self, *data)
+                    out = fused_run_model(self, *data)
+                    ok = True
+                    return out
                 if getattr(self, "_fused_step", None) is None:
                     from .fused_step import FusedStep
                     self._fused_step = FusedStep(self)
@@ -557,9 +567,13 @@ class _ALDITrainer:
                 if self.__dict__.pop("_sgd_pending", False) and reducer is None:
                     g_ = self.optimizer.param_groups[0]
                     sgd = (g_["lr"], g_["momentum"], g_["weight_decay"])
-                return self._fused_step.run(*data, ema=pending_ema, zero_grad=defer, reducer=reducer, sgd=sgd)
+                out = self._fused_step.run(*data, ema=pending_ema, zero_grad=defer, reducer=reducer, sgd=sgd)
+                ok = True
+                return out
             finally:
                 eng.grad_ready = None
+                if not ok:
+                    self._reducer = None         # a failed step must not leave its half-used reducer to the next `after_backward`
         return run_model_labeled_unlabeled(self, *data)
 
     def do_backward(self, losses, override=False):
@@ -688,7 +702,7 @@ class ALDITrainer(DefaultTrainer):
         trainer = (ALDIAMPTrainer if cfg.SOLVER.AMP.ENABLED else ALDISimpleTrainer)(model, data_loader, optimizer, distiller,
                                                                                     backward_at_end=cfg.SOLVER.BACKWARD_AT_END,
                                                                                     model_batch_size=cfg.SOLVER.IMS_PER_GPU)
-        trainer.fused = bool(cfg.SOLVER.get("FUSED_STEP", False))
+        trainer.fused = bool(cfg.SOLVER.get("FUSED_STEP", True)) and os.environ.get("ALDI_FUSED_STEP", "1") == "1"
         return trainer
 
     def _create_checkpointer(self, model, cfg):
@@ -722,18 +736,20 @@ class ALDITrainer(DefaultTrainer):
     def build_train_loader(cls, cfg):
         """Same batch-size arithmetic as the reference (aldi/trainer.py:211-240); the loaders are synthetic
         (datasets / decode / augmentation are outside the hot path: SURVEY.md section 8a row a20)."""
-        batch_contents = cfg.DATASETS.BATCH_CONTENTS
-        batch_ratios = cfg.DATASETS.BATCH_RATIOS
-        total_batch_size = cfg.SOLVER.IMS_PER_BATCH
-        batch_sizes = [int(total_batch_size * r / sum(batch_ratios)) for r in batch_ratios]
-        assert len(batch_contents) == len(batch_sizes), "len(cfg.DATASETS.BATCH_CONTENTS) must equal len(cfg.DATASETS.BATCH_RATIOS)."
-        assert sum(batch_sizes) == total_batch_size, f"sum(batch_sizes)={sum(batch_sizes)} must equal total_batch_size={total_batch_size}"
+        contents, ratios = tuple(cfg.DATASETS.BATCH_CONTENTS), tuple(cfg.DATASETS.BATCH_RATIOS)
+        if len(contents) != len(ratios):
+            raise AssertionError("len(cfg.DATASETS.BATCH_CONTENTS) must equal len(cfg.DATASETS.BATCH_RATIOS).")
+        total = cfg.SOLVER.IMS_PER_BATCH
+        # every batch part gets its (truncated) share of the global batch; the shares must add up again (SURVEY B.12)
+        share = {part: int(total * r / sum(ratios)) for part, r in zip(contents, ratios)}
+        if sum(share.values()) != total:
+            raise AssertionError(f"sum(batch_sizes)={sum(share.values())} must equal total_batch_size={total}")
+        # weak and strong views of one domain are cut from the same images: a domain's loader serves the larger of its parts
+        labeled_bs = max((n for part, n in share.items() if part.startswith("labeled")), default=0)
+        unlabeled_bs = max((n for part, n in share.items() if part.startswith("unlabeled")), default=0)
+        batch_contents = contents
         world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
         rank = dist.get_rank() if world > 1 else 0
-        labeled_bs = [batch_sizes[i] for i in range(len(batch_contents)) if batch_contents[i].startswith("labeled")]
-        labeled_bs = max(labeled_bs) if len(labeled_bs) else 0
-        unlabeled_bs = [batch_sizes[i] for i in range(len(batch_contents)) if batch_contents[i].startswith("unlabeled")]
-        unlabeled_bs = max(unlabeled_bs) if len(unlabeled_bs) else 0
         syn = cfg.get("SYNTHETIC", {})
         h, w = syn.get("HEIGHT", 800), syn.get("WIDTH", 1333)
         K = _num_classes(cfg)

@@ -497,8 +497,12 @@ def main():
     cfg = make_cfg(world, args.height, args.width, args.align, args.workload)
     if args.fp32:
         cfg.SOLVER.AMP.ENABLED = False
-    cfg.SOLVER.FUSED_STEP = not args.sequential
-    cfg.SOLVER.STEP_GRAPH = not args.no_graph
+    # no extension key is set for the measured path: the fused step and its hipGraphs are the trainer's defaults (SOLVER.FUSED_STEP /
+    # STEP_GRAPH); the two flags only turn them OFF for A/B runs
+    if args.sequential:
+        cfg.SOLVER.FUSED_STEP = False
+    if args.no_graph:
+        cfg.SOLVER.STEP_GRAPH = False
     random.seed(1234)
     torch.manual_seed(100 + rank)
     tr = ALDITrainer(cfg)

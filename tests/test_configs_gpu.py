@@ -148,6 +148,7 @@ def _bench_trainer(bf16, fused=True):
     cfg.merge_from_list(["SOLVER.IMS_PER_BATCH", 4, "SEED", 1, "SYNTHETIC.HEIGHT", 800, "SYNTHETIC.WIDTH", 1333, "SOLVER.BASE_LR", 1e-4,
                          "SOLVER.AMP.ENABLED", bf16])
     cfg.SOLVER.FUSED_STEP = fused
+    cfg.SOLVER.STEP_GRAPH = False
     random.seed(1234)
     torch.manual_seed(100)
     return ALDITrainer(cfg)
@@ -155,13 +156,25 @@ def _bench_trainer(bf16, fused=True):
 
 def test_benchmark_step_bf16_vs_fp32_parity_mode():
     """The benchmark step itself (configs[1]: 1333x800, 2 labeled + 2 unlabeled, fused schedule, default dispatch = the
-    256x128 halo igemm, the long-K tiles and the 256x256 wgrad) in bf16 against the SAME step in the fp32 parity mode,
-    whose kernels are the ones held to 1e-3 against the oracle.  Identical weights, inputs and RNG stream:
-      * the source chunk's sampled anchor labels are identical (they depend on GT and RNG only);
-      * every loss agrees within the bf16 bound; the ROI counts agree;
-      * the weight gradients agree in direction (cosine) layer group by layer group."""
+    256x128 halo igemm, the long-K tiles, the direct 1x1 epilogue and the 256x256 wgrad) in bf16 -- the dtype bench.py's number is
+    measured in -- against the SAME step in the fp32 parity mode, whose kernels are the ones held to north_star's 1e-3 on losses against
+    the oracle (tests/test_engine_gpu.py, fp32).  Identical weights, inputs and RNG stream, and the bf16 run is GIVEN the fp32 run's
+    inputs of the discrete stages (the student's proposals, the teacher's pseudo labels: `FusedStep.discrete_inputs_hook`), because
+    matching / sampling are discontinuous in them: with those equal every sampled anchor and ROI index is identical and what remains
+    is rounding, so the bounds are rounding-level:
+      * sampled anchor labels and ROI indices of all four images bit-identical;
+      * every loss within 2 % (bf16 activations through ~60 layers);
+      * the weight gradients of every layer group: cosine >= 0.99 and relative L2 error <= 3e-2."""
     from aldi_amd import synthetic as syn
-    out = {}
+    out, rec = {}, {}
+
+    def record(S, c, tc):
+        rec.update(props=c.props.clone(), scores=c.prop_scores.clone(), count=c.prop_count.clone(), gt={k: v.clone() for k, v in c.gt.items()})
+
+    def inject(S, c, tc):
+        c.props.copy_(rec["props"]); c.prop_scores.copy_(rec["scores"]); c.prop_count.copy_(rec["count"])
+        for k, v in c.gt.items():
+            v.copy_(rec["gt"][k])
     for name, bf16 in (("fp32", False), ("bf16", True)):
         tr = _bench_trainer(bf16)
         data = syn.make_batch(2, 2, 800, 1333, 8, seed=100)
@@ -171,37 +184,44 @@ def test_benchmark_step_bf16_vs_fp32_parity_mode():
         tr.before_step()
         t = tr._trainer
         t.optimizer.zero_grad()
+        from aldi_amd.fused_step import FusedStep
+        t._fused_step = FusedStep(t)
+        t._fused_step.discrete_inputs_hook = inject if bf16 else record
         ld = t.run_model(tuple(None if p is None else [dict(d) for d in p] for p in data))
         torch.cuda.synchronize()
+        assert t._fused_done
         c = tr.model._last_fused
-        out[name] = dict(losses={k: float(v) for k, v in ld.items()}, labels=c.rpn_labels[:2].cpu(), R=c.R, rows=list(c.rows),
+        out[name] = dict(losses={k: float(v) for k, v in ld.items()}, labels=c.rpn_labels.cpu(), R=c.R, rows=list(c.rows), r_idx=c.r_idx[: c.R].cpu(),
                          grad=tr.model.weights.grad.clone(), layout=tr.model.layout,
                          pl=tr.ema.model._last_inference.pseudo["count"].tolist(), err=int(tr.model.engine.err) | int(tr.ema.model.engine.err))
         del tr
         torch.cuda.empty_cache()
     a, b = out["fp32"], out["bf16"]
     assert a["err"] == 0 and b["err"] == 0
-    assert torch.equal(a["labels"], b["labels"])                          # source chunk: bit-identical anchor sampling
-    assert a["R"] == b["R"] == 2048 and a["rows"] == b["rows"]
+    assert torch.equal(a["labels"], b["labels"])                          # all four images: bit-identical anchor sampling
+    assert a["R"] == b["R"] == 2048 and a["rows"] == b["rows"] and torch.equal(a["r_idx"], b["r_idx"])
     assert list(a["losses"]) == list(b["losses"])
     for k in a["losses"]:
         x, y = a["losses"][k], b["losses"][k]
-        assert abs(x - y) <= 0.08 * max(1.0, abs(x)), (k, x, y)           # the bf16 bound of tests/test_engine_gpu.py
-    assert all(abs(p - q) <= 2 for p, q in zip(a["pl"], b["pl"])), (a["pl"], b["pl"])
+        print("loss bf16 vs fp32:", k, x, y)
+        assert abs(x - y) <= 0.02 * max(abs(x), 0.05), (k, x, y)
+    assert all(abs(p - q) <= 2 for p, q in zip(a["pl"], b["pl"])), (a["pl"], b["pl"])     # (the teacher's OWN bf16 pseudo-label counts)
     lay = a["layout"]
     groups = {"box head": ["roi_heads.box_head.fc1", "roi_heads.box_head.fc2", "box_pred"],
               "rpn + fpn": ["proposal_generator.rpn_head.conv", "rpn_head_out"] + [f"backbone.fpn_output{l}" for l in (2, 3, 4, 5)] +
                            [f"backbone.fpn_lateral{l}" for l in (2, 3, 4, 5)]}
     for st in (3, 4, 5):
         groups[f"res{st}"] = [n for n in lay.t if f".res{st}." in n]
+    worst = []
     for gname, names in groups.items():
         ga = torch.cat([a["grad"][lo:hi] for lo, hi in lay.ranges(names)])
         gb = torch.cat([b["grad"][lo:hi] for lo, hi in lay.ranges(names)])
         assert torch.isfinite(gb).all()
         cos = float((ga * gb).sum() / (ga.norm() * gb.norm() + 1e-30))
-        # the ROI samples differ (proposals are discontinuous in the scores), so this is a statistical agreement, not a rounding bound
-        print("grad cosine bf16 vs fp32:", gname, round(cos, 4))
-        assert cos > 0.5, (gname, cos)
+        rel = float((ga - gb).norm() / (ga.norm() + 1e-30))
+        print("grad bf16 vs fp32:", gname, "cosine", round(cos, 5), "rel-L2", round(rel, 5))
+        worst.append((gname, cos, rel))
+    assert all(cos >= 0.99 and rel <= 3e-2 for _, cos, rel in worst), worst
 
 
 def test_cfg2_fullsize_alignment_bf16_properties():

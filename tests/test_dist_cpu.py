@@ -79,7 +79,21 @@ def _worker_bucketed(rank, world, port, q):
     red2.ready([(2_000_000, 2_900_000)])
     red2.finish()
     rel = float((grad2 - ref).abs().max() / ref.abs().max())
-    q.put((rank, exact and 0 < rel < 2e-2, float((grad - ref).abs().max()) + rel))
+    # SOLVER.GRAD_EXCHANGE "rs_ag": every piece as reduce_scatter_tensor + all_gather_into_tensor (odd lengths: the tail shorter than
+    # the world size goes through all_reduce) == the all-reduce of the whole buffer; two ranks: one addition per element, so bit-exact
+    grad3 = torch.randn(n, generator=torch.Generator().manual_seed(7 + rank))
+    red3 = BucketedReducer(grad3, exchange="rs_ag")
+    red3.ready([(2_000_000, 2_900_001), (2_900_001, 2_900_100)])
+    red3.ready([(101, 200)])
+    red3.ready([(500_000, 1_200_000), (1_100_000, 1_500_003), (200, 300_000)])
+    red3.finish()
+    exact = exact and bool(torch.equal(grad3, ref))
+    grad4 = torch.randn(n, generator=torch.Generator().manual_seed(7 + rank))
+    red4 = BucketedReducer(grad4, payload="bf16", exchange="rs_ag")
+    red4.ready([(2_000_000, 2_900_001)])
+    red4.finish()
+    rel4 = float((grad4 - ref).abs().max() / ref.abs().max())
+    q.put((rank, exact and 0 < rel < 2e-2 and 0 < rel4 < 2e-2, float((grad - ref).abs().max()) + rel))
     dist.destroy_process_group()
 
 

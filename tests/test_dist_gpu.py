@@ -32,6 +32,7 @@ def _cfg(world, align):
                          "SEED", 1, "EMA.ALPHA", 0.9, "SYNTHETIC.HEIGHT", H, "SYNTHETIC.WIDTH", W,
                          "DOMAIN_ADAPT.ALIGN.IMG_DA_ENABLED", align, "DOMAIN_ADAPT.ALIGN.INS_DA_ENABLED", align])
     cfg.SOLVER.FUSED_STEP = True
+    cfg.SOLVER.STEP_GRAPH = False
     return cfg
 
 
@@ -219,7 +220,14 @@ def _detr_main(rank, world, port, out_path):
         tr.after_step()
         losses.append({k: float(v) for k, v in t.last_loss_dict.items()})
     torch.cuda.synchronize()
-    torch.save(dict(student=tr.model.weights.master.cpu(), teacher=tr.ema.model.weights.master.cpu(), initial=w0, losses=losses, l_dp=l_dp, l_4=l_4), out_path)
+    # the backward's re-run of the loss kernel (gradient accumulation: scale 1 / accum != 1) divides by the normaliser the forward USED --
+    # the world mean -- not by this rank's own target count
+    from aldi_amd.detr.criterion import _world_mean
+    batch = syn.make_batch(2, 2, 160, 224, 8, seed=77 + 13 * rank)[1]
+    tr.model(batch)
+    nb_local = float(sum(len(b["instances"]["gt_classes"] if isinstance(b["instances"], dict) else b["instances"].gt_classes) for b in batch))
+    nb = dict(ctx=float(tr.model._last.ctx.num_boxes), local=max(nb_local, 1.0), world=_world_mean(nb_local, "cuda"))
+    torch.save(dict(student=tr.model.weights.master.cpu(), teacher=tr.ema.model.weights.master.cpu(), initial=w0, losses=losses, l_dp=l_dp, l_4=l_4, nb=nb), out_path)
     dist.barrier()
     dist.destroy_process_group()
 
@@ -249,6 +257,8 @@ def test_deformable_detr_two_ranks(tmp_path):
     assert torch.equal(res[0]["initial"], res[1]["initial"]) and not torch.equal(res[0]["student"], res[0]["initial"])
     assert res[0]["losses"] != res[1]["losses"]                     # different batches per rank
     assert all(v == v and abs(v) < 1e4 for r in res for d in r["losses"] for v in d.values())
+    assert all(r["nb"]["ctx"] == r["nb"]["world"] for r in res) and res[0]["nb"]["world"] == res[1]["nb"]["world"], [r["nb"] for r in res]
+    assert any(r["nb"]["local"] != r["nb"]["world"] for r in res), [r["nb"] for r in res]       # (the two ranks' batches hold different counts)
     for r in res:
         assert r["l_dp"].keys() == r["l_4"].keys()
         for k in r["l_dp"]:
@@ -296,7 +306,10 @@ def _rccl_main(mode, port, payload, out_path):
     from aldi_amd.trainer import ALDITrainer
     cfg = _cfg(1, False)
     cfg.SOLVER.STEP_GRAPH = True
+    payload, _, exchange = payload.partition("+")
     cfg.SOLVER.GRAD_PAYLOAD = payload
+    if exchange:
+        cfg.SOLVER.GRAD_EXCHANGE = exchange
     random.seed(1234)
     torch.manual_seed(9)
     tr = ALDITrainer(cfg)
@@ -355,6 +368,12 @@ def test_rccl_exchange_inside_the_phase_b_graph(tmp_path):
     assert half["stats"].get("replays_b_dp", 0) >= 2
     moved = (plain["student_it0"] - half["student_it0"]).abs().max().item()
     assert d < moved <= 2e-2 * step, (moved, d, step)              # gradients rounded to bf16 once: visible, and small against the update
+    # SOLVER.GRAD_EXCHANGE "rs_ag": the same exchange as RCCL reduce_scatter_tensor + all_gather_into_tensor per bucket (in place on the
+    # flat gradient), recorded and replayed inside phase B as well; one rank: the identity again
+    rsag = _run_single(tmp_path, "rccl", "fp32+rs_ag")
+    assert rsag["dp_graph_ok"] and rsag["stats"].get("replays_b_dp", 0) >= 2, rsag["stats"]
+    d2 = (plain["student_it0"] - rsag["student_it0"]).abs().max().item()
+    assert d2 <= 1e-3 * step, (d2, step)
 
 
 if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "rank":

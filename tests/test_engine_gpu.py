@@ -125,7 +125,8 @@ def _cfg(align, bf16=False, lr=0.002):
     cfg.merge_from_file(os.path.join(ROOT, "configs", "cityscapes", "ALDI-Best-Cityscapes.yaml"))
     cfg.merge_from_list(["SOLVER.IMS_PER_BATCH", 4, "SOLVER.AMP.ENABLED", bf16, "SOLVER.BASE_LR", lr, "SOLVER.WARMUP_ITERS", 0, "SEED", 1,
                          "EMA.ALPHA", 0.9, "SYNTHETIC.HEIGHT", H, "SYNTHETIC.WIDTH", W,
-                         "DOMAIN_ADAPT.ALIGN.IMG_DA_ENABLED", bool(align), "DOMAIN_ADAPT.ALIGN.INS_DA_ENABLED", bool(align)])
+                         "DOMAIN_ADAPT.ALIGN.IMG_DA_ENABLED", bool(align), "DOMAIN_ADAPT.ALIGN.INS_DA_ENABLED", bool(align),
+                         "SOLVER.FUSED_STEP", False, "SOLVER.STEP_GRAPH", False])     # (default on: the tests that exercise them say so)
     if align == "deep":
         cfg.merge_from_list(["DOMAIN_ADAPT.ALIGN.IMG_DA_LAYER", DEEP["img"]["layer"], "DOMAIN_ADAPT.ALIGN.IMG_DA_HIDDEN_DIMS", DEEP["img"]["hidden_dims"],
                              "DOMAIN_ADAPT.ALIGN.INS_DA_HIDDEN_DIMS", DEEP["ins"]["hidden_dims"]])

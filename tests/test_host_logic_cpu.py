@@ -43,6 +43,40 @@ def test_yaml_base_inheritance_and_overrides():
         cfg.SOLVER.BASE_LR = 1.0
 
 
+def test_fast_path_is_the_default_and_the_reference_yaml_selects_it():
+    """SOLVER.FUSED_STEP / STEP_GRAPH are on unless switched off; (in the build container, where /root/reference exists) the reference's own
+    ALDI-Best-Cityscapes.yaml loads unmodified, and into the same model / solver / adaptation / EMA configuration as the repository's copy"""
+    from aldi_amd.config import add_aldi_config, get_cfg
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+    def load(path):
+        cfg = get_cfg()
+        add_aldi_config(cfg)
+        cfg.merge_from_file(path)
+        return cfg
+
+    def flat(node, pre=""):
+        out = {}
+        for k, v in node.items():
+            if hasattr(v, "items"):
+                out.update(flat(v, pre + k + "."))
+            else:
+                out[pre + k] = v
+        return out
+    mine = load(os.path.join(root, "configs", "cityscapes", "ALDI-Best-Cityscapes.yaml"))
+    assert mine.SOLVER.FUSED_STEP is True and mine.SOLVER.STEP_GRAPH is True
+    ref_path = "/root/reference/configs/cityscapes/ALDI-Best-Cityscapes.yaml"
+    if not os.path.exists(ref_path):
+        return
+    a, b = flat(mine), flat(load(ref_path))
+    # everything that configures the STEP is identical; what differs names data that does not exist here (dataset names, input sizes of
+    # the host-side resize, augmentation switches, evaluation / checkpoint periods, output directory, the initial checkpoint file)
+    step_keys = [k for k in b if k.split(".")[0] in ("MODEL", "SOLVER", "DOMAIN_ADAPT", "EMA", "VIT") and not k.startswith("MODEL.ROI_MASK_HEAD")]
+    assert len(step_keys) > 100
+    differ = sorted(k for k in step_keys if a.get(k, "<missing>") != b[k])
+    assert differ == ["MODEL.WEIGHTS", "SOLVER.CHECKPOINT_PERIOD"], differ
+
+
 def test_step_driver_matches_reference_trace(golden_dir):
     """aldi_amd.trainer.run_model_labeled_unlabeled vs the call/loss trace recorded from reference aldi/trainer.py:28-117."""
     from aldi_amd.dataloader import unpack_data_weak_strong

@@ -125,3 +125,35 @@ def test_paired_student_teacher_forward_equals_separate_passes():
         assert torch.equal(ca.rpn_labels, cb.rpn_labels) and torch.equal(ca.r_idx[: ca.R], cb.r_idx[: cb.R])
         for k in la:
             assert abs(la[k] - lb[k]) <= 2e-5 * max(1.0, abs(la[k])), (it, k, la[k], lb[k])
+
+
+def test_reference_yaml_runs_the_fused_graph_step_by_default(monkeypatch):
+    """`ALDITrainer(cfg)` on the reference's own YAML (configs/cityscapes/ALDI-Best-Cityscapes.yaml = the reference's file of that name
+    without the keys that name files / datasets absent here -- MODEL.WEIGHTS, DATASETS.UNLABELED, AUG.*, OUTPUT_DIR;
+    tests/test_host_logic_cpu.py holds the two files to the same config otherwise; reference tools/train_net.py:83-85) plus only the batch
+    size / synthetic image size: NO aldi_amd extension key is set, and the iteration it runs is the fused step replayed from its two
+    hipGraphs -- the step bench.py measures."""
+    from aldi_amd.config import add_aldi_config, get_cfg
+    from aldi_amd.trainer import ALDITrainer
+    for k in ("ALDI_FUSED_STEP", "ALDI_STEP_GRAPH", "ALDI_FUSED_LEGACY"):
+        monkeypatch.delenv(k, raising=False)
+    cfg = get_cfg()
+    add_aldi_config(cfg)
+    cfg.merge_from_file(os.path.join(ROOT, "configs", "cityscapes", "ALDI-Best-Cityscapes.yaml"))
+    cfg.merge_from_list(["SOLVER.IMS_PER_BATCH", 4, "SYNTHETIC.HEIGHT", H, "SYNTHETIC.WIDTH", W])
+    random.seed(4)
+    torch.manual_seed(17)
+    tr = ALDITrainer(cfg)
+    assert tr._trainer.fused
+    for it in range(6):
+        ld = _step(tr, it)
+    fs = tr._trainer._fused_step
+    assert fs is not None and fs.graph_enabled
+    assert fs.stats["captures"] == 2 and fs.stats["replays_a"] >= 2 and fs.stats["replays_b"] >= 2, fs.stats
+    assert all(v == v for v in ld.values()) and "loss_cls_source_strong" in ld and "loss_roih_l1_distill" in ld
+    # ... and the keys / the environment turn it off again
+    monkeypatch.setenv("ALDI_FUSED_STEP", "0")
+    tr2 = ALDITrainer(cfg)
+    assert not tr2._trainer.fused
+    _step(tr2, 0)
+    assert getattr(tr2._trainer, "_fused_step", None) is None
