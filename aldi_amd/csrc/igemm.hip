@@ -258,11 +258,155 @@ __device__ __forceinline__ void igemm_epilogue(const ConvDev& p, f32x4_t (&acc)[
     }
 }
 
+
+// ---- "direct" epilogue (bf16, BN = 64, plain output layout): no LDS staging, no workgroup barrier, no dependent global loads -----------
+// The staged epilogue above is what bounds the short-K 1x1 layers of res3..res5 (rocprofv3: 7.3 VALU per MFMA, MFMA pipes busy 12.7 % of the
+// cycles on res4 conv3, profiles/r03_pmc_conv.txt): after the K loop every wave writes its tile to the LDS, waits at a barrier, THEN requests
+// the residual from memory, waits for it, adds, rounds a second time and stores.  Here
+//   * the output channels are PERMUTED among the MFMA rows (`direct_perm`: the weight rows are fetched in that order, a free change of the
+//     DMA source address), so that a lane's accumulators of fragments 2h, 2h+1 are 8 CONSECUTIVE channels of its pixel: one 16-byte store
+//     per pixel row and 32-channel block straight from registers (the four lanes of a pixel write 64 contiguous bytes);
+//   * the residual is requested in the PROLOGUE, beside the first K slabs, straight into 16 registers per lane in that same layout (the
+//     data arrives while the K loop runs) and added in fp32: ONE rounding of conv * scale + shift + residual instead of two.  (Measured
+//     first: the residual tile by LDS-DMA into an activation-slab image + an MFMA with a 0/1 selection fragment as the A operand -- exact,
+//     no VALU -- was 10-27 % SLOWER than the staged epilogue: 16 KB more LDS per workgroup (3 instead of 4 per CU) and +17 % bytes on the
+//     L2 -> LDS path, which is what bounds the K loop of these layers);
+//   * FrozenBN scale / shift (or the ReLU-mask bits of a data-gradient launch) arrive the same way (one 4-byte-per-lane DMA per wave);
+//   * ReLU is a packed int16 max on the rounded pairs, the mask an AND with a sign-extended bit.
+template <int WNE>
+__device__ __forceinline__ int direct_perm(int row) {          // MFMA row `row` of the BN-wide tile computes channel n0 + direct_perm(row)
+    const int wv = row / WNE, rr = row % WNE, j = rr >> 4, r = rr & 15;
+    return wv * WNE + (j >> 1) * 32 + (r >> 2) * 8 + (j & 1) * 4 + (r & 3);
+}
+__device__ __forceinline__ unsigned lds_read_u8(unsigned addr) {
+    unsigned v;
+    asm volatile("ds_read_u8 %0, %1" : "=v"(v) : "v"(addr));
+    return v;
+}
+template <int BM, int BN, int WM, int WN, bool RESL>
+__device__ __forceinline__ void igemm_epilogue_direct(const ConvDev& p, f32x4_t (&acc)[BM / WM / 16][BN / WN / 16], const int m0, const int n0,
+                                                      u32x4_t (&rres)[BM / WM / 16][BN / WN / 32], const unsigned aux_addr) {
+    constexpr int TM = BM / WM / 16, TN = BN / WN / 16, WNE = BN / WN, H = WNE / 32;
+    static_assert(TN == 2 * H, "whole 32-channel blocks per wave");
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int fr = lane & 15, fq = lane >> 4;
+    if (p.dbg & 4) return;
+    // (1) y = acc * scale + shift, operands from the workgroup's LDS copy of the tile's 64 scales / shifts
+    if (p.scale || p.shift) {
+        u32x4_t sc[TN], sh[TN];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const unsigned a = aux_addr + (unsigned)(wn * WNE + (j >> 1) * 32 + fq * 8 + (j & 1) * 4) * 4u;
+            sc[j] = frag_read<0>(a);
+            sh[j] = frag_read<256>(a);
+        }
+        frag_wait<TN, TN>(sc, sh);
+        if (p.scale) {
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[i][j][e] *= __uint_as_float(sc[j][e]);
+        }
+        if (p.shift) {
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[i][j][e] += __uint_as_float(sh[j][e]);
+        }
+    }
+    // (2) + residual (fp32 add before the single rounding): requested in the prologue, in THIS lane's output layout (8 consecutive channels)
+    if constexpr (RESL) {
+        if (p.res_mode) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int h = 0; h < H; ++h) {
+                    asm volatile("" : "+v"(rres[i][h]));
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const unsigned r2 = rres[i][h][q];
+                        acc[i][2 * h + (q >> 1)][(q & 1) * 2] += __uint_as_float(r2 << 16);
+                        acc[i][2 * h + (q >> 1)][(q & 1) * 2 + 1] += __uint_as_float(r2 & 0xffff0000u);
+                    }
+                }
+        }
+    }
+    // (3) round, ReLU / mask, store: lane (fr, fq) owns pixel fr of fragment row i and channels h*32 + fq*8 .. +7 of its wave's range
+    unsigned mb[TM][H];
+    if (p.mask_bits) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int h = 0; h < H; ++h) mb[i][h] = lds_read_u8(aux_addr + (unsigned)((wm * (BM / WM) + i * 16 + fr) * (BN / 8) + (wn * H + h) * 4 + fq));
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int h = 0; h < H; ++h) asm volatile("" : "+v"(mb[i][h]));
+    }
+    const __amdgpu_buffer_rsrc_t ry = make_rsrc_uniform(p.y, 0x7fffffffu);
+    const __amdgpu_buffer_rsrc_t rbo = make_rsrc_uniform(p.bits_out, 0x7fffffffu);
+    typedef short s16x2_t __attribute__((ext_vector_type(2)));
+    typedef unsigned short u16x2_t __attribute__((ext_vector_type(2)));
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int m = m0 + wm * (BM / WM) + i * 16 + fr;
+#pragma unroll
+        for (int h = 0; h < H; ++h) {
+            const int c = n0 + wn * WNE + h * 32 + fq * 8;
+            const bool ok = m < p.M && c < p.Cout;
+            const unsigned e0 = (unsigned)m * (unsigned)p.Cout + (unsigned)c;
+            float v[8];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { v[e] = acc[i][2 * h][e]; v[4 + e] = acc[i][2 * h + 1][e]; }
+            if (p.mask_bits) {
+#pragma unroll
+                for (int t = 0; t < 8; ++t) v[t] = __uint_as_float(__float_as_uint(v[t]) & (unsigned)__builtin_amdgcn_sbfe((int)mb[i][h], t, 1));
+            }
+            uint32_t d[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) d[q] = pack2_bf16(v[2 * q], v[2 * q + 1]);
+            if (p.relu) {                       // bf16 as int16: negative floats (and -0) are negative integers
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    s16x2_t t = *reinterpret_cast<s16x2_t*>(&d[q]);
+                    t = __builtin_elementwise_max(t, s16x2_t{0, 0});
+                    d[q] = *reinterpret_cast<uint32_t*>(&t);
+                }
+            }
+            const u32x4_t ov = {d[0], d[1], d[2], d[3]};
+            __builtin_amdgcn_raw_buffer_store_b128(ov, ry, ok ? e0 * 2u : 0x80000000u, 0, 0);
+            if (p.bits_out) {                   // (y > 0) of the 8 channels = one byte: halves clamped to {0, 1}, gathered by shifts
+                unsigned u = 0;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    u16x2_t t = *reinterpret_cast<u16x2_t*>(&d[q]);
+                    // after the ReLU every half is >= +0: (half != 0) == (y > 0); without a ReLU the sign bit decides first
+                    if (!p.relu) { s16x2_t s_ = *reinterpret_cast<s16x2_t*>(&d[q]); s_ = __builtin_elementwise_max(s_, s16x2_t{0, 0}); t = *reinterpret_cast<u16x2_t*>(&s_); }
+                    t = __builtin_elementwise_min(t, u16x2_t{1, 1});
+                    u |= *reinterpret_cast<unsigned*>(&t) << (2 * q);
+                }
+                const unsigned b = (u & 0x55u) | ((u >> 15) & 0xaau);
+                __builtin_amdgcn_raw_buffer_store_b8((unsigned char)b, rbo, ok ? e0 >> 3 : 0x80000000u, 0, 0);
+            }
+        }
+    }
+}
+
 // body of one workgroup: tile `bid` of an nmt x nnt tile grid of problem p (launched alone: igemm_kernel; as one of several
 // problems of the same layer shape sharing a launch: igemm_group_kernel)
-template <typename T, int BM, int BN, int WM, int WN, int KC, bool PIPE, bool HALO = false>
+// EPI: 0 = the staged epilogue; 1 = the direct epilogue (bf16, BN = 64); 2 = direct + the residual tile prefetched into the LDS
+template <typename T, int BM, int BN, int WM, int WN, int KC, bool PIPE, bool HALO = false, int EPI = 0>
 __device__ __forceinline__ void igemm_body(const ConvDev& p, int bid, const int nmt, const int nnt) {
     constexpr int NT = WM * WN * 64;
+    constexpr bool DIRECT = EPI != 0, RESL = EPI == 2;
+    static_assert(!DIRECT || (sizeof(T) == 2 && BN == 64 && (BN / WN) % 32 == 0 && BM * BN / 32 <= NT), "direct epilogue: bf16, 64-channel tiles");
+    static_assert(!RESL || (PIPE && !HALO), "residual prefetch: the register-pipelined 1x1 loop");
     constexpr int EP = Elem<T>::kPer16B;           // elements per 16-B chunk
     constexpr int BK = KC * EP;                    // K slab: KC 16-B chunks per LDS row (KC=8: 64 bf16 / 32 fp32)
     constexpr int LOG = KC == 8 ? 3 : 2;
@@ -274,7 +418,14 @@ __device__ __forceinline__ void igemm_body(const ConvDev& p, int bid, const int 
     constexpr int NBUF = 3;                        // LDS ring: two slabs of DMA in flight across the barrier
     constexpr int SLOTS = HALO ? ((BM + 2) * KC + 63) / 64 * 64 + 3 * BN * KC : (BM + BN) * KC;     // per ring stage
     constexpr int NSTAGE = HALO ? 2 : NBUF;
-    __shared__ __attribute__((aligned(128))) uint4 lds[NSTAGE][SLOTS];
+    // one LDS object (a second one makes hipcc drain the DMA queue before LDS reads): [ring | residual tile | scale + shift or mask bits]
+    constexpr int AUX_SLOTS = DIRECT ? 64 : 0;
+    __shared__ __attribute__((aligned(128))) uint4 lds_all[NSTAGE * SLOTS + AUX_SLOTS];
+    uint4 (*const lds)[SLOTS] = reinterpret_cast<uint4 (*)[SLOTS]>(&lds_all[0]);
+    uint4* const aux_lds = &lds_all[NSTAGE * SLOTS];
+    constexpr int N_RES = RESL ? (BM / WM / 16) * (BN / WN / 32) : 0;   // residual loads per thread (16 B each: its 8 channels of a pixel and 32-block)
+    constexpr int N_PRE = DIRECT ? N_RES + 1 : 0;               // loads per wave issued once, behind the first K slabs (residual + aux)
+    u32x4_t rres[BM / WM / 16][BN / WN / 32 > 0 ? BN / WN / 32 : 1];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
@@ -301,6 +452,47 @@ __device__ __forceinline__ void igemm_body(const ConvDev& p, int bid, const int 
     const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(Wt), 0, p.w_bytes, 0x00020000);
     constexpr unsigned OOB = 0x80000000u;
     const int wbase = __builtin_amdgcn_readfirstlane(tid & ~63);      // first tile slot of this wave (wave-uniform)
+    // direct epilogue: what it reads besides the accumulators arrives by DMA while the K loop runs (N_PRE pieces per wave, always issued so
+    // that the counted waits below are static; an unused piece is an out-of-range offset)
+    auto issue_pre = [&]() {
+        if constexpr (DIRECT) {
+            if constexpr (RESL) {
+                const __amdgpu_buffer_rsrc_t rr = make_rsrc_uniform(p.res, 0x7fffffffu);
+#pragma unroll
+                for (int i = 0; i < BM / WM / 16; ++i) {
+                    const int m = m0 + wm * (BM / WM) + i * 16 + (lane & 15);
+                    unsigned ridx = (unsigned)m;
+                    if (p.res_mode == 2) {                      // FPN top-down: the coarser map's pixel (ho >> 1, wo >> 1)
+                        const int mm = m < p.M ? m : 0;
+                        const int n = mm / (p.Ho * p.Wo), r = mm - n * (p.Ho * p.Wo), ho = r / p.Wo, wo = r - ho * p.Wo;
+                        ridx = (unsigned)((n * (p.Ho >> 1) + (ho >> 1)) * (p.Wo >> 1) + (wo >> 1));
+                    }
+#pragma unroll
+                    for (int h = 0; h < BN / WN / 32; ++h) {
+                        const int ch = n0 + wn * (BN / WN) + h * 32 + (lane >> 4) * 8;
+                        const bool ok = p.res_mode && m < p.M && ch < p.Cout;
+                        rres[i][h] = __builtin_amdgcn_raw_buffer_load_b128(rr, ok ? (ridx * (unsigned)p.Cout + (unsigned)ch) * 2u : OOB, 0, 0);
+                    }
+                }
+            }
+            // aux piece, 4 bytes per lane: a data-gradient launch fetches the tile's ReLU-mask bits (BN / 8 bytes per pixel row: lane = 32
+            // channels of one row); a forward launch its 64 scales (even waves) / shifts (odd waves) -- the two never occur together
+            if (p.mask_bits) {
+                const __amdgpu_buffer_rsrc_t rb = make_rsrc_uniform(p.mask_bits, 0x7fffffffu);
+                const int row = tid >> 1, m = m0 + row, ch = n0 + (tid & 1) * 32;
+                const bool ok = tid < BM * 2 && m < p.M && ch < p.Cout;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (__attribute__((address_space(3))) void*)(reinterpret_cast<unsigned*>(aux_lds) + wbase), 4,
+                                                         ok ? ((unsigned)m * (unsigned)p.Cout + (unsigned)ch) >> 3 : OOB, 0, 0, 0);
+            } else {
+                const bool odd = __builtin_amdgcn_readfirstlane(wave) & 1;
+                const float* src = odd ? p.shift : p.scale;
+                const __amdgpu_buffer_rsrc_t rs = make_rsrc_uniform(src, 0x7fffffffu);
+                const int ch = n0 + lane;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(reinterpret_cast<unsigned*>(aux_lds) + (odd ? 64 : 0)), 4,
+                                                         src && ch < p.Cout ? (unsigned)ch * 4u : OOB, 0, 0, 0);
+            }
+        }
+    };
     f32x4_t acc[TM][TN];
 #pragma unroll
     for (int i = 0; i < TM; ++i)
@@ -308,6 +500,7 @@ __device__ __forceinline__ void igemm_body(const ConvDev& p, int bid, const int 
         for (int j = 0; j < TN; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
     const int fr = lane & 15, fq = lane >> 4;
+    bool pre_seen = true;                         // (direct epilogue) the once-per-tile DMA pieces are landed and visible when the K loop ends
     if constexpr (HALO) {
     // ---- 3x3 / stride 1 / pad 1 with operand reuse across the three horizontal taps -------------------------------
     // For a fixed (kh, 32-channel chunk) the pixel tiles of kw = 0,1,2 are the same BM+2 consecutive input pixels
@@ -337,7 +530,7 @@ __device__ __forceinline__ void igemm_body(const ConvDev& p, int bid, const int 
 #pragma unroll
     for (int it = 0; it < WH_IT; ++it) {
         const int c = tid + it * NT, kwi = c / (BN * KC), rem = c - kwi * (BN * KC), row = rem >> 2, kce = swz<KC>(row, rem & 3);
-        const int co = n0 + row;
+        const int co = n0 + (DIRECT ? direct_perm<BN / WN>(row) : row);
         hw_voff[it] = co < p.Cout ? ((unsigned)co * (unsigned)p.K + (unsigned)(kwi * p.Cin + kce * EP)) * (unsigned)sizeof(T) : OOB;
     }
     int gkh = 0, gci = 0;                                        // (kh, channel chunk) of the group being LOADED
@@ -372,6 +565,7 @@ __device__ __forceinline__ void igemm_body(const ConvDev& p, int bid, const int 
     constexpr unsigned GROUP_BYTES = (AS + WS) * 16;
     const int G = 3 * (p.Cin / BK);
     issue_group(0);
+    issue_pre();                                 // (every wait of this loop is vmcnt(0): landed and, behind the barrier, visible from group 0 on)
     int buf = 0;
     for (int g = 0; g < G; ++g) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -439,7 +633,7 @@ __device__ __forceinline__ void igemm_body(const ConvDev& p, int bid, const int 
 #pragma unroll
     for (int it = 0; it < B_IT; ++it) {
         int c = tid + it * NT, row = c >> LOG, kce = swz<KC>(row, c & (KC - 1));
-        int co = n0 + row;
+        int co = n0 + (DIRECT ? direct_perm<BN / WN>(row) : row);
         bool ok = (c < BN * KC) && co < p.Cout;
         b_voff[it] = ok ? (unsigned)((long)co * p.K + kce * EP) * (unsigned)sizeof(T) : OOB;
         b_kce[it] = kce * EP;
@@ -485,18 +679,25 @@ __device__ __forceinline__ void igemm_body(const ConvDev& p, int bid, const int 
     const int s_first = p.ksplit > 1 ? (int)blockIdx.z * p.slabs_per_split : 0;
     const int S = p.ksplit > 1 ? min(S_all - s_first, p.slabs_per_split) : S_all;
     ci0 = s_first * BK;
+    if constexpr (PIPE) pre_seen = S > 3;         // (the register-pipelined loop waits for them together with slab 3)
     issue_slab(s_first, 0);
     if (S > 1) issue_slab(s_first + 1, 1);
+    if constexpr (!PIPE) issue_pre();            // (two-level loop: behind slabs 0 and 1)
     constexpr unsigned SLAB_BYTES = (BM + BN) * KC * 16;
     const int xrow = wm * (BM / WM) + fr, wrow = wn * (BN / WN) + fr;
     const unsigned x_rd0 = lds_addr(&lds[0][0]) + (unsigned)(xrow * KC + swz<KC>(xrow, fq)) * 16u;
     const unsigned w_rd0 = lds_addr(&lds[0][0]) + (unsigned)((BM + wrow) * KC + swz<KC>(wrow, fq)) * 16u;
     if constexpr (PIPE) {
     if (S > 2) issue_slab(s_first + 2, 2);
+    // the once-per-tile pieces go out behind the (up to) three slabs of the prologue: a counted wait for slab k may leave them in flight
+    // as long as k <= 2 -- from the wait for slab 3 on they are older than everything still allowed to be outstanding
+    __builtin_amdgcn_sched_barrier(0);           // (the counted waits below assume this issue order)
+    issue_pre();
+    __builtin_amdgcn_sched_barrier(0);
     u32x4_t xf0[TM], wf0[TN], xf1[TM], wf1[TN];
-    if (S > 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * N_DMA) : "memory");
-    else if (S > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N_DMA) : "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (S > 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * N_DMA + N_PRE) : "memory");
+    else if (S > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N_DMA + N_PRE) : "memory");
+    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N_PRE) : "memory");
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
     frag_read_all<TM, KC * 16>(xf0, x_rd0);
@@ -506,19 +707,30 @@ __device__ __forceinline__ void igemm_body(const ConvDev& p, int bid, const int 
     auto step = [&](int s, u32x4_t* xc, u32x4_t* wc, u32x4_t* xn, u32x4_t* wn_) {
         const bool more = s + 1 < S;
         if (more) {
-            if (s + 2 < S) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N_DMA) : "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            // waiting for slab s + 1; younger: slab s + 2 (if any) and, while s + 1 <= 2, the once-per-tile pieces
+            if (N_PRE > 0 && s < 2) {
+                if (s + 2 < S) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N_DMA + N_PRE) : "memory");
+                else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N_PRE) : "memory");
+            } else {
+                if (s + 2 < S) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N_DMA) : "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
             __builtin_amdgcn_s_barrier();
             __builtin_amdgcn_sched_barrier(0);
-            frag_read_all<TM, KC * 16>(xn, x_rd0 + (unsigned)rbuf * SLAB_BYTES);
-            frag_read_all<TN, KC * 16>(wn_, w_rd0 + (unsigned)rbuf * SLAB_BYTES);
-            if (s + 3 < S) issue_slab(s_first + s + 3, ibuf);
         }
+        // The reads and their wait are UNCONDITIONAL (after the last slab they fetch an idle ring stage that nobody uses): the compiler takes
+        // the asm's outputs for available at once, so where two definitions of a fragment register set meet (`if (more)` around the reads: a
+        // phi) it may copy the registers on the incoming edge -- between the asynchronous read and frag_wait(), i.e. before the data has
+        // landed.  It did: 128x64 tiles with 2 or 3 K slabs returned garbage in the fourth channel fragment (tools/isa_hazard_check.py
+        // finds such copies in the generated code; tests/test_isa_hazards_cpu.py runs it over every kernel with hand-issued reads).
+        frag_read_all<TM, KC * 16>(xn, x_rd0 + (unsigned)rbuf * SLAB_BYTES);
+        frag_read_all<TN, KC * 16>(wn_, w_rd0 + (unsigned)rbuf * SLAB_BYTES);
+        if (more && s + 3 < S) issue_slab(s_first + s + 3, ibuf);
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
             for (int j = 0; j < TN; ++j) acc[i][j] = Mma<T>::run(wc[j], xc[i], acc[i][j]);
-        if (more) frag_wait<TM, TN>(xn, wn_);
+        frag_wait<TM, TN>(xn, wn_);
         rbuf = rbuf == NBUF - 1 ? 0 : rbuf + 1;
         ibuf = ibuf == NBUF - 1 ? 0 : ibuf + 1;
     };
@@ -531,7 +743,9 @@ __device__ __forceinline__ void igemm_body(const ConvDev& p, int bid, const int 
     // tile, where the extra fragment registers and issue slots cost more than the in-wave overlap returns
     int buf = 0, nbuf = 2;
     for (int s = 0; s < S; ++s) {
-        if (s + 1 < S) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N_DMA) : "memory");
+        // waiting for slab s; younger: slab s + 1 (if any) and, at s = 0, the once-per-tile pieces (issued behind slabs 0 and 1)
+        if (N_PRE > 0 && s == 0 && S > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N_DMA + N_PRE) : "memory");
+        else if (s + 1 < S) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N_DMA) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
@@ -556,13 +770,24 @@ __device__ __forceinline__ void igemm_body(const ConvDev& p, int bid, const int 
 
     }
 
+    if constexpr (DIRECT) {
+        // the once-per-tile pieces: every wave has waited for its own (the K loop's last wait is vmcnt(0)); a barrier makes the other waves'
+        // visible -- the loop's own barriers did that already when it waited for a slab younger than the pieces (PIPE: slab 3; flat: slab 1)
+        if (!pre_seen) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        igemm_epilogue_direct<BM, BN, WM, WN, RESL>(p, acc, m0, n0, rres, lds_addr(aux_lds));
+        return;
+    }
     if (p.ksplit > 1) {                              // this slice's partial tile, raw fp32, into its own slab of the workspace
         ConvDev q = p;
         q.y_f32 = p.y_f32 + (long)blockIdx.z * p.M * p.Cout;
-        igemm_epilogue<T, BM, BN, WM, WN, NSTAGE * SLOTS * 16>(q, acc, m0, n0, reinterpret_cast<unsigned char*>(&lds[0][0]));
+        igemm_epilogue<T, BM, BN, WM, WN, NSTAGE * SLOTS * 16>(q, acc, m0, n0, reinterpret_cast<unsigned char*>(&lds_all[0]));
         return;
     }
-    igemm_epilogue<T, BM, BN, WM, WN, NSTAGE * SLOTS * 16>(p, acc, m0, n0, reinterpret_cast<unsigned char*>(&lds[0][0]));
+    igemm_epilogue<T, BM, BN, WM, WN, NSTAGE * SLOTS * 16>(p, acc, m0, n0, reinterpret_cast<unsigned char*>(&lds_all[0]));
 }
 
 // ---- 3x3 / stride 1 / pad 1, halo form, with the two halves of an 8-wave workgroup in ALTERNATING ROLES ------------------------
@@ -777,9 +1002,9 @@ int launch_halo_rs(const ConvDev& d, hipStream_t st) {
 
 // (the 240-pixel halo tile is sized for TWO workgroups per CU: 6 waves each = 3 waves per SIMD, 80 KB of LDS each)
 template <int BM, int NT, bool HALO> constexpr int min_waves_per_simd() { return HALO && BM == 240 ? 2 * NT / 256 : 1; }
-template <typename T, int BM, int BN, int WM, int WN, int KC, bool PIPE, bool HALO = false>
+template <typename T, int BM, int BN, int WM, int WN, int KC, bool PIPE, bool HALO = false, int EPI = 0>
 __global__ __launch_bounds__(WM* WN * 64, (min_waves_per_simd<BM, WM * WN * 64, HALO>())) void igemm_kernel(ConvDev p) {
-    igemm_body<T, BM, BN, WM, WN, KC, PIPE, HALO>(p, (int)(blockIdx.y * gridDim.x + blockIdx.x), (int)gridDim.x, (int)gridDim.y);
+    igemm_body<T, BM, BN, WM, WN, KC, PIPE, HALO, EPI>(p, (int)(blockIdx.y * gridDim.x + blockIdx.x), (int)gridDim.x, (int)gridDim.y);
 }
 
 // Several problems of ONE layer shape in one launch -- the student's and the teacher's pass through the same layer (different
@@ -807,8 +1032,21 @@ __global__ __launch_bounds__(WM* WN * 64, (min_waves_per_simd<BM, WM * WN * 64, 
 
 static thread_local const ConvGroup* g_group = nullptr;      // set by aldi_conv_igemm_group around dispatch<T>()
 
-template <typename T, int BM, int BN, int WM, int WN, int KC, bool PIPE = true, bool HALO = false>
+template <typename T, int BM, int BN, int WM, int WN, int KC, bool PIPE = true, bool HALO = false, int EPI = 0>
 int launch(const ConvDev& d, hipStream_t st) {
+    if constexpr (EPI != 0) {
+        if (!g_group && d.ksplit <= 1) {
+            dim3 grid(cdiv(d.M, BM), cdiv(d.Cout, BN));
+            hipLaunchKernelGGL((igemm_kernel<T, BM, BN, WM, WN, KC, PIPE, HALO, EPI>), grid, dim3(WM * WN * 64), 0, st, d);
+            ALDI_CHECK_LAUNCH();
+            char name[112];
+            snprintf(name, sizeof(name), "igemm<%s,%d,%d,%d,%d,%s,%s%s,%s>", "bf16", BM, BN, WM, WN, PIPE ? "pipe" : "flat", HALO ? "halo" : "tap", KC == 8 ? ",k64" : "",
+                     EPI == 2 ? "direct+res" : "direct");
+            aldi_note_dispatch(name);
+            return ALDI_OK;
+        }
+        return launch<T, BM, BN, WM, WN, KC, PIPE, HALO, 0>(d, st);
+    }
     if (g_group) {
         ConvGroup G = *g_group;
         int wg = 0;
@@ -854,6 +1092,11 @@ int dispatch(ConvDev& d, hipStream_t st) {
     // the R50 trunk are HBM-bound and stay on 128x128.
     // igemm_halo: 3x3 / stride 1 / pad 1 (every 3x3 of the network): halo form, the pixel tile is loaded once per three taps.
     const int force = tn.igemm_force;     // 0 = heuristics; 1 = 128x128, 2 = 128x64, 3 = 64x64, 4 = 256x128, 5 = 128x16
+    // igemm_direct (bit mask: 1 = the 128x64 1x1 / tap tile, 2 = the 64x64 long-K tile, 4 = the 128x64 halo tile): the direct epilogue of
+    // the 64-channel tiles (igemm_epilogue_direct) for bf16 outputs in the plain layout; a residual needs the tile that prefetches it
+    const bool direct_ok = sizeof(T) == 2 && !g_group && d.y && !d.y_f32 && d.out_scale == 1 && (d.Cout & 7) == 0 && !d.mask && d.ksplit <= 1 &&
+                           !(d.mask_bits && (d.scale || d.shift)) && d.Cout >= 64;
+    const int direct = direct_ok ? tn.igemm_direct : 0;
     {
         // (fp32 -- the parity mode and the Deformable-DETR step's trunk: the halo form is the same code, 16 channels per group; igemm_halo_f32)
         const bool same3 = d.KH == 3 && d.KW == 3 && d.stride == 1 && d.pad == 1 && d.Ho == d.H && d.Wo == d.W && d.Cin % 32 == 0 && d.out_scale == 1;
@@ -865,6 +1108,8 @@ int dispatch(ConvDev& d, hipStream_t st) {
         const bool f32_halo = sizeof(T) == 4 && tn.igemm_halo_f32 > 0 && (long)cdiv(d.M, 128) * cdiv(d.Cout, 64) >= tn.igemm_halo_f32;
         if (tn.igemm_halo && (sizeof(T) == 2 || f32_halo) && same3) {
             if (force == 1) return launch<T, 128, 128, 2, 2, 4, false, true>(d, st);
+            if constexpr (sizeof(T) == 2)
+                if (force == 2 && (direct & 4) && !d.res_mode) return launch<T, 128, 64, 4, 1, 4, false, true, 1>(d, st);
             if (force == 2) return launch<T, 128, 64, 4, 1, 4, false, true>(d, st);
             if (force == 4) return launch<T, 256, 128, 4, 2, 4, false, true>(d, st);
             if constexpr (sizeof(T) == 2) {
@@ -882,12 +1127,17 @@ int dispatch(ConvDev& d, hipStream_t st) {
                 // below ~1000 128x128 tiles the tile count of this network sits just above a multiple of the 256 CUs (16800 pixels =
                 // 131.25 row tiles: 264 / 528 tiles) and the last partial round costs as much as a full one; half-width tiles halve that
                 // tail (measured 8-25 % faster on every res3..res5 / FPN p3..p6 3x3 at N = 2 and 4)
+                if constexpr (sizeof(T) == 2)
+                    if ((direct & 4) && !d.res_mode) return launch<T, 128, 64, 4, 1, 4, false, true, 1>(d, st);
                 return launch<T, 128, 64, 4, 1, 4, false, true>(d, st);
             }
         }
     }
     if (force == 5 || (force == 0 && d.Cout <= 16)) return launch<T, 128, 16, 4, 1, 4>(d, st);
     if (force == 1) return launch<T, 128, 128, 2, 2, 4>(d, st);
+    if constexpr (sizeof(T) == 2) {
+        if (force == 2 && (direct & 1)) return d.res_mode ? launch<T, 128, 64, 4, 1, 4, true, false, 2>(d, st) : launch<T, 128, 64, 4, 1, 4, true, false, 1>(d, st);
+    }
     if (force == 2) return launch<T, 128, 64, 4, 1, 4>(d, st);
     if (force == 3) return launch<T, 64, 64, 2, 2, 4>(d, st);
     if (force == 4) return launch<T, 256, 128, 4, 2, 4, false>(d, st);
@@ -900,7 +1150,10 @@ int dispatch(ConvDev& d, hipStream_t st) {
         if (plain && force == 6) return launch<T, 128, 128, 2, 2, 8, false>(d, st);
         if (plain && force == 7) return launch<T, 128, 64, 4, 1, 8, false>(d, st);
         const bool lin256 = tn.igemm_tile != 9 && big >= tn.igemm_lintile_min && d.K >= tn.igemm_bigtile_k;     // (the token-GEMM rule below wins)
-        if (plain && (force == 8 || (force == 0 && !lin256 && d.Cout > 64 && d.K % 64 == 0 && d.K >= tn.igemm_k64_min))) return launch<T, 64, 64, 2, 2, 8, false>(d, st);
+        if (plain && (force == 8 || (force == 0 && !lin256 && d.Cout > 64 && d.K % 64 == 0 && d.K >= tn.igemm_k64_min))) {
+            if ((direct & 2) && !d.res_mode) return launch<T, 64, 64, 2, 2, 8, false, false, 1>(d, st);
+            return launch<T, 64, 64, 2, 2, 8, false>(d, st);
+        }
     }
     // fp32 (the parity mode; the Deformable-DETR step's arithmetic): the f32-input MFMA runs at 1/16 of the bf16 rate, so a tile's K loop is
     // long and what pays is workgroups, not bytes per flop -- 64 x 64 tiles are as fast or faster than every larger tile on all of that
@@ -913,6 +1166,9 @@ int dispatch(ConvDev& d, hipStream_t st) {
     // short-K layers (the bottlenecks' 1x1 expansions and res3's reductions: K = 128 .. 512, 4-16 slabs) are all prologue and
     // epilogue: half-width tiles (twice the workgroups, half the staging epilogue each) run them 8-13 % faster than 128x128
     // (tools/fc_dgrad_sweep.py: 16800 x 256 -> 1024: 25 -> 23 us, 67200 x 128 -> 512: 31 -> 27 us, 67200 x 512 -> 128: 26 -> 24 us)
+    if constexpr (sizeof(T) == 2) {
+        if (d.K <= tn.igemm_narrow_k && (direct & 1)) return d.res_mode ? launch<T, 128, 64, 4, 1, 4, true, false, 2>(d, st) : launch<T, 128, 64, 4, 1, 4, true, false, 1>(d, st);
+    }
     if (sizeof(T) == 2 && d.K <= tn.igemm_narrow_k) return launch<T, 128, 64, 4, 1, 4>(d, st);
     return launch<T, 128, 128, 2, 2, 4>(d, st);
 }

@@ -103,6 +103,7 @@ def _check_forward(case, dtype, expect, *, force=None, full=True):
         res = res.bfloat16().float()
     dev = "cuda"
     xd, wd, rd = x.to(dev, dtype), w.to(dev, dtype), res.to(dev, dtype)
+    L.set_tuning("igemm_direct", 0)          # these cases are about the tile templates with the STAGED epilogue (the direct one: _check_direct below)
     if force is not None:
         L.set_tuning("igemm_force", force)
     y = ops.conv2d(xd, wd, stride=stride, pad=pad, scale=scale.to(dev), shift=shift.to(dev), res=rd, res_mode=1, relu=True)
@@ -623,12 +624,15 @@ def test_conv_group_equals_single_launches(geo, batches, expect):
         assert (a - b).abs().max().item() <= 2e-5 * max(1.0, b.abs().max().item())
 
 
+@pytest.mark.parametrize("direct", [0, 7])
 @pytest.mark.parametrize("case", [(2, 50, 84, 256, 1024, 1, 0), (1, 19, 23, 64, 72, 3, 1), (2, 25, 42, 512, 2048, 1, 0)])
-def test_relu_masks_as_bits(case):
+def test_relu_masks_as_bits(case, direct):
     """aldi_conv_args.bits_out / mask_bits: the forward launch writes (y > 0) of its output as one bit per element beside y, the backward
     launch multiplies by those bits -- the same result, bit for bit, as masking by the bf16 activation itself; ragged M and a Cout that is
     not a tile multiple included"""
+    from aldi_amd import _lib as L
     from aldi_amd import ops
+    L.set_tuning("igemm_direct", direct)          # 0: the staged epilogue everywhere; 7: the direct epilogue where it applies
     N, H, W_, Cin, Cout, k, pad = case
     g = torch.Generator().manual_seed(sum(case))
     x = torch.randn(N, H, W_, Cin, generator=g).to("cuda", torch.bfloat16)
@@ -652,7 +656,14 @@ def test_relu_masks_as_bits(case):
     a = ops.conv2d(gy, wt, res=r2, res_mode=1, mask=y)
     b = ops.conv2d(gy, wt, res=r2, res_mode=1, mask_bits=bits)
     torch.cuda.synchronize()
-    assert torch.equal(a, b)
+    if direct == 0:
+        assert torch.equal(a, b)
+    else:
+        # the direct epilogue adds the residual in fp32 and rounds once; the staged one (which the `mask` tensor form always takes) rounds the
+        # product first: the same masked zeros, values within the product's bf16 rounding (an exact cancellation may round to zero in one only)
+        assert bool((b[y == 0] == 0).all()) and bool((a[y == 0] == 0).all())
+        prod = ops.conv2d(gy, wt, want_f32=True)
+        assert bool(((a.float() - b.float()).abs() <= 2.0 ** -7 * prod.abs() + 2.0 ** -7 * b.float().abs() + 1e-30).all())
     with pytest.raises(Exception):
         ops.conv2d(gy, wt, mask=y, mask_bits=bits)
 
@@ -795,3 +806,152 @@ def test_bias_gradient_rides_in_the_wgrad_launch(case):
     torch.cuda.synchronize()
     assert float((db.double() - 0.5 - ref).abs().max()) <= 1e-3 * float(ref.abs().max()) + 1e-2, float((db.double() - 0.5 - ref).abs().max())
     assert float((dw0 - dw1).abs().max()) <= 1e-4 * float(dw0.abs().max())      # (fp32 atomics: summation order only)
+
+
+# ---------------------------------------------------------------------------------- the direct epilogue (igemm_epilogue_direct)
+def _bits_of(t):
+    M = t.numel() // t.shape[-1]
+    e = (t.reshape(M, t.shape[-1] // 8, 8).float() > 0).to(torch.uint8)
+    return (e * (2 ** torch.arange(8, device=t.device, dtype=torch.uint8))).sum(-1).to(torch.uint8).view(-1)
+
+
+def _check_direct(case, kind, expect, *, force=None):
+    """one launch through the direct epilogue against an fp64 evaluation of  y = mask * relu(conv * scale + shift + residual)  rounded ONCE to
+    bf16 (sampled pixels: borders, seams, tile edges, the ragged tail), the mask bits it writes against (y > 0) of the whole tensor, masked
+    positions exactly zero.  kinds: f3 forward conv3 (scale, shift, residual, ReLU, bits_out) / f1 forward conv1, conv2 (scale, shift, ReLU,
+    bits_out) / sc shortcut (scale, shift) / b bias only / d1 conv1 dgrad (residual + mask bits) / d3 conv3, conv2 dgrad (mask bits) /
+    up FPN lateral (bias + the coarser level's map, nearest-upsampled)"""
+    from aldi_amd import _lib as L
+    from aldi_amd import ops
+    N, H, W_, Cin, Cout, k, stride, pad = case
+    x, w, g = _mk(N, H, W_, Cin, Cout, k, sum(case) + len(kind), torch.bfloat16)
+    Ho, Wo = (H + 2 * pad - k) // stride + 1, (W_ + 2 * pad - k) // stride + 1
+    M = N * Ho * Wo
+    scale, shift = 0.5 + torch.rand(Cout, generator=g), torch.randn(Cout, generator=g) * 0.3
+    res = torch.randn(N, Ho, Wo, Cout, generator=g).bfloat16().float()
+    up = torch.randn(N, Ho // 2, Wo // 2, Cout, generator=g).bfloat16().float()
+    act = torch.relu(torch.randn(N, Ho, Wo, Cout, generator=g)).bfloat16()
+    dev = "cuda"
+    xd, wd = x.to(dev, torch.bfloat16), w.to(dev, torch.bfloat16)
+    kw = dict(stride=stride, pad=pad)
+    bits = torch.full((M * Cout // 8 + 64,), 0xA5, dtype=torch.uint8, device=dev)
+    mb = _bits_of(act.to(dev))
+    use_scale = kind in ("f3", "f1", "sc")
+    use_shift = kind in ("f3", "f1", "sc", "b", "up")
+    if use_scale:
+        kw.update(scale=scale.to(dev))
+    if use_shift:
+        kw.update(shift=shift.to(dev))
+    if kind in ("f3", "d1"):
+        kw.update(res=res.to(dev, torch.bfloat16), res_mode=1)
+    if kind == "up":
+        kw.update(res=up.to(dev, torch.bfloat16), res_mode=2)
+    if kind in ("f3", "f1"):
+        kw.update(relu=True, bits_out=bits)
+    if kind in ("d1", "d3"):
+        kw.update(mask_bits=mb)
+    if force is not None:
+        L.set_tuning("igemm_force", force)
+    y = ops.conv2d(xd, wd, **kw)
+    name = L.last_dispatch()
+    torch.cuda.synchronize()
+    assert name == expect, (name, expect)
+    pix = _sample_pixels(N, Ho, Wo)
+    ref = _conv_ref_at(x, w, pix, stride, pad, Ho, Wo)
+    mag = ref.abs()
+    if use_scale:
+        ref = ref * scale.double()
+        mag = mag * scale.double()
+    if use_shift:
+        ref = ref + shift.double()
+        mag = mag + shift.double().abs()
+    if kind in ("f3", "d1"):
+        r_ = res.view(-1, Cout)[pix].double()
+        ref, mag = ref + r_, mag + r_.abs()
+    if kind == "up":
+        n_, r2 = pix // (Ho * Wo), pix % (Ho * Wo)
+        r_ = up[n_, (r2 // Wo) // 2, (r2 % Wo) // 2].double()
+        ref, mag = ref + r_, mag + r_.abs()
+    if kind in ("f3", "f1"):
+        ref = torch.relu(ref)
+    if kind in ("d1", "d3"):
+        ref = ref * (act.view(-1, Cout)[pix] > 0)
+    got = y.view(-1, Cout)[pix.to(dev)].double().cpu()
+    # ONE rounding of the fp32 sum: half a bf16 ulp of the result + the fp32 accumulation noise of the terms
+    err = (got - ref).abs()
+    bound = 2.0 ** -8 * ref.abs() + 3e-6 * mag * max(1.0, (k * k * Cin / 256) ** 0.5) + 1e-30
+    assert bool((err <= bound).all()), (float((err / bound).max()), float(err.max()))
+    assert torch.isfinite(y.float()).all()
+    if "bits_out" in kw:
+        assert torch.equal(bits[:M * Cout // 8], _bits_of(y)) and bool((bits[M * Cout // 8:] == 0xA5).all())
+        assert 0.1 < float((y > 0).float().mean()) < 0.9
+    if "mask_bits" in kw:
+        assert bool((y[act.to(dev) == 0] == 0).all())
+    return name
+
+
+DIRECT_FULL = [
+    # (N, H, W, Cin, Cout, k, stride, pad), kind, the kernel the DEFAULT dispatch picks
+    ((4, 50, 84, 256, 1024, 1, 1, 0), "f3", "igemm<bf16,128,64,4,1,pipe,tap,direct+res>"),       # res4 conv3
+    ((4, 100, 168, 128, 512, 1, 1, 0), "f3", "igemm<bf16,128,64,4,1,pipe,tap,direct+res>"),      # res3 conv3 (4 K slabs)
+    ((2, 25, 42, 512, 2048, 1, 1, 0), "f3", "igemm<bf16,128,64,4,1,pipe,tap,direct+res>"),       # res5 conv3, teacher
+    ((4, 50, 84, 1024, 256, 1, 1, 0), "f1", "igemm<bf16,64,64,2,2,flat,tap,k64,direct>"),        # res4 conv1
+    ((4, 100, 168, 512, 128, 1, 1, 0), "f1", "igemm<bf16,128,64,4,1,pipe,tap,direct>"),          # res3 conv1
+    ((4, 50, 84, 256, 256, 3, 1, 1), "f1", "igemm<bf16,128,64,4,1,flat,halo,direct>"),           # res4 conv2
+    ((4, 100, 168, 512, 1024, 1, 2, 0), "sc", "igemm<bf16,128,64,4,1,pipe,tap,direct>"),         # res4 shortcut (stride 2)
+    ((4, 50, 84, 256, 1024, 1, 1, 0), "d1", "igemm<bf16,128,64,4,1,pipe,tap,direct+res>"),       # res4 conv1 dgrad (+ skip gradient, mask of the block input)
+    ((4, 50, 84, 1024, 256, 1, 1, 0), "d3", "igemm<bf16,64,64,2,2,flat,tap,k64,direct>"),        # res4 conv3 dgrad
+    ((4, 50, 84, 256, 256, 3, 1, 1), "d3", "igemm<bf16,128,64,4,1,flat,halo,direct>"),           # res4 conv2 dgrad
+    ((4, 100, 168, 512, 256, 1, 1, 0), "up", "igemm<bf16,128,64,4,1,pipe,tap,direct+res>"),      # FPN lateral 3 (+ upsampled top-down map)
+    ((4, 25, 42, 2048, 256, 1, 1, 0), "b", "igemm<bf16,64,64,2,2,flat,tap,k64,direct>"),         # FPN lateral 5 (bias only)
+]
+
+
+@pytest.mark.parametrize("case,kind,expect", DIRECT_FULL)
+def test_direct_epilogue_default_dispatch_fullsize(case, kind, expect):
+    _check_direct(case, kind, expect)
+
+
+DIRECT_SMALL = [
+    (2, 25, 42, 64, 96, 3, 1, 1),      # halo, ragged M (2100), Cout = one and a half tiles
+    (1, 19, 23, 128, 256, 3, 1, 1),    # halo, tiny image
+    (2, 24, 40, 256, 72, 1, 1, 0),     # 1x1, Cout 72: the second channel tile holds 8 channels
+    (2, 25, 41, 256, 136, 1, 2, 0),    # strided 1x1, ragged everything
+    (3, 7, 9, 64, 200, 1, 1, 0),       # two K slabs (64-channel slabs: one), M = 189
+    (1, 5, 6, 32, 64, 1, 1, 0),        # ONE K slab (the once-per-tile pieces are waited for after the loop), one partial tile
+    (130, 1, 1, 2048, 136, 1, 1, 0),   # a linear layer
+]
+
+
+@pytest.mark.parametrize("kind", ["f3", "f1", "sc", "b", "d1", "d3"])
+@pytest.mark.parametrize("case", DIRECT_SMALL)
+def test_direct_epilogue_forced_templates(case, kind):
+    """each direct arm forced onto ragged shapes: the 128x64 tap tile (with and without the residual prefetch), the 64x64 long-K tile, the
+    128x64 halo tile"""
+    N, H, W_, Cin, Cout, k, stride, pad = case
+    res = kind in ("f3", "d1")
+    if k == 3:
+        if res:
+            pytest.skip("the halo tile has no residual prefetch (no 3x3 layer of the step has a residual)")
+        _check_direct(case, kind, "igemm<bf16,128,64,4,1,flat,halo,direct>", force=2)
+        return
+    _check_direct(case, kind, "igemm<bf16,128,64,4,1,pipe,tap,direct%s>" % ("+res" if res else ""), force=2)
+    if not res and Cin % 8 == 0:
+        from aldi_amd import _lib as L
+        L.reset_tuning()
+        _check_direct(case, kind, "igemm<bf16,64,64,2,2,flat,tap,k64,direct>", force=8)
+
+
+def test_direct_epilogue_upsampled_residual_ragged():
+    _check_direct((2, 26, 42, 256, 256, 1, 1, 0), "up", "igemm<bf16,128,64,4,1,pipe,tap,direct+res>", force=2)
+
+
+def test_direct_epilogue_off_restores_the_staged_kernels():
+    from aldi_amd import _lib as L
+    L.set_tuning("igemm_direct", 0)
+    from aldi_amd import ops
+    x = torch.randn(2, 25, 42, 256, device="cuda").bfloat16()
+    w = (torch.randn(1024, 1, 1, 256, device="cuda") / 16).bfloat16()
+    x = torch.randn(4, 50, 84, 256, device="cuda").bfloat16()
+    ops.conv2d(x, w, relu=True)
+    assert L.last_dispatch() == "igemm<bf16,128,64,4,1,pipe,tap>"

@@ -1,0 +1,92 @@
+"""The direct epilogue (igemm_direct) against the staged one on the res3..res5 layer shapes of the step: results (they may differ by the one
+bf16 rounding the direct form saves) and back-to-back launch times, interleaved A/B in one process."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from aldi_amd import _lib as L, ops
+
+# (N, H, W, Cin, Cout, k, stride, kind)   kind: f3 = forward conv3 (scale, shift, residual, ReLU, bits_out); f1 = forward conv1 / conv2 (scale, shift,
+# ReLU, bits_out); d1 = conv1 dgrad (residual + mask bits); d3 = conv3 / conv2 dgrad (mask bits); sc = shortcut (scale, shift)
+SHAPES = [(4, 50, 84, 256, 1024, 1, 1, "f3"), (4, 100, 168, 128, 512, 1, 1, "f3"), (4, 25, 42, 512, 2048, 1, 1, "f3"), (2, 50, 84, 256, 1024, 1, 1, "f3"),
+          (2, 100, 168, 128, 512, 1, 1, "f3"), (2, 25, 42, 512, 2048, 1, 1, "f3"),
+          (4, 50, 84, 1024, 256, 1, 1, "f1"), (4, 100, 168, 512, 128, 1, 1, "f1"), (4, 25, 42, 2048, 512, 1, 1, "f1"), (2, 50, 84, 1024, 256, 1, 1, "f1"),
+          (4, 50, 84, 256, 256, 3, 1, "f1"), (4, 100, 168, 128, 128, 3, 1, "f1"), (4, 25, 42, 512, 512, 3, 1, "f1"), (2, 50, 84, 256, 256, 3, 1, "f1"),
+          (4, 50, 84, 256, 1024, 1, 1, "d1"), (4, 100, 168, 128, 512, 1, 1, "d1"), (4, 25, 42, 512, 2048, 1, 1, "d1"),
+          (4, 50, 84, 1024, 256, 1, 1, "d3"), (4, 100, 168, 512, 128, 1, 1, "d3"), (4, 25, 42, 2048, 512, 1, 1, "d3"),
+          (4, 50, 84, 256, 256, 3, 1, "d3"), (4, 100, 168, 128, 128, 3, 1, "d3"),
+          (4, 100, 168, 512, 1024, 1, 2, "sc"), (4, 200, 336, 256, 128, 1, 2, "f1")]
+if len(sys.argv) > 1:
+    SHAPES = [s for s in SHAPES if s[-1] in sys.argv[1].split(",")]
+g = torch.Generator(device="cuda").manual_seed(0)
+ROUNDS, REPS = 5, 20
+tot = {0: 0.0, 7: 0.0}
+for (N, H, W, Cin, Cout, k, stride, kind) in SHAPES:
+    x = torch.randn(N, H, W, Cin, device="cuda", generator=g).bfloat16()
+    w = (torch.randn(Cout, k, k, Cin, device="cuda", generator=g) / (Cin * k * k) ** 0.5).bfloat16()
+    Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
+    r = torch.randn(N, Ho, Wo, Cout, device="cuda", generator=g).bfloat16()
+    act = torch.relu(torch.randn(N, Ho, Wo, Cout, device="cuda", generator=g)).bfloat16()
+    bits = torch.empty(N * Ho * Wo * Cout // 8, dtype=torch.uint8, device="cuda")
+    ops.conv2d(act.new_zeros(1, 1, 1, 8), act.new_zeros(8, 1, 1, 8))          # (warm the library)
+    # the mask bits of `act` the way the forward writes them: an identity "conv" is overkill -- pack on the host side of the test
+    mb = ((act.view(-1, 8) > 0).to(torch.int32) * (1 << torch.arange(8, device="cuda", dtype=torch.int32))).sum(1).to(torch.uint8).contiguous()
+    sc, sh = torch.rand(Cout, device="cuda") + 0.5, torch.randn(Cout, device="cuda") * 0.1
+    kw = dict(stride=stride, pad=k // 2)
+    if kind == "f3":
+        kw.update(scale=sc, shift=sh, res=r, res_mode=1, relu=True, bits_out=bits)
+    elif kind == "f1":
+        kw.update(scale=sc, shift=sh, relu=True, bits_out=bits)
+    elif kind == "sc":
+        kw.update(scale=sc, shift=sh)
+    elif kind == "d1":
+        kw.update(res=r, res_mode=1, mask_bits=mb)
+    elif kind == "d3":
+        kw.update(mask_bits=mb)
+    outs, names, bts = {}, {}, {}
+    for d in (0, 7):
+        L.reset_tuning(); L.set_tuning("igemm_direct", d)
+        y = torch.empty(N, Ho, Wo, Cout, device="cuda", dtype=torch.bfloat16)
+        bits.zero_()
+        ops.conv2d(x, w, out=y, **kw)
+        names[d] = L.last_dispatch()
+        torch.cuda.synchronize()
+        outs[d], bts[d] = y.float(), bits.clone()
+    a, b = outs[0], outs[7]
+    # fp32 evaluation of the same launch (torch arithmetic on the kernel's own fp32 product), rounded once
+    ref = ops.conv2d(x, w, stride=stride, pad=k // 2, want_f32=True)
+    if "scale" in kw:
+        ref = ref * sc + sh
+    if "res" in kw:
+        ref = ref + r.float()
+    if kw.get("relu"):
+        ref = torch.relu(ref)
+    if "mask_bits" in kw:
+        ref = ref * (act > 0)
+    ref = ref.bfloat16().float()
+    ulp = (ref.abs().clamp(min=2.0 ** -120) * 2.0 ** -7)
+    bad = ((b - ref).abs() > 1.01 * ulp).sum().item()          # direct vs the single-rounding reference
+    zero_mismatch = ((a - ref).abs() > 1.01 * ulp).sum().item()   # staged vs the same reference (double rounding shows here)
+    bits_bad = -1
+    if "bits_out" in kw:
+        want = ((outs[7].view(-1, 8) > 0).to(torch.int32) * (1 << torch.arange(8, device="cuda", dtype=torch.int32))).sum(1).to(torch.uint8)
+        bits_bad = (want != bts[7]).sum().item()
+    t = {0: [], 7: []}
+    y = torch.empty(N, Ho, Wo, Cout, device="cuda", dtype=torch.bfloat16)
+    for rd in range(ROUNDS):
+        for d in (0, 7):
+            L.set_tuning("igemm_direct", d)
+            ops.conv2d(x, w, out=y, **kw)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(REPS):
+                ops.conv2d(x, w, out=y, **kw)
+            e1.record(); torch.cuda.synchronize()
+            t[d].append(e0.elapsed_time(e1) * 1000 / REPS)
+    m0, m7 = sorted(t[0])[ROUNDS // 2], sorted(t[7])[ROUNDS // 2]
+    tot[0] += m0; tot[7] += m7
+    fl = 2.0 * N * Ho * Wo * Cin * Cout * k * k
+    print("%-38s %-3s staged %6.1f us (%4.0f TF)  direct %6.1f us (%4.0f TF)  %+5.1f %%  | direct>1ulp %d  staged>1ulp %d  bits-bad %d  max|d| %.3g | %s -> %s" % (
+        (N, H, W, Cin, Cout, k, stride), kind, m0, fl / m0 / 1e6, m7, fl / m7 / 1e6, 100 * (m7 / m0 - 1), bad, zero_mismatch, bits_bad,
+        (a - b).abs().max().item(), names[0].replace("igemm<bf16,", "<"), names[7].replace("igemm<bf16,", "<")), flush=True)
+print("sum staged %.1f us, direct %.1f us" % (tot[0], tot[7]))
+L.reset_tuning()

@@ -1,0 +1,158 @@
+"""Static check of the generated gfx950 code for the one hazard hand-issued LDS reads bring: `asm volatile("ds_read_b128 %0, ...")` returns at
+once as far as the compiler knows, the data lands later, and only our own `s_waitcnt lgkmcnt(0)` (tile_prims.h: frag_wait) orders a use behind it.
+Nothing stops the register allocator from COPYING such a register (a phi on a control-flow edge, a split live range) between the read and the
+wait -- it then copies what the register held before.  This script compiles a .hip file to assembly, builds each kernel's control-flow graph
+and reports every instruction that touches a register with a hand-issued LDS read still in flight.
+
+    python tools/isa_hazard_check.py aldi_amd/csrc/igemm.hip [more.hip ...]        exit status 1 if anything is found
+"""
+import os
+import re
+import subprocess
+import sys
+import tempfile
+
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-S", "--cuda-device-only"]
+REG = re.compile(r"\b([va])(?:(\d+)|\[(\d+):(\d+)\])")
+
+
+def regs_of(text):
+    out = set()
+    for m in REG.finditer(text):
+        kind = m.group(1)
+        if m.group(2) is not None:
+            out.add((kind, int(m.group(2))))
+        else:
+            out.update((kind, i) for i in range(int(m.group(3)), int(m.group(4)) + 1))
+    return out
+
+
+def parse_kernels(asm_text):
+    """-> {kernel name: [(label or None, instruction text, in_asm_block)]}"""
+    kernels, cur, name, in_asm = {}, None, None, False
+    for line in asm_text.splitlines():
+        s = line.strip()
+        m = re.match(r"^([A-Za-z_][\w$.]*):", line)
+        if m and not line.startswith(".L") and cur is None and (m.group(1).startswith("_Z") or "kernel" in m.group(1)):
+            name, cur = m.group(1), []
+            continue
+        if cur is None:
+            continue
+        if s.startswith(";;#ASMSTART"):
+            in_asm = True
+            continue
+        if s.startswith(";;#ASMEND"):
+            in_asm = False
+            continue
+        lm = re.match(r"^(\.LBB[\w]*):", line)
+        if lm:
+            cur.append((lm.group(1), None, False))
+            continue
+        if not s or s.startswith(";") or s.startswith("."):
+            continue
+        ins = s.split(";")[0].strip()
+        if ins:
+            cur.append((None, ins, in_asm))
+        if ins.startswith("s_endpgm"):
+            kernels[name] = cur
+            cur, name = None, None
+    return kernels
+
+
+def check_kernel(items):
+    # basic blocks
+    blocks, order, cur = {}, [], "entry"
+    blocks[cur] = []
+    order.append(cur)
+    for label, ins, in_asm in items:
+        if label is not None:
+            blocks.setdefault(label, [])
+            if label not in order:
+                order.append(label)
+            cur = label
+            continue
+        blocks[cur].append((ins, in_asm))
+    succ = {b: [] for b in order}
+    for i, b in enumerate(order):
+        fall = True
+        for ins, _ in blocks[b]:
+            m = re.match(r"^(s_branch|s_cbranch_\w+)\s+(\.LBB\w+)", ins)
+            if m:
+                if m.group(2) in succ:
+                    succ[b].append(m.group(2))
+                if m.group(1) == "s_branch":
+                    fall = False
+            if ins.startswith("s_endpgm"):
+                fall = False
+        if fall and i + 1 < len(order):
+            succ[b].append(order[i + 1])
+
+    def transfer(b, pend, report=None):
+        pend = set(pend)
+        seen_term = False
+        for ins, in_asm in blocks[b]:
+            op = ins.split()[0]
+            if op == "s_waitcnt" and "lgkmcnt(0)" in ins:
+                pend.clear()
+                continue
+            touched = regs_of(ins[len(op):])
+            if op.startswith("ds_read") and in_asm:
+                dst = regs_of(ins[len(op):].split(",")[0])
+                bad = (touched - dst) & pend
+                if bad and report is not None:
+                    report.append((b, ins, sorted(bad)))
+                pend |= dst
+                continue
+            bad = touched & pend
+            if bad and report is not None:
+                report.append((b, ins, sorted(bad)))
+        return pend
+    IN = {b: set() for b in order}
+    changed = True
+    while changed:
+        changed = False
+        for b in order:
+            out = transfer(b, IN[b])
+            for t in succ[b]:
+                if not out <= IN[t]:
+                    IN[t] |= out
+                    changed = True
+    report = []
+    for b in order:
+        transfer(b, IN[b], report)
+    return report
+
+
+def check_file(path, keep=None):
+    with tempfile.TemporaryDirectory() as td:
+        out = os.path.join(td, "k.s")
+        subprocess.check_call([HIPCC] + FLAGS + [path, "-o", out], stderr=subprocess.DEVNULL)
+        text = open(out).read()
+        if keep:
+            open(keep, "w").write(text)
+    found = {}
+    for name, items in parse_kernels(text).items():
+        if not any(in_asm and ins.startswith("ds_read") for _, ins, in_asm in items if ins):
+            continue
+        rep = check_kernel(items)
+        found[name] = rep
+    return found
+
+
+def main():
+    rc = 0
+    for path in sys.argv[1:]:
+        res = check_file(path)
+        n_bad = sum(1 for r in res.values() if r)
+        print(f"{path}: {len(res)} kernels with hand-issued LDS reads, {n_bad} with a register touched before its wait")
+        for name, rep in res.items():
+            for b, ins, regs in rep[:12]:
+                print(f"  {name[:90]}  {b}: {ins}   <- in flight: {regs[:8]}")
+            if rep:
+                rc = 1
+    return rc
+
+
+if __name__ == "__main__":
+    sys.exit(main())
