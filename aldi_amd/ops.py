@@ -193,6 +193,11 @@ def conv_wgrad_group(problems) -> None:
     L.call("aldi_conv_wgrad_group", arr, len(problems), stream_ptr())
 
 
+def noop() -> None:
+    """an empty one-workgroup launch on the current stream (aldi_noop): a marker in kernel traces"""
+    L.call("aldi_noop", stream_ptr())
+
+
 def bias_grad(g: torch.Tensor, db: torch.Tensor) -> None:
     Cc = g.shape[-1]
     L.call("aldi_bias_grad", _p(g), _p(db), g.numel() // Cc, Cc, dtype_code(g.dtype), stream_ptr())

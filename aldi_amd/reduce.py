@@ -16,6 +16,11 @@ import torch
 import torch.distributed as dist
 
 
+import os
+
+_TRACE_MARKERS = os.environ.get("ALDI_DP_TRACE", "0") == "1"
+
+
 def merge_ranges(ranges: Sequence[Tuple[int, int]]) -> List[Tuple[int, int]]:
     out: List[Tuple[int, int]] = []
     for lo, hi in sorted(r for r in ranges if r[1] > r[0]):
@@ -126,6 +131,12 @@ class BucketedReducer:
             for ev in self.events:
                 self.launch_stream.wait_event(ev)
             with torch.cuda.stream(self.launch_stream):
+                if _TRACE_MARKERS:
+                    # (profiling aid, ALDI_DP_TRACE=1: an empty kernel on the launch stream right where the bucket's collective is issued -- RCCL
+                    # launches NO kernel for an in-place collective of a one-rank group, so on a 1-GPU box this marker is what a kernel trace
+                    # can show of the point in the backward at which the bucket's exchange becomes runnable; tools/dp_trace.py)
+                    from . import ops
+                    ops.noop()
                 w = self._exchange(lo, hi)
         else:
             w = self._exchange(lo, hi)

@@ -211,6 +211,26 @@ def cpu_baseline(cfg, height, width):
     out["single_thread"] = {"value": round(2.0 / dts, 4), "unit": "images/sec", "cores": 1,
                             "sample": f"1 ALDI step of 1 labeled + 1 unlabeled {ws}x{hs} image ({hs * ws / (height * width):.3f} of the headline "
                                       f"pixels per image), 1 thread, {dts:.2f} s/step"}
+    # (4) why the multi-thread legs use min(cores, 32) although north_star says "the box's own host cores": the oracle's dominant operation
+    # (an fp32 3x3 convolution of one 200 x 336 x 256 map, torch-CPU) timed at 1 / nthr / EVERY hardware thread, each in its own process with a
+    # hard 30 s limit -- oversubscribed, torch-CPU does not slow down gracefully (measured on this pool's 256-thread hosts: the whole ALDI step
+    # at 256 threads ran at 0.003 images/s against 1.8 at 32), so the full step is never run that way; the probe puts the choice in the line
+    probe = ("import sys, time, torch; torch.set_num_threads(int(sys.argv[1])); x = torch.randn(1, 256, 200, 336); w = torch.randn(256, 256, 3, 3); "
+             "torch.nn.functional.conv2d(x, w, padding=1); t = time.perf_counter(); n = 0\n"
+             "while time.perf_counter() - t < 2.0: torch.nn.functional.conv2d(x, w, padding=1); n += 1\n"
+             "print(n * 2 * 256 * 256 * 9 * 200 * 336 / (time.perf_counter() - t) / 1e9)")
+    legs = {}
+    for nt in sorted({1, nthr, ncpu}):
+        try:
+            r = subprocess.run([sys.executable, "-c", probe, str(nt)], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=30)
+            legs[str(nt)] = round(float(r.stdout.decode().strip().splitlines()[-1]), 1) if r.returncode == 0 else "failed"
+        except subprocess.TimeoutExpired:
+            legs[str(nt)] = "no result within 30 s"
+        except (ValueError, IndexError):
+            legs[str(nt)] = "failed"
+    out["thread_scaling"] = {"unit": "GFLOP/s", "conv3x3_gflops_by_threads": legs,
+                             "sample": f"fp32 torch-CPU conv2d 256 -> 256, 3x3, one 200x336 map (the oracle's dominant operation), ~1.5 s per thread count in "
+                                       f"its own process, 30 s limit; the legs above use {nthr} of the {ncpu} hardware threads because of this"}
     torch.set_num_threads(1)
     return out
 
@@ -321,11 +341,51 @@ def profile_insitu(step_fn, table_path=None):
         nc = kw.get("n_compute") or (teacher_compute.numel() if teacher_compute is not None else 0)
         return timed("ema", (n,), 0.0, n * 12 + 2 * nc, orig_ema, teacher, student, teacher_compute, n, *a, **kw)
 
-    def roialign(feats, rois, R, P, pooled, backward):
-        return timed("roialign_fwd", (R,), 0.0, pooled.numel() * pooled.element_size(), orig_ra, feats, rois, R, P, pooled, backward)
+    def roi_touched_bytes(feats, rois, R, esz):
+        """bytes of the feature maps a RoIAlign forward MUST read: the union of the ROIs' bilinear footprints on their pyramid levels (every
+        touched map element counted once; Detectron2's level rule and ROIAlignV2's half-pixel offset).  Evaluated on the device from the ROI
+        list of the profiled step (2-d difference arrays per level and image), outside the timed region."""
+        r = rois[:R].float()
+        ok = r[:, 0] >= 0
+        img = r[:, 0].clamp(min=0).long()
+        area = ((r[:, 3] - r[:, 1]) * (r[:, 4] - r[:, 2])).clamp(min=0)
+        lvl = torch.floor(4 + torch.log2(torch.sqrt(area) / 224 + 1e-8)).clamp(2, 5).long() - 2
+        nimg = int(img.max().item()) + 1 if R else 1
+        total = 0
+        for l in range(4):
+            H, W_ = int(feats.H[l]), int(feats.W[l])
+            if H == 0:
+                continue
+            sc = float(feats.scale[l])
+            m = ok & (lvl == l)
+            if not bool(m.any()):
+                continue
+            x0 = torch.floor(r[m, 1] * sc - 0.5).clamp(0, W_ - 1).long()
+            y0 = torch.floor(r[m, 2] * sc - 0.5).clamp(0, H - 1).long()
+            x1 = (torch.floor(r[m, 3] * sc - 0.5) + 1).clamp(0, W_ - 1).long()
+            y1 = (torch.floor(r[m, 4] * sc - 0.5) + 1).clamp(0, H - 1).long()
+            d = torch.zeros((nimg, H + 1, W_ + 1), dtype=torch.int32, device=rois.device)
+            one = torch.ones_like(x0, dtype=torch.int32)
+            b_ = img[m]
+            d.index_put_((b_, y0, x0), one, accumulate=True)
+            d.index_put_((b_, y0, x1 + 1), -one, accumulate=True)
+            d.index_put_((b_, y1 + 1, x0), -one, accumulate=True)
+            d.index_put_((b_, y1 + 1, x1 + 1), one, accumulate=True)
+            cover = d.cumsum(1).cumsum(2)[:, :H, :W_] > 0
+            total += int(cover.sum().item()) * int(feats.C) * esz
+        return total
 
-    def roialign_backward(feats, rois, R, P, g_pooled, N, **kw):
-        return timed("roialign_bwd", (R,), 0.0, g_pooled.numel() * g_pooled.element_size(), orig_rab, feats, rois, R, P, g_pooled, N, **kw)
+    def roialign(feats, rois, R, P, pooled, backward):
+        # compulsory bytes: the pooled tensor written once + every touched map element read once
+        nby = pooled.numel() * pooled.element_size() + roi_touched_bytes(feats, rois, R, pooled.element_size())
+        return timed("roialign_fwd", (R,), 0.0, nby, orig_ra, feats, rois, R, P, pooled, backward)
+
+    def roialign_backward(feats, rois, R, P, g_pooled, N, grad_dtype=torch.float32, **kw):
+        # compulsory bytes: the pooled gradient read once + every element of the four gradient maps written once (the gather form writes zeros too)
+        gsz = torch.empty((), dtype=grad_dtype).element_size()
+        maps = sum(N * int(feats.H[l]) * int(feats.W[l]) for l in range(4)) * int(feats.C) * gsz
+        return timed("roialign_bwd", (R,), 0.0, g_pooled.numel() * g_pooled.element_size() + maps, orig_rab, feats, rois, R, P, g_pooled, N,
+                     grad_dtype=grad_dtype, **kw)
     ops.conv2d, ops.conv_wgrad, ops.conv_wgrad_group, ops.conv2d_group = conv2d, conv_wgrad, conv_wgrad_group, conv2d_group
     ops.bottleneck_fused, ops.sgd_step, ops.ema_update, ops.roialign, ops.roialign_backward = bottleneck_fused, sgd_step, ema_update, roialign, roialign_backward
     ops.sgd_step_dev = sgd_step_dev
@@ -645,7 +705,7 @@ def main():
                                                  "us_per_step": round(prof[fam]["ms"] * 1e3, 1), "launches_per_step": prof[fam]["launches"],
                                                  "algorithmic_bytes_per_step": prof[fam]["bytes"]}
                                            for fam in ("sgd", "ema", "roialign_fwd", "roialign_bwd") if prof[fam]["launches"] and prof[fam]["ms"] > 0},
-                           "hbm_kernels_note": "sgd / ema: every state word read and written once; roialign_*: the pooled tensor's bytes only (the gather side is data dependent), so a lower bound of their traffic",
+                           "hbm_kernels_note": "compulsory bytes against the HBM peak.  sgd / ema: every state word read and written once; roialign_fwd: the pooled tensor written once + the union of the ROIs' bilinear footprints read once (evaluated from the profiled step's ROI list); roialign_bwd: the pooled gradient read once + every element of the four gradient maps written once",
                            "step_algorithmic_tflop": step_tflop if (headline and not args.align) else None,
                            "step_frac_of_mfma_peak": round(step_tflop / (ms * 1e-3) / PEAK_BF16_TFLOPS, 4) if (headline and not args.align) else None}
         if any(prof[f]["launches"] for f in ("msda_fwd", "msda_bwd", "msda_bwd_self")):

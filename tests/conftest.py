@@ -23,6 +23,15 @@ def pytest_collection_modifyitems(config, items):
             it.add_marker(skip)
 
 
+@pytest.fixture(scope="session", autouse=True)
+def _bounded_cpu_threads():
+    """the CPU oracle's convolutions (torch-CPU, small batches) stop scaling around 32 threads and slow down by an order of magnitude
+    when every hardware thread of a 256-thread host is used (measured in bench.py's cpu_baseline): bound them for the whole session"""
+    import torch
+    torch.set_num_threads(max(1, min(32, os.cpu_count() or 1)))
+    yield
+
+
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN

@@ -339,3 +339,59 @@ def test_cfg4_fullsize_deformable_detr_properties():
     assert torch.equal(T.master[a:b], at_ema[a:b])
     (a, b), = W.ranges(["class_embed.weight"])
     assert not torch.equal(T.master[a:b], at_ema[a:b])
+
+
+def test_cfg3_fullsize_vitdet_b_properties():
+    """BASELINE configs[3] at FULL size: ALDI++ on the ViTDet-B detector (Base-RCNN-VitDetB.yaml: ViT-B/16 -- 768 wide, 12 blocks, 12 heads, 14 x 14
+    windows with four global blocks -- SimpleFeaturePyramid, AdamW with the layer-wise lr decay 0.7 the reference turns on for this backbone,
+    aldi/backbone.py:38-43,66-84, aldi/trainer.py:200-209), per-GPU workload 1 labeled + 1 unlabeled 1333 x 800 image, bf16, fused student pass.
+    Size-independent properties over three iterations: the reference's loss keys, finite values, pyramid / token geometry, every trainable
+    tensor moves (nothing is frozen in this detector), deeper blocks move more than shallow ones under the layer decay, the teacher trails
+    the student, pseudo labels are produced."""
+    from aldi_amd.config import add_aldi_config, get_cfg
+    from aldi_amd.trainer import ALDITrainer, EngineAdamW
+    cfg = get_cfg()
+    add_aldi_config(cfg)
+    cfg.merge_from_file(os.path.join(ROOT, "configs", "cityscapes", "ALDI-VitDetB-Cityscapes.yaml"))
+    cfg.merge_from_list(["SOLVER.IMS_PER_BATCH", 2, "SEED", 1, "SYNTHETIC.HEIGHT", 800, "SYNTHETIC.WIDTH", 1333, "DOMAIN_ADAPT.TEACHER.THRESHOLD", 0.05,
+                         "SOLVER.WARMUP_ITERS", 0])
+    assert cfg.MODEL.BACKBONE.NAME == "build_vitdet_b_backbone" and cfg.SOLVER.OPTIMIZER == "ADAMW" and cfg.SOLVER.IMS_PER_GPU == 1
+    random.seed(1234)
+    torch.manual_seed(100)
+    tr = ALDITrainer(cfg)
+    opt = tr._trainer.optimizer
+    assert tr.model.vitdet and isinstance(opt, EngineAdamW) and opt.lr_decay_rate == 0.7 and opt.num_layers == 12
+    W, T = tr.model.weights, tr.ema.model.weights
+    sd0 = {k: v.clone() for k, v in tr.model.state_dict().items()}
+    assert sd0["backbone.net.blocks.11.attn.qkv.weight"].shape == (3 * 768, 768) and sd0["backbone.net.patch_embed.proj.weight"].shape == (768, 3, 16, 16)
+    assert sum(1 for k in sd0 if k.startswith("backbone.net.blocks.") and k.endswith("attn.qkv.weight")) == 12
+    w0 = W.master.clone()
+    for it in range(3):
+        tr.iter = it
+        tr.before_step()
+        tr.run_step()
+        tr.after_step()
+        assert tr._trainer._fused_done
+    torch.cuda.synchronize()
+    ld = {k: float(v) for k, v in tr._trainer.last_loss_dict.items()}
+    src = [f"{k}_source_strong" for k in ("loss_cls", "loss_box_reg", "loss_rpn_cls", "loss_rpn_loc")]
+    dst = [f"{k}_distill" for k in ("loss_cls", "loss_box_reg", "loss_rpn_cls", "loss_rpn_loc", "loss_obj_bce", "loss_rpn_l1", "loss_cls_ce", "loss_roih_l1")]
+    assert set(src + dst) <= set(ld), sorted(ld)
+    assert all(v == v and 0.0 <= v < 1e3 for v in ld.values()), ld
+    assert int(tr.model.engine.err) == 0 and int(tr.ema.model.engine.err) == 0
+    c = tr.model._last_fused
+    assert [tuple(p.shape[1:3]) for p in c.P] == [(200, 336), (100, 168), (50, 84), (25, 42), (13, 21)]          # 800 x 1344 padded input, strides 4 .. 64
+    assert int(tr.ema.model._last_inference.pseudo["count"].sum()) > 0
+    sd1 = tr.model.state_dict()
+    assert set(sd1) == set(sd0)
+    still = [k for k in sd1 if torch.equal(sd1[k], sd0[k])]
+    assert not still, still[:8]                                          # nothing frozen: every tensor of the state moved
+    assert all(torch.isfinite(v).all() for v in sd1.values())
+    # layer-wise lr decay 0.7: with AdamW's normalised steps the update of a block scales with its lr multiplier 0.7 ** (12 - i)
+    def moved(k):
+        return float((sd1[k].float() - sd0[k].float()).abs().mean())
+    m0, m11 = moved("backbone.net.blocks.0.mlp.fc1.weight"), moved("backbone.net.blocks.11.mlp.fc1.weight")
+    assert m11 > 10 * m0 > 0, (m0, m11)                                  # (0.7 ** 11 = 0.02)
+    # the teacher (EMA 0.9996) trails: it has moved, and far less than the student
+    dt, ds = float((T.master - w0).abs().max()), float((W.master - w0).abs().max())
+    assert 0 < dt < 0.05 * ds, (dt, ds)

@@ -535,17 +535,19 @@ def test_checkpoint_round_trip_and_ema_start(tmp_path):
     tr2 = ALDITrainer(cfg)
     tr2.resume_or_load(resume=True)
     assert tr2.start_iter == 2
+    s2, t2 = tr2.model.state_dict(), tr2.ema.model.state_dict()
     for k in s_sd:
-        assert torch.equal(tr2.model.state_dict()[k], s_sd[k]), k
-        assert torch.equal(tr2.ema.model.state_dict()[k], t_sd[k]), k
+        assert torch.equal(s2[k], s_sd[k]), k
+        assert torch.equal(t2[k], t_sd[k]), k
     cfg3 = _cfg(False)
     cfg3.OUTPUT_DIR = str(tmp_path / "other")
     cfg3.MODEL.WEIGHTS = os.path.join(cfg.OUTPUT_DIR, "model_0000001.pth")
     tr3 = ALDITrainer(cfg3)
     tr3.resume_or_load(resume=False)
     assert tr3.start_iter == 0
+    s3 = tr3.model.state_dict()
     for k in s_sd:
-        assert torch.equal(tr3.model.state_dict()[k], t_sd[k]), k             # student := checkpoint's EMA weights
+        assert torch.equal(s3[k], t_sd[k]), k                                  # student := checkpoint's EMA weights
 
 
 def test_teacher_coco_evaluation_and_best_checkpoint(tmp_path):

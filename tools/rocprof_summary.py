@@ -91,6 +91,34 @@ def streams(d, t_from="0"):
             print("%8.3f %8.3f q%d %7.1fus %s wg=%d" % ((s_ - t0) / 1e6, (e - t0) / 1e6, q, (e - s_) / 1e3, short(n), gx // max(wx, 1)))
 
 
+def dp(d):
+    """data-parallel trace (tools/dp_trace.py) of one step: the weight-gradient launches, the markers of the gradient exchange (noop_kernel on
+    the exchange's launch stream = the point at which a bucket's collective is issued behind its producers' events) and any RCCL kernel, by start
+    time, with their hardware queues -- does the exchange of a bucket start before the LAST weight-gradient launch of the backward ends?"""
+    dbs = glob.glob(d + "/**/*_results.db", recursive=True)
+    cur = sqlite3.connect(dbs[0]).cursor()
+    rows = list(cur.execute("select name, start, end, queue_id from kernels order by start"))
+    sgd = [i for i, r in enumerate(rows) if delim in r[0]]
+    a, b = sgd[-1 - int(per_step)], sgd[-1]
+    step = rows[a + 1:b + 1]
+    t0 = rows[a][2]
+    pick = [r for r in step if "wgrad" in r[0] or "noop_kernel" in r[0] or "nccl" in r[0].lower() or "rccl" in r[0].lower() or "sgd_kernel" in r[0]]
+    wg = [r for r in pick if "wgrad" in r[0]]
+    last_wg_end = max(r[2] for r in wg)
+    first_wg_start = min(r[1] for r in wg)
+    marks = [r for r in pick if "noop_kernel" in r[0]]
+    coll = [r for r in pick if "nccl" in r[0].lower() or "rccl" in r[0].lower()]
+    print("# one step of tools/dp_trace.py (world size 1, RCCL backend, ALDI_DP_FORCE=1, ALDI_DP_TRACE=1): weight-gradient launches, exchange markers, RCCL kernels, optimizer")
+    print("# ms from the step's first kernel: start, end, hardware queue, kernel")
+    for n, s_, e, q in pick:
+        tag = "wgrad" if "wgrad" in n else "EXCHANGE-MARK" if "noop_kernel" in n else "sgd" if "sgd_kernel" in n else "RCCL"
+        print("%8.3f %8.3f q%d %-14s %s" % ((s_ - t0) / 1e6, (e - t0) / 1e6, q, tag, n.replace("(anonymous namespace)::", "")[:70]))
+    print("# weight gradients: first launch starts %.3f ms, last one ends %.3f ms" % ((first_wg_start - t0) / 1e6, (last_wg_end - t0) / 1e6))
+    print("# exchange buckets issued: %d; %d of them BEFORE the last weight-gradient launch ends (%s ms before its end)" % (
+        len(marks), sum(1 for r in marks if r[1] < last_wg_end), ", ".join("%.3f" % ((last_wg_end - r[1]) / 1e6) for r in marks if r[1] < last_wg_end)))
+    print("# RCCL kernels in the step: %d%s" % (len(coll), "" if coll else "  (RCCL launches no kernel for an in-place collective of a one-rank group)"))
+
+
 def overlap(d):
     """multi-stream view of one step: union busy time, time with >= 2 kernels in flight, idle time"""
     dbs = glob.glob(d + "/**/*_results.db", recursive=True)
@@ -228,4 +256,4 @@ def pmc(fetch_dir, write_dir, source_sha="", git_sha=""):
 
 
 if __name__ == "__main__":
-    {"stats": stats, "pmc": pmc, "gaps": gaps, "overlap": overlap, "phases": phases, "window": window, "launches": launches, "streams": streams}[sys.argv[1]](*sys.argv[2:])
+    {"stats": stats, "pmc": pmc, "gaps": gaps, "overlap": overlap, "phases": phases, "window": window, "launches": launches, "streams": streams, "dp": dp}[sys.argv[1]](*sys.argv[2:])
