@@ -47,6 +47,7 @@ const Knob kKnobs[] = {
     {"igemm_halo_f32", &AldiTuning::igemm_halo_f32, 0},
     {"igemm_f32_tile64_max", &AldiTuning::igemm_f32_tile64_max, 4096},
     {"igemm_direct", &AldiTuning::igemm_direct, 7},
+    {"igemm_lean", &AldiTuning::igemm_lean, 1},
     {"wgrad_lean", &AldiTuning::wgrad_lean, 1},
     {"wgrad_big_min", &AldiTuning::wgrad_big_min, 28},
     {"wgrad_big_slots", &AldiTuning::wgrad_big_slots, 256},

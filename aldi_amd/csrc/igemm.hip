@@ -36,6 +36,7 @@ struct ConvDev {
     int M, K, xcd, dbg;
     unsigned x_bytes, w_bytes;
     int ksplit, slabs_per_split;     // split-K (plain 1x1 / linear): blockIdx.z = slice, slabs_per_split K slabs each
+    int lean;                        // plain 1x1 / linear with whole K slabs (direct-epilogue tiles): the K loop's DMA offsets are running sums
     // ReLU masks as BITS (bf16, Cout % 8 == 0, plain output layout): [M][Cout / 8] bytes, bit c % 8 of byte c / 8 = (y[m][c] > 0).
     // bits_out: written by the forward launch beside y; mask_bits: read by the backward launch instead of the 16x larger `mask` tensor.
     const unsigned char* mask_bits; unsigned char* bits_out;
@@ -401,8 +402,9 @@ __device__ __forceinline__ void igemm_epilogue_direct(const ConvDev& p, f32x4_t 
 // body of one workgroup: tile `bid` of an nmt x nnt tile grid of problem p (launched alone: igemm_kernel; as one of several
 // problems of the same layer shape sharing a launch: igemm_group_kernel)
 // EPI: 0 = the staged epilogue; 1 = the direct epilogue (bf16, BN = 64); 2 = direct + the residual tile prefetched into the LDS
-template <typename T, int BM, int BN, int WM, int WN, int KC, bool PIPE, bool HALO = false, int EPI = 0>
+template <typename T, int BM, int BN, int WM, int WN, int KC, bool PIPE, bool HALO = false, int EPI = 0, bool LEAN = false>
 __device__ __forceinline__ void igemm_body(const ConvDev& p, int bid, const int nmt, const int nnt) {
+    static_assert(!LEAN || (EPI != 0 && !HALO), "lean K loop: the direct-epilogue tap tiles");
     constexpr int NT = WM * WN * 64;
     constexpr bool DIRECT = EPI != 0, RESL = EPI == 2;
     static_assert(!DIRECT || (sizeof(T) == 2 && BN == 64 && (BN / WN) % 32 == 0 && BM * BN / 32 <= NT), "direct epilogue: bf16, 64-channel tiles");
@@ -601,8 +603,29 @@ __device__ __forceinline__ void igemm_body(const ConvDev& p, int bid, const int 
         buf ^= 1;
     }
     } else {
+    // LEAN (a template parameter: plain 1x1 / linear layers with whole K slabs on the direct-epilogue tiles = every res3..res5 1x1 at stride 1):
+    // the generic issue below spends ~15 scalar / vector instructions per DMA on taps, border masks and K tails that do not exist there --
+    // more issue slots than the slab's MFMAs take, and the kernels are issue-bound (measured: -10..-14 % on the 64x64 long-K tile, -3..-4 %
+    // on 128x64).  A slab's offsets are the previous slab's + one slab of bytes (an out-of-range offset stays out of range: bit 31 is set
+    // and K * 2 < 2^31), so a DMA costs one add, and the loop carries no tap / channel counters.
     unsigned a_voff[A_IT], a_mask[A_IT];
     int a_kce[A_IT];
+    unsigned b_voff[B_IT];
+    int b_kce[B_IT];
+    const bool ktail = !LEAN && (p.K % BK) != 0;  // only 1x1 convs with a short / ragged K
+    if constexpr (LEAN) {
+#pragma unroll
+        for (int it = 0; it < A_IT; ++it) {
+            const int c = tid + it * NT, row = c >> LOG, kce = swz<KC>(row, c & (KC - 1)), m = m0 + row;
+            a_voff[it] = m < p.M ? ((unsigned)m * (unsigned)p.Cin + (unsigned)(kce * EP)) * (unsigned)sizeof(T) : OOB;
+        }
+#pragma unroll
+        for (int it = 0; it < B_IT; ++it) {
+            const int c = tid + it * NT, row = c >> LOG, kce = swz<KC>(row, c & (KC - 1));
+            const int co = n0 + direct_perm<BN / WN>(row);
+            b_voff[it] = (c < BN * KC) && co < p.Cout ? ((unsigned)co * (unsigned)p.K + (unsigned)(kce * EP)) * (unsigned)sizeof(T) : OOB;
+        }
+    } else {
     const bool ident = p.KH * p.KW == 1 && p.stride == 1 && p.pad == 0;   // 1x1: pixel index == input index, no divisions
 #pragma unroll
     for (int it = 0; it < A_IT; ++it) {
@@ -628,8 +651,6 @@ __device__ __forceinline__ void igemm_body(const ConvDev& p, int bid, const int 
             if ((unsigned)(hi0 + kh_) < (unsigned)p.H) mask |= colbits << (kh_ * p.KW);
         a_mask[it] = ok ? mask : 0u;
     }
-    unsigned b_voff[B_IT];
-    int b_kce[B_IT];
 #pragma unroll
     for (int it = 0; it < B_IT; ++it) {
         int c = tid + it * NT, row = c >> LOG, kce = swz<KC>(row, c & (KC - 1));
@@ -638,11 +659,25 @@ __device__ __forceinline__ void igemm_body(const ConvDev& p, int bid, const int 
         b_voff[it] = ok ? (unsigned)((long)co * p.K + kce * EP) * (unsigned)sizeof(T) : OOB;
         b_kce[it] = kce * EP;
     }
-    const bool ktail = (p.K % BK) != 0;          // only 1x1 convs with a short / ragged K
+    }
 
     int tap = 0, kh = 0, kw = 0, ci0 = 0;   // tap / channel offset of the slab being LOADED (block uniform)
 
     auto issue_slab = [&](int s, int buf) {
+        if constexpr (LEAN) {
+#pragma unroll
+            for (int it = 0; it < A_IT; ++it) {
+                glds16(rx, &lds[buf][wbase + it * NT], a_voff[it]);
+                a_voff[it] += (unsigned)(BK * sizeof(T));
+            }
+#pragma unroll
+            for (int it = 0; it < B_IT; ++it)
+                if (wbase + it * NT < BN * KC) {                               // wave-uniform
+                    glds16(rw, &lds[buf][BM * KC + wbase + it * NT], b_voff[it]);
+                    b_voff[it] += (unsigned)(BK * sizeof(T));
+                }
+            return;
+        }
         const unsigned tap_off = (unsigned)(((kh * p.W + kw) * p.Cin + ci0) * (int)sizeof(T));
 #pragma unroll
         for (int it = 0; it < A_IT; ++it) {
@@ -1002,9 +1037,9 @@ int launch_halo_rs(const ConvDev& d, hipStream_t st) {
 
 // (the 240-pixel halo tile is sized for TWO workgroups per CU: 6 waves each = 3 waves per SIMD, 80 KB of LDS each)
 template <int BM, int NT, bool HALO> constexpr int min_waves_per_simd() { return HALO && BM == 240 ? 2 * NT / 256 : 1; }
-template <typename T, int BM, int BN, int WM, int WN, int KC, bool PIPE, bool HALO = false, int EPI = 0>
+template <typename T, int BM, int BN, int WM, int WN, int KC, bool PIPE, bool HALO = false, int EPI = 0, bool LEAN = false>
 __global__ __launch_bounds__(WM* WN * 64, (min_waves_per_simd<BM, WM * WN * 64, HALO>())) void igemm_kernel(ConvDev p) {
-    igemm_body<T, BM, BN, WM, WN, KC, PIPE, HALO, EPI>(p, (int)(blockIdx.y * gridDim.x + blockIdx.x), (int)gridDim.x, (int)gridDim.y);
+    igemm_body<T, BM, BN, WM, WN, KC, PIPE, HALO, EPI, LEAN>(p, (int)(blockIdx.y * gridDim.x + blockIdx.x), (int)gridDim.x, (int)gridDim.y);
 }
 
 // Several problems of ONE layer shape in one launch -- the student's and the teacher's pass through the same layer (different
@@ -1037,7 +1072,12 @@ int launch(const ConvDev& d, hipStream_t st) {
     if constexpr (EPI != 0) {
         if (!g_group && d.ksplit <= 1) {
             dim3 grid(cdiv(d.M, BM), cdiv(d.Cout, BN));
-            hipLaunchKernelGGL((igemm_kernel<T, BM, BN, WM, WN, KC, PIPE, HALO, EPI>), grid, dim3(WM * WN * 64), 0, st, d);
+            bool lean = false;
+            if constexpr (!HALO) lean = d.lean != 0;
+            if constexpr (!HALO) {
+                if (lean) hipLaunchKernelGGL((igemm_kernel<T, BM, BN, WM, WN, KC, PIPE, HALO, EPI, true>), grid, dim3(WM * WN * 64), 0, st, d);
+            }
+            if (!lean) hipLaunchKernelGGL((igemm_kernel<T, BM, BN, WM, WN, KC, PIPE, HALO, EPI, false>), grid, dim3(WM * WN * 64), 0, st, d);
             ALDI_CHECK_LAUNCH();
             char name[112];
             snprintf(name, sizeof(name), "igemm<%s,%d,%d,%d,%d,%s,%s%s,%s>", "bf16", BM, BN, WM, WN, PIPE ? "pipe" : "flat", HALO ? "halo" : "tap", KC == 8 ? ",k64" : "",
@@ -1097,6 +1137,7 @@ int dispatch(ConvDev& d, hipStream_t st) {
     const bool direct_ok = sizeof(T) == 2 && !g_group && d.y && !d.y_f32 && d.out_scale == 1 && (d.Cout & 7) == 0 && !d.mask && d.ksplit <= 1 &&
                            !(d.mask_bits && (d.scale || d.shift)) && d.Cout >= 64;
     const int direct = direct_ok ? tn.igemm_direct : 0;
+    d.lean = tn.igemm_lean && d.KH * d.KW == 1 && d.stride == 1 && d.pad == 0 && d.K % 64 == 0 && !(d.dbg & (8 | 16)) ? 1 : 0;
     {
         // (fp32 -- the parity mode and the Deformable-DETR step's trunk: the halo form is the same code, 16 channels per group; igemm_halo_f32)
         const bool same3 = d.KH == 3 && d.KW == 3 && d.stride == 1 && d.pad == 1 && d.Ho == d.H && d.Wo == d.W && d.Cin % 32 == 0 && d.out_scale == 1;
@@ -1205,7 +1246,7 @@ int fill_convdev(const aldi_conv_args* a, ConvDev& d) {
     d.x_bytes = (unsigned)xb;
     d.w_bytes = (unsigned)wb;
     d.xcd = 0; d.dbg = 0;
-    d.ksplit = 0; d.slabs_per_split = 0;
+    d.ksplit = 0; d.slabs_per_split = 0; d.lean = 0;
     d.mask_bits = static_cast<const unsigned char*>(a->mask_bits);
     d.bits_out = static_cast<unsigned char*>(a->bits_out);
     if ((a->mask_bits || a->bits_out) && (a->dtype != ALDI_BF16 || (a->Cout & 7) || d.out_scale != 1 || a->res_mode == 2 || !a->y || a->y_f32 || a->ksplit > 1))

@@ -20,6 +20,7 @@ if len(sys.argv) > 1:
 g = torch.Generator(device="cuda").manual_seed(0)
 ROUNDS, REPS = 5, 20
 tot = {0: 0.0, 7: 0.0}
+AB = os.environ.get("PROBE_AB", "direct")        # "direct": staged vs direct epilogue; "lean": generic vs lean DMA issue (direct on)
 for (N, H, W, Cin, Cout, k, stride, kind) in SHAPES:
     x = torch.randn(N, H, W, Cin, device="cuda", generator=g).bfloat16()
     w = (torch.randn(Cout, k, k, Cin, device="cuda", generator=g) / (Cin * k * k) ** 0.5).bfloat16()
@@ -44,7 +45,7 @@ for (N, H, W, Cin, Cout, k, stride, kind) in SHAPES:
         kw.update(mask_bits=mb)
     outs, names, bts = {}, {}, {}
     for d in (0, 7):
-        L.reset_tuning(); L.set_tuning("igemm_direct", d)
+        L.reset_tuning(); L.set_tuning("igemm_direct" if AB == "direct" else "igemm_lean", d if AB == "direct" else int(d != 0))
         y = torch.empty(N, Ho, Wo, Cout, device="cuda", dtype=torch.bfloat16)
         bits.zero_()
         ops.conv2d(x, w, out=y, **kw)
@@ -74,7 +75,7 @@ for (N, H, W, Cin, Cout, k, stride, kind) in SHAPES:
     y = torch.empty(N, Ho, Wo, Cout, device="cuda", dtype=torch.bfloat16)
     for rd in range(ROUNDS):
         for d in (0, 7):
-            L.set_tuning("igemm_direct", d)
+            L.set_tuning("igemm_direct" if AB == "direct" else "igemm_lean", d if AB == "direct" else int(d != 0))
             ops.conv2d(x, w, out=y, **kw)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
