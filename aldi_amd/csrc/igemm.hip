@@ -293,62 +293,41 @@ __device__ __forceinline__ void igemm_epilogue_direct(const ConvDev& p, f32x4_t 
     const int wm = wave / WN, wn = wave % WN;
     const int fr = lane & 15, fq = lane >> 4;
     if (p.dbg & 4) return;
-    // (1) y = acc * scale + shift, operands from the workgroup's LDS copy of the tile's 64 scales / shifts
-    if (p.scale || p.shift) {
-        u32x4_t sc[TN], sh[TN];
+    // Everything below touches an accumulator ONCE (they live in the AGPR half of the register file: every separate pass over them --
+    // scale, shift, residual -- would be a read and a write-back per element): the per-channel operands are fetched first, then each
+    // (fragment row i, 32-channel block h) is finished in one expression chain  v = acc * scale + shift + residual -> mask -> round -> store.
+    // (1) FrozenBN scale / shift from the workgroup's LDS copy of the tile's 64 scales / shifts (neutral values when the layer has none)
+    // (the LDS reads and their wait are UNCONDITIONAL -- an unused operand reads whatever the aux region holds: a conditional hand-issued
+    // read is a second definition of its registers, and the compiler may copy them on the joining edge before the data has landed)
+    u32x4_t sc[TN], sh[TN];
+    const bool has_sc = p.scale != nullptr, has_sh = p.shift != nullptr;
 #pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const unsigned a = aux_addr + (unsigned)(wn * WNE + (j >> 1) * 32 + fq * 8 + (j & 1) * 4) * 4u;
-            sc[j] = frag_read<0>(a);
-            sh[j] = frag_read<256>(a);
-        }
-        frag_wait<TN, TN>(sc, sh);
-        if (p.scale) {
-#pragma unroll
-            for (int j = 0; j < TN; ++j)
-#pragma unroll
-                for (int i = 0; i < TM; ++i)
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) acc[i][j][e] *= __uint_as_float(sc[j][e]);
-        }
-        if (p.shift) {
-#pragma unroll
-            for (int j = 0; j < TN; ++j)
-#pragma unroll
-                for (int i = 0; i < TM; ++i)
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) acc[i][j][e] += __uint_as_float(sh[j][e]);
-        }
+    for (int j = 0; j < TN; ++j) {
+        const unsigned a = aux_addr + (unsigned)(wn * WNE + (j >> 1) * 32 + fq * 8 + (j & 1) * 4) * 4u;
+        sc[j] = frag_read<0>(a);
+        sh[j] = frag_read<256>(a);
     }
-    // (2) + residual (fp32 add before the single rounding): requested in the prologue, in THIS lane's output layout (8 consecutive channels)
+    // (2) the ReLU-mask bits of a data-gradient launch (one byte = this lane's 8 channels)
+    unsigned mb[TM][H];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int h = 0; h < H; ++h) mb[i][h] = lds_read_u8(aux_addr + (unsigned)((wm * (BM / WM) + i * 16 + fr) * (BN / 8) + (wn * H + h) * 4 + fq));
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int j = 0; j < TN; ++j) { asm volatile("" : "+v"(sc[j])); asm volatile("" : "+v"(sh[j])); }
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int h = 0; h < H; ++h) asm volatile("" : "+v"(mb[i][h]));
+    const bool has_res = RESL && p.res_mode != 0;
     if constexpr (RESL) {
-        if (p.res_mode) {
+        if (has_res) {
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int h = 0; h < H; ++h) {
-                    asm volatile("" : "+v"(rres[i][h]));
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const unsigned r2 = rres[i][h][q];
-                        acc[i][2 * h + (q >> 1)][(q & 1) * 2] += __uint_as_float(r2 << 16);
-                        acc[i][2 * h + (q >> 1)][(q & 1) * 2 + 1] += __uint_as_float(r2 & 0xffff0000u);
-                    }
-                }
+                for (int h = 0; h < H; ++h) asm volatile("" : "+v"(rres[i][h]));      // (requested in the prologue; landed: the K loop's waits are behind us)
         }
-    }
-    // (3) round, ReLU / mask, store: lane (fr, fq) owns pixel fr of fragment row i and channels h*32 + fq*8 .. +7 of its wave's range
-    unsigned mb[TM][H];
-    if (p.mask_bits) {
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int h = 0; h < H; ++h) mb[i][h] = lds_read_u8(aux_addr + (unsigned)((wm * (BM / WM) + i * 16 + fr) * (BN / 8) + (wn * H + h) * 4 + fq));
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int h = 0; h < H; ++h) asm volatile("" : "+v"(mb[i][h]));
     }
     const __amdgpu_buffer_rsrc_t ry = make_rsrc_uniform(p.y, 0x7fffffffu);
     const __amdgpu_buffer_rsrc_t rbo = make_rsrc_uniform(p.bits_out, 0x7fffffffu);
@@ -365,6 +344,24 @@ __device__ __forceinline__ void igemm_epilogue_direct(const ConvDev& p, f32x4_t 
             float v[8];
 #pragma unroll
             for (int e = 0; e < 4; ++e) { v[e] = acc[i][2 * h][e]; v[4 + e] = acc[i][2 * h + 1][e]; }
+            if (has_sc) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { v[e] *= __uint_as_float(sc[2 * h][e]); v[4 + e] *= __uint_as_float(sc[2 * h + 1][e]); }
+            }
+            if (has_sh) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { v[e] += __uint_as_float(sh[2 * h][e]); v[4 + e] += __uint_as_float(sh[2 * h + 1][e]); }
+            }
+            if constexpr (RESL) {
+                if (has_res) {                  // fp32 add before the single rounding
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const unsigned r2 = rres[i][h][q];
+                        v[2 * q] += __uint_as_float(r2 << 16);
+                        v[2 * q + 1] += __uint_as_float(r2 & 0xffff0000u);
+                    }
+                }
+            }
             if (p.mask_bits) {
 #pragma unroll
                 for (int t = 0; t < 8; ++t) v[t] = __uint_as_float(__float_as_uint(v[t]) & (unsigned)__builtin_amdgcn_sbfe((int)mb[i][h], t, 1));
