@@ -398,6 +398,7 @@ class RCNN:
         self.fused_stem = os.environ.get("ALDI_FUSED_STEM", "1") == "1"                  # bf16: stem conv + max-pool in one kernel
         self.group_wgrad = os.environ.get("ALDI_WGRAD_GROUP", "1") == "1"                # bf16: a layer group's weight gradients in one launch
         self.mask_bits = os.environ.get("ALDI_MASK_BITS", "1") == "1"                    # ReLU masks of the block outputs as bits for the backward
+        self.mask_bits_inner = os.environ.get("ALDI_MASK_BITS_INNER", "1") == "1"        # ... and of the two inner maps of every bottleneck
         self.level_groups = os.environ.get("ALDI_LEVEL_GROUPS", "1") == "1"              # one launch for a layer applied to several pyramid levels
         self.fused_res2 = os.environ.get("ALDI_FUSED_RES2", "1") == "1"                  # bf16: a res2 bottleneck (no saved activations) in one kernel
         self._wg_queue: list = []
@@ -594,17 +595,30 @@ class RCNN:
                     x = ops.bottleneck_fused(x, sc, fw[p + "conv1"], fw[p + "conv2"], fw[p + "conv3"], W.shift(p + "conv1"), W.shift(p + "conv2"),
                                              W.shift(p + "conv3"))
                     continue
-                h1 = yield x, p + "conv1", dict(relu=True)
-                h2 = yield h1, p + "conv2", dict(relu=True)
-                # the block output's ReLU mask as bits (1/16 of the tensor): what the NEXT block's conv1 / the lateral conv's data gradient
-                # multiplies by instead of reading this whole activation again (those launches are HBM-bound)
-                bits = (torch.empty(h2.shape[0] * h2.shape[1] * h2.shape[2] * (W.layout.t[p + "conv3"].wshape[0] // 8), dtype=torch.uint8, device=self.device)
-                        if save and si > 0 and self.mask_bits and self.dtype == torch.bfloat16 else None)
+                # every saved ReLU output's mask as BITS beside it (1/16 of the tensor): what the data-gradient launch that needs the mask -- the
+                # next block's conv1 / the lateral conv for a block output, conv3's / conv2's for the two inner maps -- multiplies by instead of
+                # reading the whole activation again for its sign; with bits those launches also take the direct epilogue (csrc/igemm.hip)
+                want_bits = save and si > 0 and self.mask_bits and self.dtype == torch.bfloat16
+
+                def bits_for(inp, name):
+                    if not want_bits:
+                        return None
+                    lt = W.layout.t[name]
+                    ho = (inp.shape[1] + 2 * lt.pad - lt.kk) // lt.stride + 1
+                    wo = (inp.shape[2] + 2 * lt.pad - lt.kk) // lt.stride + 1
+                    return torch.empty(inp.shape[0] * ho * wo * (lt.wshape[0] // 8), dtype=torch.uint8, device=self.device)
+                b1 = bits_for(x, p + "conv1") if self.mask_bits_inner else None
+                h1 = yield x, p + "conv1", dict(relu=True, bits_out=b1)
+                b2 = bits_for(h1, p + "conv2") if self.mask_bits_inner else None
+                h2 = yield h1, p + "conv2", dict(relu=True, bits_out=b2)
+                bits = bits_for(h2, p + "conv3")
                 out = yield h2, p + "conv3", dict(relu=True, res=sc, res_mode=1, bits_out=bits)
                 if save and si > 0:
                     blocks.append((p, x, h1, h2, out, b == 0))
                     if bits is not None:
                         out_bits[out.data_ptr()] = bits
+                        if b1 is not None:
+                            out_bits[h1.data_ptr()], out_bits[h2.data_ptr()] = b1, b2
                 x = out
             cs.append(x)
         if not fpn:                            # the bare trunk (the Deformable-DETR detector takes C3..C5 themselves)
@@ -1339,9 +1353,9 @@ class RCNN:
                 bi -= 1
                 stage_names += [p + "conv3", p + "conv2", p + "conv1"] + ([p + "shortcut"] if first else [])
                 self._wgrad(p + "conv3", h2, g)
-                g2 = ops.conv2d(g, W.wt(p + "conv3"), mask=h2)
+                g2 = ops.conv2d(g, W.wt(p + "conv3"), **self._relu_mask(c, h2))
                 self._wgrad(p + "conv2", h1, g2)
-                g1 = ops.conv2d(g2, W.wt(p + "conv2"), pad=1, mask=h1)
+                g1 = ops.conv2d(g2, W.wt(p + "conv2"), pad=1, **self._relu_mask(c, h1))
                 self._wgrad(p + "conv1", xin, g1)
                 if first:
                     self._wgrad(p + "shortcut", xin, g)
