@@ -260,6 +260,14 @@ __device__ __forceinline__ void igemm_epilogue(const ConvDev& p, f32x4_t (&acc)[
 }
 
 
+template <int N, int ROWB, int I = 0>
+__device__ __forceinline__ void frag_read_each(u32x4_t* f, const unsigned* addr) {   // fragment I at addr[I] + I * 16 rows
+    if constexpr (I < N) {
+        f[I] = frag_read<I * 16 * ROWB>(addr[I]);
+        frag_read_each<N, ROWB, I + 1>(f, addr);
+    }
+}
+
 // ---- "direct" epilogue (bf16, BN = 64, plain output layout): no LDS staging, no workgroup barrier, no dependent global loads -----------
 // The staged epilogue above is what bounds the short-K 1x1 layers of res3..res5 (rocprofv3: 7.3 VALU per MFMA, MFMA pipes busy 12.7 % of the
 // cycles on res4 conv3, profiles/r03_pmc_conv.txt): after the K loop every wave writes its tile to the LDS, waits at a barrier, THEN requests
@@ -419,7 +427,8 @@ __device__ __forceinline__ void igemm_body(const ConvDev& p, int bid, const int 
     constexpr int NSTAGE = HALO ? 2 : NBUF;
     // one LDS object (a second one makes hipcc drain the DMA queue before LDS reads): [ring | residual tile | scale + shift or mask bits]
     constexpr int AUX_SLOTS = DIRECT ? 64 : 0;
-    __shared__ __attribute__((aligned(128))) uint4 lds_all[NSTAGE * SLOTS + AUX_SLOTS];
+    constexpr int ZERO_SLOTS = HALO ? 4 : 0;                    // one all-zero 64-byte row: what a tap reads at the left / right image border
+    __shared__ __attribute__((aligned(128))) uint4 lds_all[NSTAGE * SLOTS + AUX_SLOTS + ZERO_SLOTS];
     uint4 (*const lds)[SLOTS] = reinterpret_cast<uint4 (*)[SLOTS]>(&lds_all[0]);
     uint4* const aux_lds = &lds_all[NSTAGE * SLOTS];
     constexpr int N_RES = RESL ? (BM / WM / 16) * (BN / WN / 32) : 0;   // residual loads per thread (16 B each: its 8 channels of a pixel and 32-block)
@@ -532,19 +541,37 @@ __device__ __forceinline__ void igemm_body(const ConvDev& p, int bid, const int 
         const int co = n0 + (DIRECT ? direct_perm<BN / WN>(row) : row);
         hw_voff[it] = co < p.Cout ? ((unsigned)co * (unsigned)p.K + (unsigned)(kwi * p.Cin + kce * EP)) * (unsigned)sizeof(T) : OOB;
     }
+    // Offsets of the group being LOADED are running sums: inside one kernel row (kh) a group's sources are the previous group's + one
+    // 32-channel chunk (an out-of-range offset stays out of range), so a DMA costs one add; the per-lane validity of the halo rows (vertical
+    // padding) changes with kh only -- three times per tile -- and is re-derived there.
     int gkh = 0, gci = 0;                                        // (kh, channel chunk) of the group being LOADED
+    unsigned ha_cur[AH_IT], hw_cur[WH_IT];
+    auto rebase = [&]() {
+        const unsigned a_off = (unsigned)(((gkh - 1) * p.W * p.Cin) * (int)sizeof(T));
+#pragma unroll
+        for (int it = 0; it < AH_IT; ++it) ha_cur[it] = ((ha_mask[it] >> gkh) & 1u) ? ha_voff[it] + a_off : OOB;
+    };
+    rebase();
+#pragma unroll
+    for (int it = 0; it < WH_IT; ++it) hw_cur[it] = hw_voff[it];
     auto issue_group = [&](int buf) {
-        const unsigned a_off = (unsigned)(((gkh - 1) * p.W * p.Cin + gci) * (int)sizeof(T));
 #pragma unroll
         for (int it = 0; it < AH_IT; ++it)
-            if (wbase + it * NT < AS)                            // wave uniform
-                glds16(rx, &lds[buf][wbase + it * NT], ((ha_mask[it] >> gkh) & 1u) ? ha_voff[it] + a_off : OOB);
-        const unsigned w_off = (unsigned)((gkh * 3 * p.Cin + gci) * (int)sizeof(T));
+            if (wbase + it * NT < AS) {                          // wave uniform
+                glds16(rx, &lds[buf][wbase + it * NT], ha_cur[it]);
+                ha_cur[it] += (unsigned)(BK * sizeof(T));
+            }
 #pragma unroll
-        for (int it = 0; it < WH_IT; ++it)
-            glds16(rw, &lds[buf][AS + wbase + it * NT], hw_voff[it] == OOB ? OOB : hw_voff[it] + w_off);
+        for (int it = 0; it < WH_IT; ++it) glds16(rw, &lds[buf][AS + wbase + it * NT], hw_cur[it]);
         gci += BK;
-        if (gci >= p.Cin) { gci = 0; ++gkh; }
+        unsigned w_adv = (unsigned)(BK * sizeof(T));             // next chunk of this kernel row's three taps ...
+        if (gci >= p.Cin) {
+            gci = 0; ++gkh;
+            w_adv = (unsigned)((2 * p.Cin + BK) * (int)sizeof(T));   // ... or the first chunk of the next kernel row (taps 3 kh .. 3 kh + 2)
+            rebase();
+        }
+#pragma unroll
+        for (int it = 0; it < WH_IT; ++it) hw_cur[it] += w_adv;
     };
     // left / right image border of this lane's fragment rows
     bool edge_l[TM], edge_r[TM];
@@ -561,6 +588,13 @@ __device__ __forceinline__ void igemm_body(const ConvDev& p, int bid, const int 
 #pragma unroll
     for (int kw = 0; kw < 3; ++kw) x_rd[kw] = lbase + (unsigned)((xrow + kw) * KC + swz<KC>(xrow + kw, fq)) * 16u;
     const unsigned w_rd = lbase + (unsigned)((AS + wrow * KC) + swz<KC>(wrow, fq)) * 16u;
+    // The left / right border taps read ZEROS: the fragment's ADDRESS is redirected to the all-zero row (one select per fragment before
+    // the read is issued) instead of zeroing its four registers behind the read (four selects).  frag_read_each adds i * 16 rows back.
+    uint4* const zero_lds = &lds_all[NSTAGE * SLOTS + AUX_SLOTS];
+    if (tid < ZERO_SLOTS) zero_lds[tid] = make_uint4(0u, 0u, 0u, 0u);        // (visible behind the loop's first barrier)
+    unsigned zaddr[TM];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) zaddr[i] = lds_addr(zero_lds) + (unsigned)fq * 16u - (unsigned)(i * 16 * KC * 16);
     constexpr unsigned GROUP_BYTES = (AS + WS) * 16;
     const int G = 3 * (p.Cin / BK);
     issue_group(0);
@@ -574,22 +608,27 @@ __device__ __forceinline__ void igemm_body(const ConvDev& p, int bid, const int 
         // the three taps of the group: fragments of tap kw+1 are read while tap kw's MFMAs run
         u32x4_t xf[2][TM], wf[2][TN];
         const unsigned gb = (unsigned)buf * GROUP_BYTES;
-        frag_read_all<TM, KC * 16>(xf[0], x_rd[0] + gb);
+        {
+            unsigned xa[TM];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) xa[i] = edge_l[i] ? zaddr[i] : x_rd[0] + gb;
+            frag_read_each<TM, KC * 16>(xf[0], xa);
+        }
         frag_read_all<TN, KC * 16>(wf[0], w_rd + gb);
         frag_wait<TM, TN>(xf[0], wf[0]);
 #pragma unroll
         for (int kw = 0; kw < 3; ++kw) {
             const int cur = kw & 1, nxt = cur ^ 1;
             if (kw < 2) {
-                frag_read_all<TM, KC * 16>(xf[nxt], x_rd[kw + 1] + gb);
-                frag_read_all<TN, KC * 16>(wf[nxt], w_rd + gb + (unsigned)((kw + 1) * BN * KC * 16));
-            }
-            if (kw != 1) {
+                if (kw + 1 == 2) {
+                    unsigned xa[TM];
 #pragma unroll
-                for (int i = 0; i < TM; ++i) {
-                    const bool z = kw == 0 ? edge_l[i] : edge_r[i];
-                    xf[cur][i] = z ? u32x4_t{0u, 0u, 0u, 0u} : xf[cur][i];
+                    for (int i = 0; i < TM; ++i) xa[i] = edge_r[i] ? zaddr[i] : x_rd[2] + gb;
+                    frag_read_each<TM, KC * 16>(xf[nxt], xa);
+                } else {
+                    frag_read_all<TM, KC * 16>(xf[nxt], x_rd[kw + 1] + gb);
                 }
+                frag_read_all<TN, KC * 16>(wf[nxt], w_rd + gb + (unsigned)((kw + 1) * BN * KC * 16));
             }
 #pragma unroll
             for (int i = 0; i < TM; ++i)
@@ -837,13 +876,6 @@ __device__ __forceinline__ void igemm_body(const ConvDev& p, int bid, const int 
 //   WAR: a phase's fragment reads are retired (lgkmcnt(0)) right behind the barrier that ends its load segment, i.e. before the
 //        barrier that ends its compute segment; a stage is re-targeted by DMA two phases after its last read, which for the
 //        leading half is one full barrier interval after the lagging half retired its reads.
-template <int N, int ROWB, int I = 0>
-__device__ __forceinline__ void frag_read_each(u32x4_t* f, const unsigned* addr) {   // fragment I at addr[I] + I * 16 rows
-    if constexpr (I < N) {
-        f[I] = frag_read<I * 16 * ROWB>(addr[I]);
-        frag_read_each<N, ROWB, I + 1>(f, addr);
-    }
-}
 
 template <typename T, int BN>
 __device__ __forceinline__ void igemm_halo_rs_body(const ConvDev& p, int bid, const int nmt, const int nnt) {

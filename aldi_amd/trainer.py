@@ -113,7 +113,8 @@ def _teacher_stream(device):
         return None
     key = str(device)
     if key not in _TEACHER_STREAMS:
-        _TEACHER_STREAMS[key] = torch.cuda.Stream(device=device)
+        # (ALDI_TEACHER_PRIO: HIP stream priority of the teacher's branch, e.g. -1 = above the student's; measured)
+        _TEACHER_STREAMS[key] = torch.cuda.Stream(device=device, priority=int(os.environ.get("ALDI_TEACHER_PRIO", "0")))
     return _TEACHER_STREAMS[key]
 
 

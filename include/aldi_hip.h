@@ -42,6 +42,11 @@ int aldi_noop(aldi_stream_t stream);
  *   igemm_splitk_tile    tile of a split-K launch (aldi_conv_args.ksplit): 0 = 128x128, 1 = 256x128, 2 = 256x128 when that still gives about
  *                        one workgroup per CU (default)
  *   igemm_narrow_k       bf16 layers with K up to this many channels x taps take 128x64 tiles instead of 128x128 (512; 0 = never)
+ *   igemm_direct         bit mask of the 64-channel bf16 tiles that take the DIRECT epilogue (no LDS staging, permuted channel rows, residual
+ *                        prefetched into registers, scale / shift / mask bits by 4-byte LDS-DMA, one rounding): 1 = 128x64 1x1 / tap tile,
+ *                        2 = 64x64 long-K tile, 4 = 128x64 halo tile (7; 0 = the staged epilogue everywhere).  Applies to bf16 outputs in the
+ *                        plain layout with Cout % 8 == 0, Cout >= 64, no fp32 output / `mask` tensor / split-K / scatter
+ *   igemm_lean           1 = plain 1x1 / linear layers with K % 64 == 0 on those tiles run the lean K loop (running DMA offsets)
  *   igemm_halo           1 = 3x3/stride-1/pad-1 bf16 convs use the halo form (one pixel slab per three taps)
  *   igemm_bigtile_min    128x128-tile count from which a 3x3 conv takes the big halo tile (1024)
  *   igemm_bigtile        which one: 4 = 256x128 lockstep (default), 1 = 128x128, 10 = 256x128 with the two wave halves in alternating roles
