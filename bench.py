@@ -148,6 +148,14 @@ def profile_dense(trainer, step_fn, table_path=None):
     return out
 
 
+def _latest_profile(suffix):
+    """the newest round's profiles/rNN_<suffix> (tracked summaries of the rocprofv3 runs of this command)"""
+    import glob
+    import re
+    c = [f for f in glob.glob(os.path.join(ROOT, "profiles", "r*_" + suffix)) if re.fullmatch(r"r\d+_" + re.escape(suffix), os.path.basename(f))]
+    return "profiles/" + os.path.basename(sorted(c)[-1]) if c else "profiles/ (none committed)"
+
+
 def _cpu_model():
     try:
         for line in open("/proc/cpuinfo"):
@@ -430,7 +438,7 @@ def profile_insitu(step_fn, table_path=None):
     # What an event pair adds to the kernel it brackets (marker latency): with t1 = a pair around ONE launch of a small conv (T + o)
     # and t2 = a pair around TWO back-to-back launches of it (2 T + g + o), o = 2 t1 - t2 + g, where g is the dependent-kernel
     # boundary of MI355X_MICROARCH.md's price list (1.45 us).  It is subtracted from every measurement so that a launch's figure is
-    # the kernel's own duration as rocprofv3 --kernel-trace reports it (profiles/r03_kernel_stats_single_stream.txt: the
+    # the kernel's own duration as rocprofv3 --kernel-trace reports it (profiles/r0N_kernel_stats_single_stream.txt: the
     # uncorrected sum over the igemm launches read 7 % above the trace's, 2.7 us per launch).
     cx = torch.randn(1, 64, 64, 256, device="cuda").to(torch.bfloat16)
     cw = torch.randn(256, 1, 1, 256, device="cuda").to(torch.bfloat16)
@@ -682,7 +690,7 @@ def main():
                            "traffic": _traffic_per_launch(tj, "igemm", ig["launches"]),
                            "traffic_unit": "HBM bytes per igemm launch, rocprofv3 PMC passes of this command (FETCH_SIZE x2 + WRITE_SIZE)",
                            "traffic_source": tfile if tj else ("no profiles/r*_pmc_traffic.json matches this source tree (tools/source_hash.py)" if headline else "counter passes are collected for the headline workload only"),
-                           "timing": "HIP events around every dense launch of ONE extra step issued eagerly on ONE stream (ALDI_WGRAD_STREAM / TEACHER_STREAM / AUX_STREAM off), i.e. each kernel alone on the chip" + ("" if not headline else "; the matching rocprofv3 --kernel-trace --stats summary of the same single-stream step is profiles/r03_kernel_stats_single_stream.txt (the multi-stream step's is profiles/r03_kernel_stats.txt: co-resident kernels run longer there)"),
+                           "timing": "HIP events around every dense launch of ONE extra step issued eagerly on ONE stream (ALDI_WGRAD_STREAM / TEACHER_STREAM / AUX_STREAM off), i.e. each kernel alone on the chip" + ("" if not headline else "; the matching rocprofv3 --kernel-trace --stats summary of the same single-stream step is " + _latest_profile("kernel_stats_single_stream.txt") + " (the multi-stream step's is " + _latest_profile("kernel_stats.txt") + ": co-resident kernels run longer there)"),
                            "algorithmic_bytes_per_launch": round(ig["bytes"] / max(ig["launches"], 1)),
                            "launches_per_step": ig["launches"], "kernel_ms_per_step": round(ig["ms"], 3), "event_pair_us_subtracted": prof.get("event_pair_us"),
                            "avg_launch_us": round(ig["ms"] * 1e3 / max(ig["launches"], 1), 2),
