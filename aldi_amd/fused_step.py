@@ -702,7 +702,7 @@ class FusedStep:
         use_graph = self.graph_enabled and self.steps_done >= self.warmup and type(eng) is RCNN
         # captured graphs read the dgrad-weight buffers of the plan they were recorded with: a layer first requested later rebuilds
         # that plan (new buffers), so everything recorded before is dropped
-        epoch = getattr(eng.wts, "wt_epoch", 0)
+        epoch = (getattr(eng.wts, "wt_epoch", 0), ops.WGRAD_WS_EPOCH)     # (dgrad-weight plan, weight-gradient workspace: both are baked into the graphs)
         if getattr(S, "wt_epoch", epoch) != epoch:
             S.graph_a, S.A = None, None
             S.graphs_b.clear()

@@ -144,6 +144,7 @@ def conv2d_group(calls) -> List[torch.Tensor]:
 
 
 _WGRAD_WS = {}          # (device, stream handle) -> fp32 workspace of the ordered weight-gradient epilogue (grow only)
+WGRAD_WS_EPOCH = 0      # bumped whenever a workspace is REPLACED by a larger one: hipGraphs recorded before hold the old buffer's address
 WGRAD_ORDERED = os.environ.get("ALDI_WGRAD_ORDERED", "1") != "0"
 
 
@@ -160,6 +161,14 @@ def _wgrad_workspace(arr, n: int, device) -> None:
     key = (device, stream_ptr())
     buf = _WGRAD_WS.get(key)
     if buf is None or buf.numel() * 4 < need:
+        global WGRAD_WS_EPOCH
+        if buf is not None:
+            # a larger problem set (another image size, a new chunk layout) outgrew the buffer: graphs recorded with the old one would
+            # replay into freed memory -- the fused step compares this epoch with the one its graphs were recorded at and re-records
+            WGRAD_WS_EPOCH += 1
+            if torch.cuda.is_current_stream_capturing():
+                # (the eager warm-up steps size the buffer; outgrowing it DURING a recording means the shapes changed under the capture)
+                raise RuntimeError("the weight-gradient workspace has to grow during a hipGraph capture: run the new shapes eagerly once first")
         buf = torch.empty((need + (need >> 2) + 3) // 4, dtype=torch.float32, device=device)
         _WGRAD_WS[key] = buf
     arr[0].ws = buf.data_ptr()

@@ -360,6 +360,7 @@ class EngineDetrAdamW:
     def load_state_dict(self, sd):
         W = self.model.weights
         if sd.get("format") != "aldi_amd.detr_adamw":
+            logging.getLogger(__name__).warning("optimizer state of a foreign format: the Deformable-DETR AdamW moments restart from zero")
             return
         if sd.get("exp_avg") is not None:
             W.m, W.v = sd["exp_avg"].to(W.master.device).clone(), sd["exp_avg_sq"].to(W.master.device).clone()
