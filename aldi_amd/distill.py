@@ -33,6 +33,18 @@ and distill_enabled() -> bool.
 DISTILL_MIXIN_REGISTRY = Registry("DISTILL_MIXIN")
 
 
+# constructor keyword <- key under DOMAIN_ADAPT.DISTILL (aldi/config.py:60-75)
+_HARD_FLAGS = (("do_hard_cls", "HARD_ROIH_CLS_ENABLED"), ("do_hard_obj", "HARD_OBJ_ENABLED"), ("do_hard_rpn_reg", "HARD_RPN_REG_ENABLED"),
+               ("do_hard_roi_reg", "HARD_ROIH_REG_ENABLED"))
+_SOFT_FLAGS = (("do_cls_dst", "ROIH_CLS_ENABLED"), ("do_obj_dst", "OBJ_ENABLED"), ("do_rpn_reg_dst", "RPN_REG_ENABLED"),
+               ("do_roih_reg_dst", "ROIH_REG_ENABLED"))
+
+
+def _flags_from(cfg, table):
+    D = cfg.DOMAIN_ADAPT.DISTILL
+    return {arg: D[key] for arg, key in table}
+
+
 def build_distiller(cfg, teacher, student):
     name = cfg.DOMAIN_ADAPT.DISTILL.DISTILLER_NAME
     return DISTILLER_REGISTRY.get(name).from_config(cfg, teacher, student)
@@ -69,17 +81,14 @@ class HardDistiller(Distiller):
 
     @classmethod
     def from_config(cls, cfg, teacher, student):
-        D = cfg.DOMAIN_ADAPT.DISTILL
-        return HardDistiller(teacher, student, do_hard_cls=D.HARD_ROIH_CLS_ENABLED, do_hard_obj=D.HARD_OBJ_ENABLED,
-                             do_hard_rpn_reg=D.HARD_RPN_REG_ENABLED, do_hard_roi_reg=D.HARD_ROIH_REG_ENABLED,
-                             pseudo_label_threshold=cfg.DOMAIN_ADAPT.TEACHER.THRESHOLD)
+        return cls(teacher, student, pseudo_label_threshold=cfg.DOMAIN_ADAPT.TEACHER.THRESHOLD, **_flags_from(cfg, _HARD_FLAGS))
 
     def __call__(self, teacher_batched_inputs, student_batched_inputs):
         self.pseudo_labeler(teacher_batched_inputs, student_batched_inputs)
         return self.student(student_batched_inputs)
 
     def distill_enabled(self):
-        return any([self.do_hard_cls, self.do_hard_obj, self.do_hard_rpn_reg, self.do_hard_roi_reg])
+        return any(getattr(self, arg) for arg, _ in _HARD_FLAGS)
 
 
 @DISTILLER_REGISTRY.register()
@@ -96,36 +105,35 @@ class ALDIDistiller(Distiller):
     @classmethod
     def from_config(cls, cfg, teacher, student):
         D = cfg.DOMAIN_ADAPT.DISTILL
-        return ALDIDistiller(teacher, student,
-                             do_hard_cls=D.HARD_ROIH_CLS_ENABLED, do_hard_obj=D.HARD_OBJ_ENABLED,
-                             do_hard_rpn_reg=D.HARD_RPN_REG_ENABLED, do_hard_roi_reg=D.HARD_ROIH_REG_ENABLED,
-                             do_cls_dst=D.ROIH_CLS_ENABLED, do_obj_dst=D.OBJ_ENABLED,
-                             do_rpn_reg_dst=D.RPN_REG_ENABLED, do_roih_reg_dst=D.ROIH_REG_ENABLED,
-                             cls_temperature=D.CLS_TMP, obj_temperature=D.OBJ_TMP,
-                             cls_loss_type=cfg.DOMAIN_ADAPT.CLS_LOSS_TYPE,
-                             pseudo_label_threshold=cfg.DOMAIN_ADAPT.TEACHER.THRESHOLD)
+        return cls(teacher, student, cls_temperature=D.CLS_TMP, obj_temperature=D.OBJ_TMP, cls_loss_type=cfg.DOMAIN_ADAPT.CLS_LOSS_TYPE,
+                   pseudo_label_threshold=cfg.DOMAIN_ADAPT.TEACHER.THRESHOLD, **_flags_from(cfg, _HARD_FLAGS + _SOFT_FLAGS))
+
+    # where the reference taps the two models (aldi/distill.py:122-138): attribute that receives the SaveIO <- module path.  The attribute
+    # names are API (third-party distillers read `student_rpn_io` ...); the engine fires these hook points with the tensors it computed.
+    _TAPS = {"student": (("student_rpn_io", "proposal_generator"), ("student_rpn_head_io", "proposal_generator.rpn_head"),
+                         ("student_boxpred_io", "roi_heads.box_predictor")),
+             "teacher": (("teacher_backbone_io", "backbone"), ("teacher_rpn_head_io", "proposal_generator.rpn_head"),
+                         ("teacher_boxpred_io", "roi_heads.box_predictor"), ("teacher_anchor_io", "proposal_generator.anchor_generator"))}
 
     def register_hooks(self):
-        self.student_rpn_io, self.student_rpn_head_io, self.student_boxpred_io = SaveIO(), SaveIO(), SaveIO()
-        self.teacher_backbone_io, self.teacher_rpn_head_io, self.teacher_boxpred_io, self.teacher_anchor_io = SaveIO(), SaveIO(), SaveIO(), SaveIO()
-        student_model, teacher_model = _unwrap(self.student), _unwrap(self.teacher)
-        student_model.proposal_generator.register_forward_hook(self.student_rpn_io)
-        student_model.proposal_generator.rpn_head.register_forward_hook(self.student_rpn_head_io)
-        student_model.roi_heads.box_predictor.register_forward_hook(self.student_boxpred_io)
-        teacher_model.backbone.register_forward_hook(self.teacher_backbone_io)
-        teacher_model.proposal_generator.rpn_head.register_forward_hook(self.teacher_rpn_head_io)
-        teacher_model.roi_heads.box_predictor.register_forward_hook(self.teacher_boxpred_io)
-        teacher_model.proposal_generator.anchor_generator.register_forward_hook(self.teacher_anchor_io)
-        # same seeds for proposal sampling in teacher/student
+        models = {"student": _unwrap(self.student), "teacher": _unwrap(self.teacher)}
+        for side, taps in self._TAPS.items():
+            for attr, path in taps:
+                point = models[side]
+                for part in path.split("."):
+                    point = getattr(point, part)
+                io = SaveIO()
+                setattr(self, attr, io)
+                point.register_forward_hook(io)
+        # one seeder on BOTH roi_heads (teacher first: its eval inference fires it with the previous seed), so that the two
+        # models draw the same proposal samples; the teacher's train-mode forward then takes the student's proposals, once
         self.seeder = ManualSeed()
-        teacher_model.roi_heads.register_forward_pre_hook(self.seeder)
-        student_model.roi_heads.register_forward_pre_hook(self.seeder)
         self.teacher_proposal_replacer = ReplaceProposalsOnce()
-        teacher_model.roi_heads.register_forward_pre_hook(self.teacher_proposal_replacer)
+        for pre_hook, side in ((self.seeder, "teacher"), (self.seeder, "student"), (self.teacher_proposal_replacer, "teacher")):
+            models[side].roi_heads.register_forward_pre_hook(pre_hook)
 
     def distill_enabled(self):
-        return any([self.do_hard_cls, self.do_hard_obj, self.do_hard_rpn_reg, self.do_hard_roi_reg,
-                    self.do_cls_dst, self.do_obj_dst, self.do_rpn_reg_dst, self.do_roih_reg_dst])
+        return any(getattr(self, arg) for arg, _ in _HARD_FLAGS + _SOFT_FLAGS)
 
     def _distill_forward(self, teacher_batched_inputs, student_batched_inputs):
         if self.cls_loss_type not in ("CE", "KL"):
@@ -159,13 +167,14 @@ class ALDIDistiller(Distiller):
         self._soft = wire_losses(holder, student.engine.distill_loss_dict(c))
         return standard_losses
 
+    # hard (pseudo-label) loss of the student's own forward -> the flag that keeps it; everything else is reported as 0 * value so that the
+    # loss dict keeps its keys and the graph its shape (aldi/distill.py:175-186)
+    _HARD_LOSS_FLAG = {"loss_cls": "do_hard_cls", "loss_rpn_cls": "do_hard_obj", "loss_rpn_loc": "do_hard_rpn_reg", "loss_box_reg": "do_hard_roi_reg"}
+
     def __call__(self, teacher_batched_inputs, student_batched_inputs):
-        losses = {}
-        hard_losses = self._distill_forward(teacher_batched_inputs, student_batched_inputs)
-        loss_to_attr = {"loss_cls": self.do_hard_cls, "loss_rpn_cls": self.do_hard_obj,
-                        "loss_rpn_loc": self.do_hard_rpn_reg, "loss_box_reg": self.do_hard_roi_reg}
-        for k, v in hard_losses.items():
-            losses[k] = v if loss_to_attr.get(k, False) else v * 0.0
+        hard = self._distill_forward(teacher_batched_inputs, student_batched_inputs)
+        kept = {k for k, flag in self._HARD_LOSS_FLAG.items() if getattr(self, flag)}
+        losses = {k: (v if k in kept else v * 0.0) for k, v in hard.items()}
         losses.update(self.get_rpn_losses(teacher_batched_inputs))
         losses.update(self.get_roih_losses())
         return losses
