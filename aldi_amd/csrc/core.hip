@@ -69,6 +69,7 @@ const Knob kKnobs[] = {
     {"msda_bin", &AldiTuning::msda_bin, 1},
     {"msda_bin_list", &AldiTuning::msda_bin_list, 512},
     {"roialign_sep", &AldiTuning::roialign_sep, 1},
+    {"roialign_bwd_rows", &AldiTuning::roialign_bwd_rows, 2},
     {"colsum_blocks", &AldiTuning::colsum_blocks, 256},
     {"colsum_minrows", &AldiTuning::colsum_minrows, 16},
     {"colsum_nt", &AldiTuning::colsum_nt, 1024},

@@ -647,6 +647,237 @@ __global__ __launch_bounds__(256, 5) void roialign_bwd_gather_kernel(Feats ft, G
     }
 }
 
+// The gather with TWO feature rows per workgroup (what aldi_roialign_backward runs on bf16 pooled gradients).  The one-row kernel above is
+// bound by instruction issue and the per-pair barrier chain, not by bytes: its parts add up when they are removed one at a time
+// (profiles/r04_roialign_bwd_ablation.txt, the real step's ROIs: 199 us; writing the maps alone 35, + candidate scan 65, + the bare pair loop
+// 115, + row reduction 132, + loads 150, + column tables 174, + column spread 199).  A workgroup that owns rows py0, py0 + 1 of a 32-pixel
+// segment shares between the two rows the scan, the column tables, the pooled rows it loads (a run of <= 4 bin rows instead of 2 x 3) and
+// the barrier of every (segment, ROI) pair, and sees ~1.07x the candidates of one row: 213 -> 186 us on the step's ROIs.  Same terms in the
+// same order as the one-row kernel (the zero weights of a shared run contribute +0): the results are identical.  Tried on top, slower:
+// a spread with a thread owning 4 channels x 8 pixels and scalar skips of the zero weights (one branch per FMA quad: 2.5x), four
+// workgroups per CU by spilling (228 us), per-row / per-load branches in the reduction instead of zero weights (+5 us).
+template <typename GT>
+__global__ __launch_bounds__(256, 3) void roialign_bwd_gather2_kernel(Feats ft, GatherGeom gg, const float* __restrict__ rois, int R, int P,
+                                                                   const bf16_t* __restrict__ gp /*[R][P][P][C]*/, int sorted) {
+    __shared__ int cand[256];
+    __shared__ float cx1[256], cy1[256], cbw[256], cbh[256], cinv[256];
+    __shared__ int cgwh[256];
+    __shared__ int range[2];
+    __shared__ int sm[17];
+    __shared__ int rrun[4];                              // first / last bin row with weight on either row, which rows have any
+    __shared__ __attribute__((aligned(16))) float rowc[4][2][8];
+    __shared__ __attribute__((aligned(16))) float colc[4][kSeg][8];
+    __shared__ __attribute__((aligned(16))) float gsum[2][2][7][256];
+    const int tid = threadIdx.x;
+    const int px = tid >> 3, cg = tid & 7;               // column spread: pixel of the segment, channels (j * 8 + cg) * 4 ... + 3
+    const int qw = tid >> 5, c8 = tid & 31;              // row reduction: bin column, channels c8 * 8 ... + 7
+    const int bid = (int)(gridDim.x - 1 - blockIdx.x);   // coarse levels first (see above)
+    int l = 0;
+    while (l < 3 && bid >= gg.blk_off[l + 1]) ++l;
+    const int H = ft.H[l], W = ft.W[l], C = ft.C;
+    const int HP = (H + 1) >> 1;
+    int t = bid - gg.blk_off[l];
+    const int seg = t % gg.segs[l]; t /= gg.segs[l];
+    const int py0 = (t % HP) * 2, b = t / HP;
+    const int px0 = seg * kSeg;
+    const float sc = ft.scale[l];
+    float4 acc[2][8];
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[r][j] = make_float4(0.f, 0.f, 0.f, 0.f);
+
+    auto tables = [&](int k, int buf) {
+        const float x1 = cx1[k], y1 = cy1[k], bw = cbw[k], bh = cbh[k];
+        const int gw = cgwh[k] & 0xffff, gh = cgwh[k] >> 16;
+        if (tid < 64) {
+            const int r = tid >> 3, ph = tid & 7, py = py0 + r;
+            float a = 0.f;
+            if (tid < 16 && ph < P && py < H)
+                for (int iy = 0; iy < gh; ++iy) {
+                    const Bilin by = bilin_prep(y1 + (float)ph * bh + ((float)iy + 0.5f) * bh / (float)gh, H);
+                    if (by.dead) continue;
+                    if (by.lo == py) a += by.h;
+                    if (by.hi == py) a += by.l;
+                }
+            const unsigned long long m = __ballot(a != 0.f);
+            if (tid < 16) rowc[buf][r][ph] = a;
+            if (tid == 0) {
+                const unsigned m0 = (unsigned)m & 0x7fu, m1 = (unsigned)(m >> 8) & 0x7fu, mm = m0 | m1;
+                rrun[buf] = mm ? (__ffs((int)mm) - 1) | ((31 - __clz((int)mm)) << 4) | ((m0 != 0) << 8) | ((m1 != 0) << 9) : 0;
+            }
+        }
+        {
+            const int pw = tid & 7;
+            float a = 0.f;
+            if (pw < P) {
+                const int pxa = px0 + px;
+                for (int ix = 0; ix < gw; ++ix) {
+                    const Bilin bx = bilin_prep(x1 + (float)pw * bw + ((float)ix + 0.5f) * bw / (float)gw, W);
+                    if (bx.dead) continue;
+                    if (bx.lo == pxa) a += bx.h;
+                    if (bx.hi == pxa) a += bx.l;
+                }
+            }
+            colc[buf][px][pw] = a;
+        }
+    };
+
+    int r_lo = 0, r_hi = R;
+    if (sorted) {
+        if (tid < 2) {
+            const float key = (float)(b + tid);
+            int lo = 0, hi = R;
+            while (lo < hi) {
+                const int mid = (lo + hi) >> 1;
+                if (rois[(long)mid * 5] < key) lo = mid + 1; else hi = mid;
+            }
+            range[tid] = lo;
+        }
+        __syncthreads();
+        r_lo = range[0]; r_hi = range[1];
+    }
+    for (int base = r_lo; base < r_hi; base += 256) {
+        const int r = base + tid;
+        bool hit = false;
+        float x1 = 0.f, y1 = 0.f, rw = 0.f, rh = 0.f;
+        if (r < r_hi) {
+            const float* rp = rois + (long)r * 5;
+            if ((int)rp[0] == b && roi_level(rp[1], rp[2], rp[3], rp[4]) == l) {
+                x1 = rp[1] * sc - 0.5f; y1 = rp[2] * sc - 0.5f;
+                const float x2 = rp[3] * sc - 0.5f, y2 = rp[4] * sc - 0.5f;
+                rw = x2 - x1; rh = y2 - y1;
+                const int r0 = min(max((int)floorf(y1) - 1, 0), H - 1), r1 = min(max((int)floorf(y2) + 2, 0), H - 1);
+                const int c0 = min(max((int)floorf(x1) - 1, 0), W - 1), c1 = min(max((int)floorf(x2) + 2, 0), W - 1);
+                hit = py0 + 1 >= r0 && py0 <= r1 && c1 >= px0 && c0 < px0 + kSeg;
+            }
+        }
+        int ncand;
+        const int rank = block_rank(hit, sm, &ncand);
+        if (hit) {
+            const int gh = (int)ceilf(rh / (float)P), gw = (int)ceilf(rw / (float)P);
+            cand[rank] = r;
+            cx1[rank] = x1; cy1[rank] = y1; cbw[rank] = rw / (float)P; cbh[rank] = rh / (float)P;
+            cgwh[rank] = max(gw, 0) | (max(gh, 0) << 16);
+            cinv[rank] = 1.f / (float)max(gh * gw, 1);
+        }
+        __syncthreads();
+        if (ncand > 0) tables(0, 0);
+        if (ncand > 1) tables(1, 1);
+        __syncthreads();
+
+        // the candidate whose pooled rows are in flight: the run of bin rows [plo, phi], their weights on the two feature rows
+        uint4 raw[4];
+        float rc0[4] = {0.f, 0.f, 0.f, 0.f}, rc1[4] = {0.f, 0.f, 0.f, 0.f};
+        int plo = 0, phi = -1, lv = 0;
+        auto issue = [&](int k, int buf) {
+            const int m = rrun[buf];
+            lv = (m >> 8) & 3;
+            plo = m & 15; phi = lv ? (m >> 4) & 15 : -1;
+            if (!lv) return;
+            const bf16_t* g0 = gp + (long)cand[k] * P * P * C + c8 * 8;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int ph = plo + j;
+                raw[j] = make_uint4(0u, 0u, 0u, 0u);
+                rc0[j] = 0.f; rc1[j] = 0.f;
+                if (ph <= phi) {
+                    rc0[j] = rowc[buf][0][ph]; rc1[j] = rowc[buf][1][ph];
+                    if (qw < P) raw[j] = *reinterpret_cast<const uint4*>(g0 + (long)(ph * P + qw) * C);
+                }
+            }
+        };
+        if (ncand > 0) issue(0, 0);
+        for (int q = 0; q <= ncand; ++q) {
+            if (q < ncand) {
+                if (lv && qw < P) {
+                    float g0[8], g1[8], u[8];
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) { g0[i] = 0.f; g1[i] = 0.f; }
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        Raw8<bf16_t> x; x.v = raw[j];
+                        x.unpack(u);
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) { g0[i] += rc0[j] * u[i]; g1[i] += rc1[j] * u[i]; }
+                    }
+                    if (phi - plo > 3) {
+                        const bf16_t* gq = gp + (long)cand[q] * P * P * C + c8 * 8;
+                        for (int ph = plo + 4; ph <= phi; ++ph) {
+                            const float w0 = rowc[q & 3][0][ph], w1 = rowc[q & 3][1][ph];
+                            Raw8<bf16_t> x;
+                            x.load(gq + (long)(ph * P + qw) * C);
+                            x.unpack(u);
+#pragma unroll
+                            for (int i = 0; i < 8; ++i) { g0[i] += w0 * u[i]; g1[i] += w1 * u[i]; }
+                        }
+                    }
+                    const float inv = cinv[q];
+                    if (lv & 1) {
+                        float* gd = &gsum[q & 1][0][qw][c8 * 8];
+                        *reinterpret_cast<float4*>(gd) = make_float4(g0[0] * inv, g0[1] * inv, g0[2] * inv, g0[3] * inv);
+                        *reinterpret_cast<float4*>(gd + 4) = make_float4(g0[4] * inv, g0[5] * inv, g0[6] * inv, g0[7] * inv);
+                    }
+                    if (lv & 2) {
+                        float* gd = &gsum[q & 1][1][qw][c8 * 8];
+                        *reinterpret_cast<float4*>(gd) = make_float4(g1[0] * inv, g1[1] * inv, g1[2] * inv, g1[3] * inv);
+                        *reinterpret_cast<float4*>(gd + 4) = make_float4(g1[4] * inv, g1[5] * inv, g1[6] * inv, g1[7] * inv);
+                    }
+                }
+                if (q + 1 < ncand) issue(q + 1, (q + 1) & 3);
+                if (q + 2 < ncand) tables(q + 2, (q + 2) & 3);
+            }
+            if (q > 0) {
+                // this pixel's bins of candidate q - 1 (a run of 2-3 of the 7) on the rows that carry weight, four channels at a time
+                const int tb = (q - 1) & 3;
+                const int lvp = (rrun[tb] >> 8) & 3;
+                if (lvp) {
+                    const float4 w0 = *reinterpret_cast<const float4*>(&colc[tb][px][0]);
+                    const float4 w1 = *reinterpret_cast<const float4*>(&colc[tb][px][4]);
+                    const float wv[7] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z};
+#pragma unroll
+                    for (int r = 0; r < 2; ++r) {
+                        if (!((lvp >> r) & 1)) continue;
+                        const float* gsb = &gsum[(q - 1) & 1][r][0][cg * 4];
+#pragma unroll
+                        for (int pw = 0; pw < 7; ++pw) {
+                            if (wv[pw] != 0.f) {
+                                const float w = wv[pw];
+#pragma unroll
+                                for (int j = 0; j < 8; ++j) {
+                                    const float4 g = *reinterpret_cast<const float4*>(gsb + pw * 256 + j * 32);
+                                    float4& a = acc[r][j];
+                                    a.x = __builtin_fmaf(w, g.x, a.x); a.y = __builtin_fmaf(w, g.y, a.y); a.z = __builtin_fmaf(w, g.z, a.z); a.w = __builtin_fmaf(w, g.w, a.w);
+                                }
+                            }
+                        }
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const int py = py0 + r;
+        if (py >= H || px0 + px >= W) continue;
+        const long o = (((long)b * H + py) * W + px0 + px) * C + cg * 4;
+        if constexpr (sizeof(GT) == 2) {
+            bf16_t* G = reinterpret_cast<bf16_t*>(ft.g[l]) + o;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                uint2 v;
+                v.x = pack2_bf16(acc[r][j].x, acc[r][j].y); v.y = pack2_bf16(acc[r][j].z, acc[r][j].w);
+                *reinterpret_cast<uint2*>(G + j * 32) = v;
+            }
+        } else {
+            float* G = ft.g[l] + o;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) *reinterpret_cast<float4*>(G + j * 32) = acc[r][j];
+        }
+    }
+}
+
 // FastRCNNOutputLayers.losses: CE(mean over R) + L1 on the gt-class deltas of fg rows / R
 // pred row: [0,K] class logits, [K+1, K+1+4K) deltas (class*4+d).  grad += d(loss*gscale)/d(pred)
 __global__ __launch_bounds__(256) void box_loss_kernel(const float* __restrict__ pred, int Cp, int K, int R,
@@ -864,16 +1095,22 @@ extern "C" int aldi_roialign_backward(const aldi_roi_feats* f, const float* rois
     Feats ft = make_feats(f, true);
     GatherGeom gg;
     gg.N = N;
+    // bf16 pooled gradients: two feature rows per workgroup (roialign_bwd_rows knob: 1 = the one-row kernel)
+    const int rows = dtype == ALDI_BF16 && aldi_tuning().roialign_bwd_rows != 1 ? 2 : 1;
     int off = 0;
     for (int l = 0; l < 4; ++l) {
         if (!ft.g[l]) return aldi_set_error_msg(ALDI_ERR_ARG, "roialign_backward: missing gradient map");
         gg.blk_off[l] = off;
         gg.segs[l] = cdiv(ft.W[l], kSeg);
-        off += N * ft.H[l] * gg.segs[l];
+        off += N * cdiv(ft.H[l], rows) * gg.segs[l];
     }
     gg.blk_off[4] = off;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    if (dtype == ALDI_BF16 && grad_dtype == ALDI_BF16)
+    if (rows == 2 && grad_dtype == ALDI_BF16)
+        hipLaunchKernelGGL((roialign_bwd_gather2_kernel<bf16_t>), dim3(off), dim3(256), 0, st, ft, gg, rois, R, P, (const bf16_t*)g_pooled, rois_sorted);
+    else if (rows == 2)
+        hipLaunchKernelGGL((roialign_bwd_gather2_kernel<float>), dim3(off), dim3(256), 0, st, ft, gg, rois, R, P, (const bf16_t*)g_pooled, rois_sorted);
+    else if (dtype == ALDI_BF16 && grad_dtype == ALDI_BF16)
         hipLaunchKernelGGL((roialign_bwd_gather_kernel<bf16_t, bf16_t>), dim3(off), dim3(256), 0, st, ft, gg, rois, R, P, (const bf16_t*)g_pooled, rois_sorted);
     else if (dtype == ALDI_BF16)
         hipLaunchKernelGGL((roialign_bwd_gather_kernel<bf16_t, float>), dim3(off), dim3(256), 0, st, ft, gg, rois, R, P, (const bf16_t*)g_pooled, rois_sorted);

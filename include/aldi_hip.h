@@ -67,6 +67,7 @@ int aldi_noop(aldi_stream_t stream);
  *   wgrad_big_group_min  (256x256 tiles x pixels) / 4096 a group needs for that launch (64); less: its layers join the 128x128 group
  *   wgrad_db             1 = grouped weight gradients with two LDS images and one barrier per 64-pixel slab (64 KB, two workgroups per CU)
  *   roialign_sep         1 = aldi_roialign forward in the separable form (row / column weight tables, one workgroup per ROI); 0 = per sample
+ *   roialign_bwd_rows    2 = aldi_roialign_backward on bf16 pooled gradients with two feature rows per workgroup; 1 = one row (same results)
  *   wgrad_dbg            ablation bits (1 = skip the atomic epilogue): results are WRONG when set
  *   wgrad_dma            LDS-DMA + ds_read_b64_tr_b16 weight-gradient kernel: 0 off, 1 in place of the lean kernel, 2 also of the 256x256
  *   wgrad_f32_tile128    1 = fp32 weight gradients with Cout, K >= 128 on the 128x128 f32-MFMA tile (0: the 64x64 kernel)

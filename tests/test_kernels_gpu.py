@@ -369,6 +369,46 @@ def test_roialign_fwd_bwd_vs_oracle(dtype, tol):
     assert len(inside) >= 50 and float((pin.float() - 3.0).abs().max()) < 1e-5
 
 
+def test_roialign_backward_two_row_kernel_is_the_one_row_kernel_bit_for_bit():
+    """aldi_roialign_backward on bf16 pooled gradients runs two feature rows per workgroup (knob roialign_bwd_rows = 2): same terms in the
+    same order as the one-row kernel (= 1).  Odd map heights (a last row pair with one row), 700 ROIs per image (three scan chunks),
+    ROIs on three levels, rows sorted by image and not, fp32 and bf16 gradient maps."""
+    from aldi_amd import ops, _lib as L
+    g = torch.Generator().manual_seed(11)
+    N, C = 2, 256
+    shapes = [(51, 67), (26, 34), (13, 17), (7, 9)]
+    per = 700
+    boxes = torch.cat([_rand_boxes(per * N - 200, 268, 204, g, lo=2.0, hi=60.0), _rand_boxes(200, 268, 204, g, lo=60.0, hi=268.0)])
+    boxes[0] = torch.tensor([-20.0, -10.0, 30.0, 25.0])
+    boxes[1] = torch.tensor([250.0, 190.0, 300.0, 230.0])
+    perm = torch.randperm(per * N, generator=g)
+    boxes = boxes[perm]
+    img = (torch.arange(per * N) // per).float()
+    rois_sorted = torch.cat([img[:, None], boxes], 1).contiguous().to(DEV)
+    shuffle = torch.randperm(per * N, generator=g)
+    gp = torch.randn(per * N, 7, 7, C, generator=g).to(DEV, torch.bfloat16)
+    fd = [torch.zeros(N, h, w, C, dtype=torch.bfloat16, device=DEV) for h, w in shapes]
+    R = per * N
+    try:
+        for srt in (True, False):
+            rois = rois_sorted if srt else rois_sorted[shuffle.to(DEV)].contiguous()
+            gpx = gp if srt else gp[shuffle.to(DEV)].contiguous()
+            for gdt in (torch.float32, torch.bfloat16):
+                out = {}
+                for rows in (1, 2):
+                    L.reset_tuning(); L.set_tuning("roialign_bwd_rows", rows)
+                    maps = [torch.full(f.shape, float("nan"), dtype=gdt, device=DEV) for f in fd]
+                    ops.roialign_backward(ops.make_roi_feats(fd, maps, [1 / 4, 1 / 8, 1 / 16, 1 / 32]), rois, R, 7, gpx, N, rois_sorted=srt, grad_dtype=gdt)
+                    torch.cuda.synchronize()
+                    out[rows] = maps
+                for l in range(4):
+                    assert bool(torch.isfinite(out[2][l].float()).all()), (srt, gdt, l)
+                    assert torch.equal(out[1][l], out[2][l]), (srt, gdt, l)
+                assert sum(float(m.float().abs().sum()) for m in out[2]) > 0
+    finally:
+        L.reset_tuning()
+
+
 def test_rpn_and_box_losses_vs_oracle():
     from aldi_amd import ops
     from aldi_amd.engine import GMAX, ROI_WEIGHTS, make_anchors
