@@ -262,7 +262,7 @@ def profile_insitu(step_fn, table_path=None):
         s, p = kw.get("stride", 1), kw.get("pad", 0)
         Ho, Wo = (H + 2 * p - KH) // s + 1, (W_ + 2 * p - KW) // s + 1
         key = ("igemm", N, H, W_, Cin, Cout, KH, s, p, kw.get("res_mode", 0), bool(kw.get("relu")), kw.get("mask") is not None,
-               kw.get("out_scale", 1), bool(kw.get("want_f32")))
+               kw.get("out_scale", 1), bool(kw.get("want_f32")), _L.last_dispatch().split(" ")[0])     # ... and the kernel the dispatcher chose
         esz = x.element_size()
         osz = 4 if kw.get("want_f32") else esz
         nby = esz * (x.numel() + w.numel()) + osz * N * Ho * Wo * Cout \
@@ -466,15 +466,16 @@ def profile_insitu(step_fn, table_path=None):
         us = max(e0.elapsed_time(e1) * 1e3 - empty, 0.5)
         f = out[key[0]]
         f["launches"] += 1; f["flops"] += fl; f["ms"] += us / 1e3; f["bytes"] += nby
-        e = shapes.setdefault(key, {"count": 0, "flops": fl, "us": 0.0})
+        e = shapes.setdefault(key, {"count": 0, "flops": fl, "us": 0.0, "bytes": nby})
         e["count"] += 1; e["us"] += us
     if table_path:
         os.makedirs(os.path.dirname(table_path), exist_ok=True)
         with open(table_path, "w") as f:
             f.write("# dense launches of ONE ALDI step, timed in situ (HIP events on the launch stream around every launch)\n")
-            f.write("# family shape... | launches/step | mean us/launch | TFLOP/s | ms/step\n")
+            f.write("# family shape... (igemm: + the dispatched kernel) | launches/step | mean us/launch | TFLOP/s | ms/step | algorithmic TB/s\n")
             for key, e in sorted(shapes.items(), key=lambda kv: -kv[1]["us"]):
-                f.write("%-90s %4d %9.1f %8.1f %8.3f\n" % (str(key), e["count"], e["us"] / e["count"], e["flops"] * e["count"] / e["us"] / 1e6, e["us"] / 1e3))
+                f.write("%-90s %4d %9.1f %8.1f %8.3f %6.2f\n" % (str(key), e["count"], e["us"] / e["count"], e["flops"] * e["count"] / e["us"] / 1e6, e["us"] / 1e3,
+                                                                e["bytes"] * e["count"] / e["us"] / 1e6))
     return out
 
 
