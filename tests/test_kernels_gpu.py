@@ -405,6 +405,25 @@ def test_roialign_backward_two_row_kernel_is_the_one_row_kernel_bit_for_bit():
                     assert bool(torch.isfinite(out[2][l].float()).all()), (srt, gdt, l)
                     assert torch.equal(out[1][l], out[2][l]), (srt, gdt, l)
                 assert sum(float(m.float().abs().sum()) for m in out[2]) > 0
+        # a smaller pooling grid (P = 5), an image without any ROI (its maps must come back zero), and no ROI at all
+        N3 = 3
+        fd3 = [torch.zeros(N3, h, w, C, dtype=torch.bfloat16, device=DEV) for h, w in shapes]
+        gp5 = torch.randn(R, 5, 5, C, generator=g).to(DEV, torch.bfloat16)
+        for R_ in (R, 0):
+            out = {}
+            for rows in (1, 2):
+                L.reset_tuning(); L.set_tuning("roialign_bwd_rows", rows)
+                maps = [torch.full(f.shape, float("nan"), dtype=torch.bfloat16, device=DEV) for f in fd3]
+                ops.roialign_backward(ops.make_roi_feats(fd3, maps, [1 / 4, 1 / 8, 1 / 16, 1 / 32]), rois_sorted, R_, 5, gp5, N3, rois_sorted=True, grad_dtype=torch.bfloat16)
+                torch.cuda.synchronize()
+                out[rows] = maps
+            for l in range(4):
+                assert torch.equal(out[1][l], out[2][l]), (R_, l)
+                assert float(out[2][l][2].float().abs().max()) == 0.0            # the image nobody pooled from
+                if R_ == 0:
+                    assert float(out[2][l].float().abs().max()) == 0.0
+            if R_:
+                assert float(out[2][0][:2].float().abs().max()) > 0
     finally:
         L.reset_tuning()
 
