@@ -258,15 +258,13 @@ static int run_script(unsigned char* state, const long* script, int nops, int* o
     std::lock_guard<std::mutex> lock(g_set.mu);
     join_fillers();
     auto ops = [&](Seg& sg, auto& gen) {
-        static thread_local std::vector<int> scratch;
         for (int i = sg.begin; i < sg.end; ++i) {
             const long n = script[4 * i + 1], k = script[4 * i + 2], off = script[4 * i + 3];
-            int* dst = out + off;
-            if (off < 0) {
-                scratch.resize((size_t)(k < n ? k : n) + 1);
-                dst = scratch.data();
+            if (off < 0) {                               // discarded draws: only the generator moves (randperm(n) consumes n - 1 values)
+                gen.discard(n > 0 ? n - 1 : 0);
+                continue;
             }
-            randperm_prefix<int>(gen, n, k, dst);
+            randperm_prefix<int>(gen, n, k, out + off);
         }
     };
     auto run = [&](Seg& sg) { ops(sg, sg.mt); };
@@ -419,6 +417,14 @@ extern "C" int aldi_torch_rng_prefetch(const unsigned char* state, const long* s
         Stream* st = &g_streams[i];
         g_fillers.emplace_back([st, max_draws] { st->fill(max_draws); });
     }
+    return ALDI_OK;
+}
+
+// Reaps the background fillers of aldi_torch_rng_prefetch (blocks until their streams are complete).  The script joins them itself; a
+// caller that has nothing else to do before the list lengths arrive calls this first, so that the joins are not paid between the phases.
+extern "C" int aldi_torch_rng_prefetch_wait(void) {
+    std::lock_guard<std::mutex> lock(g_set.mu);
+    join_fillers();
     return ALDI_OK;
 }
 

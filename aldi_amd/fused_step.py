@@ -343,7 +343,31 @@ class FusedStep:
         st = torch.get_rng_state()
         L.call("aldi_torch_rng_prefetch", st.data_ptr(), (C.c_long * len(seeds))(*seeds), len(seeds), depth)
 
-    def _host_draws(self, S, A):
+    def _draws_prepare(self, S):
+        """what the native host phase needs that does NOT depend on the list lengths, done while the device still runs phase A: the seeds the
+        `ManualSeed` hooks will use (Python's `random` advances here, as in the reference: aldi/distill.py:148-150 -- nothing else draws from it
+        between the two phases), the argument arrays, the CPU generator's state.  None when the host phase is not the one native call."""
+        if not (self._scripted() and os.environ.get("ALDI_HOST_DRAWS_C", "1") == "1"):
+            return None
+        import ctypes as C
+        seeder = self.tr.distiller.seeder
+        seeds = [int(seeder.seed)]
+        for _ in range(S.nk):
+            seeder.reset_seed()
+            seeds.append(int(seeder.seed))
+        if getattr(S, "chunk_arr", None) is None:
+            flat = []
+            for ch in S.chunks:
+                flat += [1 if ch["kind"] == "distill" else 0, ch["n0"], ch["n1"]]
+            U = S.up
+            S.chunk_arr = (C.c_int * len(flat))(*flat)
+            S.word0_arr = (C.c_int * 8)(*[U.word0(k) for k in ("rsel", "rnsel", "osel", "onsel", "row_off", "dsel", "dnsel", "nvf")])
+            S.rows_arr = (C.c_int * S.N)()
+        from . import _lib as L
+        L.call("aldi_torch_rng_prefetch_wait")                 # (the stream fillers of _prefetch_draws: ~1 ms of a 4.5 ms phase A; reaped here, not between the phases)
+        return SimpleNamespace(seeds=(C.c_long * len(seeds))(*seeds), n_seeds=len(seeds), st=torch.get_rng_state())
+
+    def _host_draws(self, S, A, prep=None):
         """every sampling draw of the iteration on the global CPU generator, in the reference's order, chunk by chunk =
         micro-step by micro-step of the reference schedule (aldi/trainer.py:51-52,86-89):
         the RPN sample (two randperm per image), `torch.manual_seed(seed)` by the roi_heads pre-hook, the ROI sample; a distillation
@@ -376,26 +400,15 @@ class FusedStep:
             return SimpleNamespace(rows=rows, R=sum(rows), nvf=nvf, key=tuple(rows))
         if scripted and os.environ.get("ALDI_HOST_DRAWS_C", "1") == "1":
             # the whole host phase as ONE native call (aldi_step_draws): same draws, same order, none of the Python below
-            import ctypes as C
             from . import _lib as L
-            seeder = dist_.seeder
-            seeds = [int(seeder.seed)]
-            for _ in range(S.nk):
-                seeder.reset_seed()                         # aldi/distill.py:148-150 (Python's `random` advances here, as in the reference)
-                seeds.append(int(seeder.seed))
-            if getattr(S, "chunk_arr", None) is None:
-                flat = []
-                for ch in S.chunks:
-                    flat += [1 if ch["kind"] == "distill" else 0, ch["n0"], ch["n1"]]
-                S.chunk_arr = (C.c_int * len(flat))(*flat)
-                S.word0_arr = (C.c_int * 8)(*[U.word0(k) for k in ("rsel", "rnsel", "osel", "onsel", "row_off", "dsel", "dnsel", "nvf")])
-                S.rows_arr = (C.c_int * N)()
-            st = torch.get_rng_state()
-            L.call("aldi_step_draws", st.data_ptr(), S.h_counts.data_ptr(), N, S.chunk_arr, len(S.chunks), (C.c_long * len(seeds))(*seeds), len(seeds),
+            if prep is None:
+                prep = self._draws_prepare(S)
+            L.call("aldi_step_draws", prep.st.data_ptr(), S.h_counts.data_ptr(), N, S.chunk_arr, len(S.chunks), prep.seeds, prep.n_seeds,
                    P_.rpn_batch, int(P_.rpn_batch * P_.rpn_pos_frac), P_.roi_batch, int(P_.roi_batch * P_.roi_pos_frac), U.host.data_ptr(), S.word0_arr,
                    S.rows_arr, 4)
-            torch.set_rng_state(st)
-            return finish(list(S.rows_arr))
+            out = finish(list(S.rows_arr))
+            out.rng_state = prep.st                          # the generator's state after the draws: installed by the caller, behind phase B's launch
+            return out
 
         def sample(name, nname, row0, counts, batch, frac):
             """subsample_labels for the images `row0 ...`: positives then negatives, two randperm per image"""
@@ -729,36 +742,41 @@ class FusedStep:
         c, tc = A.c, A.tc
         evs[1].record()
         self._prefetch_draws(S, int(c.anchors.shape[0]))
+        # Everything the host can do WITHOUT the list lengths happens here, while the device still runs phase A: between the lengths' arrival
+        # and phase B's launch the device is idle (0.15 ms of an 8.7 ms step before this was hoisted), so that section holds only the draws
+        # themselves and the launch.
+        if S.sgd:                                                   # this iteration's learning rate etc. for the recorded optimizer launches
+            S.hyper_host[0], S.hyper_host[1], S.hyper_host[2], S.hyper_host[3] = S.hyper_vals + (float(getattr(eng.wts, "_gscale", 1.0)),)
+            S.hyper.copy_(S.hyper_host, non_blocking=True)         # (stream-ordered: behind phase A and the previous step's optimizer launches)
+        dp = getattr(eng, "grad_ready", None) is not None
+        dp_graph = dp and reducer is not None and self.dp_graph_ok and reducer.capturable()
+        graph_b = use_graph and (not dp or dp_graph) and os.environ.get("ALDI_STEP_GRAPH_B", "1") == "1"
+        from .engine import raise_on_error
+        from . import _lib as L_
         try:
+            prep = self._draws_prepare(S)
             t1 = time.perf_counter()
             self._wait_counts(S)                                   # the ONE device->host sync: list lengths for the host RNG
             t2 = time.perf_counter()
-            from .engine import raise_on_error
             raise_on_error(int(S.h_counts_np[4 * N]), "student")
             raise_on_error(int(S.h_counts_np[4 * N + 1]), "teacher")
             # ---- host: all sampling draws
-            Hst = self._host_draws(S, A)
+            Hst = self._host_draws(S, A, prep)
         except BaseException:
-            from . import _lib as L_
             L_.call("aldi_torch_rng_prefetch", None, None, 0, 0)   # joins the background stream fillers of _prefetch_draws
             raise
         t3 = time.perf_counter()
-        from . import _lib as L_
-        self.stats["rng_stream_hits"] = int(L_.lib.aldi_torch_rng_prefetch_hits())
         # ---- phase B
         # Under data parallelism the backward launches the gradient exchange (reduce.BucketedReducer: collectives on a launch stream
         # behind the producers' events).  With RCCL those launches are stream-ordered kernels, so the whole of phase B -- backward,
         # collectives, their join -- is recorded and replayed like the single-GPU one; a host-driven backend (gloo) keeps phase B eager.
-        dp = getattr(eng, "grad_ready", None) is not None
-        dp_graph = dp and reducer is not None and self.dp_graph_ok and reducer.capturable()
-        graph_b = use_graph and (not dp or dp_graph) and os.environ.get("ALDI_STEP_GRAPH_B", "1") == "1"
-        if S.sgd:                                                   # this iteration's learning rate etc. for the recorded optimizer launches
-            S.hyper_host[0], S.hyper_host[1], S.hyper_host[2], S.hyper_host[3] = S.hyper_vals + (float(getattr(eng.wts, "_gscale", 1.0)),)
-            S.hyper.copy_(S.hyper_host, non_blocking=True)
         evs[2].record()
-        ent = None
+        ent = S.graphs_b.get(Hst.key) if graph_b else None
+        rng_after = getattr(Hst, "rng_state", None)               # (native host phase: the CPU generator's state behind the draws)
+        if ent is None and rng_after is not None:
+            torch.set_rng_state(rng_after)                         # phase B runs (or is recorded) from Python: the generator first
+            rng_after = None
         if graph_b:
-            ent = S.graphs_b.get(Hst.key)
             if ent is None:
                 if len(S.graphs_b) >= 4:
                     S.graphs_b.pop(next(iter(S.graphs_b)))
@@ -783,6 +801,8 @@ class FusedStep:
                     ent = None
         if ent is not None:
             ent[0].replay()
+            if rng_after is not None:
+                torch.set_rng_state(rng_after)                     # (behind the launch: the device is already working)
             if dp_graph:
                 reducer.finished = True                        # the replayed graph contains the whole exchange
                 self.stats["replays_b_dp"] = self.stats.get("replays_b_dp", 0) + 1
@@ -802,6 +822,7 @@ class FusedStep:
             eng.wts._sgd_applied = True            # recorded or eager, phase B contained this iteration's optimizer step: EngineSGD.step skips its launch
         evs[3].record()
         t4 = time.perf_counter()
+        self.stats["rng_stream_hits"] = int(L_.lib.aldi_torch_rng_prefetch_hits())
         for k_, v_ in (("host_us_issue_a", t1 - t0), ("host_us_wait_a", t2 - t1), ("host_us_draws", t3 - t2), ("host_us_issue_b", t4 - t3)):
             self.stats[k_] = round(0.8 * self.stats.get(k_, (v_ * 1e6)) + 0.2 * v_ * 1e6, 1)       # running mean, microseconds
         self.steps_done += 1

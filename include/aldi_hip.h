@@ -434,6 +434,7 @@ int aldi_step_draws(unsigned char* state, const int* counts, int N, const int* c
                     int rpn_batch, int rpn_pos_cap, int roi_batch, int roi_pos_cap, int* words, const int* word0, int* rows_out, int threads);
 int aldi_torch_rng_prefetch(const unsigned char* state, const long* seeds, int nseeds, long max_draws);
 int aldi_torch_rng_prefetch_hits(void);       /* script segments served from a pre-generated stream so far */
+int aldi_torch_rng_prefetch_wait(void);       /* blocks until the background fillers of aldi_torch_rng_prefetch are done (the script would wait itself) */
 
 /* ---------------------------------------------------------------------------------------
  * Strong augmentation on the device (the step next to the hot path).  Images are HWC uint8 in HBM;
