@@ -365,7 +365,22 @@ class FusedStep:
             S.rows_arr = (C.c_int * S.N)()
         from . import _lib as L
         L.call("aldi_torch_rng_prefetch_wait")                 # (the stream fillers of _prefetch_draws: ~1 ms of a 4.5 ms phase A; reaped here, not between the phases)
-        return SimpleNamespace(seeds=(C.c_long * len(seeds))(*seeds), n_seeds=len(seeds), st=torch.get_rng_state())
+        prep = SimpleNamespace(seeds=(C.c_long * len(seeds))(*seeds), n_seeds=len(seeds), st=torch.get_rng_state())
+        # A rehearsal with the PREVIOUS iteration's list lengths, on a copy of the generator and into a scratch buffer: the real call's few
+        # thousand draws land in nearly the same places of the freshly written streams (the lengths move by tens of entries from step to step),
+        # and its tables and code are in this core's caches when the lengths arrive -- measured 100 -> 46 us for the call between the phases.
+        prev = getattr(S, "prev_counts", None)
+        if prev is not None and os.environ.get("ALDI_HOST_DRAWS_REHEARSAL", "1") == "1":
+            P_ = self.eng.p
+            if getattr(S, "scratch_words", None) is None:
+                import numpy as np
+                S.scratch_words = np.zeros(S.up.words.shape[0], dtype=np.int32)
+                S.scratch_rows = (C.c_int * S.N)()
+            st_copy = prep.st.clone()
+            L.call("aldi_step_draws", st_copy.data_ptr(), prev.ctypes.data, S.N, S.chunk_arr, len(S.chunks), prep.seeds, prep.n_seeds,
+                   P_.rpn_batch, int(P_.rpn_batch * P_.rpn_pos_frac), P_.roi_batch, int(P_.roi_batch * P_.roi_pos_frac), S.scratch_words.ctypes.data,
+                   S.word0_arr, S.scratch_rows, 4)
+        return prep
 
     def _host_draws(self, S, A, prep=None):
         """every sampling draw of the iteration on the global CPU generator, in the reference's order, chunk by chunk =
@@ -408,6 +423,7 @@ class FusedStep:
                    S.rows_arr, 4)
             out = finish(list(S.rows_arr))
             out.rng_state = prep.st                          # the generator's state after the draws: installed by the caller, behind phase B's launch
+            S.prev_counts = S.h_counts_np[: 4 * N].copy()    # (the next iteration's rehearsal)
             return out
 
         def sample(name, nname, row0, counts, batch, frac):
