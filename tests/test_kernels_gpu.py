@@ -428,6 +428,41 @@ def test_roialign_backward_two_row_kernel_is_the_one_row_kernel_bit_for_bit():
         L.reset_tuning()
 
 
+def test_roialign_forward_and_backward_are_adjoint_at_benchmark_size():
+    """size-independent property at BASELINE's full size (4 images of 1333 x 800: maps 200 x 336 ... 25 x 42 x 256 channels, 2048 ROIs):
+    the backward is the transpose of the forward, <pool(f), g> == <f, pool^T(g)>.  f and g hold bf16-representable values; the forward runs
+    in fp32 on them (no output rounding), the backward is the benchmark step's kernel (bf16 pooled gradients, two rows per workgroup) writing
+    fp32 maps, and again the one-row kernel: both sides are fp32 sums of the same products."""
+    from aldi_amd import ops, _lib as L
+    g = torch.Generator().manual_seed(3)
+    N, C, R = 4, 256, 2048
+    Hs, Ws = [200, 100, 50, 25], [336, 168, 84, 42]
+    w = torch.rand(R, generator=g) * 100 + 28
+    h = torch.rand(R, generator=g) * 50 + 15
+    big = torch.rand(R, generator=g) < 0.05                                       # a few ROIs for the coarse levels
+    w = torch.where(big, w * 6, w); h = torch.where(big, h * 8, h)
+    cx, cy = torch.rand(R, generator=g) * 1333, torch.rand(R, generator=g) * 800
+    rois = torch.stack([(torch.arange(R) // (R // N)).float(), (cx - w / 2).clamp(0, 1332), (cy - h / 2).clamp(0, 799), (cx + w / 2).clamp(1, 1333),
+                        (cy + h / 2).clamp(1, 800)], 1).contiguous().to(DEV)
+    feats = [torch.randn(N, Hs[l], Ws[l], C, generator=g).to(torch.bfloat16).float().to(DEV) for l in range(4)]
+    gp = torch.randn(R, 7, 7, C, generator=g).to(torch.bfloat16).to(DEV)
+    pooled = torch.empty(R, 7, 7, C, dtype=torch.float32, device=DEV)
+    ops.roialign(ops.make_roi_feats(feats, None, [1 / 4, 1 / 8, 1 / 16, 1 / 32]), rois, R, 7, pooled, backward=False)
+    lhs = float((pooled.double() * gp.double()).sum())
+    scale = float(pooled.double().norm() * gp.double().norm())
+    fb = [f.to(torch.bfloat16) for f in feats]
+    try:
+        for rows in (2, 1):
+            L.reset_tuning(); L.set_tuning("roialign_bwd_rows", rows)
+            maps = [torch.full(f.shape, float("nan"), dtype=torch.float32, device=DEV) for f in feats]
+            ops.roialign_backward(ops.make_roi_feats(fb, maps, [1 / 4, 1 / 8, 1 / 16, 1 / 32]), rois, R, 7, gp, N, rois_sorted=True)
+            rhs = sum(float((f.double() * m.double()).sum()) for f, m in zip(feats, maps))
+            assert abs(lhs - rhs) <= 2e-6 * scale, (rows, lhs, rhs, scale)
+            assert all(float(m.abs().sum()) > 0 for m in maps)                     # every level was pooled from
+    finally:
+        L.reset_tuning()
+
+
 def test_rpn_and_box_losses_vs_oracle():
     from aldi_amd import ops
     from aldi_amd.engine import GMAX, ROI_WEIGHTS, make_anchors
