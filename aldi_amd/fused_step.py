@@ -227,20 +227,25 @@ class FusedStep:
         c.N, c.sizes, c.hw, c.geom, c.anchors, c.shapes = N, stu.sizes, stu.hw, geom, anchors, shapes
         # proposal generation (top-k, NMS: latency-bound, a handful of workgroups) beside anchor matching on the second stream
         side = eng._wgrad_stream()
+        ev_props = None
+
+        def housekeeping():
+            # nothing before phase B reads these: they must not sit between the proposals and the list lengths the host is waiting for
+            # (on the side stream BEHIND the proposals they did -- the join below waited for them: 107 us of the critical path in the
+            # kernel trace, profiles/r04_kernel_stats.txt); now they run while the host draws the samples
+            if S.lazy_wt:
+                eng.wts._refresh_wt()                       # the backward's dgrad weights of the weights SGD just wrote
+            if S.zero_grad:
+                eng.wts.grad.zero_()                        # 164 MB
         if side is not None:
             side.wait_stream(main)
             with torch.cuda.stream(side):
                 c.props, c.prop_scores, c.prop_count = eng.proposals(c, geom, anchors, stu.hw, N, training=True)
-                if S.lazy_wt:
-                    eng.wts._refresh_wt()                   # the backward's dgrad weights of the weights SGD just wrote: off the critical path
-                if S.zero_grad:
-                    eng.wts.grad.zero_()                    # 164 MB: nothing reads or adds to it before phase B
+                ev_props = torch.cuda.Event()
+                ev_props.record(side)
+                housekeeping()
         else:
             c.props, c.prop_scores, c.prop_count = eng.proposals(c, geom, anchors, stu.hw, N, training=True)
-            if S.lazy_wt:
-                eng.wts._refresh_wt()
-            if S.zero_grad:
-                eng.wts.grad.zero_()
         tc = None
         if S.distill:
             # The teacher's inference (N = 2, mostly small launches) runs on its own stream beside the student's label-free work
@@ -279,13 +284,20 @@ class FusedStep:
             hook(S, c, tc)
         _, matched, lists, counts = eng.rpn_match(geom, anchors, gt, N)
         c.rpn_matched, c.rpn_lists, c.rpn_counts = matched, lists, counts
-        if side is not None:
-            main.wait_stream(side)
+        if ev_props is not None:
+            if os.environ.get("ALDI_HOUSEKEEPING_LATE", "1") == "1":
+                main.wait_event(ev_props)                    # the proposals only: the side stream's housekeeping is joined behind the hand-over
+            else:
+                main.wait_stream(side)                       # (A/B: the round-3 order)
         prep = eng._roi_prepare(c.props, c.prop_count, gt, N)
         # ... and the two engines' error words ride along (bits set by this phase, or by the previous step's phase B): the host
         # raises on them right after the hand-over instead of training on silently wrong gradients
         errs = [eng.err.view(-1), (teng if teng is not None else eng).err.view(-1)]
         S.h_counts.copy_(torch.cat([counts.view(-1), prep["counts"].view(-1)] + errs).view(torch.uint8), non_blocking=True)
+        if side is not None:
+            main.wait_stream(side)                           # (phase B starts behind the housekeeping)
+        else:
+            housekeeping()
         return SimpleNamespace(c=c, tc=tc, prep=prep)
 
     # ------------------------------------------------------------------------------------------------ host phase
