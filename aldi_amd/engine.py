@@ -959,16 +959,31 @@ class RCNN:
         # their small zero-initialised outputs come out of one arena (one fill instead of one per tensor).
         arena = torch.zeros(2 + 8 * len(c.chunks), dtype=torch.float32, device=dev)
         scratch = arena[:2]
+        # The RPN-side loss kernels (RPN losses, RPN distillation) read the head outputs of phase A and the sampled labels only: given buffers
+        # and an event from BEFORE the box head's forward (the fused step's `rpn_early`), they run on the auxiliary stream beside RoIAlign and
+        # FC1 instead of behind the box head on the chain into the backward (~45 us of small launches).
+        early = c.get("rpn_early")
+        aux0 = self._aux_stream() if early is not None else None
+        if aux0 is None:
+            early = None
+        rpn_ctx = (lambda: torch.cuda.stream(aux0)) if early is not None else contextlib.nullcontext
+        if early is not None:
+            aux0.wait_event(early["ev"])
         hf = c.get("head_flat")
-        if hf is not None:                                   # one fill for the five levels' head gradients (views like c.head)
-            gf, o = torch.zeros_like(hf), 0
-            c.ghead = []
-            for h in c.head:
-                n = h.shape[0] * h.shape[1] * h.shape[2]
-                c.ghead.append(gf[0, o:o + n, 0].view(h.shape))
-                o += n
-        else:
-            c.ghead = [torch.zeros_like(h) for h in c.head]
+        with rpn_ctx():
+            rpn_arena = arena
+            if early is not None:
+                rpn_arena = early["arena"]
+                rpn_arena.zero_()
+            if hf is not None:                                   # one fill for the five levels' head gradients (views like c.head)
+                gf, o = (early["gf"].zero_() if early is not None else torch.zeros_like(hf)), 0
+                c.ghead = []
+                for h in c.head:
+                    n = h.shape[0] * h.shape[1] * h.shape[2]
+                    c.ghead.append(gf[0, o:o + n, 0].view(h.shape))
+                    o += n
+            else:
+                c.ghead = [torch.zeros_like(h) for h in c.head]
         c.gpred = torch.zeros((max(c.R, 1), self.Cp), dtype=torch.float32, device=dev)
         gt = c.gt
         align_list = []
@@ -978,15 +993,18 @@ class RCNN:
             nc = n1 - n0
             heads = [h[n0:n1] for h in c.head]
             gheads = [g[n0:n1] for g in c.ghead]
-            l_rpn = l_box = l_drpn = l_droi = scratch
+            l_rpn = l_drpn = rpn_arena[:2]
+            l_box = l_droi = scratch
             if ch.get("values_in_backward"):
                 base = 2 + 8 * ci
-                l_rpn, l_box, l_drpn, l_droi = (arena[base + 2 * j: base + 2 * j + 2] for j in range(4))
+                l_rpn, l_drpn = rpn_arena[base: base + 2], rpn_arena[base + 4: base + 6]
+                l_box, l_droi = arena[base + 2: base + 4], arena[base + 6: base + 8]
                 ch["loss_rpn"], ch["loss_box"] = l_rpn, l_box
                 if ch["distill"] is not None:
                     ch["loss_dist_rpn"], ch["loss_dist_roi"] = l_drpn, l_droi
-            ops.rpn_loss(c.geom, heads, gheads, c.anchors, c.rpn_labels[n0:n1], c.rpn_matched[n0:n1], gt["boxes"][n0:n1], gt["count"][n0:n1],
-                         GMAX, nc, 1.0 / (self.p.rpn_batch * nc), sc("loss_rpn_cls"), sc("loss_rpn_loc"), l_rpn)
+            with rpn_ctx():
+                ops.rpn_loss(c.geom, heads, gheads, c.anchors, c.rpn_labels[n0:n1], c.rpn_matched[n0:n1], gt["boxes"][n0:n1], gt["count"][n0:n1],
+                             GMAX, nc, 1.0 / (self.p.rpn_batch * nc), sc("loss_rpn_cls"), sc("loss_rpn_loc"), l_rpn)
             ops.box_loss(c.pred[r0:r1], self.Cp, self.K, r1 - r0, c.rois[r0:r1], c.r_cls[r0:r1], c.r_gt[r0:r1], self.p.roi_weights,
                          sc("loss_cls"), sc("loss_box_reg"), c.gpred[r0:r1], l_box)
             d = ch["distill"]
@@ -997,11 +1015,12 @@ class RCNN:
 
                 def roi_d(do_cls, do_reg, s_):
                     ops.roih_distill_loss(c.pred[r0:r1], d["t_pred"], self.Cp, self.K, r1 - r0, d["cls_T"], d["kl"], do_cls, do_reg, s_, c.gpred[r0:r1], l_droi)
-                if sc("loss_obj_bce") == sc("loss_rpn_l1"):
-                    rpn_d(d["do_obj"], d["do_rpn_reg"], sc("loss_obj_bce"))
-                else:
-                    rpn_d(d["do_obj"], False, sc("loss_obj_bce"))
-                    rpn_d(False, d["do_rpn_reg"], sc("loss_rpn_l1"))
+                with rpn_ctx():
+                    if sc("loss_obj_bce") == sc("loss_rpn_l1"):
+                        rpn_d(d["do_obj"], d["do_rpn_reg"], sc("loss_obj_bce"))
+                    else:
+                        rpn_d(d["do_obj"], False, sc("loss_obj_bce"))
+                        rpn_d(False, d["do_rpn_reg"], sc("loss_rpn_l1"))
                 if sc("loss_cls_ce") == sc("loss_roih_l1"):
                     roi_d(d["do_cls"], d["do_roih_reg"], sc("loss_cls_ce"))
                 else:
@@ -1021,6 +1040,8 @@ class RCNN:
                 al["ins"] = (acts, glog)
             if "img" in al or "ins" in al:
                 align_list.append(al)
+        if early is not None:
+            torch.cuda.current_stream().wait_stream(aux0)    # (the RPN-side values and head gradients: finished long ago)
         if after_losses is not None:
             after_losses()                                   # (the loss values are final here: the caller's logging branches off)
         self._backward_trunk(c, align_list)

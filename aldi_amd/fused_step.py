@@ -517,6 +517,20 @@ class FusedStep:
         RPN_BATCH = eng.p.rpn_batch
         ops.rpn_apply_sample(labels, sumA, N, c.rpn_lists, U.d("rsel"), U.d("rnsel"), RPN_BATCH)
         c.rpn_labels = labels
+        # the distillation chunks' fresh RPN sample, and -- everything the RPN-side loss kernels read exists now -- the buffers and the event
+        # that let engine.backward_fused run them on the auxiliary stream beside the box head's forward
+        for ch in S.chunks:
+            if ch["kind"] == "distill":
+                n0, n1 = ch["n0"], ch["n1"]
+                t0, t1 = n0 - S.d0, n1 - S.d0
+                dl = torch.empty((n1 - n0, sumA), dtype=torch.int32, device=dev)
+                ops.rpn_apply_sample(dl, sumA, n1 - n0, c.rpn_lists[n0:n1], U.d("dsel")[t0:t1], U.d("dnsel")[t0:t1], RPN_BATCH)
+                ch["_dl"] = dl
+        c.rpn_early = None
+        if eng._aux_stream() is not None and c.get("head_flat") is not None and os.environ.get("ALDI_RPN_LOSS_EARLY", "1") == "1":
+            ev_rpn = torch.cuda.Event()
+            c.rpn_early = dict(arena=torch.empty(2 + 8 * len(S.chunks), dtype=torch.float32, device=dev), gf=torch.empty_like(c.head_flat), ev=ev_rpn)
+            ev_rpn.record(main)
         oh = [[0, r] for r in Hst.rows]                       # only the row sums are used downstream
         eng._roi_gather(c, prep, U.d("osel"), U.d("onsel"), oh, c.gt, N, row_off_dev=U.d("row_off"))
         t_pred = None
@@ -557,8 +571,7 @@ class FusedStep:
                 if S.tside is not None:
                     main.wait_stream(S.tside)
                 t0, t1, kd = n0 - S.d0, n1 - S.d0, ch["kd"]             # this chunk's images in the teacher's batch / its index among the distillation chunks
-                dl = torch.empty((nc, sumA), dtype=torch.int32, device=dev)
-                ops.rpn_apply_sample(dl, sumA, nc, c.rpn_lists[n0:n1], U.d("dsel")[t0:t1], U.d("dnsel")[t0:t1], RPN_BATCH)
+                dl = ch.pop("_dl")
                 eng.distill_forward_chunk(c, ch, [h[t0:t1] for h in tc.head], t_pred[ch["r0"] - tr0: ch["r1"] - tr0], dl, Hst.nvf[kd][0], Hst.nvf[kd][1],
                                           values=False, obj_T=float(dist_.obj_temperature),
                                           cls_T=float(dist_.cls_temperature), kl=dist_.cls_loss_type == "KL", do_obj=dist_.do_obj_dst,
