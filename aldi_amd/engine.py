@@ -957,17 +957,22 @@ class RCNN:
         # The loss kernels produce value AND gradient in one pass.  Chunks flagged `values_in_backward` (the fused step) take their
         # loss values from THIS pass -- no separate value launches on the chain between the box head and the backward -- and all
         # their small zero-initialised outputs come out of one arena (one fill instead of one per tensor).
-        arena = torch.zeros(2 + 8 * len(c.chunks), dtype=torch.float32, device=dev)
+        early = c.get("rpn_early")
+        if early is not None and early.get("arena_box") is not None and self._aux_stream() is not None:
+            arena, c.gpred = early["arena_box"], early["gpred"]          # (zeroed on the auxiliary stream: ev_zero)
+            torch.cuda.current_stream().wait_event(early["ev_zero"])
+        else:
+            arena = torch.zeros(2 + 8 * len(c.chunks), dtype=torch.float32, device=dev)
+            c.gpred = torch.zeros((max(c.R, 1), self.Cp), dtype=torch.float32, device=dev)
         scratch = arena[:2]
         # The RPN-side loss kernels (RPN losses, RPN distillation) read the head outputs of phase A and the sampled labels only: given buffers
         # and an event from BEFORE the box head's forward (the fused step's `rpn_early`), they run on the auxiliary stream beside RoIAlign and
         # FC1 instead of behind the box head on the chain into the backward (~45 us of small launches).
-        early = c.get("rpn_early")
         aux0 = self._aux_stream() if early is not None else None
         if aux0 is None:
             early = None
         rpn_ctx = (lambda: torch.cuda.stream(aux0)) if early is not None else contextlib.nullcontext
-        if early is not None:
+        if early is not None and early.get("ev") is not None:
             aux0.wait_event(early["ev"])
         hf = c.get("head_flat")
         with rpn_ctx():
@@ -984,7 +989,6 @@ class RCNN:
                     o += n
             else:
                 c.ghead = [torch.zeros_like(h) for h in c.head]
-        c.gpred = torch.zeros((max(c.R, 1), self.Cp), dtype=torch.float32, device=dev)
         gt = c.gt
         align_list = []
         for ci, (ch, sc_) in enumerate(zip(c.chunks, scales)):
@@ -1012,6 +1016,9 @@ class RCNN:
                 def rpn_d(do_obj, do_reg, s_):
                     ops.rpn_distill_loss(c.geom, heads, d["t_head"], gheads, d["labels"], nc, d["obj_T"], d["n_valid"], d["n_fg"], do_obj, do_reg, s_, l_drpn,
                                          counts_dev=d.get("counts_dev"))
+
+                if d.get("t_ev") is not None:
+                    torch.cuda.current_stream().wait_event(d["t_ev"])       # the teacher's box head (its own stream)
 
                 def roi_d(do_cls, do_reg, s_):
                     ops.roih_distill_loss(c.pred[r0:r1], d["t_pred"], self.Cp, self.K, r1 - r0, d["cls_T"], d["kl"], do_cls, do_reg, s_, c.gpred[r0:r1], l_droi)

@@ -515,25 +515,37 @@ class FusedStep:
         sumA = c.anchors.shape[0]
         labels = torch.empty((N, sumA), dtype=torch.int32, device=dev)
         RPN_BATCH = eng.p.rpn_batch
-        ops.rpn_apply_sample(labels, sumA, N, c.rpn_lists, U.d("rsel"), U.d("rnsel"), RPN_BATCH)
         c.rpn_labels = labels
-        # the distillation chunks' fresh RPN sample, and -- everything the RPN-side loss kernels read exists now -- the buffers and the event
-        # that let engine.backward_fused run them on the auxiliary stream beside the box head's forward
-        for ch in S.chunks:
-            if ch["kind"] == "distill":
+        # The RPN side of the losses reads phase A's head outputs and the sampled labels only.  Its buffers are allocated HERE (on the main
+        # stream, before anything of phase B ran) and handed, with an event that marks the upload, to the auxiliary stream: label scatter,
+        # the distillation chunks' fresh RPN sample, the zero fills and (engine.backward_fused) the RPN loss kernels run there beside the box
+        # head's forward instead of on the chain into the backward.
+        aux = eng._aux_stream() if (c.get("head_flat") is not None and os.environ.get("ALDI_RPN_LOSS_EARLY", "1") == "1") else None
+        dls = [(ch, torch.empty((ch["n1"] - ch["n0"], sumA), dtype=torch.int32, device=dev)) for ch in S.chunks if ch["kind"] == "distill"]
+        c.rpn_early = None
+        if aux is not None:
+            Rn = sum(Hst.rows)
+            c.rpn_early = dict(arena=torch.empty(2 + 8 * len(S.chunks), dtype=torch.float32, device=dev), gf=torch.empty_like(c.head_flat),
+                               arena_box=torch.empty(2 + 8 * len(S.chunks), dtype=torch.float32, device=dev),
+                               gpred=torch.empty((max(Rn, 1), eng.Cp), dtype=torch.float32, device=dev))
+            ev_up = torch.cuda.Event()
+            ev_up.record(main)
+            aux.wait_event(ev_up)
+        with torch.cuda.stream(aux) if aux is not None else contextlib.nullcontext():
+            ops.rpn_apply_sample(labels, sumA, N, c.rpn_lists, U.d("rsel"), U.d("rnsel"), RPN_BATCH)
+            for ch, dl in dls:
                 n0, n1 = ch["n0"], ch["n1"]
                 t0, t1 = n0 - S.d0, n1 - S.d0
-                dl = torch.empty((n1 - n0, sumA), dtype=torch.int32, device=dev)
                 ops.rpn_apply_sample(dl, sumA, n1 - n0, c.rpn_lists[n0:n1], U.d("dsel")[t0:t1], U.d("dnsel")[t0:t1], RPN_BATCH)
                 ch["_dl"] = dl
-        c.rpn_early = None
-        if eng._aux_stream() is not None and c.get("head_flat") is not None and os.environ.get("ALDI_RPN_LOSS_EARLY", "1") == "1":
-            ev_rpn = torch.cuda.Event()
-            c.rpn_early = dict(arena=torch.empty(2 + 8 * len(S.chunks), dtype=torch.float32, device=dev), gf=torch.empty_like(c.head_flat), ev=ev_rpn)
-            ev_rpn.record(main)
+            if aux is not None:
+                c.rpn_early["arena_box"].zero_()
+                c.rpn_early["gpred"].zero_()
+                c.rpn_early["ev_zero"] = torch.cuda.Event()
+                c.rpn_early["ev_zero"].record(aux)
         oh = [[0, r] for r in Hst.rows]                       # only the row sums are used downstream
         eng._roi_gather(c, prep, U.d("osel"), U.d("onsel"), oh, c.gt, N, row_off_dev=U.d("row_off"))
-        t_pred = None
+        t_pred, t_ev = None, None
         if S.distill:
             # the teacher's box head on the student's sampled proposals of ALL distillation chunks (consecutive images d0 .. N of the
             # student batch = images 0 .. of the teacher's), beside the student's own
@@ -547,6 +559,8 @@ class FusedStep:
                 rois_t.record_stream(tside)
                 with torch.cuda.stream(tside), torch.no_grad():
                     t_pred = teng.box_head_on(tc, rois_t, tr1 - tr0)
+                    t_ev = torch.cuda.Event()                  # (only the RoI distillation kernel waits for the teacher's predictions)
+                    t_ev.record(tside)
             else:
                 with torch.no_grad():
                     t_pred = teng.box_head_on(tc, rois_t, tr1 - tr0)
@@ -568,15 +582,13 @@ class FusedStep:
             if ch["kind"] == "distill":
                 hard = {"loss_cls": dist_.do_hard_cls, "loss_rpn_cls": dist_.do_hard_obj, "loss_rpn_loc": dist_.do_hard_rpn_reg,
                         "loss_box_reg": dist_.do_hard_roi_reg}
-                if S.tside is not None:
-                    main.wait_stream(S.tside)
                 t0, t1, kd = n0 - S.d0, n1 - S.d0, ch["kd"]             # this chunk's images in the teacher's batch / its index among the distillation chunks
                 dl = ch.pop("_dl")
                 eng.distill_forward_chunk(c, ch, [h[t0:t1] for h in tc.head], t_pred[ch["r0"] - tr0: ch["r1"] - tr0], dl, Hst.nvf[kd][0], Hst.nvf[kd][1],
                                           values=False, obj_T=float(dist_.obj_temperature),
                                           cls_T=float(dist_.cls_temperature), kl=dist_.cls_loss_type == "KL", do_obj=dist_.do_obj_dst,
                                           do_rpn_reg=dist_.do_rpn_reg_dst, do_cls=dist_.do_cls_dst, do_roih_reg=dist_.do_roih_reg_dst,
-                                          counts_dev=U.d("nvf")[2 * kd: 2 * kd + 2])
+                                          counts_dev=U.d("nvf")[2 * kd: 2 * kd + 2], t_ev=t_ev)
                 ch["hard"] = hard
                 sc = {k: (1.0 if hard.get(k, False) else 0.0) / accum for k in keys}
                 k_ = ch["distill"]
