@@ -511,6 +511,8 @@ class FusedStep:
         main = torch.cuda.current_stream()
         N = S.N
         U = S.up
+        if os.environ.get("ALDI_PROBE_SPIN_CYCLES"):         # (probe, as in phase A: lets a tracer's slow node submission finish before the phase runs)
+            torch.cuda._sleep(int(os.environ["ALDI_PROBE_SPIN_CYCLES"]))
         U.upload()
         sumA = c.anchors.shape[0]
         labels = torch.empty((N, sumA), dtype=torch.int32, device=dev)
