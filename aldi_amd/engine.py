@@ -680,10 +680,19 @@ class RCNN:
         R = pooled.shape[0]
         x = pooled.view(R, 1, 1, POOL * POOL * FPN_C)
         fc1 = self.conv(x, "roi_heads.box_head.fc1", relu=True)
-        fc2 = self.conv(fc1, "roi_heads.box_head.fc2", relu=True)
+        # FC2's ReLU mask as bits for the predictors' data gradient (1/16 of the bytes, and that launch takes the direct epilogue); FC1 is a
+        # split-K launch whose second pass does not write bits: its mask stays the activation itself
+        bits2 = None
+        if c is not None and self.mask_bits and self.dtype == torch.bfloat16 and R > 0 and os.environ.get("ALDI_MASK_BITS_FC", "1") == "1":
+            bits2 = torch.empty(R * (FC_DIM // 8), dtype=torch.uint8, device=self.device)
+        fc2 = self.conv(fc1, "roi_heads.box_head.fc2", relu=True, bits_out=bits2)
         pred = self.conv(fc2, "box_pred", want_f32=True).view(R, self.Cp)
         if c is not None:
             c.pooled, c.fc1, c.fc2 = pooled, fc1, fc2
+            if bits2 is not None:
+                if c.get("out_bits") is None:
+                    c.out_bits = {}
+                c.out_bits[fc2.data_ptr()] = bits2
         return pred, fc2
 
     def roi_feats(self, c: Ctx, grads=None):
@@ -1303,7 +1312,7 @@ class RCNN:
                         g_ = ops.conv2d(g_, W.wt(L_[i]), mask=acts[i])      # acts[i] is the ReLU output of layer i-1
             gpred = ops.cast_from_f32(c.gpred[:c.R], T).view(c.R, 1, 1, self.Cp)
             self._wgrad("box_pred", c.fc2, gpred)
-            g_fc2 = ops.conv2d(gpred, W.wt("box_pred"), mask=c.fc2, res=g_extra, res_mode=1 if g_extra is not None else 0)
+            g_fc2 = ops.conv2d(gpred, W.wt("box_pred"), res=g_extra, res_mode=1 if g_extra is not None else 0, **self._relu_mask(c, c.fc2))
             self._wgrad("roi_heads.box_head.fc2", c.fc1, g_fc2)
             g_fc1 = ops.conv2d(g_fc2, W.wt("roi_heads.box_head.fc2"), mask=c.fc1)
             x = c.pooled.view(c.R, 1, 1, POOL * POOL * FPN_C)

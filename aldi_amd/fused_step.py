@@ -553,17 +553,18 @@ class FusedStep:
             # student batch = images 0 .. of the teacher's), beside the student's own
             dch = [ch for ch in S.chunks if ch["kind"] == "distill"]
             tr0, tr1 = dch[0]["r0"], dch[-1]["r1"]
-            rois_t = c.rois[tr0:tr1].clone()
-            rois_t[:, 0] -= S.d0
             tside = S.tside
             if tside is not None:
                 tside.wait_stream(main)
-                rois_t.record_stream(tside)
                 with torch.cuda.stream(tside), torch.no_grad():
+                    rois_t = c.rois[tr0:tr1].clone()           # (the teacher's copy of the rows, on ITS stream: not in front of the student's RoIAlign)
+                    rois_t[:, 0] -= S.d0
                     t_pred = teng.box_head_on(tc, rois_t, tr1 - tr0)
                     t_ev = torch.cuda.Event()                  # (only the RoI distillation kernel waits for the teacher's predictions)
                     t_ev.record(tside)
             else:
+                rois_t = c.rois[tr0:tr1].clone()
+                rois_t[:, 0] -= S.d0
                 with torch.no_grad():
                     t_pred = teng.box_head_on(tc, rois_t, tr1 - tr0)
         eng.roi_forward(c)
