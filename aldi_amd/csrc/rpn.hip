@@ -705,6 +705,106 @@ extern "C" int aldi_box_match(const float* boxes, long box_stride_n, const int* 
     return ALDI_OK;
 }
 
+namespace {
+// StandardROIHeads.label_and_sample_proposals up to the ordered lists in ONE launch: append the ground truth to the proposals, match
+// (IoU >= thr, first maximum wins, no low-quality rule), classes, and the ordered foreground / background lists with their lengths.
+// The same arithmetic as roi_append_gt + match_iou + match_label + roi_classes + compact_count + compact_write (aldi_roi_prepare,
+// aldi_compact_labels): eight launches of a few microseconds each on the chain that ends in the list lengths the host waits for, with
+// nothing left to run beside them at that point of the step -- a dependent small launch costs ~10 us of that chain in a replayed graph.
+// kRoiPrepWgs workgroups per image match a slice of the candidates each (a candidate per thread, every ground-truth box from LDS); the
+// LAST one of an image to finish (a ticket per image, reset by its taker) writes the two ordered lists from the classes.
+constexpr int kRoiPrepWgs = 8;
+__global__ __launch_bounds__(256) void roi_prepare_fused_kernel(const float4* __restrict__ props, const int* __restrict__ pcount, int P,
+                                                                const float4* __restrict__ gt, const int* __restrict__ gt_classes, const int* __restrict__ gcount,
+                                                                int Gmax, int K, float thr, int L, float4* __restrict__ cand, int* __restrict__ ccount,
+                                                                float* __restrict__ best_iou, int* __restrict__ best_idx, int* __restrict__ labels,
+                                                                int* __restrict__ cls, int* __restrict__ lists /*[N][2][L]*/, int* __restrict__ counts /*[N][2]*/,
+                                                                unsigned* __restrict__ tickets /*[N], zero*/) {
+    __shared__ float4 sgt[kGtTile];
+    __shared__ int sgc[kGtTile];
+    __shared__ int wsum[2][4];
+    __shared__ int s_last;
+    const int n = blockIdx.y, part = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int pc = pcount[n], gc = gcount[n], cnt = pc + gc;
+    if (part == 0 && tid == 0) ccount[n] = cnt;
+    for (int g = tid; g < gc; g += (int)blockDim.x) { sgt[g] = gt[(long)n * Gmax + g]; sgc[g] = gt_classes[n * Gmax + g]; }
+    __syncthreads();
+    const int per = (L + kRoiPrepWgs - 1) / kRoiPrepWgs;
+    const int i_end = min(L, (part + 1) * per);
+    for (int i = part * per + tid; i < i_end; i += (int)blockDim.x) {
+        float4 b = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (i < pc) b = props[(long)n * P + i];
+        else if (i < cnt) b = sgt[i - pc];
+        const bool active = i < cnt;
+        float best = gc > 0 ? 0.f : -1.f;
+        int bi = 0;
+        if (active)
+            for (int g = 0; g < gc; ++g) {
+                const float4 gb = sgt[g];
+                const bool ov = fminf(gb.z, b.z) - fmaxf(gb.x, b.x) > 0.f && fminf(gb.w, b.w) - fmaxf(gb.y, b.y) > 0.f;
+                const float v = ov ? iou_d2(gb, b) : 0.f;
+                if (v > best) { best = v; bi = g; }
+            }
+        int lab = -2;
+        if (active) lab = gc == 0 ? 0 : (best < thr ? 0 : 1);
+        int c = -2;
+        if (lab != -2) c = gc == 0 ? K : (lab == 1 ? sgc[bi] : K);
+        const long o = (long)n * L + i;
+        cand[o] = b;
+        if (active) { best_iou[o] = best; best_idx[o] = bi; }
+        labels[o] = lab;
+        cls[o] = c;
+    }
+    // the image's last workgroup compacts
+    __threadfence();
+    __syncthreads();
+    if (tid == 0) {
+        const unsigned t = atomicAdd(&tickets[n], 1u);
+        s_last = t == (unsigned)(kRoiPrepWgs - 1);
+        if (s_last) tickets[n] = 0u;                     // (for the next launch: nobody else touches it any more)
+    }
+    __syncthreads();
+    if (!s_last) return;
+    __threadfence();
+    const volatile int* vcls = cls + (long)n * L;
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    int base_p = 0, base_n = 0;
+    for (int i0 = 0; i0 < L; i0 += (int)blockDim.x) {
+        const int i = i0 + tid;
+        bool fp = false, fn = false;
+        if (i < L) label_flags(vcls[i], K, fp, fn);
+        const unsigned long long mp = __ballot(fp), mn = __ballot(fn);
+        if (lane == 0) { wsum[0][w] = __popcll(mp); wsum[1][w] = __popcll(mn); }
+        __syncthreads();
+        int pp = base_p, pn = base_n, tp = 0, tn = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (k < w) { pp += wsum[0][k]; pn += wsum[1][k]; }
+            tp += wsum[0][k]; tn += wsum[1][k];
+        }
+        if (fp) lists[((long)n * 2 + 0) * L + pp + __popcll(mp & lt)] = i;
+        if (fn) lists[((long)n * 2 + 1) * L + pn + __popcll(mn & lt)] = i;
+        base_p += tp; base_n += tn;
+        __syncthreads();
+    }
+    if (tid == 0) { counts[n * 2] = base_p; counts[n * 2 + 1] = base_n; }
+}
+}  // namespace
+
+extern "C" int aldi_roi_prepare_lists(const float* props, const int* pcount, int P, const float* gt_boxes, const int* gt_classes, const int* gt_count,
+                                      int Gmax, int N, int K, float iou_thresh, float* cand, int* ccount, float* best_iou, int* best_idx, int* labels,
+                                      int* cls, int* lists, int* counts, unsigned* tickets, aldi_stream_t stream) {
+    if (!props || !pcount || !gt_boxes || !gt_classes || !gt_count || !cand || !ccount || !best_iou || !best_idx || !labels || !cls || !lists || !counts || !tickets)
+        return aldi_set_error_msg(ALDI_ERR_ARG, "roi_prepare_lists: null pointer");
+    if (Gmax > kGtTile || Gmax < 1 || N < 1 || P < 0) return aldi_set_error_msg(ALDI_ERR_ARG, "roi_prepare_lists: Gmax must be 1 .. 256");
+    const int L = P + Gmax;
+    hipLaunchKernelGGL(roi_prepare_fused_kernel, dim3(kRoiPrepWgs, N), dim3(256), 0, static_cast<hipStream_t>(stream), (const float4*)props, pcount, P,
+                       (const float4*)gt_boxes, gt_classes, gt_count, Gmax, K, iou_thresh, L, (float4*)cand, ccount, best_iou, best_idx, labels, cls, lists, counts,
+                       tickets);
+    ALDI_CHECK_LAUNCH();
+    return ALDI_OK;
+}
+
 extern "C" size_t aldi_compact_labels_workspace(int L, int N) { return (size_t)N * 2 * (size_t)cdiv(L > 0 ? L : 1, kSegLabels) * sizeof(int); }
 
 extern "C" int aldi_compact_labels(const int* labels, int L, int N, int bg_label, int* lists, int* counts, void* workspace, aldi_stream_t stream) {

@@ -1124,12 +1124,20 @@ class RCNN:
         best_idx = torch.empty((N, Lc), dtype=torch.int32, device=dev)
         labels = torch.empty((N, Lc), dtype=torch.int32, device=dev)
         cls = torch.empty((N, Lc), dtype=torch.int32, device=dev)
-        scratch = torch.empty((N, GMAX), dtype=torch.int32, device=dev)
-        ops.roi_prepare(props, prop_count, P, gt["boxes"], gt["classes"], gt["count"], GMAX, N, self.K, self.p.roi_iou, cand, ccount, best_iou, best_idx,
-                        scratch, labels, cls)
         lists = torch.empty((N, 2, Lc), dtype=torch.int32, device=dev)
         counts = torch.empty((N, 2), dtype=torch.int32, device=dev)
-        ops.compact_labels(cls, Lc, N, self.K, lists, counts)
+        if os.environ.get("ALDI_ROI_PREPARE_FUSED", "1") == "1" and GMAX <= 256:
+            # one launch instead of eight on the chain that ends in the list lengths the host waits for (same results: tests/test_kernels_gpu.py)
+            tk = self._ws.get("roi_tickets")
+            if tk is None or tk.numel() < N:
+                tk = self._ws["roi_tickets"] = torch.zeros(max(N, 64), dtype=torch.int32, device=dev)
+            ops.roi_prepare_lists(props, prop_count, P, gt["boxes"], gt["classes"], gt["count"], GMAX, N, self.K, self.p.roi_iou, cand, ccount, best_iou,
+                                  best_idx, labels, cls, lists, counts, tk)
+        else:
+            scratch = torch.empty((N, GMAX), dtype=torch.int32, device=dev)
+            ops.roi_prepare(props, prop_count, P, gt["boxes"], gt["classes"], gt["count"], GMAX, N, self.K, self.p.roi_iou, cand, ccount, best_iou, best_idx,
+                            scratch, labels, cls)
+            ops.compact_labels(cls, Lc, N, self.K, lists, counts)
         return dict(cand=cand, cls=cls, best_idx=best_idx, lists=lists, counts=counts, Lc=Lc)
 
     def _roi_gather(self, c: Ctx, prep: dict, sel, nsel, nsel_h, gt, N, row_off_dev=None):

@@ -463,6 +463,60 @@ def test_roialign_forward_and_backward_are_adjoint_at_benchmark_size():
         L.reset_tuning()
 
 
+def test_roi_prepare_lists_equals_the_eight_launch_path():
+    """aldi_roi_prepare_lists (one launch; the image's last workgroup writes the lists) against aldi_roi_prepare + aldi_compact_labels: candidates,
+    matches, classes, the ordered foreground / background lists and their lengths, bit for bit -- images with no ground truth, with a full ground
+    truth table, with fewer proposals than slots, with ground truth exactly equal to a proposal (IoU = 1) and an IoU tie; called three times on
+    the same ticket words (they must come back zero)."""
+    from aldi_amd import ops
+    from aldi_amd.engine import GMAX
+    g = torch.Generator().manual_seed(5)
+    N, P, K = 5, 1000, 8
+    Lc = P + GMAX
+    props = torch.zeros(N, P, 4)
+    pcount = torch.tensor([1000, 640, 1000, 3, 1000], dtype=torch.int32)
+    gcount = torch.tensor([7, 0, GMAX, 2, 100], dtype=torch.int32)
+    gtb = torch.zeros(N, GMAX, 4)
+    gtc = torch.zeros(N, GMAX, dtype=torch.int32)
+    for n in range(N):
+        props[n, : int(pcount[n])] = _rand_boxes(int(pcount[n]), 1333, 800, g, lo=8.0, hi=400.0)
+        gtb[n, : int(gcount[n])] = _rand_boxes(int(gcount[n]), 1333, 800, g, lo=16.0, hi=300.0)
+        gtc[n, : int(gcount[n])] = torch.randint(0, K, (int(gcount[n]),), generator=g, dtype=torch.int32)
+    gtb[0, 1] = props[0, 10]                       # IoU exactly 1
+    gtb[0, 2] = gtb[0, 1]                          # ... and a tie: the first maximum wins
+    props[2, 5] = gtb[2, 77]
+    dev = DEV
+    props, pcount, gcount, gtb, gtc = props.to(dev), pcount.to(dev), gcount.to(dev), gtb.to(dev), gtc.to(dev)
+
+    def bufs():
+        return dict(cand=torch.full((N, Lc, 4), -7.0, device=dev), ccount=torch.full((N,), -7, dtype=torch.int32, device=dev),
+                    best_iou=torch.full((N, Lc), -7.0, device=dev), best_idx=torch.full((N, Lc), -7, dtype=torch.int32, device=dev),
+                    labels=torch.full((N, Lc), -7, dtype=torch.int32, device=dev), cls=torch.full((N, Lc), -7, dtype=torch.int32, device=dev),
+                    lists=torch.full((N, 2, Lc), -7, dtype=torch.int32, device=dev), counts=torch.full((N, 2), -7, dtype=torch.int32, device=dev))
+    a = bufs()
+    scratch = torch.empty((N, GMAX), dtype=torch.int32, device=dev)
+    ops.roi_prepare(props, pcount, P, gtb, gtc, gcount, GMAX, N, K, 0.5, a["cand"], a["ccount"], a["best_iou"], a["best_idx"], scratch, a["labels"], a["cls"])
+    ops.compact_labels(a["cls"], Lc, N, K, a["lists"], a["counts"])
+    tickets = torch.zeros(N, dtype=torch.int32, device=dev)
+    for rep in range(3):
+        b = bufs()
+        ops.roi_prepare_lists(props, pcount, P, gtb, gtc, gcount, GMAX, N, K, 0.5, b["cand"], b["ccount"], b["best_iou"], b["best_idx"], b["labels"], b["cls"],
+                              b["lists"], b["counts"], tickets)
+        torch.cuda.synchronize()
+        assert int(tickets.abs().sum()) == 0
+        for k in ("cand", "ccount", "labels", "cls", "counts"):
+            assert torch.equal(a[k], b[k]), (rep, k)
+        for n in range(N):
+            cnt = int(a["ccount"][n])
+            assert cnt == int(pcount[n]) + int(gcount[n])
+            assert torch.equal(a["best_iou"][n, :cnt], b["best_iou"][n, :cnt]) and torch.equal(a["best_idx"][n, :cnt], b["best_idx"][n, :cnt])
+            for kind in (0, 1):
+                m = int(a["counts"][n, kind])
+                assert torch.equal(a["lists"][n, kind, :m], b["lists"][n, kind, :m]), (rep, n, kind)
+    assert int(a["counts"][0, 0]) >= 7 and int(a["counts"][1, 0]) == 0 and int(a["counts"][1, 1]) == 640
+    assert int(b["best_idx"][0, 10]) == 1                                      # the tie between ground truth 1 and 2
+
+
 def test_rpn_and_box_losses_vs_oracle():
     from aldi_amd import ops
     from aldi_amd.engine import GMAX, ROI_WEIGHTS, make_anchors
