@@ -92,6 +92,13 @@ def last_dispatch() -> str:
     return lib.aldi_last_dispatch().decode()
 
 
+class BoxLossChunk(C.Structure):
+    """aldi_box_loss_chunk (include/aldi_hip.h)"""
+    _fields_ = [("r0", c_int), ("r1", c_int), ("grad_scale_cls", c_float), ("grad_scale_box", c_float), ("loss_box", c_void_p),
+                ("teacher_pred", c_void_p), ("cls_temperature", c_float), ("kl", c_int), ("do_cls", c_int), ("do_reg", c_int),
+                ("grad_scale_distill_cls", c_float), ("grad_scale_distill_reg", c_float), ("loss_distill", c_void_p)]
+
+
 class ConvArgs(C.Structure):
     _fields_ = [
         ("x", c_void_p), ("w", c_void_p), ("y", c_void_p), ("y_f32", c_void_p),

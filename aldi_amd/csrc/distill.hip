@@ -3,6 +3,7 @@
 // (reference aldi/align.py:76-90), plus the global-average-pool pair of the ConvDiscriminator
 // (reference aldi/align.py:103-119).
 #include "common.h"
+#include "loss_rows.h"
 #include <hip/amd_detail/amd_hip_unsafe_atomics.h>
 
 namespace {
@@ -90,44 +91,8 @@ __global__ __launch_bounds__(256) void roih_distill_kernel(const float* __restri
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
     float l_cls = 0.f, l_reg = 0.f;
     const float invR = 1.f / (float)max(R, 1);
-    if (r < R) {
-        const float* s = sp + (long)r * Cp;
-        const float* t = tp + (long)r * Cp;
-        // teacher softmax at temperature T, student log-softmax
-        float tm = t[0] * inv_T, sm = s[0];
-        int amax = 0;
-        float tbest = t[0];
-        for (int k = 1; k <= K; ++k) {
-            tm = fmaxf(tm, t[k] * inv_T);
-            sm = fmaxf(sm, s[k]);
-            if (t[k] > tbest) { tbest = t[k]; amax = k; }
-        }
-        float ts = 0.f, ss = 0.f;
-        for (int k = 0; k <= K; ++k) { ts += expf(t[k] * inv_T - tm); ss += expf(s[k] - sm); }
-        const float tl = tm + logf(ts), sl = sm + logf(ss);
-        if (do_cls) {
-            float psum = 0.f;
-            for (int k = 0; k <= K; ++k) {
-                const float lt = t[k] * inv_T - tl;
-                const float pk = expf(lt);
-                const float ls = s[k] - sl;
-                l_cls += kl ? pk * (lt - ls) : -pk * ls;
-                psum += pk;
-            }
-            if (grad && gscale != 0.f)
-                for (int k = 0; k <= K; ++k)
-                    grad[(long)r * Cp + k] += (expf(s[k] - sl) * psum - expf(t[k] * inv_T - tl)) * invR * gscale;
-        }
-        if (do_reg && amax != K) {
-#pragma unroll
-            for (int d = 0; d < 4; ++d) {
-                const int c = K + 1 + amax * 4 + d;
-                const float df = s[c] - t[c];
-                l_reg += fabsf(df);
-                if (grad && gscale != 0.f) grad[(long)r * Cp + c] += (df > 0.f ? 1.f : (df < 0.f ? -1.f : 0.f)) * invR * gscale;
-            }
-        }
-    }
+    if (r < R)
+        roih_distill_row(sp + (long)r * Cp, tp + (long)r * Cp, K, inv_T, kl, do_cls, do_reg, invR, gscale, gscale, grad ? grad + (long)r * Cp : nullptr, l_cls, l_reg);
     float s0 = block_sum(l_cls, red);
     float s1 = block_sum(l_reg, red);
     if (threadIdx.x == 0) {

@@ -7,6 +7,7 @@
 // the reference's own pseudo-label filter (aldi/pseudolabeler.py:51-67); call sites
 // aldi/distill.py:157,162 and aldi/pseudolabeler.py:21.
 #include "common.h"
+#include "loss_rows.h"
 #include "sortscan.h"
 #include "nms.h"
 #include <hip/amd_detail/amd_hip_unsafe_atomics.h>
@@ -888,38 +889,70 @@ __global__ __launch_bounds__(256) void box_loss_kernel(const float* __restrict__
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
     float l_cls = 0.f, l_box = 0.f;
     const float invR = 1.f / (float)max(R, 1);
-    if (r < R) {
-        const float* p = pred + (long)r * Cp;
-        const int y = cls[r];
-        float m = p[0];
-        for (int k = 1; k <= K; ++k) m = fmaxf(m, p[k]);
-        float s = 0.f;
-        for (int k = 0; k <= K; ++k) s += expf(p[k] - m);
-        const float lse = m + logf(s);
-        l_cls = lse - p[y];
-        if (grad && gs_cls != 0.f)
-            for (int k = 0; k <= K; ++k) grad[(long)r * Cp + k] += (expf(p[k] - lse) - (k == y ? 1.f : 0.f)) * invR * gs_cls;
-        if (y >= 0 && y < K) {
-            const float* rp = rois + (long)r * 5;
-            float src_w = rp[3] - rp[1], src_h = rp[4] - rp[2];
-            float sx = rp[1] + 0.5f * src_w, sy = rp[2] + 0.5f * src_h;
-            const float4 t = gtb[r];
-            float tw = t.z - t.x, th = t.w - t.y;
-            float tx = t.x + 0.5f * tw, ty = t.y + 0.5f * th;
-            float d[4] = {wx * (tx - sx) / src_w, wy * (ty - sy) / src_h, ww * logf(tw / src_w), wh * logf(th / src_h)};
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                float df = p[K + 1 + y * 4 + k] - d[k];
-                l_box += fabsf(df);
-                if (grad && gs_box != 0.f) grad[(long)r * Cp + K + 1 + y * 4 + k] += (df > 0.f ? 1.f : (df < 0.f ? -1.f : 0.f)) * invR * gs_box;
-            }
-        }
-    }
+    if (r < R)
+        box_loss_row(pred + (long)r * Cp, K, cls[r], rois + (long)r * 5, gtb[r], wx, wy, ww, wh, invR, gs_cls, gs_box, grad ? grad + (long)r * Cp : nullptr,
+                     l_cls, l_box);
     float s0 = block_sum(l_cls, red);
     float s1 = block_sum(l_box, red);
     if (threadIdx.x == 0) {
         if (s0 != 0.f) unsafeAtomicAdd(loss + 0, s0 * invR);
         if (s1 != 0.f) unsafeAtomicAdd(loss + 1, s1 * invR);
+    }
+}
+
+// The box head's losses of EVERY chunk of a fused step in one launch: FastRCNNOutputLayers.losses per chunk (its own row count, scales and
+// loss slots), the RoI distillation of the chunks that have a teacher, and the compute-dtype copy of the finished gradient rows -- four
+// launches (box_loss x chunks, roih_distill, cast) on the chain between the box head's forward and its backward, where a dependent small
+// launch costs 10-20 us of a replayed graph.  A chunk's rows are whole workgroups (its block sums go to its slots).  grad: fp32 [R][Cp],
+// ZEROED by the caller (the rows are accumulated into exactly as the separate kernels do: (0 + box) + distillation).
+constexpr int kMaxLossChunks = 8;
+struct BoxLossChunk {
+    int r0, r1, blk0;
+    float gs_cls, gs_box;
+    float* loss_box;
+    const float* tpred;                  // teacher rows of THIS chunk (row r0 first), or null
+    float inv_T; int kl, do_cls, do_reg;
+    float gs_dcls, gs_dreg;
+    float* loss_d;
+};
+struct BoxLossArgs { int n; BoxLossChunk c[kMaxLossChunks]; };
+__global__ __launch_bounds__(256) void box_losses_fused_kernel(const float* __restrict__ pred, int Cp, int K, const float* __restrict__ rois,
+                                                               const int* __restrict__ cls, const float4* __restrict__ gtb, float wx, float wy, float ww, float wh,
+                                                               float* grad, bf16_t* __restrict__ grad_lo, BoxLossArgs A) {
+    __shared__ float red[16];
+    int ci = 0;
+    for (int k = 1; k < A.n; ++k)
+        if ((int)blockIdx.x >= A.c[k].blk0) ci = k;
+    const BoxLossChunk& ch = A.c[ci];
+    const int r = ch.r0 + ((int)blockIdx.x - ch.blk0) * (int)blockDim.x + (int)threadIdx.x;
+    const float invR = 1.f / (float)max(ch.r1 - ch.r0, 1);
+    float l_cls = 0.f, l_box = 0.f, d_cls = 0.f, d_reg = 0.f;
+    if (r < ch.r1) {
+        float* grow = grad + (long)r * Cp;
+        box_loss_row(pred + (long)r * Cp, K, cls[r], rois + (long)r * 5, gtb[r], wx, wy, ww, wh, invR, ch.gs_cls, ch.gs_box, grow, l_cls, l_box);
+        if (ch.tpred)
+            roih_distill_row(pred + (long)r * Cp, ch.tpred + (long)(r - ch.r0) * Cp, K, ch.inv_T, ch.kl, ch.do_cls, ch.do_reg, invR, ch.gs_dcls, ch.gs_dreg,
+                             grow, d_cls, d_reg);
+        if (grad_lo)
+            for (int k = 0; k < Cp; k += 2) {
+                const float a = grow[k], b = k + 1 < Cp ? grow[k + 1] : 0.f;
+                if (k + 1 < Cp) *reinterpret_cast<uint32_t*>(grad_lo + (long)r * Cp + k) = pack2_bf16(a, b);
+                else grad_lo[(long)r * Cp + k] = f32_to_bf16(a);
+            }
+    }
+    float s0 = block_sum(l_cls, red);
+    float s1 = block_sum(l_box, red);
+    if (threadIdx.x == 0) {
+        if (s0 != 0.f) unsafeAtomicAdd(ch.loss_box + 0, s0 * invR);
+        if (s1 != 0.f) unsafeAtomicAdd(ch.loss_box + 1, s1 * invR);
+    }
+    if (ch.tpred) {
+        float t0 = block_sum(d_cls, red);
+        float t1 = block_sum(d_reg, red);
+        if (threadIdx.x == 0) {
+            if (t0 != 0.f) unsafeAtomicAdd(ch.loss_d + 0, t0 * invR);
+            if (t1 != 0.f) unsafeAtomicAdd(ch.loss_d + 1, t1 * invR);
+        }
     }
 }
 
@@ -1127,6 +1160,31 @@ extern "C" int aldi_box_loss(const float* pred, int Cp, int K, int R, const floa
     if (R <= 0) return ALDI_OK;
     hipLaunchKernelGGL(box_loss_kernel, dim3(cdiv(R, 256)), dim3(256), 0, static_cast<hipStream_t>(stream), pred, Cp, K, R, rois, cls, (const float4*)gt_boxes,
                        weights4[0], weights4[1], weights4[2], weights4[3], grad_scale_cls, grad_scale_box, grad, loss2);
+    ALDI_CHECK_LAUNCH();
+    return ALDI_OK;
+}
+
+extern "C" int aldi_box_losses_fused(const float* pred, int Cp, int K, const float* rois, const int* cls, const float* gt_boxes, const float* weights4,
+                                     const aldi_box_loss_chunk* chunks, int nchunks, float* grad, void* grad_lo, aldi_stream_t stream) {
+    if (!pred || !rois || !cls || !gt_boxes || !weights4 || !chunks || !grad) return aldi_set_error_msg(ALDI_ERR_ARG, "box_losses_fused: null pointer");
+    if (nchunks < 1 || nchunks > kMaxLossChunks || (Cp & 1)) return aldi_set_error_msg(ALDI_ERR_ARG, "box_losses_fused: 1 .. 8 chunks, even row length");
+    BoxLossArgs A;
+    A.n = 0;
+    int blk = 0;
+    for (int i = 0; i < nchunks; ++i) {
+        const aldi_box_loss_chunk& q = chunks[i];
+        if (q.r1 <= q.r0) continue;
+        if (!q.loss_box || (q.teacher_pred && !q.loss_distill)) return aldi_set_error_msg(ALDI_ERR_ARG, "box_losses_fused: missing loss slot");
+        BoxLossChunk& c = A.c[A.n++];
+        c.r0 = q.r0; c.r1 = q.r1; c.blk0 = blk;
+        c.gs_cls = q.grad_scale_cls; c.gs_box = q.grad_scale_box; c.loss_box = q.loss_box;
+        c.tpred = q.teacher_pred; c.inv_T = q.teacher_pred ? 1.f / q.cls_temperature : 1.f; c.kl = q.kl; c.do_cls = q.do_cls; c.do_reg = q.do_reg;
+        c.gs_dcls = q.grad_scale_distill_cls; c.gs_dreg = q.grad_scale_distill_reg; c.loss_d = q.loss_distill;
+        blk += cdiv(q.r1 - q.r0, 256);
+    }
+    if (A.n == 0) return ALDI_OK;
+    hipLaunchKernelGGL(box_losses_fused_kernel, dim3(blk), dim3(256), 0, static_cast<hipStream_t>(stream), pred, Cp, K, rois, cls, (const float4*)gt_boxes,
+                       weights4[0], weights4[1], weights4[2], weights4[3], grad, (bf16_t*)grad_lo, A);
     ALDI_CHECK_LAUNCH();
     return ALDI_OK;
 }

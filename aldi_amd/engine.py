@@ -1000,6 +1000,9 @@ class RCNN:
                 c.ghead = [torch.zeros_like(h) for h in c.head]
         gt = c.gt
         align_list = []
+        # the box head's losses of all chunks (+ RoI distillation + the compute-dtype copy of the gradient rows) as ONE launch: csrc/roi.hip
+        box_fused = [] if (c.R > 0 and len(c.chunks) <= 8 and self.Cp % 2 == 0 and os.environ.get("ALDI_BOX_LOSS_FUSED", "1") == "1") else None
+        c.gpred_lo = None
         for ci, (ch, sc_) in enumerate(zip(c.chunks, scales)):
             sc = lambda k: float(sc_.get(k, 0.0))
             n0, n1, r0, r1 = ch["n0"], ch["n1"], ch["r0"], ch["r1"]
@@ -1018,8 +1021,11 @@ class RCNN:
             with rpn_ctx():
                 ops.rpn_loss(c.geom, heads, gheads, c.anchors, c.rpn_labels[n0:n1], c.rpn_matched[n0:n1], gt["boxes"][n0:n1], gt["count"][n0:n1],
                              GMAX, nc, 1.0 / (self.p.rpn_batch * nc), sc("loss_rpn_cls"), sc("loss_rpn_loc"), l_rpn)
-            ops.box_loss(c.pred[r0:r1], self.Cp, self.K, r1 - r0, c.rois[r0:r1], c.r_cls[r0:r1], c.r_gt[r0:r1], self.p.roi_weights,
-                         sc("loss_cls"), sc("loss_box_reg"), c.gpred[r0:r1], l_box)
+            if box_fused is not None:
+                box_fused.append(dict(r0=r0, r1=r1, gs_cls=sc("loss_cls"), gs_box=sc("loss_box_reg"), loss_box=l_box))
+            else:
+                ops.box_loss(c.pred[r0:r1], self.Cp, self.K, r1 - r0, c.rois[r0:r1], c.r_cls[r0:r1], c.r_gt[r0:r1], self.p.roi_weights,
+                             sc("loss_cls"), sc("loss_box_reg"), c.gpred[r0:r1], l_box)
             d = ch["distill"]
             if d is not None:
                 def rpn_d(do_obj, do_reg, s_):
@@ -1028,8 +1034,13 @@ class RCNN:
 
                 if d.get("t_ev") is not None:
                     torch.cuda.current_stream().wait_event(d["t_ev"])       # the teacher's box head (its own stream)
+                if box_fused is not None:
+                    box_fused[-1].update(t_pred=d["t_pred"], cls_T=d["cls_T"], kl=d["kl"], do_cls=d["do_cls"], do_reg=d["do_roih_reg"],
+                                         gs_dcls=sc("loss_cls_ce"), gs_dreg=sc("loss_roih_l1"), loss_d=l_droi)
 
                 def roi_d(do_cls, do_reg, s_):
+                    if box_fused is not None:
+                        return
                     ops.roih_distill_loss(c.pred[r0:r1], d["t_pred"], self.Cp, self.K, r1 - r0, d["cls_T"], d["kl"], do_cls, do_reg, s_, c.gpred[r0:r1], l_droi)
                 with rpn_ctx():
                     if sc("loss_obj_bce") == sc("loss_rpn_l1"):
@@ -1056,6 +1067,10 @@ class RCNN:
                 al["ins"] = (acts, glog)
             if "img" in al or "ins" in al:
                 align_list.append(al)
+        if box_fused:
+            if T == torch.bfloat16:
+                c.gpred_lo = torch.empty((c.R, self.Cp), dtype=T, device=dev)
+            ops.box_losses_fused(c.pred, self.Cp, self.K, c.rois, c.r_cls, c.r_gt, self.p.roi_weights, box_fused, c.gpred, c.gpred_lo)
         if early is not None:
             torch.cuda.current_stream().wait_stream(aux0)    # (the RPN-side values and head gradients: finished long ago)
         if after_losses is not None:
@@ -1318,7 +1333,8 @@ class RCNN:
                         ops.conv2d(g_, W.wt(L_[0], negate=True), out=g_extra[r0:r1])
                     else:
                         g_ = ops.conv2d(g_, W.wt(L_[i]), mask=acts[i])      # acts[i] is the ReLU output of layer i-1
-            gpred = ops.cast_from_f32(c.gpred[:c.R], T).view(c.R, 1, 1, self.Cp)
+            lo = c.get("gpred_lo")
+            gpred = (lo if lo is not None else ops.cast_from_f32(c.gpred[:c.R], T)).view(c.R, 1, 1, self.Cp)
             self._wgrad("box_pred", c.fc2, gpred)
             g_fc2 = ops.conv2d(gpred, W.wt("box_pred"), res=g_extra, res_mode=1 if g_extra is not None else 0, **self._relu_mask(c, c.fc2))
             self._wgrad("roi_heads.box_head.fc2", c.fc1, g_fc2)

@@ -548,6 +548,18 @@ def rpn_distill_loss(geom, s_head, t_head, grad, labels, N, obj_T, n_valid, n_fg
            _p(counts_dev), int(do_obj), int(do_reg), grad_scale, _p(loss2), stream_ptr())
 
 
+def box_losses_fused(pred, Cp, K, rois, cls, gt_boxes, weights4, chunks, grad, grad_lo):
+    """aldi_box_losses_fused: chunks = [dict(r0, r1, gs_cls, gs_box, loss_box, t_pred=None, cls_T=1.0, kl=False, do_cls=False, do_reg=False,
+    gs_dcls=0.0, gs_dreg=0.0, loss_d=None)] -- box_loss per chunk + roih_distill_loss where t_pred is given + the bf16 copy of the rows"""
+    arr = (L.BoxLossChunk * len(chunks))()
+    for i, q in enumerate(chunks):
+        arr[i] = L.BoxLossChunk(q["r0"], q["r1"], q["gs_cls"], q["gs_box"], _p(q["loss_box"]), _p(q.get("t_pred")), float(q.get("cls_T", 1.0)),
+                                int(bool(q.get("kl"))), int(bool(q.get("do_cls"))), int(bool(q.get("do_reg"))), float(q.get("gs_dcls", 0.0)),
+                                float(q.get("gs_dreg", 0.0)), _p(q.get("loss_d")))
+    w = (C.c_float * 4)(*weights4)
+    L.call("aldi_box_losses_fused", _p(pred), Cp, K, _p(rois), _p(cls), _p(gt_boxes), w, arr, len(chunks), _p(grad), _p(grad_lo), stream_ptr())
+
+
 def roih_distill_loss(s_pred, t_pred, Cp, K, R, cls_T, kl, do_cls, do_reg, grad_scale, grad, loss2):
     L.call("aldi_roih_distill_loss", _p(s_pred), _p(t_pred), Cp, K, R, cls_T, int(kl), int(do_cls), int(do_reg), grad_scale, _p(grad),
            _p(loss2), stream_ptr())

@@ -381,6 +381,22 @@ int aldi_roialign_backward(const aldi_roi_feats* f, const float* rois, int R, in
  * grad (fp32 [R][Cp], nullable) += d(scale_cls*loss_cls + scale_box*loss_box_reg)/d(pred). */
 int aldi_box_loss(const float* pred, int Cp, int K, int R, const float* rois, const int* cls, const float* gt_boxes,
                   const float* weights4, float grad_scale_cls, float grad_scale_box, float* grad, float* loss2, aldi_stream_t stream);
+/* The box head's losses of every chunk of a fused step in ONE launch: aldi_box_loss per chunk (rows r0 .. r1 of pred / rois / cls / gt_boxes,
+ * normalised by the chunk's row count, its own scales and loss2 slot), aldi_roih_distill_loss for the chunks with teacher_pred (the chunk's
+ * teacher rows, row r0 first; separate gradient scales for the classification and the regression part), and grad_lo (nullable): the bf16
+ * copy of the finished gradient rows [R][Cp].  grad: fp32 [R][Cp], zeroed by the caller.  The same values as the separate launches. */
+typedef struct {
+    int r0, r1;
+    float grad_scale_cls, grad_scale_box;
+    float* loss_box;                 /* [2] += {CE mean, L1 sum / rows} */
+    const float* teacher_pred;       /* NULL: no distillation for this chunk */
+    float cls_temperature;
+    int kl, do_cls, do_reg;
+    float grad_scale_distill_cls, grad_scale_distill_reg;
+    float* loss_distill;             /* [2] += {loss_cls_ce, loss_roih_l1} */
+} aldi_box_loss_chunk;
+int aldi_box_losses_fused(const float* pred, int Cp, int K, const float* rois, const int* cls, const float* gt_boxes, const float* weights4,
+                          const aldi_box_loss_chunk* chunks, int nchunks, float* grad, void* grad_lo, aldi_stream_t stream);
 size_t aldi_detections_workspace(int N);
 /* fast_rcnn_inference + pseudo-label filter. pred fp32 [N*P][Cp] for all proposals.
  * det_* [N][topk], pl_* [N][pl_rows >= topk] (detections with score > pl_thresh, order kept, the rest of each row cleared: the

@@ -517,6 +517,54 @@ def test_roi_prepare_lists_equals_the_eight_launch_path():
     assert int(b["best_idx"][0, 10]) == 1                                      # the tie between ground truth 1 and 2
 
 
+def test_box_losses_fused_equals_the_separate_launches():
+    """aldi_box_losses_fused against aldi_box_loss per chunk + aldi_roih_distill_loss (once with one scale, once split into its two parts with
+    different scales) + aldi_cast_from_f32: gradient rows bit for bit (fp32 and the bf16 copy), loss values to the order of the block sums'
+    atomic adds."""
+    from aldi_amd import ops
+    g = torch.Generator().manual_seed(9)
+    K, Cp = 8, 48
+    chunks = [(0, 700), (700, 700 + 513), (1213, 1213 + 300)]
+    R = chunks[-1][1]
+    pred = (torch.randn(R, Cp, generator=g) * 2).to(DEV)
+    tpred = (torch.randn(R, Cp, generator=g) * 2).to(DEV)
+    rois = torch.cat([torch.zeros(R, 1), _rand_boxes(R, 1333, 800, g, lo=8.0, hi=300.0)], 1).contiguous().to(DEV)
+    cls = torch.randint(0, K + 1, (R,), generator=g, dtype=torch.int32).to(DEV)
+    gtb = _rand_boxes(R, 1333, 800, g, lo=8.0, hi=300.0).to(DEV)
+    w4 = (10.0, 10.0, 5.0, 5.0)
+    for split_scales in (False, True):
+        spec = [dict(gs_cls=0.5, gs_box=0.5), dict(gs_cls=0.0, gs_box=0.25, distill=(0.5, 0.125 if split_scales else 0.5), kl=split_scales),
+                dict(gs_cls=1.0 / 3, gs_box=0.0, distill=(0.0 if split_scales else 0.25, 0.0 if split_scales else 0.25))]
+        ref_g = torch.zeros(R, Cp, device=DEV)
+        ref_l = torch.zeros(len(chunks), 4, device=DEV)
+        for i, ((r0, r1), sp) in enumerate(zip(chunks, spec)):
+            ops.box_loss(pred[r0:r1], Cp, K, r1 - r0, rois[r0:r1], cls[r0:r1], gtb[r0:r1], w4, sp["gs_cls"], sp["gs_box"], ref_g[r0:r1], ref_l[i, 0:2])
+            if "distill" in sp:
+                a, b = sp["distill"]
+                kl = sp.get("kl", False)
+                if a == b:
+                    ops.roih_distill_loss(pred[r0:r1], tpred[r0:r1], Cp, K, r1 - r0, 2.0, kl, True, True, a, ref_g[r0:r1], ref_l[i, 2:4])
+                else:
+                    ops.roih_distill_loss(pred[r0:r1], tpred[r0:r1], Cp, K, r1 - r0, 2.0, kl, True, False, a, ref_g[r0:r1], ref_l[i, 2:4])
+                    ops.roih_distill_loss(pred[r0:r1], tpred[r0:r1], Cp, K, r1 - r0, 2.0, kl, False, True, b, ref_g[r0:r1], ref_l[i, 2:4])
+        ref_lo = ops.cast_from_f32(ref_g, torch.bfloat16)
+        got_g = torch.zeros(R, Cp, device=DEV)
+        got_lo = torch.full((R, Cp), float("nan"), dtype=torch.bfloat16, device=DEV)
+        got_l = torch.zeros(len(chunks), 4, device=DEV)
+        desc = []
+        for i, ((r0, r1), sp) in enumerate(zip(chunks, spec)):
+            q = dict(r0=r0, r1=r1, gs_cls=sp["gs_cls"], gs_box=sp["gs_box"], loss_box=got_l[i, 0:2])
+            if "distill" in sp:
+                q.update(t_pred=tpred[r0:r1], cls_T=2.0, kl=sp.get("kl", False), do_cls=True, do_reg=True, gs_dcls=sp["distill"][0], gs_dreg=sp["distill"][1],
+                         loss_d=got_l[i, 2:4])
+            desc.append(q)
+        ops.box_losses_fused(pred, Cp, K, rois, cls, gtb, w4, desc, got_g, got_lo)
+        torch.cuda.synchronize()
+        assert torch.equal(ref_g, got_g), split_scales
+        assert torch.equal(ref_lo, got_lo), split_scales
+        assert float(ref_g.abs().sum()) > 0 and float((ref_l - got_l).abs().max()) <= 2e-6 * float(ref_l.abs().max()), (ref_l, got_l)
+
+
 def test_rpn_and_box_losses_vs_oracle():
     from aldi_amd import ops
     from aldi_amd.engine import GMAX, ROI_WEIGHTS, make_anchors
