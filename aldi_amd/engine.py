@@ -1506,10 +1506,7 @@ class RCNN:
         ops.rpn_sparse_gather(c.geom, c.ghead, c.rpn_t, c.P, N, Cf, cap, idx, count, G, Tm, X9)
         g_t = ops.conv2d(G, W.wt("rpn_head_out"), mask=Tm)
         Y = ops.conv2d(g_t, W.wt_flat("proposal_generator.rpn_head.conv"))           # [cap][9][Cf]: contributions to the 3x3 neighbourhood
-        # (P6 has no ROIAlign share: its gradient map starts from zero -- cleared here, off the chain into the FPN's backward)
-        g_dt = T if T == torch.bfloat16 else torch.float32
-        gp6 = torch.zeros(c.P[4].shape, dtype=g_dt, device=dev)
-        return dict(cap=cap, idx=idx, count=count, G=G, Tm=Tm, X9=X9, g_t=g_t, Y=Y, gp6=gp6)
+        return dict(cap=cap, idx=idx, count=count, G=G, Tm=Tm, X9=X9, g_t=g_t, Y=Y)
 
     def _rpn_sparse_finish(self, c: Ctx, gP_roi: List[torch.Tensor], sp: dict) -> List[torch.Tensor]:
         """queue the two weight gradients and scatter the rows into d(loss)/d(P_l) (ROIAlign's contribution gP_roi included: fp32
@@ -1517,10 +1514,7 @@ class RCNN:
         T, dev = self.dtype, self.device
         self._wgrad("rpn_head_out", sp["Tm"], sp["G"], temp_x=True)
         self._wgrad("proposal_generator.rpn_head.conv", sp["X9"], sp["g_t"], flat=True, temp_x=True)
-        gp6 = sp.get("gp6")
-        if gp6 is None or gp6.dtype != gP_roi[0].dtype:
-            gp6 = torch.zeros(c.P[4].shape, dtype=gP_roi[0].dtype, device=dev)
-        g32 = list(gP_roi) + [gp6]
+        g32 = list(gP_roi) + [torch.zeros(c.P[4].shape, dtype=gP_roi[0].dtype, device=dev)]
         ops.rpn_sparse_scatter(c.geom, g32, sp["Y"], c.N, FPN_C, sp["cap"], sp["idx"], sp["count"])
         return g32 if g32[0].dtype == T else [ops.cast_from_f32(g, T) for g in g32]
 
