@@ -367,8 +367,11 @@ constexpr int kTopkCap = 2048;     // >= PRE_NMS_TOPK (2000)
 constexpr int kMergeCap = 16384;   // >= 5 * 2000
 
 // order-preserving keys of every objectness logit, [N][sumA] (level-major, (h, w, a) inside a level)
-__global__ void rpn_keys_kernel(Geom g, int N, unsigned* __restrict__ keys) {
+// (it also clears the `zero_words` ints of the radix select's histograms / states behind it: a memset node of its own was one more
+// dependent launch on the proposal chain)
+__global__ void rpn_keys_kernel(Geom g, int N, unsigned* __restrict__ keys, int* __restrict__ zero_ptr, long zero_words) {
     const long t = blockIdx.x * (long)blockDim.x + threadIdx.x;
+    for (long z = t; z < zero_words; z += (long)gridDim.x * blockDim.x) zero_ptr[z] = 0;
     if (t >= (long)N * g.sumA) return;
     const int n = (int)(t / g.sumA), i = (int)(t - (long)n * g.sumA);
     const int l = find_level(g, i);
@@ -875,15 +878,14 @@ extern "C" int aldi_rpn_proposals(const aldi_rpn_geom* gm, float* const* head, c
     auto* keep_count = (int*)take(B * 4);
     if (g.sumA > 512 * 1024) return aldi_set_error_msg(ALDI_ERR_ARG, "rpn_proposals: more than 512K anchors per image");
     auto* okeys = (unsigned*)take((size_t)N * g.sumA * 4);
-    hipLaunchKernelGGL(rpn_keys_kernel, dim3(cdiv((long)N * g.sumA, 256)), dim3(256), 0, st, g, N, okeys);
-    ALDI_CHECK_LAUNCH();
     {
         // exact top-k per (level, image): multi-workgroup radix select (see topk_hist_kernel)
         auto* hists = (int*)take((size_t)3 * B * 4096 * 4);
         auto* tstate = (TopkState*)take((size_t)3 * B * sizeof(TopkState));     // [current | staging | final]
         auto* fill = (int*)take(B * 4);
-        hipError_t e = hipMemsetAsync(hists, 0, (size_t)((char*)fill + B * 4 - (char*)hists), st);
-        if (e != hipSuccess) return aldi_set_error(e, __FILE__, __LINE__);
+        const long zero_words = (long)(((char*)fill + B * 4 - (char*)hists + 3) / 4);
+        hipLaunchKernelGGL(rpn_keys_kernel, dim3(cdiv((long)N * g.sumA, 256)), dim3(256), 0, st, g, N, okeys, hists, zero_words);
+        ALDI_CHECK_LAUNCH();
         int max_nel = 0;
         for (int l = 0; l < g.nl; ++l) max_nel = g.H[l] * g.W[l] * g.A > max_nel ? g.H[l] * g.W[l] * g.A : max_nel;
         dim3 grid(cdiv(max_nel, kTopkChunk), g.nl, N);

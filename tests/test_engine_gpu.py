@@ -190,7 +190,7 @@ def test_full_aldi_iterations_vs_oracle(align):
         orc_idx.append(torch.cat([s_["sampled_idxs"] for s_ in orc.last["student_cap"]["sampled"]]).to(torch.int32))
         return out
     orc.model = omodel_rec
-    prop_diffs, prop_noise = [], []
+    prop_diffs, prop_shift, prop_noise = [], [], []
     try:
         for it in range(2):
             hip_idx.clear()
@@ -247,8 +247,13 @@ def test_full_aldi_iterations_vs_oracle(align):
                 # coordinate by up to a few 1e-2 px on boxes hundreds of pixels wide), and the largest coordinate difference among
                 # the boxes that are the same
                 d_ = (a_[:m_] - b_[:m_]).abs().max(1)[0]
-                prop_diffs.append(abs(len(a_) - len(b_)) + int((d_ >= 0.5).sum()))
+                prop_shift.append(abs(len(a_) - len(b_)) + int((d_ >= 0.5).sum()))
                 prop_noise.append(float(d_[d_ < 0.5].max()) if bool((d_ < 0.5).any()) else 0.0)
+                # ... and as SETS (a box of one list with no box of the other within 0.5 px): a flipped NMS decision in the middle of the
+                # ranking shifts every later rank -- seen once in ~20 runs: 78 ranks of 1000 -- but changes the set by the box it keeps or
+                # drops and the one that enters or leaves at the cut
+                pair = (a_[:, None, :] - b_[None, :, :]).abs().max(2)[0]
+                prop_diffs.append(int((pair.min(1)[0] >= 0.5).sum()) + int((pair.min(0)[0] >= 0.5).sum()))
             for k in ref:
                 assert abs(ref[k] - hip[k]) < tol * max(1.0, abs(ref[k])), (it, k, ref[k], hip[k], ndiff)
             own = orc.last["pseudo_own"]
@@ -275,11 +280,12 @@ def test_full_aldi_iterations_vs_oracle(align):
     assert int(tr.model.engine.err) == 0 and int(tr.ema.model.engine.err) == 0
     # proposals from the oracle's OWN trunk vs the device's: identical lists (count and every box to 1e-2 px) for at least one image
     # and iteration, i.e. where no NMS / top-k decision sat on an fp32 near-tie
-    print("different proposals per (iteration, image):", prop_diffs, "largest coordinate noise among equal ones [px]:", [round(v, 4) for v in prop_noise])
-    # measured: [6, 6, 0, 0] / [6, 6, 6, 2] (align off, two runs: the second iteration starts from weights that carry the fp32
-    # atomics' summation order), [6, 6, 2, 0] (on), [6, 6, 4, 2] ("deep") of ~1000 proposals per image, the equal ones to 6e-4 px:
-    # ONE decision flipped near the post-NMS cut of an image (a score pair within fp32 noise of the two trunks) shows up as the tail
-    # behind it; no image differs by more than 1 %, and where no such pair exists the lists are identical
+    print("different proposals per (iteration, image):", prop_diffs, "rank by rank:", prop_shift, "largest coordinate noise among equal ones [px]:",
+          [round(v, 4) for v in prop_noise])
+    # measured over ~40 runs: as sets 0 (2 once) of ~1000 proposals per image; rank by rank [6, 6, 0..4, 0..4] -- three pairs of equal scores in
+    # another order in the first iteration, and in the second (whose weights carry the fp32 atomics' summation order of the first) now and then
+    # ONE NMS decision flipped by a score pair within fp32 noise of the two trunks: once at rank ~920, which moves the 78 ranks behind it (the
+    # rank-by-rank count is therefore printed, not bounded); the boxes that are the same agree to 6e-4 px
     assert len(prop_diffs) == 4 and max(prop_diffs) <= 10 and max(prop_noise) < 5e-3, (prop_diffs, prop_noise)
 
 
