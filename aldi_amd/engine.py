@@ -1568,7 +1568,17 @@ class RCNN:
             cache = self.__dict__.setdefault("_sub_cache", {})
             hit = cache.get(id(x))
             if hit is None or hit[0] is not x:
-                hit = (x, ops.subsample2(x))
+                side_ = self._wgrad_stream()
+                if side_ is not None and os.environ.get("ALDI_WGRAD_SUBSAMPLE_SIDE", "1") == "1":
+                    # only the weight gradients read the gathered map: on THEIR stream, not as one more dependent launch of the
+                    # data-gradient chain (x is a saved activation: complete long before this point of the main stream)
+                    ev_ = torch.cuda.Event()
+                    ev_.record()
+                    side_.wait_event(ev_)
+                    with torch.cuda.stream(side_):
+                        hit = (x, ops.subsample2(x))
+                else:
+                    hit = (x, ops.subsample2(x))
                 cache.clear()
                 cache[id(x)] = hit
             x, temp_x = hit[1], True
