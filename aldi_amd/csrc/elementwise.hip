@@ -444,6 +444,72 @@ __global__ void upsample2_bwd_kernel(const T* __restrict__ g, T* __restrict__ ou
     }
 }
 
+// The FPN's top-down backward as ONE launch: o3 += blocks(g2); o4 += blocks(o3); o5 += blocks(o4) -- three dependent calls of the kernel
+// above, each a launch on the chain between the FPN's output convolutions' and the lateral convolutions' data gradients.  A thread owns 4
+// channels of one pixel of the COARSEST map and walks its 4 / 16 / 64 descendants; every level's sums are formed in the order of the kernel
+// above and pass through the storage type (store4 + what it would read back) before the next level uses them: the same bits.
+template <typename T> __device__ __forceinline__ void through_storage(float v[4]);
+template <> __device__ __forceinline__ void through_storage<float>(float v[4]) {}
+template <> __device__ __forceinline__ void through_storage<bf16_t>(float v[4]) {
+    bf16_t t[4];
+    store4(t, v);
+    load4(t, v);
+}
+template <typename T>
+__global__ void upsample2_bwd_chain_kernel(const T* __restrict__ g2, T* __restrict__ o3, T* __restrict__ o4, T* __restrict__ o5, int N, int H5, int W5, int C) {
+    const long total = (long)N * H5 * W5 * (C / 4);
+    const int H4 = H5 * 2, W4 = W5 * 2, H3 = H5 * 4, W3 = W5 * 4, H2 = H5 * 8, W2 = W5 * 8;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int c4 = (int)(i % (C / 4));
+        long r = i / (C / 4);
+        const int w5 = (int)(r % W5); r /= W5;
+        const int h5 = (int)(r % H5);
+        const int n = (int)(r / H5);
+        float s5[4] = {0, 0, 0, 0};
+        for (int a = 0; a < 4; ++a) {                                  // the 2 x 2 block of the middle map, (dy, dx) order
+            const int h4 = h5 * 2 + (a >> 1), w4 = w5 * 2 + (a & 1);
+            float s4[4] = {0, 0, 0, 0};
+            for (int b = 0; b < 4; ++b) {
+                const int h3 = h4 * 2 + (b >> 1), w3 = w4 * 2 + (b & 1);
+                float s3[4] = {0, 0, 0, 0};
+#pragma unroll
+                for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+                    for (int dx = 0; dx < 2; ++dx) {
+                        float v[4];
+                        load4(g2 + (((long)n * H2 + h3 * 2 + dy) * W2 + w3 * 2 + dx) * C + c4 * 4, v);
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) s3[k] += v[k];
+                    }
+                T* p3 = o3 + (((long)n * H3 + h3) * W3 + w3) * C + c4 * 4;
+                float o[4];
+                load4(p3, o);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) s3[k] += o[k];
+                store4(p3, s3);
+                through_storage<T>(s3);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) s4[k] += s3[k];
+            }
+            T* p4 = o4 + (((long)n * H4 + h4) * W4 + w4) * C + c4 * 4;
+            float o[4];
+            load4(p4, o);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) s4[k] += o[k];
+            store4(p4, s4);
+            through_storage<T>(s4);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) s5[k] += s4[k];
+        }
+        T* p5 = o5 + i * 4;
+        float o[4];
+        load4(p5, o);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) s5[k] += o[k];
+        store4(p5, s5);
+    }
+}
+
 // out = (a ? a : 0) + (b ? b : 0) * bscale, optionally masked by relu_src > 0; a is T, b is fp32
 template <typename T>
 __global__ void add_f32_kernel(const T* __restrict__ a, const float* __restrict__ b, const T* __restrict__ relu_src, T* __restrict__ out, long n4) {
@@ -673,6 +739,16 @@ extern "C" int aldi_upsample2_bwd(const void* g, void* out, int N, int Hc, int W
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (dtype == ALDI_BF16) hipLaunchKernelGGL(upsample2_bwd_kernel<bf16_t>, dim3(nblocks(total)), dim3(256), 0, st, (const bf16_t*)g, (bf16_t*)out, N, Hc, Wc, C, accumulate);
     else hipLaunchKernelGGL(upsample2_bwd_kernel<float>, dim3(nblocks(total)), dim3(256), 0, st, (const float*)g, (float*)out, N, Hc, Wc, C, accumulate);
+    ALDI_CHECK_LAUNCH();
+    return ALDI_OK;
+}
+
+extern "C" int aldi_upsample2_bwd_chain(const void* g2, void* o3, void* o4, void* o5, int N, int H5, int W5, int C, int dtype, aldi_stream_t stream) {
+    if (!g2 || !o3 || !o4 || !o5 || N < 1 || H5 < 1 || W5 < 1 || (C & 3)) return aldi_set_error_msg(ALDI_ERR_ARG, "upsample2_bwd_chain: bad args");
+    const long total = (long)N * H5 * W5 * (C / 4);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (dtype == ALDI_BF16) hipLaunchKernelGGL(upsample2_bwd_chain_kernel<bf16_t>, dim3(cdiv(total, 256)), dim3(256), 0, st, (const bf16_t*)g2, (bf16_t*)o3, (bf16_t*)o4, (bf16_t*)o5, N, H5, W5, C);
+    else hipLaunchKernelGGL(upsample2_bwd_chain_kernel<float>, dim3(cdiv(total, 256)), dim3(256), 0, st, (const float*)g2, (float*)o3, (float*)o4, (float*)o5, N, H5, W5, C);
     ALDI_CHECK_LAUNCH();
     return ALDI_OK;
 }

@@ -1397,8 +1397,13 @@ class RCNN:
         else:
             for i, lvl in enumerate((2, 3, 4, 5)):
                 gprev[lvl] = ops.conv2d(gP[i], W.wt(f"backbone.fpn_output{lvl}"), pad=1)
-        for lvl in (3, 4, 5):
-            ops.upsample2_bwd(gprev[lvl - 1], gprev[lvl], accumulate=True)
+        sh = [tuple(gprev[lvl].shape) for lvl in (2, 3, 4, 5)]
+        if (all(sh[i][1] == 2 * sh[i + 1][1] and sh[i][2] == 2 * sh[i + 1][2] for i in range(3)) and all(gprev[lvl].is_contiguous() for lvl in (2, 3, 4, 5))
+                and os.environ.get("ALDI_UPSAMPLE_CHAIN", "1") == "1"):
+            ops.upsample2_bwd_chain(gprev[2], gprev[3], gprev[4], gprev[5])      # one launch instead of three dependent ones (same bits)
+        else:
+            for lvl in (3, 4, 5):
+                ops.upsample2_bwd(gprev[lvl - 1], gprev[lvl], accumulate=True)
         for lvl in (2, 3, 4, 5):
             self._wgrad(f"backbone.fpn_lateral{lvl}", c.cs[lvl - 2], gprev[lvl])
         self._grads_final(["rpn_head_out", "proposal_generator.rpn_head.conv"] + [f"backbone.fpn_output{l}" for l in (2, 3, 4, 5)] +

@@ -373,6 +373,13 @@ def upsample2_bwd(g: torch.Tensor, out: torch.Tensor, accumulate: bool) -> None:
     L.call("aldi_upsample2_bwd", _p(g), _p(out), N, Hc, Wc, Cc, int(accumulate), dtype_code(g.dtype), stream_ptr())
 
 
+def upsample2_bwd_chain(g2: torch.Tensor, o3: torch.Tensor, o4: torch.Tensor, o5: torch.Tensor) -> None:
+    """o3 += blocks(g2); o4 += blocks(o3); o5 += blocks(o4) in one launch (aldi_upsample2_bwd_chain)"""
+    N, H5, W5, Cc = o5.shape
+    assert o4.shape == (N, H5 * 2, W5 * 2, Cc) and o3.shape == (N, H5 * 4, W5 * 4, Cc) and g2.shape == (N, H5 * 8, W5 * 8, Cc)
+    L.call("aldi_upsample2_bwd_chain", _p(g2), _p(o3), _p(o4), _p(o5), N, H5, W5, Cc, dtype_code(g2.dtype), stream_ptr())
+
+
 def add_f32(a: Optional[torch.Tensor], b: Optional[torch.Tensor], out: torch.Tensor, relu_src: Optional[torch.Tensor] = None) -> torch.Tensor:
     L.call("aldi_add_f32", _p(a), _p(b), _p(relu_src), _p(out), out.numel(), dtype_code(out.dtype), stream_ptr())
     return out

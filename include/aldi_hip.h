@@ -249,6 +249,9 @@ int aldi_stage_images(const void* const* images, const int* heights, const int* 
 int aldi_subsample2(const void* x, void* y, int N, int H, int W, int C, int backward, int dtype, aldi_stream_t stream);
 /* backward of FPN nearest-upsample-x2 + add: out[N][Hc][Wc][C] (=|+=) 2x2 block sums of g[N][2Hc][2Wc][C]. */
 int aldi_upsample2_bwd(const void* g, void* out, int N, int Hc, int Wc, int C, int accumulate, int dtype, aldi_stream_t stream);
+/* three accumulating calls of the above in one launch (the FPN's top-down backward, detectron2 FPN.forward's `prev_features = lateral + top_down`
+ * reached from aldi/trainer.py:87): o3 += blocks(g2); o4 += blocks(o3); o5 += blocks(o4).  g2 [N][8 H5][8 W5][C] ... o5 [N][H5][W5][C]; same bits. */
+int aldi_upsample2_bwd_chain(const void* g2, void* o3, void* o4, void* o5, int N, int H5, int W5, int C, int dtype, aldi_stream_t stream);
 /* out = a + b (b fp32), optionally masked by relu_src > 0; a, relu_src nullable. */
 int aldi_add_f32(const void* a, const float* b, const void* relu_src, void* out, long n, int dtype, aldi_stream_t stream);
 int aldi_cast_from_f32(const float* src, void* dst, long n, int dtype, aldi_stream_t stream);

@@ -565,6 +565,24 @@ def test_box_losses_fused_equals_the_separate_launches():
         assert float(ref_g.abs().sum()) > 0 and float((ref_l - got_l).abs().max()) <= 2e-6 * float(ref_l.abs().max()), (ref_l, got_l)
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_upsample2_bwd_chain_equals_three_launches(dtype):
+    """aldi_upsample2_bwd_chain against three accumulating aldi_upsample2_bwd calls (the FPN's top-down backward): the same bits on all three maps."""
+    from aldi_amd import ops
+    g = torch.Generator().manual_seed(13)
+    N, H5, W5, C = 2, 7, 11, 256
+    maps = [torch.randn(N, H5 * s_, W5 * s_, C, generator=g).to(DEV, dtype) for s_ in (8, 4, 2, 1)]
+    ref = [m.clone() for m in maps]
+    for i in range(3):
+        ops.upsample2_bwd(ref[i], ref[i + 1], accumulate=True)
+    got = [m.clone() for m in maps]
+    ops.upsample2_bwd_chain(got[0], got[1], got[2], got[3])
+    torch.cuda.synchronize()
+    for a, b in zip(ref, got):
+        assert torch.equal(a, b)
+    assert not torch.equal(got[3], maps[3])
+
+
 def test_rpn_and_box_losses_vs_oracle():
     from aldi_amd import ops
     from aldi_amd.engine import GMAX, ROI_WEIGHTS, make_anchors
