@@ -548,8 +548,44 @@ __global__ __launch_bounds__(1024) void topk_collect_kernel(Geom g, const unsign
 }
 
 // per (level, image): bring the candidates into LDS, resolve ties beyond k (rare), sort by (key desc, index asc)
+__device__ __forceinline__ float4 apply_deltas_d2(const float4 box, float dx, float dy, float dw, float dh, float wx, float wy, float ww, float wh) {
+    const float clampv = 4.135166556742356f;   // log(1000/16)
+    float w = box.z - box.x, h = box.w - box.y;
+    float cx = box.x + 0.5f * w, cy = box.y + 0.5f * h;
+    dx = dx / wx; dy = dy / wy; dw = dw / ww; dh = dh / wh;
+    dw = fminf(dw, clampv); dh = fminf(dh, clampv);
+    float pcx = dx * w + cx, pcy = dy * h + cy;
+    float pw = expf(dw) * w, ph = expf(dh) * h;
+    return make_float4(pcx - 0.5f * pw, pcy - 0.5f * ph, pcx + 0.5f * pw, pcy + 0.5f * ph);
+}
+
+__device__ __forceinline__ float clampf(float v, float lo, float hi) { return fminf(fmaxf(v, lo), hi); }
+
+// decode + clip + validity of sorted candidate r of (level l, image n); k = the number of candidates of that list
+__device__ __forceinline__ void decode_candidate(const Geom& g, const float4* __restrict__ anchors, unsigned long long key, int r, int k, int l, int n,
+                                                 const int* __restrict__ img_hw /*[N][2]*/, float4* __restrict__ boxes /*[N][nl][cap]*/,
+                                                 float* __restrict__ scores, int* __restrict__ valid, int* __restrict__ err) {
+    const long slot = ((long)n * g.nl + l) * kTopkCap + r;
+    if (r >= k) { valid[slot] = 0; return; }
+    int i = (int)(key & 0xffffffffu);
+    int cell = i / g.A, a = i - cell * g.A;
+    const float* hp = g.head[l] + ((long)n * g.H[l] * g.W[l] + cell) * g.C;
+    float sc = hp[a];
+    float4 b = apply_deltas_d2(anchors[g.off[l] + i], hp[g.A + a * 4 + 0], hp[g.A + a * 4 + 1], hp[g.A + a * 4 + 2], hp[g.A + a * 4 + 3], 1.f, 1.f, 1.f, 1.f);
+    bool fin = isfinite(b.x) && isfinite(b.y) && isfinite(b.z) && isfinite(b.w) && isfinite(sc);
+    if (!fin) atomicOr(err, 1);
+    float ih = (float)img_hw[n * 2], iw = (float)img_hw[n * 2 + 1];
+    b.x = clampf(b.x, 0.f, iw); b.y = clampf(b.y, 0.f, ih); b.z = clampf(b.z, 0.f, iw); b.w = clampf(b.w, 0.f, ih);
+    bool ok = fin && (b.z - b.x) > 0.f && (b.w - b.y) > 0.f;
+    boxes[slot] = b;
+    scores[slot] = sc;
+    valid[slot] = ok ? 1 : 0;
+}
+
 __global__ __launch_bounds__(1024) void topk_sort_kernel(Geom g, const unsigned* __restrict__ keys_all, int pre_nms_topk, const TopkState* __restrict__ final_state,
-                                                         const int* __restrict__ fill, unsigned long long* __restrict__ cand, int* __restrict__ cand_count) {
+                                                         const int* __restrict__ fill, unsigned long long* __restrict__ cand, int* __restrict__ cand_count,
+                                                         const float4* __restrict__ anchors, const int* __restrict__ img_hw, float4* __restrict__ boxes,
+                                                         float* __restrict__ scores, int* __restrict__ valid, int* __restrict__ err) {
     __shared__ unsigned long long keys[kTopkCap];
     __shared__ int sm[17];
     const int l = blockIdx.x, n = blockIdx.y, bl = n * g.nl + l;
@@ -574,46 +610,12 @@ __global__ __launch_bounds__(1024) void topk_sort_kernel(Geom g, const unsigned*
         __syncthreads();
     }
     bitonic_sort_u64(keys, kTopkCap);
-    for (int i = threadIdx.x; i < kTopkCap; i += 1024) io[i] = keys[i];
+    // ... and the sorted candidates are decoded here (boxes, scores, validity): a launch of its own was one more dependent step of the proposal chain
+    for (int i = threadIdx.x; i < kTopkCap; i += 1024) {
+        io[i] = keys[i];
+        decode_candidate(g, anchors, keys[i], i, k, l, n, img_hw, boxes, scores, valid, err);
+    }
     if (threadIdx.x == 0) cand_count[bl] = k;
-}
-
-__device__ __forceinline__ float4 apply_deltas_d2(const float4 box, float dx, float dy, float dw, float dh, float wx, float wy, float ww, float wh) {
-    const float clampv = 4.135166556742356f;   // log(1000/16)
-    float w = box.z - box.x, h = box.w - box.y;
-    float cx = box.x + 0.5f * w, cy = box.y + 0.5f * h;
-    dx = dx / wx; dy = dy / wy; dw = dw / ww; dh = dh / wh;
-    dw = fminf(dw, clampv); dh = fminf(dh, clampv);
-    float pcx = dx * w + cx, pcy = dy * h + cy;
-    float pw = expf(dw) * w, ph = expf(dh) * h;
-    return make_float4(pcx - 0.5f * pw, pcy - 0.5f * ph, pcx + 0.5f * pw, pcy + 0.5f * ph);
-}
-
-__device__ __forceinline__ float clampf(float v, float lo, float hi) { return fminf(fmaxf(v, lo), hi); }
-
-// decode + clip + validity of the sorted candidates
-__global__ void rpn_decode_kernel(Geom g, const float4* __restrict__ anchors, const unsigned long long* __restrict__ cand,
-                                  const int* __restrict__ cand_count, const int* __restrict__ img_hw /*[N][2]*/,
-                                  float4* __restrict__ boxes /*[N][nl][cap]*/, float* __restrict__ scores, int* __restrict__ valid, int* __restrict__ err) {
-    const int l = blockIdx.y, n = blockIdx.z;
-    const int r = blockIdx.x * blockDim.x + threadIdx.x;
-    const long slot = ((long)n * g.nl + l) * kTopkCap + r;
-    if (r >= kTopkCap) return;
-    if (r >= cand_count[n * g.nl + l]) { valid[slot] = 0; return; }
-    unsigned long long key = cand[slot];
-    int i = (int)(key & 0xffffffffu);
-    int cell = i / g.A, a = i - cell * g.A;
-    const float* hp = g.head[l] + ((long)n * g.H[l] * g.W[l] + cell) * g.C;
-    float sc = hp[a];
-    float4 b = apply_deltas_d2(anchors[g.off[l] + i], hp[g.A + a * 4 + 0], hp[g.A + a * 4 + 1], hp[g.A + a * 4 + 2], hp[g.A + a * 4 + 3], 1.f, 1.f, 1.f, 1.f);
-    bool fin = isfinite(b.x) && isfinite(b.y) && isfinite(b.z) && isfinite(b.w) && isfinite(sc);
-    if (!fin) atomicOr(err, 1);
-    float ih = (float)img_hw[n * 2], iw = (float)img_hw[n * 2 + 1];
-    b.x = clampf(b.x, 0.f, iw); b.y = clampf(b.y, 0.f, ih); b.z = clampf(b.z, 0.f, iw); b.w = clampf(b.w, 0.f, ih);
-    bool ok = fin && (b.z - b.x) > 0.f && (b.w - b.y) > 0.f;
-    boxes[slot] = b;
-    scores[slot] = sc;
-    valid[slot] = ok ? 1 : 0;
 }
 
 // merge the per-level survivors of one image by (score desc, level asc, rank asc); keep post_nms_topk.
@@ -895,11 +897,10 @@ extern "C" int aldi_rpn_proposals(const aldi_rpn_geom* gm, float* const* head, c
         }
         hipLaunchKernelGGL(topk_collect_kernel, grid, dim3(1024), 0, st, g, okeys, hists, tstate, cand, fill, tstate + 2 * B);
         ALDI_CHECK_LAUNCH();
-        hipLaunchKernelGGL(topk_sort_kernel, dim3(g.nl, N), dim3(1024), 0, st, g, okeys, pre_nms_topk, tstate + 2 * B, fill, cand, cand_count);
+        hipLaunchKernelGGL(topk_sort_kernel, dim3(g.nl, N), dim3(1024), 0, st, g, okeys, pre_nms_topk, tstate + 2 * B, fill, cand, cand_count,
+                           (const float4*)anchors, img_hw, boxes, scores, valid, err_flag);
         ALDI_CHECK_LAUNCH();
     }
-    hipLaunchKernelGGL(rpn_decode_kernel, dim3(cap / 256, g.nl, N), dim3(256), 0, st, g, (const float4*)anchors, cand, cand_count, img_hw, boxes, scores, valid, err_flag);
-    ALDI_CHECK_LAUNCH();
     hipLaunchKernelGGL(nms_mask_kernel, dim3(cap / 64, cap / 64, (unsigned)B), dim3(64), 0, st, boxes, valid, (const int*)nullptr, cand_count, (int)cap, nms_thresh, mask);
     ALDI_CHECK_LAUNCH();
     // (a level can place at most post_nms_topk boxes in the image's merged list: its scan stops there)
