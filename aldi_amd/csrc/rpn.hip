@@ -724,7 +724,8 @@ __global__ __launch_bounds__(256) void roi_prepare_fused_kernel(const float4* __
                                                                 int Gmax, int K, float thr, int L, float4* __restrict__ cand, int* __restrict__ ccount,
                                                                 float* __restrict__ best_iou, int* __restrict__ best_idx, int* __restrict__ labels,
                                                                 int* __restrict__ cls, int* __restrict__ lists /*[N][2][L]*/, int* __restrict__ counts /*[N][2]*/,
-                                                                unsigned* __restrict__ tickets /*[N], zero*/) {
+                                                                unsigned* __restrict__ tickets /*[N], zero*/, const int* __restrict__ tail_a,
+                                                                const int* __restrict__ tail_b /* words copied to counts[2N], counts[2N + 1] */) {
     __shared__ float4 sgt[kGtTile];
     __shared__ int sgc[kGtTile];
     __shared__ int wsum[2][4];
@@ -792,20 +793,23 @@ __global__ __launch_bounds__(256) void roi_prepare_fused_kernel(const float4* __
         base_p += tp; base_n += tn;
         __syncthreads();
     }
-    if (tid == 0) { counts[n * 2] = base_p; counts[n * 2 + 1] = base_n; }
+    if (tid == 0) {
+        counts[n * 2] = base_p; counts[n * 2 + 1] = base_n;
+        if (n == 0 && tail_a) { counts[2 * (int)gridDim.y] = *tail_a; counts[2 * (int)gridDim.y + 1] = tail_b ? *tail_b : 0; }
+    }
 }
 }  // namespace
 
 extern "C" int aldi_roi_prepare_lists(const float* props, const int* pcount, int P, const float* gt_boxes, const int* gt_classes, const int* gt_count,
                                       int Gmax, int N, int K, float iou_thresh, float* cand, int* ccount, float* best_iou, int* best_idx, int* labels,
-                                      int* cls, int* lists, int* counts, unsigned* tickets, aldi_stream_t stream) {
+                                      int* cls, int* lists, int* counts, unsigned* tickets, const int* tail_a, const int* tail_b, aldi_stream_t stream) {
     if (!props || !pcount || !gt_boxes || !gt_classes || !gt_count || !cand || !ccount || !best_iou || !best_idx || !labels || !cls || !lists || !counts || !tickets)
         return aldi_set_error_msg(ALDI_ERR_ARG, "roi_prepare_lists: null pointer");
     if (Gmax > kGtTile || Gmax < 1 || N < 1 || P < 0) return aldi_set_error_msg(ALDI_ERR_ARG, "roi_prepare_lists: Gmax must be 1 .. 256");
     const int L = P + Gmax;
     hipLaunchKernelGGL(roi_prepare_fused_kernel, dim3(kRoiPrepWgs, N), dim3(256), 0, static_cast<hipStream_t>(stream), (const float4*)props, pcount, P,
                        (const float4*)gt_boxes, gt_classes, gt_count, Gmax, K, iou_thresh, L, (float4*)cand, ccount, best_iou, best_idx, labels, cls, lists, counts,
-                       tickets);
+                       tickets, tail_a, tail_b);
     ALDI_CHECK_LAUNCH();
     return ALDI_OK;
 }

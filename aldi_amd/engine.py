@@ -1128,7 +1128,7 @@ class RCNN:
             d["loss_roih_l1"] = c.loss_dist_roi[1]
         return d
 
-    def _roi_prepare(self, props, prop_count, gt, N) -> dict:
+    def _roi_prepare(self, props, prop_count, gt, N, tail=None) -> dict:
         """append GT, match (IoU >= 0.5), classes, ordered fg/bg lists + their counts (device)."""
         dev = self.device
         P = props.shape[1]
@@ -1140,20 +1140,23 @@ class RCNN:
         labels = torch.empty((N, Lc), dtype=torch.int32, device=dev)
         cls = torch.empty((N, Lc), dtype=torch.int32, device=dev)
         lists = torch.empty((N, 2, Lc), dtype=torch.int32, device=dev)
-        counts = torch.empty((N, 2), dtype=torch.int32, device=dev)
-        if os.environ.get("ALDI_ROI_PREPARE_FUSED", "1") == "1" and GMAX <= 256:
+        fused = os.environ.get("ALDI_ROI_PREPARE_FUSED", "1") == "1" and GMAX <= 256
+        # tail = (word_a, word_b): two device words the fused launch appends to the counts (the fused step's error words: one copy to the host)
+        cbuf = torch.empty((2 * N + 2,), dtype=torch.int32, device=dev) if (tail is not None and fused) else None
+        counts = cbuf[: 2 * N].view(N, 2) if cbuf is not None else torch.empty((N, 2), dtype=torch.int32, device=dev)
+        if fused:
             # one launch instead of eight on the chain that ends in the list lengths the host waits for (same results: tests/test_kernels_gpu.py)
             tk = self._ws.get("roi_tickets")
             if tk is None or tk.numel() < N:
                 tk = self._ws["roi_tickets"] = torch.zeros(max(N, 64), dtype=torch.int32, device=dev)
             ops.roi_prepare_lists(props, prop_count, P, gt["boxes"], gt["classes"], gt["count"], GMAX, N, self.K, self.p.roi_iou, cand, ccount, best_iou,
-                                  best_idx, labels, cls, lists, counts, tk)
+                                  best_idx, labels, cls, lists, counts, tk, *(tail if cbuf is not None else ()))
         else:
             scratch = torch.empty((N, GMAX), dtype=torch.int32, device=dev)
             ops.roi_prepare(props, prop_count, P, gt["boxes"], gt["classes"], gt["count"], GMAX, N, self.K, self.p.roi_iou, cand, ccount, best_iou, best_idx,
                             scratch, labels, cls)
             ops.compact_labels(cls, Lc, N, self.K, lists, counts)
-        return dict(cand=cand, cls=cls, best_idx=best_idx, lists=lists, counts=counts, Lc=Lc)
+        return dict(cand=cand, cls=cls, best_idx=best_idx, lists=lists, counts=counts, Lc=Lc, counts_tail=cbuf)
 
     def _roi_gather(self, c: Ctx, prep: dict, sel, nsel, nsel_h, gt, N, row_off_dev=None):
         dev = self.device

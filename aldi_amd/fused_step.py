@@ -284,16 +284,22 @@ class FusedStep:
             hook(S, c, tc)
         _, matched, lists, counts = eng.rpn_match(geom, anchors, gt, N)
         c.rpn_matched, c.rpn_lists, c.rpn_counts = matched, lists, counts
+        S.h_counts.view(torch.int32)[: 2 * N].copy_(counts.view(-1), non_blocking=True)      # (the anchor lists' lengths: ready long before the proposals)
         if ev_props is not None:
             if os.environ.get("ALDI_HOUSEKEEPING_LATE", "1") == "1":
                 main.wait_event(ev_props)                    # the proposals only: the side stream's housekeeping is joined behind the hand-over
             else:
                 main.wait_stream(side)                       # (A/B: the round-3 order)
-        prep = eng._roi_prepare(c.props, c.prop_count, gt, N)
         # ... and the two engines' error words ride along (bits set by this phase, or by the previous step's phase B): the host
         # raises on them right after the hand-over instead of training on silently wrong gradients
         errs = [eng.err.view(-1), (teng if teng is not None else eng).err.view(-1)]
-        S.h_counts.copy_(torch.cat([counts.view(-1), prep["counts"].view(-1)] + errs).view(torch.uint8), non_blocking=True)
+        prep = eng._roi_prepare(c.props, c.prop_count, gt, N, tail=(errs[0], errs[1]))
+        if prep.get("counts_tail") is not None:
+            # no concatenation launch: the anchor lists' lengths left above, the hand-over is the ROI lists' lengths with the error words the
+            # preparation kernel appended
+            S.h_counts.view(torch.int32)[2 * N: 4 * N + 2].copy_(prep["counts_tail"], non_blocking=True)
+        else:
+            S.h_counts.copy_(torch.cat([counts.view(-1), prep["counts"].view(-1)] + errs).view(torch.uint8), non_blocking=True)
         if side is not None:
             main.wait_stream(side)                           # (phase B starts behind the housekeeping)
         else:

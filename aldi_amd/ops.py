@@ -506,10 +506,12 @@ def roi_prepare(props, pcount, P, gt_boxes, gt_classes, gt_count, Gmax, N, K, th
            _p(best_iou), _p(best_idx), _p(scratch), _p(labels), _p(cls), stream_ptr())
 
 
-def roi_prepare_lists(props, pcount, P, gt_boxes, gt_classes, gt_count, Gmax, N, K, thr, cand, ccount, best_iou, best_idx, labels, cls, lists, counts, tickets):
-    """roi_prepare + compact_labels(cls, bg = K) in one launch (aldi_roi_prepare_lists); tickets: N zero uint32 words, left zero"""
+def roi_prepare_lists(props, pcount, P, gt_boxes, gt_classes, gt_count, Gmax, N, K, thr, cand, ccount, best_iou, best_idx, labels, cls, lists, counts, tickets,
+                      tail_a=None, tail_b=None):
+    """roi_prepare + compact_labels(cls, bg = K) in one launch (aldi_roi_prepare_lists); tickets: N zero uint32 words, left zero;
+    tail_a / tail_b: two int32 device words copied behind the counts (counts then holds 2N + 2 words)"""
     L.call("aldi_roi_prepare_lists", _p(props), _p(pcount), P, _p(gt_boxes), _p(gt_classes), _p(gt_count), Gmax, N, K, thr, _p(cand), _p(ccount),
-           _p(best_iou), _p(best_idx), _p(labels), _p(cls), _p(lists), _p(counts), _p(tickets), stream_ptr())
+           _p(best_iou), _p(best_idx), _p(labels), _p(cls), _p(lists), _p(counts), _p(tickets), _p(tail_a), _p(tail_b), stream_ptr())
 
 
 def roi_gather(cand, cls, best_idx, Lb, lists, sel, nsel, S, row_off, gt_boxes, gt_count, Gmax, N, rois, r_cls, r_gt, r_idx):

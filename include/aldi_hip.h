@@ -357,11 +357,12 @@ int aldi_roi_prepare(const float* props, const int* pcount, int P, const float* 
                      unsigned* gt_best_scratch, int* labels, int* cls, aldi_stream_t stream);
 /* The same, AND the ordered foreground / background lists of aldi_compact_labels(cls, bg = K) with their lengths, in ONE launch (Gmax <= 256;
  * the ROI heads' matcher: one threshold, no low-quality rule).  lists [N][2][L], counts [N][2], L = P + Gmax.  tickets: N uint32 words that
- * are ZERO before the first call (the kernel leaves them zero).  Replaces label_and_sample_proposals' matching part (detectron2
+ * are ZERO before the first call (the kernel leaves them zero).  tail_a / tail_b (nullable): two device words copied to counts[2N] and
+ * counts[2N + 1] (counts then has 2N + 2 words: the list lengths and e.g. two error words leave in ONE device -> host copy).  Replaces label_and_sample_proposals' matching part (detectron2
  * StandardROIHeads, reached from aldi/trainer.py:87, aldi/distill.py:157): identical results to aldi_roi_prepare + aldi_compact_labels. */
 int aldi_roi_prepare_lists(const float* props, const int* pcount, int P, const float* gt_boxes, const int* gt_classes, const int* gt_count,
                            int Gmax, int N, int K, float iou_thresh, float* cand, int* ccount, float* best_iou, int* best_idx, int* labels,
-                           int* cls, int* lists, int* counts, unsigned* tickets, aldi_stream_t stream);
+                           int* cls, int* lists, int* counts, unsigned* tickets, const int* tail_a, const int* tail_b, aldi_stream_t stream);
 /* sampled rows = cat(fg_list[sel_fg], bg_list[sel_bg]) per image, packed from row_off[n]:
  * rois [R][5] (batch, x1,y1,x2,y2), r_cls [R], r_gt [R][4], r_idx [R] (index into cand). */
 int aldi_roi_gather(const float* cand, const int* cls, const int* best_idx, int L, const int* lists, const int* sel, const int* nsel, int S,

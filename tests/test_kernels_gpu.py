@@ -500,10 +500,15 @@ def test_roi_prepare_lists_equals_the_eight_launch_path():
     tickets = torch.zeros(N, dtype=torch.int32, device=dev)
     for rep in range(3):
         b = bufs()
+        wide = torch.full((2 * N + 2,), -7, dtype=torch.int32, device=dev)                 # counts + two appended words (third repetition)
+        if rep == 2:
+            b["counts"] = wide[: 2 * N].view(N, 2)
+        ta, tb = torch.tensor([41], dtype=torch.int32, device=dev), torch.tensor([42], dtype=torch.int32, device=dev)
         ops.roi_prepare_lists(props, pcount, P, gtb, gtc, gcount, GMAX, N, K, 0.5, b["cand"], b["ccount"], b["best_iou"], b["best_idx"], b["labels"], b["cls"],
-                              b["lists"], b["counts"], tickets)
+                              b["lists"], b["counts"], tickets, *((ta, tb) if rep == 2 else ()))
         torch.cuda.synchronize()
         assert int(tickets.abs().sum()) == 0
+        assert rep != 2 or wide[2 * N:].tolist() == [41, 42]
         for k in ("cand", "ccount", "labels", "cls", "counts"):
             assert torch.equal(a[k], b[k]), (rep, k)
         for n in range(N):
