@@ -35,7 +35,7 @@ const Knob kKnobs[] = {
     {"igemm_tile", &AldiTuning::igemm_tile, 0},
     {"igemm_dbg", &AldiTuning::igemm_dbg, 0},
     {"igemm_bigtile_min", &AldiTuning::igemm_bigtile_min, 1024},
-    {"igemm_bigtile", &AldiTuning::igemm_bigtile, 4},
+    {"igemm_bigtile", &AldiTuning::igemm_bigtile, 64},
     {"igemm_bigtile_k", &AldiTuning::igemm_bigtile_k, 768},
     {"igemm_lintile_min", &AldiTuning::igemm_lintile_min, 768},
     {"igemm_halo", &AldiTuning::igemm_halo, 1},
@@ -46,7 +46,7 @@ const Knob kKnobs[] = {
     {"igemm_splitk_tile", &AldiTuning::igemm_splitk_tile, 2},
     {"igemm_halo_f32", &AldiTuning::igemm_halo_f32, 0},
     {"igemm_f32_tile64_max", &AldiTuning::igemm_f32_tile64_max, 4096},
-    {"igemm_direct", &AldiTuning::igemm_direct, 7},
+    {"igemm_direct", &AldiTuning::igemm_direct, 15},
     {"igemm_lean", &AldiTuning::igemm_lean, 1},
     {"wgrad_lean", &AldiTuning::wgrad_lean, 1},
     {"wgrad_big_min", &AldiTuning::wgrad_big_min, 28},

@@ -526,7 +526,7 @@ __device__ __forceinline__ void igemm_body(const ConvDev& p, int bid, const int 
     unsigned ha_voff[AH_IT], ha_mask[AH_IT];
 #pragma unroll
     for (int it = 0; it < AH_IT; ++it) {
-        const int c = tid + it * NT, row = c >> 2, kce = swz<KC>(row, c & 3);
+        const int c = tid + it * NT, row = c >> 2, kce = swz_halo(row, c & 3);
         const int q0 = m0 - 1 + row;                             // input pixel under the CENTRE row (kh = 1), flat index
         const bool ok = row < BM + 2 && q0 >= 0 && q0 < p.M;
         const int qq = ok ? q0 : 0;
@@ -537,7 +537,7 @@ __device__ __forceinline__ void igemm_body(const ConvDev& p, int bid, const int 
     unsigned hw_voff[WH_IT];
 #pragma unroll
     for (int it = 0; it < WH_IT; ++it) {
-        const int c = tid + it * NT, kwi = c / (BN * KC), rem = c - kwi * (BN * KC), row = rem >> 2, kce = swz<KC>(row, rem & 3);
+        const int c = tid + it * NT, kwi = c / (BN * KC), rem = c - kwi * (BN * KC), row = rem >> 2, kce = swz_halo(row, rem & 3);
         const int co = n0 + (DIRECT ? direct_perm<BN / WN>(row) : row);
         hw_voff[it] = co < p.Cout ? ((unsigned)co * (unsigned)p.K + (unsigned)(kwi * p.Cin + kce * EP)) * (unsigned)sizeof(T) : OOB;
     }
@@ -586,8 +586,8 @@ __device__ __forceinline__ void igemm_body(const ConvDev& p, int bid, const int 
     const unsigned lbase = lds_addr(&lds[0][0]);
     unsigned x_rd[3];
 #pragma unroll
-    for (int kw = 0; kw < 3; ++kw) x_rd[kw] = lbase + (unsigned)((xrow + kw) * KC + swz<KC>(xrow + kw, fq)) * 16u;
-    const unsigned w_rd = lbase + (unsigned)((AS + wrow * KC) + swz<KC>(wrow, fq)) * 16u;
+    for (int kw = 0; kw < 3; ++kw) x_rd[kw] = lbase + (unsigned)((xrow + kw) * KC + swz_halo(xrow + kw, fq)) * 16u;
+    const unsigned w_rd = lbase + (unsigned)((AS + wrow * KC) + swz_halo(wrow, fq)) * 16u;
     // The left / right border taps read ZEROS: the fragment's ADDRESS is redirected to the all-zero row (one select per fragment before
     // the read is issued) instead of zeroing its four registers behind the read (four selects).  frag_read_each adds i * 16 rows back.
     uint4* const zero_lds = &lds_all[NSTAGE * SLOTS + AUX_SLOTS];
@@ -916,7 +916,7 @@ __device__ __forceinline__ void igemm_halo_rs_body(const ConvDev& p, int bid, co
     unsigned ha_voff[AH_IT], ha_mask[AH_IT];
 #pragma unroll
     for (int it = 0; it < AH_IT; ++it) {
-        const int c = tid + it * NT, row = c >> 2, kce = swz<KC>(row, c & 3);
+        const int c = tid + it * NT, row = c >> 2, kce = swz_halo(row, c & 3);
         const int q0 = m0 - 1 + row;
         const bool ok = row < BM + 2 && q0 >= 0 && q0 < p.M;
         const int qq = ok ? q0 : 0;
@@ -927,7 +927,7 @@ __device__ __forceinline__ void igemm_halo_rs_body(const ConvDev& p, int bid, co
     unsigned hw_voff[WH_IT];
 #pragma unroll
     for (int it = 0; it < WH_IT; ++it) {
-        const int c = tid + it * NT, kwi = c / (BN * KC), rem = c - kwi * (BN * KC), row = rem >> 2, kce = swz<KC>(row, rem & 3);
+        const int c = tid + it * NT, kwi = c / (BN * KC), rem = c - kwi * (BN * KC), row = rem >> 2, kce = swz_halo(row, rem & 3);
         const int co = n0 + row;
         hw_voff[it] = co < p.Cout ? ((unsigned)co * (unsigned)p.K + (unsigned)(kwi * p.Cin + kce * EP)) * (unsigned)sizeof(T) : OOB;
     }
@@ -949,8 +949,8 @@ __device__ __forceinline__ void igemm_halo_rs_body(const ConvDev& p, int bid, co
     }
     unsigned x_rd[3];
 #pragma unroll
-    for (int kw = 0; kw < 3; ++kw) x_rd[kw] = lbase + (unsigned)((xrow + kw) * KC + swz<KC>(xrow + kw, fq)) * 16u;
-    const unsigned w_rd = lbase + (unsigned)((AS + wrow * KC) + swz<KC>(wrow, fq)) * 16u;
+    for (int kw = 0; kw < 3; ++kw) x_rd[kw] = lbase + (unsigned)((xrow + kw) * KC + swz_halo(xrow + kw, fq)) * 16u;
+    const unsigned w_rd = lbase + (unsigned)((AS + wrow * KC) + swz_halo(wrow, fq)) * 16u;
     constexpr unsigned STAGE_BYTES = STAGE * 16;
     const int G = 3 * (p.Cin / BK);
 
@@ -1064,6 +1064,8 @@ int launch_halo_rs(const ConvDev& d, hipStream_t st) {
     return ALDI_OK;
 }
 
+#include "igemm_halo64.h"
+
 // (the 240-pixel halo tile is sized for TWO workgroups per CU: 6 waves each = 3 waves per SIMD, 80 KB of LDS each)
 template <int BM, int NT, bool HALO> constexpr int min_waves_per_simd() { return HALO && BM == 240 ? 2 * NT / 256 : 1; }
 template <typename T, int BM, int BN, int WM, int WN, int KC, bool PIPE, bool HALO = false, int EPI = 0, bool LEAN = false>
@@ -1095,6 +1097,54 @@ __global__ __launch_bounds__(WM* WN * 64, (min_waves_per_simd<BM, WM * WN * 64, 
 }
 
 static thread_local const ConvGroup* g_group = nullptr;      // set by aldi_conv_igemm_group around dispatch<T>()
+
+template <int BN, bool DIRECT>
+__global__ __launch_bounds__(512) void igemm_halo64_group_kernel(ConvGroup G) {
+    const int bid = (int)blockIdx.x;
+    int i = 0;
+    for (int k = 1; k < G.n; ++k)
+        if (bid >= G.wg_begin[k]) i = k;
+    i = __builtin_amdgcn_readfirstlane(i);
+    const int local = bid - G.wg_begin[i];
+    if (local >= G.nmt[i] * G.nnt[i]) return;  // alignment padding
+    igemm_halo64_body<BN, DIRECT>(G.p[i], local, G.nmt[i], G.nnt[i]);
+}
+
+// the 128-byte-slab halo kernel (igemm_halo64.h), alone or over the problems of a group; the direct epilogue (igemm_direct bit 8) when every
+// problem's output is plain bf16 with at most scale / shift / ReLU
+inline bool halo64_direct_ok(const ConvDev& d) {
+    return d.y && !d.y_f32 && d.out_scale == 1 && (d.Cout & 7) == 0 && !d.mask && !d.mask_bits && !d.bits_out && !d.res_mode;
+}
+template <int BN>
+int launch_halo64(const ConvDev& d, hipStream_t st) {
+    char name[96];
+    bool direct = (aldi_tuning().igemm_direct & 8) != 0;
+    if (g_group) {
+        ConvGroup G = *g_group;
+        int wg = 0;
+        for (int i = 0; i < G.n; ++i) {
+            G.p[i].xcd = d.xcd; G.p[i].dbg = d.dbg;
+            G.nmt[i] = cdiv(G.p[i].M, 256); G.nnt[i] = cdiv(G.p[i].Cout, BN);
+            G.wg_begin[i] = wg;
+            wg += (G.nmt[i] * G.nnt[i] + 7) / 8 * 8;
+            direct = direct && halo64_direct_ok(G.p[i]);
+        }
+        for (int i = G.n; i <= kMaxConvGroup; ++i) G.wg_begin[i] = wg;
+        if (direct) hipLaunchKernelGGL((igemm_halo64_group_kernel<BN, true>), dim3(wg), dim3(512), 0, st, G);
+        else hipLaunchKernelGGL((igemm_halo64_group_kernel<BN, false>), dim3(wg), dim3(512), 0, st, G);
+        ALDI_CHECK_LAUNCH();
+        snprintf(name, sizeof(name), "igemm_group%d<bf16,256,%d,4,2,halo64%s>", G.n, BN, direct ? ",direct" : "");
+    } else {
+        direct = direct && halo64_direct_ok(d);
+        dim3 grid(cdiv(d.M, 256), cdiv(d.Cout, BN));
+        if (direct) hipLaunchKernelGGL((igemm_halo64_kernel<BN, true>), grid, dim3(512), 0, st, d);
+        else hipLaunchKernelGGL((igemm_halo64_kernel<BN, false>), grid, dim3(512), 0, st, d);
+        ALDI_CHECK_LAUNCH();
+        snprintf(name, sizeof(name), "igemm<bf16,256,%d,4,2,halo64%s>", BN, direct ? ",direct" : "");
+    }
+    aldi_note_dispatch(name);
+    return ALDI_OK;
+}
 
 template <typename T, int BM, int BN, int WM, int WN, int KC, bool PIPE = true, bool HALO = false, int EPI = 0>
 int launch(const ConvDev& d, hipStream_t st) {
@@ -1185,10 +1235,14 @@ int dispatch(ConvDev& d, hipStream_t st) {
             if constexpr (sizeof(T) == 2) {
                 if (force == 9) return launch<T, 240, 128, 3, 2, 4, false, true>(d, st);
                 if (force == 10 && !g_group) return launch_halo_rs<T, 128>(d, st);
+                if (force == 11 && d.Cin % 64 == 0) return launch_halo64<256>(d, st);
             }
             if (force == 0 || force == 3) {      // (no 64x64 halo form; 5 = the 128x16 tap form)
                 if (d.Cout <= 64) return launch<T, 128, 64, 4, 1, 4, false, true>(d, st);
                 if (big >= tn.igemm_bigtile_min) {
+                    // igemm_bigtile 64: 128-byte K slabs on a 256 x 256 tile (igemm_halo64.h) where the channels fill it
+                    if constexpr (sizeof(T) == 2)
+                        if (tn.igemm_bigtile == 64 && d.Cin % 64 == 0 && d.Cout % 256 == 0) return launch_halo64<256>(d, st);
                     if (tn.igemm_bigtile == 1) return launch<T, 128, 128, 2, 2, 4, false, true>(d, st);
                     if constexpr (sizeof(T) == 2)
                         if (tn.igemm_bigtile == 10 && !g_group) return launch_halo_rs<T, 128>(d, st);

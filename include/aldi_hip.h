@@ -36,7 +36,8 @@ int aldi_noop(aldi_stream_t stream);
  * Each knob can also be preset from the environment as ALDI_<UPPER-CASE NAME>, read once at first use.
  *   igemm_force          0 heuristics | 1 128x128 | 2 128x64 | 3 64x64 | 4 256x128 | 5 128x16 tile of aldi_conv_igemm |
  *                        6 / 7 / 8: the 128x128 / 128x64 / 64x64 tile with 128-byte K slabs (plain 1x1 / linear layers) |
- *                        9 / 10 (3x3 halo form only): 240x128 on six waves, two workgroups per CU / 256x128 role-split
+ *                        9 / 10 (3x3 halo form only): 240x128 on six waves, two workgroups per CU / 256x128 role-split |
+ *                        11 (3x3 halo form, bf16, Cin % 64 == 0): the 256x256 tile with 128-byte K slabs (igemm_halo64.h)
  *   igemm_k64_min        plain 1x1 / linear layers with K >= this (and K % 64 == 0) take the 64x64 128-byte-slab form (1024)
  *   igemm_group          1 = aldi_conv_igemm_group shares one launch (0: always n single launches)
  *   igemm_splitk_tile    tile of a split-K launch (aldi_conv_args.ksplit): 0 = 128x128, 1 = 256x128, 2 = 256x128 when that still gives about
@@ -44,12 +45,14 @@ int aldi_noop(aldi_stream_t stream);
  *   igemm_narrow_k       bf16 layers with K up to this many channels x taps take 128x64 tiles instead of 128x128 (512; 0 = never)
  *   igemm_direct         bit mask of the 64-channel bf16 tiles that take the DIRECT epilogue (no LDS staging, permuted channel rows, residual
  *                        prefetched into registers, scale / shift / mask bits by 4-byte LDS-DMA, one rounding): 1 = 128x64 1x1 / tap tile,
- *                        2 = 64x64 long-K tile, 4 = 128x64 halo tile (7; 0 = the staged epilogue everywhere).  Applies to bf16 outputs in the
+ *                        2 = 64x64 long-K tile, 4 = 128x64 halo tile, 8 = the 256x256 128-byte-slab halo tile (scale / shift / ReLU outputs
+ *                        only) (15; 0 = the staged epilogue everywhere).  Applies to bf16 outputs in the
  *                        plain layout with Cout % 8 == 0, Cout >= 64, no fp32 output / `mask` tensor / split-K / scatter
  *   igemm_lean           1 = plain 1x1 / linear layers with K % 64 == 0 on those tiles run the lean K loop (running DMA offsets)
  *   igemm_halo           1 = 3x3/stride-1/pad-1 bf16 convs use the halo form (one pixel slab per three taps)
  *   igemm_bigtile_min    128x128-tile count from which a 3x3 conv takes the big halo tile (1024)
- *   igemm_bigtile        which one: 4 = 256x128 lockstep (default), 1 = 128x128, 10 = 256x128 with the two wave halves in alternating roles
+ *   igemm_bigtile        which one: 64 = 256x256 with 128-byte K slabs where Cin % 64 == 0 and Cout % 256 == 0 (default; else 256x128),
+ *                        4 = 256x128 lockstep, 1 = 128x128, 10 = 256x128 with the two wave halves in alternating roles
  *   igemm_lintile_min, igemm_bigtile_k   tile count / K from which a 1x1 conv or linear takes the 256x128 tile (768, 768)
  *   igemm_tile           9 = never use the 256x128 tile for 1x1 / linear
  *   igemm_xcd            1 = XCD-aware workgroup -> tile order
