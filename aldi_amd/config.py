@@ -228,7 +228,8 @@ def add_aldi_config(cfg: CfgNode):
     _C.SOLVER.FUSED_STEP = True           # the step's student passes as one fused launch sequence (numerically the sequential schedule)
     _C.SOLVER.STEP_GRAPH = True           # replay the fused step's two device phases as hipGraphs (aldi_amd/fused_step.py)
     _C.SOLVER.GRAD_PAYLOAD = "fp32"       # data-parallel gradient exchange: "fp32" (exact) or "bf16" (half the bytes per xGMI link; sums in bf16)
-    _C.SOLVER.GRAD_EXCHANGE = "all_reduce"  # per bucket: "all_reduce" or "rs_ag" (reduce_scatter_tensor + all_gather_into_tensor, aldi_amd/reduce.py)
+    _C.SOLVER.GRAD_EXCHANGE = "auto"        # per bucket: "all_reduce" or "rs_ag" (reduce_scatter_tensor + all_gather_into_tensor, aldi_amd/reduce.py);
+                                            # "auto" = rs_ag on the 8 ranks of one fully connected xGMI node, all_reduce otherwise
 
     # Deformable-DETR (the reference's absent submodule adds these through its own add_deformable_detr_config; configs/Base-DETR.yaml)
     _C.MODEL.DEFORMABLE_DETR = CN()

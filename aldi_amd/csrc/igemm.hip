@@ -1214,7 +1214,8 @@ int dispatch(ConvDev& d, hipStream_t st) {
     // igemm_direct (bit mask: 1 = the 128x64 1x1 / tap tile, 2 = the 64x64 long-K tile, 4 = the 128x64 halo tile): the direct epilogue of
     // the 64-channel tiles (igemm_epilogue_direct) for bf16 outputs in the plain layout; a residual needs the tile that prefetches it
     const bool direct_ok = sizeof(T) == 2 && !g_group && d.y && !d.y_f32 && d.out_scale == 1 && (d.Cout & 7) == 0 && !d.mask && d.ksplit <= 1 &&
-                           !(d.mask_bits && (d.scale || d.shift)) && d.Cout >= 64;
+                           !(d.mask_bits && (d.scale || d.shift)) && d.Cout >= 64 &&
+                           !(d.mask_bits && (d.Cout & 31));        // (the mask bits arrive by a 4-byte LDS-DMA at bit offset (m * Cout + ch): dword-aligned for Cout % 32 == 0 only)
     const int direct = direct_ok ? tn.igemm_direct : 0;
     d.lean = tn.igemm_lean && d.KH * d.KW == 1 && d.stride == 1 && d.pad == 0 && d.K % 64 == 0 && !(d.dbg & (8 | 16)) ? 1 : 0;
     {

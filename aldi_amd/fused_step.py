@@ -539,6 +539,7 @@ class FusedStep:
             ev_up = torch.cuda.Event()
             ev_up.record(main)
             aux.wait_event(ev_up)
+            c.rpn_early["ev"] = ev_up          # (engine.backward_fused orders its auxiliary stream behind the upload through this event as well)
         with torch.cuda.stream(aux) if aux is not None else contextlib.nullcontext():
             ops.rpn_apply_sample(labels, sumA, N, c.rpn_lists, U.d("rsel"), U.d("rnsel"), RPN_BATCH)
             for ch, dl in dls:
@@ -859,7 +860,7 @@ class FusedStep:
                     logging.getLogger(__name__).warning("phase B with its collectives could not be captured; data-parallel phase B stays eager", exc_info=True)
                     self.dp_graph_ok = False
                     torch.cuda.synchronize()
-                    reducer.__init__(reducer.grad, reducer.group, reducer.payload)
+                    reducer.__init__(reducer.grad, reducer.group, reducer.payload, reducer.exchange)
                     ent = None
         if ent is not None:
             ent[0].replay()

@@ -84,3 +84,24 @@ class HookPoint:
     def fire(self, inp, out):
         for h in self.hooks:
             h(self, inp, out)
+
+
+def hook_points(model):
+    """every HookPoint of a detector (the places the reference registers module hooks on), nested ones included"""
+    seen, todo = [], [v for v in vars(model).values() if isinstance(v, HookPoint)]
+    while todo:
+        p = todo.pop()
+        if any(p is q for q in seen):
+            continue
+        seen.append(p)
+        todo += [v for v in vars(p).values() if isinstance(v, HookPoint)]
+    return seen
+
+
+def foreign_hooks(model, own) -> bool:
+    """True when a hook point of `model` carries a hook that is not one of `own` (identity): somebody outside the distiller is listening"""
+    for p in hook_points(model):
+        for h in list(p.pre_hooks) + list(p.hooks):
+            if not any(h is o for o in own):
+                return True
+    return False

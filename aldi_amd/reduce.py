@@ -42,6 +42,21 @@ def complement(ranges: Sequence[Tuple[int, int]], n: int) -> List[Tuple[int, int
     return out
 
 
+def resolve_exchange(name: str, group=None) -> str:
+    """SOLVER.GRAD_EXCHANGE -> the form a reducer runs.  "auto": reduce-scatter + all-gather when the group is the 8 ranks of ONE node (the fully
+    connected xGMI mesh: every rank talks to its 7 peers at once, DESIGN.md section 7 / SURVEY 8(e)), one all-reduce per bucket otherwise;
+    "all_reduce" / "rs_ag" are taken as given (the key that turns the default back)."""
+    name = str(name)
+    if name != "auto":
+        return name
+    try:
+        world = dist.get_world_size(group)
+    except Exception:
+        return "all_reduce"
+    local = int(os.environ.get("LOCAL_WORLD_SIZE", world))
+    return "rs_ag" if world == 8 and local == 8 else "all_reduce"
+
+
 class BucketedReducer:
     """all-reduce(SUM) of a flat gradient tensor in the order its pieces become final."""
 

@@ -490,6 +490,30 @@ class _ALDITrainer:
         self.model_batch_size = model_batch_size
         self.fused = False
 
+    def _fusable_distiller(self) -> bool:
+        """the fused driver evaluates ALDIDistiller's losses with its own kernels and does not fire the models' hook points: it stands in
+        only for the built-in distiller -- the class itself, or a subclass that overrides none of the loss / forward methods -- and only
+        while nobody else listens on the student's or the teacher's hook points (a third-party distiller or a user's SaveIO tap would be
+        silently bypassed: those take the reference's sequential schedule, logged once)"""
+        from .distill import ALDIDistiller
+        from .helpers import foreign_hooks
+        d = self.distiller
+        why = None
+        if not isinstance(d, ALDIDistiller):
+            why = "distiller %s is not ALDIDistiller" % type(d).__name__
+        elif any(getattr(type(d), m) is not getattr(ALDIDistiller, m) for m in ("__call__", "_distill_forward", "get_rpn_losses", "get_roih_losses", "register_hooks")):
+            why = "distiller %s overrides a loss / forward method of ALDIDistiller" % type(d).__name__
+        else:
+            own = [getattr(d, a) for side in d._TAPS.values() for a, _ in side] + [d.seeder, d.teacher_proposal_replacer]
+            models = [m.module if hasattr(m, "module") else m for m in (d.student, d.teacher)]
+            if any(foreign_hooks(m, own) for m in models):
+                why = "a forward (pre-)hook that the distiller did not register sits on the student or the teacher"
+        if why is not None and not self.__dict__.get("_fuse_warned"):
+            self._fuse_warned = True
+            import logging
+            logging.getLogger(__name__).warning("fused step not used (%s): taking the reference's sequential schedule", why)
+        return why is None
+
     def _can_fuse(self, data):
         """the fused driver takes the reference's FPN batch contents (labeled_strong [+ unlabeled weak / strong pairs]) in any whole
         number of IMS_PER_GPU-sized micro-batches per part -- e.g. the shipped IMS_PER_BATCH 48 / IMS_PER_GPU 2 on 8 GPUs = three
@@ -505,8 +529,7 @@ class _ALDITrainer:
         do_align, do_distill = _schedule_flags(self)
         total = len(ls)
         if do_distill:
-            from .distill import ALDIDistiller
-            if not isinstance(self.distiller, ALDIDistiller) or uw is None or us is None:
+            if not self._fusable_distiller() or uw is None or us is None:
                 return False
             if len(uw) != len(us) or len(us) == 0 or len(us) % bs:
                 return False
@@ -552,9 +575,9 @@ class _ALDITrainer:
             eng = self.model.engine
             reducer = None
             if _data_parallel():
-                from .reduce import BucketedReducer
+                from .reduce import BucketedReducer, resolve_exchange
                 reducer = self._reducer = BucketedReducer(self.model.weights.grad, payload=str(self.model.cfg.SOLVER.get("GRAD_PAYLOAD", "fp32")),
-                                                          exchange=str(self.model.cfg.SOLVER.get("GRAD_EXCHANGE", "all_reduce")))
+                                                          exchange=resolve_exchange(self.model.cfg.SOLVER.get("GRAD_EXCHANGE", "auto")))
                 eng.grad_ready = reducer.ready
             ok = False
             try:
@@ -743,9 +766,13 @@ class ALDITrainer(DefaultTrainer):
             raise AssertionError("len(cfg.DATASETS.BATCH_CONTENTS) must equal len(cfg.DATASETS.BATCH_RATIOS).")
         total = cfg.SOLVER.IMS_PER_BATCH
         # every batch part gets its (truncated) share of the global batch; the shares must add up again
-        share = {part: int(total * r / sum(ratios)) for part, r in zip(contents, ratios)}
-        if sum(share.values()) != total:
-            raise AssertionError(f"sum(batch_sizes)={sum(share.values())} must equal total_batch_size={total}")
+        # (a LIST, one entry per batch part: a content named twice counts twice, as in the reference's loop, aldi/trainer.py:211-222)
+        sizes = [int(total * r / sum(ratios)) for r in ratios]
+        if sum(sizes) != total:
+            raise AssertionError(f"sum(batch_sizes)={sum(sizes)} must equal total_batch_size={total}")
+        share = {}
+        for part, n in zip(contents, sizes):
+            share[part] = max(share.get(part, 0), n)
         # weak and strong views of one domain are cut from the same images: a domain's loader serves the larger of its parts
         labeled_bs = max((n for part, n in share.items() if part.startswith("labeled")), default=0)
         unlabeled_bs = max((n for part, n in share.items() if part.startswith("unlabeled")), default=0)

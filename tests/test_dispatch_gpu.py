@@ -625,7 +625,7 @@ def test_conv_group_equals_single_launches(geo, batches, expect):
 
 
 @pytest.mark.parametrize("direct", [0, 7])
-@pytest.mark.parametrize("case", [(2, 50, 84, 256, 1024, 1, 0), (1, 19, 23, 64, 72, 3, 1), (2, 25, 42, 512, 2048, 1, 0)])
+@pytest.mark.parametrize("case", [(2, 50, 84, 256, 1024, 1, 0), (1, 19, 23, 64, 72, 3, 1), (2, 25, 42, 512, 2048, 1, 0), (2, 24, 40, 256, 72, 1, 0), (3, 7, 9, 128, 88, 1, 0)])
 def test_relu_masks_as_bits(case, direct):
     """aldi_conv_args.bits_out / mask_bits: the forward launch writes (y > 0) of its output as one bit per element beside y, the backward
     launch multiplies by those bits -- the same result, bit for bit, as masking by the bf16 activation itself; ragged M and a Cout that is

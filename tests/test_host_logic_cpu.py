@@ -265,3 +265,28 @@ def test_d2params_from_cfg_reads_and_validates():
         c2.merge_from_list(bad)
         with pytest.raises(ValueError):
             D2Params.from_cfg(c2)
+
+
+def test_build_train_loader_batch_shares_follow_the_reference_loop():
+    """aldi/trainer.py:211-222: one batch size per entry of BATCH_CONTENTS (a LIST: a content named twice counts twice), the sizes must add up
+    to IMS_PER_BATCH, and a domain's loader serves the largest of its parts"""
+    from aldi_amd.config import add_aldi_config, get_cfg
+    from aldi_amd.trainer import ALDITrainer
+    from aldi_amd.reduce import resolve_exchange
+
+    def loaders(contents, ratios, total):
+        cfg = get_cfg()
+        add_aldi_config(cfg)
+        cfg.merge_from_list(["DATASETS.BATCH_CONTENTS", contents, "DATASETS.BATCH_RATIOS", ratios, "SOLVER.IMS_PER_BATCH", total,
+                             "SYNTHETIC.HEIGHT", 64, "SYNTHETIC.WIDTH", 96])
+        dl = ALDITrainer.build_train_loader(cfg)
+        return dl.labeled_loader, dl.unlabeled_loader
+
+    lab, unl = loaders(("labeled_strong", "labeled_strong"), (1, 1), 4)            # duplicates: 2 + 2 = 4, the labeled loader serves 2
+    assert lab is not None and unl is None and lab.bs == 2
+    lab, unl = loaders(("labeled_weak", "labeled_strong", "unlabeled_strong"), (1, 1, 2), 8)
+    assert lab.bs == 2 and unl.bs == 4
+    with pytest.raises(AssertionError):
+        loaders(("labeled_strong", "unlabeled_strong"), (1, 2), 4)                 # int(4/3) + int(8/3) = 3 != 4
+    # SOLVER.GRAD_EXCHANGE "auto" outside a process group is the plain all-reduce; explicit names pass through
+    assert resolve_exchange("auto") == "all_reduce" and resolve_exchange("rs_ag") == "rs_ag" and resolve_exchange("all_reduce") == "all_reduce"

@@ -157,3 +157,51 @@ def test_reference_yaml_runs_the_fused_graph_step_by_default(monkeypatch):
     assert not tr2._trainer.fused
     _step(tr2, 0)
     assert getattr(tr2._trainer, "_fused_step", None) is None
+
+
+@pytest.mark.gpu
+def test_fused_step_steps_aside_for_foreign_distillers_and_hooks(monkeypatch):
+    """the fused driver replaces ALDIDistiller's losses and does not fire the hook points: a subclass that overrides a loss method, or a
+    hook somebody else registered on the student (a SaveIO tap, reference aldi/helpers.py:7-20), must get the reference's sequential schedule"""
+    from aldi_amd.config import add_aldi_config, get_cfg
+    from aldi_amd.distill import ALDIDistiller
+    from aldi_amd.helpers import SaveIO
+    from aldi_amd.trainer import ALDITrainer
+    for k in ("ALDI_FUSED_STEP", "ALDI_STEP_GRAPH", "ALDI_FUSED_LEGACY"):
+        monkeypatch.delenv(k, raising=False)
+    cfg = get_cfg()
+    add_aldi_config(cfg)
+    cfg.merge_from_file(os.path.join(ROOT, "configs", "cityscapes", "ALDI-Best-Cityscapes.yaml"))
+    cfg.merge_from_list(["SOLVER.IMS_PER_BATCH", 4, "SYNTHETIC.HEIGHT", H, "SYNTHETIC.WIDTH", W])
+    random.seed(4)
+    torch.manual_seed(17)
+    tr = ALDITrainer(cfg)
+    assert tr._trainer._fusable_distiller()
+    # (a) a tap of the user's own on the student's box predictor
+    tap = SaveIO()
+    tr.model.roi_heads.box_predictor.register_forward_hook(tap)
+    assert not tr._trainer._fusable_distiller()
+    ld = _step(tr, 0)
+    assert getattr(tr._trainer, "_fused_step", None) is None and tap.output is not None      # sequential schedule: the hook fired
+    assert "loss_roih_l1_distill" in ld
+    tr.model.roi_heads.box_predictor.hooks.remove(tap)
+    assert tr._trainer._fusable_distiller()
+
+    # (b) a subclass with its own RoI-head loss
+    class Mine(ALDIDistiller):
+        calls = 0
+
+        def get_roih_losses(self, *a, **kw):
+            Mine.calls += 1
+            return super().get_roih_losses(*a, **kw)
+
+    tr._trainer.distiller.__class__ = Mine
+    assert not tr._trainer._fusable_distiller()
+    _step(tr, 1)
+    assert Mine.calls == 1 and getattr(tr._trainer, "_fused_step", None) is None
+    # a subclass that only adds attributes keeps the fast path
+    class Plain(ALDIDistiller):
+        note = "same methods"
+
+    tr._trainer.distiller.__class__ = Plain
+    assert tr._trainer._fusable_distiller()
