@@ -771,6 +771,190 @@ __global__ __launch_bounds__(WM* WN * 64) void wgrad_bf16_dma_kernel(WgDev p) {
     }
 }
 
+// ------------------------------------------------------------------------------------ bf16, LDS-DMA in full cache lines + transpose reads
+// wgrad_bf16_dma_kernel above fills the LDS in 32-byte segments (a [32 pixels][16 channels] image per 16-channel block: two lanes per pixel
+// row): a QUARTER of a 128-byte line per lane group.  tools/probes/dma_rate_probe.hip: the L2 -> LDS path is paced per line touched (64-byte
+// segments 16.5 TB/s, 128-byte segments 27 TB/s over the chip), which is why that kernel only tied the register-staged one.  Here the image of
+// a 64-channel block is [32 pixels][64 channels] = 32 rows of 128 bytes: one DMA instruction = 8 pixel rows x one full line each.  The
+// transpose read takes a per-lane address, so the row pitch is free; what it needs is that the 32 lanes of a half-wave (8 pixel rows x 32 bytes
+// of one 16-channel fragment) hit 64 distinct banks: rows of equal parity are 256 bytes apart, so the 32-byte chunk of a row is XORed with
+// (row >> 1) & 3 -- on the DMA's SOURCE address (16-byte chunk ^ ((row >> 1) & 3) << 1), the LDS image itself is lane-linear.
+// Four-slab ring (32 pixels = one MFMA k-step per slab), counted vmcnt, one raw barrier per slab; waves 0 .. TCO/64-1 load the g blocks,
+// the rest the x blocks (4 DMA instructions per wave and slab), every wave owns a (TCO / WM) x (TKK / WN) piece of the accumulator.
+// Same domain and epilogues (wgrad_finish_tile: ordered partial tiles, sole-owner read-modify-write, float atomics; bias gradient as a ones
+// column) as wgrad_bf16_lean_tile, with Cin % 64 == 0 for K x K convs.
+template <int TCO, int TKK, int WM, int WN, int NBUF>
+__device__ __forceinline__ void wgrad_bf16_dma64_tile(const WgDev& p, unsigned char* lds, int bx, int by, int bz) {
+    constexpr int NW = WM * WN;
+    static_assert(NW * 64 == TCO + TKK, "one loader wave per 64-channel block");
+    static_assert(NBUF == 3 || NBUF == 4, "ring depth");
+    constexpr int NGW = TCO / 64;                       // g-loader waves (= g blocks)
+    constexpr int BP = 32;
+    constexpr int NBLK = (TCO + TKK) / 64, STAGE = NBLK * 4096;
+    constexpr int TM = TCO / WM / 16, TN = TKK / WN / 16;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int co0 = bx * TCO, kk0 = by * TKK;
+    const int pbeg = bz * p.pix_per_split;
+    const int pend = min(p.M, pbeg + p.pix_per_split);
+    if (pbeg >= pend) return;
+    constexpr unsigned OOB = 0x80000000u;
+    const bool isB = wave >= NGW;
+    const int blk = isB ? wave - NGW : wave;            // 64-channel block of this operand's tile
+    const int lrow = lane >> 3;                          // pixel row of a piece (8 rows per DMA instruction)
+    const int chunk = (lane & 7) ^ (((lrow >> 1) & 3) << 1);       // source chunk: row k * 8 + lrow has the same (row >> 1) & 3 for every piece k
+    // per-lane byte offset of (pixel pbeg + lrow, this block's channels, this lane's chunk); pieces / slabs are uniform adds
+    unsigned off0;
+    int dh = 0, dw = 0;
+    if (!isB) {
+        const int ch = co0 + blk * 64 + chunk * 8;
+        off0 = ch < p.Cout ? ((unsigned)(pbeg + lrow) * (unsigned)p.Cout + (unsigned)ch) * 2u : OOB;
+    } else {
+        const int c0 = kk0 + blk * 64;                  // (a block lies inside one tap: Cin % 64 == 0)
+        const int tap = c0 / p.Cin, ci = c0 - tap * p.Cin + chunk * 8;
+        const int kh = tap / p.KW, kw = tap - kh * p.KW;
+        dh = kh - p.pad; dw = kw - p.pad;
+        off0 = c0 + chunk * 8 < p.K ? ((unsigned)(pbeg + lrow + dh * p.W + dw) * (unsigned)p.Cin + (unsigned)ci) * 2u : OOB;      // mod 2^32
+    }
+    const bool track = isB && !p.ident;                 // border validity needed (K x K x-loader waves)
+    const unsigned row_bytes = (unsigned)(isB ? p.Cin : p.Cout) * 2u;
+    const unsigned g_lim = (unsigned)pend * (unsigned)p.Cout * 2u;    // g rows >= pend read as zeros (their products vanish whatever x holds)
+    const unsigned lim = isB ? p.x_bytes : (g_lim < p.g_bytes ? g_lim : p.g_bytes);
+    const uintptr_t base = reinterpret_cast<uintptr_t>(isB ? p.x : p.g);
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        reinterpret_cast<void*>(((uintptr_t)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)(base >> 32)) << 32) |
+                                (uintptr_t)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)base)),
+        0, __builtin_amdgcn_readfirstlane(lim), 0x00020000);
+    // (h, w) of this lane's pixel of each of the four pieces of the slab being LOADED (K x K convs: the tap leaves the image at the borders)
+    int ph[4] = {0, 0, 0, 0}, pw[4] = {0, 0, 0, 0};
+    if (track) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int r = (pbeg + k * 8 + lrow) % (p.H * p.W);
+            ph[k] = r / p.W; pw[k] = r - ph[k] * p.W;
+        }
+    }
+    unsigned off = off0;
+    const int wbase_slot = (isB ? NGW + blk : blk) * 4096;          // this wave's block inside a stage (bytes)
+    auto issue_slab = [&](int buf) {
+        unsigned char* dst = lds + buf * STAGE + wbase_slot;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            unsigned o = off == OOB ? OOB : off + (unsigned)(k * 8) * row_bytes;
+            if (track) {
+                const bool ok = (unsigned)(ph[k] + dh) < (unsigned)p.H && (unsigned)(pw[k] + dw) < (unsigned)p.W;
+                o = ok ? o : OOB;
+                pw[k] += BP;
+                while (pw[k] >= p.W) { pw[k] -= p.W; ++ph[k]; }
+                while (ph[k] >= p.H) ph[k] -= p.H;
+            }
+            glds16w(rsrc, dst + k * 1024, o);
+        }
+        if (off != OOB) off += BP * row_bytes;
+    };
+
+    const int wm = wave / WN, wn = wave % WN;
+    f32x4_t acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    const bool do_bias = p.db != nullptr && by == 0 && wn == 0;
+    f32x4_t accb[TM];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) accb[i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    const u32x4 ones4 = {0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};      // eight bf16 1.0
+    const int fq = lane >> 4;
+    // transpose read (tools/probes/tr_probe.hip): the 16 lanes of group q cover the [4 pixels][16 channels] block of pixels 4q .. 4q + 3 -- lane
+    // l points at the 8 bytes of pixel row 4q + (l & 15) / 4, channels 4 (l & 3) .. + 3 -- and lane l RECEIVES channel l & 15 of the four pixels.
+    // Fragment f of an operand = channels 16 f .. of its tile: block f / 4, 32-byte chunk f % 4 of the 128-byte rows, swizzled by the row.
+    const int trow = fq * 4 + ((lane & 15) >> 2);
+    const unsigned lbase = (unsigned)(uintptr_t)(const __attribute__((address_space(3))) void*)lds;
+    unsigned rd[4];                                     // byte address of chunk c (0 .. 3) of this lane's row, block 0, stage 0
+#pragma unroll
+    for (int c = 0; c < 4; ++c) rd[c] = lbase + (unsigned)(trow * 128 + ((c ^ ((trow >> 1) & 3)) << 5) + (lane & 3) * 8);
+    constexpr int FA0 = 0, FB0 = NGW * 4096;            // first byte of the g / x blocks inside a stage
+    const unsigned a_blk = (unsigned)(FA0 + (wm * TM / 4) * 4096), b_blk = (unsigned)(FB0 + (wn * TN / 4) * 4096);
+    static_assert(TM % 4 == 0 && TN % 4 == 0, "a wave's fragments are whole 64-channel blocks");
+
+    const int S = (pend - pbeg + BP - 1) / BP;
+    issue_slab(0);
+    if (S > 1) issue_slab(1);
+    if (NBUF > 3 && S > 2) issue_slab(2);
+    int buf = 0, nbuf = NBUF - 1;
+    for (int s = 0; s < S; ++s) {
+        // slab s has landed (mine: counted; everybody's: the barrier); NBUF - 2 younger slabs stay in flight
+        if (NBUF > 3 && s + 2 < S) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else if (s + 1 < S) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        if (s + NBUF - 1 < S) issue_slab(nbuf);
+        u32x2_t alo[TM], ahi[TM], blo[TN], bhi[TN];
+        const unsigned sb = (unsigned)buf * STAGE;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const unsigned a = rd[i & 3] + sb + a_blk;
+            if ((i >> 2) == 0) { alo[i] = tr_read<0>(a); ahi[i] = tr_read<2048>(a); }
+            else { alo[i] = tr_read<4096>(a); ahi[i] = tr_read<4096 + 2048>(a); }
+        }
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const unsigned b = rd[j & 3] + sb + b_blk;
+            if ((j >> 2) == 0) { blo[j] = tr_read<0>(b); bhi[j] = tr_read<2048>(b); }
+            else { blo[j] = tr_read<4096>(b); bhi[j] = tr_read<4096 + 2048>(b); }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int i = 0; i < TM; ++i) asm volatile("" : "+v"(alo[i]), "+v"(ahi[i]));
+#pragma unroll
+        for (int j = 0; j < TN; ++j) asm volatile("" : "+v"(blo[j]), "+v"(bhi[j]));
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const u32x4 af = {alo[i][0], alo[i][1], ahi[i][0], ahi[i][1]};
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const u32x4 bf = {blo[j][0], blo[j][1], bhi[j][0], bhi[j][1]};
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, af), __builtin_bit_cast(bf16x8_t, bf), acc[i][j], 0, 0, 0);
+            }
+            if (do_bias) accb[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, af), __builtin_bit_cast(bf16x8_t, ones4), accb[i], 0, 0, 0);
+        }
+        buf = buf == NBUF - 1 ? 0 : buf + 1;
+        nbuf = nbuf == NBUF - 1 ? 0 : nbuf + 1;
+    }
+    wgrad_finish_tile<TCO, TKK, WM, WN>(p, acc, accb, do_bias, bx, by, bz, wave, lane);
+}
+
+// the 256 x 256 tile on that loop (8 waves: four g blocks, four x blocks; 128 KB of LDS: one workgroup per CU), alone and grouped
+__global__ __launch_bounds__(512) void wgrad_bf16_big64_kernel(WgDev p) {
+    __shared__ __attribute__((aligned(1024))) unsigned char lds[4 * 8 * 4096];
+    int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+    {
+        const int gx = gridDim.x, gy = gridDim.y, total = gx * gy * gridDim.z;
+        int bid = bx + gx * (by + gy * bz);
+        if (p.xcd) {
+            const int q = total >> 3, r = total & 7, xcd = bid & 7, idx = bid >> 3;
+            bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+        }
+        bx = bid % gx; bid /= gx;
+        by = bid % gy; bz = bid / gy;
+    }
+    wgrad_bf16_dma64_tile<256, 256, 2, 4, 4>(p, lds, bx, by, bz);
+}
+__global__ __launch_bounds__(512) void wgrad_bf16_big64_group_kernel(WgGroup G) {
+    __shared__ __attribute__((aligned(1024))) unsigned char lds[4 * 8 * 4096];
+    int i, tx, ty, bz;
+    wgrad_group_pick(G, i, tx, ty, bz);
+    wgrad_bf16_dma64_tile<256, 256, 2, 4, 4>(G.p[i], lds, tx, ty, bz);
+}
+// the 128 x 128 tile on that loop (4 waves, three-slab ring: 48 KB, three workgroups per CU), grouped (the layers with 128-channel sides)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void wgrad_bf16_lean64_group_kernel(WgGroup G) {
+    __shared__ __attribute__((aligned(1024))) unsigned char lds[3 * 4 * 4096];
+    int i, tx, ty, bz;
+    wgrad_group_pick(G, i, tx, ty, bz);
+    wgrad_bf16_dma64_tile<128, 128, 2, 2, 3>(G.p[i], lds, tx, ty, bz);
+}
+
 // ------------------------------------------------------------------------------------ fp32
 // 64 (co) x 64 (kk) tile, 16 pixels per slab, 4 waves (2x2), wave tile 32x32.
 __global__ __launch_bounds__(256) void wgrad_f32_kernel(WgDev p) {
@@ -1133,10 +1317,11 @@ int wgrad_single(const aldi_wgrad_args* a, hipStream_t st, WsCarver& ws, FinBuil
         if (ordered) plan_ordered(d, big, ws, fin);
         if (!ws.fits()) return aldi_set_error_msg(ALDI_ERR_ARG, "conv_wgrad: workspace too small (aldi_conv_wgrad_group_workspace)");
         if (!dry) {
-            if (big) hipLaunchKernelGGL(wgrad_bf16_big_kernel, grid, dim3(512), 0, st, d);
+            if (big && (tn.wgrad_dma64 & 1)) hipLaunchKernelGGL(wgrad_bf16_big64_kernel, grid, dim3(512), 0, st, d);
+            else if (big) hipLaunchKernelGGL(wgrad_bf16_big_kernel, grid, dim3(512), 0, st, d);
             else hipLaunchKernelGGL(wgrad_bf16_lean_kernel, grid, dim3(256), 0, st, d);
         }
-        which = big ? "wgrad_bf16_big" : "wgrad_bf16_lean";
+        which = big ? ((tn.wgrad_dma64 & 1) ? "wgrad_bf16_big64" : "wgrad_bf16_big") : "wgrad_bf16_lean";
     }
     else if (a->dtype == ALDI_BF16) { if (!dry) hipLaunchKernelGGL(wgrad_bf16_kernel, grid, dim3(256), 0, st, d); which = "wgrad_bf16_generic"; }
     else if (a->dtype == ALDI_F32 && f32_t128) { if (!dry) hipLaunchKernelGGL(wgrad_f32_t128_kernel<32>, grid, dim3(256), 0, st, d); which = "wgrad_f32_t128"; }
@@ -1215,11 +1400,16 @@ int launch_group(const WgDev* probs, int ng, bool big, hipStream_t st, WsCarver&
     if (!ws.fits()) return aldi_set_error_msg(ALDI_ERR_ARG, "conv_wgrad_group: workspace too small (aldi_conv_wgrad_group_workspace)");
     for (int k = ng; k <= kMaxGroup; ++k) L_.wg_begin[k] = wg;
     if (dry) return ALDI_OK;
-    if (big) hipLaunchKernelGGL(wgrad_bf16_big_group_kernel, dim3(wg), dim3(512), 0, st, L_);
+    // wgrad_dma64 bit 2: the 128 x 128 group on the LDS-DMA + transpose-read loop when every layer's rows are whole 16-byte chunks
+    bool lean64 = !big && (tn.wgrad_dma64 & 2);
+    for (int k = 0; k < ng && lean64; ++k) lean64 = L_.p[k].Cin % 8 == 0 && L_.p[k].Cout % 8 == 0;
+    if (big && (tn.wgrad_dma64 & 1)) hipLaunchKernelGGL(wgrad_bf16_big64_group_kernel, dim3(wg), dim3(512), 0, st, L_);
+    else if (big) hipLaunchKernelGGL(wgrad_bf16_big_group_kernel, dim3(wg), dim3(512), 0, st, L_);
+    else if (lean64) hipLaunchKernelGGL(wgrad_bf16_lean64_group_kernel, dim3(wg), dim3(256), 0, st, L_);
     else if (tn.wgrad_db) hipLaunchKernelGGL(wgrad_bf16_lean_group_db_kernel, dim3(wg), dim3(256), 0, st, L_);
     else hipLaunchKernelGGL(wgrad_bf16_lean_group_kernel, dim3(wg), dim3(256), (size_t)tn.wgrad_lds_pad_kb << 10, st, L_);
     ALDI_CHECK_LAUNCH();
-    snprintf(name, name_len, "wgrad_bf16_%s_group%s n=%d wgs=%d pix=%ld%s", big ? "big" : "lean", (!big && tn.wgrad_db) ? "_db" : "", ng, wg, T, ordered ? " ordered" : "");
+    snprintf(name, name_len, "wgrad_bf16_%s_group%s n=%d wgs=%d pix=%ld%s", big ? ((tn.wgrad_dma64 & 1) ? "big64" : "big") : (lean64 ? "lean64" : "lean"), (!big && tn.wgrad_db) ? "_db" : "", ng, wg, T, ordered ? " ordered" : "");
     return ALDI_OK;
 }
 

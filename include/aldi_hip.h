@@ -58,6 +58,8 @@ int aldi_noop(aldi_stream_t stream);
  *   igemm_xcd            1 = XCD-aware workgroup -> tile order
  *   igemm_dbg            ablation bits (4 skip epilogue, 8 one K slab, 16 L1-resident loads): results are WRONG when set
  *   wgrad_lean           1 = lean bf16 weight-gradient kernel for 1x1 and "same" KxK convs (0: generic gather kernel)
+ *   wgrad_dma64          bit mask: 1 = the 256x256 bf16 tile, 2 = the grouped 128x128 tile run the LDS-DMA (full 128-byte lines) + transpose-read
+ *                        loop (3; 0: the register-staged loops)
  *   wgrad_big_min        slabs (64 pixels) per workgroup from which the 256x256 tile is used (28; 0 = never)
  *   wgrad_big_slots, wgrad_slots   target workgroup counts of the 256x256 / 128x128 forms (256, 384)
  *   wgrad_xcd            1 = XCD-aware order

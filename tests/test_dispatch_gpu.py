@@ -355,14 +355,14 @@ def _check_wgrad(case, dtype, expect, knobs=()):
 
 
 @pytest.mark.parametrize("case,expect", [
-    ((4, 200, 336, 256, 256, 3, 1, 1), "wgrad_bf16_big"),         # FPN output / RPN conv on p2: the 256x256 tile
-    ((4, 100, 168, 256, 256, 3, 1, 1), "wgrad_bf16_big"),         # p3 3x3
+    ((4, 200, 336, 256, 256, 3, 1, 1), "wgrad_bf16_big64"),         # FPN output / RPN conv on p2: the 256x256 tile
+    ((4, 100, 168, 256, 256, 3, 1, 1), "wgrad_bf16_big64"),         # p3 3x3
     ((4, 200, 336, 256, 256, 1, 1, 0), "wgrad_bf16_lean"),        # FPN lateral p2
     ((4, 50, 84, 256, 256, 3, 1, 1), "wgrad_bf16_lean"),          # res4 conv2
     ((4, 50, 84, 1024, 256, 1, 1, 0), "wgrad_bf16_lean"),         # res4 conv1
     ((4, 100, 168, 128, 512, 1, 1, 0), "wgrad_bf16_lean"),        # res3 conv3
     ((4, 200, 336, 256, 512, 1, 2, 0), "wgrad_bf16_generic"),     # res3.0 shortcut: strided -> gather kernel
-    ((2048, 1, 1, 12544, 1024, 1, 1, 0), "wgrad_bf16_big"),       # box head FC1
+    ((2048, 1, 1, 12544, 1024, 1, 1, 0), "wgrad_bf16_big64"),       # box head FC1
     ((4, 200, 336, 256, 16, 1, 1, 0), "wgrad_bf16_lean"),         # RPN heads (Cout 16 < tile)
     ((2, 200, 336, 256, 256, 3, 1, 0), "wgrad_bf16_generic"),     # image-level discriminator conv (no padding), full p2
 ])
@@ -379,7 +379,7 @@ def test_wgrad_forced_big_and_generic_small(case):
     N, H, W_, Cin, Cout, k, stride, pad = case
     K = k * k * Cin
     big_ok = Cout % 256 == 0 and K % 256 == 0
-    _check_wgrad(case, torch.bfloat16, "wgrad_bf16_big" if big_ok else "wgrad_bf16_lean", knobs=[("wgrad_big_min", 1), ("wgrad_big_slots", 2)])
+    _check_wgrad(case, torch.bfloat16, "wgrad_bf16_big64" if big_ok else "wgrad_bf16_lean", knobs=[("wgrad_big_min", 1), ("wgrad_big_slots", 2)])
     _check_wgrad(case, torch.bfloat16, "wgrad_bf16_lean", knobs=[("wgrad_big_min", 0)])
     _check_wgrad(case, torch.bfloat16, "wgrad_bf16_generic", knobs=[("wgrad_lean", 0)])
     _check_wgrad(case, torch.float32, "wgrad_f32_t128")
@@ -391,7 +391,14 @@ def test_wgrad_split_count_does_not_change_the_result(slots):
     """split-K over pixel ranges: one long split, the default, and many short ones (ragged last split)"""
     case = (2, 50, 84, 256, 256, 3, 1, 1)
     _check_wgrad(case, torch.bfloat16, "wgrad_bf16_lean", knobs=[("wgrad_slots", slots), ("wgrad_big_min", 0)])
-    _check_wgrad(case, torch.bfloat16, "wgrad_bf16_big", knobs=[("wgrad_big_slots", max(slots, 1)), ("wgrad_big_min", 1)])
+    _check_wgrad(case, torch.bfloat16, "wgrad_bf16_big64", knobs=[("wgrad_big_slots", max(slots, 1)), ("wgrad_big_min", 1)])
+
+
+@pytest.mark.parametrize("case", [(4, 100, 168, 256, 256, 3, 1, 1), (2, 25, 42, 256, 256, 3, 1, 1), (1, 19, 23, 256, 512, 1, 1, 0), (2048, 1, 1, 1024, 256, 1, 1, 0)])
+def test_wgrad_big_tile_register_staged_arm(case):
+    """wgrad_dma64 0: the 256x256 tile on the register-staged loop (global -> VGPR -> 8x8 transposes -> LDS) instead of the LDS-DMA + transpose-read one"""
+    _check_wgrad(case, torch.bfloat16, "wgrad_bf16_big", knobs=[("wgrad_dma64", 0), ("wgrad_big_min", 1), ("wgrad_big_slots", 8)])
+    _check_wgrad(case, torch.bfloat16, "wgrad_bf16_big64", knobs=[("wgrad_dma64", 1), ("wgrad_big_min", 1), ("wgrad_big_slots", 8)])
 
 
 def test_wgrad_fp32_fullsize():
@@ -437,6 +444,33 @@ def test_wgrad_dma_split_counts(slots):
 
 
 # ---------------------------------------------------------------------------------- grouped weight gradients (one launch per layer group)
+def test_wgrad_group_register_staged_loops():
+    """wgrad_dma64 0: both grouped tiles on the register-staged loops of rounds 1-4 (same sums; the default is the LDS-DMA + transpose-read loop)"""
+    from aldi_amd import _lib as L
+    from aldi_amd import ops
+    gen = torch.Generator().manual_seed(9)
+    dev = "cuda"
+    cases = [(4, 50, 84, 256, 256, 3, 1, 1), (4, 50, 84, 1024, 256, 1, 1, 0), (2, 100, 168, 128, 128, 3, 1, 1), (2, 100, 168, 512, 128, 1, 1, 0), (1, 37, 41, 72, 136, 1, 1, 0)]
+    outs = {}
+    for dma in (3, 0):
+        L.reset_tuning(); L.set_tuning("wgrad_dma64", dma)
+        g2 = torch.Generator().manual_seed(9)
+        probs = []
+        for (N, H, W_, Cin, Cout, k, stride, pad) in cases:
+            x = torch.randn(N, H, W_, Cin, generator=g2).to(dev, torch.bfloat16)
+            g = (torch.randn(N, H, W_, Cout, generator=g2) * 0.1).to(dev, torch.bfloat16)
+            probs.append((x, g, torch.zeros(Cout, k, k, Cin, device=dev), dict(KH=k, KW=k, stride=stride, pad=pad, db=torch.zeros(Cout, device=dev))))
+        ops.conv_wgrad_group(probs)
+        name = L.last_dispatch()
+        torch.cuda.synchronize()
+        assert ("64_group" in name) == bool(dma) and "_group" in name, name
+        outs[dma] = [(p[2], p[3]["db"]) for p in probs]
+    for (a, ab), (b, bb), case in zip(outs[3], outs[0], cases):
+        M = case[0] * case[1] * case[2]
+        assert (a - b).abs().max().item() <= 2e-5 * max(1.0, b.abs().max().item()) * max(1.0, (M / 1024) ** 0.5), case
+        assert (ab - bb).abs().max().item() <= 2e-5 * max(1.0, bb.abs().max().item()) * max(1.0, (M / 1024) ** 0.5), case
+
+
 @pytest.mark.parametrize("knobs", [(), (("wgrad_big_group", 0),), (("wgrad_ordered", 0),), (("wgrad_big_group", 0), ("wgrad_ordered", 0))],
                          ids=["default", "no-big-group", "atomics", "r02"])
 def test_wgrad_group_equals_single_launches(knobs):
@@ -471,11 +505,11 @@ def test_wgrad_group_equals_single_launches(knobs):
     kn = dict(knobs)
     ordered = " ordered" if kn.get("wgrad_ordered", 1) else ""
     if kn.get("wgrad_big_group", 1):     # 9 problems: strided -> generic, Cout 16 -> 128x128 group of one, 7 in the 256x256 group
-        assert name.startswith("wgrad_bf16_lean_group n=1") and "| wgrad_bf16_big_group n=7" in name and name.endswith(ordered or name[-1]), name
-        wgs = int(name.split("wgrad_bf16_big_group")[1].split("wgs=")[1].split()[0])
+        assert name.startswith("wgrad_bf16_lean64_group n=1") and "| wgrad_bf16_big64_group n=7" in name and name.endswith(ordered or name[-1]), name
+        wgs = int(name.split("wgrad_bf16_big64_group")[1].split("wgs=")[1].split()[0])
         assert 128 <= wgs <= 1024, name         # one to four rounds of one workgroup per CU
     else:                                # r02 form: p2 3x3 -> its own big-tile launch, strided -> generic, 7 grouped
-        assert name.startswith("wgrad_bf16_lean_group n=7") and (ordered in name), name
+        assert name.startswith("wgrad_bf16_lean64_group n=7") and (ordered in name), name
         wgs = int(name.split("wgs=")[1].split()[0])
         assert 300 <= wgs <= 2400, name          # fewer pixel splits than the single launches
     for (x, g, dw, geo), (ref, ref_b), case in zip(probs, refs, cases):
@@ -811,7 +845,7 @@ def test_bias_gradient_rides_in_the_wgrad_launch(case):
         assert float((db2.double() - ref).abs().max()) <= 1e-3 * float(ref.abs().max()) + 1e-2
     else:
         ops.conv_wgrad(x, g, dw1, db=db, **geo)
-        want = {"lean_1x1": "wgrad_bf16_lean", "lean_3x3": "wgrad_bf16_lean", "big_3x3": "wgrad_bf16_big", "generic_stride2": "wgrad_bf16_generic", "fp32": "wgrad_f32"}[case]
+        want = {"lean_1x1": "wgrad_bf16_lean", "lean_3x3": "wgrad_bf16_lean", "big_3x3": "wgrad_bf16_big64", "generic_stride2": "wgrad_bf16_generic", "fp32": "wgrad_f32"}[case]
         assert L.last_dispatch().startswith(want), L.last_dispatch()
     torch.cuda.synchronize()
     assert float((db.double() - 0.5 - ref).abs().max()) <= 1e-3 * float(ref.abs().max()) + 1e-2, float((db.double() - 0.5 - ref).abs().max())
