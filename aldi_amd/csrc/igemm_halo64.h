@@ -72,6 +72,7 @@ __device__ __forceinline__ void igemm_halo64_body(const ConvDev& p, int bid, con
     const int wbase = __builtin_amdgcn_readfirstlane(tid & ~63);
     const bool tail = wbase + 4 * NT < XS;                 // this wave owns the slab's fifth piece (wave 0)
     const int fr = lane & 15, fq = lane >> 4;
+    const bool prio = __builtin_amdgcn_readfirstlane(p.dbg & 128) == 0;       // raised priority around every MFMA block (+3-4 %; igemm_dbg 128 turns it off for A/B runs)
     const bool no_dma = p.dbg & 32, no_mfma = p.dbg & 64;  // ablation (igemm_dbg): 32 = no DMA inside the K loop, 64 = no MFMAs, 4 = no epilogue
 
     f32x4_t acc[TM][TN];
@@ -187,10 +188,12 @@ __device__ __forceinline__ void igemm_halo64_body(const ConvDev& p, int bid, con
         if (more1) issue_w(2, (u + 1) & 1, woff_a);
         __builtin_amdgcn_sched_barrier(0);
         if (!no_mfma) {
+            if (prio) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TH; ++j) acc[i][j] = Mma<T>::run(wa[j], x0[i], acc[i][j]);
+            if (prio) __builtin_amdgcn_s_setprio(0);
         }
         frag_wait1<TH>(wb);
         __builtin_amdgcn_sched_barrier(0);
@@ -200,10 +203,12 @@ __device__ __forceinline__ void igemm_halo64_body(const ConvDev& p, int bid, con
         if (more1) issue_w(3, (u + 1) & 1, woff_a);
         __builtin_amdgcn_sched_barrier(0);
         if (!no_mfma) {
+            if (prio) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TH; ++j) acc[i][TH + j] = Mma<T>::run(wb[j], x0[i], acc[i][TH + j]);
+            if (prio) __builtin_amdgcn_s_setprio(0);
         }
         frag_wait<TM, TH>(x1, wa);
         __builtin_amdgcn_sched_barrier(0);
@@ -217,10 +222,12 @@ __device__ __forceinline__ void igemm_halo64_body(const ConvDev& p, int bid, con
         }
         __builtin_amdgcn_sched_barrier(0);
         if (!no_mfma) {
+            if (prio) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TH; ++j) acc[i][j] = Mma<T>::run(wa[j], x1[i], acc[i][j]);
+            if (prio) __builtin_amdgcn_s_setprio(0);
         }
         frag_wait1<TH>(wb);
         __builtin_amdgcn_sched_barrier(0);
@@ -245,10 +252,12 @@ __device__ __forceinline__ void igemm_halo64_body(const ConvDev& p, int bid, con
         }
         __builtin_amdgcn_sched_barrier(0);
         if (!no_mfma) {
+            if (prio) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TH; ++j) acc[i][TH + j] = Mma<T>::run(wb[j], x1[i], acc[i][TH + j]);
+            if (prio) __builtin_amdgcn_s_setprio(0);
         }
         frag_wait<TM, TH>(x0, wa);
         __builtin_amdgcn_sched_barrier(0);

@@ -877,6 +877,7 @@ __device__ __forceinline__ void wgrad_bf16_dma64_tile(const WgDev& p, unsigned c
     static_assert(TM % 4 == 0 && TN % 4 == 0, "a wave's fragments are whole 64-channel blocks");
 
     const int S = (pend - pbeg + BP - 1) / BP;
+    const bool prio = __builtin_amdgcn_readfirstlane(p.dbg & 2) == 0;       // raised priority around the MFMA block (+2-3 %; wgrad_dbg 2 turns it off for A/B runs)
     issue_slab(0);
     if (S > 1) issue_slab(1);
     if (NBUF > 3 && S > 2) issue_slab(2);
@@ -888,7 +889,6 @@ __device__ __forceinline__ void wgrad_bf16_dma64_tile(const WgDev& p, unsigned c
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
-        if (s + NBUF - 1 < S) issue_slab(nbuf);
         u32x2_t alo[TM], ahi[TM], blo[TN], bhi[TN];
         const unsigned sb = (unsigned)buf * STAGE;
 #pragma unroll
@@ -903,12 +903,17 @@ __device__ __forceinline__ void wgrad_bf16_dma64_tile(const WgDev& p, unsigned c
             if ((j >> 2) == 0) { blo[j] = tr_read<0>(b); bhi[j] = tr_read<2048>(b); }
             else { blo[j] = tr_read<4096>(b); bhi[j] = tr_read<4096 + 2048>(b); }
         }
+        // (the fragment reads go out first: their latency runs under the issue of the next slab's DMA pieces)
+        __builtin_amdgcn_sched_barrier(0);
+        if (s + NBUF - 1 < S) issue_slab(nbuf);
+        __builtin_amdgcn_sched_barrier(0);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
         for (int i = 0; i < TM; ++i) asm volatile("" : "+v"(alo[i]), "+v"(ahi[i]));
 #pragma unroll
         for (int j = 0; j < TN; ++j) asm volatile("" : "+v"(blo[j]), "+v"(bhi[j]));
         __builtin_amdgcn_sched_barrier(0);
+        if (prio) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
             const u32x4 af = {alo[i][0], alo[i][1], ahi[i][0], ahi[i][1]};
@@ -919,6 +924,7 @@ __device__ __forceinline__ void wgrad_bf16_dma64_tile(const WgDev& p, unsigned c
             }
             if (do_bias) accb[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, af), __builtin_bit_cast(bf16x8_t, ones4), accb[i], 0, 0, 0);
         }
+        if (prio) __builtin_amdgcn_s_setprio(0);
         buf = buf == NBUF - 1 ? 0 : buf + 1;
         nbuf = nbuf == NBUF - 1 ? 0 : nbuf + 1;
     }

@@ -1,6 +1,6 @@
 """3x3 'same' conv shapes of the R50 step under the halo tile templates, INTERLEAVED in one process (variant x round, median and min per
 variant: single runs on this pool differ by up to 10 % between boxes and by 3 % between launches), each checked against the first listed
-variant's output.  A variant is igemm_force[:igemm_direct], e.g. SWEEP_FORCE=1,4,11,11:7 python tools/halo_sweep.py
+variant's output.  A variant is igemm_force[:igemm_direct[:igemm_dbg]], e.g. SWEEP_FORCE=1,4,11,11:7 python tools/halo_sweep.py
 (1 = 128x128, 4 = 256x128, 9 = 240x128, 10 = role-split 256x128, 11 = 256x256 with 128-byte K slabs; 11:7 = the same with the staged epilogue)"""
 import os, sys, statistics
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -26,6 +26,8 @@ for (N, H, W, Cin, Cout) in SHAPES:
         L.reset_tuning(); L.set_tuning("igemm_force", int(v[0]))
         if len(v) > 1:
             L.set_tuning("igemm_direct", int(v[1]))
+        if len(v) > 2:
+            L.set_tuning("igemm_dbg", int(v[2]))
     for v in variants:
         setup(v)
         y = torch.empty(N, H, W, Cout, device="cuda", dtype=torch.bfloat16)
