@@ -48,6 +48,7 @@ const Knob kKnobs[] = {
     {"igemm_f32_tile64_max", &AldiTuning::igemm_f32_tile64_max, 4096},
     {"igemm_direct", &AldiTuning::igemm_direct, 15},
     {"igemm_lean", &AldiTuning::igemm_lean, 1},
+    {"igemm_halo64_mid", &AldiTuning::igemm_halo64_mid, 0},
     {"wgrad_lean", &AldiTuning::wgrad_lean, 1},
     {"wgrad_big_min", &AldiTuning::wgrad_big_min, 28},
     {"wgrad_big_slots", &AldiTuning::wgrad_big_slots, 256},
@@ -79,6 +80,7 @@ const Knob kKnobs[] = {
     {"sab_blocks", &AldiTuning::sab_blocks, 512},
     {"ln_bwd_blocks", &AldiTuning::ln_bwd_blocks, 512},
     {"ln_bwd_blocks_narrow", &AldiTuning::ln_bwd_blocks_narrow, 1024},
+    {"rpn_topk_fused", &AldiTuning::rpn_topk_fused, 1},
 };
 AldiTuning make_tuning() {
     AldiTuning t;

@@ -1098,8 +1098,8 @@ __global__ __launch_bounds__(WM* WN * 64, (min_waves_per_simd<BM, WM * WN * 64, 
 
 static thread_local const ConvGroup* g_group = nullptr;      // set by aldi_conv_igemm_group around dispatch<T>()
 
-template <int BN, bool DIRECT>
-__global__ __launch_bounds__(512) void igemm_halo64_group_kernel(ConvGroup G) {
+template <int BM, int BN, int WM, int WN, bool DIRECT>
+__global__ __launch_bounds__(WM* WN * 64) void igemm_halo64_group_kernel(ConvGroup G) {
     const int bid = (int)blockIdx.x;
     int i = 0;
     for (int k = 1; k < G.n; ++k)
@@ -1107,7 +1107,7 @@ __global__ __launch_bounds__(512) void igemm_halo64_group_kernel(ConvGroup G) {
     i = __builtin_amdgcn_readfirstlane(i);
     const int local = bid - G.wg_begin[i];
     if (local >= G.nmt[i] * G.nnt[i]) return;  // alignment padding
-    igemm_halo64_body<BN, DIRECT>(G.p[i], local, G.nmt[i], G.nnt[i]);
+    igemm_halo64_body<BM, BN, WM, WN, DIRECT>(G.p[i], local, G.nmt[i], G.nnt[i]);
 }
 
 // the 128-byte-slab halo kernel (igemm_halo64.h), alone or over the problems of a group; the direct epilogue (igemm_direct bit 8) when every
@@ -1115,32 +1115,33 @@ __global__ __launch_bounds__(512) void igemm_halo64_group_kernel(ConvGroup G) {
 inline bool halo64_direct_ok(const ConvDev& d) {
     return d.y && !d.y_f32 && d.out_scale == 1 && (d.Cout & 7) == 0 && !d.mask && !d.mask_bits && !d.bits_out && !d.res_mode;
 }
-template <int BN>
+template <int BM, int BN, int WM, int WN>
 int launch_halo64(const ConvDev& d, hipStream_t st) {
     char name[96];
+    constexpr int NT = WM * WN * 64;
     bool direct = (aldi_tuning().igemm_direct & 8) != 0;
     if (g_group) {
         ConvGroup G = *g_group;
         int wg = 0;
         for (int i = 0; i < G.n; ++i) {
             G.p[i].xcd = d.xcd; G.p[i].dbg = d.dbg;
-            G.nmt[i] = cdiv(G.p[i].M, 256); G.nnt[i] = cdiv(G.p[i].Cout, BN);
+            G.nmt[i] = cdiv(G.p[i].M, BM); G.nnt[i] = cdiv(G.p[i].Cout, BN);
             G.wg_begin[i] = wg;
             wg += (G.nmt[i] * G.nnt[i] + 7) / 8 * 8;
             direct = direct && halo64_direct_ok(G.p[i]);
         }
         for (int i = G.n; i <= kMaxConvGroup; ++i) G.wg_begin[i] = wg;
-        if (direct) hipLaunchKernelGGL((igemm_halo64_group_kernel<BN, true>), dim3(wg), dim3(512), 0, st, G);
-        else hipLaunchKernelGGL((igemm_halo64_group_kernel<BN, false>), dim3(wg), dim3(512), 0, st, G);
+        if (direct) hipLaunchKernelGGL((igemm_halo64_group_kernel<BM, BN, WM, WN, true>), dim3(wg), dim3(NT), 0, st, G);
+        else hipLaunchKernelGGL((igemm_halo64_group_kernel<BM, BN, WM, WN, false>), dim3(wg), dim3(NT), 0, st, G);
         ALDI_CHECK_LAUNCH();
-        snprintf(name, sizeof(name), "igemm_group%d<bf16,256,%d,4,2,halo64%s>", G.n, BN, direct ? ",direct" : "");
+        snprintf(name, sizeof(name), "igemm_group%d<bf16,%d,%d,%d,%d,halo64%s>", G.n, BM, BN, WM, WN, direct ? ",direct" : "");
     } else {
         direct = direct && halo64_direct_ok(d);
-        dim3 grid(cdiv(d.M, 256), cdiv(d.Cout, BN));
-        if (direct) hipLaunchKernelGGL((igemm_halo64_kernel<BN, true>), grid, dim3(512), 0, st, d);
-        else hipLaunchKernelGGL((igemm_halo64_kernel<BN, false>), grid, dim3(512), 0, st, d);
+        dim3 grid(cdiv(d.M, BM), cdiv(d.Cout, BN));
+        if (direct) hipLaunchKernelGGL((igemm_halo64_kernel<BM, BN, WM, WN, true>), grid, dim3(NT), 0, st, d);
+        else hipLaunchKernelGGL((igemm_halo64_kernel<BM, BN, WM, WN, false>), grid, dim3(NT), 0, st, d);
         ALDI_CHECK_LAUNCH();
-        snprintf(name, sizeof(name), "igemm<bf16,256,%d,4,2,halo64%s>", BN, direct ? ",direct" : "");
+        snprintf(name, sizeof(name), "igemm<bf16,%d,%d,%d,%d,halo64%s>", BM, BN, WM, WN, direct ? ",direct" : "");
     }
     aldi_note_dispatch(name);
     return ALDI_OK;
@@ -1236,19 +1237,24 @@ int dispatch(ConvDev& d, hipStream_t st) {
             if constexpr (sizeof(T) == 2) {
                 if (force == 9) return launch<T, 240, 128, 3, 2, 4, false, true>(d, st);
                 if (force == 10 && !g_group) return launch_halo_rs<T, 128>(d, st);
-                if (force == 11 && d.Cin % 64 == 0) return launch_halo64<256>(d, st);
+                if (force == 11 && d.Cin % 64 == 0) return launch_halo64<256, 256, 4, 2>(d, st);
+                if (force == 13 && d.Cin % 64 == 0) return launch_halo64<128, 128, 2, 2>(d, st);
             }
             if (force == 0 || force == 3) {      // (no 64x64 halo form; 5 = the 128x16 tap form)
                 if (d.Cout <= 64) return launch<T, 128, 64, 4, 1, 4, false, true>(d, st);
                 if (big >= tn.igemm_bigtile_min) {
                     // igemm_bigtile 64: 128-byte K slabs on a 256 x 256 tile (igemm_halo64.h) where the channels fill it
                     if constexpr (sizeof(T) == 2)
-                        if (tn.igemm_bigtile == 64 && d.Cin % 64 == 0 && d.Cout % 256 == 0) return launch_halo64<256>(d, st);
+                        if (tn.igemm_bigtile == 64 && d.Cin % 64 == 0 && d.Cout % 256 == 0) return launch_halo64<256, 256, 4, 2>(d, st);
                     if (tn.igemm_bigtile == 1) return launch<T, 128, 128, 2, 2, 4, false, true>(d, st);
                     if constexpr (sizeof(T) == 2)
                         if (tn.igemm_bigtile == 10 && !g_group) return launch_halo_rs<T, 128>(d, st);
                     return launch<T, 256, 128, 4, 2, 4, false, true>(d, st);
                 }
+                // igemm_halo64_mid: mid-size layers with at least this many 128 x 128 tiles (two workgroups per CU: res3 / res4 conv2 at N = 4,
+                // res3 at N = 2) take that tile with 128-byte K slabs (igemm_halo64.h); 0 = never
+                if constexpr (sizeof(T) == 2)
+                    if (tn.igemm_halo64_mid > 0 && big >= tn.igemm_halo64_mid && d.Cin % 64 == 0 && d.Cout % 128 == 0) return launch_halo64<128, 128, 2, 2>(d, st);
                 // below ~1000 128x128 tiles the tile count of this network sits just above a multiple of the 256 CUs (16800 pixels =
                 // 131.25 row tiles: 264 / 528 tiles) and the last partial round costs as much as a full one; half-width tiles halve that
                 // tail (measured 8-25 % faster on every res3..res5 / FPN p3..p6 3x3 at N = 2 and 4)
@@ -1274,6 +1280,7 @@ int dispatch(ConvDev& d, hipStream_t st) {
         const bool plain = d.KH * d.KW == 1 && d.stride == 1 && d.pad == 0;
         if (plain && force == 6) return launch<T, 128, 128, 2, 2, 8, false>(d, st);
         if (plain && force == 7) return launch<T, 128, 64, 4, 1, 8, false>(d, st);
+        if (plain && force == 12 && (direct & 1) && !d.res_mode && d.K % 64 == 0) return launch<T, 128, 64, 4, 1, 8, false, false, 1>(d, st);
         const bool lin256 = tn.igemm_tile != 9 && big >= tn.igemm_lintile_min && d.K >= tn.igemm_bigtile_k;     // (the token-GEMM rule below wins)
         if (plain && (force == 8 || (force == 0 && !lin256 && d.Cout > 64 && d.K % 64 == 0 && d.K >= tn.igemm_k64_min))) {
             if ((direct & 2) && !d.res_mode) return launch<T, 64, 64, 2, 2, 8, false, false, 1>(d, st);

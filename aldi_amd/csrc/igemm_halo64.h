@@ -41,13 +41,19 @@ template <int V> struct KwTag { static constexpr int value = V; };
 // `direct_perm` order so that a lane's fragments 2h, 2h + 1 are 8 consecutive channels of its pixel (one 16-byte store); no LDS staging, no
 // barrier, and nothing waits for the stores -- the workgroup ends (the next one's prologue runs) while they drain.  The staged epilogue of a
 // 256 x 256 tile is 10 us per tile with one workgroup per CU and nothing beside it (16 % of the kernel).
-template <int BN, bool DIRECT>
+// Two tile shapes run this body: 256 x 256 on 8 waves (64 pixels x 128 channels per wave: four 16-MFMA sub-phases per tap) for the p2-size layers,
+// and 128 x 128 on 4 waves (64 x 64 per wave: two sub-phases per tap, 68 KB of LDS: two workgroups per CU) for the mid-size ones (res3 / res4
+// conv2 and their data gradients), whose 128 x 64 tiles with 32-channel slabs spent half their loop on the L2 -> LDS path.  Both have NT / 64
+// threads per 16-byte slot of a tap and of the slab, i.e. the same piece schedule (4 + 1 slab pieces, 4 tap pieces per thread).
+template <int BM, int BN, int WM, int WN, bool DIRECT>
 __device__ __forceinline__ void igemm_halo64_body(const ConvDev& p, int bid, const int nmt, const int nnt) {
     typedef bf16_t T;
-    constexpr int BM = 256, WM = 4, WN = 2, NT = 512, KC = 8, EP = 8, BK = 64;
+    constexpr int NT = WM * WN * 64, KC = 8, EP = 8, BK = 64;
     constexpr int TM = BM / WM / 16;                       // 4 pixel fragments per wave
-    constexpr int TN = BN / WN / 16;                       // 8 channel fragments per wave (BN = 256)
-    constexpr int TH = TN / 2;                             // ... per sub-phase
+    constexpr int TN = BN / WN / 16;                       // 8 or 4 channel fragments per wave
+    constexpr int CS = TN / 4;                             // channel blocks of 64 per wave = sub-phases per k-step
+    constexpr int TH = 4;                                  // channel fragments per sub-phase
+    static_assert(TM == 4 && (CS == 1 || CS == 2), "64 pixels x 64 / 128 channels per wave");
     constexpr int XS = ((BM + 2) * KC + 63) / 64 * 64;     // halo slab, 16-B slots, padded to whole waves of DMA (2112)
     constexpr int WS = BN * KC;                            // one tap of weights (2048)
     constexpr int X_IT = (XS + NT - 1) / NT;               // DMA pieces per thread: slab 5 (the fifth: wave 0 only), tap 4
@@ -98,7 +104,7 @@ __device__ __forceinline__ void igemm_halo64_body(const ConvDev& p, int bid, con
 #pragma unroll
     for (int it = 0; it < W_IT; ++it) {
         const int c = tid + it * NT, row = c >> 3, kce = (c & 7) ^ (row & 6);
-        const int co = n0 + (DIRECT ? direct_perm<BN / WN>(row) : row);
+        const int co = n0 + (DIRECT ? direct_perm<BN / WN>(row) : row);      // (direct_perm: per wave block of BN / WN rows)
         wa_voff[it] = co < p.Cout ? ((unsigned)co * (unsigned)p.K + (unsigned)(kce * EP)) * 2u : OOB;
     }
     // (kh, first channel) of the slab / (kh, first channel, kw) of the tap that is issued NEXT (wave-uniform scalars)
@@ -180,7 +186,7 @@ __device__ __forceinline__ void igemm_halo64_body(const ConvDev& p, int bid, con
     unsigned xoff = 0, woff = 0;                            // LDS byte offsets of the slab / tap stage being READ
     constexpr unsigned XSB = XS * 16, WSB = WS * 16;
     // one tap (kw a compile-time constant: the border selects of read_x and the slab schedule fold; no hand-issued read sits in a branch)
-    auto tap = [&](auto KW, const int g, const int u) {
+    auto tap4 = [&](auto KW, const int g, const int u) {
         constexpr int kw = decltype(KW)::value;
         const bool more1 = u + 1 < U, more2 = u + 2 < U;
         // ---- sub-phase 0: (h 0, channels 0-63) from x0 / wa; reads of (h 0, channels 64-127); DMA point a
@@ -263,6 +269,63 @@ __device__ __forceinline__ void igemm_halo64_body(const ConvDev& p, int bid, con
         __builtin_amdgcn_sched_barrier(0);
         xoff = xoff_n; woff = woff_n;
     };
+    // the same for 64 channels per wave (CS = 1): two sub-phases per tap, one per 32-channel k-step
+    auto tap2 = [&](auto KW, const int g, const int u) {
+        constexpr int kw = decltype(KW)::value;
+        const bool more1 = u + 1 < U, more2 = u + 2 < U;
+        // ---- sub-phase 0: k-step 0 from x0 / wa; reads of k-step 1; DMA points a, b (tap u + 1's pieces 2, 3) and c (the next group's slab)
+        read_x(x1, KW, KwTag<1>{}, xoff);
+        frag_read_n<TH, FR, 0>(wb, w_rd[1] + woff);
+        if (more1) { issue_w(2, (u + 1) & 1, woff_a); issue_w(3, (u + 1) & 1, woff_a); }
+        int nx = 0;
+        if (kw < 2 && g + 1 < ngroups) {
+            const int st = (g + 1) & 1;
+            if constexpr (kw == 0) { issue_x(0, st); issue_x(1, st); nx = 2; }
+            if constexpr (kw == 1) { issue_x(2, st); issue_x(3, st); nx = 2; if (tail) { issue_x(4, st); nx = 3; } next_x(); }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (!no_mfma) {
+            if (prio) __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TH; ++j) acc[i][j] = Mma<T>::run(wa[j], x0[i], acc[i][j]);
+            if (prio) __builtin_amdgcn_s_setprio(0);
+        }
+        frag_wait<TM, TH>(x1, wb);
+        __builtin_amdgcn_sched_barrier(0);
+        if (no_dma || nx == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else if (nx == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- sub-phase 1: k-step 1 from x1 / wb; reads of tap u + 1's k-step 0; DMA point d
+        constexpr int kw_n = kw == 2 ? 0 : kw + 1;
+        const unsigned xoff_n = kw == 2 ? xoff ^ XSB : xoff, woff_n = woff ^ WSB;
+        read_x(x0, KwTag<kw_n>{}, KwTag<0>{}, xoff_n);
+        frag_read_n<TH, FR, 0>(wa, w_rd[0] + woff_n);
+        if (more2) {
+            woff_a = tap_off();
+            issue_w(0, u & 1, woff_a);
+            issue_w(1, u & 1, woff_a);
+            next_tap();
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (!no_mfma) {
+            if (prio) __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TH; ++j) acc[i][j] = Mma<T>::run(wb[j], x1[i], acc[i][j]);
+            if (prio) __builtin_amdgcn_s_setprio(0);
+        }
+        frag_wait<TM, TH>(x0, wa);
+        __builtin_amdgcn_sched_barrier(0);
+        xoff = xoff_n; woff = woff_n;
+    };
+    auto tap = [&](auto KW, const int g, const int u) {
+        if constexpr (CS == 2) tap4(KW, g, u); else tap2(KW, g, u);
+    };
     for (int g = 0; g < ngroups; ++g) {
         tap(KwTag<0>{}, g, 3 * g);
         tap(KwTag<1>{}, g, 3 * g + 1);
@@ -324,7 +387,7 @@ __device__ __forceinline__ void igemm_halo64_body(const ConvDev& p, int bid, con
     igemm_epilogue<T, BM, BN, WM, WN, LDS_SLOTS * 16>(p, acc, m0, n0, reinterpret_cast<unsigned char*>(&lds_all[0]));
 }
 
-template <int BN, bool DIRECT>
-__global__ __launch_bounds__(512) void igemm_halo64_kernel(ConvDev p) {
-    igemm_halo64_body<BN, DIRECT>(p, (int)(blockIdx.y * gridDim.x + blockIdx.x), (int)gridDim.x, (int)gridDim.y);
+template <int BM, int BN, int WM, int WN, bool DIRECT>
+__global__ __launch_bounds__(WM* WN * 64) void igemm_halo64_kernel(ConvDev p) {
+    igemm_halo64_body<BM, BN, WM, WN, DIRECT>(p, (int)(blockIdx.y * gridDim.x + blockIdx.x), (int)gridDim.x, (int)gridDim.y);
 }

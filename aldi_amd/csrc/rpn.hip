@@ -618,6 +618,140 @@ __global__ __launch_bounds__(1024) void topk_sort_kernel(Geom g, const unsigned*
     if (threadIdx.x == 0) cand_count[bl] = k;
 }
 
+// ---------------------------------------------------------------------------------------
+// The whole exact top-k of a (level, image) list -- the three radix passes, the collect and the sort + decode -- as ONE launch.  The five
+// launches above sit on the proposal chain, which ends phase A with the chip idle (~20 dependent launches, 0.37 ms): a
+// dependent launch costs 8-20 us of that chain in a replayed graph whatever it computes.  Here the launch boundaries between the passes are
+// barriers among the workgroups of ONE (level, image) group (1-25 of them: every workgroup owns an 8192-key chunk):
+//   arrive = plain stores / device-scope atomics -> __syncthreads -> lane 0: agent-scope release fence, s_waitcnt, relaxed atomic add;
+//   wait   = lane 0 polls the counter with relaxed agent-scope loads (s_sleep between polls), ONE agent-scope acquire fence, __syncthreads
+// (cdna_hip_programming.md, guideline 16).  The groups are independent, all workgroups of a launch fit the chip several times over (<= 500 of
+// 1024 threads: a spinning workgroup never keeps a peer from being scheduled), and the poll is BOUNDED: after ~2^22 polls a workgroup gives up,
+// raises bit 3 of the error word and goes on (wrong proposals, flagged -- never a hang).  The LAST workgroup of a group to finish its collect
+// (a ticket) sorts and decodes the group's candidates; the chain state stays in registers, the counters are cleared by rpn_keys_kernel.
+// Same arithmetic as topk_hist / topk_collect / topk_sort: bit-identical candidates.
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ void topk_group_barrier(int* counter, int P, int* err) {
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_fetch_add(counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        int spins = 0;
+        while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < P) {
+            __builtin_amdgcn_s_sleep(8);
+            if (++spins > (1 << 22)) { atomicOr(err, 8); break; }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(1024) void topk_fused_kernel(Geom g, const unsigned* __restrict__ keys_all, int pre_nms_topk, int* __restrict__ hists /*[3][B][4096]*/,
+                                                          int* __restrict__ sync /*[B][4]*/, int* __restrict__ fill /*[B]*/, unsigned long long* __restrict__ cand,
+                                                          int* __restrict__ cand_count, const float4* __restrict__ anchors, const int* __restrict__ img_hw,
+                                                          float4* __restrict__ boxes, float* __restrict__ scores, int* __restrict__ valid, int* __restrict__ err) {
+    __shared__ unsigned long long buf[kTopkCap];     // the passes' 4096-bin histogram, then the sorter's keys (16 KB)
+    __shared__ int sm[20];
+    __shared__ int s_last;
+    int* hist = reinterpret_cast<int*>(buf);
+    const int c = blockIdx.x, l = blockIdx.y, n = blockIdx.z, B = gridDim.y * gridDim.z, bl = n * g.nl + l;
+    const int nel = g.H[l] * g.W[l] * g.A;
+    if (c * kTopkChunk >= nel) return;
+    const int P = (nel + kTopkChunk - 1) / kTopkChunk;
+    const int shifts[3] = {20, 8, 0}, widths[3] = {12, 12, 8};
+    const unsigned* kp = keys_all + (long)n * g.sumA + g.off[l] + (long)c * kTopkChunk;
+    const int cnt = min(kTopkChunk, nel - c * kTopkChunk);
+    TopkState s;
+    s.prefix = 0; s.mask = 0; s.need = min(pre_nms_topk, nel); s.bucket_count = 0;
+    for (int pass = 0; pass < 3; ++pass) {
+        if (pass > 0) {
+            int b, above, bc;
+            find_bucket(hists + ((long)(pass - 1) * B + bl) * 4096, 1 << widths[pass - 1], s.need, sm, &b, &above, &bc);
+            s.prefix |= (unsigned)b << shifts[pass - 1];
+            s.mask |= (unsigned)((1 << widths[pass - 1]) - 1) << shifts[pass - 1];
+            s.need -= above;
+            s.bucket_count = bc;
+        }
+        const int shift = shifts[pass], nb = 1 << widths[pass];
+        for (int i = threadIdx.x; i < nb; i += 1024) hist[i] = 0;
+        __syncthreads();
+        for_each_key(kp, cnt, [&](unsigned key, int, bool ok) {
+            hist_add(hist, (key >> shift) & (nb - 1), ok && (key & s.mask) == s.prefix);
+        });
+        __syncthreads();
+        int* out = hists + ((long)pass * B + bl) * 4096;
+        for (int i = threadIdx.x; i < nb; i += 1024) {
+            const int v = hist[i];
+            if (v) atomicAdd(out + i, v);
+        }
+        topk_group_barrier(sync + bl * 4 + pass, P, err);
+    }
+    // ---- the k-th key, this chunk's winners (unordered append)
+    int b, above, bc;
+    find_bucket(hists + ((long)2 * B + bl) * 4096, 256, s.need, sm, &b, &above, &bc);
+    const unsigned kth = s.prefix | (unsigned)b;
+    const int need = s.need - above;                 // copies of kth to take (lowest indices), of `bc`
+    const bool take_all_eq = bc == need;
+    unsigned long long* out = cand + (long)bl * kTopkCap;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int mine = 0;
+    for_each_key(kp, cnt, [&](unsigned key, int, bool ok) {
+        mine += __popcll(__ballot(ok && (key > kth || (take_all_eq && key == kth))));
+    });
+    __syncthreads();
+    if (lane == 0) sm[wave] = mine;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int tot = 0;
+        for (int w = 0; w < 16; ++w) { const int v = sm[w]; sm[w] = tot; tot += v; }
+        sm[16] = tot ? atomicAdd(fill + bl, tot) : 0;
+    }
+    __syncthreads();
+    int pos = sm[16] + sm[wave];
+    for_each_key(kp, cnt, [&](unsigned key, int i, bool ok) {
+        const bool win = ok && (key > kth || (take_all_eq && key == kth));
+        const unsigned long long m = __ballot(win);
+        if (win) out[pos + __popcll(m & ((1ull << lane) - 1ull))] = ((unsigned long long)(~key) << 32) | (unsigned)(c * kTopkChunk + i);
+        pos += __popcll(m);
+    });
+    // ---- ticket: the group's last workgroup sorts
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const int t = __hip_atomic_fetch_add(sync + bl * 4 + 3, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_last = t == P - 1;
+        if (t == P - 1) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
+    __syncthreads();
+    if (!s_last) return;
+    const int k = min(pre_nms_topk, nel);
+    const int have = __hip_atomic_load(fill + bl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    unsigned long long* keys = buf;
+    for (int i = threadIdx.x; i < kTopkCap; i += 1024) keys[i] = i < have ? out[i] : ~0ull;
+    __syncthreads();
+    if (bc != need) {                                // more copies of the k-th key than fit: take the lowest indices
+        const unsigned* kall = keys_all + (long)n * g.sumA + g.off[l];
+        int base_eq = 0;
+        for (int s0 = 0; s0 < nel && base_eq < need; s0 += 1024) {
+            const int i = s0 + threadIdx.x;
+            const bool eq = i < nel && kall[i] == kth;
+            int te;
+            const int re = block_rank(eq, sm, &te);
+            if (eq && base_eq + re < need) keys[(k - need) + base_eq + re] = ((unsigned long long)(~kth) << 32) | (unsigned)i;
+            base_eq += te;
+        }
+        __syncthreads();
+    }
+    bitonic_sort_u64(keys, kTopkCap);
+    for (int i = threadIdx.x; i < kTopkCap; i += 1024) {
+        out[i] = keys[i];
+        decode_candidate(g, anchors, keys[i], i, k, l, n, img_hw, boxes, scores, valid, err);
+    }
+    if (threadIdx.x == 0) cand_count[bl] = k;
+}
+
 // merge the per-level survivors of one image by (score desc, level asc, rank asc); keep post_nms_topk.
 // Every level's survivor list is already in that order (NMS keeps score order), so an element's final position is its
 // own rank plus, for every other level, the number of that level's elements ordered before it: a binary search per
@@ -859,7 +993,7 @@ extern "C" size_t aldi_rpn_proposals_workspace(int N, int num_levels) {
     s += B * cap * (cap / 64) * 8;   // nms mask
     s += B * cap * 4 + B * 4 + 256;  // keep, keep_count
     s += (size_t)N * 512 * 1024 * 4; // objectness keys (sumA <= 512K per image)
-    s += (size_t)3 * B * 4096 * 4 + 3 * B * 16 + B * 4 + 1024;   // radix-select histograms, chain state, fill counters
+    s += (size_t)3 * B * 4096 * 4 + 3 * B * 16 + B * 4 + B * 16 + 2048;   // radix-select histograms, chain state, fill counters, group counters
     return s + 1024;
 }
 
@@ -889,12 +1023,18 @@ extern "C" int aldi_rpn_proposals(const aldi_rpn_geom* gm, float* const* head, c
         auto* hists = (int*)take((size_t)3 * B * 4096 * 4);
         auto* tstate = (TopkState*)take((size_t)3 * B * sizeof(TopkState));     // [current | staging | final]
         auto* fill = (int*)take(B * 4);
-        const long zero_words = (long)(((char*)fill + B * 4 - (char*)hists + 3) / 4);
+        auto* gsync = (int*)take(B * 4 * 4);                   // group barrier / ticket counters of the fused top-k
+        const long zero_words = (long)(((char*)gsync + B * 16 - (char*)hists + 3) / 4);
         hipLaunchKernelGGL(rpn_keys_kernel, dim3(cdiv((long)N * g.sumA, 256)), dim3(256), 0, st, g, N, okeys, hists, zero_words);
         ALDI_CHECK_LAUNCH();
         int max_nel = 0;
         for (int l = 0; l < g.nl; ++l) max_nel = g.H[l] * g.W[l] * g.A > max_nel ? g.H[l] * g.W[l] * g.A : max_nel;
         dim3 grid(cdiv(max_nel, kTopkChunk), g.nl, N);
+        if (aldi_tuning().rpn_topk_fused) {
+            hipLaunchKernelGGL(topk_fused_kernel, grid, dim3(1024), 0, st, g, okeys, pre_nms_topk, hists, gsync, fill, cand, cand_count, (const float4*)anchors, img_hw,
+                               boxes, scores, valid, err_flag);
+            ALDI_CHECK_LAUNCH();
+        } else {
         for (int pass = 0; pass < 3; ++pass) {
             hipLaunchKernelGGL(topk_hist_kernel, grid, dim3(1024), 0, st, g, okeys, pre_nms_topk, pass, hists, tstate);
             ALDI_CHECK_LAUNCH();
@@ -904,6 +1044,7 @@ extern "C" int aldi_rpn_proposals(const aldi_rpn_geom* gm, float* const* head, c
         hipLaunchKernelGGL(topk_sort_kernel, dim3(g.nl, N), dim3(1024), 0, st, g, okeys, pre_nms_topk, tstate + 2 * B, fill, cand, cand_count,
                            (const float4*)anchors, img_hw, boxes, scores, valid, err_flag);
         ALDI_CHECK_LAUNCH();
+        }
     }
     hipLaunchKernelGGL(nms_mask_kernel, dim3(cap / 64, cap / 64, (unsigned)B), dim3(64), 0, st, boxes, valid, (const int*)nullptr, cand_count, (int)cap, nms_thresh, mask);
     ALDI_CHECK_LAUNCH();

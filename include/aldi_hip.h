@@ -37,7 +37,7 @@ int aldi_noop(aldi_stream_t stream);
  *   igemm_force          0 heuristics | 1 128x128 | 2 128x64 | 3 64x64 | 4 256x128 | 5 128x16 tile of aldi_conv_igemm |
  *                        6 / 7 / 8: the 128x128 / 128x64 / 64x64 tile with 128-byte K slabs (plain 1x1 / linear layers) |
  *                        9 / 10 (3x3 halo form only): 240x128 on six waves, two workgroups per CU / 256x128 role-split |
- *                        11 (3x3 halo form, bf16, Cin % 64 == 0): the 256x256 tile with 128-byte K slabs (igemm_halo64.h)
+ *                        11 / 13 (3x3 halo form, bf16, Cin % 64 == 0): the 256x256 / 128x128 tile with 128-byte K slabs (igemm_halo64.h)
  *   igemm_k64_min        plain 1x1 / linear layers with K >= this (and K % 64 == 0) take the 64x64 128-byte-slab form (1024)
  *   igemm_group          1 = aldi_conv_igemm_group shares one launch (0: always n single launches)
  *   igemm_splitk_tile    tile of a split-K launch (aldi_conv_args.ksplit): 0 = 128x128, 1 = 256x128, 2 = 256x128 when that still gives about
@@ -48,6 +48,8 @@ int aldi_noop(aldi_stream_t stream);
  *                        2 = 64x64 long-K tile, 4 = 128x64 halo tile, 8 = the 256x256 128-byte-slab halo tile (scale / shift / ReLU outputs
  *                        only) (15; 0 = the staged epilogue everywhere).  Applies to bf16 outputs in the
  *                        plain layout with Cout % 8 == 0, Cout >= 64, no fp32 output / `mask` tensor / split-K / scatter
+ *   igemm_halo64_mid     mid-size 3x3 layers with at least this many 128x128 tiles take the 128x128 tile with 128-byte K slabs (0 = never, the
+ *                        default: measured 10-20 % slower than the 128x64 tiles on res3 / res4 conv2 -- those layers are bound by workgroup count)
  *   igemm_lean           1 = plain 1x1 / linear layers with K % 64 == 0 on those tiles run the lean K loop (running DMA offsets)
  *   igemm_halo           1 = 3x3/stride-1/pad-1 bf16 convs use the halo form (one pixel slab per three taps)
  *   igemm_bigtile_min    128x128-tile count from which a 3x3 conv takes the big halo tile (1024)
@@ -57,6 +59,7 @@ int aldi_noop(aldi_stream_t stream);
  *   igemm_tile           9 = never use the 256x128 tile for 1x1 / linear
  *   igemm_xcd            1 = XCD-aware workgroup -> tile order
  *   igemm_dbg            ablation bits (4 skip epilogue, 8 one K slab, 16 L1-resident loads): results are WRONG when set
+ *   rpn_topk_fused       1 = the RPN's exact top-k (radix passes, collect, sort + decode) as ONE launch with group barriers (0: five launches)
  *   wgrad_lean           1 = lean bf16 weight-gradient kernel for 1x1 and "same" KxK convs (0: generic gather kernel)
  *   wgrad_dma64          bit mask: 1 = the 256x256 bf16 tile, 2 = the grouped 128x128 tile run the LDS-DMA (full 128-byte lines) + transpose-read
  *                        loop (3; 0: the register-staged loops)

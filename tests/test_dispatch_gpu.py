@@ -981,16 +981,21 @@ def test_direct_epilogue_forced_templates(case, kind):
     128x64 halo tile"""
     N, H, W_, Cin, Cout, k, stride, pad = case
     res = kind in ("f3", "d1")
+    # mask bits reach the direct epilogue by a 4-byte LDS-DMA at bit offset (m * Cout + channel): dword-aligned for Cout % 32 == 0 only --
+    # other widths take the staged epilogue (byte loads)
+    direct = not (kind in ("d1", "d3") and Cout % 32)
+    if not direct and res:
+        pytest.skip("staged epilogue with a residual rounds the product before the add: _check_direct's single-rounding bound does not apply (test_dgrad_* cover it)")
     if k == 3:
         if res:
             pytest.skip("the halo tile has no residual prefetch (no 3x3 layer of the step has a residual)")
-        _check_direct(case, kind, "igemm<bf16,128,64,4,1,flat,halo,direct>", force=2)
+        _check_direct(case, kind, "igemm<bf16,128,64,4,1,flat,halo%s>" % (",direct" if direct else ""), force=2)
         return
-    _check_direct(case, kind, "igemm<bf16,128,64,4,1,pipe,tap,direct%s>" % ("+res" if res else ""), force=2)
+    _check_direct(case, kind, "igemm<bf16,128,64,4,1,pipe,tap%s>" % ((",direct" + ("+res" if res else "")) if direct else ""), force=2)
     if not res and stride == 1:                  # (the 64-channel-slab tile takes plain 1x1 / linear layers only)
         from aldi_amd import _lib as L
         L.reset_tuning()
-        _check_direct(case, kind, "igemm<bf16,64,64,2,2,flat,tap,k64,direct>", force=8)
+        _check_direct(case, kind, "igemm<bf16,64,64,2,2,flat,tap,k64%s>" % (",direct" if direct else ""), force=8)
 
 
 HALO64_SMALL = [
@@ -1007,6 +1012,26 @@ def test_halo64_forced_on_ragged_shapes(case, kind):
     """the 256 x 256 tile with 128-byte K slabs (igemm_halo64.h): direct epilogue for scale / shift / ReLU outputs, the staged one for mask bits"""
     direct = kind in ("f1x", "b", "n", "sc")
     _check_direct(case, kind, "igemm<bf16,256,256,4,2,halo64%s>" % (",direct" if direct else ""), force=11)
+
+
+@pytest.mark.parametrize("kind", ["f1x", "n", "d3"])
+@pytest.mark.parametrize("case", HALO64_SMALL)
+def test_halo64_mid_tile_forced_on_ragged_shapes(case, kind):
+    """the same loop on the 128 x 128 tile (4 waves, 64 x 64 per wave: two sub-phases per tap), igemm_force 13 / igemm_halo64_mid"""
+    direct = kind in ("f1x", "n")
+    _check_direct(case, kind, "igemm<bf16,128,128,2,2,halo64%s>" % (",direct" if direct else ""), force=13)
+
+
+def test_halo64_mid_knob_selects_the_tile():
+    from aldi_amd import _lib as L
+    from aldi_amd import ops
+    x = torch.randn(4, 50, 84, 256, device="cuda").bfloat16()
+    w = (torch.randn(256, 3, 3, 256, device="cuda") / 48).bfloat16()
+    ops.conv2d(x, w, pad=1, relu=True)
+    assert L.last_dispatch() == "igemm<bf16,128,64,4,1,flat,halo,direct>"            # default: off (measured slower on the mid-size layers)
+    L.set_tuning("igemm_halo64_mid", 256)
+    ops.conv2d(x, w, pad=1, relu=True)
+    assert L.last_dispatch() == "igemm<bf16,128,128,2,2,halo64,direct>"
 
 
 @pytest.mark.parametrize("case", HALO64_SMALL[:2])

@@ -10,6 +10,8 @@ SHAPES = [(4, 50, 84, 256, 1024, 1, 1, 1, 0), (4, 50, 84, 1024, 256, 1, 0, 1, 0)
           (4, 50, 84, 256, 256, 3, 0, 1, 0), (2, 50, 84, 256, 256, 3, 0, 1, 0), (4, 100, 168, 128, 128, 3, 0, 1, 0), (4, 25, 42, 512, 512, 3, 0, 1, 0),
           (4, 200, 336, 256, 256, 1, 2, 0, 0)]
 g = torch.Generator(device="cuda").manual_seed(0)
+if os.environ.get("SHAPES"):
+    SHAPES = [tuple(int(v) for v in t.split(",")) for t in os.environ["SHAPES"].split(";")]
 for (N, H, W, Cin, Cout, k, res, relu, mask) in SHAPES:
     x = torch.randn(N, H, W, Cin, device="cuda", generator=g).bfloat16()
     w = (torch.randn(Cout, k, k, Cin, device="cuda", generator=g) / (Cin * k * k) ** 0.5).bfloat16()
