@@ -81,6 +81,7 @@ const Knob kKnobs[] = {
     {"ln_bwd_blocks", &AldiTuning::ln_bwd_blocks, 512},
     {"ln_bwd_blocks_narrow", &AldiTuning::ln_bwd_blocks_narrow, 1024},
     {"rpn_topk_fused", &AldiTuning::rpn_topk_fused, 1},
+    {"ema_blocks", &AldiTuning::ema_blocks, 2048},
 };
 AldiTuning make_tuning() {
     AldiTuning t;

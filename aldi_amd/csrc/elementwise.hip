@@ -797,8 +797,11 @@ extern "C" int aldi_ema_update(float* teacher, const float* student, void* teach
     const float oma = (float)(1.0 - alpha);
     const float alpha_f = (float)alpha;
     const long nc = teacher_compute ? (n_compute < n ? n_compute : n) : 0;
-    if (dtype == ALDI_BF16) hipLaunchKernelGGL(ema_kernel<bf16_t>, dim3(nblocks(n / 4 + 1)), dim3(256), 0, st, teacher, student, (bf16_t*)teacher_compute, n, nc, oma, alpha_f, copy_only);
-    else hipLaunchKernelGGL(ema_kernel<float>, dim3(nblocks(n / 4 + 1)), dim3(256), 0, st, teacher, student, (float*)nullptr, n, 0L, oma, alpha_f, copy_only);
+    // ema_blocks: the tick runs beside the student's stem at the head of the step; a grid that fills every wave slot of the chip starves that
+    // (latency-bound) kernel, a grid-stride loop over fewer workgroups streams as fast
+    const int cap = aldi_tuning().ema_blocks > 0 ? aldi_tuning().ema_blocks : 16384;
+    if (dtype == ALDI_BF16) hipLaunchKernelGGL(ema_kernel<bf16_t>, dim3(nblocks(n / 4 + 1, 256, cap)), dim3(256), 0, st, teacher, student, (bf16_t*)teacher_compute, n, nc, oma, alpha_f, copy_only);
+    else hipLaunchKernelGGL(ema_kernel<float>, dim3(nblocks(n / 4 + 1, 256, cap)), dim3(256), 0, st, teacher, student, (float*)nullptr, n, 0L, oma, alpha_f, copy_only);
     ALDI_CHECK_LAUNCH();
     return ALDI_OK;
 }

@@ -59,6 +59,7 @@ int aldi_noop(aldi_stream_t stream);
  *   igemm_tile           9 = never use the 256x128 tile for 1x1 / linear
  *   igemm_xcd            1 = XCD-aware workgroup -> tile order
  *   igemm_dbg            ablation bits (4 skip epilogue, 8 one K slab, 16 L1-resident loads): results are WRONG when set
+ *   ema_blocks           workgroups of the EMA tick's grid-stride loop (2048: it runs beside the student's stem, a chip-filling grid starves it)
  *   rpn_topk_fused       1 = the RPN's exact top-k (radix passes, collect, sort + decode) as ONE launch with group barriers (0: five launches)
  *   wgrad_lean           1 = lean bf16 weight-gradient kernel for 1x1 and "same" KxK convs (0: generic gather kernel)
  *   wgrad_dma64          bit mask: 1 = the 256x256 bf16 tile, 2 = the grouped 128x128 tile run the LDS-DMA (full 128-byte lines) + transpose-read
