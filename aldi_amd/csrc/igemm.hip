@@ -1378,8 +1378,14 @@ int conv_splitk(const aldi_conv_args* a, ConvDev& d, hipStream_t st) {
     s.xcd = aldi_tuning().igemm_xcd; s.dbg = aldi_tuning().igemm_dbg;
     // igemm_splitk_tile: 0 = 128x128 tiles with 128-byte K slabs (4 waves); 1 = 256x128 tiles, 64-byte slabs (8 waves: two per SIMD
     // also when the launch is one workgroup per CU: FC1 at 2048 rows 86 -> 72 us, at 2000 rows 94 -> 72 us, tools/fc1_splitk_sweep.py)
-    const int tile_knob = aldi_tuning().igemm_splitk_tile;       // 2 (default): 256x128 when its launch still has ~one workgroup per CU
-    if (tile_knob == 1 || (tile_knob == 2 && (long)cdiv(d.M, 256) * cdiv(d.Cout, 128) * ks >= 200)) {
+    const int tile_knob = aldi_tuning().igemm_splitk_tile;       // 2 (default): 256x128 (128-byte slabs) when its launch still has ~one workgroup per CU; 4: the same rule with 64-byte slabs
+    const bool big_ok = (long)cdiv(d.M, 256) * cdiv(d.Cout, 128) * ks >= 200;
+    if (tile_knob == 3 || (tile_knob == 2 && big_ok)) {
+        // 256x128 tiles with 128-byte K slabs (full cache lines per DMA lane group, half the barriers per MFMA of the 64-byte form: FC1 at 2048
+        // rows 94 -> 79 us on cold weights, tools/fc1_cold.py)
+        s.slabs_per_split = d.K / 64 / ks;
+        if (int rc = launch<bf16_t, 256, 128, 4, 2, 8, false>(s, st)) return rc;
+    } else if (tile_knob == 1 || (tile_knob == 4 && big_ok)) {
         s.slabs_per_split = d.K / 32 / ks;
         if (int rc = launch<bf16_t, 256, 128, 4, 2, 4, false>(s, st)) return rc;
     } else {

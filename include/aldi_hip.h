@@ -40,8 +40,8 @@ int aldi_noop(aldi_stream_t stream);
  *                        11 / 13 (3x3 halo form, bf16, Cin % 64 == 0): the 256x256 / 128x128 tile with 128-byte K slabs (igemm_halo64.h)
  *   igemm_k64_min        plain 1x1 / linear layers with K >= this (and K % 64 == 0) take the 64x64 128-byte-slab form (1024)
  *   igemm_group          1 = aldi_conv_igemm_group shares one launch (0: always n single launches)
- *   igemm_splitk_tile    tile of a split-K launch (aldi_conv_args.ksplit): 0 = 128x128, 1 = 256x128, 2 = 256x128 when that still gives about
- *                        one workgroup per CU (default)
+ *   igemm_splitk_tile    tile of a split-K launch (aldi_conv_args.ksplit): 0 = 128x128 (128-byte K slabs), 1 = 256x128 (64-byte slabs), 3 = 256x128
+ *                        (128-byte slabs), 2 = 3 when that still gives about one workgroup per CU, else 0 (default), 4 = the same rule with 1
  *   igemm_narrow_k       bf16 layers with K up to this many channels x taps take 128x64 tiles instead of 128x128 (512; 0 = never)
  *   igemm_direct         bit mask of the 64-channel bf16 tiles that take the DIRECT epilogue (no LDS staging, permuted channel rows, residual
  *                        prefetched into registers, scale / shift / mask bits by 4-byte LDS-DMA, one rounding): 1 = 128x64 1x1 / tap tile,

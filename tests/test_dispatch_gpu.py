@@ -799,9 +799,9 @@ def test_splitk_linear_equals_plain(M, Cout, K, ks):
     assert "splitk" in name1 and "splitk" not in name0, (name0, name1)
     # default tile of the split launch: 256x128 (8 waves) when that still gives about one workgroup per CU, else 128x128 with 128-byte slabs
     wide = ((M + 255) // 256) * ((Cout + 127) // 128) * ks >= 200
-    assert name1.startswith("igemm<bf16,256,128,4,2,flat,tap>" if wide else "igemm<bf16,128,128,2,2,flat,tap,k64>"), name1
+    assert name1.startswith("igemm<bf16,256,128,4,2,flat,tap,k64>" if wide else "igemm<bf16,128,128,2,2,flat,tap,k64>"), name1
     assert torch.equal(y1, y2)
-    for tile, tname in ((0, "igemm<bf16,128,128,2,2,flat,tap,k64>"), (1, "igemm<bf16,256,128,4,2,flat,tap>")):     # both tiles, forced
+    for tile, tname in ((0, "igemm<bf16,128,128,2,2,flat,tap,k64>"), (1, "igemm<bf16,256,128,4,2,flat,tap>"), (3, "igemm<bf16,256,128,4,2,flat,tap,k64>")):     # every tile, forced
         L.set_tuning("igemm_splitk_tile", tile)
         yt = ops.conv2d(x, w, scale=sc, shift=sh, relu=True, ksplit=ks)
         assert L.last_dispatch().startswith(tname), L.last_dispatch()

@@ -14,7 +14,7 @@ def timed(run, cold, n=8):
         e0.record(); run(); e1.record(); torch.cuda.synchronize()
         ts.append(e0.elapsed_time(e1) * 1e3)
     return statistics.median(ts)
-variants = [v.split(":") for v in (sys.argv[1:] or ["0"])]          # igemm_force[:ksplit]
+variants = [v.split(":") for v in (sys.argv[1:] or ["0"])]          # igemm_force[:ksplit[:igemm_splitk_tile]]
 SH = [("fc1 fwd", 2048, 12544, 1024), ("fc1 fwd teacher", 1024, 12544, 1024), ("fc1 dgrad", 2048, 1024, 12544), ("fc2", 2048, 1024, 1024)]
 for name, M, K, Cout in SH:
     x = torch.randn(M, 1, 1, K, device="cuda").bfloat16()
@@ -23,7 +23,9 @@ for name, M, K, Cout in SH:
     ref, row = None, []
     for v in variants:
         L.reset_tuning(); L.set_tuning("igemm_force", int(v[0]))
-        ks = int(v[1]) if len(v) > 1 else None
+        ks = int(v[1]) if len(v) > 1 and v[1] != "" else None
+        if len(v) > 2:
+            L.set_tuning("igemm_splitk_tile", int(v[2]))
         y = torch.empty(M, 1, 1, Cout, device="cuda", dtype=torch.bfloat16)
         run = lambda: ops.conv2d(x, w, shift=b, relu=True, out=y, ksplit=ks)
         try:
