@@ -1293,7 +1293,13 @@ int dispatch(ConvDev& d, hipStream_t st) {
     // 100 -> 85, 44 646 x 1024 -> 256 205 -> 201); same K order per output element as the other tap-form tiles (bit-identical results)
     if (sizeof(T) == 4 && force == 0 && big < tn.igemm_f32_tile64_max) return launch<T, 64, 64, 2, 2, 4>(d, st);
     if (d.Cout <= 64) return launch<T, 128, 64, 4, 1, 4>(d, st);
-    if (tn.igemm_tile != 9 && big >= tn.igemm_lintile_min && d.K >= tn.igemm_bigtile_k) return launch<T, 256, 128, 4, 2, 4, false>(d, st);
+    if (tn.igemm_tile != 9 && big >= tn.igemm_lintile_min && d.K >= tn.igemm_bigtile_k) {
+        // 128-byte K slabs on this tile for plain bf16 layers with K % 64 == 0 (+8-17 % on the box head's FC1 dgrad and the ViT linears,
+        // tools/lin_tile_ab.py; igemm_tile 7: the 64-byte slabs)
+        if constexpr (sizeof(T) == 2)
+            if (tn.igemm_tile != 7 && d.KH * d.KW == 1 && d.stride == 1 && d.pad == 0 && d.K % 64 == 0) return launch<T, 256, 128, 4, 2, 8, false>(d, st);
+        return launch<T, 256, 128, 4, 2, 4, false>(d, st);
+    }
     if (big < 200) return launch<T, 64, 64, 2, 2, 4>(d, st);
     // short-K layers (the bottlenecks' 1x1 expansions and res3's reductions: K = 128 .. 512, 4-16 slabs) are all prologue and
     // epilogue: half-width tiles (twice the workgroups, half the staging epilogue each) run them 8-13 % faster than 128x128

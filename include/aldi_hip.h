@@ -56,7 +56,7 @@ int aldi_noop(aldi_stream_t stream);
  *   igemm_bigtile        which one: 64 = 256x256 with 128-byte K slabs where Cin % 64 == 0 and Cout % 256 == 0 (default; else 256x128),
  *                        4 = 256x128 lockstep, 1 = 128x128, 10 = 256x128 with the two wave halves in alternating roles
  *   igemm_lintile_min, igemm_bigtile_k   tile count / K from which a 1x1 conv or linear takes the 256x128 tile (768, 768)
- *   igemm_tile           9 = never use the 256x128 tile for 1x1 / linear
+ *   igemm_tile           9 = never use the 256x128 tile for 1x1 / linear; 7 = that tile with 64-byte K slabs (default: 128-byte slabs where K % 64 == 0)
  *   igemm_xcd            1 = XCD-aware workgroup -> tile order
  *   igemm_dbg            ablation bits (4 skip epilogue, 8 one K slab, 16 L1-resident loads): results are WRONG when set
  *   ema_blocks           workgroups of the EMA tick's grid-stride loop (2048: it runs beside the student's stem, a chip-filling grid starves it)

@@ -147,7 +147,7 @@ FULL_FWD = [
     ((4, 200, 336, 256, 512, 1, 2, 0), "igemm<bf16,128,64,4,1,pipe,tap>"),        # res3 shortcut (stride 2, K = 256)
     ((4, 50, 84, 768, 1024, 1, 2, 0), "igemm<bf16,128,128,2,2,pipe,tap>"),        # a strided 1x1 with K > 512: full tiles
     ((4, 200, 336, 256, 16, 1, 1, 0), "igemm<bf16,128,16,4,1,pipe,tap>"),         # RPN objectness + deltas
-    ((1, 120, 140, 3072, 768, 1, 1, 0), "igemm<bf16,256,128,4,2,flat,tap>"),      # 16800 x 3072 -> 768 (ViT MLP fc2)
+    ((1, 120, 140, 3072, 768, 1, 1, 0), "igemm<bf16,256,128,4,2,flat,tap,k64>"),  # 16800 x 3072 -> 768 (ViT MLP fc2): 128-byte K slabs
     ((2048, 1, 1, 12544, 1024, 1, 1, 0), "igemm<bf16,64,64,2,2,flat,tap,k64>"),   # box head FC1 (long K: 128-byte slabs)
     ((4, 25, 42, 512, 2048, 1, 1, 0), "igemm<bf16,128,64,4,1,pipe,tap>"),         # res5 conv3
     ((2, 25, 42, 512, 512, 3, 1, 1), "igemm<bf16,128,64,4,1,flat,halo>"),         # res5 conv2, teacher
