@@ -82,6 +82,7 @@ const Knob kKnobs[] = {
     {"ln_bwd_blocks_narrow", &AldiTuning::ln_bwd_blocks_narrow, 1024},
     {"rpn_topk_fused", &AldiTuning::rpn_topk_fused, 1},
     {"ema_blocks", &AldiTuning::ema_blocks, 2048},
+    {"nms_mask_tri", &AldiTuning::nms_mask_tri, 1},
 };
 AldiTuning make_tuning() {
     AldiTuning t;

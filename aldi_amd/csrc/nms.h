@@ -42,6 +42,49 @@ static __global__ __launch_bounds__(64) void nms_mask_kernel(const float4* __res
     if (i < n) mask[((long)b * cap + i) * (cap / 64) + cb] = bits;
 }
 
+// The same mask from a triangular grid: one WAVE per 64 x 64 block (rb <= cb) of a batch item, four blocks per workgroup, no LDS -- lane j holds
+// column box j and every row thread reads it through v_readlane (scalar operands); the square grid above launches 2 x the workgroups (half
+// return at once) of one wave each and stages the column boxes through the LDS behind a barrier.  Identical arithmetic, identical bits.
+static __global__ __launch_bounds__(256) void nms_mask_tri_kernel(const float4* __restrict__ boxes, const int* __restrict__ valid, const int* __restrict__ cat,
+                                                                  const int* __restrict__ count, int cap, float thr, unsigned long long* __restrict__ mask) {
+    const int b = blockIdx.y, lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+    const int nb = cap / 64;
+    int pidx = (int)blockIdx.x * 4 + wave;               // index into the row-major list of blocks (rb, cb >= rb)
+    if (pidx >= nb * (nb + 1) / 2) return;
+    int rb = 0;
+    while (pidx >= nb - rb) { pidx -= nb - rb; ++rb; }   // (scalar: at most nb steps)
+    const int cb = rb + pidx;
+    const int n = count ? count[b] : cap;
+    if (rb * 64 >= n || cb * 64 >= n) return;
+    const int j = cb * 64 + lane;
+    const bool jv = j < n && valid[(long)b * cap + j];
+    const float4 cbx = jv ? boxes[(long)b * cap + j] : make_float4(0, 0, 0, 0);
+    const int ccat = jv ? (cat ? cat[(long)b * cap + j] : 0) : -1;
+    const int i = rb * 64 + lane;
+    const bool iv = i < n && valid[(long)b * cap + i];
+    const float4 bi = iv ? boxes[(long)b * cap + i] : make_float4(0, 0, 0, 0);
+    const int ci = cat ? (iv ? cat[(long)b * cap + i] : 0) : 0;
+    unsigned long long bits = 0;
+#pragma unroll
+    for (int t = 0; t < 64; ++t) {
+        float4 cbt;
+        cbt.x = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, cbx.x), t));
+        cbt.y = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, cbx.y), t));
+        cbt.z = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, cbx.z), t));
+        cbt.w = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, cbx.w), t));
+        const int ct = __builtin_amdgcn_readlane(ccat, t);
+        const int jj = cb * 64 + t;
+        if (iv && jj > i && ct == ci && nms_over(bi, cbt, thr)) bits |= 1ull << t;
+    }
+    if (i < n) mask[((long)b * cap + i) * (cap / 64) + cb] = bits;
+}
+static inline void nms_mask_launch(hipStream_t st, int B, const float4* boxes, const int* valid, const int* cat, const int* count, int cap, float thr,
+                                   unsigned long long* mask, int tri) {
+    const int nb = cap / 64;
+    if (tri) hipLaunchKernelGGL(nms_mask_tri_kernel, dim3((nb * (nb + 1) / 2 + 3) / 4, B), dim3(256), 0, st, boxes, valid, cat, count, cap, thr, mask);
+    else hipLaunchKernelGGL(nms_mask_kernel, dim3(nb, nb, B), dim3(64), 0, st, boxes, valid, cat, count, cap, thr, mask);
+}
+
 // OR over the 64 lanes of a wave by DPP (row rotations, then the two row broadcasts): ~7 VALU ops instead of a six-deep chain of
 // LDS permutes per 32 bits.  The total is read from lane 63 and returned wave-uniform.
 static __device__ __forceinline__ unsigned wave_or_u32(unsigned v) {

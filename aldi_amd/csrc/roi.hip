@@ -1226,7 +1226,7 @@ extern "C" int aldi_detections(const float* pred, int Cp, int K, const float* pr
     hipLaunchKernelGGL(det_sort_kernel, dim3(N), dim3(1024), kDetCap * 8, st, pred, Cp, K, (const float4*)props, P, img_hw, weights4[0], weights4[1], weights4[2], weights4[3],
                        keys, cnt, boxes, scores, cats, valid);
     ALDI_CHECK_LAUNCH();
-    hipLaunchKernelGGL(nms_mask_kernel, dim3(cap / 64, cap / 64, N), dim3(64), 0, st, boxes, valid, cats, cnt, (int)cap, nms_thresh, mask);
+    nms_mask_launch(st, N, boxes, valid, cats, cnt, (int)cap, nms_thresh, mask, aldi_tuning().nms_mask_tri);
     ALDI_CHECK_LAUNCH();
     if (!nms_scan_launch(st, N, mask, valid, cnt, (int)cap, topk, keep, keep_count)) return aldi_set_error_msg(ALDI_ERR_ARG, "detections: NMS capacity too large");
     ALDI_CHECK_LAUNCH();

@@ -1046,7 +1046,7 @@ extern "C" int aldi_rpn_proposals(const aldi_rpn_geom* gm, float* const* head, c
         ALDI_CHECK_LAUNCH();
         }
     }
-    hipLaunchKernelGGL(nms_mask_kernel, dim3(cap / 64, cap / 64, (unsigned)B), dim3(64), 0, st, boxes, valid, (const int*)nullptr, cand_count, (int)cap, nms_thresh, mask);
+    nms_mask_launch(st, (int)B, boxes, valid, (const int*)nullptr, cand_count, (int)cap, nms_thresh, mask, aldi_tuning().nms_mask_tri);
     ALDI_CHECK_LAUNCH();
     // (a level can place at most post_nms_topk boxes in the image's merged list: its scan stops there)
     if (!nms_scan_launch(st, (int)B, mask, valid, cand_count, (int)cap, post_nms_topk < (int)cap ? post_nms_topk : (int)cap, keep, keep_count))

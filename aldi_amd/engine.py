@@ -396,6 +396,7 @@ class RCNN:
         self.ins_da_layers = sorted((n for n in names if n.startswith("ins_align.model.")), key=idx)
         self.has_img_da, self.has_ins_da = bool(self.img_da_layers), bool(self.ins_da_layers)
         self.fused_stem = os.environ.get("ALDI_FUSED_STEM", "1") == "1"                  # bf16: stem conv + max-pool in one kernel
+        self.wgrad_tail_split = int(os.environ.get("ALDI_WGRAD_TAIL_SPLIT", "2"))       # res3's weight-gradient group launched every this many blocks (0: once)
         self.group_wgrad = os.environ.get("ALDI_WGRAD_GROUP", "1") == "1"                # bf16: a layer group's weight gradients in one launch
         self.mask_bits = os.environ.get("ALDI_MASK_BITS", "1") == "1"                    # ReLU masks of the block outputs as bits for the backward
         self.mask_bits_inner = os.environ.get("ALDI_MASK_BITS_INNER", "1") == "1"        # ... and of the two inner maps of every bottleneck
@@ -1426,6 +1427,11 @@ class RCNN:
                 self._wgrad(p + "conv2", h1, g2)
                 g1 = ops.conv2d(g2, W.wt(p + "conv2"), pad=1, **self._relu_mask(c, h1))
                 self._wgrad(p + "conv1", xin, g1)
+                if si == 1 and not first and self.wgrad_tail_split > 0 and (STAGE_BLOCKS[si] - b) % self.wgrad_tail_split == 0:
+                    # res3 is the LAST stage of the backward: launched as one group behind its last data gradient, its weight gradients
+                    # (0.28 ms) run alone at the end of the step -- nothing is left to run beside them.  Launching the blocks done so
+                    # far puts that part under the remaining blocks' data gradients (profiles/r05_timeline_spin.txt)
+                    self._flush_wgrads()
                 if first:
                     self._wgrad(p + "shortcut", xin, g)
                     self._grads_final(stage_names)

@@ -60,6 +60,7 @@ int aldi_noop(aldi_stream_t stream);
  *   igemm_xcd            1 = XCD-aware workgroup -> tile order
  *   igemm_dbg            ablation bits (4 skip epilogue, 8 one K slab, 16 L1-resident loads): results are WRONG when set
  *   ema_blocks           workgroups of the EMA tick's grid-stride loop (2048: it runs beside the student's stem, a chip-filling grid starves it)
+ *   nms_mask_tri         1 = the NMS suppression mask from a triangular grid, one wave per 64x64 block, column boxes by v_readlane (0: square grid + LDS)
  *   rpn_topk_fused       1 = the RPN's exact top-k (radix passes, collect, sort + decode) as ONE launch with group barriers (0: five launches)
  *   wgrad_lean           1 = lean bf16 weight-gradient kernel for 1x1 and "same" KxK convs (0: generic gather kernel)
  *   wgrad_dma64          bit mask: 1 = the 256x256 bf16 tile, 2 = the grouped 128x128 tile run the LDS-DMA (full 128-byte lines) + transpose-read
