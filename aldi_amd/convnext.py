@@ -163,10 +163,13 @@ class ConvNeXt:
         ops.bias_grad(g2d, self.p.g(name + ".bias"))
         return ops.conv2d(g2d.view(T, 1, 1, -1), self.p.wt(name + ".weight")).view(T, -1) if need_dx else None
 
-    def forward(self, img_u8: torch.Tensor, sizes: Sequence[Sequence[int]], save: bool = True, drop_scales: Optional[torch.Tensor] = None) -> Ctx:
+    def forward(self, img_u8: torch.Tensor, sizes: Sequence[Sequence[int]], save: bool = True, drop_scales: Optional[torch.Tensor] = None,
+                hw_dev: Optional[torch.Tensor] = None) -> Ctx:
         c, p = self.cfg, self.p
         N, _, Hs, Ws = img_u8.shape
-        hw = ops.upload_packed([torch.tensor([[int(h), int(w)] for h, w in sizes], dtype=torch.int32).flatten()], self.device)[0]
+        # (the fused step hands over its persistent [N][2] image-size buffer: a per-call pinned upload cannot be recorded into a graph)
+        hw = hw_dev.view(-1) if hw_dev is not None and hw_dev.numel() == 2 * len(sizes) else \
+            ops.upload_packed([torch.tensor([[int(h), int(w)] for h, w in sizes], dtype=torch.int32).flatten()], self.device)[0]
         ctx = Ctx(N=N, save=save, rec={}, blocks=[])
         rec = ctx.rec if save else None
         pre = "downsample_layers."
@@ -263,11 +266,18 @@ class ConvNeXtRCNN(_engine_base()):
         self.net = ConvNeXt(params)
         self.anchor_sizes = tuple(params.cfg.anchor_sizes)
 
+    graph_safe = True            # (fused_step: the launches of a pass are the same every step)
+
+    def refresh_drop_scales(self, N: int):
+        from .vitdet import _refresh
+        _refresh(self, self.net.drop_path_scales(N, self.drop_gen))
+
     # ------------------------------------------------------------------ forward
     def trunk(self, st_u8: torch.Tensor, sizes, save: bool) -> Ctx:
         N = st_u8.shape[0]
-        ds = self.net.drop_path_scales(N, self.drop_gen) if save else None
-        cn = self.net.forward(st_u8, sizes, save=save, drop_scales=ds)
+        from .vitdet import _staged_drop_scales
+        ds = _staged_drop_scales(self, None, N) if save else None
+        cn = self.net.forward(st_u8, sizes, save=save, drop_scales=ds, hw_dev=self.__dict__.get("_hw_dev", {}).get(st_u8.data_ptr()))
         cs = cn.outs
         prev, P = {}, {}
         prev[5] = ops.conv2d(cs[3], self._w("backbone.fpn_lateral5"), shift=self._b("backbone.fpn_lateral5"))

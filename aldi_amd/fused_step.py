@@ -775,7 +775,15 @@ class FusedStep:
             S.h_counts_np = S.h_counts.numpy().view("int32")[: 4 * N + 2]
         S.h_counts_np.fill(-1)                                    # (phase A's last copy overwrites every word with a length >= 0)
         # (the ViTDet / ConvNeXt trunks draw their stochastic-depth masks on the host every step: their launches are not replayable as recorded)
-        use_graph = self.graph_enabled and self.steps_done >= self.warmup and type(eng) is RCNN
+        # -- they stage those masks in a persistent device buffer now (vitdet._staged_drop_scales), refreshed here before every pass:
+        graph_flat = getattr(eng, "graph_safe", False) and os.environ.get("ALDI_STEP_GRAPH_FLAT", "1") == "1"
+        if hasattr(eng, "refresh_drop_scales"):
+            eng.refresh_drop_scales(N)
+            # (their trunks mask the padding with the image sizes on the device: the persistent buffers of the staged batches, keyed by the batch)
+            eng._hw_dev = {S.stu.img.data_ptr(): S.stu.hw}
+            if S.tea is not None and self.teng is not None and hasattr(self.teng, "refresh_drop_scales"):
+                self.teng._hw_dev = {S.tea.img.data_ptr(): S.tea.hw}
+        use_graph = self.graph_enabled and self.steps_done >= self.warmup and (type(eng) is RCNN or graph_flat)
         # captured graphs read the dgrad-weight buffers of the plan they were recorded with: a layer first requested later rebuilds
         # that plan (new buffers), so everything recorded before is dropped
         epoch = (getattr(eng.wts, "wt_epoch", 0), ops.WGRAD_WS_EPOCH)     # (dgrad-weight plan, weight-gradient workspace: both are baked into the graphs)

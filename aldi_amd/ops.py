@@ -169,6 +169,10 @@ def _wgrad_workspace(arr, n: int, device) -> None:
             if torch.cuda.is_current_stream_capturing():
                 # (the eager warm-up steps size the buffer; outgrowing it DURING a recording means the shapes changed under the capture)
                 raise RuntimeError("the weight-gradient workspace has to grow during a hipGraph capture: run the new shapes eagerly once first")
+        else:
+            # a stream's first buffer (e.g. the capture stream of a step graph) starts at the size the other streams' buffers have reached: the
+            # eager warm-up steps have seen the step's largest problem there, the first call on this stream need not be it
+            need = max([need] + [b.numel() * 4 for (d_, _), b in _WGRAD_WS.items() if d_ == device])
         buf = torch.empty((need + (need >> 2) + 3) // 4, dtype=torch.float32, device=device)
         _WGRAD_WS[key] = buf
     arr[0].ws = buf.data_ptr()

@@ -502,13 +502,15 @@ class ViT:
 
     # ------------------------------------------------------------------------------------------------- forward
     def forward(self, img_u8: torch.Tensor, sizes: Sequence[Sequence[int]], save: bool = True,
-                drop_scales: Optional[torch.Tensor] = None) -> Ctx:
+                drop_scales: Optional[torch.Tensor] = None, hw_dev: Optional[torch.Tensor] = None) -> Ctx:
         c, p = self.cfg, self.p
         N, _, Hs, Ws = img_u8.shape
         gh, gw = Hs // c.patch, Ws // c.patch
         T, E = N * gh * gw, c.embed
         geo = self.geometry(N, gh, gw)
-        hw = ops.upload_packed([torch.tensor([[int(h), int(w)] for h, w in sizes], dtype=torch.int32).flatten()], self.device)[0]
+        # (the fused step hands over its persistent [N][2] image-size buffer: a per-call pinned upload cannot be recorded into a graph)
+        hw = hw_dev.view(-1) if hw_dev is not None and hw_dev.numel() == 2 * len(sizes) else \
+            ops.upload_packed([torch.tensor([[int(h), int(w)] for h, w in sizes], dtype=torch.int32).flatten()], self.device)[0]
         ctx = Ctx(N=N, gh=gh, gw=gw, blocks=[], save=save)
         patches = V.patchify(img_u8, hw, c.patch, c.pixel_mean, c.pixel_std, torch.bfloat16)
         tok = ops.conv2d(patches.view(T, 1, 1, -1), p.w("patch_embed.proj.weight", (E, 1, 1, 3 * c.patch * c.patch)),

@@ -67,6 +67,42 @@ class FlatParamRCNN(RCNN):
         raise RuntimeError("engine.RCNN._wgrad is tied to the R50-FPN layout; the flat-container engines do not use it")
 
 
+def _refresh(eng, ds):
+    if ds is None:
+        eng._ds_dev = None
+    else:
+        ring = eng.__dict__.get("_ds_ring")
+        if ring is None or ring[0][0].shape != ds.shape:
+            # two pinned slots, each guarded by the event of its last upload: the host may be a step ahead of the GPU, and the copy out of a slot
+            # must have run before the next draw overwrites it
+            cuda = torch.cuda.is_available()
+            ring = eng._ds_ring = [[torch.empty_like(ds).pin_memory() if cuda else torch.empty_like(ds), None] for _ in range(2)]
+            eng._ds_dev = torch.empty(ds.shape, dtype=ds.dtype, device=eng.device)
+            eng._ds_slot = 0
+        slot = ring[eng._ds_slot]
+        eng._ds_slot ^= 1
+        if slot[1] is not None:
+            slot[1].synchronize()
+        slot[0].copy_(ds)
+        eng._ds_dev.copy_(slot[0], non_blocking=True)
+        if eng._ds_dev.is_cuda:
+            slot[1] = slot[1] or torch.cuda.Event()
+            slot[1].record()
+        eng._ds_host = slot[0]                      # (the draw the device buffer holds once the stream reaches this point: tests compare the two)
+    eng._ds_fresh = True
+
+
+def _staged_drop_scales(eng, draw, N):
+    """stochastic-depth multipliers of one training pass in a PERSISTENT device buffer: the host draws them (same generator stream as before) into
+    pinned memory and one stream-ordered copy refreshes the buffer -- the kernels read the multipliers from device memory, so the launches of the
+    pass do not depend on what was drawn and a captured step can be replayed (FusedStep calls `refresh_drop_scales` before every replay; a pass
+    that finds no fresh draw -- the eager paths -- draws itself)."""
+    if not eng.__dict__.pop("_ds_fresh", False):
+        eng.refresh_drop_scales(N)
+        eng.__dict__.pop("_ds_fresh", None)
+    return eng.__dict__.get("_ds_dev")
+
+
 class VitDetRCNN(FlatParamRCNN):
     def __init__(self, params: VitParams, num_classes: int, seed: int = 0):
         assert params.cfg.sfp
@@ -74,12 +110,17 @@ class VitDetRCNN(FlatParamRCNN):
         self.vit = ViT(params)
         self.sfp = SimpleFeaturePyramid(params)
 
+    graph_safe = True            # (fused_step: the launches of a pass are the same every step)
+
+    def refresh_drop_scales(self, N: int):
+        _refresh(self, self.vit.drop_path_scales(N, self.drop_gen))
+
     # ------------------------------------------------------------------ forward
     def trunk(self, st_u8: torch.Tensor, sizes, save: bool) -> Ctx:
         cfg = self.vp.cfg
         N = st_u8.shape[0]
-        ds = self.vit.drop_path_scales(N, self.drop_gen) if save else None      # stochastic depth: training (student) passes only
-        cv = self.vit.forward(st_u8, sizes, save=save, drop_scales=ds)
+        ds = _staged_drop_scales(self, None, N) if save else None               # stochastic depth: training (student) passes only
+        cv = self.vit.forward(st_u8, sizes, save=save, drop_scales=ds, hw_dev=self.__dict__.get("_hw_dev", {}).get(st_u8.data_ptr()))
         gh, gw = st_u8.shape[2] // cfg.patch, st_u8.shape[3] // cfg.patch
         cs = self.sfp.forward(cv.out.view(N, gh, gw, cfg.embed), save=save)
         c = Ctx()
