@@ -49,6 +49,9 @@ const Knob kKnobs[] = {
     {"igemm_direct", &AldiTuning::igemm_direct, 15},
     {"igemm_lean", &AldiTuning::igemm_lean, 1},
     {"igemm_halo64_mid", &AldiTuning::igemm_halo64_mid, 0},
+    {"igemm_ws", &AldiTuning::igemm_ws, 1},
+    {"igemm_ws_wgs", &AldiTuning::igemm_ws_wgs, 512},
+    {"igemm_ws_min", &AldiTuning::igemm_ws_min, 40000},
     {"wgrad_lean", &AldiTuning::wgrad_lean, 1},
     {"wgrad_big_min", &AldiTuning::wgrad_big_min, 28},
     {"wgrad_big_slots", &AldiTuning::wgrad_big_slots, 256},

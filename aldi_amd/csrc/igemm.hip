@@ -1065,6 +1065,7 @@ int launch_halo_rs(const ConvDev& d, hipStream_t st) {
 }
 
 #include "igemm_halo64.h"
+#include "igemm_ws.h"
 
 // (the 240-pixel halo tile is sized for TWO workgroups per CU: 6 waves each = 3 waves per SIMD, 80 KB of LDS each)
 template <int BM, int NT, bool HALO> constexpr int min_waves_per_simd() { return HALO && BM == 240 ? 2 * NT / 256 : 1; }
@@ -1264,6 +1265,10 @@ int dispatch(ConvDev& d, hipStream_t st) {
             }
         }
     }
+    // igemm_ws: the short-K 1x1 layers of the trunk (bottleneck expansions / reductions, their data gradients) on the weight-stationary persistent
+    // kernel (igemm_ws.h; its epilogue is the direct one: igemm_direct bit 1 turns it off with that); igemm_force 14 forces it wherever it is eligible
+    if constexpr (sizeof(T) == 2)
+        if (!g_group && ws_ok(d) && (force == 14 || (force == 0 && tn.igemm_ws && (tn.igemm_direct & 1) && d.M >= tn.igemm_ws_min))) return launch_ws(d, st, tn.igemm_ws_wgs);
     if (force == 5 || (force == 0 && d.Cout <= 16)) return launch<T, 128, 16, 4, 1, 4>(d, st);
     if (force == 1) return launch<T, 128, 128, 2, 2, 4>(d, st);
     if constexpr (sizeof(T) == 2) {

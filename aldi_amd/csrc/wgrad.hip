@@ -1478,6 +1478,13 @@ extern "C" int aldi_conv_wgrad_group(const aldi_wgrad_args* args, int n, aldi_st
 extern "C" long aldi_conv_wgrad_group_workspace(const aldi_wgrad_args* args, int n) {
     size_t need = 0;
     if (wgrad_group_impl(args, n, nullptr, true, &need)) return -1;
+    if (n == 1) {
+        // one problem may be handed to aldi_conv_wgrad instead, whose dispatcher splits the pixels by its own rule (knob wgrad_slots): the larger of the two
+        WsCarver ws{nullptr, 0, 0, true};
+        FinBuilder fin(nullptr, true);
+        if (wgrad_single(&args[0], nullptr, ws, fin, true, true)) return -1;
+        if (ws.used * 4 > need) need = ws.used * 4;
+    }
     return (long)need;
 }
 

@@ -939,13 +939,15 @@ def _check_direct(case, kind, expect, *, force=None):
 DIRECT_FULL = [
     # (N, H, W, Cin, Cout, k, stride, pad), kind, the kernel the DEFAULT dispatch picks
     ((4, 50, 84, 256, 1024, 1, 1, 0), "f3", "igemm<bf16,128,64,4,1,pipe,tap,direct+res>"),       # res4 conv3
-    ((4, 100, 168, 128, 512, 1, 1, 0), "f3", "igemm<bf16,128,64,4,1,pipe,tap,direct+res>"),      # res3 conv3 (4 K slabs)
+    ((4, 100, 168, 128, 512, 1, 1, 0), "f3", "igemm_ws<bf16,32,256,k128>"),                      # res3 conv3 (>= 40 000 pixels: the weight-stationary persistent kernel, igemm_ws.h)
     ((2, 25, 42, 512, 2048, 1, 1, 0), "f3", "igemm<bf16,128,64,4,1,pipe,tap,direct+res>"),       # res5 conv3, teacher
     ((4, 50, 84, 1024, 256, 1, 1, 0), "f1", "igemm<bf16,64,64,2,2,flat,tap,k64,direct>"),        # res4 conv1
-    ((4, 100, 168, 512, 128, 1, 1, 0), "f1", "igemm<bf16,128,64,4,1,pipe,tap,direct>"),          # res3 conv1
+    ((4, 100, 168, 512, 128, 1, 1, 0), "f1", "igemm_ws<bf16,16,128,k512>"),                      # res3 conv1
     ((4, 50, 84, 256, 256, 3, 1, 1), "f1", "igemm<bf16,128,64,4,1,flat,halo,direct>"),           # res4 conv2
     ((4, 100, 168, 512, 1024, 1, 2, 0), "sc", "igemm<bf16,128,64,4,1,pipe,tap,direct>"),         # res4 shortcut (stride 2)
     ((4, 50, 84, 256, 1024, 1, 1, 0), "d1", "igemm<bf16,128,64,4,1,pipe,tap,direct+res>"),       # res4 conv1 dgrad (+ skip gradient, mask of the block input)
+    ((4, 100, 168, 128, 512, 1, 1, 0), "d1", "igemm_ws<bf16,32,256,k128>"),                      # res3 conv1 dgrad
+    ((4, 100, 168, 512, 128, 1, 1, 0), "d3", "igemm_ws<bf16,16,128,k512>"),                      # res3 conv3 dgrad
     ((4, 50, 84, 1024, 256, 1, 1, 0), "d3", "igemm<bf16,64,64,2,2,flat,tap,k64,direct>"),        # res4 conv3 dgrad
     ((4, 50, 84, 256, 256, 3, 1, 1), "d3", "igemm<bf16,128,64,4,1,flat,halo,direct>"),           # res4 conv2 dgrad
     ((4, 100, 168, 512, 256, 1, 1, 0), "up", "igemm<bf16,128,64,4,1,pipe,tap,direct+res>"),      # FPN lateral 3 (+ upsampled top-down map)
@@ -996,6 +998,69 @@ def test_direct_epilogue_forced_templates(case, kind):
         from aldi_amd import _lib as L
         L.reset_tuning()
         _check_direct(case, kind, "igemm<bf16,64,64,2,2,flat,tap,k64%s>" % (",direct" if direct else ""), force=8)
+
+
+WS_SMALL = [
+    (3, 7, 9, 64, 256, 1, 1, 0),       # K = 64 (one 128-byte slab), M = 189: six pixel tiles of 32, the last one ragged
+    (2, 25, 41, 128, 512, 1, 1, 0),    # K = 128, two channel groups, M = 2050
+    (1, 19, 23, 256, 256, 1, 1, 0),    # K = 256 (the weights fill 128 registers per lane), M = 437
+    (2, 13, 30, 512, 128, 1, 1, 0),    # K = 512: 16-pixel tiles, one channel group
+    (130, 1, 1, 128, 768, 1, 1, 0),    # a linear layer, three channel groups
+]
+
+
+@pytest.mark.parametrize("kind", ["f3", "f1", "f1x", "sc", "b", "n", "d1", "d3"])
+@pytest.mark.parametrize("case", WS_SMALL)
+def test_weight_stationary_kernel_forced_on_ragged_shapes(case, kind):
+    """igemm_ws.h (weights in registers, pixel tiles through a 3-stage LDS ring, persistent workgroups) with every epilogue operand set of the
+    bottleneck layers: more pixel-tile sequences than tiles, ragged last tiles, one to three channel groups"""
+    K = case[3]
+    _check_direct(case, kind, "igemm_ws<bf16,%d,%d,k%d>" % (32 if K <= 256 else 16, 128 if K == 512 else 256, K), force=14)
+
+
+@pytest.mark.parametrize("wgs", [8, 64, 4096])
+def test_weight_stationary_kernel_workgroup_count_does_not_change_the_result(wgs):
+    """igemm_ws_wgs: 8 workgroups walk 263 pixel tiles each ... one tile each; the same bits as the tile kernel's direct epilogue (same K order, one rounding)"""
+    from aldi_amd import _lib as L
+    from aldi_amd import ops
+    g = torch.Generator(device="cuda").manual_seed(5)
+    x = torch.randn(2, 50, 84, 128, device="cuda", generator=g).bfloat16()
+    w = (torch.randn(512, 1, 1, 128, device="cuda", generator=g) / 11).bfloat16()
+    r = torch.randn(2, 50, 84, 512, device="cuda", generator=g).bfloat16()
+    sc, sh = torch.rand(512, device="cuda", generator=g) + 0.5, torch.randn(512, device="cuda", generator=g)
+    kw = dict(scale=sc, shift=sh, res=r, res_mode=1, relu=True)
+    L.set_tuning("igemm_ws", 0)
+    b0 = torch.zeros(8400 * 64, dtype=torch.uint8, device="cuda")
+    y0 = ops.conv2d(x, w, bits_out=b0, **kw)
+    assert L.last_dispatch() == "igemm<bf16,128,64,4,1,pipe,tap,direct+res>"
+    L.set_tuning("igemm_ws", 1)
+    L.set_tuning("igemm_ws_min", 0)
+    L.set_tuning("igemm_ws_wgs", wgs)
+    b1 = torch.zeros(8400 * 64, dtype=torch.uint8, device="cuda")
+    y1 = ops.conv2d(x, w, bits_out=b1, **kw)
+    assert L.last_dispatch() == "igemm_ws<bf16,32,256,k128>"
+    assert torch.equal(y0, y1) and torch.equal(b0, b1)
+
+
+def test_weight_stationary_kernel_eligibility():
+    """what it does not take stays on the tile kernels: small maps (igemm_ws_min), an upsampled residual, K = 1024, channel counts that are not whole groups"""
+    from aldi_amd import _lib as L
+    from aldi_amd import ops
+    g = torch.Generator(device="cuda").manual_seed(6)
+    mk = lambda *s_: torch.randn(*s_, device="cuda", generator=g).bfloat16()
+    ops.conv2d(mk(2, 100, 168, 128), mk(512, 1, 1, 128))                    # 33 600 pixels (the teacher's res3): below igemm_ws_min = 40 000
+    assert not L.last_dispatch().startswith("igemm_ws")
+    L.set_tuning("igemm_ws_min", 4096)
+    ops.conv2d(mk(1, 40, 50, 128), mk(512, 1, 1, 128))                      # 2000 pixels
+    assert not L.last_dispatch().startswith("igemm_ws")
+    ops.conv2d(mk(2, 50, 84, 512), mk(256, 1, 1, 512), res=mk(2, 25, 42, 256), res_mode=2)
+    assert not L.last_dispatch().startswith("igemm_ws")
+    ops.conv2d(mk(2, 50, 84, 1024), mk(256, 1, 1, 1024))
+    assert not L.last_dispatch().startswith("igemm_ws")
+    ops.conv2d(mk(2, 50, 84, 128), mk(384, 1, 1, 128))
+    assert not L.last_dispatch().startswith("igemm_ws")                     # 384 channels = one and a half groups of 256
+    ops.conv2d(mk(2, 50, 84, 128), mk(512, 1, 1, 128))
+    assert L.last_dispatch() == "igemm_ws<bf16,32,256,k128>"
 
 
 HALO64_SMALL = [

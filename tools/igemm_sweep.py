@@ -21,8 +21,10 @@ for (N, H, W, Cin, Cout, k, res, relu, mask) in SHAPES:
     sc = torch.rand(Cout, device="cuda") + 0.5
     row = []
     nby = 2 * (x.numel() + w.numel() + y.numel() + (r.numel() if res else 0) + (m.numel() if mask else 0))
-    for force in [int(v) for v in os.environ.get("SWEEP_FORCE", "0,1,2,3,4").split(",")]:
-        L.reset_tuning(); L.set_tuning("igemm_force", force)
+    # a variant is igemm_force[:igemm_dbg] (igemm_dbg ablation bits of igemm_body: 4 = no epilogue, 8 = one K slab only, 16 = every DMA source inside one 4-KB window)
+    for var in os.environ.get("SWEEP_FORCE", "0,1,2,3,4").split(","):
+        force, dbg = (int(v) for v in (var + ":0").split(":")[:2])
+        L.reset_tuning(); L.set_tuning("igemm_force", force); L.set_tuning("igemm_dbg", dbg)
         run = lambda: ops.conv2d(x, w, pad=k // 2, out=y, relu=bool(relu), res=r, res_mode=res, mask=m, scale=sc, shift=sc)
         run(); which = L.last_dispatch()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -31,6 +33,6 @@ for (N, H, W, Cin, Cout, k, res, relu, mask) in SHAPES:
             run()
         e1.record(); torch.cuda.synchronize()
         us = e0.elapsed_time(e1) * 100
-        row.append("f%d %.1fus %.0fTF %.1fTB/s [%s]" % (force, us, 2.0 * N * H * W * Cin * Cout * k * k / us / 1e6, nby / us / 1e6, which.replace("igemm<bf16,", "<")))
+        row.append("f%s %.1fus %.0fTF %.1fTB/s [%s]" % (var, us, 2.0 * N * H * W * Cin * Cout * k * k / us / 1e6, nby / us / 1e6, which.replace("igemm<bf16,", "<")))
     print((N, H, W, Cin, Cout, k, "res%d" % res, "relu%d" % relu, "mask%d" % mask), " | ".join(row), flush=True)
 L.reset_tuning()
