@@ -360,6 +360,58 @@ class DeformableDETR:
         self._last = h
         return wire_losses(h, losses)
 
+    # ---- the fused student pass --------------------------------------------------------------
+    def forward_fused(self, parts: List[List[Dict]]):
+        """the micro-batches of one iteration (the sequential driver's IMS_PER_GPU-sized chunks: source, pseudo-labelled target) through ONE
+        trunk + transformer pass; the set criterion runs PER CHUNK on its slice of the outputs -- its own Hungarian assignment and its own
+        normaliser (the chunk's target count, world mean), exactly what `model(chunk)` computes -- so every kernel of the trunk and the
+        transformer sees twice the rows and the step issues half the launches.  Batch elements are independent in this detector except
+        through the padded canvas (GroupNorm statistics of the input projections run over it): the trainer fuses only chunks whose canvases
+        coincide.  -> (ctx, [weighted loss dict per chunk]); `backward_fused(ctx, scales)` differentiates sum_i scales[i] * sum(losses[i]).
+        Dropout draws come from the same stateless per-site generator, over the fused batch's shapes (another stream than two half-size passes).
+        Two halves: `forward_fused_begin` reads the images only (the labels -- the teacher's pseudo labels, produced meanwhile on another
+        stream -- are first read by `forward_fused_finish`)."""
+        return self.forward_fused_finish(self.forward_fused_begin(parts), parts)
+
+    def forward_fused_begin(self, parts: List[List[Dict]]) -> Ctx:
+        assert self.training
+        images = [b["image"] for part in parts for b in part]
+        ctr, sizes, mask = self._trunk(images, save=True)
+        logits, boxes = self.transformer.forward([ctr.cs[1], ctr.cs[2], ctr.cs[3]], mask, record=True, feats_need_grad=True)
+        if not self.aux_loss:
+            logits, boxes = logits[-1:], boxes[-1:]
+        c = Ctx()
+        c.trunk, c.sizes, c.logits, c.boxes = ctr, sizes, logits, boxes
+        self._last = None                                         # (the tape belongs to this pass: an older holder's backward must raise)
+        self._last_fused = c
+        return c
+
+    def forward_fused_finish(self, c: Ctx, parts: List[List[Dict]]):
+        per, lo = [], 0
+        for part in parts:
+            hi = lo + len(part)
+            targets = self._targets([b["instances"] for b in part], c.sizes[lo:hi])
+            self._check_labels(targets)
+            losses, gl, gb = self.criterion(c.logits[:, lo:hi].contiguous(), c.boxes[:, lo:hi].contiguous(), targets)
+            per.append(dict(lo=lo, hi=hi, losses=losses, gl=gl, gb=gb))
+            lo = hi
+        c.parts = per
+        return c, [p_["losses"] for p_ in per]
+
+    def backward_fused(self, c: Ctx, scales: List[float]):
+        if self.__dict__.get("_last_fused") is not c:
+            raise RuntimeError("DeformableDETR: backward of an earlier fused forward")
+        T = self.transformer
+        gl = T._out[0].new_zeros(T._out[0].shape).view(T.nd, -1, *c.parts[0]["gl"].shape[2:])
+        gb = T._out[1].new_zeros(T._out[1].shape).view(T.nd, -1, *c.parts[0]["gb"].shape[2:])
+        for p_, s in zip(c.parts, scales):                        # (AUX_LOSS off: only the last layer's slot is filled)
+            ld = p_["gl"].shape[0]
+            gl[T.nd - ld:, p_["lo"]:p_["hi"]] = p_["gl"] * float(s)
+            gb[T.nd - ld:, p_["lo"]:p_["hi"]] = p_["gb"] * float(s)
+        self._last_fused = None
+        gfeats = T.backward(gl, gb)
+        self.bengine.trunk_backward(c.trunk, {3: gfeats[0], 4: gfeats[1], 5: gfeats[2]})
+
     def inference(self, batched_inputs: List[Dict], do_postprocess: bool = False, pl_thresh: float = 2.0):
         """-> list[Instances] (top-100 detections of the last decoder layer, absolute xyxy in network-input pixels); the detections scoring
         above pl_thresh are also left on the device as this inference's pseudo labels (`_last_inference.pseudo`)"""

@@ -5,6 +5,7 @@ chunk by chunk (``run_model_labeled_unlabeled``, the reference's order) or as on
 (``fused_run_model``) on the HIP engine."""
 from __future__ import annotations
 
+import contextlib
 import copy
 import logging
 import os
@@ -91,6 +92,51 @@ def run_model_labeled_unlabeled(trainer, labeled_weak, labeled_strong, unlabeled
                     key = f"{k}_{row.name}"
                     v = v / accum
                     metrics[key] = metrics.get(key, 0) + (v.detach() if early else v)
+    if DEBUG and do_distill:
+        debug_dict["last_pseudolabeled"] = copy.deepcopy(unlabeled_strong)
+    return metrics
+
+
+def fused_run_model_detr(trainer, labeled_weak, labeled_strong, unlabeled_weak, unlabeled_strong):
+    """the plan of `run_model_labeled_unlabeled` for the Deformable-DETR detector with its student passes FUSED (reference schedule:
+    aldi/trainer.py:28-117 with HardDistiller, aldi/distill.py:62-84): the teacher pseudo-labels every target chunk first (the EMA tick of
+    this iteration has run; the teacher does not depend on the student's passes), then all student chunks -- source and pseudo-labelled
+    target -- go through ONE trunk + transformer pass and ONE backward (`DeformableDETR.forward_fused`: the set criterion per chunk, so
+    matching, normalisers, loss keys, the 1 / accum scaling and the early-backward semantics are the sequential driver's)."""
+    model = trainer.model
+    do_align, do_distill = _schedule_flags(trainer)
+    plan = plan_micro_steps(labeled_weak, labeled_strong, unlabeled_weak, unlabeled_strong, do_align=do_align, do_distill=do_distill)
+    bs = trainer.model_batch_size
+    accum = sum(len(part or []) for part in (labeled_weak, labeled_strong, unlabeled_weak)) // bs
+    parts, rows, pairs = [], [], []
+    for row in plan:
+        for lo in range(0, len(row.data), bs):
+            chunk = row.data[lo:lo + bs]
+            if row.teacher_data is not None:
+                pairs.append((row.teacher_data[lo:lo + bs], chunk))
+            parts.append(chunk)
+            rows.append(row)
+    # the teacher's inference (what HardDistiller.__call__ runs before the student's pass) on the second stream, beside the student's label-free
+    # forward: its pseudo labels are first read by the set criterion
+    side = _teacher_stream(model.device) if pairs else None
+    main = torch.cuda.current_stream()
+    if side is not None:
+        side.wait_stream(main)
+    with torch.cuda.stream(side) if side is not None else contextlib.nullcontext():
+        for weak, strong in pairs:
+            trainer.distiller.pseudo_labeler(weak, strong)
+    ctx = model.forward_fused_begin(parts)
+    if side is not None:
+        main.wait_stream(side)
+    ctx, losses = model.forward_fused_finish(ctx, parts)
+    model.backward_fused(ctx, [1.0 / accum] * len(parts))
+    trainer._detr_fused_steps = getattr(trainer, "_detr_fused_steps", 0) + 1
+    metrics: Dict[str, torch.Tensor] = {}
+    for row, ld in zip(rows, losses):
+        for k, v in ld.items():
+            if row.keep(k):
+                key = f"{k}_{row.name}"
+                metrics[key] = metrics.get(key, 0) + (v / accum).detach()
     if DEBUG and do_distill:
         debug_dict["last_pseudolabeled"] = copy.deepcopy(unlabeled_strong)
     return metrics
@@ -544,6 +590,36 @@ class _ALDITrainer:
             return False                                     # (the older single-chunk driver, kept for A/B runs)
         return True
 
+    def _can_fuse_detr(self, data) -> bool:
+        """the Deformable-DETR detector's fused student pass (fused_run_model_detr): plain source + hard-pseudo-label batches with an early
+        backward per chunk (every loss kept with the weight 1 / accum), the built-in HardDistiller (or none), nobody listening on the hook
+        points, and chunks that share ONE padded canvas -- the input projections' GroupNorm runs over the canvas, so a chunk padded to a
+        larger one than its own would normalise differently than `model(chunk)` does"""
+        lw, ls, uw, us = data
+        bs = self.model_batch_size
+        model = self.model
+        if not getattr(model, "detr", False) or not self.fused or hasattr(model, "module") or self.backward_at_end:
+            return False
+        if lw is not None or ls is None or len(ls) == 0 or len(ls) % bs:
+            return False
+        do_align, do_distill = _schedule_flags(self)
+        if do_align:
+            return False
+        chunks = [ls[i:i + bs] for i in range(0, len(ls), bs)]
+        if do_distill:
+            from .distill import HardDistiller
+            from .helpers import foreign_hooks
+            d = self.distiller
+            if type(d) is not HardDistiller or uw is None or us is None or len(uw) != len(us) or len(us) == 0 or len(us) % bs:
+                return False
+            if any(foreign_hooks(m.module if hasattr(m, "module") else m, []) for m in (d.student, d.teacher)):
+                return False
+            chunks += [us[i:i + bs] for i in range(0, len(us), bs)]
+        if sum(len(c_) for c_ in chunks) > 16:
+            return False
+        canvas = {(max(int(b["image"].shape[-2]) for b in c_), max(int(b["image"].shape[-1]) for b in c_)) for c_ in chunks}
+        return len({((h + 31) // 32, (w + 31) // 32) for h, w in canvas}) == 1
+
     def _defers_zero_grad(self) -> bool:
         from .engine import RCNN
         model = self.model.module if hasattr(self.model, "module") else self.model
@@ -599,6 +675,9 @@ class _ALDITrainer:
                 eng.grad_ready = None
                 if not ok:
                     self._reducer = None         # a failed step must not leave its half-used reducer to the next `after_backward`
+        if self._can_fuse_detr(data):
+            self._fused_done = True
+            return fused_run_model_detr(self, *data)
         return run_model_labeled_unlabeled(self, *data)
 
     def do_backward(self, losses, override=False):

@@ -632,7 +632,9 @@ def main():
     pl_count = tr.ema.model._last_inference.pseudo["count"].tolist()
 
     fs_stats = dict(getattr(getattr(tr._trainer, "_fused_step", None), "stats", {}))
-    if args.sequential or args.workload == "detr" or not fs_stats:
+    if args.workload == "detr" and not args.sequential and getattr(tr._trainer, "_detr_fused_steps", 0) > 0:
+        schedule = "fused source+target student pass (one trunk + transformer pass and one backward, set criterion per chunk), eager launches"
+    elif args.sequential or args.workload == "detr" or not fs_stats:
         schedule = "sequential micro-steps, eager launches"
     elif fs_stats.get("replays_b", 0) + fs_stats.get("replays_b_dp", 0) > 0:          # what the timed steps actually did
         schedule = "fused source+target student pass, two hipGraph replays per step" + (" (RCCL collectives inside the second)" if world > 1 else "")

@@ -460,3 +460,78 @@ def test_aldi_iterations_with_the_hard_distiller():
     assert not torch.equal(T.master[a:b], at_ema[a:b])
     # the pseudo labels the teacher produced at this threshold were consumed by the student step
     assert tr.ema.model._last_inference.pseudo["count"].sum().item() > 0
+
+
+def test_fused_student_pass_equals_the_sequential_schedule():
+    """SOLVER.FUSED_STEP on the Deformable-DETR detector (trainer.fused_run_model_detr / DeformableDETR.forward_fused): the source chunk and the
+    pseudo-labelled target chunk through ONE trunk + transformer pass and ONE backward, the set criterion per chunk == the reference's
+    sequential micro-steps (model(source) + backward, distiller(weak, strong) + backward): the same loss keys and values, the same gradient,
+    the same weights after the AdamW step.  Dropout off (its masks are drawn per site over the pass's shapes: another stream for the fused batch)."""
+    import os
+    import random
+    from aldi_amd.config import add_aldi_config, get_cfg
+    from aldi_amd.trainer import ALDITrainer
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = {}
+    for fused in (True, False):
+        cfg = get_cfg()
+        add_aldi_config(cfg)
+        cfg.merge_from_file(os.path.join(root, "configs", "cityscapes", "ALDI-Best-DETR-Cityscapes.yaml"))
+        cfg.merge_from_list(["MODEL.DEFORMABLE_DETR.TRANSFORMER.NUM_QUERIES", 40, "MODEL.DEFORMABLE_DETR.TRANSFORMER.ENC_LAYERS", 2,
+                             "MODEL.DEFORMABLE_DETR.TRANSFORMER.DEC_LAYERS", 2, "MODEL.DEFORMABLE_DETR.TRANSFORMER.DROPOUT", 0.0, "SEED", 3, "SOLVER.IMS_PER_BATCH", 4,
+                             "SOLVER.IMS_PER_GPU", 2, "SOLVER.WARMUP_ITERS", 0, "SYNTHETIC.HEIGHT", 160, "SYNTHETIC.WIDTH", 224, "EMA.ALPHA", 0.9,
+                             "DOMAIN_ADAPT.TEACHER.THRESHOLD", 0.011, "SOLVER.BASE_LR", 1e-4])
+        cfg.SOLVER.FUSED_STEP = fused
+        random.seed(0)
+        torch.manual_seed(1)
+        tr = ALDITrainer(cfg)
+        W = tr.model.weights
+        steps = []
+        for it in range(2):
+            tr.iter = it
+            tr.before_step()
+            tr.run_step()
+            g = W.grad.clone()
+            tr.after_step()
+            torch.cuda.synchronize()
+            steps.append(({k: float(v) for k, v in tr._trainer.last_loss_dict.items()}, g, W.master.clone()))
+        assert int(getattr(tr._trainer, "_detr_fused_steps", 0)) == (2 if fused else 0)
+        assert tr.ema.model._last_inference.pseudo["count"].sum().item() > 0
+        out[fused] = steps
+    for (la, ga, wa), (lb, gb, wb) in zip(out[True], out[False]):
+        assert list(la) == list(lb) and any(k.endswith("_distill") for k in la) and any(k.endswith("_source_strong") for k in la)
+        for k in la:
+            assert abs(la[k] - lb[k]) <= 2e-4 * max(1.0, abs(lb[k])), (k, la[k], lb[k])
+        # (fp32 sums in another order: the fused pass adds both chunks' weight gradients in one launch)
+        assert float((ga - gb).norm() / gb.norm()) <= 2e-3, float((ga - gb).norm() / gb.norm())
+        assert float((wa - wb).abs().max()) <= 1e-4 * float(wb.abs().max())
+
+
+def test_fused_student_pass_steps_aside_for_unequal_canvases_and_foreign_distillers():
+    from aldi_amd.distill import HardDistiller
+
+    class T:
+        pass
+    t = T()
+    from aldi_amd import trainer as TR
+    t.model_batch_size, t.fused, t.backward_at_end = 2, True, False
+    t.model = T(); t.model.detr = True
+    t.model.img_align = t.model.ins_align = None
+    t.distiller = HardDistiller.__new__(HardDistiller)
+    t.distiller.do_hard_cls = True
+    t.distiller.do_hard_obj = t.distiller.do_hard_rpn_reg = t.distiller.do_hard_roi_reg = False
+    t.distiller.student = t.distiller.teacher = T()
+    img = lambda h, w: {"image": torch.zeros(3, h, w, dtype=torch.uint8)}
+    can = lambda data: TR._ALDITrainer._can_fuse_detr(t, data)
+    same = [img(160, 224), img(150, 200)]
+    assert can((None, same, same, same))
+    assert not can((None, same, same, [img(160, 224), img(200, 300)]))            # the target chunk's canvas is larger than the source chunk's
+    assert not can((same, same, same, same))                                        # labeled_weak rows are not part of this schedule
+    t.backward_at_end = True
+    assert not can((None, same, same, same))
+    t.backward_at_end = False
+
+    class Mine(HardDistiller):
+        pass
+    t.distiller.__class__ = Mine
+    assert not can((None, same, same, same))
