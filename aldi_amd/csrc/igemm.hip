@@ -1240,6 +1240,7 @@ int dispatch(ConvDev& d, hipStream_t st) {
                 if (force == 10 && !g_group) return launch_halo_rs<T, 128>(d, st);
                 if (force == 11 && d.Cin % 64 == 0) return launch_halo64<256, 256, 4, 2>(d, st);
                 if (force == 13 && d.Cin % 64 == 0) return launch_halo64<128, 128, 2, 2>(d, st);
+                if (force == 15 && d.Cin % 64 == 0) return launch_halo64<256, 256, 2, 2>(d, st);
             }
             if (force == 0 || force == 3) {      // (no 64x64 halo form; 5 = the 128x16 tap form)
                 if (d.Cout <= 64) return launch<T, 128, 64, 4, 1, 4, false, true>(d, st);
@@ -1247,6 +1248,8 @@ int dispatch(ConvDev& d, hipStream_t st) {
                     // igemm_bigtile 64: 128-byte K slabs on a 256 x 256 tile (igemm_halo64.h) where the channels fill it
                     if constexpr (sizeof(T) == 2)
                         if (tn.igemm_bigtile == 64 && d.Cin % 64 == 0 && d.Cout % 256 == 0) return launch_halo64<256, 256, 4, 2>(d, st);
+                    if constexpr (sizeof(T) == 2)
+                        if (tn.igemm_bigtile == 65 && d.Cin % 64 == 0 && d.Cout % 256 == 0) return launch_halo64<256, 256, 2, 2>(d, st);
                     if (tn.igemm_bigtile == 1) return launch<T, 128, 128, 2, 2, 4, false, true>(d, st);
                     if constexpr (sizeof(T) == 2)
                         if (tn.igemm_bigtile == 10 && !g_group) return launch_halo_rs<T, 128>(d, st);

@@ -41,6 +41,9 @@ template <int V> struct KwTag { static constexpr int value = V; };
 // `direct_perm` order so that a lane's fragments 2h, 2h + 1 are 8 consecutive channels of its pixel (one 16-byte store); no LDS staging, no
 // barrier, and nothing waits for the stores -- the workgroup ends (the next one's prologue runs) while they drain.  The staged epilogue of a
 // 256 x 256 tile is 10 us per tile with one workgroup per CU and nothing beside it (16 % of the kernel).
+// (A third instantiation, 256 x 256 on FOUR waves of 128 pixels x 128 channels each -- the accumulators fill the AGPR half of a 512-register
+// budget, one wave per SIMD, 0.25 fragment reads per MFMA instead of 0.375 -- is igemm_force 15 / igemm_bigtile 65: 10-12 % SLOWER, one wave per
+// SIMD issues an MFMA every 27 clocks, two every 17.5 (profiles/r05_mfma_clock_probe.txt))
 // Two tile shapes run this body: 256 x 256 on 8 waves (64 pixels x 128 channels per wave: four 16-MFMA sub-phases per tap) for the p2-size layers,
 // and 128 x 128 on 4 waves (64 x 64 per wave: two sub-phases per tap, 68 KB of LDS: two workgroups per CU) for the mid-size ones (res3 / res4
 // conv2 and their data gradients), whose 128 x 64 tiles with 32-channel slabs spent half their loop on the L2 -> LDS path.  Both have NT / 64
@@ -53,12 +56,13 @@ __device__ __forceinline__ void igemm_halo64_body(const ConvDev& p, int bid, con
     constexpr int TN = BN / WN / 16;                       // 8 or 4 channel fragments per wave
     constexpr int CS = TN / 4;                             // channel blocks of 64 per wave = sub-phases per k-step
     constexpr int TH = 4;                                  // channel fragments per sub-phase
-    static_assert(TM == 4 && (CS == 1 || CS == 2), "64 pixels x 64 / 128 channels per wave");
+    static_assert((TM == 4 || TM == 8) && (CS == 1 || CS == 2), "64 / 128 pixels x 64 / 128 channels per wave");
     constexpr int XS = ((BM + 2) * KC + 63) / 64 * 64;     // halo slab, 16-B slots, padded to whole waves of DMA (2112)
     constexpr int WS = BN * KC;                            // one tap of weights (2048)
     constexpr int X_IT = (XS + NT - 1) / NT;               // DMA pieces per thread: slab 5 (the fifth: wave 0 only), tap 4
     constexpr int W_IT = WS / NT;
-    static_assert(X_IT == 5 && W_IT == 4 && WS % NT == 0 && XS - 4 * NT <= 64, "piece schedule below: 4 + 1 slab pieces, 4 tap pieces");
+    constexpr int XQ = (X_IT - 1) / 4, WQ = W_IT / 4;      // pieces per thread and QUARTER of a slab / a tap: the schedule below issues quarters (1: 8 waves x 256 x 256 and 4 waves x 128 x 128; 2: 4 waves x 256 x 256)
+    static_assert((X_IT - 1) % 4 == 0 && W_IT % 4 == 0 && WS % NT == 0 && XS - (X_IT - 1) * NT <= 64, "piece schedule below: four quarters + one tail piece (wave 0) per slab, four quarters per tap");
     constexpr int RING = 2 * XS + 2 * WS;
     constexpr int EPI_SLOTS = BM * (BN * 2 + 16) / 16;     // the staged epilogue's tile
     constexpr int LDS_SLOTS = RING + 8 > EPI_SLOTS ? RING + 8 : EPI_SLOTS;
@@ -76,7 +80,7 @@ __device__ __forceinline__ void igemm_halo64_body(const ConvDev& p, int bid, con
     const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(static_cast<const T*>(p.w)), 0, p.w_bytes, 0x00020000);
     constexpr unsigned OOB = 0x80000000u;
     const int wbase = __builtin_amdgcn_readfirstlane(tid & ~63);
-    const bool tail = wbase + 4 * NT < XS;                 // this wave owns the slab's fifth piece (wave 0)
+    const bool tail = wbase + (X_IT - 1) * NT < XS;        // this wave owns the slab's last, partial piece (wave 0)
     const int fr = lane & 15, fq = lane >> 4;
     const bool prio = __builtin_amdgcn_readfirstlane(p.dbg & 128) == 0;       // raised priority around every MFMA block (+3-4 %; igemm_dbg 128 turns it off for A/B runs)
     const bool no_dma = p.dbg & 32, no_mfma = p.dbg & 64;  // ablation (igemm_dbg): 32 = no DMA inside the K loop, 64 = no MFMAs, 4 = no epilogue
@@ -159,8 +163,8 @@ __device__ __forceinline__ void igemm_halo64_body(const ConvDev& p, int bid, con
     const int ngroups = 3 * (p.Cin / BK), U = 3 * ngroups;
     // ---- prologue: slab 0, tap 0, the first half of tap 1
 #pragma unroll
-    for (int it = 0; it < 4; ++it) issue_x(it, 0);
-    if (tail) issue_x(4, 0);
+    for (int it = 0; it < X_IT - 1; ++it) issue_x(it, 0);
+    if (tail) issue_x(X_IT - 1, 0);
     next_x();
     {
         const unsigned o = tap_off();
@@ -169,11 +173,11 @@ __device__ __forceinline__ void igemm_halo64_body(const ConvDev& p, int bid, con
         next_tap();
     }
     unsigned woff_a = tap_off();                            // byte offset of the tap whose pieces 2, 3 go out at points a, b of the current tap
-    issue_w(0, 1, woff_a);
-    issue_w(1, 1, woff_a);
+#pragma unroll
+    for (int q = 0; q < 2 * WQ; ++q) issue_w(q, 1, woff_a);
     next_tap();
     __builtin_amdgcn_sched_barrier(0);
-    asm volatile("s_waitcnt vmcnt(2)" ::: "memory");       // slab 0 and tap 0 have landed (mine); the barrier makes everyone's visible
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * WQ) : "memory");       // slab 0 and tap 0 have landed (mine); the barrier makes everyone's visible
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
 
@@ -191,7 +195,10 @@ __device__ __forceinline__ void igemm_halo64_body(const ConvDev& p, int bid, con
         const bool more1 = u + 1 < U, more2 = u + 2 < U;
         // ---- sub-phase 0: (h 0, channels 0-63) from x0 / wa; reads of (h 0, channels 64-127); DMA point a
         frag_read_n<TH, FR, TH * FR>(wb, w_rd[0] + woff);
-        if (more1) issue_w(2, (u + 1) & 1, woff_a);
+        if (more1) {
+#pragma unroll
+            for (int q = 0; q < WQ; ++q) issue_w(2 * WQ + q, (u + 1) & 1, woff_a);
+        }
         __builtin_amdgcn_sched_barrier(0);
         if (!no_mfma) {
             if (prio) __builtin_amdgcn_s_setprio(1);
@@ -206,7 +213,10 @@ __device__ __forceinline__ void igemm_halo64_body(const ConvDev& p, int bid, con
         // ---- sub-phase 1: (h 0, channels 64-127) from x0 / wb; reads of (h 1, channels 0-63); DMA point b
         read_x(x1, KW, KwTag<1>{}, xoff);
         frag_read_n<TH, FR, 0>(wa, w_rd[1] + woff);
-        if (more1) issue_w(3, (u + 1) & 1, woff_a);
+        if (more1) {
+#pragma unroll
+            for (int q = 0; q < WQ; ++q) issue_w(3 * WQ + q, (u + 1) & 1, woff_a);
+        }
         __builtin_amdgcn_sched_barrier(0);
         if (!no_mfma) {
             if (prio) __builtin_amdgcn_s_setprio(1);
@@ -223,8 +233,18 @@ __device__ __forceinline__ void igemm_halo64_body(const ConvDev& p, int bid, con
         int nx = 0;                                         // slab pieces issued at c (younger than everything the tap barrier waits for)
         if (kw < 2 && g + 1 < ngroups) {
             const int st = (g + 1) & 1;
-            if constexpr (kw == 0) { issue_x(0, st); issue_x(1, st); nx = 2; }
-            if constexpr (kw == 1) { issue_x(2, st); issue_x(3, st); nx = 2; if (tail) { issue_x(4, st); nx = 3; } next_x(); }
+            if constexpr (kw == 0) {
+#pragma unroll
+                for (int q = 0; q < 2 * XQ; ++q) issue_x(q, st);
+                nx = 2 * XQ;
+            }
+            if constexpr (kw == 1) {
+#pragma unroll
+                for (int q = 0; q < 2 * XQ; ++q) issue_x(2 * XQ + q, st);
+                nx = 2 * XQ;
+                if (tail) { issue_x(X_IT - 1, st); nx = 2 * XQ + 1; }
+                next_x();
+            }
         }
         __builtin_amdgcn_sched_barrier(0);
         if (!no_mfma) {
@@ -240,8 +260,8 @@ __device__ __forceinline__ void igemm_halo64_body(const ConvDev& p, int bid, con
         // ---- tap barrier: tap u + 1 (and, behind kw = 2, the next slab) has landed; every read of tap u is retired (its last fragments are in
         // registers), so the tap's stage may be overwritten
         if (no_dma || nx == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        else if (nx == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+        else if (nx == 2 * XQ) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * XQ) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * XQ + 1) : "memory");
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
         // ---- sub-phase 3: (h 1, channels 64-127) from x1 / wb; reads of tap u + 1's first sub-phase; DMA point d: pieces 0, 1 of tap u + 2
@@ -252,8 +272,8 @@ __device__ __forceinline__ void igemm_halo64_body(const ConvDev& p, int bid, con
         frag_read_n<TH, FR, 0>(wa, w_rd[0] + woff_n);
         if (more2) {
             woff_a = tap_off();
-            issue_w(0, u & 1, woff_a);
-            issue_w(1, u & 1, woff_a);
+#pragma unroll
+            for (int q = 0; q < 2 * WQ; ++q) issue_w(q, u & 1, woff_a);
             next_tap();
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -276,12 +296,25 @@ __device__ __forceinline__ void igemm_halo64_body(const ConvDev& p, int bid, con
         // ---- sub-phase 0: k-step 0 from x0 / wa; reads of k-step 1; DMA points a, b (tap u + 1's pieces 2, 3) and c (the next group's slab)
         read_x(x1, KW, KwTag<1>{}, xoff);
         frag_read_n<TH, FR, 0>(wb, w_rd[1] + woff);
-        if (more1) { issue_w(2, (u + 1) & 1, woff_a); issue_w(3, (u + 1) & 1, woff_a); }
+        if (more1) {
+#pragma unroll
+            for (int q = 0; q < 2 * WQ; ++q) issue_w(2 * WQ + q, (u + 1) & 1, woff_a);
+        }
         int nx = 0;
         if (kw < 2 && g + 1 < ngroups) {
             const int st = (g + 1) & 1;
-            if constexpr (kw == 0) { issue_x(0, st); issue_x(1, st); nx = 2; }
-            if constexpr (kw == 1) { issue_x(2, st); issue_x(3, st); nx = 2; if (tail) { issue_x(4, st); nx = 3; } next_x(); }
+            if constexpr (kw == 0) {
+#pragma unroll
+                for (int q = 0; q < 2 * XQ; ++q) issue_x(q, st);
+                nx = 2 * XQ;
+            }
+            if constexpr (kw == 1) {
+#pragma unroll
+                for (int q = 0; q < 2 * XQ; ++q) issue_x(2 * XQ + q, st);
+                nx = 2 * XQ;
+                if (tail) { issue_x(X_IT - 1, st); nx = 2 * XQ + 1; }
+                next_x();
+            }
         }
         __builtin_amdgcn_sched_barrier(0);
         if (!no_mfma) {
@@ -295,8 +328,8 @@ __device__ __forceinline__ void igemm_halo64_body(const ConvDev& p, int bid, con
         frag_wait<TM, TH>(x1, wb);
         __builtin_amdgcn_sched_barrier(0);
         if (no_dma || nx == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        else if (nx == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+        else if (nx == 2 * XQ) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * XQ) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * XQ + 1) : "memory");
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
         // ---- sub-phase 1: k-step 1 from x1 / wb; reads of tap u + 1's k-step 0; DMA point d
@@ -306,8 +339,8 @@ __device__ __forceinline__ void igemm_halo64_body(const ConvDev& p, int bid, con
         frag_read_n<TH, FR, 0>(wa, w_rd[0] + woff_n);
         if (more2) {
             woff_a = tap_off();
-            issue_w(0, u & 1, woff_a);
-            issue_w(1, u & 1, woff_a);
+#pragma unroll
+            for (int q = 0; q < 2 * WQ; ++q) issue_w(q, u & 1, woff_a);
             next_tap();
         }
         __builtin_amdgcn_sched_barrier(0);

@@ -37,7 +37,8 @@ int aldi_noop(aldi_stream_t stream);
  *   igemm_force          0 heuristics | 1 128x128 | 2 128x64 | 3 64x64 | 4 256x128 | 5 128x16 tile of aldi_conv_igemm |
  *                        6 / 7 / 8: the 128x128 / 128x64 / 64x64 tile with 128-byte K slabs (plain 1x1 / linear layers) |
  *                        9 / 10 (3x3 halo form only): 240x128 on six waves, two workgroups per CU / 256x128 role-split |
- *                        11 / 13 (3x3 halo form, bf16, Cin % 64 == 0): the 256x256 / 128x128 tile with 128-byte K slabs (igemm_halo64.h)
+ *                        11 / 13 / 15 (3x3 halo form, bf16, Cin % 64 == 0): the 256x256 / 128x128 / 256x256-on-four-waves tile with 128-byte K slabs (igemm_halo64.h);
+ *                        14 (plain 1x1, bf16): the weight-stationary persistent kernel (igemm_ws.h)
  *   igemm_k64_min        plain 1x1 / linear layers with K >= this (and K % 64 == 0) take the 64x64 128-byte-slab form (1024)
  *   igemm_group          1 = aldi_conv_igemm_group shares one launch (0: always n single launches)
  *   igemm_splitk_tile    tile of a split-K launch (aldi_conv_args.ksplit): 0 = 128x128 (128-byte K slabs), 1 = 256x128 (64-byte slabs), 3 = 256x128
@@ -56,7 +57,7 @@ int aldi_noop(aldi_stream_t stream);
  *   igemm_lean           1 = plain 1x1 / linear layers with K % 64 == 0 on those tiles run the lean K loop (running DMA offsets)
  *   igemm_halo           1 = 3x3/stride-1/pad-1 bf16 convs use the halo form (one pixel slab per three taps)
  *   igemm_bigtile_min    128x128-tile count from which a 3x3 conv takes the big halo tile (1024)
- *   igemm_bigtile        which one: 64 = 256x256 with 128-byte K slabs where Cin % 64 == 0 and Cout % 256 == 0 (default; else 256x128),
+ *   igemm_bigtile        which one: 64 = 256x256 with 128-byte K slabs where Cin % 64 == 0 and Cout % 256 == 0 (default; else 256x128), 65 = the same tile on four waves,
  *                        4 = 256x128 lockstep, 1 = 128x128, 10 = 256x128 with the two wave halves in alternating roles
  *   igemm_lintile_min, igemm_bigtile_k   tile count / K from which a 1x1 conv or linear takes the 256x128 tile (768, 768)
  *   igemm_tile           9 = never use the 256x128 tile for 1x1 / linear; 7 = that tile with 64-byte K slabs (default: 128-byte slabs where K % 64 == 0)

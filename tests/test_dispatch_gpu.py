@@ -1087,6 +1087,15 @@ def test_halo64_mid_tile_forced_on_ragged_shapes(case, kind):
     _check_direct(case, kind, "igemm<bf16,128,128,2,2,halo64%s>" % (",direct" if direct else ""), force=13)
 
 
+@pytest.mark.parametrize("kind", ["f1x", "n"])
+@pytest.mark.parametrize("case", HALO64_SMALL[:3])
+def test_halo64_four_wave_tile_forced_on_ragged_shapes(case, kind):
+    """igemm_force 15: the 256 x 256 tile on FOUR waves of 128 pixels x 128 channels (accumulators in the AGPR half of a 512-register budget, two DMA
+    pieces per quarter of a slab / tap); measured slower than the 8-wave form (one wave per SIMD issues an MFMA every 27 clocks, two every 17.5:
+    profiles/r05_mfma_clock_probe.txt) -- kept as a tested arm"""
+    _check_direct(case, kind, "igemm<bf16,256,256,2,2,halo64,direct>", force=15)
+
+
 def test_halo64_mid_knob_selects_the_tile():
     from aldi_amd import _lib as L
     from aldi_amd import ops

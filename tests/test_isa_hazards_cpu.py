@@ -42,3 +42,18 @@ _Z6kernelv:
     (rep,) = H.parse_kernels(asm).values()
     found = H.check_kernel(rep)
     assert len(found) == 1 and found[0][1] == "v_mov_b32_e32 v9, v6"
+
+
+@pytest.mark.skipif(shutil.which("hipcc") is None and not os.path.exists("/opt/rocm/bin/hipcc"), reason="needs hipcc")
+def test_hot_kernels_do_not_spill():
+    """the production instantiations of the kernels with counted `vmcnt` waits use no scratch: a spilled register is a vector-memory operation inside
+    their loops that the counts do not include (and the 256 x 256 halo tile is within 30 registers of its budget: tools/isa_hazard_check.scratch_sizes)"""
+    import isa_hazard_check as H
+    sizes = H.scratch_sizes(os.path.join(ROOT, "aldi_amd", "csrc", "igemm.hip"))
+    hot = {k: v for k, v in sizes.items() if ("igemm_halo64" in k and "Li256ELi256ELi4ELi2E" in k) or ("igemm_halo64" in k and "Li128ELi128E" in k)
+           or "igemm_ws_kernelILi4E" in k or "igemm_ws_kernelILi2E" in k or "igemm_ws_kernelILi16E" in k}
+    assert len(hot) >= 11, sorted(sizes)
+    assert not {k: v for k, v in hot.items() if v}, {k: v for k, v in hot.items() if v}
+    wg = H.scratch_sizes(os.path.join(ROOT, "aldi_amd", "csrc", "wgrad.hip"))
+    hot = {k: v for k, v in wg.items() if "big64" in k or "lean64" in k}
+    assert len(hot) >= 3 and not any(hot.values()), hot

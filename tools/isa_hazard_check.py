@@ -124,13 +124,39 @@ def check_kernel(items):
     return report
 
 
+_ASM = {}
+
+
+def assembly_of(path):
+    """the gfx950 assembly of one .hip file (compiled once per process)"""
+    if path not in _ASM:
+        with tempfile.TemporaryDirectory() as td:
+            out = os.path.join(td, "k.s")
+            subprocess.check_call([HIPCC] + FLAGS + [path, "-o", out], stderr=subprocess.DEVNULL)
+            _ASM[path] = open(out).read()
+    return _ASM[path]
+
+
+def scratch_sizes(path):
+    """-> {kernel symbol: bytes of scratch per lane} (the `.amdhsa_private_segment_fixed_size` of each kernel descriptor).  The hot kernels with
+    hand-placed counted waits sit within a few registers of their budget: a spill puts scratch loads / stores -- vector-memory operations the
+    counted `vmcnt` waits do not know about -- into their loops (the 256 x 256 halo tile ran 30 % slower when its ablation flags became
+    compile-time constants and the allocator, with more freedom, spilled 24 registers)."""
+    out, name = {}, None
+    for line in assembly_of(path).splitlines():
+        m = re.match(r"^\s*\.amdhsa_kernel\s+(\S+)", line)
+        if m:
+            name = m.group(1)
+        m = re.match(r"^\s*\.amdhsa_private_segment_fixed_size\s+(\d+)", line)
+        if m and name:
+            out[name] = int(m.group(1))
+    return out
+
+
 def check_file(path, keep=None):
-    with tempfile.TemporaryDirectory() as td:
-        out = os.path.join(td, "k.s")
-        subprocess.check_call([HIPCC] + FLAGS + [path, "-o", out], stderr=subprocess.DEVNULL)
-        text = open(out).read()
-        if keep:
-            open(keep, "w").write(text)
+    text = assembly_of(path)
+    if keep:
+        open(keep, "w").write(text)
     found = {}
     for name, items in parse_kernels(text).items():
         if not any(in_asm and ins.startswith("ds_read") for _, ins, in_asm in items if ins):
