@@ -707,7 +707,7 @@ def main():
         tj, tfile = matching_traffic() if headline else (None, None)
         PEAK = PEAK_F32_TFLOPS if args.fp32 else PEAK_BF16_TFLOPS
         kname = "igemm_kernel<float> (conv fwd + dgrad + the transformer's linear maps; f32-input MFMA)" if args.fp32 else \
-            "igemm_kernel<bf16> + igemm_group_kernel<bf16> (conv fwd + dgrad + FC)"
+            "igemm family, bf16: igemm_kernel + igemm_group_kernel + igemm_halo64 (p2-size 3x3) + igemm_ws (short-K 1x1) (conv fwd + dgrad + FC)"
         out["roofline"] = {"bound": "mfma", "kernel": kname, "achieved": round(ach, 2), "peak": PEAK,
                            "unit": "TFLOP/s", "frac": round(ach / PEAK, 4),
                            "traffic": _traffic_per_launch(tj, "igemm", ig["launches"]),
