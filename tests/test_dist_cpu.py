@@ -115,6 +115,47 @@ def test_bucketed_overlapped_allreduce_world2_gloo():
         assert same, (rank, err)
 
 
+def _worker_rs_ag8(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from aldi_amd.reduce import BucketedReducer
+    n = 400_003
+    grad = torch.randn(n, generator=torch.Generator().manual_seed(11 + rank))
+    ref = grad.clone()
+    dist.all_reduce(ref, op=dist.ReduceOp.SUM)
+    red = BucketedReducer(grad, exchange="rs_ag")
+    red.ready([(300_000, 390_001), (390_001, 390_006)])            # lengths that are not multiples of 8; a piece shorter than the world size
+    red.ready([(13, 100_000)])
+    red.ready([(100_000, 250_007), (240_000, 300_000)])
+    red.finish()
+    err = float((grad - ref).abs().max() / ref.abs().max())
+    same_everywhere = grad.clone()
+    dist.broadcast(same_everywhere, src=0)
+    q.put((rank, err, bool(torch.equal(same_everywhere, grad))))
+    dist.destroy_process_group()
+
+
+def test_bucketed_rs_ag_world8_gloo():
+    """SOLVER.GRAD_EXCHANGE "auto" picks reduce-scatter + all-gather on the 8 ranks of one node: the exchange at THAT world size -- ragged
+    pieces, a piece shorter than the world size, overlapping reports -- equals the all-reduce of the whole buffer (eight addends: fp32 sum
+    order may differ) and leaves every rank with the same bits"""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_worker_rs_ag8, args=(r, 8, port, q)) for r in range(8)]
+    for p in ps:
+        p.start()
+    res = sorted(q.get(timeout=300) for _ in range(8))
+    for p in ps:
+        p.join(timeout=60)
+    for rank, err, same in res:
+        assert err <= 2e-6 and same, (rank, err, same)
+
+
 def test_range_helpers():
     from aldi_amd.reduce import complement, merge_ranges
     assert merge_ranges([(5, 9), (0, 3), (3, 4), (8, 12), (20, 20)]) == [(0, 4), (5, 12)]
