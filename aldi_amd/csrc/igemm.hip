@@ -1269,9 +1269,10 @@ int dispatch(ConvDev& d, hipStream_t st) {
         }
     }
     // igemm_ws: the short-K 1x1 layers of the trunk (bottleneck expansions / reductions, their data gradients) on the weight-stationary persistent
-    // kernel (igemm_ws.h; its epilogue is the direct one: igemm_direct bit 1 turns it off with that); igemm_force 14 forces it wherever it is eligible
+    // kernel (igemm_ws.h; its epilogue is the direct one: igemm_direct bit 1 turns it off with that); igemm_force 14 forces it wherever it is eligible.
+    // With an upsampled residual (FPN laterals) from 4 x igemm_ws_min pixels: p2's lateral 115 -> 107 us, p3's 39.7 -> 41.0 (tools/ws_ab.py)
     if constexpr (sizeof(T) == 2)
-        if (!g_group && ws_ok(d) && (force == 14 || (force == 0 && tn.igemm_ws && (tn.igemm_direct & 1) && d.M >= tn.igemm_ws_min))) return launch_ws(d, st, tn.igemm_ws_wgs);
+        if (!g_group && ws_ok(d) && (force == 14 || (force == 0 && tn.igemm_ws && (tn.igemm_direct & 1) && d.M >= (d.res_mode == 2 ? 4L : 1L) * tn.igemm_ws_min))) return launch_ws(d, st, tn.igemm_ws_wgs);
     if (force == 5 || (force == 0 && d.Cout <= 16)) return launch<T, 128, 16, 4, 1, 4>(d, st);
     if (force == 1) return launch<T, 128, 128, 2, 2, 4>(d, st);
     if constexpr (sizeof(T) == 2) {

@@ -6,7 +6,7 @@
 // MFMAs per wave), + 6-10 us for the K loop's operands, + 10-13 us for the stores -- and the three ADD: every workgroup re-fetches its weight tile
 // (69 MB over the launch, as much as the output) and the pixel tile is fetched once per 64 output channels (8 x 17 MB), all through the same
 // per-CU vector-memory path the stores and the residual loads go through.  Here the WEIGHTS STAY IN REGISTERS:
-//   * a workgroup (4 waves) owns 64 x TN output channels for the whole launch; wave w keeps the MFMA B fragments of its 16 x TN channels for ALL of K
+//   * a workgroup (4 waves) owns 64 x TN output channels (256; 128 for K >= 256) for the whole launch; wave w keeps the MFMA B fragments of its 16 x TN channels for ALL of K
 //     in VGPRs (TN x K/32 fragments = 64-128 registers), fetched once -- the K loop reads only pixel fragments from the LDS (0.25-0.5 reads per MFMA)
 //     and there is no weight traffic after the prologue;
 //   * it is persistent: ~2 workgroups per CU walk the pixel tiles (BM = 16 x TM rows) in a strided order; the tiles of K x BM x 2 bytes arrive by
@@ -57,7 +57,8 @@ __global__ __launch_bounds__(256, 2) void igemm_ws_kernel(ConvDev p, const int n
     }
     const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(static_cast<const T*>(p.x)), 0, p.x_bytes, 0x00020000);
     const unsigned out_bytes = (unsigned)p.M * (unsigned)p.Cout * 2u;
-    const __amdgpu_buffer_rsrc_t rr = make_rsrc_uniform(p.res, out_bytes);
+    const bool res_up = p.res_mode == 2;                      // the residual is the coarser pyramid level's map, nearest-upsampled (FPN top-down sum): [N][Ho / 2][Wo / 2][Cout]
+    const __amdgpu_buffer_rsrc_t rr = make_rsrc_uniform(p.res, res_up ? out_bytes >> 2 : out_bytes);
     const __amdgpu_buffer_rsrc_t rmb = make_rsrc_uniform(p.mask_bits, out_bytes >> 4);
     const __amdgpu_buffer_rsrc_t ry = make_rsrc_uniform(p.y, out_bytes);
     const __amdgpu_buffer_rsrc_t rbo = make_rsrc_uniform(p.bits_out, out_bytes >> 4);
@@ -87,6 +88,14 @@ __global__ __launch_bounds__(256, 2) void igemm_ws_kernel(ConvDev p, const int n
     typedef short s16x2_t __attribute__((ext_vector_type(2)));
     typedef unsigned short u16x2_t __attribute__((ext_vector_type(2)));
 
+    // m / d for m < 2^24 without the 40-instruction integer division (twice per fragment row and tile here): float quotient, one correction step
+    const float inv_wo = 1.f / (float)p.Wo, inv_ho = 1.f / (float)p.Ho;
+    auto fdiv = [](unsigned m, unsigned d, float inv) {
+        unsigned q = (unsigned)(((float)m + 0.5f) * inv);
+        if (q * d > m) --q;
+        else if ((q + 1) * d <= m) ++q;
+        return q;
+    };
     // the per-pixel operands of a tile's epilogue (residual, ReLU-mask bits), straight into registers in the accumulator layout -- requested ONE TILE
     // AHEAD (two register sets, the tile loop is unrolled by two): the wait for them never includes a round trip started in the same iteration
     auto fetch_pre = [&](int k, u32x4_t (&rres)[TM][H], unsigned (&mb)[TM][H]) {
@@ -96,7 +105,14 @@ __global__ __launch_bounds__(256, 2) void igemm_ws_kernel(ConvDev p, const int n
 #pragma unroll
             for (int h = 0; h < H; ++h) {
                 const unsigned m = (unsigned)(m0 + i * 16 + fr), c = (unsigned)(n0 + h * 32 + fq * 8);
-                if (has_res) rres[i][h] = __builtin_amdgcn_raw_buffer_load_b128(rr, m * C2 + c * 2u, 0, 0);
+                if (has_res) {
+                    unsigned row = m;
+                    if (res_up) {
+                        const unsigned t_ = fdiv(m, (unsigned)p.Wo, inv_wo), wo = m - t_ * (unsigned)p.Wo, n = fdiv(t_, (unsigned)p.Ho, inv_ho), ho = t_ - n * (unsigned)p.Ho;
+                        row = (n * (unsigned)(p.Ho >> 1) + (ho >> 1)) * (unsigned)(p.Wo >> 1) + (wo >> 1);
+                    }
+                    rres[i][h] = __builtin_amdgcn_raw_buffer_load_b128(rr, m < (unsigned)p.M ? row * C2 + c * 2u : OOB, 0, 0);      // (rows >= M: out of range, zeros)
+                }
                 if (has_mb) mb[i][h] = __builtin_amdgcn_raw_buffer_load_b8(rmb, m * C8 + (c >> 3), 0, 0);
             }
     };
@@ -222,12 +238,12 @@ __global__ __launch_bounds__(256, 2) void igemm_ws_kernel(ConvDev p, const int n
 }
 
 // eligible: bf16, 1x1 / stride 1 / no padding, plain output layout, K = Cin in {64, 128, 256, 512}, whole channel groups, no full-tensor mask / fp32
-// output / upsampled residual / split-K
-inline int ws_channels(int K) { return K == 64 || K == 128 || K == 256 ? 256 : K == 512 ? 128 : 0; }      // BN of the instantiation for this K
+// output / split-K
+inline int ws_channels(int K) { return K == 64 || K == 128 ? 256 : K == 256 || K == 512 ? 128 : 0; }      // BN of the instantiation for this K
 inline bool ws_ok(const ConvDev& d) {
     const int bn = ws_channels(d.K);
     return d.KH * d.KW == 1 && d.stride == 1 && d.pad == 0 && d.K == d.Cin && bn && d.Cout % bn == 0 && d.y && !d.y_f32 && !d.mask && d.out_scale == 1 &&
-           d.res_mode != 2 && d.ksplit <= 1 && (long)d.M * d.Cout * 2 < (1L << 31);
+           d.ksplit <= 1 && (long)d.M * d.Cout * 2 < (1L << 31);
 }
 int launch_ws(const ConvDev& d, hipStream_t st, int wgs) {
     const int bn = ws_channels(d.K), ncg = d.Cout / bn;
@@ -240,7 +256,7 @@ int launch_ws(const ConvDev& d, hipStream_t st, int wgs) {
     const dim3 grid(sets * 8 * ncg), block(256);
     if (d.K == 64) hipLaunchKernelGGL((igemm_ws_kernel<2, 2, 4>), grid, block, 0, st, d, n_mtiles, ncg);
     else if (d.K == 128) hipLaunchKernelGGL((igemm_ws_kernel<4, 2, 4>), grid, block, 0, st, d, n_mtiles, ncg);
-    else if (d.K == 256) hipLaunchKernelGGL((igemm_ws_kernel<8, 2, 4>), grid, block, 0, st, d, n_mtiles, ncg);
+    else if (d.K == 256) hipLaunchKernelGGL((igemm_ws_kernel<8, 2, 2>), grid, block, 0, st, d, n_mtiles, ncg);
     else hipLaunchKernelGGL((igemm_ws_kernel<16, 1, 2>), grid, block, 0, st, d, n_mtiles, ncg);
     ALDI_CHECK_LAUNCH();
     char name[112];

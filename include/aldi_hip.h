@@ -51,7 +51,7 @@ int aldi_noop(aldi_stream_t stream);
  *                        plain layout with Cout % 8 == 0, Cout >= 64, no fp32 output / `mask` tensor / split-K / scatter
  *   igemm_halo64_mid     mid-size 3x3 layers with at least this many 128x128 tiles take the 128x128 tile with 128-byte K slabs (0 = never, the
  *                        default: measured 10-20 % slower than the 128x64 tiles on res3 / res4 conv2 -- those layers are bound by workgroup count)
- *   igemm_ws             1 = plain 1x1 bf16 layers with K = Cin in {64, 128, 256, 512}, whole groups of 256 (K = 512: 128) output channels and at least
+ *   igemm_ws             1 = plain 1x1 bf16 layers with K = Cin in {64, 128, 256, 512}, whole groups of 256 (K >= 256: 128) output channels and at least
  *                        igemm_ws_min (40000: res3 / p2-size maps of the student; measured equal or slower below) pixels run the weight-stationary persistent kernel (igemm_ws.h: weights in registers, pixel tiles streamed
  *                        through a 3-stage LDS ring, epilogue from the accumulators); igemm_ws_wgs (512) = its workgroup count; igemm_force 14 forces it
  *   igemm_lean           1 = plain 1x1 / linear layers with K % 64 == 0 on those tiles run the lean K loop (running DMA offsets)

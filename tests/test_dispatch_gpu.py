@@ -1009,13 +1009,15 @@ WS_SMALL = [
 ]
 
 
-@pytest.mark.parametrize("kind", ["f3", "f1", "f1x", "sc", "b", "n", "d1", "d3"])
-@pytest.mark.parametrize("case", WS_SMALL)
+@pytest.mark.parametrize("kind", ["f3", "f1", "f1x", "sc", "b", "n", "d1", "d3", "up"])
+@pytest.mark.parametrize("case", WS_SMALL + [(2, 26, 42, 256, 256, 1, 1, 0), (3, 6, 10, 512, 128, 1, 1, 0)])
 def test_weight_stationary_kernel_forced_on_ragged_shapes(case, kind):
+    if kind == "up" and (case[1] % 2 or case[2] % 2):
+        pytest.skip("the upsampled residual needs even output sizes")
     """igemm_ws.h (weights in registers, pixel tiles through a 3-stage LDS ring, persistent workgroups) with every epilogue operand set of the
     bottleneck layers: more pixel-tile sequences than tiles, ragged last tiles, one to three channel groups"""
     K = case[3]
-    _check_direct(case, kind, "igemm_ws<bf16,%d,%d,k%d>" % (32 if K <= 256 else 16, 128 if K == 512 else 256, K), force=14)
+    _check_direct(case, kind, "igemm_ws<bf16,%d,%d,k%d>" % (32 if K <= 256 else 16, 128 if K >= 256 else 256, K), force=14)
 
 
 @pytest.mark.parametrize("wgs", [8, 64, 4096])
@@ -1054,7 +1056,11 @@ def test_weight_stationary_kernel_eligibility():
     ops.conv2d(mk(1, 40, 50, 128), mk(512, 1, 1, 128))                      # 2000 pixels
     assert not L.last_dispatch().startswith("igemm_ws")
     ops.conv2d(mk(2, 50, 84, 512), mk(256, 1, 1, 512), res=mk(2, 25, 42, 256), res_mode=2)
-    assert not L.last_dispatch().startswith("igemm_ws")
+    assert not L.last_dispatch().startswith("igemm_ws")                     # an FPN lateral + the upsampled top-down map: from 4 x igemm_ws_min pixels
+    ops.conv2d(mk(2, 100, 168, 256), mk(256, 1, 1, 256), res=mk(2, 50, 84, 256), res_mode=2)
+    assert L.last_dispatch() == "igemm_ws<bf16,32,128,k256>"
+    ops.conv2d(mk(2, 50, 84, 512), mk(256, 1, 1, 512), want_f32=True)
+    assert not L.last_dispatch().startswith("igemm_ws")                     # fp32 output
     ops.conv2d(mk(2, 50, 84, 1024), mk(256, 1, 1, 1024))
     assert not L.last_dispatch().startswith("igemm_ws")
     ops.conv2d(mk(2, 50, 84, 128), mk(384, 1, 1, 128))

@@ -27,7 +27,7 @@ for (N, H, W, Cin, Cout, res, relu, mbits, bout, scale) in SHAPES:
     M = N * H * W
     x = torch.randn(N, H, W, Cin, device="cuda", generator=g).bfloat16()
     w = (torch.randn(Cout, 1, 1, Cin, device="cuda", generator=g) / Cin ** 0.5).bfloat16()
-    r = torch.randn(N, H, W, Cout, device="cuda", generator=g).bfloat16() if res else None
+    r = torch.randn(N, H // (2 if res == 2 else 1), W // (2 if res == 2 else 1), Cout, device="cuda", generator=g).bfloat16() if res else None      # (res 2: the coarser level's map, upsampled)
     mb = torch.randint(0, 256, (M * Cout // 8,), device="cuda", generator=g, dtype=torch.int32).to(torch.uint8) if mbits else None
     sc = (torch.rand(Cout, device="cuda", generator=g) + 0.5) if scale else None
     sh = torch.randn(Cout, device="cuda", generator=g) * 0.1 if scale else None
