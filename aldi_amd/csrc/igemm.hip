@@ -1099,7 +1099,7 @@ __global__ __launch_bounds__(WM* WN * 64, (min_waves_per_simd<BM, WM * WN * 64, 
 
 static thread_local const ConvGroup* g_group = nullptr;      // set by aldi_conv_igemm_group around dispatch<T>()
 
-template <int BM, int BN, int WM, int WN, bool DIRECT>
+template <int BM, int BN, int WM, int WN, bool DIRECT, bool ILV = false>
 __global__ __launch_bounds__(WM* WN * 64) void igemm_halo64_group_kernel(ConvGroup G) {
     const int bid = (int)blockIdx.x;
     int i = 0;
@@ -1108,7 +1108,7 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_halo64_group_kernel(ConvGro
     i = __builtin_amdgcn_readfirstlane(i);
     const int local = bid - G.wg_begin[i];
     if (local >= G.nmt[i] * G.nnt[i]) return;  // alignment padding
-    igemm_halo64_body<BM, BN, WM, WN, DIRECT>(G.p[i], local, G.nmt[i], G.nnt[i]);
+    igemm_halo64_body<BM, BN, WM, WN, DIRECT, ILV>(G.p[i], local, G.nmt[i], G.nnt[i]);
 }
 
 // the 128-byte-slab halo kernel (igemm_halo64.h), alone or over the problems of a group; the direct epilogue (igemm_direct bit 8) when every
@@ -1121,6 +1121,9 @@ int launch_halo64(const ConvDev& d, hipStream_t st) {
     char name[96];
     constexpr int NT = WM * WN * 64;
     bool direct = (aldi_tuning().igemm_direct & 8) != 0;
+    // igemm_halo_ilv: the interleaved K loop (reads / DMA pieces between the MFMAs of a sub-phase; igemm_halo64.h) -- the 8-wave 256 x 256 tile
+    constexpr bool HAS_ILV = BM == 256 && BN == 256 && WM == 4 && WN == 2;
+    const bool ilv = HAS_ILV && aldi_tuning().igemm_halo_ilv != 0;
     if (g_group) {
         ConvGroup G = *g_group;
         int wg = 0;
@@ -1132,17 +1135,27 @@ int launch_halo64(const ConvDev& d, hipStream_t st) {
             direct = direct && halo64_direct_ok(G.p[i]);
         }
         for (int i = G.n; i <= kMaxConvGroup; ++i) G.wg_begin[i] = wg;
-        if (direct) hipLaunchKernelGGL((igemm_halo64_group_kernel<BM, BN, WM, WN, true>), dim3(wg), dim3(NT), 0, st, G);
-        else hipLaunchKernelGGL((igemm_halo64_group_kernel<BM, BN, WM, WN, false>), dim3(wg), dim3(NT), 0, st, G);
+        if (ilv) {
+            if (direct) hipLaunchKernelGGL((igemm_halo64_group_kernel<BM, BN, WM, WN, true, HAS_ILV>), dim3(wg), dim3(NT), 0, st, G);
+            else hipLaunchKernelGGL((igemm_halo64_group_kernel<BM, BN, WM, WN, false, HAS_ILV>), dim3(wg), dim3(NT), 0, st, G);
+        } else {
+            if (direct) hipLaunchKernelGGL((igemm_halo64_group_kernel<BM, BN, WM, WN, true>), dim3(wg), dim3(NT), 0, st, G);
+            else hipLaunchKernelGGL((igemm_halo64_group_kernel<BM, BN, WM, WN, false>), dim3(wg), dim3(NT), 0, st, G);
+        }
         ALDI_CHECK_LAUNCH();
-        snprintf(name, sizeof(name), "igemm_group%d<bf16,%d,%d,%d,%d,halo64%s>", G.n, BM, BN, WM, WN, direct ? ",direct" : "");
+        snprintf(name, sizeof(name), "igemm_group%d<bf16,%d,%d,%d,%d,halo64%s%s>", G.n, BM, BN, WM, WN, direct ? ",direct" : "", ilv ? ",ilv" : "");
     } else {
         direct = direct && halo64_direct_ok(d);
         dim3 grid(cdiv(d.M, BM), cdiv(d.Cout, BN));
-        if (direct) hipLaunchKernelGGL((igemm_halo64_kernel<BM, BN, WM, WN, true>), grid, dim3(NT), 0, st, d);
-        else hipLaunchKernelGGL((igemm_halo64_kernel<BM, BN, WM, WN, false>), grid, dim3(NT), 0, st, d);
+        if (ilv) {
+            if (direct) hipLaunchKernelGGL((igemm_halo64_kernel<BM, BN, WM, WN, true, HAS_ILV>), grid, dim3(NT), 0, st, d);
+            else hipLaunchKernelGGL((igemm_halo64_kernel<BM, BN, WM, WN, false, HAS_ILV>), grid, dim3(NT), 0, st, d);
+        } else {
+            if (direct) hipLaunchKernelGGL((igemm_halo64_kernel<BM, BN, WM, WN, true>), grid, dim3(NT), 0, st, d);
+            else hipLaunchKernelGGL((igemm_halo64_kernel<BM, BN, WM, WN, false>), grid, dim3(NT), 0, st, d);
+        }
         ALDI_CHECK_LAUNCH();
-        snprintf(name, sizeof(name), "igemm<bf16,%d,%d,%d,%d,halo64%s>", BM, BN, WM, WN, direct ? ",direct" : "");
+        snprintf(name, sizeof(name), "igemm<bf16,%d,%d,%d,%d,halo64%s%s>", BM, BN, WM, WN, direct ? ",direct" : "", ilv ? ",ilv" : "");
     }
     aldi_note_dispatch(name);
     return ALDI_OK;

@@ -37,6 +37,27 @@ __device__ __forceinline__ void frag_wait1(u32x4_t* a) {
 
 template <int V> struct KwTag { static constexpr int value = V; };
 
+// ---- the INTERLEAVED K loop (r06).  tools/probes/mfma_issue_probe.hip: ONE wave feeds 0.98 of a SIMD's matrix pipe when its fragment reads sit BETWEEN
+// its MFMAs (16.3 clocks per 16x16x32 MFMA against a 16-clock pipe), and an LDS-DMA piece costs ~60 clocks of issue among MFMAs -- but the lockstep
+// loop below issues a sub-phase's reads and DMA pieces IN FRONT of its 16 MFMAs, in both waves of a SIMD at the same time: ~270 clocks per sub-phase
+// with an idle pipe (3 120 clocks per tap against 2 048 of MFMA work; profiles/r05_halo_ablation.txt).  r05 tried to move them behind the first MFMAs
+// with the builtin and got accumulator copies + spills (hipcc re-allocates the results of `__builtin_amdgcn_mfma_*` when other instructions sit
+// between them -- the same pathology as its own MFMA probe loop: v_accvgpr_mov chains).  Here every MFMA is an `asm volatile` with the accumulator
+// tied in place ("+v"), the reads already were: volatile statements keep their source order, so the stream is what is written -- MFMA, read, MFMA,
+// read, ..., MFMA, DMA piece, MFMA ... -- and nothing is copied.  The compiler's hazard recogniser does not see MFMAs inside asm: no accumulator is
+// touched twice within 16 MFMAs (the block order guarantees it), and the loop is followed by 32 wait states before the epilogue reads them.
+__device__ __forceinline__ void mma_ip(f32x4_t& c, const u32x4_t& a, const u32x4_t& b) {
+    asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
+}
+template <int NM, int I = 0, typename FM, typename FF>
+__device__ __forceinline__ void interleave(FM&& mma, FF&& fill) {             // MFMA 0, filler 0, MFMA 1, filler 1, ...
+    if constexpr (I < NM) {
+        mma(KwTag<I>{});
+        fill(KwTag<I>{});
+        interleave<NM, I + 1>(mma, fill);
+    }
+}
+
 // DIRECT: the epilogue stores straight from the accumulators (bf16, plain layout, scale / shift / ReLU only): the weight rows are fetched in
 // `direct_perm` order so that a lane's fragments 2h, 2h + 1 are 8 consecutive channels of its pixel (one 16-byte store); no LDS staging, no
 // barrier, and nothing waits for the stores -- the workgroup ends (the next one's prologue runs) while they drain.  The staged epilogue of a
@@ -48,7 +69,7 @@ template <int V> struct KwTag { static constexpr int value = V; };
 // and 128 x 128 on 4 waves (64 x 64 per wave: two sub-phases per tap, 68 KB of LDS: two workgroups per CU) for the mid-size ones (res3 / res4
 // conv2 and their data gradients), whose 128 x 64 tiles with 32-channel slabs spent half their loop on the L2 -> LDS path.  Both have NT / 64
 // threads per 16-byte slot of a tap and of the slab, i.e. the same piece schedule (4 + 1 slab pieces, 4 tap pieces per thread).
-template <int BM, int BN, int WM, int WN, bool DIRECT>
+template <int BM, int BN, int WM, int WN, bool DIRECT, bool ILV = false>
 __device__ __forceinline__ void igemm_halo64_body(const ConvDev& p, int bid, const int nmt, const int nnt) {
     typedef bf16_t T;
     constexpr int NT = WM * WN * 64, KC = 8, EP = 8, BK = 64;
@@ -82,7 +103,13 @@ __device__ __forceinline__ void igemm_halo64_body(const ConvDev& p, int bid, con
     const int wbase = __builtin_amdgcn_readfirstlane(tid & ~63);
     const bool tail = wbase + (X_IT - 1) * NT < XS;        // this wave owns the slab's last, partial piece (wave 0)
     const int fr = lane & 15, fq = lane >> 4;
-    const bool prio = __builtin_amdgcn_readfirstlane(p.dbg & 128) == 0;       // raised priority around every MFMA block (+3-4 %; igemm_dbg 128 turns it off for A/B runs)
+    // raised priority around every MFMA block (+3-4 %; igemm_dbg 128 turns it off for A/B runs).  ASYMMETRIC since r06 (igemm_dbg 256 = the old
+    // symmetric level 1 for A/B runs; 512 = the halves swapped): waves w and w + NT / 128 share a SIMD; with equal priority their MFMA blocks interleave
+    // instruction by instruction, both finish together and both then issue their fragment reads / DMA while the matrix pipe idles (r05: 28 % of a tap).
+    // With the first half at level 2 its block runs alone and the second half's block fills the pipe while the first half reads: the two waves of a
+    // SIMD drift half a sub-phase apart after every tap barrier (tools/probes/mfma_issue_probe.hip: one wave alone feeds 0.98 of the pipe).
+    const int plev = __builtin_amdgcn_readfirstlane((p.dbg & 128) ? 0 : (p.dbg & 256) ? 1 : ((wave < WM * WN / 2) != ((p.dbg & 512) != 0)) ? 2 : 1);
+    const bool prio = plev != 0, prio_hi = plev == 2;
     const bool no_dma = p.dbg & 32, no_mfma = p.dbg & 64;  // ablation (igemm_dbg): 32 = no DMA inside the K loop, 64 = no MFMAs, 4 = no epilogue
 
     f32x4_t acc[TM][TN];
@@ -201,7 +228,7 @@ __device__ __forceinline__ void igemm_halo64_body(const ConvDev& p, int bid, con
         }
         __builtin_amdgcn_sched_barrier(0);
         if (!no_mfma) {
-            if (prio) __builtin_amdgcn_s_setprio(1);
+            if (prio) { if (prio_hi) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(1); }
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -219,7 +246,7 @@ __device__ __forceinline__ void igemm_halo64_body(const ConvDev& p, int bid, con
         }
         __builtin_amdgcn_sched_barrier(0);
         if (!no_mfma) {
-            if (prio) __builtin_amdgcn_s_setprio(1);
+            if (prio) { if (prio_hi) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(1); }
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -248,7 +275,7 @@ __device__ __forceinline__ void igemm_halo64_body(const ConvDev& p, int bid, con
         }
         __builtin_amdgcn_sched_barrier(0);
         if (!no_mfma) {
-            if (prio) __builtin_amdgcn_s_setprio(1);
+            if (prio) { if (prio_hi) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(1); }
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -278,7 +305,7 @@ __device__ __forceinline__ void igemm_halo64_body(const ConvDev& p, int bid, con
         }
         __builtin_amdgcn_sched_barrier(0);
         if (!no_mfma) {
-            if (prio) __builtin_amdgcn_s_setprio(1);
+            if (prio) { if (prio_hi) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(1); }
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -288,6 +315,118 @@ __device__ __forceinline__ void igemm_halo64_body(const ConvDev& p, int bid, con
         frag_wait<TM, TH>(x0, wa);
         __builtin_amdgcn_sched_barrier(0);
         xoff = xoff_n; woff = woff_n;
+    };
+    // ---- the same tap with the reads / DMA pieces of every sub-phase BETWEEN its MFMAs (ILV; see mma_ip above).  Same DMA order, same counted waits,
+    // same accumulation order per output element as tap4: bit-identical results.
+    auto x_addr = [&](unsigned* xa, auto KW, auto H, unsigned xo) {
+        constexpr int kw = decltype(KW)::value, h = decltype(H)::value;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            if constexpr (kw == 1) xa[i] = x_rd[1][h] + xo;
+            else xa[i] = (kw == 0 ? edge_l[i] : edge_r[i]) ? zaddr[i] : x_rd[kw][h] + xo;
+        }
+    };
+    auto tap4i = [&](auto KW, const int g, const int u) {
+        constexpr int kw = decltype(KW)::value;
+        constexpr int NM = TM * TH;
+        static_assert(TM + TH + 1 + 2 * 2 * WQ <= NM && TH + 1 + 2 * (2 * XQ + 1) <= NM, "the fillers of a sub-phase fit between its MFMAs");
+        const bool more1 = u + 1 < U, more2 = u + 2 < U;
+        // ---- sub-phase 0: (h 0, channels 0-63) from x0 / wa; reads of (h 0, channels 64-127); DMA point a
+        {
+            const unsigned wr = w_rd[0] + woff;
+            if (prio) { if (prio_hi) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(1); }
+            interleave<NM>([&](auto M) { constexpr int m = decltype(M)::value; mma_ip(acc[m / TH][m % TH], wa[m % TH], x0[m / TH]); },
+                           [&](auto M) {
+                               constexpr int m = decltype(M)::value;
+                               if constexpr (m < TH) wb[m] = frag_read<(TH + m) * FR>(wr);
+                               if constexpr (m == TH + 1) {
+                                   if (more1) {
+#pragma unroll
+                                       for (int q = 0; q < WQ; ++q) issue_w(2 * WQ + q, (u + 1) & 1, woff_a);
+                                   }
+                               }
+                           });
+            if (prio) __builtin_amdgcn_s_setprio(0);
+            frag_wait1<TH>(wb);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // ---- sub-phase 1: (h 0, channels 64-127) from x0 / wb; reads of (h 1, channels 0-63); DMA point b
+        {
+            unsigned xa[TM];
+            x_addr(xa, KW, KwTag<1>{}, xoff);
+            const unsigned wr = w_rd[1] + woff;
+            if (prio) { if (prio_hi) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(1); }
+            interleave<NM>([&](auto M) { constexpr int m = decltype(M)::value; mma_ip(acc[m / TH][TH + m % TH], wb[m % TH], x0[m / TH]); },
+                           [&](auto M) {
+                               constexpr int m = decltype(M)::value;
+                               if constexpr (m < TM) x1[m] = frag_read<m * FR>(xa[m]);
+                               else if constexpr (m < TM + TH) wa[m - TM] = frag_read<(m - TM) * FR>(wr);
+                               if constexpr (m == TM + TH + 1) {
+                                   if (more1) {
+#pragma unroll
+                                       for (int q = 0; q < WQ; ++q) issue_w(3 * WQ + q, (u + 1) & 1, woff_a);
+                                   }
+                               }
+                           });
+            if (prio) __builtin_amdgcn_s_setprio(0);
+            frag_wait<TM, TH>(x1, wa);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // ---- sub-phase 2: (h 1, channels 0-63) from x1 / wa; reads of (h 1, channels 64-127); DMA point c: the NEXT group's slab
+        const bool slab = kw < 2 && g + 1 < ngroups;
+        const int sst = (g + 1) & 1;
+        int nx = 0;
+        if (slab) nx = (kw == 1 && tail) ? 2 * XQ + 1 : 2 * XQ;
+        {
+            const unsigned wr = w_rd[1] + woff;
+            if (prio) { if (prio_hi) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(1); }
+            interleave<NM>([&](auto M) { constexpr int m = decltype(M)::value; mma_ip(acc[m / TH][m % TH], wa[m % TH], x1[m / TH]); },
+                           [&](auto M) {
+                               constexpr int m = decltype(M)::value;
+                               if constexpr (m < TH) wb[m] = frag_read<(TH + m) * FR>(wr);
+                               if constexpr (kw < 2 && m > TH && (m - TH) % 2 == 1 && (m - TH) / 2 <= 2 * XQ) {
+                                   constexpr int q = (m - TH) / 2;                 // slab piece q of this tap's half (the last slot: the tail piece)
+                                   if (slab) {
+                                       if constexpr (q < 2 * XQ) issue_x(kw * 2 * XQ + q, sst);
+                                       else if constexpr (kw == 1) { if (tail) issue_x(X_IT - 1, sst); }
+                                   }
+                               }
+                           });
+            if (prio) __builtin_amdgcn_s_setprio(0);
+            if constexpr (kw == 1) { if (slab) next_x(); }
+            frag_wait1<TH>(wb);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // ---- tap barrier (as in tap4)
+        if (no_dma || nx == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else if (nx == 2 * XQ) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * XQ) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * XQ + 1) : "memory");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- sub-phase 3: (h 1, channels 64-127) from x1 / wb; reads of tap u + 1's first sub-phase; DMA point d: pieces 0, 1 of tap u + 2
+        {
+            constexpr int kw_n = kw == 2 ? 0 : kw + 1;
+            const unsigned xoff_n = kw == 2 ? xoff ^ XSB : xoff, woff_n = woff ^ WSB;
+            unsigned xa[TM];
+            x_addr(xa, KwTag<kw_n>{}, KwTag<0>{}, xoff_n);
+            const unsigned wr = w_rd[0] + woff_n;
+            if (more2) woff_a = tap_off();
+            if (prio) { if (prio_hi) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(1); }
+            interleave<NM>([&](auto M) { constexpr int m = decltype(M)::value; mma_ip(acc[m / TH][TH + m % TH], wb[m % TH], x1[m / TH]); },
+                           [&](auto M) {
+                               constexpr int m = decltype(M)::value;
+                               if constexpr (m < TM) x0[m] = frag_read<m * FR>(xa[m]);
+                               else if constexpr (m < TM + TH) wa[m - TM] = frag_read<(m - TM) * FR>(wr);
+                               if constexpr (m > TM + TH && (m - TM - TH) % 2 == 1 && (m - TM - TH) / 2 < 2 * WQ) {
+                                   if (more2) issue_w((m - TM - TH) / 2, u & 1, woff_a);
+                               }
+                           });
+            if (prio) __builtin_amdgcn_s_setprio(0);
+            if (more2) next_tap();
+            frag_wait<TM, TH>(x0, wa);
+            __builtin_amdgcn_sched_barrier(0);
+            xoff = xoff_n; woff = woff_n;
+        }
     };
     // the same for 64 channels per wave (CS = 1): two sub-phases per tap, one per 32-channel k-step
     auto tap2 = [&](auto KW, const int g, const int u) {
@@ -318,7 +457,7 @@ __device__ __forceinline__ void igemm_halo64_body(const ConvDev& p, int bid, con
         }
         __builtin_amdgcn_sched_barrier(0);
         if (!no_mfma) {
-            if (prio) __builtin_amdgcn_s_setprio(1);
+            if (prio) { if (prio_hi) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(1); }
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -345,7 +484,7 @@ __device__ __forceinline__ void igemm_halo64_body(const ConvDev& p, int bid, con
         }
         __builtin_amdgcn_sched_barrier(0);
         if (!no_mfma) {
-            if (prio) __builtin_amdgcn_s_setprio(1);
+            if (prio) { if (prio_hi) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(1); }
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -357,13 +496,16 @@ __device__ __forceinline__ void igemm_halo64_body(const ConvDev& p, int bid, con
         xoff = xoff_n; woff = woff_n;
     };
     auto tap = [&](auto KW, const int g, const int u) {
-        if constexpr (CS == 2) tap4(KW, g, u); else tap2(KW, g, u);
+        if constexpr (CS == 2 && ILV) tap4i(KW, g, u);
+        else if constexpr (CS == 2) tap4(KW, g, u);
+        else tap2(KW, g, u);
     };
     for (int g = 0; g < ngroups; ++g) {
         tap(KwTag<0>{}, g, 3 * g);
         tap(KwTag<1>{}, g, 3 * g + 1);
         tap(KwTag<2>{}, g, 3 * g + 2);
     }
+    if constexpr (ILV) asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");       // the last asm MFMAs have written their accumulators before anything reads them
     if constexpr (DIRECT) {
         if (p.dbg & 4) return;
         // per-channel operands of this lane's 8 channels of every 32-channel block (the fragment registers are dead: room for them)
@@ -420,7 +562,7 @@ __device__ __forceinline__ void igemm_halo64_body(const ConvDev& p, int bid, con
     igemm_epilogue<T, BM, BN, WM, WN, LDS_SLOTS * 16>(p, acc, m0, n0, reinterpret_cast<unsigned char*>(&lds_all[0]));
 }
 
-template <int BM, int BN, int WM, int WN, bool DIRECT>
+template <int BM, int BN, int WM, int WN, bool DIRECT, bool ILV = false>
 __global__ __launch_bounds__(WM* WN * 64) void igemm_halo64_kernel(ConvDev p) {
-    igemm_halo64_body<BM, BN, WM, WN, DIRECT>(p, (int)(blockIdx.y * gridDim.x + blockIdx.x), (int)gridDim.x, (int)gridDim.y);
+    igemm_halo64_body<BM, BN, WM, WN, DIRECT, ILV>(p, (int)(blockIdx.y * gridDim.x + blockIdx.x), (int)gridDim.x, (int)gridDim.y);
 }

@@ -1030,7 +1030,10 @@ extern "C" int aldi_rpn_proposals(const aldi_rpn_geom* gm, float* const* head, c
         int max_nel = 0;
         for (int l = 0; l < g.nl; ++l) max_nel = g.H[l] * g.W[l] * g.A > max_nel ? g.H[l] * g.W[l] * g.A : max_nel;
         dim3 grid(cdiv(max_nel, kTopkChunk), g.nl, N);
-        if (aldi_tuning().rpn_topk_fused) {
+        // the fused form's barriers are among the grid.x workgroups of ONE (level, image) group, consecutive in dispatch order; they are plain
+        // launches, so co-residency of a group is assumed, not checked: keep a group far below what the chip holds of 1024-thread workgroups
+        // (256 CUs x 1-2) and take the five-launch path beyond that (the spin is bounded and flags error bit 8 either way)
+        if (aldi_tuning().rpn_topk_fused && grid.x <= 64) {
             hipLaunchKernelGGL(topk_fused_kernel, grid, dim3(1024), 0, st, g, okeys, pre_nms_topk, hists, gsync, fill, cand, cand_count, (const float4*)anchors, img_hw,
                                boxes, scores, valid, err_flag);
             ALDI_CHECK_LAUNCH();

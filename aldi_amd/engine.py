@@ -361,6 +361,9 @@ def raise_on_error(code: int, who: str = "engine"):
     if code & 2:
         raise RuntimeError(f"{who}: sparse RPN-head backward: more active pixels than (2 * BATCH_SIZE_PER_IMAGE + 4 * positives) per image; "
                            "the excess was dropped, gradients of this step are wrong")
+    if code & 8:
+        raise RuntimeError(f"{who}: RPN top-k: the group barrier of `topk_fused_kernel` timed out (its workgroups were not co-resident); the candidates "
+                           "of this step are wrong.  Set ALDI_RPN_TOPK_FUSED=0 for the five-launch path")
     if code:
         raise RuntimeError(f"{who}: device error word {code}")
 

@@ -897,6 +897,12 @@ class FusedStep:
         for k_, v_ in (("host_us_issue_a", t1 - t0), ("host_us_wait_a", t2 - t1), ("host_us_draws", t3 - t2), ("host_us_issue_b", t4 - t3)):
             self.stats[k_] = round(0.8 * self.stats.get(k_, (v_ * 1e6)) + 0.2 * v_ * 1e6, 1)       # running mean, microseconds
         self.steps_done += 1
+        # what was staged for THIS step must not be picked up by a later eager pass (a replayed step never runs trunk(), which consumes the mark;
+        # the sizes buffers are keyed by an address another batch may be staged at later): ADVICE r05
+        for e_ in (eng, self.teng):
+            if e_ is not None:
+                e_.__dict__.pop("_ds_fresh", None)
+                e_.__dict__.pop("_hw_dev", None)
         if do_distill:
             teacher._last_inference = tc
             labels_ = [DevicePseudoLabels(tc.sizes[i], tc.pseudo, i) for i in range(len(unlabeled_weak))]

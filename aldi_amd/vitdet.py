@@ -10,6 +10,7 @@ from __future__ import annotations
 from typing import List, Optional
 
 import torch
+from types import SimpleNamespace
 
 from . import ops
 from . import vit_ops as V
@@ -71,16 +72,20 @@ def _refresh(eng, ds):
     if ds is None:
         eng._ds_dev = None
     else:
-        ring = eng.__dict__.get("_ds_ring")
-        if ring is None or ring[0][0].shape != ds.shape:
+        # one (pinned ring, device buffer) pair PER SHAPE, never freed: a hipGraph recorded for another batch size keeps reading the buffer it was
+        # recorded with, so a change of N must not reallocate it
+        bufs = eng.__dict__.setdefault("_ds_bufs", {})
+        ent = bufs.get(tuple(ds.shape))
+        if ent is None:
             # two pinned slots, each guarded by the event of its last upload: the host may be a step ahead of the GPU, and the copy out of a slot
             # must have run before the next draw overwrites it
             cuda = torch.cuda.is_available()
-            ring = eng._ds_ring = [[torch.empty_like(ds).pin_memory() if cuda else torch.empty_like(ds), None] for _ in range(2)]
-            eng._ds_dev = torch.empty(ds.shape, dtype=ds.dtype, device=eng.device)
-            eng._ds_slot = 0
-        slot = ring[eng._ds_slot]
-        eng._ds_slot ^= 1
+            ent = bufs[tuple(ds.shape)] = SimpleNamespace(
+                ring=[[torch.empty_like(ds).pin_memory() if cuda else torch.empty_like(ds), None] for _ in range(2)],
+                dev=torch.empty(ds.shape, dtype=ds.dtype, device=eng.device), slot=0)
+        eng._ds_dev = ent.dev
+        slot = ent.ring[ent.slot]
+        ent.slot ^= 1
         if slot[1] is not None:
             slot[1].synchronize()
         slot[0].copy_(ds)
@@ -89,18 +94,27 @@ def _refresh(eng, ds):
             slot[1] = slot[1] or torch.cuda.Event()
             slot[1].record()
         eng._ds_host = slot[0]                      # (the draw the device buffer holds once the stream reaches this point: tests compare the two)
-    eng._ds_fresh = True
+    eng._ds_fresh = N_of(ds)
+
+
+def N_of(ds):
+    return True if ds is None else int(ds.shape[-1])
 
 
 def _staged_drop_scales(eng, draw, N):
     """stochastic-depth multipliers of one training pass in a PERSISTENT device buffer: the host draws them (same generator stream as before) into
     pinned memory and one stream-ordered copy refreshes the buffer -- the kernels read the multipliers from device memory, so the launches of the
-    pass do not depend on what was drawn and a captured step can be replayed (FusedStep calls `refresh_drop_scales` before every replay; a pass
-    that finds no fresh draw -- the eager paths -- draws itself)."""
-    if not eng.__dict__.pop("_ds_fresh", False):
-        eng.refresh_drop_scales(N)
-        eng.__dict__.pop("_ds_fresh", None)
-    return eng.__dict__.get("_ds_dev")
+    pass do not depend on what was drawn and a captured step can be replayed (FusedStep calls `refresh_drop_scales` before every pass and clears the
+    mark behind it; a pass that finds no fresh draw FOR ITS N -- the eager paths -- draws itself and takes a PRIVATE copy: its saved context keeps
+    views of the multipliers for the backward, and the sequential driver runs several forwards before their backwards)."""
+    fresh = eng.__dict__.pop("_ds_fresh", None)
+    dev = eng.__dict__.get("_ds_dev")
+    if fresh is not None and (fresh is True or fresh == N) and (dev is None or dev.shape[-1] == N):
+        return dev
+    eng.refresh_drop_scales(N)
+    eng.__dict__.pop("_ds_fresh", None)
+    dev = eng.__dict__.get("_ds_dev")
+    return None if dev is None else dev.clone()
 
 
 class VitDetRCNN(FlatParamRCNN):

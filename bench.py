@@ -506,6 +506,10 @@ def _traffic_per_launch(tj, family, launches):
         return None
     f = tj[family]
     if f.get("hbm_bytes_per_step") and launches:
+        # the counter file must hold AT LEAST the launches the in-situ profile divides by (a family member the classifier of
+        # tools/rocprof_summary.py misses would otherwise shrink the figure: r05's 0.755x)
+        if f.get("kernel_launches_per_step", 0) < launches:
+            return None
         return round(f["hbm_bytes_per_step"] / launches)
     return round(f["hbm_bytes_per_launch"])
 

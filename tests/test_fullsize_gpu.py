@@ -111,3 +111,103 @@ def test_ema_is_a_convex_combination_at_full_size():
     lo, hi = torch.minimum(s, t0), torch.maximum(s, t0)
     assert bool(((t >= lo - 1e-6) & (t <= hi + 1e-6)).all())
     assert float((t - (s * (1 - 0.9996) + t0 * 0.9996)).abs().max()) < 1e-6
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------------------
+# The full-size ORACLE link (VERDICT r05 missing #7): every other HIP-vs-oracle end-to-end test runs at <= 192x256; here ONE source micro-step of
+# one 800x1333 image (K = 8) and one teacher inference pass go through the default fp32-mode dispatch and are compared with the CPU oracle at the
+# tolerance BASELINE.json's north_star states for the benchmark batch (losses 1e-3, index assignment bit-exact).  ~10-20 s of host CPU.
+@pytest.fixture(scope="module")
+def full_fp32():
+    import subprocess
+    from aldi_amd import synthetic as syn
+    from aldi_amd.arch import ParamLayout
+    from aldi_amd.engine import RCNN, Weights
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle")], stdout=subprocess.DEVNULL)
+    torch.set_num_threads(min(os.cpu_count() or 1, 32))
+    sd = syn.init_state_dict(K, seed=1)
+    lay = ParamLayout(K)
+    w = Weights(lay, torch.device("cuda"), torch.float32, trainable=True)
+    w.load_state_dict(sd)
+    _, data, uw, _ = syn.make_batch(1, 1, 800, 1333, K, seed=3)
+    return sd, RCNN(w, K), data, uw
+
+
+def _match_ranked_boxes(dev_boxes, dev_scores, orc_boxes, orc_scores, tol_box=2e-3, tol_score=1e-4):
+    """two ranked box lists that came out of the SAME top-k -> NMS chain on logits that agree to ~1e-6 (two fp32 summation orders): the same boxes in
+    the same order, except that (a) neighbours whose scores are closer than the arithmetic noise may swap and (b) an NMS decision whose IoU sits on
+    the threshold may flip (one box more or less).  Returns (#boxes without a partner, #order inversions among partners beyond a score tie)."""
+    d = (dev_boxes[:, None, :] - orc_boxes[None, :, :]).abs().amax(2)
+    j = d.argmin(1)
+    ok = d[torch.arange(len(j)), j] < tol_box
+    unmatched = int((~ok).sum()) + (len(orc_boxes) - int(ok.sum()))
+    assert (dev_scores[ok] - orc_scores[j[ok]]).abs().max() < tol_score
+    jo = j[ok]                                                   # oracle rank of the i-th matched device box
+    so = orc_scores[jo]
+    # a later device box with an oracle score HIGHER than an earlier one's by more than the tie tolerance is a real inversion
+    run_min = torch.cummin(so, 0).values
+    inversions = int((so[1:] > run_min[:-1] + tol_score).sum())
+    return unmatched, inversions
+
+
+def test_fullsize_source_step_vs_oracle_fp32(full_fp32):
+    """GeneralizedRCNN.forward(training) at 800 x 1333 (reached from /root/reference/aldi/trainer.py:87): four losses <= 1e-3, p2..p6 <= 2e-5 rel,
+    the 268 569 anchor labels bit-exact, the 1000 proposals the oracle's (same boxes, same order up to score ties below the fp32 noise), and -- from
+    identical proposals, as every end-to-end test of this suite does (matching / sampling are discontinuous in them) -- the sampled ROI indices and
+    classes bit-exact."""
+    from oracle import d2_rcnn as d2
+    sd, m, data, _ = full_fp32
+    cfg = d2.make_cfg(num_classes=K)
+    torch.manual_seed(123)
+    c = m.forward_train([d["image"] for d in data], [d["instances"] for d in data], roi_seed=77)
+    torch.cuda.synchronize()
+    assert int(m.err) == 0
+    assert c.anchors.shape[0] == 268569
+    kk = int(c.prop_count[0])
+    dev_props = [{"proposal_boxes": c.props[0, :kk].cpu(), "objectness_logits": c.prop_scores[0, :kk].cpu(), "image_size": c.sizes[0]}]
+    torch.manual_seed(123)
+    cap = d2.Captured()
+    with torch.no_grad():
+        ol = d2.forward_train(cfg, sd, data, roi_seed=77, cap=cap, replace_proposals=dev_props)
+    for i, k in enumerate(("p2", "p3", "p4", "p5", "p6")):
+        ref = cap["features"][k]
+        assert (c.P[i].cpu().permute(0, 3, 1, 2) - ref).abs().max() < 2e-5 * ref.abs().max(), k
+    assert torch.equal(c.rpn_labels.cpu(), torch.stack(cap["rpn_gt_labels"]).to(torch.int32))
+    po = cap["proposals"][0]                                     # the ORACLE's own proposals (before the replacement)
+    assert abs(kk - len(po["proposal_boxes"])) <= 2 and kk > 100
+    unmatched, inversions = _match_ranked_boxes(dev_props[0]["proposal_boxes"], dev_props[0]["objectness_logits"], po["proposal_boxes"], po["objectness_logits"])
+    print("full-size proposals: %d device / %d oracle, %d without a partner, %d order inversions beyond a score tie" % (kk, len(po["proposal_boxes"]), unmatched, inversions))
+    assert unmatched <= 4 and inversions == 0
+    assert torch.equal(c.r_idx.cpu()[: c.R], torch.cat([s["sampled_idxs"] for s in cap["sampled"]]).to(torch.int32))
+    assert torch.equal(c.r_cls.cpu()[: c.R], torch.cat([s["gt_classes"] for s in cap["sampled"]]).to(torch.int32))
+    assert (c.pred[:, : K + 1].cpu() - cap["box_scores"]).abs().max() < 1e-3
+    hl = {k: float(v) for k, v in m.loss_dict(c).items()}
+    for k in ol:
+        assert abs(hl[k] - float(ol[k])) < 1e-3 * max(1.0, abs(float(ol[k]))), (k, hl[k], float(ol[k]))
+    print("full-size losses hip/oracle:", {k: (round(hl[k], 6), round(float(ol[k]), 6)) for k in ol})
+
+
+def test_fullsize_teacher_inference_vs_oracle_fp32(full_fp32):
+    """GeneralizedRCNN.inference + the pseudo-label threshold at 800 x 1333 (/root/reference/aldi/pseudolabeler.py:15-32): detections in the oracle's
+    order, classes exact, boxes <= 2e-3, scores <= 1e-5."""
+    from oracle import aldi_ops as ao
+    from oracle import d2_rcnn as d2
+    sd, m, _, uw = full_fp32
+    cfg = d2.make_cfg(num_classes=K)
+    ref = d2.inference(cfg, sd, uw)[0]
+    scores = ref["scores"]
+    # a threshold between two detection scores (strict >), so that the pseudo-label filter keeps some and drops some
+    thr = float((scores[len(scores) // 2 - 1] + scores[len(scores) // 2]) / 2) if len(scores) > 1 else 0.5
+    t = m.inference([d["image"] for d in uw], thr)
+    torch.cuda.synchronize()
+    assert int(m.err) == 0
+    k = int(t.det.count[0])
+    assert k == len(scores) and k > 0
+    assert torch.equal(t.det.classes[0, :k].cpu().long(), ref["pred_classes"])
+    assert (t.det.scores[0, :k].cpu() - scores).abs().max() < 1e-5
+    assert (t.det.boxes[0, :k].cpu() - ref["pred_boxes"]).abs().max() < 2e-3
+    pl = ao.process_bbox(ref, thr)
+    n = int(t.pseudo["count"][0])
+    assert n == len(pl["scores"])
+    assert torch.equal(t.pseudo["classes"][0, :n].cpu().long(), pl["gt_classes"])
+    assert (t.pseudo["boxes"][0, :n].cpu() - pl["gt_boxes"]).abs().max() < 2e-3
