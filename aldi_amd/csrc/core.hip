@@ -70,6 +70,7 @@ const Knob kKnobs[] = {
     {"wgrad_lds_pad_kb", &AldiTuning::wgrad_lds_pad_kb, 0},
     {"wgrad_f32_tile128", &AldiTuning::wgrad_f32_tile128, 1},
     {"wgrad_dma64", &AldiTuning::wgrad_dma64, 3},
+    {"wgrad_ilv", &AldiTuning::wgrad_ilv, 0},
     {"msda_gather", &AldiTuning::msda_gather, 7},
     {"msda_gather_list", &AldiTuning::msda_gather_list, 1500},
     {"msda_bin", &AldiTuning::msda_bin, 1},

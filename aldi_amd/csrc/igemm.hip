@@ -1143,7 +1143,7 @@ int launch_halo64(const ConvDev& d, hipStream_t st) {
             else hipLaunchKernelGGL((igemm_halo64_group_kernel<BM, BN, WM, WN, false>), dim3(wg), dim3(NT), 0, st, G);
         }
         ALDI_CHECK_LAUNCH();
-        snprintf(name, sizeof(name), "igemm_group%d<bf16,%d,%d,%d,%d,halo64%s%s>", G.n, BM, BN, WM, WN, direct ? ",direct" : "", ilv ? ",ilv" : "");
+        snprintf(name, sizeof(name), "igemm_group%d<bf16,%d,%d,%d,%d,halo64%s%s>", G.n, BM, BN, WM, WN, direct ? ",direct" : "", (HAS_ILV && !ilv) ? ",lockstep" : "");
     } else {
         direct = direct && halo64_direct_ok(d);
         dim3 grid(cdiv(d.M, BM), cdiv(d.Cout, BN));
@@ -1155,7 +1155,7 @@ int launch_halo64(const ConvDev& d, hipStream_t st) {
             else hipLaunchKernelGGL((igemm_halo64_kernel<BM, BN, WM, WN, false>), grid, dim3(NT), 0, st, d);
         }
         ALDI_CHECK_LAUNCH();
-        snprintf(name, sizeof(name), "igemm<bf16,%d,%d,%d,%d,halo64%s%s>", BM, BN, WM, WN, direct ? ",direct" : "", ilv ? ",ilv" : "");
+        snprintf(name, sizeof(name), "igemm<bf16,%d,%d,%d,%d,halo64%s%s>", BM, BN, WM, WN, direct ? ",direct" : "", (HAS_ILV && !ilv) ? ",lockstep" : "");
     }
     aldi_note_dispatch(name);
     return ALDI_OK;

@@ -110,6 +110,9 @@ __device__ __forceinline__ void igemm_halo64_body(const ConvDev& p, int bid, con
     // SIMD drift half a sub-phase apart after every tap barrier (tools/probes/mfma_issue_probe.hip: one wave alone feeds 0.98 of the pipe).
     const int plev = __builtin_amdgcn_readfirstlane((p.dbg & 128) ? 0 : (p.dbg & 256) ? 1 : ((wave < WM * WN / 2) != ((p.dbg & 512) != 0)) ? 2 : 1);
     const bool prio = plev != 0, prio_hi = plev == 2;
+    // ILV: ALL four pieces of tap u + 2 are requested behind the barrier of tap u (a full tap ahead; the lockstep loop spreads them over three sub-phases
+    // to keep its DMA issue bursts short: pieces 2, 3 go out only 1-2 sub-phases before the barrier that waits for them).  igemm_dbg 1024 = the old points
+    const bool early_w = ILV && __builtin_amdgcn_readfirstlane(p.dbg & 1024) == 0;
     const bool no_dma = p.dbg & 32, no_mfma = p.dbg & 64;  // ablation (igemm_dbg): 32 = no DMA inside the K loop, 64 = no MFMAs, 4 = no epilogue
 
     f32x4_t acc[TM][TN];
@@ -202,9 +205,15 @@ __device__ __forceinline__ void igemm_halo64_body(const ConvDev& p, int bid, con
     unsigned woff_a = tap_off();                            // byte offset of the tap whose pieces 2, 3 go out at points a, b of the current tap
 #pragma unroll
     for (int q = 0; q < 2 * WQ; ++q) issue_w(q, 1, woff_a);
+    if (early_w) {
+#pragma unroll
+        for (int q = 2 * WQ; q < 4 * WQ; ++q) issue_w(q, 1, woff_a);
+    }
     next_tap();
     __builtin_amdgcn_sched_barrier(0);
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * WQ) : "memory");       // slab 0 and tap 0 have landed (mine); the barrier makes everyone's visible
+    // slab 0 and tap 0 have landed (mine); the barrier makes everyone's visible
+    if (early_w) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * WQ) : "memory");
+    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * WQ) : "memory");
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
 
@@ -329,7 +338,7 @@ __device__ __forceinline__ void igemm_halo64_body(const ConvDev& p, int bid, con
     auto tap4i = [&](auto KW, const int g, const int u) {
         constexpr int kw = decltype(KW)::value;
         constexpr int NM = TM * TH;
-        static_assert(TM + TH + 1 + 2 * 2 * WQ <= NM && TH + 1 + 2 * (2 * XQ + 1) <= NM, "the fillers of a sub-phase fit between its MFMAs");
+        static_assert(TM + TH + 1 + 2 * 2 * WQ <= NM && TH + 1 + 2 * (2 * XQ + 1) <= NM && TM + TH + 2 * 2 * WQ < NM, "the fillers of a sub-phase fit between its MFMAs");
         const bool more1 = u + 1 < U, more2 = u + 2 < U;
         // ---- sub-phase 0: (h 0, channels 0-63) from x0 / wa; reads of (h 0, channels 64-127); DMA point a
         {
@@ -340,7 +349,7 @@ __device__ __forceinline__ void igemm_halo64_body(const ConvDev& p, int bid, con
                                constexpr int m = decltype(M)::value;
                                if constexpr (m < TH) wb[m] = frag_read<(TH + m) * FR>(wr);
                                if constexpr (m == TH + 1) {
-                                   if (more1) {
+                                   if (more1 && !early_w) {
 #pragma unroll
                                        for (int q = 0; q < WQ; ++q) issue_w(2 * WQ + q, (u + 1) & 1, woff_a);
                                    }
@@ -362,7 +371,7 @@ __device__ __forceinline__ void igemm_halo64_body(const ConvDev& p, int bid, con
                                if constexpr (m < TM) x1[m] = frag_read<m * FR>(xa[m]);
                                else if constexpr (m < TM + TH) wa[m - TM] = frag_read<(m - TM) * FR>(wr);
                                if constexpr (m == TM + TH + 1) {
-                                   if (more1) {
+                                   if (more1 && !early_w) {
 #pragma unroll
                                        for (int q = 0; q < WQ; ++q) issue_w(3 * WQ + q, (u + 1) & 1, woff_a);
                                    }
@@ -419,6 +428,9 @@ __device__ __forceinline__ void igemm_halo64_body(const ConvDev& p, int bid, con
                                else if constexpr (m < TM + TH) wa[m - TM] = frag_read<(m - TM) * FR>(wr);
                                if constexpr (m > TM + TH && (m - TM - TH) % 2 == 1 && (m - TM - TH) / 2 < 2 * WQ) {
                                    if (more2) issue_w((m - TM - TH) / 2, u & 1, woff_a);
+                               }
+                               if constexpr (m > TM + TH && (m - TM - TH) % 2 == 0 && (m - TM - TH) / 2 - 1 < 2 * WQ) {
+                                   if (more2 && early_w) issue_w(2 * WQ + (m - TM - TH) / 2 - 1, u & 1, woff_a);
                                }
                            });
             if (prio) __builtin_amdgcn_s_setprio(0);

@@ -783,7 +783,26 @@ __global__ __launch_bounds__(WM* WN * 64) void wgrad_bf16_dma_kernel(WgDev p) {
 // the rest the x blocks (4 DMA instructions per wave and slab), every wave owns a (TCO / WM) x (TKK / WN) piece of the accumulator.
 // Same domain and epilogues (wgrad_finish_tile: ordered partial tiles, sole-owner read-modify-write, float atomics; bias gradient as a ones
 // column) as wgrad_bf16_lean_tile, with Cin % 64 == 0 for K x K convs.
-template <int TCO, int TKK, int WM, int WN, int NBUF>
+template <int V> struct WgTag { static constexpr int value = V; };
+template <int N, int I = 0, typename F>
+__device__ __forceinline__ void wg_static_for(F&& f) {
+    if constexpr (I < N) {
+        f(WgTag<I>{});
+        wg_static_for<N, I + 1>(f);
+    }
+}
+// ILV (r06; wgrad_ilv 1 -- a tested arm, NOT the default: alone on the chip it measures equal (354 vs 357 us on the p2 3x3), in the step, beside the
+// data-gradient stream, the lockstep loop is 1.5 % faster: profiles/r06_ab_ilv.txt): the slab loop with its transpose reads and DMA pieces BETWEEN the MFMAs.  The lockstep form below issues a slab's 24
+// reads and 4 DMA pieces, waits for all of them and only then starts its 32 MFMAs -- in all 8 waves at once, behind a barrier per slab: ~500 clocks per
+// slab with an idle matrix pipe against 1 024 of MFMA work per SIMD (0.36 of the peak alone on the chip).  tools/probes/mfma_issue_probe.hip: reads
+// between MFMAs are free, one wave feeds 0.98 of its pipe.  Here a slab starts with the x fragments and the first TWO g fragments only, every MFMA is
+// an `asm volatile` with its accumulator tied in place (hipcc re-allocates the results of the builtin when other instructions sit between them), the
+// reads of g fragment i + 2 and one DMA piece sit between the MFMAs of row i, and the waits are counted (`lgkmcnt(2)`: LDS data returns in order).
+// Same products in the same order per accumulator: bit-identical results.
+__device__ __forceinline__ void wg_mma_ip(f32x4_t& c, const u32x4& a, const u32x4& b) {
+    asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
+}
+template <int TCO, int TKK, int WM, int WN, int NBUF, bool ILV = false>
 __device__ __forceinline__ void wgrad_bf16_dma64_tile(const WgDev& p, unsigned char* lds, int bx, int by, int bz) {
     constexpr int NW = WM * WN;
     static_assert(NW * 64 == TCO + TKK, "one loader wave per 64-channel block");
@@ -835,21 +854,23 @@ __device__ __forceinline__ void wgrad_bf16_dma64_tile(const WgDev& p, unsigned c
     }
     unsigned off = off0;
     const int wbase_slot = (isB ? NGW + blk : blk) * 4096;          // this wave's block inside a stage (bytes)
-    auto issue_slab = [&](int buf) {
+    auto issue_piece = [&](int k, int buf) {             // piece k (8 pixel rows) of the slab being loaded into ring stage `buf`
         unsigned char* dst = lds + buf * STAGE + wbase_slot;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            unsigned o = off == OOB ? OOB : off + (unsigned)(k * 8) * row_bytes;
-            if (track) {
-                const bool ok = (unsigned)(ph[k] + dh) < (unsigned)p.H && (unsigned)(pw[k] + dw) < (unsigned)p.W;
-                o = ok ? o : OOB;
-                pw[k] += BP;
-                while (pw[k] >= p.W) { pw[k] -= p.W; ++ph[k]; }
-                while (ph[k] >= p.H) ph[k] -= p.H;
-            }
-            glds16w(rsrc, dst + k * 1024, o);
+        unsigned o = off == OOB ? OOB : off + (unsigned)(k * 8) * row_bytes;
+        if (track) {
+            const bool ok = (unsigned)(ph[k] + dh) < (unsigned)p.H && (unsigned)(pw[k] + dw) < (unsigned)p.W;
+            o = ok ? o : OOB;
+            pw[k] += BP;
+            while (pw[k] >= p.W) { pw[k] -= p.W; ++ph[k]; }
+            while (ph[k] >= p.H) ph[k] -= p.H;
         }
-        if (off != OOB) off += BP * row_bytes;
+        glds16w(rsrc, dst + k * 1024, o);
+    };
+    auto slab_done = [&]() { if (off != OOB) off += BP * row_bytes; };
+    auto issue_slab = [&](int buf) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) issue_piece(k, buf);
+        slab_done();
     };
 
     const int wm = wave / WN, wn = wave % WN;
@@ -882,6 +903,68 @@ __device__ __forceinline__ void wgrad_bf16_dma64_tile(const WgDev& p, unsigned c
     if (S > 1) issue_slab(1);
     if (NBUF > 3 && S > 2) issue_slab(2);
     int buf = 0, nbuf = NBUF - 1;
+    if constexpr (ILV) {
+        static_assert(TM >= 4 && TN == 4, "four DMA pieces ride in the first four g rows");
+        // the ones column as an OPAQUE four-register value: as a known constant hipcc keeps one register and rebuilds the tuple with three v_mov in front of
+        // every bias MFMA, then reuses those registers for address arithmetic right behind it -- VALU writes next to an MFMA it cannot see inside the asm
+        // (measured: bias gradients wrong and different from run to run; the weight gradients, whose operands only LDS reads touch, were exact)
+        u32x4 ones_t = ones4;
+        asm volatile("" : "+v"(ones_t));
+        const bool abl_nomfma = __builtin_amdgcn_readfirstlane(p.dbg & 4) != 0, abl_nodma = __builtin_amdgcn_readfirstlane(p.dbg & 8) != 0;   // ablation (wgrad_dbg): no MFMAs / no DMA behind the prologue
+        for (int s = 0; s < S; ++s) {
+            if (NBUF > 3 && s + 2 < S) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else if (s + 1 < S) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            u32x2_t alo[TM], ahi[TM], blo[TN], bhi[TN];
+            const unsigned sb = (unsigned)buf * STAGE;
+            const bool more = s + NBUF - 1 < S && !abl_nodma;
+            auto read_a = [&](auto I) {
+                constexpr int i = decltype(I)::value;
+                const unsigned a = rd[i & 3] + sb + a_blk;
+                alo[i] = tr_read<(i >> 2) * 4096>(a);
+                ahi[i] = tr_read<(i >> 2) * 4096 + 2048>(a);
+            };
+            wg_static_for<TN>([&](auto J) {
+                constexpr int j = decltype(J)::value;
+                const unsigned b = rd[j & 3] + sb + b_blk;
+                blo[j] = tr_read<(j >> 2) * 4096>(b);
+                bhi[j] = tr_read<(j >> 2) * 4096 + 2048>(b);
+            });
+            read_a(WgTag<0>{});
+            read_a(WgTag<1>{});
+            if (prio) __builtin_amdgcn_s_setprio(1);
+            wg_static_for<TM>([&](auto I) {
+                constexpr int i = decltype(I)::value;
+                // row i's g fragment has landed; the youngest reads (fragment i + 1) may still be in flight
+                if constexpr (i + 1 < TM) asm volatile("s_waitcnt lgkmcnt(2)" ::: "memory");
+                else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                if constexpr (i == 0) {
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) asm volatile("" : "+v"(blo[j]), "+v"(bhi[j]));
+                }
+                asm volatile("" : "+v"(alo[i]), "+v"(ahi[i]));
+                const u32x4 af = {alo[i][0], alo[i][1], ahi[i][0], ahi[i][1]};
+                wg_static_for<TN>([&](auto J) {
+                    constexpr int j = decltype(J)::value;
+                    const u32x4 bf = {blo[j][0], blo[j][1], bhi[j][0], bhi[j][1]};
+                    if (!abl_nomfma) wg_mma_ip(acc[i][j], af, bf);
+                    if constexpr (j == 0 && i + 2 < TM) read_a(WgTag<i + 2>{});
+                    if constexpr (j == 1 && i < 4) { if (more) issue_piece(i, nbuf); }
+                });
+                if (do_bias) wg_mma_ip(accb[i], af, ones_t);
+            });
+            if (prio) __builtin_amdgcn_s_setprio(0);
+            if (more) slab_done();
+            __builtin_amdgcn_sched_barrier(0);
+            buf = buf == NBUF - 1 ? 0 : buf + 1;
+            nbuf = nbuf == NBUF - 1 ? 0 : nbuf + 1;
+        }
+        asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");       // the asm MFMAs have written their accumulators before the epilogue reads them
+        wgrad_finish_tile<TCO, TKK, WM, WN>(p, acc, accb, do_bias, bx, by, bz, wave, lane);
+        return;
+    }
     for (int s = 0; s < S; ++s) {
         // slab s has landed (mine: counted; everybody's: the barrier); NBUF - 2 younger slabs stay in flight
         if (NBUF > 3 && s + 2 < S) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
@@ -932,6 +1015,7 @@ __device__ __forceinline__ void wgrad_bf16_dma64_tile(const WgDev& p, unsigned c
 }
 
 // the 256 x 256 tile on that loop (8 waves: four g blocks, four x blocks; 128 KB of LDS: one workgroup per CU), alone and grouped
+template <bool ILV>
 __global__ __launch_bounds__(512) void wgrad_bf16_big64_kernel(WgDev p) {
     __shared__ __attribute__((aligned(1024))) unsigned char lds[4 * 8 * 4096];
     int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
@@ -945,20 +1029,22 @@ __global__ __launch_bounds__(512) void wgrad_bf16_big64_kernel(WgDev p) {
         bx = bid % gx; bid /= gx;
         by = bid % gy; bz = bid / gy;
     }
-    wgrad_bf16_dma64_tile<256, 256, 2, 4, 4>(p, lds, bx, by, bz);
+    wgrad_bf16_dma64_tile<256, 256, 2, 4, 4, ILV>(p, lds, bx, by, bz);
 }
+template <bool ILV>
 __global__ __launch_bounds__(512) void wgrad_bf16_big64_group_kernel(WgGroup G) {
     __shared__ __attribute__((aligned(1024))) unsigned char lds[4 * 8 * 4096];
     int i, tx, ty, bz;
     wgrad_group_pick(G, i, tx, ty, bz);
-    wgrad_bf16_dma64_tile<256, 256, 2, 4, 4>(G.p[i], lds, tx, ty, bz);
+    wgrad_bf16_dma64_tile<256, 256, 2, 4, 4, ILV>(G.p[i], lds, tx, ty, bz);
 }
 // the 128 x 128 tile on that loop (4 waves, three-slab ring: 48 KB, three workgroups per CU), grouped (the layers with 128-channel sides)
+template <bool ILV>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void wgrad_bf16_lean64_group_kernel(WgGroup G) {
     __shared__ __attribute__((aligned(1024))) unsigned char lds[3 * 4 * 4096];
     int i, tx, ty, bz;
     wgrad_group_pick(G, i, tx, ty, bz);
-    wgrad_bf16_dma64_tile<128, 128, 2, 2, 3>(G.p[i], lds, tx, ty, bz);
+    wgrad_bf16_dma64_tile<128, 128, 2, 2, 3, ILV>(G.p[i], lds, tx, ty, bz);
 }
 
 // ------------------------------------------------------------------------------------ fp32
@@ -1323,7 +1409,7 @@ int wgrad_single(const aldi_wgrad_args* a, hipStream_t st, WsCarver& ws, FinBuil
         if (ordered) plan_ordered(d, big, ws, fin);
         if (!ws.fits()) return aldi_set_error_msg(ALDI_ERR_ARG, "conv_wgrad: workspace too small (aldi_conv_wgrad_group_workspace)");
         if (!dry) {
-            if (big && (tn.wgrad_dma64 & 1)) hipLaunchKernelGGL(wgrad_bf16_big64_kernel, grid, dim3(512), 0, st, d);
+            if (big && (tn.wgrad_dma64 & 1)) { if (tn.wgrad_ilv) hipLaunchKernelGGL(wgrad_bf16_big64_kernel<true>, grid, dim3(512), 0, st, d); else hipLaunchKernelGGL(wgrad_bf16_big64_kernel<false>, grid, dim3(512), 0, st, d); }
             else if (big) hipLaunchKernelGGL(wgrad_bf16_big_kernel, grid, dim3(512), 0, st, d);
             else hipLaunchKernelGGL(wgrad_bf16_lean_kernel, grid, dim3(256), 0, st, d);
         }
@@ -1409,9 +1495,9 @@ int launch_group(const WgDev* probs, int ng, bool big, hipStream_t st, WsCarver&
     // wgrad_dma64 bit 2: the 128 x 128 group on the LDS-DMA + transpose-read loop when every layer's rows are whole 16-byte chunks
     bool lean64 = !big && (tn.wgrad_dma64 & 2);
     for (int k = 0; k < ng && lean64; ++k) lean64 = L_.p[k].Cin % 8 == 0 && L_.p[k].Cout % 8 == 0;
-    if (big && (tn.wgrad_dma64 & 1)) hipLaunchKernelGGL(wgrad_bf16_big64_group_kernel, dim3(wg), dim3(512), 0, st, L_);
+    if (big && (tn.wgrad_dma64 & 1)) { if (tn.wgrad_ilv) hipLaunchKernelGGL(wgrad_bf16_big64_group_kernel<true>, dim3(wg), dim3(512), 0, st, L_); else hipLaunchKernelGGL(wgrad_bf16_big64_group_kernel<false>, dim3(wg), dim3(512), 0, st, L_); }
     else if (big) hipLaunchKernelGGL(wgrad_bf16_big_group_kernel, dim3(wg), dim3(512), 0, st, L_);
-    else if (lean64) hipLaunchKernelGGL(wgrad_bf16_lean64_group_kernel, dim3(wg), dim3(256), 0, st, L_);
+    else if (lean64) { if (tn.wgrad_ilv) hipLaunchKernelGGL(wgrad_bf16_lean64_group_kernel<true>, dim3(wg), dim3(256), 0, st, L_); else hipLaunchKernelGGL(wgrad_bf16_lean64_group_kernel<false>, dim3(wg), dim3(256), 0, st, L_); }
     else if (tn.wgrad_db) hipLaunchKernelGGL(wgrad_bf16_lean_group_db_kernel, dim3(wg), dim3(256), 0, st, L_);
     else hipLaunchKernelGGL(wgrad_bf16_lean_group_kernel, dim3(wg), dim3(256), (size_t)tn.wgrad_lds_pad_kb << 10, st, L_);
     ALDI_CHECK_LAUNCH();

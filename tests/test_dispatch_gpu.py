@@ -1154,3 +1154,58 @@ def test_direct_epilogue_off_restores_the_staged_kernels():
     x = torch.randn(4, 50, 84, 256, device="cuda").bfloat16()
     ops.conv2d(x, w, relu=True)
     assert L.last_dispatch() == "igemm<bf16,128,64,4,1,pipe,tap>"
+
+
+# ---------------------------------------------------------------------------------- r06: interleaved K loops (asm MFMAs tied in place, reads / DMA between them)
+@pytest.mark.parametrize("case", [(4, 200, 336, 256, 256), (2, 100, 168, 256, 256), (1, 37, 41, 192, 256), (2, 13, 21, 64, 512)])
+def test_halo64_interleaved_loop_equals_lockstep_bit_for_bit(case):
+    """igemm_halo_ilv 1 (default) vs 0 on the 256 x 256 halo64 tile: same products in the same order per accumulator -> identical bits; also with the weight
+    taps requested at the lockstep loop's DMA points (igemm_dbg 1024) and with the staged epilogue"""
+    from aldi_amd import _lib as L
+    from aldi_amd import ops
+    N, H, W_, Cin, Cout = case
+    gen = torch.Generator().manual_seed(sum(case))
+    x = torch.randn(N, H, W_, Cin, generator=gen).to("cuda", torch.bfloat16)
+    w = (torch.randn(Cout, 3, 3, Cin, generator=gen) / (9 * Cin) ** 0.5).to("cuda", torch.bfloat16)
+    sh = (torch.randn(Cout, generator=gen) * 0.1).to("cuda")
+    outs = {}
+    for direct in (8, 0):
+        for ilv, dbg in ((1, 0), (0, 0), (1, 1024)):
+            L.reset_tuning(); L.set_tuning("igemm_force", 11); L.set_tuning("igemm_halo_ilv", ilv); L.set_tuning("igemm_dbg", dbg); L.set_tuning("igemm_direct", direct)
+            outs[(direct, ilv, dbg)] = ops.conv2d(x, w, pad=1, shift=sh, relu=True)
+            name = L.last_dispatch()
+            assert ("lockstep" in name) == (ilv == 0) and ("direct" in name) == bool(direct), name
+        torch.cuda.synchronize()
+        assert torch.equal(outs[(direct, 1, 0)], outs[(direct, 0, 0)])
+        assert torch.equal(outs[(direct, 1, 0)], outs[(direct, 1, 1024)])
+    assert float(outs[(8, 1, 0)].float().abs().max()) > 0
+    L.reset_tuning()
+
+
+def test_wgrad_interleaved_loop_equals_lockstep_bit_for_bit():
+    """wgrad_ilv 1 vs 0 (default) on both LDS-DMA tiles (256 x 256 alone and grouped, 128 x 128 grouped), bias column included"""
+    from aldi_amd import _lib as L
+    from aldi_amd import ops
+    dev = "cuda"
+    cases = [(4, 50, 84, 256, 256, 3, 1, 1), (4, 50, 84, 1024, 256, 1, 1, 0), (2, 100, 168, 128, 128, 3, 1, 1), (2, 100, 168, 512, 128, 1, 1, 0), (2, 13, 21, 256, 256, 3, 1, 1)]
+    outs = {}
+    for ilv in (1, 0):
+        L.reset_tuning(); L.set_tuning("wgrad_ilv", ilv)
+        g2 = torch.Generator().manual_seed(9)
+        probs = []
+        for (N, H, W_, Cin, Cout, k, stride, pad) in cases:
+            x = torch.randn(N, H, W_, Cin, generator=g2).to(dev, torch.bfloat16)
+            g = (torch.randn(N, H, W_, Cout, generator=g2) * 0.1).to(dev, torch.bfloat16)
+            probs.append((x, g, torch.zeros(Cout, k, k, Cin, device=dev), dict(KH=k, KW=k, stride=stride, pad=pad, db=torch.zeros(Cout, device=dev))))
+        ops.conv_wgrad_group(probs)
+        assert "64_group" in L.last_dispatch(), L.last_dispatch()
+        single = torch.zeros(256, 3, 3, 256, device=dev)
+        L.set_tuning("wgrad_big_min", 1); L.set_tuning("wgrad_big_slots", 8)
+        ops.conv_wgrad(probs[0][0], probs[0][1], single, KH=3, KW=3, stride=1, pad=1)
+        assert "big64" in L.last_dispatch(), L.last_dispatch()
+        torch.cuda.synchronize()
+        outs[ilv] = [(p[2], p[3]["db"]) for p in probs] + [(single, single)]
+    for (a, ab), (b, bb) in zip(outs[1], outs[0]):
+        assert torch.equal(a, b) and torch.equal(ab, bb)
+        assert float(a.abs().max()) > 0
+    L.reset_tuning()

@@ -23,10 +23,17 @@ typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
 #define RD(D, OFF) "ds_read_b128 %[" #D "], %[ad] offset:" #OFF "\n"
 
 // MODE 0: 16x16x32 VGPR acc; 1: 16x16x32 AGPR acc; 2: 32x32x16 VGPR; 3: 32x32x16 AGPR
+// operand data: rnd = 0 -> near-constant values (few bits toggle: the chip holds ~2.39 GHz); rnd = 1 -> every lane's eight bf16 values are hashed
+// (random sign and mantissa, exponents spread over 2^-3 .. 2^0: what activations x weights look like) -- DVFS then sets the clock by the power drawn
+__device__ __forceinline__ short rnd_bf16(unsigned k) {
+    k ^= k >> 16; k *= 0x7feb352du; k ^= k >> 15; k *= 0x846ca68bu; k ^= k >> 16;
+    return (short)(((k & 1u) << 15) | ((0x7cu + ((k >> 1) & 3u)) << 7) | ((k >> 3) & 0x7fu));
+}
 template <int MODE>
-__global__ __launch_bounds__(256) void bare_kernel(int iters, float* out, unsigned long long* clk) {
+__global__ __launch_bounds__(256) void bare_kernel(int iters, float* out, unsigned long long* clk, int rnd) {
     bf16x8_t a, b;
     for (int i = 0; i < 8; ++i) { a[i] = (short)(0x3f80 + threadIdx.x % 3); b[i] = (short)(0x3c00 + threadIdx.x % 5); }
+    if (rnd) for (int i = 0; i < 8; ++i) { a[i] = rnd_bf16((blockIdx.x * 256 + threadIdx.x) * 16 + i); b[i] = rnd_bf16((blockIdx.x * 256 + threadIdx.x) * 16 + 8 + i); }
     float s = 0.f;
     unsigned long long c0, c1, w0, w1;
     if constexpr (MODE < 2) {
@@ -80,14 +87,25 @@ __global__ __launch_bounds__(256) void bare_kernel(int iters, float* out, unsign
 // 16x16x32: 4 pixel fragments (x) + 8 channel fragments (w) = 12 reads, 32 MFMAs.  32x32x16: per 16-channel half 2 + 4 = 6 reads and 8 MFMAs; x2 halves.
 // Reads of the NEXT block's fragments are interleaved one per MFMA from the block's first MFMA on.
 template <int MODE>   // 0: 16x16x32, 1: 32x32x16  (accumulators "+v": 128 registers either way)
-__global__ __launch_bounds__(256) void lds_kernel(int iters, float* out, unsigned long long* clk, int lds_stride) {
-    __shared__ __attribute__((aligned(128))) uint4 lds[4096];            // 64 KB (one workgroup per CU when doubled below by dynamic padding is not needed: see main)
-    for (int i = threadIdx.x; i < 4096; i += 256) lds[i] = make_uint4(0x3f803f80u, 0x3c003c00u, 0x3f803f80u, 0x3c003c00u);
+__global__ __launch_bounds__(256) void lds_kernel(int iters, float* out, unsigned long long* clk, int lds_stride, int rnd) {
+    __shared__ __attribute__((aligned(128))) uint4 lds[4096];            // 64 KB: two workgroups per CU fit
+    for (int i = threadIdx.x; i < 4096; i += 256) {
+        lds[i] = make_uint4(0x3f803f80u, 0x3c003c00u, 0x3f803f80u, 0x3c003c00u);
+        if (rnd) {
+            unsigned w[4];
+            for (int q = 0; q < 4; ++q) w[q] = (unsigned)(unsigned short)rnd_bf16((blockIdx.x * 4096 + i) * 8 + 2 * q) | ((unsigned)(unsigned short)rnd_bf16((blockIdx.x * 4096 + i) * 8 + 2 * q + 1) << 16);
+            lds[i] = make_uint4(w[0], w[1], w[2], w[3]);
+        }
+    }
     __syncthreads();
     const unsigned ad = (unsigned)(uintptr_t)(const __attribute__((address_space(3))) void*)&lds[0] + (threadIdx.x & 63) * 16u + (threadIdx.x >> 6) * (unsigned)lds_stride;
     u32x4_t x0, x1, x2, x3, w0_, w1_, w2_, w3_, w4_, w5_, w6_, w7_;         // set A
     u32x4_t y0, y1, y2, y3, v0, v1, v2, v3, v4, v5, v6, v7;                 // set B
     x0 = x1 = x2 = x3 = w0_ = w1_ = w2_ = w3_ = w4_ = w5_ = w6_ = w7_ = u32x4_t{0x3f803f80u, 0x3c003c00u, 0x3f803f80u, 0x3c003c00u};
+    if (rnd) {       // (the first block's fragments; every later block reads its own from the hashed LDS image)
+        x0 = x1 = x2 = x3 = *reinterpret_cast<u32x4_t*>(&lds[threadIdx.x]);
+        w0_ = w1_ = w2_ = w3_ = w4_ = w5_ = w6_ = w7_ = *reinterpret_cast<u32x4_t*>(&lds[256 + threadIdx.x]);
+    }
     y0 = y1 = y2 = y3 = v0 = v1 = v2 = v3 = v4 = v5 = v6 = v7 = x0;
     float s = 0.f;
     unsigned long long c0, c1, w0, w1;
@@ -198,13 +216,16 @@ int main() {
     CK(hipMalloc(&out, 64)); CK(hipMalloc(&clk, 4096 * 16));
     const double F16 = 2.0 * 16 * 16 * 32, F32 = 2.0 * 32 * 32 * 16;
     printf("# register-only / LDS-fed bf16 MFMA streams, inline asm (the stream is what the source says), 256-thread workgroups, 20000 iterations\n");
-    for (int w : {1, 2}) {
-        run("16x16x32 bare, acc VGPR", [&](int g, int it) { hipLaunchKernelGGL(bare_kernel<0>, dim3(g), dim3(256), 0, 0, it, out, clk); }, w, 20000, 16, F16, 16, out, clk);
-        run("16x16x32 bare, acc AGPR", [&](int g, int it) { hipLaunchKernelGGL(bare_kernel<1>, dim3(g), dim3(256), 0, 0, it, out, clk); }, w, 20000, 16, F16, 16, out, clk);
-        run("32x32x16 bare, acc VGPR", [&](int g, int it) { hipLaunchKernelGGL(bare_kernel<2>, dim3(g), dim3(256), 0, 0, it, out, clk); }, w, 20000, 8, F32, 32, out, clk);
-        run("32x32x16 bare, acc AGPR", [&](int g, int it) { hipLaunchKernelGGL(bare_kernel<3>, dim3(g), dim3(256), 0, 0, it, out, clk); }, w, 20000, 8, F32, 32, out, clk);
-        run("16x16x32 + 12 ds_read_b128 / 32", [&](int g, int it) { hipLaunchKernelGGL(lds_kernel<0>, dim3(g), dim3(256), 0, 0, it, out, clk, 1024); }, w, 10000, 64, F16, 16, out, clk);
-        run("32x32x16 + 12 ds_read_b128 / 16", [&](int g, int it) { hipLaunchKernelGGL(lds_kernel<1>, dim3(g), dim3(256), 0, 0, it, out, clk, 1024); }, w, 10000, 32, F32, 32, out, clk);
+    for (int rnd : {0, 1}) {
+        printf("# operand data: %s\n", rnd ? "hashed bf16 (random sign / mantissa, four exponents)" : "near-constant");
+        for (int w : {1, 2}) {
+            run("16x16x32 bare, acc VGPR", [&](int g, int it) { hipLaunchKernelGGL(bare_kernel<0>, dim3(g), dim3(256), 0, 0, it, out, clk, rnd); }, w, 20000, 16, F16, 16, out, clk);
+            run("16x16x32 bare, acc AGPR", [&](int g, int it) { hipLaunchKernelGGL(bare_kernel<1>, dim3(g), dim3(256), 0, 0, it, out, clk, rnd); }, w, 20000, 16, F16, 16, out, clk);
+            run("32x32x16 bare, acc VGPR", [&](int g, int it) { hipLaunchKernelGGL(bare_kernel<2>, dim3(g), dim3(256), 0, 0, it, out, clk, rnd); }, w, 20000, 8, F32, 32, out, clk);
+            run("32x32x16 bare, acc AGPR", [&](int g, int it) { hipLaunchKernelGGL(bare_kernel<3>, dim3(g), dim3(256), 0, 0, it, out, clk, rnd); }, w, 20000, 8, F32, 32, out, clk);
+            run("16x16x32 + 12 ds_read_b128 / 32", [&](int g, int it) { hipLaunchKernelGGL(lds_kernel<0>, dim3(g), dim3(256), 0, 0, it, out, clk, 1024, rnd); }, w, 10000, 64, F16, 16, out, clk);
+            run("32x32x16 + 12 ds_read_b128 / 16", [&](int g, int it) { hipLaunchKernelGGL(lds_kernel<1>, dim3(g), dim3(256), 0, 0, it, out, clk, 1024, rnd); }, w, 10000, 32, F32, 32, out, clk);
+        }
     }
     return 0;
 }
