@@ -227,6 +227,10 @@ def add_aldi_config(cfg: CfgNode):
     # Turn them off with these keys or ALDI_FUSED_STEP=0 / ALDI_STEP_GRAPH=0.
     _C.SOLVER.FUSED_STEP = True           # the step's student passes as one fused launch sequence (numerically the sequential schedule)
     _C.SOLVER.STEP_GRAPH = True           # replay the fused step's two device phases as hipGraphs (aldi_amd/fused_step.py)
+    # stem + res2 (frozen) of batch k + 1 inside step k (fused_step: cross-step pipelining; needs the trainer's one-batch look-ahead).  Built, tested
+    # (bit-identical prefix, same steps) and OFF: measured 8.12-8.31 ms against 7.97-8.11 in order (profiles/r06_ab_pipeline*.txt) -- the student's
+    # prefix already overlaps the teacher's pass at the head of phase A (removing it there saves 0.06 ms), anywhere else it costs its full 0.3-0.4 ms
+    _C.SOLVER.PIPELINE_PREFIX = False
     _C.SOLVER.GRAD_PAYLOAD = "fp32"       # data-parallel gradient exchange: "fp32" (exact) or "bf16" (half the bytes per xGMI link; sums in bf16)
     _C.SOLVER.GRAD_EXCHANGE = "auto"        # per bucket: "all_reduce" or "rs_ag" (reduce_scatter_tensor + all_gather_into_tensor, aldi_amd/reduce.py);
                                             # "auto" = rs_ag on the 8 ranks of one fully connected xGMI node, all_reduce otherwise

@@ -570,11 +570,21 @@ class RCNN:
         """preprocess + ResNet-50 + FPN -> P2..P6.  `save` keeps the activations backward needs."""
         return self._drive(self.trunk_steps(st_u8, sizes, save))
 
-    def trunk_steps(self, st_u8: torch.Tensor, sizes, save: bool, fpn: bool = True):
+    def prefix_pipelinable(self) -> bool:
+        """stem + res2 are frozen (FREEZE_AT = 2: nothing of them is saved for the backward and no update touches their weights) and run as the
+        fused bf16 kernels: their forward for batch k + 1 may run while step k still computes (fused_step: cross-step pipelining)"""
+        return type(self) is RCNN and self.dtype == torch.bfloat16 and self.fused_stem and self.fused_res2
+
+    def trunk_steps(self, st_u8: torch.Tensor, sizes, save: bool, fpn: bool = True, pre: Optional[torch.Tensor] = None,
+                    prefix_out: Optional[torch.Tensor] = None):
+        """pre = the res2 output of THIS batch computed earlier (by a `prefix_out` run of the same images): the pass starts at res3.
+        prefix_out = run stem + res2 only, the last res2 block writes into this buffer; returns it."""
         W = self.wts
         c = Ctx()
         bu = "backbone.bottom_up."
-        if self.dtype == torch.bfloat16 and self.fused_stem:
+        if pre is not None:
+            x = pre
+        elif self.dtype == torch.bfloat16 and self.fused_stem:
             x = ops.stem_pool_forward(st_u8, sizes, W.stem_packed(bu + "stem.conv1"), W.scale(bu + "stem.conv1"), W.shift(bu + "stem.conv1"),
                                       self.p.pixel_mean, self.p.pixel_std)
         else:
@@ -591,13 +601,17 @@ class RCNN:
         if fuse2:
             res2 = [f"{bu}res2.{b}.conv{k}" for b in range(STAGE_BLOCKS[0]) for k in (1, 2, 3)]
             fw = dict(zip(res2, W.folded(res2)))
+        assert prefix_out is None or (fuse2 and pre is None)
         for si, nb in enumerate(STAGE_BLOCKS):
+            if si == 0 and pre is not None:
+                cs.append(x)
+                continue
             for b in range(nb):
                 p = f"{bu}res{si + 2}.{b}."
                 sc = (yield x, p + "shortcut", {}) if b == 0 else x
                 if si == 0 and fuse2:
                     x = ops.bottleneck_fused(x, sc, fw[p + "conv1"], fw[p + "conv2"], fw[p + "conv3"], W.shift(p + "conv1"), W.shift(p + "conv2"),
-                                             W.shift(p + "conv3"))
+                                             W.shift(p + "conv3"), out=prefix_out if (prefix_out is not None and b == nb - 1) else None)
                     continue
                 # every saved ReLU output's mask as BITS beside it (1/16 of the tensor): what the data-gradient launch that needs the mask -- the
                 # next block's conv1 / the lateral conv for a block output, conv3's / conv2's for the two inner maps -- multiplies by instead of
@@ -625,6 +639,8 @@ class RCNN:
                             out_bits[h1.data_ptr()], out_bits[h2.data_ptr()] = b1, b2
                 x = out
             cs.append(x)
+            if prefix_out is not None:
+                return x
         if not fpn:                            # the bare trunk (the Deformable-DETR detector takes C3..C5 themselves)
             if save:
                 c.blocks, c.cs, c.out_bits = blocks, cs, out_bits

@@ -126,6 +126,12 @@ class FusedStep:
         self.teacher_first = os.environ.get("ALDI_TEACHER_FIRST", "0") == "1"
         self.interleave = os.environ.get("ALDI_INTERLEAVE", "1") == "1"
         self.spin_wait = os.environ.get("ALDI_SPIN_WAIT", "1") == "1"
+        # stem + res2 of batch k + 1 under step k's proposal chain (needs the next batch: trainer._fetch_batch); ALDI_PIPELINE_PREFIX=0 for A/B runs
+        self.pipeline = (bool(trainer.model.cfg.SOLVER.get("PIPELINE_PREFIX", False)) or os.environ.get("ALDI_PIPELINE_PREFIX") == "1") and os.environ.get("ALDI_PIPELINE_PREFIX") != "0"
+        self.prefix_at = os.environ.get("ALDI_PREFIX_AT", "b")     # "a": behind the RPN head, under the proposal chain; "b": beside the head of phase B
+        self._parity = 0
+        self._pslots: Dict[tuple, SimpleNamespace] = {}
+        self._pre_ready = None               # (slot, the list objects of the batch whose prefix that slot holds)
         self.warmup = 3                     # eager steps before capturing (lazy initialisation: anchors, dgrad weights, workspaces)
         self.dp_graph_ok = True             # cleared if recording phase B together with its collectives ever fails
         self.stats = dict(captures=0, replays_a=0, replays_b=0, eager=0)
@@ -177,6 +183,81 @@ class FusedStep:
         P.upload()
         return {"boxes": P.d("boxes"), "classes": P.d("classes"), "count": P.d("count")}
 
+    # ------------------------------------------------------------------------------------------------ cross-step pipelining of the frozen prefix
+    def _fused_images(self, data, do_align, do_distill):
+        """the student images of an iteration in the fused batch's order (what `run` assembles for the current one)"""
+        from .trainer import plan_micro_steps
+        plan = plan_micro_steps(*data, do_align=do_align, do_distill=do_distill)
+        return [d["image"] for row in plan for d in row.data]
+
+    def _prefix_slot(self, par: int, images):
+        sizes = [(int(im.shape[1]), int(im.shape[2])) for im in images]
+        Hs, Ws = pad_to(max(s[0] for s in sizes), 32), pad_to(max(s[1] for s in sizes), 32)
+        k = (par, len(images), Hs, Ws)
+        sl = self._pslots.get(k)
+        if sl is None:
+            dev = self.eng.device
+            Hc, Wc = Hs // 2, Ws // 2
+            sl = SimpleNamespace(img=torch.zeros((len(images), 3, Hs, Ws), dtype=torch.uint8, device=dev), sizes=None,
+                                 hw=torch.zeros((len(images), 2), dtype=torch.int32, device=dev),
+                                 out=torch.empty((len(images), (Hc - 1) // 2 + 1, (Wc - 1) // 2 + 1, 256), dtype=torch.bfloat16, device=dev), key=k)
+            self._pslots[k] = sl
+        return sl, sizes
+
+    def _stage_into_slot(self, sl, images, sizes):
+        if sl.sizes != sizes:
+            if sl.sizes is not None:
+                sl.img.zero_()
+            sl.hw.copy_(torch.tensor(sizes, dtype=torch.int32))
+            sl.sizes = sizes
+        if all(im.is_cuda and im.dtype == torch.uint8 and im.is_contiguous() for im in images) and len(images) <= 16:
+            ops.stage_images(images, sl.img)
+        else:
+            for i, im in enumerate(images):
+                sl.img[i, :, : sizes[i][0], : sizes[i][1]].copy_(im, non_blocking=True)
+
+    def _prefix_begin(self, S, par, images, next_data, do_align, do_distill):
+        """S.stu = this parity's slot holding the current student images AND their res2 output (computed by the previous step's phase A when the
+        trainer had handed this batch over as `next_data`; otherwise computed here, in order); S.nxt = the other parity's slot with the next
+        iteration's images staged, whose prefix this step's phase A computes.  Nothing is cached: every step's prefix is computed once, from
+        that step's images -- one step early."""
+        eng = self.eng
+        cur, sizes = self._prefix_slot(par, images)
+        ready = self._pre_ready
+        self._pre_ready = None
+        have = (ready is not None and ready[0] is cur and len(ready[1]) == len(images) and all(a is b for a, b in zip(ready[1], images))
+                and cur.sizes == sizes)
+        if not have:
+            self._stage_into_slot(cur, images, sizes)
+            with torch.no_grad():
+                eng._drive(eng.trunk_steps(cur.img, sizes, False, prefix_out=cur.out))
+            self.stats["prefix_inline"] = self.stats.get("prefix_inline", 0) + 1
+        else:
+            self.stats["prefix_ahead"] = self.stats.get("prefix_ahead", 0) + 1
+        S.stu = cur
+        S.nxt = None
+        S.nxt_images = None
+        nxt_slot, _ = self._prefix_slot(par ^ 1, images)            # what this S's graphs are recorded with: the same shapes, the other parity
+        S.nxt = nxt_slot
+        if next_data is not None:
+            try:
+                nimg = self._fused_images(next_data, do_align, do_distill)
+            except Exception:
+                nimg = None
+            if nimg is not None and len(nimg) == len(images):
+                nsizes = [(int(im.shape[1]), int(im.shape[2])) for im in nimg]
+                if nsizes == sizes:                                 # (the stem kernel's launch carries the image sizes: same sizes, or no look-ahead)
+                    self._stage_into_slot(nxt_slot, nimg, nsizes)
+                    S.nxt_images = nimg
+        if nxt_slot.sizes is None:                                   # never staged: the recorded prefix pass still runs on it (zeros)
+            nxt_slot.sizes = sizes
+            nxt_slot.hw.copy_(torch.tensor(sizes, dtype=torch.int32))
+
+    def _prefix_stream(self):
+        if not hasattr(self, "_pfx_stream"):
+            self._pfx_stream = torch.cuda.Stream(device=self.eng.device, priority=int(os.environ.get("ALDI_PREFIX_PRIO", "0")))
+        return self._pfx_stream
+
     # ------------------------------------------------------------------------------------------------ phase A
     def _phase_a(self, S):
         eng, teng, dist_ = self.eng, self.teng, self.tr.distiller
@@ -192,6 +273,7 @@ class FusedStep:
         pair = S.distill and self.pair_forward and type(eng) is RCNN and type(teng) is RCNN
         inter = S.distill and self.interleave and not pair and tside is not None and type(eng) is RCNN and type(teng) is RCNN
         tcx = None
+        pre_in = S.stu.out if getattr(S, "pipe", False) else None
         if inter:
             # Student on the main stream, teacher on its own, their launches ISSUED alternately layer by layer: both branches of the
             # captured graph are fed from the first microsecond (captured one after the other, the second branch's first node
@@ -202,7 +284,7 @@ class FusedStep:
                 with torch.cuda.stream(tside):
                     teng.wts.ema_from(eng.wts, S.ema_alpha, copy_only=S.ema_mode == "copy")
             with torch.no_grad():
-                c, tcx = RCNN.drive_pair(eng, eng.trunk_steps(stu.img, stu.sizes, True), teng, teng.trunk_steps(tea.img, tea.sizes, False), streams=(main, tside))
+                c, tcx = RCNN.drive_pair(eng, eng.trunk_steps(stu.img, stu.sizes, True, pre=pre_in), teng, teng.trunk_steps(tea.img, tea.sizes, False), streams=(main, tside))
                 RCNN.drive_pair(eng, eng.rpn_head_steps(c, True), teng, teng.rpn_head_steps(tcx, False), streams=(main, tside))
         elif pair:
             # Student (N = 4) and teacher (N = 2) go through the same layers with different weights: ONE launch per layer for both
@@ -210,7 +292,7 @@ class FusedStep:
             # to come first then (the teacher's weights are read from the first layer on).
             if S.ema_mode is not None:
                 teng.wts.ema_from(eng.wts, S.ema_alpha, copy_only=S.ema_mode == "copy")
-            c, tcx = RCNN.drive_pair(eng, eng.trunk_steps(stu.img, stu.sizes, True), teng, teng.trunk_steps(tea.img, tea.sizes, False))
+            c, tcx = RCNN.drive_pair(eng, eng.trunk_steps(stu.img, stu.sizes, True, pre=pre_in), teng, teng.trunk_steps(tea.img, tea.sizes, False))
             RCNN.drive_pair(eng, eng.rpn_head_steps(c, True), teng, teng.rpn_head_steps(tcx, False))
         else:
             if S.distill and self.teacher_first and tside is not None:
@@ -222,9 +304,17 @@ class FusedStep:
                     if S.ema_mode is not None:
                         teng.wts.ema_from(eng.wts, S.ema_alpha, copy_only=S.ema_mode == "copy")
                     tc_early = teng.inference(None, dist_.pseudo_label_threshold, staged=(tea.img, tea.sizes, tea.hw), pl_out=S.pl_out)
-            c = eng.trunk(stu.img, stu.sizes, save=True)
+            c = eng._drive(eng.trunk_steps(stu.img, stu.sizes, True, pre=pre_in))
             eng.rpn_head(c, save=True)
         c.N, c.sizes, c.hw, c.geom, c.anchors, c.shapes = N, stu.sizes, stu.hw, geom, anchors, shapes
+        pfx = None
+        if getattr(S, "pipe", False) and self.prefix_at == "a":
+            # the NEXT iteration's frozen prefix: from here on the student's chain is a handful of latency-bound launches (keys, top-k, NMS, merge,
+            # ROI preparation: ~0.34 ms with the chip idle) -- dense work that depends on nothing of this step runs under it
+            pfx = self._prefix_stream()
+            pfx.wait_stream(main)
+            with torch.cuda.stream(pfx), torch.no_grad():
+                eng._drive(eng.trunk_steps(S.nxt.img, S.nxt.sizes, False, prefix_out=S.nxt.out))
         # proposal generation (top-k, NMS: latency-bound, a handful of workgroups) beside anchor matching on the second stream
         side = eng._wgrad_stream()
         ev_props = None
@@ -304,6 +394,8 @@ class FusedStep:
             main.wait_stream(side)                           # (phase B starts behind the housekeeping)
         else:
             housekeeping()
+        if pfx is not None:
+            main.wait_stream(pfx)
         return SimpleNamespace(c=c, tc=tc, prep=prep)
 
     # ------------------------------------------------------------------------------------------------ host phase
@@ -520,6 +612,14 @@ class FusedStep:
         if os.environ.get("ALDI_PROBE_SPIN_CYCLES"):         # (probe, as in phase A: lets a tracer's slow node submission finish before the phase runs)
             torch.cuda._sleep(int(os.environ["ALDI_PROBE_SPIN_CYCLES"]))
         U.upload()
+        pfx = None
+        if getattr(S, "pipe", False) and self.prefix_at == "b":
+            # the NEXT iteration's frozen prefix beside the head of phase B: sample scatter, RoIAlign, the box head's forward, the loss kernels and
+            # the box head's backward are ~0.5 ms of launches that fill a fraction of the chip (profiles/r05_timeline_spin.txt)
+            pfx = self._prefix_stream()
+            pfx.wait_stream(main)
+            with torch.cuda.stream(pfx), torch.no_grad():
+                eng._drive(eng.trunk_steps(S.nxt.img, S.nxt.sizes, False, prefix_out=S.nxt.out))
         sumA = c.anchors.shape[0]
         labels = torch.empty((N, sumA), dtype=torch.int32, device=dev)
         RPN_BATCH = eng.p.rpn_batch
@@ -626,6 +726,8 @@ class FusedStep:
         else:
             eng.backward_fused(c, scales, after_losses=lambda: holder.update(loss_dict=self._loss_dict(S, accum, main)))
         loss_dict = holder["loss_dict"]
+        if pfx is not None:
+            main.wait_stream(pfx)
         if S.tside is not None:
             main.wait_stream(S.tside)
         fields = {k: c[k] for k in ("rpn_labels", "R", "rows", "rois", "r_cls", "r_gt", "r_idx", "pred", "pooled", "fc1", "fc2", "ghead", "gpred") if k in c}
@@ -682,7 +784,7 @@ class FusedStep:
     def _static_for(self, key):
         S = self.static.get(key)
         if S is None:
-            if len(self.static) >= 4:                          # multi-scale input: keep the most recent shapes only
+            if len(self.static) >= 8:                          # multi-scale input: keep the most recent shapes only (two parities each)
                 self.static.pop(next(iter(self.static)))
             S = SimpleNamespace(bufs={}, gt_pack=None, up=None, h_counts=None, graph_a=None, A=None, graphs_b={})
             self.static[key] = S
@@ -690,8 +792,10 @@ class FusedStep:
             self.static[key] = self.static.pop(key)
         return S
 
-    def run(self, labeled_weak, labeled_strong, unlabeled_weak, unlabeled_strong, ema=None, zero_grad=False, reducer=None, sgd=None):
-        """sgd = (lr, momentum, weight_decay): the optimizer step the caller would run right after this (EngineSGD.step), applied here
+    def run(self, labeled_weak, labeled_strong, unlabeled_weak, unlabeled_strong, ema=None, zero_grad=False, reducer=None, sgd=None, next_data=None):
+        """next_data = the 4-tuple of the NEXT iteration (or None): its student images are staged now and their frozen prefix (stem + res2) runs
+        inside this step's phase A, under the latency-bound proposal chain; the next call starts its student pass at res3 (`_prefix_*`).
+        sgd = (lr, momentum, weight_decay): the optimizer step the caller would run right after this (EngineSGD.step), applied here
         instead, layer group by layer group as the backward completes their gradients (sets eng.wts._sgd_applied)"""
         from .model import DevicePseudoLabels
         from .trainer import _schedule_flags, _teacher_stream, plan_micro_steps
@@ -741,7 +845,14 @@ class FusedStep:
                 ema[0].update_weights(model, ema[1])               # not the teacher of this step's distiller: nothing to overlap with
         key = (tuple((ch["name"], ch["n1"] - ch["n0"]) for ch in chunks), tuple(tuple(im.shape[1:]) for im in images),
                tuple(tuple(d["image"].shape[1:]) for d in (unlabeled_weak or [])) if do_distill else (), ema_mode, bool(zero_grad), sgd is not None)
+        # cross-step pipelining of the frozen prefix: the steps alternate between two sets of static buffers / graphs (parity), each reading the
+        # student's res2 output from ITS prefix slot and writing the next step's into the other one
+        pipe = self.pipeline and eng.prefix_pipelinable()
+        par = self._parity = (self._parity ^ 1) if pipe else 0
+        if pipe:
+            key = key + (("pipe", par),)
         S = self._static_for(key)
+        S.pipe = pipe
         S.sgd = sgd is not None
         if S.sgd:
             if getattr(S, "hyper_host", None) is None:
@@ -759,7 +870,10 @@ class FusedStep:
         if S.lazy_wt:
             eng.wts.lazy_wt = True
         S.tside = _teacher_stream(dev) if do_distill else None
-        S.stu = self._stage_images(S, "student", images)
+        if pipe:
+            self._prefix_begin(S, par, images, next_data, do_align, do_distill)
+        else:
+            S.stu = self._stage_images(S, "student", images)
         S.tea = self._stage_images(S, "teacher", [d["image"] for d in unlabeled_weak]) if do_distill else None
         S.gt_all = self._stage_gt(S, lab_rows, N)
         S.pl_out = None
@@ -811,6 +925,8 @@ class FusedStep:
         else:
             A = self._phase_a(S)
         c, tc = A.c, A.tc
+        if getattr(S, "pipe", False) and S.nxt_images is not None:
+            self._pre_ready = (S.nxt, S.nxt_images)                # this step (phase A or B, recorded or eager) computes the next iteration's res2 output into that slot
         evs[1].record()
         self._prefetch_draws(S, int(c.anchors.shape[0]))
         # Everything the host can do WITHOUT the list lengths happens here, while the device still runs phase A: between the lengths' arrival

@@ -464,7 +464,7 @@ class SimpleTrainer:
         if not self.model.training:
             raise AssertionError("[SimpleTrainer] model was changed to eval mode!")
         t0 = time.perf_counter()
-        batch = next(self._data_loader_iter)
+        batch = self._fetch_batch()
         fetch_s = time.perf_counter() - t0
         clear_first = self.zero_grad_before_forward
         if clear_first and self._defers_zero_grad():
@@ -490,6 +490,26 @@ class SimpleTrainer:
 
     def run_model(self, data):
         return self.model(data)
+
+    def _wants_lookahead(self) -> bool:
+        """True when run_model can use batch k + 1 while it runs step k (the fused step's cross-step pipelining of the frozen prefix)"""
+        return False
+
+    def _fetch_batch(self):
+        """the batch of this step; with look-ahead the NEXT one is fetched too (the reference's loader is asynchronous and always a batch ahead,
+        aldi/trainer.py:211-238, aldi/dataloader.py:45-55) and left in `_next_batch` for run_model -- the order of batches is unchanged"""
+        if not self._wants_lookahead():
+            ahead = self.__dict__.pop("_ahead_batch", None)
+            self._next_batch = None
+            return ahead if ahead is not None else next(self._data_loader_iter)
+        ahead = self.__dict__.pop("_ahead_batch", None)
+        batch = ahead if ahead is not None else next(self._data_loader_iter)
+        try:
+            self._ahead_batch = next(self._data_loader_iter)
+        except StopIteration:
+            self._ahead_batch = None
+        self._next_batch = self._ahead_batch
+        return batch
 
     def _defers_zero_grad(self) -> bool:
         """True when run_model clears the gradients itself (the fused step does it on a side stream beside its forward)"""
@@ -620,6 +640,13 @@ class _ALDITrainer:
         canvas = {(max(int(b["image"].shape[-2]) for b in c_), max(int(b["image"].shape[-1]) for b in c_)) for c_ in chunks}
         return len({((h + 31) // 32, (w + 31) // 32) for h, w in canvas}) == 1
 
+    def _wants_lookahead(self) -> bool:
+        from .engine import RCNN
+        model = self.model.module if hasattr(self.model, "module") else self.model
+        eng = getattr(model, "engine", None)
+        return (bool(self.fused) and (bool(model.cfg.SOLVER.get("PIPELINE_PREFIX", False)) or os.environ.get("ALDI_PIPELINE_PREFIX") == "1") and os.environ.get("ALDI_PIPELINE_PREFIX") != "0"
+                and os.environ.get("ALDI_FUSED_LEGACY", "0") != "1" and type(eng) is RCNN and eng.prefix_pipelinable())
+
     def _defers_zero_grad(self) -> bool:
         from .engine import RCNN
         model = self.model.module if hasattr(self.model, "module") else self.model
@@ -668,7 +695,8 @@ class _ALDITrainer:
                 if self.__dict__.pop("_sgd_pending", False) and reducer is None:
                     g_ = self.optimizer.param_groups[0]
                     sgd = (g_["lr"], g_["momentum"], g_["weight_decay"])
-                out = self._fused_step.run(*data, ema=pending_ema, zero_grad=defer, reducer=reducer, sgd=sgd)
+                out = self._fused_step.run(*data, ema=pending_ema, zero_grad=defer, reducer=reducer, sgd=sgd,
+                                           next_data=self.__dict__.get("_next_batch") if self._wants_lookahead() else None)
                 ok = True
                 return out
             finally:

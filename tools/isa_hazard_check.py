@@ -88,36 +88,71 @@ def check_kernel(items):
         if fall and i + 1 < len(order):
             succ[b].append(order[i + 1])
 
-    def transfer(b, pend, report=None):
-        pend = set(pend)
-        seen_term = False
+    CAP = 96
+
+    def transfer(b, state, report=None):
+        # LDS operations return IN ORDER: `s_waitcnt lgkmcnt(N)` leaves the N youngest of them in flight (the interleaved loops of r06 wait with
+        # counts).  The state is the QUEUE of LDS operations in flight, oldest first, each with the registers a hand-issued read will write
+        # (compiler-issued LDS / scalar-memory operations take a slot with no tracked registers).
+        q = list(state)
         for ins, in_asm in blocks[b]:
             op = ins.split()[0]
-            if op == "s_waitcnt" and "lgkmcnt(0)" in ins:
-                pend.clear()
+            m = re.search(r"lgkmcnt\((\d+)\)", ins) if op == "s_waitcnt" else None
+            if m:
+                n = int(m.group(1))
+                q = q[len(q) - n:] if (n and n < len(q)) else ([] if n == 0 else q)
                 continue
             touched = regs_of(ins[len(op):])
+            inflight = set().union(*q) if q else set()
             if op.startswith("ds_read") and in_asm:
                 dst = regs_of(ins[len(op):].split(",")[0])
-                bad = (touched - dst) & pend
+                bad = (touched - dst) & inflight
                 if bad and report is not None:
                     report.append((b, ins, sorted(bad)))
-                pend |= dst
-                continue
-            bad = touched & pend
-            if bad and report is not None:
-                report.append((b, ins, sorted(bad)))
-        return pend
-    IN = {b: set() for b in order}
-    changed = True
-    while changed:
+                q.append(frozenset(dst))
+            else:
+                bad = touched & inflight
+                if bad and report is not None:
+                    report.append((b, ins, sorted(bad)))
+                if op.startswith("ds_") or op.startswith("s_load") or op.startswith("s_buffer_load"):
+                    q.append(frozenset())
+            if len(q) > CAP:
+                q = [frozenset().union(*q[: len(q) - CAP + 1])] + q[len(q) - CAP + 1:]
+        return tuple(q)
+
+    def merge(x, y):
+        # two queues reaching one block: aligned at the YOUNGEST end (what a counted wait counts from), entry-wise unions; the surplus of the
+        # longer one joins the oldest entry
+        if x == y:
+            return x
+        if len(x) < len(y):
+            x, y = y, x
+        k = len(y)
+        if k == 0:
+            return (frozenset().union(*x),) if x else ()
+        head = x[: len(x) - k]
+        out = [x[len(x) - k + i] | y[i] for i in range(k)]
+        if head:
+            out[0] = out[0] | frozenset().union(*head)
+        return tuple(out)
+    IN = {b: None for b in order}
+    IN[order[0]] = ()
+    changed, rounds = True, 0
+    while changed and rounds < 200:
         changed = False
+        rounds += 1
         for b in order:
+            if IN[b] is None:
+                continue
             out = transfer(b, IN[b])
             for t in succ[b]:
-                if not out <= IN[t]:
-                    IN[t] |= out
+                new = out if IN[t] is None else merge(IN[t], out)
+                if new != IN[t]:
+                    IN[t] = new
                     changed = True
+    for b in order:
+        if IN[b] is None:
+            IN[b] = ()
     report = []
     for b in order:
         transfer(b, IN[b], report)
