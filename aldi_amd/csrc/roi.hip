@@ -304,6 +304,17 @@ template <> struct Raw8<float> {
     __device__ __forceinline__ void unpack(float* o) const { o[0] = a.x; o[1] = a.y; o[2] = a.z; o[3] = a.w; o[4] = b.x; o[5] = b.y; o[6] = b.z; o[7] = b.w; }
 };
 
+// acc[0..7] += w * u[0..7] as four fused packed multiply-adds (v_pk_fma_f32).  The file is built with -ffp-contract=off, where `acc += w * u` is a
+// v_pk_mul_f32 + v_pk_add_f32 pair; the RoIAlign kernels are bound by VALU issue (r06: forward 2048 ROIs x 4 waves x ~3 700 instructions = 58 of its
+// 62 us).  One rounding instead of two per term.
+__device__ __forceinline__ void fma8(float* acc, const float w, const float* u) {
+#pragma unroll
+    for (int i = 0; i < 8; i += 2) {
+        const f32x2_t r2 = __builtin_elementwise_fma(f32x2_t{w, w}, f32x2_t{u[i], u[i + 1]}, f32x2_t{acc[i], acc[i + 1]});
+        acc[i] = r2[0]; acc[i + 1] = r2[1];
+    }
+}
+
 // Forward, separable form (what aldi_roialign runs): the adaptive sample grid of a bin is a product grid, so
 //   out[ph][pw][c] = 1/count * sum_yy rowc[ph][yy] * ( sum_xx colc[pw][xx] * f[yy][xx][c] )
 // with rowc / colc the summed bilinear weights the bin's sample rows / columns put on feature row yy / column xx (the same
@@ -404,15 +415,34 @@ __global__ __launch_bounds__(256) void roialign_fwd_sep_kernel(Feats ft, const f
 #pragma unroll
             for (int k = 0; k < XB; ++k) {
                 q[k].unpack(u);
+                // The kernel is bound by VALU issue (2048 ROIs x 4 waves x ~3 700 instructions = 58 of its 62 us), and the file is built with
+                // -ffp-contract=off: every multiply-add was a v_pk_mul_f32 + v_pk_add_f32 pair.  bf16 maps: fused packed multiply-adds (one
+                // v_pk_fma_f32 per channel pair: fewer roundings, not more); the fp32 parity mode keeps the unfused arithmetic of the oracle.
+                if constexpr (sizeof(T) == 2) {
 #pragma unroll
-                for (int i = 0; i < 8; ++i) t[i] += wc[k] * u[i];
+                    for (int i = 0; i < 8; i += 2) {
+                        const f32x2_t r2 = __builtin_elementwise_fma(f32x2_t{wc[k], wc[k]}, f32x2_t{u[i], u[i + 1]}, f32x2_t{t[i], t[i + 1]});
+                        t[i] = r2[0]; t[i + 1] = r2[1];
+                    }
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) t[i] += wc[k] * u[i];
+                }
             }
         }
 #pragma unroll
         for (int ph = 0; ph < 7; ++ph)
             if (wr[ph] != 0.f) {
+                if constexpr (sizeof(T) == 2) {
 #pragma unroll
-                for (int i = 0; i < 8; ++i) acc[ph][i] += wr[ph] * t[i];
+                    for (int i = 0; i < 8; i += 2) {
+                        const f32x2_t r2 = __builtin_elementwise_fma(f32x2_t{wr[ph], wr[ph]}, f32x2_t{t[i], t[i + 1]}, f32x2_t{acc[ph][i], acc[ph][i + 1]});
+                        acc[ph][i] = r2[0]; acc[ph][i + 1] = r2[1];
+                    }
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) acc[ph][i] += wr[ph] * t[i];
+                }
             }
     }
 #pragma unroll
@@ -585,8 +615,7 @@ __global__ __launch_bounds__(256, 5) void roialign_bwd_gather_kernel(Feats ft, G
 #pragma unroll
                     for (int j = 0; j < 3; ++j) {
                         raw[j].unpack(u);
-#pragma unroll
-                        for (int i = 0; i < 8; ++i) g8[i] += rc[j] * u[i];
+                        fma8(g8, rc[j], u);
                     }
                     if (phi - plo > 2) {
                         const T* g0 = gp + (long)cand[q] * P * P * C + c8 * 8;
@@ -595,8 +624,7 @@ __global__ __launch_bounds__(256, 5) void roialign_bwd_gather_kernel(Feats ft, G
                             Raw8<T> x;
                             x.load(g0 + (long)(ph * P + qw) * C);
                             x.unpack(u);
-#pragma unroll
-                            for (int i = 0; i < 8; ++i) g8[i] += w * u[i];
+                            fma8(g8, w, u);
                         }
                     }
                     const float inv = cinv[q];
@@ -799,8 +827,8 @@ __global__ __launch_bounds__(256, 3) void roialign_bwd_gather2_kernel(Feats ft, 
                     for (int j = 0; j < 4; ++j) {
                         Raw8<bf16_t> x; x.v = raw[j];
                         x.unpack(u);
-#pragma unroll
-                        for (int i = 0; i < 8; ++i) { g0[i] += rc0[j] * u[i]; g1[i] += rc1[j] * u[i]; }
+                        fma8(g0, rc0[j], u);
+                        fma8(g1, rc1[j], u);
                     }
                     if (phi - plo > 3) {
                         const bf16_t* gq = gp + (long)cand[q] * P * P * C + c8 * 8;
@@ -809,8 +837,7 @@ __global__ __launch_bounds__(256, 3) void roialign_bwd_gather2_kernel(Feats ft, 
                             Raw8<bf16_t> x;
                             x.load(gq + (long)(ph * P + qw) * C);
                             x.unpack(u);
-#pragma unroll
-                            for (int i = 0; i < 8; ++i) { g0[i] += w0 * u[i]; g1[i] += w1 * u[i]; }
+                            { fma8(g0, w0, u); fma8(g1, w1, u); }
                         }
                     }
                     const float inv = cinv[q];
