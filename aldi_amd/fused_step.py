@@ -304,7 +304,8 @@ class FusedStep:
                     if S.ema_mode is not None:
                         teng.wts.ema_from(eng.wts, S.ema_alpha, copy_only=S.ema_mode == "copy")
                     tc_early = teng.inference(None, dist_.pseudo_label_threshold, staged=(tea.img, tea.sizes, tea.hw), pl_out=S.pl_out)
-            c = eng._drive(eng.trunk_steps(stu.img, stu.sizes, True, pre=pre_in))
+            # (the flat-container engines override trunk(), not trunk_steps())
+            c = eng._drive(eng.trunk_steps(stu.img, stu.sizes, True, pre=pre_in)) if pre_in is not None else eng.trunk(stu.img, stu.sizes, save=True)
             eng.rpn_head(c, save=True)
         c.N, c.sizes, c.hw, c.geom, c.anchors, c.shapes = N, stu.sizes, stu.hw, geom, anchors, shapes
         pfx = None

@@ -380,3 +380,45 @@ def test_ema_copies_excluded_keys_instead_of_averaging():
     other = slice(0, lo)
     assert torch.allclose(Tm.master[other], 0.9 * t0[other] + 0.1 * S.master[other], atol=1e-6)
     assert not torch.equal(Tm.master[other], S.master[other])
+
+
+def test_two_forwards_then_two_backwards_keep_their_own_stochastic_depth_masks():
+    """the stochastic-depth multipliers live in one persistent device buffer that a refresh overwrites in place; the saved
+    contexts keep VIEWS of them for the backward.  With SOLVER.BACKWARD_AT_END (the reference's default) two training forwards run before their
+    backwards: the first backward must still see the FIRST pass's masks.  Here: forward(A), forward(B), backward(A) == forward(A), backward(A)."""
+    cfg, params, sd, m = _model(7, drop=0.5)
+    dA, dB = _batch(0), _batch(1)
+
+    def fwd(data, seed):
+        torch.manual_seed(seed)
+        return m.forward_train([d["image"] for d in data], [d["instances"] for d in data], roi_seed=seed)
+    keys = ("loss_cls", "loss_box_reg", "loss_rpn_cls", "loss_rpn_loc")
+    # reference: A alone
+    m.drop_gen.manual_seed(11)
+    cA = fwd(dA, 3)
+    params.zero_grad()
+    m.backward(cA, {k: 1.0 for k in keys})
+    torch.cuda.synchronize()
+    g_ref = params.grad.clone()
+    # A, then B (another draw into the same persistent buffer), then A's backward
+    m.drop_gen.manual_seed(11)
+    cA2 = fwd(dA, 3)
+    cB = fwd(dB, 4)
+    params.zero_grad()
+    m.backward(cA2, {k: 1.0 for k in keys})
+    torch.cuda.synchronize()
+    g_two = params.grad.clone()
+    assert float(g_ref.abs().max()) > 0
+    assert _rel(g_two, g_ref) < 1e-3, _rel(g_two, g_ref)          # (float atomics: not bit for bit; foreign masks give rel-L2 ~ 1)
+    # and the second pass's backward sees ITS masks: B alone with the same draw
+    params.zero_grad()
+    m.backward(cB, {k: 1.0 for k in keys})
+    torch.cuda.synchronize()
+    g_b = params.grad.clone()
+    m.drop_gen.manual_seed(11)
+    _ = m.vit.drop_path_scales(len(dA), m.drop_gen)                # (consume A's draw)
+    cB2 = fwd(dB, 4)
+    params.zero_grad()
+    m.backward(cB2, {k: 1.0 for k in keys})
+    torch.cuda.synchronize()
+    assert _rel(g_b, params.grad) < 1e-3
