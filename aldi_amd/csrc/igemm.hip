@@ -1249,6 +1249,10 @@ int dispatch(ConvDev& d, hipStream_t st) {
             if (force == 2) return launch<T, 128, 64, 4, 1, 4, false, true>(d, st);
             if (force == 4) return launch<T, 256, 128, 4, 2, 4, false, true>(d, st);
             if constexpr (sizeof(T) == 2) {
+                // 64 x 64 halo tiles (4 waves of 32 x 32): four times the workgroups of the 128 x 128 count -- for the layers whose 128 x 64 tile count sits just
+                // above a multiple of the 256 CUs (tools/quant_probe.py: 508 -> 516 workgroups = +23 % time)
+                if (force == 16 && (direct & 4) && !d.res_mode) return launch<T, 64, 64, 2, 2, 4, false, true, 1>(d, st);
+                if (force == 16) return launch<T, 64, 64, 2, 2, 4, false, true>(d, st);
                 if (force == 9) return launch<T, 240, 128, 3, 2, 4, false, true>(d, st);
                 if (force == 10 && !g_group) return launch_halo_rs<T, 128>(d, st);
                 if (force == 11 && d.Cin % 64 == 0) return launch_halo64<256, 256, 4, 2>(d, st);
@@ -1275,6 +1279,15 @@ int dispatch(ConvDev& d, hipStream_t st) {
                 // below ~1000 128x128 tiles the tile count of this network sits just above a multiple of the 256 CUs (16800 pixels =
                 // 131.25 row tiles: 264 / 528 tiles) and the last partial round costs as much as a full one; half-width tiles halve that
                 // tail (measured 8-25 % faster on every res3..res5 / FPN p3..p6 3x3 at N = 2 and 4)
+                // igemm_halo_small: long-K layers that do not even give every CU one or two 128 x 64 tiles (res5 conv2: 264 tiles at N = 4, 136 at N = 2)
+                // take 64 x 64 tiles -- four waves of 32 x 32, four times the workgroups per pixel: 32.9 -> 30.4 / 27.7 -> 24.3 us, bit-identical (same K order;
+                // tools/quant_probe.py, profiles/r06_quant_probe.txt).  At res4's K (16 800 px: 528 tiles) and res3's the larger tile wins (31.6 vs 38.3 us).
+                // OFF by default (0; 320 selects res5 conv2): in the step, beside the other stream's workgroups, it measured 0.5 % slower (8.07 vs 8.02 ms).
+                if constexpr (sizeof(T) == 2)
+                    if (tn.igemm_halo_small > 0 && (long)cdiv(d.M, 128) * cdiv(d.Cout, 64) <= tn.igemm_halo_small && d.Cin >= 512) {
+                        if ((direct & 4) && !d.res_mode) return launch<T, 64, 64, 2, 2, 4, false, true, 1>(d, st);
+                        return launch<T, 64, 64, 2, 2, 4, false, true>(d, st);
+                    }
                 if constexpr (sizeof(T) == 2)
                     if ((direct & 4) && !d.res_mode) return launch<T, 128, 64, 4, 1, 4, false, true, 1>(d, st);
                 return launch<T, 128, 64, 4, 1, 4, false, true>(d, st);

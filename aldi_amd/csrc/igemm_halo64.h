@@ -148,28 +148,19 @@ __device__ __forceinline__ void igemm_halo64_body(const ConvDev& p, int bid, con
         const unsigned a_off = (unsigned)(((xkh - 1) * p.W * p.Cin + xci) * 2);
         glds16(rx, &lds_all[st * XS + wbase + it * NT], ((xa_ok >> (3 * it + xkh)) & 1u) ? xa_voff[it] + a_off : OOB);
     };
-    // K order of the groups: (64-channel chunk, kh) with kh INNER since r06 (igemm_dbg 2048 = the r05 order, kh outer).  All workgroups of a launch walk
-    // the groups in step; a pixel's chunk is fetched by three tiles (the one that holds it and the ones an image row above / below) in their kh = 0 / 1 / 2
-    // groups.  With kh outer those are a THIRD OF A TILE apart in time (~15 us) and an XCD streams 4 MB of slabs in between -- its whole L2: every slab
-    // read missed, the launch fetched 2.5 x its input from the fabric (profiles/r05_pmc_conv.txt: FETCH_SIZE 173 MB x 2 against 137 MB).  With kh
-    // inner the three reads are one group (~4 us, 1 MB per XCD) apart.
-    const bool kh_inner = __builtin_amdgcn_readfirstlane(p.dbg & 2048) == 0;
-    auto next_x = [&]() {
-        if (kh_inner) { if (++xkh == 3) { xkh = 0; xci += BK; } }
-        else { xci += BK; if (xci >= p.Cin) { xci = 0; ++xkh; } }
-    };
+    // K order of the groups: (64-channel chunk, kh) with kh INNER since r06 (r05: kh outer).  All workgroups of a launch walk the groups in step; a
+    // pixel's chunk is fetched by three tiles (the one that holds it and the ones an image row above / below) in their kh = 0 / 1 / 2 groups.  With kh
+    // outer those are a THIRD OF A TILE apart in time (~15 us) and an XCD streams 4 MB of slabs in between -- its whole L2: every slab read missed, the
+    // launch fetched 2.5 x its input from the fabric (profiles/r05_pmc_conv.txt: FETCH_SIZE 173 MB x 2 against 137 MB).  With kh inner the three reads
+    // are one group (~4 us, 1 MB per XCD) apart: 102 MB x 2 (profiles/r06_pmc_conv.txt), -8 % kernel time.  (A run-time switch between the two orders
+    // cost 4 more SGPRs than the kernel has: 56 bytes of scratch and a quarter of its speed -- the order is a compile-time fact.)
+    auto next_x = [&]() { if (++xkh == 3) { xkh = 0; xci += BK; } };
     auto issue_w = [&](int it, int st, unsigned w_off) {   // piece `it` of a tap into tap stage st
         if (no_dma) return;
         glds16(rw, &lds_all[2 * XS + st * WS + wbase + it * NT], wa_voff[it] == OOB ? OOB : wa_voff[it] + w_off);
     };
     auto tap_off = [&]() { return (unsigned)(((tkh * 3 + tkw) * p.Cin + tci) * 2); };
-    auto next_tap = [&]() {
-        if (++tkw == 3) {
-            tkw = 0;
-            if (kh_inner) { if (++tkh == 3) { tkh = 0; tci += BK; } }
-            else { tci += BK; if (tci >= p.Cin) { tci = 0; ++tkh; } }
-        }
-    };
+    auto next_tap = [&]() { if (++tkw == 3) { tkw = 0; if (++tkh == 3) { tkh = 0; tci += BK; } } };
 
     // ---- fragment read addresses (stage 0): X rows xrow + kw (the three taps), k-step h = 0 / 1; W rows wrow
     const int xrow = wm * (BM / WM) + fr, wrow = wn * (BN / WN) + fr;

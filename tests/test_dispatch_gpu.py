@@ -1209,3 +1209,25 @@ def test_wgrad_interleaved_loop_equals_lockstep_bit_for_bit():
         assert torch.equal(a, b) and torch.equal(ab, bb)
         assert float(a.abs().max()) > 0
     L.reset_tuning()
+
+
+@pytest.mark.parametrize("case,kind", [((4, 25, 42, 512, 512, 3, 1, 1), "f1"), ((2, 25, 42, 512, 512, 3, 1, 1), "d3"), ((1, 19, 23, 128, 256, 3, 1, 1), "f1x"), ((2, 25, 42, 64, 96, 3, 1, 1), "n")])
+def test_halo_64x64_tile_forced(case, kind):
+    """igemm_force 16 / igemm_halo_small: the 3x3 halo form on 64 x 64 tiles (four waves of 32 x 32), direct epilogue"""
+    _check_direct(case, kind, "igemm<bf16,64,64,2,2,flat,halo,direct>", force=16)
+
+
+def test_halo_small_knob_selects_the_64x64_tile():
+    from aldi_amd import _lib as L
+    from aldi_amd import ops
+    gen = torch.Generator().manual_seed(3)
+    x = torch.randn(2, 25, 42, 512, generator=gen).to("cuda", torch.bfloat16)
+    w = (torch.randn(512, 3, 3, 512, generator=gen) / 68.0).to("cuda", torch.bfloat16)
+    a = ops.conv2d(x, w, pad=1, relu=True)
+    assert L.last_dispatch() == "igemm<bf16,128,64,4,1,flat,halo,direct>", L.last_dispatch()
+    L.set_tuning("igemm_halo_small", 320)
+    b = ops.conv2d(x, w, pad=1, relu=True)
+    assert L.last_dispatch() == "igemm<bf16,64,64,2,2,flat,halo,direct>", L.last_dispatch()
+    torch.cuda.synchronize()
+    assert torch.equal(a, b)                    # same K order per output element
+    L.reset_tuning()
