@@ -654,7 +654,7 @@ def main():
                                                                                                    args.height, "on" if args.align else "off", per, per),
                       "global_batch": imgs_per_step, "parallelism": f"dp{world}",
                       "inputs": "device-resident synthetic batch: no host-to-device copy, no data loader and no augmentation inside the timed region",
-                      "parity": {"fp32_mode": "losses within 1e-3 of the CPU oracle, ROI / anchor indices bit-exact (tests/test_engine_gpu.py, tests/test_configs_gpu.py)",
+                      "parity": {"fp32_mode": "losses within 1e-3 of the CPU oracle, ROI / anchor indices bit-exact: at 192x256 over whole ALDI iterations (tests/test_engine_gpu.py, tests/test_configs_gpu.py) and at THIS size, 800x1333, for one source micro-step and one teacher inference pass (tests/test_fullsize_gpu.py::test_fullsize_source_step_vs_oracle_fp32, ::test_fullsize_teacher_inference_vs_oracle_fp32)",
                                  "measured_dtype_vs_fp32_mode": "bf16 with the fp32 run's proposals and pseudo labels injected: every sampled index identical, losses within 2 %, "
                                                                 "per-group gradient cosine >= 0.99 and rel-L2 <= 3e-2 (tests/test_configs_gpu.py::test_benchmark_step_bf16_vs_fp32_parity_mode)",
                                  "this_line": "the throughput is the %s step; the 1e-3 loss bound is shown in the fp32 parity mode, not in this dtype" % ("fp32" if args.fp32 else "bf16")},
@@ -718,6 +718,7 @@ def main():
                            "traffic": _traffic_per_launch(tj, "igemm", ig["launches"]),
                            "traffic_unit": "HBM bytes per igemm launch, rocprofv3 PMC passes of this command (FETCH_SIZE x2 + WRITE_SIZE)",
                            "traffic_source": tfile if tj else ("no profiles/r*_pmc_traffic.json matches this source tree (tools/source_hash.py)" if headline else "counter passes are collected for the headline workload only"),
+                           "peak_note": "peak = the dense bf16 MFMA figure of MI355X_MICROARCH.md.  With real operand data the chip does not hold the clock that figure assumes: a register / LDS-fed loop of independent v_mfma_f32_16x16x32_bf16 at 0.98 pipe occupancy sustains 2 460 TFLOP/s on near-constant operands (2.39 GHz) and 1 930 TFLOP/s on hashed bf16 operands (1.9 GHz); 32x32x16: 1 717 (profiles/r06_mfma_issue_probe.txt, tools/probes/mfma_issue_probe.hip)",
                            "timing": "HIP events around every dense launch of ONE extra step issued eagerly on ONE stream (ALDI_WGRAD_STREAM / TEACHER_STREAM / AUX_STREAM off), i.e. each kernel alone on the chip" + ("" if not headline else "; the matching rocprofv3 --kernel-trace --stats summary of the same single-stream step is " + _latest_profile("kernel_stats_single_stream.txt") + " (the multi-stream step's is " + _latest_profile("kernel_stats.txt") + ": co-resident kernels run longer there)"),
                            "algorithmic_bytes_per_launch": round(ig["bytes"] / max(ig["launches"], 1)),
                            "launches_per_step": ig["launches"], "kernel_ms_per_step": round(ig["ms"], 3), "event_pair_us_subtracted": prof.get("event_pair_us"),
