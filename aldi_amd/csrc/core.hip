@@ -59,6 +59,7 @@ const Knob kKnobs[] = {
     {"wgrad_xcd", &AldiTuning::wgrad_xcd, 1},
     {"igemm_halo_ilv", &AldiTuning::igemm_halo_ilv, 1},
     {"igemm_halo_small", &AldiTuning::igemm_halo_small, 0},
+    {"igemm_halo96", &AldiTuning::igemm_halo96, 0},
     {"wgrad_dma", &AldiTuning::wgrad_dma, 0},
     {"wgrad_dbg", &AldiTuning::wgrad_dbg, 0},
     {"wgrad_group_slots", &AldiTuning::wgrad_group_slots, 0},

@@ -1251,6 +1251,10 @@ int dispatch(ConvDev& d, hipStream_t st) {
             if constexpr (sizeof(T) == 2) {
                 // 64 x 64 halo tiles (4 waves of 32 x 32): four times the workgroups of the 128 x 128 count -- for the layers whose 128 x 64 tile count sits just
                 // above a multiple of the 256 CUs (tools/quant_probe.py: 508 -> 516 workgroups = +23 % time)
+                // 96 x 64 halo tiles on THREE waves (32 x 64 per wave, as in the 128 x 64 tile): 4/3 of its workgroups -- tools/quant_probe.py: a CU runs three
+                // 128 x 64 workgroups in 1.23 x the time of two, and the mid-size layers of this network give it 2.06 (528 tiles) or 1.03 (264)
+                if (force == 17 && (direct & 4) && !d.res_mode) return launch<T, 96, 64, 3, 1, 4, false, true, 1>(d, st);
+                if (force == 17) return launch<T, 96, 64, 3, 1, 4, false, true>(d, st);
                 if (force == 16 && (direct & 4) && !d.res_mode) return launch<T, 64, 64, 2, 2, 4, false, true, 1>(d, st);
                 if (force == 16) return launch<T, 64, 64, 2, 2, 4, false, true>(d, st);
                 if (force == 9) return launch<T, 240, 128, 3, 2, 4, false, true>(d, st);
@@ -1283,6 +1287,16 @@ int dispatch(ConvDev& d, hipStream_t st) {
                 // take 64 x 64 tiles -- four waves of 32 x 32, four times the workgroups per pixel: 32.9 -> 30.4 / 27.7 -> 24.3 us, bit-identical (same K order;
                 // tools/quant_probe.py, profiles/r06_quant_probe.txt).  At res4's K (16 800 px: 528 tiles) and res3's the larger tile wins (31.6 vs 38.3 us).
                 // OFF by default (0; 320 selects res5 conv2): in the step, beside the other stream's workgroups, it measured 0.5 % slower (8.07 vs 8.02 ms).
+                // igemm_halo96: layers with 200 .. 600 tiles of 128 x 64 (one or two per CU and a few left over: res4 conv2 at both batch sizes, res5 / res3 conv2
+                // at one of them) on 96 x 64 three-wave tiles: 2-6 % faster alone, bit-identical (profiles/r06_quant_probe.txt)
+                if constexpr (sizeof(T) == 2)
+                    if (tn.igemm_halo96 > 0) {
+                        const long t64 = (long)cdiv(d.M, 128) * cdiv(d.Cout, 64);
+                        if (t64 >= 200 && t64 <= 600) {
+                            if ((direct & 4) && !d.res_mode) return launch<T, 96, 64, 3, 1, 4, false, true, 1>(d, st);
+                            return launch<T, 96, 64, 3, 1, 4, false, true>(d, st);
+                        }
+                    }
                 if constexpr (sizeof(T) == 2)
                     if (tn.igemm_halo_small > 0 && (long)cdiv(d.M, 128) * cdiv(d.Cout, 64) <= tn.igemm_halo_small && d.Cin >= 512) {
                         if ((direct & 4) && !d.res_mode) return launch<T, 64, 64, 2, 2, 4, false, true, 1>(d, st);

@@ -37,7 +37,7 @@ int aldi_noop(aldi_stream_t stream);
  *   igemm_force          0 heuristics | 1 128x128 | 2 128x64 | 3 64x64 | 4 256x128 | 5 128x16 tile of aldi_conv_igemm |
  *                        6 / 7 / 8: the 128x128 / 128x64 / 64x64 tile with 128-byte K slabs (plain 1x1 / linear layers) |
  *                        9 / 10 (3x3 halo form only): 240x128 on six waves, two workgroups per CU / 256x128 role-split |
- *                        16 (3x3 halo form, bf16): 64x64 tiles;
+ *                        16 / 17 (3x3 halo form, bf16): 64x64 tiles / 96x64 tiles on three waves;
  *                        11 / 13 / 15 (3x3 halo form, bf16, Cin % 64 == 0): the 256x256 / 128x128 / 256x256-on-four-waves tile with 128-byte K slabs (igemm_halo64.h);
  *                        14 (plain 1x1, bf16): the weight-stationary persistent kernel (igemm_ws.h)
  *   igemm_k64_min        plain 1x1 / linear layers with K >= this (and K % 64 == 0) take the 64x64 128-byte-slab form (1024)
@@ -53,6 +53,7 @@ int aldi_noop(aldi_stream_t stream);
  *   igemm_halo64_mid     mid-size 3x3 layers with at least this many 128x128 tiles take the 128x128 tile with 128-byte K slabs (0 = never, the
  *                        default: measured 10-20 % slower than the 128x64 tiles on res3 / res4 conv2 -- those layers are bound by workgroup count)
  *   igemm_halo_small     3x3 layers with Cin >= 512 and at most this many 128x64 tiles take 64x64 halo tiles (0 = never, the default; 320 = res5 conv2: faster alone, 0.5 % slower in the step)
+ *   igemm_halo96         1 = 3x3 layers with 200-600 tiles of 128x64 take 96x64 three-wave tiles (0 = never, the default: 2-6 % faster alone, neutral in the step)
  *   igemm_halo_ilv       1 = the 256x256 halo64 tile runs its interleaved K loop (reads / DMA pieces between the MFMAs; 0 = the lockstep loop of r05)
  *   igemm_ws             1 = plain 1x1 bf16 layers with K = Cin in {64, 128, 256, 512}, whole groups of 256 (K >= 256: 128) output channels and at least
  *                        igemm_ws_min (40000: res3 / p2-size maps of the student; measured equal or slower below) pixels run the weight-stationary persistent kernel (igemm_ws.h: weights in registers, pixel tiles streamed

@@ -1231,3 +1231,25 @@ def test_halo_small_knob_selects_the_64x64_tile():
     torch.cuda.synchronize()
     assert torch.equal(a, b)                    # same K order per output element
     L.reset_tuning()
+
+
+@pytest.mark.parametrize("case,kind", [((4, 50, 84, 256, 256, 3, 1, 1), "f1"), ((2, 50, 84, 256, 256, 3, 1, 1), "d3"), ((1, 19, 23, 128, 256, 3, 1, 1), "f1x"), ((2, 25, 42, 64, 96, 3, 1, 1), "n")])
+def test_halo_96x64_three_wave_tile_forced(case, kind):
+    """igemm_force 17 / igemm_halo96: the 3x3 halo form on 96 x 64 tiles (three waves of 32 x 64), direct epilogue"""
+    _check_direct(case, kind, "igemm<bf16,96,64,3,1,flat,halo,direct>", force=17)
+
+
+def test_halo96_knob_selects_the_three_wave_tile_bit_identically():
+    from aldi_amd import _lib as L
+    from aldi_amd import ops
+    gen = torch.Generator().manual_seed(4)
+    x = torch.randn(4, 50, 84, 256, generator=gen).to("cuda", torch.bfloat16)
+    w = (torch.randn(256, 3, 3, 256, generator=gen) / 48.0).to("cuda", torch.bfloat16)
+    a = ops.conv2d(x, w, pad=1, relu=True)
+    assert L.last_dispatch() == "igemm<bf16,128,64,4,1,flat,halo,direct>", L.last_dispatch()
+    L.set_tuning("igemm_halo96", 1)
+    b = ops.conv2d(x, w, pad=1, relu=True)
+    assert L.last_dispatch() == "igemm<bf16,96,64,3,1,flat,halo,direct>", L.last_dispatch()
+    torch.cuda.synchronize()
+    assert torch.equal(a, b)                    # same K order per output element
+    L.reset_tuning()
