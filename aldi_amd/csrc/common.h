@@ -19,7 +19,7 @@ struct AldiTuning {
     int igemm_xcd, igemm_tile, igemm_dbg, igemm_bigtile_min, igemm_bigtile_k, igemm_lintile_min, igemm_halo, igemm_force, igemm_group, igemm_k64_min, igemm_bigtile, igemm_narrow_k, igemm_splitk_tile, igemm_halo_f32, igemm_f32_tile64_max, igemm_direct, igemm_lean, igemm_halo64_mid, igemm_ws, igemm_ws_wgs, igemm_ws_min, igemm_halo_ilv, igemm_halo_small, igemm_halo96;
     int wgrad_lean, wgrad_big_min, wgrad_big_slots, wgrad_slots, wgrad_xcd, wgrad_dma, wgrad_dbg, wgrad_group_slots, wgrad_group_epi, roialign_sep, roialign_bwd_rows, wgrad_db, wgrad_ordered, wgrad_big_group, wgrad_big_epi, wgrad_big_group_min, wgrad_lds_pad_kb, wgrad_f32_tile128, wgrad_dma64, wgrad_ilv, msda_gather, msda_gather_list, msda_bin, msda_bin_list;
     int colsum_blocks, colsum_minrows, colsum_nt, colsum_block_kb;
-    int stem_mfma, sab_blocks, ln_bwd_blocks, ln_bwd_blocks_narrow, rpn_topk_fused, ema_blocks, nms_mask_tri;
+    int stem_mfma, sab_blocks, ln_bwd_blocks, ln_bwd_blocks_narrow, rpn_topk_fused, ema_blocks, nms_mask_tri, match_wave;
 };
 AldiTuning& aldi_tuning();
 void aldi_note_dispatch(const char* kernel);   // what aldi_last_dispatch() reports (thread local)

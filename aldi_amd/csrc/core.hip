@@ -90,6 +90,7 @@ const Knob kKnobs[] = {
     {"rpn_topk_fused", &AldiTuning::rpn_topk_fused, 1},
     {"ema_blocks", &AldiTuning::ema_blocks, 2048},
     {"nms_mask_tri", &AldiTuning::nms_mask_tri, 1},
+    {"match_wave", &AldiTuning::match_wave, 1},
 };
 AldiTuning make_tuning() {
     AldiTuning t;

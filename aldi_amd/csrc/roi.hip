@@ -1103,7 +1103,7 @@ extern "C" int aldi_roi_prepare(const float* props, const int* pcount, int P, co
     hipLaunchKernelGGL(roi_append_gt_kernel, dim3(cdiv(L, 256), N), dim3(256), 0, st, (const float4*)props, pcount, P, (const float4*)gt_boxes, gt_count, Gmax,
                        (float4*)cand, ccount, L);
     ALDI_CHECK_LAUNCH();
-    int rc = aldi_box_match(cand, L, ccount, L, gt_boxes, gt_count, Gmax, N, iou_thresh, iou_thresh, 0, best_iou, best_idx, gt_best_scratch, labels, stream);
+    int rc = aldi_box_match(cand, L, ccount, L, gt_boxes, gt_count, Gmax, N, iou_thresh, iou_thresh, 0, best_iou, best_idx, gt_best_scratch, sizeof(unsigned) * (size_t)N * Gmax, labels, stream);
     if (rc) return rc;
     hipLaunchKernelGGL(roi_classes_kernel, dim3(cdiv(L, 256), N), dim3(256), 0, st, labels, best_idx, gt_classes, gt_count, Gmax, L, K, cls);
     ALDI_CHECK_LAUNCH();

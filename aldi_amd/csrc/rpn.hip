@@ -134,6 +134,146 @@ __global__ __launch_bounds__(1024) void match_iou_kernel(const float4* __restric
     }
 }
 
+// r06: the same matcher with the GT list culled PER WAVE instead of per workgroup.  The kernels are bound by VALU issue (tools/match_bench.py: the time
+// grows by ~1 us per GT box, 116 us at 100 boxes on four images; replacing the global atomics by plain stores changes nothing): a workgroup's 1024
+// anchors are one feature row of p2, whose union box is as wide as the image and meets every GT that crosses the row (~16 of 100), and every wave walked
+// that list.  A wave's 64 anchors are ~21 neighbouring pixels: their union meets 2-3 GTs.  Every wave builds its own list, IN GT ORDER (ballot
+// compaction), from the GT tile in LDS; first maximum, per-GT best and the low-quality rule are unchanged -- same labels bit for bit.
+struct WaveUnion { float x0, y0, x1, y1; };
+__device__ __forceinline__ WaveUnion wave_union(const float4 b, bool active) {
+    float x0 = active ? b.x : INFINITY, y0 = active ? b.y : INFINITY, x1 = active ? b.z : -INFINITY, y1 = active ? b.w : -INFINITY;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        x0 = fminf(x0, __shfl_xor(x0, o, 64)); y0 = fminf(y0, __shfl_xor(y0, o, 64));
+        x1 = fmaxf(x1, __shfl_xor(x1, o, 64)); y1 = fmaxf(y1, __shfl_xor(y1, o, 64));
+    }
+    return WaveUnion{x0, y0, x1, y1};
+}
+// the GTs of the tile in LDS (count nt) that meet this wave's union, ascending, into wl[]; returns their number (wave uniform)
+__device__ __forceinline__ int wave_hits(const float4* sgt, const unsigned* skip_zero, int nt, const WaveUnion u, unsigned char* wl) {
+    const int lane = threadIdx.x & 63;
+    int n = 0;
+    for (int t = 0; t < nt; t += 64) {
+        const int g = t + lane;
+        bool hit = false;
+        if (g < nt) {
+            const float4 q = sgt[g];
+            hit = fminf(q.z, u.x1) - fmaxf(q.x, u.x0) > 0.f && fminf(q.w, u.y1) - fmaxf(q.y, u.y0) > 0.f && (skip_zero == nullptr || skip_zero[g] != 0u);
+        }
+        const unsigned long long m = __ballot(hit);
+        if (hit) wl[n + __popcll(m & ((1ull << lane) - 1ull))] = (unsigned char)g;
+        n += __popcll(m);
+    }
+    return n;
+}
+
+template <int NT>
+__global__ __launch_bounds__(NT) void match_iou_wave_kernel(const float4* __restrict__ boxes, long box_stride_n, const int* __restrict__ box_count, int L,
+                                                            const float4* __restrict__ gt, const int* __restrict__ gt_count, int Gmax,
+                                                            float* __restrict__ best_iou, int* __restrict__ best_idx, unsigned* __restrict__ gt_best, int gstride) {
+    constexpr int NW = NT / 64;
+    static_assert(kGtTile == 256, "GT indices of a tile fit a byte");
+    __shared__ float4 sgt[kGtTile];
+    __shared__ unsigned smax[kGtTile];
+    __shared__ unsigned char wlist[NW][kGtTile];
+    const int n = blockIdx.y, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int i = blockIdx.x * NT + tid;
+    const int cnt = box_count ? box_count[n] : L;
+    const bool active = i < cnt;
+    const int G = gt_count[n];
+    const float4 b = active ? boxes[n * box_stride_n + i] : make_float4(0.f, 0.f, 0.f, 0.f);
+    const WaveUnion u = wave_union(b, active);
+    float best = G > 0 ? 0.f : -1.f;       // (the first GT always takes the running maximum to >= 0 with index 0; later ones must be strictly greater)
+    int bi = 0;
+    for (int g0 = 0; g0 < G; g0 += kGtTile) {
+        const int nt = min(kGtTile, G - g0);
+        __syncthreads();                   // (the previous tile's readers are done)
+        if (tid < kGtTile) {
+            smax[tid] = 0u;
+            if (tid < nt) sgt[tid] = gt[n * Gmax + g0 + tid];
+        }
+        __syncthreads();
+        const int nl = wave_hits(sgt, nullptr, nt, u, wlist[w]);
+        for (int k = 0; k < nl; ++k) {
+            const int g = wlist[w][k];
+            const float4 gb = sgt[g];
+            const bool ov = active && fminf(gb.z, b.z) - fmaxf(gb.x, b.x) > 0.f && fminf(gb.w, b.w) - fmaxf(gb.y, b.y) > 0.f;
+            if (!__ballot(ov)) continue;
+            const float v = ov ? iou_d2(gb, b) : 0.f;
+            if (v > best) { best = v; bi = g0 + g; }
+            if (__ballot(v > 0.f)) {
+                const unsigned wm = wave_max_u32(__float_as_uint(v));       // (IoUs are >= 0: their bit patterns order like the values)
+                if (lane == 0) atomicMax(&smax[g], wm);
+            }
+        }
+        __syncthreads();
+        if (tid < nt && smax[tid] != 0u) {
+            // (read first and only raise the maximum: a stale read is lower than the truth, so skipping is always safe)
+            // gstride 32: every GT's word in its OWN 128-byte line.  Packed (400 bytes for 100 GTs = 4 lines) the ~4 000 device-scope loads / atomics of
+            // an image serialise on those lines at the memory side: the matcher's time grew by 0.76 us per GT box (tools/match_bench.py)
+            unsigned* dst = gt_best + ((long)n * Gmax + g0 + tid) * gstride;
+            if (__hip_atomic_load(dst, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < smax[tid]) atomicMax(dst, smax[tid]);
+        }
+    }
+    if (active) {
+        best_iou[(long)n * L + i] = best;
+        best_idx[(long)n * L + i] = bi;
+    }
+}
+
+__global__ __launch_bounds__(256) void match_label_wave_kernel(const float4* __restrict__ boxes, long box_stride_n, const int* __restrict__ box_count, int L,
+                                                               const float4* __restrict__ gt, const int* __restrict__ gt_count, int Gmax,
+                                                               const float* __restrict__ best_iou, const unsigned* __restrict__ gt_best, int gstride,
+                                                               float lo, float hi, int allow_low_quality, int* __restrict__ labels) {
+    __shared__ float4 sgt[kGtTile];
+    __shared__ unsigned sbest[kGtTile];
+    __shared__ unsigned char wlist[4][kGtTile];
+    __shared__ int s_zero;
+    const int n = blockIdx.y, tid = threadIdx.x, w = tid >> 6;
+    const int i = blockIdx.x * blockDim.x + tid;
+    const int cnt = box_count ? box_count[n] : L;
+    const int G = gt_count[n];
+    const bool active = i < cnt;
+    int lab = -2;                                               // padding slot, never sampled
+    if (active) {
+        if (G == 0) lab = 0;
+        else {
+            const float v = best_iou[(long)n * L + i];
+            lab = v < lo ? 0 : (v < hi ? -1 : 1);
+        }
+    }
+    if (allow_low_quality && G > 0) {                           // (block uniform)
+        // low-quality rule: IoU == the GT's best over all boxes.  A GT nothing overlaps has best 0 and claims EVERY box (the
+        // reference's `match_quality_matrix == highest_quality_foreach_gt`); the others can only claim boxes they overlap.
+        const float4 b = active ? boxes[n * box_stride_n + i] : make_float4(0.f, 0.f, 0.f, 0.f);
+        const WaveUnion u = wave_union(b, active);
+        if (tid == 0) s_zero = 0;
+        bool done = false;
+        for (int g0 = 0; g0 < G; g0 += kGtTile) {
+            const int nt = min(kGtTile, G - g0);
+            __syncthreads();
+            if (tid < nt) {
+                sgt[tid] = gt[n * Gmax + g0 + tid];
+                const unsigned top = gt_best[((long)n * Gmax + g0 + tid) * gstride];
+                sbest[tid] = top;
+                if (top == 0u) s_zero = 1;
+            }
+            __syncthreads();
+            const int nl = wave_hits(sgt, sbest, nt, u, wlist[w]);
+            if (active && !done)
+                for (int k = 0; k < nl; ++k) {
+                    const int g = wlist[w][k];
+                    const float4 gb = sgt[g];
+                    if (fminf(gb.z, b.z) - fmaxf(gb.x, b.x) > 0.f && fminf(gb.w, b.w) - fmaxf(gb.y, b.y) > 0.f &&
+                        __float_as_uint(iou_d2(gb, b)) == sbest[g]) { lab = 1; done = true; break; }
+                }
+        }
+        __syncthreads();
+        if (active && s_zero) lab = 1;
+    }
+    if (i < L) labels[(long)n * L + i] = lab;
+}
+
 __global__ __launch_bounds__(256) void match_label_kernel(const float4* __restrict__ boxes, long box_stride_n, const int* __restrict__ box_count, int L,
                                                           const float4* __restrict__ gt, const int* __restrict__ gt_count, int Gmax,
                                                           const float* __restrict__ best_iou, const unsigned* __restrict__ gt_best,
@@ -825,16 +965,29 @@ Geom make_geom(const aldi_rpn_geom* gm, float* const* head, float* const* grad) 
 extern "C" int aldi_box_match(const float* boxes, long box_stride_n, const int* box_count, int L,
                               const float* gt_boxes, const int* gt_count, int Gmax, int N,
                               float lo, float hi, int allow_low_quality,
-                              float* best_iou, int* best_idx, unsigned* gt_best_scratch, int* labels, aldi_stream_t stream) {
+                              float* best_iou, int* best_idx, unsigned* gt_best_scratch, size_t gt_best_bytes, int* labels, aldi_stream_t stream) {
     if (!boxes || !gt_boxes || !gt_count || !best_iou || !best_idx || !gt_best_scratch || !labels) return aldi_set_error_msg(ALDI_ERR_ARG, "box_match: null pointer");
+    if (gt_best_bytes < sizeof(unsigned) * (size_t)N * Gmax) return aldi_set_error_msg(ALDI_ERR_ARG, "box_match: gt_best_scratch smaller than N * Gmax words");
     hipStream_t st = static_cast<hipStream_t>(stream);
-    hipError_t e = hipMemsetAsync(gt_best_scratch, 0, sizeof(unsigned) * (size_t)N * Gmax, st);
+    // one word per GT, or (a scratch of N * Gmax * 128 bytes) one 128-byte line per GT: see match_iou_wave_kernel
+    const int gstride = gt_best_bytes >= (size_t)N * Gmax * 128 ? 32 : 1;
+    hipError_t e = hipMemsetAsync(gt_best_scratch, 0, sizeof(unsigned) * (size_t)N * Gmax * gstride, st);
     if (e != hipSuccess) return aldi_set_error(e, __FILE__, __LINE__);
     dim3 grid(cdiv(L, 256), N);
     // anchors (spatially ordered, ~268 k per image): big workgroups = few global atomics per GT; proposals (a few thousand,
     // unordered: every GT is on every workgroup's list): one wave per workgroup so that they spread over the chip
     const bool big = (long)L * N >= (1 << 16);
     const int parts = !big && Gmax <= kGtTile ? 4 : 1;       // (the split keeps GT order only within one list tile)
+    const bool wave_cull = (big && aldi_tuning().match_wave != 0) || gstride != 1;       // (the padded scratch is the wave kernels' layout)     // the anchors: per-wave GT lists (r06; match_wave 0 = the per-workgroup lists)
+    if (wave_cull) {
+        hipLaunchKernelGGL(match_iou_wave_kernel<1024>, dim3(cdiv(L, 1024), N), dim3(1024), 0, st, (const float4*)boxes, box_stride_n, box_count, L,
+                           (const float4*)gt_boxes, gt_count, Gmax, best_iou, best_idx, gt_best_scratch, gstride);
+        ALDI_CHECK_LAUNCH();
+        hipLaunchKernelGGL(match_label_wave_kernel, grid, dim3(256), 0, st, (const float4*)boxes, box_stride_n, box_count, L, (const float4*)gt_boxes, gt_count, Gmax,
+                           best_iou, gt_best_scratch, gstride, lo, hi, allow_low_quality, labels);
+        ALDI_CHECK_LAUNCH();
+        return ALDI_OK;
+    }
     hipLaunchKernelGGL(match_iou_kernel, dim3(cdiv(L, big ? 1024 : 64), N), dim3(big ? 1024 : 64 * parts), 0, st, (const float4*)boxes, box_stride_n, box_count, L,
                        (const float4*)gt_boxes, gt_count, Gmax, best_iou, best_idx, gt_best_scratch, parts);
     ALDI_CHECK_LAUNCH();

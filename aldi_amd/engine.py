@@ -747,7 +747,7 @@ class RCNN:
         best_iou = torch.empty((N, sumA), dtype=torch.float32, device=dev)
         best_idx = torch.empty((N, sumA), dtype=torch.int32, device=dev)
         labels = torch.empty((N, sumA), dtype=torch.int32, device=dev)
-        scratch = torch.empty((N, GMAX), dtype=torch.int32, device=dev)
+        scratch = ops.box_match_scratch(N, GMAX, dev)
         ops.box_match(anchors, 0, None, sumA, gt["boxes"], gt["count"], GMAX, N, self.p.rpn_iou[0], self.p.rpn_iou[1], True, best_iou, best_idx, scratch, labels)
         lists = torch.empty((N, 2, sumA), dtype=torch.int32, device=dev)
         counts = torch.empty((N, 2), dtype=torch.int32, device=dev)

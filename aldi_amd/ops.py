@@ -439,8 +439,14 @@ def ptrs(ts: Optional[Sequence[Optional[torch.Tensor]]]):
 
 
 def box_match(boxes, box_stride_n, box_count, Lb, gt_boxes, gt_count, Gmax, N, lo, hi, lowq, best_iou, best_idx, scratch, labels):
+    """scratch: >= N * Gmax int32 words; N * Gmax * 32 words give every GT's best-IoU word its own 128-byte line (box_match_scratch)"""
     L.call("aldi_box_match", _p(boxes), box_stride_n, _p(box_count), Lb, _p(gt_boxes), _p(gt_count), Gmax, N, lo, hi, int(lowq),
-           _p(best_iou), _p(best_idx), _p(scratch), _p(labels), stream_ptr())
+           _p(best_iou), _p(best_idx), _p(scratch), scratch.numel() * scratch.element_size(), _p(labels), stream_ptr())
+
+
+def box_match_scratch(N: int, Gmax: int, device) -> torch.Tensor:
+    """the matcher's per-GT scratch in its padded layout (one 128-byte line per GT)"""
+    return torch.empty((N, Gmax * 32), dtype=torch.int32, device=device)
 
 
 def stage_images(images, batch: torch.Tensor) -> None:

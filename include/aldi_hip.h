@@ -310,11 +310,12 @@ typedef struct {
 /* Matcher: boxes [*(N)][L][4] (box_stride_n = 0 when shared by all images, else L), optional
  * per-image box_count; gt [N][Gmax][4] + gt_count[N] (device).  labels: iou<lo -> 0,
  * lo<=iou<hi -> -1, >=hi -> 1, low-quality matches -> 1; padding slots -> -2.
- * best_idx = argmax GT (first max).  gt_best_scratch: [N][Gmax] uint32. */
+ * best_idx = argmax GT (first max).  gt_best_scratch: gt_best_bytes >= N * Gmax * 4 ([N][Gmax] uint32: the per-GT best IoU bits); with
+ * N * Gmax * 128 bytes every GT's word gets its own 128-byte line ([N][Gmax][32]: the anchor matcher's same-line atomics no longer serialise). */
 int aldi_box_match(const float* boxes, long box_stride_n, const int* box_count, int L,
                    const float* gt_boxes, const int* gt_count, int Gmax, int N,
                    float lo, float hi, int allow_low_quality,
-                   float* best_iou, int* best_idx, unsigned* gt_best_scratch, int* labels, aldi_stream_t stream);
+                   float* best_iou, int* best_idx, unsigned* gt_best_scratch, size_t gt_best_bytes, int* labels, aldi_stream_t stream);
 /* subsample_labels, step 1: ordered index lists. lists [N][2][L] (0: positives = not -1/-2/bg,
  * 1: negatives = bg), counts [N][2].  workspace: aldi_compact_labels_workspace(L, N) bytes (per-segment counts). */
 size_t aldi_compact_labels_workspace(int L, int N);

@@ -761,3 +761,41 @@ def test_avgpool_large_and_small_maps(shape):
     xf = x.float()
     yf = ops.avgpool(xf)
     assert (yf - ref).abs().max().item() <= 1e-5
+
+
+@pytest.mark.parametrize("G", [0, 1, 7, 100, "ragged"])
+def test_anchor_matcher_per_wave_lists_equal_per_workgroup_lists(G):
+    """match_wave 1 (default, r06: every wave culls the GT list against ITS 64 anchors' union box) vs 0 (one list per 1024-anchor workgroup): labels,
+    matched indices and IoUs bit for bit, at the benchmark's anchor count, incl. images without GT, a GT nothing overlaps (the low-quality rule's
+    'claims every box' case) and different counts per image"""
+    from aldi_amd import _lib as L
+    from aldi_amd import ops
+    from aldi_amd.engine import GMAX, make_anchors
+    shapes = [(200, 336), (100, 168), (50, 84), (25, 42), (13, 21)]
+    anchors = make_anchors(shapes, DEV)
+    N, sumA = 4, anchors.shape[0]
+    g = torch.Generator().manual_seed(5)
+    counts = [100, 0, 13, GMAX] if G == "ragged" else [G] * N
+    gb = torch.zeros(N, GMAX, 4)
+    for i, k in enumerate(counts):
+        w = torch.rand(k, generator=g) * 200 + 4; h = torch.rand(k, generator=g) * 150 + 4
+        x = torch.rand(k, generator=g) * 1300; y = torch.rand(k, generator=g) * 780
+        gb[i, :k] = torch.stack([x, y, x + w, y + h], 1)
+    if G == "ragged":
+        gb[0, 3] = torch.tensor([5000.0, 5000.0, 5010.0, 5010.0])        # overlaps no anchor: best IoU 0
+    gbd, cntd = gb.to(DEV), torch.tensor(counts, dtype=torch.int32, device=DEV)
+    out = {}
+    for mode in (2, 1, 0):                   # 2: per-wave lists + one 128-byte line per GT in the scratch (the engine's form), 1: per-wave lists, packed scratch
+        L.reset_tuning(); L.set_tuning("match_wave", min(mode, 1))
+        best_iou = torch.empty(N, sumA, device=DEV); best_idx = torch.empty(N, sumA, dtype=torch.int32, device=DEV)
+        labels = torch.empty(N, sumA, dtype=torch.int32, device=DEV)
+        scratch = ops.box_match_scratch(N, GMAX, DEV) if mode == 2 else torch.empty(N, GMAX, dtype=torch.int32, device=DEV)
+        ops.box_match(anchors, 0, None, sumA, gbd, cntd, GMAX, N, 0.3, 0.7, True, best_iou, best_idx, scratch, labels)
+        torch.cuda.synchronize()
+        out[mode] = (best_iou, best_idx, labels, scratch.view(N, GMAX, -1)[:, :, 0].contiguous())
+    L.reset_tuning()
+    for m in (2, 1):
+        for a, b in zip(out[m], out[0]):
+            assert torch.equal(a, b)
+    if G != 0:
+        assert int((out[1][2] == 1).sum()) > 0

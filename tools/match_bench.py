@@ -26,7 +26,7 @@ for G in (0, 8, 100):
     cnt = torch.full((N,), G, dtype=torch.int32)
     gbd, cntd = gb.to(DEV), cnt.to(DEV)
     best_iou = torch.empty(N, sumA, device=DEV); best_idx = torch.empty(N, sumA, dtype=torch.int32, device=DEV)
-    labels = torch.empty(N, sumA, dtype=torch.int32, device=DEV); scratch = torch.empty(N, GMAX, dtype=torch.int32, device=DEV)
+    labels = torch.empty(N, sumA, dtype=torch.int32, device=DEV); scratch = ops.box_match_scratch(N, GMAX, DEV) if os.environ.get("PACKED") != "1" else torch.empty(N, GMAX, dtype=torch.int32, device=DEV)
     lists = torch.empty(N, 2, sumA, dtype=torch.int32, device=DEV); counts = torch.empty(N, 2, dtype=torch.int32, device=DEV)
     t1 = timeit(lambda: ops.box_match(anchors, 0, None, sumA, gbd, cntd, GMAX, N, 0.3, 0.7, True, best_iou, best_idx, scratch, labels))
     t2 = timeit(lambda: ops.compact_labels(labels, sumA, N, 0, lists, counts))
