@@ -347,7 +347,7 @@ class FusedStep:
                 if S.ema_mode is not None:                   # the EMA tick of this iteration (aldi/trainer.py:242-246), beside the student's forward
                     teng.wts.ema_from(eng.wts, S.ema_alpha, copy_only=S.ema_mode == "copy")
                 return teng.inference(None, dist_.pseudo_label_threshold, staged=(tea.img, tea.sizes, tea.hw), pl_out=S.pl_out)
-            if tside is not None and self.teacher_first and not pair:
+            if tside is not None and self.teacher_first and not pair and not inter:      # (the knob applies to the non-interleaved issue order only)
                 tc = tc_early
                 main.wait_stream(tside)
             elif tside is not None:
