@@ -409,7 +409,7 @@ def test_two_forwards_then_two_backwards_keep_their_own_stochastic_depth_masks()
     torch.cuda.synchronize()
     g_two = params.grad.clone()
     assert float(g_ref.abs().max()) > 0
-    assert _rel(g_two, g_ref) < 1e-3, _rel(g_two, g_ref)          # (float atomics: not bit for bit; foreign masks give rel-L2 ~ 1)
+    assert l2err(g_two, g_ref) < 1e-3, l2err(g_two, g_ref)          # (float atomics: not bit for bit; foreign masks give rel-L2 ~ 1)
     # and the second pass's backward sees ITS masks: B alone with the same draw
     params.zero_grad()
     m.backward(cB, {k: 1.0 for k in keys})
@@ -421,4 +421,4 @@ def test_two_forwards_then_two_backwards_keep_their_own_stochastic_depth_masks()
     params.zero_grad()
     m.backward(cB2, {k: 1.0 for k in keys})
     torch.cuda.synchronize()
-    assert _rel(g_b, params.grad) < 1e-3
+    assert l2err(g_b, params.grad) < 1e-3
