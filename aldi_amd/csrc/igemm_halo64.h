@@ -152,8 +152,10 @@ __device__ __forceinline__ void igemm_halo64_body(const ConvDev& p, int bid, con
     // pixel's chunk is fetched by three tiles (the one that holds it and the ones an image row above / below) in their kh = 0 / 1 / 2 groups.  With kh
     // outer those are a THIRD OF A TILE apart in time (~15 us) and an XCD streams 4 MB of slabs in between -- its whole L2: every slab read missed, the
     // launch fetched 2.5 x its input from the fabric (profiles/r05_pmc_conv.txt: FETCH_SIZE 173 MB x 2 against 137 MB).  With kh inner the three reads
-    // are one group (~4 us, 1 MB per XCD) apart: 102 MB x 2 (profiles/r06_pmc_conv.txt), -8 % kernel time.  (A run-time switch between the two orders
-    // cost 4 more SGPRs than the kernel has: 56 bytes of scratch and a quarter of its speed -- the order is a compile-time fact.)
+    // are one group (~4 us, 1 MB per XCD) apart: 97 MB x 2 (profiles/r06_pmc_conv.txt; HBM-side bytes of the launch 1.79x -> 1.19x algorithmic).  The
+    // TIME of the launch did not move (287 vs 288 us alone, step -0.3 %: profiles/r06_halo_khorder_clean.txt): the misses were already covered by the
+    // group-ahead prefetch.  (A run-time switch between the two orders cost 4 more SGPRs than the kernel has: 56 bytes of scratch and a quarter of
+    // its speed -- both arms of that first A/B were slowed, and read as -8 %; the order is a compile-time fact.)
     auto next_x = [&]() { if (++xkh == 3) { xkh = 0; xci += BK; } };
     auto issue_w = [&](int it, int st, unsigned w_off) {   // piece `it` of a tap into tap stage st
         if (no_dma) return;
