@@ -654,7 +654,7 @@ def main():
                                                                                                    args.height, "on" if args.align else "off", per, per),
                       "global_batch": imgs_per_step, "parallelism": f"dp{world}",
                       "inputs": "device-resident synthetic batch: no host-to-device copy, no data loader and no augmentation inside the timed region",
-                      "parity": {"fp32_mode": "losses within 1e-3 of the CPU oracle, ROI / anchor indices bit-exact: at 192x256 over whole ALDI iterations (tests/test_engine_gpu.py, tests/test_configs_gpu.py) and at THIS size, 800x1333, for one source micro-step and one teacher inference pass (tests/test_fullsize_gpu.py::test_fullsize_source_step_vs_oracle_fp32, ::test_fullsize_teacher_inference_vs_oracle_fp32)",
+                      "parity": {"fp32_mode": "losses within 1e-3 of the CPU oracle, ROI / anchor indices bit-exact: at 192x256 over whole ALDI iterations (tests/test_engine_gpu.py, tests/test_configs_gpu.py) and at THIS size, 800x1333, for one source micro-step (forward: tests/test_fullsize_gpu.py::test_fullsize_source_step_vs_oracle_fp32; backward, every trainable tensor's gradient within 2e-3 rel-L2 of the oracle's autograd: ::test_fullsize_source_step_gradients_vs_oracle_fp32) and one teacher inference pass (::test_fullsize_teacher_inference_vs_oracle_fp32)",
                                  "measured_dtype_vs_fp32_mode": "bf16 with the fp32 run's proposals and pseudo labels injected: every sampled index identical, losses within 2 %, "
                                                                 "per-group gradient cosine >= 0.99 and rel-L2 <= 3e-2 (tests/test_configs_gpu.py::test_benchmark_step_bf16_vs_fp32_parity_mode)",
                                  "this_line": "the throughput is the %s step; the 1e-3 loss bound is shown in the fp32 parity mode, not in this dtype" % ("fp32" if args.fp32 else "bf16")},

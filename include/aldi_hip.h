@@ -53,6 +53,7 @@ int aldi_noop(aldi_stream_t stream);
  *   igemm_halo64_mid     mid-size 3x3 layers with at least this many 128x128 tiles take the 128x128 tile with 128-byte K slabs (0 = never, the
  *                        default: measured 10-20 % slower than the 128x64 tiles on res3 / res4 conv2 -- those layers are bound by workgroup count)
  *   igemm_halo_small     3x3 layers with Cin >= 512 and at most this many 128x64 tiles take 64x64 halo tiles (0 = never, the default; 320 = res5 conv2: faster alone, 0.5 % slower in the step)
+ *   match_wave           1 = the anchor matcher culls the GT list per wave (64 anchors) instead of per 1024-anchor workgroup (default; same labels bit for bit)
  *   igemm_halo96         1 = 3x3 layers with 200-600 tiles of 128x64 take 96x64 three-wave tiles (0 = never, the default: 2-6 % faster alone, neutral in the step)
  *   igemm_halo_ilv       1 = the 256x256 halo64 tile runs its interleaved K loop (reads / DMA pieces between the MFMAs; 0 = the lockstep loop of r05)
  *   igemm_ws             1 = plain 1x1 bf16 layers with K = Cin in {64, 128, 256, 512}, whole groups of 256 (K >= 256: 128) output channels and at least
