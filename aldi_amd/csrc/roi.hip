@@ -323,6 +323,7 @@ __device__ __forceinline__ void fma8(float* acc, const float w, const float* u) 
 // (16 B each) instead of 4 corners per sample -- a 19 x 10-pixel ROI reads ~215 KB instead of ~600 KB, and the bilinear
 // bookkeeping is done once per ROI in LDS tables instead of once per (sample, 16 B).  Sums associate differently from the
 // sample-by-sample form (same terms; fp32 differences of a few ulps).
+template <int V> struct SepTag { static constexpr int value = V; };
 constexpr int kSepMaxH = 208, kSepMaxW = 344;      // footprint bounds: the p2 map of a 1333 x 800 image is 200 x 336
 template <typename T>
 __global__ __launch_bounds__(256) void roialign_fwd_sep_kernel(Feats ft, const float* __restrict__ rois, int P, T* __restrict__ pooled /*[R][P][P][C]*/) {
@@ -392,57 +393,101 @@ __global__ __launch_bounds__(256) void roialign_fwd_sep_kernel(Feats ft, const f
 #pragma unroll
         for (int i = 0; i < 8; ++i) acc[ph][i] = 0.f;
     const T* F = static_cast<const T*>(ft.f[l]) + (long)b * H * W * C + c8 * 8;
-    for (int y = 0; y < nrow; ++y) {
-        float wr[7];
-        bool any = false;
-#pragma unroll
-        for (int ph = 0; ph < 7; ++ph) { wr[ph] = rowc[ph][y]; any = any || wr[ph] != 0.f; }
-        if (!any) continue;                            // (uniform: margin rows of the footprint)
-        float t[8], u[8];
-#pragma unroll
-        for (int i = 0; i < 8; ++i) t[i] = 0.f;
-        const T* Fr = F + ((long)(fy0 + y) * W + fx0) * C;
-        constexpr int XB = 4;       // pixels whose loads are in flight together (past the run: the last pixel again, weight 0; 8 measured slower: runs are 4-5 px)
-        for (int x = xlo; x <= xhi; x += XB) {
-            Raw8<T> q[XB];
-            float wc[XB];
-#pragma unroll
-            for (int k = 0; k < XB; ++k) {
-                const int xk = min(x + k, xhi);
-                q[k].load(Fr + (long)xk * C);
-                wc[k] = x + k <= xhi ? colc[pw][xk] : 0.f;
-            }
-#pragma unroll
-            for (int k = 0; k < XB; ++k) {
-                q[k].unpack(u);
-                // The kernel is bound by VALU issue (2048 ROIs x 4 waves x ~3 700 instructions = 58 of its 62 us), and the file is built with
-                // -ffp-contract=off: every multiply-add was a v_pk_mul_f32 + v_pk_add_f32 pair.  bf16 maps: fused packed multiply-adds (one
-                // v_pk_fma_f32 per channel pair: fewer roundings, not more); the fp32 parity mode keeps the unfused arithmetic of the oracle.
-                if constexpr (sizeof(T) == 2) {
-#pragma unroll
-                    for (int i = 0; i < 8; i += 2) {
-                        const f32x2_t r2 = __builtin_elementwise_fma(f32x2_t{wc[k], wc[k]}, f32x2_t{u[i], u[i + 1]}, f32x2_t{t[i], t[i + 1]});
-                        t[i] = r2[0]; t[i + 1] = r2[1];
-                    }
-                } else {
-#pragma unroll
-                    for (int i = 0; i < 8; ++i) t[i] += wc[k] * u[i];
-                }
-            }
-        }
+    auto row_stage = [&](const float* wr, const float* t) {     // acc[ph] += rowc[ph][y] * t for the bin rows with weight on this feature row
 #pragma unroll
         for (int ph = 0; ph < 7; ++ph)
             if (wr[ph] != 0.f) {
-                if constexpr (sizeof(T) == 2) {
-#pragma unroll
-                    for (int i = 0; i < 8; i += 2) {
-                        const f32x2_t r2 = __builtin_elementwise_fma(f32x2_t{wr[ph], wr[ph]}, f32x2_t{t[i], t[i + 1]}, f32x2_t{acc[ph][i], acc[ph][i + 1]});
-                        acc[ph][i] = r2[0]; acc[ph][i + 1] = r2[1];
-                    }
-                } else {
+                if constexpr (sizeof(T) == 2) fma8(acc[ph], wr[ph], t);
+                else {
 #pragma unroll
                     for (int i = 0; i < 8; ++i) acc[ph][i] += wr[ph] * t[i];
                 }
+            }
+    };
+    // The kernel is bound by VALU issue (2048 ROIs x 4 waves x ~3 700 instructions = 58 of its 62 us; -ffp-contract=off made every multiply-add a
+    // v_pk_mul + v_pk_add pair: fused for bf16 maps, r06).  A bin column's run of pixels with weight is 4-5 long; walked four at a time a 5-pixel run cost
+    // 8 pixels of unpack + multiply-add per row, and every row re-read the column weights from LDS and rebuilt the pixel addresses.  Here the wave's
+    // LONGEST run (a wave holds two bin columns) picks an exactly unrolled row loop (1 .. 6 pixels), the column weights and pixel offsets are
+    // computed once per ROI; longer runs (large ROIs) take the generic loop.  Same terms in the same order: identical results.
+    const int run = xhi - xlo + 1;
+    int maxrun = run;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) maxrun = max(maxrun, __shfl_xor(maxrun, o, 64));
+    maxrun = __builtin_amdgcn_readfirstlane(maxrun);
+    auto rows_exact = [&](auto NPt) {
+        constexpr int NP = decltype(NPt)::value;
+        float wcr[NP];
+        int po[NP];
+#pragma unroll
+        for (int k = 0; k < NP; ++k) {
+            const int xk = min(xlo + k, xhi);
+            wcr[k] = k < run ? colc[pw][xk] : 0.f;
+            po[k] = xk * C;
+        }
+        for (int y = 0; y < nrow; ++y) {
+            float wr[7];
+            bool any = false;
+#pragma unroll
+            for (int ph = 0; ph < 7; ++ph) { wr[ph] = rowc[ph][y]; any = any || wr[ph] != 0.f; }
+            if (!any) continue;                            // (uniform: margin rows of the footprint)
+            const T* Fr = F + ((long)(fy0 + y) * W + fx0) * C;
+            Raw8<T> q[NP];
+#pragma unroll
+            for (int k = 0; k < NP; ++k) q[k].load(Fr + po[k]);
+            float t[8], u[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) t[i] = 0.f;
+#pragma unroll
+            for (int k = 0; k < NP; ++k) {
+                q[k].unpack(u);
+                if constexpr (sizeof(T) == 2) fma8(t, wcr[k], u);
+                else {
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) t[i] += wcr[k] * u[i];
+                }
+            }
+            row_stage(wr, t);
+        }
+    };
+    switch (maxrun) {
+        case 1: rows_exact(SepTag<1>{}); break;
+        case 2: rows_exact(SepTag<2>{}); break;
+        case 3: rows_exact(SepTag<3>{}); break;
+        case 4: rows_exact(SepTag<4>{}); break;
+        case 5: rows_exact(SepTag<5>{}); break;
+        case 6: rows_exact(SepTag<6>{}); break;
+        default:
+            for (int y = 0; y < nrow; ++y) {
+                float wr[7];
+                bool any = false;
+#pragma unroll
+                for (int ph = 0; ph < 7; ++ph) { wr[ph] = rowc[ph][y]; any = any || wr[ph] != 0.f; }
+                if (!any) continue;
+                float t[8], u[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) t[i] = 0.f;
+                const T* Fr = F + ((long)(fy0 + y) * W + fx0) * C;
+                constexpr int XB = 4;       // pixels whose loads are in flight together (past the run: the last pixel again, weight 0)
+                for (int x = xlo; x <= xhi; x += XB) {
+                    Raw8<T> q[XB];
+                    float wc[XB];
+#pragma unroll
+                    for (int k = 0; k < XB; ++k) {
+                        const int xk = min(x + k, xhi);
+                        q[k].load(Fr + (long)xk * C);
+                        wc[k] = x + k <= xhi ? colc[pw][xk] : 0.f;
+                    }
+#pragma unroll
+                    for (int k = 0; k < XB; ++k) {
+                        q[k].unpack(u);
+                        if constexpr (sizeof(T) == 2) fma8(t, wc[k], u);
+                        else {
+#pragma unroll
+                            for (int i = 0; i < 8; ++i) t[i] += wc[k] * u[i];
+                        }
+                    }
+                }
+                row_stage(wr, t);
             }
     }
 #pragma unroll
